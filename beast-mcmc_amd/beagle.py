@@ -1,0 +1,384 @@
+"""ctypes binding of the C ABI (include/beagle_mi355.h) — the Python-side stand-in for
+``beagle.BeagleJNIImpl`` (lib/beagle.jar!beagle/BeagleJNIImpl.class), which wraps the JNI natives in
+the ``beagle.Beagle`` interface and turns non-zero return codes into ``BeagleException``.
+
+Method names and argument order are those of the ``beagle.Beagle`` Java interface, so test code reads
+like the reference's callers (e.g. ``beagle.updatePartials(operations, operationCount, Beagle.NONE)``,
+src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1003).
+
+There is NO fallback: if the HIP library is missing this module raises at load time
+(``BeagleFactory.loadBeagleInstance`` would fall back to a Java implementation; this engine does not).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ENGINE_LIB = os.path.join(_HERE, "lib", "libhmsbeagle-jni.so")
+HOST_LIB = os.path.join(_HERE, "lib", "libbeast_host.so")
+
+NONE = -1
+OPERATION_TUPLE_SIZE = 7
+
+ERROR_NAMES = {0: "NO_ERROR", -1: "GENERAL_ERROR", -2: "OUT_OF_MEMORY_ERROR", -3: "UNIDENTIFIED_EXCEPTION_ERROR",
+               -4: "UNINITIALIZED_INSTANCE_ERROR", -5: "OUT_OF_RANGE_ERROR", -6: "NO_RESOURCE_ERROR",
+               -7: "NO_IMPLEMENTATION_ERROR", -8: "FLOATING_POINT_ERROR"}
+
+
+class BeagleException(RuntimeError):
+    """Mirror of beagle.BeagleException(functionName, errCode)."""
+
+    def __init__(self, function_name, code):
+        super().__init__("%s returned %d (%s)" % (function_name, code, ERROR_NAMES.get(code, "?")))
+        self.function_name = function_name
+        self.code = code
+
+
+class InstanceDetails(C.Structure):
+    _fields_ = [("resourceNumber", C.c_int), ("resourceName", C.c_char_p), ("implName", C.c_char_p),
+                ("implDescription", C.c_char_p), ("flags", C.c_long)]
+
+
+class _Resource(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("description", C.c_char_p), ("supportFlags", C.c_long),
+                ("requiredFlags", C.c_long)]
+
+
+class _ResourceList(C.Structure):
+    _fields_ = [("list", C.POINTER(_Resource)), ("length", C.c_int)]
+
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_IP)
+
+
+_PROTOS = {
+    "CreateInstance": ([C.c_int] * 9 + [_IP, C.c_int, C.c_long, C.c_long, C.POINTER(InstanceDetails)], C.c_int),
+    "FinalizeInstance": ([C.c_int], C.c_int),
+    "SetCPUThreadCount": ([C.c_int, C.c_int], C.c_int),
+    "SetPatternWeights": ([C.c_int, _DP], C.c_int),
+    "SetPatternPartitions": ([C.c_int, C.c_int, _IP], C.c_int),
+    "SetTipStates": ([C.c_int, C.c_int, _IP], C.c_int),
+    "GetTipStates": ([C.c_int, C.c_int, _IP], C.c_int),
+    "SetTipPartials": ([C.c_int, C.c_int, _DP], C.c_int),
+    "SetPartials": ([C.c_int, C.c_int, _DP], C.c_int),
+    "GetPartials": ([C.c_int, C.c_int, C.c_int, _DP], C.c_int),
+    "GetLogScaleFactors": ([C.c_int, C.c_int, _DP], C.c_int),
+    "SetEigenDecomposition": ([C.c_int, C.c_int, _DP, _DP, _DP], C.c_int),
+    "SetStateFrequencies": ([C.c_int, C.c_int, _DP], C.c_int),
+    "SetCategoryWeights": ([C.c_int, C.c_int, _DP], C.c_int),
+    "SetCategoryRates": ([C.c_int, _DP], C.c_int),
+    "SetCategoryRatesWithIndex": ([C.c_int, C.c_int, _DP], C.c_int),
+    "SetTransitionMatrix": ([C.c_int, C.c_int, _DP, C.c_double], C.c_int),
+    "GetTransitionMatrix": ([C.c_int, C.c_int, _DP], C.c_int),
+    "ConvolveTransitionMatrices": ([C.c_int, _IP, _IP, _IP, C.c_int], C.c_int),
+    "UpdateTransitionMatrices": ([C.c_int, C.c_int, _IP, _IP, _IP, _DP, C.c_int], C.c_int),
+    "UpdateTransitionMatricesWithMultipleModels": ([C.c_int, _IP, _IP, _IP, _IP, _IP, _DP, C.c_int], C.c_int),
+    "UpdatePartials": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
+    "UpdatePartialsByPartition": ([C.c_int, _IP, C.c_int], C.c_int),
+    "WaitForPartials": ([C.c_int, _IP, C.c_int], C.c_int),
+    "AccumulateScaleFactors": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
+    "AccumulateScaleFactorsByPartition": ([C.c_int, _IP, C.c_int, C.c_int, C.c_int], C.c_int),
+    "RemoveScaleFactors": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
+    "RemoveScaleFactorsByPartition": ([C.c_int, _IP, C.c_int, C.c_int, C.c_int], C.c_int),
+    "ResetScaleFactors": ([C.c_int, C.c_int], C.c_int),
+    "ResetScaleFactorsByPartition": ([C.c_int, C.c_int, C.c_int], C.c_int),
+    "CopyScaleFactors": ([C.c_int, C.c_int, C.c_int], C.c_int),
+    "CalculateRootLogLikelihoods": ([C.c_int, _IP, _IP, _IP, _IP, C.c_int, _DP], C.c_int),
+    "CalculateRootLogLikelihoodsByPartition": ([C.c_int, _IP, _IP, _IP, _IP, _IP, C.c_int, C.c_int, _DP, _DP], C.c_int),
+    "GetSiteLogLikelihoods": ([C.c_int, _DP], C.c_int),
+    "SetRootPrePartials": ([C.c_int, _IP, _IP, C.c_int], C.c_int),
+    "SetDifferentialMatrix": ([C.c_int, C.c_int, _DP], C.c_int),
+    "AddTransitionMatrices": ([C.c_int, _IP, _IP, _IP, C.c_int], C.c_int),
+    "TransposeTransitionMatrices": ([C.c_int, _IP, _IP, C.c_int], C.c_int),
+    "UpdatePrePartials": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
+    "UpdatePrePartialsByPartition": ([C.c_int, _IP, C.c_int], C.c_int),
+}
+
+# symbols every engine library must export (tests assert this list against include/beagle_mi355.h)
+ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetApiTable"] + \
+              ["beagle" + k for k in _PROTOS] + \
+              ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
+               "beagleMi355KernelTimer", "beagleMi355DeviceBytes"]
+
+
+class EngineLibrary:
+    """A loaded engine shared object (the HIP engine, or — in tests only — the CPU oracle, whose
+    symbols carry the ``oracle_`` prefix)."""
+
+    def __init__(self, path=ENGINE_LIB, prefix=""):
+        if not os.path.exists(path):
+            raise OSError("engine library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % path)
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        self.fn = {}
+        for name, (argtypes, restype) in _PROTOS.items():
+            f = getattr(self.lib, prefix + "beagle" + name, None)
+            if f is None:
+                continue
+            f.argtypes = argtypes
+            f.restype = restype
+            self.fn[name] = f
+        gv = getattr(self.lib, prefix + "beagleGetVersion")
+        gv.restype = C.c_char_p
+        self.version = gv().decode()
+        tab = getattr(self.lib, prefix + "beagleGetApiTable")
+        tab.restype = C.c_void_p
+        self.api_table = tab()
+
+    def has(self, name):
+        return name in self.fn
+
+    def resource_list(self):
+        f = getattr(self.lib, self.prefix + "beagleGetResourceList")
+        f.restype = C.POINTER(_ResourceList)
+        rl = f().contents
+        return [(rl.list[i].name.decode(), rl.list[i].description.decode(), rl.list[i].supportFlags)
+                for i in range(rl.length)]
+
+
+_engine = None
+
+
+def engine():
+    """The HIP engine library (loaded once)."""
+    global _engine
+    if _engine is None:
+        _engine = EngineLibrary(ENGINE_LIB)
+    return _engine
+
+
+class Beagle:
+    """One engine instance behind the ``beagle.Beagle`` method set."""
+
+    NONE = NONE
+    OPERATION_TUPLE_SIZE = OPERATION_TUPLE_SIZE
+
+    def __init__(self, tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount,
+                 eigenBufferCount, matrixBufferCount, categoryCount, scaleBufferCount,
+                 resourceList=(1,), preferenceFlags=0, requirementFlags=0, library=None):
+        self.lib = library or engine()
+        self._f = self.lib.fn
+        self.stateCount, self.patternCount, self.categoryCount = stateCount, patternCount, categoryCount
+        self.details = InstanceDetails()
+        rl = _i(list(resourceList)) if resourceList is not None else None
+        h = self._f["CreateInstance"](tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount,
+                                      eigenBufferCount, matrixBufferCount, categoryCount, scaleBufferCount,
+                                      _ip(rl), 0 if rl is None else len(rl), preferenceFlags, requirementFlags,
+                                      C.byref(self.details))
+        if h < 0:
+            raise BeagleException("create", h)
+        self.instance = h
+
+    def _check(self, name, rc):
+        if rc != 0:
+            raise BeagleException(name, rc)
+
+    def finalize(self):
+        if self.instance >= 0:
+            self._check("finalize", self._f["FinalizeInstance"](self.instance))
+            self.instance = -1
+
+    def setCPUThreadCount(self, n):
+        self._check("setCPUThreadCount", self._f["SetCPUThreadCount"](self.instance, n))
+
+    def setPatternWeights(self, w):
+        w = _d(w)
+        assert w.size >= self.patternCount
+        self._check("setPatternWeights", self._f["SetPatternWeights"](self.instance, _dp(w)))
+
+    def setPatternPartitions(self, partitionCount, partitions):
+        a = _i(partitions)
+        self._check("setPatternPartitions", self._f["SetPatternPartitions"](self.instance, partitionCount, _ip(a)))
+
+    def setTipStates(self, tipIndex, states):
+        a = _i(states)
+        assert a.size >= self.patternCount
+        self._check("setTipStates", self._f["SetTipStates"](self.instance, tipIndex, _ip(a)))
+
+    def getTipStates(self, tipIndex):
+        out = np.empty(self.patternCount, dtype=np.int32)
+        self._check("getTipStates", self._f["GetTipStates"](self.instance, tipIndex, _ip(out)))
+        return out
+
+    def setTipPartials(self, tipIndex, partials):
+        a = _d(partials)
+        assert a.size >= self.patternCount * self.stateCount
+        self._check("setTipPartials", self._f["SetTipPartials"](self.instance, tipIndex, _dp(a)))
+
+    def setPartials(self, bufferIndex, partials):
+        a = _d(partials)
+        assert a.size >= self.patternCount * self.stateCount * self.categoryCount
+        self._check("setPartials", self._f["SetPartials"](self.instance, bufferIndex, _dp(a)))
+
+    def getPartials(self, bufferIndex, scaleIndex=NONE):
+        out = np.empty(self.categoryCount * self.patternCount * self.stateCount)
+        self._check("getPartials", self._f["GetPartials"](self.instance, bufferIndex, scaleIndex, _dp(out)))
+        return out.reshape(self.categoryCount, self.patternCount, self.stateCount)
+
+    def getLogScaleFactors(self, scaleIndex):
+        out = np.empty(self.patternCount)
+        self._check("getLogScaleFactors", self._f["GetLogScaleFactors"](self.instance, scaleIndex, _dp(out)))
+        return out
+
+    def setEigenDecomposition(self, eigenIndex, eigenVectors, inverseEigenValues, eigenValues):
+        u, ui, lam = _d(eigenVectors), _d(inverseEigenValues), _d(eigenValues)
+        self._check("setEigenDecomposition",
+                    self._f["SetEigenDecomposition"](self.instance, eigenIndex, _dp(u), _dp(ui), _dp(lam)))
+
+    def setStateFrequencies(self, index, freqs):
+        a = _d(freqs)
+        self._check("setStateFrequencies", self._f["SetStateFrequencies"](self.instance, index, _dp(a)))
+
+    def setCategoryWeights(self, index, weights):
+        a = _d(weights)
+        self._check("setCategoryWeights", self._f["SetCategoryWeights"](self.instance, index, _dp(a)))
+
+    def setCategoryRates(self, rates):
+        a = _d(rates)
+        self._check("setCategoryRates", self._f["SetCategoryRates"](self.instance, _dp(a)))
+
+    def setCategoryRatesWithIndex(self, index, rates):
+        a = _d(rates)
+        self._check("setCategoryRatesWithIndex", self._f["SetCategoryRatesWithIndex"](self.instance, index, _dp(a)))
+
+    def setTransitionMatrix(self, matrixIndex, matrix, paddedValue=1.0):
+        a = _d(matrix)
+        self._check("setTransitionMatrix", self._f["SetTransitionMatrix"](self.instance, matrixIndex, _dp(a), paddedValue))
+
+    def getTransitionMatrix(self, matrixIndex):
+        out = np.empty(self.categoryCount * self.stateCount * self.stateCount)
+        self._check("getTransitionMatrix", self._f["GetTransitionMatrix"](self.instance, matrixIndex, _dp(out)))
+        return out.reshape(self.categoryCount, self.stateCount, self.stateCount)
+
+    def convolveTransitionMatrices(self, first, second, result, count):
+        a, b, c = _i(first), _i(second), _i(result)
+        self._check("convolveTransitionMatrices",
+                    self._f["ConvolveTransitionMatrices"](self.instance, _ip(a), _ip(b), _ip(c), count))
+
+    def updateTransitionMatrices(self, eigenIndex, probabilityIndices, firstDerivativeIndices,
+                                 secondDerivativeIndices, edgeLengths, count):
+        p, d1, d2, t = _i(probabilityIndices), _i(firstDerivativeIndices), _i(secondDerivativeIndices), _d(edgeLengths)
+        self._check("updateTransitionMatrices",
+                    self._f["UpdateTransitionMatrices"](self.instance, eigenIndex, _ip(p), _ip(d1), _ip(d2), _dp(t), count))
+
+    def updateTransitionMatricesWithMultipleModels(self, eigenIndices, categoryRateIndices, probabilityIndices,
+                                                   firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count):
+        e, r, p = _i(eigenIndices), _i(categoryRateIndices), _i(probabilityIndices)
+        d1, d2, t = _i(firstDerivativeIndices), _i(secondDerivativeIndices), _d(edgeLengths)
+        self._check("updateTransitionMatricesWithMultipleModels",
+                    self._f["UpdateTransitionMatricesWithMultipleModels"](self.instance, _ip(e), _ip(r), _ip(p),
+                                                                           _ip(d1), _ip(d2), _dp(t), count))
+
+    def updatePartials(self, operations, operationCount, cumulativeScaleIndex=NONE):
+        a = _i(operations)
+        assert a.size >= operationCount * OPERATION_TUPLE_SIZE
+        self._check("updatePartials", self._f["UpdatePartials"](self.instance, _ip(a), operationCount, cumulativeScaleIndex))
+
+    def updatePartialsByPartition(self, operations, operationCount):
+        a = _i(operations)
+        assert a.size >= operationCount * 9
+        self._check("updatePartialsByPartition", self._f["UpdatePartialsByPartition"](self.instance, _ip(a), operationCount))
+
+    def accumulateScaleFactors(self, scaleIndices, count, cumulativeScaleIndex):
+        a = _i(scaleIndices)
+        self._check("accumulateScaleFactors",
+                    self._f["AccumulateScaleFactors"](self.instance, _ip(a), count, cumulativeScaleIndex))
+
+    def removeScaleFactors(self, scaleIndices, count, cumulativeScaleIndex):
+        a = _i(scaleIndices)
+        self._check("removeScaleFactors", self._f["RemoveScaleFactors"](self.instance, _ip(a), count, cumulativeScaleIndex))
+
+    def resetScaleFactors(self, cumulativeScaleIndex):
+        self._check("resetScaleFactors", self._f["ResetScaleFactors"](self.instance, cumulativeScaleIndex))
+
+    def copyScaleFactors(self, dest, src):
+        self._check("copyScaleFactors", self._f["CopyScaleFactors"](self.instance, dest, src))
+
+    def accumulateScaleFactorsByPartition(self, scaleIndices, count, cumulativeScaleIndex, partitionIndex):
+        a = _i(scaleIndices)
+        self._check("accumulateScaleFactorsByPartition",
+                    self._f["AccumulateScaleFactorsByPartition"](self.instance, _ip(a), count, cumulativeScaleIndex, partitionIndex))
+
+    def resetScaleFactorsByPartition(self, cumulativeScaleIndex, partitionIndex):
+        self._check("resetScaleFactorsByPartition",
+                    self._f["ResetScaleFactorsByPartition"](self.instance, cumulativeScaleIndex, partitionIndex))
+
+    def calculateRootLogLikelihoods(self, bufferIndices, categoryWeightsIndices, stateFrequenciesIndices,
+                                    cumulativeScaleIndices, count, outSumLogLikelihood):
+        """``outSumLogLikelihood``: writable sequence of length >= 1 (as the Java double[1]).
+        Error -8 (FLOATING_POINT) is tolerated exactly as BeagleJNIImpl#calculateRootLogLikelihoods does."""
+        b, w, f, s = _i(bufferIndices), _i(categoryWeightsIndices), _i(stateFrequenciesIndices), _i(cumulativeScaleIndices)
+        out = np.zeros(1)
+        rc = self._f["CalculateRootLogLikelihoods"](self.instance, _ip(b), _ip(w), _ip(f), _ip(s), count, _dp(out))
+        outSumLogLikelihood[0] = out[0]
+        if rc != 0 and rc != -8:
+            raise BeagleException("calculateRootLogLikelihoods", rc)
+
+    def calculateRootLogLikelihoodsByPartition(self, bufferIndices, categoryWeightsIndices, stateFrequenciesIndices,
+                                               cumulativeScaleIndices, partitionIndices, partitionCount, count,
+                                               outSumLogLikelihoodByPartition, outSumLogLikelihood):
+        b, w, f = _i(bufferIndices), _i(categoryWeightsIndices), _i(stateFrequenciesIndices)
+        s, p = _i(cumulativeScaleIndices), _i(partitionIndices)
+        byp = np.zeros(partitionCount * count)
+        tot = np.zeros(1)
+        rc = self._f["CalculateRootLogLikelihoodsByPartition"](self.instance, _ip(b), _ip(w), _ip(f), _ip(s), _ip(p),
+                                                               partitionCount, count, _dp(byp), _dp(tot))
+        outSumLogLikelihoodByPartition[:len(byp)] = byp
+        outSumLogLikelihood[0] = tot[0]
+        if rc != 0 and rc != -8:
+            raise BeagleException("calculateRootLogLikelihoodsByPartition", rc)
+
+    def getSiteLogLikelihoods(self, out=None):
+        if out is None:
+            out = np.empty(self.patternCount)
+        self._check("getSiteLogLikelihoods", self._f["GetSiteLogLikelihoods"](self.instance, _dp(out)))
+        return out
+
+    # --- MI355X extensions -----------------------------------------------------------------
+    def _ext(self, name, argtypes, restype=C.c_int):
+        f = getattr(self.lib.lib, name)
+        f.argtypes = argtypes
+        f.restype = restype
+        return f
+
+    def setStream(self, hip_stream):
+        self._check("setStream", self._ext("beagleMi355SetStream", [C.c_int, C.c_void_p])(self.instance, hip_stream))
+
+    def calculateRootLogLikelihoodsDevice(self, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex,
+                                          cumulativeScaleIndex, device_ptr):
+        f = self._ext("beagleMi355CalculateRootLogLikelihoodsDevice", [C.c_int] * 5 + [C.c_void_p])
+        self._check("calculateRootLogLikelihoodsDevice",
+                    f(self.instance, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, device_ptr))
+
+    def synchronize(self):
+        self._check("synchronize", self._ext("beagleMi355Synchronize", [C.c_int])(self.instance))
+
+    def kernelTimer(self, enable):
+        ms = C.c_double(0.0)
+        n = C.c_long(0)
+        f = self._ext("beagleMi355KernelTimer", [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)])
+        self._check("kernelTimer", f(self.instance, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def deviceBytes(self):
+        return self._ext("beagleMi355DeviceBytes", [C.c_int], C.c_long)(self.instance)

@@ -1,0 +1,70 @@
+"""In-tree build of the native pieces (explicit hipcc / g++ command lines, no build system):
+
+  lib/libhmsbeagle-jni.so   HIP engine + C ABI + JNI shim, gfx950 only   (csrc/*.hip, csrc/*.cpp)
+  lib/libbeast_host.so      C++ host driver mirroring BeagleTreeLikelihood  (host/tree_likelihood.cpp)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the built
+``.so`` files travel to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "lib")
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+ " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_engine(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "libhmsbeagle-jni.so")
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(ROOT, "include", "beagle_mi355.h")]
+    if force or _newer(out, deps):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-DBEAGLE_MI355_BUILD", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+        for s in srcs:
+            cmd += ["-x", "hip", s]
+        cmd += ["-o", out]
+        _run(cmd)
+    return out
+
+
+def build_host(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "libbeast_host.so")
+    src = os.path.join(HOST, "tree_likelihood.cpp")
+    if force or _newer(out, [src, os.path.join(ROOT, "include", "beagle_mi355.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", out])
+    return out
+
+
+def build_all(force=False):
+    return [build_engine(force), build_host(force)]
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

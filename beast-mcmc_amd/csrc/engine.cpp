@@ -1,0 +1,906 @@
+// engine.cpp — host side of the MI355X engine: instance table, HBM buffer management, the C ABI of
+// include/beagle_mi355.h.  All arithmetic is in kernels.hip; this file validates indices, resolves
+// buffer indices to device pointers, levelises operation lists and enqueues kernels on the
+// instance's HIP stream.  Results are only observed at calculateRootLogLikelihoods / get*, so every
+// other call returns as soon as its work is enqueued (SURVEY 8b "Threading").
+//
+// There is no CPU path in this library: with no visible MI355X beagleCreateInstance returns
+// BEAGLE_ERROR_NO_RESOURCE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/beagle_mi355.h"
+#include "kernels.h"
+
+using mi355::OpDesc;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            if (getenv("BEAGLE_MI355_DEBUG"))                                                 \
+                fprintf(stderr, "[beagle-mi355] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return e__ == hipErrorOutOfMemory ? BEAGLE_ERROR_OUT_OF_MEMORY : BEAGLE_ERROR_GENERAL; \
+        }                                                                                     \
+    } while (0)
+
+constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
+constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
+
+struct Instance {
+    int device = 0;
+    hipStream_t stream = nullptr, ownStream = nullptr;
+    int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
+    size_t partialsBytes = 0;
+    std::vector<double*> partials;
+    std::vector<uint8_t*> tipStates;
+    std::vector<void*> allocations;
+    char* slabCur = nullptr; int slabLeft = 0;
+    char* scaleSlabCur = nullptr; int scaleSlabLeft = 0;
+    char* stateSlabCur = nullptr; int stateSlabLeft = 0;
+    double* matrices = nullptr; double* eigen = nullptr; double* rates = nullptr; double* weights = nullptr;
+    double* freqs = nullptr; double* patternWeights = nullptr; double* siteLogL = nullptr;
+    std::vector<double*> scale; std::vector<char> scaleIsRaw;
+    double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr;
+    char* hRing = nullptr; char* dRing = nullptr; size_t ringHead = 0;
+    int partitionCount = 1;
+    std::vector<int> partStart, partEnd;
+    // levelisation scratch
+    std::vector<int> wStamp, wLevel, rStamp, rLevel; int stamp = 0;
+    // kernel timer
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
+    double timedMs = 0.0; long timedLaunches = 0;
+    size_t deviceBytes = 0;
+    std::string resourceName;
+};
+
+std::mutex g_mutex;
+std::vector<Instance*> g_instances;
+
+Instance* lookup(int h) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (h < 0 || h >= (int)g_instances.size()) return nullptr;
+    return g_instances[h];
+}
+
+int devAlloc(Instance* in, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    in->allocations.push_back(*p);
+    in->deviceBytes += bytes;
+    return 0;
+}
+
+// Stage `bytes` of host data into the pinned ring; returns the ring offset (or <0).  Wrapping first
+// drains the stream, so a region is never overwritten while a copy from it is still in flight.
+long stage(Instance* in, const void* src, size_t bytes) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > RING_BYTES) return -1;
+    if (in->ringHead + need > RING_BYTES) {
+        if (hipStreamSynchronize(in->stream) != hipSuccess) return -1;
+        in->ringHead = 0;
+    }
+    const size_t off = in->ringHead;
+    memcpy(in->hRing + off, src, bytes);
+    in->ringHead += need;
+    return (long)off;
+}
+
+// host array -> persistent device location, asynchronously when it fits the ring
+int upload(Instance* in, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (bytes <= RING_BYTES / 4) {
+        long off = stage(in, src, bytes);
+        if (off < 0) return BEAGLE_ERROR_GENERAL;
+        HIP_TRY(hipMemcpyAsync(dst, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
+        return 0;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, in->stream));
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    return 0;
+}
+
+// host array -> the device mirror of the ring (transient kernel arguments: op descriptors, index lists)
+int uploadTransient(Instance* in, const void* src, size_t bytes, void** dptr) {
+    long off = stage(in, src, bytes);
+    if (off < 0) return BEAGLE_ERROR_GENERAL;
+    HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
+    *dptr = in->dRing + off;
+    return 0;
+}
+
+int download(Instance* in, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, in->stream));
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->ringHead = 0;   // everything staged so far has been consumed
+    return 0;
+}
+
+int ensurePartials(Instance* in, int idx) {
+    if (in->partials[idx]) return 0;
+    if (in->slabLeft == 0) {
+        int remaining = 0;
+        for (double* p : in->partials) if (!p) remaining++;
+        const int n = std::min(remaining, SLAB_BUFFERS);
+        void* slab = nullptr;
+        int rc = devAlloc(in, &slab, in->partialsBytes * n);
+        if (rc) return rc;
+        in->slabCur = (char*)slab; in->slabLeft = n;
+    }
+    in->partials[idx] = (double*)in->slabCur;
+    in->slabCur += in->partialsBytes; in->slabLeft--;
+    return 0;
+}
+
+int ensureScale(Instance* in, int idx) {
+    if (in->scale[idx]) return 0;
+    const size_t bytes = ((size_t)in->P * sizeof(double) + 255) & ~(size_t)255;
+    if (in->scaleSlabLeft == 0) {
+        int remaining = 0;
+        for (double* p : in->scale) if (!p) remaining++;
+        const int n = std::min(remaining, 256);
+        void* slab = nullptr;
+        int rc = devAlloc(in, &slab, bytes * n);
+        if (rc) return rc;
+        if (hipMemsetAsync(slab, 0, bytes * n, in->stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+        in->scaleSlabCur = (char*)slab; in->scaleSlabLeft = n;
+    }
+    in->scale[idx] = (double*)in->scaleSlabCur;
+    in->scaleSlabCur += bytes; in->scaleSlabLeft--;
+    in->scaleIsRaw[idx] = 0;
+    return 0;
+}
+
+int ensureStates(Instance* in, int idx) {
+    if (in->tipStates[idx]) return 0;
+    const size_t bytes = ((size_t)in->P + 255) & ~(size_t)255;
+    if (in->stateSlabLeft == 0) {
+        const int n = std::max(1, std::min(in->compactCount, 1024));
+        void* slab = nullptr;
+        int rc = devAlloc(in, &slab, bytes * n);
+        if (rc) return rc;
+        in->stateSlabCur = (char*)slab; in->stateSlabLeft = n;
+    }
+    in->tipStates[idx] = (uint8_t*)in->stateSlabCur;
+    in->stateSlabCur += bytes; in->stateSlabLeft--;
+    return 0;
+}
+
+void destroy(Instance* in) {
+    hipSetDevice(in->device);
+    if (in->ownStream) hipStreamSynchronize(in->ownStream);
+    if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
+    for (void* p : in->allocations) hipFree(p);
+    if (in->hRing) hipHostFree(in->hRing);
+    if (in->hResult) hipHostFree(in->hResult);
+    for (auto& ev : in->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    if (in->ownStream) hipStreamDestroy(in->ownStream);
+    delete in;
+}
+
+struct Resources {
+    std::vector<std::string> names, descs;
+    std::vector<BeagleResource> list;
+    BeagleResourceList rl;
+    int gpuCount = 0;
+};
+Resources* g_resources = nullptr;
+
+const long GPU_FLAGS = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_COMPUTATION_SYNCH | BEAGLE_FLAG_EIGEN_REAL |
+                       BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC |
+                       BEAGLE_FLAG_SCALERS_RAW | BEAGLE_FLAG_VECTOR_NONE | BEAGLE_FLAG_THREADING_NONE |
+                       BEAGLE_FLAG_PROCESSOR_GPU | BEAGLE_FLAG_PARALLELOPS_GRID;
+
+Resources* resources() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_resources) return g_resources;
+    Resources* r = new Resources();
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    r->gpuCount = n;
+    // resource 0 is "the CPU" by BEAST convention (BeagleTreeLikelihood.java:90-92); this library has no
+    // CPU implementation, the entry only keeps the numbering of the GPUs at 1..G.
+    r->names.push_back("CPU"); r->descs.push_back("not provided by this library (MI355X engine only)");
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t prop;
+        char buf[256];
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess) {
+            snprintf(buf, sizeof(buf), "Global memory (MB): %zu | Compute units: %d | Arch: %s",
+                     (size_t)(prop.totalGlobalMem >> 20), prop.multiProcessorCount, prop.gcnArchName);
+            r->names.push_back(prop.name);
+        } else {
+            snprintf(buf, sizeof(buf), "device %d", d);
+            r->names.push_back("AMD GPU");
+        }
+        r->descs.push_back(buf);
+    }
+    for (size_t i = 0; i < r->names.size(); i++) {
+        BeagleResource br;
+        br.name = (char*)r->names[i].c_str(); br.description = (char*)r->descs[i].c_str();
+        br.supportFlags = i == 0 ? 0 : GPU_FLAGS; br.requiredFlags = 0;
+        r->list.push_back(br);
+    }
+    r->rl.list = r->list.data(); r->rl.length = (int)r->list.size();
+    g_resources = r;
+    return r;
+}
+
+#define GET_INSTANCE(h)                                          \
+    Instance* in = lookup(h);                                    \
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;         \
+    if (hipSetDevice(in->device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+
+inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
+
+// Enqueue an op list.  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
+int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+    if (count <= 0) return 0;
+    const int parts = in->partitionCount;
+    std::vector<OpDesc> descs(count);
+    std::vector<int> level(count);
+    std::vector<int> opCum(count, BEAGLE_OP_NONE), opWrite(count, BEAGLE_OP_NONE), opPart(count, 0);
+    in->stamp++;
+    int maxLevel = 0;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
+        int part = 0, cum = globalCum;
+        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
+        if (badIndex(dest, in->partialsCount) || badIndex(c1, in->partialsCount) || badIndex(c2, in->partialsCount) ||
+            badIndex(m1, in->matrixCount) || badIndex(m2, in->matrixCount) || badIndex(part, parts) ||
+            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+            (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        OpDesc& d = descs[k];
+        memset(&d, 0, sizeof(d));
+        int rc = ensurePartials(in, dest);
+        if (rc) return rc;
+        d.dest = in->partials[dest];
+        d.kind = 0;
+        if (in->tipStates[c1] && c1 < in->tipCount) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
+        else if (in->partials[c1]) d.child1 = in->partials[c1];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (in->tipStates[c2] && c2 < in->tipCount) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
+        else if (in->partials[c2]) d.child2 = in->partials[c2];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.mat1 = m1; d.mat2 = m2;
+        if (wS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, wS); if (rc) return rc;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
+        } else if (rS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, rS); if (rc) return rc;
+            if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
+            d.scaleRead = in->scale[rS];
+        }
+        d.pStart = in->partStart[part]; d.pEnd = in->partEnd[part];
+        opCum[k] = cum; opPart[k] = part;
+        // dependency level: after the ops (of this call) that produced my children (RAW), that read my
+        // destination (WAR) or that wrote it (WAW); hazards are tracked per (buffer, partition)
+        int lvl = 0;
+        const size_t kc1 = (size_t)c1 * parts + part, kc2 = (size_t)c2 * parts + part, kd = (size_t)dest * parts + part;
+        if (in->wStamp[kc1] == in->stamp) lvl = std::max(lvl, in->wLevel[kc1] + 1);
+        if (in->wStamp[kc2] == in->stamp) lvl = std::max(lvl, in->wLevel[kc2] + 1);
+        if (in->wStamp[kd] == in->stamp) lvl = std::max(lvl, in->wLevel[kd] + 1);
+        if (in->rStamp[kd] == in->stamp) lvl = std::max(lvl, in->rLevel[kd] + 1);
+        level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
+        in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl;
+        if (in->rStamp[kc1] != in->stamp || in->rLevel[kc1] < lvl) { in->rStamp[kc1] = in->stamp; in->rLevel[kc1] = lvl; }
+        if (in->rStamp[kc2] != in->stamp || in->rLevel[kc2] < lvl) { in->rStamp[kc2] = in->stamp; in->rLevel[kc2] = lvl; }
+    }
+    // counting sort by level (stable)
+    std::vector<int> start(maxLevel + 2, 0);
+    for (int k = 0; k < count; k++) start[level[k] + 1]++;
+    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
+    std::vector<OpDesc> sorted(count);
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
+
+    // descriptors go through the ring in chunks (a 1e5-op list would not fit at once)
+    const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
+    for (int l = 0; l <= maxLevel; l++) {
+        int begin = start[l];
+        const int end = start[l + 1];
+        while (begin < end) {
+            const int n = (int)std::min<size_t>(end - begin, maxChunkOps);
+            void* dOps = nullptr;
+            int rc = uploadTransient(in, &sorted[begin], (size_t)n * sizeof(OpDesc), &dOps);
+            if (rc) return rc;
+            int maxRange = 0;
+            for (int k = begin; k < begin + n; k++) maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (in->timing) {
+                if (in->eventsUsed == in->events.size()) {
+                    hipEvent_t a, b;
+                    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+                    in->events.emplace_back(a, b);
+                }
+                e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
+                HIP_TRY(hipEventRecord(e0, in->stream));
+            }
+            mi355::launchPruneLevel(in->stream, (const OpDesc*)dOps, n, in->matrices, in->P, in->S, in->C, maxRange);
+            if (in->timing) HIP_TRY(hipEventRecord(e1, in->stream));
+            begin += n;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    // cumulative scale factors requested together with the update: fold the factors this call wrote
+    // into the cumulative buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
+    for (int k = 0; k < count; k++) {
+        if (opCum[k] == BEAGLE_OP_NONE || opWrite[k] == BEAGLE_OP_NONE) continue;
+        int rc = ensureScale(in, opCum[k]); if (rc) return rc;
+        const double* src = in->scale[opWrite[k]];
+        int one = 1;
+        void *dSrc = nullptr, *dRaw = nullptr;
+        rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
+        rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
+        mi355::launchAccumulateScale(in->stream, in->scale[opCum[k]], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0,
+                                     in->partStart[opPart[k]], in->partEnd[opPart[k]]);
+    }
+    return 0;
+}
+
+int accumulate(Instance* in, const int* idx, int count, int cum, double sign, int part) {
+    if (badIndex(cum, in->scaleCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureScale(in, cum); if (rc) return rc;
+    if (in->scaleIsRaw[cum]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    std::vector<const double*> srcs(count);
+    std::vector<int> raw(count);
+    for (int k = 0; k < count; k++) {
+        if (badIndex(idx[k], in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        rc = ensureScale(in, idx[k]); if (rc) return rc;
+        srcs[k] = in->scale[idx[k]]; raw[k] = in->scaleIsRaw[idx[k]];
+    }
+    const int chunk = 4096;
+    for (int b = 0; b < count; b += chunk) {
+        const int n = std::min(chunk, count - b);
+        void *dSrc = nullptr, *dRaw = nullptr;
+        rc = uploadTransient(in, &srcs[b], (size_t)n * sizeof(double*), &dSrc); if (rc) return rc;
+        rc = uploadTransient(in, &raw[b], (size_t)n * sizeof(int), &dRaw); if (rc) return rc;
+        mi355::launchAccumulateScale(in->stream, in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, n, sign,
+                                     in->partStart[part], in->partEnd[part]);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int part, double* dOut) {
+    // part < 0: the whole pattern range
+    if (badIndex(rootIdx, in->partialsCount) || !in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) ||
+        badIndex(fIdx, in->eigenCount) || (part >= 0 && badIndex(part, in->partitionCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const int pStart = part < 0 ? 0 : in->partStart[part], pEnd = part < 0 ? in->P : in->partEnd[part];
+    const double* cum = nullptr; int cumRaw = 0;
+    if (cumIdx != BEAGLE_OP_NONE) {
+        if (badIndex(cumIdx, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        int rc = ensureScale(in, cumIdx); if (rc) return rc;
+        cum = in->scale[cumIdx]; cumRaw = in->scaleIsRaw[cumIdx];
+    }
+    mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+                                   in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
+                                   in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* beagleGetVersion(void) { return "4.0.0-mi355"; }
+
+const char* beagleGetCitation(void) {
+    return "MI355X-native tree-likelihood engine behind the beagle.Beagle surface (gfx950 HIP kernels).\n"
+           "API after: Ayres et al. (2019) BEAGLE 3, Systematic Biology 68:1052-1061.";
+}
+
+BeagleResourceList* beagleGetResourceList(void) { return &resources()->rl; }
+
+int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
+                         int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
+                         int scaleBufferCount, const int* resourceList, int resourceCount,
+                         long preferenceFlags, long requirementFlags, BeagleInstanceDetails* returnInfo) {
+    (void)preferenceFlags;
+    if (tipCount < 0 || partialsBufferCount < 1 || compactBufferCount < 0 || stateCount < 2 || stateCount > 255 ||
+        patternCount < 1 || eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
+        return BEAGLE_ERROR_OUT_OF_RANGE;
+    // requirement flags this engine cannot honour
+    if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
+                            BEAGLE_FLAG_FRAMEWORK_CPU | BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL |
+                            BEAGLE_FLAG_SCALING_AUTO | BEAGLE_FLAG_VECTOR_SSE))
+        return BEAGLE_ERROR_NO_RESOURCE;
+    Resources* res = resources();
+    int device = -1;
+    if (resourceList == nullptr || resourceCount <= 0) {
+        if (res->gpuCount > 0) device = 0;
+    } else {
+        for (int i = 0; i < resourceCount && device < 0; i++)
+            if (resourceList[i] >= 1 && resourceList[i] <= res->gpuCount) device = resourceList[i] - 1;
+    }
+    if (device < 0) return BEAGLE_ERROR_NO_RESOURCE;
+    if (hipSetDevice(device) != hipSuccess) return BEAGLE_ERROR_NO_RESOURCE;
+
+    Instance* in = new Instance();
+    in->device = device;
+    in->tipCount = tipCount; in->partialsCount = partialsBufferCount; in->compactCount = compactBufferCount;
+    in->S = stateCount; in->P = patternCount; in->eigenCount = std::max(1, eigenBufferCount);
+    in->matrixCount = matrixBufferCount; in->C = categoryCount; in->scaleCount = scaleBufferCount;
+    in->partialsBytes = (((size_t)categoryCount * patternCount * stateCount * sizeof(double)) + 255) & ~(size_t)255;
+    in->partials.assign(partialsBufferCount, nullptr);
+    in->tipStates.assign(partialsBufferCount, nullptr);
+    in->scale.assign(std::max(1, scaleBufferCount), nullptr);
+    in->scaleIsRaw.assign(std::max(1, scaleBufferCount), 0);
+    in->partStart.assign(1, 0); in->partEnd.assign(1, patternCount);
+    in->wStamp.assign(partialsBufferCount, 0); in->wLevel.assign(partialsBufferCount, 0);
+    in->rStamp.assign(partialsBufferCount, 0); in->rLevel.assign(partialsBufferCount, 0);
+    in->resourceName = res->names[device + 1];
+
+    bool ok = hipStreamCreateWithFlags(&in->ownStream, hipStreamNonBlocking) == hipSuccess;
+    in->stream = in->ownStream;
+    ok = ok && hipHostMalloc((void**)&in->hRing, RING_BYTES, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&in->hResult, 4096, hipHostMallocDefault) == hipSuccess;
+    const size_t S = stateCount, C = categoryCount, E = in->eigenCount;
+    const int rootBlocks = (patternCount + 255) / 256;
+    ok = ok && devAlloc(in, (void**)&in->dRing, RING_BYTES) == 0;
+    ok = ok && devAlloc(in, (void**)&in->matrices, std::max<size_t>(1, matrixBufferCount) * C * S * S * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->eigen, E * (2 * S * S + S) * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->rates, E * C * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->weights, E * C * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->freqs, E * S * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->patternWeights, (size_t)patternCount * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->siteLogL, (size_t)patternCount * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->blockSums, (size_t)rootBlocks * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->dResult, 4096) == 0;
+    if (ok) {
+        // defaults: category rates 1, weights 1/C, pattern weights 1 (beagle.jar!GeneralBeagleImpl#<init>)
+        std::vector<double> ones(std::max<size_t>((size_t)patternCount, E * C), 1.0);
+        ok = upload(in, in->rates, ones.data(), E * C * sizeof(double)) == 0;
+        ok = ok && upload(in, in->patternWeights, ones.data(), (size_t)patternCount * sizeof(double)) == 0;
+        std::vector<double> w(E * C, 1.0 / (double)C);
+        ok = ok && upload(in, in->weights, w.data(), E * C * sizeof(double)) == 0;
+        ok = ok && hipMemsetAsync(in->matrices, 0, std::max<size_t>(1, matrixBufferCount) * C * S * S * sizeof(double), in->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(in->siteLogL, 0, (size_t)patternCount * sizeof(double), in->stream) == hipSuccess;
+    }
+    if (!ok) { destroy(in); return BEAGLE_ERROR_OUT_OF_MEMORY; }
+
+    int handle = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (size_t i = 0; i < g_instances.size(); i++) if (!g_instances[i]) { handle = (int)i; break; }
+        if (handle < 0) { g_instances.push_back(nullptr); handle = (int)g_instances.size() - 1; }
+        g_instances[handle] = in;
+    }
+    if (returnInfo) {
+        returnInfo->resourceNumber = device + 1;
+        returnInfo->resourceName = (char*)in->resourceName.c_str();
+        returnInfo->implName = (char*)"HIP-gfx950-fp64";
+        returnInfo->implDescription = (char*)"hand-written CDNA4 kernels, level-batched pruning";
+        returnInfo->flags = GPU_FLAGS & ~(BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC);
+    }
+    return handle;
+}
+
+int beagleFinalizeInstance(int instance) {
+    Instance* in = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (instance < 0 || instance >= (int)g_instances.size() || !g_instances[instance]) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+        in = g_instances[instance];
+        g_instances[instance] = nullptr;
+    }
+    destroy(in);
+    return BEAGLE_SUCCESS;
+}
+
+int beagleSetCPUThreadCount(int instance, int threadCount) {
+    (void)threadCount;
+    return lookup(instance) ? BEAGLE_SUCCESS : BEAGLE_ERROR_UNINITIALIZED_INSTANCE;   // no-op on a GPU instance
+}
+
+int beagleSetPatternWeights(int instance, const double* w) {
+    GET_INSTANCE(instance);
+    return upload(in, in->patternWeights, w, (size_t)in->P * sizeof(double));
+}
+
+int beagleSetPatternPartitions(int instance, int partitionCount, const int* partitions) {
+    GET_INSTANCE(instance);
+    if (partitionCount < 1) return BEAGLE_ERROR_OUT_OF_RANGE;
+    // partitions are contiguous pattern ranges in concatenation order
+    // (MultiPartitionDataLikelihoodDelegate.java:520-535); anything else is rejected
+    std::vector<int> s(partitionCount, -1), e(partitionCount, -1);
+    for (int p = 0; p < in->P; p++) {
+        const int k = partitions[p];
+        if (badIndex(k, partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (s[k] < 0) s[k] = p;
+        else if (e[k] != p) return BEAGLE_ERROR_NO_IMPLEMENTATION;   // not contiguous
+        e[k] = p + 1;
+    }
+    for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
+    in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e;
+    const size_t n = (size_t)in->partialsCount * partitionCount;
+    in->wStamp.assign(n, 0); in->wLevel.assign(n, 0); in->rStamp.assign(n, 0); in->rLevel.assign(n, 0);
+    in->stamp = 0;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
+    GET_INSTANCE(instance);
+    if (badIndex(tipIndex, in->tipCount) || badIndex(tipIndex, in->partialsCount) || tipIndex >= in->compactCount)
+        return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureStates(in, tipIndex); if (rc) return rc;
+    std::vector<uint8_t> s(in->P);
+    for (int p = 0; p < in->P; p++) s[p] = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
+    return upload(in, in->tipStates[tipIndex], s.data(), (size_t)in->P);
+}
+
+int beagleGetTipStates(int instance, int tipIndex, int* outStates) {
+    GET_INSTANCE(instance);
+    if (badIndex(tipIndex, in->partialsCount) || !in->tipStates[tipIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    std::vector<uint8_t> s(in->P);
+    int rc = download(in, s.data(), in->tipStates[tipIndex], (size_t)in->P); if (rc) return rc;
+    for (int p = 0; p < in->P; p++) outStates[p] = s[p];
+    return BEAGLE_SUCCESS;
+}
+
+int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
+    GET_INSTANCE(instance);
+    if (badIndex(tipIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensurePartials(in, tipIndex); if (rc) return rc;
+    const size_t n = (size_t)in->P * in->S * sizeof(double);
+    if (in->C == 1) { rc = upload(in, in->partials[tipIndex], inPartials, n); }
+    else {
+        // upload one category plane to the LAST plane, replicate it into all planes on the device
+        double* last = in->partials[tipIndex] + (size_t)(in->C - 1) * in->P * in->S;
+        rc = upload(in, last, inPartials, n);
+        if (!rc) mi355::launchReplicateCategories(in->stream, last, in->partials[tipIndex], in->P, in->S, in->C - 1);
+    }
+    in->tipStates[tipIndex] = nullptr;   // the buffer now holds partials (slab memory stays owned by the instance)
+    return rc;
+}
+
+int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
+    GET_INSTANCE(instance);
+    if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensurePartials(in, bufferIndex); if (rc) return rc;
+    in->tipStates[bufferIndex] = nullptr;
+    return upload(in, in->partials[bufferIndex], inPartials, (size_t)in->C * in->P * in->S * sizeof(double));
+}
+
+int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials) {
+    GET_INSTANCE(instance);
+    if (badIndex(bufferIndex, in->partialsCount) || !in->partials[bufferIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = download(in, outPartials, in->partials[bufferIndex], (size_t)in->C * in->P * in->S * sizeof(double));
+    if (rc) return rc;
+    if (scaleIndex != BEAGLE_OP_NONE) {
+        if (badIndex(scaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        rc = ensureScale(in, scaleIndex); if (rc) return rc;
+        std::vector<double> f(in->P);
+        rc = download(in, f.data(), in->scale[scaleIndex], (size_t)in->P * sizeof(double)); if (rc) return rc;
+        const bool raw = in->scaleIsRaw[scaleIndex];
+        for (int c = 0; c < in->C; c++)
+            for (int p = 0; p < in->P; p++) {
+                const double m = raw ? f[p] : exp(f[p]);
+                for (int i = 0; i < in->S; i++) outPartials[((size_t)c * in->P + p) * in->S + i] *= m;
+            }
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int beagleGetLogScaleFactors(int instance, int scaleIndex, double* out) {
+    GET_INSTANCE(instance);
+    if (badIndex(scaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureScale(in, scaleIndex); if (rc) return rc;
+    rc = download(in, out, in->scale[scaleIndex], (size_t)in->P * sizeof(double)); if (rc) return rc;
+    if (in->scaleIsRaw[scaleIndex]) for (int p = 0; p < in->P; p++) out[p] = log(out[p]);
+    return BEAGLE_SUCCESS;
+}
+
+int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, const double* Uinv, const double* lambda) {
+    GET_INSTANCE(instance);
+    if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const size_t S = in->S, stride = 2 * S * S + S;
+    std::vector<double> pack(stride);
+    memcpy(&pack[0], U, S * S * sizeof(double));
+    memcpy(&pack[S * S], Uinv, S * S * sizeof(double));
+    memcpy(&pack[2 * S * S], lambda, S * sizeof(double));
+    return upload(in, in->eigen + stride * eigenIndex, pack.data(), stride * sizeof(double));
+}
+
+int beagleSetStateFrequencies(int instance, int idx, const double* f) {
+    GET_INSTANCE(instance);
+    if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return upload(in, in->freqs + (size_t)idx * in->S, f, (size_t)in->S * sizeof(double));
+}
+
+int beagleSetCategoryWeights(int instance, int idx, const double* w) {
+    GET_INSTANCE(instance);
+    if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return upload(in, in->weights + (size_t)idx * in->C, w, (size_t)in->C * sizeof(double));
+}
+
+int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
+    GET_INSTANCE(instance);
+    if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return upload(in, in->rates + (size_t)idx * in->C, r, (size_t)in->C * sizeof(double));
+}
+
+int beagleSetCategoryRates(int instance, const double* r) { return beagleSetCategoryRatesWithIndex(instance, 0, r); }
+
+int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMatrix, double paddedValue) {
+    (void)paddedValue;
+    GET_INSTANCE(instance);
+    if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const size_t n = (size_t)in->C * in->S * in->S;
+    return upload(in, in->matrices + n * matrixIndex, inMatrix, n * sizeof(double));
+}
+
+int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix) {
+    GET_INSTANCE(instance);
+    if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const size_t n = (size_t)in->C * in->S * in->S;
+    return download(in, outMatrix, in->matrices + n * matrixIndex, n * sizeof(double));
+}
+
+int beagleConvolveTransitionMatrices(int instance, const int* first, const int* second, const int* result, int count) {
+    GET_INSTANCE(instance);
+    if (count <= 0) return BEAGLE_SUCCESS;
+    for (int k = 0; k < count; k++) {
+        if (badIndex(first[k], in->matrixCount) || badIndex(second[k], in->matrixCount) || badIndex(result[k], in->matrixCount) ||
+            result[k] == first[k] || result[k] == second[k]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    // a result may feed a later triple of the same call (epoch chains): run dependent triples in order
+    int b = 0;
+    while (b < count) {
+        int e = b + 1;
+        for (; e < count; e++) {
+            bool dep = false;
+            for (int k = b; k < e && !dep; k++)
+                dep = result[k] == first[e] || result[k] == second[e] || result[k] == result[e] ||
+                      first[k] == result[e] || second[k] == result[e];
+            if (dep) break;
+        }
+        const int n = e - b;
+        void *dF, *dS, *dR;
+        int rc = uploadTransient(in, first + b, n * sizeof(int), &dF); if (rc) return rc;
+        rc = uploadTransient(in, second + b, n * sizeof(int), &dS); if (rc) return rc;
+        rc = uploadTransient(in, result + b, n * sizeof(int), &dR); if (rc) return rc;
+        mi355::launchConvolveMatrices(in->stream, in->matrices, (const int*)dF, (const int*)dS, (const int*)dR, n, in->S, in->C);
+        b = e;
+    }
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar, const int* rateIdx,
+                              const int* probIdx, const double* lens, int count) {
+    if (count <= 0) return BEAGLE_SUCCESS;
+    std::vector<int> eig(count), rate(count);
+    for (int k = 0; k < count; k++) {
+        eig[k] = eigenIdx ? eigenIdx[k] : eigenScalar;
+        rate[k] = rateIdx ? rateIdx[k] : 0;
+        if (badIndex(probIdx[k], in->matrixCount) || badIndex(eig[k], in->eigenCount) || badIndex(rate[k], in->eigenCount))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    void *dIdx, *dLen, *dEig, *dRate;
+    int rc = uploadTransient(in, probIdx, (size_t)count * sizeof(int), &dIdx); if (rc) return rc;
+    rc = uploadTransient(in, lens, (size_t)count * sizeof(double), &dLen); if (rc) return rc;
+    rc = uploadTransient(in, eig.data(), (size_t)count * sizeof(int), &dEig); if (rc) return rc;
+    rc = uploadTransient(in, rate.data(), (size_t)count * sizeof(int), &dRate); if (rc) return rc;
+    mi355::launchTransitionMatrices(in->stream, in->matrices, in->eigen, in->rates, (const int*)dIdx, (const double*)dLen,
+                                    (const int*)dEig, (const int*)dRate, count, in->S, in->C);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* probabilityIndices,
+                                   const int* firstDerivativeIndices, const int* secondDerivativeIndices,
+                                   const double* edgeLengths, int count) {
+    GET_INSTANCE(instance);
+    if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    return transitionMatrices(in, nullptr, eigenIndex, nullptr, probabilityIndices, edgeLengths, count);
+}
+
+int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices, const int* categoryRateIndices,
+                                   const int* probabilityIndices, const int* firstDerivativeIndices,
+                                   const int* secondDerivativeIndices, const double* edgeLengths, int count) {
+    GET_INSTANCE(instance);
+    if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (!eigenIndices || !categoryRateIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return transitionMatrices(in, eigenIndices, 0, categoryRateIndices, probabilityIndices, edgeLengths, count);
+}
+
+int beagleUpdatePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
+    GET_INSTANCE(instance);
+    return runOperations(in, operations, operationCount, BEAGLE_OP_COUNT, cumulativeScaleIndex);
+}
+
+int beagleUpdatePartialsByPartition(int instance, const int* operations, int operationCount) {
+    GET_INSTANCE(instance);
+    return runOperations(in, operations, operationCount, BEAGLE_PARTITION_OP_COUNT, BEAGLE_OP_NONE);
+}
+
+int beagleWaitForPartials(int instance, const int* destinationPartials, int count) {
+    (void)destinationPartials; (void)count;
+    GET_INSTANCE(instance);
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->ringHead = 0;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
+    GET_INSTANCE(instance);
+    return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, 0);
+}
+int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
+    GET_INSTANCE(instance);
+    return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, partitionIndex);
+}
+int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
+    GET_INSTANCE(instance);
+    return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, 0);
+}
+int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
+    GET_INSTANCE(instance);
+    return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, partitionIndex);
+}
+
+int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex) {
+    GET_INSTANCE(instance);
+    if (badIndex(cumulativeScaleIndex, in->scaleCount) || badIndex(partitionIndex, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
+    if (in->scaleIsRaw[cumulativeScaleIndex] && in->partitionCount > 1) {
+        // a per-node (raw) buffer is being recycled as a cumulative one: clear all of it first
+        mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
+    }
+    in->scaleIsRaw[cumulativeScaleIndex] = 0;
+    mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, in->partStart[partitionIndex], in->partEnd[partitionIndex]);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
+    GET_INSTANCE(instance);
+    if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
+    in->scaleIsRaw[cumulativeScaleIndex] = 0;
+    mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+int beagleCopyScaleFactors(int instance, int dest, int src) {
+    GET_INSTANCE(instance);
+    if (badIndex(dest, in->scaleCount) || badIndex(src, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = ensureScale(in, dest); if (rc) return rc;
+    rc = ensureScale(in, src); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+    in->scaleIsRaw[dest] = in->scaleIsRaw[src];
+    return BEAGLE_SUCCESS;
+}
+
+int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, const int* categoryWeightsIndices,
+                                      const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
+                                      int count, double* outSumLogLikelihood) {
+    GET_INSTANCE(instance);
+    if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;   // BEAST always passes 1 (BeagleTreeLikelihood.java:1038)
+    int rc = rootEnqueue(in, bufferIndices[0], categoryWeightsIndices[0], stateFrequenciesIndices[0],
+                         cumulativeScaleIndices[0], -1, in->dResult);
+    if (rc) return rc;
+    rc = download(in, in->hResult, in->dResult, sizeof(double));
+    if (rc) return rc;
+    const double v = in->hResult[0];
+    *outSumLogLikelihood = v;
+    return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+}
+
+int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* bufferIndices, const int* categoryWeightsIndices,
+                                      const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
+                                      const int* partitionIndices, int partitionCount, int count,
+                                      double* outByPartition, double* outSum) {
+    GET_INSTANCE(instance);
+    if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (partitionCount < 1 || partitionCount > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
+    for (int k = 0; k < partitionCount; k++) {
+        int rc = rootEnqueue(in, bufferIndices[k], categoryWeightsIndices[k], stateFrequenciesIndices[k],
+                             cumulativeScaleIndices[k], partitionIndices[k], in->dResult + k);
+        if (rc) return rc;
+    }
+    int rc = download(in, in->hResult, in->dResult, (size_t)partitionCount * sizeof(double));
+    if (rc) return rc;
+    double tot = 0.0;
+    for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[k]; tot += in->hResult[k]; }
+    *outSum = tot;
+    return (tot != tot) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+}
+
+int beagleGetSiteLogLikelihoods(int instance, double* out) {
+    GET_INSTANCE(instance);
+    return download(in, out, in->siteLogL, (size_t)in->P * sizeof(double));
+}
+
+// ---- outside SURVEY 8 (a)-(e): exported so the JNI shim links ---------------------------------
+int beagleSetRootPrePartials(int, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+int beagleSetDifferentialMatrix(int, int, const double*) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+int beagleAddTransitionMatrices(int, const int*, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+int beagleTransposeTransitionMatrices(int, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+int beagleUpdatePrePartials(int, const int*, int, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+int beagleUpdatePrePartialsByPartition(int, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+
+// ---- MI355X extensions -----------------------------------------------------------------------
+int beagleMi355SetStream(int instance, void* hipStream) {
+    GET_INSTANCE(instance);
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->ringHead = 0;
+    in->stream = hipStream ? (hipStream_t)hipStream : in->ownStream;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
+                                                 int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut) {
+    GET_INSTANCE(instance);
+    if (!deviceOut) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
+}
+
+int beagleMi355Synchronize(int instance) {
+    GET_INSTANCE(instance);
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->ringHead = 0;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* outLaunches) {
+    GET_INSTANCE(instance);
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->ringHead = 0;
+    for (size_t k = 0; k < in->eventsUsed; k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) { in->timedMs += ms; in->timedLaunches++; }
+    }
+    in->eventsUsed = 0;
+    if (outMillis) *outMillis = in->timedMs;
+    if (outLaunches) *outLaunches = in->timedLaunches;
+    in->timedMs = 0.0; in->timedLaunches = 0;
+    in->timing = enable != 0;
+    return BEAGLE_SUCCESS;
+}
+
+long beagleMi355DeviceBytes(int instance) {
+    Instance* in = lookup(instance);
+    return in ? (long)in->deviceBytes : -1;
+}
+
+static const BeagleApi g_api = {
+    beagleGetVersion,
+    beagleCreateInstance,
+    beagleFinalizeInstance,
+    beagleSetPatternWeights,
+    beagleSetTipStates,
+    beagleSetTipPartials,
+    beagleSetPartials,
+    beagleGetPartials,
+    beagleGetLogScaleFactors,
+    beagleSetEigenDecomposition,
+    beagleSetStateFrequencies,
+    beagleSetCategoryWeights,
+    beagleSetCategoryRates,
+    beagleSetTransitionMatrix,
+    beagleGetTransitionMatrix,
+    beagleUpdateTransitionMatrices,
+    beagleUpdatePartials,
+    beagleAccumulateScaleFactors,
+    beagleRemoveScaleFactors,
+    beagleResetScaleFactors,
+    beagleCopyScaleFactors,
+    beagleCalculateRootLogLikelihoods,
+    beagleGetSiteLogLikelihoods,
+};
+const BeagleApi* beagleGetApiTable(void) { return &g_api; }
+
+}  // extern "C"

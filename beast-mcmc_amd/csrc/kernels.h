@@ -1,0 +1,64 @@
+// kernels.h — device-side data structures and launcher prototypes of the MI355X engine.
+// Everything here is gfx950-only HIP; there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+// One pruning operation as the kernels see it: pointers already resolved on the host from the
+// reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
+// [, partition, cumulativeScale]} (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1266-1299).
+struct OpDesc {
+    double*        dest;        // [C][P][S] partials, written on [pStart, pEnd)
+    const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0)
+    const void*    child2;      // same (kind bit 1)
+    double*        scaleWrite;  // per-pattern raw scale factors to WRITE (rescale now), or nullptr
+    const double*  scaleRead;   // per-pattern raw scale factors to READ (divide by existing), or nullptr
+    int            mat1, mat2;  // transition-matrix buffer indices
+    int            kind;        // bit0: child1 is compact states; bit1: child2 is compact states
+    int            pStart, pEnd;// pattern range of this op (whole buffer unless a ...ByPartition call)
+    int            pad;
+};
+static_assert(sizeof(OpDesc) == 64, "OpDesc must stay 64 bytes");
+
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2 };
+
+// ---- launchers (all asynchronous on `stream`) -------------------------------------------------
+
+// P(t) = U diag(exp(lambda * t * r_c)) U^-1, negatives clamped to 0, for `count` branches.
+// dIdx/dLen/dEig/dRate: device arrays of length `count`: destination matrix index, edge length,
+// eigen-system index and category-rate-set index per branch.
+void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,
+                              const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
+                              int count, int S, int C);
+
+// C_c = A_c * B_c per category, `count` triples (device index arrays).
+void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,
+                            const int* dResult, int count, int S, int C);
+
+// One dependency level of pruning operations: `nOps` independent ops, descriptors on the device.
+// maxRange = max over ops of (pEnd - pStart).
+void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices,
+                      int P, int S, int C, int maxRange);
+
+// site[p] = log(sum_c w_c sum_i pi_i root[c][p][i]) + cum[p];  blockSums[b] = sum_p weight[p]*site[p] over block b
+// then out[0] = sum_b blockSums[b] in a fixed order (deterministic).  cum may be nullptr; cumIsRaw says the
+// buffer holds raw factors (log is taken on the fly).  Restricted to [pStart, pEnd).
+void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
+                             const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
+                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd);
+
+// cum[p] += sign * sum_k (raw_k ? log(src_k[p]) : src_k[p]) on [pStart, pEnd); srcs/raws are device arrays.
+void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
+                           int count, double sign, int pStart, int pEnd);
+
+void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd);
+// out[p] = raw ? log(in[p]) : in[p]
+void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
+// dst[c][p][i] = src[p][i] for every category (setTipPartials replication)
+void launchReplicateCategories(hipStream_t stream, const double* src, double* dst, int P, int S, int C);
+
+int  pruneBlocksForRange(int S, int range);
+
+}  // namespace mi355

@@ -1,0 +1,437 @@
+// kernels.hip — hand-written CDNA4 (gfx950) kernels of the tree-likelihood hot path.
+//
+// Data layout in HBM:
+//   partials  double[C][P][S]  — pattern-major inside each rate category: consecutive lanes own consecutive
+//                                patterns, so a wave's loads/stores of one category plane are one contiguous
+//                                run (S=4: 64 lanes x 32 B = 2 KiB per plane per wave)
+//   tip states uint8[P]        — 1 byte per pattern, value == S means missing/ambiguous
+//   matrices  double[M][C][S][S]
+//   scale     double[P]        — RAW per-pattern factors for per-node buffers (read mode needs 1/f, not exp),
+//                                LOG for cumulative buffers
+//
+// What each kernel restates (reference = /root/reference):
+//   k_prune4 / k_pruneGeneral   src/dr/oldevomodel/treelikelihood/GeneralLikelihoodCore.java:52-203
+//                               (+ 4-state unrolling as NucleotideLikelihoodCore.java:54-270), rescale as
+//                               AbstractLikelihoodCore.java:406-440 applied unconditionally (BEAGLE semantics)
+//   k_root*                     GeneralLikelihoodCore.java:358-406
+//   k_transition                src/dr/evomodel/substmodel/BaseSubstitutionModel.java:206-245,
+//                               lib/beagle.jar!beagle/GeneralBeagleImpl#updateTransitionMatrices
+//   k_accumulate                AbstractLikelihoodCore.java:442-458 as a persistent cumulative buffer
+#include "kernels.h"
+
+namespace mi355 {
+
+// ------------------------------------------------------------------------------------------------
+// transition matrices
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrices, const double* __restrict__ eigen,
+                                                    const double* __restrict__ rates, const int* __restrict__ dIdx,
+                                                    const double* __restrict__ dLen, const int* __restrict__ dEig,
+                                                    const int* __restrict__ dRate, int S, int C) {
+    extern __shared__ double sh[];            // iexp[S][S]
+    const int u = blockIdx.x, c = blockIdx.y;
+    const size_t eigStride = (size_t)2 * S * S + S;
+    const double* U = eigen + eigStride * dEig[u];
+    const double* Ui = U + (size_t)S * S;
+    const double* lam = Ui + (size_t)S * S;
+    const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+        const int k = e / S;
+        sh[e] = Ui[e] * exp(dist * lam[k]);
+    }
+    __syncthreads();
+    double* M = matrices + ((size_t)dIdx[u] * C + c) * S * S;
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+        const int i = e / S, j = e - i * S;
+        double s = 0.0;
+        for (int k = 0; k < S; k++) s += U[i * S + k] * sh[k * S + j];
+        M[e] = s > 0.0 ? s : 0.0;
+    }
+}
+
+void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,
+                              const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
+                              int count, int S, int C) {
+    if (count <= 0) return;
+    const int threads = S * S >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), (size_t)S * S * sizeof(double), stream,
+                       matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C);
+}
+
+__global__ __launch_bounds__(256) void k_convolve(double* __restrict__ matrices, const int* __restrict__ dFirst,
+                                                  const int* __restrict__ dSecond, const int* __restrict__ dResult,
+                                                  int S, int C) {
+    const int u = blockIdx.x, c = blockIdx.y;
+    const double* A = matrices + ((size_t)dFirst[u] * C + c) * S * S;
+    const double* B = matrices + ((size_t)dSecond[u] * C + c) * S * S;
+    double* R = matrices + ((size_t)dResult[u] * C + c) * S * S;
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+        const int i = e / S, j = e - i * S;
+        double s = 0.0;
+        for (int k = 0; k < S; k++) s += A[i * S + k] * B[k * S + j];
+        R[e] = s;
+    }
+}
+
+void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,
+                            const int* dResult, int count, int S, int C) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_convolve, dim3(count, C), dim3(S * S >= 256 ? 256 : 64), 0, stream,
+                       matrices, dFirst, dSecond, dResult, S, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4-state pruning: one thread = one pattern, all C categories (so the per-pattern rescale max never
+// leaves the thread's registers).  Both children's transition matrices for all categories are staged
+// in LDS once per workgroup and read by every lane at a wave-uniform address (LDS broadcast); the
+// compact-state path reads a [state][i] column table whose extra row (state == 4) is all ones.
+// ------------------------------------------------------------------------------------------------
+constexpr int NUC_BLOCK = 256;
+
+struct __attribute__((aligned(32))) d4 { double x, y, z, w; };
+
+template <int C>
+struct NucLds {
+    double row[2][C][16];      // [child][c][i*4 + j]
+    double col[2][C][5][4];    // [child][c][state][i]; state 4 = unknown -> 1.0
+};
+
+template <int C, bool ST>
+__device__ __forceinline__ void nucChild(const NucLds<C>& L, int child, const void* __restrict__ src, int P, int p,
+                                         double (&f)[C][4]) {
+    if (ST) {
+        const int s = reinterpret_cast<const uint8_t*>(src)[p];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[c][i] = L.col[child][c][s][i];
+        }
+    } else {
+        const double* x = reinterpret_cast<const double*>(src);
+        d4 v[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) v[c] = *reinterpret_cast<const d4*>(x + ((size_t)c * P + p) * 4);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double* m = &L.row[child][c][i * 4];
+                f[c][i] = m[0] * v[c].x + m[1] * v[c].y + m[2] * v[c].z + m[3] * v[c].w;
+            }
+        }
+    }
+}
+
+template <int C, bool ST1, bool ST2>
+__device__ __forceinline__ void nucBody(const NucLds<C>& L, const OpDesc& op, int P, int p) {
+    double a[C][4], b[C][4];
+    nucChild<C, ST1>(L, 0, op.child1, P, p, a);
+    nucChild<C, ST2>(L, 1, op.child2, P, p, b);
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[c][i] *= b[c][i];
+    if (op.scaleWrite) {
+        double m = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) m = fmax(m, a[c][i]);
+        if (!(m > 0.0)) m = 1.0;
+        op.scaleWrite[p] = m;
+        const double inv = 1.0 / m;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[c][i] *= inv;
+    } else if (op.scaleRead) {
+        const double inv = 1.0 / op.scaleRead[p];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[c][i] *= inv;
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        d4 o; o.x = a[c][0]; o.y = a[c][1]; o.z = a[c][2]; o.w = a[c][3];
+        *reinterpret_cast<d4*>(op.dest + ((size_t)c * P + p) * 4) = o;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
+    __shared__ NucLds<C> L;
+    const OpDesc op = ops[blockIdx.y];
+    const int p0 = op.pStart + blockIdx.x * NUC_BLOCK;
+    if (p0 >= op.pEnd) return;
+    for (int t = threadIdx.x; t < 2 * C * 16; t += NUC_BLOCK) {
+        const int child = t / (C * 16), r = t - child * (C * 16);
+        const int c = r >> 4, e = r & 15;
+        const double v = matrices[(size_t)(child ? op.mat2 : op.mat1) * (C * 16) + r];
+        L.row[child][c][e] = v;
+        L.col[child][c][e & 3][e >> 2] = v;
+    }
+    for (int t = threadIdx.x; t < 2 * C * 4; t += NUC_BLOCK) {
+        const int child = t / (C * 4), r = t - child * (C * 4);
+        L.col[child][r >> 2][4][r & 3] = 1.0;
+    }
+    __syncthreads();
+    const int p = p0 + threadIdx.x;
+    if (p >= op.pEnd) return;
+    switch (op.kind) {
+        case 0:                              nucBody<C, false, false>(L, op, P, p); break;
+        case KIND_STATES1:                   nucBody<C, true,  false>(L, op, P, p); break;
+        case KIND_STATES2:                   nucBody<C, false, true >(L, op, P, p); break;
+        default:                             nucBody<C, true,  true >(L, op, P, p); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// general state count (20, 61, ...): VALU kernel, any S <= 256 and any C.  A workgroup owns a strided set
+// of pattern tiles of one op; per category it stages both transposed matrices in LDS once and then
+// streams its tiles through: thread (pl, i) computes parent state i of pattern pl.
+// Rescaling in write mode is two-phase (running max per pattern, then a divide pass over the
+// workgroup's own tiles) because the max spans categories.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_BLOCK = 256;
+
+__global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
+                                                            int P, int S, int C) {
+    extern __shared__ double sh[];
+    const int ppb = GEN_BLOCK / S;                   // patterns per pass
+    double* mT1 = sh;                                // [S+1][S]  (row S = ones: unknown state)
+    double* mT2 = mT1 + (size_t)(S + 1) * S;
+    double* x1 = mT2 + (size_t)(S + 1) * S;          // [ppb][S]
+    double* x2 = x1 + (size_t)ppb * S;
+    double* red = x2 + (size_t)ppb * S;              // [ppb][S] products for the max reduction
+    const OpDesc op = ops[blockIdx.y];
+    const int range = op.pEnd - op.pStart;
+    const int tiles = (range + ppb - 1) / ppb;
+    if ((int)blockIdx.x >= tiles) return;
+    const int pl = threadIdx.x / S, i = threadIdx.x - pl * S;
+    const bool lane = pl < ppb;
+    const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
+    const uint8_t* s1 = reinterpret_cast<const uint8_t*>(op.child1);
+    const uint8_t* s2 = reinterpret_cast<const uint8_t*>(op.child2);
+    const double* c1 = reinterpret_cast<const double*>(op.child1);
+    const double* c2 = reinterpret_cast<const double*>(op.child2);
+
+    for (int c = 0; c < C; c++) {
+        __syncthreads();
+        const double* M1 = matrices + ((size_t)op.mat1 * C + c) * S * S;
+        const double* M2 = matrices + ((size_t)op.mat2 * C + c) * S * S;
+        for (int e = threadIdx.x; e < S * S; e += GEN_BLOCK) {
+            const int r = e / S, q = e - r * S;
+            mT1[q * S + r] = M1[e];
+            mT2[q * S + r] = M2[e];
+        }
+        for (int e = threadIdx.x; e < S; e += GEN_BLOCK) { mT1[S * S + e] = 1.0; mT2[S * S + e] = 1.0; }
+        for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+            const int pBase = op.pStart + tile * ppb;
+            const int np = min(ppb, op.pEnd - pBase);
+            __syncthreads();
+            if (!st1) for (int e = threadIdx.x; e < np * S; e += GEN_BLOCK) x1[e] = c1[((size_t)c * P + pBase) * S + e];
+            if (!st2) for (int e = threadIdx.x; e < np * S; e += GEN_BLOCK) x2[e] = c2[((size_t)c * P + pBase) * S + e];
+            __syncthreads();
+            const bool act = lane && pl < np;
+            double v = 0.0;
+            if (act) {
+                const int p = pBase + pl;
+                double sum1, sum2;
+                if (st1) sum1 = mT1[(int)s1[p] * S + i];
+                else { sum1 = 0.0; for (int j = 0; j < S; j++) sum1 += mT1[j * S + i] * x1[pl * S + j]; }
+                if (st2) sum2 = mT2[(int)s2[p] * S + i];
+                else { sum2 = 0.0; for (int j = 0; j < S; j++) sum2 += mT2[j * S + i] * x2[pl * S + j]; }
+                v = sum1 * sum2;
+                if (op.scaleRead) v *= 1.0 / op.scaleRead[p];
+                op.dest[((size_t)c * P + p) * S + i] = v;
+            }
+            if (op.scaleWrite) {
+                if (lane) red[pl * S + i] = act ? v : 0.0;
+                __syncthreads();
+                if (act && i == 0) {
+                    double m = 0.0;
+                    for (int j = 0; j < S; j++) m = fmax(m, red[pl * S + j]);
+                    const int p = pBase + pl;
+                    if (c > 0) m = fmax(m, op.scaleWrite[p]);
+                    op.scaleWrite[p] = m;
+                }
+            }
+        }
+    }
+    if (op.scaleWrite) {
+        __syncthreads();
+        for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+            const int pBase = op.pStart + tile * ppb;
+            const int np = min(ppb, op.pEnd - pBase);
+            __syncthreads();
+            if (lane && pl < np && i == 0) {
+                const int p = pBase + pl;
+                double m = op.scaleWrite[p];
+                if (!(m > 0.0)) { m = 1.0; op.scaleWrite[p] = 1.0; }
+                red[pl] = 1.0 / m;
+            }
+            __syncthreads();
+            if (lane && pl < np) {
+                const int p = pBase + pl;
+                const double inv = red[pl];
+                for (int c = 0; c < C; c++) op.dest[((size_t)c * P + p) * S + i] *= inv;
+            }
+        }
+    }
+}
+
+int pruneBlocksForRange(int S, int range) {
+    if (S == 4) return (range + NUC_BLOCK - 1) / NUC_BLOCK;
+    const int ppb = GEN_BLOCK / S;
+    const int tiles = (range + ppb - 1) / ppb;
+    // enough workgroups to fill the chip, few enough that the per-category matrix staging is amortised
+    const int cap = 1024;
+    return tiles < cap ? tiles : cap;
+}
+
+void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices,
+                      int P, int S, int C, int maxRange) {
+    if (nOps <= 0 || maxRange <= 0) return;
+    if (S == 4 && C <= 8) {
+        dim3 grid(pruneBlocksForRange(4, maxRange), nOps), block(NUC_BLOCK);
+        switch (C) {
+            case 1: hipLaunchKernelGGL(k_prune4<1>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 2: hipLaunchKernelGGL(k_prune4<2>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 3: hipLaunchKernelGGL(k_prune4<3>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 4: hipLaunchKernelGGL(k_prune4<4>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 5: hipLaunchKernelGGL(k_prune4<5>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 6: hipLaunchKernelGGL(k_prune4<6>, grid, block, 0, stream, dOps, matrices, P); break;
+            case 7: hipLaunchKernelGGL(k_prune4<7>, grid, block, 0, stream, dOps, matrices, P); break;
+            default: hipLaunchKernelGGL(k_prune4<8>, grid, block, 0, stream, dOps, matrices, P); break;
+        }
+        return;
+    }
+    const int ppb = GEN_BLOCK / S;
+    const size_t lds = ((size_t)2 * (S + 1) * S + (size_t)3 * ppb * S) * sizeof(double);
+    int blocks = pruneBlocksForRange(S, maxRange);
+    // keep total workgroups around a few per CU when many ops share the launch
+    if (nOps > 1) { int per = (4096 + nOps - 1) / nOps; if (per < 1) per = 1; if (blocks > per) blocks = per; }
+    static size_t ldsGranted = 48 * 1024;
+    if (lds > ldsGranted) {   // S = 61 needs 66 KB of the CU's 160 KB
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneGeneral), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ldsGranted = lds;
+    }
+    hipLaunchKernelGGL(k_pruneGeneral, dim3(blocks, nOps), dim3(GEN_BLOCK), lds, stream, dOps, matrices, P, S, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// root: integrate over categories and states, log, add cumulative scale, weighted deterministic sum
+// ------------------------------------------------------------------------------------------------
+constexpr int ROOT_BLOCK = 256;
+
+__device__ __forceinline__ double blockSum(double v, double* sh) {
+    // fixed-shape tree: wave shuffle (64 lanes) then LDS across the 4 waves — same order every run
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) { for (int k = 0; k < ROOT_BLOCK / 64; k++) t += sh[k]; }
+    return t;
+}
+
+__global__ __launch_bounds__(ROOT_BLOCK) void k_rootSite(const double* __restrict__ root, const double* __restrict__ catWeights,
+                                                         const double* __restrict__ freqs, const double* __restrict__ cum,
+                                                         int cumIsRaw, const double* __restrict__ patternWeights,
+                                                         double* __restrict__ siteLogL, double* __restrict__ blockSums,
+                                                         int P, int S, int C, int pStart, int pEnd) {
+    __shared__ double sh[ROOT_BLOCK / 64];
+    const int p = pStart + blockIdx.x * ROOT_BLOCK + threadIdx.x;
+    double contrib = 0.0;
+    if (p < pEnd) {
+        double sum = 0.0;
+        if (S == 4) {
+            for (int c = 0; c < C; c++) {
+                const d4 v = *reinterpret_cast<const d4*>(root + ((size_t)c * P + p) * 4);
+                sum += catWeights[c] * (freqs[0] * v.x + freqs[1] * v.y + freqs[2] * v.z + freqs[3] * v.w);
+            }
+        } else {
+            for (int c = 0; c < C; c++) {
+                const double* r = root + ((size_t)c * P + p) * S;
+                double s = 0.0;
+                for (int i = 0; i < S; i++) s += freqs[i] * r[i];
+                sum += catWeights[c] * s;
+            }
+        }
+        double site = log(sum);
+        if (cum) site += cumIsRaw ? log(cum[p]) : cum[p];
+        siteLogL[p] = site;
+        contrib = site * patternWeights[p];
+    }
+    const double t = blockSum(contrib, sh);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinal(const double* __restrict__ blockSums, int n, double* __restrict__ out) {
+    __shared__ double sh[ROOT_BLOCK / 64];
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += ROOT_BLOCK) v += blockSums[k];
+    const double t = blockSum(v, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
+                             const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
+                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd) {
+    const int n = (pEnd - pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
+    hipLaunchKernelGGL(k_rootSite, dim3(n), dim3(ROOT_BLOCK), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
+                       patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
+    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scale-factor bookkeeping
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_accumulate(double* __restrict__ cum, const double* const* __restrict__ srcs,
+                                                    const int* __restrict__ raw, int count, double sign, int pStart, int pEnd) {
+    const int p = pStart + blockIdx.x * 256 + threadIdx.x;
+    if (p >= pEnd) return;
+    double acc = 0.0;
+    for (int k = 0; k < count; k++) {
+        const double v = srcs[k][p];
+        acc += raw[k] ? log(v) : v;
+    }
+    cum[p] += sign * acc;
+}
+
+void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
+                           int count, double sign, int pStart, int pEnd) {
+    if (count <= 0 || pEnd <= pStart) return;
+    hipLaunchKernelGGL(k_accumulate, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, cum, dSrcs, dRaw, count, sign, pStart, pEnd);
+}
+
+__global__ void k_fill(double* dst, double value, int pStart, int pEnd) {
+    const int p = pStart + blockIdx.x * 256 + threadIdx.x;
+    if (p < pEnd) dst[p] = value;
+}
+void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd) {
+    if (pEnd <= pStart) return;
+    hipLaunchKernelGGL(k_fill, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, dst, value, pStart, pEnd);
+}
+
+__global__ void k_logScale(const double* in, double* out, int raw, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) out[p] = raw ? log(in[p]) : in[p];
+}
+void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P) {
+    hipLaunchKernelGGL(k_logScale, dim3((P + 255) / 256), dim3(256), 0, stream, in, out, raw, P);
+}
+
+__global__ void k_replicate(const double* src, double* dst, size_t n, int C) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const double v = src[e];
+    for (int c = 0; c < C; c++) dst[(size_t)c * n + e] = v;
+}
+void launchReplicateCategories(hipStream_t stream, const double* src, double* dst, int P, int S, int C) {
+    const size_t n = (size_t)P * S;
+    hipLaunchKernelGGL(k_replicate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n, C);
+}
+
+}  // namespace mi355

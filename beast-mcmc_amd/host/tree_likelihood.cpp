@@ -1,0 +1,436 @@
+// tree_likelihood.cpp — host-side mirror of the reference's BEAGLE caller, in C++ (no JDK in the
+// build image), written against the engine's C ABI (include/beagle_mi355.h) only.
+//
+// It reproduces the bookkeeping BEAST does ABOVE the beagle.Beagle surface, so that tests and the
+// benchmark drive the engine with exactly the call sequence the reference issues:
+//
+//   BufferIndexHelper         src/dr/evomodel/treedatalikelihood/BufferIndexHelper.java:40-116
+//   calculateLogLikelihood    src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:863-1130
+//                             (rescaling policy :883-910, call order :944-1050, underflow retry :1059-1113)
+//   traverse (post-order)     BeagleTreeLikelihood.java:1202-1322
+//   reverse level order       src/dr/evomodel/treedatalikelihood/LikelihoodTreeTraversal.java:133-205
+//   store / restore           BeagleTreeLikelihood.java:816-851 (index flips only, no data copies)
+//   instance shape            BeagleTreeLikelihood.java:193-203, 420-433
+//   branch length             rate * (parent height - node height), BeagleTreeLikelihood.java:1221-1231
+//   rescaling schemes         src/dr/evomodel/treelikelihood/PartialsRescalingScheme.java:34-42
+//
+// It holds no likelihood arithmetic: every O(patterns) operation is a call through BeagleApi.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+#include "../../include/beagle_mi355.h"
+
+namespace {
+
+class BufferIndexHelper {
+public:
+    BufferIndexHelper() : minIndex(0), dbl(0) {}
+    BufferIndexHelper(int maxIndexValue, int minIndexValue)
+        : minIndex(minIndexValue), dbl(maxIndexValue - minIndexValue),
+          offsets(dbl, 0), stored(dbl, 0), flipped(dbl, 0) {}
+    int getBufferCount() const { return 2 * dbl + minIndex; }
+    void flipOffset(int i) {
+        int k = i - minIndex;
+        if (!flipped[k]) { offsets[k] = dbl - offsets[k]; flipped[k] = 1; }  // only once before accept/reject
+    }
+    int getOffsetIndex(int i) const { return i < minIndex ? i : offsets[i - minIndex] + i; }
+    void storeState() { std::fill(flipped.begin(), flipped.end(), 0); stored = offsets; }
+    void restoreState() { offsets.swap(stored); std::fill(flipped.begin(), flipped.end(), 0); }
+private:
+    int minIndex, dbl;
+    std::vector<int> offsets, stored;
+    std::vector<char> flipped;
+};
+
+enum Scheme { SCHEME_NONE = 0, SCHEME_ALWAYS = 1, SCHEME_DYNAMIC = 2, SCHEME_DELAYED = 3 };
+enum Traversal { POST_ORDER = 0, REVERSE_LEVEL_ORDER = 1 };
+
+struct TreeLikelihood {
+    const BeagleApi* api = nullptr;
+    int inst = -1;
+    int tipCount = 0, nodeCount = 0, internalNodeCount = 0, S = 0, P = 0, C = 0;
+    int root = -1;
+    std::vector<int> parent, left, right;
+    std::vector<double> height, branchRate;
+    std::vector<char> updateNode;
+    bool updateSubstitutionModel = true, updateSiteModel = true;
+    bool likelihoodKnown = false;
+    double logLikelihood = 0.0, storedLogLikelihood = 0.0;
+    bool storedLikelihoodKnown = false;
+
+    BufferIndexHelper partialBufferHelper, scaleBufferHelper, matrixBufferHelper, eigenBufferHelper;
+    std::vector<int> scaleBufferIndices, storedScaleBufferIndices;
+
+    int scheme = SCHEME_DYNAMIC;
+    bool delayRescalingUntilUnderflow = true;
+    int rescalingFrequency = 100;          // beagle.rescale default, BeagleTreeLikelihood.java:116
+    static const int RESCALE_TIMES = 1;    // :117
+    int rescalingCount = 0, rescalingCountInner = 0;
+    bool everUnderflowed = false, useScaleFactors = false, recomputeScaleFactors = false;
+    int traversal = POST_ORDER;
+
+    std::vector<double> U, Uinv, lambda, freqs, catRates, catWeights;
+
+    std::vector<int> branchUpdateIndices, operations;
+    std::vector<double> branchLengths;
+    int branchUpdateCount = 0, operationCount = 0;
+    std::map<int, std::vector<int>> levelOps;   // level -> flat op tuples (reverse level order)
+
+    long totalOperationCount = 0, totalMatrixUpdateCount = 0, totalEvaluations = 0, totalRescaleRetries = 0;
+    int lastError = 0;
+
+    void updateAllNodes() { std::fill(updateNode.begin(), updateNode.end(), 1); likelihoodKnown = false; }
+
+    // BeagleTreeLikelihood.traverse :1202-1322; `level` >= 0 collects per-depth lists as
+    // LikelihoodTreeTraversal.traverseLevelOrder :151-195 does.
+    bool traverse(int node, bool flip, int level) {
+        bool update = false;
+        if (parent[node] >= 0 && updateNode[node]) {
+            const double branchLength = branchRate[node] * (height[parent[node]] - height[node]);
+            if (branchLength < 0.0) { lastError = BEAGLE_ERROR_OUT_OF_RANGE; }
+            if (flip) matrixBufferHelper.flipOffset(node);
+            branchUpdateIndices[branchUpdateCount] = node;
+            branchLengths[branchUpdateCount] = branchLength;
+            branchUpdateCount++;
+            update = true;
+        }
+        if (node >= tipCount) {
+            const int c1 = left[node], c2 = right[node];
+            const bool u1 = traverse(c1, flip, level < 0 ? -1 : level + 1);
+            const bool u2 = traverse(c2, flip, level < 0 ? -1 : level + 1);
+            if (u1 || u2) {
+                if (flip) partialBufferHelper.flipOffset(node);
+                int op[BEAGLE_OP_COUNT];
+                op[0] = partialBufferHelper.getOffsetIndex(node);
+                if (useScaleFactors) {
+                    const int n = node - tipCount;
+                    if (recomputeScaleFactors) {
+                        scaleBufferHelper.flipOffset(n);
+                        scaleBufferIndices[n] = scaleBufferHelper.getOffsetIndex(n);
+                        op[1] = scaleBufferIndices[n];     // write new scale factors
+                        op[2] = BEAGLE_OP_NONE;
+                    } else {
+                        op[1] = BEAGLE_OP_NONE;
+                        op[2] = scaleBufferIndices[n];     // read existing scale factors
+                    }
+                } else {
+                    op[1] = BEAGLE_OP_NONE;
+                    op[2] = BEAGLE_OP_NONE;
+                }
+                op[3] = partialBufferHelper.getOffsetIndex(c1);
+                op[4] = matrixBufferHelper.getOffsetIndex(c1);
+                op[5] = partialBufferHelper.getOffsetIndex(c2);
+                op[6] = matrixBufferHelper.getOffsetIndex(c2);
+                if (level < 0) {
+                    std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], op, sizeof(op));
+                    operationCount++;
+                } else {
+                    std::vector<int>& v = levelOps[level];
+                    v.insert(v.end(), op, op + BEAGLE_OP_COUNT);
+                }
+                update = true;
+            }
+        }
+        return update;
+    }
+
+    void runTraversal(bool flip) {
+        branchUpdateCount = 0;
+        operationCount = 0;
+        if (traversal == POST_ORDER) {
+            traverse(root, flip, -1);
+        } else {
+            levelOps.clear();
+            traverse(root, flip, 0);
+            for (auto it = levelOps.rbegin(); it != levelOps.rend(); ++it) {   // deepest level first
+                std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], it->second.data(),
+                            it->second.size() * sizeof(int));
+                operationCount += (int)(it->second.size() / BEAGLE_OP_COUNT);
+            }
+        }
+    }
+
+    double calculateLogLikelihood() {
+        recomputeScaleFactors = false;
+        if (!delayRescalingUntilUnderflow || everUnderflowed) {
+            if (scheme == SCHEME_ALWAYS || scheme == SCHEME_DELAYED) {
+                useScaleFactors = true;
+                recomputeScaleFactors = true;
+            } else if (scheme == SCHEME_DYNAMIC) {
+                useScaleFactors = true;
+                if (rescalingCount > rescalingFrequency) { rescalingCount = 0; rescalingCountInner = 0; }
+                if (rescalingCountInner < RESCALE_TIMES) {
+                    recomputeScaleFactors = true;
+                    updateAllNodes();
+                    rescalingCountInner++;
+                }
+                rescalingCount++;
+            }
+        }
+        if (scheme == SCHEME_NONE) { useScaleFactors = false; recomputeScaleFactors = false; }
+
+        runTraversal(true);
+
+        int rc;
+        if (updateSubstitutionModel) {
+            eigenBufferHelper.flipOffset(0);
+            rc = api->setEigenDecomposition(inst, eigenBufferHelper.getOffsetIndex(0), U.data(), Uinv.data(), lambda.data());
+            if (rc) { lastError = rc; return NAN; }
+        }
+        if (updateSiteModel) {
+            rc = api->setCategoryRates(inst, catRates.data());
+            if (rc) { lastError = rc; return NAN; }
+        }
+        if (branchUpdateCount > 0) {
+            std::vector<int> probIdx(branchUpdateCount);
+            for (int i = 0; i < branchUpdateCount; i++) probIdx[i] = matrixBufferHelper.getOffsetIndex(branchUpdateIndices[i]);
+            rc = api->updateTransitionMatrices(inst, eigenBufferHelper.getOffsetIndex(0), probIdx.data(), nullptr, nullptr,
+                                               branchLengths.data(), branchUpdateCount);
+            if (rc) { lastError = rc; return NAN; }
+            totalMatrixUpdateCount += branchUpdateCount;
+        }
+
+        double logL = NAN;
+        bool done, firstRescaleAttempt = true;
+        do {
+            rc = api->updatePartials(inst, operations.data(), operationCount, BEAGLE_OP_NONE);
+            if (rc) { lastError = rc; return NAN; }
+            totalOperationCount += operationCount;
+
+            const int rootIndex = partialBufferHelper.getOffsetIndex(root);
+            int cumulateScaleBufferIndex = BEAGLE_OP_NONE;
+            if (useScaleFactors) {
+                if (recomputeScaleFactors) {
+                    scaleBufferHelper.flipOffset(internalNodeCount);
+                    cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
+                    rc = api->resetScaleFactors(inst, cumulateScaleBufferIndex);
+                    if (rc) { lastError = rc; return NAN; }
+                    rc = api->accumulateScaleFactors(inst, scaleBufferIndices.data(), internalNodeCount, cumulateScaleBufferIndex);
+                    if (rc) { lastError = rc; return NAN; }
+                } else {
+                    cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
+                }
+            }
+            // "these could be set only when they change but store/restore would need to be considered" (:1028)
+            rc = api->setCategoryWeights(inst, 0, catWeights.data());
+            if (rc) { lastError = rc; return NAN; }
+            rc = api->setStateFrequencies(inst, 0, freqs.data());
+            if (rc) { lastError = rc; return NAN; }
+
+            double sum = 0.0;
+            const int zero = 0;
+            rc = api->calculateRootLogLikelihoods(inst, &rootIndex, &zero, &zero, &cumulateScaleBufferIndex, 1, &sum);
+            if (rc != 0 && rc != BEAGLE_ERROR_FLOATING_POINT) { lastError = rc; return NAN; }   // BeagleJNIImpl tolerates -8
+            logL = sum;
+            totalEvaluations++;
+
+            if (std::isnan(logL) || std::isinf(logL)) {
+                everUnderflowed = true;
+                logL = -INFINITY;
+                if (firstRescaleAttempt && (delayRescalingUntilUnderflow || scheme == SCHEME_DELAYED) && scheme != SCHEME_NONE) {
+                    useScaleFactors = true;
+                    recomputeScaleFactors = true;
+                    updateAllNodes();
+                    // traverse again without flipping the partials (overwrite the failed attempt);
+                    // scale buffer indices are flipped because they are being recomputed (:1094-1099)
+                    runTraversal(false);
+                    // the branch updates found by this second traversal are already current
+                    done = false;
+                    firstRescaleAttempt = false;
+                    totalRescaleRetries++;
+                } else {
+                    done = true;
+                }
+            } else {
+                done = true;
+            }
+        } while (!done);
+
+        std::fill(updateNode.begin(), updateNode.end(), 0);
+        updateSubstitutionModel = false;
+        updateSiteModel = false;
+        return logL;
+    }
+
+    double getLogLikelihood() {
+        if (!likelihoodKnown) { logLikelihood = calculateLogLikelihood(); likelihoodKnown = true; }
+        return logLikelihood;
+    }
+
+    void storeState() {
+        partialBufferHelper.storeState();
+        matrixBufferHelper.storeState();
+        eigenBufferHelper.storeState();
+        if (useScaleFactors) {
+            scaleBufferHelper.storeState();
+            storedScaleBufferIndices = scaleBufferIndices;
+        }
+        storedLikelihoodKnown = likelihoodKnown;
+        storedLogLikelihood = logLikelihood;
+    }
+    void restoreState() {
+        updateSiteModel = true;   // :834
+        partialBufferHelper.restoreState();
+        matrixBufferHelper.restoreState();
+        eigenBufferHelper.restoreState();
+        if (useScaleFactors) {
+            scaleBufferHelper.restoreState();
+            scaleBufferIndices.swap(storedScaleBufferIndices);
+        }
+        likelihoodKnown = storedLikelihoodKnown;
+        logLikelihood = storedLogLikelihood;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Create the host object and its engine instance with the reference's buffer counts
+// (BeagleTreeLikelihood.java:193-203): partials = tips + 2*internal, compact = tips,
+// eigen = 2, matrices = 2*nodes, scale buffers = 2*(internal+1).
+void* btlCreate(const BeagleApi* api, int tipCount, int stateCount, int patternCount, int categoryCount,
+                int rescalingScheme, int delayRescaling, int traversal,
+                const int* resourceList, int resourceCount, long preferenceFlags, long requirementFlags) {
+    if (!api || tipCount < 2) return nullptr;
+    TreeLikelihood* t = new TreeLikelihood();
+    t->api = api;
+    t->tipCount = tipCount; t->nodeCount = 2 * tipCount - 1; t->internalNodeCount = tipCount - 1;
+    t->S = stateCount; t->P = patternCount; t->C = categoryCount;
+    t->scheme = rescalingScheme; t->delayRescalingUntilUnderflow = delayRescaling != 0; t->traversal = traversal;
+    t->partialBufferHelper = BufferIndexHelper(t->nodeCount, tipCount);
+    t->scaleBufferHelper = BufferIndexHelper(t->internalNodeCount + 1, 0);
+    t->matrixBufferHelper = BufferIndexHelper(t->nodeCount, 0);
+    t->eigenBufferHelper = BufferIndexHelper(1, 0);
+    t->scaleBufferIndices.assign(t->internalNodeCount, 0);
+    t->storedScaleBufferIndices.assign(t->internalNodeCount, 0);
+    t->parent.assign(t->nodeCount, -1); t->left.assign(t->nodeCount, -1); t->right.assign(t->nodeCount, -1);
+    t->height.assign(t->nodeCount, 0.0); t->branchRate.assign(t->nodeCount, 1.0);
+    t->updateNode.assign(t->nodeCount, 1);
+    t->branchUpdateIndices.assign(t->nodeCount, 0); t->branchLengths.assign(t->nodeCount, 0.0);
+    t->operations.assign((size_t)t->internalNodeCount * BEAGLE_OP_COUNT, 0);
+    t->U.assign((size_t)stateCount * stateCount, 0.0); t->Uinv = t->U; t->lambda.assign(stateCount, 0.0);
+    t->freqs.assign(stateCount, 1.0 / stateCount);
+    t->catRates.assign(categoryCount, 1.0); t->catWeights.assign(categoryCount, 1.0 / categoryCount);
+    BeagleInstanceDetails details;
+    std::memset(&details, 0, sizeof(details));
+    t->inst = api->createInstance(tipCount, t->partialBufferHelper.getBufferCount(), tipCount, stateCount, patternCount,
+                                  t->eigenBufferHelper.getBufferCount(), t->matrixBufferHelper.getBufferCount(), categoryCount,
+                                  t->scaleBufferHelper.getBufferCount(), resourceList, resourceCount,
+                                  preferenceFlags, requirementFlags, &details);
+    if (t->inst < 0) { delete t; return nullptr; }
+    return t;
+}
+
+void btlDestroy(void* h) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    if (!t) return;
+    if (t->inst >= 0) t->api->finalizeInstance(t->inst);
+    delete t;
+}
+
+int btlInstance(void* h) { return ((TreeLikelihood*)h)->inst; }
+
+// Tree as arrays over node numbers: tips 0..T-1, internal T..2T-2 (BeagleTreeLikelihood.java:484-487).
+int btlSetTree(void* h, const int* left, const int* right, const double* heights, int root) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    std::fill(t->parent.begin(), t->parent.end(), -1);
+    for (int n = 0; n < t->nodeCount; n++) {
+        t->left[n] = left[n]; t->right[n] = right[n]; t->height[n] = heights[n];
+        if (n >= t->tipCount) {
+            if (left[n] < 0 || left[n] >= t->nodeCount || right[n] < 0 || right[n] >= t->nodeCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+            t->parent[left[n]] = n; t->parent[right[n]] = n;
+        }
+    }
+    if (root < t->tipCount || root >= t->nodeCount || t->parent[root] != -1) return BEAGLE_ERROR_OUT_OF_RANGE;
+    t->root = root;
+    t->updateAllNodes();
+    return 0;
+}
+
+int btlSetTipStates(void* h, int tip, const int* states) {
+    TreeLikelihood* t = (TreeLikelihood*)h; t->likelihoodKnown = false;
+    return t->api->setTipStates(t->inst, tip, states);
+}
+int btlSetTipPartials(void* h, int tip, const double* partials) {
+    TreeLikelihood* t = (TreeLikelihood*)h; t->likelihoodKnown = false;
+    return t->api->setTipPartials(t->inst, tip, partials);
+}
+int btlSetPatternWeights(void* h, const double* w) {
+    TreeLikelihood* t = (TreeLikelihood*)h; t->likelihoodKnown = false;
+    return t->api->setPatternWeights(t->inst, w);
+}
+
+// model changed -> all matrices dirty (AbstractTreeLikelihood.handleModelChangedEvent: updateAllNodes)
+int btlSetSubstitutionModel(void* h, const double* U, const double* Uinv, const double* lambda, const double* freqs) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    std::memcpy(t->U.data(), U, t->U.size() * sizeof(double));
+    std::memcpy(t->Uinv.data(), Uinv, t->Uinv.size() * sizeof(double));
+    std::memcpy(t->lambda.data(), lambda, t->lambda.size() * sizeof(double));
+    std::memcpy(t->freqs.data(), freqs, t->freqs.size() * sizeof(double));
+    t->updateSubstitutionModel = true;
+    t->updateAllNodes();
+    return 0;
+}
+int btlSetSiteModel(void* h, const double* rates, const double* weights) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    std::memcpy(t->catRates.data(), rates, t->C * sizeof(double));
+    std::memcpy(t->catWeights.data(), weights, t->C * sizeof(double));
+    t->updateSiteModel = true;
+    t->updateAllNodes();
+    return 0;
+}
+int btlSetBranchRates(void* h, const double* ratePerNode) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    std::memcpy(t->branchRate.data(), ratePerNode, t->nodeCount * sizeof(double));
+    t->updateAllNodes();
+    return 0;
+}
+// A node-height move dirties the node and both children (TreeChangedEvent handling,
+// AbstractTreeLikelihood.updateNodeAndChildren).
+int btlSetNodeHeight(void* h, int node, double height) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    if (node < 0 || node >= t->nodeCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    t->height[node] = height;
+    t->updateNode[node] = 1;
+    if (node >= t->tipCount) { t->updateNode[t->left[node]] = 1; t->updateNode[t->right[node]] = 1; }
+    t->likelihoodKnown = false;
+    return 0;
+}
+int btlMakeDirty(void* h) { ((TreeLikelihood*)h)->updateAllNodes(); return 0; }
+int btlSetRescalingFrequency(void* h, int f) { ((TreeLikelihood*)h)->rescalingFrequency = f; return 0; }
+
+double btlGetLogLikelihood(void* h) { return ((TreeLikelihood*)h)->getLogLikelihood(); }
+int btlStoreState(void* h) { ((TreeLikelihood*)h)->storeState(); return 0; }
+int btlRestoreState(void* h) { ((TreeLikelihood*)h)->restoreState(); return 0; }
+int btlGetSiteLogLikelihoods(void* h, double* out) {
+    TreeLikelihood* t = (TreeLikelihood*)h; return t->api->getSiteLogLikelihoods(t->inst, out);
+}
+int btlLastError(void* h) { return ((TreeLikelihood*)h)->lastError; }
+int btlRootBufferIndex(void* h) { TreeLikelihood* t = (TreeLikelihood*)h; return t->partialBufferHelper.getOffsetIndex(t->root); }
+int btlNodeBufferIndex(void* h, int node) { return ((TreeLikelihood*)h)->partialBufferHelper.getOffsetIndex(node); }
+int btlNodeScaleIndex(void* h, int node) { TreeLikelihood* t = (TreeLikelihood*)h; return t->scaleBufferIndices[node - t->tipCount]; }
+int btlCumulativeScaleIndex(void* h) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    return t->useScaleFactors ? t->scaleBufferHelper.getOffsetIndex(t->internalNodeCount) : BEAGLE_OP_NONE;
+}
+// counters: {operations, matrix updates, evaluations, rescale retries, last op count, last branch count,
+//            useScaleFactors, recomputeScaleFactors(last)}
+int btlCounters(void* h, long* out8) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    out8[0] = t->totalOperationCount; out8[1] = t->totalMatrixUpdateCount; out8[2] = t->totalEvaluations;
+    out8[3] = t->totalRescaleRetries; out8[4] = t->operationCount; out8[5] = t->branchUpdateCount;
+    out8[6] = t->useScaleFactors; out8[7] = t->everUnderflowed;
+    return 0;
+}
+// last operation list (7 ints per op), for tests that assert the call protocol
+int btlLastOperations(void* h, int* out, int maxOps) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    int n = t->operationCount < maxOps ? t->operationCount : maxOps;
+    std::memcpy(out, t->operations.data(), (size_t)n * BEAGLE_OP_COUNT * sizeof(int));
+    return t->operationCount;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Substitution-model inputs for the engine: rate matrix -> normalised eigen system.
+
+The engine never sees a substitution model; it is handed ``(U, U^-1, lambda)`` through
+``setEigenDecomposition`` (reference caller:
+src/dr/evomodel/treedatalikelihood/HomogenousSubstitutionModelDelegate.java:228-240).  This module
+produces that triple the way the reference's host code does:
+
+* Q construction           src/dr/evomodel/substmodel/BaseSubstitutionModel.java:256-266 (``setupQMatrix``:
+                           ``Q[i][j] = r_k * pi[j]`` over the upper-triangle rate order)
+* rows sum to zero         BaseSubstitutionModel ``makeValid``
+* normalisation            BaseSubstitutionModel.java:314-319 (``-sum_i Q_ii pi_i``), applied to the
+                           eigenvalues (``EigenDecomposition.normalizeEigenValues``)
+* GTR rate order           src/dr/evomodel/substmodel/nucleotide/GTR.java:161-184 (AC, AG, AT, CG, CT, GT)
+* HKY                      src/dr/evomodel/substmodel/nucleotide/HKY.java:157-230 (kappa on AG and CT)
+* GY94 codon rates         src/dr/evomodel/substmodel/codon/GY94CodonModel.java:165-188
+
+The decomposition itself is numpy's symmetric eigensolver on the pi-symmetrised matrix (the
+reference uses Colt / its own Householder-QL; any exact decomposition yields the same P(t)).
+"""
+import numpy as np
+
+
+class EigenDecomposition:
+    """Mirror of dr.evomodel.substmodel.EigenDecomposition: row-major U, U^-1 and eigenvalues."""
+
+    def __init__(self, evec, ievc, evals):
+        self.evec = np.ascontiguousarray(evec, dtype=np.float64)
+        self.ievc = np.ascontiguousarray(ievc, dtype=np.float64)
+        self.evals = np.ascontiguousarray(evals, dtype=np.float64)
+
+    def transition_probabilities(self, distance):
+        """BaseSubstitutionModel.java:206-245 without the abs()."""
+        return (self.evec * np.exp(distance * self.evals)[None, :]) @ self.ievc
+
+
+def reversible_q(rel_rates_upper, pi):
+    """Upper-triangle relative rates (row-major i<j order) + frequencies -> unnormalised Q."""
+    pi = np.asarray(pi, dtype=np.float64)
+    s = pi.shape[0]
+    q = np.zeros((s, s))
+    k = 0
+    for i in range(s):
+        for j in range(i + 1, s):
+            q[i, j] = rel_rates_upper[k] * pi[j]
+            q[j, i] = rel_rates_upper[k] * pi[i]
+            k += 1
+    np.fill_diagonal(q, 0.0)
+    np.fill_diagonal(q, -q.sum(axis=1))
+    return q
+
+
+def normalization(q, pi):
+    return float(-(np.diag(q) * np.asarray(pi)).sum())
+
+
+def decompose_reversible(q, pi):
+    """Eigen system of a time-reversible Q, eigenvalues normalised to one expected substitution
+    per unit time."""
+    pi = np.asarray(pi, dtype=np.float64)
+    norm = normalization(q, pi)
+    sq = np.sqrt(pi)
+    sym = (q * sq[:, None]) / sq[None, :]
+    sym = 0.5 * (sym + sym.T)
+    evals, v = np.linalg.eigh(sym)
+    evec = v / sq[:, None]
+    ievc = v.T * sq[None, :]
+    return EigenDecomposition(evec, ievc, evals / norm)
+
+
+def gtr(rates_ac_ag_at_cg_ct_gt, pi):
+    return decompose_reversible(reversible_q(rates_ac_ag_at_cg_ct_gt, pi), pi)
+
+
+def hky(kappa, pi):
+    return gtr([1.0, kappa, 1.0, 1.0, kappa, 1.0], pi)
+
+
+def jc69():
+    return hky(1.0, [0.25, 0.25, 0.25, 0.25])
+
+
+def random_reversible(state_count, rng, concentration=5.0):
+    """Seeded reversible model for the 20-state config (SURVEY 8d allows a seeded symmetric
+    exchangeability matrix + Dirichlet frequencies in place of the WAG table)."""
+    n = state_count * (state_count - 1) // 2
+    rates = rng.gamma(shape=1.0, scale=1.0, size=n) + 0.05
+    pi = rng.dirichlet(np.full(state_count, concentration))
+    return decompose_reversible(reversible_q(rates, pi), pi), pi
+
+
+# ---- GY94 codon model (61 sense codons, universal code) -------------------------------------
+_BASES = "TCAG"
+_AA = ("FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG")
+
+
+def _codons():
+    out = []
+    for i, a in enumerate(_BASES):
+        for j, b in enumerate(_BASES):
+            for k, c in enumerate(_BASES):
+                aa = _AA[16 * i + 4 * j + k]
+                if aa != "*":
+                    out.append((a + b + c, aa))
+    return out
+
+
+def gy94(kappa, omega, codon_pi=None):
+    """GY94CodonModel.java:165-188: rate 0 for multi-position changes, kappa for synonymous
+    transitions, 1 for synonymous transversions, kappa*omega / omega for the non-synonymous ones;
+    Q_ij = rate * pi_j."""
+    cods = _codons()
+    s = len(cods)
+    assert s == 61
+    if codon_pi is None:
+        codon_pi = np.full(s, 1.0 / s)
+    purines = set("AG")
+    rates = []
+    for i in range(s):
+        for j in range(i + 1, s):
+            ci, ai = cods[i]
+            cj, aj = cods[j]
+            diff = [p for p in range(3) if ci[p] != cj[p]]
+            if len(diff) != 1:
+                rates.append(0.0)
+                continue
+            x, y = ci[diff[0]], cj[diff[0]]
+            transition = (x in purines) == (y in purines)
+            r = kappa if transition else 1.0
+            if ai != aj:
+                r *= omega
+            rates.append(r)
+    q = reversible_q(rates, codon_pi)
+    return decompose_reversible(q, codon_pi), np.asarray(codon_pi, dtype=np.float64)

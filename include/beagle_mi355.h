@@ -1,0 +1,279 @@
+/*
+ * beagle_mi355.h — C ABI of the MI355X-native tree-likelihood engine.
+ *
+ * This is the drop-in boundary.  Every entry point below is the plain-C shape of one
+ * `native` method of the reference's JNI binding class
+ *     /root/reference/lib/beagle.jar!beagle/BeagleJNIWrapper.class
+ * (descriptors listed next to each function; the leading `I` of every descriptor is the
+ * instance handle).  The Java-side caller of each method is cited as file:line relative
+ * to /root/reference/.  Names follow BEAGLE's public C API (`beagle*`), which is what the
+ * reference's `libhmsbeagle-jni.so` forwards to; the JNI symbols
+ * `Java_beagle_BeagleJNIWrapper_<name>` live in csrc/jni_shim.cpp and call these functions
+ * one-to-one.
+ *
+ * Conventions (lib/beagle.jar!beagle/BeagleErrorCode, BeagleJNIImpl):
+ *   - every function returns an int error code: 0 = success, <0 = BEAGLE_ERROR_*;
+ *     beagleCreateInstance returns the instance handle (>=0) or an error (<0);
+ *   - arrays are borrowed for the duration of the call and may be LONGER than `count`
+ *     (BeagleDataLikelihoodDelegate.java:179-183): exactly `count` (or 7*count / 9*count)
+ *     entries are read;
+ *   - index arrays documented "may be NULL" are accepted as NULL
+ *     (HomogenousSubstitutionModelDelegate.java:260-261 passes null derivative indices);
+ *   - BEAGLE_OP_NONE (-1) marks an unused scale/cumulative index (beagle.Beagle.NONE).
+ *
+ * Layouts at the boundary (lib/beagle.jar!beagle/GeneralBeagleImpl; BeagleTreeLikelihood.java:625-658):
+ *   partials   double[C][P][S]      index c*P*S + p*S + i
+ *   matrices   double[C][S][S]      row = parent state i, column = child state j
+ *   eigen      U[i*S+k], Uinv[k*S+j] row-major S x S, lambda[S]
+ *   tip states int[P], value >= S means missing/ambiguous (all-ones partial)
+ * The layout in HBM is the engine's own.
+ */
+#ifndef BEAGLE_MI355_H
+#define BEAGLE_MI355_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: lib/beagle.jar!beagle/BeagleErrorCode#<clinit> ------------------- */
+#define BEAGLE_SUCCESS                      0
+#define BEAGLE_ERROR_GENERAL               -1
+#define BEAGLE_ERROR_OUT_OF_MEMORY         -2
+#define BEAGLE_ERROR_UNIDENTIFIED_EXCEPTION -3
+#define BEAGLE_ERROR_UNINITIALIZED_INSTANCE -4
+#define BEAGLE_ERROR_OUT_OF_RANGE          -5
+#define BEAGLE_ERROR_NO_RESOURCE           -6
+#define BEAGLE_ERROR_NO_IMPLEMENTATION     -7
+#define BEAGLE_ERROR_FLOATING_POINT        -8
+
+#define BEAGLE_OP_NONE                     -1
+#define BEAGLE_OP_COUNT                     7   /* beagle.Beagle.OPERATION_TUPLE_SIZE */
+#define BEAGLE_PARTITION_OP_COUNT           9   /* MultiPartitionDataLikelihoodDelegate.java:972-997 */
+
+/* ---- flag bits: lib/beagle.jar!beagle/BeagleFlag#<clinit> --------------------------- */
+#define BEAGLE_FLAG_PRECISION_SINGLE    (1L << 0)
+#define BEAGLE_FLAG_PRECISION_DOUBLE    (1L << 1)
+#define BEAGLE_FLAG_COMPUTATION_SYNCH   (1L << 2)
+#define BEAGLE_FLAG_COMPUTATION_ASYNCH  (1L << 3)
+#define BEAGLE_FLAG_EIGEN_REAL          (1L << 4)
+#define BEAGLE_FLAG_EIGEN_COMPLEX       (1L << 5)
+#define BEAGLE_FLAG_SCALING_MANUAL      (1L << 6)
+#define BEAGLE_FLAG_SCALING_AUTO        (1L << 7)
+#define BEAGLE_FLAG_SCALING_ALWAYS      (1L << 8)
+#define BEAGLE_FLAG_SCALERS_RAW         (1L << 9)
+#define BEAGLE_FLAG_SCALERS_LOG         (1L << 10)
+#define BEAGLE_FLAG_VECTOR_SSE          (1L << 11)
+#define BEAGLE_FLAG_VECTOR_NONE         (1L << 12)
+#define BEAGLE_FLAG_THREADING_OPENMP    (1L << 13)
+#define BEAGLE_FLAG_THREADING_NONE      (1L << 14)
+#define BEAGLE_FLAG_PROCESSOR_CPU       (1L << 15)
+#define BEAGLE_FLAG_PROCESSOR_GPU       (1L << 16)
+#define BEAGLE_FLAG_SCALING_DYNAMIC     (1L << 19)
+#define BEAGLE_FLAG_FRAMEWORK_CUDA      (1L << 22)
+#define BEAGLE_FLAG_FRAMEWORK_OPENCL    (1L << 23)
+#define BEAGLE_FLAG_FRAMEWORK_CPU       (1L << 27)
+#define BEAGLE_FLAG_PARALLELOPS_STREAMS (1L << 28)
+#define BEAGLE_FLAG_PARALLELOPS_GRID    (1L << 29)
+#define BEAGLE_FLAG_THREADING_CPP       (1L << 30)
+
+/* Filled by beagleCreateInstance; mirrors beagle.InstanceDetails (setResourceNumber,
+ * setFlags, setResourceName, setImplementationName — BeagleDataLikelihoodDelegate.java:454-480). */
+typedef struct {
+    int   resourceNumber;
+    char* resourceName;
+    char* implName;
+    char* implDescription;
+    long  flags;
+} BeagleInstanceDetails;
+
+/* One entry of beagleGetResourceList; mirrors beagle.ResourceDetails. */
+typedef struct {
+    char* name;
+    char* description;
+    long  supportFlags;
+    long  requiredFlags;
+} BeagleResource;
+
+typedef struct {
+    BeagleResource* list;
+    int length;
+} BeagleResourceList;
+
+/* getVersion ()Ljava/lang/String;  — must match (\d+)\.(\d+)\.(\d+).* (beagle.jar!BeagleInfo#getVersionNumbers;
+ * gates in treedatalikelihood/BeagleFunctionality.java:40-70). */
+const char* beagleGetVersion(void);
+/* getCitation ()Ljava/lang/String; */
+const char* beagleGetCitation(void);
+/* getResourceList ()[Lbeagle/ResourceDetails;  — resource 0 is the host by BEAST convention
+ * (BeagleTreeLikelihood.java:90-92); resources 1..G are the visible MI355X devices. */
+BeagleResourceList* beagleGetResourceList(void);
+
+/* createInstance (IIIIIIIII[IIJJLbeagle/InstanceDetails;)I
+ * callers: BeagleTreeLikelihood.java:420-433, BeagleDataLikelihoodDelegate.java:439-452 */
+int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount,
+                         int stateCount, int patternCount, int eigenBufferCount,
+                         int matrixBufferCount, int categoryCount, int scaleBufferCount,
+                         const int* resourceList, int resourceCount,
+                         long preferenceFlags, long requirementFlags,
+                         BeagleInstanceDetails* returnInfo);
+/* finalize (I)I — BeagleDataLikelihoodDelegate.java:1234-1238 */
+int beagleFinalizeInstance(int instance);
+/* setCPUThreadCount (II)I — BeagleTreeLikelihood.java:461-467 (must return 0 on a GPU instance) */
+int beagleSetCPUThreadCount(int instance, int threadCount);
+
+/* setPatternWeights (I[D)I — BeagleTreeLikelihood.java:533 */
+int beagleSetPatternWeights(int instance, const double* inPatternWeights);
+/* setPatternPartitions (II[I)I — MultiPartitionDataLikelihoodDelegate.java:553 */
+int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPatternPartitions);
+/* setTipStates (II[I)I — BeagleTreeLikelihood.java:696-710 */
+int beagleSetTipStates(int instance, int tipIndex, const int* inStates);
+/* getTipStates (II[I)I */
+int beagleGetTipStates(int instance, int tipIndex, int* outStates);
+/* setTipPartials (II[D)I — double[P*S], replicated over categories by the library
+ * (beagle.jar!GeneralBeagleImpl#setTipPartials) */
+int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials);
+/* setPartials (II[D)I — double[C*P*S]; BeagleTreeLikelihood.java:621-661 */
+int beagleSetPartials(int instance, int bufferIndex, const double* inPartials);
+/* getPartials (III[D)I — BeagleTreeLikelihood.java:1132-1136; scaleIndex != NONE un-scales */
+int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials);
+/* getLogScaleFactors (II[D)I */
+int beagleGetLogScaleFactors(int instance, int scaleIndex, double* outScaleFactors);
+
+/* setEigenDecomposition (II[D[D[D)I — HomogenousSubstitutionModelDelegate.java:228-240 */
+int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEigenVectors,
+                                const double* inInverseEigenVectors, const double* inEigenValues);
+/* setStateFrequencies (II[D)I — BeagleTreeLikelihood.java:1030 */
+int beagleSetStateFrequencies(int instance, int stateFrequenciesIndex, const double* inStateFrequencies);
+/* setCategoryWeights (II[D)I — BeagleTreeLikelihood.java:1029 */
+int beagleSetCategoryWeights(int instance, int categoryWeightsIndex, const double* inCategoryWeights);
+/* setCategoryRates (I[D)I — BeagleTreeLikelihood.java:970 */
+int beagleSetCategoryRates(int instance, const double* inCategoryRates);
+/* setCategoryRatesWithIndex (II[D)I — MultiPartitionDataLikelihoodDelegate.java:835 */
+int beagleSetCategoryRatesWithIndex(int instance, int categoryRatesIndex, const double* inCategoryRates);
+/* setTransitionMatrix (II[DD)I — double[C*S*S] */
+int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMatrix, double paddedValue);
+/* getTransitionMatrix (II[D)I — AncestralStateBeagleTreeLikelihood.java:331 */
+int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix);
+/* convolveTransitionMatrices (I[I[I[II)I — treelikelihood/SubstitutionModelDelegate.java:382-405 */
+int beagleConvolveTransitionMatrices(int instance, const int* firstIndices, const int* secondIndices,
+                                     const int* resultIndices, int matrixCount);
+/* updateTransitionMatrices (II[I[I[I[DI)I — HomogenousSubstitutionModelDelegate.java:247-266;
+ * derivative index arrays may be NULL */
+int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* probabilityIndices,
+                                   const int* firstDerivativeIndices, const int* secondDerivativeIndices,
+                                   const double* edgeLengths, int count);
+/* updateTransitionMatricesWithMultipleModels (I[I[I[I[I[I[DI)I — MultiPartitionDataLikelihoodDelegate.java:880-887 */
+int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices,
+                                   const int* categoryRateIndices, const int* probabilityIndices,
+                                   const int* firstDerivativeIndices, const int* secondDerivativeIndices,
+                                   const double* edgeLengths, int count);
+
+/* updatePartials (I[III)I — BeagleTreeLikelihood.java:1003, BeagleDataLikelihoodDelegate.java:904.
+ * operations = int[7*count]: {dest, writeScale, readScale, child1, matrix1, child2, matrix2}
+ * (tuple built at BeagleTreeLikelihood.java:1266-1299).  The list must be dependency ordered;
+ * it need not be level ordered (the engine levelises it). */
+int beagleUpdatePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex);
+/* updatePartialsByPartition (I[II)I — int[9*count]:
+ * {dest, writeScale, readScale, child1, matrix1, child2, matrix2, partition, cumulativeScale} */
+int beagleUpdatePartialsByPartition(int instance, const int* operations, int operationCount);
+/* waitForPartials (I[II)I */
+int beagleWaitForPartials(int instance, const int* destinationPartials, int destinationPartialsCount);
+
+/* accumulateScaleFactors (I[III)I — BeagleTreeLikelihood.java:1016-1023 */
+int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex);
+/* accumulateScaleFactorsByPartition (I[IIII)I */
+int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count,
+                                            int cumulativeScaleIndex, int partitionIndex);
+/* removeScaleFactors (I[III)I */
+int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex);
+/* removeScaleFactorsByPartition (I[IIII)I */
+int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count,
+                                        int cumulativeScaleIndex, int partitionIndex);
+/* resetScaleFactors (II)I */
+int beagleResetScaleFactors(int instance, int cumulativeScaleIndex);
+/* resetScaleFactorsByPartition (III)I */
+int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex);
+/* copyScaleFactors (III)I */
+int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingIndex);
+
+/* calculateRootLogLikelihoods (I[I[I[I[II[D)I — BeagleTreeLikelihood.java:1038-1039,
+ * BeagleDataLikelihoodDelegate.java:934-935.  Returns BEAGLE_ERROR_FLOATING_POINT (-8) when
+ * the sum is NaN; outSumLogLikelihood is still written (BeagleJNIImpl tolerates -8). */
+int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices,
+                                      const int* categoryWeightsIndices, const int* stateFrequenciesIndices,
+                                      const int* cumulativeScaleIndices, int count,
+                                      double* outSumLogLikelihood);
+/* calculateRootLogLikelihoodsByPartition (I[I[I[I[I[III[D[D)I — MultiPartitionDataLikelihoodDelegate.java:1074-1083 */
+int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* bufferIndices,
+                                      const int* categoryWeightsIndices, const int* stateFrequenciesIndices,
+                                      const int* cumulativeScaleIndices, const int* partitionIndices,
+                                      int partitionCount, int count,
+                                      double* outSumLogLikelihoodByPartition, double* outSumLogLikelihood);
+/* getSiteLogLikelihoods (I[D)I — BeagleTreeLikelihood.java:1050 */
+int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods);
+
+/* ---- entry points that exist in the binding but are outside SURVEY §8 (a)-(e): they are
+ * exported so the JNI shim links, and return BEAGLE_ERROR_NO_IMPLEMENTATION (-7). ------- */
+int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* stateFrequenciesIndices, int count);
+int beagleSetDifferentialMatrix(int instance, int matrixIndex, const double* inMatrix);
+int beagleAddTransitionMatrices(int instance, const int* firstIndices, const int* secondIndices,
+                                const int* resultIndices, int matrixCount);
+int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount);
+int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex);
+int beagleUpdatePrePartialsByPartition(int instance, const int* operations, int operationCount);
+
+/* ---- MI355X extensions (not part of the reference binding) -------------------------- */
+
+/* Make every subsequent call of this instance enqueue on `hipStream` (a hipStream_t) instead
+ * of the instance's own stream — lets a host that owns streams (torch, a JVM-side pool)
+ * order the engine against its collectives. */
+int beagleMi355SetStream(int instance, void* hipStream);
+/* As beagleCalculateRootLogLikelihoods with count == 1, but the weighted sum stays on the
+ * device: it is written to `deviceOut` (a device pointer to one double) on the instance's
+ * stream and nothing is synchronised.  The pattern-sharded multi-GPU path all-reduces that
+ * double over RCCL (DESIGN.md, row e). */
+int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
+                                      int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut);
+/* Block until everything enqueued for the instance has completed. */
+int beagleMi355Synchronize(int instance);
+/* Engine-side timing of the hot kernel: HIP events recorded on the instance's stream around
+ * every updatePartials level launch while enabled; returns accumulated milliseconds and the
+ * number of launches since the last reset. */
+int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* outLaunches);
+/* Bytes of HBM currently allocated by the instance. */
+long beagleMi355DeviceBytes(int instance);
+
+/* Function table: lets a host driver (host/tree_likelihood.cpp) or a test drive any engine
+ * that implements this ABI (the HIP engine, or the CPU oracle under oracle/) through one type. */
+typedef struct BeagleApi {
+    const char* (*getVersion)(void);
+    int (*createInstance)(int, int, int, int, int, int, int, int, int, const int*, int, long, long, BeagleInstanceDetails*);
+    int (*finalizeInstance)(int);
+    int (*setPatternWeights)(int, const double*);
+    int (*setTipStates)(int, int, const int*);
+    int (*setTipPartials)(int, int, const double*);
+    int (*setPartials)(int, int, const double*);
+    int (*getPartials)(int, int, int, double*);
+    int (*getLogScaleFactors)(int, int, double*);
+    int (*setEigenDecomposition)(int, int, const double*, const double*, const double*);
+    int (*setStateFrequencies)(int, int, const double*);
+    int (*setCategoryWeights)(int, int, const double*);
+    int (*setCategoryRates)(int, const double*);
+    int (*setTransitionMatrix)(int, int, const double*, double);
+    int (*getTransitionMatrix)(int, int, double*);
+    int (*updateTransitionMatrices)(int, int, const int*, const int*, const int*, const double*, int);
+    int (*updatePartials)(int, const int*, int, int);
+    int (*accumulateScaleFactors)(int, const int*, int, int);
+    int (*removeScaleFactors)(int, const int*, int, int);
+    int (*resetScaleFactors)(int, int);
+    int (*copyScaleFactors)(int, int, int);
+    int (*calculateRootLogLikelihoods)(int, const int*, const int*, const int*, const int*, int, double*);
+    int (*getSiteLogLikelihoods)(int, double*);
+} BeagleApi;
+
+const BeagleApi* beagleGetApiTable(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAGLE_MI355_H */

@@ -1,0 +1,489 @@
+/*
+ * beagle_cpu_oracle.c — CPU fp64 ORACLE for the tree-likelihood hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker the HIP engine is compared against; it is
+ * never the product path.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+ * leg may load it.  Nothing under beast-mcmc_amd/ links, imports or executes it.
+ *
+ * What it restates (all paths relative to /root/reference/):
+ *   pruning                src/dr/oldevomodel/treelikelihood/GeneralLikelihoodCore.java:52-107 (states x states),
+ *                          :112-166 (states x partials), :171-203 (partials x partials)
+ *   rescaling              src/dr/oldevomodel/treelikelihood/AbstractLikelihoodCore.java:406-440 (max over
+ *                          categories and states per pattern, divide, store log) — BEAGLE rescales
+ *                          unconditionally when an op carries a write-scale index (call protocol
+ *                          src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1268-1294), so the 1e-40
+ *                          threshold of the Java core is not applied
+ *   category integration   GeneralLikelihoodCore.java:358-384
+ *   log + scale factors    GeneralLikelihoodCore.java:395-406, AbstractLikelihoodCore.java:442-458
+ *   transition matrices    src/dr/evomodel/substmodel/BaseSubstitutionModel.java:206-245 and
+ *                          lib/beagle.jar!beagle/GeneralBeagleImpl#updateTransitionMatrices
+ *                          (P = U diag(exp(lambda t r_c)) U^-1, negatives clamped to 0)
+ *   API semantics          lib/beagle.jar!beagle/GeneralBeagleImpl (layouts, tip-partials replication, op dispatch)
+ *   call protocol          BeagleTreeLikelihood.java:863-1130 (what each scale index means)
+ *
+ * The arithmetic engine BEAST actually runs (beagle-dev/beagle-lib, branch v4_release, unpinned commit:
+ * .github/workflows/ci.yml:15-20) is NOT in /root/reference and cannot be built here; parity is pinned
+ * through the reference's own golden values instead (tests/golden/, tests/test_oracle_golden.py):
+ * 19 PAUP* values (LikelihoodTest / TreeDataLikelihoodTest), the jar smoke test -1574.63623 and the two
+ * 1e-13 values of tests/TestXML/testBranchSpecificSubstitutionModel.xml.  20- and 61-state absolute lnL
+ * are unpinned by the reference ("parity unpinned" for those two state counts).
+ *
+ * It implements the same C ABI as include/beagle_mi355.h (prefixed oracle_) so one test
+ * driver can run both engines on identical calls.  Threads over patterns with OpenMP; the
+ * thread count is whatever omp_get_max_threads() says (bench.py reports it as `cores`).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/beagle_mi355.h"
+
+#define MAX_INSTANCES 256
+
+typedef struct {
+    int used;
+    int tipCount, partialsCount, compactCount, S, P, eigenCount, matrixCount, C, scaleCount;
+    double** partials;   /* [partialsCount] -> double[C*P*S] or NULL */
+    int**    tipStates;  /* [partialsCount] -> int[P] or NULL (index = tip buffer index) */
+    double** matrices;   /* [matrixCount]   -> double[C*S*S] */
+    double** eigU;       /* [eigenCount] */
+    double** eigUinv;
+    double** eigLambda;
+    double** catRates;   /* [eigenCount] (index 0 is the default set) */
+    double** catWeights; /* [eigenCount] */
+    double** freqs;      /* [eigenCount] */
+    double*  patternWeights;
+    double** scale;      /* [scaleCount] -> double[P] of LOG factors */
+    double*  siteLogL;
+} Inst;
+
+static Inst g_inst[MAX_INSTANCES];
+
+static Inst* get(int h) {
+    if (h < 0 || h >= MAX_INSTANCES || !g_inst[h].used) return NULL;
+    return &g_inst[h];
+}
+
+static double* partials_buf(Inst* in, int idx) {
+    if (!in->partials[idx]) in->partials[idx] = (double*)calloc((size_t)in->C * in->P * in->S, sizeof(double));
+    return in->partials[idx];
+}
+static double* scale_buf(Inst* in, int idx) {
+    if (!in->scale[idx]) in->scale[idx] = (double*)calloc((size_t)in->P, sizeof(double));
+    return in->scale[idx];
+}
+
+const char* oracle_beagleGetVersion(void) { return "4.0.0-cpu-oracle"; }
+
+int oracle_beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount,
+                                int stateCount, int patternCount, int eigenBufferCount,
+                                int matrixBufferCount, int categoryCount, int scaleBufferCount,
+                                const int* resourceList, int resourceCount, long pref, long req,
+                                BeagleInstanceDetails* info) {
+    (void)resourceList; (void)resourceCount; (void)pref; (void)req;
+    if (stateCount < 2 || patternCount < 1 || categoryCount < 1 || partialsBufferCount < 1) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int h = -1;
+    for (int i = 0; i < MAX_INSTANCES; i++) if (!g_inst[i].used) { h = i; break; }
+    if (h < 0) return BEAGLE_ERROR_OUT_OF_MEMORY;
+    Inst* in = &g_inst[h];
+    memset(in, 0, sizeof(*in));
+    in->used = 1;
+    in->tipCount = tipCount; in->partialsCount = partialsBufferCount; in->compactCount = compactBufferCount;
+    in->S = stateCount; in->P = patternCount; in->eigenCount = eigenBufferCount > 0 ? eigenBufferCount : 1;
+    in->matrixCount = matrixBufferCount; in->C = categoryCount; in->scaleCount = scaleBufferCount;
+    in->partials  = (double**)calloc(partialsBufferCount, sizeof(double*));
+    in->tipStates = (int**)calloc(partialsBufferCount, sizeof(int*));
+    in->matrices  = (double**)calloc(matrixBufferCount > 0 ? matrixBufferCount : 1, sizeof(double*));
+    for (int i = 0; i < matrixBufferCount; i++)
+        in->matrices[i] = (double*)calloc((size_t)categoryCount * stateCount * stateCount, sizeof(double));
+    int E = in->eigenCount;
+    in->eigU = (double**)calloc(E, sizeof(double*)); in->eigUinv = (double**)calloc(E, sizeof(double*));
+    in->eigLambda = (double**)calloc(E, sizeof(double*)); in->catRates = (double**)calloc(E, sizeof(double*));
+    in->catWeights = (double**)calloc(E, sizeof(double*)); in->freqs = (double**)calloc(E, sizeof(double*));
+    for (int i = 0; i < E; i++) {
+        in->eigU[i] = (double*)calloc((size_t)stateCount * stateCount, sizeof(double));
+        in->eigUinv[i] = (double*)calloc((size_t)stateCount * stateCount, sizeof(double));
+        in->eigLambda[i] = (double*)calloc(stateCount, sizeof(double));
+        in->catRates[i] = (double*)calloc(categoryCount, sizeof(double));
+        in->catWeights[i] = (double*)calloc(categoryCount, sizeof(double));
+        in->freqs[i] = (double*)calloc(stateCount, sizeof(double));
+        for (int c = 0; c < categoryCount; c++) { in->catRates[i][c] = 1.0; in->catWeights[i][c] = 1.0 / categoryCount; }
+    }
+    in->patternWeights = (double*)malloc(sizeof(double) * patternCount);
+    for (int p = 0; p < patternCount; p++) in->patternWeights[p] = 1.0;
+    in->scale = (double**)calloc(scaleBufferCount > 0 ? scaleBufferCount : 1, sizeof(double*));
+    in->siteLogL = (double*)calloc(patternCount, sizeof(double));
+    if (info) {
+        info->resourceNumber = 0;
+        info->resourceName = (char*)"CPU (oracle)";
+        info->implName = (char*)"CPU-oracle-fp64";
+        info->implDescription = (char*)"plain C restatement, test infrastructure";
+        info->flags = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_PROCESSOR_CPU | BEAGLE_FLAG_FRAMEWORK_CPU |
+                      BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALERS_LOG | BEAGLE_FLAG_EIGEN_REAL;
+    }
+    return h;
+}
+
+int oracle_beagleFinalizeInstance(int h) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    for (int i = 0; i < in->partialsCount; i++) { free(in->partials[i]); free(in->tipStates[i]); }
+    for (int i = 0; i < in->matrixCount; i++) free(in->matrices[i]);
+    for (int i = 0; i < in->eigenCount; i++) {
+        free(in->eigU[i]); free(in->eigUinv[i]); free(in->eigLambda[i]);
+        free(in->catRates[i]); free(in->catWeights[i]); free(in->freqs[i]);
+    }
+    for (int i = 0; i < in->scaleCount; i++) free(in->scale[i]);
+    free(in->partials); free(in->tipStates); free(in->matrices); free(in->eigU); free(in->eigUinv);
+    free(in->eigLambda); free(in->catRates); free(in->catWeights); free(in->freqs);
+    free(in->patternWeights); free(in->scale); free(in->siteLogL);
+    in->used = 0;
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleSetPatternWeights(int h, const double* w) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    memcpy(in->patternWeights, w, sizeof(double) * in->P);
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleSetTipStates(int h, int tip, const int* states) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (tip < 0 || tip >= in->compactCount || tip >= in->partialsCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (!in->tipStates[tip]) in->tipStates[tip] = (int*)malloc(sizeof(int) * in->P);
+    for (int p = 0; p < in->P; p++) in->tipStates[tip][p] = (states[p] >= 0 && states[p] < in->S) ? states[p] : in->S;
+    return BEAGLE_SUCCESS;
+}
+
+/* lib/beagle.jar!beagle/GeneralBeagleImpl#setTipPartials: double[P*S] replicated over categories */
+int oracle_beagleSetTipPartials(int h, int tip, const double* inP) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (tip < 0 || tip >= in->partialsCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    double* d = partials_buf(in, tip);
+    size_t n = (size_t)in->P * in->S;
+    for (int c = 0; c < in->C; c++) memcpy(d + c * n, inP, n * sizeof(double));
+    free(in->tipStates[tip]); in->tipStates[tip] = NULL;
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleSetPartials(int h, int idx, const double* inP) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (idx < 0 || idx >= in->partialsCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(partials_buf(in, idx), inP, sizeof(double) * in->C * in->P * in->S);
+    free(in->tipStates[idx]); in->tipStates[idx] = NULL;
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleGetPartials(int h, int idx, int scaleIdx, double* out) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (idx < 0 || idx >= in->partialsCount || !in->partials[idx]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(out, in->partials[idx], sizeof(double) * in->C * in->P * in->S);
+    if (scaleIdx != BEAGLE_OP_NONE) {
+        if (scaleIdx < 0 || scaleIdx >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        const double* sc = scale_buf(in, scaleIdx);
+        for (int c = 0; c < in->C; c++)
+            for (int p = 0; p < in->P; p++) {
+                double f = exp(sc[p]);
+                for (int i = 0; i < in->S; i++) out[((size_t)c * in->P + p) * in->S + i] *= f;
+            }
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleGetLogScaleFactors(int h, int idx, double* out) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (idx < 0 || idx >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(out, scale_buf(in, idx), sizeof(double) * in->P);
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleSetEigenDecomposition(int h, int e, const double* U, const double* Uinv, const double* lam) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (e < 0 || e >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    size_t n = (size_t)in->S * in->S;
+    memcpy(in->eigU[e], U, n * sizeof(double)); memcpy(in->eigUinv[e], Uinv, n * sizeof(double));
+    memcpy(in->eigLambda[e], lam, in->S * sizeof(double));
+    return BEAGLE_SUCCESS;
+}
+int oracle_beagleSetStateFrequencies(int h, int i, const double* f) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (i < 0 || i >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(in->freqs[i], f, in->S * sizeof(double)); return BEAGLE_SUCCESS;
+}
+int oracle_beagleSetCategoryWeights(int h, int i, const double* w) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (i < 0 || i >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(in->catWeights[i], w, in->C * sizeof(double)); return BEAGLE_SUCCESS;
+}
+int oracle_beagleSetCategoryRates(int h, const double* r) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    memcpy(in->catRates[0], r, in->C * sizeof(double)); return BEAGLE_SUCCESS;
+}
+int oracle_beagleSetTransitionMatrix(int h, int m, const double* inM, double padded) {
+    (void)padded;
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (m < 0 || m >= in->matrixCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(in->matrices[m], inM, sizeof(double) * in->C * in->S * in->S); return BEAGLE_SUCCESS;
+}
+int oracle_beagleGetTransitionMatrix(int h, int m, double* out) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (m < 0 || m >= in->matrixCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(out, in->matrices[m], sizeof(double) * in->C * in->S * in->S); return BEAGLE_SUCCESS;
+}
+
+/* BaseSubstitutionModel.java:206-245 (iexp = Uinv row scaled by exp(t*lambda), then U * iexp);
+ * GeneralBeagleImpl#updateTransitionMatrices applies the category rate to t and clamps negatives. */
+int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, const int* d1, const int* d2,
+                                          const double* t, int count) {
+    (void)d1; (void)d2;
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (e < 0 || e >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const int S = in->S;
+    const double* U = in->eigU[e]; const double* Ui = in->eigUinv[e]; const double* lam = in->eigLambda[e];
+    for (int u = 0; u < count; u++) if (probIdx[u] < 0 || probIdx[u] >= in->matrixCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    #pragma omp parallel for schedule(static)
+    for (int u = 0; u < count; u++) {
+        double* iexp = (double*)malloc(sizeof(double) * S * S);
+        double* M = in->matrices[probIdx[u]];
+        for (int c = 0; c < in->C; c++) {
+            double dist = t[u] * in->catRates[0][c];
+            for (int k = 0; k < S; k++) {
+                double ex = exp(dist * lam[k]);
+                for (int j = 0; j < S; j++) iexp[k * S + j] = Ui[k * S + j] * ex;
+            }
+            for (int i = 0; i < S; i++)
+                for (int j = 0; j < S; j++) {
+                    double s = 0.0;
+                    for (int k = 0; k < S; k++) s += U[i * S + k] * iexp[k * S + j];
+                    M[(size_t)c * S * S + i * S + j] = s > 0.0 ? s : 0.0;
+                }
+        }
+        free(iexp);
+    }
+    return BEAGLE_SUCCESS;
+}
+
+/* GeneralLikelihoodCore.java:52-107 */
+static void states_states(const Inst* in, const int* s1, const double* m1, const int* s2, const double* m2, double* dest) {
+    const int S = in->S, P = in->P;
+    for (int l = 0; l < in->C; l++) {
+        const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
+        #pragma omp parallel for schedule(static)
+        for (int k = 0; k < P; k++) {
+            double* d = dest + ((size_t)l * P + k) * S;
+            int a = s1[k], b = s2[k];
+            for (int i = 0; i < S; i++) {
+                double x = (a < S) ? M1[i * S + a] : 1.0;
+                double y = (b < S) ? M2[i * S + b] : 1.0;
+                d[i] = x * y;
+            }
+        }
+    }
+}
+/* GeneralLikelihoodCore.java:112-166 */
+static void states_partials(const Inst* in, const int* s1, const double* m1, const double* p2, const double* m2, double* dest) {
+    const int S = in->S, P = in->P;
+    for (int l = 0; l < in->C; l++) {
+        const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
+        #pragma omp parallel for schedule(static)
+        for (int k = 0; k < P; k++) {
+            const double* x2 = p2 + ((size_t)l * P + k) * S;
+            double* d = dest + ((size_t)l * P + k) * S;
+            int a = s1[k];
+            for (int i = 0; i < S; i++) {
+                double sum = 0.0;
+                for (int j = 0; j < S; j++) sum += M2[i * S + j] * x2[j];
+                d[i] = (a < S) ? M1[i * S + a] * sum : sum;
+            }
+        }
+    }
+}
+/* GeneralLikelihoodCore.java:171-203 */
+static void partials_partials(const Inst* in, const double* p1, const double* m1, const double* p2, const double* m2, double* dest) {
+    const int S = in->S, P = in->P;
+    for (int l = 0; l < in->C; l++) {
+        const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
+        #pragma omp parallel for schedule(static)
+        for (int k = 0; k < P; k++) {
+            const double* x1 = p1 + ((size_t)l * P + k) * S;
+            const double* x2 = p2 + ((size_t)l * P + k) * S;
+            double* d = dest + ((size_t)l * P + k) * S;
+            for (int i = 0; i < S; i++) {
+                double sum1 = 0.0, sum2 = 0.0;
+                for (int j = 0; j < S; j++) { sum1 += M1[i * S + j] * x1[j]; sum2 += M2[i * S + j] * x2[j]; }
+                d[i] = sum1 * sum2;
+            }
+        }
+    }
+}
+
+/* AbstractLikelihoodCore.java:406-440 without the threshold (see header) */
+static void rescale_write(const Inst* in, double* dest, double* logScale) {
+    const int S = in->S, P = in->P, C = in->C;
+    #pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; p++) {
+        double mx = 0.0;
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < S; i++) { double v = dest[((size_t)c * P + p) * S + i]; if (v > mx) mx = v; }
+        if (mx == 0.0) mx = 1.0;
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < S; i++) dest[((size_t)c * P + p) * S + i] /= mx;
+        logScale[p] = log(mx);
+    }
+}
+/* read mode: divide by the factors stored by an earlier write-mode pass (BeagleTreeLikelihood.java:1282-1285) */
+static void rescale_read(const Inst* in, double* dest, const double* logScale) {
+    const int S = in->S, P = in->P, C = in->C;
+    #pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; p++) {
+        double f = exp(logScale[p]);
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < S; i++) dest[((size_t)c * P + p) * S + i] /= f;
+    }
+}
+
+int oracle_beagleAccumulateScaleFactors(int h, const int* idx, int count, int cum);
+
+int oracle_beagleUpdatePartials(int h, const int* ops, int count, int cumIdx) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    for (int o = 0; o < count; o++) {
+        const int* op = ops + o * BEAGLE_OP_COUNT;
+        int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
+        if (dest < 0 || dest >= in->partialsCount || c1 < 0 || c1 >= in->partialsCount || c2 < 0 || c2 >= in->partialsCount ||
+            m1 < 0 || m1 >= in->matrixCount || m2 < 0 || m2 >= in->matrixCount ||
+            wS >= in->scaleCount || rS >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        double* d = partials_buf(in, dest);
+        const int* s1 = in->tipStates[c1]; const int* s2 = in->tipStates[c2];
+        if (!s1 && !in->partials[c1]) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (!s2 && !in->partials[c2]) return BEAGLE_ERROR_OUT_OF_RANGE;
+        /* dispatch as AbstractLikelihoodCore.java:252-275 */
+        if (s1 && s2)       states_states(in, s1, in->matrices[m1], s2, in->matrices[m2], d);
+        else if (s1)        states_partials(in, s1, in->matrices[m1], in->partials[c2], in->matrices[m2], d);
+        else if (s2)        states_partials(in, s2, in->matrices[m2], in->partials[c1], in->matrices[m1], d);
+        else                partials_partials(in, in->partials[c1], in->matrices[m1], in->partials[c2], in->matrices[m2], d);
+        free(in->tipStates[dest]); in->tipStates[dest] = NULL;
+        if (wS >= 0) {
+            rescale_write(in, d, scale_buf(in, wS));
+            if (cumIdx != BEAGLE_OP_NONE) { int one = wS; oracle_beagleAccumulateScaleFactors(h, &one, 1, cumIdx); }
+        } else if (rS >= 0) {
+            rescale_read(in, d, scale_buf(in, rS));
+        }
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleResetScaleFactors(int h, int cum) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (cum < 0 || cum >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memset(scale_buf(in, cum), 0, sizeof(double) * in->P); return BEAGLE_SUCCESS;
+}
+/* AbstractLikelihoodCore.java:442-458 (sum of per-node log factors), as a persistent buffer */
+int oracle_beagleAccumulateScaleFactors(int h, const int* idx, int count, int cum) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (cum < 0 || cum >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    double* c = scale_buf(in, cum);
+    for (int k = 0; k < count; k++) {
+        if (idx[k] < 0 || idx[k] >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        const double* s = scale_buf(in, idx[k]);
+        for (int p = 0; p < in->P; p++) c[p] += s[p];
+    }
+    return BEAGLE_SUCCESS;
+}
+int oracle_beagleRemoveScaleFactors(int h, const int* idx, int count, int cum) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (cum < 0 || cum >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    double* c = scale_buf(in, cum);
+    for (int k = 0; k < count; k++) {
+        if (idx[k] < 0 || idx[k] >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        const double* s = scale_buf(in, idx[k]);
+        for (int p = 0; p < in->P; p++) c[p] -= s[p];
+    }
+    return BEAGLE_SUCCESS;
+}
+int oracle_beagleCopyScaleFactors(int h, int dst, int src) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (dst < 0 || dst >= in->scaleCount || src < 0 || src >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(scale_buf(in, dst), scale_buf(in, src), sizeof(double) * in->P); return BEAGLE_SUCCESS;
+}
+
+/* GeneralLikelihoodCore.java:358-384 (integrate over categories) + :395-406 (log, add scale factors);
+ * weighted sum as src/dr/oldevomodel/treelikelihood/TreeLikelihood.java:446-560 */
+int oracle_beagleCalculateRootLogLikelihoods(int h, const int* bufIdx, const int* wIdx, const int* fIdx,
+                                             const int* cumIdx, int count, double* outSum) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    int rb = bufIdx[0];
+    if (rb < 0 || rb >= in->partialsCount || !in->partials[rb]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (wIdx[0] < 0 || wIdx[0] >= in->eigenCount || fIdx[0] < 0 || fIdx[0] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const double* root = in->partials[rb];
+    const double* w = in->catWeights[wIdx[0]]; const double* pi = in->freqs[fIdx[0]];
+    const double* cum = NULL;
+    if (cumIdx[0] != BEAGLE_OP_NONE) {
+        if (cumIdx[0] < 0 || cumIdx[0] >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        cum = scale_buf(in, cumIdx[0]);
+    }
+    const int S = in->S, P = in->P, C = in->C;
+    #pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; p++) {
+        double sum = 0.0;
+        for (int i = 0; i < S; i++) {
+            double integ = 0.0;
+            for (int c = 0; c < C; c++) integ += root[((size_t)c * P + p) * S + i] * w[c];
+            sum += pi[i] * integ;
+        }
+        in->siteLogL[p] = log(sum) + (cum ? cum[p] : 0.0);
+    }
+    double total = 0.0;
+    for (int p = 0; p < P; p++) total += in->siteLogL[p] * in->patternWeights[p];
+    *outSum = total;
+    return (total != total) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+}
+
+int oracle_beagleGetSiteLogLikelihoods(int h, double* out) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    memcpy(out, in->siteLogL, sizeof(double) * in->P); return BEAGLE_SUCCESS;
+}
+
+int oracle_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+static const BeagleApi g_api = {
+    oracle_beagleGetVersion,
+    oracle_beagleCreateInstance,
+    oracle_beagleFinalizeInstance,
+    oracle_beagleSetPatternWeights,
+    oracle_beagleSetTipStates,
+    oracle_beagleSetTipPartials,
+    oracle_beagleSetPartials,
+    oracle_beagleGetPartials,
+    oracle_beagleGetLogScaleFactors,
+    oracle_beagleSetEigenDecomposition,
+    oracle_beagleSetStateFrequencies,
+    oracle_beagleSetCategoryWeights,
+    oracle_beagleSetCategoryRates,
+    oracle_beagleSetTransitionMatrix,
+    oracle_beagleGetTransitionMatrix,
+    oracle_beagleUpdateTransitionMatrices,
+    oracle_beagleUpdatePartials,
+    oracle_beagleAccumulateScaleFactors,
+    oracle_beagleRemoveScaleFactors,
+    oracle_beagleResetScaleFactors,
+    oracle_beagleCopyScaleFactors,
+    oracle_beagleCalculateRootLogLikelihoods,
+    oracle_beagleGetSiteLogLikelihoods,
+};
+const BeagleApi* oracle_beagleGetApiTable(void) { return &g_api; }

@@ -1,0 +1,39 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries():
+    """Build what is missing (the GPU box receives prebuilt .so files; the build container builds)."""
+    import beast_mcmc_amd as bm
+    build = __import__("importlib").import_module("beast-mcmc_amd.build")
+    if not (os.path.exists(bm.beagle.ENGINE_LIB) and os.path.exists(bm.beagle.HOST_LIB)):
+        build.build_all()
+    oracle = os.path.join(ROOT, "oracle", "liboracle_beagle.so")
+    if not os.path.exists(oracle):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    yield
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import helpers
+    return helpers.oracle_library()
+
+
+@pytest.fixture(scope="session")
+def engine_lib():
+    import beast_mcmc_amd as bm
+    return bm.beagle.engine()

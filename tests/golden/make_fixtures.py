@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Transcribe the reference's golden vectors for the tree-likelihood path into JSON fixtures.
+
+Run in the build container only (reads /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_fixtures.py
+
+Outputs (data only — inputs and expected outputs, no reference source text):
+  primates.json          6 primate mtDNA sequences x 768 sites, the fixed tree and the PAUP* lnL values asserted by
+                         src/test/dr/evomodel/treedatalikelihood/TreeDataLikelihoodTest.java:116-315 and
+                         src/test/dr/evomodel/treelikelihood/LikelihoodTest.java:86-345
+                         (sequences: src/test/dr/inference/trace/TraceCorrelationAssert.java:192-198,
+                          node heights: :145-190)
+  branch_specific.json   4 taxa x 14 sites, two GTR models, 1e-13 values from
+                         tests/TestXML/testBranchSpecificSubstitutionModel.xml:44-61, 77-79, 114-207, 209-235
+  jar_smoke.json         the API-level smoke test baked into lib/beagle.jar (beagle.BeagleFactory#main):
+                         3 taxa, literal JC69 eigen system, literal op list, "PAUP logL = -1574.63623"
+"""
+import json
+import os
+import re
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def primate_sequences():
+    src = open(os.path.join(REF, "src/test/dr/inference/trace/TraceCorrelationAssert.java")).read()
+    block = src[src.index("PRIMATES_TAXON_SEQUENCE"):src.index("DENGUE4_TAXON_SEQUENCE")]
+    strings = re.findall(r'"([^"]*)"', block)
+    names = strings[:6]
+    seqs = strings[6:12]
+    assert names == ["human", "chimp", "bonobo", "gorilla", "orangutan", "siamang"], names
+    assert all(len(s) == 768 for s in seqs), [len(s) for s in seqs]
+    return names, seqs
+
+
+def main():
+    names, seqs = primate_sequences()
+    primates = {
+        "source": "src/test/dr/inference/trace/TraceCorrelationAssert.java:145-198",
+        "taxa": names,
+        "sequences": seqs,
+        # createPrimateTreeModel(): ((((human,(chimp,bonobo)),gorilla),orangutan),siamang), node heights
+        "tree_nested": [[[[0, [1, 2, 0.010772], 0.024003], 3, 0.036038], 4, 0.069125], 5, 0.099582],
+        "newick": "((((human:0.024003,(chimp:0.010772,bonobo:0.010772):0.013231):0.012035,gorilla:0.036038):0.033087,"
+                  "orangutan:0.069125):0.030457,siamang:0.099582);",
+        # model: "hky"/"gtr"; pi: "equal"/"empirical"; alpha/cats: gamma; pinv: invariant class
+        "tree_data_likelihood_test": [
+            {"name": "JC69", "model": "hky", "kappa": 1.0, "pi": "equal", "lnL": -1992.20564, "cite": "TreeDataLikelihoodTest.java:116-132"},
+            {"name": "K80", "model": "hky", "kappa": 8.0, "pi": "equal", "lnL": -1868.89782, "cite": ":135-147"},
+            {"name": "HKY85", "model": "hky", "kappa": 8.0, "pi": "empirical", "lnL": -1839.84514, "cite": ":149-161"},
+            {"name": "HKY85G", "model": "hky", "kappa": 8.0, "pi": "empirical", "alpha": 0.5, "cats": 4, "lnL": -1816.82611, "cite": ":163-178"},
+            {"name": "HKY85I", "model": "hky", "kappa": 8.0, "pi": "empirical", "pinv": 0.75, "lnL": -1822.37478, "cite": ":180-196"},
+            {"name": "HKY85GI", "model": "hky", "kappa": 8.0, "pi": "empirical", "alpha": 0.5, "cats": 4, "pinv": 0.75, "lnL": -1815.02176, "cite": ":198-214"},
+            {"name": "GTR", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "lnL": -1969.14584, "cite": ":216-238"},
+            {"name": "GTRI", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "pinv": 0.5, "lnL": -1948.84175, "cite": ":240-262"},
+            {"name": "GTRG", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "alpha": 0.5, "cats": 4, "lnL": -1949.03601, "cite": ":264-286"},
+            {"name": "GTRGI", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "alpha": 0.5, "cats": 4, "pinv": 0.5, "lnL": -1951.62188, "cite": ":288-315"},
+        ],
+        # old TreeLikelihood path (LikelihoodTest.java): same pruning arithmetic, PAUP-optimised parameters,
+        # site rates from the OLDER discretisation src/dr/oldevomodel/sitemodel/GammaSiteModel.java:271-311
+        # (textbook Gamma+I mixture) — hence the different GTR+G+I value.
+        "likelihood_test": [
+            {"name": "JC69", "model": "hky", "kappa": 1.0, "pi": "equal", "lnL": -1992.20564, "cite": "LikelihoodTest.java:86-107"},
+            {"name": "K80", "model": "hky", "kappa": 27.402591, "pi": "equal", "lnL": -1856.30305, "cite": ":109-129"},
+            {"name": "HKY85", "model": "hky", "kappa": 29.739445, "pi": "empirical", "lnL": -1825.21317, "cite": ":132-152"},
+            {"name": "HKY85G", "model": "hky", "kappa": 38.829740, "pi": "empirical", "alpha": 0.137064, "cats": 4, "lnL": -1789.75936, "cite": ":155-176"},
+            {"name": "HKY85I", "model": "hky", "kappa": 38.564672, "pi": "empirical", "pinv": 0.701211, "lnL": -1789.91240, "cite": ":179-200"},
+            {"name": "HKY85GI", "model": "hky", "kappa": 39.464538, "pi": "empirical", "alpha": 0.587649, "cats": 4, "pinv": 0.486548, "lnL": -1789.63923, "cite": ":203-225"},
+            {"name": "GTR", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "lnL": -1969.14584, "cite": ":228-253"},
+            {"name": "GTRI", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "pinv": 0.5, "lnL": -1948.84175, "cite": ":256-282"},
+            {"name": "GTRG", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "alpha": 0.5, "cats": 4, "lnL": -1949.03601, "cite": ":285-311"},
+            {"name": "GTRGI", "model": "gtr", "rates": [1, 1, 1, 1, 1, 1], "pi": "empirical", "alpha": 0.5, "cats": 4, "pinv": 0.5, "lnL": -1947.58294, "cite": ":314-341"},
+        ],
+    }
+    json.dump(primates, open(os.path.join(HERE, "primates.json"), "w"), indent=1)
+
+    branch = {
+        "source": "tests/TestXML/testBranchSpecificSubstitutionModel.xml:44-61,77-79,114-207,209-235",
+        "taxa": ["A", "B", "C", "D"],
+        "sequences": ["AAACCCGGTAACAA", "AAACCTGGGAATAA", "AAACTCGGGAATGA", "ATACCCGGTGGTAG"],
+        "tree_nested": [0, [1, [2, 3, 1.0], 2.0], 3.0],        # (A:1,(B:1,(C:1,D:1):1):1): internal heights 1, 2, 3
+        "tip_heights": [2.0, 1.0, 0.0, 0.0],                   # every branch has length 1
+        "clock_rate": 0.1,
+        "gtr1": {"pi": [0.1, 0.2, 0.3, 0.4], "rates": [1.0, 2.0, 1.0, 1.0, 2.0, 1.0]},
+        "gtr2": {"pi": [0.4, 0.3, 0.2, 0.1], "rates": [1.0, 25.0, 1.0, 1.0, 25.0, 1.0]},
+        "alpha": 0.5, "cats": 4,
+        "clade": ["C", "D"],
+        "tolerance": 1e-13,
+        "cases": [{"stem_weight": 0.0, "lnL": -68.07217469138813}, {"stem_weight": 1.0, "lnL": -67.91898348796958}],
+    }
+    json.dump(branch, open(os.path.join(HERE, "branch_specific.json"), "w"), indent=1)
+
+    smoke = {
+        "source": "lib/beagle.jar!beagle/BeagleFactory.class#main (literal arrays and string constants); "
+                  "sequences as src/test/dr/app/beagle/TinyTest.java:101-107",
+        "taxa": ["human", "chimp", "gorilla"],
+        "sequences": [seqs[0], seqs[1], seqs[3]],
+        "instance": {"tipCount": 3, "partialsBufferCount": 10, "compactBufferCount": 3, "stateCount": 4,
+                     "eigenBufferCount": 1, "matrixBufferCount": 4, "categoryCount": 1, "scaleBufferCount": 3},
+        "evec": [1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0, 1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0],
+        "ivec": [0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125, 0.0, 1.0, 0.0, -1.0, 1.0, 0.0, -1.0, 0.0],
+        "eval": [0.0, -1.3333333333333333, -1.3333333333333333, -1.3333333333333333],
+        "freqs": [0.25, 0.25, 0.25, 0.25],
+        "rates": [1.0], "weights": [1.0],
+        "matrix_indices": [0, 1, 2, 3],
+        "edge_lengths": [0.1, 0.1, 0.2, 0.1],
+        # {dest, writeScale, readScale, child1, matrix1, child2, matrix2}; the jar passes 0/1 in the scale
+        # fields, which its Java implementation ignores -> NONE (-1) here
+        "operations": [3, -1, -1, 0, 0, 1, 1, 4, -1, -1, 2, 2, 3, 3],
+        "root": 4,
+        "lnL": -1574.63623,
+        "decimals": 5,
+    }
+    json.dump(smoke, open(os.path.join(HERE, "jar_smoke.json"), "w"), indent=1)
+    print("wrote primates.json, branch_specific.json, jar_smoke.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Shared test plumbing: the CPU oracle as an EngineLibrary, golden fixtures as workloads."""
+import json
+import os
+
+import numpy as np
+
+import beast_mcmc_amd as bm
+from beast_mcmc_amd.inputs import patterns, siterates, substmodel, trees
+from beast_mcmc_amd.inputs.synth import Workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle_beagle.so")
+
+_oracle = None
+
+
+def oracle_library():
+    """The CPU oracle (oracle/beagle_cpu_oracle.c) behind the same binding class as the engine."""
+    global _oracle
+    if _oracle is None:
+        _oracle = bm.beagle.EngineLibrary(ORACLE_SO, prefix="oracle_")
+    return _oracle
+
+
+def golden(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def rel_err(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def primates_case(case, site_model="new"):
+    """One TreeDataLikelihoodTest / LikelihoodTest case of tests/golden/primates.json as a Workload."""
+    g = golden("primates.json")
+    rows = np.stack([patterns.nucleotide_states(s) for s in g["sequences"]])
+    pats, weights = patterns.site_patterns(rows, unique=True)
+    tree = trees.from_nested(_tuplify(g["tree_nested"]), len(g["taxa"]))
+    pi = np.full(4, 0.25) if case["pi"] == "equal" else patterns.empirical_frequencies(rows)
+    if case["model"] == "hky":
+        eig = substmodel.hky(case["kappa"], pi)
+    else:
+        eig = substmodel.gtr(case["rates"], pi)
+    cls = siterates.GammaSiteRateModel if site_model == "new" else siterates.OldGammaSiteModel
+    sm = cls(alpha=case.get("alpha"), gamma_categories=case.get("cats", 1), p_inv=case.get("pinv"))
+    rates, props = sm.category_rates_and_proportions()
+    return Workload("primates:" + case["name"], tree, eig, pi, rates, props, pats, weights, 4)
+
+
+def _tuplify(x):
+    if isinstance(x, list):
+        return tuple(_tuplify(y) for y in x)
+    return x
+
+
+def random_workload(tip_count, pattern_count, state_count, categories, seed, tree_kind="coalescent",
+                    root_to_tip=0.5, unknown_fraction=0.05):
+    """Small seeded workload with arbitrary state count (random reversible model for S != 4)."""
+    rng = np.random.default_rng(seed)
+    if state_count == 4:
+        pi = rng.dirichlet(np.full(4, 10.0))
+        eig = substmodel.gtr(rng.gamma(2.0, 1.0, size=6) + 0.1, pi)
+    else:
+        eig, pi = substmodel.random_reversible(state_count, rng)
+    from beast_mcmc_amd.inputs import synth
+    return synth.make_workload("rand-S%d" % state_count, tip_count, pattern_count, eig, pi, alpha=0.7,
+                               categories=categories, seed=seed, tree_kind=tree_kind,
+                               root_to_tip=root_to_tip, unknown_fraction=unknown_fraction)

@@ -1,0 +1,149 @@
+"""Pin the CPU oracle (oracle/beagle_cpu_oracle.c), the input front-end and the C++ host driver against
+every golden vector the reference's own tests hold for the tree-likelihood path.
+No GPU needed: these run the oracle through the SAME binding and host driver the HIP engine uses.
+"""
+import numpy as np
+import pytest
+
+import beast_mcmc_amd as bm
+import helpers
+from beast_mcmc_amd.inputs import patterns, siterates, substmodel, trees
+from beast_mcmc_amd.treelikelihood import (BeagleTreeLikelihood, POST_ORDER, RESCALE_ALWAYS, RESCALE_DYNAMIC,
+                                           RESCALE_NONE, REVERSE_LEVEL_ORDER)
+
+PRIMATES = helpers.golden("primates.json")
+
+
+def fmt5(x):
+    """NumberFormat with 5 fraction digits (TreeDataLikelihoodTest.java:79) — HALF_EVEN on the decimal expansion."""
+    return "%.5f" % x
+
+
+@pytest.mark.parametrize("case", PRIMATES["tree_data_likelihood_test"], ids=lambda c: c["name"])
+def test_tree_data_likelihood_test_values(case, oracle_lib):
+    """src/test/dr/evomodel/treedatalikelihood/TreeDataLikelihoodTest.java:116-315 (10 PAUP* values)."""
+    wl = helpers.primates_case(case, site_model="new")
+    tl = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, traversal=REVERSE_LEVEL_ORDER)
+    assert fmt5(tl.getLogLikelihood()) == fmt5(case["lnL"])
+    tl.close()
+
+
+@pytest.mark.parametrize("case", PRIMATES["likelihood_test"], ids=lambda c: c["name"])
+def test_likelihood_test_values(case, oracle_lib):
+    """src/test/dr/evomodel/treelikelihood/LikelihoodTest.java:86-345 (12 PAUP* values, older site model)."""
+    wl = helpers.primates_case(case, site_model="old")
+    tl = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_NONE, traversal=POST_ORDER)
+    assert fmt5(tl.getLogLikelihood()) == fmt5(case["lnL"])
+    tl.close()
+
+
+def test_primates_pattern_compression():
+    rows = np.stack([patterns.nucleotide_states(s) for s in PRIMATES["sequences"]])
+    pats, w = patterns.site_patterns(rows)
+    assert rows.shape == (6, 768)
+    assert w.sum() == 768
+    assert pats.shape[1] == len(w) < 768
+    # newick of the fixture tree (TreeDataLikelihoodTest.testNewickTree, 6 fraction digits)
+    tree = trees.from_nested(helpers._tuplify(PRIMATES["tree_nested"]), 6)
+    assert abs(tree.branch_length(0) - 0.024003) < 1e-12
+    assert abs(tree.branch_length(tree.parent[1]) - 0.013231) < 1e-12
+
+
+def run_jar_smoke(library):
+    g = helpers.golden("jar_smoke.json")
+    n_sites = len(g["sequences"][0])
+    inst = g["instance"]
+    b = bm.beagle.Beagle(inst["tipCount"], inst["partialsBufferCount"], inst["compactBufferCount"], inst["stateCount"],
+                         n_sites, inst["eigenBufferCount"], inst["matrixBufferCount"], inst["categoryCount"],
+                         inst["scaleBufferCount"], library=library)
+    try:
+        for t, seq in enumerate(g["sequences"]):
+            st = patterns.nucleotide_states(seq).copy()
+            st[st > 3] = 4                                   # BeagleFactory#getStates: anything else -> 4
+            b.setTipStates(t, st)
+        b.setPatternWeights(np.ones(n_sites))
+        b.setStateFrequencies(0, g["freqs"])
+        b.setCategoryWeights(0, g["weights"])
+        b.setCategoryRates(g["rates"])
+        b.setEigenDecomposition(0, g["evec"], g["ivec"], g["eval"])
+        b.updateTransitionMatrices(0, g["matrix_indices"], None, None, g["edge_lengths"], 4)
+        b.updatePartials(g["operations"], 2, bm.beagle.NONE)
+        out = [0.0]
+        b.calculateRootLogLikelihoods([g["root"]], [0], [0], [bm.beagle.NONE], 1, out)
+        return out[0], g
+    finally:
+        b.finalize()
+
+
+def test_beagle_jar_smoke_value(oracle_lib):
+    """lib/beagle.jar!beagle/BeagleFactory#main: 'PAUP logL = -1574.63623'."""
+    lnl, g = run_jar_smoke(oracle_lib)
+    assert fmt5(lnl) == fmt5(g["lnL"])
+
+
+def run_branch_specific(library, stem_weight):
+    """tests/TestXML/testBranchSpecificSubstitutionModel.xml: GTR2 on the branches leading to C and D
+    (stem weight 0), plus the stem branch above (C,D) (stem weight 1); GTR1 elsewhere and at the root."""
+    g = helpers.golden("branch_specific.json")
+    rows = np.stack([patterns.nucleotide_states(s) for s in g["sequences"]])
+    tree = trees.from_nested(helpers._tuplify(g["tree_nested"]), 4)
+    tree.height[:4] = g["tip_heights"]
+    n_sites = rows.shape[1]
+    e1 = substmodel.gtr(g["gtr1"]["rates"], g["gtr1"]["pi"])
+    e2 = substmodel.gtr(g["gtr2"]["rates"], g["gtr2"]["pi"])
+    rates, props = siterates.GammaSiteRateModel(alpha=g["alpha"], gamma_categories=g["cats"]).category_rates_and_proportions()
+    # patterns are NOT compressed here (<patterns strip="false"> over 14 sites, weights 1)
+    b = bm.beagle.Beagle(4, 4 + 3, 4, 4, n_sites, 2, 7, len(rates), 0, library=library)
+    try:
+        for t in range(4):
+            b.setTipStates(t, rows[t])
+        b.setPatternWeights(np.ones(n_sites))
+        b.setEigenDecomposition(0, e1.evec, e1.ievc, e1.evals)
+        b.setEigenDecomposition(1, e2.evec, e2.ievc, e2.evals)
+        b.setCategoryRates(rates)
+        b.setCategoryWeights(0, props)
+        b.setStateFrequencies(0, g["gtr1"]["pi"])
+        cd = tree.parent[2]
+        assert cd == tree.parent[3]
+        clade_branches = [2, 3] + ([int(cd)] if stem_weight == 1.0 else [])
+        other = [n for n in range(tree.node_count) if n != tree.root and n not in clade_branches]
+        bl = lambda n: tree.branch_length(n, g["clock_rate"])
+        b.updateTransitionMatrices(0, other, None, None, [bl(n) for n in other], len(other))
+        b.updateTransitionMatrices(1, clade_branches, None, None, [bl(n) for n in clade_branches], len(clade_branches))
+        ops = []
+        for n in tree.postorder():
+            if n >= 4:
+                l, r = int(tree.left[n]), int(tree.right[n])
+                ops += [n, -1, -1, l, l, r, r]
+        b.updatePartials(ops, 3, bm.beagle.NONE)
+        out = [0.0]
+        b.calculateRootLogLikelihoods([tree.root], [0], [0], [bm.beagle.NONE], 1, out)
+        return out[0], g
+    finally:
+        b.finalize()
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_branch_specific_full_precision(case, oracle_lib):
+    """The only full-precision lnL values the reference pins on this path (tolerance 1e-13, absolute)."""
+    g = helpers.golden("branch_specific.json")
+    c = g["cases"][case]
+    lnl, _ = run_branch_specific(oracle_lib, c["stem_weight"])
+    # the XML's tolerance is 1e-13; the eigen solver here is numpy's, not Colt's, so allow a few ulps more
+    assert abs(lnl - c["lnL"]) < 5e-13, (lnl, c["lnL"])
+
+
+def test_gamma_rates_match_reference_discretisation():
+    """GammaSiteRateModel.java:445-472 with alpha = 0.5, 4 categories: AS 91 quantiles, mean-normalised."""
+    rates, props = siterates.GammaSiteRateModel(alpha=0.5, gamma_categories=4).category_rates_and_proportions()
+    assert abs(sum(rates) / 4 - 1.0) < 1e-15
+    assert props == [0.25] * 4
+    from scipy import stats
+    exact = stats.gamma.ppf([(2 * i + 1) / 8.0 for i in range(4)], 0.5, scale=2.0)
+    exact = exact / exact.mean()
+    # the reference's quantile is within ~1e-6 of the exact one, and NOT equal to it
+    assert np.allclose(rates, exact, rtol=1e-5)
+    assert not np.allclose(rates, exact, rtol=1e-12)
+    # +I only: literal 2.0 for the variable class (GammaSiteRateModel.java:254)
+    r, p = siterates.GammaSiteRateModel(p_inv=0.75).category_rates_and_proportions()
+    assert r == [0.0, 2.0] and p == [0.75, 0.25]
