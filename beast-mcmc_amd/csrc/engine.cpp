@@ -900,6 +900,7 @@ static const BeagleApi g_api = {
     beagleCopyScaleFactors,
     beagleCalculateRootLogLikelihoods,
     beagleGetSiteLogLikelihoods,
+    beagleMi355CalculateRootLogLikelihoodsDevice,
 };
 const BeagleApi* beagleGetApiTable(void) { return &g_api; }
 

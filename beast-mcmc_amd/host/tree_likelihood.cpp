@@ -73,7 +73,7 @@ struct TreeLikelihood {
 
     std::vector<double> U, Uinv, lambda, freqs, catRates, catWeights;
 
-    std::vector<int> branchUpdateIndices, operations;
+    std::vector<int> branchUpdateIndices, operations, probIdx;
     std::vector<double> branchLengths;
     int branchUpdateCount = 0, operationCount = 0;
     std::map<int, std::vector<int>> levelOps;   // level -> flat op tuples (reverse level order)
@@ -152,7 +152,15 @@ struct TreeLikelihood {
         }
     }
 
-    double calculateLogLikelihood() {
+    // calculateLogLikelihood (BeagleTreeLikelihood.java:863-1130) in three phases, so that a pattern-sharded
+    // multi-GPU host can put ONE all-reduce between attempt() and finish():
+    //   prepare()  rescaling policy :883-910, traverse :944, model/rate/matrix updates :953-974
+    //   attempt()  updatePartials :1003, scale-factor accumulation :1013-1026, weights/frequencies :1029-1030,
+    //              root integration :1038  (deviceOut != null: the sum stays on the device)
+    //   finish()   NaN/Inf handling and the rescale-and-retry decision :1059-1113
+    bool firstRescaleAttempt = true;
+
+    int prepare() {
         recomputeScaleFactors = false;
         if (!delayRescalingUntilUnderflow || everUnderflowed) {
             if (scheme == SCHEME_ALWAYS || scheme == SCHEME_DELAYED) {
@@ -177,80 +185,93 @@ struct TreeLikelihood {
         if (updateSubstitutionModel) {
             eigenBufferHelper.flipOffset(0);
             rc = api->setEigenDecomposition(inst, eigenBufferHelper.getOffsetIndex(0), U.data(), Uinv.data(), lambda.data());
-            if (rc) { lastError = rc; return NAN; }
+            if (rc) return lastError = rc;
         }
         if (updateSiteModel) {
             rc = api->setCategoryRates(inst, catRates.data());
-            if (rc) { lastError = rc; return NAN; }
+            if (rc) return lastError = rc;
         }
         if (branchUpdateCount > 0) {
-            std::vector<int> probIdx(branchUpdateCount);
+            probIdx.resize(branchUpdateCount);
             for (int i = 0; i < branchUpdateCount; i++) probIdx[i] = matrixBufferHelper.getOffsetIndex(branchUpdateIndices[i]);
             rc = api->updateTransitionMatrices(inst, eigenBufferHelper.getOffsetIndex(0), probIdx.data(), nullptr, nullptr,
                                                branchLengths.data(), branchUpdateCount);
-            if (rc) { lastError = rc; return NAN; }
+            if (rc) return lastError = rc;
             totalMatrixUpdateCount += branchUpdateCount;
         }
+        firstRescaleAttempt = true;
+        return 0;
+    }
 
-        double logL = NAN;
-        bool done, firstRescaleAttempt = true;
-        do {
-            rc = api->updatePartials(inst, operations.data(), operationCount, BEAGLE_OP_NONE);
-            if (rc) { lastError = rc; return NAN; }
-            totalOperationCount += operationCount;
+    int attempt(void* deviceOut, double* hostOut) {
+        int rc = api->updatePartials(inst, operations.data(), operationCount, BEAGLE_OP_NONE);
+        if (rc) return lastError = rc;
+        totalOperationCount += operationCount;
 
-            const int rootIndex = partialBufferHelper.getOffsetIndex(root);
-            int cumulateScaleBufferIndex = BEAGLE_OP_NONE;
-            if (useScaleFactors) {
-                if (recomputeScaleFactors) {
-                    scaleBufferHelper.flipOffset(internalNodeCount);
-                    cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
-                    rc = api->resetScaleFactors(inst, cumulateScaleBufferIndex);
-                    if (rc) { lastError = rc; return NAN; }
-                    rc = api->accumulateScaleFactors(inst, scaleBufferIndices.data(), internalNodeCount, cumulateScaleBufferIndex);
-                    if (rc) { lastError = rc; return NAN; }
-                } else {
-                    cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
-                }
-            }
-            // "these could be set only when they change but store/restore would need to be considered" (:1028)
-            rc = api->setCategoryWeights(inst, 0, catWeights.data());
-            if (rc) { lastError = rc; return NAN; }
-            rc = api->setStateFrequencies(inst, 0, freqs.data());
-            if (rc) { lastError = rc; return NAN; }
-
-            double sum = 0.0;
-            const int zero = 0;
-            rc = api->calculateRootLogLikelihoods(inst, &rootIndex, &zero, &zero, &cumulateScaleBufferIndex, 1, &sum);
-            if (rc != 0 && rc != BEAGLE_ERROR_FLOATING_POINT) { lastError = rc; return NAN; }   // BeagleJNIImpl tolerates -8
-            logL = sum;
-            totalEvaluations++;
-
-            if (std::isnan(logL) || std::isinf(logL)) {
-                everUnderflowed = true;
-                logL = -INFINITY;
-                if (firstRescaleAttempt && (delayRescalingUntilUnderflow || scheme == SCHEME_DELAYED) && scheme != SCHEME_NONE) {
-                    useScaleFactors = true;
-                    recomputeScaleFactors = true;
-                    updateAllNodes();
-                    // traverse again without flipping the partials (overwrite the failed attempt);
-                    // scale buffer indices are flipped because they are being recomputed (:1094-1099)
-                    runTraversal(false);
-                    // the branch updates found by this second traversal are already current
-                    done = false;
-                    firstRescaleAttempt = false;
-                    totalRescaleRetries++;
-                } else {
-                    done = true;
-                }
+        const int rootIndex = partialBufferHelper.getOffsetIndex(root);
+        int cumulateScaleBufferIndex = BEAGLE_OP_NONE;
+        if (useScaleFactors) {
+            if (recomputeScaleFactors) {
+                scaleBufferHelper.flipOffset(internalNodeCount);
+                cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
+                rc = api->resetScaleFactors(inst, cumulateScaleBufferIndex);
+                if (rc) return lastError = rc;
+                rc = api->accumulateScaleFactors(inst, scaleBufferIndices.data(), internalNodeCount, cumulateScaleBufferIndex);
+                if (rc) return lastError = rc;
             } else {
-                done = true;
+                cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
             }
-        } while (!done);
+        }
+        // "these could be set only when they change but store/restore would need to be considered" (:1028)
+        rc = api->setCategoryWeights(inst, 0, catWeights.data());
+        if (rc) return lastError = rc;
+        rc = api->setStateFrequencies(inst, 0, freqs.data());
+        if (rc) return lastError = rc;
 
+        const int zero = 0;
+        if (deviceOut) {
+            if (!api->calculateRootLogLikelihoodsDevice) return lastError = BEAGLE_ERROR_NO_IMPLEMENTATION;
+            rc = api->calculateRootLogLikelihoodsDevice(inst, rootIndex, 0, 0, cumulateScaleBufferIndex, deviceOut);
+            if (rc) return lastError = rc;
+        } else {
+            double sum = 0.0;
+            rc = api->calculateRootLogLikelihoods(inst, &rootIndex, &zero, &zero, &cumulateScaleBufferIndex, 1, &sum);
+            if (rc != 0 && rc != BEAGLE_ERROR_FLOATING_POINT) return lastError = rc;   // BeagleJNIImpl tolerates -8
+            *hostOut = sum;
+        }
+        totalEvaluations++;
+        return 0;
+    }
+
+    // returns true when the evaluation is complete, false when attempt() must run again (rescaling retry)
+    bool finish(double& logL) {
+        if (std::isnan(logL) || std::isinf(logL)) {
+            everUnderflowed = true;
+            logL = -INFINITY;
+            if (firstRescaleAttempt && (delayRescalingUntilUnderflow || scheme == SCHEME_DELAYED) && scheme != SCHEME_NONE) {
+                useScaleFactors = true;
+                recomputeScaleFactors = true;
+                updateAllNodes();
+                // traverse again without flipping the partials (overwrite the failed attempt);
+                // scale buffer indices are flipped because they are being recomputed (:1094-1099)
+                runTraversal(false);
+                firstRescaleAttempt = false;
+                totalRescaleRetries++;
+                return false;
+            }
+        }
         std::fill(updateNode.begin(), updateNode.end(), 0);
         updateSubstitutionModel = false;
         updateSiteModel = false;
+        return true;
+    }
+
+    double calculateLogLikelihood() {
+        if (prepare()) return NAN;
+        double logL = NAN;
+        do {
+            if (attempt(nullptr, &logL)) return NAN;
+        } while (!finish(logL));
         return logL;
     }
 
@@ -403,6 +424,18 @@ int btlMakeDirty(void* h) { ((TreeLikelihood*)h)->updateAllNodes(); return 0; }
 int btlSetRescalingFrequency(void* h, int f) { ((TreeLikelihood*)h)->rescalingFrequency = f; return 0; }
 
 double btlGetLogLikelihood(void* h) { return ((TreeLikelihood*)h)->getLogLikelihood(); }
+// Phased evaluation for the pattern-sharded multi-GPU path: btlPrepare, then repeat
+// { btlAttemptDevice(deviceDouble); <all-reduce the device double, read it>; } until btlFinish(global) == 1.
+int btlPrepare(void* h) { return ((TreeLikelihood*)h)->prepare(); }
+int btlAttemptDevice(void* h, void* deviceOut) { return ((TreeLikelihood*)h)->attempt(deviceOut, nullptr); }
+int btlAttemptHost(void* h, double* localLogL) { return ((TreeLikelihood*)h)->attempt(nullptr, localLogL); }
+int btlFinish(void* h, double globalLogL) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    double v = globalLogL;
+    if (!t->finish(v)) return 0;
+    t->logLikelihood = v; t->likelihoodKnown = true;
+    return 1;
+}
 int btlStoreState(void* h) { ((TreeLikelihood*)h)->storeState(); return 0; }
 int btlRestoreState(void* h) { ((TreeLikelihood*)h)->restoreState(); return 0; }
 int btlGetSiteLogLikelihoods(void* h, double* out) {

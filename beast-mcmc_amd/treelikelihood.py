@@ -44,6 +44,10 @@ def host_library():
         lib.btlSetRescalingFrequency.argtypes = [C.c_void_p, C.c_int]
         lib.btlGetLogLikelihood.argtypes = [C.c_void_p]
         lib.btlGetLogLikelihood.restype = C.c_double
+        lib.btlPrepare.argtypes = [C.c_void_p]
+        lib.btlAttemptDevice.argtypes = [C.c_void_p, C.c_void_p]
+        lib.btlAttemptHost.argtypes = [C.c_void_p, _DP]
+        lib.btlFinish.argtypes = [C.c_void_p, C.c_double]
         lib.btlStoreState.argtypes = [C.c_void_p]
         lib.btlRestoreState.argtypes = [C.c_void_p]
         lib.btlGetSiteLogLikelihoods.argtypes = [C.c_void_p, _DP]
@@ -139,6 +143,21 @@ class BeagleTreeLikelihood:
         if err != 0:
             raise _b.BeagleException("calculateLogLikelihood", err)
         return v
+
+    # phased evaluation (pattern-sharded multi-GPU): prepare; { attempt; <all-reduce>; } until finish(global)
+    def prepare(self):
+        self._chk(self.h.btlPrepare(self.ptr), "prepare")
+
+    def attempt_device(self, device_ptr):
+        self._chk(self.h.btlAttemptDevice(self.ptr, device_ptr), "attempt")
+
+    def attempt_host(self):
+        out = C.c_double(0.0)
+        self._chk(self.h.btlAttemptHost(self.ptr, C.byref(out)), "attempt")
+        return out.value
+
+    def finish(self, global_log_likelihood):
+        return bool(self.h.btlFinish(self.ptr, global_log_likelihood))
 
     def storeState(self):
         self.h.btlStoreState(self.ptr)

@@ -269,6 +269,8 @@ typedef struct BeagleApi {
     int (*copyScaleFactors)(int, int, int);
     int (*calculateRootLogLikelihoods)(int, const int*, const int*, const int*, const int*, int, double*);
     int (*getSiteLogLikelihoods)(int, double*);
+    /* optional (NULL when the engine has no device memory): beagleMi355CalculateRootLogLikelihoodsDevice */
+    int (*calculateRootLogLikelihoodsDevice)(int, int, int, int, int, void*);
 } BeagleApi;
 
 const BeagleApi* beagleGetApiTable(void);

@@ -485,5 +485,6 @@ static const BeagleApi g_api = {
     oracle_beagleCopyScaleFactors,
     oracle_beagleCalculateRootLogLikelihoods,
     oracle_beagleGetSiteLogLikelihoods,
+    NULL,
 };
 const BeagleApi* oracle_beagleGetApiTable(void) { return &g_api; }

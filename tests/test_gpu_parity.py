@@ -1,0 +1,281 @@
+"""Parity of the HIP engine with the CPU oracle and with the reference's golden values, through the C ABI.
+
+Tolerance (BASELINE.json north_star): per-tree log-likelihood within 1e-10 RELATIVE of the fp64 CPU path on the
+same inputs.  Site log-likelihoods and partials are held to the same relative bound.
+"""
+import numpy as np
+import pytest
+
+import beast_mcmc_amd as bm
+import helpers
+from beast_mcmc_amd.inputs import synth
+from beast_mcmc_amd.treelikelihood import (BeagleTreeLikelihood, POST_ORDER, RESCALE_ALWAYS, RESCALE_DELAYED,
+                                           RESCALE_DYNAMIC, RESCALE_NONE, REVERSE_LEVEL_ORDER)
+from test_oracle_golden import PRIMATES, fmt5, run_branch_specific, run_jar_smoke
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-10
+
+
+def both(wl, oracle_lib, **kw):
+    g = BeagleTreeLikelihood(wl, **kw)
+    o = BeagleTreeLikelihood(wl, library=oracle_lib, **kw)
+    return g, o
+
+
+def assert_parity(g, o, what=""):
+    a, b = g.getLogLikelihood(), o.getLogLikelihood()
+    assert np.isfinite(b), what
+    assert helpers.rel_err(a, b) <= REL_TOL, (what, a, b)
+    sa, sb = g.getSiteLogLikelihoods(), o.getSiteLogLikelihoods()
+    assert np.max(np.abs(sa - sb) / np.maximum(np.abs(sb), 1e-300)) <= REL_TOL, what
+    return a, b
+
+
+# ---- the reference's golden vectors, through the HIP engine -----------------------------------
+
+@pytest.mark.parametrize("case", PRIMATES["tree_data_likelihood_test"], ids=lambda c: c["name"])
+def test_golden_tree_data_likelihood(case):
+    wl = helpers.primates_case(case, site_model="new")
+    tl = BeagleTreeLikelihood(wl)
+    assert fmt5(tl.getLogLikelihood()) == fmt5(case["lnL"])
+    tl.close()
+
+
+@pytest.mark.parametrize("case", PRIMATES["likelihood_test"], ids=lambda c: c["name"])
+def test_golden_likelihood_test(case):
+    wl = helpers.primates_case(case, site_model="old")
+    tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_ALWAYS, delay_rescaling=False, traversal=POST_ORDER)
+    assert fmt5(tl.getLogLikelihood()) == fmt5(case["lnL"])
+    tl.close()
+
+
+def test_golden_jar_smoke(engine_lib):
+    lnl, g = run_jar_smoke(engine_lib)
+    assert fmt5(lnl) == fmt5(g["lnL"])
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_golden_branch_specific(case, engine_lib):
+    g = helpers.golden("branch_specific.json")
+    c = g["cases"][case]
+    lnl, _ = run_branch_specific(engine_lib, c["stem_weight"])
+    assert abs(lnl - c["lnL"]) < 5e-13, (lnl, c["lnL"])
+
+
+# ---- engine vs oracle on seeded workloads -------------------------------------------------------
+
+@pytest.mark.parametrize("S,C,T,P", [(4, 4, 33, 1000), (4, 1, 17, 257), (4, 2, 9, 64), (4, 8, 12, 300), (4, 10, 8, 130),
+                                     (20, 4, 12, 333), (20, 1, 7, 50), (61, 4, 9, 150), (61, 2, 5, 33), (3, 3, 6, 100),
+                                     (2, 1, 5, 77), (7, 5, 10, 200)])
+@pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_ALWAYS])
+def test_engine_matches_oracle(S, C, T, P, scheme, oracle_lib):
+    wl = helpers.random_workload(T, P, S, C, seed=100 + S + C)
+    g, o = both(wl, oracle_lib, rescaling=scheme, delay_rescaling=False)
+    assert_parity(g, o, "S=%d C=%d" % (S, C))
+    # every internal node's partials, and the scale factors written for it
+    for node in range(wl.tip_count, 2 * wl.tip_count - 1):
+        pg = _partials(g, node)
+        po = _partials(o, node)
+        scale = np.maximum(np.abs(po), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= 1e-9, node
+    g.close(); o.close()
+
+
+def _raw(tl):
+    """A Beagle binding object over the host driver's existing instance (no new instance)."""
+    b = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
+    b.lib = tl.engine
+    b._f = tl.engine.fn
+    b.instance = tl.instance
+    b.stateCount, b.patternCount, b.categoryCount = tl.state_count, tl.pattern_count, tl.category_count
+    return b
+
+
+def _partials(tl, node):
+    return _raw(tl).getPartials(tl.node_buffer_index(node), bm.beagle.NONE)
+
+
+@pytest.mark.parametrize("traversal", [POST_ORDER, REVERSE_LEVEL_ORDER])
+@pytest.mark.parametrize("kind", ["coalescent", "yule", "caterpillar"])
+def test_tree_shapes_and_traversals(traversal, kind, oracle_lib):
+    wl = helpers.random_workload(40, 500, 4, 4, seed=7, tree_kind=kind)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False, traversal=traversal)
+    assert_parity(g, o, kind)
+    g.close(); o.close()
+
+
+def test_scale_factors_and_cumulative_buffer(oracle_lib):
+    wl = helpers.random_workload(25, 400, 4, 4, seed=3)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    assert_parity(g, o)
+    rg, ro = _raw(g), _raw(o)
+    for node in range(wl.tip_count, 2 * wl.tip_count - 1):
+        a = rg.getLogScaleFactors(g.node_scale_index(node))
+        b = ro.getLogScaleFactors(o.node_scale_index(node))
+        assert np.max(np.abs(a - b)) <= 1e-12
+    ca = rg.getLogScaleFactors(g.cumulative_scale_index())
+    cb = ro.getLogScaleFactors(o.cumulative_scale_index())
+    assert np.max(np.abs(ca - cb)) <= 1e-9
+    # un-scaled partials read back through getPartials(buffer, cumulativeScaleIndex)
+    pa = rg.getPartials(g.root_buffer_index(), g.cumulative_scale_index())
+    pb = ro.getPartials(o.root_buffer_index(), o.cumulative_scale_index())
+    assert np.max(np.abs(pa - pb) / np.maximum(np.abs(pb), 1e-300)) <= 1e-9
+    g.close(); o.close()
+
+
+def test_underflow_triggers_rescaling_retry(oracle_lib):
+    """DYNAMIC + delayed scaling: the first evaluation underflows (lnL = -inf), the host retries with
+    rescaling on (BeagleTreeLikelihood.java:1059-1113) and later evaluations read the stored factors."""
+    # Yule tree, 900 tips, saturated branches: about -960 log-units per pattern, so unscaled fp64 partials underflow
+    wl = helpers.random_workload(900, 300, 4, 4, seed=11, root_to_tip=20.0, tree_kind="yule")
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+    assert_parity(g, o)
+    assert g.counters()["rescale_retries"] == 1 and g.counters()["ever_underflowed"] == 1
+    assert o.counters()["rescale_retries"] == 1
+    # steady state: read-mode evaluations after a parameter change
+    for step in range(3):
+        new = wl.tree.height[wl.tree.root] * (1.0 + 0.01 * (step + 1))
+        for t in (g, o):
+            t.set_node_height(wl.tree.root, new)
+        assert_parity(g, o, "step %d" % step)
+    ops = g.last_operations()
+    assert len(ops) == 1 and ops[0][1] == -1 and ops[0][2] >= 0      # a single read-scale op: the root
+    g.close(); o.close()
+
+
+def test_partial_updates_store_restore(oracle_lib):
+    """MCMC-style protocol: store, perturb one node (dirty path only), evaluate, reject -> restore, re-evaluate."""
+    wl = helpers.random_workload(30, 700, 4, 4, seed=5)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    base_g, base_o = assert_parity(g, o)
+    rng = np.random.default_rng(0)
+    tree = wl.tree
+    for it in range(6):
+        node = int(rng.integers(wl.tip_count, 2 * wl.tip_count - 1))
+        lo = max(tree.height[tree.left[node]], tree.height[tree.right[node]])
+        hi = tree.height[tree.parent[node]] if tree.parent[node] >= 0 else tree.height[node] * 1.2
+        h = lo + (hi - lo) * rng.random()
+        for t in (g, o):
+            t.storeState()
+            t.set_node_height(node, h)
+        assert_parity(g, o, "proposal %d" % it)
+        assert g.counters()["last_op_count"] <= tree.depth()          # only the dirty path to the root
+        for t in (g, o):
+            t.restoreState()
+            t.set_node_height(node, tree.height[node])    # the tree model restores itself in BEAST
+        a, b = assert_parity(g, o, "after restore %d" % it)
+        assert helpers.rel_err(a, base_g) <= 1e-12
+    g.close(); o.close()
+
+
+def test_run_to_run_determinism():
+    """Checkpoint/resume in the reference re-evaluates lnL and requires identical digits
+    (BeastCheckpointer.java:201-262): the engine must be bitwise reproducible."""
+    wl = helpers.random_workload(50, 5000, 4, 4, seed=9)
+    vals = []
+    for _ in range(3):
+        tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+        vals.append(tl.getLogLikelihood())
+        tl.makeDirty()
+        vals.append(tl.getLogLikelihood())
+        tl.close()
+    assert len(set(vals)) == 1, vals
+
+
+def test_post_order_list_is_levelised(oracle_lib):
+    """BeagleTreeLikelihood always sends POST-ORDER op lists; the engine levelises them itself and must
+    give the same answer as for BEAST's level-ordered list."""
+    wl = helpers.random_workload(64, 900, 4, 4, seed=21)
+    a = BeagleTreeLikelihood(wl, traversal=POST_ORDER, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    b = BeagleTreeLikelihood(wl, traversal=REVERSE_LEVEL_ORDER, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    assert a.getLogLikelihood() == b.getLogLikelihood()
+    a.close(); b.close()
+
+
+def test_tip_partials_and_ambiguity(oracle_lib):
+    """setTipPartials (replicated over categories) must agree with compact states for unambiguous data."""
+    wl = helpers.random_workload(10, 300, 4, 4, seed=2)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_NONE)
+    ref = g.getLogLikelihood()
+    for t in (g, o):
+        for tip in (0, 3, 7):
+            st = wl.tip_states[tip]
+            part = np.zeros((wl.pattern_count, 4))
+            known = st < 4
+            part[np.arange(wl.pattern_count)[known], st[known]] = 1.0
+            part[~known] = 1.0
+            t._chk(t.h.btlSetTipPartials(t.ptr, tip, part.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))), "setTipPartials")
+        t.makeDirty()
+    a, b = assert_parity(g, o)
+    assert helpers.rel_err(a, ref) <= 1e-12
+    g.close(); o.close()
+
+
+def test_error_codes(engine_lib):
+    B = bm.beagle
+    b = B.Beagle(3, 5, 3, 4, 10, 1, 4, 1, 2)
+    with pytest.raises(B.BeagleException) as e:
+        b.updatePartials([9, -1, -1, 0, 0, 1, 1], 1, B.NONE)
+    assert e.value.code == -5
+    with pytest.raises(B.BeagleException) as e:
+        b.updatePartials([3, -1, -1, 0, 0, 1, 1], 1, B.NONE)        # tips never set
+    assert e.value.code == -5
+    with pytest.raises(B.BeagleException) as e:
+        b.setEigenDecomposition(7, np.eye(4), np.eye(4), np.zeros(4))
+    assert e.value.code == -5
+    b.setCPUThreadCount(8)                                          # must succeed on a GPU instance
+    assert (b.details.flags & (1 << 27)) == 0                       # not FRAMEWORK_CPU -> BEAST sends level order
+    assert (b.details.flags & (1 << 16)) != 0                       # PROCESSOR_GPU
+    b.finalize()
+    with pytest.raises(B.BeagleException):
+        B.Beagle(3, 5, 3, 4, 10, 1, 4, 1, 2, resourceList=(0,))     # resource 0 = CPU: not provided
+    rl = engine_lib.resource_list()
+    assert rl[0][0] == "CPU" and len(rl) >= 2
+
+
+# ---- full-size properties (BASELINE.json config A: 1000 taxa x 1e5 patterns) ---------------------
+
+@pytest.fixture(scope="module")
+def config_a():
+    return synth.config_a()
+
+
+def test_config_a_sampled_against_oracle(config_a, oracle_lib):
+    """Patterns are independent given the tree: the oracle evaluates a random 1 % sample of the 1e5 patterns
+    (seconds on the CPU) and must agree with the engine's site log-likelihoods for those patterns."""
+    wl = config_a
+    g = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+    lnl = g.getLogLikelihood()
+    assert np.isfinite(lnl)
+    site = g.getSiteLogLikelihoods()
+    assert helpers.rel_err(float(np.dot(site, wl.weights)), lnl) <= 1e-12
+    idx = np.sort(np.random.default_rng(4).choice(wl.pattern_count, size=1000, replace=False))
+    sub = synth.Workload("A-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
+                         np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], 4)
+    o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+    o.getLogLikelihood()
+    so = o.getSiteLogLikelihoods()
+    assert np.max(np.abs(site[idx] - so) / np.abs(so)) <= REL_TOL
+    # read-mode (steady-state DYNAMIC) evaluation must reproduce the recompute-mode value
+    g.makeDirty()
+    again = g.getLogLikelihood()
+    assert helpers.rel_err(again, lnl) <= 1e-12
+    o.close(); g.close()
+
+
+def test_config_a_shards_sum_to_whole(config_a):
+    """Multi-GPU row (e): contiguous pattern shards (Patterns.java:142-167) evaluated independently must sum
+    to the unsharded lnL to ~1e-12 (the all-reduce is a plain sum of per-shard doubles)."""
+    from beast_mcmc_amd.inputs import patterns
+    wl = config_a
+    whole = BeagleTreeLikelihood(wl)
+    total = whole.getLogLikelihood()
+    whole.close()
+    parts = 0.0
+    for (s, e) in patterns.shard_bounds(wl.pattern_count, 8)[:8]:
+        tl = BeagleTreeLikelihood(wl.shard(s, e))
+        parts += tl.getLogLikelihood()
+        tl.close()
+    assert helpers.rel_err(parts, total) <= 1e-11

@@ -1,0 +1,200 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/beagle_mi355.h declares, the C++
+host driver reproduces the reference's call protocol, and the pattern-sharded N>1 path (world_size 2, gloo).
+No compute call reaches the HIP engine here (there is no GPU in this tier)."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import beast_mcmc_amd as bm
+import helpers
+from beast_mcmc_amd.inputs import patterns
+from beast_mcmc_amd.treelikelihood import (BeagleTreeLikelihood, POST_ORDER, RESCALE_ALWAYS, RESCALE_DYNAMIC,
+                                           RESCALE_NONE, REVERSE_LEVEL_ORDER)
+
+ROOT = helpers.ROOT
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "beagle_mi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    body = hdr[:hdr.index("typedef struct BeagleApi")]
+    names = re.findall(r"\b(beagle[A-Za-z0-9]+)\s*\(", body)
+    return sorted(set(names) | {"beagleGetApiTable"})
+
+
+def test_engine_library_exports_every_declared_symbol(engine_lib):
+    names = declared_functions()
+    assert len(names) >= 49
+    missing = [n for n in names if not hasattr(engine_lib.lib, n)]
+    assert not missing, missing
+    assert sorted(bm.beagle.ABI_SYMBOLS) == names
+    assert re.match(r"(\d+)\.(\d+)\.(\d+).*", engine_lib.version)      # BeagleInfo#getVersionNumbers
+    major, minor = [int(x) for x in engine_lib.version.split(".")[:2]]
+    assert (major, minor) >= (3, 2)                                     # BeagleFunctionality.java:53-70 gates
+
+
+def test_jni_symbols_exported(engine_lib):
+    """One Java_beagle_BeagleJNIWrapper_<name> per native method of lib/beagle.jar!beagle/BeagleJNIWrapper.class."""
+    natives = ["getVersion", "getCitation", "getResourceList", "getBenchmarkedResourceList", "createInstance", "finalize",
+               "setCPUThreadCount", "setPatternWeights", "setPatternPartitions", "setTipStates", "getTipStates",
+               "setTipPartials", "setRootPrePartials", "setPartials", "getPartials", "getLogScaleFactors",
+               "setEigenDecomposition", "setStateFrequencies", "setCategoryWeights", "setCategoryRates",
+               "setCategoryRatesWithIndex", "setTransitionMatrix", "setDifferentialMatrix", "getTransitionMatrix",
+               "convolveTransitionMatrices", "addTransitionMatrices", "transposeTransitionMatrices",
+               "updateTransitionMatrices", "updateTransitionMatricesWithMultipleModels", "updatePrePartials",
+               "updatePrePartialsByPartition", "updatePartials", "updatePartialsByPartition", "waitForPartials",
+               "accumulateScaleFactors", "accumulateScaleFactorsByPartition", "removeScaleFactors",
+               "removeScaleFactorsByPartition", "resetScaleFactors", "resetScaleFactorsByPartition", "copyScaleFactors",
+               "calculateRootLogLikelihoods", "calculateRootLogLikelihoodsByPartition", "getSiteLogLikelihoods",
+               "calculateEdgeDifferentials", "calculateCrossProductDifferentials", "calculateEdgeDerivative"]
+    assert len(natives) == 47
+    missing = [n for n in natives if not hasattr(engine_lib.lib, "Java_beagle_BeagleJNIWrapper_" + n)]
+    assert not missing, missing
+
+
+def test_no_gpu_means_no_resource_not_a_fallback(engine_lib):
+    """Without a visible MI355X the engine must refuse (-6), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bm.beagle.BeagleException) as e:
+        bm.beagle.Beagle(3, 5, 3, 4, 10, 1, 4, 1, 2)
+    assert e.value.code == -6
+
+
+def test_product_code_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "beast-mcmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle/" not in txt and "liboracle" not in txt and "oracle_beagle" not in txt, f
+
+
+def test_buffer_protocol_matches_reference(oracle_lib):
+    """Instance shape and op tuples as BeagleTreeLikelihood builds them (:193-203, :1266-1299)."""
+    wl = helpers.random_workload(9, 60, 4, 2, seed=1)
+    t = wl.tip_count
+    tl = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False, traversal=POST_ORDER)
+    tl.getLogLikelihood()
+    ops = tl.last_operations()
+    assert len(ops) == t - 1
+    dbl = t - 1
+    for op in ops:
+        dest, ws, rs, c1, m1, c2, m2 = op
+        assert dest >= t and (dest - t) < 2 * dbl
+        assert ws >= 0 and rs == -1                           # ALWAYS: write mode every evaluation
+        for c in (c1, c2):
+            assert 0 <= c < t + 2 * dbl
+    # post-order: every child that is an internal node was produced earlier in the list
+    produced = set()
+    for op in ops:
+        for c in (op[3], op[5]):
+            assert c < t or c in produced
+        produced.add(op[0])
+    first = {int(o[0]) for o in ops}
+    tl.storeState()       # MarkovChain stores before every proposal; a buffer flips once per store (BufferIndexHelper.java:71-77)
+    tl.makeDirty()
+    tl.getLogLikelihood()
+    second = {int(o[0]) for o in tl.last_operations()}
+    assert first.isdisjoint(second)                           # every partials buffer flipped (BufferIndexHelper)
+    # store / evaluate / restore returns the stored value without recomputation
+    v = tl.getLogLikelihood()
+    tl.storeState()
+    tl.set_node_height(wl.tree.root, wl.tree.height[wl.tree.root] * 1.1)
+    v2 = tl.getLogLikelihood()
+    assert v2 != v
+    n_eval = tl.counters()["evaluations"]
+    tl.restoreState()
+    assert tl.getLogLikelihood() == v and tl.counters()["evaluations"] == n_eval
+    tl.close()
+
+
+def test_level_order_groups_are_independent(oracle_lib):
+    wl = helpers.random_workload(40, 50, 4, 1, seed=4)
+    a = BeagleTreeLikelihood(wl, library=oracle_lib, traversal=REVERSE_LEVEL_ORDER, rescaling=RESCALE_NONE)
+    b = BeagleTreeLikelihood(wl, library=oracle_lib, traversal=POST_ORDER, rescaling=RESCALE_NONE)
+    assert a.getLogLikelihood() == b.getLogLikelihood()
+    ops = a.last_operations()
+    produced = set()
+    for op in ops:
+        for c in (op[3], op[5]):
+            assert c < wl.tip_count or c in produced
+        produced.add(int(op[0]))
+    a.close(); b.close()
+
+
+def test_dynamic_rescaling_policy(oracle_lib):
+    """DYNAMIC + delay: no scaling until the first underflow; then one recompute, then read mode, and a fresh
+    recompute every `beagle.rescale` evaluations (BeagleTreeLikelihood.java:883-910)."""
+    # Yule tree, 900 tips, saturated branches: about -960 log-units per pattern, so unscaled fp64 partials underflow
+    wl = helpers.random_workload(900, 40, 4, 4, seed=6, root_to_tip=20.0, tree_kind="yule")
+    tl = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+    tl.set_rescaling_frequency(3)
+    v = tl.getLogLikelihood()
+    assert np.isfinite(v) and tl.counters()["rescale_retries"] == 1
+    modes = []
+    for _ in range(8):
+        tl.makeDirty()
+        assert tl.getLogLikelihood() == pytest.approx(v, rel=1e-12)
+        op = tl.last_operations()[0]
+        modes.append("W" if op[1] >= 0 else "R")
+    assert "R" in modes and "W" in modes
+    assert "".join(modes).count("W") <= 4
+    tl.close()
+    ref = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    assert ref.getLogLikelihood() == pytest.approx(v, rel=1e-12)
+    ref.close()
+
+
+def test_shard_bounds_follow_patterns_java():
+    assert patterns.shard_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert patterns.shard_bounds(100000, 8)[-1] == (87500, 100000)
+    b = patterns.shard_bounds(7, 8)
+    assert b[-1] == (7, 7) and sum(e - s for s, e in b) == 7
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch.distributed as dist
+import helpers
+from beast_mcmc_amd.sharding import ShardedTreeLikelihood
+from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+wl = helpers.random_workload(900, 101, 4, 4, seed=12, root_to_tip=20.0, tree_kind="yule")
+tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, library=helpers.oracle_library(),
+                           rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+a = tl.getLogLikelihood()
+tl.makeDirty()
+b = tl.getLogLikelihood()
+retries = tl.local.counters()["rescale_retries"]
+if rank == 0:
+    whole = BeagleTreeLikelihood(wl, library=helpers.oracle_library(), rescaling=RESCALE_DYNAMIC, delay_rescaling=True)
+    print("RESULT %%r %%r %%r %%d" %% (a, b, whole.getLogLikelihood(), retries))
+dist.destroy_process_group()
+"""
+
+
+def test_pattern_sharded_two_ranks_gloo(tmp_path):
+    """N>1 path on CPU: 2 ranks, gloo, the oracle as each shard's engine; the all-reduced lnL equals the
+    unsharded value and both ranks take the rescaling retry together."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
+    a, b, whole, retries = float(line[1]), float(line[2]), float(line[3]), int(line[4])
+    assert np.isfinite(whole) and retries == 1
+    assert abs(a - whole) / abs(whole) < 1e-12 and abs(b - whole) / abs(whole) < 1e-12
