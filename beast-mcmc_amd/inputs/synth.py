@@ -61,10 +61,16 @@ def simulate_unique_patterns(tree, eig, freqs, cat_rates, cat_weights, pattern_c
     dtype = np.uint8
     h1 = rng.integers(1, 2 ** 62, size=t, dtype=np.int64) | 1
     h2 = rng.integers(1, 2 ** 62, size=t, dtype=np.int64) | 1
+    if t * np.log(s) < np.log(pattern_count * 4.0):
+        raise ValueError("%d unique patterns requested but only %d^%d distinct columns exist" % (pattern_count, s, t))
     seen = set()
     cols = []
     have = 0
+    rounds = 0
     while have < pattern_count:
+        rounds += 1
+        if rounds > 200:
+            raise RuntimeError("could not simulate %d unique patterns (have %d)" % (pattern_count, have))
         n_sites = batch or max(1024, int((pattern_count - have) * 1.25) + 64)
         cats = rng.choice(len(cat_rates), size=n_sites, p=np.asarray(cat_weights) / np.sum(cat_weights))
         states = np.empty((tree.node_count, n_sites), dtype=dtype)

@@ -68,7 +68,7 @@ def test_golden_branch_specific(case, engine_lib):
 
 @pytest.mark.parametrize("S,C,T,P", [(4, 4, 33, 1000), (4, 1, 17, 257), (4, 2, 9, 64), (4, 8, 12, 300), (4, 10, 8, 130),
                                      (20, 4, 12, 333), (20, 1, 7, 50), (61, 4, 9, 150), (61, 2, 5, 33), (3, 3, 6, 100),
-                                     (2, 1, 5, 77), (7, 5, 10, 200)])
+                                     (2, 1, 12, 77), (7, 5, 10, 200)])
 @pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_ALWAYS])
 def test_engine_matches_oracle(S, C, T, P, scheme, oracle_lib):
     wl = helpers.random_workload(T, P, S, C, seed=100 + S + C)
