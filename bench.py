@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="patterns in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="patterns in the CPU-baseline sample")
     args = ap.parse_args()
 
     import numpy as np

@@ -266,12 +266,13 @@ int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, cons
 }
 
 /* GeneralLikelihoodCore.java:52-107 */
-static void states_states(const Inst* in, const int* s1, const double* m1, const int* s2, const double* m2, double* dest) {
+/* Every pruning routine works on the pattern range [p0, p1): patterns are independent, so the caller gives
+ * each OpenMP thread one contiguous block and runs the whole op list on it without synchronisation. */
+static void states_states(const Inst* in, const int* s1, const double* m1, const int* s2, const double* m2, double* dest, int p0, int p1) {
     const int S = in->S, P = in->P;
     for (int l = 0; l < in->C; l++) {
         const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
-        #pragma omp parallel for schedule(static)
-        for (int k = 0; k < P; k++) {
+        for (int k = p0; k < p1; k++) {
             double* d = dest + ((size_t)l * P + k) * S;
             int a = s1[k], b = s2[k];
             for (int i = 0; i < S; i++) {
@@ -283,12 +284,11 @@ static void states_states(const Inst* in, const int* s1, const double* m1, const
     }
 }
 /* GeneralLikelihoodCore.java:112-166 */
-static void states_partials(const Inst* in, const int* s1, const double* m1, const double* p2, const double* m2, double* dest) {
+static void states_partials(const Inst* in, const int* s1, const double* m1, const double* p2, const double* m2, double* dest, int p0, int p1) {
     const int S = in->S, P = in->P;
     for (int l = 0; l < in->C; l++) {
         const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
-        #pragma omp parallel for schedule(static)
-        for (int k = 0; k < P; k++) {
+        for (int k = p0; k < p1; k++) {
             const double* x2 = p2 + ((size_t)l * P + k) * S;
             double* d = dest + ((size_t)l * P + k) * S;
             int a = s1[k];
@@ -301,13 +301,12 @@ static void states_partials(const Inst* in, const int* s1, const double* m1, con
     }
 }
 /* GeneralLikelihoodCore.java:171-203 */
-static void partials_partials(const Inst* in, const double* p1, const double* m1, const double* p2, const double* m2, double* dest) {
+static void partials_partials(const Inst* in, const double* c1, const double* m1, const double* p2, const double* m2, double* dest, int p0, int p1) {
     const int S = in->S, P = in->P;
     for (int l = 0; l < in->C; l++) {
         const double* M1 = m1 + (size_t)l * S * S; const double* M2 = m2 + (size_t)l * S * S;
-        #pragma omp parallel for schedule(static)
-        for (int k = 0; k < P; k++) {
-            const double* x1 = p1 + ((size_t)l * P + k) * S;
+        for (int k = p0; k < p1; k++) {
+            const double* x1 = c1 + ((size_t)l * P + k) * S;
             const double* x2 = p2 + ((size_t)l * P + k) * S;
             double* d = dest + ((size_t)l * P + k) * S;
             for (int i = 0; i < S; i++) {
@@ -320,10 +319,9 @@ static void partials_partials(const Inst* in, const double* p1, const double* m1
 }
 
 /* AbstractLikelihoodCore.java:406-440 without the threshold (see header) */
-static void rescale_write(const Inst* in, double* dest, double* logScale) {
+static void rescale_write(const Inst* in, double* dest, double* logScale, int p0, int p1) {
     const int S = in->S, P = in->P, C = in->C;
-    #pragma omp parallel for schedule(static)
-    for (int p = 0; p < P; p++) {
+    for (int p = p0; p < p1; p++) {
         double mx = 0.0;
         for (int c = 0; c < C; c++)
             for (int i = 0; i < S; i++) { double v = dest[((size_t)c * P + p) * S + i]; if (v > mx) mx = v; }
@@ -334,10 +332,9 @@ static void rescale_write(const Inst* in, double* dest, double* logScale) {
     }
 }
 /* read mode: divide by the factors stored by an earlier write-mode pass (BeagleTreeLikelihood.java:1282-1285) */
-static void rescale_read(const Inst* in, double* dest, const double* logScale) {
+static void rescale_read(const Inst* in, double* dest, const double* logScale, int p0, int p1) {
     const int S = in->S, P = in->P, C = in->C;
-    #pragma omp parallel for schedule(static)
-    for (int p = 0; p < P; p++) {
+    for (int p = p0; p < p1; p++) {
         double f = exp(logScale[p]);
         for (int c = 0; c < C; c++)
             for (int i = 0; i < S; i++) dest[((size_t)c * P + p) * S + i] /= f;
@@ -348,29 +345,51 @@ int oracle_beagleAccumulateScaleFactors(int h, const int* idx, int count, int cu
 
 int oracle_beagleUpdatePartials(int h, const int* ops, int count, int cumIdx) {
     Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (count <= 0) return BEAGLE_SUCCESS;
+    /* pass 1 (serial): validate, resolve buffer indices to pointers exactly as the sequential list would see them */
+    typedef struct { double* d; const int* s1; const int* s2; const double* x1; const double* x2;
+                     const double* m1; const double* m2; double* wS; const double* rS; } Res;
+    Res* r = (Res*)calloc((size_t)count, sizeof(Res));
     for (int o = 0; o < count; o++) {
         const int* op = ops + o * BEAGLE_OP_COUNT;
         int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
         if (dest < 0 || dest >= in->partialsCount || c1 < 0 || c1 >= in->partialsCount || c2 < 0 || c2 >= in->partialsCount ||
             m1 < 0 || m1 >= in->matrixCount || m2 < 0 || m2 >= in->matrixCount ||
-            wS >= in->scaleCount || rS >= in->scaleCount) return BEAGLE_ERROR_OUT_OF_RANGE;
-        double* d = partials_buf(in, dest);
-        const int* s1 = in->tipStates[c1]; const int* s2 = in->tipStates[c2];
-        if (!s1 && !in->partials[c1]) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (!s2 && !in->partials[c2]) return BEAGLE_ERROR_OUT_OF_RANGE;
-        /* dispatch as AbstractLikelihoodCore.java:252-275 */
-        if (s1 && s2)       states_states(in, s1, in->matrices[m1], s2, in->matrices[m2], d);
-        else if (s1)        states_partials(in, s1, in->matrices[m1], in->partials[c2], in->matrices[m2], d);
-        else if (s2)        states_partials(in, s2, in->matrices[m2], in->partials[c1], in->matrices[m1], d);
-        else                partials_partials(in, in->partials[c1], in->matrices[m1], in->partials[c2], in->matrices[m2], d);
+            wS >= in->scaleCount || rS >= in->scaleCount ||
+            (!in->tipStates[c1] && !in->partials[c1]) || (!in->tipStates[c2] && !in->partials[c2])) { free(r); return BEAGLE_ERROR_OUT_OF_RANGE; }
+        r[o].s1 = in->tipStates[c1]; r[o].s2 = in->tipStates[c2];
+        r[o].x1 = in->partials[c1]; r[o].x2 = in->partials[c2];
+        r[o].m1 = in->matrices[m1]; r[o].m2 = in->matrices[m2];
+        r[o].d = partials_buf(in, dest);
         free(in->tipStates[dest]); in->tipStates[dest] = NULL;
-        if (wS >= 0) {
-            rescale_write(in, d, scale_buf(in, wS));
-            if (cumIdx != BEAGLE_OP_NONE) { int one = wS; oracle_beagleAccumulateScaleFactors(h, &one, 1, cumIdx); }
-        } else if (rS >= 0) {
-            rescale_read(in, d, scale_buf(in, rS));
+        r[o].wS = wS >= 0 ? scale_buf(in, wS) : NULL;
+        r[o].rS = (wS < 0 && rS >= 0) ? scale_buf(in, rS) : NULL;
+    }
+    /* pass 2: one parallel region; every thread runs the whole list on its own pattern block */
+    #pragma omp parallel
+    {
+        int nt = 1, tid = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+        const int div = in->P / nt, rem = in->P % nt;
+        const int p0 = tid * div + (tid < rem ? tid : rem), p1 = p0 + div + (tid < rem ? 1 : 0);
+        if (p1 > p0) for (int o = 0; o < count; o++) {
+            /* dispatch as AbstractLikelihoodCore.java:252-275 */
+            if (r[o].s1 && r[o].s2) states_states(in, r[o].s1, r[o].m1, r[o].s2, r[o].m2, r[o].d, p0, p1);
+            else if (r[o].s1)       states_partials(in, r[o].s1, r[o].m1, r[o].x2, r[o].m2, r[o].d, p0, p1);
+            else if (r[o].s2)       states_partials(in, r[o].s2, r[o].m2, r[o].x1, r[o].m1, r[o].d, p0, p1);
+            else                    partials_partials(in, r[o].x1, r[o].m1, r[o].x2, r[o].m2, r[o].d, p0, p1);
+            if (r[o].wS)      rescale_write(in, r[o].d, r[o].wS, p0, p1);
+            else if (r[o].rS) rescale_read(in, r[o].d, r[o].rS, p0, p1);
         }
     }
+    if (cumIdx != BEAGLE_OP_NONE)
+        for (int o = 0; o < count; o++) {
+            int wS = ops[o * BEAGLE_OP_COUNT + 1];
+            if (wS >= 0) oracle_beagleAccumulateScaleFactors(h, &wS, 1, cumIdx);
+        }
+    free(r);
     return BEAGLE_SUCCESS;
 }
 
