@@ -55,11 +55,12 @@ struct Instance {
     int partitionCount = 1;
     std::vector<int> partStart, partEnd;
     // levelisation scratch
-    std::vector<int> wStamp, wLevel, rStamp, rLevel; int stamp = 0;
+    std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
+    bool fuseCherries = true;   // BEAGLE_MI355_NO_FUSE=1 turns cherry fusion off (A/B measurements)
     // kernel timer
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
-    double timedMs = 0.0; long timedLaunches = 0;
+    double timedMs = 0.0; long timedLaunches = 0, pendingLaunches = 0;
     size_t deviceBytes = 0;
     std::string resourceName;
 };
@@ -291,8 +292,22 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         if (in->wStamp[kc2] == in->stamp) lvl = std::max(lvl, in->wLevel[kc2] + 1);
         if (in->wStamp[kd] == in->stamp) lvl = std::max(lvl, in->wLevel[kd] + 1);
         if (in->rStamp[kd] == in->stamp) lvl = std::max(lvl, in->rLevel[kd] + 1);
+        // cherry fusion (4-state kernel): a child that an earlier op OF THIS CALL computed from two compact tips is
+        // recomputed from the tip states instead of being re-read (kernels.hip, CH_CHERRY)
+        if (in->S == 4 && in->C <= 8 && in->fuseCherries) {
+            const size_t keys[2] = {kc1, kc2};
+            for (int ci = 0; ci < 2; ci++) {
+                if ((d.kind & (ci ? mi355::KIND_STATES2 : mi355::KIND_STATES1)) || in->wStamp[keys[ci]] != in->stamp) continue;
+                const OpDesc& w = descs[in->wOp[keys[ci]]];
+                if ((w.kind & 3) != 3 || w.pStart != d.pStart || w.pEnd != d.pEnd) continue;
+                d.kind |= ci ? mi355::KIND_CHERRY2 : mi355::KIND_CHERRY1;
+                d.cherry[ci].statesA = (const uint8_t*)w.child1; d.cherry[ci].statesB = (const uint8_t*)w.child2;
+                d.cherry[ci].scale = w.scaleWrite ? w.scaleWrite : w.scaleRead;
+                d.cherry[ci].matA = w.mat1; d.cherry[ci].matB = w.mat2;
+            }
+        }
         level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
-        in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl;
+        in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl; in->wOp[kd] = k;
         if (in->rStamp[kc1] != in->stamp || in->rLevel[kc1] < lvl) { in->rStamp[kc1] = in->stamp; in->rLevel[kc1] = lvl; }
         if (in->rStamp[kc2] != in->stamp || in->rLevel[kc2] < lvl) { in->rStamp[kc2] = in->stamp; in->rLevel[kc2] = lvl; }
     }
@@ -304,33 +319,39 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
 
-    // descriptors go through the ring in chunks (a 1e5-op list would not fit at once)
+    // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
+    // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
+    // launch per dependency level reading its slice.  With the kernel timer on, ONE HIP-event pair brackets
+    // all level launches of the call (gaps between levels included — they are part of what the path costs).
     const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
-    for (int l = 0; l <= maxLevel; l++) {
-        int begin = start[l];
-        const int end = start[l + 1];
-        while (begin < end) {
-            const int n = (int)std::min<size_t>(end - begin, maxChunkOps);
-            void* dOps = nullptr;
-            int rc = uploadTransient(in, &sorted[begin], (size_t)n * sizeof(OpDesc), &dOps);
-            if (rc) return rc;
-            int maxRange = 0;
-            for (int k = begin; k < begin + n; k++) maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (in->timing) {
-                if (in->eventsUsed == in->events.size()) {
-                    hipEvent_t a, b;
-                    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-                    in->events.emplace_back(a, b);
-                }
-                e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
-                HIP_TRY(hipEventRecord(e0, in->stream));
-            }
-            mi355::launchPruneLevel(in->stream, (const OpDesc*)dOps, n, in->matrices, in->P, in->S, in->C, maxRange);
-            if (in->timing) HIP_TRY(hipEventRecord(e1, in->stream));
-            begin += n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (in->timing) {
+        if (in->eventsUsed == in->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            in->events.emplace_back(a, b);
         }
+        e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
     }
+    int launches = 0;
+    for (int chunkBegin = 0; chunkBegin < count;) {
+        const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
+        void* dChunk = nullptr;
+        int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
+        if (rc) return rc;
+        if (e0 && chunkBegin == 0) HIP_TRY(hipEventRecord(e0, in->stream));
+        for (int l = 0; l <= maxLevel; l++) {
+            const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
+            if (begin >= end) continue;
+            int maxRange = 0;
+            for (int k = begin; k < end; k++) maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
+            mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                                    in->P, in->S, in->C, maxRange);
+            launches++;
+        }
+        chunkBegin = chunkEnd;
+    }
+    if (e1) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
     HIP_TRY(hipGetLastError());
     // cumulative scale factors requested together with the update: fold the factors this call wrote
     // into the cumulative buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
@@ -438,7 +459,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->scale.assign(std::max(1, scaleBufferCount), nullptr);
     in->scaleIsRaw.assign(std::max(1, scaleBufferCount), 0);
     in->partStart.assign(1, 0); in->partEnd.assign(1, patternCount);
-    in->wStamp.assign(partialsBufferCount, 0); in->wLevel.assign(partialsBufferCount, 0);
+    in->wStamp.assign(partialsBufferCount, 0); in->wLevel.assign(partialsBufferCount, 0); in->wOp.assign(partialsBufferCount, 0);
+    in->fuseCherries = !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0);
     in->rStamp.assign(partialsBufferCount, 0); in->rLevel.assign(partialsBufferCount, 0);
     in->resourceName = res->names[device + 1];
 
@@ -525,7 +547,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e;
     const size_t n = (size_t)in->partialsCount * partitionCount;
-    in->wStamp.assign(n, 0); in->wLevel.assign(n, 0); in->rStamp.assign(n, 0); in->rLevel.assign(n, 0);
+    in->wStamp.assign(n, 0); in->wLevel.assign(n, 0); in->rStamp.assign(n, 0); in->rLevel.assign(n, 0); in->wOp.assign(n, 0);
     in->stamp = 0;
     return BEAGLE_SUCCESS;
 }
@@ -688,13 +710,20 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
         if (badIndex(probIdx[k], in->matrixCount) || badIndex(eig[k], in->eigenCount) || badIndex(rate[k], in->eigenCount))
             return BEAGLE_ERROR_OUT_OF_RANGE;
     }
-    void *dIdx, *dLen, *dEig, *dRate;
-    int rc = uploadTransient(in, probIdx, (size_t)count * sizeof(int), &dIdx); if (rc) return rc;
-    rc = uploadTransient(in, lens, (size_t)count * sizeof(double), &dLen); if (rc) return rc;
-    rc = uploadTransient(in, eig.data(), (size_t)count * sizeof(int), &dEig); if (rc) return rc;
-    rc = uploadTransient(in, rate.data(), (size_t)count * sizeof(int), &dRate); if (rc) return rc;
-    mi355::launchTransitionMatrices(in->stream, in->matrices, in->eigen, in->rates, (const int*)dIdx, (const double*)dLen,
-                                    (const int*)dEig, (const int*)dRate, count, in->S, in->C);
+    // one packed upload: [lengths double[count] | matrix idx | eigen idx | rate idx] (each copy is a blit kernel)
+    std::vector<char> pack((size_t)count * (sizeof(double) + 3 * sizeof(int)));
+    double* pLen = (double*)pack.data();
+    int* pIdx = (int*)(pack.data() + (size_t)count * sizeof(double));
+    memcpy(pLen, lens, (size_t)count * sizeof(double));
+    memcpy(pIdx, probIdx, (size_t)count * sizeof(int));
+    memcpy(pIdx + count, eig.data(), (size_t)count * sizeof(int));
+    memcpy(pIdx + 2 * (size_t)count, rate.data(), (size_t)count * sizeof(int));
+    void* dPack;
+    int rc = uploadTransient(in, pack.data(), pack.size(), &dPack); if (rc) return rc;
+    const double* dLen = (const double*)dPack;
+    const int* dIdx = (const int*)((const char*)dPack + (size_t)count * sizeof(double));
+    mi355::launchTransitionMatrices(in->stream, in->matrices, in->eigen, in->rates, dIdx, dLen,
+                                    dIdx + count, dIdx + 2 * (size_t)count, count, in->S, in->C);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -861,8 +890,10 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     in->ringHead = 0;
     for (size_t k = 0; k < in->eventsUsed; k++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) { in->timedMs += ms; in->timedLaunches++; }
+        if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) in->timedMs += ms;
     }
+    in->timedLaunches += in->pendingLaunches;
+    in->pendingLaunches = 0;
     in->eventsUsed = 0;
     if (outMillis) *outMillis = in->timedMs;
     if (outLaunches) *outLaunches = in->timedLaunches;

@@ -9,6 +9,15 @@ namespace mi355 {
 // One pruning operation as the kernels see it: pointers already resolved on the host from the
 // reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
 // [, partition, cumulativeScale]} (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1266-1299).
+// A child that is itself a tip-tip node ("cherry") computed earlier in the same call: the 4-state kernel
+// recomputes it from the two grand-child state arrays instead of re-reading its partials from HBM.
+struct CherryDesc {
+    const uint8_t* statesA;     // compact states of the cherry's two tips
+    const uint8_t* statesB;
+    const double*  scale;       // the cherry's per-pattern raw scale factors (written or read by its own op), or nullptr
+    int            matA, matB;  // the cherry's two branch matrices
+};
+
 struct OpDesc {
     double*        dest;        // [C][P][S] partials, written on [pStart, pEnd)
     const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0)
@@ -16,13 +25,14 @@ struct OpDesc {
     double*        scaleWrite;  // per-pattern raw scale factors to WRITE (rescale now), or nullptr
     const double*  scaleRead;   // per-pattern raw scale factors to READ (divide by existing), or nullptr
     int            mat1, mat2;  // transition-matrix buffer indices
-    int            kind;        // bit0: child1 is compact states; bit1: child2 is compact states
+    int            kind;        // KIND_* bits
     int            pStart, pEnd;// pattern range of this op (whole buffer unless a ...ByPartition call)
     int            pad;
+    CherryDesc     cherry[2];   // valid when KIND_CHERRY1 / KIND_CHERRY2 is set (child pointer is still the partials)
 };
-static_assert(sizeof(OpDesc) == 64, "OpDesc must stay 64 bytes");
+static_assert(sizeof(OpDesc) == 128, "OpDesc must stay 128 bytes");
 
-enum { KIND_STATES1 = 1, KIND_STATES2 = 2 };
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_CHERRY1 = 4, KIND_CHERRY2 = 8 };
 
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------------
 

@@ -126,6 +126,23 @@ def make_workload(name, tip_count, pattern_count, eig, freqs, alpha=0.5, categor
     return Workload(name, tree, eig, freqs, rates, props, np.ascontiguousarray(tip_states), weights, s)
 
 
+def cached(path, maker):
+    """Generate a workload once per machine: ``maker()`` on a miss, unpickle ``path`` on a hit (the seeded
+    simulation of 1000 x 1e5 states takes ~10-30 s; several bench invocations on one box share it)."""
+    import os
+    import pickle
+    if path and os.path.exists(path):
+        with open(path, "rb") as fh:
+            return pickle.load(fh)
+    wl = maker()
+    if path:
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as fh:
+            pickle.dump(wl, fh, protocol=4)
+        os.replace(tmp, path)
+    return wl
+
+
 # BASELINE.json configs (SURVEY 8d).  `scale` shrinks taxa and patterns for parity-test sizes.
 def config_a(scale=1.0, seed=1, tree_kind="coalescent"):
     """GTR+G4 nucleotide, 1000 taxa x 1e5 unique patterns (the metric's config)."""

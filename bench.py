@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="patterns in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -80,14 +81,18 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     t_gen = time.time()
-    if args.config == "A":
-        wl = bm.synth.config_a(scale=args.scale, tree_kind=args.tree)
-    elif args.config == "B":
-        wl = bm.synth.config_b(scale=args.scale)
-    elif args.config == "C":
-        wl = bm.synth.config_c(scale=args.scale)
-    else:
-        wl = bm.synth.config_d(categories=1)
+    makers = {"A": lambda: bm.synth.config_a(scale=args.scale, tree_kind=args.tree),
+              "B": lambda: bm.synth.config_b(scale=args.scale),
+              "C": lambda: bm.synth.config_c(scale=args.scale),
+              "D": lambda: bm.synth.config_d(categories=1)}
+    if args.cache:
+        os.makedirs(args.cache, exist_ok=True)
+    cache = os.path.join(args.cache, "wl_%s_%g_%s.pkl" % (args.config, args.scale, args.tree)) if args.cache else None
+    if cache and world > 1 and rank != 0:
+        dist.barrier()                                  # rank 0 generates, the others read its file
+    wl = bm.synth.cached(cache, makers[args.config])
+    if cache and world > 1 and rank == 0:
+        dist.barrier()
     t_gen = time.time() - t_gen
 
     # resource numbering: 0 = CPU (absent), 1..G = GPUs as THIS process sees them
