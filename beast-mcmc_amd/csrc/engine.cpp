@@ -57,6 +57,7 @@ struct Instance {
     // levelisation scratch
     std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
     bool fuseCherries = true;   // BEAGLE_MI355_NO_FUSE=1 turns cherry fusion off (A/B measurements)
+    bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
     // kernel timer
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
@@ -344,9 +345,17 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
             const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
             if (begin >= end) continue;
             int maxRange = 0;
-            for (int k = begin; k < end; k++) maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
-            mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                    in->P, in->S, in->C, maxRange);
+            bool anyWrite = false;
+            for (int k = begin; k < end; k++) {
+                maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
+                anyWrite = anyWrite || sorted[k].scaleWrite != nullptr;
+            }
+            if (in->tiled)
+                mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                                             in->P, in->S, in->C, anyWrite);
+            else
+                mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                                        in->P, in->S, in->C, maxRange);
             launches++;
         }
         chunkBegin = chunkEnd;
@@ -404,11 +413,39 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         int rc = ensureScale(in, cumIdx); if (rc) return rc;
         cum = in->scale[cumIdx]; cumRaw = in->scaleIsRaw[cumIdx];
     }
-    mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+    if (in->tiled) {
+        mi355::launchRootSiteTiled(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                    in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
-                                   in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd);
+                                   in->blockSums, in->P, in->S, in->C, pStart, pEnd);
+        mi355::launchRootFinal(in->stream, in->blockSums, (pEnd - pStart + 255) / 256, dOut);
+    } else {
+        mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+                                       in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
+                                       in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// API layout double[C][P][S]  <->  T32 layout double[C][tile][S][32] (kernels_mfma.hip); padded patterns are zero
+void toTiled(const Instance* in, const double* api, double* tiled, int categories) {
+    const size_t S = in->S, P = in->P, nt = in->ntile;
+    std::fill(tiled, tiled + (size_t)categories * nt * S * 32, 0.0);
+    for (int c = 0; c < categories; c++)
+        for (size_t p = 0; p < P; p++) {
+            const double* src = api + ((size_t)c * P + p) * S;
+            double* dst = tiled + ((size_t)c * nt + p / 32) * S * 32 + p % 32;
+            for (size_t j = 0; j < S; j++) dst[j * 32] = src[j];
+        }
+}
+void fromTiled(const Instance* in, const double* tiled, double* api) {
+    const size_t S = in->S, P = in->P, nt = in->ntile;
+    for (int c = 0; c < in->C; c++)
+        for (size_t p = 0; p < P; p++) {
+            double* dst = api + ((size_t)c * P + p) * S;
+            const double* src = tiled + ((size_t)c * nt + p / 32) * S * 32 + p % 32;
+            for (size_t j = 0; j < S; j++) dst[j] = src[j * 32];
+        }
 }
 
 }  // namespace
@@ -453,7 +490,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->tipCount = tipCount; in->partialsCount = partialsBufferCount; in->compactCount = compactBufferCount;
     in->S = stateCount; in->P = patternCount; in->eigenCount = std::max(1, eigenBufferCount);
     in->matrixCount = matrixBufferCount; in->C = categoryCount; in->scaleCount = scaleBufferCount;
-    in->partialsBytes = (((size_t)categoryCount * patternCount * stateCount * sizeof(double)) + 255) & ~(size_t)255;
+    // 16..64 states: T32 layout + fp64 MFMA kernels (amino acids, codons); BEAGLE_MI355_NO_MFMA=1 keeps the VALU kernel
+    in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
+    in->ntile = (patternCount + 31) / 32;
+    const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
+    in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
     in->tipStates.assign(partialsBufferCount, nullptr);
     in->scale.assign(std::max(1, scaleBufferCount), nullptr);
@@ -576,7 +617,13 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
     if (badIndex(tipIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = ensurePartials(in, tipIndex); if (rc) return rc;
     const size_t n = (size_t)in->P * in->S * sizeof(double);
-    if (in->C == 1) { rc = upload(in, in->partials[tipIndex], inPartials, n); }
+    if (in->tiled) {
+        const size_t plane = (size_t)in->ntile * 32 * in->S;
+        std::vector<double> t(plane * in->C);
+        toTiled(in, inPartials, t.data(), 1);
+        for (int c = 1; c < in->C; c++) memcpy(&t[plane * c], &t[0], plane * sizeof(double));
+        rc = upload(in, in->partials[tipIndex], t.data(), t.size() * sizeof(double));
+    } else if (in->C == 1) { rc = upload(in, in->partials[tipIndex], inPartials, n); }
     else {
         // upload one category plane to the LAST plane, replicate it into all planes on the device
         double* last = in->partials[tipIndex] + (size_t)(in->C - 1) * in->P * in->S;
@@ -592,13 +639,25 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = ensurePartials(in, bufferIndex); if (rc) return rc;
     in->tipStates[bufferIndex] = nullptr;
+    if (in->tiled) {
+        std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
+        toTiled(in, inPartials, t.data(), in->C);
+        return upload(in, in->partials[bufferIndex], t.data(), t.size() * sizeof(double));
+    }
     return upload(in, in->partials[bufferIndex], inPartials, (size_t)in->C * in->P * in->S * sizeof(double));
 }
 
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials) {
     GET_INSTANCE(instance);
     if (badIndex(bufferIndex, in->partialsCount) || !in->partials[bufferIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = download(in, outPartials, in->partials[bufferIndex], (size_t)in->C * in->P * in->S * sizeof(double));
+    int rc;
+    if (in->tiled) {
+        std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
+        rc = download(in, t.data(), in->partials[bufferIndex], t.size() * sizeof(double));
+        if (!rc) fromTiled(in, t.data(), outPartials);
+    } else {
+        rc = download(in, outPartials, in->partials[bufferIndex], (size_t)in->C * in->P * in->S * sizeof(double));
+    }
     if (rc) return rc;
     if (scaleIndex != BEAGLE_OP_NONE) {
         if (badIndex(scaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;

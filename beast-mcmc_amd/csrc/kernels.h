@@ -71,4 +71,15 @@ void launchReplicateCategories(hipStream_t stream, const double* src, double* ds
 
 int  pruneBlocksForRange(int S, int range);
 
+// ---- T32 layout (20-/61-state MFMA path, kernels_mfma.hip): partials[c][tile][state][32 patterns] --------------
+// One dependency level on the fp64 matrix cores; anyScaleWrite adds the second (max + divide) pass.
+void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
+                           bool anyScaleWrite);
+// per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)
+void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
+                         const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
+                         double* blockSums, int P, int S, int C, int pStart, int pEnd);
+// out[0] = sum of n block sums in a fixed order
+void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out);
+
 }  // namespace mi355

@@ -364,7 +364,9 @@ void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const do
     if (nOps <= 0 || maxRange <= 0) return;
     if (S == 4 && C <= 8) {
         dim3 grid(pruneBlocksForRange(4, maxRange), nOps), block(NUC_BLOCK);
-        static const bool nt = getenv("BEAGLE_MI355_NT") && atoi(getenv("BEAGLE_MI355_NT")) != 0;
+        // non-temporal loads/stores of the partials streams: +3 % on config A (each buffer is touched once per launch
+        // and is far larger than L2); BEAGLE_MI355_NT=0 switches them off for A/B runs
+        static const bool nt = !(getenv("BEAGLE_MI355_NT") && atoi(getenv("BEAGLE_MI355_NT")) == 0);
 #define LAUNCH_NUC(CC)                                                                                          \
         if (nt) hipLaunchKernelGGL((k_prune4<CC, true>), grid, block, 0, stream, dOps, matrices, P);            \
         else    hipLaunchKernelGGL((k_prune4<CC, false>), grid, block, 0, stream, dOps, matrices, P)
@@ -456,6 +458,10 @@ void launchRootLogLikelihood(hipStream_t stream, const double* root, const doubl
     const int n = (pEnd - pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
     hipLaunchKernelGGL(k_rootSite, dim3(n), dim3(ROOT_BLOCK), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
                        patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
+    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out);
+}
+
+void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out) {
     hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out);
 }
 

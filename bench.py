@@ -168,17 +168,31 @@ def main():
                 traffic = json.load(open(tj)).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        s_ = wl.state_count
+        kname = "k_prune4<4,nt>" if s_ == 4 else ("k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral")
         roofline = {
-            "bound": "hbm", "kernel": "k_prune4<4>" if wl.state_count == 4 else "k_pruneGeneral",
+            "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
+            "traffic": traffic if args.config == "A" else None,
             "algorithmic_bytes_per_launch": round(pb / max(1.0, launches_per_eval)),
             "avg_launch_us": round(kernel_ms * 1e3 / max(1, launches), 2),
             "launches_per_eval": round(launches_per_eval, 2),
             "kernel_time_fraction_of_step": round(kernel_s_per_eval * evals_per_s, 4),
             "whole_eval_GBs": round(eval_bytes(shard) * evals_per_s / 1e9, 1),
         }
+        # arithmetic side of the roofline (matters for 61 states): 2*S*S flops per internal child per (pattern, category)
+        # + S products; fp64 matrix/vector peak 78.6 TFLOP/s (nominal), 73.9 measured for mfma_f64_4x4x4
+        tr = shard.tree
+        n_int_children = sum(1 for n in range(shard.tip_count, 2 * shard.tip_count - 1)
+                             for ch in (int(tr.left[n]), int(tr.right[n])) if ch >= shard.tip_count)
+        flops = (n_int_children * 2.0 * s_ * s_ + (shard.tip_count - 1) * s_) * shard.pattern_count * shard.category_count
+        tflops = flops / kernel_s_per_eval / 1e12 if kernel_s_per_eval > 0 else 0.0
+        roofline["fp64_TFLOPs"] = round(tflops, 2)
+        roofline["fp64_frac_of_78.6"] = round(tflops / 78.6, 4)
+        if tflops / 78.6 > achieved / HBM_PEAK_GBS:            # the compute roof is the nearer one (codon models)
+            roofline.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s",
+                             "frac": round(tflops / 78.6, 4), "hbm_GBs": round(achieved, 1)})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(bm, wl, args.cpu_sample, tl)

@@ -68,7 +68,9 @@ def test_golden_branch_specific(case, engine_lib):
 
 @pytest.mark.parametrize("S,C,T,P", [(4, 4, 33, 1000), (4, 1, 17, 257), (4, 2, 9, 64), (4, 8, 12, 300), (4, 10, 8, 130),
                                      (20, 4, 12, 333), (20, 1, 7, 50), (61, 4, 9, 150), (61, 2, 5, 33), (3, 3, 6, 100),
-                                     (2, 1, 12, 77), (7, 5, 10, 200)])
+                                     (2, 1, 12, 77), (7, 5, 10, 200),
+                                     # MFMA / T32-layout path (16..64 states), incl. partial 4-tiles and ragged 32-tiles
+                                     (16, 2, 6, 70), (21, 3, 6, 95), (60, 1, 5, 31), (64, 2, 5, 65), (20, 4, 30, 1000)])
 @pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_ALWAYS])
 def test_engine_matches_oracle(S, C, T, P, scheme, oracle_lib):
     wl = helpers.random_workload(T, P, S, C, seed=100 + S + C)
@@ -194,16 +196,18 @@ def test_post_order_list_is_levelised(oracle_lib):
     a.close(); b.close()
 
 
-def test_tip_partials_and_ambiguity(oracle_lib):
-    """setTipPartials (replicated over categories) must agree with compact states for unambiguous data."""
-    wl = helpers.random_workload(10, 300, 4, 4, seed=2)
+@pytest.mark.parametrize("S", [4, 20])
+def test_tip_partials_and_ambiguity(S, oracle_lib):
+    """setTipPartials (replicated over categories) must agree with compact states for unambiguous data
+    (S = 20 also exercises the API <-> T32 layout conversion of the MFMA path)."""
+    wl = helpers.random_workload(10, 300, S, 4, seed=2)
     g, o = both(wl, oracle_lib, rescaling=RESCALE_NONE)
     ref = g.getLogLikelihood()
     for t in (g, o):
         for tip in (0, 3, 7):
             st = wl.tip_states[tip]
-            part = np.zeros((wl.pattern_count, 4))
-            known = st < 4
+            part = np.zeros((wl.pattern_count, S))
+            known = st < S
             part[np.arange(wl.pattern_count)[known], st[known]] = 1.0
             part[~known] = 1.0
             t._chk(t.h.btlSetTipPartials(t.ptr, tip, part.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))), "setTipPartials")

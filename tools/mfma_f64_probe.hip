@@ -100,16 +100,16 @@ int main() {
     hipLaunchKernelGGL(k_map4, dim3(1), dim3(64), 0, 0, d);
     hipMemcpy(h.data(), d, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost);
     {
-        // hypothesis: lane l: block = l >> 4;  A(i = l & 3, k = (l >> 2) & 3); B(k = (l >> 2) & 3, j = l & 3);
-        //             D lane: block = l >> 4, row = (l >> 2) & 3, col = l & 3
+        // map (first derived from this probe's one-hot dump on an MI355X, now asserted):
+        //   lane l: block = (l >> 2) & 3;  A(i = l & 3, k = l >> 4);  B(k = l >> 4, j = l & 3);  D(row = l >> 4, col = l & 3)
         int bad = 0;
         for (int la = 0; la < 64; la++) for (int lane = 0; lane < 64; lane++) {
-            const int blkA = la >> 4, i = la & 3, k = (la >> 2) & 3;
-            const int blkD = lane >> 4, row = (lane >> 2) & 3, col = lane & 3;
-            const double expect = (blkA == blkD && row == i) ? (double)((blkD << 4 | k << 2 | col) + 1) : 0.0;
+            const int blkA = (la >> 2) & 3, i = la & 3, k = la >> 4;
+            const int blkD = (lane >> 2) & 3, row = lane >> 4, col = lane & 3;
+            const double expect = (blkA == blkD && row == i) ? (double)((k << 4 | blkD << 2 | col) + 1) : 0.0;
             if (h[la * 64 + lane] != expect) bad++;
         }
-        printf("mfma_f64_4x4x4_4b: blk=l>>4 A(i=l&3,k=(l>>2)&3) B(k=(l>>2)&3,j=l&3) D(row=(l>>2)&3,col=l&3): %s (%d mismatches)\n", bad ? "WRONG" : "confirmed", bad);
+        printf("mfma_f64_4x4x4_4b: blk=(l>>2)&3 A(i=l&3,k=l>>4) B(k=l>>4,j=l&3) D(row=l>>4,col=l&3): %s (%d mismatches)\n", bad ? "WRONG" : "confirmed", bad);
         if (bad) for (int la = 0; la < 20; la++) { printf(" la=%d:", la); for (int lane = 0; lane < 64; lane++) { double v = h[la * 64 + lane]; if (v != 0) printf(" l%d=%g", lane, v); } printf("\n"); }
     }
     double* r = d + 64 * 64 * 4;
