@@ -80,8 +80,11 @@ def test_engine_matches_oracle(S, C, T, P, scheme, oracle_lib):
     for node in range(wl.tip_count, 2 * wl.tip_count - 1):
         pg = _partials(g, node)
         po = _partials(o, node)
-        scale = np.maximum(np.abs(po), 1e-300)
-        assert np.max(np.abs(pg - po) / scale) <= 1e-9, node
+        # per pattern, relative to that pattern's largest partial: tiny entries inherit the ABSOLUTE rounding error of the
+        # transition-matrix entries they came from (exp() differs by an ulp between libm and the device), so an
+        # element-wise relative bound is not meaningful for them
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= REL_TOL, node
     g.close(); o.close()
 
 
