@@ -58,6 +58,7 @@ struct Instance {
     std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
     bool fuseCherries = true;   // BEAGLE_MI355_NO_FUSE=1 turns cherry fusion off (A/B measurements)
     bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
+    bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
     // kernel timer
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
@@ -250,6 +251,9 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     std::vector<OpDesc> descs(count);
     std::vector<int> level(count);
     std::vector<int> opCum(count, BEAGLE_OP_NONE), opWrite(count, BEAGLE_OP_NONE), opPart(count, 0);
+    std::vector<int> predOff(count + 1, 0), predList;                 // RAW / WAW edges: producer op -> this op
+    bool warSeen = false;                                             // a write-after-read hazard inside the list (never in BEAST's lists)
+    predList.reserve((size_t)count * 3);
     in->stamp++;
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {
@@ -289,10 +293,11 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         // destination (WAR) or that wrote it (WAW); hazards are tracked per (buffer, partition)
         int lvl = 0;
         const size_t kc1 = (size_t)c1 * parts + part, kc2 = (size_t)c2 * parts + part, kd = (size_t)dest * parts + part;
-        if (in->wStamp[kc1] == in->stamp) lvl = std::max(lvl, in->wLevel[kc1] + 1);
-        if (in->wStamp[kc2] == in->stamp) lvl = std::max(lvl, in->wLevel[kc2] + 1);
-        if (in->wStamp[kd] == in->stamp) lvl = std::max(lvl, in->wLevel[kd] + 1);
-        if (in->rStamp[kd] == in->stamp) lvl = std::max(lvl, in->rLevel[kd] + 1);
+        predOff[k] = (int)predList.size();
+        if (in->wStamp[kc1] == in->stamp) { lvl = std::max(lvl, in->wLevel[kc1] + 1); predList.push_back(in->wOp[kc1]); }
+        if (in->wStamp[kc2] == in->stamp) { lvl = std::max(lvl, in->wLevel[kc2] + 1); predList.push_back(in->wOp[kc2]); }
+        if (in->wStamp[kd] == in->stamp) { lvl = std::max(lvl, in->wLevel[kd] + 1); predList.push_back(in->wOp[kd]); }
+        if (in->rStamp[kd] == in->stamp) { lvl = std::max(lvl, in->rLevel[kd] + 1); warSeen = true; }
         // cherry fusion (4-state kernel): a child that an earlier op OF THIS CALL computed from two compact tips is
         // recomputed from the tip states instead of being re-read (kernels.hip, CH_CHERRY)
         if (in->S == 4 && in->C <= 8 && in->fuseCherries) {
@@ -311,6 +316,20 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl; in->wOp[kd] = k;
         if (in->rStamp[kc1] != in->stamp || in->rLevel[kc1] < lvl) { in->rStamp[kc1] = in->stamp; in->rLevel[kc1] = lvl; }
         if (in->rStamp[kc2] != in->stamp || in->rLevel[kc2] < lvl) { in->rStamp[kc2] = in->stamp; in->rLevel[kc2] = lvl; }
+    }
+    // ASAP levels put every tip-tip op ("cherry", write-only traffic) into the first launch and leave the read-heavy
+    // ops to later ones, so the HBM sees a write-bound phase (~3.7 TB/s) followed by read-heavy phases.  ALAP levels
+    // (= depth below the root, BEAST's own "reverse level order") spread the cherries over all launches: every launch
+    // then mixes reads and writes, which is where the memory system is fastest.  Same number of launches either way.
+    predOff[count] = (int)predList.size();
+    if (in->schedAlap && !warSeen) {
+        std::vector<int> alap(count, maxLevel);
+        for (int k = count - 1; k >= 0; k--)
+            for (int e = predOff[k]; e < predOff[k + 1]; e++) {
+                const int a = predList[e];
+                if (alap[a] > alap[k] - 1) alap[a] = alap[k] - 1;
+            }
+        level.swap(alap);
     }
     // counting sort by level (stable)
     std::vector<int> start(maxLevel + 2, 0);
@@ -493,6 +512,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // 16..64 states: T32 layout + fp64 MFMA kernels (amino acids, codons); BEAGLE_MI355_NO_MFMA=1 keeps the VALU kernel
     in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
     in->ntile = (patternCount + 31) / 32;
+    in->schedAlap = !(getenv("BEAGLE_MI355_SCHED") && strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") == 0);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);

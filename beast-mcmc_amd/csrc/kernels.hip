@@ -117,21 +117,21 @@ struct NucLds {
 
 enum { CH_PARTIALS = 0, CH_STATES = 1, CH_CHERRY = 2 };
 
-template <int C, bool NT>
+template <int C, int NT>
 struct NucChildRegs {
     v4d v[C];       // PARTIALS: the child's partials
     int sa, sb;     // STATES: sa; CHERRY: both grand-child states
     double inv;     // CHERRY: 1 / the cherry's scale factor (1 when unscaled)
 };
 
-template <int C, bool NT>
+template <int C, int NT>
 __device__ __forceinline__ void nucIssue(NucChildRegs<C, NT>& r, int kind, const void* __restrict__ src,
                                          const CherryDesc& ch, int P, int p) {
     r.sa = 4; r.sb = 4; r.inv = 1.0;
     if (kind == CH_PARTIALS) {
         const double* x = reinterpret_cast<const double*>(src);
 #pragma unroll
-        for (int c = 0; c < C; c++) r.v[c] = ldv4<NT>(x + ((size_t)c * P + p) * 4);
+        for (int c = 0; c < C; c++) r.v[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
     } else if (kind == CH_STATES) {
         r.sa = reinterpret_cast<const uint8_t*>(src)[p];
     } else {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void nucIssue(NucChildRegs<C, NT>& r, int kind, const
     }
 }
 
-template <int C, bool NT>
+template <int C, int NT>
 __device__ __forceinline__ void nucApply(const NucLds<C>& L, const NucChildRegs<C, NT>& r, int kind, int child,
                                          double (&f)[C][4]) {
     if (kind == CH_STATES) {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void nucStage(NucLds<C>& L, int m, const double* __re
     for (int t = threadIdx.x; t < C * 4; t += NUC_BLOCK) L.col[m][t >> 2][4][t & 3] = 1.0;
 }
 
-template <int C, bool NT>
+template <int C, int NT>
 __global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
     __shared__ NucLds<C> L;
     const OpDesc& op = ops[blockIdx.y];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__
 #pragma unroll
     for (int c = 0; c < C; c++) {
         v4d o; o.x = a[c][0]; o.y = a[c][1]; o.z = a[c][2]; o.w = a[c][3];
-        stv4<NT>(op.dest + ((size_t)c * P + p) * 4, o);
+        stv4<(NT & 2) != 0>(op.dest + ((size_t)c * P + p) * 4, o);
     }
 }
 
@@ -366,10 +366,13 @@ void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const do
         dim3 grid(pruneBlocksForRange(4, maxRange), nOps), block(NUC_BLOCK);
         // non-temporal loads/stores of the partials streams: +3 % on config A (each buffer is touched once per launch
         // and is far larger than L2); BEAGLE_MI355_NT=0 switches them off for A/B runs
-        static const bool nt = !(getenv("BEAGLE_MI355_NT") && atoi(getenv("BEAGLE_MI355_NT")) == 0);
+        // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3)
+        static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
 #define LAUNCH_NUC(CC)                                                                                          \
-        if (nt) hipLaunchKernelGGL((k_prune4<CC, true>), grid, block, 0, stream, dOps, matrices, P);            \
-        else    hipLaunchKernelGGL((k_prune4<CC, false>), grid, block, 0, stream, dOps, matrices, P)
+        if (nt == 3)      hipLaunchKernelGGL((k_prune4<CC, 3>), grid, block, 0, stream, dOps, matrices, P);     \
+        else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2>), grid, block, 0, stream, dOps, matrices, P);     \
+        else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1>), grid, block, 0, stream, dOps, matrices, P);     \
+        else              hipLaunchKernelGGL((k_prune4<CC, 0>), grid, block, 0, stream, dOps, matrices, P)
         switch (C) {
             case 1: LAUNCH_NUC(1); break;
             case 2: LAUNCH_NUC(2); break;
