@@ -36,8 +36,13 @@ namespace {
 constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
 
+struct Virt { bool on = false; int tipA = -1, tipB = -1, scaleIdx = -1; };   // see "virtual cherries" below
+
 struct Instance {
     int device = 0;
+    std::vector<Virt> virt;                              // per partials buffer
+    std::vector<std::vector<int>> tipUsers, scaleUsers;  // virtual buffers defined by a tip / a scale buffer
+    bool virtualCherries = false;                        // 4 states, single partition; BEAGLE_MI355_NO_VIRTUAL=1 disables
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
     size_t partialsBytes = 0;
@@ -244,6 +249,51 @@ Resources* resources() {
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 
+// ---- virtual cherries ---------------------------------------------------------------------------------------
+// A partials buffer is "virtual" when its content is defined as  (M_A[:, sA] * M_B[:, sB]) / scale  for two compact
+// tips A, B, private snapshots of the two branch matrices (stored behind the regular matrices at index
+// matrixCount + 2*buffer [+1]) and an optional per-pattern scale factor — and has NOT been written to HBM.
+// Parents fuse the recomputation (kernels.hip CH_CHERRY).  Anything that would change one of the defining inputs
+// (tip states, the scale buffer) or that needs the real data (getPartials, root, non-fusing readers) first calls
+// materializeVirtual, which runs the ordinary tip-tip op from the snapshot; the result is bitwise what the op would
+// have stored in the first place.
+void clearVirtual(Instance* in, int X) {
+    Virt& v = in->virt[X];
+    if (!v.on) return;
+    auto drop = [X](std::vector<int>& u) { u.erase(std::remove(u.begin(), u.end(), X), u.end()); };
+    drop(in->tipUsers[v.tipA]); drop(in->tipUsers[v.tipB]);
+    if (v.scaleIdx >= 0) drop(in->scaleUsers[v.scaleIdx]);
+    v.on = false;
+}
+
+int materializeVirtual(Instance* in, int X) {
+    Virt& v = in->virt[X];
+    if (!v.on) return 0;
+    int rc = ensurePartials(in, X); if (rc) return rc;
+    OpDesc d;
+    memset(&d, 0, sizeof(d));
+    d.dest = in->partials[X];
+    d.child1 = in->tipStates[v.tipA]; d.child2 = in->tipStates[v.tipB];
+    d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
+    d.mat1 = in->matrixCount + 2 * X; d.mat2 = d.mat1 + 1;
+    d.scaleRead = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;    // write-mode cherries stored their factor there too
+    d.pStart = 0; d.pEnd = in->P;
+    void* dOp = nullptr;
+    rc = uploadTransient(in, &d, sizeof(d), &dOp); if (rc) return rc;
+    mi355::launchPruneLevel(in->stream, (const OpDesc*)dOp, 1, in->matrices, in->P, in->S, in->C, in->P);
+    clearVirtual(in, X);
+    return 0;
+}
+
+int materializeScaleUsers(Instance* in, int scaleIdx) {
+    while (!in->scaleUsers[scaleIdx].empty()) { int rc = materializeVirtual(in, in->scaleUsers[scaleIdx].back()); if (rc) return rc; }
+    return 0;
+}
+int materializeTipUsers(Instance* in, int tip) {
+    while (!in->tipUsers[tip].empty()) { int rc = materializeVirtual(in, in->tipUsers[tip].back()); if (rc) return rc; }
+    return 0;
+}
+
 // Enqueue an op list.  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
 int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (count <= 0) return 0;
@@ -254,6 +304,16 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     std::vector<int> predOff(count + 1, 0), predList;                 // RAW / WAW edges: producer op -> this op
     bool warSeen = false;                                             // a write-after-read hazard inside the list (never in BEAST's lists)
     predList.reserve((size_t)count * 3);
+    std::vector<char> skip(count, 0);            // virtual cherries in read/no-scale mode launch nothing at all
+    std::vector<int> snapPairs;                  // (src matrix, dst snapshot slot) pairs for this call
+    const bool canVirtual = in->virtualCherries && parts == 1 && tuple == BEAGLE_OP_COUNT;
+    // a scale buffer about to be rewritten may still define virtual cherries of earlier evaluations: give those
+    // their real partials first (enqueued ahead of everything this call launches)
+    if (canVirtual)
+        for (int k = 0; k < count; k++) {
+            const int wS = ops[(size_t)k * tuple + 1];
+            if (wS != BEAGLE_OP_NONE && !badIndex(wS, in->scaleCount)) { int rc = materializeScaleUsers(in, wS); if (rc) return rc; }
+        }
     in->stamp++;
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {
@@ -268,17 +328,46 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
             return BEAGLE_ERROR_OUT_OF_RANGE;
         OpDesc& d = descs[k];
         memset(&d, 0, sizeof(d));
-        int rc = ensurePartials(in, dest);
-        if (rc) return rc;
+        const bool tip1 = in->tipStates[c1] && c1 < in->tipCount, tip2 = in->tipStates[c2] && c2 < in->tipCount;
+        const size_t kdest = (size_t)dest * parts + part;
+        // Virtual cherry: both children are compact tips -> the node's partials are a pure function of two state bytes,
+        // two (snapshotted) matrices and a scale factor; fusing parents recompute them, so they are not written to HBM
+        // at all unless something else asks for them (materializeVirtual).  Not when an earlier op of this call read
+        // the previous virtual content of the same buffer (its snapshot slot must stay intact until that op has run).
+        const bool makeVirtual = canVirtual && tip1 && tip2 && c1 != dest && c2 != dest &&
+                                 !(in->rStamp[kdest] == in->stamp && in->virt[dest].on);
+        if (in->virt[dest].on) clearVirtual(in, dest);          // whatever it was, this op replaces it
+        int rc = 0;
+        if (!makeVirtual) { rc = ensurePartials(in, dest); if (rc) return rc; }
         d.dest = in->partials[dest];
         d.kind = 0;
-        if (in->tipStates[c1] && c1 < in->tipCount) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
-        else if (in->partials[c1]) d.child1 = in->partials[c1];
+        if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
+        else if (in->virt[c1].on || in->partials[c1]) d.child1 = in->partials[c1];
         else return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (in->tipStates[c2] && c2 < in->tipCount) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
-        else if (in->partials[c2]) d.child2 = in->partials[c2];
+        if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
+        else if (in->virt[c2].on || in->partials[c2]) d.child2 = in->partials[c2];
         else return BEAGLE_ERROR_OUT_OF_RANGE;
+        // children that are virtual cherries (of this or an earlier call): recompute from the snapshot
+        for (int ci = 0; ci < 2; ci++) {
+            const int c = ci ? c2 : c1;
+            if ((ci ? tip2 : tip1) || !in->virt[c].on) continue;
+            const Virt& v = in->virt[c];
+            d.kind |= ci ? mi355::KIND_CHERRY2 : mi355::KIND_CHERRY1;
+            d.cherry[ci].statesA = in->tipStates[v.tipA]; d.cherry[ci].statesB = in->tipStates[v.tipB];
+            d.cherry[ci].scale = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;
+            d.cherry[ci].matA = in->matrixCount + 2 * c; d.cherry[ci].matB = in->matrixCount + 2 * c + 1;
+        }
         d.mat1 = m1; d.mat2 = m2;
+        if (makeVirtual) {
+            Virt& v = in->virt[dest];
+            v.on = true; v.tipA = c1; v.tipB = c2; v.scaleIdx = wS != BEAGLE_OP_NONE ? wS : rS;
+            in->tipUsers[c1].push_back(dest); in->tipUsers[c2].push_back(dest);
+            if (v.scaleIdx >= 0) in->scaleUsers[v.scaleIdx].push_back(dest);
+            snapPairs.push_back(m1); snapPairs.push_back(in->matrixCount + 2 * dest);
+            snapPairs.push_back(m2); snapPairs.push_back(in->matrixCount + 2 * dest + 1);
+            if (wS != BEAGLE_OP_NONE) d.kind |= mi355::KIND_NO_STORE;   // still has to produce its scale factors
+            else skip[k] = 1;
+        }
         if (wS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, wS); if (rc) return rc;
             d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
@@ -303,7 +392,8 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         if (in->S == 4 && in->C <= 8 && in->fuseCherries) {
             const size_t keys[2] = {kc1, kc2};
             for (int ci = 0; ci < 2; ci++) {
-                if ((d.kind & (ci ? mi355::KIND_STATES2 : mi355::KIND_STATES1)) || in->wStamp[keys[ci]] != in->stamp) continue;
+                if ((d.kind & (ci ? (mi355::KIND_STATES2 | mi355::KIND_CHERRY2) : (mi355::KIND_STATES1 | mi355::KIND_CHERRY1))) ||
+                    in->wStamp[keys[ci]] != in->stamp) continue;
                 const OpDesc& w = descs[in->wOp[keys[ci]]];
                 if ((w.kind & 3) != 3 || w.pStart != d.pStart || w.pEnd != d.pEnd) continue;
                 d.kind |= ci ? mi355::KIND_CHERRY2 : mi355::KIND_CHERRY1;
@@ -331,13 +421,19 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
             }
         level.swap(alap);
     }
-    // counting sort by level (stable)
+    // counting sort by level (stable); ops that launch nothing (virtual cherries without a scale write) drop out
     std::vector<int> start(maxLevel + 2, 0);
-    for (int k = 0; k < count; k++) start[level[k] + 1]++;
+    for (int k = 0; k < count; k++) if (!skip[k]) start[level[k] + 1]++;
     for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
-    std::vector<OpDesc> sorted(count);
+    const int launchCount = start[maxLevel + 1];
+    std::vector<OpDesc> sorted(std::max(1, launchCount));
     std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
+    for (int k = 0; k < count; k++) if (!skip[k]) sorted[fill[level[k]]++] = descs[k];
+    if (!snapPairs.empty()) {
+        void* dPairs = nullptr;
+        int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
+    }
 
     // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
     // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
@@ -354,8 +450,8 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
     }
     int launches = 0;
-    for (int chunkBegin = 0; chunkBegin < count;) {
-        const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
+    for (int chunkBegin = 0; chunkBegin < launchCount;) {
+        const int chunkEnd = (int)std::min<size_t>((size_t)launchCount, (size_t)chunkBegin + maxChunkOps);
         void* dChunk = nullptr;
         int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
         if (rc) return rc;
@@ -379,7 +475,8 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         }
         chunkBegin = chunkEnd;
     }
-    if (e1) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
+    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
+    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
     HIP_TRY(hipGetLastError());
     // cumulative scale factors requested together with the update: fold the factors this call wrote
     // into the cumulative buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
@@ -399,7 +496,8 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
 
 int accumulate(Instance* in, const int* idx, int count, int cum, double sign, int part) {
     if (badIndex(cum, in->scaleCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensureScale(in, cum); if (rc) return rc;
+    int rc = materializeScaleUsers(in, cum); if (rc) return rc;
+    rc = ensureScale(in, cum); if (rc) return rc;
     if (in->scaleIsRaw[cum]) return BEAGLE_ERROR_OUT_OF_RANGE;
     std::vector<const double*> srcs(count);
     std::vector<int> raw(count);
@@ -423,7 +521,9 @@ int accumulate(Instance* in, const int* idx, int count, int cum, double sign, in
 
 int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int part, double* dOut) {
     // part < 0: the whole pattern range
-    if (badIndex(rootIdx, in->partialsCount) || !in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) ||
+    if (badIndex(rootIdx, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    { int rcv = materializeVirtual(in, rootIdx); if (rcv) return rcv; }
+    if (!in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) ||
         badIndex(fIdx, in->eigenCount) || (part >= 0 && badIndex(part, in->partitionCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
     const int pStart = part < 0 ? 0 : in->partStart[part], pEnd = part < 0 ? in->P : in->partEnd[part];
     const double* cum = nullptr; int cumRaw = 0;
@@ -513,6 +613,14 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
     in->ntile = (patternCount + 31) / 32;
     in->schedAlap = !(getenv("BEAGLE_MI355_SCHED") && strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") == 0);
+    in->virtualCherries = stateCount == 4 && categoryCount <= 8 &&
+                          !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0) &&
+                          !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
+    in->virt.assign(partialsBufferCount, Virt());
+    in->tipUsers.assign(partialsBufferCount, std::vector<int>());
+    in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());
+    // matrix storage: the caller's buffers, then two private snapshot slots per partials buffer (virtual cherries)
+    const size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)partialsBufferCount : 0);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
@@ -532,7 +640,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     const size_t S = stateCount, C = categoryCount, E = in->eigenCount;
     const int rootBlocks = (patternCount + 255) / 256;
     ok = ok && devAlloc(in, (void**)&in->dRing, RING_BYTES) == 0;
-    ok = ok && devAlloc(in, (void**)&in->matrices, std::max<size_t>(1, matrixBufferCount) * C * S * S * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->matrices, matrixSlots * C * S * S * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->eigen, E * (2 * S * S + S) * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->rates, E * C * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->weights, E * C * sizeof(double)) == 0;
@@ -548,7 +656,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         ok = ok && upload(in, in->patternWeights, ones.data(), (size_t)patternCount * sizeof(double)) == 0;
         std::vector<double> w(E * C, 1.0 / (double)C);
         ok = ok && upload(in, in->weights, w.data(), E * C * sizeof(double)) == 0;
-        ok = ok && hipMemsetAsync(in->matrices, 0, std::max<size_t>(1, matrixBufferCount) * C * S * S * sizeof(double), in->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(in->matrices, 0, matrixSlots * C * S * S * sizeof(double), in->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(in->siteLogL, 0, (size_t)patternCount * sizeof(double), in->stream) == hipSuccess;
     }
     if (!ok) { destroy(in); return BEAGLE_ERROR_OUT_OF_MEMORY; }
@@ -595,6 +703,7 @@ int beagleSetPatternWeights(int instance, const double* w) {
 int beagleSetPatternPartitions(int instance, int partitionCount, const int* partitions) {
     GET_INSTANCE(instance);
     if (partitionCount < 1) return BEAGLE_ERROR_OUT_OF_RANGE;
+    for (int x = 0; x < in->partialsCount; x++) { int rcv = materializeVirtual(in, x); if (rcv) return rcv; }   // whole-range definitions
     // partitions are contiguous pattern ranges in concatenation order
     // (MultiPartitionDataLikelihoodDelegate.java:520-535); anything else is rejected
     std::vector<int> s(partitionCount, -1), e(partitionCount, -1);
@@ -617,7 +726,8 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->tipCount) || badIndex(tipIndex, in->partialsCount) || tipIndex >= in->compactCount)
         return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensureStates(in, tipIndex); if (rc) return rc;
+    int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;   // virtual cherries defined by the OLD states
+    rc = ensureStates(in, tipIndex); if (rc) return rc;
     std::vector<uint8_t> s(in->P);
     for (int p = 0; p < in->P; p++) s[p] = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
     return upload(in, in->tipStates[tipIndex], s.data(), (size_t)in->P);
@@ -635,7 +745,9 @@ int beagleGetTipStates(int instance, int tipIndex, int* outStates) {
 int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensurePartials(in, tipIndex); if (rc) return rc;
+    int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;
+    clearVirtual(in, tipIndex);
+    rc = ensurePartials(in, tipIndex); if (rc) return rc;
     const size_t n = (size_t)in->P * in->S * sizeof(double);
     if (in->tiled) {
         const size_t plane = (size_t)in->ntile * 32 * in->S;
@@ -657,7 +769,9 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     GET_INSTANCE(instance);
     if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensurePartials(in, bufferIndex); if (rc) return rc;
+    int rc = materializeTipUsers(in, bufferIndex); if (rc) return rc;
+    clearVirtual(in, bufferIndex);
+    rc = ensurePartials(in, bufferIndex); if (rc) return rc;
     in->tipStates[bufferIndex] = nullptr;
     if (in->tiled) {
         std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
@@ -669,8 +783,9 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
 
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials) {
     GET_INSTANCE(instance);
-    if (badIndex(bufferIndex, in->partialsCount) || !in->partials[bufferIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc;
+    if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int rc = materializeVirtual(in, bufferIndex); if (rc) return rc;
+    if (!in->partials[bufferIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (in->tiled) {
         std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
         rc = download(in, t.data(), in->partials[bufferIndex], t.size() * sizeof(double));
@@ -862,7 +977,8 @@ int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, i
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex) {
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount) || badIndex(partitionIndex, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
+    int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
+    rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
     if (in->scaleIsRaw[cumulativeScaleIndex] && in->partitionCount > 1) {
         // a per-node (raw) buffer is being recycled as a cumulative one: clear all of it first
         mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
@@ -875,7 +991,8 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
+    int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
+    rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
     mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     HIP_TRY(hipGetLastError());
@@ -885,7 +1002,8 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
 int beagleCopyScaleFactors(int instance, int dest, int src) {
     GET_INSTANCE(instance);
     if (badIndex(dest, in->scaleCount) || badIndex(src, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = ensureScale(in, dest); if (rc) return rc;
+    int rc = materializeScaleUsers(in, dest); if (rc) return rc;
+    rc = ensureScale(in, dest); if (rc) return rc;
     rc = ensureScale(in, src); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
     in->scaleIsRaw[dest] = in->scaleIsRaw[src];

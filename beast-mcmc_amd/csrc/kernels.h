@@ -32,7 +32,12 @@ struct OpDesc {
 };
 static_assert(sizeof(OpDesc) == 128, "OpDesc must stay 128 bytes");
 
-enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_CHERRY1 = 4, KIND_CHERRY2 = 8 };
+// KIND_NO_STORE: compute (and write the scale factors) but do not store the partials — used for "virtual" cherries
+// whose partials are never materialised unless somebody other than a fusing parent asks for them (engine.cpp).
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_CHERRY1 = 4, KIND_CHERRY2 = 8, KIND_NO_STORE = 16 };
+
+// matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
+void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);
 
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------------
 

@@ -248,11 +248,23 @@ __global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; i++) a[c][i] *= invRead;
     }
+    if (kindBits & KIND_NO_STORE) return;     // virtual cherry: only its scale factors are kept
 #pragma unroll
     for (int c = 0; c < C; c++) {
         v4d o; o.x = a[c][0]; o.y = a[c][1]; o.z = a[c][2]; o.w = a[c][3];
         stv4<(NT & 2) != 0>(op.dest + ((size_t)c * P + p) * 4, o);
     }
+}
+
+__global__ void k_snapshot(double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
+    const double* s = matrices + (size_t)srcDst[2 * blockIdx.x] * elems;
+    double* d = matrices + (size_t)srcDst[2 * blockIdx.x + 1] * elems;
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) d[e] = s[e];
+}
+
+void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_snapshot, dim3(n), dim3(64), 0, stream, matrices, dSrcDst, elems);
 }
 
 // ------------------------------------------------------------------------------------------------

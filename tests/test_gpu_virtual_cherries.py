@@ -1,0 +1,106 @@
+"""The 4-state engine never writes tip-tip nodes' partials to HBM unless somebody needs the real data ("virtual
+cherries", engine.cpp).  BEAGLE semantics must survive that: a partials buffer keeps the value its op gave it even
+if the tip states, the matrices or the scale buffer it was computed from are changed afterwards.  Every step below is
+issued identically to the HIP engine and to the CPU oracle, and every buffer is compared after every step."""
+import numpy as np
+import pytest
+
+import beast_mcmc_amd as bm
+import helpers
+from beast_mcmc_amd.inputs import substmodel
+
+pytestmark = pytest.mark.gpu
+NONE = bm.beagle.NONE
+T, P, C = 4, 300, 4          # tips 0..3; internal buffers 4 = (0,1) cherry, 5 = (2,3) cherry, 6 = (4,5) root, 7 = (4,2)
+
+
+def make(lib, states, eig, rates):
+    b = bm.beagle.Beagle(T, 8, T, 4, P, 1, 8, C, 6, library=lib)
+    for t in range(T):
+        b.setTipStates(t, states[t])
+    b.setEigenDecomposition(0, eig.evec, eig.ievc, eig.evals)
+    b.setCategoryRates(rates)
+    b.updateTransitionMatrices(0, [0, 1, 2, 3, 4, 5], None, None, [0.1, 0.3, 0.2, 0.05, 0.4, 0.15], 6)
+    return b
+
+
+def same(g, o, bufs, what):
+    for x in bufs:
+        a, b = g.getPartials(x, NONE), o.getPartials(x, NONE)
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b).max(axis=(0, 2), keepdims=True), 1e-300)) <= 1e-12, (what, x)
+
+
+def test_virtual_cherries_keep_beagle_semantics(oracle_lib, engine_lib):
+    rng = np.random.default_rng(5)
+    states = rng.integers(0, 5, size=(T, P)).astype(np.int32)           # 4 = missing
+    pi = np.array([0.3, 0.2, 0.25, 0.25])
+    eig = substmodel.gtr([1.0, 3.0, 0.7, 1.1, 4.0, 1.0], pi)
+    rates = [0.1, 0.5, 1.0, 2.4]
+    g, o = make(engine_lib, states, eig, rates), make(oracle_lib, states, eig, rates)
+    try:
+        both = (g, o)
+        # 1. write-mode rescaling: cherries 4, 5 (scale buffers 0, 1), root 6 (scale 2)
+        ops1 = [4, 0, NONE, 0, 0, 1, 1,   5, 1, NONE, 2, 2, 3, 3,   6, 2, NONE, 4, 4, 5, 5]
+        for b in both:
+            b.updatePartials(ops1, 3, NONE)
+        same(g, o, [6], "root after write-mode ops")
+        assert np.max(np.abs(g.getLogScaleFactors(0) - o.getLogScaleFactors(0))) < 1e-12
+        # 2. read-mode: recompute 4 (reads scale 0) and a second parent 7 = (4, tip 2) that fuses it
+        ops2 = [4, NONE, 0, 0, 0, 1, 1,   7, NONE, 2, 4, 4, 2, 2]
+        for b in both:
+            b.updatePartials(ops2, 2, NONE)
+        same(g, o, [7], "parent of a read-mode virtual cherry")
+        # 3. change a tip of cherry 4: buffers 4 and 7 must keep their OLD values (no op recomputed them) ...
+        new0 = rng.integers(0, 4, size=P).astype(np.int32)
+        for b in both:
+            b.setTipStates(0, new0)
+        same(g, o, [4, 7, 6], "after setTipStates")
+        # ... and a later parent that uses buffer 4 WITHOUT recomputing it sees those old values
+        for b in both:
+            b.updatePartials([7, NONE, NONE, 4, 4, 3, 3], 1, NONE)
+        same(g, o, [7], "later parent of a materialised cherry")
+        # 4. recompute 4 from the new states, then overwrite its scale buffer: 4 keeps its value, parents still agree
+        for b in both:
+            b.updatePartials([4, NONE, 0, 0, 0, 1, 1], 1, NONE)
+            b.resetScaleFactors(0)
+            b.updatePartials([7, NONE, NONE, 4, 4, 2, 2], 1, NONE)
+        same(g, o, [4, 7], "after the cherry's scale buffer was reset")
+        # 5. new matrices for the cherry's branches: buffer 5 (computed in step 1, never read back so far) is unchanged
+        for b in both:
+            b.updateTransitionMatrices(0, [2, 3], None, None, [0.9, 0.8], 2)
+            b.updatePartials([6, NONE, NONE, 4, 4, 5, 5], 1, NONE)
+        same(g, o, [5, 6], "after the cherry's branch matrices were rewritten")
+        # 6. root likelihood straight from a cherry buffer
+        for b in both:
+            b.setStateFrequencies(0, pi); b.setCategoryWeights(0, [0.25] * 4); b.setPatternWeights(np.ones(P))
+            b.updatePartials([5, NONE, NONE, 2, 2, 3, 3], 1, NONE)
+        out_g, out_o = [0.0], [0.0]
+        g.calculateRootLogLikelihoods([5], [0], [0], [NONE], 1, out_g)
+        o.calculateRootLogLikelihoods([5], [0], [0], [NONE], 1, out_o)
+        assert helpers.rel_err(out_g[0], out_o[0]) <= 1e-12
+    finally:
+        g.finalize(); o.finalize()
+
+
+def test_virtual_and_stored_cherries_agree_bitwise(engine_lib):
+    """BEAGLE_MI355_NO_VIRTUAL is read at instance creation: the same evaluation with virtual cherries on and off
+    must give the same lnL to the last bit (the fused recomputation repeats the cherry op's own arithmetic)."""
+    import os
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_ALWAYS, RESCALE_DYNAMIC
+    wl = helpers.random_workload(60, 2000, 4, 4, seed=77)
+    vals = {}
+    for flag in ("0", "1"):
+        os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
+        try:
+            for scheme, delay in ((RESCALE_ALWAYS, False), (RESCALE_DYNAMIC, False)):
+                tl = BeagleTreeLikelihood(wl, rescaling=scheme, delay_rescaling=delay)
+                a = tl.getLogLikelihood()
+                tl.storeState(); tl.makeDirty()
+                b = tl.getLogLikelihood()
+                vals.setdefault((scheme, "first"), []).append(a)
+                vals.setdefault((scheme, "second"), []).append(b)
+                tl.close()
+        finally:
+            os.environ.pop("BEAGLE_MI355_NO_VIRTUAL", None)
+    for k, v in vals.items():
+        assert v[0] == v[1], (k, v)
