@@ -67,6 +67,38 @@ def decompose_reversible(q, pi):
     return EigenDecomposition(evec, ievc, evals / norm)
 
 
+def decompose_general(q, pi):
+    """Eigen system of a (possibly non-reversible) Q with a REAL spectrum, normalised like ``decompose_reversible``
+    (the reference uses this for asymmetric ``generalSubstitutionModel``s; complex spectra need EIGEN_COMPLEX, which
+    this engine does not offer)."""
+    pi = np.asarray(pi, dtype=np.float64)
+    norm = normalization(q, pi)
+    evals, evec = np.linalg.eig(np.asarray(q, dtype=np.float64))
+    if np.max(np.abs(np.imag(evals))) > 1e-12:
+        raise ValueError("complex eigenvalues: not supported")
+    evec = np.real(evec)
+    return EigenDecomposition(evec, np.linalg.inv(evec), np.real(evals) / norm)
+
+
+def asymmetric_q(rates_upper_then_lower, pi):
+    """S(S-1) relative rates: upper triangle row-major, then lower triangle (generalSubstitutionModel ordering);
+    Q_ij = r_ij * pi_j."""
+    pi = np.asarray(pi, dtype=np.float64)
+    s = pi.shape[0]
+    q = np.zeros((s, s))
+    k = 0
+    for i in range(s):
+        for j in range(i + 1, s):
+            q[i, j] = rates_upper_then_lower[k] * pi[j]
+            k += 1
+    for j in range(s):
+        for i in range(j + 1, s):
+            q[i, j] = rates_upper_then_lower[k] * pi[j]
+            k += 1
+    np.fill_diagonal(q, -q.sum(axis=1))
+    return q
+
+
 def gtr(rates_ac_ag_at_cg_ct_gt, pi):
     return decompose_reversible(reversible_q(rates_ac_ag_at_cg_ct_gt, pi), pi)
 

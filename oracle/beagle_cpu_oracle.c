@@ -233,6 +233,29 @@ int oracle_beagleGetTransitionMatrix(int h, int m, double* out) {
     memcpy(out, in->matrices[m], sizeof(double) * in->C * in->S * in->S); return BEAGLE_SUCCESS;
 }
 
+/* C_c = A_c * B_c per category — what src/dr/evomodel/treelikelihood/SubstitutionModelDelegate.java:382-405 asks the
+ * library for when a branch spans several epochs (result pinned by tests/TestXML/testEpochConvolutionOrder.xml) */
+int oracle_beagleConvolveTransitionMatrices(int h, const int* first, const int* second, const int* result, int count) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    const int S = in->S;
+    for (int u = 0; u < count; u++) {
+        if (first[u] < 0 || first[u] >= in->matrixCount || second[u] < 0 || second[u] >= in->matrixCount ||
+            result[u] < 0 || result[u] >= in->matrixCount || result[u] == first[u] || result[u] == second[u]) return BEAGLE_ERROR_OUT_OF_RANGE;
+        for (int c = 0; c < in->C; c++) {
+            const double* A = in->matrices[first[u]] + (size_t)c * S * S;
+            const double* B = in->matrices[second[u]] + (size_t)c * S * S;
+            double* R = in->matrices[result[u]] + (size_t)c * S * S;
+            for (int i = 0; i < S; i++)
+                for (int j = 0; j < S; j++) {
+                    double s = 0.0;
+                    for (int k = 0; k < S; k++) s += A[i * S + k] * B[k * S + j];
+                    R[i * S + j] = s;
+                }
+        }
+    }
+    return BEAGLE_SUCCESS;
+}
+
 /* BaseSubstitutionModel.java:206-245 (iexp = Uinv row scaled by exp(t*lambda), then U * iexp);
  * GeneralBeagleImpl#updateTransitionMatrices applies the category rate to t and clamps negatives. */
 int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, const int* d1, const int* d2,

@@ -114,6 +114,21 @@ def main():
         "decimals": 5,
     }
     json.dump(smoke, open(os.path.join(HERE, "jar_smoke.json"), "w"), indent=1)
+
+    epoch = {
+        "source": "tests/TestXML/testEpochConvolutionOrder.xml:9-19 (taxa, dates, states), :31-33 (tree (X:7,Y:3)), :46-49 (clock 0.1), "
+                  ":60-119 (four asymmetric 2-state models), :120-132 (epoch transition times 2, 4, 6), :179-193 (expected value)",
+        "taxa": ["X", "Y"], "tip_heights": [0.0, 4.0], "root_height": 7.0, "states": [0, 1],
+        "clock_rate": 0.1,
+        "root_freqs": [0.5, 0.5],
+        # generalSubstitutionModel with S(S-1) = 2 relative rates {0->1, 1->0}, frequencies 0.5/0.5, normalised
+        "epoch_rates": [[0.9, 0.1], [0.7, 0.3], [0.2, 0.8], [0.5, 0.5]],
+        "transition_times": [2.0, 4.0, 6.0],
+        "lnL": -2.17228, "tolerance": 1e-3,
+        "note": "branch matrix = product of the per-epoch matrices from the ROOT end of the branch to the tip end "
+                "(the test's name: the other order gives -1.74802)",
+    }
+    json.dump(epoch, open(os.path.join(HERE, "epoch_convolution.json"), "w"), indent=1)
     print("wrote primates.json, branch_specific.json, jar_smoke.json")
 
 

@@ -64,6 +64,13 @@ def test_golden_branch_specific(case, engine_lib):
     assert abs(lnl - c["lnL"]) < 5e-13, (lnl, c["lnL"])
 
 
+def test_golden_epoch_convolution(engine_lib):
+    """tests/TestXML/testEpochConvolutionOrder.xml:179-193 — pins convolveTransitionMatrices and its order."""
+    from test_oracle_golden import run_epoch_convolution
+    lnl, g = run_epoch_convolution(engine_lib)
+    assert abs(lnl - g["lnL"]) < 1e-5, lnl
+
+
 # ---- engine vs oracle on seeded workloads -------------------------------------------------------
 
 @pytest.mark.parametrize("S,C,T,P", [(4, 4, 33, 1000), (4, 1, 17, 257), (4, 2, 9, 64), (4, 8, 12, 300), (4, 10, 8, 130),

@@ -133,6 +133,57 @@ def test_branch_specific_full_precision(case, oracle_lib):
     assert abs(lnl - c["lnL"]) < 5e-13, (lnl, c["lnL"])
 
 
+def run_epoch_convolution(library):
+    """tests/TestXML/testEpochConvolutionOrder.xml: a branch that spans several epochs gets the PRODUCT of the per-epoch
+    transition matrices, root end first, built with convolveTransitionMatrices
+    (src/dr/evomodel/treelikelihood/SubstitutionModelDelegate.java:271-405)."""
+    g = helpers.golden("epoch_convolution.json")
+    pi = [0.5, 0.5]
+    b = bm.beagle.Beagle(2, 3, 2, 2, 1, 4, 24, 1, 0, library=library)
+    try:
+        for k, r in enumerate(g["epoch_rates"]):
+            e = substmodel.decompose_general(substmodel.asymmetric_q(r, pi), pi)
+            b.setEigenDecomposition(k, e.evec, e.ievc, e.evals)
+        b.setCategoryRates([1.0]); b.setCategoryWeights(0, [1.0]); b.setStateFrequencies(0, g["root_freqs"])
+        b.setPatternWeights([1.0])
+        bounds = [0.0] + g["transition_times"] + [float("inf")]
+        nxt = [4]                                   # next free matrix buffer (0..1 are the final branch matrices)
+
+        def branch_matrix(tip, final_idx):
+            lo, hi = g["tip_heights"][tip], g["root_height"]
+            pieces = []
+            for k in reversed(range(4)):            # root end (oldest epoch) first
+                a, z = max(lo, bounds[k]), min(hi, bounds[k + 1])
+                if z > a:
+                    pieces.append((k, (z - a) * g["clock_rate"]))
+            idx = []
+            for k, t in pieces:
+                b.updateTransitionMatrices(k, [nxt[0]], None, None, [t], 1)
+                idx.append(nxt[0]); nxt[0] += 1
+            acc = idx[0]
+            for j, m in enumerate(idx[1:]):
+                res = final_idx if j == len(idx) - 2 else nxt[0]
+                if res != final_idx:
+                    nxt[0] += 1
+                b.convolveTransitionMatrices([acc], [m], [res], 1)
+                acc = res
+            return acc
+
+        mx, my = branch_matrix(0, 0), branch_matrix(1, 1)
+        b.setTipStates(0, [g["states"][0]]); b.setTipStates(1, [g["states"][1]])
+        b.updatePartials([2, -1, -1, 0, mx, 1, my], 1, bm.beagle.NONE)
+        out = [0.0]
+        b.calculateRootLogLikelihoods([2], [0], [0], [bm.beagle.NONE], 1, out)
+        return out[0], g
+    finally:
+        b.finalize()
+
+
+def test_epoch_convolution_value(oracle_lib):
+    lnl, g = run_epoch_convolution(oracle_lib)
+    assert abs(lnl - g["lnL"]) < 1e-5, lnl          # the XML's tolerance is 1e-3; the value is known to 5 dp
+
+
 def test_gamma_rates_match_reference_discretisation():
     """GammaSiteRateModel.java:445-472 with alpha = 0.5, 4 categories: AS 91 quantiles, mean-normalised."""
     rates, props = siterates.GammaSiteRateModel(alpha=0.5, gamma_categories=4).category_rates_and_proportions()
