@@ -43,7 +43,7 @@ class ShardedTreeLikelihood:
     def _all_reduce(self, local_value=None):
         """Sum of the per-shard log-likelihoods over all ranks, as a Python float."""
         if self.device is not None:
-            if self.dist is not None and self.world > 1:
+            if self.dist is not None:
                 self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
             return float(self._buf.item())          # the only host<-device transfer of the evaluation
         if self.dist is not None and self.world > 1:

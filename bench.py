@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--patterns", type=int, default=0, help="development: keep only the first N patterns (size of one shard of an N-GPU job)")
+    ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="patterns in the CPU-baseline sample")
     args = ap.parse_args()
@@ -76,8 +78,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # --force-sharded without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29555", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     t_gen = time.time()
@@ -94,6 +99,8 @@ def main():
     if cache and world > 1 and rank == 0:
         dist.barrier()
     t_gen = time.time() - t_gen
+    if args.patterns:
+        wl = wl.shard(0, min(args.patterns, wl.pattern_count))
 
     # resource numbering: 0 = CPU (absent), 1..G = GPUs as THIS process sees them
     res = (local_rank + 1,)
@@ -103,7 +110,7 @@ def main():
     # switch on: fewer bytes, an easier benchmark.)
     from beast_mcmc_amd.treelikelihood import RESCALE_DYNAMIC
     kw = dict(resource_list=res, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
-    if world > 1:
+    if sharded:
         tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, device=device, **kw)
         local = tl.local
     else:
@@ -156,7 +163,7 @@ def main():
 
     out = None
     if rank == 0:
-        shard = wl if world == 1 else wl.shard(*tl.range)
+        shard = wl.shard(*tl.range) if sharded else wl
         pb = prune_bytes_per_eval(shard)                      # this rank's pruning bytes per evaluation
         launches_per_eval = launches / max(1, args.steps)
         kernel_s_per_eval = kernel_ms * 1e-3 / max(1, args.steps)
