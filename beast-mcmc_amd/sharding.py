@@ -10,7 +10,13 @@ tensors, which is how the N>1 path is tested without GPUs.
 
 Tree, eigen system, matrices and op lists are replicated (KB-scale); nothing else crosses GPUs.  The rescaling
 retry decision is taken on the GLOBAL value, so every rank takes the same branch.
+
+Stream discipline on the GPU: the engine, the collective and the 8-byte read-back all run on ONE dedicated torch
+stream (never the legacy default stream, whose handle is 0 and which the engine would read as "use your own"):
+kernels -> device-side sum -> all_reduce -> D2H are ordered by the stream itself, with no event or host sync in between.
 """
+import contextlib
+
 import numpy as np
 
 from .inputs import patterns as _patterns
@@ -26,26 +32,36 @@ class ShardedTreeLikelihood:
         self.local = BeagleTreeLikelihood(workload.shard(start, stop), library=library, **kw)
         self.device = device
         self._buf = None
+        self._stream = None
         if device is not None:
             import torch
             self._torch = torch
-            self._buf = torch.zeros(1, dtype=torch.float64, device=device)
-            # the engine enqueues on torch's current stream so its kernels are ordered with the collective
+            self._stream = torch.cuda.Stream(device=device)
+            assert self._stream.cuda_stream != 0
+            with torch.cuda.stream(self._stream):
+                self._buf = torch.zeros(1, dtype=torch.float64, device=device)
+                self._host = torch.zeros(1, dtype=torch.float64).pin_memory()
             from . import beagle as _b
             raw = _b.Beagle.__new__(_b.Beagle)
             raw.lib, raw._f, raw.instance = self.local.engine, self.local.engine.fn, self.local.instance
-            raw.setStream(torch.cuda.current_stream(device).cuda_stream)
+            raw.setStream(self._stream.cuda_stream)
         elif dist is not None:
             import torch
             self._torch = torch
             self._buf = torch.zeros(1, dtype=torch.float64)
 
+    def stream_ctx(self):
+        return self._torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
+
     def _all_reduce(self, local_value=None):
         """Sum of the per-shard log-likelihoods over all ranks, as a Python float."""
         if self.device is not None:
-            if self.dist is not None:
-                self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
-            return float(self._buf.item())          # the only host<-device transfer of the evaluation
+            with self.stream_ctx():
+                if self.dist is not None:
+                    self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
+                self._host.copy_(self._buf, non_blocking=True)   # the only host<-device transfer of the evaluation
+            self._stream.synchronize()
+            return float(self._host[0])
         if self.dist is not None and self.world > 1:
             self._buf[0] = local_value
             self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
