@@ -266,32 +266,45 @@ void clearVirtual(Instance* in, int X) {
     v.on = false;
 }
 
-int materializeVirtual(Instance* in, int X) {
-    Virt& v = in->virt[X];
-    if (!v.on) return 0;
-    int rc = ensurePartials(in, X); if (rc) return rc;
-    OpDesc d;
-    memset(&d, 0, sizeof(d));
-    d.dest = in->partials[X];
-    d.child1 = in->tipStates[v.tipA]; d.child2 = in->tipStates[v.tipB];
-    d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
-    d.mat1 = in->matrixCount + 2 * X; d.mat2 = d.mat1 + 1;
-    d.scaleRead = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;    // write-mode cherries stored their factor there too
-    d.pStart = 0; d.pEnd = in->P;
-    void* dOp = nullptr;
-    rc = uploadTransient(in, &d, sizeof(d), &dOp); if (rc) return rc;
-    mi355::launchPruneLevel(in->stream, (const OpDesc*)dOp, 1, in->matrices, in->P, in->S, in->C, in->P);
-    clearVirtual(in, X);
+// Give every buffer of `xs` its real partials: ONE descriptor upload and ONE launch for the whole list.
+int materializeList(Instance* in, const std::vector<int>& xs) {
+    std::vector<OpDesc> descs;
+    descs.reserve(xs.size());
+    for (int X : xs) {
+        Virt& v = in->virt[X];
+        if (!v.on) continue;
+        int rc = ensurePartials(in, X); if (rc) return rc;
+        OpDesc d;
+        memset(&d, 0, sizeof(d));
+        d.dest = in->partials[X];
+        d.child1 = in->tipStates[v.tipA]; d.child2 = in->tipStates[v.tipB];
+        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
+        d.mat1 = in->matrixCount + 2 * X; d.mat2 = d.mat1 + 1;
+        d.scaleRead = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;    // write-mode cherries stored their factor there too
+        d.pStart = 0; d.pEnd = in->P;
+        descs.push_back(d);
+        clearVirtual(in, X);
+    }
+    const size_t maxChunk = (RING_BYTES / 4) / sizeof(OpDesc);
+    for (size_t b = 0; b < descs.size(); b += maxChunk) {
+        const size_t n = std::min(maxChunk, descs.size() - b);
+        void* dOps = nullptr;
+        int rc = uploadTransient(in, &descs[b], n * sizeof(OpDesc), &dOps); if (rc) return rc;
+        mi355::launchPruneLevel(in->stream, (const OpDesc*)dOps, (int)n, in->matrices, in->P, in->S, in->C, in->P);
+    }
     return 0;
 }
-
+int materializeVirtual(Instance* in, int X) {
+    if (!in->virt[X].on) return 0;
+    return materializeList(in, std::vector<int>(1, X));
+}
 int materializeScaleUsers(Instance* in, int scaleIdx) {
-    while (!in->scaleUsers[scaleIdx].empty()) { int rc = materializeVirtual(in, in->scaleUsers[scaleIdx].back()); if (rc) return rc; }
-    return 0;
+    if (in->scaleUsers[scaleIdx].empty()) return 0;
+    return materializeList(in, std::vector<int>(in->scaleUsers[scaleIdx]));
 }
 int materializeTipUsers(Instance* in, int tip) {
-    while (!in->tipUsers[tip].empty()) { int rc = materializeVirtual(in, in->tipUsers[tip].back()); if (rc) return rc; }
-    return 0;
+    if (in->tipUsers[tip].empty()) return 0;
+    return materializeList(in, std::vector<int>(in->tipUsers[tip]));
 }
 
 // Enqueue an op list.  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
@@ -309,11 +322,15 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     const bool canVirtual = in->virtualCherries && parts == 1 && tuple == BEAGLE_OP_COUNT;
     // a scale buffer about to be rewritten may still define virtual cherries of earlier evaluations: give those
     // their real partials first (enqueued ahead of everything this call launches)
-    if (canVirtual)
+    if (canVirtual) {
+        std::vector<int> need;
         for (int k = 0; k < count; k++) {
             const int wS = ops[(size_t)k * tuple + 1];
-            if (wS != BEAGLE_OP_NONE && !badIndex(wS, in->scaleCount)) { int rc = materializeScaleUsers(in, wS); if (rc) return rc; }
+            if (wS != BEAGLE_OP_NONE && !badIndex(wS, in->scaleCount))
+                need.insert(need.end(), in->scaleUsers[wS].begin(), in->scaleUsers[wS].end());
         }
+        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    }
     in->stamp++;
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {

@@ -141,6 +141,13 @@ def main():
     raw.lib, raw._f, raw.instance = local.engine, local.engine.fn, local.instance
     raw.kernelTimer(True)
 
+    # The harness is Python: a generation-2 garbage collection of a process that has torch loaded takes ~40 ms
+    # (measured: tools/shard_overhead.py per-step trace) — ten evaluations' worth — and is triggered by the ctypes
+    # argument objects of the harness itself, not by anything on the measured path.  Collect now, pause the collector
+    # for the timed region (no cycles are created in it), restore afterwards.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     lnl = 0.0
@@ -148,6 +155,7 @@ def main():
         lnl = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     kernel_ms, launches = raw.kernelTimer(False)
     if dist is not None:
