@@ -36,7 +36,20 @@ namespace {
 constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
 
-struct Virt { bool on = false; int tipA = -1, tipB = -1, scaleIdx = -1; };   // see "virtual cherries" below
+// Definition of a virtual partials buffer (see "virtual subtrees" below): one step per internal node of its subtree.
+struct VStepHost {
+    int type;               // mi355::VS_*
+    int tipA, tipB;         // tip buffer indices (CHERRY: both, EXTEND: tipB)
+    int scaleIdx;           // this node's scale buffer, or -1
+    int originA, originB;   // where the two matrices were copied FROM (stable for the call that created the node)
+};
+struct Virt {
+    bool on = false;
+    bool chainOnly = true;  // no JOIN step: the program may also run on accumulator B
+    int nSteps = 0;
+    int stamp = -1;         // Instance::stamp of the creating updatePartials call
+    VStepHost steps[mi355::VIRT_MAX_STEPS];
+};
 
 struct Instance {
     int device = 0;
@@ -249,21 +262,137 @@ Resources* resources() {
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 
-// ---- virtual cherries ---------------------------------------------------------------------------------------
-// A partials buffer is "virtual" when its content is defined as  (M_A[:, sA] * M_B[:, sB]) / scale  for two compact
-// tips A, B, private snapshots of the two branch matrices (stored behind the regular matrices at index
-// matrixCount + 2*buffer [+1]) and an optional per-pattern scale factor — and has NOT been written to HBM.
-// Parents fuse the recomputation (kernels.hip CH_CHERRY).  Anything that would change one of the defining inputs
-// (tip states, the scale buffer) or that needs the real data (getPartials, root, non-fusing readers) first calls
-// materializeVirtual, which runs the ordinary tip-tip op from the snapshot; the result is bitwise what the op would
-// have stored in the first place.
+// ---- virtual subtrees ---------------------------------------------------------------------------------------
+// A partials buffer is "virtual" when its content is DEFINED instead of stored: a straight-line program with one step
+// per internal node of a small all-compact-tip subtree (kernels.h VStep; at most VIRT_MAX_STEPS nodes, evaluable with
+// two accumulators), the tip buffers it reads, private snapshots of every branch matrix in the subtree (kept behind
+// the caller's matrices: slot(X, step, 0/1)) and each node's scale buffer.  Nothing is written to HBM for such a
+// buffer; parents recompute it in registers (kernels_nuc4.hip CH_VIRTUAL), bitwise as the ordinary ops would have.
+// The definition is self-contained: it never refers to other partials buffers or to the caller's matrix buffers, so
+// buffer flips and matrix updates cannot invalidate it.  What CAN change a defining input — new tip states, a write to
+// one of its scale buffers — and everything that needs the real data — getPartials, use as root, a reader that cannot
+// fuse — first calls materializeList, which runs the defining op from the snapshot.
+inline int snapSlot(const Instance* in, int X, int step, int which) {
+    return in->matrixCount + X * 2 * mi355::VIRT_MAX_STEPS + 2 * step + which;
+}
+
 void clearVirtual(Instance* in, int X) {
     Virt& v = in->virt[X];
     if (!v.on) return;
     auto drop = [X](std::vector<int>& u) { u.erase(std::remove(u.begin(), u.end(), X), u.end()); };
-    drop(in->tipUsers[v.tipA]); drop(in->tipUsers[v.tipB]);
-    if (v.scaleIdx >= 0) drop(in->scaleUsers[v.scaleIdx]);
+    for (int s = 0; s < v.nSteps; s++) {
+        const VStepHost& h = v.steps[s];
+        if (h.tipA >= 0) drop(in->tipUsers[h.tipA]);
+        if (h.tipB >= 0) drop(in->tipUsers[h.tipB]);
+        if (h.scaleIdx >= 0) drop(in->scaleUsers[h.scaleIdx]);
+    }
     v.on = false;
+}
+
+void registerVirtual(Instance* in, int X) {
+    const Virt& v = in->virt[X];
+    auto add = [X](std::vector<int>& u) { if (std::find(u.begin(), u.end(), X) == u.end()) u.push_back(X); };
+    for (int s = 0; s < v.nSteps; s++) {
+        const VStepHost& h = v.steps[s];
+        if (h.tipA >= 0) add(in->tipUsers[h.tipA]);
+        if (h.tipB >= 0) add(in->tipUsers[h.tipB]);
+        if (h.scaleIdx >= 0) add(in->scaleUsers[h.scaleIdx]);
+    }
+}
+
+// Device form of steps [first, last) of X's program; `toA` renames a B-chain to accumulator A (used stand-alone).
+void emitProgram(const Instance* in, int X, int first, int last, bool toA, mi355::VStep* out) {
+    const Virt& v = in->virt[X];
+    int n = 0;
+    for (int s = first; s < last; s++, n++) {
+        const VStepHost& h = v.steps[s];
+        mi355::VStep& d = out[n];
+        d.type = h.type;
+        if (toA && d.type == mi355::VS_CHERRY_B) d.type = mi355::VS_CHERRY_A;
+        if (toA && d.type == mi355::VS_EXTEND_B) d.type = mi355::VS_EXTEND_A;
+        d.tipA = h.tipA >= 0 ? in->tipStates[h.tipA] : nullptr;
+        d.tipB = h.tipB >= 0 ? in->tipStates[h.tipB] : nullptr;
+        d.scale = h.scaleIdx >= 0 ? in->scale[h.scaleIdx] : nullptr;
+        d.matA = snapSlot(in, X, s, 0); d.matB = snapSlot(in, X, s, 1);
+        d.pad = 0;
+    }
+    for (; n < mi355::VIRT_MAX_STEPS; n++) { memset(&out[n], 0, sizeof(mi355::VStep)); out[n].type = mi355::VS_END; }
+}
+
+// Try to define buffer X = node(child1 over matrix m1, child2 over matrix m2, scale).  Children are compact tips or
+// virtual buffers.  Appends (source, destination) matrix-copy pairs for k_snapshot.  false: not expressible.
+bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
+    Virt nv;
+    nv.on = true; nv.stamp = in->stamp; nv.nSteps = 0; nv.chainOnly = true;
+    std::vector<int> pairs;
+    auto append = [&](int srcBuf, bool toB) -> bool {
+        const Virt& src = in->virt[srcBuf];
+        for (int s = 0; s < src.nSteps; s++) {
+            if (nv.nSteps >= mi355::VIRT_MAX_STEPS) return false;
+            VStepHost h = src.steps[s];
+            if (toB) h.type = h.type == mi355::VS_CHERRY_A ? mi355::VS_CHERRY_B : mi355::VS_EXTEND_B;
+            // a child defined in THIS call has its slots written by the same k_snapshot launch: copy from its origins
+            const int fromA = src.stamp == in->stamp ? h.originA : snapSlot(in, srcBuf, s, 0);
+            const int fromB = src.stamp == in->stamp ? h.originB : snapSlot(in, srcBuf, s, 1);
+            h.originA = fromA; h.originB = fromB;
+            pairs.push_back(fromA); pairs.push_back(snapSlot(in, X, nv.nSteps, 0));
+            pairs.push_back(fromB); pairs.push_back(snapSlot(in, X, nv.nSteps, 1));
+            nv.steps[nv.nSteps++] = h;
+        }
+        return true;
+    };
+    VStepHost last;
+    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1;
+    if (tip1 && tip2) {
+        last.type = mi355::VS_CHERRY_A; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
+    } else if (tip1 != tip2) {
+        const int v = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
+        if (!in->virt[v].on || !append(v, false)) return false;
+        nv.chainOnly = in->virt[v].chainOnly;
+        last.type = mi355::VS_EXTEND_A; last.tipB = t; last.originA = mv; last.originB = mt;
+    } else {
+        int u = c1, v = c2, mu = m1, mv = m2;
+        if (!in->virt[u].on || !in->virt[v].on) return false;
+        if (!in->virt[v].chainOnly) { std::swap(u, v); std::swap(mu, mv); }
+        if (!in->virt[v].chainOnly) return false;                 // would need a third accumulator
+        if (!append(u, false) || !append(v, true)) return false;
+        nv.chainOnly = false;
+        last.type = mi355::VS_JOIN; last.originA = mu; last.originB = mv;
+    }
+    if (nv.nSteps >= mi355::VIRT_MAX_STEPS) return false;
+    pairs.push_back(last.originA); pairs.push_back(snapSlot(in, X, nv.nSteps, 0));
+    pairs.push_back(last.originB); pairs.push_back(snapSlot(in, X, nv.nSteps, 1));
+    nv.steps[nv.nSteps++] = last;
+    in->virt[X] = nv;
+    registerVirtual(in, X);
+    snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
+    return true;
+}
+
+// The ordinary op that computes X's real partials from its definition (children: tips and/or sub-programs).
+void materializeDesc(const Instance* in, int X, OpDesc& d) {
+    const Virt& v = in->virt[X];
+    const int n = v.nSteps;
+    const VStepHost& last = v.steps[n - 1];
+    memset(&d, 0, sizeof(d));
+    d.dest = in->partials[X];
+    d.mat1 = snapSlot(in, X, n - 1, 0); d.mat2 = snapSlot(in, X, n - 1, 1);
+    d.scaleRead = last.scaleIdx >= 0 ? in->scale[last.scaleIdx] : nullptr;   // write-mode nodes stored their factor there too
+    d.pStart = 0; d.pEnd = in->P;
+    if (last.type == mi355::VS_CHERRY_A) {
+        d.child1 = in->tipStates[last.tipA]; d.child2 = in->tipStates[last.tipB];
+        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
+    } else if (last.type == mi355::VS_EXTEND_A) {
+        emitProgram(in, X, 0, n - 1, false, d.prog[0]);
+        d.child2 = in->tipStates[last.tipB];
+        d.kind = mi355::KIND_VIRT1 | mi355::KIND_STATES2;
+    } else {   // JOIN: the A part is the leading steps, the B chain follows
+        int split = 0;
+        while (split < n - 1 && v.steps[split].type != mi355::VS_CHERRY_B && v.steps[split].type != mi355::VS_EXTEND_B) split++;
+        emitProgram(in, X, 0, split, false, d.prog[0]);
+        emitProgram(in, X, split, n - 1, true, d.prog[1]);
+        d.kind = mi355::KIND_VIRT1 | mi355::KIND_VIRT2;
+    }
 }
 
 // Give every buffer of `xs` its real partials: ONE descriptor upload and ONE launch for the whole list.
@@ -271,17 +400,10 @@ int materializeList(Instance* in, const std::vector<int>& xs) {
     std::vector<OpDesc> descs;
     descs.reserve(xs.size());
     for (int X : xs) {
-        Virt& v = in->virt[X];
-        if (!v.on) continue;
+        if (!in->virt[X].on) continue;
         int rc = ensurePartials(in, X); if (rc) return rc;
         OpDesc d;
-        memset(&d, 0, sizeof(d));
-        d.dest = in->partials[X];
-        d.child1 = in->tipStates[v.tipA]; d.child2 = in->tipStates[v.tipB];
-        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
-        d.mat1 = in->matrixCount + 2 * X; d.mat2 = d.mat1 + 1;
-        d.scaleRead = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;    // write-mode cherries stored their factor there too
-        d.pStart = 0; d.pEnd = in->P;
+        materializeDesc(in, X, d);
         descs.push_back(d);
         clearVirtual(in, X);
     }
@@ -347,41 +469,36 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         memset(&d, 0, sizeof(d));
         const bool tip1 = in->tipStates[c1] && c1 < in->tipCount, tip2 = in->tipStates[c2] && c2 < in->tipCount;
         const size_t kdest = (size_t)dest * parts + part;
-        // Virtual cherry: both children are compact tips -> the node's partials are a pure function of two state bytes,
-        // two (snapshotted) matrices and a scale factor; fusing parents recompute them, so they are not written to HBM
-        // at all unless something else asks for them (materializeVirtual).  Not when an earlier op of this call read
-        // the previous virtual content of the same buffer (its snapshot slot must stay intact until that op has run).
-        const bool makeVirtual = canVirtual && tip1 && tip2 && c1 != dest && c2 != dest &&
-                                 !(in->rStamp[kdest] == in->stamp && in->virt[dest].on);
-        if (in->virt[dest].on) clearVirtual(in, dest);          // whatever it was, this op replaces it
+        // Virtual node: every child is a compact tip or itself virtual, and the subtree fits a VIRT_MAX_STEPS program ->
+        // nothing is written to HBM for it (see "virtual subtrees").  Not when an earlier op of this call read the
+        // previous virtual content of the same buffer: its snapshot slots must stay intact until that op has run.
+        const bool v1 = !tip1 && in->virt[c1].on, v2 = !tip2 && in->virt[c2].on;
+        const int ownScale = wS != BEAGLE_OP_NONE ? wS : rS;
+        if (wS != BEAGLE_OP_NONE || rS != BEAGLE_OP_NONE) { int rcs = ensureScale(in, ownScale); if (rcs) return rcs; }
+        const bool warOnVirtual = in->rStamp[kdest] == in->stamp && in->virt[dest].on;
+        // children first (their definitions must be read before `dest` is redefined when dest aliases nothing here)
+        d.kind = 0;
+        if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
+        else if (v1) { d.kind |= mi355::KIND_VIRT1; emitProgram(in, c1, 0, in->virt[c1].nSteps, false, d.prog[0]); }
+        else if (in->partials[c1]) d.child1 = in->partials[c1];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
+        else if (v2) { d.kind |= mi355::KIND_VIRT2; emitProgram(in, c2, 0, in->virt[c2].nSteps, false, d.prog[1]); }
+        else if (in->partials[c2]) d.child2 = in->partials[c2];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        bool makeVirtual = false;
+        if (canVirtual && (tip1 || v1) && (tip2 || v2) && c1 != dest && c2 != dest && !warOnVirtual) {
+            Virt saved = in->virt[dest];
+            if (saved.on) clearVirtual(in, dest);
+            makeVirtual = buildVirtual(in, dest, c1, tip1, m1, c2, tip2, m2, ownScale, snapPairs);
+            if (!makeVirtual && saved.on) { in->virt[dest] = saved; registerVirtual(in, dest); }
+        }
+        if (!makeVirtual && in->virt[dest].on) clearVirtual(in, dest);      // whatever it was, this op replaces it
         int rc = 0;
         if (!makeVirtual) { rc = ensurePartials(in, dest); if (rc) return rc; }
         d.dest = in->partials[dest];
-        d.kind = 0;
-        if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
-        else if (in->virt[c1].on || in->partials[c1]) d.child1 = in->partials[c1];
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
-        else if (in->virt[c2].on || in->partials[c2]) d.child2 = in->partials[c2];
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        // children that are virtual cherries (of this or an earlier call): recompute from the snapshot
-        for (int ci = 0; ci < 2; ci++) {
-            const int c = ci ? c2 : c1;
-            if ((ci ? tip2 : tip1) || !in->virt[c].on) continue;
-            const Virt& v = in->virt[c];
-            d.kind |= ci ? mi355::KIND_CHERRY2 : mi355::KIND_CHERRY1;
-            d.cherry[ci].statesA = in->tipStates[v.tipA]; d.cherry[ci].statesB = in->tipStates[v.tipB];
-            d.cherry[ci].scale = v.scaleIdx >= 0 ? in->scale[v.scaleIdx] : nullptr;
-            d.cherry[ci].matA = in->matrixCount + 2 * c; d.cherry[ci].matB = in->matrixCount + 2 * c + 1;
-        }
         d.mat1 = m1; d.mat2 = m2;
         if (makeVirtual) {
-            Virt& v = in->virt[dest];
-            v.on = true; v.tipA = c1; v.tipB = c2; v.scaleIdx = wS != BEAGLE_OP_NONE ? wS : rS;
-            in->tipUsers[c1].push_back(dest); in->tipUsers[c2].push_back(dest);
-            if (v.scaleIdx >= 0) in->scaleUsers[v.scaleIdx].push_back(dest);
-            snapPairs.push_back(m1); snapPairs.push_back(in->matrixCount + 2 * dest);
-            snapPairs.push_back(m2); snapPairs.push_back(in->matrixCount + 2 * dest + 1);
             if (wS != BEAGLE_OP_NONE) d.kind |= mi355::KIND_NO_STORE;   // still has to produce its scale factors
             else skip[k] = 1;
         }
@@ -404,21 +521,6 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         if (in->wStamp[kc2] == in->stamp) { lvl = std::max(lvl, in->wLevel[kc2] + 1); predList.push_back(in->wOp[kc2]); }
         if (in->wStamp[kd] == in->stamp) { lvl = std::max(lvl, in->wLevel[kd] + 1); predList.push_back(in->wOp[kd]); }
         if (in->rStamp[kd] == in->stamp) { lvl = std::max(lvl, in->rLevel[kd] + 1); warSeen = true; }
-        // cherry fusion (4-state kernel): a child that an earlier op OF THIS CALL computed from two compact tips is
-        // recomputed from the tip states instead of being re-read (kernels.hip, CH_CHERRY)
-        if (in->S == 4 && in->C <= 8 && in->fuseCherries) {
-            const size_t keys[2] = {kc1, kc2};
-            for (int ci = 0; ci < 2; ci++) {
-                if ((d.kind & (ci ? (mi355::KIND_STATES2 | mi355::KIND_CHERRY2) : (mi355::KIND_STATES1 | mi355::KIND_CHERRY1))) ||
-                    in->wStamp[keys[ci]] != in->stamp) continue;
-                const OpDesc& w = descs[in->wOp[keys[ci]]];
-                if ((w.kind & 3) != 3 || w.pStart != d.pStart || w.pEnd != d.pEnd) continue;
-                d.kind |= ci ? mi355::KIND_CHERRY2 : mi355::KIND_CHERRY1;
-                d.cherry[ci].statesA = (const uint8_t*)w.child1; d.cherry[ci].statesB = (const uint8_t*)w.child2;
-                d.cherry[ci].scale = w.scaleWrite ? w.scaleWrite : w.scaleRead;
-                d.cherry[ci].matA = w.mat1; d.cherry[ci].matB = w.mat2;
-            }
-        }
         level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
         in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl; in->wOp[kd] = k;
         if (in->rStamp[kc1] != in->stamp || in->rLevel[kc1] < lvl) { in->rStamp[kc1] = in->stamp; in->rLevel[kc1] = lvl; }
@@ -637,7 +739,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->tipUsers.assign(partialsBufferCount, std::vector<int>());
     in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());
     // matrix storage: the caller's buffers, then two private snapshot slots per partials buffer (virtual cherries)
-    const size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)partialsBufferCount : 0);
+    const size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)mi355::VIRT_MAX_STEPS * partialsBufferCount : 0);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);

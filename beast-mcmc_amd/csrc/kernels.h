@@ -9,32 +9,45 @@ namespace mi355 {
 // One pruning operation as the kernels see it: pointers already resolved on the host from the
 // reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
 // [, partition, cumulativeScale]} (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1266-1299).
-// A child that is itself a tip-tip node ("cherry") computed earlier in the same call: the 4-state kernel
-// recomputes it from the two grand-child state arrays instead of re-reading its partials from HBM.
-struct CherryDesc {
-    const uint8_t* statesA;     // compact states of the cherry's two tips
-    const uint8_t* statesB;
-    const double*  scale;       // the cherry's per-pattern raw scale factors (written or read by its own op), or nullptr
-    int            matA, matB;  // the cherry's two branch matrices
+//
+// VIRTUAL CHILDREN (4-state kernel).  A child whose whole subtree consists of a few compact tips is not read from HBM:
+// the kernel recomputes its partials in registers from the tip state bytes, following a tiny straight-line program
+// over two accumulators A and B (kernels.hip).  One step = one internal node of the child's subtree:
+//   VS_CHERRY_A / _B   acc = col(matA)[tipA] * col(matB)[tipB] * (1/scale)                         node with two tips
+//   VS_EXTEND_A / _B   acc = (matA . acc) * col(matB)[tipB] * (1/scale)                            node with (subtree, tip)
+//   VS_JOIN            A   = (matA . A) * (matB . B) * (1/scale)                                   node with two subtrees
+// Every step repeats exactly the arithmetic the node's own op performs, so the values are bitwise those the op would
+// have stored.  matA/matB index private SNAPSHOTS of the branch matrices (engine.cpp, "virtual subtrees").
+constexpr int VIRT_MAX_STEPS = 4;
+enum { VS_END = 0, VS_CHERRY_A = 1, VS_CHERRY_B = 2, VS_EXTEND_A = 3, VS_EXTEND_B = 4, VS_JOIN = 5 };
+
+struct VStep {
+    const uint8_t* tipA;        // CHERRY: first tip's states; EXTEND/JOIN: unused
+    const uint8_t* tipB;        // CHERRY: second tip; EXTEND: the tip
+    const double*  scale;       // this node's per-pattern raw scale factors, or nullptr
+    int            matA, matB;  // matrix indices (snapshots)
+    int            type;        // VS_*
+    int            pad;
 };
 
 struct OpDesc {
     double*        dest;        // [C][P][S] partials, written on [pStart, pEnd)
-    const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0)
+    const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0); unused for a virtual child
     const void*    child2;      // same (kind bit 1)
     double*        scaleWrite;  // per-pattern raw scale factors to WRITE (rescale now), or nullptr
     const double*  scaleRead;   // per-pattern raw scale factors to READ (divide by existing), or nullptr
-    int            mat1, mat2;  // transition-matrix buffer indices
+    int            mat1, mat2;  // transition-matrix buffer indices of the two child branches
     int            kind;        // KIND_* bits
     int            pStart, pEnd;// pattern range of this op (whole buffer unless a ...ByPartition call)
     int            pad;
-    CherryDesc     cherry[2];   // valid when KIND_CHERRY1 / KIND_CHERRY2 is set (child pointer is still the partials)
+    VStep          prog[2][VIRT_MAX_STEPS];   // valid when KIND_VIRT1 / KIND_VIRT2 is set; terminated by VS_END if shorter
 };
-static_assert(sizeof(OpDesc) == 128, "OpDesc must stay 128 bytes");
+static_assert(sizeof(VStep) == 40, "VStep layout");
+static_assert(sizeof(OpDesc) == 64 + 2 * VIRT_MAX_STEPS * 40, "OpDesc layout");
 
-// KIND_NO_STORE: compute (and write the scale factors) but do not store the partials — used for "virtual" cherries
-// whose partials are never materialised unless somebody other than a fusing parent asks for them (engine.cpp).
-enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_CHERRY1 = 4, KIND_CHERRY2 = 8, KIND_NO_STORE = 16 };
+// KIND_NO_STORE: compute (and write the scale factors) but do not store the partials — the op of a virtual node in
+// write-mode rescaling.
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_VIRT1 = 4, KIND_VIRT2 = 8, KIND_NO_STORE = 16 };
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);
@@ -75,6 +88,8 @@ void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, 
 void launchReplicateCategories(hipStream_t stream, const double* src, double* dst, int P, int S, int C);
 
 int  pruneBlocksForRange(int S, int range);
+// 4-state kernel (kernels_nuc4.hip); false when C is outside its template range
+bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int C, int maxRange);
 
 // ---- T32 layout (20-/61-state MFMA path, kernels_mfma.hip): partials[c][tile][state][32 patterns] --------------
 // One dependency level on the fp64 matrix cores; anyScaleWrite adds the second (max + divide) pass.

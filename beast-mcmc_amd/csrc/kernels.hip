@@ -81,181 +81,6 @@ void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFi
                        matrices, dFirst, dSecond, dResult, S, C);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 4-state pruning: one thread = one pattern, all C categories (so the per-pattern rescale max never
-// leaves the thread's registers).  The transition matrices of both child branches for all categories are
-// staged in LDS once per workgroup and read by every lane at a wave-uniform address (LDS broadcast);
-// compact-state children read a [state][i] column table whose extra row (state == 4) is all ones.
-//
-// A child can be one of three kinds (block-uniform):
-//   PARTIALS  read 32 B per category from the child's buffer, multiply by its branch matrix
-//   STATES    compact tip: a column of the branch matrix
-//   CHERRY    the child is a tip-tip node computed EARLIER IN THIS CALL: instead of re-reading its 128 B per
-//             pattern from HBM, recompute it from the two grand-child state bytes with exactly the arithmetic
-//             the cherry's own op used (so the values are bitwise those stored in its buffer), then multiply by
-//             the branch matrix.  Saves one full partials read for every cherry (~1/3 of the internal nodes).
-// Child loads are issued BEFORE the matrix staging barrier so HBM latency overlaps the staging.
-// ------------------------------------------------------------------------------------------------
-constexpr int NUC_BLOCK = 256;
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-struct __attribute__((aligned(32))) d4 { double x, y, z, w; };
-
-template <bool NT> __device__ __forceinline__ v4d ldv4(const double* p) {
-    return NT ? __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p)) : *reinterpret_cast<const v4d*>(p);
-}
-template <bool NT> __device__ __forceinline__ void stv4(double* p, v4d v) {
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4d*>(p)); else *reinterpret_cast<v4d*>(p) = v;
-}
-
-template <int C>
-struct NucLds {
-    double row[2][C][16];      // [child][c][i*4 + j]           branch matrices of the two children
-    double col[6][C][5][4];    // [m][c][state][i]; state 4 = unknown -> 1.0
-                               // m = 0,1: the children's branch matrices; 2,3 / 4,5: grand-child branches of cherry child 1 / 2
-};
-
-enum { CH_PARTIALS = 0, CH_STATES = 1, CH_CHERRY = 2 };
-
-template <int C, int NT>
-struct NucChildRegs {
-    v4d v[C];       // PARTIALS: the child's partials
-    int sa, sb;     // STATES: sa; CHERRY: both grand-child states
-    double inv;     // CHERRY: 1 / the cherry's scale factor (1 when unscaled)
-};
-
-template <int C, int NT>
-__device__ __forceinline__ void nucIssue(NucChildRegs<C, NT>& r, int kind, const void* __restrict__ src,
-                                         const CherryDesc& ch, int P, int p) {
-    r.sa = 4; r.sb = 4; r.inv = 1.0;
-    if (kind == CH_PARTIALS) {
-        const double* x = reinterpret_cast<const double*>(src);
-#pragma unroll
-        for (int c = 0; c < C; c++) r.v[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
-    } else if (kind == CH_STATES) {
-        r.sa = reinterpret_cast<const uint8_t*>(src)[p];
-    } else {
-        r.sa = ch.statesA[p];
-        r.sb = ch.statesB[p];
-        if (ch.scale) r.inv = 1.0 / ch.scale[p];
-    }
-}
-
-template <int C, int NT>
-__device__ __forceinline__ void nucApply(const NucLds<C>& L, const NucChildRegs<C, NT>& r, int kind, int child,
-                                         double (&f)[C][4]) {
-    if (kind == CH_STATES) {
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) f[c][i] = L.col[child][c][r.sa][i];
-        return;
-    }
-    v4d x[C];
-    if (kind == CH_PARTIALS) {
-#pragma unroll
-        for (int c = 0; c < C; c++) x[c] = r.v[c];
-    } else {
-        const int ma = 2 + 2 * child, mb = 3 + 2 * child;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            // same operation order as the cherry's own op: (colA * colB) * inv
-            x[c].x = (L.col[ma][c][r.sa][0] * L.col[mb][c][r.sb][0]) * r.inv;
-            x[c].y = (L.col[ma][c][r.sa][1] * L.col[mb][c][r.sb][1]) * r.inv;
-            x[c].z = (L.col[ma][c][r.sa][2] * L.col[mb][c][r.sb][2]) * r.inv;
-            x[c].w = (L.col[ma][c][r.sa][3] * L.col[mb][c][r.sb][3]) * r.inv;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double* m = &L.row[child][c][i * 4];
-            f[c][i] = m[0] * x[c].x + m[1] * x[c].y + m[2] * x[c].z + m[3] * x[c].w;
-        }
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void nucStage(NucLds<C>& L, int m, const double* __restrict__ M, bool rows, int rowSlot) {
-    // M = [C][4][4] row-major (parent state i, child state j)
-    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) {
-        const int c = t >> 4, e = t & 15;
-        const double v = M[t];
-        if (rows) L.row[rowSlot][c][e] = v;
-        L.col[m][c][e & 3][e >> 2] = v;
-    }
-    for (int t = threadIdx.x; t < C * 4; t += NUC_BLOCK) L.col[m][t >> 2][4][t & 3] = 1.0;
-}
-
-template <int C, int NT>
-__global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
-    __shared__ NucLds<C> L;
-    const OpDesc& op = ops[blockIdx.y];
-    const int pStart = op.pStart, pEnd = op.pEnd;
-    const int p0 = pStart + blockIdx.x * NUC_BLOCK;
-    if (p0 >= pEnd) return;
-    const int kindBits = op.kind;
-    const int k1 = (kindBits & KIND_STATES1) ? CH_STATES : (kindBits & KIND_CHERRY1) ? CH_CHERRY : CH_PARTIALS;
-    const int k2 = (kindBits & KIND_STATES2) ? CH_STATES : (kindBits & KIND_CHERRY2) ? CH_CHERRY : CH_PARTIALS;
-    const int p = p0 + threadIdx.x;
-    const bool valid = p < pEnd;
-
-    NucChildRegs<C, NT> r1, r2;
-    if (valid) {
-        nucIssue<C, NT>(r1, k1, op.child1, op.cherry[0], P, p);
-        nucIssue<C, NT>(r2, k2, op.child2, op.cherry[1], P, p);
-    }
-    double invRead = 1.0;
-    if (valid && !op.scaleWrite && op.scaleRead) invRead = 1.0 / op.scaleRead[p];
-
-    nucStage<C>(L, 0, matrices + (size_t)op.mat1 * (C * 16), true, 0);
-    nucStage<C>(L, 1, matrices + (size_t)op.mat2 * (C * 16), true, 1);
-    if (k1 == CH_CHERRY) {
-        nucStage<C>(L, 2, matrices + (size_t)op.cherry[0].matA * (C * 16), false, 0);
-        nucStage<C>(L, 3, matrices + (size_t)op.cherry[0].matB * (C * 16), false, 0);
-    }
-    if (k2 == CH_CHERRY) {
-        nucStage<C>(L, 4, matrices + (size_t)op.cherry[1].matA * (C * 16), false, 0);
-        nucStage<C>(L, 5, matrices + (size_t)op.cherry[1].matB * (C * 16), false, 0);
-    }
-    __syncthreads();
-    if (!valid) return;
-
-    double a[C][4], b[C][4];
-    nucApply<C, NT>(L, r1, k1, 0, a);
-    nucApply<C, NT>(L, r2, k2, 1, b);
-#pragma unroll
-    for (int c = 0; c < C; c++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[c][i] *= b[c][i];
-    if (op.scaleWrite) {
-        double m = 0.0;
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) m = fmax(m, a[c][i]);
-        if (!(m > 0.0)) m = 1.0;
-        op.scaleWrite[p] = m;
-        const double inv = 1.0 / m;
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[c][i] *= inv;
-    } else if (op.scaleRead) {
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[c][i] *= invRead;
-    }
-    if (kindBits & KIND_NO_STORE) return;     // virtual cherry: only its scale factors are kept
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        v4d o; o.x = a[c][0]; o.y = a[c][1]; o.z = a[c][2]; o.w = a[c][3];
-        stv4<(NT & 2) != 0>(op.dest + ((size_t)c * P + p) * 4, o);
-    }
-}
-
 __global__ void k_snapshot(double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
     const double* s = matrices + (size_t)srcDst[2 * blockIdx.x] * elems;
     double* d = matrices + (size_t)srcDst[2 * blockIdx.x + 1] * elems;
@@ -363,7 +188,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __rest
 }
 
 int pruneBlocksForRange(int S, int range) {
-    if (S == 4) return (range + NUC_BLOCK - 1) / NUC_BLOCK;
+    if (S == 4) return (range + 255) / 256;
     const int ppb = GEN_BLOCK / S;
     const int tiles = (range + ppb - 1) / ppb;
     // enough workgroups to fill the chip, few enough that the per-category matrix staging is amortised
@@ -374,30 +199,7 @@ int pruneBlocksForRange(int S, int range) {
 void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices,
                       int P, int S, int C, int maxRange) {
     if (nOps <= 0 || maxRange <= 0) return;
-    if (S == 4 && C <= 8) {
-        dim3 grid(pruneBlocksForRange(4, maxRange), nOps), block(NUC_BLOCK);
-        // non-temporal loads/stores of the partials streams: +3 % on config A (each buffer is touched once per launch
-        // and is far larger than L2); BEAGLE_MI355_NT=0 switches them off for A/B runs
-        // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3)
-        static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
-#define LAUNCH_NUC(CC)                                                                                          \
-        if (nt == 3)      hipLaunchKernelGGL((k_prune4<CC, 3>), grid, block, 0, stream, dOps, matrices, P);     \
-        else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2>), grid, block, 0, stream, dOps, matrices, P);     \
-        else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1>), grid, block, 0, stream, dOps, matrices, P);     \
-        else              hipLaunchKernelGGL((k_prune4<CC, 0>), grid, block, 0, stream, dOps, matrices, P)
-        switch (C) {
-            case 1: LAUNCH_NUC(1); break;
-            case 2: LAUNCH_NUC(2); break;
-            case 3: LAUNCH_NUC(3); break;
-            case 4: LAUNCH_NUC(4); break;
-            case 5: LAUNCH_NUC(5); break;
-            case 6: LAUNCH_NUC(6); break;
-            case 7: LAUNCH_NUC(7); break;
-            default: LAUNCH_NUC(8); break;
-        }
-#undef LAUNCH_NUC
-        return;
-    }
+    if (S == 4 && launchPruneLevelNuc4(stream, dOps, nOps, matrices, P, C, maxRange)) return;   // kernels_nuc4.hip
     const int ppb = GEN_BLOCK / S;
     const size_t lds = ((size_t)2 * (S + 1) * S + (size_t)3 * ppb * S) * sizeof(double);
     int blocks = pruneBlocksForRange(S, maxRange);
@@ -415,6 +217,7 @@ void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const do
 // root: integrate over categories and states, log, add cumulative scale, weighted deterministic sum
 // ------------------------------------------------------------------------------------------------
 constexpr int ROOT_BLOCK = 256;
+struct __attribute__((aligned(32))) d4 { double x, y, z, w; };
 
 __device__ __forceinline__ double blockSum(double v, double* sh) {
     // fixed-shape tree: wave shuffle (64 lanes) then LDS across the 4 waves — same order every run

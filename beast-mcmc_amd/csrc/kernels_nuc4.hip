@@ -1,0 +1,230 @@
+// kernels_nuc4.hip — 4-state (nucleotide) pruning, the kernel the headline benchmark runs.
+//
+// One thread = one pattern, all C rate categories (so the per-pattern rescale max never leaves the thread's
+// registers).  The branch matrices of both children for all categories are staged in LDS once per workgroup and read
+// by every lane at a wave-uniform address (LDS broadcast); compact-state children read a [state][i] column table whose
+// extra row (state == 4) is all ones.  Loads/stores of the partials streams are non-temporal.
+//
+// A child is one of (block-uniform):
+//   PARTIALS  32 B per category from the child's buffer, then the branch mat-vec
+//   STATES    compact tip: a column of the branch matrix
+//   VIRTUAL   the child's whole subtree is a handful of compact tips: recompute its partials in registers from the
+//             state bytes (kernels.h, VStep) — no HBM read, and the child's own op wrote nothing either
+// Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
+// GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace mi355 {
+
+constexpr int NUC_BLOCK = 256;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <bool NT> __device__ __forceinline__ v4d ldv4(const double* p) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p)) : *reinterpret_cast<const v4d*>(p);
+}
+template <bool NT> __device__ __forceinline__ void stv4(double* p, v4d v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4d*>(p)); else *reinterpret_cast<v4d*>(p) = v;
+}
+
+// THE arithmetic of one node, shared by the ordinary path and by the virtual-child programs so both give bitwise the
+// same numbers: y = M x (row-major 4x4), and the element-wise product of the two child factors times 1/scale.
+__device__ __forceinline__ v4d matvec4(const double* __restrict__ m, v4d x) {
+    v4d y;
+    y.x = m[0] * x.x + m[1] * x.y + m[2] * x.z + m[3] * x.w;
+    y.y = m[4] * x.x + m[5] * x.y + m[6] * x.z + m[7] * x.w;
+    y.z = m[8] * x.x + m[9] * x.y + m[10] * x.z + m[11] * x.w;
+    y.w = m[12] * x.x + m[13] * x.y + m[14] * x.z + m[15] * x.w;
+    return y;
+}
+__device__ __forceinline__ v4d colvec4(const double* __restrict__ col5x4, int s) {   // [state][i], row 4 = ones
+    const double* c = col5x4 + 4 * s;
+    v4d y; y.x = c[0]; y.y = c[1]; y.z = c[2]; y.w = c[3];
+    return y;
+}
+__device__ __forceinline__ v4d combine4(v4d a, v4d b, double inv) {
+    v4d y;
+    y.x = (a.x * b.x) * inv; y.y = (a.y * b.y) * inv; y.z = (a.z * b.z) * inv; y.w = (a.w * b.w) * inv;
+    return y;
+}
+
+template <int C>
+struct NucLds {
+    double row[2][C][16];                          // [child][c][i*4+j]       the op's two branch matrices
+    double col[2][C][20];                          // [child][c][state*4+i]   same, as column tables (STATES children)
+    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: a row table (16 used) or a column table
+};
+
+enum { CH_PARTIALS = 0, CH_STATES = 1, CH_VIRTUAL = 2 };
+
+template <int C>
+__device__ __forceinline__ void stageRow(double (*dst)[20], const double* __restrict__ M) {
+    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) dst[t >> 4][t & 15] = M[t];
+}
+template <int C>
+__device__ __forceinline__ void stageCol(double (*dst)[20], const double* __restrict__ M) {
+    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { const int e = t & 15; dst[t >> 4][(e & 3) * 4 + (e >> 2)] = M[t]; }
+    for (int t = threadIdx.x; t < C * 4; t += NUC_BLOCK) dst[t >> 2][16 + (t & 3)] = 1.0;
+}
+
+template <int C>
+struct VirtRegs {            // everything a virtual child needs from memory, fetched before the staging barrier
+    int sa[VIRT_MAX_STEPS], sb[VIRT_MAX_STEPS];
+    double inv[VIRT_MAX_STEPS];
+};
+
+template <int C>
+__device__ __forceinline__ void virtIssue(VirtRegs<C>& r, const VStep* __restrict__ prog, int p) {
+#pragma unroll
+    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+        r.sa[s] = 4; r.sb[s] = 4; r.inv[s] = 1.0;
+        const int type = prog[s].type;
+        if (type == VS_END) continue;
+        if (type == VS_CHERRY_A || type == VS_CHERRY_B) r.sa[s] = prog[s].tipA[p];
+        if (type != VS_JOIN) r.sb[s] = prog[s].tipB[p];
+        if (prog[s].scale) r.inv[s] = 1.0 / prog[s].scale[p];
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* __restrict__ prog, const double* __restrict__ matrices) {
+#pragma unroll
+    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+        const int type = prog[s].type;
+        if (type == VS_END) continue;
+        const double* MA = matrices + (size_t)prog[s].matA * (C * 16);
+        const double* MB = matrices + (size_t)prog[s].matB * (C * 16);
+        if (type == VS_CHERRY_A || type == VS_CHERRY_B) stageCol<C>(L.prog[child][s][0], MA); else stageRow<C>(L.prog[child][s][0], MA);
+        if (type == VS_JOIN) stageRow<C>(L.prog[child][s][1], MB); else stageCol<C>(L.prog[child][s][1], MB);
+    }
+}
+
+// run the program; the child's partials end up in A
+template <int C>
+__device__ __forceinline__ void virtRun(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const VirtRegs<C>& r, v4d (&A)[C]) {
+    v4d B[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { A[c] = v4d{1.0, 1.0, 1.0, 1.0}; B[c] = A[c]; }
+#pragma unroll
+    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+        const int type = prog[s].type;
+        if (type == VS_END) continue;
+        const double (*t0)[20] = L.prog[child][s][0];
+        const double (*t1)[20] = L.prog[child][s][1];
+        if (type == VS_CHERRY_A) {
+#pragma unroll
+            for (int c = 0; c < C; c++) A[c] = combine4(colvec4(t0[c], r.sa[s]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+        } else if (type == VS_CHERRY_B) {
+#pragma unroll
+            for (int c = 0; c < C; c++) B[c] = combine4(colvec4(t0[c], r.sa[s]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+        } else if (type == VS_EXTEND_A) {
+#pragma unroll
+            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(t0[c], A[c]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+        } else if (type == VS_EXTEND_B) {
+#pragma unroll
+            for (int c = 0; c < C; c++) B[c] = combine4(matvec4(t0[c], B[c]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+        } else {   // VS_JOIN
+#pragma unroll
+            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(t0[c], A[c]), matvec4(t1[c], B[c]), r.inv[s]);
+        }
+    }
+}
+
+template <int C, int NT>
+__global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
+    __shared__ NucLds<C> L;
+    const OpDesc& op = ops[blockIdx.y];
+    const int pEnd = op.pEnd;
+    const int p0 = op.pStart + blockIdx.x * NUC_BLOCK;
+    if (p0 >= pEnd) return;
+    const int kindBits = op.kind;
+    const int k1 = (kindBits & KIND_STATES1) ? CH_STATES : (kindBits & KIND_VIRT1) ? CH_VIRTUAL : CH_PARTIALS;
+    const int k2 = (kindBits & KIND_STATES2) ? CH_STATES : (kindBits & KIND_VIRT2) ? CH_VIRTUAL : CH_PARTIALS;
+    const int p = p0 + threadIdx.x;
+    const bool valid = p < pEnd;
+
+    // ---- everything that comes from memory is requested first ...
+    v4d x1[C], x2[C];
+    int s1 = 4, s2 = 4;
+    VirtRegs<C> r1, r2;
+    double invRead = 1.0;
+    if (valid) {
+        if (k1 == CH_PARTIALS) {
+            const double* x = reinterpret_cast<const double*>(op.child1);
+#pragma unroll
+            for (int c = 0; c < C; c++) x1[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
+        } else if (k1 == CH_STATES) s1 = reinterpret_cast<const uint8_t*>(op.child1)[p];
+        else virtIssue<C>(r1, op.prog[0], p);
+        if (k2 == CH_PARTIALS) {
+            const double* x = reinterpret_cast<const double*>(op.child2);
+#pragma unroll
+            for (int c = 0; c < C; c++) x2[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
+        } else if (k2 == CH_STATES) s2 = reinterpret_cast<const uint8_t*>(op.child2)[p];
+        else virtIssue<C>(r2, op.prog[1], p);
+        if (!op.scaleWrite && op.scaleRead) invRead = 1.0 / op.scaleRead[p];
+    }
+    // ---- ... then the matrices are staged while those requests are in flight
+    {
+        const double* M1 = matrices + (size_t)op.mat1 * (C * 16);
+        const double* M2 = matrices + (size_t)op.mat2 * (C * 16);
+        for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { L.row[0][t >> 4][t & 15] = M1[t]; L.row[1][t >> 4][t & 15] = M2[t]; }
+        if (k1 == CH_STATES) stageCol<C>(L.col[0], M1);
+        if (k2 == CH_STATES) stageCol<C>(L.col[1], M2);
+        if (k1 == CH_VIRTUAL) virtStage<C>(L, 0, op.prog[0], matrices);
+        if (k2 == CH_VIRTUAL) virtStage<C>(L, 1, op.prog[1], matrices);
+    }
+    __syncthreads();
+    if (!valid) return;
+
+    if (k1 == CH_VIRTUAL) virtRun<C>(L, 0, op.prog[0], r1, x1);
+    if (k2 == CH_VIRTUAL) virtRun<C>(L, 1, op.prog[1], r2, x2);
+    v4d a[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const v4d f1 = k1 == CH_STATES ? colvec4(L.col[0][c], s1) : matvec4(L.row[0][c], x1[c]);
+        const v4d f2 = k2 == CH_STATES ? colvec4(L.col[1][c], s2) : matvec4(L.row[1][c], x2[c]);
+        a[c] = combine4(f1, f2, 1.0);
+    }
+    if (op.scaleWrite) {
+        double m = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; c++) m = fmax(fmax(fmax(m, a[c].x), fmax(a[c].y, a[c].z)), a[c].w);
+        if (!(m > 0.0)) m = 1.0;
+        op.scaleWrite[p] = m;
+        const double inv = 1.0 / m;
+#pragma unroll
+        for (int c = 0; c < C; c++) a[c] = a[c] * inv;
+    } else if (op.scaleRead) {
+#pragma unroll
+        for (int c = 0; c < C; c++) a[c] = a[c] * invRead;
+    }
+    if (kindBits & KIND_NO_STORE) return;     // virtual node in write-mode rescaling: only its scale factors are kept
+#pragma unroll
+    for (int c = 0; c < C; c++) stv4<(NT & 2) != 0>(op.dest + ((size_t)c * P + p) * 4, a[c]);
+}
+
+bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int C, int maxRange) {
+    if (C > 8) return false;
+    dim3 grid((maxRange + NUC_BLOCK - 1) / NUC_BLOCK, nOps), block(NUC_BLOCK);
+    // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3: +3 % on config A)
+    static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
+#define LAUNCH_NUC(CC)                                                                                          \
+    if (nt == 3)      hipLaunchKernelGGL((k_prune4<CC, 3>), grid, block, 0, stream, dOps, matrices, P);         \
+    else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2>), grid, block, 0, stream, dOps, matrices, P);         \
+    else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1>), grid, block, 0, stream, dOps, matrices, P);         \
+    else              hipLaunchKernelGGL((k_prune4<CC, 0>), grid, block, 0, stream, dOps, matrices, P)
+    switch (C) {
+        case 1: LAUNCH_NUC(1); break;
+        case 2: LAUNCH_NUC(2); break;
+        case 3: LAUNCH_NUC(3); break;
+        case 4: LAUNCH_NUC(4); break;
+        case 5: LAUNCH_NUC(5); break;
+        case 6: LAUNCH_NUC(6); break;
+        case 7: LAUNCH_NUC(7); break;
+        default: LAUNCH_NUC(8); break;
+    }
+#undef LAUNCH_NUC
+    return true;
+}
+
+}  // namespace mi355
