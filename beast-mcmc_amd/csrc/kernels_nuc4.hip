@@ -1,15 +1,22 @@
 // kernels_nuc4.hip — 4-state (nucleotide) pruning, the kernel the headline benchmark runs.
 //
 // One thread = one pattern, all C rate categories (so the per-pattern rescale max never leaves the thread's
-// registers).  The branch matrices of both children for all categories are staged in LDS once per workgroup and read
-// by every lane at a wave-uniform address (LDS broadcast); compact-state children read a [state][i] column table whose
-// extra row (state == 4) is all ones.  Loads/stores of the partials streams are non-temporal.
+// registers).  Loads/stores of the partials streams are non-temporal 16-byte accesses; a wave covers 2 KiB contiguous
+// per category plane.
 //
 // A child is one of (block-uniform):
 //   PARTIALS  32 B per category from the child's buffer, then the branch mat-vec
 //   STATES    compact tip: a column of the branch matrix
 //   VIRTUAL   the child's whole subtree is a handful of compact tips: recompute its partials in registers from the
 //             state bytes (kernels.h, VStep) — no HBM read, and the child's own op wrote nothing either
+//
+// Where the transition matrices live:
+//   * matrices that multiply a VECTOR (mat-vec) are read straight from global memory at wave-uniform addresses; the
+//     compiler turns those into scalar loads, so every FMA takes its matrix element from an SGPR;
+//   * matrices that are indexed by a lane's own TIP STATE are staged in LDS as [state][i] column tables whose extra
+//     row (state == 4) is all ones (missing data), read with two ds_read_b128 per lookup.
+//   (With row tables in LDS as well, the virtual-child programs made the kernel LDS-bound at ~3 TB/s: profiles/.)
+//
 // Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
 // GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.
 #include "kernels.h"
@@ -50,39 +57,35 @@ __device__ __forceinline__ v4d combine4(v4d a, v4d b, double inv) {
 
 template <int C>
 struct NucLds {
-    double row[2][C][16];                          // [child][c][i*4+j]       the op's two branch matrices
-    double col[2][C][20];                          // [child][c][state*4+i]   same, as column tables (STATES children)
-    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: a row table (16 used) or a column table
+    double col[2][C][20];                          // [child][c][state*4+i]  the op's branch matrices (STATES children)
+    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: column table when that operand is a tip
 };
 
 enum { CH_PARTIALS = 0, CH_STATES = 1, CH_VIRTUAL = 2 };
 
-template <int C>
-__device__ __forceinline__ void stageRow(double (*dst)[20], const double* __restrict__ M) {
-    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) dst[t >> 4][t & 15] = M[t];
-}
 template <int C>
 __device__ __forceinline__ void stageCol(double (*dst)[20], const double* __restrict__ M) {
     for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { const int e = t & 15; dst[t >> 4][(e & 3) * 4 + (e >> 2)] = M[t]; }
     for (int t = threadIdx.x; t < C * 4; t += NUC_BLOCK) dst[t >> 2][16 + (t & 3)] = 1.0;
 }
 
-template <int C>
-struct VirtRegs {            // everything a virtual child needs from memory, fetched before the staging barrier
-    int sa[VIRT_MAX_STEPS], sb[VIRT_MAX_STEPS];
-    double inv[VIRT_MAX_STEPS];
-};
+// What a virtual child needs from memory is requested before the staging barrier and parked in registers the child
+// does not otherwise use yet: the 1/scale of each step in `inv` (one v4d, VIRT_MAX_STEPS == 4), the tip-state bytes
+// packed into one 64-bit word (step s: byte s = tipA state, byte 4+s = tipB state).
+static_assert(VIRT_MAX_STEPS == 4, "inv is one v4d, states are packed 4+4 bytes");
 
-template <int C>
-__device__ __forceinline__ void virtIssue(VirtRegs<C>& r, const VStep* __restrict__ prog, int p) {
+__device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p, v4d& inv, unsigned long long& packed) {
+    inv = v4d{1.0, 1.0, 1.0, 1.0};
+    packed = 0x0404040404040404ull;
 #pragma unroll
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
-        r.sa[s] = 4; r.sb[s] = 4; r.inv[s] = 1.0;
         const int type = prog[s].type;
         if (type == VS_END) continue;
-        if (type == VS_CHERRY_A || type == VS_CHERRY_B) r.sa[s] = prog[s].tipA[p];
-        if (type != VS_JOIN) r.sb[s] = prog[s].tipB[p];
-        if (prog[s].scale) r.inv[s] = 1.0 / prog[s].scale[p];
+        if (type == VS_CHERRY_A || type == VS_CHERRY_B)
+            packed = (packed & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipA[p] << (8 * s));
+        if (type != VS_JOIN)
+            packed = (packed & ~(0xffull << (8 * (4 + s)))) | ((unsigned long long)prog[s].tipB[p] << (8 * (4 + s)));
+        if (prog[s].scale) inv[s] = 1.0 / prog[s].scale[p];
     }
 }
 
@@ -92,16 +95,15 @@ __device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* 
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
-        const double* MA = matrices + (size_t)prog[s].matA * (C * 16);
-        const double* MB = matrices + (size_t)prog[s].matB * (C * 16);
-        if (type == VS_CHERRY_A || type == VS_CHERRY_B) stageCol<C>(L.prog[child][s][0], MA); else stageRow<C>(L.prog[child][s][0], MA);
-        if (type == VS_JOIN) stageRow<C>(L.prog[child][s][1], MB); else stageCol<C>(L.prog[child][s][1], MB);
+        if (type == VS_CHERRY_A || type == VS_CHERRY_B) stageCol<C>(L.prog[child][s][0], matrices + (size_t)prog[s].matA * (C * 16));
+        if (type != VS_JOIN) stageCol<C>(L.prog[child][s][1], matrices + (size_t)prog[s].matB * (C * 16));
     }
 }
 
 // run the program; the child's partials end up in A
 template <int C>
-__device__ __forceinline__ void virtRun(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const VirtRegs<C>& r, v4d (&A)[C]) {
+__device__ __forceinline__ void virtRun(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const double* __restrict__ matrices,
+                                        v4d inv, unsigned long long packed, v4d (&A)[C]) {
     v4d B[C];
 #pragma unroll
     for (int c = 0; c < C; c++) { A[c] = v4d{1.0, 1.0, 1.0, 1.0}; B[c] = A[c]; }
@@ -111,27 +113,32 @@ __device__ __forceinline__ void virtRun(const NucLds<C>& L, int child, const VSt
         if (type == VS_END) continue;
         const double (*t0)[20] = L.prog[child][s][0];
         const double (*t1)[20] = L.prog[child][s][1];
+        const double* gA = matrices + (size_t)prog[s].matA * (C * 16);     // wave-uniform: scalar loads
+        const double* gB = matrices + (size_t)prog[s].matB * (C * 16);
+        const int sa = (int)((packed >> (8 * s)) & 0xff), sb = (int)((packed >> (8 * (4 + s))) & 0xff);
+        const double iv = inv[s];
         if (type == VS_CHERRY_A) {
 #pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(colvec4(t0[c], r.sa[s]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+            for (int c = 0; c < C; c++) A[c] = combine4(colvec4(t0[c], sa), colvec4(t1[c], sb), iv);
         } else if (type == VS_CHERRY_B) {
 #pragma unroll
-            for (int c = 0; c < C; c++) B[c] = combine4(colvec4(t0[c], r.sa[s]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+            for (int c = 0; c < C; c++) B[c] = combine4(colvec4(t0[c], sa), colvec4(t1[c], sb), iv);
         } else if (type == VS_EXTEND_A) {
 #pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(t0[c], A[c]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(gA + c * 16, A[c]), colvec4(t1[c], sb), iv);
         } else if (type == VS_EXTEND_B) {
 #pragma unroll
-            for (int c = 0; c < C; c++) B[c] = combine4(matvec4(t0[c], B[c]), colvec4(t1[c], r.sb[s]), r.inv[s]);
+            for (int c = 0; c < C; c++) B[c] = combine4(matvec4(gA + c * 16, B[c]), colvec4(t1[c], sb), iv);
         } else {   // VS_JOIN
 #pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(t0[c], A[c]), matvec4(t1[c], B[c]), r.inv[s]);
+            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(gA + c * 16, A[c]), matvec4(gB + c * 16, B[c]), iv);
         }
     }
 }
 
-template <int C, int NT>
-__global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
+// MINW = waves per SIMD the register allocator must leave room for (2: 178 VGPRs, no spill; 3: 168 VGPRs, 44 B/lane scratch)
+template <int C, int NT, int MINW>
+__global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
     __shared__ NucLds<C> L;
     const OpDesc& op = ops[blockIdx.y];
     const int pEnd = op.pEnd;
@@ -144,46 +151,46 @@ __global__ __launch_bounds__(NUC_BLOCK) void k_prune4(const OpDesc* __restrict__
     const bool valid = p < pEnd;
 
     // ---- everything that comes from memory is requested first ...
+    // x1/x2: the child's partials (PARTIALS), or — until its program runs — a virtual child's 1/scale vector in x[0];
+    // w1/w2: a compact tip's state, or a virtual child's packed tip states
     v4d x1[C], x2[C];
-    int s1 = 4, s2 = 4;
-    VirtRegs<C> r1, r2;
+    unsigned long long w1 = 4, w2 = 4;
     double invRead = 1.0;
     if (valid) {
         if (k1 == CH_PARTIALS) {
             const double* x = reinterpret_cast<const double*>(op.child1);
 #pragma unroll
             for (int c = 0; c < C; c++) x1[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
-        } else if (k1 == CH_STATES) s1 = reinterpret_cast<const uint8_t*>(op.child1)[p];
-        else virtIssue<C>(r1, op.prog[0], p);
+        } else if (k1 == CH_STATES) w1 = reinterpret_cast<const uint8_t*>(op.child1)[p];
+        else virtIssue(op.prog[0], p, x1[0], w1);
         if (k2 == CH_PARTIALS) {
             const double* x = reinterpret_cast<const double*>(op.child2);
 #pragma unroll
             for (int c = 0; c < C; c++) x2[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
-        } else if (k2 == CH_STATES) s2 = reinterpret_cast<const uint8_t*>(op.child2)[p];
-        else virtIssue<C>(r2, op.prog[1], p);
+        } else if (k2 == CH_STATES) w2 = reinterpret_cast<const uint8_t*>(op.child2)[p];
+        else virtIssue(op.prog[1], p, x2[0], w2);
         if (!op.scaleWrite && op.scaleRead) invRead = 1.0 / op.scaleRead[p];
     }
-    // ---- ... then the matrices are staged while those requests are in flight
-    {
-        const double* M1 = matrices + (size_t)op.mat1 * (C * 16);
-        const double* M2 = matrices + (size_t)op.mat2 * (C * 16);
-        for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { L.row[0][t >> 4][t & 15] = M1[t]; L.row[1][t >> 4][t & 15] = M2[t]; }
-        if (k1 == CH_STATES) stageCol<C>(L.col[0], M1);
-        if (k2 == CH_STATES) stageCol<C>(L.col[1], M2);
-        if (k1 == CH_VIRTUAL) virtStage<C>(L, 0, op.prog[0], matrices);
-        if (k2 == CH_VIRTUAL) virtStage<C>(L, 1, op.prog[1], matrices);
-    }
+    // ---- ... then the column tables are staged while those requests are in flight
+    const double* G1 = matrices + (size_t)op.mat1 * (C * 16);
+    const double* G2 = matrices + (size_t)op.mat2 * (C * 16);
+    if (k1 == CH_STATES) stageCol<C>(L.col[0], G1);
+    if (k2 == CH_STATES) stageCol<C>(L.col[1], G2);
+    if (k1 == CH_VIRTUAL) virtStage<C>(L, 0, op.prog[0], matrices);
+    if (k2 == CH_VIRTUAL) virtStage<C>(L, 1, op.prog[1], matrices);
     __syncthreads();
     if (!valid) return;
 
-    if (k1 == CH_VIRTUAL) virtRun<C>(L, 0, op.prog[0], r1, x1);
-    if (k2 == CH_VIRTUAL) virtRun<C>(L, 1, op.prog[1], r2, x2);
+    // child 1 -> its factor f1 (x1 is dead afterwards), then child 2
     v4d a[C];
+    if (k1 == CH_VIRTUAL) virtRun<C>(L, 0, op.prog[0], matrices, x1[0], w1, x1);
+#pragma unroll
+    for (int c = 0; c < C; c++) a[c] = k1 == CH_STATES ? colvec4(L.col[0][c], (int)w1) : matvec4(G1 + c * 16, x1[c]);
+    if (k2 == CH_VIRTUAL) virtRun<C>(L, 1, op.prog[1], matrices, x2[0], w2, x2);
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const v4d f1 = k1 == CH_STATES ? colvec4(L.col[0][c], s1) : matvec4(L.row[0][c], x1[c]);
-        const v4d f2 = k2 == CH_STATES ? colvec4(L.col[1][c], s2) : matvec4(L.row[1][c], x2[c]);
-        a[c] = combine4(f1, f2, 1.0);
+        const v4d f2 = k2 == CH_STATES ? colvec4(L.col[1][c], (int)w2) : matvec4(G2 + c * 16, x2[c]);
+        a[c] = combine4(a[c], f2, 1.0);
     }
     if (op.scaleWrite) {
         double m = 0.0;
@@ -208,11 +215,13 @@ bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, cons
     dim3 grid((maxRange + NUC_BLOCK - 1) / NUC_BLOCK, nOps), block(NUC_BLOCK);
     // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3: +3 % on config A)
     static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
+    static const int minw = getenv("BEAGLE_MI355_WAVES") ? atoi(getenv("BEAGLE_MI355_WAVES")) : 2;
 #define LAUNCH_NUC(CC)                                                                                          \
-    if (nt == 3)      hipLaunchKernelGGL((k_prune4<CC, 3>), grid, block, 0, stream, dOps, matrices, P);         \
-    else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2>), grid, block, 0, stream, dOps, matrices, P);         \
-    else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1>), grid, block, 0, stream, dOps, matrices, P);         \
-    else              hipLaunchKernelGGL((k_prune4<CC, 0>), grid, block, 0, stream, dOps, matrices, P)
+    if (minw >= 3)    hipLaunchKernelGGL((k_prune4<CC, 3, 3>), grid, block, 0, stream, dOps, matrices, P);      \
+    else if (nt == 3) hipLaunchKernelGGL((k_prune4<CC, 3, 2>), grid, block, 0, stream, dOps, matrices, P);      \
+    else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2, 2>), grid, block, 0, stream, dOps, matrices, P);      \
+    else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1, 2>), grid, block, 0, stream, dOps, matrices, P);      \
+    else              hipLaunchKernelGGL((k_prune4<CC, 0, 2>), grid, block, 0, stream, dOps, matrices, P)
     switch (C) {
         case 1: LAUNCH_NUC(1); break;
         case 2: LAUNCH_NUC(2); break;
