@@ -10,12 +10,11 @@
 //   VIRTUAL   the child's whole subtree is a handful of compact tips: recompute its partials in registers from the
 //             state bytes (kernels.h, VStep) — no HBM read, and the child's own op wrote nothing either
 //
-// Where the transition matrices live:
-//   * matrices that multiply a VECTOR (mat-vec) are read straight from global memory at wave-uniform addresses; the
-//     compiler turns those into scalar loads, so every FMA takes its matrix element from an SGPR;
-//   * matrices that are indexed by a lane's own TIP STATE are staged in LDS as [state][i] column tables whose extra
-//     row (state == 4) is all ones (missing data), read with two ds_read_b128 per lookup.
-//   (With row tables in LDS as well, the virtual-child programs made the kernel LDS-bound at ~3 TB/s: profiles/.)
+// Where the transition matrices live: all in LDS, staged once per workgroup — as [i][j] row tables when they multiply a
+// vector (read at wave-uniform addresses: LDS broadcast) and as [state][i] column tables, with an all-ones row for
+// "missing" (state 4), when they are indexed by a lane's own tip state.  (Measured alternative: mat-vec operands
+// through scalar loads/SGPRs was 10 % slower at equal occupancy — SMEM latency is exposed at 2-3 waves per SIMD.)
+// A virtual child is evaluated one rate category at a time, so its two accumulators cost 16 VGPRs, not 16 * C.
 //
 // Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
 // GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.
@@ -57,12 +56,17 @@ __device__ __forceinline__ v4d combine4(v4d a, v4d b, double inv) {
 
 template <int C>
 struct NucLds {
-    double col[2][C][20];                          // [child][c][state*4+i]  the op's branch matrices (STATES children)
-    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: column table when that operand is a tip
+    double row[2][C][16];                          // [child][c][i*4+j]      the op's two branch matrices
+    double col[2][C][20];                          // [child][c][state*4+i]  same as column tables (STATES children)
+    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: row table (16 used) or column table
 };
 
 enum { CH_PARTIALS = 0, CH_STATES = 1, CH_VIRTUAL = 2 };
 
+template <int C>
+__device__ __forceinline__ void stageRow(double (*dst)[20], const double* __restrict__ M) {
+    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) dst[t >> 4][t & 15] = M[t];
+}
 template <int C>
 __device__ __forceinline__ void stageCol(double (*dst)[20], const double* __restrict__ M) {
     for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { const int e = t & 15; dst[t >> 4][(e & 3) * 4 + (e >> 2)] = M[t]; }
@@ -95,48 +99,35 @@ __device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* 
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
-        if (type == VS_CHERRY_A || type == VS_CHERRY_B) stageCol<C>(L.prog[child][s][0], matrices + (size_t)prog[s].matA * (C * 16));
-        if (type != VS_JOIN) stageCol<C>(L.prog[child][s][1], matrices + (size_t)prog[s].matB * (C * 16));
+        const double* MA = matrices + (size_t)prog[s].matA * (C * 16);
+        const double* MB = matrices + (size_t)prog[s].matB * (C * 16);
+        if (type == VS_CHERRY_A || type == VS_CHERRY_B) stageCol<C>(L.prog[child][s][0], MA); else stageRow<C>(L.prog[child][s][0], MA);
+        if (type == VS_JOIN) stageRow<C>(L.prog[child][s][1], MB); else stageCol<C>(L.prog[child][s][1], MB);
     }
 }
 
-// run the program; the child's partials end up in A
+// run the program for ONE rate category; returns the child's partials for that category
 template <int C>
-__device__ __forceinline__ void virtRun(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const double* __restrict__ matrices,
-                                        v4d inv, unsigned long long packed, v4d (&A)[C]) {
-    v4d B[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) { A[c] = v4d{1.0, 1.0, 1.0, 1.0}; B[c] = A[c]; }
+__device__ __forceinline__ v4d virtEval(const NucLds<C>& L, int child, const VStep* __restrict__ prog, v4d inv, unsigned long long packed, int c) {
+    v4d A = v4d{1.0, 1.0, 1.0, 1.0}, B = A;
 #pragma unroll
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
-        const double (*t0)[20] = L.prog[child][s][0];
-        const double (*t1)[20] = L.prog[child][s][1];
-        const double* gA = matrices + (size_t)prog[s].matA * (C * 16);     // wave-uniform: scalar loads
-        const double* gB = matrices + (size_t)prog[s].matB * (C * 16);
+        const double* t0 = L.prog[child][s][0][c];
+        const double* t1 = L.prog[child][s][1][c];
         const int sa = (int)((packed >> (8 * s)) & 0xff), sb = (int)((packed >> (8 * (4 + s))) & 0xff);
         const double iv = inv[s];
-        if (type == VS_CHERRY_A) {
-#pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(colvec4(t0[c], sa), colvec4(t1[c], sb), iv);
-        } else if (type == VS_CHERRY_B) {
-#pragma unroll
-            for (int c = 0; c < C; c++) B[c] = combine4(colvec4(t0[c], sa), colvec4(t1[c], sb), iv);
-        } else if (type == VS_EXTEND_A) {
-#pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(gA + c * 16, A[c]), colvec4(t1[c], sb), iv);
-        } else if (type == VS_EXTEND_B) {
-#pragma unroll
-            for (int c = 0; c < C; c++) B[c] = combine4(matvec4(gA + c * 16, B[c]), colvec4(t1[c], sb), iv);
-        } else {   // VS_JOIN
-#pragma unroll
-            for (int c = 0; c < C; c++) A[c] = combine4(matvec4(gA + c * 16, A[c]), matvec4(gB + c * 16, B[c]), iv);
-        }
+        if (type == VS_CHERRY_A)      A = combine4(colvec4(t0, sa), colvec4(t1, sb), iv);
+        else if (type == VS_CHERRY_B) B = combine4(colvec4(t0, sa), colvec4(t1, sb), iv);
+        else if (type == VS_EXTEND_A) A = combine4(matvec4(t0, A), colvec4(t1, sb), iv);
+        else if (type == VS_EXTEND_B) B = combine4(matvec4(t0, B), colvec4(t1, sb), iv);
+        else                          A = combine4(matvec4(t0, A), matvec4(t1, B), iv);     // VS_JOIN
     }
+    return A;
 }
 
-// MINW = waves per SIMD the register allocator must leave room for (2: 178 VGPRs, no spill; 3: 168 VGPRs, 44 B/lane scratch)
+// MINW = waves per SIMD the register allocator must leave room for
 template <int C, int NT, int MINW>
 __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P) {
     __shared__ NucLds<C> L;
@@ -174,6 +165,7 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
     // ---- ... then the column tables are staged while those requests are in flight
     const double* G1 = matrices + (size_t)op.mat1 * (C * 16);
     const double* G2 = matrices + (size_t)op.mat2 * (C * 16);
+    for (int t = threadIdx.x; t < C * 16; t += NUC_BLOCK) { L.row[0][t >> 4][t & 15] = G1[t]; L.row[1][t >> 4][t & 15] = G2[t]; }
     if (k1 == CH_STATES) stageCol<C>(L.col[0], G1);
     if (k2 == CH_STATES) stageCol<C>(L.col[1], G2);
     if (k1 == CH_VIRTUAL) virtStage<C>(L, 0, op.prog[0], matrices);
@@ -181,15 +173,19 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
     __syncthreads();
     if (!valid) return;
 
-    // child 1 -> its factor f1 (x1 is dead afterwards), then child 2
+    // child 1 -> its factor (x1 is dead afterwards), then child 2; virtual children one category at a time
     v4d a[C];
-    if (k1 == CH_VIRTUAL) virtRun<C>(L, 0, op.prog[0], matrices, x1[0], w1, x1);
-#pragma unroll
-    for (int c = 0; c < C; c++) a[c] = k1 == CH_STATES ? colvec4(L.col[0][c], (int)w1) : matvec4(G1 + c * 16, x1[c]);
-    if (k2 == CH_VIRTUAL) virtRun<C>(L, 1, op.prog[1], matrices, x2[0], w2, x2);
+    const v4d inv1 = x1[0], inv2 = x2[0];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const v4d f2 = k2 == CH_STATES ? colvec4(L.col[1][c], (int)w2) : matvec4(G2 + c * 16, x2[c]);
+        if (k1 == CH_STATES) a[c] = colvec4(L.col[0][c], (int)w1);
+        else a[c] = matvec4(L.row[0][c], k1 == CH_VIRTUAL ? virtEval<C>(L, 0, op.prog[0], inv1, w1, c) : x1[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        v4d f2;
+        if (k2 == CH_STATES) f2 = colvec4(L.col[1][c], (int)w2);
+        else f2 = matvec4(L.row[1][c], k2 == CH_VIRTUAL ? virtEval<C>(L, 1, op.prog[1], inv2, w2, c) : x2[c]);
         a[c] = combine4(a[c], f2, 1.0);
     }
     if (op.scaleWrite) {
@@ -215,7 +211,7 @@ bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, cons
     dim3 grid((maxRange + NUC_BLOCK - 1) / NUC_BLOCK, nOps), block(NUC_BLOCK);
     // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3: +3 % on config A)
     static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
-    static const int minw = getenv("BEAGLE_MI355_WAVES") ? atoi(getenv("BEAGLE_MI355_WAVES")) : 2;
+    static const int minw = getenv("BEAGLE_MI355_WAVES") ? atoi(getenv("BEAGLE_MI355_WAVES")) : 3;   // 3: 123 VGPRs = 4 waves per SIMD; 2: 134 VGPRs = 3 waves
 #define LAUNCH_NUC(CC)                                                                                          \
     if (minw >= 3)    hipLaunchKernelGGL((k_prune4<CC, 3, 3>), grid, block, 0, stream, dOps, matrices, P);      \
     else if (nt == 3) hipLaunchKernelGGL((k_prune4<CC, 3, 2>), grid, block, 0, stream, dOps, matrices, P);      \
