@@ -56,6 +56,7 @@ struct Instance {
     std::vector<Virt> virt;                              // per partials buffer
     std::vector<std::vector<int>> tipUsers, scaleUsers;  // virtual buffers defined by a tip / a scale buffer
     bool virtualCherries = false;                        // 4 states, single partition; BEAGLE_MI355_NO_VIRTUAL=1 disables
+    int maxVirtSteps = mi355::VIRT_MAX_STEPS;            // longest virtual-subtree program (BEAGLE_MI355_VSTEPS, 1..8)
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
     size_t partialsBytes = 0;
@@ -328,7 +329,7 @@ bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool t
     auto append = [&](int srcBuf, bool toB) -> bool {
         const Virt& src = in->virt[srcBuf];
         for (int s = 0; s < src.nSteps; s++) {
-            if (nv.nSteps >= mi355::VIRT_MAX_STEPS) return false;
+            if (nv.nSteps >= in->maxVirtSteps) return false;
             VStepHost h = src.steps[s];
             if (toB) h.type = h.type == mi355::VS_CHERRY_A ? mi355::VS_CHERRY_B : mi355::VS_EXTEND_B;
             // a child defined in THIS call has its slots written by the same k_snapshot launch: copy from its origins
@@ -359,7 +360,7 @@ bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool t
         nv.chainOnly = false;
         last.type = mi355::VS_JOIN; last.originA = mu; last.originB = mv;
     }
-    if (nv.nSteps >= mi355::VIRT_MAX_STEPS) return false;
+    if (nv.nSteps >= in->maxVirtSteps) return false;
     pairs.push_back(last.originA); pairs.push_back(snapSlot(in, X, nv.nSteps, 0));
     pairs.push_back(last.originB); pairs.push_back(snapSlot(in, X, nv.nSteps, 1));
     nv.steps[nv.nSteps++] = last;
@@ -735,6 +736,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->virtualCherries = stateCount == 4 && categoryCount <= 8 &&
                           !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0) &&
                           !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
+    if (getenv("BEAGLE_MI355_VSTEPS")) in->maxVirtSteps = std::max(1, std::min(mi355::VIRT_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->virt.assign(partialsBufferCount, Virt());
     in->tipUsers.assign(partialsBufferCount, std::vector<int>());
     in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());

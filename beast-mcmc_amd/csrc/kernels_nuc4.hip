@@ -73,23 +73,25 @@ __device__ __forceinline__ void stageCol(double (*dst)[20], const double* __rest
     for (int t = threadIdx.x; t < C * 4; t += NUC_BLOCK) dst[t >> 2][16 + (t & 3)] = 1.0;
 }
 
-// What a virtual child needs from memory is requested before the staging barrier and parked in registers the child
-// does not otherwise use yet: the 1/scale of each step in `inv` (one v4d, VIRT_MAX_STEPS == 4), the tip-state bytes
-// packed into one 64-bit word (step s: byte s = tipA state, byte 4+s = tipB state).
-static_assert(VIRT_MAX_STEPS == 4, "inv is one v4d, states are packed 4+4 bytes");
+// What a virtual child needs from memory is requested before the staging barrier: the 1/scale of each step (two v4d,
+// VIRT_MAX_STEPS == 8) and the tip-state bytes packed into two 64-bit words (byte s of `pa` = step s tipA state,
+// byte s of `pb` = its tipB state).
+static_assert(VIRT_MAX_STEPS == 8, "1/scale values are two v4d, states are packed 8 + 8 bytes");
 
-__device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p, v4d& inv, unsigned long long& packed) {
-    inv = v4d{1.0, 1.0, 1.0, 1.0};
-    packed = 0x0404040404040404ull;
+struct VirtPark { v4d invLo, invHi; unsigned long long pa, pb; };
+
+__device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p, VirtPark& k) {
+    k.invLo = v4d{1.0, 1.0, 1.0, 1.0}; k.invHi = k.invLo;
+    k.pa = 0x0404040404040404ull; k.pb = k.pa;
 #pragma unroll
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
         if (type == VS_CHERRY_A || type == VS_CHERRY_B)
-            packed = (packed & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipA[p] << (8 * s));
+            k.pa = (k.pa & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipA[p] << (8 * s));
         if (type != VS_JOIN)
-            packed = (packed & ~(0xffull << (8 * (4 + s)))) | ((unsigned long long)prog[s].tipB[p] << (8 * (4 + s)));
-        if (prog[s].scale) inv[s] = 1.0 / prog[s].scale[p];
+            k.pb = (k.pb & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipB[p] << (8 * s));
+        if (prog[s].scale) { const double v = 1.0 / prog[s].scale[p]; if (s < 4) k.invLo[s] = v; else k.invHi[s - 4] = v; }
     }
 }
 
@@ -108,16 +110,20 @@ __device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* 
 
 // run the program for ONE rate category; returns the child's partials for that category
 template <int C>
-__device__ __forceinline__ v4d virtEval(const NucLds<C>& L, int child, const VStep* __restrict__ prog, v4d inv, unsigned long long packed, int c) {
+__device__ __forceinline__ v4d virtEval(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const VirtPark& k, int c) {
     v4d A = v4d{1.0, 1.0, 1.0, 1.0}, B = A;
-#pragma unroll
+    // a RUNTIME loop over the steps (wave-uniform trip count and branches): unrolling it for every category of both
+    // children multiplies the code by ~60 and the compile time with it
+#pragma unroll 1
     for (int s = 0; s < VIRT_MAX_STEPS; s++) {
         const int type = prog[s].type;
-        if (type == VS_END) continue;
+        if (type == VS_END) break;
         const double* t0 = L.prog[child][s][0][c];
         const double* t1 = L.prog[child][s][1][c];
-        const int sa = (int)((packed >> (8 * s)) & 0xff), sb = (int)((packed >> (8 * (4 + s))) & 0xff);
-        const double iv = inv[s];
+        const int sa = (int)((k.pa >> (8 * s)) & 0xff), sb = (int)((k.pb >> (8 * s)) & 0xff);
+        const double lo = (s & 2) ? ((s & 1) ? k.invLo.w : k.invLo.z) : ((s & 1) ? k.invLo.y : k.invLo.x);
+        const double hi = (s & 2) ? ((s & 1) ? k.invHi.w : k.invHi.z) : ((s & 1) ? k.invHi.y : k.invHi.x);
+        const double iv = (s & 4) ? hi : lo;
         if (type == VS_CHERRY_A)      A = combine4(colvec4(t0, sa), colvec4(t1, sb), iv);
         else if (type == VS_CHERRY_B) B = combine4(colvec4(t0, sa), colvec4(t1, sb), iv);
         else if (type == VS_EXTEND_A) A = combine4(matvec4(t0, A), colvec4(t1, sb), iv);
@@ -142,10 +148,10 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
     const bool valid = p < pEnd;
 
     // ---- everything that comes from memory is requested first ...
-    // x1/x2: the child's partials (PARTIALS), or — until its program runs — a virtual child's 1/scale vector in x[0];
-    // w1/w2: a compact tip's state, or a virtual child's packed tip states
+    // x1/x2: the child's partials (PARTIALS); w1/w2: a compact tip's state; v1/v2: a virtual child's parked inputs
     v4d x1[C], x2[C];
-    unsigned long long w1 = 4, w2 = 4;
+    int w1 = 4, w2 = 4;
+    VirtPark v1, v2;
     double invRead = 1.0;
     if (valid) {
         if (k1 == CH_PARTIALS) {
@@ -153,13 +159,13 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
 #pragma unroll
             for (int c = 0; c < C; c++) x1[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
         } else if (k1 == CH_STATES) w1 = reinterpret_cast<const uint8_t*>(op.child1)[p];
-        else virtIssue(op.prog[0], p, x1[0], w1);
+        else virtIssue(op.prog[0], p, v1);
         if (k2 == CH_PARTIALS) {
             const double* x = reinterpret_cast<const double*>(op.child2);
 #pragma unroll
             for (int c = 0; c < C; c++) x2[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
         } else if (k2 == CH_STATES) w2 = reinterpret_cast<const uint8_t*>(op.child2)[p];
-        else virtIssue(op.prog[1], p, x2[0], w2);
+        else virtIssue(op.prog[1], p, v2);
         if (!op.scaleWrite && op.scaleRead) invRead = 1.0 / op.scaleRead[p];
     }
     // ---- ... then the column tables are staged while those requests are in flight
@@ -175,17 +181,16 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
 
     // child 1 -> its factor (x1 is dead afterwards), then child 2; virtual children one category at a time
     v4d a[C];
-    const v4d inv1 = x1[0], inv2 = x2[0];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        if (k1 == CH_STATES) a[c] = colvec4(L.col[0][c], (int)w1);
-        else a[c] = matvec4(L.row[0][c], k1 == CH_VIRTUAL ? virtEval<C>(L, 0, op.prog[0], inv1, w1, c) : x1[c]);
+        if (k1 == CH_STATES) a[c] = colvec4(L.col[0][c], w1);
+        else a[c] = matvec4(L.row[0][c], k1 == CH_VIRTUAL ? virtEval<C>(L, 0, op.prog[0], v1, c) : x1[c]);
     }
 #pragma unroll
     for (int c = 0; c < C; c++) {
         v4d f2;
-        if (k2 == CH_STATES) f2 = colvec4(L.col[1][c], (int)w2);
-        else f2 = matvec4(L.row[1][c], k2 == CH_VIRTUAL ? virtEval<C>(L, 1, op.prog[1], inv2, w2, c) : x2[c]);
+        if (k2 == CH_STATES) f2 = colvec4(L.col[1][c], w2);
+        else f2 = matvec4(L.row[1][c], k2 == CH_VIRTUAL ? virtEval<C>(L, 1, op.prog[1], v2, c) : x2[c]);
         a[c] = combine4(a[c], f2, 1.0);
     }
     if (op.scaleWrite) {
@@ -211,13 +216,12 @@ bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, cons
     dim3 grid((maxRange + NUC_BLOCK - 1) / NUC_BLOCK, nOps), block(NUC_BLOCK);
     // BEAGLE_MI355_NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (default 3: +3 % on config A)
     static const int nt = getenv("BEAGLE_MI355_NT") ? (atoi(getenv("BEAGLE_MI355_NT")) & 3) : 3;
-    static const int minw = getenv("BEAGLE_MI355_WAVES") ? atoi(getenv("BEAGLE_MI355_WAVES")) : 3;   // 3: 123 VGPRs = 4 waves per SIMD; 2: 134 VGPRs = 3 waves
+    // two variants per category count only (compile time): non-temporal streams on (default) or off
+    static const int minw = getenv("BEAGLE_MI355_WAVES") ? atoi(getenv("BEAGLE_MI355_WAVES")) : 3;
 #define LAUNCH_NUC(CC)                                                                                          \
-    if (minw >= 3)    hipLaunchKernelGGL((k_prune4<CC, 3, 3>), grid, block, 0, stream, dOps, matrices, P);      \
-    else if (nt == 3) hipLaunchKernelGGL((k_prune4<CC, 3, 2>), grid, block, 0, stream, dOps, matrices, P);      \
-    else if (nt == 2) hipLaunchKernelGGL((k_prune4<CC, 2, 2>), grid, block, 0, stream, dOps, matrices, P);      \
-    else if (nt == 1) hipLaunchKernelGGL((k_prune4<CC, 1, 2>), grid, block, 0, stream, dOps, matrices, P);      \
-    else              hipLaunchKernelGGL((k_prune4<CC, 0, 2>), grid, block, 0, stream, dOps, matrices, P)
+    if (nt == 0)        hipLaunchKernelGGL((k_prune4<CC, 0, 3>), grid, block, 0, stream, dOps, matrices, P);    \
+    else if (minw >= 4) hipLaunchKernelGGL((k_prune4<CC, 3, 4>), grid, block, 0, stream, dOps, matrices, P);    \
+    else                hipLaunchKernelGGL((k_prune4<CC, 3, 3>), grid, block, 0, stream, dOps, matrices, P)
     switch (C) {
         case 1: LAUNCH_NUC(1); break;
         case 2: LAUNCH_NUC(2); break;
