@@ -42,6 +42,7 @@ struct VStepHost {
     int tipA, tipB;         // tip buffer indices (CHERRY: both, EXTEND: tipB)
     int scaleIdx;           // this node's scale buffer, or -1
     int originA, originB;   // where the two matrices were copied FROM (stable for the call that created the node)
+    int split;              // JOIN: number of leading steps that belong to the A operand (the rest, up to this step, is the B chain)
 };
 struct Virt {
     bool on = false;
@@ -56,7 +57,7 @@ struct Instance {
     std::vector<Virt> virt;                              // per partials buffer
     std::vector<std::vector<int>> tipUsers, scaleUsers;  // virtual buffers defined by a tip / a scale buffer
     bool virtualCherries = false;                        // 4 states, single partition; BEAGLE_MI355_NO_VIRTUAL=1 disables
-    int maxVirtSteps = mi355::VIRT_MAX_STEPS;            // longest virtual-subtree program (BEAGLE_MI355_VSTEPS, 1..8)
+    int maxVirtSteps = VIRT_EMIT_STEPS;                  // longest virtual-subtree program (BEAGLE_MI355_VSTEPS lowers it)
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
     size_t partialsBytes = 0;
@@ -343,7 +344,7 @@ bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool t
         return true;
     };
     VStepHost last;
-    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1;
+    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.split = 0;
     if (tip1 && tip2) {
         last.type = mi355::VS_CHERRY_A; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
     } else if (tip1 != tip2) {
@@ -356,7 +357,9 @@ bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool t
         if (!in->virt[u].on || !in->virt[v].on) return false;
         if (!in->virt[v].chainOnly) { std::swap(u, v); std::swap(mu, mv); }
         if (!in->virt[v].chainOnly) return false;                 // would need a third accumulator
-        if (!append(u, false) || !append(v, true)) return false;
+        if (!append(u, false)) return false;
+        last.split = nv.nSteps;
+        if (!append(v, true)) return false;
         nv.chainOnly = false;
         last.type = mi355::VS_JOIN; last.originA = mu; last.originB = mv;
     }
@@ -388,8 +391,7 @@ void materializeDesc(const Instance* in, int X, OpDesc& d) {
         d.child2 = in->tipStates[last.tipB];
         d.kind = mi355::KIND_VIRT1 | mi355::KIND_STATES2;
     } else {   // JOIN: the A part is the leading steps, the B chain follows
-        int split = 0;
-        while (split < n - 1 && v.steps[split].type != mi355::VS_CHERRY_B && v.steps[split].type != mi355::VS_EXTEND_B) split++;
+        const int split = last.split;    // the A operand may itself contain B-type steps (an inner JOIN): use the recorded boundary
         emitProgram(in, X, 0, split, false, d.prog[0]);
         emitProgram(in, X, split, n - 1, true, d.prog[1]);
         d.kind = mi355::KIND_VIRT1 | mi355::KIND_VIRT2;
@@ -736,7 +738,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->virtualCherries = stateCount == 4 && categoryCount <= 8 &&
                           !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0) &&
                           !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
-    if (getenv("BEAGLE_MI355_VSTEPS")) in->maxVirtSteps = std::max(1, std::min(mi355::VIRT_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
+    if (getenv("BEAGLE_MI355_VSTEPS")) in->maxVirtSteps = std::max(1, std::min(VIRT_EMIT_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->virt.assign(partialsBufferCount, Virt());
     in->tipUsers.assign(partialsBufferCount, std::vector<int>());
     in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());

@@ -18,7 +18,10 @@ namespace mi355 {
 //   VS_JOIN            A   = (matA . A) * (matB . B) * (1/scale)                                   node with two subtrees
 // Every step repeats exactly the arithmetic the node's own op performs, so the values are bitwise those the op would
 // have stored.  matA/matB index private SNAPSHOTS of the branch matrices (engine.cpp, "virtual subtrees").
-constexpr int VIRT_MAX_STEPS = 8;
+constexpr int VIRT_MAX_STEPS = 8;     // descriptor / snapshot capacity
+#ifndef VIRT_EMIT_STEPS
+#define VIRT_EMIT_STEPS 6              // longest program the host emits and the kernel is unrolled for
+#endif
 enum { VS_END = 0, VS_CHERRY_A = 1, VS_CHERRY_B = 2, VS_EXTEND_A = 3, VS_EXTEND_B = 4, VS_JOIN = 5 };
 
 struct VStep {

@@ -58,7 +58,7 @@ template <int C>
 struct NucLds {
     double row[2][C][16];                          // [child][c][i*4+j]      the op's two branch matrices
     double col[2][C][20];                          // [child][c][state*4+i]  same as column tables (STATES children)
-    double prog[2][VIRT_MAX_STEPS][2][C][20];      // per child, step, operand: row table (16 used) or column table
+    double prog[2][VIRT_EMIT_STEPS][2][C][20];     // per child, step, operand: row table (16 used) or column table
 };
 
 enum { CH_PARTIALS = 0, CH_STATES = 1, CH_VIRTUAL = 2 };
@@ -84,7 +84,7 @@ __device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p,
     k.invLo = v4d{1.0, 1.0, 1.0, 1.0}; k.invHi = k.invLo;
     k.pa = 0x0404040404040404ull; k.pb = k.pa;
 #pragma unroll
-    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+    for (int s = 0; s < VIRT_EMIT_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
         if (type == VS_CHERRY_A || type == VS_CHERRY_B)
@@ -98,7 +98,7 @@ __device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p,
 template <int C>
 __device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* __restrict__ prog, const double* __restrict__ matrices) {
 #pragma unroll
-    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+    for (int s = 0; s < VIRT_EMIT_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) continue;
         const double* MA = matrices + (size_t)prog[s].matA * (C * 16);
@@ -112,10 +112,11 @@ __device__ __forceinline__ void virtStage(NucLds<C>& L, int child, const VStep* 
 template <int C>
 __device__ __forceinline__ v4d virtEval(const NucLds<C>& L, int child, const VStep* __restrict__ prog, const VirtPark& k, int c) {
     v4d A = v4d{1.0, 1.0, 1.0, 1.0}, B = A;
-    // a RUNTIME loop over the steps (wave-uniform trip count and branches): unrolling it for every category of both
-    // children multiplies the code by ~60 and the compile time with it
-#pragma unroll 1
-    for (int s = 0; s < VIRT_MAX_STEPS; s++) {
+    // Up to 4 categories: fully unrolled over the steps the host may emit (VIRT_EMIT_STEPS) — the compiler then
+    // interleaves the LDS reads of different steps and categories (a runtime loop is ~20 % slower: every step waits for
+    // its own LDS latency).  More categories: runtime loop, or the code (and the compile time) grows ~C * steps * 10.
+#pragma unroll (C <= 4 ? VIRT_EMIT_STEPS : 1)
+    for (int s = 0; s < VIRT_EMIT_STEPS; s++) {
         const int type = prog[s].type;
         if (type == VS_END) break;
         const double* t0 = L.prog[child][s][0][c];
