@@ -34,62 +34,73 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-// One child of one (tile, category): out_e/out_o[it] = sum_j M[4it+g][j] * X[j][2m / 2m+1]
+// B operands of one partials child for one (tile, category): b[jt] = { X[4jt+g][2m], X[4jt+g][2m+1] }
 template <int NTMAX>
-__device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int nt, int S, bool isStates,
-                                           const void* __restrict__ src, const double* __restrict__ Mc, size_t tileBase,
-                                           int pe, int P, int g, int m, int lane,
-                                           double (&oe)[NTMAX], double (&oo)[NTMAX]) {
-    if (isStates) {
-        const uint8_t* st = reinterpret_cast<const uint8_t*>(src);
-        const int se = pe < P ? st[pe] : S, so = pe + 1 < P ? st[pe + 1] : S;
+__device__ __forceinline__ void tiledLoadB(const void* __restrict__ src, size_t tileBase, int nt, int S, int g, int m, v2d (&b)[NTMAX]) {
+    const double* x = reinterpret_cast<const double*>(src) + tileBase + 2 * m;
 #pragma unroll
-        for (int it = 0; it < NTMAX; it++) {
-            const int i = 4 * it + g;
-            const bool row = it < nt && i < S;
-            oe[it] = (row && se < S) ? Mc[(size_t)i * S + se] : 1.0;
-            oo[it] = (row && so < S) ? Mc[(size_t)i * S + so] : 1.0;
+    for (int jt = 0; jt < NTMAX; jt++) {
+        // rows >= S do not exist in the buffer: read the last real row instead (branch-free) and zero the operand
+        const int j = 4 * jt + g, jc = j < S ? j : S - 1;
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + (size_t)jc * TILE));
+        b[jt] = j < S ? v : v2d{0.0, 0.0};
+    }
+}
+
+// One child's factor for the parent-state tiles [it0, it0 + IH): oe/oo[k] = sum_j M[4(it0+k)+g][j] * X[j][2m / 2m+1]
+template <int NTMAX, int IH>
+__device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int nt, int S, bool isStates, int se, int so,
+                                           const double* __restrict__ Mc, const v2d (&b)[NTMAX], int it0, int g, int fl,
+                                           double (&oe)[IH], double (&oo)[IH]) {
+    if (isStates) {
+        // column `state` of the matrix, straight from the staged fragments: M[4it+g][s] = frag[(it, s>>2)][(s&3)*4 + g]
+        const bool ge = se < S, go = so < S;
+        const double* fe = frag + (ge ? (se >> 2) * 16 + (se & 3) * 4 + g : 0);
+        const double* fo = frag + (go ? (so >> 2) * 16 + (so & 3) * 4 + g : 0);
+#pragma unroll
+        for (int k = 0; k < IH; k++) {
+            const double ve = fe[(it0 + k) * NTMAX * 16], vo = fo[(it0 + k) * NTMAX * 16];
+            oe[k] = ge ? ve : 1.0;
+            oo[k] = go ? vo : 1.0;
         }
         return;
     }
-    const double* x = reinterpret_cast<const double*>(src) + tileBase;
-    v2d b[NTMAX];
 #pragma unroll
-    for (int jt = 0; jt < NTMAX; jt++) {
-        const int j = 4 * jt + g;
-        b[jt] = (jt < nt && j < S) ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + (size_t)j * TILE + 2 * m))
-                                   : v2d{0.0, 0.0};
-    }
-#pragma unroll
-    for (int it = 0; it < NTMAX; it++) { oe[it] = 0.0; oo[it] = 0.0; }
-    const int fl = g * 4 + (lane & 3);
+    for (int k = 0; k < IH; k++) { oe[k] = 0.0; oo[k] = 0.0; }
 #pragma unroll
     for (int jt = 0; jt < NTMAX; jt++) {
         if (jt < nt) {
 #pragma unroll
-            for (int it = 0; it < NTMAX; it++) {
-                if (it < nt) {
-                    const double a = frag[(it * nt + jt) * 16 + fl];
-                    oe[it] = mfma4(a, b[jt].x, oe[it]);
-                    oo[it] = mfma4(a, b[jt].y, oo[it]);
+            for (int k = 0; k < IH; k++) {
+                if (it0 + k < nt) {
+                    const double a = frag[((it0 + k) * NTMAX + jt) * 16 + fl];
+                    oe[k] = mfma4(a, b[jt].x, oe[k]);
+                    oo[k] = mfma4(a, b[jt].y, oo[k]);
                 }
             }
         }
     }
 }
 
-template <int NTMAX>
-__global__ __launch_bounds__(MF_BLOCK) void k_pruneTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
-                                                         int P, int S, int C) {
-    extern __shared__ double frag[];          // [2][nt*nt][16] A fragments of the two branch matrices, current category
+// Child 1's factors for all parent-state tiles are accumulated first; child 2's are then produced IH tiles at a time,
+// multiplied in and stored, so that only one child's B operands and one full set of accumulators are live at once.
+// NTMAX = 5 (<= 20 states) runs at 4 waves per SIMD, NTMAX = 16 (<= 64 states) at 2 — one wave's loads and stores
+// overlap the other's MFMAs.
+// EXACT: the state count fills all NTMAX tiles (20 and 61..64 states), so every tile bound folds at compile time.
+template <int NTMAX, bool EXACT>
+__global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
+                                                                              int P, int S, int C) {
+    constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
+    extern __shared__ double frag[];          // [2][NTMAX*NTMAX][16] A fragments of the two branch matrices, current category
     const OpDesc& op = ops[blockIdx.y];
-    const int nt = (S + 3) >> 2;
+    const int nt = EXACT ? NTMAX : (S + 3) >> 2;
     const int ntile = (P + TILE - 1) / TILE;
     const int tile0 = op.pStart / TILE, tile1 = (op.pEnd + TILE - 1) / TILE;
     if (tile0 + (int)blockIdx.x * 4 >= tile1) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
     const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
-    const int fragN = nt * nt * 16;
+    constexpr int fragN = NTMAX * NTMAX * 16;
 
     for (int c = 0; c < C; c++) {
         const double* M1 = matrices + ((size_t)op.mat1 * C + c) * S * S;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_pruneTiled(const OpDesc* __restric
         for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) {
             const int child = e >= fragN, r = e - child * fragN;
             const int f = r >> 4, q = r & 15;
-            const int it = f / nt, jt = f - it * nt;
+            const int it = f / NTMAX, jt = f - it * NTMAX;
             const int i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
             frag[e] = (i < S && j < S) ? (child ? M2 : M1)[(size_t)i * S + j] : 0.0;
         }
@@ -106,9 +117,22 @@ __global__ __launch_bounds__(MF_BLOCK) void k_pruneTiled(const OpDesc* __restric
         for (int tile = tile0 + blockIdx.x * 4 + wave; tile < tile1; tile += gridDim.x * 4) {
             const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
             const int pe = tile * TILE + 2 * m;           // even pattern of this lane; odd = pe + 1
-            double re[NTMAX], ro[NTMAX], te[NTMAX], to[NTMAX];
-            tiledChild<NTMAX>(frag, nt, S, st1, op.child1, M1, tileBase, pe, P, g, m, lane, re, ro);
-            tiledChild<NTMAX>(frag + fragN, nt, S, st2, op.child2, M2, tileBase, pe, P, g, m, lane, te, to);
+            v2d b[NTMAX];
+            double re[NTMAX], ro[NTMAX];
+            int se = S, so = S;
+            if (st1) {
+                const uint8_t* st = reinterpret_cast<const uint8_t*>(op.child1);
+                if (pe < P) se = st[pe];
+                if (pe + 1 < P) so = st[pe + 1];
+            } else tiledLoadB<NTMAX>(op.child1, tileBase, nt, S, g, m, b);
+            tiledChild<NTMAX, NTMAX>(frag, nt, S, st1, se, so, M1, b, 0, g, fl, re, ro);
+            if (NTMAX > 5) __builtin_amdgcn_sched_barrier(0);     // keep child 2's operands out of child 1's register budget
+            se = S; so = S;
+            if (st2) {
+                const uint8_t* st = reinterpret_cast<const uint8_t*>(op.child2);
+                if (pe < P) se = st[pe];
+                if (pe + 1 < P) so = st[pe + 1];
+            } else tiledLoadB<NTMAX>(op.child2, tileBase, nt, S, g, m, b);
             double inve = 1.0, invo = 1.0;
             if (!op.scaleWrite && op.scaleRead) {
                 if (pe < P) inve = 1.0 / op.scaleRead[pe];
@@ -117,13 +141,20 @@ __global__ __launch_bounds__(MF_BLOCK) void k_pruneTiled(const OpDesc* __restric
             const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
             double* d = op.dest + tileBase;
 #pragma unroll
-            for (int it = 0; it < NTMAX; it++) {
-                const int i = 4 * it + g;
-                if (it < nt && i < S) {
-                    v2d o; o.x = re[it] * te[it] * inve; o.y = ro[it] * to[it] * invo;
-                    double* q = d + (size_t)i * TILE + 2 * m;
-                    if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(q));
-                    else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+            for (int it0 = 0; it0 < NTMAX; it0 += IH) {
+                if (it0 < nt) {
+                    double te[IH], to[IH];
+                    tiledChild<NTMAX, IH>(frag + fragN, nt, S, st2, se, so, M2, b, it0, g, fl, te, to);
+#pragma unroll
+                    for (int k = 0; k < IH; k++) {
+                        const int i = 4 * (it0 + k) + g;
+                        if (it0 + k < nt && i < S) {
+                            v2d o; o.x = re[it0 + k] * te[k] * inve; o.y = ro[it0 + k] * to[k] * invo;
+                            double* q = d + (size_t)i * TILE + 2 * m;
+                            if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(q));
+                            else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+                        }
+                    }
                 }
             }
         }
@@ -179,17 +210,21 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
                            bool anyScaleWrite) {
     if (nOps <= 0) return;
     const int nt = (S + 3) / 4;
-    const size_t lds = (size_t)2 * nt * nt * 16 * sizeof(double);
     dim3 grid(tiledBlocksPerOp(P, nOps), nOps), block(MF_BLOCK);
     if (nt <= 5) {
-        hipLaunchKernelGGL(k_pruneTiled<5>, grid, block, lds, stream, dOps, matrices, P, S, C);
+        const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double);
+        if (nt == 5) hipLaunchKernelGGL((k_pruneTiled<5, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        else hipLaunchKernelGGL((k_pruneTiled<5, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
     } else {
+        const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);          // 64 KiB: above the default 48 KiB cap
         static bool granted = false;
-        if (!granted && lds > 48 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneTiled<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (!granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneTiled<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneTiled<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             granted = true;
         }
-        hipLaunchKernelGGL(k_pruneTiled<16>, grid, block, lds, stream, dOps, matrices, P, S, C);
+        if (nt == 16) hipLaunchKernelGGL((k_pruneTiled<16, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        else hipLaunchKernelGGL((k_pruneTiled<16, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
     }
     if (anyScaleWrite) hipLaunchKernelGGL(k_rescaleTiled, grid, block, 0, stream, dOps, P, S, C);
 }
