@@ -24,6 +24,14 @@ constexpr int VIRT_MAX_STEPS = 8;     // descriptor / snapshot capacity
 #endif
 enum { VS_END = 0, VS_CHERRY_A = 1, VS_CHERRY_B = 2, VS_EXTEND_A = 3, VS_EXTEND_B = 4, VS_JOIN = 5 };
 
+// Pointers read out of a descriptor are generic ("flat") to the compiler; flat loads count against the LDS counter as well
+// as the vector-memory one and cannot use scalar-base addressing.  Every buffer the engine hands the kernels lives in
+// HBM, so device code converts descriptor pointers with gptr() before dereferencing.
+#if defined(__HIPCC__)
+#define MI355_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ T MI355_GLOBAL* gptr(T* p) { return (T MI355_GLOBAL*)p; }
+#endif
+
 struct VStep {
     const uint8_t* tipA;        // CHERRY: first tip's states; EXTEND/JOIN: unused
     const uint8_t* tipB;        // CHERRY: second tip; EXTEND: the tip

@@ -22,6 +22,7 @@
 // Restates src/dr/oldevomodel/treelikelihood/GeneralLikelihoodCore.java:52-203 (same arithmetic, different
 // summation order: 4-wide partial sums accumulate in the matrix core).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mi355 {
 
@@ -35,16 +36,34 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
 }
 
 // B operands of one partials child for one (tile, category): b[jt] = { X[4jt+g][2m], X[4jt+g][2m+1] }
-template <int NTMAX>
-__device__ __forceinline__ void tiledLoadB(const void* __restrict__ src, size_t tileBase, int nt, int S, int g, int m, v2d (&b)[NTMAX]) {
-    const double* x = reinterpret_cast<const double*>(src) + tileBase + 2 * m;
+template <int NTMAX, bool EXACT>
+__device__ __forceinline__ void tiledLoadB(const void* __restrict__ src, size_t tileBase, int S, int g, int m, v2d (&b)[NTMAX]) {
+    // wave-uniform base + one 32-bit lane offset; the tile rows are immediates
+    const char* x = reinterpret_cast<const char*>(reinterpret_cast<const double*>(src) + tileBase);
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
 #pragma unroll
     for (int jt = 0; jt < NTMAX; jt++) {
-        // rows >= S do not exist in the buffer: read the last real row instead (branch-free) and zero the operand
-        const int j = 4 * jt + g, jc = j < S ? j : S - 1;
-        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + (size_t)jc * TILE));
-        b[jt] = j < S ? v : v2d{0.0, 0.0};
+        if (EXACT && jt < NTMAX - 1) {
+            b[jt] = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (lane8 + (unsigned)jt * 4u * TILE * 8u))));
+        } else {
+            // rows >= S do not exist in the buffer: read the last real row instead (branch-free) and zero the operand
+            const int j = 4 * jt + g, jc = j < S ? j : S - 1;
+            const v2d v = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (unsigned)(jc * TILE + 2 * m) * 8u)));
+            b[jt] = j < S ? v : v2d{0.0, 0.0};
+        }
     }
+}
+
+// child 1 of tile `tile`: its B operands (partials) or its two state codes (compact tip)
+template <int NTMAX, bool EXACT>
+__device__ __forceinline__ void tiledFetch1(const OpDesc& op, bool st1, int c, int ntile, int tile, int P, int S, int g, int m,
+                                            v2d (&b)[NTMAX], int& se, int& so) {
+    if (st1) {
+        const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child1));
+        const int pe = tile * TILE + 2 * m;
+        se = pe < P ? st[pe] : S;
+        so = pe + 1 < P ? st[pe + 1] : S;
+    } else tiledLoadB<NTMAX, EXACT>(op.child1, ((size_t)c * ntile + tile) * S * TILE, S, g, m, b);
 }
 
 // One child's factor for the parent-state tiles [it0, it0 + IH): oe/oo[k] = sum_j M[4(it0+k)+g][j] * X[j][2m / 2m+1]
@@ -83,29 +102,37 @@ __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int 
 }
 
 // Child 1's factors for all parent-state tiles are accumulated first; child 2's are then produced IH tiles at a time,
-// multiplied in and stored, so that only one child's B operands and one full set of accumulators are live at once.
-// NTMAX = 5 (<= 20 states) runs at 4 waves per SIMD, NTMAX = 16 (<= 64 states) at 2 — one wave's loads and stores
-// overlap the other's MFMAs.
+// multiplied in and stored.  The loads are software-pipelined against the MFMAs: child 2's B operands are requested before
+// child 1's MFMAs start, the next tile's child-1 operands before child 2's (and the first tile's before the matrix staging).
+// NTMAX = 5 (<= 20 states) runs at 4 waves per SIMD, NTMAX = 16 (<= 64 states) at 2.
 // EXACT: the state count fills all NTMAX tiles (20 and 61..64 states), so every tile bound folds at compile time.
-template <int NTMAX, bool EXACT>
+// PIPE: 0 = loads where they are needed, 1 = child 2 early, 2 = child 2 early + next tile's child 1 (register budget permitting).
+template <int NTMAX, bool EXACT, int PIPE>
 __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
                                                                               int P, int S, int C) {
     constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
     extern __shared__ double frag[];          // [2][NTMAX*NTMAX][16] A fragments of the two branch matrices, current category
-    const OpDesc& op = ops[blockIdx.y];
+    const OpDesc& op = ops[blockIdx.y / C];      // one (op, rate category) per grid row: single-op levels still fill the chip
+    const int c = blockIdx.y % C;
     const int nt = EXACT ? NTMAX : (S + 3) >> 2;
     const int ntile = (P + TILE - 1) / TILE;
     const int tile0 = op.pStart / TILE, tile1 = (op.pEnd + TILE - 1) / TILE;
     if (tile0 + (int)blockIdx.x * 4 >= tile1) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: everything derived from the tile index stays in SGPRs
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int fl = g * 4 + (lane & 3);
     const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
     constexpr int fragN = NTMAX * NTMAX * 16;
+    const int tstep = gridDim.x * 4;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
 
-    for (int c = 0; c < C; c++) {
+    {
         const double* M1 = matrices + ((size_t)op.mat1 * C + c) * S * S;
         const double* M2 = matrices + ((size_t)op.mat2 * C + c) * S * S;
-        __syncthreads();
+        int tile = tile0 + blockIdx.x * 4 + wave;
+        v2d b1[NTMAX], b2[NTMAX];
+        int se1 = S, so1 = S;
+        if (PIPE == 2 && tile < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);   // in flight across the staging
         for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) {
             const int child = e >= fragN, r = e - child * fragN;
             const int f = r >> 4, q = r & 15;
@@ -114,44 +141,44 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
             frag[e] = (i < S && j < S) ? (child ? M2 : M1)[(size_t)i * S + j] : 0.0;
         }
         __syncthreads();
-        for (int tile = tile0 + blockIdx.x * 4 + wave; tile < tile1; tile += gridDim.x * 4) {
+        for (; tile < tile1; tile += tstep) {
             const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
             const int pe = tile * TILE + 2 * m;           // even pattern of this lane; odd = pe + 1
-            v2d b[NTMAX];
-            double re[NTMAX], ro[NTMAX];
-            int se = S, so = S;
-            if (st1) {
-                const uint8_t* st = reinterpret_cast<const uint8_t*>(op.child1);
-                if (pe < P) se = st[pe];
-                if (pe + 1 < P) so = st[pe + 1];
-            } else tiledLoadB<NTMAX>(op.child1, tileBase, nt, S, g, m, b);
-            tiledChild<NTMAX, NTMAX>(frag, nt, S, st1, se, so, M1, b, 0, g, fl, re, ro);
-            if (NTMAX > 5) __builtin_amdgcn_sched_barrier(0);     // keep child 2's operands out of child 1's register budget
-            se = S; so = S;
+            if (PIPE < 2) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);
+            // child 2's operands fly while child 1's MFMAs run
+            int se2 = S, so2 = S;
             if (st2) {
-                const uint8_t* st = reinterpret_cast<const uint8_t*>(op.child2);
-                if (pe < P) se = st[pe];
-                if (pe + 1 < P) so = st[pe + 1];
-            } else tiledLoadB<NTMAX>(op.child2, tileBase, nt, S, g, m, b);
+                const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child2));
+                if (pe < P) se2 = st[pe];
+                if (pe + 1 < P) so2 = st[pe + 1];
+            } else if (PIPE >= 1) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
             double inve = 1.0, invo = 1.0;
             if (!op.scaleWrite && op.scaleRead) {
-                if (pe < P) inve = 1.0 / op.scaleRead[pe];
-                if (pe + 1 < P) invo = 1.0 / op.scaleRead[pe + 1];
+                const double MI355_GLOBAL* sr = gptr(op.scaleRead);
+                if (pe < P) inve = 1.0 / sr[pe];
+                if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
             }
+            double re[NTMAX], ro[NTMAX];
+            tiledChild<NTMAX, NTMAX>(frag, nt, S, st1, se1, so1, M1, b1, 0, g, fl, re, ro);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE == 0 && !st2) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
+            // the next tile's child-1 operands fly while child 2's MFMAs run
+            if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
+            __builtin_amdgcn_sched_barrier(0);
             const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
             double* d = op.dest + tileBase;
 #pragma unroll
             for (int it0 = 0; it0 < NTMAX; it0 += IH) {
                 if (it0 < nt) {
                     double te[IH], to[IH];
-                    tiledChild<NTMAX, IH>(frag + fragN, nt, S, st2, se, so, M2, b, it0, g, fl, te, to);
+                    tiledChild<NTMAX, IH>(frag + fragN, nt, S, st2, se2, so2, M2, b2, it0, g, fl, te, to);
 #pragma unroll
                     for (int k = 0; k < IH; k++) {
                         const int i = 4 * (it0 + k) + g;
                         if (it0 + k < nt && i < S) {
                             v2d o; o.x = re[it0 + k] * te[k] * inve; o.y = ro[it0 + k] * to[k] * invo;
-                            double* q = d + (size_t)i * TILE + 2 * m;
-                            if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(q));
+                            double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
+                            if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
                             else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
                         }
                     }
@@ -198,10 +225,12 @@ __global__ __launch_bounds__(MF_BLOCK) void k_rescaleTiled(const OpDesc* __restr
     }
 }
 
-int tiledBlocksPerOp(int P, int nOps) {
+// workgroups per grid row (one row = one (op, category) for pruning, one op for the rescale pass): enough rows x groups for
+// about `target` workgroups in the launch, each restaging its two matrices once and then streaming its share of the tiles
+static int tiledBlocksPerRow(int P, int rows, int target) {
     const int tiles = (P + TILE - 1) / TILE;
-    int blocks = (tiles + 3) / 4;
-    int per = 1024 / (nOps > 0 ? nOps : 1);          // ~4 workgroups per CU in total; each restages the matrices per category
+    const int blocks = (tiles + 3) / 4;
+    int per = target / (rows > 0 ? rows : 1);
     if (per < 1) per = 1;
     return blocks < per ? blocks : per;
 }
@@ -209,24 +238,39 @@ int tiledBlocksPerOp(int P, int nOps) {
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
                            bool anyScaleWrite) {
     if (nOps <= 0) return;
+    const int maxOps = 65535 / C;                    // grid.y limit
+    if (nOps > maxOps) {
+        for (int o = 0; o < nOps; o += maxOps)
+            launchPruneLevelTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C, anyScaleWrite);
+        return;
+    }
     const int nt = (S + 3) / 4;
-    dim3 grid(tiledBlocksPerOp(P, nOps), nOps), block(MF_BLOCK);
+    // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
+    dim3 grid(tiledBlocksPerRow(P, nOps * C, nt <= 5 ? 2048 : 1024), nOps * C), block(MF_BLOCK);
+    static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
+#define TILED_LAUNCH(NT, EX, PI) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI>), grid, block, lds, stream, dOps, matrices, P, S, C)
     if (nt <= 5) {
         const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double);
-        if (nt == 5) hipLaunchKernelGGL((k_pruneTiled<5, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
-        else hipLaunchKernelGGL((k_pruneTiled<5, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        if (nt < 5) TILED_LAUNCH(5, false, 0);
+        else if (pipe >= 2) TILED_LAUNCH(5, true, 2);
+        else if (pipe == 1) TILED_LAUNCH(5, true, 1);
+        else TILED_LAUNCH(5, true, 0);
     } else {
         const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);          // 64 KiB: above the default 48 KiB cap
         static bool granted = false;
         if (!granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneTiled<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneTiled<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const void* fns[] = {(const void*)k_pruneTiled<16, false, 0>, (const void*)k_pruneTiled<16, true, 0>,
+                                 (const void*)k_pruneTiled<16, true, 1>, (const void*)k_pruneTiled<16, true, 2>};
+            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             granted = true;
         }
-        if (nt == 16) hipLaunchKernelGGL((k_pruneTiled<16, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
-        else hipLaunchKernelGGL((k_pruneTiled<16, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        if (nt < 16) TILED_LAUNCH(16, false, 0);
+        else if (pipe >= 2) TILED_LAUNCH(16, true, 2);
+        else if (pipe == 1) TILED_LAUNCH(16, true, 1);
+        else TILED_LAUNCH(16, true, 0);
     }
-    if (anyScaleWrite) hipLaunchKernelGGL(k_rescaleTiled, grid, block, 0, stream, dOps, P, S, C);
+#undef TILED_LAUNCH
+    if (anyScaleWrite) hipLaunchKernelGGL(k_rescaleTiled, dim3(tiledBlocksPerRow(P, nOps, 2048), nOps), block, 0, stream, dOps, P, S, C);
 }
 
 // root integration on the T32 layout: thread per pattern, consecutive lanes = consecutive patterns of a tile

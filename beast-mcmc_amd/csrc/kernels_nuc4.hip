@@ -27,10 +27,12 @@ constexpr int NUC_BLOCK = 256;
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 template <bool NT> __device__ __forceinline__ v4d ldv4(const double* p) {
-    return NT ? __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p)) : *reinterpret_cast<const v4d*>(p);
+    const v4d MI355_GLOBAL* q = gptr(reinterpret_cast<const v4d*>(p));
+    return NT ? __builtin_nontemporal_load(q) : *q;
 }
 template <bool NT> __device__ __forceinline__ void stv4(double* p, v4d v) {
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4d*>(p)); else *reinterpret_cast<v4d*>(p) = v;
+    v4d MI355_GLOBAL* q = gptr(reinterpret_cast<v4d*>(p));
+    if (NT) __builtin_nontemporal_store(v, q); else *q = v;
 }
 
 // THE arithmetic of one node, shared by the ordinary path and by the virtual-child programs so both give bitwise the
@@ -88,10 +90,10 @@ __device__ __forceinline__ void virtIssue(const VStep* __restrict__ prog, int p,
         const int type = prog[s].type;
         if (type == VS_END) continue;
         if (type == VS_CHERRY_A || type == VS_CHERRY_B)
-            k.pa = (k.pa & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipA[p] << (8 * s));
+            k.pa = (k.pa & ~(0xffull << (8 * s))) | ((unsigned long long)gptr(prog[s].tipA)[p] << (8 * s));
         if (type != VS_JOIN)
-            k.pb = (k.pb & ~(0xffull << (8 * s))) | ((unsigned long long)prog[s].tipB[p] << (8 * s));
-        if (prog[s].scale) { const double v = 1.0 / prog[s].scale[p]; if (s < 4) k.invLo[s] = v; else k.invHi[s - 4] = v; }
+            k.pb = (k.pb & ~(0xffull << (8 * s))) | ((unsigned long long)gptr(prog[s].tipB)[p] << (8 * s));
+        if (prog[s].scale) { const double v = 1.0 / gptr(prog[s].scale)[p]; if (s < 4) k.invLo[s] = v; else k.invHi[s - 4] = v; }
     }
 }
 
@@ -159,15 +161,15 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
             const double* x = reinterpret_cast<const double*>(op.child1);
 #pragma unroll
             for (int c = 0; c < C; c++) x1[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
-        } else if (k1 == CH_STATES) w1 = reinterpret_cast<const uint8_t*>(op.child1)[p];
+        } else if (k1 == CH_STATES) w1 = gptr(reinterpret_cast<const uint8_t*>(op.child1))[p];
         else virtIssue(op.prog[0], p, v1);
         if (k2 == CH_PARTIALS) {
             const double* x = reinterpret_cast<const double*>(op.child2);
 #pragma unroll
             for (int c = 0; c < C; c++) x2[c] = ldv4<(NT & 1) != 0>(x + ((size_t)c * P + p) * 4);
-        } else if (k2 == CH_STATES) w2 = reinterpret_cast<const uint8_t*>(op.child2)[p];
+        } else if (k2 == CH_STATES) w2 = gptr(reinterpret_cast<const uint8_t*>(op.child2))[p];
         else virtIssue(op.prog[1], p, v2);
-        if (!op.scaleWrite && op.scaleRead) invRead = 1.0 / op.scaleRead[p];
+        if (!op.scaleWrite && op.scaleRead) invRead = 1.0 / gptr(op.scaleRead)[p];
     }
     // ---- ... then the column tables are staged while those requests are in flight
     const double* G1 = matrices + (size_t)op.mat1 * (C * 16);
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NUC_BLOCK, MINW) void k_prune4(const OpDesc* __rest
 #pragma unroll
         for (int c = 0; c < C; c++) m = fmax(fmax(fmax(m, a[c].x), fmax(a[c].y, a[c].z)), a[c].w);
         if (!(m > 0.0)) m = 1.0;
-        op.scaleWrite[p] = m;
+        gptr(op.scaleWrite)[p] = m;
         const double inv = 1.0 / m;
 #pragma unroll
         for (int c = 0; c < C; c++) a[c] = a[c] * inv;
