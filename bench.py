@@ -50,8 +50,8 @@ def eval_bytes(wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="A", choices=["A", "B", "C", "D"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
@@ -266,10 +266,32 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
     rel = float(np.max(np.abs(site_gpu - site_cpu) / np.abs(site_cpu)))
     o.close()
     sample_evals_per_s = reps / dt
+    # the same port on ONE core (SURVEY 8d asks for both): a tenth of the sample, at most ~10 s
+    n1 = max(1, n // 10)
+    sub1 = Workload(wl.name + "-sample1", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
+                    np.ascontiguousarray(wl.tip_states[:, idx[:n1]]), wl.weights[idx[:n1]], wl.state_count)
+    lib.lib.oracle_set_threads(1)
+    try:
+        o1 = BeagleTreeLikelihood(sub1, library=lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+        o1.getLogLikelihood()
+        reps1, t1 = 0, time.perf_counter()
+        while True:
+            o1.set_substitution_model(wl.eig, wl.freqs)
+            o1.getLogLikelihood()
+            reps1 += 1
+            dt1 = time.perf_counter() - t1
+            if dt1 > 8.0 or reps1 >= 50:
+                break
+        o1.close()
+    finally:
+        lib.lib.oracle_set_threads(int(threads))
+    one_core = reps1 / dt1 * n1 / wl.pattern_count
     return {"value": round(sample_evals_per_s * n / wl.pattern_count, 4), "unit": "evals/s", "cores": int(threads),
             "kind": "port",
             "sample": "%d of %d patterns, full %d-taxon tree, %d evaluations in %.1f s on %d OpenMP threads; scaled by %d/%d"
                       % (n, wl.pattern_count, wl.tip_count, reps, dt, threads, n, wl.pattern_count),
+            "single_core_value": round(one_core, 5),
+            "single_core_sample": "%d patterns, %d evaluations in %.1f s on 1 thread" % (n1, reps1, dt1),
             "gpu_vs_cpu_site_lnL_max_rel_err": rel}
 
 
