@@ -110,6 +110,7 @@ _PROTOS = {
     "TransposeTransitionMatrices": ([C.c_int, _IP, _IP, C.c_int], C.c_int),
     "UpdatePrePartials": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
     "UpdatePrePartialsByPartition": ([C.c_int, _IP, C.c_int], C.c_int),
+    "CalculateEdgeDifferentials": ([C.c_int, _IP, _IP, _IP, _IP, C.c_int, _DP, _DP, _DP], C.c_int),
 }
 
 # symbols every engine library must export (tests assert this list against include/beagle_mi355.h)
@@ -347,6 +348,37 @@ class Beagle:
         outSumLogLikelihood[0] = tot[0]
         if rc != 0 and rc != -8:
             raise BeagleException("calculateRootLogLikelihoodsByPartition", rc)
+
+    # ---- pre-order partials and branch gradients (AbstractBeagleGradientDelegate / ...BranchGradientDelegate) ----
+    def setRootPrePartials(self, bufferIndices, stateFrequenciesIndices, count):
+        b, f = _i(bufferIndices), _i(stateFrequenciesIndices)
+        self._check("setRootPrePartials", self._f["SetRootPrePartials"](self.instance, _ip(b), _ip(f), count))
+
+    def setDifferentialMatrix(self, matrixIndex, matrix):
+        m = _d(matrix)
+        assert m.size == self.stateCount * self.stateCount * self.categoryCount
+        self._check("setDifferentialMatrix", self._f["SetDifferentialMatrix"](self.instance, matrixIndex, _dp(m)))
+
+    def transposeTransitionMatrices(self, inputIndices, resultIndices, count):
+        a, b = _i(inputIndices), _i(resultIndices)
+        self._check("transposeTransitionMatrices",
+                    self._f["TransposeTransitionMatrices"](self.instance, _ip(a), _ip(b), count))
+
+    def updatePrePartials(self, operations, operationCount, cumulativeScaleIndex=NONE):
+        ops = _i(operations)
+        self._check("updatePrePartials", self._f["UpdatePrePartials"](self.instance, _ip(ops), operationCount,
+                                                                     cumulativeScaleIndex))
+
+    def calculateEdgeDifferentials(self, postBufferIndices, preBufferIndices, derivativeMatrixIndices,
+                                   categoryWeightsIndices, count, want_per_pattern=False):
+        """-> (outSumDerivatives[count], outSumSquaredDerivatives[count], outDerivatives[count, P] or None)"""
+        po, pr, dm, cw = _i(postBufferIndices), _i(preBufferIndices), _i(derivativeMatrixIndices), _i(categoryWeightsIndices)
+        s1, s2 = np.zeros(count), np.zeros(count)
+        per = np.zeros((count, self.patternCount)) if want_per_pattern else None
+        self._check("calculateEdgeDifferentials",
+                    self._f["CalculateEdgeDifferentials"](self.instance, _ip(po), _ip(pr), _ip(dm), _ip(cw), count,
+                                                          _dp(per) if per is not None else None, _dp(s1), _dp(s2)))
+        return s1, s2, per
 
     def getSiteLogLikelihoods(self, out=None):
         if out is None:

@@ -212,14 +212,37 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
 /* getSiteLogLikelihoods (I[D)I — BeagleTreeLikelihood.java:1050 */
 int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods);
 
-/* ---- entry points that exist in the binding but are outside SURVEY §8 (a)-(e): they are
- * exported so the JNI shim links, and return BEAGLE_ERROR_NO_IMPLEMENTATION (-7). ------- */
+/* ---- pre-order partials and branch gradients ---------------------------
+ * Semantics from the callers (the implementing library is not in the reference tree):
+ * src/dr/evomodel/treedatalikelihood/preorder/AbstractBeagleGradientDelegate.java:115-151, 207-221 and
+ * AbstractBeagleBranchGradientDelegate.java:52-95 (+ the arithmetic spelled out at :103-140). */
+
+/* setRootPrePartials (I[I[II)I — pre-order partial of a root = its state frequencies, replicated over
+ * patterns and categories (what AbstractBeagleGradientDelegate.java:142-151 does through setPartials). */
 int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* stateFrequenciesIndices, int count);
+/* setDifferentialMatrix (II[D)I — HomogenousSubstitutionModelDelegate.java:179-193: stateCount^2 * categoryCount
+ * doubles into a matrix buffer (the infinitesimal matrix scaled per category rate,
+ * discrete/DiscreteTraitBranchRateDelegate.java:49-89). */
 int beagleSetDifferentialMatrix(int instance, int matrixIndex, const double* inMatrix);
+/* transposeTransitionMatrices (I[I[II)I — AbstractBeagleGradientDelegate.java:93-105: result[n] = input[n]^T per category */
+int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount);
+/* updatePrePartials (I[III)I — AbstractBeagleGradientDelegate.java:120.  7-int tuples
+ * {pre(child) dest, writeScale, readScale, pre(parent), matrix(child), post(sibling), matrix(sibling)} (:211-217), matrices
+ * untransposed:  dest[j] = sum_i P_child[i][j] * ( pre(parent)[i] * sum_k P_sib[i][k] post(sib)[k] ).
+ * The list is in pre-order (a parent's op before its children's); the engine levelises it. */
+int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex);
+/* calculateEdgeDifferentials (I[I[I[I[II[D[D[D)I — AbstractBeagleBranchGradientDelegate.java:82-92.  Per edge e and
+ * pattern p: num = sum_c w_c sum_j pre[c,p,j] sum_k D[c][j][k] post[c,p,k], den = sum_c w_c sum_j pre[c,p,j] post[c,p,j];
+ * outSumDerivatives[e] = sum_p weight_p num/den, outSumSquaredDerivatives[e] = sum_p weight_p (num/den)^2,
+ * outDerivatives[e*P + p] = num/den.  Any of the three outputs may be NULL (BEAST passes null for outDerivatives). */
+int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
+                                     const int* derivativeMatrixIndices, const int* categoryWeightsIndices, int count,
+                                     double* outDerivatives, double* outSumDerivatives, double* outSumSquaredDerivatives);
+
+/* ---- entry points that exist in the binding but are not built yet: exported so the JNI shim links, and
+ * return BEAGLE_ERROR_NO_IMPLEMENTATION (-7). ------------------------------------------------------ */
 int beagleAddTransitionMatrices(int instance, const int* firstIndices, const int* secondIndices,
                                 const int* resultIndices, int matrixCount);
-int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount);
-int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex);
 int beagleUpdatePrePartialsByPartition(int instance, const int* operations, int operationCount);
 
 /* ---- MI355X extensions (not part of the reference binding) -------------------------- */

@@ -488,6 +488,163 @@ int oracle_beagleGetSiteLogLikelihoods(int h, double* out) {
     memcpy(out, in->siteLogL, sizeof(double) * in->P); return BEAGLE_SUCCESS;
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Pre-order partials and branch gradients.
+ *
+ * Call protocol restated from src/dr/evomodel/treedatalikelihood/preorder/AbstractBeagleGradientDelegate.java:
+ *   :142-151  root pre-order partial = the state frequencies replicated over patterns and categories (setPartials)
+ *   :211-217  op tuple {pre(child), NONE, NONE, pre(parent), matrix(child), post(sibling), matrix(sibling)};
+ *             the matrix indices are the ordinary (untransposed) branch matrices — the library owns any transpose
+ *             (BeagleDataLikelihoodDelegate.java:393-395 asks for PREORDER_TRANSPOSE_AUTO above 4 states)
+ *   :120      updatePrePartials(ops, n, NONE)
+ * so   pre(child)[j] = sum_i P_child[i][j] * ( pre(parent)[i] * sum_k P_sib[i][k] post(sib)[k] ),
+ * which keeps  sum_j pre(child)[j] post(child)[j] = sum_i pre(parent)[i] post(parent)[i] = the site likelihood.
+ * Edge derivatives: the arithmetic spelled out in AbstractBeagleBranchGradientDelegate.java:120-140 (checkReduction):
+ *   numerator[p]   = sum_c w_c sum_j pre[c,p,j] sum_k D[c][j][k] post[c,p,k]
+ *   denominator[p] = sum_c w_c sum_j pre[c,p,j] post[c,p,j]
+ *   outSum[e] = sum_p weight_p num/den,  outSumSquared[e] = sum_p weight_p (num/den)^2,  outDerivatives[e*P+p] = num/den
+ * with D the C*S*S "differential matrix" the caller stored with setDifferentialMatrix (the infinitesimal matrix scaled
+ * by each category rate, discrete/DiscreteTraitBranchRateDelegate.java:49-89).
+ * The library that implements these natives for BEAST (beagle-lib) is not in the reference: parity UNPINNED by golden
+ * values; tests/test_oracle_golden.py checks the gradients against central finite differences of the pinned lnL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int oracle_beagleSetDifferentialMatrix(int h, int m, const double* inM) {
+    return oracle_beagleSetTransitionMatrix(h, m, inM, 0.0);
+}
+
+int oracle_beagleTransposeTransitionMatrices(int h, const int* inIdx, const int* outIdx, int count) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    const int S = in->S, C = in->C;
+    for (int n = 0; n < count; n++) {
+        int a = inIdx[n], b = outIdx[n];
+        if (a < 0 || a >= in->matrixCount || b < 0 || b >= in->matrixCount || a == b) return BEAGLE_ERROR_OUT_OF_RANGE;
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < S; i++)
+                for (int j = 0; j < S; j++)
+                    in->matrices[b][(size_t)c * S * S + j * S + i] = in->matrices[a][(size_t)c * S * S + i * S + j];
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int oracle_beagleSetRootPrePartials(int h, const int* bufIdx, const int* freqIdx, int count) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    for (int n = 0; n < count; n++) {
+        if (bufIdx[n] < 0 || bufIdx[n] >= in->partialsCount || freqIdx[n] < 0 || freqIdx[n] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+        double* d = partials_buf(in, bufIdx[n]);
+        const double* pi = in->freqs[freqIdx[n]];
+        for (size_t e = 0; e < (size_t)in->C * in->P; e++) memcpy(d + e * in->S, pi, sizeof(double) * in->S);
+    }
+    return BEAGLE_SUCCESS;
+}
+
+/* one pre-order op on the pattern range [p0, p1); sib is partials (sx) or compact states (ss) */
+static void pre_partials(const Inst* in, const double* parent, const double* mChild, const int* ss, const double* sx,
+                         const double* mSib, double* dest, int p0, int p1) {
+    const int S = in->S, P = in->P;
+    double* v = (double*)malloc(sizeof(double) * S);
+    for (int l = 0; l < in->C; l++) {
+        const double* MC = mChild + (size_t)l * S * S; const double* MS = mSib + (size_t)l * S * S;
+        for (int k = p0; k < p1; k++) {
+            const double* u = parent + ((size_t)l * P + k) * S;
+            double* d = dest + ((size_t)l * P + k) * S;
+            for (int i = 0; i < S; i++) {
+                double f;
+                if (ss) f = (ss[k] < S) ? MS[i * S + ss[k]] : 1.0;
+                else { const double* x = sx + ((size_t)l * P + k) * S; f = 0.0; for (int j = 0; j < S; j++) f += MS[i * S + j] * x[j]; }
+                v[i] = u[i] * f;
+            }
+            for (int j = 0; j < S; j++) {
+                double sum = 0.0;
+                for (int i = 0; i < S; i++) sum += v[i] * MC[i * S + j];
+                d[j] = sum;
+            }
+        }
+    }
+    free(v);
+}
+
+static int pre_ops(int h, const int* ops, int count, int tuple, int cumIdx) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (tuple != BEAGLE_OP_COUNT) return BEAGLE_ERROR_NO_IMPLEMENTATION;   /* partitioned instances: not restated */
+    for (int o = 0; o < count; o++) {
+        const int* op = ops + o * tuple;
+        int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        if (dest < 0 || dest >= in->partialsCount || par < 0 || par >= in->partialsCount || sib < 0 || sib >= in->partialsCount ||
+            mc < 0 || mc >= in->matrixCount || ms < 0 || ms >= in->matrixCount || wS >= in->scaleCount || rS >= in->scaleCount ||
+            !in->partials[par] || (!in->tipStates[sib] && !in->partials[sib]) || dest == par || dest == sib) return BEAGLE_ERROR_OUT_OF_RANGE;
+        double* d = partials_buf(in, dest);
+        free(in->tipStates[dest]); in->tipStates[dest] = NULL;
+        const double* parent = in->partials[par];
+        const int* ss = in->tipStates[sib]; const double* sx = in->partials[sib];
+        double* wBuf = wS >= 0 ? scale_buf(in, wS) : NULL;
+        const double* rBuf = (wS < 0 && rS >= 0) ? scale_buf(in, rS) : NULL;
+        #pragma omp parallel
+        {
+            int nt = 1, tid = 0;
+#ifdef _OPENMP
+            nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+            const int div = in->P / nt, rem = in->P % nt;
+            const int p0 = tid * div + (tid < rem ? tid : rem), p1 = p0 + div + (tid < rem ? 1 : 0);
+            if (p1 > p0) {
+                pre_partials(in, parent, in->matrices[mc], ss, sx, in->matrices[ms], d, p0, p1);
+                if (wBuf)      rescale_write(in, d, wBuf, p0, p1);
+                else if (rBuf) rescale_read(in, d, rBuf, p0, p1);
+            }
+        }
+        if (wS >= 0 && cumIdx != BEAGLE_OP_NONE) oracle_beagleAccumulateScaleFactors(h, &wS, 1, cumIdx);
+    }
+    return BEAGLE_SUCCESS;
+}
+int oracle_beagleUpdatePrePartials(int h, const int* ops, int count, int cumIdx) { return pre_ops(h, ops, count, BEAGLE_OP_COUNT, cumIdx); }
+
+int oracle_beagleCalculateEdgeDifferentials(int h, const int* postIdx, const int* preIdx, const int* dIdx, const int* wIdx, int count,
+                                            double* outDerivatives, double* outSum, double* outSumSquared) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    const int S = in->S, P = in->P, C = in->C;
+    if (!wIdx || wIdx[0] < 0 || wIdx[0] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const double* w = in->catWeights[wIdx[0]];
+    double* deriv = (double*)malloc(sizeof(double) * P);
+    for (int e = 0; e < count; e++) {
+        int po = postIdx[e], pr = preIdx[e], dm = dIdx[e];
+        if (po < 0 || po >= in->partialsCount || pr < 0 || pr >= in->partialsCount || dm < 0 || dm >= in->matrixCount ||
+            !in->partials[pr] || (!in->tipStates[po] && !in->partials[po])) { free(deriv); return BEAGLE_ERROR_OUT_OF_RANGE; }
+        const int* ps = in->tipStates[po]; const double* px = in->partials[po];
+        const double* pre = in->partials[pr]; const double* D = in->matrices[dm];
+        #pragma omp parallel for schedule(static)
+        for (int p = 0; p < P; p++) {
+            double num = 0.0, den = 0.0;
+            for (int c = 0; c < C; c++) {
+                const double* Dc = D + (size_t)c * S * S;
+                const double* u = pre + ((size_t)c * P + p) * S;
+                double n = 0.0, d = 0.0;
+                for (int j = 0; j < S; j++) {
+                    double t, xj;
+                    if (ps) {
+                        const int s = ps[p];
+                        if (s < S) { t = Dc[j * S + s]; xj = (j == s) ? 1.0 : 0.0; }
+                        else { t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k]; xj = 1.0; }
+                    } else {
+                        const double* x = px + ((size_t)c * P + p) * S;
+                        t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k] * x[k];
+                        xj = x[j];
+                    }
+                    n += u[j] * t; d += u[j] * xj;
+                }
+                num += w[c] * n; den += w[c] * d;
+            }
+            deriv[p] = num / den;
+        }
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < P; p++) { s1 += in->patternWeights[p] * deriv[p]; s2 += in->patternWeights[p] * deriv[p] * deriv[p]; }
+        if (outSum) outSum[e] = s1;
+        if (outSumSquared) outSumSquared[e] = s2;
+        if (outDerivatives) memcpy(outDerivatives + (size_t)e * P, deriv, sizeof(double) * P);
+    }
+    free(deriv);
+    return BEAGLE_SUCCESS;
+}
+
 int oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
