@@ -616,6 +616,150 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     return 0;
 }
 
+// Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
+// matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
+// levelised like a post-order one and each level is one launch.
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    const int n = in->partialsCount;
+    // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
+    std::vector<int> need;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
+            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+            (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (in->virt[sib].on) need.push_back(sib);
+        if (in->virt[par].on) need.push_back(par);
+        need.insert(need.end(), in->tipUsers[dest].begin(), in->tipUsers[dest].end());
+        if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->scaleUsers[wS].begin(), in->scaleUsers[wS].end());
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    std::vector<OpDesc> descs(count);
+    std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
+    int maxLevel = 0;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        OpDesc& d = descs[k];
+        memset(&d, 0, sizeof(d));
+        if (in->virt[dest].on) clearVirtual(in, dest);
+        int rc = ensurePartials(in, dest); if (rc) return rc;
+        in->tipStates[dest] = nullptr;
+        if (!in->partials[par] || (in->tipStates[par] && par < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.dest = in->partials[dest];
+        d.child1 = in->partials[par];
+        if (in->tipStates[sib] && sib < in->tipCount) { d.child2 = in->tipStates[sib]; d.kind = mi355::KIND_STATES2; }
+        else if (in->partials[sib]) d.child2 = in->partials[sib];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.mat1 = mc; d.mat2 = ms;
+        if (wS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, wS); if (rc) return rc;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
+        } else if (rS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, rS); if (rc) return rc;
+            if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;
+            d.scaleRead = in->scale[rS];
+        }
+        d.pStart = 0; d.pEnd = in->P;
+        const int lvl = std::max(std::max(wLevel[par], wLevel[sib]), std::max(wLevel[dest], rLevel[dest])) + 1;
+        level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
+        wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
+    }
+    std::vector<int> start(maxLevel + 2, 0);
+    for (int k = 0; k < count; k++) start[level[k] + 1]++;
+    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
+    std::vector<OpDesc> sorted(count);
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
+    const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
+    for (int chunkBegin = 0; chunkBegin < count;) {
+        const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
+        void* dChunk = nullptr;
+        int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
+        if (rc) return rc;
+        for (int l = 0; l <= maxLevel; l++) {
+            const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
+            if (begin >= end) continue;
+            mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                                     in->P, in->S, in->C, in->tiled, in->P);
+        }
+        chunkBegin = chunkEnd;
+    }
+    HIP_TRY(hipGetLastError());
+    if (globalCum != BEAGLE_OP_NONE)
+        for (int k = 0; k < count; k++) {
+            if (opWrite[k] == BEAGLE_OP_NONE) continue;
+            int rc = ensureScale(in, globalCum); if (rc) return rc;
+            const double* src = in->scale[opWrite[k]];
+            int one = 1;
+            void *dSrc = nullptr, *dRaw = nullptr;
+            rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
+            rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
+            mi355::launchAccumulateScale(in->stream, in->scale[globalCum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, 0, in->P);
+        }
+    return 0;
+}
+
+// Per-edge derivative sums (AbstractBeagleBranchGradientDelegate.java:82-92).  Edges are processed in chunks that bound
+// the scratch memory (block sums, and the optional per-pattern matrix) to a few hundred MB.
+int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
+                      double* outDerivatives, double* outSum, double* outSumSquared) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    std::vector<int> need;
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (in->virt[postIdx[e]].on) need.push_back(postIdx[e]);
+        if (in->virt[preIdx[e]].on) need.push_back(preIdx[e]);
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    const int nb = mi355::edgeBlocks(in->P);
+    const size_t perEdgeBytes = (size_t)nb * 2 * sizeof(double) + 2 * sizeof(double) + (outDerivatives ? (size_t)in->P * sizeof(double) : 0);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / perEdgeBytes));
+    chunk = std::min(chunk, 32768);
+    double *dBlock = nullptr, *dSums = nullptr, *dPer = nullptr;
+    HIP_TRY(hipMalloc((void**)&dBlock, (size_t)chunk * nb * 2 * sizeof(double)));
+    hipError_t e1 = hipMalloc((void**)&dSums, (size_t)chunk * 2 * sizeof(double));
+    hipError_t e2 = outDerivatives ? hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) : hipSuccess;
+    int rc = (e1 != hipSuccess || e2 != hipSuccess) ? BEAGLE_ERROR_OUT_OF_MEMORY : 0;
+    std::vector<mi355::EdgeDesc> descs;
+    std::vector<double> sums;
+    for (int b = 0; b < count && !rc; b += chunk) {
+        const int m = std::min(chunk, count - b);
+        descs.assign(m, mi355::EdgeDesc());
+        for (int e = 0; e < m && !rc; e++) {
+            const int po = postIdx[b + e], pr = preIdx[b + e];
+            mi355::EdgeDesc& d = descs[e];
+            if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
+            else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
+            else rc = BEAGLE_ERROR_OUT_OF_RANGE;
+            if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) rc = BEAGLE_ERROR_OUT_OF_RANGE;
+            d.pre = in->partials[pr];
+            d.dmat = dIdx[b + e];
+        }
+        if (rc) break;
+        void* dDesc = nullptr;
+        rc = uploadTransient(in, descs.data(), descs.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+        mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, m, in->matrices, in->weights + (size_t)wIdx * in->C,
+                                       in->patternWeights, dPer, dBlock, dSums, in->P, in->S, in->C, in->tiled);
+        sums.resize((size_t)m * 2);
+        rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) break;
+        for (int e = 0; e < m; e++) {
+            if (outSum) outSum[b + e] = sums[2 * e];
+            if (outSumSquared) outSumSquared[b + e] = sums[2 * e + 1];
+        }
+        if (outDerivatives) rc = download(in, outDerivatives + (size_t)b * in->P, dPer, (size_t)m * in->P * sizeof(double));
+    }
+    hipStreamSynchronize(in->stream);
+    hipFree(dBlock); hipFree(dSums); if (dPer) hipFree(dPer);
+    return rc;
+}
+
 int accumulate(Instance* in, const int* idx, int count, int cum, double sign, int part) {
     if (badIndex(cum, in->scaleCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cum); if (rc) return rc;
@@ -1174,11 +1318,59 @@ int beagleGetSiteLogLikelihoods(int instance, double* out) {
 }
 
 // ---- outside SURVEY 8 (a)-(e): exported so the JNI shim links ---------------------------------
-int beagleSetRootPrePartials(int, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
-int beagleSetDifferentialMatrix(int, int, const double*) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+// ---- pre-order partials and branch gradients ----
+int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* stateFrequenciesIndices, int count) {
+    GET_INSTANCE(instance);
+    for (int k = 0; k < count; k++) {
+        const int b = bufferIndices[k], f = stateFrequenciesIndices[k];
+        if (badIndex(b, in->partialsCount) || badIndex(f, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        int rc = materializeTipUsers(in, b); if (rc) return rc;
+        clearVirtual(in, b);
+        rc = ensurePartials(in, b); if (rc) return rc;
+        in->tipStates[b] = nullptr;
+        mi355::launchFillFrequencies(in->stream, in->partials[b], in->freqs + (size_t)f * in->S, in->P, in->S, in->C, in->tiled);
+    }
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+int beagleSetDifferentialMatrix(int instance, int matrixIndex, const double* inMatrix) {
+    return beagleSetTransitionMatrix(instance, matrixIndex, inMatrix, 0.0);
+}
+
 int beagleAddTransitionMatrices(int, const int*, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
-int beagleTransposeTransitionMatrices(int, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
-int beagleUpdatePrePartials(int, const int*, int, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+
+int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount) {
+    GET_INSTANCE(instance);
+    if (matrixCount <= 0) return BEAGLE_SUCCESS;
+    std::vector<int> pairs((size_t)matrixCount * 2);
+    for (int k = 0; k < matrixCount; k++) {
+        if (badIndex(inputIndices[k], in->matrixCount) || badIndex(resultIndices[k], in->matrixCount) || inputIndices[k] == resultIndices[k])
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        pairs[2 * k] = inputIndices[k]; pairs[2 * k + 1] = resultIndices[k];
+    }
+    void* dPairs = nullptr;
+    int rc = uploadTransient(in, pairs.data(), pairs.size() * sizeof(int), &dPairs); if (rc) return rc;
+    mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, matrixCount, in->S, in->C);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
+    GET_INSTANCE(instance);
+    return runPreOperations(in, operations, operationCount, cumulativeScaleIndex);
+}
+
+int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
+                                     const int* derivativeMatrixIndices, const int* categoryWeightsIndices, int count,
+                                     double* outDerivatives, double* outSumDerivatives, double* outSumSquaredDerivatives) {
+    GET_INSTANCE(instance);
+    if (!postBufferIndices || !preBufferIndices || !derivativeMatrixIndices || !categoryWeightsIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (badIndex(categoryWeightsIndices[0], in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return edgeDifferentials(in, postBufferIndices, preBufferIndices, derivativeMatrixIndices, categoryWeightsIndices[0], count,
+                             outDerivatives, outSumDerivatives, outSumSquaredDerivatives);
+}
+
 int beagleUpdatePrePartialsByPartition(int, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
 
 // ---- MI355X extensions -----------------------------------------------------------------------

@@ -213,9 +213,15 @@ JNI_FN(jint, getSiteLogLikelihoods)(JNIEnv* env, jobject, jint instance, jdouble
     DblArr o(env, out, true); return beagleGetSiteLogLikelihoods(instance, o);
 }
 
-// gradient entry points — not on the (a)-(e) path yet
-JNI_FN(jint, calculateEdgeDifferentials)(JNIEnv*, jobject, jint, jintArray, jintArray, jintArray, jintArray, jint, jdoubleArray,
-                                         jdoubleArray, jdoubleArray) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+// gradient entry points.  BEAST passes null for outDerivatives and, on the second-derivative call, for
+// outSumSquaredDerivatives (AbstractBeagleBranchGradientDelegate.java:82-92): IntArr/DblArr turn a null array into nullptr.
+JNI_FN(jint, calculateEdgeDifferentials)(JNIEnv* env, jobject, jint instance, jintArray post, jintArray pre, jintArray dmat,
+                                         jintArray weights, jint count, jdoubleArray outDeriv, jdoubleArray outSum,
+                                         jdoubleArray outSumSquared) {
+    IntArr a(env, post), b(env, pre), c(env, dmat), w(env, weights);
+    DblArr o0(env, outDeriv, true), o1(env, outSum, true), o2(env, outSumSquared, true);
+    return beagleCalculateEdgeDifferentials(instance, a, b, c, w, count, o0, o1, o2);
+}
 JNI_FN(jint, calculateCrossProductDifferentials)(JNIEnv*, jobject, jint, jintArray, jintArray, jintArray, jintArray, jdoubleArray,
                                                  jint, jdoubleArray, jdoubleArray) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
 JNI_FN(jint, calculateEdgeDerivative)(JNIEnv*, jobject, jint, jintArray, jintArray, jint, jintArray, jintArray, jint, jint, jint,

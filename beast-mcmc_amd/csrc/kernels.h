@@ -98,6 +98,26 @@ void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, 
 // dst[c][p][i] = src[p][i] for every category (setTipPartials replication)
 void launchReplicateCategories(hipStream_t stream, const double* src, double* dst, int P, int S, int C);
 
+// ---- pre-order partials and edge derivatives (kernels_preorder.hip) -----------------------------
+// One level of pre-order ops.  The OpDesc fields are reused: dest = pre(child), child1 = pre(parent) (always partials),
+// mat1 = the child's branch matrix (used transposed), child2 / mat2 = the sibling's post-order partials (or compact
+// states, KIND_STATES2) and branch matrix.  Works on either partials layout.
+void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
+                       int maxRange);
+struct EdgeDesc {
+    const void*   post;          // post-order partials of the node below the edge (double*) or its compact states (uint8*)
+    const double* pre;           // pre-order partials of the same node
+    int           dmat;          // differential matrix index (C*S*S doubles)
+    int           postIsStates;
+};
+int  edgeBlocks(int P);          // workgroups per edge = entries per edge in blockSums (x2 doubles)
+// outSums[2e] = sum_p w_p num/den, outSums[2e+1] = sum_p w_p (num/den)^2; perPattern (nullable) [e][P]
+void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
+                             const double* patternWeights, double* perPattern, double* blockSums, double* outSums,
+                             int P, int S, int C, bool tiled);
+void launchTransposeMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int count, int S, int C);
+void launchFillFrequencies(hipStream_t stream, double* dest, const double* freqs, int P, int S, int C, bool tiled);
+
 int  pruneBlocksForRange(int S, int range);
 // 4-state kernel (kernels_nuc4.hip); false when C is outside its template range
 bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int C, int maxRange);

@@ -1,0 +1,208 @@
+// Pre-order partials and edge derivatives for gfx950 — first correct version, any state count,
+// both partials layouts.  One thread = one pattern; a workgroup is one wavefront (64 patterns) whose branch matrices
+// live in LDS (read at wave-uniform addresses) next to the wave's own operand columns.  Not yet tuned: these kernels
+// run once per *gradient* evaluation, the pruning kernels once per likelihood evaluation.
+//
+// Arithmetic (callers: src/dr/evomodel/treedatalikelihood/preorder/AbstractBeagleGradientDelegate.java:207-221,
+// AbstractBeagleBranchGradientDelegate.java:82-92 with the formula spelled out at :103-140):
+//   pre(child)[j] = sum_i P_child[i][j] * ( pre(parent)[i] * sum_k P_sib[i][k] post(sib)[k] )
+//   num = sum_c w_c sum_j pre[j] sum_k D_c[j][k] post[k],   den = sum_c w_c sum_j pre[j] post[j],   derivative = num / den
+#include "kernels.h"
+
+namespace mi355 {
+
+constexpr int PRE_BLOCK = 64;
+
+// element (category c, pattern p, state i) of a partials buffer
+template <bool TILED>
+__device__ __forceinline__ size_t pidx(int c, int p, int i, int P, int S, int ntile) {
+    return TILED ? (((size_t)c * ntile + (p >> 5)) * S + i) * 32 + (p & 31) : ((size_t)c * P + p) * S + i;
+}
+
+template <bool TILED>
+__global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
+                                                           int P, int S, int C) {
+    extern __shared__ double sh[];                 // Ms[S*S] | Mc[S*S] | v[S][64] | x[S][64]
+    double* Ms = sh; double* Mc = sh + S * S; double* v = Mc + S * S; double* x = v + S * PRE_BLOCK;
+    const OpDesc& op = ops[blockIdx.y];
+    const int base = op.pStart + blockIdx.x * PRE_BLOCK;
+    if (base >= op.pEnd) return;
+    const int tid = threadIdx.x, p = base + tid, ntile = (P + 31) >> 5;
+    const bool valid = p < op.pEnd, sibStates = op.kind & KIND_STATES2;
+    const double MI355_GLOBAL* parent = gptr(reinterpret_cast<const double*>(op.child1));
+    double MI355_GLOBAL* dest = gptr(op.dest);
+    int s = S;
+    if (valid && sibStates) s = gptr(reinterpret_cast<const uint8_t*>(op.child2))[p];
+    double inv = 1.0;
+    if (valid && !op.scaleWrite && op.scaleRead) inv = 1.0 / gptr(op.scaleRead)[p];
+    for (int c = 0; c < C; c++) {
+        const double* GS = matrices + ((size_t)op.mat2 * C + c) * S * S;
+        const double* GC = matrices + ((size_t)op.mat1 * C + c) * S * S;
+        __syncthreads();
+        for (int e = tid; e < S * S; e += PRE_BLOCK) { Ms[e] = GS[e]; Mc[e] = GC[e]; }
+        if (valid) {
+            for (int i = 0; i < S; i++) v[i * PRE_BLOCK + tid] = parent[pidx<TILED>(c, p, i, P, S, ntile)];
+            if (!sibStates) {
+                const double MI355_GLOBAL* sib = gptr(reinterpret_cast<const double*>(op.child2));
+                for (int i = 0; i < S; i++) x[i * PRE_BLOCK + tid] = sib[pidx<TILED>(c, p, i, P, S, ntile)];
+            }
+        }
+        __syncthreads();
+        if (!valid) continue;
+        for (int i = 0; i < S; i++) {
+            double f;
+            if (sibStates) f = s < S ? Ms[i * S + s] : 1.0;
+            else { f = 0.0; for (int k = 0; k < S; k++) f += Ms[i * S + k] * x[k * PRE_BLOCK + tid]; }
+            v[i * PRE_BLOCK + tid] *= f;
+        }
+        for (int j = 0; j < S; j++) {
+            double acc = 0.0;
+            for (int i = 0; i < S; i++) acc += v[i * PRE_BLOCK + tid] * Mc[i * S + j];
+            dest[pidx<TILED>(c, p, j, P, S, ntile)] = acc * inv;
+        }
+    }
+    if (op.scaleWrite && valid) {                  // rescale now: max over categories and states, divide, keep the raw factor
+        double m = 0.0;
+        for (int c = 0; c < C; c++) for (int j = 0; j < S; j++) m = fmax(m, dest[pidx<TILED>(c, p, j, P, S, ntile)]);
+        if (!(m > 0.0)) m = 1.0;
+        gptr(op.scaleWrite)[p] = m;
+        const double im = 1.0 / m;
+        for (int c = 0; c < C; c++) for (int j = 0; j < S; j++) dest[pidx<TILED>(c, p, j, P, S, ntile)] *= im;
+    }
+}
+
+static size_t preLds(int S) { return ((size_t)2 * S * S + (size_t)2 * S * PRE_BLOCK) * sizeof(double); }
+
+void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
+                       int maxRange) {
+    if (nOps <= 0 || maxRange <= 0) return;
+    const size_t lds = preLds(S);
+    static bool granted = false;
+    if (!granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prePartials<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prePartials<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        granted = true;
+    }
+    for (int o = 0; o < nOps; o += 65535) {
+        const int n = nOps - o < 65535 ? nOps - o : 65535;
+        dim3 grid((maxRange + PRE_BLOCK - 1) / PRE_BLOCK, n), block(PRE_BLOCK);
+        if (tiled) hipLaunchKernelGGL(k_prePartials<true>, grid, block, lds, stream, dOps + o, matrices, P, S, C);
+        else hipLaunchKernelGGL(k_prePartials<false>, grid, block, lds, stream, dOps + o, matrices, P, S, C);
+    }
+}
+
+// ---- edge derivatives ---------------------------------------------------------------------------------------------
+template <bool TILED>
+__global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc* __restrict__ edges, const double* __restrict__ matrices,
+                                                                 const double* __restrict__ catWeights,
+                                                                 const double* __restrict__ patternWeights,
+                                                                 double* __restrict__ perPattern, double* __restrict__ blockSums,
+                                                                 int P, int S, int C) {
+    extern __shared__ double sh[];                 // D[S*S] | u[S][64] | x[S][64]
+    double* D = sh; double* u = sh + S * S; double* x = u + S * PRE_BLOCK;
+    const EdgeDesc& ed = edges[blockIdx.y];
+    const int tid = threadIdx.x, p = blockIdx.x * PRE_BLOCK + tid, ntile = (P + 31) >> 5;
+    const bool valid = p < P, postStates = ed.postIsStates != 0;
+    const double MI355_GLOBAL* pre = gptr(ed.pre);
+    int s = S;
+    if (valid && postStates) s = gptr(reinterpret_cast<const uint8_t*>(ed.post))[p];
+    double num = 0.0, den = 0.0;
+    for (int c = 0; c < C; c++) {
+        const double* G = matrices + ((size_t)ed.dmat * C + c) * S * S;
+        __syncthreads();
+        for (int e = tid; e < S * S; e += PRE_BLOCK) D[e] = G[e];
+        if (valid) {
+            for (int i = 0; i < S; i++) u[i * PRE_BLOCK + tid] = pre[pidx<TILED>(c, p, i, P, S, ntile)];
+            if (!postStates) {
+                const double MI355_GLOBAL* post = gptr(reinterpret_cast<const double*>(ed.post));
+                for (int i = 0; i < S; i++) x[i * PRE_BLOCK + tid] = post[pidx<TILED>(c, p, i, P, S, ntile)];
+            }
+        }
+        __syncthreads();
+        if (!valid) continue;
+        double n = 0.0, d = 0.0;
+        for (int j = 0; j < S; j++) {
+            double t, xj;
+            if (postStates) {
+                if (s < S) { t = D[j * S + s]; xj = j == s ? 1.0 : 0.0; }
+                else { t = 0.0; for (int k = 0; k < S; k++) t += D[j * S + k]; xj = 1.0; }
+            } else {
+                t = 0.0; for (int k = 0; k < S; k++) t += D[j * S + k] * x[k * PRE_BLOCK + tid];
+                xj = x[j * PRE_BLOCK + tid];
+            }
+            n += u[j * PRE_BLOCK + tid] * t; d += u[j * PRE_BLOCK + tid] * xj;
+        }
+        num += catWeights[c] * n; den += catWeights[c] * d;
+    }
+    double w1 = 0.0, w2 = 0.0;
+    if (valid) {
+        const double deriv = num / den;
+        if (perPattern) perPattern[(size_t)blockIdx.y * P + p] = deriv;
+        w1 = patternWeights[p] * deriv; w2 = w1 * deriv;
+    }
+    // fixed-shape butterfly over the wave: deterministic
+    for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
+    if (tid == 0) {
+        double* b = blockSums + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        b[0] = w1; b[1] = w2;
+    }
+}
+
+// out[e] = sum over the edge's workgroups, in a fixed order
+__global__ __launch_bounds__(64) void k_edgeFinal(const double* __restrict__ blockSums, int nBlocks, double* __restrict__ out) {
+    const double* b = blockSums + (size_t)blockIdx.x * nBlocks * 2;
+    double w1 = 0.0, w2 = 0.0;
+    for (int k = threadIdx.x; k < nBlocks; k += 64) { w1 += b[2 * k]; w2 += b[2 * k + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = w1; out[2 * blockIdx.x + 1] = w2; }
+}
+
+int edgeBlocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
+
+void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
+                             const double* patternWeights, double* perPattern, double* blockSums, double* outSums,
+                             int P, int S, int C, bool tiled) {
+    if (nEdges <= 0) return;
+    const size_t lds = ((size_t)S * S + (size_t)2 * S * PRE_BLOCK) * sizeof(double);
+    static bool granted = false;
+    if (!granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        granted = true;
+    }
+    const int nb = edgeBlocks(P);
+    dim3 grid(nb, nEdges), block(PRE_BLOCK);
+    if (tiled) hipLaunchKernelGGL(k_edgeDifferentials<true>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
+    else hipLaunchKernelGGL(k_edgeDifferentials<false>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
+    hipLaunchKernelGGL(k_edgeFinal, dim3(nEdges), dim3(64), 0, stream, blockSums, nb, outSums);
+}
+
+// ---- small helpers ------------------------------------------------------------------------------------------------
+// matrices[dst] = transpose(matrices[src]) per category
+__global__ void k_transposeMatrices(double* __restrict__ matrices, const int* __restrict__ srcDst, int S, int C) {
+    const int src = srcDst[2 * blockIdx.x], dst = srcDst[2 * blockIdx.x + 1];
+    const double* a = matrices + (size_t)src * C * S * S;
+    double* b = matrices + (size_t)dst * C * S * S;
+    for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) {
+        const int c = e / (S * S), r = e - c * S * S, i = r / S, j = r - i * S;
+        b[(size_t)c * S * S + j * S + i] = a[e];
+    }
+}
+void launchTransposeMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int count, int S, int C) {
+    if (count > 0) hipLaunchKernelGGL(k_transposeMatrices, dim3(count), dim3(256), 0, stream, matrices, dSrcDst, S, C);
+}
+
+// dest[c][p][i] = freqs[i]
+template <bool TILED>
+__global__ void k_fillFrequencies(double* __restrict__ dest, const double* __restrict__ freqs, int P, int S, int C) {
+    const int p = blockIdx.x * 256 + threadIdx.x, ntile = (P + 31) >> 5;
+    if (p >= P) return;
+    for (int c = 0; c < C; c++) for (int i = 0; i < S; i++) dest[pidx<TILED>(c, p, i, P, S, ntile)] = freqs[i];
+}
+void launchFillFrequencies(hipStream_t stream, double* dest, const double* freqs, int P, int S, int C, bool tiled) {
+    dim3 grid((P + 255) / 256), block(256);
+    if (tiled) hipLaunchKernelGGL(k_fillFrequencies<true>, grid, block, 0, stream, dest, freqs, P, S, C);
+    else hipLaunchKernelGGL(k_fillFrequencies<false>, grid, block, 0, stream, dest, freqs, P, S, C);
+}
+
+}  // namespace mi355

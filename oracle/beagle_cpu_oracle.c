@@ -566,80 +566,117 @@ static void pre_partials(const Inst* in, const double* parent, const double* mCh
 static int pre_ops(int h, const int* ops, int count, int tuple, int cumIdx) {
     Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     if (tuple != BEAGLE_OP_COUNT) return BEAGLE_ERROR_NO_IMPLEMENTATION;   /* partitioned instances: not restated */
+    if (count <= 0) return BEAGLE_SUCCESS;
+    /* pass 1 (serial): validate and resolve, as oracle_beagleUpdatePartials does */
+    typedef struct { double* d; const double* parent; const int* ss; const double* sx; const double* mc; const double* ms;
+                     double* wS; const double* rS; } Res;
+    Res* r = (Res*)calloc((size_t)count, sizeof(Res));
     for (int o = 0; o < count; o++) {
         const int* op = ops + o * tuple;
         int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
         if (dest < 0 || dest >= in->partialsCount || par < 0 || par >= in->partialsCount || sib < 0 || sib >= in->partialsCount ||
             mc < 0 || mc >= in->matrixCount || ms < 0 || ms >= in->matrixCount || wS >= in->scaleCount || rS >= in->scaleCount ||
-            !in->partials[par] || (!in->tipStates[sib] && !in->partials[sib]) || dest == par || dest == sib) return BEAGLE_ERROR_OUT_OF_RANGE;
-        double* d = partials_buf(in, dest);
+            !in->partials[par] || (!in->tipStates[sib] && !in->partials[sib]) || dest == par || dest == sib) { free(r); return BEAGLE_ERROR_OUT_OF_RANGE; }
+        r[o].d = partials_buf(in, dest);
         free(in->tipStates[dest]); in->tipStates[dest] = NULL;
-        const double* parent = in->partials[par];
-        const int* ss = in->tipStates[sib]; const double* sx = in->partials[sib];
-        double* wBuf = wS >= 0 ? scale_buf(in, wS) : NULL;
-        const double* rBuf = (wS < 0 && rS >= 0) ? scale_buf(in, rS) : NULL;
+        r[o].parent = in->partials[par];
+        r[o].ss = in->tipStates[sib]; r[o].sx = in->partials[sib];
+        r[o].mc = in->matrices[mc]; r[o].ms = in->matrices[ms];
+        r[o].wS = wS >= 0 ? scale_buf(in, wS) : NULL;
+        r[o].rS = (wS < 0 && rS >= 0) ? scale_buf(in, rS) : NULL;
+    }
+    /* pass 2: one parallel region; every thread runs the whole list on its own pattern block */
+    #pragma omp parallel
+    {
+        int nt = 1, tid = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+        const int div = in->P / nt, rem = in->P % nt;
+        const int p0 = tid * div + (tid < rem ? tid : rem), p1 = p0 + div + (tid < rem ? 1 : 0);
+        if (p1 > p0) for (int o = 0; o < count; o++) {
+            pre_partials(in, r[o].parent, r[o].mc, r[o].ss, r[o].sx, r[o].ms, r[o].d, p0, p1);
+            if (r[o].wS)      rescale_write(in, r[o].d, r[o].wS, p0, p1);
+            else if (r[o].rS) rescale_read(in, r[o].d, r[o].rS, p0, p1);
+        }
+    }
+    if (cumIdx != BEAGLE_OP_NONE)
+        for (int o = 0; o < count; o++) {
+            int wS = ops[o * tuple + 1];
+            if (wS >= 0) oracle_beagleAccumulateScaleFactors(h, &wS, 1, cumIdx);
+        }
+    free(r);
+    return BEAGLE_SUCCESS;
+}
+int oracle_beagleUpdatePrePartials(int h, const int* ops, int count, int cumIdx) { return pre_ops(h, ops, count, BEAGLE_OP_COUNT, cumIdx); }
+
+/* derivative num/den of one edge for the patterns [p0, p1) */
+static void edge_derivative(const Inst* in, const int* ps, const double* px, const double* pre, const double* D, const double* w,
+                            double* deriv, int p0, int p1) {
+    const int S = in->S, P = in->P, C = in->C;
+    for (int p = p0; p < p1; p++) {
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < C; c++) {
+            const double* Dc = D + (size_t)c * S * S;
+            const double* u = pre + ((size_t)c * P + p) * S;
+            double n = 0.0, d = 0.0;
+            for (int j = 0; j < S; j++) {
+                double t, xj;
+                if (ps) {
+                    const int s = ps[p];
+                    if (s < S) { t = Dc[j * S + s]; xj = (j == s) ? 1.0 : 0.0; }
+                    else { t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k]; xj = 1.0; }
+                } else {
+                    const double* x = px + ((size_t)c * P + p) * S;
+                    t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k] * x[k];
+                    xj = x[j];
+                }
+                n += u[j] * t; d += u[j] * xj;
+            }
+            num += w[c] * n; den += w[c] * d;
+        }
+        deriv[p] = num / den;
+    }
+}
+
+int oracle_beagleCalculateEdgeDifferentials(int h, const int* postIdx, const int* preIdx, const int* dIdx, const int* wIdx, int count,
+                                            double* outDerivatives, double* outSum, double* outSumSquared) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    const int P = in->P;
+    if (count <= 0) return BEAGLE_SUCCESS;
+    if (!wIdx || wIdx[0] < 0 || wIdx[0] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const double* w = in->catWeights[wIdx[0]];
+    for (int e = 0; e < count; e++) {
+        int po = postIdx[e], pr = preIdx[e], dm = dIdx[e];
+        if (po < 0 || po >= in->partialsCount || pr < 0 || pr >= in->partialsCount || dm < 0 || dm >= in->matrixCount ||
+            !in->partials[pr] || (!in->tipStates[po] && !in->partials[po])) return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    /* edges in chunks of <= 8M derivative values; one parallel region per chunk (threads own pattern blocks), then the
+     * weighted sums serially in pattern order */
+    int chunk = (int)(((size_t)8 << 20) / (size_t)P); if (chunk < 1) chunk = 1; if (chunk > count) chunk = count;
+    double* deriv = (double*)malloc(sizeof(double) * (size_t)chunk * P);
+    for (int b = 0; b < count; b += chunk) {
+        const int m = count - b < chunk ? count - b : chunk;
         #pragma omp parallel
         {
             int nt = 1, tid = 0;
 #ifdef _OPENMP
             nt = omp_get_num_threads(); tid = omp_get_thread_num();
 #endif
-            const int div = in->P / nt, rem = in->P % nt;
+            const int div = P / nt, rem = P % nt;
             const int p0 = tid * div + (tid < rem ? tid : rem), p1 = p0 + div + (tid < rem ? 1 : 0);
-            if (p1 > p0) {
-                pre_partials(in, parent, in->matrices[mc], ss, sx, in->matrices[ms], d, p0, p1);
-                if (wBuf)      rescale_write(in, d, wBuf, p0, p1);
-                else if (rBuf) rescale_read(in, d, rBuf, p0, p1);
-            }
+            if (p1 > p0) for (int e = 0; e < m; e++)
+                edge_derivative(in, in->tipStates[postIdx[b + e]], in->partials[postIdx[b + e]], in->partials[preIdx[b + e]],
+                                in->matrices[dIdx[b + e]], w, deriv + (size_t)e * P, p0, p1);
         }
-        if (wS >= 0 && cumIdx != BEAGLE_OP_NONE) oracle_beagleAccumulateScaleFactors(h, &wS, 1, cumIdx);
-    }
-    return BEAGLE_SUCCESS;
-}
-int oracle_beagleUpdatePrePartials(int h, const int* ops, int count, int cumIdx) { return pre_ops(h, ops, count, BEAGLE_OP_COUNT, cumIdx); }
-
-int oracle_beagleCalculateEdgeDifferentials(int h, const int* postIdx, const int* preIdx, const int* dIdx, const int* wIdx, int count,
-                                            double* outDerivatives, double* outSum, double* outSumSquared) {
-    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
-    const int S = in->S, P = in->P, C = in->C;
-    if (!wIdx || wIdx[0] < 0 || wIdx[0] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
-    const double* w = in->catWeights[wIdx[0]];
-    double* deriv = (double*)malloc(sizeof(double) * P);
-    for (int e = 0; e < count; e++) {
-        int po = postIdx[e], pr = preIdx[e], dm = dIdx[e];
-        if (po < 0 || po >= in->partialsCount || pr < 0 || pr >= in->partialsCount || dm < 0 || dm >= in->matrixCount ||
-            !in->partials[pr] || (!in->tipStates[po] && !in->partials[po])) { free(deriv); return BEAGLE_ERROR_OUT_OF_RANGE; }
-        const int* ps = in->tipStates[po]; const double* px = in->partials[po];
-        const double* pre = in->partials[pr]; const double* D = in->matrices[dm];
-        #pragma omp parallel for schedule(static)
-        for (int p = 0; p < P; p++) {
-            double num = 0.0, den = 0.0;
-            for (int c = 0; c < C; c++) {
-                const double* Dc = D + (size_t)c * S * S;
-                const double* u = pre + ((size_t)c * P + p) * S;
-                double n = 0.0, d = 0.0;
-                for (int j = 0; j < S; j++) {
-                    double t, xj;
-                    if (ps) {
-                        const int s = ps[p];
-                        if (s < S) { t = Dc[j * S + s]; xj = (j == s) ? 1.0 : 0.0; }
-                        else { t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k]; xj = 1.0; }
-                    } else {
-                        const double* x = px + ((size_t)c * P + p) * S;
-                        t = 0.0; for (int k = 0; k < S; k++) t += Dc[j * S + k] * x[k];
-                        xj = x[j];
-                    }
-                    n += u[j] * t; d += u[j] * xj;
-                }
-                num += w[c] * n; den += w[c] * d;
-            }
-            deriv[p] = num / den;
+        for (int e = 0; e < m; e++) {
+            const double* dv = deriv + (size_t)e * P;
+            double s1 = 0.0, s2 = 0.0;
+            for (int p = 0; p < P; p++) { s1 += in->patternWeights[p] * dv[p]; s2 += in->patternWeights[p] * dv[p] * dv[p]; }
+            if (outSum) outSum[b + e] = s1;
+            if (outSumSquared) outSumSquared[b + e] = s2;
+            if (outDerivatives) memcpy(outDerivatives + (size_t)(b + e) * P, dv, sizeof(double) * P);
         }
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = 0; p < P; p++) { s1 += in->patternWeights[p] * deriv[p]; s2 += in->patternWeights[p] * deriv[p] * deriv[p]; }
-        if (outSum) outSum[e] = s1;
-        if (outSumSquared) outSumSquared[e] = s2;
-        if (outDerivatives) memcpy(outDerivatives + (size_t)e * P, deriv, sizeof(double) * P);
     }
     free(deriv);
     return BEAGLE_SUCCESS;

@@ -1,0 +1,63 @@
+"""Secondary measurement: full branch-length gradient evaluations per second.
+
+One evaluation = post-order pass + root lnL + pre-order pass (2T-2 ops) + edge derivatives for all 2T-2 branches, driven
+exactly as beast-mcmc_amd/gradient.py mirrors the reference's gradient delegates.  Not the headline metric (bench.py);
+the pre-order kernels are the first correct version.
+
+    python tools/gradient_bench.py --config A --patterns 20000 --steps 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="A", choices=["A", "B", "C"])
+    ap.add_argument("--patterns", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cache", default="/tmp/beagle_mi355_cache")
+    args = ap.parse_args()
+    import beast_mcmc_amd as bm
+    from beast_mcmc_amd.gradient import BranchGradient
+    from beast_mcmc_amd.inputs import synth
+    maker = {"A": synth.config_a, "B": synth.config_b, "C": synth.config_c}[args.config]
+    os.makedirs(args.cache, exist_ok=True)
+    wl = synth.cached(os.path.join(args.cache, "config_%s.pkl" % args.config), maker)
+    if args.patterns:
+        wl = wl.shard(0, min(args.patterns, wl.pattern_count))
+    g = BranchGradient(wl)
+    for _ in range(args.warmup):
+        lnl, grad = g.gradient()
+    g.b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl, grad = g.gradient()
+    g.b.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.log_likelihood()
+    dl = (time.perf_counter() - t0) / args.steps
+    buf = wl.pattern_count * wl.state_count * wl.category_count * 8
+    n = wl.tree.node_count
+    # pre-order: read pre(parent) + post(sibling), write pre(child) per op; edge derivatives: read pre + post per edge
+    pre_bytes = (n - 1) * 3 * buf + (n - 1) * 2 * buf
+    print(json.dumps({"metric": "branch-gradient evals/sec (secondary)", "value": round(1.0 / dt, 3), "ms_per_gradient": round(dt * 1e3, 2),
+                      "ms_per_likelihood_same_driver": round(dl * 1e3, 2),
+                      "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
+                                                                                          wl.state_count, wl.category_count),
+                      "pre_order_plus_edge_algorithmic_GBs": round(pre_bytes / max(dt - dl, 1e-9) / 1e9, 1),
+                      "lnL": lnl, "grad_norm": float((grad ** 2).sum() ** 0.5),
+                      "hbm_bytes_resident": int(g.b.deviceBytes())}))
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
