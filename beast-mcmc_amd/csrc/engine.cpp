@@ -15,6 +15,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <atomic>
 
 #include "../../include/beagle_mi355.h"
 #include "kernels.h"
@@ -70,7 +72,7 @@ struct Instance {
     double* matrices = nullptr; double* eigen = nullptr; double* rates = nullptr; double* weights = nullptr;
     double* freqs = nullptr; double* patternWeights = nullptr; double* siteLogL = nullptr;
     std::vector<double*> scale; std::vector<char> scaleIsRaw;
-    double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr; double* hResultDev = nullptr;
+    double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr; double* hResultDev = nullptr; unsigned long long resultSeq = 0;
     char* hRing = nullptr; char* dRing = nullptr; size_t ringHead = 0;
     int partitionCount = 1;
     std::vector<int> partStart, partEnd;
@@ -84,6 +86,8 @@ struct Instance {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
     double timedMs = 0.0; long timedLaunches = 0, pendingLaunches = 0;
     size_t deviceBytes = 0;
+    std::vector<double> shEigen, shFreqs, shWeights, shRates;      // host shadows of the small model arrays ...
+    std::vector<char> okEigen, okFreqs, okWeights, okRates;         // ... valid flags per index
     std::string resourceName;
 };
 
@@ -793,7 +797,8 @@ int accumulate(Instance* in, const int* idx, int count, int cum, double sign, in
     return 0;
 }
 
-int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int part, double* dOut) {
+int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int part, double* dOut,
+                unsigned long long* flag = nullptr, unsigned long long seq = 0) {
     // part < 0: the whole pattern range
     if (badIndex(rootIdx, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     { int rcv = materializeVirtual(in, rootIdx); if (rcv) return rcv; }
@@ -810,11 +815,11 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         mi355::launchRootSiteTiled(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                    in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
                                    in->blockSums, in->P, in->S, in->C, pStart, pEnd);
-        mi355::launchRootFinal(in->stream, in->blockSums, (pEnd - pStart + 255) / 256, dOut);
+        mi355::launchRootFinal(in->stream, in->blockSums, (pEnd - pStart + 255) / 256, dOut, flag, seq);
     } else {
         mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                        in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
-                                       in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd);
+                                       in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd, flag, seq);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1096,6 +1101,19 @@ int beagleGetLogScaleFactors(int instance, int scaleIndex, double* out) {
     return BEAGLE_SUCCESS;
 }
 
+// Small model arrays are re-sent by BEAST before every evaluation whether they changed or not (frequencies and category
+// weights right before calculateRootLogLikelihoods, BeagleTreeLikelihood.java:1029-1030, i.e. behind the last pruning
+// kernel in stream order): an identical value is not uploaded again.
+static int uploadIfChanged(Instance* in, std::vector<double>& shadow, std::vector<char>& ok, int count, int idx, size_t n,
+                           double* dst, const double* src) {
+    if (shadow.empty()) { shadow.assign((size_t)count * n, 0.0); ok.assign(count, 0); }
+    double* sh = &shadow[(size_t)idx * n];
+    if (ok[idx] && memcmp(sh, src, n * sizeof(double)) == 0) return 0;
+    memcpy(sh, src, n * sizeof(double));
+    ok[idx] = 1;
+    return upload(in, dst, src, n * sizeof(double));
+}
+
 int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, const double* Uinv, const double* lambda) {
     GET_INSTANCE(instance);
     if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1104,25 +1122,25 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, c
     memcpy(&pack[0], U, S * S * sizeof(double));
     memcpy(&pack[S * S], Uinv, S * S * sizeof(double));
     memcpy(&pack[2 * S * S], lambda, S * sizeof(double));
-    return upload(in, in->eigen + stride * eigenIndex, pack.data(), stride * sizeof(double));
+    return uploadIfChanged(in, in->shEigen, in->okEigen, in->eigenCount, eigenIndex, stride, in->eigen + stride * eigenIndex, pack.data());
 }
 
 int beagleSetStateFrequencies(int instance, int idx, const double* f) {
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    return upload(in, in->freqs + (size_t)idx * in->S, f, (size_t)in->S * sizeof(double));
+    return uploadIfChanged(in, in->shFreqs, in->okFreqs, in->eigenCount, idx, in->S, in->freqs + (size_t)idx * in->S, f);
 }
 
 int beagleSetCategoryWeights(int instance, int idx, const double* w) {
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    return upload(in, in->weights + (size_t)idx * in->C, w, (size_t)in->C * sizeof(double));
+    return uploadIfChanged(in, in->shWeights, in->okWeights, in->eigenCount, idx, in->C, in->weights + (size_t)idx * in->C, w);
 }
 
 int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    return upload(in, in->rates + (size_t)idx * in->C, r, (size_t)in->C * sizeof(double));
+    return uploadIfChanged(in, in->shRates, in->okRates, in->eigenCount, idx, in->C, in->rates + (size_t)idx * in->C, r);
 }
 
 int beagleSetCategoryRates(int instance, const double* r) { return beagleSetCategoryRatesWithIndex(instance, 0, r); }
@@ -1293,10 +1311,24 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
                                       int count, double* outSumLogLikelihood) {
     GET_INSTANCE(instance);
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;   // BEAST always passes 1 (BeagleTreeLikelihood.java:1038)
+    // the reduction kernel writes the sum and then a sequence number into mapped host memory; the kernel is the last
+    // thing in the (in-order) stream, so seeing the number means everything before it has completed
+    const unsigned long long seq = ++in->resultSeq;
     int rc = rootEnqueue(in, bufferIndices[0], categoryWeightsIndices[0], stateFrequenciesIndices[0],
-                         cumulativeScaleIndices[0], -1, in->hResultDev);
+                         cumulativeScaleIndices[0], -1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(in->stream));
+    {
+        volatile unsigned long long* flag = (volatile unsigned long long*)(in->hResult + 8);
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (*flag != seq) HIP_TRY(hipStreamSynchronize(in->stream));     // long evaluation (or an error): block instead of spinning
+        if (*flag != seq) return BEAGLE_ERROR_GENERAL;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     in->ringHead = 0;   // everything staged so far has been consumed
     const double v = in->hResult[0];
     *outSumLogLikelihood = v;

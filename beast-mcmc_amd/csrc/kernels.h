@@ -86,7 +86,8 @@ void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const do
 // buffer holds raw factors (log is taken on the fly).  Restricted to [pStart, pEnd).
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
-                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd);
+                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,
+                             unsigned long long* flag = nullptr, unsigned long long seq = 0);
 
 // cum[p] += sign * sum_k (raw_k ? log(src_k[p]) : src_k[p]) on [pStart, pEnd); srcs/raws are device arrays.
 void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
@@ -131,6 +132,7 @@ void launchRootSiteTiled(hipStream_t stream, const double* root, const double* c
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                          double* blockSums, int P, int S, int C, int pStart, int pEnd);
 // out[0] = sum of n block sums in a fixed order
-void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out);
+void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out, unsigned long long* flag = nullptr,
+                     unsigned long long seq = 0);
 
 }  // namespace mi355

@@ -262,25 +262,32 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSite(const double* __restric
     if (threadIdx.x == 0) blockSums[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinal(const double* __restrict__ blockSums, int n, double* __restrict__ out) {
+// `flag` (nullable): a word next to `out` in host-visible memory that receives `seq` after the sum — the host polls it
+// instead of paying a stream-synchronisation wake-up once per evaluation.
+__global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinal(const double* __restrict__ blockSums, int n, double* __restrict__ out,
+                                                          unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[ROOT_BLOCK / 64];
     double v = 0.0;
     for (int k = threadIdx.x; k < n; k += ROOT_BLOCK) v += blockSums[k];
     const double t = blockSum(v, sh);
-    if (threadIdx.x == 0) out[0] = t;
+    if (threadIdx.x == 0) {
+        out[0] = t;
+        if (flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
+    }
 }
 
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
-                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd) {
+                             double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,
+                             unsigned long long* flag, unsigned long long seq) {
     const int n = (pEnd - pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
     hipLaunchKernelGGL(k_rootSite, dim3(n), dim3(ROOT_BLOCK), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
                        patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
-    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out);
+    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
 }
 
-void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out) {
-    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out);
+void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out, unsigned long long* flag, unsigned long long seq) {
+    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
