@@ -104,3 +104,60 @@ def test_virtual_and_stored_cherries_agree_bitwise(engine_lib):
             os.environ.pop("BEAGLE_MI355_NO_VIRTUAL", None)
     for k, v in vals.items():
         assert v[0] == v[1], (k, v)
+
+
+def test_steady_state_chain_matches_stored_buffers_bitwise(oracle_lib):
+    """An MCMC-like chain: the same op lists come back every other evaluation (buffer flips), which is what the
+    engine's steady-state fast path keys on (definitions re-confirmed, only the matrix snapshots refreshed).  Model
+    parameters, branch rates and node heights change between evaluations, some moves are rejected (restoreState).
+    Every evaluation must equal, to the last bit, the same chain with virtual buffers off — and the oracle to 1e-10."""
+    import os
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
+    wl = helpers.random_workload(80, 1500, 4, 4, seed=99)
+    rng = np.random.default_rng(3)
+    moves = []
+    for step in range(14):
+        kind = ("model", "rates", "height", "none")[step % 4]
+        moves.append((kind, rng.gamma(2.0, 1.0, size=6) + 0.1, rng.uniform(0.5, 1.5, size=wl.tree.node_count),
+                      int(rng.integers(wl.tip_count, wl.tree.node_count)), step % 5 == 4))
+
+    def chain(tl):
+        out = [tl.getLogLikelihood()]
+        height = wl.tree.height.copy()          # the chain's own view of the node heights (moves accumulate)
+        for kind, gtr, rates, node, reject in moves:
+            tl.storeState()
+            saved = height.copy()
+            if kind == "model":
+                tl.set_substitution_model(substmodel.gtr(gtr, wl.freqs), wl.freqs)
+            elif kind == "rates":
+                tl.set_branch_rates(rates)
+            elif kind == "height" and node != wl.tree.root:
+                lo = max(height[wl.tree.left[node]], height[wl.tree.right[node]])
+                hi = height[wl.tree.parent[node]]
+                height[node] = lo + 0.37 * (hi - lo)
+                tl.set_node_height(node, float(height[node]))
+            else:
+                tl.makeDirty()
+            out.append(tl.getLogLikelihood())
+            if reject:
+                tl.restoreState()
+                height = saved
+                out.append(tl.getLogLikelihood())
+        return out
+
+    runs = {}
+    for flag in ("0", "1"):
+        os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
+        try:
+            tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+            runs[flag] = chain(tl)
+            tl.close()
+        finally:
+            os.environ.pop("BEAGLE_MI355_NO_VIRTUAL", None)
+    assert runs["0"] == runs["1"]
+    o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    ref = chain(o)
+    o.close()
+    assert len(ref) == len(runs["0"])
+    for a, b in zip(runs["0"], ref):
+        assert helpers.rel_err(a, b) <= 1e-10
