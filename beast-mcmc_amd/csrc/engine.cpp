@@ -86,7 +86,6 @@ struct Instance {
     std::vector<int> partStart, partEnd;
     // levelisation scratch
     std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
-    bool fuseCherries = true;   // BEAGLE_MI355_NO_FUSE=1 turns cherry fusion off (A/B measurements)
     bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
     bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
     // kernel timer
@@ -945,7 +944,6 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->scaleIsRaw.assign(std::max(1, scaleBufferCount), 0);
     in->partStart.assign(1, 0); in->partEnd.assign(1, patternCount);
     in->wStamp.assign(partialsBufferCount, 0); in->wLevel.assign(partialsBufferCount, 0); in->wOp.assign(partialsBufferCount, 0);
-    in->fuseCherries = !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0);
     in->rStamp.assign(partialsBufferCount, 0); in->rLevel.assign(partialsBufferCount, 0);
     in->resourceName = res->names[device + 1];
 

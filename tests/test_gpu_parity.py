@@ -293,3 +293,36 @@ def test_config_a_shards_sum_to_whole(config_a):
         parts += tl.getLogLikelihood()
         tl.close()
     assert helpers.rel_err(parts, total) <= 1e-11
+
+
+def test_concurrent_instances_from_two_threads(oracle_lib):
+    """BEAST drives different instances concurrently from CompoundLikelihood's thread pool
+    (src/dr/inference/model/CompoundLikelihood.java:64-81, 208-214): two instances evaluated from two threads at the
+    same time must give exactly what each gives alone."""
+    import threading
+    wls = [helpers.random_workload(40, 3000, 4, 4, seed=500), helpers.random_workload(25, 2500, 20, 2, seed=501)]
+
+    def chain(wl, out):
+        tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+        vals = []
+        for k in range(25):
+            tl.storeState()
+            tl.set_branch_rates(np.full(wl.tree.node_count, 1.0 + 0.01 * k))
+            vals.append(tl.getLogLikelihood())
+        tl.close()
+        out.append(vals)
+
+    serial = []
+    for wl in wls:
+        chain(wl, serial)
+    par = [[], []]
+    threads = [threading.Thread(target=chain, args=(wls[i], par[i])) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert par[0][0] == serial[0] and par[1][0] == serial[1]
+    o = BeagleTreeLikelihood(wls[0], library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    o.storeState(); o.set_branch_rates(np.full(wls[0].tree.node_count, 1.0))
+    assert helpers.rel_err(serial[0][0], o.getLogLikelihood()) <= REL_TOL
+    o.close()
