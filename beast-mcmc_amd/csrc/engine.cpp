@@ -37,6 +37,7 @@ namespace {
 
 constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
+constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
 
 // Definition of a virtual partials buffer (see "virtual subtrees" below): one step per internal node of its subtree.
 struct VStepHost {
@@ -87,6 +88,9 @@ struct Instance {
     // levelisation scratch
     std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
     bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
+    // pre-order on the T32 layout runs as two passes of the pruning kernel (see runPreOperations): scratch partials
+    // buffers, an identity matrix and transposed-matrix slots behind the caller's matrices, an all-missing tip
+    std::vector<double*> preScratch; uint8_t* preMissing = nullptr; int preIdentity = -1, preTransposed = -1;
     bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
     // kernel timer
     bool timing = false;
@@ -663,6 +667,59 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     return 0;
 }
 
+// One dependency level of pre-order ops on the T32 layout, expressed with the tuned pruning kernel:
+//   pass A   tmp        = (I . pre(parent)) * (P_sib . post(sib))         a pruning op whose first branch matrix is the identity
+//   pass B   pre(child) = (P_child^T . tmp) * 1                            a pruning op whose second child is an all-missing tip
+// (products with the identity's 0/1 entries and the sums of the resulting zeros are exact, so pass A adds no rounding).
+// PRE_SCRATCH ops at a time: their tmp buffers and transposed matrices are reused by the next chunk in stream order.
+int ensurePreScratch(Instance* in) {
+    if (!in->preScratch.empty()) return 0;
+    void* slab = nullptr;
+    int rc = devAlloc(in, &slab, in->partialsBytes * PRE_SCRATCH); if (rc) return rc;
+    void* miss = nullptr;
+    rc = devAlloc(in, &miss, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
+    in->preMissing = (uint8_t*)miss;
+    HIP_TRY(hipMemsetAsync(in->preMissing, in->S, (size_t)in->P, in->stream));
+    in->preScratch.assign(PRE_SCRATCH, nullptr);
+    for (int j = 0; j < PRE_SCRATCH; j++) in->preScratch[j] = (double*)((char*)slab + in->partialsBytes * j);
+    return 0;
+}
+
+int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
+    { int rc0 = ensurePreScratch(in); if (rc0) return rc0; }
+    std::vector<OpDesc> pass(2 * PRE_SCRATCH);
+    std::vector<int> pairs(2 * PRE_SCRATCH);
+    for (int b = 0; b < nOps; b += PRE_SCRATCH) {
+        const int n = std::min(PRE_SCRATCH, nOps - b);
+        bool anyWrite = false;
+        for (int j = 0; j < n; j++) {
+            const OpDesc& o = ops[b + j];
+            pairs[2 * j] = o.mat1; pairs[2 * j + 1] = in->preTransposed + j;
+            OpDesc& a = pass[j];
+            memset(&a, 0, sizeof(a));
+            a.dest = in->preScratch[j];
+            a.child1 = o.child1; a.mat1 = in->preIdentity;
+            a.child2 = o.child2; a.mat2 = o.mat2; a.kind = o.kind & mi355::KIND_STATES2;
+            a.pStart = 0; a.pEnd = in->P;
+            OpDesc& c = pass[n + j];
+            memset(&c, 0, sizeof(c));
+            c.dest = o.dest;
+            c.child1 = in->preScratch[j]; c.mat1 = in->preTransposed + j;
+            c.child2 = in->preMissing; c.mat2 = in->preIdentity; c.kind = mi355::KIND_STATES2;
+            c.scaleWrite = o.scaleWrite; c.scaleRead = o.scaleRead;
+            c.pStart = 0; c.pEnd = in->P;
+            anyWrite = anyWrite || o.scaleWrite != nullptr;
+        }
+        void *dPairs = nullptr, *dPass = nullptr;
+        int rc = uploadTransient(in, pairs.data(), (size_t)2 * n * sizeof(int), &dPairs); if (rc) return rc;
+        rc = uploadTransient(in, pass.data(), (size_t)2 * n * sizeof(OpDesc), &dPass); if (rc) return rc;
+        mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, n, in->S, in->C);
+        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass + n, n, in->matrices, in->P, in->S, in->C, anyWrite);
+    }
+    return 0;
+}
+
 // Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
 // matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
 // levelised like a post-order one and each level is one launch.
@@ -723,14 +780,19 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
     const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
+    // T32 layout (16..64 states): two passes of the MFMA pruning kernel per op instead of the VALU pre-order kernel
+    // (BEAGLE_MI355_PRE_NAIVE=1 keeps the latter, for A/B runs)
+    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    const bool twoPass = in->tiled && !preNaive;
     for (int chunkBegin = 0; chunkBegin < count;) {
         const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
         void* dChunk = nullptr;
-        int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
+        int rc = twoPass ? 0 : uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
         if (rc) return rc;
         for (int l = 0; l <= maxLevel; l++) {
             const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
             if (begin >= end) continue;
+            if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
             mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                      in->P, in->S, in->C, in->tiled, in->P);
         }
@@ -776,6 +838,9 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     int rc = (e1 != hipSuccess || e2 != hipSuccess) ? BEAGLE_ERROR_OUT_OF_MEMORY : 0;
     std::vector<mi355::EdgeDesc> descs;
     std::vector<double> sums;
+    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    const bool twoStep = in->tiled && !preNaive;
+    if (twoStep && !rc) rc = ensurePreScratch(in);
     for (int b = 0; b < count && !rc; b += chunk) {
         const int m = std::min(chunk, count - b);
         descs.assign(m, mi355::EdgeDesc());
@@ -790,10 +855,42 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
             d.dmat = dIdx[b + e];
         }
         if (rc) break;
-        void* dDesc = nullptr;
-        rc = uploadTransient(in, descs.data(), descs.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-        mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, m, in->matrices, in->weights + (size_t)wIdx * in->C,
-                                       in->patternWeights, dPer, dBlock, dSums, in->P, in->S, in->C, in->tiled);
+        // 16..64 states: an edge below an internal node takes the O(S^2) part through one pass of the MFMA pruning kernel
+        // (tmp = (I . pre) * (D . post)) and a streaming reduction; tip edges (O(S) per pattern) and every other state
+        // count use the direct kernel.  Output rows are addressed by EdgeDesc::slot, so the two groups can interleave.
+        std::vector<mi355::EdgeDesc> direct, viaPrune;
+        for (int e = 0; e < m; e++) {
+            descs[e].slot = e;
+            (twoStep && !descs[e].postIsStates ? viaPrune : direct).push_back(descs[e]);
+        }
+        if (!direct.empty()) {
+            void* dDesc = nullptr;
+            rc = uploadTransient(in, direct.data(), direct.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+            mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                                           in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
+        }
+        for (size_t q = 0; q < viaPrune.size() && !rc; q += PRE_SCRATCH) {
+            const int n = (int)std::min<size_t>(PRE_SCRATCH, viaPrune.size() - q);
+            std::vector<OpDesc> pass(n);
+            for (int j = 0; j < n; j++) {
+                mi355::EdgeDesc& ed = viaPrune[q + j];
+                OpDesc& a = pass[j];
+                memset(&a, 0, sizeof(a));
+                a.dest = in->preScratch[j];
+                a.child1 = ed.pre; a.mat1 = in->preIdentity;
+                a.child2 = ed.post; a.mat2 = ed.dmat;
+                a.pStart = 0; a.pEnd = in->P;
+                ed.tmp = in->preScratch[j];
+            }
+            void *dPass = nullptr, *dDesc = nullptr;
+            rc = uploadTransient(in, pass.data(), (size_t)n * sizeof(OpDesc), &dPass); if (rc) break;
+            rc = uploadTransient(in, &viaPrune[q], (size_t)n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+            mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+            mi355::launchEdgeReduce(in->stream, (const mi355::EdgeDesc*)dDesc, n, in->weights + (size_t)wIdx * in->C, in->patternWeights,
+                                    dPer, dBlock, in->P, in->S, in->C, in->tiled);
+        }
+        if (rc) break;
+        mi355::launchEdgeFinal(in->stream, dBlock, m, in->P, dSums);
         sums.resize((size_t)m * 2);
         rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) break;
         for (int e = 0; e < m; e++) {
@@ -935,7 +1032,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->tipUsers.assign(partialsBufferCount, std::vector<int>());
     in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());
     // matrix storage: the caller's buffers, then two private snapshot slots per partials buffer (virtual cherries)
-    const size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)mi355::VIRT_MAX_STEPS * partialsBufferCount : 0);
+    size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)mi355::VIRT_MAX_STEPS * partialsBufferCount : 0);
+    if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
@@ -975,6 +1073,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         ok = ok && upload(in, in->weights, w.data(), E * C * sizeof(double)) == 0;
         ok = ok && hipMemsetAsync(in->matrices, 0, matrixSlots * C * S * S * sizeof(double), in->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(in->siteLogL, 0, (size_t)patternCount * sizeof(double), in->stream) == hipSuccess;
+        if (ok && in->tiled) {   // identity matrix for the two-pass pre-order path
+            std::vector<double> eye(C * S * S, 0.0);
+            for (size_t c = 0; c < C; c++) for (size_t i = 0; i < S; i++) eye[c * S * S + i * S + i] = 1.0;
+            ok = upload(in, in->matrices + (size_t)in->preIdentity * C * S * S, eye.data(), eye.size() * sizeof(double)) == 0;
+        }
     }
     if (!ok) { destroy(in); return BEAGLE_ERROR_OUT_OF_MEMORY; }
 

@@ -108,14 +108,23 @@ void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const d
 struct EdgeDesc {
     const void*   post;          // post-order partials of the node below the edge (double*) or its compact states (uint8*)
     const double* pre;           // pre-order partials of the same node
+    const double* tmp;           // launchEdgeReduce only: pre[j] * (D . post)[j], produced by a pass of the pruning kernel
     int           dmat;          // differential matrix index (C*S*S doubles)
     int           postIsStates;
+    int           slot;          // output row: perPattern[slot][P], blockSums[slot][blocks][2]
+    int           pad;
 };
 int  edgeBlocks(int P);          // workgroups per edge = entries per edge in blockSums (x2 doubles)
-// outSums[2e] = sum_p w_p num/den, outSums[2e+1] = sum_p w_p (num/den)^2; perPattern (nullable) [e][P]
+// per edge: blockSums[slot][b] = {sum_p w_p num/den, sum_p w_p (num/den)^2} over workgroup b; perPattern (nullable) [slot][P];
+// finish with launchEdgeFinal
 void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
-                             const double* patternWeights, double* perPattern, double* blockSums, double* outSums,
+                             const double* patternWeights, double* perPattern, double* blockSums,
                              int P, int S, int C, bool tiled);
+// same outputs from tmp = pre * (D . post) (see EdgeDesc): num = sum_c w_c sum_j tmp, den = sum_c w_c sum_j pre * post
+void launchEdgeReduce(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* catWeights, const double* patternWeights,
+                      double* perPattern, double* blockSums, int P, int S, int C, bool tiled);
+// outSums[2r], outSums[2r+1] = fixed-order sums of row r's block sums, r < nRows
+void launchEdgeFinal(hipStream_t stream, const double* blockSums, int nRows, int P, double* outSums);
 void launchTransposeMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int count, int S, int C);
 void launchFillFrequencies(hipStream_t stream, double* dest, const double* freqs, int P, int S, int C, bool tiled);
 

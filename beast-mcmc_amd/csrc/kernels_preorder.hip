@@ -98,12 +98,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc*
                                                                  const double* __restrict__ patternWeights,
                                                                  double* __restrict__ perPattern, double* __restrict__ blockSums,
                                                                  int P, int S, int C) {
-    extern __shared__ double sh[];                 // D[S*S] | u[S][64] | x[S][64]
-    double* D = sh; double* u = sh + S * S; double* x = u + S * PRE_BLOCK;
+    extern __shared__ double sh[];                 // D[S*S] | rowsum[S] | u[S][64] | x[S][64]
+    double* D = sh; double* rs = sh + S * S; double* u = rs + S; double* x = u + S * PRE_BLOCK;
     const EdgeDesc& ed = edges[blockIdx.y];
     const int tid = threadIdx.x, p = blockIdx.x * PRE_BLOCK + tid, ntile = (P + 31) >> 5;
     const bool valid = p < P, postStates = ed.postIsStates != 0;
     const double MI355_GLOBAL* pre = gptr(ed.pre);
+    const size_t row = (size_t)ed.slot;
     int s = S;
     if (valid && postStates) s = gptr(reinterpret_cast<const uint8_t*>(ed.post))[p];
     double num = 0.0, den = 0.0;
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc*
         const double* G = matrices + ((size_t)ed.dmat * C + c) * S * S;
         __syncthreads();
         for (int e = tid; e < S * S; e += PRE_BLOCK) D[e] = G[e];
+        if (postStates) {                           // a missing tip state is the all-ones vector: D . 1 = the row sums
+            __syncthreads();
+            for (int j = tid; j < S; j += PRE_BLOCK) { double t = 0.0; for (int k = 0; k < S; k++) t += D[j * S + k]; rs[j] = t; }
+        }
         if (valid) {
             for (int i = 0; i < S; i++) u[i * PRE_BLOCK + tid] = pre[pidx<TILED>(c, p, i, P, S, ntile)];
             if (!postStates) {
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc*
             double t, xj;
             if (postStates) {
                 if (s < S) { t = D[j * S + s]; xj = j == s ? 1.0 : 0.0; }
-                else { t = 0.0; for (int k = 0; k < S; k++) t += D[j * S + k]; xj = 1.0; }
+                else { t = rs[j]; xj = 1.0; }
             } else {
                 t = 0.0; for (int k = 0; k < S; k++) t += D[j * S + k] * x[k * PRE_BLOCK + tid];
                 xj = x[j * PRE_BLOCK + tid];
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc*
     double w1 = 0.0, w2 = 0.0;
     if (valid) {
         const double deriv = num / den;
-        if (perPattern) perPattern[(size_t)blockIdx.y * P + p] = deriv;
+        if (perPattern) perPattern[row * P + p] = deriv;
         w1 = patternWeights[p] * deriv; w2 = w1 * deriv;
     }
     // fixed-shape butterfly over the wave: deterministic
     for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
     if (tid == 0) {
-        double* b = blockSums + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        double* b = blockSums + (row * gridDim.x + blockIdx.x) * 2;
         b[0] = w1; b[1] = w2;
     }
 }
@@ -160,21 +165,65 @@ __global__ __launch_bounds__(64) void k_edgeFinal(const double* __restrict__ blo
 int edgeBlocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
 
 void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
-                             const double* patternWeights, double* perPattern, double* blockSums, double* outSums,
+                             const double* patternWeights, double* perPattern, double* blockSums,
                              int P, int S, int C, bool tiled) {
     if (nEdges <= 0) return;
-    const size_t lds = ((size_t)S * S + (size_t)2 * S * PRE_BLOCK) * sizeof(double);
+    const size_t lds = ((size_t)S * S + S + (size_t)2 * S * PRE_BLOCK) * sizeof(double);
     static bool granted = false;
     if (!granted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         granted = true;
     }
-    const int nb = edgeBlocks(P);
-    dim3 grid(nb, nEdges), block(PRE_BLOCK);
+    dim3 grid(edgeBlocks(P), nEdges), block(PRE_BLOCK);
     if (tiled) hipLaunchKernelGGL(k_edgeDifferentials<true>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
     else hipLaunchKernelGGL(k_edgeDifferentials<false>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
-    hipLaunchKernelGGL(k_edgeFinal, dim3(nEdges), dim3(64), 0, stream, blockSums, nb, outSums);
+}
+
+// The streaming half of the two-step edge derivative (the O(S^2) half ran on the matrix cores as a pruning pass)
+template <bool TILED>
+__global__ __launch_bounds__(PRE_BLOCK) void k_edgeReduce(const EdgeDesc* __restrict__ edges, const double* __restrict__ catWeights,
+                                                          const double* __restrict__ patternWeights, double* __restrict__ perPattern,
+                                                          double* __restrict__ blockSums, int P, int S, int C) {
+    const EdgeDesc& ed = edges[blockIdx.y];
+    const int tid = threadIdx.x, p = blockIdx.x * PRE_BLOCK + tid, ntile = (P + 31) >> 5;
+    const bool valid = p < P;
+    const double MI355_GLOBAL* pre = gptr(ed.pre);
+    const double MI355_GLOBAL* post = gptr(reinterpret_cast<const double*>(ed.post));
+    const double MI355_GLOBAL* tmp = gptr(ed.tmp);
+    const size_t row = (size_t)ed.slot;
+    double w1 = 0.0, w2 = 0.0;
+    if (valid) {
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < C; c++) {
+            double n = 0.0, d = 0.0;
+            for (int j = 0; j < S; j++) {
+                const size_t a = pidx<TILED>(c, p, j, P, S, ntile);
+                n += tmp[a]; d += pre[a] * post[a];
+            }
+            num += catWeights[c] * n; den += catWeights[c] * d;
+        }
+        const double deriv = num / den;
+        if (perPattern) perPattern[row * P + p] = deriv;
+        w1 = patternWeights[p] * deriv; w2 = w1 * deriv;
+    }
+    for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
+    if (tid == 0) {
+        double* b = blockSums + (row * gridDim.x + blockIdx.x) * 2;
+        b[0] = w1; b[1] = w2;
+    }
+}
+
+void launchEdgeReduce(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* catWeights, const double* patternWeights,
+                      double* perPattern, double* blockSums, int P, int S, int C, bool tiled) {
+    if (nEdges <= 0) return;
+    dim3 grid(edgeBlocks(P), nEdges), block(PRE_BLOCK);
+    if (tiled) hipLaunchKernelGGL(k_edgeReduce<true>, grid, block, 0, stream, dEdges, catWeights, patternWeights, perPattern, blockSums, P, S, C);
+    else hipLaunchKernelGGL(k_edgeReduce<false>, grid, block, 0, stream, dEdges, catWeights, patternWeights, perPattern, blockSums, P, S, C);
+}
+
+void launchEdgeFinal(hipStream_t stream, const double* blockSums, int nRows, int P, double* outSums) {
+    if (nRows > 0) hipLaunchKernelGGL(k_edgeFinal, dim3(nRows), dim3(64), 0, stream, blockSums, edgeBlocks(P), outSums);
 }
 
 // ---- small helpers ------------------------------------------------------------------------------------------------
