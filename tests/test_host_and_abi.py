@@ -198,3 +198,62 @@ def test_pattern_sharded_two_ranks_gloo(tmp_path):
     a, b, whole, retries = float(line[1]), float(line[2]), float(line[3]), int(line[4])
     assert np.isfinite(whole) and retries == 1
     assert abs(a - whole) / abs(whole) < 1e-12 and abs(b - whole) / abs(whole) < 1e-12
+
+
+# ---- gradient call sequence: host-side structure, checked without a GPU ---------------------------
+
+def test_pre_order_op_list_mirrors_the_reference_delegate():
+    """beast-mcmc_amd/gradient.py builds the tuples of AbstractBeagleGradientDelegate.java:207-221
+    {pre(child), NONE, NONE, pre(parent), matrix(child), post(sibling), matrix(sibling)} in pre-order, with the
+    pre-order partials placed right after the post-order ones (BeagleDataLikelihoodDelegate.java:236-244)."""
+    import helpers
+    from beast_mcmc_amd.gradient import BranchGradient
+    wl = helpers.random_workload(11, 20, 4, 2, seed=8)
+    g = BranchGradient(wl, library=helpers.oracle_library())
+    tr = wl.tree
+    ops = g._pre_ops.reshape(-1, 7)
+    assert len(ops) == tr.node_count - 1                       # one op per non-root node
+    written = {g.pre_offset + tr.root}                         # the root's pre-order partial is set by the caller
+    seen_children = set()
+    for dest, ws, rs, par, mc, sib, ms in ops:
+        child = dest - g.pre_offset
+        parent = par - g.pre_offset
+        assert ws == bm.beagle.NONE and rs == bm.beagle.NONE
+        assert tr.parent[child] == parent and par in written    # a parent's op comes before its children's
+        sibling = tr.right[parent] if tr.left[parent] == child else tr.left[parent]
+        assert (mc, sib, ms) == (child, sibling, sibling)
+        written.add(dest); seen_children.add(child)
+    assert seen_children == set(range(tr.node_count)) - {tr.root}
+    post = g._post_ops.reshape(-1, 7)
+    assert [int(o[0]) for o in post] == [n for n in tr.postorder() if n >= tr.tip_count]
+    g.close()
+
+
+def test_oracle_pre_order_error_codes_and_null_outputs():
+    import helpers
+    from beast_mcmc_amd.gradient import BranchGradient
+    wl = helpers.random_workload(5, 12, 4, 1, seed=2)
+    g = BranchGradient(wl, library=helpers.oracle_library())
+    g.gradient()
+    ops = g._pre_ops[:7].copy()
+    for field, value in ((0, 10 ** 6), (3, -5), (4, 10 ** 6), (5, 10 ** 6)):
+        bad = ops.copy(); bad[field] = value
+        with pytest.raises(bm.beagle.BeagleException) as e:
+            g.b.updatePrePartials(bad, 1, bm.beagle.NONE)
+        assert e.value.code == -5
+    bad = ops.copy(); bad[0] = bad[3]                          # destination aliases the parent
+    with pytest.raises(bm.beagle.BeagleException) as e:
+        g.b.updatePrePartials(bad, 1, bm.beagle.NONE)
+    assert e.value.code == -5
+    # BEAST passes null for outDerivatives (and for outSumSquared on the second-derivative call)
+    import ctypes as C
+    f = g.b.lib.fn["CalculateEdgeDifferentials"]
+    post = np.asarray(g.edges, dtype=np.int32); pre = post + g.pre_offset
+    dm = np.full(len(post), g.q_index, dtype=np.int32); w = np.zeros(1, dtype=np.int32)
+    out = np.zeros(len(post))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = f(g.b.instance, ip(post), ip(pre), ip(dm), ip(w), len(post), None, out.ctypes.data_as(C.POINTER(C.c_double)), None)
+    assert rc == 0
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, dm, [0], len(post))
+    assert np.array_equal(out, s1)
+    g.close()
