@@ -111,6 +111,7 @@ _PROTOS = {
     "UpdatePrePartials": ([C.c_int, _IP, C.c_int, C.c_int], C.c_int),
     "UpdatePrePartialsByPartition": ([C.c_int, _IP, C.c_int], C.c_int),
     "CalculateEdgeDifferentials": ([C.c_int, _IP, _IP, _IP, _IP, C.c_int, _DP, _DP, _DP], C.c_int),
+    "CalculateCrossProductDifferentials": ([C.c_int, _IP, _IP, _IP, _IP, _DP, C.c_int, _DP, _DP], C.c_int),
 }
 
 # symbols every engine library must export (tests assert this list against include/beagle_mi355.h)
@@ -379,6 +380,17 @@ class Beagle:
                     self._f["CalculateEdgeDifferentials"](self.instance, _ip(po), _ip(pr), _ip(dm), _ip(cw), count,
                                                           _dp(per) if per is not None else None, _dp(s1), _dp(s2)))
         return s1, s2, per
+
+    def calculateCrossProductDifferentials(self, postBufferIndices, preBufferIndices, categoryRateIndices,
+                                           categoryWeightsIndices, edgeLengths, count, out=None):
+        """-> outSumDerivatives[S*S] (accumulated into ``out`` when given, as BEAST's zero-filled array)."""
+        po, pr = _i(postBufferIndices), _i(preBufferIndices)
+        cr, cw, t = _i(categoryRateIndices), _i(categoryWeightsIndices), _d(edgeLengths)
+        acc = np.zeros(self.stateCount * self.stateCount) if out is None else out
+        self._check("calculateCrossProductDifferentials",
+                    self._f["CalculateCrossProductDifferentials"](self.instance, _ip(po), _ip(pr), _ip(cr), _ip(cw), _dp(t),
+                                                                  count, _dp(acc), None))
+        return acc
 
     def getSiteLogLikelihoods(self, out=None):
         if out is None:

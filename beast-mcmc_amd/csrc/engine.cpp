@@ -904,6 +904,50 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     return rc;
 }
 
+// calculateCrossProductDifferentials (semantics: include/beagle_mi355.h)
+int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    std::vector<int> need;
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (in->virt[postIdx[e]].on) need.push_back(postIdx[e]);
+        if (in->virt[preIdx[e]].on) need.push_back(preIdx[e]);
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    std::vector<mi355::EdgeDesc> descs(count);
+    for (int e = 0; e < count; e++) {
+        const int po = postIdx[e], pr = preIdx[e];
+        mi355::EdgeDesc& d = descs[e];
+        if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
+        else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.pre = in->partials[pr];
+    }
+    const size_t nOut = (size_t)in->S * in->S;
+    const int nb = mi355::edgeBlocks(in->P);
+    double *dPartial = nullptr, *dOut = nullptr;
+    HIP_TRY(hipMalloc((void**)&dPartial, (size_t)nb * nOut * sizeof(double)));
+    if (hipMalloc((void**)&dOut, nOut * sizeof(double)) != hipSuccess) { hipFree(dPartial); return BEAGLE_ERROR_OUT_OF_MEMORY; }
+    std::vector<double> sums(nOut);
+    int rc = 0;
+    const size_t maxChunk = (RING_BYTES / 8) / sizeof(mi355::EdgeDesc);
+    for (size_t b = 0; b < (size_t)count && !rc; b += maxChunk) {
+        const size_t n = std::min(maxChunk, (size_t)count - b);
+        void *dDesc = nullptr, *dLen = nullptr;
+        rc = uploadTransient(in, &descs[b], n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+        rc = uploadTransient(in, lengths + b, n * sizeof(double), &dLen); if (rc) break;
+        mi355::launchCrossProducts(in->stream, (const mi355::EdgeDesc*)dDesc, (int)n, (const double*)dLen, in->weights + (size_t)wIdx * in->C,
+                                   in->rates + (size_t)rateIdx * in->C, in->patternWeights, dPartial, dOut, in->P, in->S, in->C, in->tiled);
+        rc = download(in, sums.data(), dOut, nOut * sizeof(double)); if (rc) break;
+        for (size_t k = 0; k < nOut; k++) outSum[k] += sums[k];
+    }
+    hipStreamSynchronize(in->stream);
+    hipFree(dPartial); hipFree(dOut);
+    return rc;
+}
+
 int accumulate(Instance* in, const int* idx, int count, int cum, double sign, int part) {
     if (badIndex(cum, in->scaleCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cum); if (rc) return rc;
@@ -1539,6 +1583,19 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
     GET_INSTANCE(instance);
     return runPreOperations(in, operations, operationCount, cumulativeScaleIndex);
+}
+
+int beagleCalculateCrossProductDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
+                                             const int* categoryRateIndices, const int* categoryWeightsIndices,
+                                             const double* edgeLengths, int count,
+                                             double* outSumDerivatives, double* outSumSquaredDerivatives) {
+    GET_INSTANCE(instance);
+    if (outSumSquaredDerivatives) return BEAGLE_ERROR_NO_IMPLEMENTATION;       // BEAST passes null
+    if (!postBufferIndices || !preBufferIndices || !categoryRateIndices || !categoryWeightsIndices || !edgeLengths || !outSumDerivatives)
+        return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (badIndex(categoryRateIndices[0], in->eigenCount) || badIndex(categoryWeightsIndices[0], in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return crossProducts(in, postBufferIndices, preBufferIndices, categoryRateIndices[0], categoryWeightsIndices[0], edgeLengths, count,
+                         outSumDerivatives);
 }
 
 int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,

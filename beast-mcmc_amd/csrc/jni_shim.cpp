@@ -222,7 +222,12 @@ JNI_FN(jint, calculateEdgeDifferentials)(JNIEnv* env, jobject, jint instance, ji
     DblArr o0(env, outDeriv, true), o1(env, outSum, true), o2(env, outSumSquared, true);
     return beagleCalculateEdgeDifferentials(instance, a, b, c, w, count, o0, o1, o2);
 }
-JNI_FN(jint, calculateCrossProductDifferentials)(JNIEnv*, jobject, jint, jintArray, jintArray, jintArray, jintArray, jdoubleArray,
-                                                 jint, jdoubleArray, jdoubleArray) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+JNI_FN(jint, calculateCrossProductDifferentials)(JNIEnv* env, jobject, jint instance, jintArray post, jintArray pre, jintArray rates,
+                                                 jintArray weights, jdoubleArray lengths, jint count, jdoubleArray outSum,
+                                                 jdoubleArray outSumSquared) {
+    IntArr a(env, post), b(env, pre), r(env, rates), w(env, weights);
+    DblArr t(env, lengths), o1(env, outSum, true), o2(env, outSumSquared, true);
+    return beagleCalculateCrossProductDifferentials(instance, a, b, r, w, t, count, o1, o2);
+}
 JNI_FN(jint, calculateEdgeDerivative)(JNIEnv*, jobject, jint, jintArray, jintArray, jint, jintArray, jintArray, jint, jint, jint,
                                       jintArray, jint, jdoubleArray, jdoubleArray) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }

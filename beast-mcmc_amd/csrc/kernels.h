@@ -125,6 +125,9 @@ void launchEdgeReduce(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, co
                       double* perPattern, double* blockSums, int P, int S, int C, bool tiled);
 // outSums[2r], outSums[2r+1] = fixed-order sums of row r's block sums, r < nRows
 void launchEdgeFinal(hipStream_t stream, const double* blockSums, int nRows, int P, double* outSums);
+// out[S*S] = sum over edges and patterns of the weighted pre x post cross products (see kernels_preorder.hip); partial: [edgeBlocks(P)][S*S]
+void launchCrossProducts(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* dEdgeLengths, const double* catWeights,
+                         const double* catRates, const double* patternWeights, double* partial, double* out, int P, int S, int C, bool tiled);
 void launchTransposeMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int count, int S, int C);
 void launchFillFrequencies(hipStream_t stream, double* dest, const double* freqs, int P, int S, int C, bool tiled);
 

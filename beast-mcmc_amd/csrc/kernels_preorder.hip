@@ -226,6 +226,97 @@ void launchEdgeFinal(hipStream_t stream, const double* blockSums, int nRows, int
     if (nRows > 0) hipLaunchKernelGGL(k_edgeFinal, dim3(nRows), dim3(64), 0, stream, blockSums, edgeBlocks(P), outSums);
 }
 
+// ---- cross products (calculateCrossProductDifferentials) -------------------------------------------------------------
+// out[i][j] = sum_e t_e sum_p weight_p (sum_c w_c r_c pre_e[c,p,i] post_e[c,p,j]) / (sum_c w_c pre_e . post_e)
+// One wave = one block of 64 patterns, looping over every edge: per (edge, category) the scaled pre column and the post
+// column of the 64 patterns go to LDS and thread t accumulates the outputs t, t+64, ... as 64-long dot products — a small
+// S x 64 by 64 x S product per step, accumulators in registers.  partial[block][S*S] is then summed over the blocks in
+// a fixed order (k_crossFinal).  First correct version (VALU; the shape is MFMA-able).
+constexpr int CROSS_MAXM = 64;     // outputs per thread: ceil(64 * 64 / 64)
+
+template <bool TILED>
+__global__ __launch_bounds__(PRE_BLOCK) void k_crossProducts(const EdgeDesc* __restrict__ edges, int nEdges,
+                                                             const double* __restrict__ edgeLengths,
+                                                             const double* __restrict__ catWeights, const double* __restrict__ catRates,
+                                                             const double* __restrict__ patternWeights,
+                                                             double* __restrict__ partial, int P, int S, int C) {
+    extern __shared__ double sh[];                 // u[S][64] | x[S][64]
+    double* u = sh; double* x = sh + S * PRE_BLOCK;
+    const int tid = threadIdx.x, p = blockIdx.x * PRE_BLOCK + tid, ntile = (P + 31) >> 5, nOut = S * S;
+    const bool valid = p < P;
+    double acc[CROSS_MAXM];
+#pragma unroll
+    for (int m = 0; m < CROSS_MAXM; m++) acc[m] = 0.0;
+    const double pw = valid ? patternWeights[p] : 0.0;
+    for (int e = 0; e < nEdges; e++) {
+        const EdgeDesc& ed = edges[e];
+        const bool postStates = ed.postIsStates != 0;
+        const double MI355_GLOBAL* pre = gptr(ed.pre);
+        const double MI355_GLOBAL* post = gptr(reinterpret_cast<const double*>(ed.post));
+        int s = S;
+        if (valid && postStates) s = gptr(reinterpret_cast<const uint8_t*>(ed.post))[p];
+        double den = 0.0;
+        if (valid)
+            for (int c = 0; c < C; c++) {
+                double d = 0.0;
+                for (int k = 0; k < S; k++) {
+                    const double xk = postStates ? (s < S ? (k == s ? 1.0 : 0.0) : 1.0) : post[pidx<TILED>(c, p, k, P, S, ntile)];
+                    d += pre[pidx<TILED>(c, p, k, P, S, ntile)] * xk;
+                }
+                den += catWeights[c] * d;
+            }
+        const double f = valid ? edgeLengths[e] * pw / den : 0.0;
+        for (int c = 0; c < C; c++) {
+            const double g = f * catWeights[c] * catRates[c];
+            __syncthreads();
+            for (int k = 0; k < S; k++) {
+                u[k * PRE_BLOCK + tid] = valid ? g * pre[pidx<TILED>(c, p, k, P, S, ntile)] : 0.0;
+                x[k * PRE_BLOCK + tid] = !valid ? 0.0 : postStates ? (s < S ? (k == s ? 1.0 : 0.0) : 1.0) : post[pidx<TILED>(c, p, k, P, S, ntile)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < CROSS_MAXM; m++) {
+                const int o = tid + m * PRE_BLOCK;
+                if (o < nOut) {
+                    const int i = o / S, j = o - i * S;
+                    double t = 0.0;
+                    for (int l = 0; l < PRE_BLOCK; l++) t += u[i * PRE_BLOCK + l] * x[j * PRE_BLOCK + l];
+                    acc[m] += t;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < CROSS_MAXM; m++) {
+        const int o = tid + m * PRE_BLOCK;
+        if (o < nOut) partial[(size_t)blockIdx.x * nOut + o] = acc[m];
+    }
+}
+
+__global__ void k_crossFinal(const double* __restrict__ partial, int nBlocks, int nOut, double* __restrict__ out) {
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= nOut) return;
+    double t = 0.0;
+    for (int b = 0; b < nBlocks; b++) t += partial[(size_t)b * nOut + o];
+    out[o] = t;
+}
+
+void launchCrossProducts(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* dEdgeLengths, const double* catWeights,
+                         const double* catRates, const double* patternWeights, double* partial, double* out, int P, int S, int C, bool tiled) {
+    if (nEdges <= 0) return;
+    const size_t lds = (size_t)2 * S * PRE_BLOCK * sizeof(double);
+    static bool granted = false;
+    if (!granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_crossProducts<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_crossProducts<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        granted = true;
+    }
+    const int nb = edgeBlocks(P);
+    if (tiled) hipLaunchKernelGGL(k_crossProducts<true>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
+    else hipLaunchKernelGGL(k_crossProducts<false>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
+    hipLaunchKernelGGL(k_crossFinal, dim3((S * S + 63) / 64), dim3(64), 0, stream, partial, nb, S * S, out);
+}
+
 // ---- small helpers ------------------------------------------------------------------------------------------------
 // matrices[dst] = transpose(matrices[src]) per category
 __global__ void k_transposeMatrices(double* __restrict__ matrices, const int* __restrict__ srcDst, int S, int C) {

@@ -113,6 +113,13 @@ class BranchGradient:
             result.append(per)
         return tuple(result)
 
+    def cross_products(self):
+        """SubstitutionModelCrossProductDelegate.java:149-162 (one substitution model): d lnL / d Q_ij, first-order form.
+        Call after gradient() (needs the pre-order partials)."""
+        post = np.asarray(self.edges, dtype=np.int32)
+        return self.b.calculateCrossProductDifferentials(post, post + self.pre_offset, [0], [0], self.branch_lengths[post],
+                                                         len(post)).reshape(self.S, self.S)
+
     def pre_partials(self, node):
         return self.b.getPartials(self.pre_offset + node, _b.NONE)
 

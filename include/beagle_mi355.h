@@ -239,6 +239,16 @@ int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices,
                                      const int* derivativeMatrixIndices, const int* categoryWeightsIndices, int count,
                                      double* outDerivatives, double* outSumDerivatives, double* outSumSquaredDerivatives);
 
+/* calculateCrossProductDifferentials (I[I[I[I[I[DI[D[D)I — discrete/SubstitutionModelCrossProductDelegate.java:153-178.
+ * Semantics INFERRED from the call site and its consumer (AbstractLogAdditiveSubstitutionModelGradient.java:246-270 reads the
+ * result as d lnL / d Q_ij), first-order form:
+ *   outSumDerivatives[i*S+j] += sum_e edgeLengths[e] sum_p weight_p (sum_c w_c r_c pre_e[c,p,i] post_e[c,p,j]) / (sum_c w_c pre_e . post_e)
+ * outSumSquaredDerivatives must be NULL (BEAST passes null); otherwise BEAGLE_ERROR_NO_IMPLEMENTATION. */
+int beagleCalculateCrossProductDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
+                                             const int* categoryRateIndices, const int* categoryWeightsIndices,
+                                             const double* edgeLengths, int count,
+                                             double* outSumDerivatives, double* outSumSquaredDerivatives);
+
 /* ---- entry points that exist in the binding but are not built yet: exported so the JNI shim links, and
  * return BEAGLE_ERROR_NO_IMPLEMENTATION (-7). ------------------------------------------------------ */
 int beagleAddTransitionMatrices(int instance, const int* firstIndices, const int* secondIndices,

@@ -682,6 +682,56 @@ int oracle_beagleCalculateEdgeDifferentials(int h, const int* postIdx, const int
     return BEAGLE_SUCCESS;
 }
 
+/* calculateCrossProductDifferentials — the one gradient native BEAST uses besides the edge derivatives
+ * (src/dr/evomodel/treedatalikelihood/discrete/SubstitutionModelCrossProductDelegate.java:153-178; the S*S result is consumed
+ * as d lnL / d Q_ij by AbstractLogAdditiveSubstitutionModelGradient.java:246-270).  Its arithmetic lives only in beagle-lib
+ * (absent); INFERRED from the call site and its consumer as the first-order form in which dP/dQ_ij ~ t P E_ij:
+ *   out[i*S+j] += sum_e t_e sum_p weight_p ( sum_c w_c r_c pre_e[c,p,i] post_e[c,p,j] ) / ( sum_c w_c sum_k pre_e[c,p,k] post_e[c,p,k] )
+ * Checked (tests/test_oracle_golden.py) through the one direction in which it is exact: sum_ij Q_ij out[ij] must equal
+ * sum_e t_e * (edge derivative of e), because scaling Q is scaling every branch.  PARITY UNPINNED beyond that identity. */
+int oracle_beagleCalculateCrossProductDifferentials(int h, const int* postIdx, const int* preIdx, const int* rateIdx, const int* wIdx,
+                                                    const double* edgeLengths, int count, double* outSum, double* outSumSquared) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (outSumSquared) return BEAGLE_ERROR_NO_IMPLEMENTATION;      /* BEAST passes null (:158-162) */
+    if (count <= 0) return BEAGLE_SUCCESS;
+    const int S = in->S, P = in->P, C = in->C;
+    if (!wIdx || !rateIdx || wIdx[0] < 0 || wIdx[0] >= in->eigenCount || rateIdx[0] < 0 || rateIdx[0] >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const double* w = in->catWeights[wIdx[0]]; const double* r = in->catRates[rateIdx[0]];
+    for (int e = 0; e < count; e++) {
+        int po = postIdx[e], pr = preIdx[e];
+        if (po < 0 || po >= in->partialsCount || pr < 0 || pr >= in->partialsCount || !in->partials[pr] ||
+            (!in->tipStates[po] && !in->partials[po])) return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    double* acc = (double*)calloc((size_t)S * S, sizeof(double));
+    double* xs = (double*)malloc(sizeof(double) * S);
+    for (int e = 0; e < count; e++) {
+        const int* ps = in->tipStates[postIdx[e]]; const double* px = in->partials[postIdx[e]];
+        const double* pre = in->partials[preIdx[e]];
+        for (int p = 0; p < P; p++) {
+            double den = 0.0;
+            for (int c = 0; c < C; c++) {
+                const double* u = pre + ((size_t)c * P + p) * S;
+                double d = 0.0;
+                for (int k = 0; k < S; k++) {
+                    double xk = ps ? ((ps[p] < S) ? (k == ps[p] ? 1.0 : 0.0) : 1.0) : px[((size_t)c * P + p) * S + k];
+                    d += u[k] * xk;
+                }
+                den += w[c] * d;
+            }
+            const double f = edgeLengths[e] * in->patternWeights[p] / den;
+            for (int c = 0; c < C; c++) {
+                const double* u = pre + ((size_t)c * P + p) * S;
+                for (int k = 0; k < S; k++) xs[k] = ps ? ((ps[p] < S) ? (k == ps[p] ? 1.0 : 0.0) : 1.0) : px[((size_t)c * P + p) * S + k];
+                const double g = f * w[c] * r[c];
+                for (int i = 0; i < S; i++) { const double gi = g * u[i]; for (int j = 0; j < S; j++) acc[i * S + j] += gi * xs[j]; }
+            }
+        }
+    }
+    for (int k = 0; k < S * S; k++) outSum[k] += acc[k];
+    free(acc); free(xs);
+    return BEAGLE_SUCCESS;
+}
+
 int oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

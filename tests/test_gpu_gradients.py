@@ -41,6 +41,10 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
     close(gg, go, "gradient")
     close(hg, ho, "second derivatives")
     close(pg, po, "per-pattern derivatives")
+    cg, co = g.cross_products(), o.cross_products()
+    close(cg, co, "cross products")
+    q = (wl.eig.evec * wl.eig.evals[None, :]) @ wl.eig.ievc
+    assert helpers.rel_err(float(np.sum(q * cg)), float(np.dot(g.branch_lengths, gg))) <= 1e-9      # exact direction (scaling Q)
     for n in range(g.N):
         if n == wl.tree.root:
             continue

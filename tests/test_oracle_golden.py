@@ -249,3 +249,23 @@ def test_oracle_pre_order_partials_invariant():
     mt = g.b.getTransitionMatrix(g.q2_index).reshape(g.C, g.S, g.S)
     assert np.array_equal(mt, np.transpose(m, (0, 2, 1)))
     g.close()
+
+
+@pytest.mark.parametrize("S,C", [(4, 4), (20, 2), (61, 1)])
+def test_oracle_cross_products_scaling_identity(S, C):
+    """calculateCrossProductDifferentials is inferred (header of the oracle function).  The one direction in which the
+    first-order form is exact pins its structure — category rates, branch lengths, pattern weights, the per-pattern
+    denominator: scaling Q by (1 + a) is scaling every branch, so sum_ij Q_ij dlnL/dQ_ij = sum_b t_b dlnL/dt_b."""
+    from beast_mcmc_amd.gradient import BranchGradient
+    wl = helpers.random_workload(8, 45, S, C, seed=31 + S)
+    g = BranchGradient(wl, library=helpers.oracle_library())
+    lnl, grad = g.gradient()
+    cp = g.cross_products()
+    q = (wl.eig.evec * wl.eig.evals[None, :]) @ wl.eig.ievc
+    assert helpers.rel_err(float(np.sum(q * cp)), float(np.dot(g.branch_lengths, grad))) < 1e-12
+    # accumulates into the caller's array, as BEAST's zero-filled buffer expects
+    post = np.asarray(g.edges, dtype=np.int32)
+    acc = np.ones(S * S)
+    g.b.calculateCrossProductDifferentials(post, post + g.pre_offset, [0], [0], g.branch_lengths[post], len(post), out=acc)
+    assert np.allclose(acc - 1.0, cp.ravel(), rtol=1e-12, atol=1e-12)
+    g.close()
