@@ -1,7 +1,11 @@
-// Pre-order partials and edge derivatives for gfx950 — first correct version, any state count,
-// both partials layouts.  One thread = one pattern; a workgroup is one wavefront (64 patterns) whose branch matrices
-// live in LDS (read at wave-uniform addresses) next to the wave's own operand columns.  Not yet tuned: these kernels
-// run once per *gradient* evaluation, the pruning kernels once per likelihood evaluation.
+// Pre-order partials, edge derivatives and cross products for gfx950.
+//
+// The kernels in this file are the DIRECT forms: any state count, both partials layouts, one thread = one pattern, a
+// workgroup = one wavefront (64 patterns) whose matrices live in LDS (read at wave-uniform addresses) next to the wave's own
+// operand columns.  They are what 4-state (and S < 16, S > 64) instances run — at 4 states they are pure streaming and
+// sit near the HBM roofline.  For 16..64 states the engine routes the O(S^2) work through the MFMA pruning kernel instead
+// (engine.cpp preLevelTwoPass / edgeDifferentials: a pre-order op = two pruning passes, an internal edge = one pass +
+// k_edgeReduce) and uses the direct kernels only for tip edges, which are O(S) per pattern.
 //
 // Arithmetic (callers: src/dr/evomodel/treedatalikelihood/preorder/AbstractBeagleGradientDelegate.java:207-221,
 // AbstractBeagleBranchGradientDelegate.java:82-92 with the formula spelled out at :103-140):
