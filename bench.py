@@ -233,6 +233,22 @@ def main():
     return out
 
 
+def _host_cpu_info():
+    """What the box actually grants this process (the OpenMP default may exceed a container's CPU quota)."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup:" + os.path.basename(path)] = open(path).read().strip()
+            break
+        except Exception:
+            pass
+    return info
+
+
 def cpu_baseline(bm, wl, sample, gpu_tl):
     """The CPU oracle (oracle/beagle_cpu_oracle.c — a plain-C restatement, NOT beagle-lib) timed on this box's
     host cores on a bounded sample of the same workload: the full tree, `sample` of the P patterns (patterns
@@ -290,6 +306,7 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
             "kind": "port",
             "sample": "%d of %d patterns, full %d-taxon tree, %d evaluations in %.1f s on %d OpenMP threads; scaled by %d/%d"
                       % (n, wl.pattern_count, wl.tip_count, reps, dt, threads, n, wl.pattern_count),
+            "host_cpus": _host_cpu_info(),
             "single_core_value": round(one_core, 5),
             "single_core_sample": "%d patterns, %d evaluations in %.1f s on 1 thread" % (n1, reps1, dt1),
             "gpu_vs_cpu_site_lnL_max_rel_err": rel}
