@@ -249,27 +249,6 @@ def _host_cpu_info():
     return info
 
 
-def _granted_cpus():
-    n = None
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:
-        n = os.cpu_count()
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return n
-
-
 def cpu_baseline(bm, wl, sample, gpu_tl):
     """The CPU oracle (oracle/beagle_cpu_oracle.c — a plain-C restatement, NOT beagle-lib) timed on this box's
     host cores on a bounded sample of the same workload: the full tree, `sample` of the P patterns (patterns
@@ -285,12 +264,9 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
     sub = Workload(wl.name + "-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
                    np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], wl.state_count)
     lib = helpers.oracle_library()
+    # a container's CPU quota can be far below the core count OpenMP sees: helpers.oracle_library() caps the oracle's
+    # thread count to helpers.granted_cpus(), so the baseline runs on what the box actually grants
     threads = lib.lib.oracle_threads()
-    # a container's CPU quota can be far below the core count OpenMP sees: run the baseline on what is actually granted
-    granted = _granted_cpus()
-    if granted and granted < threads:
-        threads = granted
-        lib.lib.oracle_set_threads(int(threads))
     from beast_mcmc_amd.treelikelihood import RESCALE_DYNAMIC
     o = BeagleTreeLikelihood(sub, library=lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
     o.getLogLikelihood()

@@ -15,11 +15,36 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle_beagle.so")
 _oracle = None
 
 
+def granted_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (a container can see 256 cores and be
+    granted 16 — OpenMP's default thread count then oversubscribes the oracle badly)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def oracle_library():
     """The CPU oracle (oracle/beagle_cpu_oracle.c) behind the same binding class as the engine."""
     global _oracle
     if _oracle is None:
         _oracle = bm.beagle.EngineLibrary(ORACLE_SO, prefix="oracle_")
+        n = granted_cpus()
+        if n < _oracle.lib.oracle_threads():
+            _oracle.lib.oracle_set_threads(int(n))
     return _oracle
 
 
