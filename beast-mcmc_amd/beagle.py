@@ -118,7 +118,7 @@ _PROTOS = {
 ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetApiTable"] + \
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
-               "beagleMi355KernelTimer", "beagleMi355DeviceBytes"]
+               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats"]
 
 
 class EngineLibrary:
@@ -423,6 +423,13 @@ class Beagle:
         f = self._ext("beagleMi355KernelTimer", [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)])
         self._check("kernelTimer", f(self.instance, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def walkStats(self):
+        """Counters of the 4-state pattern walk since the last kernelTimer call (include/beagle_mi355.h)."""
+        out = (C.c_long * 8)()
+        self._check("walkStats", self._ext("beagleMi355WalkStats", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
+        keys = ("micro_ops", "stored", "mem_reads", "tip_reads", "scale_reads", "walks", "scale_writes")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def deviceBytes(self):
         return self._ext("beagleMi355DeviceBytes", [C.c_int], C.c_long)(self.instance)

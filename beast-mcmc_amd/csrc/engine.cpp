@@ -20,6 +20,7 @@
 
 #include "../../include/beagle_mi355.h"
 #include "kernels.h"
+#include "planner.h"
 
 using mi355::OpDesc;
 
@@ -39,36 +40,17 @@ constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its dev
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
 constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
 
-// Definition of a virtual partials buffer (see "virtual subtrees" below): one step per internal node of its subtree.
-struct VStepHost {
-    int type;               // mi355::VS_*
-    int tipA, tipB;         // tip buffer indices (CHERRY: both, EXTEND: tipB)
-    int scaleIdx;           // this node's scale buffer, or -1
-    int originA, originB;   // where the two matrices were copied FROM (stable for the call that created the node)
-    int split;              // JOIN: number of leading steps that belong to the A operand (the rest, up to this step, is the B chain)
-};
-struct Virt {
-    bool on = false;
-    bool chainOnly = true;  // no JOIN step: the program may also run on accumulator B
-    int nSteps = 0;
-    int stamp = -1;         // Instance::stamp of the updatePartials call that created (or last re-confirmed) it
-    VStepHost steps[mi355::VIRT_MAX_STEPS];
-    // the op that defined it, for the steady-state fast path of runOperations (an MCMC chain re-issues the same op on the
-    // same buffers every other evaluation): child/matrix/scale indices, whether each child was a tip, and for virtual
-    // children their definition version and whether they were (re)defined in the same call
-    int version = 0;
-    int sigC1 = -1, sigM1 = -1, sigC2 = -1, sigM2 = -1, sigScale = -2;
-    bool sigTip1 = false, sigTip2 = false, fresh1 = false, fresh2 = false;
-    int childVer1 = -1, childVer2 = -1;
-};
-
 struct Instance {
     int device = 0;
-    std::vector<Virt> virt;                              // per partials buffer
-    std::vector<std::vector<int>> tipUsers, scaleUsers;  // virtual buffers defined by a tip / a scale buffer
-    int virtVersion = 0;                                 // bumped by every (re)definition
-    bool virtualCherries = false;                        // 4 states, single partition; BEAGLE_MI355_NO_VIRTUAL=1 disables
-    int maxVirtSteps = VIRT_EMIT_STEPS;                  // longest virtual-subtree program (BEAGLE_MI355_VSTEPS lowers it)
+    // 4 states: every operation list runs as ONE launch of the pattern-walk kernel (kernels_walk4.hip), programmed by the
+    // walk planner (planner.h), which also owns the definitions of virtual buffers
+    bool walk = false;
+    mi355::WalkPlanner planner;
+    mi355::Plan plan;                                    // scratch of the current call
+    std::vector<mi355::WalkOp> walkOps;                  // scratch: resolved program
+    size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals], this many doubles apart
+    char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
+    long statMicroOps = 0, statStored = 0, statMemReads = 0, statTipReads = 0, statScaleReads = 0, statWalks = 0, statScaleWrites = 0;   // since the last timer reset
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
     size_t partialsBytes = 0;
@@ -181,7 +163,8 @@ int ensurePartials(Instance* in, int idx) {
 
 int ensureScale(Instance* in, int idx) {
     if (in->scale[idx]) return 0;
-    const size_t bytes = ((size_t)in->P * sizeof(double) + 255) & ~(size_t)255;
+    // walk instances keep [factors | reciprocals] so that read mode never divides (kernels_walk4.hip)
+    const size_t bytes = in->walk ? 2 * in->scaleStride * sizeof(double) : (((size_t)in->P * sizeof(double) + 255) & ~(size_t)255);
     if (in->scaleSlabLeft == 0) {
         int remaining = 0;
         for (double* p : in->scale) if (!p) remaining++;
@@ -218,6 +201,7 @@ void destroy(Instance* in) {
     if (in->ownStream) hipStreamSynchronize(in->ownStream);
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
+    if (in->bigStage) hipFree(in->bigStage);
     if (in->hRing) hipHostFree(in->hRing);
     if (in->hResult) hipHostFree(in->hResult);
     for (auto& ev : in->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -279,200 +263,180 @@ Resources* resources() {
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 
-// ---- virtual subtrees ---------------------------------------------------------------------------------------
-// A partials buffer is "virtual" when its content is DEFINED instead of stored: a straight-line program with one step
-// per internal node of a small all-compact-tip subtree (kernels.h VStep; at most VIRT_MAX_STEPS nodes, evaluable with
-// two accumulators), the tip buffers it reads, private snapshots of every branch matrix in the subtree (kept behind
-// the caller's matrices: slot(X, step, 0/1)) and each node's scale buffer.  Nothing is written to HBM for such a
-// buffer; parents recompute it in registers (kernels_nuc4.hip CH_VIRTUAL), bitwise as the ordinary ops would have.
-// The definition is self-contained: it never refers to other partials buffers or to the caller's matrix buffers, so
-// buffer flips and matrix updates cannot invalidate it.  What CAN change a defining input — new tip states, a write to
-// one of its scale buffers — and everything that needs the real data — getPartials, use as root, a reader that cannot
-// fuse — first calls materializeList, which runs the defining op from the snapshot.
-inline int snapSlot(const Instance* in, int X, int step, int which) {
-    return in->matrixCount + X * 2 * mi355::VIRT_MAX_STEPS + 2 * step + which;
-}
+// ---- the pattern walk (4 states) ------------------------------------------------------------------------------------
+// A partials buffer is "virtual" when its content is DEFINED instead of stored (planner.h VirtDef): a few steps over
+// compact tips, private snapshots of every branch matrix in the subtree (kept behind the caller's matrices) and each
+// node's scale buffer.  Nothing is written to HBM for such a buffer; the walk recomputes it in registers where a parent
+// needs it, bitwise as the ordinary operation would have.  The definition is self-contained: it never refers to other
+// partials buffers or to the caller's matrix buffers, so buffer flips and matrix updates cannot invalidate it.  What CAN
+// change a defining input — new tip states, a write to one of its scale buffers — and everything that needs the real
+// data — getPartials, use as root, the pre-order kernels — first calls materializeList, which runs the definition with
+// a store.
+static_assert(mi355::PK_MEM == mi355::WK_MEM && mi355::PK_TIPS == mi355::WK_TIPS && mi355::PK_ACC == mi355::WK_ACC &&
+              mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1, "planner kinds = kernel kinds");
+static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_READ && mi355::PS_WRITE == mi355::WS_WRITE, "scale modes");
 
-void clearVirtual(Instance* in, int X) {
-    Virt& v = in->virt[X];
-    if (!v.on) return;
-    auto drop = [X](std::vector<int>& u) { u.erase(std::remove(u.begin(), u.end(), X), u.end()); };
-    for (int s = 0; s < v.nSteps; s++) {
-        const VStepHost& h = v.steps[s];
-        if (h.tipA >= 0) drop(in->tipUsers[h.tipA]);
-        if (h.tipB >= 0) drop(in->tipUsers[h.tipB]);
-        if (h.scaleIdx >= 0) drop(in->scaleUsers[h.scaleIdx]);
-    }
-    v.on = false;
-}
+inline bool isVirt(const Instance* in, int X) { return in->walk && in->planner.isVirtual(X); }
+inline void clearVirtual(Instance* in, int X) { if (in->walk) in->planner.clearVirtual(X); }
+inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
+inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X] = on ? 1 : 0; }
 
-void registerVirtual(Instance* in, int X) {
-    const Virt& v = in->virt[X];
-    auto add = [X](std::vector<int>& u) { if (std::find(u.begin(), u.end(), X) == u.end()) u.push_back(X); };
-    for (int s = 0; s < v.nSteps; s++) {
-        const VStepHost& h = v.steps[s];
-        if (h.tipA >= 0) add(in->tipUsers[h.tipA]);
-        if (h.tipB >= 0) add(in->tipUsers[h.tipB]);
-        if (h.scaleIdx >= 0) add(in->scaleUsers[h.scaleIdx]);
-    }
-}
-
-// Device form of steps [first, last) of X's program; `toA` renames a B-chain to accumulator A (used stand-alone).
-void emitProgram(const Instance* in, int X, int first, int last, bool toA, mi355::VStep* out) {
-    const Virt& v = in->virt[X];
-    int n = 0;
-    for (int s = first; s < last; s++, n++) {
-        const VStepHost& h = v.steps[s];
-        mi355::VStep& d = out[n];
-        d.type = h.type;
-        if (toA && d.type == mi355::VS_CHERRY_B) d.type = mi355::VS_CHERRY_A;
-        if (toA && d.type == mi355::VS_EXTEND_B) d.type = mi355::VS_EXTEND_A;
-        d.tipA = h.tipA >= 0 ? in->tipStates[h.tipA] : nullptr;
-        d.tipB = h.tipB >= 0 ? in->tipStates[h.tipB] : nullptr;
-        d.scale = h.scaleIdx >= 0 ? in->scale[h.scaleIdx] : nullptr;
-        d.matA = snapSlot(in, X, s, 0); d.matB = snapSlot(in, X, s, 1);
-        d.pad = 0;
-    }
-    for (; n < mi355::VIRT_MAX_STEPS; n++) { memset(&out[n], 0, sizeof(mi355::VStep)); out[n].type = mi355::VS_END; }
-}
-
-// Try to define buffer X = node(child1 over matrix m1, child2 over matrix m2, scale).  Children are compact tips or
-// virtual buffers.  Appends (source, destination) matrix-copy pairs for k_snapshot.  false: not expressible.
-bool buildVirtual(Instance* in, int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
-    Virt nv;
-    nv.on = true; nv.stamp = in->stamp; nv.nSteps = 0; nv.chainOnly = true;
-    std::vector<int> pairs;
-    auto append = [&](int srcBuf, bool toB) -> bool {
-        const Virt& src = in->virt[srcBuf];
-        for (int s = 0; s < src.nSteps; s++) {
-            if (nv.nSteps >= in->maxVirtSteps) return false;
-            VStepHost h = src.steps[s];
-            if (toB) h.type = h.type == mi355::VS_CHERRY_A ? mi355::VS_CHERRY_B : mi355::VS_EXTEND_B;
-            // a child defined in THIS call has its slots written by the same k_snapshot launch: copy from its origins
-            const int fromA = src.stamp == in->stamp ? h.originA : snapSlot(in, srcBuf, s, 0);
-            const int fromB = src.stamp == in->stamp ? h.originB : snapSlot(in, srcBuf, s, 1);
-            h.originA = fromA; h.originB = fromB;
-            pairs.push_back(fromA); pairs.push_back(snapSlot(in, X, nv.nSteps, 0));
-            pairs.push_back(fromB); pairs.push_back(snapSlot(in, X, nv.nSteps, 1));
-            nv.steps[nv.nSteps++] = h;
+// Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
+// micro-operations travel together) and enqueue the snapshot copies and the walk.
+int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk = nullptr) {
+    const size_t n = plan.prog.size();
+    if (n == 0) return 0;
+    std::vector<mi355::WalkOp>& w = in->walkOps;
+    w.resize(n);
+    const unsigned matStride = (unsigned)in->C * 16;
+    for (size_t i = 0; i < n; i++) {
+        const mi355::MicroOp& m = plan.prog[i];
+        mi355::WalkOp& d = w[i];
+        d.src1 = nullptr; d.src2 = nullptr; d.scale = nullptr; d.store = nullptr; d.pad = 0;
+        if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+        else if (m.k1 == mi355::PK_TIPS) { d.src1 = in->tipStates[m.a1]; if (!d.src1) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+        if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+        else if (m.k2 == mi355::PK_TIPS) { d.src2 = in->tipStates[m.a2]; if (!d.src2) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+        if (m.smode != mi355::PS_NONE) {
+            int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
+            if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; }
+            else { if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE; in->statScaleReads++; }   // never written by a rescaling op
+            d.scale = in->scale[m.scaleIdx];
         }
-        return true;
-    };
-    VStepHost last;
-    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.split = 0;
-    if (tip1 && tip2) {
-        last.type = mi355::VS_CHERRY_A; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
-    } else if (tip1 != tip2) {
-        const int v = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
-        if (!in->virt[v].on || !append(v, false)) return false;
-        nv.chainOnly = in->virt[v].chainOnly;
-        last.type = mi355::VS_EXTEND_A; last.tipB = t; last.originA = mv; last.originB = mt;
-    } else {
-        int u = c1, v = c2, mu = m1, mv = m2;
-        if (!in->virt[u].on || !in->virt[v].on) return false;
-        if (!in->virt[v].chainOnly) { std::swap(u, v); std::swap(mu, mv); }
-        if (!in->virt[v].chainOnly) return false;                 // would need a third accumulator
-        if (!append(u, false)) return false;
-        last.split = nv.nSteps;
-        if (!append(v, true)) return false;
-        nv.chainOnly = false;
-        last.type = mi355::VS_JOIN; last.originA = mu; last.originB = mv;
+        if (m.storeBuf >= 0) {
+            int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
+            d.store = in->partials[m.storeBuf];
+            in->statStored++;
+        }
+        d.mat1 = (int)((unsigned)m.mat1 * matStride); d.mat2 = (int)((unsigned)m.mat2 * matStride);
+        d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode);
     }
-    if (nv.nSteps >= in->maxVirtSteps) return false;
-    pairs.push_back(last.originA); pairs.push_back(snapSlot(in, X, nv.nSteps, 0));
-    pairs.push_back(last.originB); pairs.push_back(snapSlot(in, X, nv.nSteps, 1));
-    nv.steps[nv.nSteps++] = last;
-    in->virt[X] = nv;
-    registerVirtual(in, X);
-    snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
-    return true;
-}
-
-// The ordinary op that computes X's real partials from its definition (children: tips and/or sub-programs).
-void materializeDesc(const Instance* in, int X, OpDesc& d) {
-    const Virt& v = in->virt[X];
-    const int n = v.nSteps;
-    const VStepHost& last = v.steps[n - 1];
-    memset(&d, 0, sizeof(d));
-    d.dest = in->partials[X];
-    d.mat1 = snapSlot(in, X, n - 1, 0); d.mat2 = snapSlot(in, X, n - 1, 1);
-    d.scaleRead = last.scaleIdx >= 0 ? in->scale[last.scaleIdx] : nullptr;   // write-mode nodes stored their factor there too
-    d.pStart = 0; d.pEnd = in->P;
-    if (last.type == mi355::VS_CHERRY_A) {
-        d.child1 = in->tipStates[last.tipA]; d.child2 = in->tipStates[last.tipB];
-        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
-    } else if (last.type == mi355::VS_EXTEND_A) {
-        emitProgram(in, X, 0, n - 1, false, d.prog[0]);
-        d.child2 = in->tipStates[last.tipB];
-        d.kind = mi355::KIND_VIRT1 | mi355::KIND_STATES2;
-    } else {   // JOIN: the A part is the leading steps, the B chain follows
-        const int split = last.split;    // the A operand may itself contain B-type steps (an inner JOIN): use the recorded boundary
-        emitProgram(in, X, 0, split, false, d.prog[0]);
-        emitProgram(in, X, split, n - 1, true, d.prog[1]);
-        d.kind = mi355::KIND_VIRT1 | mi355::KIND_VIRT2;
+    in->statMicroOps += (long)n; in->statWalks++;
+    std::vector<mi355::WalkSeg> segs(plan.segs.size());
+    int maxRange = 0;
+    for (size_t i = 0; i < segs.size(); i++) {
+        const mi355::PlanSeg& ps = plan.segs[i];
+        segs[i].progStart = ps.progStart; segs[i].progCount = ps.progCount;
+        segs[i].pStart = in->partStart[ps.partition]; segs[i].pEnd = in->partEnd[ps.partition];
+        maxRange = std::max(maxRange, segs[i].pEnd - segs[i].pStart);
     }
-}
-
-// Give every buffer of `xs` its real partials: ONE descriptor upload and ONE launch for the whole list.
-int materializeList(Instance* in, const std::vector<int>& xs) {
-    std::vector<OpDesc> descs;
-    descs.reserve(xs.size());
-    for (int X : xs) {
-        if (!in->virt[X].on) continue;
-        int rc = ensurePartials(in, X); if (rc) return rc;
-        OpDesc d;
-        materializeDesc(in, X, d);
-        descs.push_back(d);
-        clearVirtual(in, X);
+    // pack: [micro-ops (48 B each) | segments (16 B each) | snapshot pairs]
+    const size_t opBytes = n * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
+    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
+    char* dBase = nullptr;
+    if (total <= RING_BYTES / 4) {
+        const long off = stage(in, w.data(), opBytes + segBytes + pairBytes);   // reserves `total` bytes, copies only the ops ...
+        if (off < 0) return BEAGLE_ERROR_GENERAL;
+        memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
+        if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
+        HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
+        dBase = in->dRing + off;
+    } else {                                  // a tree of > ~80 000 nodes: its own staging buffer, synchronous copy
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        if (in->bigStageBytes < total) {
+            if (in->bigStage) hipFree(in->bigStage);
+            in->bigStage = nullptr; in->bigStageBytes = 0;
+            HIP_TRY(hipMalloc((void**)&in->bigStage, total));
+            in->bigStageBytes = total;
+        }
+        HIP_TRY(hipMemcpy(in->bigStage, w.data(), opBytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segBytes, hipMemcpyHostToDevice));
+        if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
+        dBase = in->bigStage;
     }
-    const size_t maxChunk = (RING_BYTES / 4) / sizeof(OpDesc);
-    for (size_t b = 0; b < descs.size(); b += maxChunk) {
-        const size_t n = std::min(maxChunk, descs.size() - b);
-        void* dOps = nullptr;
-        int rc = uploadTransient(in, &descs[b], n * sizeof(OpDesc), &dOps); if (rc) return rc;
-        mi355::launchPruneLevel(in->stream, (const OpDesc*)dOps, (int)n, in->matrices, in->P, in->S, in->C, in->P);
-    }
+    if (pairBytes)
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
+                                      in->C * in->S * in->S);
+    if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
+    mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes), (int)segs.size(), maxRange,
+                       in->matrices, in->P, in->C, (long)in->scaleStride);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
+
+// Give every (virtual) buffer of `xs` its real partials: one program, one launch.
+int materializeList(Instance* in, const std::vector<int>& xs) {
+    if (!in->walk || xs.empty()) return 0;
+    mi355::Plan mp;
+    in->planner.planMaterialize(xs, mp);
+    return runPlan(in, mp);
+}
 int materializeVirtual(Instance* in, int X) {
-    if (!in->virt[X].on) return 0;
+    if (!isVirt(in, X)) return 0;
     return materializeList(in, std::vector<int>(1, X));
 }
 int materializeScaleUsers(Instance* in, int scaleIdx) {
-    if (in->scaleUsers[scaleIdx].empty()) return 0;
-    return materializeList(in, std::vector<int>(in->scaleUsers[scaleIdx]));
+    if (!in->walk || in->planner.scaleUsers(scaleIdx).empty()) return 0;
+    return materializeList(in, std::vector<int>(in->planner.scaleUsers(scaleIdx)));
 }
 int materializeTipUsers(Instance* in, int tip) {
-    if (in->tipUsers[tip].empty()) return 0;
-    return materializeList(in, std::vector<int>(in->tipUsers[tip]));
+    if (!in->walk || in->planner.tipUsers(tip).empty()) return 0;
+    return materializeList(in, std::vector<int>(in->planner.tipUsers(tip)));
 }
 
-// Enqueue an op list.  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
-int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum);
+
+// 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
+int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+    if (count <= 0) return 0;
+    const int parts = in->partitionCount;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
+        int part = 0, cum = globalCum;
+        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
+        if (badIndex(dest, in->partialsCount) || badIndex(c1, in->partialsCount) || badIndex(c2, in->partialsCount) ||
+            badIndex(m1, in->matrixCount) || badIndex(m2, in->matrixCount) || badIndex(part, parts) ||
+            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+            (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (in->timing) {
+        if (in->eventsUsed == in->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            in->events.emplace_back(a, b);
+        }
+        e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
+    }
+    int launches = 0;
+    for (int begin = 0; begin < count;) {
+        const int n = in->planner.hazardFreePrefix(ops, begin, count, tuple, parts);
+        const int* sub = ops + (size_t)begin * tuple;
+        for (int k = 0; k < n; k++) {                       // a tip index reused as a destination now holds partials
+            const int dest = sub[(size_t)k * tuple];
+            if (isCompactTip(in, dest)) { int rcm = materializeTipUsers(in, dest); if (rcm) return rcm; in->tipStates[dest] = nullptr; setCompact(in, dest, false); }
+        }
+        std::vector<int> need;
+        in->planner.mustMaterializeBefore(sub, n, tuple, need);
+        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+        int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan);
+        if (rc) return rc;
+        // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
+        // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
+        if (!in->plan.prog.empty()) {
+            rc = runPlan(in, in->plan, launches == 0 ? e0 : nullptr); if (rc) return rc;
+            launches++;
+        }
+        begin += n;
+    }
+    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
+    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
+    return foldCumulative(in, ops, count, tuple, globalCum);
+}
+
+// Enqueue an op list level by level (every state count but 4).  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
+int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (count <= 0) return 0;
     const int parts = in->partitionCount;
     std::vector<OpDesc> descs;                   // one per op that launches (never reallocated: references stay valid)
     descs.reserve(count);
     std::vector<int> descOf(count, -1);
     std::vector<int> level(count);
-    std::vector<int> opCum(count, BEAGLE_OP_NONE), opWrite(count, BEAGLE_OP_NONE), opPart(count, 0);
     std::vector<int> predOff(count + 1, 0), predList;                 // RAW / WAW edges: producer op -> this op
     bool warSeen = false;                                             // a write-after-read hazard inside the list (never in BEAST's lists)
     predList.reserve((size_t)count * 3);
-    std::vector<char> skip(count, 0);            // virtual cherries in read/no-scale mode launch nothing at all
-    std::vector<int> snapPairs;                  // (src matrix, dst snapshot slot) pairs for this call
-    const bool canVirtual = in->virtualCherries && parts == 1 && tuple == BEAGLE_OP_COUNT;
-    // a scale buffer about to be rewritten may still define virtual cherries of earlier evaluations: give those
-    // their real partials first (enqueued ahead of everything this call launches)
-    if (canVirtual) {
-        std::vector<int> need;
-        for (int k = 0; k < count; k++) {
-            const int wS = ops[(size_t)k * tuple + 1];
-            if (wS != BEAGLE_OP_NONE && !badIndex(wS, in->scaleCount))
-                need.insert(need.end(), in->scaleUsers[wS].begin(), in->scaleUsers[wS].end());
-        }
-        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-    }
     in->stamp++;
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {
@@ -485,87 +449,30 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
             (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
             (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
             return BEAGLE_ERROR_OUT_OF_RANGE;
-        const bool tip1 = in->tipStates[c1] && c1 < in->tipCount, tip2 = in->tipStates[c2] && c2 < in->tipCount;
-        const size_t kdest = (size_t)dest * parts + part;
-        // Virtual node: every child is a compact tip or itself virtual, and the subtree fits a VIRT_MAX_STEPS program ->
-        // nothing is written to HBM for it (see "virtual subtrees").  Not when an earlier op of this call read the
-        // previous virtual content of the same buffer: its snapshot slots must stay intact until that op has run.
-        const bool v1 = !tip1 && in->virt[c1].on, v2 = !tip2 && in->virt[c2].on;
+        const bool tip1 = isCompactTip(in, c1), tip2 = isCompactTip(in, c2);
         const int ownScale = wS != BEAGLE_OP_NONE ? wS : rS;
         if (wS != BEAGLE_OP_NONE || rS != BEAGLE_OP_NONE) { int rcs = ensureScale(in, ownScale); if (rcs) return rcs; }
-        const bool warOnVirtual = in->rStamp[kdest] == in->stamp && in->virt[dest].on;
-        bool makeVirtual = false;
-        if (canVirtual && (tip1 || v1) && (tip2 || v2) && c1 != dest && c2 != dest && !warOnVirtual) {
-            Virt& ev = in->virt[dest];
-            // Steady state: the same op on the same buffers as when `dest` was last defined, its virtual children unchanged
-            // (same definition version) and re-confirmed in this call exactly as they were fresh then -> the definition
-            // stands; only its matrix snapshots are refreshed.  Anything else rebuilds it.
-            auto childSame = [&](int c, bool tip, bool sigTip, int ver, bool fresh) {
-                if (tip != sigTip) return false;
-                if (tip) return true;
-                const Virt& cv = in->virt[c];
-                return fresh && cv.stamp == in->stamp && cv.version == ver;
-            };
-            if (ev.on && ev.sigC1 == c1 && ev.sigM1 == m1 && ev.sigC2 == c2 && ev.sigM2 == m2 && ev.sigScale == ownScale &&
-                childSame(c1, tip1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(c2, tip2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
-                for (int st = 0; st < ev.nSteps; st++) {
-                    snapPairs.push_back(ev.steps[st].originA); snapPairs.push_back(snapSlot(in, dest, st, 0));
-                    snapPairs.push_back(ev.steps[st].originB); snapPairs.push_back(snapSlot(in, dest, st, 1));
-                }
-                ev.stamp = in->stamp;
-                makeVirtual = true;
-            } else {
-                Virt saved = ev;
-                if (saved.on) clearVirtual(in, dest);
-                makeVirtual = buildVirtual(in, dest, c1, tip1, m1, c2, tip2, m2, ownScale, snapPairs);
-                if (!makeVirtual && saved.on) { in->virt[dest] = saved; registerVirtual(in, dest); }
-                if (makeVirtual) {
-                    Virt& nv = in->virt[dest];
-                    nv.version = ++in->virtVersion;
-                    nv.sigC1 = c1; nv.sigM1 = m1; nv.sigC2 = c2; nv.sigM2 = m2; nv.sigScale = ownScale;
-                    nv.sigTip1 = tip1; nv.sigTip2 = tip2;
-                    nv.fresh1 = !tip1 && in->virt[c1].stamp == in->stamp; nv.fresh2 = !tip2 && in->virt[c2].stamp == in->stamp;
-                    nv.childVer1 = tip1 ? -1 : in->virt[c1].version; nv.childVer2 = tip2 ? -1 : in->virt[c2].version;
-                }
-            }
-        }
-        // A virtual node without a scale write launches nothing: it needs no descriptor at all (3 of 4 ops of the
-        // benchmark tree), which keeps the host-side preparation — time the GPU spends idle — short.
-        if (makeVirtual && wS == BEAGLE_OP_NONE) skip[k] = 1;
-        OpDesc scratch;
-        if (!skip[k]) { descOf[k] = (int)descs.size(); descs.emplace_back(); }
-        OpDesc& d = skip[k] ? scratch : descs.back();
-        if (!skip[k]) {
-            memset(&d, 0, sizeof(d));
-            // the children's definitions are read before `dest` is redefined below (dest may alias a child when it is not virtual)
-            if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
-            else if (v1) { d.kind |= mi355::KIND_VIRT1; emitProgram(in, c1, 0, in->virt[c1].nSteps, false, d.prog[0]); }
-            else if (in->partials[c1]) d.child1 = in->partials[c1];
-            else return BEAGLE_ERROR_OUT_OF_RANGE;
-            if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
-            else if (v2) { d.kind |= mi355::KIND_VIRT2; emitProgram(in, c2, 0, in->virt[c2].nSteps, false, d.prog[1]); }
-            else if (in->partials[c2]) d.child2 = in->partials[c2];
-            else return BEAGLE_ERROR_OUT_OF_RANGE;
-        }
-        if (!makeVirtual && in->virt[dest].on) clearVirtual(in, dest);      // whatever it was, this op replaces it
-        int rc = 0;
-        if (!makeVirtual) { rc = ensurePartials(in, dest); if (rc) return rc; }
+        descOf[k] = (int)descs.size(); descs.emplace_back();
+        OpDesc& d = descs.back();
+        memset(&d, 0, sizeof(d));
+        if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
+        else if (in->partials[c1]) d.child1 = in->partials[c1];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
+        else if (in->partials[c2]) d.child2 = in->partials[c2];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        int rc = ensurePartials(in, dest); if (rc) return rc;
         d.dest = in->partials[dest];
         d.mat1 = m1; d.mat2 = m2;
-        if (makeVirtual) {
-            if (wS != BEAGLE_OP_NONE) d.kind |= mi355::KIND_NO_STORE;   // still has to produce its scale factors
-            else skip[k] = 1;
-        }
         if (wS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, wS); if (rc) return rc;
-            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1;
         } else if (rS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, rS); if (rc) return rc;
             if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
             d.scaleRead = in->scale[rS];
         }
         d.pStart = in->partStart[part]; d.pEnd = in->partEnd[part];
-        opCum[k] = cum; opPart[k] = part;
         // dependency level: after the ops (of this call) that produced my children (RAW), that read my
         // destination (WAR) or that wrote it (WAW); hazards are tracked per (buffer, partition)
         int lvl = 0;
@@ -594,20 +501,14 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
             }
         level.swap(alap);
     }
-    // counting sort by level (stable); ops that launch nothing (virtual cherries without a scale write) drop out
+    // counting sort by level (stable)
     std::vector<int> start(maxLevel + 2, 0);
-    for (int k = 0; k < count; k++) if (!skip[k]) start[level[k] + 1]++;
+    for (int k = 0; k < count; k++) start[level[k] + 1]++;
     for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
     const int launchCount = start[maxLevel + 1];
     std::vector<OpDesc> sorted(std::max(1, launchCount));
     std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int k = 0; k < count; k++) if (!skip[k]) sorted[fill[level[k]]++] = descs[descOf[k]];
-    if (!snapPairs.empty()) {
-        void* dPairs = nullptr;
-        int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
-    }
-
+    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[descOf[k]];
     // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
     // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
     // launch per dependency level reading its slice.  With the kernel timer on, ONE HIP-event pair brackets
@@ -651,20 +552,33 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
     else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
     HIP_TRY(hipGetLastError());
-    // cumulative scale factors requested together with the update: fold the factors this call wrote
-    // into the cumulative buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
+    return foldCumulative(in, ops, count, tuple, globalCum);
+}
+
+// cumulative scale factors requested together with an update: fold the factors the list wrote into the cumulative
+// buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
+int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     for (int k = 0; k < count; k++) {
-        if (opCum[k] == BEAGLE_OP_NONE || opWrite[k] == BEAGLE_OP_NONE) continue;
-        int rc = ensureScale(in, opCum[k]); if (rc) return rc;
-        const double* src = in->scale[opWrite[k]];
+        const int* op = ops + (size_t)k * tuple;
+        const int wS = op[1];
+        int part = 0, cum = globalCum;
+        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
+        if (cum == BEAGLE_OP_NONE || wS == BEAGLE_OP_NONE) continue;
+        int rc = materializeScaleUsers(in, cum); if (rc) return rc;
+        rc = ensureScale(in, cum); if (rc) return rc;
+        const double* src = in->scale[wS];
         int one = 1;
         void *dSrc = nullptr, *dRaw = nullptr;
         rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
         rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
-        mi355::launchAccumulateScale(in->stream, in->scale[opCum[k]], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0,
-                                     in->partStart[opPart[k]], in->partEnd[opPart[k]]);
+        mi355::launchAccumulateScale(in->stream, in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0,
+                                     in->partStart[part], in->partEnd[part]);
     }
     return 0;
+}
+
+int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+    return in->walk ? runOperationsWalk(in, ops, count, tuple, globalCum) : runOperationsLevels(in, ops, count, tuple, globalCum);
 }
 
 // One dependency level of pre-order ops on the T32 layout, expressed with the tuned pruning kernel:
@@ -736,10 +650,12 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
             (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
             (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
             return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (in->virt[sib].on) need.push_back(sib);
-        if (in->virt[par].on) need.push_back(par);
-        need.insert(need.end(), in->tipUsers[dest].begin(), in->tipUsers[dest].end());
-        if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->scaleUsers[wS].begin(), in->scaleUsers[wS].end());
+        if (isVirt(in, sib)) need.push_back(sib);
+        if (isVirt(in, par)) need.push_back(par);
+        if (in->walk) {
+            need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
+            if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
+        }
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     std::vector<OpDesc> descs(count);
@@ -750,9 +666,9 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
         const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
         OpDesc& d = descs[k];
         memset(&d, 0, sizeof(d));
-        if (in->virt[dest].on) clearVirtual(in, dest);
+        clearVirtual(in, dest);
         int rc = ensurePartials(in, dest); if (rc) return rc;
-        in->tipStates[dest] = nullptr;
+        in->tipStates[dest] = nullptr; setCompact(in, dest, false);
         if (!in->partials[par] || (in->tipStates[par] && par < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
         d.dest = in->partials[dest];
         d.child1 = in->partials[par];
@@ -794,7 +710,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
             if (begin >= end) continue;
             if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
             mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                     in->P, in->S, in->C, in->tiled, in->P);
+                                     in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
         }
         chunkBegin = chunkEnd;
     }
@@ -823,8 +739,8 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     for (int e = 0; e < count; e++) {
         if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
             return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (in->virt[postIdx[e]].on) need.push_back(postIdx[e]);
-        if (in->virt[preIdx[e]].on) need.push_back(preIdx[e]);
+        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
+        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     const int nb = mi355::edgeBlocks(in->P);
@@ -911,8 +827,8 @@ int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateI
     std::vector<int> need;
     for (int e = 0; e < count; e++) {
         if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (in->virt[postIdx[e]].on) need.push_back(postIdx[e]);
-        if (in->virt[preIdx[e]].on) need.push_back(preIdx[e]);
+        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
+        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     std::vector<mi355::EdgeDesc> descs(count);
@@ -1068,15 +984,16 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
     in->ntile = (patternCount + 31) / 32;
     in->schedAlap = !(getenv("BEAGLE_MI355_SCHED") && strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") == 0);
-    in->virtualCherries = stateCount == 4 && categoryCount <= 8 &&
-                          !(getenv("BEAGLE_MI355_NO_FUSE") && atoi(getenv("BEAGLE_MI355_NO_FUSE")) != 0) &&
-                          !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
-    if (getenv("BEAGLE_MI355_VSTEPS")) in->maxVirtSteps = std::max(1, std::min(VIRT_EMIT_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
-    in->virt.assign(partialsBufferCount, Virt());
-    in->tipUsers.assign(partialsBufferCount, std::vector<int>());
-    in->scaleUsers.assign(std::max(1, scaleBufferCount), std::vector<int>());
-    // matrix storage: the caller's buffers, then two private snapshot slots per partials buffer (virtual cherries)
-    size_t matrixSlots = std::max<size_t>(1, matrixBufferCount) + (in->virtualCherries ? 2 * (size_t)mi355::VIRT_MAX_STEPS * partialsBufferCount : 0);
+    // 4 states (nucleotides), up to 16 rate categories: the pattern walk.  BEAGLE_MI355_NO_VIRTUAL=1 keeps every buffer real,
+    // BEAGLE_MI355_VSTEPS=n caps the length of a virtual definition (A/B runs).
+    in->walk = stateCount == 4 && categoryCount <= 16;
+    const bool virtualOn = in->walk && !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
+    int maxVirtSteps = 6;
+    if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
+    in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
+    in->scaleStride = ((size_t)patternCount + 31) & ~(size_t)31;
+    // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
+    size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
@@ -1192,6 +1109,7 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
         return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;   // virtual cherries defined by the OLD states
     rc = ensureStates(in, tipIndex); if (rc) return rc;
+    setCompact(in, tipIndex, true);
     std::vector<uint8_t> s(in->P);
     for (int p = 0; p < in->P; p++) s[p] = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
     return upload(in, in->tipStates[tipIndex], s.data(), (size_t)in->P);
@@ -1227,6 +1145,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
         if (!rc) mi355::launchReplicateCategories(in->stream, last, in->partials[tipIndex], in->P, in->S, in->C - 1);
     }
     in->tipStates[tipIndex] = nullptr;   // the buffer now holds partials (slab memory stays owned by the instance)
+    setCompact(in, tipIndex, false);
     return rc;
 }
 
@@ -1236,7 +1155,7 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     int rc = materializeTipUsers(in, bufferIndex); if (rc) return rc;
     clearVirtual(in, bufferIndex);
     rc = ensurePartials(in, bufferIndex); if (rc) return rc;
-    in->tipStates[bufferIndex] = nullptr;
+    in->tipStates[bufferIndex] = nullptr; setCompact(in, bufferIndex, false);
     if (in->tiled) {
         std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
         toTiled(in, inPartials, t.data(), in->C);
@@ -1482,7 +1401,8 @@ int beagleCopyScaleFactors(int instance, int dest, int src) {
     int rc = materializeScaleUsers(in, dest); if (rc) return rc;
     rc = ensureScale(in, dest); if (rc) return rc;
     rc = ensureScale(in, src); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+    const size_t scaleDoubles = in->walk ? 2 * in->scaleStride : (size_t)in->P;      // walk instances: factors and reciprocals
+    HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], scaleDoubles * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
     in->scaleIsRaw[dest] = in->scaleIsRaw[src];
     return BEAGLE_SUCCESS;
 }
@@ -1551,7 +1471,7 @@ int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* 
         int rc = materializeTipUsers(in, b); if (rc) return rc;
         clearVirtual(in, b);
         rc = ensurePartials(in, b); if (rc) return rc;
-        in->tipStates[b] = nullptr;
+        in->tipStates[b] = nullptr; setCompact(in, b, false);
         mi355::launchFillFrequencies(in->stream, in->partials[b], in->freqs + (size_t)f * in->S, in->P, in->S, in->C, in->tiled);
     }
     HIP_TRY(hipGetLastError());
@@ -1647,7 +1567,16 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     if (outMillis) *outMillis = in->timedMs;
     if (outLaunches) *outLaunches = in->timedLaunches;
     in->timedMs = 0.0; in->timedLaunches = 0;
+    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = 0;
     in->timing = enable != 0;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355WalkStats(int instance, long* out8) {
+    Instance* in = lookup(instance);
+    if (!in || !out8) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    out8[0] = in->statMicroOps; out8[1] = in->statStored; out8[2] = in->statMemReads; out8[3] = in->statTipReads;
+    out8[4] = in->statScaleReads; out8[5] = in->statWalks; out8[6] = in->statScaleWrites; out8[7] = 0;
     return BEAGLE_SUCCESS;
 }
 

@@ -6,24 +6,9 @@
 
 namespace mi355 {
 
-// One pruning operation as the kernels see it: pointers already resolved on the host from the
-// reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
+// One pruning operation as the level kernels see it (every state count but 4): pointers already resolved on the host
+// from the reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
 // [, partition, cumulativeScale]} (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1266-1299).
-//
-// VIRTUAL CHILDREN (4-state kernel).  A child whose whole subtree consists of a few compact tips is not read from HBM:
-// the kernel recomputes its partials in registers from the tip state bytes, following a tiny straight-line program
-// over two accumulators A and B (kernels.hip).  One step = one internal node of the child's subtree:
-//   VS_CHERRY_A / _B   acc = col(matA)[tipA] * col(matB)[tipB] * (1/scale)                         node with two tips
-//   VS_EXTEND_A / _B   acc = (matA . acc) * col(matB)[tipB] * (1/scale)                            node with (subtree, tip)
-//   VS_JOIN            A   = (matA . A) * (matB . B) * (1/scale)                                   node with two subtrees
-// Every step repeats exactly the arithmetic the node's own op performs, so the values are bitwise those the op would
-// have stored.  matA/matB index private SNAPSHOTS of the branch matrices (engine.cpp, "virtual subtrees").
-constexpr int VIRT_MAX_STEPS = 8;     // descriptor / snapshot capacity
-#ifndef VIRT_EMIT_STEPS
-#define VIRT_EMIT_STEPS 6              // longest program the host emits and the kernel is unrolled for
-#endif
-enum { VS_END = 0, VS_CHERRY_A = 1, VS_CHERRY_B = 2, VS_EXTEND_A = 3, VS_EXTEND_B = 4, VS_JOIN = 5 };
-
 // Pointers read out of a descriptor are generic ("flat") to the compiler; flat loads count against the LDS counter as well
 // as the vector-memory one and cannot use scalar-base addressing.  Every buffer the engine hands the kernels lives in
 // HBM, so device code converts descriptor pointers with gptr() before dereferencing.
@@ -32,18 +17,9 @@ enum { VS_END = 0, VS_CHERRY_A = 1, VS_CHERRY_B = 2, VS_EXTEND_A = 3, VS_EXTEND_
 template <class T> __device__ __forceinline__ T MI355_GLOBAL* gptr(T* p) { return (T MI355_GLOBAL*)p; }
 #endif
 
-struct VStep {
-    const uint8_t* tipA;        // CHERRY: first tip's states; EXTEND/JOIN: unused
-    const uint8_t* tipB;        // CHERRY: second tip; EXTEND: the tip
-    const double*  scale;       // this node's per-pattern raw scale factors, or nullptr
-    int            matA, matB;  // matrix indices (snapshots)
-    int            type;        // VS_*
-    int            pad;
-};
-
 struct OpDesc {
     double*        dest;        // [C][P][S] partials, written on [pStart, pEnd)
-    const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0); unused for a virtual child
+    const void*    child1;      // double [C][P][S] partials, or uint8 [P] compact states (kind bit 0)
     const void*    child2;      // same (kind bit 1)
     double*        scaleWrite;  // per-pattern raw scale factors to WRITE (rescale now), or nullptr
     const double*  scaleRead;   // per-pattern raw scale factors to READ (divide by existing), or nullptr
@@ -51,14 +27,38 @@ struct OpDesc {
     int            kind;        // KIND_* bits
     int            pStart, pEnd;// pattern range of this op (whole buffer unless a ...ByPartition call)
     int            pad;
-    VStep          prog[2][VIRT_MAX_STEPS];   // valid when KIND_VIRT1 / KIND_VIRT2 is set; terminated by VS_END if shorter
 };
-static_assert(sizeof(VStep) == 40, "VStep layout");
-static_assert(sizeof(OpDesc) == 64 + 2 * VIRT_MAX_STEPS * 40, "OpDesc layout");
+static_assert(sizeof(OpDesc) == 64, "OpDesc layout");
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2 };
 
-// KIND_NO_STORE: compute (and write the scale factors) but do not store the partials — the op of a virtual node in
-// write-mode rescaling.
-enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_VIRT1 = 4, KIND_VIRT2 = 8, KIND_NO_STORE = 16 };
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: granted once per (kernel, device) —
+// several instances on different GPUs of one process (BEAST's -beagle_instances) each get theirs.  false: the runtime refused.
+bool grantDynamicLds(const void* kernel, size_t bytes);
+
+// ---- the pattern walk (4 states, kernels_walk4.hip) ------------------------------------------------------------------
+// One micro-operation of a walk program: node = (M1 . child1) * (M2 . child2) [* 1/scale].  A child is read from a
+// partials buffer (WK_MEM), is a compact tip (WK_TIPS), or is a value the same thread computed earlier in the program:
+// the previous micro-operation's result (WK_ACC, second operand only) or one of two hold registers (WK_H0/WK_H1, first
+// operand only; `hold` copies ACC into one of them before this micro-operation overwrites it).  The product commutes
+// bitwise, so the planner is free to order the two children that way.
+enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4 };
+enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
+struct WalkOp {
+    double*        store;       // partials buffer the result is written to, or nullptr (virtual node)
+    const void*    src1;        // WK_MEM: const double* partials [C][P][4];  WK_TIPS: const uint8_t* states
+    const void*    src2;
+    double*        scale;       // WS_READ: reciprocals at scale[recipOff + p];  WS_WRITE: writes factor and reciprocal
+    int            mat1, mat2;  // ELEMENT offsets (matrix index * C * 16) of the two child branches' matrices
+    unsigned       flags;       // k1 | k2 << 3 | hold << 6 | scaleMode << 8
+    int            pad;
+};
+static_assert(sizeof(WalkOp) == 48, "WalkOp layout");
+inline unsigned walkFlags(int k1, int k2, int hold, int smode) { return (unsigned)(k1 | (k2 << 3) | (hold << 6) | (smode << 8)); }
+// A program slice and the pattern range that executes it (one per partition of a partitioned instance)
+struct WalkSeg { int progStart, progCount, pStart, pEnd; };
+// one launch: every 64-pattern group of every segment walks its program; maxRange = max (pEnd - pStart)
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange,
+                 const double* matrices, int P, int C, long recipOff);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);
@@ -103,8 +103,9 @@ void launchReplicateCategories(hipStream_t stream, const double* src, double* ds
 // One level of pre-order ops.  The OpDesc fields are reused: dest = pre(child), child1 = pre(parent) (always partials),
 // mat1 = the child's branch matrix (used transposed), child2 / mat2 = the sibling's post-order partials (or compact
 // states, KIND_STATES2) and branch matrix.  Works on either partials layout.
+// recipOff != 0: a rescaling op also stores the reciprocal of its factor at scaleWrite[recipOff + p] (walk instances)
 void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
-                       int maxRange);
+                       int maxRange, long recipOff);
 struct EdgeDesc {
     const void*   post;          // post-order partials of the node below the edge (double*) or its compact states (uint8*)
     const double* pre;           // pre-order partials of the same node
@@ -132,8 +133,6 @@ void launchTransposeMatrices(hipStream_t stream, double* matrices, const int* dS
 void launchFillFrequencies(hipStream_t stream, double* dest, const double* freqs, int P, int S, int C, bool tiled);
 
 int  pruneBlocksForRange(int S, int range);
-// 4-state kernel (kernels_nuc4.hip); false when C is outside its template range
-bool launchPruneLevelNuc4(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int C, int maxRange);
 
 // ---- T32 layout (20-/61-state MFMA path, kernels_mfma.hip): partials[c][tile][state][32 patterns] --------------
 // One dependency level on the fp64 matrix cores; anyScaleWrite adds the second (max + divide) pass.

@@ -19,8 +19,24 @@
 //   k_accumulate                AbstractLikelihoodCore.java:442-458 as a persistent cumulative buffer
 #include "kernels.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace mi355 {
+
+bool grantDynamicLds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;     // (kernel, device) -> bytes granted so far
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[std::make_pair(kernel, dev)];
+    if (bytes <= g) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    g = bytes;
+    return true;
+}
 
 // ------------------------------------------------------------------------------------------------
 // transition matrices
@@ -188,7 +204,6 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __rest
 }
 
 int pruneBlocksForRange(int S, int range) {
-    if (S == 4) return (range + 255) / 256;
     const int ppb = GEN_BLOCK / S;
     const int tiles = (range + ppb - 1) / ppb;
     // enough workgroups to fill the chip, few enough that the per-category matrix staging is amortised
@@ -199,17 +214,12 @@ int pruneBlocksForRange(int S, int range) {
 void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices,
                       int P, int S, int C, int maxRange) {
     if (nOps <= 0 || maxRange <= 0) return;
-    if (S == 4 && launchPruneLevelNuc4(stream, dOps, nOps, matrices, P, C, maxRange)) return;   // kernels_nuc4.hip
     const int ppb = GEN_BLOCK / S;
     const size_t lds = ((size_t)2 * (S + 1) * S + (size_t)3 * ppb * S) * sizeof(double);
     int blocks = pruneBlocksForRange(S, maxRange);
     // keep total workgroups around a few per CU when many ops share the launch
     if (nOps > 1) { int per = (4096 + nOps - 1) / nOps; if (per < 1) per = 1; if (blocks > per) blocks = per; }
-    static size_t ldsGranted = 48 * 1024;
-    if (lds > ldsGranted) {   // S = 61 needs 66 KB of the CU's 160 KB
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pruneGeneral), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ldsGranted = lds;
-    }
+    if (lds > 48 * 1024 && !grantDynamicLds(reinterpret_cast<const void*>(k_pruneGeneral), lds)) return;   // S = 61 needs 66 KB of the CU's 160 KB
     hipLaunchKernelGGL(k_pruneGeneral, dim3(blocks, nOps), dim3(GEN_BLOCK), lds, stream, dOps, matrices, P, S, C);
 }
 

@@ -257,13 +257,9 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
         else TILED_LAUNCH(5, true, 0);
     } else {
         const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);          // 64 KiB: above the default 48 KiB cap
-        static bool granted = false;
-        if (!granted) {
-            const void* fns[] = {(const void*)k_pruneTiled<16, false, 0>, (const void*)k_pruneTiled<16, true, 0>,
-                                 (const void*)k_pruneTiled<16, true, 1>, (const void*)k_pruneTiled<16, true, 2>};
-            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            granted = true;
-        }
+        const void* fns[] = {(const void*)k_pruneTiled<16, false, 0>, (const void*)k_pruneTiled<16, true, 0>,
+                             (const void*)k_pruneTiled<16, true, 1>, (const void*)k_pruneTiled<16, true, 2>};
+        for (const void* f : fns) if (!grantDynamicLds(f, lds)) return;
         if (nt < 16) TILED_LAUNCH(16, false, 0);
         else if (pipe >= 2) TILED_LAUNCH(16, true, 2);
         else if (pipe == 1) TILED_LAUNCH(16, true, 1);

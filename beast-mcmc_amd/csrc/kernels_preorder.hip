@@ -25,7 +25,7 @@ __device__ __forceinline__ size_t pidx(int c, int p, int i, int P, int S, int nt
 
 template <bool TILED>
 __global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
-                                                           int P, int S, int C) {
+                                                           int P, int S, int C, long recipOff) {
     extern __shared__ double sh[];                 // Ms[S*S] | Mc[S*S] | v[S][64] | x[S][64]
     double* Ms = sh; double* Mc = sh + S * S; double* v = Mc + S * S; double* x = v + S * PRE_BLOCK;
     const OpDesc& op = ops[blockIdx.y];
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restr
         if (!(m > 0.0)) m = 1.0;
         gptr(op.scaleWrite)[p] = m;
         const double im = 1.0 / m;
+        if (recipOff) gptr(op.scaleWrite)[recipOff + p] = im;
         for (int c = 0; c < C; c++) for (int j = 0; j < S; j++) dest[pidx<TILED>(c, p, j, P, S, ntile)] *= im;
     }
 }
@@ -78,20 +79,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restr
 static size_t preLds(int S) { return ((size_t)2 * S * S + (size_t)2 * S * PRE_BLOCK) * sizeof(double); }
 
 void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
-                       int maxRange) {
+                       int maxRange, long recipOff) {
     if (nOps <= 0 || maxRange <= 0) return;
     const size_t lds = preLds(S);
-    static bool granted = false;
-    if (!granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prePartials<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prePartials<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        granted = true;
-    }
+    if (!grantDynamicLds(reinterpret_cast<const void*>(k_prePartials<false>), 160 * 1024) ||
+        !grantDynamicLds(reinterpret_cast<const void*>(k_prePartials<true>), 160 * 1024)) return;
     for (int o = 0; o < nOps; o += 65535) {
         const int n = nOps - o < 65535 ? nOps - o : 65535;
         dim3 grid((maxRange + PRE_BLOCK - 1) / PRE_BLOCK, n), block(PRE_BLOCK);
-        if (tiled) hipLaunchKernelGGL(k_prePartials<true>, grid, block, lds, stream, dOps + o, matrices, P, S, C);
-        else hipLaunchKernelGGL(k_prePartials<false>, grid, block, lds, stream, dOps + o, matrices, P, S, C);
+        if (tiled) hipLaunchKernelGGL(k_prePartials<true>, grid, block, lds, stream, dOps + o, matrices, P, S, C, recipOff);
+        else hipLaunchKernelGGL(k_prePartials<false>, grid, block, lds, stream, dOps + o, matrices, P, S, C, recipOff);
     }
 }
 
@@ -173,12 +170,8 @@ void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEd
                              int P, int S, int C, bool tiled) {
     if (nEdges <= 0) return;
     const size_t lds = ((size_t)S * S + S + (size_t)2 * S * PRE_BLOCK) * sizeof(double);
-    static bool granted = false;
-    if (!granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_edgeDifferentials<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        granted = true;
-    }
+    if (!grantDynamicLds(reinterpret_cast<const void*>(k_edgeDifferentials<false>), 160 * 1024) ||
+        !grantDynamicLds(reinterpret_cast<const void*>(k_edgeDifferentials<true>), 160 * 1024)) return;
     dim3 grid(edgeBlocks(P), nEdges), block(PRE_BLOCK);
     if (tiled) hipLaunchKernelGGL(k_edgeDifferentials<true>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
     else hipLaunchKernelGGL(k_edgeDifferentials<false>, grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C);
@@ -309,12 +302,8 @@ void launchCrossProducts(hipStream_t stream, const EdgeDesc* dEdges, int nEdges,
                          const double* catRates, const double* patternWeights, double* partial, double* out, int P, int S, int C, bool tiled) {
     if (nEdges <= 0) return;
     const size_t lds = (size_t)2 * S * PRE_BLOCK * sizeof(double);
-    static bool granted = false;
-    if (!granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_crossProducts<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_crossProducts<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        granted = true;
-    }
+    if (!grantDynamicLds(reinterpret_cast<const void*>(k_crossProducts<false>), 160 * 1024) ||
+        !grantDynamicLds(reinterpret_cast<const void*>(k_crossProducts<true>), 160 * 1024)) return;
     const int nb = edgeBlocks(P);
     if (tiled) hipLaunchKernelGGL(k_crossProducts<true>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
     else hipLaunchKernelGGL(k_crossProducts<false>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);

@@ -1,0 +1,391 @@
+// planner.cpp — see planner.h.  Pure host logic (compiled into the engine by hipcc and into the planner test by g++).
+#include "planner.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mi355 {
+
+namespace {
+constexpr int OP_NONE = -1;                 // BEAGLE_OP_NONE
+constexpr int MAX_RECURSION = 4000;         // deeper dependency chains (caterpillar trees of >4000 taxa) are emitted flat
+enum { CL_TIPS = 0, CL_MEM = 1, CL_VIRT = 2, CL_REAL = 3 };
+inline int popcount2(unsigned m) { return (int)(m & 1u) + (int)((m >> 1) & 1u); }
+inline int lowestSlot(unsigned m) { return (m & 1u) ? 0 : 1; }
+}  // namespace
+
+void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled) {
+    partialsCount_ = partialsCount; tipCount_ = tipCount; matrixCount_ = matrixCount; scaleCount_ = std::max(1, scaleCount);
+    maxSteps_ = std::max(1, std::min(maxVirtSteps, PLAN_MAX_STEPS));
+    enabled_ = virtualEnabled;
+    virt_.assign(partialsCount, VirtDef());
+    tipUsers_.assign(partialsCount, std::vector<int>());
+    scaleUsers_.assign(scaleCount_, std::vector<int>());
+    compactTip.assign(partialsCount, 0);
+    wStamp_.assign(partialsCount, 0); rStamp_.assign(partialsCount, 0); wOp_.assign(partialsCount, 0);
+    sWStamp_.assign(scaleCount_, 0); sRStamp_.assign(scaleCount_, 0); sDone_.assign(scaleCount_, 0);
+    stamp_ = 0; virtVersion_ = 0;
+}
+
+void WalkPlanner::clearVirtual(int X) {
+    VirtDef& v = virt_[X];
+    if (!v.on) return;
+    auto drop = [X](std::vector<int>& u) { u.erase(std::remove(u.begin(), u.end(), X), u.end()); };
+    for (int s = 0; s < v.nSteps; s++) {
+        const VirtStep& h = v.steps[s];
+        if (h.tipA >= 0) drop(tipUsers_[h.tipA]);
+        if (h.tipB >= 0) drop(tipUsers_[h.tipB]);
+        if (h.scaleIdx >= 0) drop(scaleUsers_[h.scaleIdx]);
+    }
+    v.on = false;
+}
+
+void WalkPlanner::registerVirtual(int X) {
+    const VirtDef& v = virt_[X];
+    auto add = [X](std::vector<int>& u) { if (std::find(u.begin(), u.end(), X) == u.end()) u.push_back(X); };
+    for (int s = 0; s < v.nSteps; s++) {
+        const VirtStep& h = v.steps[s];
+        if (h.tipA >= 0) add(tipUsers_[h.tipA]);
+        if (h.tipB >= 0) add(tipUsers_[h.tipB]);
+        if (h.scaleIdx >= 0) add(scaleUsers_[h.scaleIdx]);
+    }
+}
+
+// Try to define buffer X = node(child1 over matrix m1, child2 over matrix m2, scale).  Children are compact tips or
+// virtual buffers.  Appends (source, destination) matrix-copy pairs.  false: not expressible with one hold slot.
+bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
+    VirtDef nv;
+    nv.on = true; nv.stamp = stamp_; nv.nSteps = 0; nv.chainOnly = true;
+    std::vector<int> pairs;
+    auto append = [&](int srcBuf) -> bool {
+        const VirtDef& src = virt_[srcBuf];
+        for (int s = 0; s < src.nSteps; s++) {
+            if (nv.nSteps >= maxSteps_) return false;
+            VirtStep h = src.steps[s];
+            // a child defined in THIS list has its slots written by the same snapshot launch: copy from its origins
+            const int fromA = src.stamp == stamp_ ? h.originA : snapSlot(srcBuf, s, 0);
+            const int fromB = src.stamp == stamp_ ? h.originB : snapSlot(srcBuf, s, 1);
+            h.originA = fromA; h.originB = fromB;
+            pairs.push_back(fromA); pairs.push_back(snapSlot(X, nv.nSteps, 0));
+            pairs.push_back(fromB); pairs.push_back(snapSlot(X, nv.nSteps, 1));
+            nv.steps[nv.nSteps++] = h;
+        }
+        return true;
+    };
+    VirtStep last;
+    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.split = 0;
+    if (tip1 && tip2) {
+        last.type = VT_CHERRY; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
+    } else if (tip1 != tip2) {
+        const int v = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
+        if (!virt_[v].on || !append(v)) return false;
+        nv.chainOnly = virt_[v].chainOnly;
+        last.type = VT_EXTEND; last.tipB = t; last.originA = mv; last.originB = mt;
+    } else {
+        int u = c1, v = c2, mu = m1, mv = m2;
+        if (!virt_[u].on || !virt_[v].on) return false;
+        if (!virt_[v].chainOnly) { std::swap(u, v); std::swap(mu, mv); }
+        if (!virt_[v].chainOnly) return false;                 // the second operand would need a hold slot of its own
+        if (!append(u)) return false;
+        last.split = nv.nSteps;
+        if (!append(v)) return false;
+        nv.chainOnly = false;
+        last.type = VT_JOIN; last.originA = mu; last.originB = mv;
+    }
+    if (nv.nSteps >= maxSteps_) return false;
+    pairs.push_back(last.originA); pairs.push_back(snapSlot(X, nv.nSteps, 0));
+    pairs.push_back(last.originB); pairs.push_back(snapSlot(X, nv.nSteps, 1));
+    nv.steps[nv.nSteps++] = last;
+    virt_[X] = nv;
+    registerVirtual(X);
+    snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
+    return true;
+}
+
+int WalkPlanner::hazardFreePrefix(const int* ops, int begin, int count, int tuple, int parts) {
+    const size_t nKeys = (size_t)partialsCount_ * parts, nS = (size_t)scaleCount_ * parts;
+    if (wStamp_.size() < nKeys) { wStamp_.assign(nKeys, 0); rStamp_.assign(nKeys, 0); wOp_.assign(nKeys, 0); }
+    if (sWStamp_.size() < nS) { sWStamp_.assign(nS, 0); sRStamp_.assign(nS, 0); sDone_.assign(nS, 0); }
+    stamp_++;
+    int k = begin;
+    for (; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        const int part = tuple > 7 ? op[7] : 0;
+        const size_t kd = (size_t)op[0] * parts + part, k1 = (size_t)op[3] * parts + part, k2 = (size_t)op[5] * parts + part;
+        bool hazard = wStamp_[kd] == stamp_ || rStamp_[kd] == stamp_;
+        if (op[1] != OP_NONE) { const size_t s = (size_t)op[1] * parts + part; hazard = hazard || sWStamp_[s] == stamp_ || sRStamp_[s] == stamp_; }
+        if (op[2] != OP_NONE && op[1] == OP_NONE) { const size_t s = (size_t)op[2] * parts + part; hazard = hazard || sWStamp_[s] == stamp_; }
+        if (hazard && k > begin) break;
+        rStamp_[k1] = stamp_; rStamp_[k2] = stamp_; wStamp_[kd] = stamp_;
+        if (op[1] != OP_NONE) sWStamp_[(size_t)op[1] * parts + part] = stamp_;
+        else if (op[2] != OP_NONE) sRStamp_[(size_t)op[2] * parts + part] = stamp_;
+    }
+    return k - begin;
+}
+
+void WalkPlanner::mustMaterializeBefore(const int* ops, int count, int tuple, std::vector<int>& out) {
+    if (!enabled_) return;
+    stamp_++;
+    for (int k = 0; k < count; k++) wStamp_[ops[(size_t)k * tuple]] = stamp_;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        if ((op[3] == op[0] || op[5] == op[0]) && virt_[op[0]].on) out.push_back(op[0]);     // in-place update of a virtual buffer
+        const int wS = op[1];
+        if (wS == OP_NONE || wS < 0 || wS >= scaleCount_) continue;
+        for (int u : scaleUsers_[wS])
+            if (wStamp_[u] != stamp_) out.push_back(u);          // a destination of this list is redefined anyway
+    }
+}
+
+// ---- emission ----------------------------------------------------------------------------------------------------
+namespace {
+struct Child { int cls, buf, mat, prod, need, size; };
+inline MicroOp blankOp() {
+    MicroOp m; m.storeBuf = PLAN_NONE; m.k1 = PK_MEM; m.a1 = 0; m.k2 = PK_MEM; m.a2 = 0; m.mat1 = 0; m.mat2 = 0;
+    m.scaleIdx = PLAN_NONE; m.smode = PS_NONE; m.hold = 0;
+    return m;
+}
+inline void setLeaf(MicroOp& m, int which, const Child& c) {
+    const int kind = c.cls == CL_TIPS ? PK_TIPS : PK_MEM;
+    if (which == 0) { m.k1 = kind; m.a1 = c.buf; m.mat1 = c.mat; } else { m.k2 = kind; m.a2 = c.buf; m.mat2 = c.mat; }
+}
+}  // namespace
+
+void WalkPlanner::emitVirtualSteps(int buf, int lo, int hi, unsigned freeMask, bool writeMode, Plan& out) {
+    const VirtDef& v = virt_[buf];
+    const int idx = hi - 1;
+    const VirtStep& st = v.steps[idx];
+    MicroOp m = blankOp();
+    if (st.type == VT_CHERRY) {
+        m.k1 = PK_TIPS; m.a1 = st.tipA; m.mat1 = snapSlot(buf, idx, 0);
+        m.k2 = PK_TIPS; m.a2 = st.tipB; m.mat2 = snapSlot(buf, idx, 1);
+    } else if (st.type == VT_EXTEND) {
+        emitVirtualSteps(buf, lo, hi - 1, freeMask, writeMode, out);
+        m.k1 = PK_TIPS; m.a1 = st.tipB; m.mat1 = snapSlot(buf, idx, 1);
+        m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, 0);
+    } else {   // VT_JOIN: first operand = steps [0, split), then the JOIN-free second chain [split, idx)
+        emitVirtualSteps(buf, lo, st.split, freeMask, writeMode, out);
+        const int h = lowestSlot(freeMask);
+        out.prog.back().hold = h + 1;
+        lastHolds++;
+        emitVirtualSteps(buf, st.split, idx, freeMask & ~(1u << h), writeMode, out);
+        m.k1 = PK_H0 + h; m.mat1 = snapSlot(buf, idx, 0);
+        m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, 1);
+    }
+    if (st.scaleIdx >= 0) {
+        m.scaleIdx = st.scaleIdx;
+        const bool w = writeMode && sWStamp_[st.scaleIdx] == stamp_;
+        m.smode = w ? PS_WRITE : PS_READ;
+        if (w) sDone_[st.scaleIdx] = stamp_;
+    }
+    out.prog.push_back(m);
+}
+
+void WalkPlanner::emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out) {
+    emitVirtualSteps(buf, 0, virt_[buf].nSteps, freeMask, writeMode, out);
+}
+
+void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {
+    OpInfo& o = info_[j];
+    Child ch[2];
+    for (int w = 0; w < 2; w++) {
+        Child& c = ch[w];
+        c.buf = w ? o.c2 : o.c1; c.mat = w ? o.m2 : o.m1;
+        const bool tip = w ? o.tip2 : o.tip1;
+        c.prod = -1; c.need = 0; c.size = 0;
+        if (tip) { c.cls = CL_TIPS; continue; }
+        const int prod = w ? prod2_[j] : prod1_[j];
+        if (prod >= 0) {
+            const OpInfo& p = info_[prod];
+            if (p.virtDest) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); c.size = 0; }
+            else if (p.emitted || flat_) c.cls = CL_MEM;
+            else { c.cls = CL_REAL; c.prod = prod; c.need = p.need; c.size = p.size; }
+        } else if (virt_[c.buf].on) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); }
+        else c.cls = CL_MEM;
+    }
+    auto emitChild = [&](const Child& c, unsigned fm) {
+        if (c.cls == CL_VIRT) emitVirtual(c.buf, fm, true, out);
+        else emitReal(c.prod, fm, out, depth + 1);
+    };
+    const bool e0 = ch[0].cls >= CL_VIRT, e1 = ch[1].cls >= CL_VIRT;
+    MicroOp m = blankOp();
+    if (!e0 && !e1) {
+        setLeaf(m, 0, ch[0]); setLeaf(m, 1, ch[1]);
+        if (ch[0].cls == CL_MEM) lastMemReads++;
+        if (ch[1].cls == CL_MEM) lastMemReads++;
+    } else if (e0 != e1) {
+        const Child& e = e0 ? ch[0] : ch[1];
+        const Child& l = e0 ? ch[1] : ch[0];
+        emitChild(e, freeMask);
+        setLeaf(m, 0, l);
+        if (l.cls == CL_MEM) lastMemReads++;
+        m.k2 = PK_ACC; m.mat2 = e.mat;
+    } else {
+        const int F = popcount2(freeMask);
+        auto holdOK = [&](const Child& a, const Child& b) { return a.need <= F && 1 + b.need <= F; };
+        auto plainOK = [&](const Child& a, const Child& b) { return a.cls == CL_REAL && a.need <= F && b.need <= F; };
+        int first = -1; bool hold = false;
+        const bool h01 = holdOK(ch[0], ch[1]), h10 = holdOK(ch[1], ch[0]);
+        if (h01 || h10) {
+            hold = true;
+            if (h01 && h10) first = (ch[1].need > ch[0].need || (ch[1].need == ch[0].need && ch[1].size > ch[0].size)) ? 1 : 0;
+            else first = h01 ? 0 : 1;
+        } else {
+            const bool p01 = plainOK(ch[0], ch[1]), p10 = plainOK(ch[1], ch[0]);
+            if (p01 && p10) first = ch[1].size > ch[0].size ? 1 : 0;
+            else first = p01 ? 0 : 1;      // by construction one of them holds (planner.h: need <= 2)
+        }
+        const Child& a = ch[first];
+        const Child& b = ch[1 - first];
+        emitChild(a, freeMask);
+        if (hold) {
+            const int h = lowestSlot(freeMask);
+            out.prog.back().hold = h + 1;
+            lastHolds++;
+            emitChild(b, freeMask & ~(1u << h));
+            m.k1 = PK_H0 + h; m.mat1 = a.mat;
+        } else {
+            emitChild(b, freeMask);
+            m.k1 = PK_MEM; m.a1 = a.buf; m.mat1 = a.mat;
+            lastMemReads++;
+        }
+        m.k2 = PK_ACC; m.mat2 = b.mat;
+    }
+    m.storeBuf = o.dest;
+    if (o.wS != OP_NONE) { m.scaleIdx = o.wS; m.smode = PS_WRITE; sDone_[(size_t)o.wS * parts_ + o.part] = stamp_; }
+    else if (o.rS != OP_NONE) { m.scaleIdx = o.rS; m.smode = PS_READ; }
+    out.prog.push_back(m);
+    o.emitted = true;
+    lastStored++;
+}
+
+int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allowVirtual, Plan& out) {
+    out.clear();
+    lastStored = lastMemReads = lastHolds = 0;
+    if (count <= 0) return 0;
+    parts_ = parts;
+    const size_t nKeys = (size_t)partialsCount_ * parts, nS = (size_t)scaleCount_ * parts;
+    if (wStamp_.size() < nKeys) { wStamp_.assign(nKeys, 0); rStamp_.assign(nKeys, 0); wOp_.assign(nKeys, 0); }
+    if (sWStamp_.size() < nS) { sWStamp_.assign(nS, 0); sRStamp_.assign(nS, 0); sDone_.assign(nS, 0); }
+    stamp_++;
+    allowVirtual = allowVirtual && enabled_ && parts == 1 && tuple == 7;
+    info_.assign(count, OpInfo());
+    prod1_.assign(count, -1); prod2_.assign(count, -1);
+    std::vector<char> consumed(count, 0);
+    std::vector<int> depthOf(count, 1);
+    int maxDepth = 1;
+
+    // ---- pass 1, list order: virtual definitions, producers, hold needs
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        OpInfo& o = info_[k];
+        o.dest = op[0]; o.wS = op[1]; o.rS = op[2]; o.c1 = op[3]; o.m1 = op[4]; o.c2 = op[5]; o.m2 = op[6];
+        o.part = tuple > 7 ? op[7] : 0;
+        o.tip1 = compactTip[o.c1] != 0; o.tip2 = compactTip[o.c2] != 0;
+        o.virtDest = false; o.emitted = false; o.need = 0; o.size = 1;
+        const size_t kd = (size_t)o.dest * parts + o.part, kc1 = (size_t)o.c1 * parts + o.part, kc2 = (size_t)o.c2 * parts + o.part;
+        if (!o.tip1 && wStamp_[kc1] == stamp_) { prod1_[k] = wOp_[kc1]; consumed[prod1_[k]] = 1; }
+        if (!o.tip2 && wStamp_[kc2] == stamp_) { prod2_[k] = wOp_[kc2]; consumed[prod2_[k]] = 1; }
+        if (o.wS != OP_NONE) sWStamp_[(size_t)o.wS * parts + o.part] = stamp_;
+
+        const bool v1 = !o.tip1 && virt_[o.c1].on, v2 = !o.tip2 && virt_[o.c2].on;
+        const int ownScale = o.wS != OP_NONE ? o.wS : o.rS;
+        bool makeVirtual = false;
+        if (allowVirtual && (o.tip1 || v1) && (o.tip2 || v2) && o.c1 != o.dest && o.c2 != o.dest) {
+            VirtDef& ev = virt_[o.dest];
+            // Steady state: the same op on the same buffers as when `dest` was last defined, its virtual children unchanged
+            // (same definition version) and re-confirmed in this list exactly as they were fresh then -> the definition
+            // stands; only its matrix snapshots are refreshed.  Anything else rebuilds it.
+            auto childSame = [&](int c, bool tip, bool sigTip, int ver, bool fresh) {
+                if (tip != sigTip) return false;
+                if (tip) return true;
+                const VirtDef& cv = virt_[c];
+                return fresh && cv.stamp == stamp_ && cv.version == ver;
+            };
+            if (ev.on && ev.sigC1 == o.c1 && ev.sigM1 == o.m1 && ev.sigC2 == o.c2 && ev.sigM2 == o.m2 && ev.sigScale == ownScale &&
+                childSame(o.c1, o.tip1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(o.c2, o.tip2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
+                for (int st = 0; st < ev.nSteps; st++) {
+                    out.snapPairs.push_back(ev.steps[st].originA); out.snapPairs.push_back(snapSlot(o.dest, st, 0));
+                    out.snapPairs.push_back(ev.steps[st].originB); out.snapPairs.push_back(snapSlot(o.dest, st, 1));
+                }
+                ev.stamp = stamp_;
+                makeVirtual = true;
+            } else {
+                VirtDef saved = ev;
+                if (saved.on) clearVirtual(o.dest);
+                makeVirtual = buildVirtual(o.dest, o.c1, o.tip1, o.m1, o.c2, o.tip2, o.m2, ownScale, out.snapPairs);
+                if (!makeVirtual && saved.on) { virt_[o.dest] = saved; registerVirtual(o.dest); }
+                if (makeVirtual) {
+                    VirtDef& nv = virt_[o.dest];
+                    nv.version = ++virtVersion_;
+                    nv.sigC1 = o.c1; nv.sigM1 = o.m1; nv.sigC2 = o.c2; nv.sigM2 = o.m2; nv.sigScale = ownScale;
+                    nv.sigTip1 = o.tip1; nv.sigTip2 = o.tip2;
+                    nv.fresh1 = !o.tip1 && virt_[o.c1].stamp == stamp_; nv.fresh2 = !o.tip2 && virt_[o.c2].stamp == stamp_;
+                    nv.childVer1 = o.tip1 ? -1 : virt_[o.c1].version; nv.childVer2 = o.tip2 ? -1 : virt_[o.c2].version;
+                }
+            }
+        }
+        if (!makeVirtual && virt_[o.dest].on) clearVirtual(o.dest);      // whatever it was, this op replaces it
+        o.virtDest = makeVirtual;
+        wStamp_[kd] = stamp_; wOp_[kd] = k;
+
+        // hold slots the evaluation of this (real) node needs, and its size — children come earlier in the list
+        if (!makeVirtual) {
+            int need[2] = {0, 0}, size[2] = {0, 0}; bool eval[2] = {false, false}, real[2] = {false, false};
+            for (int w = 0; w < 2; w++) {
+                const bool tip = w ? o.tip2 : o.tip1;
+                const int c = w ? o.c2 : o.c1, prod = w ? prod2_[k] : prod1_[k];
+                if (tip) continue;
+                if (prod >= 0 && !info_[prod].virtDest) { eval[w] = real[w] = true; need[w] = info_[prod].need; size[w] = info_[prod].size; depthOf[k] = std::max(depthOf[k], depthOf[prod] + 1); }
+                else if (virt_[c].on) { eval[w] = true; need[w] = virtNeed(c); }
+            }
+            maxDepth = std::max(maxDepth, depthOf[k]);
+            o.size = 1 + size[0] + size[1];
+            if (eval[0] && eval[1]) {
+                auto cost = [&](int a, int b) { return real[a] ? std::max(need[a], need[b]) : std::max(need[a], 1 + need[b]); };
+                o.need = std::min(cost(0, 1), cost(1, 0));
+            } else o.need = eval[0] ? need[0] : eval[1] ? need[1] : 0;
+        }
+    }
+    flat_ = maxDepth > MAX_RECURSION;
+
+    // ---- pass 2: walk order.  One segment per partition; inside it, every unconsumed real op is a root of the forest.
+    std::vector<int> partsSeen;
+    {
+        std::vector<char> seen(parts, 0);
+        for (int k = 0; k < count; k++) if (!seen[info_[k].part]) { seen[info_[k].part] = 1; partsSeen.push_back(info_[k].part); }
+    }
+    for (int part : partsSeen) {
+        PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part;
+        for (int k = 0; k < count; k++) {
+            OpInfo& o = info_[k];
+            if (o.part != part || o.virtDest || o.emitted) continue;
+            if (flat_ || !consumed[k]) emitReal(k, 3u, out, 0);
+        }
+        // virtual nodes of a rescaling evaluation still owe their scale factors if nothing above evaluated them
+        for (int k = 0; k < count; k++) {
+            const OpInfo& o = info_[k];
+            if (o.part != part || !o.virtDest || o.wS == OP_NONE) continue;
+            if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, 3u, true, out);
+        }
+        seg.progCount = (int)out.prog.size() - seg.progStart;
+        if (seg.progCount > 0) out.segs.push_back(seg);
+    }
+    return 0;
+}
+
+void WalkPlanner::planMaterialize(const std::vector<int>& xs, Plan& out) {
+    out.clear();
+    parts_ = 1;
+    PlanSeg seg; seg.progStart = 0; seg.partition = 0;
+    for (int X : xs) {
+        if (!virt_[X].on) continue;
+        emitVirtual(X, 3u, false, out);
+        out.prog.back().storeBuf = X;
+        clearVirtual(X);
+    }
+    seg.progCount = (int)out.prog.size();
+    if (seg.progCount > 0) out.segs.push_back(seg);
+}
+
+}  // namespace mi355

@@ -1,0 +1,137 @@
+// planner.h — the walk planner: turns an updatePartials operation list into the micro-operation program the 4-state
+// pattern-walk kernel executes (kernels_walk4.hip), and keeps the definitions of "virtual" partials buffers.
+//
+// Pure host logic: no HIP types, no device pointers — everything is expressed in buffer / matrix / scale INDICES; the
+// engine resolves them to addresses (engine.cpp).  That keeps the planner testable without a GPU: tests/native/ holds
+// an index-level interpreter of the micro-operations and checks planner output against list-order evaluation.
+//
+// Reference behaviour this has to preserve (all paths relative to /root/reference):
+//   * an operation list is any dependency-ordered list of 7-int tuples {dest, writeScale, readScale, child1, matrix1,
+//     child2, matrix2} (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java:1266-1299), post-order or the reverse
+//     level order of src/dr/evomodel/treedatalikelihood/LikelihoodTreeTraversal.java:133-205; 9-int tuples add
+//     {partition, cumulativeScale} (MultiPartitionDataLikelihoodDelegate.java:972-997);
+//   * every buffer index is independent storage that keeps the value its last operation gave it
+//     (src/dr/evomodel/treedatalikelihood/BufferIndexHelper.java:71-106 flips between two indices per node and expects
+//     the unflipped one to survive a rejected proposal).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mi355 {
+
+constexpr int PLAN_MAX_STEPS = 8;        // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
+constexpr int PLAN_NONE = -1;
+
+// kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine.cpp)
+enum { PK_MEM = 0, PK_TIPS = 1, PK_ACC = 2, PK_H0 = 3, PK_H1 = 4 };
+enum { PS_NONE = 0, PS_READ = 1, PS_WRITE = 2 };
+
+struct MicroOp {
+    int storeBuf;        // partials buffer that receives the result, or PLAN_NONE
+    int k1, a1;          // first child: kind, and the partials / tip buffer index for PK_MEM / PK_TIPS
+    int k2, a2;          // second child (PK_MEM, PK_TIPS or PK_ACC)
+    int mat1, mat2;      // matrix slot of each child's branch (caller's index, or a snapshot slot >= matrixCount)
+    int scaleIdx, smode; // scale buffer and PS_*
+    int hold;            // 0, or 1 + hold slot that ALSO receives the result
+};
+
+struct PlanSeg { int progStart, progCount, partition; };
+
+struct Plan {
+    std::vector<MicroOp> prog;
+    std::vector<PlanSeg> segs;
+    std::vector<int> snapPairs;      // (source matrix slot, destination snapshot slot) pairs to copy BEFORE the program runs
+    void clear() { prog.clear(); segs.clear(); snapPairs.clear(); }
+};
+
+// Definition of a virtual buffer: one step per internal node of a small all-compact-tip subtree, in evaluation order,
+// evaluable with the accumulator and ONE hold slot (the "A operand" first, then a JOIN-free "B chain").
+enum { VT_CHERRY = 1, VT_EXTEND = 2, VT_JOIN = 3 };
+struct VirtStep {
+    int type;               // VT_*
+    int tipA, tipB;         // CHERRY: both tips; EXTEND: tipB
+    int scaleIdx;           // this node's scale buffer, or PLAN_NONE
+    int originA, originB;   // matrix slots the snapshots were last copied FROM
+    int split;              // JOIN: number of leading steps of the program that form its first operand
+};
+struct VirtDef {
+    bool on = false;
+    bool chainOnly = true;  // no JOIN: evaluates without a hold slot
+    int nSteps = 0;
+    int stamp = -1;         // planner stamp of the list that created or last re-confirmed it
+    VirtStep steps[PLAN_MAX_STEPS];
+    // the op that defined it, for the steady-state path (an MCMC chain re-issues the same op on the same buffers every
+    // other evaluation): a definition whose op and children are unchanged is re-confirmed, not rebuilt
+    int version = 0;
+    int sigC1 = -1, sigM1 = -1, sigC2 = -1, sigM2 = -1, sigScale = -2;
+    bool sigTip1 = false, sigTip2 = false, fresh1 = false, fresh2 = false;
+    int childVer1 = -1, childVer2 = -1;
+};
+
+class WalkPlanner {
+public:
+    void init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled);
+
+    // maintained by the engine: buffer holds compact tip states (index < tipCount and setTipStates was the last setter)
+    std::vector<char> compactTip;
+
+    bool isVirtual(int buf) const { return virt_[buf].on; }
+    const VirtDef& definition(int buf) const { return virt_[buf]; }
+    bool virtualEnabled() const { return enabled_; }
+    int snapSlot(int buf, int step, int which) const { return matrixCount_ + buf * 2 * PLAN_MAX_STEPS + 2 * step + which; }
+    int matrixSlots() const { return matrixCount_ + (enabled_ ? partialsCount_ * 2 * PLAN_MAX_STEPS : 0); }
+
+    const std::vector<int>& tipUsers(int tip) const { return tipUsers_[tip]; }
+    const std::vector<int>& scaleUsers(int idx) const { return scaleUsers_[idx]; }
+    void clearVirtual(int buf);          // forget the definition (the buffer is about to get real data)
+
+    // Length of the longest prefix of ops[begin..count) that can run as one walk: no buffer (or scale buffer) is written
+    // twice, written after an earlier op of the prefix read it, or read through a scale index another op writes.
+    int hazardFreePrefix(const int* ops, int begin, int count, int tuple, int partitionCount);
+
+    // Virtual buffers that must get real data before this (hazard-free) list runs: definitions that read a scale buffer
+    // the list rewrites (unless the list redefines that buffer anyway), and a virtual destination that is its own child.
+    void mustMaterializeBefore(const int* ops, int count, int tuple, std::vector<int>& out);
+
+    // Plan a hazard-free list.  Indices must have been range-checked by the caller.  `allowVirtual`: destinations may
+    // become virtual (single-partition 7-int lists only).  Returns 0, or a BEAGLE error code.
+    int plan(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, Plan& out);
+
+    // Program that gives every (virtual) buffer of xs its real partials; the definitions are dropped.
+    void planMaterialize(const std::vector<int>& xs, Plan& out);
+
+    // statistics of the last plan() (bench / tests)
+    int lastStored = 0, lastMemReads = 0, lastHolds = 0;
+
+private:
+    struct OpInfo {
+        int dest, wS, rS, c1, m1, c2, m2, part;
+        bool tip1, tip2, virtDest;
+        int need;           // hold slots the evaluation needs (-1: not computed yet)
+        int size;           // real micro-ops below (ordering heuristic)
+        bool emitted;
+    };
+    bool buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs);
+    void registerVirtual(int X);
+    // emission
+    void emitReal(int j, unsigned freeMask, Plan& out, int depth);
+    void emitVirtualSteps(int buf, int lo, int hi, unsigned freeMask, bool writeMode, Plan& out);
+    void emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out);
+    int virtNeed(int buf) const { return virt_[buf].chainOnly ? 0 : 1; }
+
+    int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6;
+    bool enabled_ = false;
+    std::vector<VirtDef> virt_;
+    std::vector<std::vector<int>> tipUsers_, scaleUsers_;
+    int virtVersion_ = 0;
+    int stamp_ = 0;
+    // per-list scratch (stamped, so nothing is cleared between calls)
+    std::vector<int> wStamp_, rStamp_, wOp_;          // per (buffer, partition)
+    std::vector<int> sWStamp_, sRStamp_, sDone_;      // per scale buffer: written / read in this list, write emitted
+    std::vector<OpInfo> info_;
+    std::vector<int> prod1_, prod2_;                   // op of this list that produced each child (or -1)
+    int parts_ = 1;
+    bool flat_ = false;                                // recursion too deep: children of real ops are read from memory
+};
+
+}  // namespace mi355

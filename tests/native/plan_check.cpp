@@ -1,0 +1,412 @@
+// plan_check.cpp — CPU check of the walk planner (beast-mcmc_amd/csrc/planner.cpp).  TEST INFRASTRUCTURE, not product.
+//
+// Two worlds are driven by the same sequence of BEAGLE-style calls:
+//   truth   every buffer index is real storage; an operation list is evaluated in list order, one op after the other
+//           (the semantics of lib/beagle.jar!beagle/GeneralBeagleImpl#updatePartials)
+//   planned the planner's micro-operation programs are executed by an index-level interpreter of the walk kernel's
+//           register model (ACC + two hold slots per (pattern, category)); virtual buffers hold no data
+// After every list all real buffers and scale buffers must agree BITWISE; virtual buffers are compared when they are
+// materialised (at random, and all of them at the end).  Scenarios: full evaluations in both traversal orders, rescaling
+// write / read mode, MCMC-style partial updates with BufferIndexHelper flips and rejections
+// (src/dr/evomodel/treedatalikelihood/BufferIndexHelper.java:71-106), tip-state changes, partitioned 9-int lists,
+// lists with hazards, a 5000-tip caterpillar (flat emission).
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <vector>
+
+#include "../../beast-mcmc_amd/csrc/planner.h"
+
+using namespace mi355;
+
+static int P = 7, C = 2;
+static const char* g_where = "";
+static long g_list = 0;
+#define CHECK(cond, m, k) do { if (!(cond)) { fprintf(stderr, "FAILED %s [%s, list %ld] micro-op %d: store %d k1 %d a1 %d k2 %d a2 %d mat %d %d scale %d mode %d hold %d\n", #cond, g_where, g_list, k, (m).storeBuf, (m).k1, (m).a1, (m).k2, (m).a2, (m).mat1, (m).mat2, (m).scaleIdx, (m).smode, (m).hold); exit(1); } } while (0)
+struct V4 { double v[4]; };
+static inline V4 matvec(const double* m, const V4& x) {
+    V4 y;
+    for (int i = 0; i < 4; i++) y.v[i] = std::fma(m[4 * i + 3], x.v[3], std::fma(m[4 * i + 2], x.v[2], std::fma(m[4 * i + 1], x.v[1], m[4 * i] * x.v[0])));
+    return y;
+}
+static inline V4 column(const double* m, int s) { V4 y; for (int i = 0; i < 4; i++) y.v[i] = s < 4 ? m[4 * i + s] : 1.0; return y; }
+
+struct World {
+    std::vector<std::vector<double>> partials;     // [buf] -> C*P*4 or empty
+    std::vector<std::vector<uint8_t>> tips;        // [buf] -> P or empty
+    std::vector<std::vector<double>> mats;         // [slot] -> C*16
+    std::vector<std::vector<double>> scale;        // [idx] -> P raw factors (empty: never written)
+};
+
+static V4 childFactor(const World& w, int buf, bool tip, int mat, int c, int p) {
+    const double* m = &w.mats[mat][(size_t)c * 16];
+    if (tip) return column(m, w.tips[buf][p]);
+    assert(!w.partials[buf].empty());
+    V4 x; memcpy(x.v, &w.partials[buf][((size_t)c * P + p) * 4], 32);
+    return matvec(m, x);
+}
+
+// list-order evaluation of one op (all patterns of [p0, p1))
+static void truthOp(World& w, const std::vector<char>& compact, const int* op, int p0, int p1) {
+    const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
+    std::vector<double> out = w.partials[dest];
+    if (out.empty()) out.assign((size_t)C * P * 4, 0.0);
+    for (int p = p0; p < p1; p++) {
+        V4 r[8];
+        for (int c = 0; c < C; c++) {
+            const V4 a = childFactor(w, c1, compact[c1], m1, c, p), b = childFactor(w, c2, compact[c2], m2, c, p);
+            for (int i = 0; i < 4; i++) r[c].v[i] = a.v[i] * b.v[i];
+        }
+        if (wS >= 0) {
+            double m = 0.0;
+            for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) m = std::fmax(m, r[c].v[i]);
+            if (!(m > 0.0)) m = 1.0;
+            if (w.scale[wS].empty()) w.scale[wS].assign(P, 0.0);
+            w.scale[wS][p] = m;
+            const double im = 1.0 / m;
+            for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
+        } else if (rS >= 0) {
+            const double im = 1.0 / w.scale[rS][p];
+            for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
+        }
+        for (int c = 0; c < C; c++) memcpy(&out[((size_t)c * P + p) * 4], r[c].v, 32);
+    }
+    w.partials[dest] = out;
+}
+
+// the walk kernel's register model, index level
+static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStart, const std::vector<int>& partEnd) {
+    // snapshot copies: one parallel launch (all sources are read before any destination is written)
+    std::vector<std::vector<double>> src;
+    for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) src.push_back(w.mats[plan.snapPairs[i]]);
+    for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) w.mats[plan.snapPairs[i + 1]] = src[i / 2];
+    for (const PlanSeg& sg : plan.segs) {
+        for (int p = partStart[sg.partition]; p < partEnd[sg.partition]; p++) {
+            V4 ACC[8], H[2][8];
+            for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
+                const MicroOp& m = plan.prog[k];
+                V4 r[8];
+                for (int c = 0; c < C; c++) {
+                    V4 f1, f2;
+                    const double* M1 = &w.mats[m.mat1][(size_t)c * 16];
+                    const double* M2 = &w.mats[m.mat2][(size_t)c * 16];
+                    if (m.k1 == PK_TIPS) f1 = column(M1, w.tips[m.a1][p]);
+                    else if (m.k1 == PK_MEM) { CHECK(!w.partials[m.a1].empty(), m, k); V4 x; memcpy(x.v, &w.partials[m.a1][((size_t)c * P + p) * 4], 32); f1 = matvec(M1, x); }
+                    else { assert(m.k1 == PK_H0 || m.k1 == PK_H1); f1 = matvec(M1, H[m.k1 - PK_H0][c]); }
+                    if (m.k2 == PK_TIPS) f2 = column(M2, w.tips[m.a2][p]);
+                    else if (m.k2 == PK_MEM) { CHECK(!w.partials[m.a2].empty(), m, k); V4 x; memcpy(x.v, &w.partials[m.a2][((size_t)c * P + p) * 4], 32); f2 = matvec(M2, x); }
+                    else { assert(m.k2 == PK_ACC); f2 = matvec(M2, ACC[c]); }
+                    for (int i = 0; i < 4; i++) r[c].v[i] = f1.v[i] * f2.v[i];
+                }
+                if (m.smode == PS_WRITE) {
+                    double mx = 0.0;
+                    for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) mx = std::fmax(mx, r[c].v[i]);
+                    if (!(mx > 0.0)) mx = 1.0;
+                    if (w.scale[m.scaleIdx].empty()) w.scale[m.scaleIdx].assign(P, 0.0);
+                    w.scale[m.scaleIdx][p] = mx;
+                    const double im = 1.0 / mx;
+                    for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
+                } else if (m.smode == PS_READ) {
+                    CHECK(!w.scale[m.scaleIdx].empty(), m, k);
+                    const double im = 1.0 / w.scale[m.scaleIdx][p];
+                    for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
+                }
+                if (m.storeBuf >= 0) {
+                    if (w.partials[m.storeBuf].empty()) w.partials[m.storeBuf].assign((size_t)C * P * 4, 0.0);
+                    for (int c = 0; c < C; c++) memcpy(&w.partials[m.storeBuf][((size_t)c * P + p) * 4], r[c].v, 32);
+                }
+                for (int c = 0; c < C; c++) { ACC[c] = r[c]; if (m.hold) H[m.hold - 1][c] = r[c]; }
+            }
+        }
+    }
+}
+
+struct Harness {
+    int T, nBuf, nMat, nScale;
+    World truth, plan;
+    WalkPlanner pl;
+    std::vector<char> compact;
+    std::vector<int> partStart{0}, partEnd;
+    int parts = 1;
+    std::mt19937 rng;
+    long lists = 0, micro = 0, holds = 0, memReads = 0, stored = 0, materialised = 0;
+
+    void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
+        T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
+        pl.init(nBuf, T, nMat, nScale, 6, virt);
+        const int slots = pl.matrixSlots();
+        for (World* w : {&truth, &plan}) {
+            w->partials.assign(nBuf, {}); w->tips.assign(nBuf, {}); w->mats.assign(slots, std::vector<double>((size_t)C * 16, 0.0));
+            w->scale.assign(nScale, {});
+        }
+        compact.assign(nBuf, 0);
+        partEnd.assign(1, P);
+    }
+    void setTipStates(int tip) {
+        materialise(pl.tipUsers(tip));
+        std::vector<uint8_t> s(P);
+        for (int p = 0; p < P; p++) s[p] = (uint8_t)(rng() % 5);
+        truth.tips[tip] = s; plan.tips[tip] = s;
+        compact[tip] = 1; pl.compactTip[tip] = 1;
+    }
+    void setTipPartials(int tip) {
+        materialise(pl.tipUsers(tip));
+        pl.clearVirtual(tip);
+        std::vector<double> x((size_t)C * P * 4);
+        std::uniform_real_distribution<double> u(0.05, 1.0);
+        for (double& v : x) v = u(rng);
+        truth.partials[tip] = x; plan.partials[tip] = x;
+        compact[tip] = 0; pl.compactTip[tip] = 0;
+    }
+    void setMatrix(int slot) {
+        std::uniform_real_distribution<double> u(0.01, 1.0);
+        std::vector<double> m((size_t)C * 16);
+        for (double& v : m) v = u(rng) * 1e-3;     // small entries: products shrink, rescaling matters
+        truth.mats[slot] = m; plan.mats[slot] = m;
+    }
+    void materialise(std::vector<int> xs) {
+        if (xs.empty()) return;
+        Plan mp;
+        std::vector<int> which;
+        for (int x : xs) if (pl.isVirtual(x)) which.push_back(x);
+        pl.planMaterialize(xs, mp);
+        runPlan(plan, mp, partStart, partEnd);
+        for (int x : which) { compareBuffer(x, "materialised"); materialised++; }
+    }
+    void compareBuffer(int b, const char* what) {
+        if (truth.partials[b].empty()) return;
+        if (plan.partials[b].size() != truth.partials[b].size() ||
+            memcmp(plan.partials[b].data(), truth.partials[b].data(), truth.partials[b].size() * 8) != 0) {
+            fprintf(stderr, "MISMATCH (%s) buffer %d after %ld lists\n", what, b, lists);
+            exit(1);
+        }
+    }
+    void compareAll() {
+        for (int b = 0; b < nBuf; b++) if (!pl.isVirtual(b) && !compact[b]) compareBuffer(b, "real");
+        for (int s = 0; s < nScale; s++) {
+            if (truth.scale[s].empty()) continue;
+            if (plan.scale[s].size() != truth.scale[s].size() || memcmp(plan.scale[s].data(), truth.scale[s].data(), (size_t)P * 8) != 0) {
+                fprintf(stderr, "MISMATCH scale %d after %ld lists\n", s, lists); exit(1);
+            }
+        }
+    }
+    // one updatePartials call, the way the engine drives the planner
+    void update(const std::vector<int>& ops, int tuple) {
+        const int count = (int)(ops.size() / tuple);
+        for (int k = 0; k < count; k++) {
+            const int* op = &ops[(size_t)k * tuple];
+            const int part = tuple > 7 ? op[7] : 0;
+            truthOp(truth, compact, op, partStart[part], partEnd[part]);
+        }
+        int begin = 0;
+        while (begin < count) {
+            const int n = pl.hazardFreePrefix(ops.data(), begin, count, tuple, parts);
+            assert(n >= 1);
+            const int* sub = ops.data() + (size_t)begin * tuple;
+            std::vector<int> need;
+            pl.mustMaterializeBefore(sub, n, tuple, need);
+            materialiseNoCompare(need);
+            Plan p;
+            const int rc = pl.plan(sub, n, tuple, parts, true, p);
+            assert(rc == 0);
+            // every MEM child must be real data, every destination must end up real or virtual
+            runPlan(plan, p, partStart, partEnd);
+            micro += (long)p.prog.size(); holds += pl.lastHolds; memReads += pl.lastMemReads; stored += pl.lastStored;
+            begin += n;
+        }
+        lists++; g_list = lists;
+        compareAll();
+    }
+    // materialise without comparing: the truth world already holds the values AFTER the list (used for buffers whose
+    // old definition is about to be invalidated by a scale rewrite — their truth value is the OLD one only if the list
+    // does not rewrite them; they are checked by compareAll afterwards)
+    void materialiseNoCompare(const std::vector<int>& xs) {
+        if (xs.empty()) return;
+        Plan mp;
+        pl.planMaterialize(xs, mp);
+        runPlan(plan, mp, partStart, partEnd);
+    }
+};
+
+// ---- a tree and BEAST's buffer-index protocol -------------------------------------------------------------------
+struct Tree {
+    int T; std::vector<int> left, right, parent;   // internal nodes T..2T-2; root = 2T-2
+    void random(int tips, std::mt19937& rng, bool caterpillar) {
+        T = tips; const int N = 2 * T - 1;
+        left.assign(N, -1); right.assign(N, -1); parent.assign(N, -1);
+        std::vector<int> roots;
+        for (int i = 0; i < T; i++) roots.push_back(i);
+        for (int n = T; n < N; n++) {
+            int a, b;
+            if (caterpillar) { a = roots.size() - 1; b = 0; if (a == b) b = 1; }
+            else { a = rng() % roots.size(); do { b = rng() % roots.size(); } while (b == a); }
+            left[n] = roots[a]; right[n] = roots[b]; parent[roots[a]] = n; parent[roots[b]] = n;
+            if (a < b) std::swap(a, b);
+            roots.erase(roots.begin() + a); roots.erase(roots.begin() + b);
+            roots.push_back(n);
+        }
+    }
+    void postOrder(int n, std::vector<int>& out) const { if (n < T) return; postOrder(left[n], out); postOrder(right[n], out); out.push_back(n); }
+    std::vector<int> levelOrder() const {   // reverse level order: deepest internal nodes first
+        const int N = 2 * T - 1;
+        std::vector<int> depth(N, 0), order;
+        for (int n = N - 2; n >= 0; n--) {}
+        std::vector<int> stack{N - 1};
+        std::vector<std::pair<int, int>> byDepth;
+        while (!stack.empty()) { int n = stack.back(); stack.pop_back(); if (n < T) continue; byDepth.push_back({depth[n], n});
+            depth[left[n]] = depth[right[n]] = depth[n] + 1; stack.push_back(left[n]); stack.push_back(right[n]); }
+        std::stable_sort(byDepth.begin(), byDepth.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        for (auto& d : byDepth) order.push_back(d.second);
+        return order;
+    }
+};
+
+// partials buffers: tips 0..T-1, internal node n -> T + 2(n-T) + flip;  matrices: node n -> 2n + flip;  scale: node n-T -> 2(n-T)+flip
+struct Protocol {
+    const Tree& t; int T;
+    std::vector<int> pFlip, mFlip, sFlip, pSaved, mSaved, sSaved;
+    explicit Protocol(const Tree& tr) : t(tr), T(tr.T) { const int N = 2 * T - 1; pFlip.assign(N, 0); mFlip.assign(N, 0); sFlip.assign(N, 0); }
+    int pBuf(int n) const { return n < T ? n : T + 2 * (n - T) + pFlip[n]; }
+    int mBuf(int n) const { return 2 * n + mFlip[n]; }
+    int sBuf(int n) const { return 2 * (n - T) + sFlip[n]; }
+    void store() { pSaved = pFlip; mSaved = mFlip; sSaved = sFlip; }
+    void restore() { pFlip = pSaved; mFlip = mSaved; sFlip = sSaved; }
+    void emit(const std::vector<int>& nodes, int scaleMode /*0 none 1 write 2 read*/, std::vector<int>& ops) {
+        for (int n : nodes) {
+            if (scaleMode == 1) sFlip[n] ^= 1;
+            ops.insert(ops.end(), {pBuf(n), scaleMode == 1 ? sBuf(n) : -1, scaleMode == 2 ? sBuf(n) : -1, pBuf(t.left[n]), mBuf(t.left[n]), pBuf(t.right[n]), mBuf(t.right[n])});
+        }
+    }
+};
+
+static void scenarioMcmc(int T, bool virt, bool caterpillar, unsigned seed, int steps, bool someTipPartials) {
+    std::mt19937 rng(seed);
+    static char where[128]; snprintf(where, sizeof where, "mcmc T=%d virt=%d cat=%d seed=%u tipPartials=%d", T, (int)virt, (int)caterpillar, seed, (int)someTipPartials); g_where = where; g_list = 0;
+    Tree tree; tree.random(T, rng, caterpillar);
+    const int N = 2 * T - 1;
+    Harness h; h.init(T, T + 2 * (T - 1), 2 * N, 2 * (T - 1), virt, seed + 1);
+    for (int i = 0; i < T; i++) { if (someTipPartials && rng() % 7 == 0) h.setTipPartials(i); else h.setTipStates(i); }
+    for (int s = 0; s < 2 * N; s++) h.setMatrix(s);
+    Protocol pr(tree);
+    std::vector<int> all; tree.postOrder(N - 1, all);
+    std::vector<int> lvl = tree.levelOrder();
+    // full evaluation, no scaling, post-order; then level order with rescaling (write), then read mode
+    { std::vector<int> ops; for (int n : all) pr.pFlip[n] ^= 1; pr.emit(all, 0, ops); h.update(ops, 7); }
+    { std::vector<int> ops; for (int n : lvl) pr.pFlip[n] ^= 1; pr.emit(lvl, 1, ops); h.update(ops, 7); }
+    { std::vector<int> ops; for (int n : lvl) pr.pFlip[n] ^= 1; pr.emit(lvl, 2, ops); h.update(ops, 7); }
+    for (int step = 0; step < steps; step++) {
+        pr.store();
+        // a proposal: change one or two branches -> their matrices and the path(s) to the root
+        std::vector<char> dirty(N, 0);
+        const int nChanges = 1 + rng() % 2;
+        for (int q = 0; q < nChanges; q++) {
+            const int n = rng() % (N - 1);
+            pr.mFlip[n] ^= 1; h.setMatrix(pr.mBuf(n));
+            for (int a = tree.parent[n]; a >= 0; a = tree.parent[a]) dirty[a] = 1;
+        }
+        std::vector<int> nodes;
+        const bool level = rng() % 2;
+        for (int n : (level ? lvl : all)) if (dirty[n]) nodes.push_back(n);
+        const int mode = step % 9 == 4 ? 1 : 2;      // every ninth proposal recomputes the scale factors of ITS nodes
+        if (mode == 1) {                               // BEAST recomputes all of them: full traversal in write mode
+            nodes = level ? lvl : all;
+        }
+        for (int n : nodes) pr.pFlip[n] ^= 1;
+        std::vector<int> ops; pr.emit(nodes, mode, ops);
+        h.update(ops, 7);
+        if (rng() % 3 == 0) pr.restore();              // rejected: the unflipped buffers must still hold their values
+        if (rng() % 4 == 0) { std::vector<int> xs; for (int q = 0; q < 3; q++) xs.push_back(T + rng() % (2 * (T - 1))); h.materialise(xs); }
+        if (rng() % 11 == 0) { const int tip = rng() % T; if (h.compact[tip]) {
+            // new tip data invalidates everything above it: BEAST would re-evaluate; here only the planner hooks are exercised
+            h.setTipStates(tip);
+            std::vector<int> nodes2; std::vector<char> d2(N, 0);
+            for (int a = tree.parent[tip]; a >= 0; a = tree.parent[a]) d2[a] = 1;
+            for (int n : all) if (d2[n]) nodes2.push_back(n);
+            pr.store(); for (int n : nodes2) pr.pFlip[n] ^= 1;
+            std::vector<int> ops2; pr.emit(nodes2, 2, ops2); h.update(ops2, 7);
+            // the OTHER flip of those nodes is now stale in BEAST too (it never reads it again before rewriting it)
+        } }
+    }
+    std::vector<int> every; for (int b = T; b < h.nBuf; b++) every.push_back(b);
+    h.materialise(every);
+    h.compareAll();
+    printf("  mcmc T=%d virt=%d cat=%d: %ld lists, %ld micro-ops, %ld stored, %ld holds, %ld memory reads, %ld materialised\n",
+           T, (int)virt, (int)caterpillar, h.lists, h.micro, h.stored, h.holds, h.memReads, h.materialised);
+}
+
+static void scenarioPartitions(unsigned seed) {
+    g_where = "partitions"; g_list = 0;
+    std::mt19937 rng(seed);
+    const int T = 9; Tree tree; tree.random(T, rng, false);
+    const int N = 2 * T - 1;
+    Harness h; h.init(T, T + 2 * (T - 1), 2 * N * 3, 2 * (T - 1) * 3, true, seed);
+    h.parts = 3; h.partStart = {0, 2, 5}; h.partEnd = {2, 5, P};
+    for (int i = 0; i < T; i++) h.setTipStates(i);
+    for (int s = 0; s < 2 * N * 3; s++) h.setMatrix(s);
+    std::vector<int> all; tree.postOrder(N - 1, all);
+    for (int rep = 0; rep < 6; rep++) {
+        std::vector<int> ops;
+        const int mode = rep == 1 ? 1 : rep == 0 ? 0 : 2;
+        for (int part = 0; part < 3; part++)
+            for (int n : all) {
+                if (rep > 2 && rng() % 3 == 0 && n != N - 1) continue;   // partial lists (a node above a skipped one re-reads it)
+                auto pb = [&](int x) { return x < T ? x : T + 2 * (x - T) + (rep & 1); };
+                auto pbOld = [&](int x) { return x < T ? x : T + 2 * (x - T) + ((rep & 1) ^ 0); };
+                (void)pbOld;
+                const int s = (2 * (n - T)) * 3 + part;
+                ops.insert(ops.end(), {pb(n), mode == 1 ? s : -1, mode == 2 ? s : -1, pb(tree.left[n]), (2 * tree.left[n]) * 3 + part,
+                                       pb(tree.right[n]), (2 * tree.right[n]) * 3 + part, part, -1});
+            }
+        if (rep > 2) {   // skipped nodes must exist in this flip: run a full list first in that case
+            std::vector<int> full;
+            for (int part = 0; part < 3; part++) for (int n : all) {
+                auto pb = [&](int x) { return x < T ? x : T + 2 * (x - T) + (rep & 1); };
+                const int s = (2 * (n - T)) * 3 + part;
+                full.insert(full.end(), {pb(n), -1, 2 > 1 ? s : -1, pb(tree.left[n]), (2 * tree.left[n]) * 3 + part, pb(tree.right[n]), (2 * tree.right[n]) * 3 + part, part, -1});
+            }
+            h.update(full, 9);
+        }
+        h.update(ops, 9);
+    }
+    printf("  partitions: %ld lists, %ld micro-ops\n", h.lists, h.micro);
+}
+
+static void scenarioHazards(unsigned seed) {
+    g_where = "hazards"; g_list = 0;
+    Harness h; h.init(4, 12, 16, 8, true, seed);
+    for (int i = 0; i < 4; i++) h.setTipStates(i);
+    for (int s = 0; s < 16; s++) h.setMatrix(s);
+    // X(4) = f(0,1); Y(5) = g(X, 2); X(4) = h(2,3) [WAW + WAR]; Z(6) = k(X, Y); Z(6) = k'(Z, 3) [in place]
+    std::vector<int> ops = {4, -1, -1, 0, 0, 1, 1,   5, -1, -1, 4, 2, 2, 3,   4, -1, -1, 2, 4, 3, 5,   6, -1, -1, 4, 6, 5, 7,   6, -1, -1, 6, 8, 3, 9};
+    h.update(ops, 7);
+    // the same scale buffer written by one op and read by a later one of the same list
+    std::vector<int> ops2 = {7, 0, -1, 0, 0, 1, 1,   8, -1, 0, 7, 2, 2, 3,   9, 1, -1, 8, 4, 7, 5};
+    h.update(ops2, 7);
+    std::vector<int> every; for (int b = 4; b < 12; b++) every.push_back(b);
+    h.materialise(every);
+    printf("  hazards: %ld lists, %ld micro-ops\n", h.lists, h.micro);
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 3;
+    for (int r = 0; r < reps; r++) {
+        for (int T : {2, 3, 5, 8, 13, 40, 150}) {
+            scenarioMcmc(T, true, false, 1000 * r + T, 60, false);
+            scenarioMcmc(T, true, false, 2000 * r + T, 40, true);
+            scenarioMcmc(T, false, false, 3000 * r + T, 20, false);
+            scenarioMcmc(T, true, true, 4000 * r + T, 30, false);
+        }
+        scenarioPartitions(77 + r);
+        scenarioHazards(5 + r);
+    }
+    P = 2; C = 1;
+    scenarioMcmc(5000, true, true, 9, 3, false);     // deeper than the recursion limit: flat emission
+    scenarioMcmc(3000, true, false, 10, 5, false);
+    printf("plan_check: OK\n");
+    return 0;
+}
