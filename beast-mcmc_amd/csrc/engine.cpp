@@ -285,7 +285,14 @@ inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X]
 // micro-operations travel together) and enqueue the snapshot copies and the walk.
 int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk = nullptr) {
     const size_t n = plan.prog.size();
-    if (n == 0) return 0;
+    if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
+        if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
+        void* dPairs = nullptr;
+        int rc = uploadTransient(in, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     std::vector<mi355::WalkOp>& w = in->walkOps;
     w.resize(n);
     const unsigned matStride = (unsigned)in->C * 16;
@@ -418,7 +425,7 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         if (!in->plan.prog.empty()) {
             rc = runPlan(in, in->plan, launches == 0 ? e0 : nullptr); if (rc) return rc;
             launches++;
-        }
+        } else { rc = runPlan(in, in->plan); if (rc) return rc; }
         begin += n;
     }
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
