@@ -102,8 +102,8 @@ int devAlloc(Instance* in, void** p, size_t bytes) {
 
 // Stage `bytes` of host data into the pinned ring; returns the ring offset (or <0).  Wrapping first
 // drains the stream, so a region is never overwritten while a copy from it is still in flight.
-long stage(Instance* in, const void* src, size_t bytes) {
-    const size_t need = (bytes + 255) & ~(size_t)255;
+long stage(Instance* in, const void* src, size_t bytes, size_t reserve = 0) {
+    const size_t need = (std::max(bytes, reserve) + 255) & ~(size_t)255;
     if (need > RING_BYTES) return -1;
     if (in->ringHead + need > RING_BYTES) {
         if (hipStreamSynchronize(in->stream) != hipSuccess) return -1;
@@ -293,52 +293,66 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    // Device program: per segment its micro-operations, a no-op when their number is odd, and two more no-ops the
+    // kernel's descriptor prefetch may read (kernels.h WalkSeg).
     std::vector<mi355::WalkOp>& w = in->walkOps;
-    w.resize(n);
-    const unsigned matStride = (unsigned)in->C * 16;
-    for (size_t i = 0; i < n; i++) {
-        const mi355::MicroOp& m = plan.prog[i];
-        mi355::WalkOp& d = w[i];
-        d.src1 = nullptr; d.src2 = nullptr; d.scale = nullptr; d.store = nullptr; d.pad = 0;
-        if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-        else if (m.k1 == mi355::PK_TIPS) { d.src1 = in->tipStates[m.a1]; if (!d.src1) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
-        if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-        else if (m.k2 == mi355::PK_TIPS) { d.src2 = in->tipStates[m.a2]; if (!d.src2) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
-        if (m.smode != mi355::PS_NONE) {
-            int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-            if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; }
-            else { if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE; in->statScaleReads++; }   // never written by a rescaling op
-            d.scale = in->scale[m.scaleIdx];
+    w.clear();
+    w.reserve(n + 3 * plan.segs.size());
+    std::vector<mi355::WalkSeg> segs(plan.segs.size());
+    const size_t matStride = (size_t)in->C * 16;
+    mi355::WalkOp nop;
+    memset(&nop, 0, sizeof(nop));
+    nop.m1 = in->matrices; nop.m2 = in->matrices;
+    nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
+    int maxRange = 0;
+    for (size_t si = 0; si < plan.segs.size(); si++) {
+        const mi355::PlanSeg& ps = plan.segs[si];
+        segs[si].progStart = (int)w.size();
+        for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
+            const mi355::MicroOp& m = plan.prog[i];
+            mi355::WalkOp d;
+            memset(&d, 0, sizeof(d));
+            if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+            else if (m.k1 == mi355::PK_TIPS) { d.src1 = in->tipStates[m.a1]; if (!d.src1) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+            if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+            else if (m.k2 == mi355::PK_TIPS) { d.src2 = in->tipStates[m.a2]; if (!d.src2) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+            if (m.smode != mi355::PS_NONE) {
+                int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
+                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scale = in->scale[m.scaleIdx]; }
+                else {
+                    if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
+                    in->statScaleReads++;
+                    d.scale = in->scale[m.scaleIdx] + in->scaleStride;                    // read mode multiplies by the reciprocal
+                }
+            }
+            if (m.storeBuf >= 0) {
+                int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
+                d.store = in->partials[m.storeBuf];
+                in->statStored++;
+            }
+            d.m1 = in->matrices + (size_t)m.mat1 * matStride; d.m2 = in->matrices + (size_t)m.mat2 * matStride;
+            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
+            w.push_back(d);
         }
-        if (m.storeBuf >= 0) {
-            int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
-            d.store = in->partials[m.storeBuf];
-            in->statStored++;
-        }
-        d.mat1 = (int)((unsigned)m.mat1 * matStride); d.mat2 = (int)((unsigned)m.mat2 * matStride);
-        d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode);
+        if (ps.progCount & 1) w.push_back(nop);
+        segs[si].progCount = (int)w.size() - segs[si].progStart;
+        w.push_back(nop); w.push_back(nop);
+        segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
+        maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
     in->statMicroOps += (long)n; in->statWalks++;
-    std::vector<mi355::WalkSeg> segs(plan.segs.size());
-    int maxRange = 0;
-    for (size_t i = 0; i < segs.size(); i++) {
-        const mi355::PlanSeg& ps = plan.segs[i];
-        segs[i].progStart = ps.progStart; segs[i].progCount = ps.progCount;
-        segs[i].pStart = in->partStart[ps.partition]; segs[i].pEnd = in->partEnd[ps.partition];
-        maxRange = std::max(maxRange, segs[i].pEnd - segs[i].pStart);
-    }
-    // pack: [micro-ops (48 B each) | segments (16 B each) | snapshot pairs]
-    const size_t opBytes = n * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
+    // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
+    const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
     char* dBase = nullptr;
     if (total <= RING_BYTES / 4) {
-        const long off = stage(in, w.data(), opBytes + segBytes + pairBytes);   // reserves `total` bytes, copies only the ops ...
+        const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
         if (off < 0) return BEAGLE_ERROR_GENERAL;
         memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
         if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
         HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
         dBase = in->dRing + off;
-    } else {                                  // a tree of > ~80 000 nodes: its own staging buffer, synchronous copy
+    } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->bigStageBytes < total) {
             if (in->bigStage) hipFree(in->bigStage);
@@ -356,7 +370,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
                                       in->C * in->S * in->S);
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes), (int)segs.size(), maxRange,
-                       in->matrices, in->P, in->C, (long)in->scaleStride);
+                       in->P, in->C, (long)in->scaleStride);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -993,7 +1007,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->schedAlap = !(getenv("BEAGLE_MI355_SCHED") && strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") == 0);
     // 4 states (nucleotides), up to 16 rate categories: the pattern walk.  BEAGLE_MI355_NO_VIRTUAL=1 keeps every buffer real,
     // BEAGLE_MI355_VSTEPS=n caps the length of a virtual definition (A/B runs).
-    in->walk = stateCount == 4 && categoryCount <= 16;
+    in->walk = stateCount == 4 && categoryCount <= 16 &&
+               (size_t)categoryCount * patternCount * 32 < ((size_t)1 << 32);     // the kernel addresses a buffer with 32-bit lane offsets
     const bool virtualOn = in->walk && !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
     int maxVirtSteps = 6;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));

@@ -38,27 +38,39 @@ bool grantDynamicLds(const void* kernel, size_t bytes);
 // ---- the pattern walk (4 states, kernels_walk4.hip) ------------------------------------------------------------------
 // One micro-operation of a walk program: node = (M1 . child1) * (M2 . child2) [* 1/scale].  A child is read from a
 // partials buffer (WK_MEM), is a compact tip (WK_TIPS), or is a value the same thread computed earlier in the program:
-// the previous micro-operation's result (WK_ACC, second operand only) or one of two hold registers (WK_H0/WK_H1, first
-// operand only; `hold` copies ACC into one of them before this micro-operation overwrites it).  The product commutes
-// bitwise, so the planner is free to order the two children that way.
+// the previous micro-operation's result (WK_ACC, second operand only) or one of two hold slots (WK_H0/WK_H1, first
+// operand only; `hold` = 1 + slot: the result of THIS micro-operation is also parked there).  The product commutes
+// bitwise, so the planner is free to order the two children that way; a child in memory comes first.
 enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4 };
 enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
-struct WalkOp {
-    double*        store;       // partials buffer the result is written to, or nullptr (virtual node)
-    const void*    src1;        // WK_MEM: const double* partials [C][P][4];  WK_TIPS: const uint8_t* states
-    const void*    src2;
-    double*        scale;       // WS_READ: reciprocals at scale[recipOff + p];  WS_WRITE: writes factor and reciprocal
-    int            mat1, mat2;  // ELEMENT offsets (matrix index * C * 16) of the two child branches' matrices
-    unsigned       flags;       // k1 | k2 << 3 | hold << 6 | scaleMode << 8
-    int            pad;
+// flags: what the kernel's fetch stage has to load for the micro-operation (WF_*), then the kinds
+enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
+struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
+    const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
+    const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
+    double*        store;    // partials buffer the result is written to (WF_STORE)
+    double*        scale;    // WS_READ: the RECIPROCAL half of the scale buffer;  WS_WRITE: the buffer (factor half first)
+    const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles)
+    const double*  m2;
+    unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13
+    unsigned       pad0;
+    unsigned long long pad1;
 };
-static_assert(sizeof(WalkOp) == 48, "WalkOp layout");
-inline unsigned walkFlags(int k1, int k2, int hold, int smode) { return (unsigned)(k1 | (k2 << 3) | (hold << 6) | (smode << 8)); }
-// A program slice and the pattern range that executes it (one per partition of a partitioned instance)
+static_assert(sizeof(WalkOp) == 64, "WalkOp layout");
+inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
+    unsigned f = (unsigned)((k1 << 5) | (k2 << 8) | (hold << 11) | (smode << 13));
+    if (k1 == WK_MEM) f |= WF_X;
+    if (k1 == WK_TIPS) f |= WF_T1;
+    if (k2 == WK_TIPS) f |= WF_T2;
+    if (smode == WS_READ) f |= WF_INV;
+    if (store) f |= WF_STORE;
+    return f;
+}
+// A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
+// software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
 struct WalkSeg { int progStart, progCount, pStart, pEnd; };
 // one launch: every 64-pattern group of every segment walks its program; maxRange = max (pEnd - pStart)
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange,
-                 const double* matrices, int P, int C, long recipOff);
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);

@@ -3,19 +3,32 @@
 // A site pattern never needs another pattern's data, so a thread that owns (pattern p, rate category c) can execute a
 // whole dependency-ordered operation list by itself, one operation after the other, with no grid-wide synchronisation:
 // what it reads was either there before the launch or written by the same thread earlier in the same launch (program
-// order makes a thread's own stores visible to its later loads).  The host (engine.cpp, "walk planner") turns an
-// updatePartials list into a post-order program of micro-operations; the result of a micro-operation stays in the
-// thread's registers (ACC, and two hold registers H0/H1 for a value that has to wait for its sibling's subtree), so a
-// child that was computed by the previous micro-operation is not read back from HBM, and a node whose subtree is a few
-// compact tips ("virtual" buffer, engine.cpp) is never written at all.
+// order makes a thread's own stores visible to its later loads).  The host (planner.cpp) turns an updatePartials list
+// into a post-order program of micro-operations; the result of a micro-operation stays in the thread's registers (ACC)
+// or in one of two LDS hold slots (a value that has to wait for its sibling's subtree), so a child that was computed by
+// the previous micro-operation is not read back from HBM, and a node whose subtree is a few compact tips ("virtual"
+// buffer) is never written at all.
 //
 // Mapping:  workgroup = 64 consecutive patterns x all C categories; wave w = category w; lane l = pattern p0 + l.
 //           A wave's loads/stores of a partials buffer ([C][P][4] doubles) are 64 x 32 B = 2 KiB contiguous.
-//           All C*P/64 waves of a 1e5-pattern alignment are resident at once (6 waves per SIMD at C = 4).
-// Branch matrices are wave-uniform (one category per wave): the 4x4 mat-vec takes its matrix from SGPRs (scalar loads
-// through the constant address space), no LDS.  A compact tip child needs column `state` of the matrix per lane: the
-// wave loads the 16 entries once (lane j <- M[j], lanes >= 16 hold 1.0 for a missing state) and every lane picks its
-// four entries with ds_bpermute (crossbar only, no LDS storage).
+//           All C*P/64 waves of a 1e5-pattern alignment are resident at once (6.1 waves per SIMD at C = 4; the kernel is
+//           held to 72 VGPRs = 7 waves per SIMD for that reason: a wave walks the whole list, so a second round of
+//           workgroups would double the time).
+//
+// What bounds a wave is LATENCY: it executes ~T dependent micro-operations.  So the loop is software-pipelined by hand:
+// while micro-operation k computes, everything k+1 needs from memory is already in flight — its child partials (32 B per
+// lane), tip-state bytes, reciprocal scale factor and BOTH branch matrices.  The compiler cannot express that (its
+// s_waitcnt insertion has to assume the worst path of the kind-dependent branches and drains the queue every iteration:
+// measured 64 % of wave cycles parked, profiles/r02_*), therefore every vector-memory instruction of the loop is inline
+// assembly with a FIXED count per stage — loads a micro-operation does not need are issued with EXEC = 0, which costs
+// nothing and still counts in vmcnt (tools/walk_probe.hip checks that on the box) — and the one wait is an exact
+// "s_waitcnt vmcnt(9)": the 2 stores of k-1 and the 7 loads of k+1 may still be outstanding, the 7 loads of k may not.
+//
+// Branch matrices are wave-uniform (one category per wave).  A matrix lives in ONE 64-bit VGPR, lane l holding entry
+// l & 15 (one 8-byte load per lane, 128 B per wave), and the 4x4 mat-vec is 16 x v_fmac_f64_dpp row_newbcast:n (DPP64:
+// every lane multiplies by lane n of its 16-lane row) — no SGPRs, no LDS, no scalar loads, full fp64 rate
+// (tools/walk_probe.hip).  A compact tip child picks column `state` of the same register with ds_bpermute (crossbar
+// only, no LDS storage).
 // Rescaling in write mode needs the per-pattern maximum over all categories: the C waves exchange their maxima
 // through 2 x C x 64 doubles of LDS and one barrier (double-buffered); read mode multiplies by the stored reciprocal.
 //
@@ -26,22 +39,86 @@
 namespace mi355 {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
 #define MI355_CONST __attribute__((address_space(4)))
 
-__device__ __forceinline__ v4d ldg4(const void* base, size_t elemOff) {
-    return *gptr(reinterpret_cast<const v4d*>(reinterpret_cast<const double*>(base) + elemOff));
+// what a micro-operation needs from memory; two of these ping-pong (one being consumed, one in flight)
+struct Fetched {
+    v2d xa, xb;          // first child's partials (WF_X)
+    unsigned s1, s2;     // tip states of the two children (WF_T1 / WF_T2)
+    double inv;          // reciprocal scale factor (WF_INV)
+    double sp1, sp2;     // the two branch matrices, lane l = entry l & 15
+};
+
+struct Desc {            // a WalkOp in SGPRs
+    u64 src1, src2, store, scale, m1, m2;
+    unsigned flags;
+};
+__device__ __forceinline__ Desc unpack(const u32x16 d) {
+    Desc r;
+    r.src1 = ((u64)d.s1 << 32) | d.s0; r.src2 = ((u64)d.s3 << 32) | d.s2; r.store = ((u64)d.s5 << 32) | d.s4;
+    r.scale = ((u64)d.s7 << 32) | d.s6; r.m1 = ((u64)d.s9 << 32) | d.s8; r.m2 = ((u64)d.sb << 32) | d.sa;
+    r.flags = d.sc;
+    return r;
 }
 
-// y = M x with the (wave-uniform) matrix read through the scalar cache; the element order of every sum is the one
-// NucleotideLikelihoodCore uses (j = 0..3), shared by every path of this file so that a value is bitwise the same
-// whichever micro-operation produced it
-__device__ __forceinline__ v4d matvec4s(const double MI355_CONST* __restrict__ m, v4d x) {
-    v4d y;      // explicit FMA chains: the rounding sequence is fixed by the source, not by the optimiser
-    y.x = __builtin_fma(m[3], x.w, __builtin_fma(m[2], x.z, __builtin_fma(m[1], x.y, m[0] * x.x)));
-    y.y = __builtin_fma(m[7], x.w, __builtin_fma(m[6], x.z, __builtin_fma(m[5], x.y, m[4] * x.x)));
-    y.z = __builtin_fma(m[11], x.w, __builtin_fma(m[10], x.z, __builtin_fma(m[9], x.y, m[8] * x.x)));
-    y.w = __builtin_fma(m[15], x.w, __builtin_fma(m[14], x.z, __builtin_fma(m[13], x.y, m[12] * x.x)));
-    return y;
+// issue the 7 loads of one micro-operation (always 7 instructions; the ones it does not need run with EXEC = 0)
+__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, unsigned oPart, unsigned oTip, unsigned oScale, unsigned oMat) {
+    const u64 mx = (d.flags & WF_X) ? ~0ull : 0ull, mt1 = (d.flags & WF_T1) ? ~0ull : 0ull;
+    const u64 mt2 = (d.flags & WF_T2) ? ~0ull : 0ull, mi = (d.flags & WF_INV) ? ~0ull : 0ull;
+    asm volatile(
+        "s_mov_b64 exec, %[mx]\n\t"
+        "global_load_dwordx4 %[xa], %[oP], %[src1]\n\t"
+        "global_load_dwordx4 %[xb], %[oP], %[src1] offset:16\n\t"
+        "s_mov_b64 exec, %[mt1]\n\t"
+        "global_load_ubyte %[s1], %[oT], %[src1]\n\t"
+        "s_mov_b64 exec, %[mt2]\n\t"
+        "global_load_ubyte %[s2], %[oT], %[src2]\n\t"
+        "s_mov_b64 exec, %[mi]\n\t"
+        "global_load_dwordx2 %[inv], %[oS], %[scale]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "global_load_dwordx2 %[sp1], %[oM], %[m1]\n\t"
+        "global_load_dwordx2 %[sp2], %[oM], %[m2]"
+        : [xa] "=&v"(f.xa), [xb] "=&v"(f.xb), [s1] "=&v"(f.s1), [s2] "=&v"(f.s2), [inv] "=&v"(f.inv), [sp1] "=&v"(f.sp1), [sp2] "=&v"(f.sp2)
+        : [mx] "s"(mx), [mt1] "s"(mt1), [mt2] "s"(mt2), [mi] "s"(mi), [oP] "v"(oPart), [oT] "v"(oTip), [oS] "v"(oScale), [oM] "v"(oMat),
+          [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [m1] "s"(d.m1), [m2] "s"(d.m2)
+        : "memory");
+}
+// the loads of `f` have landed once at most 9 younger vector-memory instructions are outstanding (file header)
+__device__ __forceinline__ void fetchWait(Fetched& f) {
+    asm volatile("s_waitcnt vmcnt(9)" : "+v"(f.xa), "+v"(f.xb), "+v"(f.s1), "+v"(f.s2), "+v"(f.inv), "+v"(f.sp1), "+v"(f.sp2) : : "memory");
+}
+// the 2 stores of one micro-operation (always 2 instructions; EXEC = the lanes that really store)
+__device__ __forceinline__ void storeIssue(const v4d r, u64 mask, unsigned oPart, u64 base) {
+    const v2d lo = v2d{r.x, r.y}, hi = v2d{r.z, r.w};
+    asm volatile(
+        "s_mov_b64 exec, %[m]\n\t"
+        "global_store_dwordx4 %[oP], %[lo], %[base]\n\t"
+        "global_store_dwordx4 %[oP], %[hi], %[base] offset:16\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_nop 0"
+        : : [m] "s"(mask), [oP] "v"(oPart), [lo] "v"(lo), [hi] "v"(hi), [base] "s"(base) : "memory");
+}
+
+// y = M x with M spread over the lanes of `sp` (lane l = entry l & 15, row-major).  The rounding sequence is fixed:
+// y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0)))) — the element order NucleotideLikelihoodCore uses.
+__device__ __forceinline__ v4d matvecDpp(const double sp, const v4d x) {
+    double y0, y1, y2, y3;
+    const double x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+#define FM(Y, N, X) "v_fmac_f64_dpp %[" #Y "], %[sp], %[" #X "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile(
+        "v_mov_b64 %[y0], 0\n\tv_mov_b64 %[y1], 0\n\tv_mov_b64 %[y2], 0\n\tv_mov_b64 %[y3], 0\n\t"
+        FM(y0, 0, x0) FM(y1, 4, x0) FM(y2, 8, x0) FM(y3, 12, x0)
+        FM(y0, 1, x1) FM(y1, 5, x1) FM(y2, 9, x1) FM(y3, 13, x1)
+        FM(y0, 2, x2) FM(y1, 6, x2) FM(y2, 10, x2) FM(y3, 14, x2)
+        FM(y0, 3, x3) FM(y1, 7, x3) FM(y2, 11, x3) FM(y3, 15, x3)
+        "s_nop 0"
+        : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3)
+        : [sp] "v"(sp), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3));
+#undef FM
+    return v4d{y0, y1, y2, y3};
 }
 
 __device__ __forceinline__ double bperm(double v, int byteAddr) {
@@ -49,28 +126,20 @@ __device__ __forceinline__ double bperm(double v, int byteAddr) {
     const int hi = __builtin_amdgcn_ds_bpermute(byteAddr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// column `s` of the matrix spread over lanes 0..15 (lane 16.. = 1.0): y[i] = M[i][s], or 1 for a missing state (s >= 4)
-__device__ __forceinline__ v4d column4(double spread, int s) {
-    const int base = s < 4 ? s * 4 : 64;            // byte address of lane s (or lane 16)
-    const int step = s < 4 ? 16 : 0;                // next row = 4 lanes further
+// column `s` of the spread matrix: y[i] = M[i][s] = lane 4i + s, or 1 for a missing state (s >= 4)
+__device__ __forceinline__ v4d column4(double sp, unsigned s) {
+    const int base = (int)(s & 3u) * 4;
+    const bool known = s < 4u;
     v4d y;
-    y.x = bperm(spread, base);
-    y.y = bperm(spread, base + step);
-    y.z = bperm(spread, base + 2 * step);
-    y.w = bperm(spread, base + 3 * step);
+    y.x = bperm(sp, base); y.y = bperm(sp, base + 16); y.z = bperm(sp, base + 32); y.w = bperm(sp, base + 48);
+    y.x = known ? y.x : 1.0; y.y = known ? y.y : 1.0; y.z = known ? y.z : 1.0; y.w = known ? y.w : 1.0;
     return y;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ const void* mkptr(unsigned lo, unsigned hi) { return (const void*)(((unsigned long long)hi << 32) | lo); }
-
-// LDS of one workgroup: two hold slots per thread (a v4d as two 16-byte halves, each half contiguous over the lanes of
-// a wave: conflict-free ds_read/write_b128) and the write-mode exchange area
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_walk4(const u32x4 MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
-                                                const double* __restrict__ matrices, int P, int C, long recipOff) {
+// MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header)
+template <int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void k_walk4(const u32x16 MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
+                                                      int P, int C, long recipOff) {
     extern __shared__ v2d lds[];                      // hold[2][C][2][64] (v2d), then exch[2][C][64] (double)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
@@ -80,90 +149,94 @@ __global__ __launch_bounds__(MAXT) void k_walk4(const u32x4 MI355_CONST* __restr
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool valid = p0 + lane < pEnd;
     const int p = valid ? p0 + lane : pEnd - 1;       // lanes past the end recompute the last pattern and store nothing
-    const size_t off = ((size_t)c * P + p) * 4;
-    const double MI355_CONST* mats = (const double MI355_CONST*)matrices + (size_t)c * 16;
-    const double* matsG = matrices + (size_t)c * 16 + (lane & 15);
+    const u64 validMask = __ballot(valid);
+    // loop-invariant 32-bit byte offsets: every address of the loop is (64-bit SGPR base from the descriptor) + one of these
+    const unsigned oPart = (unsigned)(((size_t)c * P + p) * 32), oTip = (unsigned)p, oScale = (unsigned)p * 8u;
+    const unsigned oMat = (unsigned)(c * 128 + (lane & 15) * 8);
     v2d* holdBase = lds + (size_t)c * 128 + lane;     // + slot * C * 128 (+ 64 for the second half)
     double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 128);
     int buf = 0;
 
     v4d ACC = v4d{1.0, 1.0, 1.0, 1.0};
-    const u32x4 MI355_CONST* dp = prog + (size_t)progStart * 3;
-    u32x4 n0 = dp[0], n1 = dp[1], n2 = dp[2];         // descriptor of the first micro-operation
-    for (int k = 0; k < progCount; k++) {
-        const u32x4 d0 = n0, d1 = n1, d2 = n2;
-        dp += 3;
-        if (k + 1 < progCount) { n0 = dp[0]; n1 = dp[1]; n2 = dp[2]; }     // next descriptor: in flight during this one
-        const unsigned fl = d2.z;
-        const int k1 = fl & 7, k2 = (fl >> 3) & 7, hold = (fl >> 6) & 3, smode = (fl >> 8) & 3;
-        const unsigned mat1 = d2.x, mat2 = d2.y;            // element offsets of the two matrices (category 0)
-        const void* src1 = mkptr(d0.z, d0.w);
-        const void* src2 = mkptr(d1.x, d1.y);
-        double* scale = (double*)mkptr(d1.z, d1.w);
-        double* store = (double*)mkptr(d0.x, d0.y);
+    const u32x16 MI355_CONST* dp = prog + progStart;  // the host pads every segment: progCount is even and two more
+    u32x16 D0 = dp[0], D1 = dp[1];                     // descriptors (no-ops) follow it, so k + 2 is always readable
+    Fetched A, B;
+    fetchIssue(A, unpack(D0), oPart, oTip, oScale, oMat);
+    storeIssue(ACC, 0ull, oPart, 0ull);               // two masked-off stores: the queue now looks as in steady state
 
-        // ---- everything that comes from memory is requested first
-        v4d x1, x2;
-        int s1 = 4, s2 = 4;
-        double spread1 = 1.0, spread2 = 1.0, inv = 1.0;
-        if (k1 == WK_MEM) x1 = ldg4(src1, off);
-        else if (k1 == WK_TIPS) {
-            s1 = gptr(reinterpret_cast<const uint8_t*>(src1))[p];
-            spread1 = gptr(matsG + mat1)[0];
-        } else {                                       // WK_H0 / WK_H1: the thread's own hold slot
-            const v2d* h = holdBase + (size_t)(k1 - WK_H0) * C * 128;
-            const v2d lo = h[0], hi = h[64];
-            x1 = v4d{lo.x, lo.y, hi.x, hi.y};
-        }
-        if (k2 == WK_MEM) x2 = ldg4(src2, off);
-        else if (k2 == WK_TIPS) {
-            s2 = gptr(reinterpret_cast<const uint8_t*>(src2))[p];
-            spread2 = gptr(matsG + mat2)[0];
-        }
-        if (smode == WS_READ) inv = gptr(scale)[recipOff + p];
-
-        // ---- the two child factors
-        v4d f1, f2;
-        if (k1 == WK_TIPS) f1 = column4(lane < 16 ? spread1 : 1.0, s1);
-        else f1 = matvec4s(mats + mat1, x1);
-        if (k2 == WK_TIPS) f2 = column4(lane < 16 ? spread2 : 1.0, s2);
-        else if (k2 == WK_MEM) f2 = matvec4s(mats + mat2, x2);
-        else f2 = matvec4s(mats + mat2, ACC);
-        v4d r = f1 * f2;
-        if (smode == WS_READ) r = r * inv;
-        else if (smode == WS_WRITE) {
-            double m = fmax(fmax(fmax(0.0, r.x), fmax(r.y, r.z)), r.w);
-            double* e = exch + (size_t)buf * C * 64;
-            e[c * 64 + lane] = m;
-            __syncthreads();
-            m = 0.0;
-            for (int cc = 0; cc < C; cc++) m = fmax(m, e[cc * 64 + lane]);
-            buf ^= 1;
-            if (!(m > 0.0)) m = 1.0;
-            const double im = 1.0 / m;
-            r = r * im;
-            if (c == 0 && valid) { gptr(scale)[p] = m; gptr(scale)[recipOff + p] = im; }
-        }
-        if (store != nullptr && valid) *gptr(reinterpret_cast<v4d*>(store + off)) = r;
-        if (hold) {                                    // this value waits for its sibling's subtree
-            v2d* h = holdBase + (size_t)(hold - 1) * C * 128;
-            h[0] = v2d{r.x, r.y}; h[64] = v2d{r.z, r.w};
-        }
-        ACC = r;
+    // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
+#define WALK_STAGE(CUR, NXT, DCUR, DNXT)                                                                                  \
+    {                                                                                                                     \
+        const Desc d = unpack(DCUR);                   /* the few fields the compute stage needs stay in SGPRs ... */      \
+        DCUR = dp[2];                                  /* ... the rest is replaced by descriptor k + 2 (used two stages on) */ \
+        fetchIssue(NXT, unpack(DNXT), oPart, oTip, oScale, oMat);                                                         \
+        dp += 1;                                                                                                          \
+        const unsigned fl = d.flags;                                                                                      \
+        const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
+        fetchWait(CUR);                                                                                                   \
+        v4d f1, f2;                                                                                                       \
+        if (k1 == WK_TIPS) f1 = column4(CUR.sp1, CUR.s1);                                                                 \
+        else {                                                                                                            \
+            v4d x;                                                                                                        \
+            if (k1 == WK_MEM) x = v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y};                                            \
+            else {                                     /* WK_H0 / WK_H1: the thread's own hold slot */                    \
+                const v2d* h = holdBase + (size_t)(k1 - WK_H0) * C * 128;                                                 \
+                const v2d lo = h[0], hi = h[64];                                                                          \
+                x = v4d{lo.x, lo.y, hi.x, hi.y};                                                                          \
+            }                                                                                                             \
+            f1 = matvecDpp(CUR.sp1, x);                                                                                   \
+        }                                                                                                                 \
+        if (k2 == WK_TIPS) f2 = column4(CUR.sp2, CUR.s2);                                                                 \
+        else if (k2 == WK_ACC) f2 = matvecDpp(CUR.sp2, ACC);                                                              \
+        else {                                         /* both children in memory (rare): the second one is not prefetched */ \
+            v2d ya, yb;                                                                                                   \
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16\n\ts_waitcnt vmcnt(0)"  \
+                         : "=&v"(ya), "=&v"(yb) : "v"(oPart), "s"(d.src2) : "memory");                                    \
+            f2 = matvecDpp(CUR.sp2, v4d{ya.x, ya.y, yb.x, yb.y});                                                         \
+        }                                                                                                                 \
+        v4d r = f1 * f2;                                                                                                  \
+        if (smode == WS_READ) r = r * CUR.inv;                                                                            \
+        else if (smode == WS_WRITE) {                                                                                     \
+            double m = fmax(fmax(fmax(0.0, r.x), fmax(r.y, r.z)), r.w);                                                   \
+            double* e = exch + (size_t)buf * C * 64;                                                                      \
+            e[c * 64 + lane] = m;                                                                                         \
+            __syncthreads();                                                                                              \
+            m = 0.0;                                                                                                      \
+            for (int cc = 0; cc < C; cc++) m = fmax(m, e[cc * 64 + lane]);                                                \
+            buf ^= 1;                                                                                                     \
+            if (!(m > 0.0)) m = 1.0;                                                                                      \
+            const double im = 1.0 / m;                                                                                    \
+            r = r * im;                                                                                                   \
+            const u64 wm = c == 0 ? validMask : 0ull;  /* category 0 stores the factor and its reciprocal; then drain */  \
+            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %3, %5\n\tglobal_store_dwordx2 %2, %4, %5\n\t"   \
+                         "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                       \
+                         : : "s"(wm), "v"(oScale), "v"(oScale + (unsigned)recipOff * 8u), "v"(m), "v"(im), "s"(d.scale) : "memory"); \
+        }                                                                                                                 \
+        storeIssue(r, (fl & WF_STORE) ? validMask : 0ull, oPart, d.store);                                                \
+        if (hold) {                                    /* this value waits for its sibling's subtree */                   \
+            v2d* h = holdBase + (size_t)(hold - 1) * C * 128;                                                             \
+            h[0] = v2d{r.x, r.y}; h[64] = v2d{r.z, r.w};                                                                  \
+        }                                                                                                                 \
+        ACC = r;                                                                                                          \
     }
+
+    for (int k = 0; k < progCount; k += 2) {
+        WALK_STAGE(A, B, D0, D1)
+        WALK_STAGE(B, A, D1, D0)
+    }
+#undef WALK_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange,
-                 const double* matrices, int P, int C, long recipOff) {
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     const dim3 grid((maxRange + 63) / 64, nSegs), block(64 * C);
     const size_t lds = (size_t)2 * C * 128 * sizeof(v2d) + (size_t)2 * C * 64 * sizeof(double);
-    if (C <= 4)
-        hipLaunchKernelGGL((k_walk4<256>), grid, block, lds, stream, (const u32x4 MI355_CONST*)dProg, (const WalkSeg MI355_CONST*)dSegs,
-                           matrices, P, C, recipOff);
-    else
-        hipLaunchKernelGGL((k_walk4<1024>), grid, block, lds, stream, (const u32x4 MI355_CONST*)dProg, (const WalkSeg MI355_CONST*)dSegs,
-                           matrices, P, C, recipOff);
+    const u32x16 MI355_CONST* prog = (const u32x16 MI355_CONST*)dProg;
+    const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
+    if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 7>), grid, block, lds, stream, prog, segs, P, C, recipOff);
+    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 6>), grid, block, lds, stream, prog, segs, P, C, recipOff);
+    else hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
 }
 
 }  // namespace mi355

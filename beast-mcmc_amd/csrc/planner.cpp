@@ -210,7 +210,8 @@ void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {
     const bool e0 = ch[0].cls >= CL_VIRT, e1 = ch[1].cls >= CL_VIRT;
     MicroOp m = blankOp();
     if (!e0 && !e1) {
-        setLeaf(m, 0, ch[0]); setLeaf(m, 1, ch[1]);
+        const int firstLeaf = (ch[0].cls == CL_TIPS && ch[1].cls == CL_MEM) ? 1 : 0;      // a child in memory goes first
+        setLeaf(m, 0, ch[firstLeaf]); setLeaf(m, 1, ch[1 - firstLeaf]);
         if (ch[0].cls == CL_MEM) lastMemReads++;
         if (ch[1].cls == CL_MEM) lastMemReads++;
     } else if (e0 != e1) {

@@ -19,3 +19,10 @@ def test_planner_programs_equal_list_order_evaluation(tmp_path):
     out = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "plan_check: OK" in out.stdout
+
+
+def test_walk_kernel_isa_keeps_in_flight_registers_untouched():
+    """tools/check_walk_isa.py: the hand-pipelined kernel's in-flight load destinations are not read or written before
+    their s_waitcnt, no scratch, <= 72 VGPRs (cross-compiles gfx950 on the CPU box)."""
+    out = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_walk_isa.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

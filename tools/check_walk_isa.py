@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Static check of the hand-pipelined pattern-walk kernel (beast-mcmc_amd/csrc/kernels_walk4.hip).
+
+The kernel keeps the loads of micro-operation k+1 in flight while k computes; the loads are inline assembly, so the
+compiler's own s_waitcnt bookkeeping does not know their destination registers are pending.  That is only correct if
+NOTHING reads or writes those registers between a fetch block and the `s_waitcnt vmcnt(9)` that retires it (one stage
+later).  This script compiles the kernel to gfx950 assembly and verifies exactly that for every instantiation, plus the
+resource figures the design depends on (no scratch, <= 72 VGPRs so that 7 waves fit a SIMD).
+Exit code 0 = ok.  Runs without a GPU (hipcc cross-compiles)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "beast-mcmc_amd", "csrc", "kernels_walk4.hip")
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def all_regs(line):
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|v\d+", line):
+        out |= regs(tok)
+    return out
+
+
+def check_function(name, lines):
+    problems = []
+    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(9)" in l]
+    blocks = []
+    i = 0
+    while i < len(lines):
+        if "global_load_dwordx4" in lines[i] and any("global_load_ubyte" in x for x in lines[i:i + 8]):
+            j, dst, nload = i, set(), 0
+            while j < len(lines) and (lines[j].strip().startswith("global_load") or lines[j].strip().startswith("s_mov_b64 exec")):
+                if lines[j].strip().startswith("global_load"):
+                    dst |= regs(lines[j].split()[1].rstrip(","))
+                    nload += 1
+                j += 1
+            if nload != 7:
+                problems.append("%s: fetch block at line %d has %d loads, expected 7" % (name, i, nload))
+            blocks.append((i, j, dst))
+            i = j
+        else:
+            i += 1
+    labels = [i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l)]
+    loop_blocks = [b for b in blocks if labels and b[0] > labels[0]]
+    if len(blocks) != 3 or len(loop_blocks) != 2 or len(waits) != 2:
+        problems.append("%s: expected 1 prologue + 2 loop fetch blocks and 2 waits, found %d / %d / %d"
+                        % (name, len(blocks) - len(loop_blocks), len(loop_blocks), len(waits)))
+        return problems
+    loop_start = labels[0]
+    for (a, b, dst) in loop_blocks:
+        later = [w for w in waits if w >= b]
+        if len(later) >= 2:
+            span = list(range(b, later[1]))
+        else:        # wraps around the loop: to the end of the function text, then from the loop start
+            span = list(range(b, len(lines))) + list(range(loop_start, [w for w in waits if w > loop_start][1 - len(later)]))
+        for k in span:
+            if "s_waitcnt" not in lines[k] and all_regs(lines[k]) & dst:
+                problems.append("%s: line %d touches in-flight registers of the fetch at line %d: %s" % (name, k, a, lines[k].strip()))
+    # the prologue fetch must land in the registers the second loop block refills (no copies on the back edge)
+    if blocks[0][2] != loop_blocks[1][2]:
+        problems.append("%s: prologue fetch registers differ from the loop's second fetch block" % name)
+    for l in lines:
+        m = re.match(r"\s*s_waitcnt vmcnt\((\d+)\)", l)
+        if m and int(m.group(1)) not in (0, 9):
+            problems.append("%s: unexpected compiler-inserted wait: %s" % (name, l.strip()))
+    return problems
+
+
+def main():
+    hipcc = "/opt/rocm/bin/hipcc"
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "walk4.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip", SRC, "-o", out,
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        if r.returncode:
+            print(r.stderr)
+            return 2
+        text = open(out).read()
+        remarks = r.stderr
+    problems = []
+    vg = [int(x) for x in re.findall(r"VGPRs: (\d+)", remarks)]
+    sc = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
+    if not vg or max(vg) > 72:
+        problems.append("VGPRs %s: more than 72 (7 waves per SIMD are needed to keep a 1e5-pattern alignment resident)" % vg)
+    if any(sc):
+        problems.append("scratch in use: %s" % sc)
+    funcs = re.findall(r"^(_ZN5mi3557k_walk4[^:\n]*):\s*;.*?\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    if len(funcs) < 3:
+        problems.append("found %d kernel instantiations, expected 3" % len(funcs))
+    for name, body in funcs:
+        lines = [l for l in body.split("\n") if not l.strip().startswith(";")]
+        problems += check_function(name[:40], lines)
+    for p in problems:
+        print("PROBLEM:", p)
+    print("walk kernel ISA check: %s (VGPRs %s, %d instantiations)" % ("FAILED" if problems else "ok", vg, len(funcs)))
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
