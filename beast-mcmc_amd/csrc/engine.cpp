@@ -337,6 +337,12 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         if (ps.progCount & 1) w.push_back(nop);
         segs[si].progCount = (int)w.size() - segs[si].progStart;
         w.push_back(nop); w.push_back(nop);
+        // the wait of every stage: "at most N vector-memory instructions outstanding" with N = the LOADS younger than the
+        // stage's own (those of the next micro-operation).  Loads return in order among themselves, but loads and stores
+        // share the counter and may complete out of order with each other, so the stores of the previous stage are NOT
+        // counted: if they are still pending the wait is merely longer than necessary, never too short.
+        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++)
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags), 12));
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }

@@ -52,7 +52,7 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
     double*        scale;    // WS_READ: the RECIPROCAL half of the scale buffer;  WS_WRITE: the buffer (factor half first)
     const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles)
     const double*  m2;
-    unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13
+    unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13 | waitJump << 16 (walkWaitJump)
     unsigned       pad0;
     unsigned long long pad1;
 };
@@ -66,6 +66,11 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     if (store) f |= WF_STORE;
     return f;
 }
+// vector-memory instructions the kernel's fetch stage issues for a micro-operation / its store stage
+inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 2 : 0) + ((f & WF_T1) ? 1 : 0) + ((f & WF_T2) ? 1 : 0) + ((f & WF_INV) ? 1 : 0) + 2; }
+inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 2 : 0; }
+// flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine.cpp runPlan, kernels_walk4.hip)
+inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
 // software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
 struct WalkSeg { int progStart, progCount, pStart, pEnd; };

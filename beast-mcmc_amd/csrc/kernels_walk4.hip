@@ -20,9 +20,12 @@
 // lane), tip-state bytes, reciprocal scale factor and BOTH branch matrices.  The compiler cannot express that (its
 // s_waitcnt insertion has to assume the worst path of the kind-dependent branches and drains the queue every iteration:
 // measured 64 % of wave cycles parked, profiles/r02_*), therefore every vector-memory instruction of the loop is inline
-// assembly with a FIXED count per stage — loads a micro-operation does not need are issued with EXEC = 0, which costs
-// nothing and still counts in vmcnt (tools/walk_probe.hip checks that on the box) — and the one wait is an exact
-// "s_waitcnt vmcnt(9)": the 2 stores of k-1 and the 7 loads of k+1 may still be outstanding, the 7 loads of k may not.
+// assembly, and the one wait per stage is EXACT: "s_waitcnt vmcnt(N)" with N = the number of vector-memory instructions
+// issued after the loads of micro-operation k (the stores of k-1 and the loads of k+1), which the host knows when it
+// builds the program and passes in the descriptor; the kernel jumps into a table of s_waitcnt instructions.
+// Loads a micro-operation does not need are BRANCHED around, not masked: on this chip a vector-memory instruction with 8
+// or 16 bytes per lane occupies the CU's address unit for ~16 cycles whatever its EXEC mask or coalescing, a byte load
+// for ~4 (tools/vmem_rate_probe.hip) — with 24 waves per CU that unit, not HBM, is the first thing to saturate.
 //
 // Branch matrices are wave-uniform (one category per wave).  A matrix lives in ONE 64-bit VGPR, lane l holding entry
 // l & 15 (one 8-byte load per lane, 128 B per wave), and the 4x4 mat-vec is 16 x v_fmac_f64_dpp row_newbcast:n (DPP64:
@@ -64,42 +67,72 @@ __device__ __forceinline__ Desc unpack(const u32x16 d) {
     return r;
 }
 
-// issue the 7 loads of one micro-operation (always 7 instructions; the ones it does not need run with EXEC = 0)
+// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the two matrices
 __device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, unsigned oPart, unsigned oTip, unsigned oScale, unsigned oMat) {
-    const u64 mx = (d.flags & WF_X) ? ~0ull : 0ull, mt1 = (d.flags & WF_T1) ? ~0ull : 0ull;
-    const u64 mt2 = (d.flags & WF_T2) ? ~0ull : 0ull, mi = (d.flags & WF_INV) ? ~0ull : 0ull;
     asm volatile(
-        "s_mov_b64 exec, %[mx]\n\t"
+        "s_bitcmp1_b32 %[fl], 0\n\t"
+        "s_cbranch_scc0 .Lfx%=\n\t"
         "global_load_dwordx4 %[xa], %[oP], %[src1]\n\t"
-        "global_load_dwordx4 %[xb], %[oP], %[src1] offset:16\n\t"
-        "s_mov_b64 exec, %[mt1]\n\t"
-        "global_load_ubyte %[s1], %[oT], %[src1]\n\t"
-        "s_mov_b64 exec, %[mt2]\n\t"
-        "global_load_ubyte %[s2], %[oT], %[src2]\n\t"
-        "s_mov_b64 exec, %[mi]\n\t"
-        "global_load_dwordx2 %[inv], %[oS], %[scale]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "global_load_dwordx4 %[xb], %[oP], %[src1] offset:16\n"
+        ".Lfx%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 1\n\t"
+        "s_cbranch_scc0 .Lft1%=\n\t"
+        "global_load_ubyte %[s1], %[oT], %[src1]\n"
+        ".Lft1%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 2\n\t"
+        "s_cbranch_scc0 .Lft2%=\n\t"
+        "global_load_ubyte %[s2], %[oT], %[src2]\n"
+        ".Lft2%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 3\n\t"
+        "s_cbranch_scc0 .Lfi%=\n\t"
+        "global_load_dwordx2 %[inv], %[oS], %[scale]\n"
+        ".Lfi%=:\n\t"
         "global_load_dwordx2 %[sp1], %[oM], %[m1]\n\t"
         "global_load_dwordx2 %[sp2], %[oM], %[m2]"
         : [xa] "=&v"(f.xa), [xb] "=&v"(f.xb), [s1] "=&v"(f.s1), [s2] "=&v"(f.s2), [inv] "=&v"(f.inv), [sp1] "=&v"(f.sp1), [sp2] "=&v"(f.sp2)
-        : [mx] "s"(mx), [mt1] "s"(mt1), [mt2] "s"(mt2), [mi] "s"(mi), [oP] "v"(oPart), [oT] "v"(oTip), [oS] "v"(oScale), [oM] "v"(oMat),
+        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oS] "v"(oScale), [oM] "v"(oMat),
           [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [m1] "s"(d.m1), [m2] "s"(d.m2)
-        : "memory");
+        : "memory", "scc");
 }
-// the loads of `f` have landed once at most 9 younger vector-memory instructions are outstanding (file header)
-__device__ __forceinline__ void fetchWait(Fetched& f) {
-    asm volatile("s_waitcnt vmcnt(9)" : "+v"(f.xa), "+v"(f.xb), "+v"(f.s1), "+v"(f.s2), "+v"(f.inv), "+v"(f.sp1), "+v"(f.sp2) : : "memory");
+// The loads of `f` have landed once at most N younger vector-memory instructions are outstanding; jump = 8 N + 12 is the
+// byte offset of "s_waitcnt vmcnt(N)" in the table below, counted from the instruction after s_getpc_b64 (every
+// instruction here is 4 bytes; an entry is a wait and a branch).
+__device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
+    asm volatile(
+        "s_getpc_b64 s[80:81]\n\t"
+        "s_add_u32 s80, s80, %[jump]\n\t"
+        "s_addc_u32 s81, s81, 0\n\t"
+        "s_setpc_b64 s[80:81]\n\t"
+        "s_waitcnt vmcnt(0)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(1)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(2)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(3)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(4)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(5)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(6)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(7)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(8)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(9)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(10)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(11)\n\ts_branch .Lwd%=\n\t"
+        "s_waitcnt vmcnt(12)\n"
+        ".Lwd%=:"
+        : "+v"(f.xa), "+v"(f.xb), "+v"(f.s1), "+v"(f.s2), "+v"(f.inv), "+v"(f.sp1), "+v"(f.sp2)
+        : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
-// the 2 stores of one micro-operation (always 2 instructions; EXEC = the lanes that really store)
-__device__ __forceinline__ void storeIssue(const v4d r, u64 mask, unsigned oPart, u64 base) {
+// the stores of one micro-operation (`mask` = the lanes that really store; nothing is issued when it has no destination)
+__device__ __forceinline__ void storeIssue(const v4d r, unsigned flags, u64 mask, unsigned oPart, u64 base) {
     const v2d lo = v2d{r.x, r.y}, hi = v2d{r.z, r.w};
     asm volatile(
+        "s_bitcmp1_b32 %[fl], 4\n\t"
+        "s_cbranch_scc0 .Lst%=\n\t"
         "s_mov_b64 exec, %[m]\n\t"
-        "global_store_dwordx4 %[oP], %[lo], %[base]\n\t"
-        "global_store_dwordx4 %[oP], %[hi], %[base] offset:16\n\t"
+        "global_store_dwordx4 %[oP], %[lo], %[base] nt\n\t"
+        "global_store_dwordx4 %[oP], %[hi], %[base] offset:16 nt\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_nop 0"
-        : : [m] "s"(mask), [oP] "v"(oPart), [lo] "v"(lo), [hi] "v"(hi), [base] "s"(base) : "memory");
+        "s_nop 0\n"
+        ".Lst%=:"
+        : : [fl] "s"(flags), [m] "s"(mask), [oP] "v"(oPart), [lo] "v"(lo), [hi] "v"(hi), [base] "s"(base) : "memory", "scc");
 }
 
 // y = M x with M spread over the lanes of `sp` (lane l = entry l & 15, row-major).  The rounding sequence is fixed:
@@ -162,37 +195,40 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const u32x16 MI355_CONST* 
     u32x16 D0 = dp[0], D1 = dp[1];                     // descriptors (no-ops) follow it, so k + 2 is always readable
     Fetched A, B;
     fetchIssue(A, unpack(D0), oPart, oTip, oScale, oMat);
-    storeIssue(ACC, 0ull, oPart, 0ull);               // two masked-off stores: the queue now looks as in steady state
 
-    // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
+    // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one.
+    // The few descriptor fields the compute stage needs are moved out of DCUR first (explicit s_mov: the register
+    // allocator then lets descriptor k + 2 land in DCUR's own registers instead of rotating 16 SGPRs per stage).
 #define WALK_STAGE(CUR, NXT, DCUR, DNXT)                                                                                  \
     {                                                                                                                     \
-        const Desc d = unpack(DCUR);                   /* the few fields the compute stage needs stay in SGPRs ... */      \
-        DCUR = dp[2];                                  /* ... the rest is replaced by descriptor k + 2 (used two stages on) */ \
+        unsigned fl; u64 dStore, dScale, dSrc2;                                                                           \
+        asm volatile("s_mov_b32 %0, %4\n\ts_mov_b64 %1, %5\n\ts_mov_b64 %2, %6\n\ts_mov_b64 %3, %7"                     \
+                     : "=&s"(fl), "=&s"(dStore), "=&s"(dScale), "=&s"(dSrc2)                                              \
+                     : "s"(DCUR.sc), "s"(((u64)DCUR.s5 << 32) | DCUR.s4), "s"(((u64)DCUR.s7 << 32) | DCUR.s6),            \
+                       "s"(((u64)DCUR.s3 << 32) | DCUR.s2));                                                              \
+        DCUR = dp[2];                                  /* descriptor k + 2 (used two stages on) */                        \
         fetchIssue(NXT, unpack(DNXT), oPart, oTip, oScale, oMat);                                                         \
         dp += 1;                                                                                                          \
-        const unsigned fl = d.flags;                                                                                      \
-        const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
-        fetchWait(CUR);                                                                                                   \
+        const int shape = (fl >> 5) & 63, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                                  \
+        fetchWait(CUR, (fl >> 16) & 0xffu);            /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
         v4d f1, f2;                                                                                                       \
-        if (k1 == WK_TIPS) f1 = column4(CUR.sp1, CUR.s1);                                                                 \
-        else {                                                                                                            \
-            v4d x;                                                                                                        \
-            if (k1 == WK_MEM) x = v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y};                                            \
-            else {                                     /* WK_H0 / WK_H1: the thread's own hold slot */                    \
-                const v2d* h = holdBase + (size_t)(k1 - WK_H0) * C * 128;                                                 \
+        switch (shape) {                                                                                                  \
+            case WK_TIPS | (WK_TIPS << 3): f1 = column4(CUR.sp1, CUR.s1); f2 = column4(CUR.sp2, CUR.s2); break;           \
+            case WK_TIPS | (WK_ACC << 3):  f1 = column4(CUR.sp1, CUR.s1); f2 = matvecDpp(CUR.sp2, ACC); break;            \
+            case WK_MEM | (WK_ACC << 3):   f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});          \
+                                           f2 = matvecDpp(CUR.sp2, ACC); break;                                           \
+            case WK_MEM | (WK_TIPS << 3):  f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});          \
+                                           f2 = column4(CUR.sp2, CUR.s2); break;                                          \
+            case WK_H0 | (WK_ACC << 3): case WK_H1 | (WK_ACC << 3): {        /* the thread's own hold slot */             \
+                const v2d* h = holdBase + (size_t)((shape & 7) - WK_H0) * C * 128;                                        \
                 const v2d lo = h[0], hi = h[64];                                                                          \
-                x = v4d{lo.x, lo.y, hi.x, hi.y};                                                                          \
-            }                                                                                                             \
-            f1 = matvecDpp(CUR.sp1, x);                                                                                   \
-        }                                                                                                                 \
-        if (k2 == WK_TIPS) f2 = column4(CUR.sp2, CUR.s2);                                                                 \
-        else if (k2 == WK_ACC) f2 = matvecDpp(CUR.sp2, ACC);                                                              \
-        else {                                         /* both children in memory (rare): the second one is not prefetched */ \
-            v2d ya, yb;                                                                                                   \
-            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16\n\ts_waitcnt vmcnt(0)"  \
-                         : "=&v"(ya), "=&v"(yb) : "v"(oPart), "s"(d.src2) : "memory");                                    \
-            f2 = matvecDpp(CUR.sp2, v4d{ya.x, ya.y, yb.x, yb.y});                                                         \
+                f1 = matvecDpp(CUR.sp1, v4d{lo.x, lo.y, hi.x, hi.y}); f2 = matvecDpp(CUR.sp2, ACC); break; }              \
+            default: {                                 /* both children in memory (rare): the second one is not prefetched */ \
+                v2d ya, yb;                                                                                               \
+                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16\n\ts_waitcnt vmcnt(0)" \
+                             : "=&v"(ya), "=&v"(yb) : "v"(oPart), "s"(dSrc2) : "memory");                                 \
+                f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});                                     \
+                f2 = matvecDpp(CUR.sp2, v4d{ya.x, ya.y, yb.x, yb.y}); break; }                                            \
         }                                                                                                                 \
         v4d r = f1 * f2;                                                                                                  \
         if (smode == WS_READ) r = r * CUR.inv;                                                                            \
@@ -210,9 +246,9 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const u32x16 MI355_CONST* 
             const u64 wm = c == 0 ? validMask : 0ull;  /* category 0 stores the factor and its reciprocal; then drain */  \
             asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %3, %5\n\tglobal_store_dwordx2 %2, %4, %5\n\t"   \
                          "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                       \
-                         : : "s"(wm), "v"(oScale), "v"(oScale + (unsigned)recipOff * 8u), "v"(m), "v"(im), "s"(d.scale) : "memory"); \
+                         : : "s"(wm), "v"(oScale), "v"(oScale + (unsigned)recipOff * 8u), "v"(m), "v"(im), "s"(dScale) : "memory"); \
         }                                                                                                                 \
-        storeIssue(r, (fl & WF_STORE) ? validMask : 0ull, oPart, d.store);                                                \
+        storeIssue(r, fl, validMask, oPart, dStore);                                                                      \
         if (hold) {                                    /* this value waits for its sibling's subtree */                   \
             v2d* h = holdBase + (size_t)(hold - 1) * C * 128;                                                             \
             h[0] = v2d{r.x, r.y}; h[64] = v2d{r.z, r.w};                                                                  \

@@ -34,19 +34,23 @@ def all_regs(line):
 
 def check_function(name, lines):
     problems = []
-    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(9)" in l]
+    waits = [i for i, l in enumerate(lines) if "s_setpc_b64" in l]          # the jump into the s_waitcnt table = the stage's wait
     blocks = []
     i = 0
     while i < len(lines):
-        if "global_load_dwordx4" in lines[i] and any("global_load_ubyte" in x for x in lines[i:i + 8]):
-            j, dst, nload = i, set(), 0
-            while j < len(lines) and (lines[j].strip().startswith("global_load") or lines[j].strip().startswith("s_mov_b64 exec")):
-                if lines[j].strip().startswith("global_load"):
-                    dst |= regs(lines[j].split()[1].rstrip(","))
-                    nload += 1
+        if re.match(r"\s*s_bitcmp1_b32 s\d+, 0$", lines[i]) and i + 1 < len(lines) and ".Lfx" in lines[i + 1]:
+            j, dst = i, set()
+            while j < len(lines):
+                t = lines[j].strip()
+                if t.startswith("global_load"):
+                    dst |= regs(t.split()[1].rstrip(","))
+                    if "v[" in t.split()[1] and t.startswith("global_load_dwordx2") and any("global_load_dwordx2" in lines[q] for q in (j + 1,)) is False and \
+                            sum(1 for q in range(i, j + 1) if lines[q].strip().startswith("global_load_dwordx2")) >= 3:
+                        j += 1
+                        break
+                elif not (t.startswith("s_bitcmp1") or t.startswith("s_cbranch_scc0") or t.startswith(".Lf")):
+                    break
                 j += 1
-            if nload != 7:
-                problems.append("%s: fetch block at line %d has %d loads, expected 7" % (name, i, nload))
             blocks.append((i, j, dst))
             i = j
         else:
@@ -57,6 +61,9 @@ def check_function(name, lines):
         problems.append("%s: expected 1 prologue + 2 loop fetch blocks and 2 waits, found %d / %d / %d"
                         % (name, len(blocks) - len(loop_blocks), len(loop_blocks), len(waits)))
         return problems
+    for (a, b, dst) in blocks:
+        if len(dst) != 16:
+            problems.append("%s: fetch block at line %d writes %d registers, expected 16" % (name, a, len(dst)))
     loop_start = labels[0]
     for (a, b, dst) in loop_blocks:
         later = [w for w in waits if w >= b]
@@ -70,10 +77,13 @@ def check_function(name, lines):
     # the prologue fetch must land in the registers the second loop block refills (no copies on the back edge)
     if blocks[0][2] != loop_blocks[1][2]:
         problems.append("%s: prologue fetch registers differ from the loop's second fetch block" % name)
-    for l in lines:
-        m = re.match(r"\s*s_waitcnt vmcnt\((\d+)\)", l)
-        if m and int(m.group(1)) not in (0, 9):
-            problems.append("%s: unexpected compiler-inserted wait: %s" % (name, l.strip()))
+    # every vmcnt wait is ours: a table entry (followed by its branch / the table end) or a full drain
+    for k, l in enumerate(lines):
+        m = re.match(r"\s*s_waitcnt vmcnt\((\d+)\)\s*$", l)
+        if m and int(m.group(1)) != 0:
+            nxt = lines[k + 1].strip() if k + 1 < len(lines) else ""
+            if not (nxt.startswith("s_branch .Lwd") or nxt.startswith(".Lwd")):
+                problems.append("%s: unexpected compiler-inserted wait at line %d: %s" % (name, k, l.strip()))
     return problems
 
 
