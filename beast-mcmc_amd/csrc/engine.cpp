@@ -183,7 +183,7 @@ int ensureScale(Instance* in, int idx) {
 
 int ensureStates(Instance* in, int idx) {
     if (in->tipStates[idx]) return 0;
-    const size_t bytes = ((size_t)in->P + 255) & ~(size_t)255;
+    const size_t bytes = ((size_t)in->P + 2 + 255) & ~(size_t)255;
     if (in->stateSlabLeft == 0) {
         const int n = std::max(1, std::min(in->compactCount, 1024));
         void* slab = nullptr;
@@ -1019,12 +1019,12 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     int maxVirtSteps = 6;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
-    in->scaleStride = ((size_t)patternCount + 31) & ~(size_t)31;
+    in->scaleStride = ((size_t)patternCount + 2 + 31) & ~(size_t)31;      // the walk kernel may read one pattern past the end
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
-    in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255) & ~(size_t)255;
+    in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255 + (in->walk ? 256 : 0)) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
     in->tipStates.assign(partialsBufferCount, nullptr);
     in->scale.assign(std::max(1, scaleBufferCount), nullptr);

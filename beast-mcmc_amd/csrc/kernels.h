@@ -67,14 +67,15 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     return f;
 }
 // vector-memory instructions the kernel's fetch stage issues for a micro-operation / its store stage
-inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 2 : 0) + ((f & WF_T1) ? 1 : 0) + ((f & WF_T2) ? 1 : 0) + ((f & WF_INV) ? 1 : 0) + 2; }
-inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 2 : 0; }
+inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? 2 : 0) + ((f & WF_T2) ? 2 : 0) + ((f & WF_INV) ? 2 : 0) + 2; }
+inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 // flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine.cpp runPlan, kernels_walk4.hip)
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
 // software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
 struct WalkSeg { int progStart, progCount, pStart, pEnd; };
-// one launch: every 64-pattern group of every segment walks its program; maxRange = max (pEnd - pStart)
+// one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
+// patterns, 64 apart.
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices

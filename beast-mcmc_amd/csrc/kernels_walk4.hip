@@ -9,10 +9,15 @@
 // the previous micro-operation is not read back from HBM, and a node whose subtree is a few compact tips ("virtual"
 // buffer) is never written at all.
 //
-// Mapping:  workgroup = 64 consecutive patterns x all C categories; wave w = category w; lane l = pattern p0 + l.
-//           A wave's loads/stores of a partials buffer ([C][P][4] doubles) are 64 x 32 B = 2 KiB contiguous.
-//           All C*P/64 waves of a 1e5-pattern alignment are resident at once (6.1 waves per SIMD at C = 4; the kernel is
-//           held to 72 VGPRs = 7 waves per SIMD for that reason: a wave walks the whole list, so a second round of
+// Mapping:  workgroup = 128 consecutive patterns x all C categories; wave w = category w; lane l owns the TWO patterns
+//           p0 + l and p0 + 64 + l, so every vector-memory instruction of a wave is dense (64 x 16 B = 1 KiB contiguous
+//           for a partials buffer [C][P][4] doubles; pairing ADJACENT patterns instead makes every access 16 B at a 64-B
+//           stride and the kernel twice as slow).  What a micro-operation costs PER WAVE whatever the lane does — ~50 scalar and
+//           branch instructions on the CU's single scalar pipe, the two matrix loads — is so shared by two patterns:
+//           measured, those per-wave costs and the address unit (~16 cycles per vector-memory instruction per CU,
+//           tools/vmem_rate_probe.hip), not HBM or the fp64 pipes, are what saturates first.
+//           All C*P/128 waves of a 1e5-pattern alignment are resident at once (3.05 waves per SIMD at C = 4; the kernel
+//           is held to 128 VGPRs = 4 waves per SIMD for that reason: a wave walks the whole list, so a second round of
 //           workgroups would double the time).
 //
 // What bounds a wave is LATENCY: it executes ~T dependent micro-operations.  So the loop is software-pipelined by hand:
@@ -43,55 +48,69 @@ namespace mi355 {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 #define MI355_CONST __attribute__((address_space(4)))
 
-// what a micro-operation needs from memory; two of these ping-pong (one being consumed, one in flight)
+// what a micro-operation needs from memory, for the lane's two patterns (a, b); two of these ping-pong (one being
+// consumed, one in flight)
 struct Fetched {
-    v2d xa, xb;          // first child's partials (WF_X)
-    unsigned s1, s2;     // tip states of the two children (WF_T1 / WF_T2)
-    double inv;          // reciprocal scale factor (WF_INV)
-    double sp1, sp2;     // the two branch matrices, lane l = entry l & 15
+    v2d xa0, xa1, xb0, xb1;   // first child's partials (WF_X) or the hold slot it comes from: pattern a, pattern b
+    unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2), pattern a / b
+    double inva, invb;        // reciprocal scale factors of the pair (WF_INV)
+    double sp1, sp2;          // the two branch matrices, lane l = entry l & 15
 };
 
-struct Desc {            // a WalkOp in SGPRs
+struct Desc {                 // a WalkOp in SGPRs (13 dwords)
     u64 src1, src2, store, scale, m1, m2;
     unsigned flags;
 };
-__device__ __forceinline__ Desc unpack(const u32x16 d) {
+// three scalar loads of exactly the dwords in use: an unused lane of a wider load would be a register the allocator
+// hands out while the load is still pending
+__device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
+    const u32x8 a = *reinterpret_cast<const u32x8 MI355_CONST*>(p);
+    const u32x4 b = *reinterpret_cast<const u32x4 MI355_CONST*>(p + 8);
     Desc r;
-    r.src1 = ((u64)d.s1 << 32) | d.s0; r.src2 = ((u64)d.s3 << 32) | d.s2; r.store = ((u64)d.s5 << 32) | d.s4;
-    r.scale = ((u64)d.s7 << 32) | d.s6; r.m1 = ((u64)d.s9 << 32) | d.s8; r.m2 = ((u64)d.sb << 32) | d.sa;
-    r.flags = d.sc;
+    r.src1 = ((u64)a.s1 << 32) | a.s0; r.src2 = ((u64)a.s3 << 32) | a.s2; r.store = ((u64)a.s5 << 32) | a.s4;
+    r.scale = ((u64)a.s7 << 32) | a.s6; r.m1 = ((u64)b.s1 << 32) | b.s0; r.m2 = ((u64)b.s3 << 32) | b.s2;
+    r.flags = p[12];
     return r;
 }
 
-// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the two matrices
-__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, unsigned oPart, unsigned oTip, unsigned oScale, unsigned oMat) {
+// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the two matrices.
+// Registers of a skipped group keep their contents (a hold-slot operand is placed in xa0..xb1 by the caller).
+struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };   // loop-invariant 32-bit byte offsets of the lane
+__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o) {
     asm volatile(
         "s_bitcmp1_b32 %[fl], 0\n\t"
         "s_cbranch_scc0 .Lfx%=\n\t"
-        "global_load_dwordx4 %[xa], %[oP], %[src1]\n\t"
-        "global_load_dwordx4 %[xb], %[oP], %[src1] offset:16\n"
+        "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
+        "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
+        "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
+        "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
         ".Lfx%=:\n\t"
         "s_bitcmp1_b32 %[fl], 1\n\t"
         "s_cbranch_scc0 .Lft1%=\n\t"
-        "global_load_ubyte %[s1], %[oT], %[src1]\n"
+        "global_load_ubyte %[s1a], %[oTA], %[src1]\n\t"
+        "global_load_ubyte %[s1b], %[oTB], %[src1]\n"
         ".Lft1%=:\n\t"
         "s_bitcmp1_b32 %[fl], 2\n\t"
         "s_cbranch_scc0 .Lft2%=\n\t"
-        "global_load_ubyte %[s2], %[oT], %[src2]\n"
+        "global_load_ubyte %[s2a], %[oTA], %[src2]\n\t"
+        "global_load_ubyte %[s2b], %[oTB], %[src2]\n"
         ".Lft2%=:\n\t"
         "s_bitcmp1_b32 %[fl], 3\n\t"
         "s_cbranch_scc0 .Lfi%=\n\t"
-        "global_load_dwordx2 %[inv], %[oS], %[scale]\n"
+        "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
+        "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
         ".Lfi%=:\n\t"
         "global_load_dwordx2 %[sp1], %[oM], %[m1]\n\t"
         "global_load_dwordx2 %[sp2], %[oM], %[m2]"
-        : [xa] "=&v"(f.xa), [xb] "=&v"(f.xb), [s1] "=&v"(f.s1), [s2] "=&v"(f.s2), [inv] "=&v"(f.inv), [sp1] "=&v"(f.sp1), [sp2] "=&v"(f.sp2)
-        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oS] "v"(oScale), [oM] "v"(oMat),
-          [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [m1] "s"(d.m1), [m2] "s"(d.m2)
+        : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
+          [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb), [sp1] "+v"(f.sp1), [sp2] "+v"(f.sp2)
+        : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
+          [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [m1] "s"(d.m1), [m2] "s"(d.m2)
         : "memory", "scc");
 }
 // The loads of `f` have landed once at most N younger vector-memory instructions are outstanding; jump = 8 N + 12 is the
@@ -117,41 +136,50 @@ __device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
         "s_waitcnt vmcnt(11)\n\ts_branch .Lwd%=\n\t"
         "s_waitcnt vmcnt(12)\n"
         ".Lwd%=:"
-        : "+v"(f.xa), "+v"(f.xb), "+v"(f.s1), "+v"(f.s2), "+v"(f.inv), "+v"(f.sp1), "+v"(f.sp2)
+        : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb),
+          "+v"(f.sp1), "+v"(f.sp2)
         : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
-// the stores of one micro-operation (`mask` = the lanes that really store; nothing is issued when it has no destination)
-__device__ __forceinline__ void storeIssue(const v4d r, unsigned flags, u64 mask, unsigned oPart, u64 base) {
-    const v2d lo = v2d{r.x, r.y}, hi = v2d{r.z, r.w};
+// the stores of one micro-operation (maskA / maskB = the lanes whose first / second pattern really stores; nothing is
+// issued when the micro-operation has no destination).  Non-temporal: the line is written once and, if at all, read
+// back by this very thread (+7 % on the headline configuration).
+__device__ __forceinline__ void storeIssue(const v4d ra, const v4d rb, unsigned flags, u64 maskA, u64 maskB, unsigned oPartA, unsigned oPartB, u64 base) {
+    const v2d a0 = v2d{ra.x, ra.y}, a1 = v2d{ra.z, ra.w}, b0 = v2d{rb.x, rb.y}, b1 = v2d{rb.z, rb.w};
     asm volatile(
         "s_bitcmp1_b32 %[fl], 4\n\t"
         "s_cbranch_scc0 .Lst%=\n\t"
-        "s_mov_b64 exec, %[m]\n\t"
-        "global_store_dwordx4 %[oP], %[lo], %[base] nt\n\t"
-        "global_store_dwordx4 %[oP], %[hi], %[base] offset:16 nt\n\t"
+        "s_mov_b64 exec, %[ma]\n\t"
+        "global_store_dwordx4 %[oPA], %[a0], %[base] nt\n\t"
+        "global_store_dwordx4 %[oPA], %[a1], %[base] offset:16 nt\n\t"
+        "s_mov_b64 exec, %[mb]\n\t"
+        "global_store_dwordx4 %[oPB], %[b0], %[base] nt\n\t"
+        "global_store_dwordx4 %[oPB], %[b1], %[base] offset:16 nt\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_nop 0\n"
         ".Lst%=:"
-        : : [fl] "s"(flags), [m] "s"(mask), [oP] "v"(oPart), [lo] "v"(lo), [hi] "v"(hi), [base] "s"(base) : "memory", "scc");
+        : : [fl] "s"(flags), [ma] "s"(maskA), [mb] "s"(maskB), [oPA] "v"(oPartA), [oPB] "v"(oPartB), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+            [base] "s"(base) : "memory", "scc");
 }
 
-// y = M x with M spread over the lanes of `sp` (lane l = entry l & 15, row-major).  The rounding sequence is fixed:
-// y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0)))) — the element order NucleotideLikelihoodCore uses.
-__device__ __forceinline__ v4d matvecDpp(const double sp, const v4d x) {
-    double y0, y1, y2, y3;
-    const double x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+// y = M x for the lane's two patterns, M spread over the lanes of `sp` (lane l = entry l & 15, row-major).  The rounding
+// sequence is fixed: y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0)))) — the element order
+// NucleotideLikelihoodCore uses.  Eight independent accumulator chains keep the fp64 pipe busy.
+__device__ __forceinline__ void matvecDpp2(const double sp, const v4d xa, const v4d xb, v4d& ya, v4d& yb) {
+    double a0, a1, a2, a3, b0, b1, b2, b3;
+    const double p0 = xa.x, p1 = xa.y, p2 = xa.z, p3 = xa.w, q0 = xb.x, q1 = xb.y, q2 = xb.z, q3 = xb.w;
 #define FM(Y, N, X) "v_fmac_f64_dpp %[" #Y "], %[sp], %[" #X "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
     asm volatile(
-        "v_mov_b64 %[y0], 0\n\tv_mov_b64 %[y1], 0\n\tv_mov_b64 %[y2], 0\n\tv_mov_b64 %[y3], 0\n\t"
-        FM(y0, 0, x0) FM(y1, 4, x0) FM(y2, 8, x0) FM(y3, 12, x0)
-        FM(y0, 1, x1) FM(y1, 5, x1) FM(y2, 9, x1) FM(y3, 13, x1)
-        FM(y0, 2, x2) FM(y1, 6, x2) FM(y2, 10, x2) FM(y3, 14, x2)
-        FM(y0, 3, x3) FM(y1, 7, x3) FM(y2, 11, x3) FM(y3, 15, x3)
+        "v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\tv_mov_b64 %[a2], 0\n\tv_mov_b64 %[a3], 0\n\t"
+        "v_mov_b64 %[b0], 0\n\tv_mov_b64 %[b1], 0\n\tv_mov_b64 %[b2], 0\n\tv_mov_b64 %[b3], 0\n\t"
+        FM(a0, 0, p0) FM(a1, 4, p0) FM(a2, 8, p0) FM(a3, 12, p0) FM(b0, 0, q0) FM(b1, 4, q0) FM(b2, 8, q0) FM(b3, 12, q0)
+        FM(a0, 1, p1) FM(a1, 5, p1) FM(a2, 9, p1) FM(a3, 13, p1) FM(b0, 1, q1) FM(b1, 5, q1) FM(b2, 9, q1) FM(b3, 13, q1)
+        FM(a0, 2, p2) FM(a1, 6, p2) FM(a2, 10, p2) FM(a3, 14, p2) FM(b0, 2, q2) FM(b1, 6, q2) FM(b2, 10, q2) FM(b3, 14, q2)
+        FM(a0, 3, p3) FM(a1, 7, p3) FM(a2, 11, p3) FM(a3, 15, p3) FM(b0, 3, q3) FM(b1, 7, q3) FM(b2, 11, q3) FM(b3, 15, q3)
         "s_nop 0"
-        : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3)
-        : [sp] "v"(sp), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3));
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+        : [sp] "v"(sp), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3));
 #undef FM
-    return v4d{y0, y1, y2, y3};
+    ya = v4d{a0, a1, a2, a3}; yb = v4d{b0, b1, b2, b3};
 }
 
 __device__ __forceinline__ double bperm(double v, int byteAddr) {
@@ -171,89 +199,89 @@ __device__ __forceinline__ v4d column4(double sp, unsigned s) {
 
 // MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header)
 template <int MAXT, int MINW>
-__global__ __launch_bounds__(MAXT, MINW) void k_walk4(const u32x16 MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
+__global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                       int P, int C, long recipOff) {
-    extern __shared__ v2d lds[];                      // hold[2][C][2][64] (v2d), then exch[2][C][64] (double)
+    extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), then exch[2][C][128] (double)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
-    const int p0 = pStart + (int)blockIdx.x * 64;
+    const int p0 = pStart + (int)blockIdx.x * 128;
     if (p0 >= pEnd) return;                           // the whole workgroup
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool valid = p0 + lane < pEnd;
-    const int p = valid ? p0 + lane : pEnd - 1;       // lanes past the end recompute the last pattern and store nothing
-    const u64 validMask = __ballot(valid);
+    const int pa = p0 + lane, pb = p0 + 64 + lane;
+    const u64 validA = __ballot(pa < pEnd), validB = __ballot(pb < pEnd);
+    const int qa = pa < pEnd ? pa : pEnd - 1, qb = pb < pEnd ? pb : pEnd - 1;   // lanes past the end recompute the last pattern, store nothing
     // loop-invariant 32-bit byte offsets: every address of the loop is (64-bit SGPR base from the descriptor) + one of these
-    const unsigned oPart = (unsigned)(((size_t)c * P + p) * 32), oTip = (unsigned)p, oScale = (unsigned)p * 8u;
-    const unsigned oMat = (unsigned)(c * 128 + (lane & 15) * 8);
-    v2d* holdBase = lds + (size_t)c * 128 + lane;     // + slot * C * 128 (+ 64 for the second half)
-    double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 128);
+    LaneOffsets o;
+    o.partA = (unsigned)(((size_t)c * P + qa) * 32); o.partB = (unsigned)(((size_t)c * P + qb) * 32);
+    o.tipA = (unsigned)qa; o.tipB = (unsigned)qb; o.scaleA = (unsigned)qa * 8u; o.scaleB = (unsigned)qb * 8u;
+    o.mat = (unsigned)(c * 128 + (lane & 15) * 8);
+    v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
+    double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 256);
     int buf = 0;
 
-    v4d ACC = v4d{1.0, 1.0, 1.0, 1.0};
-    const u32x16 MI355_CONST* dp = prog + progStart;  // the host pads every segment: progCount is even and two more
-    u32x16 D0 = dp[0], D1 = dp[1];                     // descriptors (no-ops) follow it, so k + 2 is always readable
+    v4d ACCa = v4d{1.0, 1.0, 1.0, 1.0}, ACCb = ACCa;
+    const unsigned MI355_CONST* dp = prog + (size_t)progStart * 16;   // the host pads every segment: progCount is even and
+    Desc D0 = loadDesc(dp), D1 = loadDesc(dp + 16);                    // two more descriptors (no-ops) follow it
     Fetched A, B;
-    fetchIssue(A, unpack(D0), oPart, oTip, oScale, oMat);
+    A.xa0 = A.xa1 = A.xb0 = A.xb1 = v2d{1.0, 1.0}; A.s1a = A.s1b = A.s2a = A.s2b = 4u; A.inva = A.invb = A.sp1 = A.sp2 = 1.0;
+    B = A;
+    fetchIssue(A, D0, o);
 
-    // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one.
-    // The few descriptor fields the compute stage needs are moved out of DCUR first (explicit s_mov: the register
-    // allocator then lets descriptor k + 2 land in DCUR's own registers instead of rotating 16 SGPRs per stage).
+    // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
 #define WALK_STAGE(CUR, NXT, DCUR, DNXT)                                                                                  \
     {                                                                                                                     \
-        unsigned fl; u64 dStore, dScale, dSrc2;                                                                           \
-        asm volatile("s_mov_b32 %0, %4\n\ts_mov_b64 %1, %5\n\ts_mov_b64 %2, %6\n\ts_mov_b64 %3, %7"                     \
-                     : "=&s"(fl), "=&s"(dStore), "=&s"(dScale), "=&s"(dSrc2)                                              \
-                     : "s"(DCUR.sc), "s"(((u64)DCUR.s5 << 32) | DCUR.s4), "s"(((u64)DCUR.s7 << 32) | DCUR.s6),            \
-                       "s"(((u64)DCUR.s3 << 32) | DCUR.s2));                                                              \
-        DCUR = dp[2];                                  /* descriptor k + 2 (used two stages on) */                        \
-        fetchIssue(NXT, unpack(DNXT), oPart, oTip, oScale, oMat);                                                         \
-        dp += 1;                                                                                                          \
-        const int shape = (fl >> 5) & 63, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                                  \
+        const unsigned fl = DCUR.flags;                                                                                   \
+        const u64 dStore = DCUR.store, dScale = DCUR.scale, dSrc2 = DCUR.src2;                                            \
+        const int k1n = (DNXT.flags >> 5) & 7;         /* a hold-slot operand of the NEXT micro-operation is read now */  \
+        if (k1n >= WK_H0) {                                                                                               \
+            const v2d* h = holdBase + (size_t)(k1n - WK_H0) * C * 256;                                                    \
+            NXT.xa0 = h[0]; NXT.xa1 = h[64]; NXT.xb0 = h[128]; NXT.xb1 = h[192];                                          \
+        }                                                                                                                 \
+        fetchIssue(NXT, DNXT, o);                                                               \
+        DCUR = loadDesc(dp + 32);                      /* descriptor k + 2 (used two stages on) */                        \
+        dp += 16;                                                                                                         \
+        const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
         fetchWait(CUR, (fl >> 16) & 0xffu);            /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
-        v4d f1, f2;                                                                                                       \
-        switch (shape) {                                                                                                  \
-            case WK_TIPS | (WK_TIPS << 3): f1 = column4(CUR.sp1, CUR.s1); f2 = column4(CUR.sp2, CUR.s2); break;           \
-            case WK_TIPS | (WK_ACC << 3):  f1 = column4(CUR.sp1, CUR.s1); f2 = matvecDpp(CUR.sp2, ACC); break;            \
-            case WK_MEM | (WK_ACC << 3):   f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});          \
-                                           f2 = matvecDpp(CUR.sp2, ACC); break;                                           \
-            case WK_MEM | (WK_TIPS << 3):  f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});          \
-                                           f2 = column4(CUR.sp2, CUR.s2); break;                                          \
-            case WK_H0 | (WK_ACC << 3): case WK_H1 | (WK_ACC << 3): {        /* the thread's own hold slot */             \
-                const v2d* h = holdBase + (size_t)((shape & 7) - WK_H0) * C * 128;                                        \
-                const v2d lo = h[0], hi = h[64];                                                                          \
-                f1 = matvecDpp(CUR.sp1, v4d{lo.x, lo.y, hi.x, hi.y}); f2 = matvecDpp(CUR.sp2, ACC); break; }              \
-            default: {                                 /* both children in memory (rare): the second one is not prefetched */ \
-                v2d ya, yb;                                                                                               \
-                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16\n\ts_waitcnt vmcnt(0)" \
-                             : "=&v"(ya), "=&v"(yb) : "v"(oPart), "s"(dSrc2) : "memory");                                 \
-                f1 = matvecDpp(CUR.sp1, v4d{CUR.xa.x, CUR.xa.y, CUR.xb.x, CUR.xb.y});                                     \
-                f2 = matvecDpp(CUR.sp2, v4d{ya.x, ya.y, yb.x, yb.y}); break; }                                            \
+        v4d fa, fb, ga, gb;                                                                                               \
+        if (k1 == WK_TIPS) { fa = column4(CUR.sp1, CUR.s1a); fb = column4(CUR.sp1, CUR.s1b); }                               \
+        else matvecDpp2(CUR.sp1, v4d{CUR.xa0.x, CUR.xa0.y, CUR.xa1.x, CUR.xa1.y}, v4d{CUR.xb0.x, CUR.xb0.y, CUR.xb1.x, CUR.xb1.y}, fa, fb); \
+        if (k2 == WK_TIPS) { ga = column4(CUR.sp2, CUR.s2a); gb = column4(CUR.sp2, CUR.s2b); }                               \
+        else if (k2 == WK_ACC) matvecDpp2(CUR.sp2, ACCa, ACCb, ga, gb);                                                   \
+        else {                                         /* both children in memory (rare): the second one is not prefetched */ \
+            v2d y0, y1, y2, y3;                                                                                           \
+            asm volatile("global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:16\n\t"                \
+                         "global_load_dwordx4 %2, %5, %6\n\tglobal_load_dwordx4 %3, %5, %6 offset:16\n\ts_waitcnt vmcnt(0)"   \
+                         : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(o.partA), "v"(o.partB), "s"(dSrc2) : "memory"); \
+            matvecDpp2(CUR.sp2, v4d{y0.x, y0.y, y1.x, y1.y}, v4d{y2.x, y2.y, y3.x, y3.y}, ga, gb);                        \
         }                                                                                                                 \
-        v4d r = f1 * f2;                                                                                                  \
-        if (smode == WS_READ) r = r * CUR.inv;                                                                            \
+        v4d ra = fa * ga, rb = fb * gb;                                                                                   \
+        if (smode == WS_READ) { ra = ra * CUR.inva; rb = rb * CUR.invb; }                                                 \
         else if (smode == WS_WRITE) {                                                                                     \
-            double m = fmax(fmax(fmax(0.0, r.x), fmax(r.y, r.z)), r.w);                                                   \
-            double* e = exch + (size_t)buf * C * 64;                                                                      \
-            e[c * 64 + lane] = m;                                                                                         \
+            double ma = fmax(fmax(fmax(0.0, ra.x), fmax(ra.y, ra.z)), ra.w), mb = fmax(fmax(fmax(0.0, rb.x), fmax(rb.y, rb.z)), rb.w); \
+            v2d* e = reinterpret_cast<v2d*>(exch + (size_t)buf * C * 128);                                                \
+            e[c * 64 + lane] = v2d{ma, mb};                                                                               \
             __syncthreads();                                                                                              \
-            m = 0.0;                                                                                                      \
-            for (int cc = 0; cc < C; cc++) m = fmax(m, e[cc * 64 + lane]);                                                \
+            ma = 0.0; mb = 0.0;                                                                                           \
+            for (int cc = 0; cc < C; cc++) { const v2d t = e[cc * 64 + lane]; ma = fmax(ma, t.x); mb = fmax(mb, t.y); }   \
             buf ^= 1;                                                                                                     \
-            if (!(m > 0.0)) m = 1.0;                                                                                      \
-            const double im = 1.0 / m;                                                                                    \
-            r = r * im;                                                                                                   \
-            const u64 wm = c == 0 ? validMask : 0ull;  /* category 0 stores the factor and its reciprocal; then drain */  \
-            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %3, %5\n\tglobal_store_dwordx2 %2, %4, %5\n\t"   \
+            if (!(ma > 0.0)) ma = 1.0;                                                                                    \
+            if (!(mb > 0.0)) mb = 1.0;                                                                                    \
+            const double ia = 1.0 / ma, ib = 1.0 / mb;                                                                    \
+            ra = ra * ia; rb = rb * ib;                                                                                   \
+            /* category 0 stores the pair's factors and reciprocals (8 bytes per pattern each); then drain */              \
+            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %6, %10\n\tglobal_store_dwordx2 %3, %7, %10\n\t"  \
+                         "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %4, %8, %10\n\tglobal_store_dwordx2 %5, %9, %10\n\t"     \
                          "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                       \
-                         : : "s"(wm), "v"(oScale), "v"(oScale + (unsigned)recipOff * 8u), "v"(m), "v"(im), "s"(dScale) : "memory"); \
+                         : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(o.scaleA), "v"(o.scaleA + (unsigned)recipOff * 8u), \
+                             "v"(o.scaleB), "v"(o.scaleB + (unsigned)recipOff * 8u), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory"); \
         }                                                                                                                 \
-        storeIssue(r, fl, validMask, oPart, dStore);                                                                      \
+        storeIssue(ra, rb, fl, validA, validB, o.partA, o.partB, dStore);                                                         \
         if (hold) {                                    /* this value waits for its sibling's subtree */                   \
-            v2d* h = holdBase + (size_t)(hold - 1) * C * 128;                                                             \
-            h[0] = v2d{r.x, r.y}; h[64] = v2d{r.z, r.w};                                                                  \
+            v2d* h = holdBase + (size_t)(hold - 1) * C * 256;                                                             \
+            h[0] = v2d{ra.x, ra.y}; h[64] = v2d{ra.z, ra.w}; h[128] = v2d{rb.x, rb.y}; h[192] = v2d{rb.z, rb.w};          \
         }                                                                                                                 \
-        ACC = r;                                                                                                          \
+        ACCa = ra; ACCb = rb;                                                                                             \
     }
 
     for (int k = 0; k < progCount; k += 2) {
@@ -266,12 +294,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const u32x16 MI355_CONST* 
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
-    const dim3 grid((maxRange + 63) / 64, nSegs), block(64 * C);
-    const size_t lds = (size_t)2 * C * 128 * sizeof(v2d) + (size_t)2 * C * 64 * sizeof(double);
-    const u32x16 MI355_CONST* prog = (const u32x16 MI355_CONST*)dProg;
+    const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
+    const size_t lds = (size_t)2 * C * 256 * sizeof(v2d) + (size_t)2 * C * 128 * sizeof(double);
+    const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
-    if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 7>), grid, block, lds, stream, prog, segs, P, C, recipOff);
-    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 6>), grid, block, lds, stream, prog, segs, P, C, recipOff);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
+    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
     else hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
 }
 
