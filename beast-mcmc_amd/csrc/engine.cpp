@@ -346,7 +346,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
-    in->statMicroOps += (long)n; in->statWalks++;
+    in->statMicroOps += (long)n;
     // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
     const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
@@ -375,8 +375,17 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
-    mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes), (int)segs.size(), maxRange,
-                       in->P, in->C, (long)in->scaleStride);
+    // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
+    for (size_t b = 0; b < segs.size();) {
+        size_t e = b + 1;
+        while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
+        int range = 0;
+        for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
+        mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                           in->P, in->C, (long)in->scaleStride);
+        in->statWalks++;
+        b = e;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -402,6 +411,19 @@ int materializeTipUsers(Instance* in, int tip) {
 }
 
 int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum);
+
+// A walk is one workgroup per 128 patterns; with few patterns (a shard of a multi-GPU run, a small alignment) that leaves
+// most of the 256 CUs idle while every wave executes the whole list one dependent step after the other.  Then the planner
+// cuts the forest into independent subtrees that run side by side, wave after wave (planner.h).  Returns the target
+// number of micro-operations per subtree, 0 = one walk.  BEAGLE_MI355_CHUNK overrides (0 = never).
+int walkChunkOps(const Instance* in, int opCount) {
+    static const int forced = getenv("BEAGLE_MI355_CHUNK") ? atoi(getenv("BEAGLE_MI355_CHUNK")) : -1;
+    if (forced >= 0) return forced;
+    const int groups = (in->P + 127) / 128;
+    const int wanted = 1024 / std::max(1, groups);          // slices per wave that would fill the chip (4 workgroups per CU)
+    if (wanted < 2 || opCount < 64) return 0;
+    return std::max(24, opCount / wanted);
+}
 
 // 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
 int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum) {
@@ -438,7 +460,7 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         std::vector<int> need;
         in->planner.mustMaterializeBefore(sub, n, tuple, need);
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-        int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan);
+        int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
         // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
         // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)

@@ -260,7 +260,7 @@ void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {
     lastStored++;
 }
 
-int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allowVirtual, Plan& out) {
+int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allowVirtual, Plan& out, int chunkOps) {
     out.clear();
     lastStored = lastMemReads = lastHolds = 0;
     if (count <= 0) return 0;
@@ -350,35 +350,99 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     }
     flat_ = maxDepth > MAX_RECURSION;
 
-    // ---- pass 2: walk order.  One segment per partition; inside it, every unconsumed real op is a root of the forest.
+    // ---- pass 2: walk order.  One slice per partition; inside it, every unconsumed real op is a root of the forest.
+    // With chunkOps > 0 the forest is peeled in waves: a wave = the maximal subtrees of at most chunkOps micro-operations
+    // among what is left, one slice each; what is above them reads their (stored) roots in a later wave.
     std::vector<int> partsSeen;
     {
         std::vector<char> seen(parts, 0);
         for (int k = 0; k < count; k++) if (!seen[info_[k].part]) { seen[info_[k].part] = 1; partsSeen.push_back(info_[k].part); }
     }
+    lastWaves = 0;
+    std::vector<int> weight, chunkRoots, stack;
     for (int part : partsSeen) {
-        PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part;
-        for (int k = 0; k < count; k++) {
-            OpInfo& o = info_[k];
-            if (o.part != part || o.virtDest || o.emitted) continue;
-            if (flat_ || !consumed[k]) emitReal(k, 3u, out, 0);
+        int wave = 0;
+        for (;;) {
+            bool chunked = false;
+            if (chunkOps > 0 && !flat_) {
+                // micro-operations below every op that is still to be emitted (children precede parents in the list)
+                weight.assign(count, 0);
+                long total = 0;
+                for (int k = 0; k < count; k++) {
+                    const OpInfo& o = info_[k];
+                    if (o.part != part || o.virtDest || o.emitted) continue;
+                    int w = 1;
+                    for (int c = 0; c < 2; c++) {
+                        const bool tip = c ? o.tip2 : o.tip1;
+                        const int buf = c ? o.c2 : o.c1, prod = c ? prod2_[k] : prod1_[k];
+                        if (tip) continue;
+                        if (prod >= 0 && !info_[prod].virtDest) { if (!info_[prod].emitted) w += weight[prod]; }
+                        else if (virt_[buf].on) w += virt_[buf].nSteps;
+                    }
+                    weight[k] = w;
+                    if (!consumed[k]) total += w;
+                }
+                if (total > chunkOps + chunkOps / 2) {
+                    chunkRoots.clear(); stack.clear();
+                    for (int k = count - 1; k >= 0; k--) {
+                        const OpInfo& o = info_[k];
+                        if (o.part == part && !o.virtDest && !o.emitted && !consumed[k]) stack.push_back(k);
+                    }
+                    while (!stack.empty()) {
+                        const int k = stack.back(); stack.pop_back();
+                        if (weight[k] <= chunkOps) { chunkRoots.push_back(k); continue; }
+                        bool descended = false;
+                        for (int c = 1; c >= 0; c--) {
+                            const int prod = c ? prod2_[k] : prod1_[k];
+                            if (prod >= 0 && !info_[prod].virtDest && !info_[prod].emitted) { stack.push_back(prod); descended = true; }
+                        }
+                        if (!descended) chunkRoots.push_back(k);      // heavier than a chunk but nothing below is left to peel
+                    }
+                    // a DAG may reach the same op twice: emit once
+                    std::sort(chunkRoots.begin(), chunkRoots.end());
+                    chunkRoots.erase(std::unique(chunkRoots.begin(), chunkRoots.end()), chunkRoots.end());
+                    // only worth a wave of its own when it really runs side by side
+                    if (chunkRoots.size() >= 2) {
+                        for (int k : chunkRoots) {
+                            if (info_[k].emitted) continue;
+                            PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part; seg.wave = wave;
+                            emitReal(k, 3u, out, 0);
+                            seg.progCount = (int)out.prog.size() - seg.progStart;
+                            out.segs.push_back(seg);
+                        }
+                        chunked = true;
+                        wave++;
+                    }
+                }
+            }
+            if (chunked) continue;
+            PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part; seg.wave = wave;
+            for (int k = 0; k < count; k++) {
+                OpInfo& o = info_[k];
+                if (o.part != part || o.virtDest || o.emitted) continue;
+                if (flat_ || !consumed[k]) emitReal(k, 3u, out, 0);
+            }
+            // virtual nodes of a rescaling evaluation still owe their scale factors if nothing above evaluated them
+            for (int k = 0; k < count; k++) {
+                const OpInfo& o = info_[k];
+                if (o.part != part || !o.virtDest || o.wS == OP_NONE) continue;
+                if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, 3u, true, out);
+            }
+            seg.progCount = (int)out.prog.size() - seg.progStart;
+            if (seg.progCount > 0) { out.segs.push_back(seg); wave++; }
+            break;
         }
-        // virtual nodes of a rescaling evaluation still owe their scale factors if nothing above evaluated them
-        for (int k = 0; k < count; k++) {
-            const OpInfo& o = info_[k];
-            if (o.part != part || !o.virtDest || o.wS == OP_NONE) continue;
-            if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, 3u, true, out);
-        }
-        seg.progCount = (int)out.prog.size() - seg.progStart;
-        if (seg.progCount > 0) out.segs.push_back(seg);
+        lastWaves = std::max(lastWaves, wave);
     }
+    // launches run wave by wave: order the slices that way (stable: partitions keep their order inside a wave)
+    std::stable_sort(out.segs.begin(), out.segs.end(), [](const PlanSeg& a, const PlanSeg& b) { return a.wave < b.wave; });
     return 0;
 }
 
 void WalkPlanner::planMaterialize(const std::vector<int>& xs, Plan& out) {
     out.clear();
     parts_ = 1;
-    PlanSeg seg; seg.progStart = 0; seg.partition = 0;
+    PlanSeg seg; seg.progStart = 0; seg.partition = 0; seg.wave = 0;
     for (int X : xs) {
         if (!virt_[X].on) continue;
         emitVirtual(X, 3u, false, out);

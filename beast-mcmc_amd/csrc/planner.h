@@ -35,7 +35,9 @@ struct MicroOp {
     int hold;            // 0, or 1 + hold slot that ALSO receives the result
 };
 
-struct PlanSeg { int progStart, progCount, partition; };
+// A program slice: every pattern group of `partition` walks it.  Slices of the same `wave` are independent of each other
+// (one launch); a slice may read what slices of EARLIER waves stored.
+struct PlanSeg { int progStart, progCount, partition, wave; };
 
 struct Plan {
     std::vector<MicroOp> prog;
@@ -95,13 +97,15 @@ public:
 
     // Plan a hazard-free list.  Indices must have been range-checked by the caller.  `allowVirtual`: destinations may
     // become virtual (single-partition 7-int lists only).  Returns 0, or a BEAGLE error code.
-    int plan(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, Plan& out);
+    // `chunkOps` > 0 (few pattern groups, so a launch cannot fill the chip with one walk per group): the forest is cut
+    // into independent subtrees of about that many micro-operations, run side by side, wave after wave.
+    int plan(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, Plan& out, int chunkOps = 0);
 
     // Program that gives every (virtual) buffer of xs its real partials; the definitions are dropped.
     void planMaterialize(const std::vector<int>& xs, Plan& out);
 
     // statistics of the last plan() (bench / tests)
-    int lastStored = 0, lastMemReads = 0, lastHolds = 0;
+    int lastStored = 0, lastMemReads = 0, lastHolds = 0, lastWaves = 0;
 
 private:
     struct OpInfo {

@@ -134,7 +134,7 @@ struct Harness {
     std::vector<int> partStart{0}, partEnd;
     int parts = 1;
     std::mt19937 rng;
-    long lists = 0, micro = 0, holds = 0, memReads = 0, stored = 0, materialised = 0;
+    long lists = 0, micro = 0, holds = 0, memReads = 0, stored = 0, materialised = 0, waves = 0, segsTotal = 0;
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
@@ -212,7 +212,10 @@ struct Harness {
             pl.mustMaterializeBefore(sub, n, tuple, need);
             materialiseNoCompare(need);
             Plan p;
-            const int rc = pl.plan(sub, n, tuple, parts, true, p);
+            static const int chunkChoices[6] = {0, 0, 3, 8, 20, 64};
+            const int rc = pl.plan(sub, n, tuple, parts, true, p, chunkChoices[rng() % 6]);
+            for (size_t q = 1; q < p.segs.size(); q++) assert(p.segs[q].wave >= p.segs[q - 1].wave);
+            waves += pl.lastWaves; segsTotal += (long)p.segs.size();
             assert(rc == 0);
             // every MEM child must be real data, every destination must end up real or virtual
             runPlan(plan, p, partStart, partEnd);
@@ -335,8 +338,8 @@ static void scenarioMcmc(int T, bool virt, bool caterpillar, unsigned seed, int 
     std::vector<int> every; for (int b = T; b < h.nBuf; b++) every.push_back(b);
     h.materialise(every);
     h.compareAll();
-    printf("  mcmc T=%d virt=%d cat=%d: %ld lists, %ld micro-ops, %ld stored, %ld holds, %ld memory reads, %ld materialised\n",
-           T, (int)virt, (int)caterpillar, h.lists, h.micro, h.stored, h.holds, h.memReads, h.materialised);
+    printf("  mcmc T=%d virt=%d cat=%d: %ld lists, %ld micro-ops, %ld stored, %ld holds, %ld memory reads, %ld materialised, %ld slices in %ld waves\n",
+           T, (int)virt, (int)caterpillar, h.lists, h.micro, h.stored, h.holds, h.memReads, h.materialised, h.segsTotal, h.waves);
 }
 
 static void scenarioPartitions(unsigned seed) {
