@@ -10,5 +10,5 @@ Layout (only what the hot path needs — SURVEY.md §8):
 
 The directory name contains a hyphen, so import it through the root-level shim: ``import beast_mcmc_amd``.
 """
-from . import beagle, treelikelihood          # noqa: F401
+from . import beagle, multipartition, treelikelihood          # noqa: F401
 from .inputs import patterns, siterates, substmodel, synth, trees   # noqa: F401

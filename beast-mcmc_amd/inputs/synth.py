@@ -172,3 +172,81 @@ def config_d(categories=1, seed=31):
     eig = substmodel.hky(2.0, pi)
     return make_workload("D:benchmark1-like", 1441, 593, eig, pi, categories=categories, seed=seed,
                          root_to_tip=0.05)
+
+
+def simulate_sites(tree, eig, freqs, cat_rates, cat_weights, n_sites, rng):
+    """Simulate exactly ``n_sites`` alignment columns down ``tree`` (no uniqueness filter): uint8 [T][n_sites]."""
+    s = len(freqs)
+    cat_rates = np.asarray(cat_rates)
+    order = [n for n in reversed(tree.postorder())]
+    cats = rng.choice(len(cat_rates), size=n_sites, p=np.asarray(cat_weights) / np.sum(cat_weights))
+    states = np.empty((tree.node_count, n_sites), dtype=np.uint8)
+    states[tree.root] = rng.choice(s, size=n_sites, p=np.asarray(freqs) / np.sum(freqs))
+    for n in order:
+        if n == tree.root:
+            continue
+        bl = tree.branch_length(n)
+        mats = np.stack([np.clip(eig.transition_probabilities(bl * r), 0.0, None) for r in cat_rates])
+        mats /= mats.sum(axis=2, keepdims=True)
+        rows = np.cumsum(mats, axis=2)[cats, states[tree.parent[n]]]
+        u = rng.random(n_sites)[:, None]
+        states[n] = np.minimum((u > rows).sum(axis=1), s - 1)
+    return states[:tree.tip_count]
+
+
+class PartitionedWorkload:
+    """Several data partitions on ONE tree, each with its own substitution and site model — what
+    MultiPartitionDataLikelihoodDelegate hands to a single instance (patterns concatenated, partition = contiguous
+    pattern range, src/dr/evomodel/treedatalikelihood/MultiPartitionDataLikelihoodDelegate.java:520-553)."""
+
+    def __init__(self, name, tree, parts):
+        self.name = name
+        self.tree = tree
+        self.parts = parts                      # list of Workload on the same tree
+
+    @property
+    def tip_count(self):
+        return self.tree.tip_count
+
+    @property
+    def pattern_count(self):
+        return sum(w.pattern_count for w in self.parts)
+
+    @property
+    def pattern_counts(self):
+        return [w.pattern_count for w in self.parts]
+
+    def shard(self, rank, world):
+        """What one GPU of a pattern-sharded job owns: block `rank` of every partition's pattern range."""
+        from . import patterns
+        parts = []
+        for w in self.parts:
+            s, e = patterns.shard_bounds(w.pattern_count, world)[rank]
+            parts.append(w.shard(s, e))
+        return PartitionedWorkload(self.name, self.tree, parts)
+
+
+def config_e(scale=1.0, seed=41):
+    """Makona-like (BASELINE.json config 5; the real alignment is absent from the reference tree): 1610 taxa,
+    an 18 992-nt genome as four nucleotide partitions — codon positions 1, 2, 3 and non-coding — HKY+G4 each with its own
+    kappa / frequencies / alpha / relative rate, simulated at low divergence (an outbreak: root-to-tip ~8e-3
+    substitutions per site) and compressed to unique site patterns per partition."""
+    from . import patterns
+    t = max(8, int(1610 * scale))
+    rng = np.random.default_rng(seed)
+    tree = trees.coalescent_tree(t, rng, root_height=0.008)
+    n_sites = [max(40, int(x * scale)) for x in (4900, 4900, 4900, 4292)]
+    kappas, alphas, mus = (4.0, 3.5, 8.0, 6.0), (0.6, 0.4, 1.2, 0.8), (0.6, 0.4, 2.2, 0.9)
+    pis = ([0.30, 0.20, 0.28, 0.22], [0.32, 0.22, 0.18, 0.28], [0.28, 0.24, 0.22, 0.26], [0.31, 0.21, 0.20, 0.28])
+    parts = []
+    for k in range(4):
+        pi = np.asarray(pis[k])
+        eig = substmodel.hky(kappas[k], pi)
+        rates, props = GammaSiteRateModel(alpha=alphas[k], gamma_categories=4).category_rates_and_proportions()
+        rates = np.asarray(rates) * mus[k]                  # the partition's relative rate folded into its category rates
+        cols = simulate_sites(tree, eig, pi, rates, props, n_sites[k], rng).astype(np.int32)
+        for taxon in rng.choice(t, size=max(1, t // 40), replace=False):      # sequencing gaps: a stretch of a few genomes
+            a = int(rng.integers(0, n_sites[k])); cols[taxon, a:a + max(1, n_sites[k] // 10)] = 4
+        pats, weights = patterns.site_patterns(cols, unique=True)
+        parts.append(Workload("E:part%d" % k, tree, eig, pi, rates, props, pats, weights, 4))
+    return PartitionedWorkload("E:Makona-like 4 x HKY+G4", tree, parts)

@@ -1,0 +1,115 @@
+"""Host-side mirror of the reference's multi-partition caller for ONE engine instance.
+
+What ``MultiPartitionDataLikelihoodDelegate`` does per evaluation, call for call
+(src/dr/evomodel/treedatalikelihood/MultiPartitionDataLikelihoodDelegate.java): partitions are contiguous pattern
+ranges of one instance (:520-553 ``setPatternPartitions``); every partition has its own eigen system, category rates,
+weights and frequencies (:835 ``setCategoryRatesWithIndex``); all branch matrices of all partitions go out in ONE
+``updateTransitionMatricesWithMultipleModels`` (:880-887); the operation list carries 9-int tuples
+{dest, writeScale, readScale, child1, matrix1, child2, matrix2, partition, cumulativeScale} (:972-997) through
+``updatePartialsByPartition``; scale factors are accumulated per partition (:1016-1017) and the root is integrated with
+``calculateRootLogLikelihoodsByPartition`` (:1074-1083).  Partials and matrix indices flip between two buffers per node
+(``BufferIndexHelper``), the traversal is the reverse level order of ``LikelihoodTreeTraversal.java:133-205``.
+
+Python because it only sequences calls; the arithmetic is in the engine behind ``beagle.Beagle``.
+"""
+import numpy as np
+
+from . import beagle as _b
+
+NONE = _b.NONE
+
+
+class MultiPartitionTreeLikelihood:
+    def __init__(self, pw, *, library=None, resource_list=(1,), always_rescale=False):
+        self.pw = pw
+        self.tree = tree = pw.tree
+        self.T = T = tree.tip_count
+        self.K = K = len(pw.parts)
+        self.nodes = nodes = tree.node_count
+        self.C = len(pw.parts[0].cat_rates)
+        self.P = pw.pattern_count
+        self.always_rescale = always_rescale
+        self.flip = np.zeros(nodes, dtype=np.int32)          # BufferIndexHelper offsets of the internal nodes
+        self.mflip = 0
+        self.evaluations = 0
+        # partials: tips 0..T-1, internal node n -> T + 2 (n - T) + flip; matrices: (partition, node, flip); scale: node + cumulative
+        self.b = _b.Beagle(T, T + 2 * (T - 1), T, pw.parts[0].state_count, self.P, K, 2 * K * nodes, self.C, (T - 1) + 1,
+                           resourceList=list(resource_list), library=library)
+        for t in range(T):
+            self.b.setTipStates(t, np.concatenate([w.tip_states[t] for w in pw.parts]))
+        self.b.setPatternWeights(np.concatenate([w.weights for w in pw.parts]))
+        if K > 1:
+            self.b.setPatternPartitions(K, np.concatenate([np.full(w.pattern_count, k, dtype=np.int32) for k, w in enumerate(pw.parts)]))
+        # reverse level order: deepest internal nodes first (children always before parents)
+        depth = np.zeros(nodes, dtype=np.int64)
+        for n in reversed(tree.postorder()):
+            if n != tree.root:
+                depth[n] = depth[tree.parent[n]] + 1
+        self.order = [int(n) for n in sorted((n for n in range(T, nodes)), key=lambda n: -depth[n])]
+        self.branch_rates = np.ones(nodes)
+
+    def pbuf(self, n):
+        return n if n < self.T else self.T + 2 * (n - self.T) + int(self.flip[n])
+
+    def mbuf(self, k, n):
+        return (k * self.nodes + n) * 2 + self.mflip
+
+    def set_branch_rates(self, rates):
+        self.branch_rates = np.asarray(rates, dtype=np.float64)
+
+    def calculate(self):
+        """One full evaluation; returns (per-partition log-likelihoods, total)."""
+        b, tree, K, T = self.b, self.tree, self.K, self.T
+        self.mflip ^= 1
+        self.flip[T:] ^= 1
+        eig_idx, rate_idx, mat_idx, lens = [], [], [], []
+        for k, w in enumerate(self.pw.parts):
+            b.setEigenDecomposition(k, w.eig.evec, w.eig.ievc, w.eig.evals)
+            b.setCategoryRatesWithIndex(k, w.cat_rates)
+            for n in range(self.nodes):
+                if n != tree.root:
+                    eig_idx.append(k); rate_idx.append(k); mat_idx.append(self.mbuf(k, n))
+                    lens.append(tree.branch_length(n) * self.branch_rates[n])
+        b.updateTransitionMatricesWithMultipleModels(eig_idx, rate_idx, mat_idx, None, None, lens, len(lens))
+        ops, scale_idx = [], []
+        for n in self.order:
+            l, r = int(tree.left[n]), int(tree.right[n])
+            ws = (n - T) if self.always_rescale else NONE
+            for k in range(K):
+                ops += [self.pbuf(n), ws, NONE, self.pbuf(l), self.mbuf(k, l), self.pbuf(r), self.mbuf(k, r), k, NONE]
+            scale_idx.append(n - T)
+        if K > 1:
+            b.updatePartialsByPartition(ops, len(ops) // 9)
+        else:
+            b.updatePartials([x for i in range(0, len(ops), 9) for x in ops[i:i + 7]], len(ops) // 9, NONE)
+        cum = (T - 1) if self.always_rescale else NONE
+        if self.always_rescale:
+            for k in range(K):
+                if K > 1:
+                    b.resetScaleFactorsByPartition(cum, k)
+                    b.accumulateScaleFactorsByPartition(scale_idx, len(scale_idx), cum, k)
+                else:
+                    b.resetScaleFactors(cum)
+                    b.accumulateScaleFactors(scale_idx, len(scale_idx), cum)
+        for k, w in enumerate(self.pw.parts):
+            b.setCategoryWeights(k, w.cat_weights)
+            b.setStateFrequencies(k, w.freqs)
+        self.evaluations += 1
+        root = self.pbuf(tree.root)
+        if K > 1:
+            by_part = np.zeros(K)
+            total = [0.0]
+            b.calculateRootLogLikelihoodsByPartition([root] * K, list(range(K)), list(range(K)), [cum] * K, list(range(K)), K, 1,
+                                                     by_part, total)
+            return by_part, total[0]
+        out = [0.0]
+        b.calculateRootLogLikelihoods([root], [0], [0], [cum], 1, out)
+        return np.array(out), out[0]
+
+    def getSiteLogLikelihoods(self):
+        return self.b.getSiteLogLikelihoods()
+
+    def close(self):
+        if self.b is not None:
+            self.b.finalize()
+            self.b = None

@@ -1,0 +1,147 @@
+"""Every BASELINE.json configuration at (or near) its full size on the GPU, against the CPU oracle.
+
+  B  20 states, 500 taxa x 5e4 patterns   — the fp64-MFMA tiled kernel with MANY 32-pattern tiles per wave: its software-
+  C  61 states, 200 taxa x 2e4 patterns     pipelined multi-tile loop (kernels_mfma.hip) only iterates more than once at
+                                            this size; the small parity cases give every wave exactly one tile
+  mid-size 20-state case                  — the same loop with BEAGLE_MI355_MFMA_PIPE = 0, 1, 2 (prefetch depth)
+  D  benchmark1-like 1441 taxa x 593 patterns, 1 and 4 rate categories — the whole alignment against the oracle
+  E  Makona-like 1610 taxa, four nucleotide partitions on one instance through updatePartialsByPartition
+     (MultiPartitionDataLikelihoodDelegate.java:520-553, 972-997, 1074-1083), each partition against the oracle
+
+Patterns are independent given the tree, so for B and C the oracle evaluates a random 1 % sample of the patterns (seconds
+on the CPU) and must agree with the engine's site log-likelihoods for exactly those patterns; tolerance 1e-10 relative
+(BASELINE.json north_star).  First evaluation = rescaling in write mode, second = read mode."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import beast_mcmc_amd as bm
+import helpers
+from beast_mcmc_amd.inputs import synth
+from beast_mcmc_amd.multipartition import MultiPartitionTreeLikelihood
+from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_ALWAYS, RESCALE_DYNAMIC, RESCALE_NONE
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-10
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sampled_check(wl, oracle_lib, n_sample, seed):
+    g = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    lnl = g.getLogLikelihood()                              # write mode: every op recomputes its scale factors
+    assert np.isfinite(lnl)
+    site = g.getSiteLogLikelihoods()
+    assert helpers.rel_err(float(np.dot(site, wl.weights)), lnl) <= 1e-12
+    idx = np.sort(np.random.default_rng(seed).choice(wl.pattern_count, size=n_sample, replace=False))
+    sub = synth.Workload(wl.name + "-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
+                         np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], wl.state_count)
+    o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    o.getLogLikelihood()
+    so = o.getSiteLogLikelihoods()
+    assert np.max(np.abs(site[idx] - so) / np.abs(so)) <= REL_TOL
+    g.makeDirty()                                           # read mode: the stored factors divide
+    again = g.getLogLikelihood()
+    site2 = g.getSiteLogLikelihoods()
+    assert helpers.rel_err(again, lnl) <= 1e-12
+    assert np.max(np.abs(site2[idx] - so) / np.abs(so)) <= REL_TOL
+    o.makeDirty()
+    assert helpers.rel_err(float(np.dot(site2[idx], wl.weights[idx])), o.getLogLikelihood()) <= REL_TOL
+    o.close(); g.close()
+
+
+def test_config_b_sampled_against_oracle(oracle_lib):
+    wl = synth.config_b()
+    assert (wl.tip_count, wl.pattern_count, wl.state_count) == (500, 50000, 20)
+    sampled_check(wl, oracle_lib, 500, seed=5)
+
+
+def test_config_c_sampled_against_oracle(oracle_lib):
+    wl = synth.config_c()
+    assert (wl.tip_count, wl.pattern_count, wl.state_count) == (200, 20000, 61)
+    sampled_check(wl, oracle_lib, 200, seed=6)
+
+
+_MIDSIZE = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers
+from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
+wl = helpers.random_workload(40, 40000, 20, 4, seed=77)
+g = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+o = BeagleTreeLikelihood(wl, library=helpers.oracle_library(), rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+for rep in range(2):                      # write mode, then read mode
+    a, b = g.getLogLikelihood(), o.getLogLikelihood()
+    sa, sb = g.getSiteLogLikelihoods(), o.getSiteLogLikelihoods()
+    assert abs(a - b) <= 1e-10 * abs(b), (rep, a, b)
+    assert np.max(np.abs(sa - sb) / np.abs(sb)) <= 1e-10, rep
+    g.makeDirty(); o.makeDirty()
+print("midsize ok", a)
+"""
+
+
+@pytest.mark.parametrize("pipe", ["0", "1", "2"])
+def test_mfma_multi_tile_loop_every_prefetch_depth(pipe):
+    """40 taxa x 40 000 patterns, 20 states: 1 250 tiles per (op, category) row, so every wave of the tiled kernel runs
+    its tile loop several times; the prefetch depth is read once per process, hence one process per value."""
+    env = dict(os.environ, BEAGLE_MI355_MFMA_PIPE=pipe)
+    out = subprocess.run([sys.executable, "-c", _MIDSIZE % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "midsize ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("categories", [1, 4])
+def test_config_d_whole_alignment_against_oracle(categories, oracle_lib):
+    wl = synth.config_d(categories=categories)
+    assert (wl.tip_count, wl.pattern_count) == (1441, 593)
+    for rescaling in (RESCALE_NONE, RESCALE_ALWAYS):
+        g = BeagleTreeLikelihood(wl, rescaling=rescaling, delay_rescaling=False)
+        o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=rescaling, delay_rescaling=False)
+        a, b = g.getLogLikelihood(), o.getLogLikelihood()
+        assert np.isfinite(b) and helpers.rel_err(a, b) <= REL_TOL, (categories, rescaling, a, b)
+        sa, sb = g.getSiteLogLikelihoods(), o.getSiteLogLikelihoods()
+        assert np.max(np.abs(sa - sb) / np.abs(sb)) <= REL_TOL
+        g.close(); o.close()
+
+
+@pytest.mark.parametrize("always_rescale", [False, True])
+def test_config_e_partitioned_instance_against_per_partition_oracle(always_rescale, oracle_lib):
+    pw = synth.config_e()
+    assert pw.tip_count == 1610 and len(pw.parts) == 4
+    tl = MultiPartitionTreeLikelihood(pw, always_rescale=always_rescale)
+    by_part, total = tl.calculate()
+    site = tl.getSiteLogLikelihoods()
+    by_part2, total2 = tl.calculate()                       # the flipped buffers: same numbers
+    tl.close()
+    assert total2 == total and np.array_equal(by_part, by_part2)
+    off, expect = 0, []
+    for k, w in enumerate(pw.parts):
+        o = BeagleTreeLikelihood(w, library=oracle_lib, rescaling=RESCALE_ALWAYS if always_rescale else RESCALE_NONE,
+                                 delay_rescaling=False)
+        v = o.getLogLikelihood()
+        so = o.getSiteLogLikelihoods()
+        o.close()
+        expect.append(v)
+        assert np.isfinite(v) and helpers.rel_err(by_part[k], v) <= REL_TOL, (k, by_part[k], v)
+        assert np.max(np.abs(site[off:off + w.pattern_count] - so) / np.abs(so)) <= REL_TOL
+        off += w.pattern_count
+    assert helpers.rel_err(total, sum(expect)) <= REL_TOL
+
+
+def test_config_e_pattern_shards_sum_to_whole():
+    """Row (e) for a partitioned analysis: every partition's pattern range is cut into contiguous blocks
+    (Patterns.java:142-167); the per-shard, per-partition log-likelihoods add up to the unsharded ones."""
+    pw = synth.config_e(scale=0.25)
+    tl = MultiPartitionTreeLikelihood(pw)
+    whole, total = tl.calculate()
+    tl.close()
+    acc = np.zeros(len(pw.parts))
+    for rank in range(4):
+        sh = pw.shard(rank, 4)
+        t2 = MultiPartitionTreeLikelihood(sh)
+        bp, _ = t2.calculate()
+        t2.close()
+        acc += bp
+    assert np.max(np.abs(acc - whole) / np.abs(whole)) <= 1e-11
