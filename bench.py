@@ -2,19 +2,27 @@
 """Headline benchmark: full-tree log-likelihood evaluations per second, GTR+G4, 1000 taxa x 1e5 unique
 patterns, fp64 (BASELINE.json `metric`, config "GTR+G4 nucleotide (4-state), 1000 taxa x 1e5 unique patterns").
 
-One "step" = one full-tree evaluation driven through the C ABI exactly as BEAST drives it after a substitution-
-model move: setEigenDecomposition + setCategoryRates + updateTransitionMatrices(2T-2 branches) +
+One "step" = one full-tree evaluation driven through the C ABI exactly as BEAST drives it after a substitution-model
++ site-model move: setEigenDecomposition + setCategoryRates (NEW values every step: the parameters alternate between
+two nearby models, so nothing the engine could skip as "unchanged" is) + updateTransitionMatrices(2T-2 branches) +
 updatePartials(T-1 level-ordered ops, steady-state DYNAMIC rescaling: read mode) + setCategoryWeights /
-setStateFrequencies + calculateRootLogLikelihoods, with the scalar result read back on the host
-(SURVEY 8d "Timing protocol").  All inputs are resident in HBM before the timed region.
+setStateFrequencies + calculateRootLogLikelihoods, with the scalar result read back on the host (SURVEY 8d "Timing
+protocol").  `--caller btl` adds what the class north_star names, BeagleTreeLikelihood, does on top of that every
+evaluation: getSiteLogLikelihoods (P doubles back to the host, BeagleTreeLikelihood.java:1050); the default is the
+TreeDataLikelihood protocol (BeagleDataLikelihoodDelegate.java:904-935), and the line reports both.
+All inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the 1e5 patterns are split into contiguous blocks
-(Patterns.java:142-167), every rank evaluates its block, ONE RCCL all-reduce of the per-shard lnL per step.
-Total work is fixed as N grows -> "scaling": "strong".
+--config A (default) | B (20 states, 500 x 5e4) | C (61 states, 200 x 2e4) | D (benchmark1-like) | E (Makona-like, four
+partitions on one instance through updatePartialsByPartition).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the patterns (of every partition) are split into contiguous
+blocks (Patterns.java:142-167), every rank evaluates its block, ONE RCCL all-reduce of the per-shard lnL per step (E: of
+the partitionCount per-partition values).  Total work is fixed as N grows -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,13 +31,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable with a copy kernel)
+KERNEL_SOURCES = ("kernels_walk4.hip", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine.cpp")
+
+
+def kernel_source_hash():
+    """Identifies the build a profile belongs to: sha256 over the kernel and planner sources."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "beast-mcmc_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def prune_bytes_per_eval(wl):
-    """Algorithmic HBM bytes of the pruning launches of ONE full-tree evaluation (SURVEY 8d / DESIGN.md §5):
-    per op: destination write B + B per internal child (P bytes per compact tip child) + one 8-byte scale
-    factor per pattern (read in steady-state DYNAMIC); B = P*S*C*8."""
+    """ALGORITHMIC HBM bytes of the pruning of ONE full-tree evaluation: per op the destination write B + B
+    per internal child (P bytes per compact tip child) + one 8-byte scale factor per pattern; B = P*S*C*8."""
     t, p = wl.tip_count, wl.pattern_count
     b = p * wl.state_count * wl.category_count * 8
     total = 0
@@ -41,10 +58,26 @@ def prune_bytes_per_eval(wl):
     return total
 
 
-def eval_bytes(wl):
-    """Whole-evaluation algorithmic bytes: pruning + root read + weights, cumulative scalers, site-lnL write."""
-    p = wl.pattern_count
-    return prune_bytes_per_eval(wl) + p * wl.state_count * wl.category_count * 8 + 3 * p * 8
+def perturbed_models(bm, wl, config):
+    """Two nearby substitution + site models per workload; a step alternates between them, as a chain's substitution- and
+    site-model moves would (every step uploads a DIFFERENT eigen system and category rates)."""
+    import numpy as np
+    from beast_mcmc_amd.inputs import substmodel
+    from beast_mcmc_amd.inputs.siterates import GammaSiteRateModel
+    out = [(wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights)]
+    pi = np.asarray(wl.freqs)
+    if config == "A":
+        eig2 = substmodel.gtr([1.0, 4.0 * (1 + 1e-6), 0.8, 1.2, 4.5, 1.0], pi)
+    elif config in ("D",):
+        eig2 = substmodel.hky(2.0 * (1 + 1e-6), pi)
+    else:                                   # B, C: the same rate matrix at a slightly different normalisation
+        eig2 = substmodel.EigenDecomposition(wl.eig.evec, wl.eig.ievc, np.asarray(wl.eig.evals) * (1 + 1e-6))
+    if wl.category_count > 1:
+        r2, w2 = GammaSiteRateModel(alpha=0.5 * (1 + 1e-6), gamma_categories=wl.category_count).category_rates_and_proportions()
+    else:
+        r2, w2 = wl.cat_rates, wl.cat_weights
+    out.append((eig2, wl.freqs, np.asarray(r2, dtype=float), np.asarray(w2, dtype=float)))
+    return out
 
 
 def main():
@@ -52,21 +85,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="A", choices=["A", "B", "C", "D"])
+    ap.add_argument("--config", default="A", choices=["A", "B", "C", "D", "E"])
+    ap.add_argument("--caller", default="tdl", choices=["tdl", "btl"],
+                    help="tdl: TreeDataLikelihood protocol (default); btl: BeagleTreeLikelihood also reads the site log-likelihoods back every evaluation")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--patterns", type=int, default=0, help="development: keep only the first N patterns (size of one shard of an N-GPU job)")
     ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="patterns in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="patterns in the CPU-baseline sample (0 = sized for ~10-20 s of CPU work)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import beast_mcmc_amd as bm
     from beast_mcmc_amd.sharding import ShardedTreeLikelihood
-    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,7 +124,8 @@ def main():
     makers = {"A": lambda: bm.synth.config_a(scale=args.scale, tree_kind=args.tree),
               "B": lambda: bm.synth.config_b(scale=args.scale),
               "C": lambda: bm.synth.config_c(scale=args.scale),
-              "D": lambda: bm.synth.config_d(categories=1)}
+              "D": lambda: bm.synth.config_d(categories=1),
+              "E": lambda: bm.synth.config_e(scale=args.scale)}
     if args.cache:
         os.makedirs(args.cache, exist_ok=True)
     cache = os.path.join(args.cache, "wl_%s_%g_%s.pkl" % (args.config, args.scale, args.tree)) if args.cache else None
@@ -99,32 +135,25 @@ def main():
     if cache and world > 1 and rank == 0:
         dist.barrier()
     t_gen = time.time() - t_gen
-    if args.patterns:
+    if args.patterns and args.config != "E":
         wl = wl.shard(0, min(args.patterns, wl.pattern_count))
+    res = (local_rank + 1,)                              # resource numbering: 0 = CPU (absent), 1..G = GPUs as THIS process sees them
 
-    # resource numbering: 0 = CPU (absent), 1..G = GPUs as THIS process sees them
-    res = (local_rank + 1,)
-    # DYNAMIC rescaling with beagle.delay.scaling off: scalers are recomputed on the first evaluation and every
-    # `beagle.rescale` = 100 evaluations, every other evaluation READS the stored factors.
-    # (With the delay on, this realistic low-divergence tree never underflows in fp64 and scaling would never
-    # switch on: fewer bytes, an easier benchmark.)
-    from beast_mcmc_amd.treelikelihood import RESCALE_DYNAMIC
-    kw = dict(resource_list=res, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
-    if sharded:
-        tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, device=device, **kw)
-        local = tl.local
+    if args.config == "E":
+        out = bench_partitioned(args, bm, wl, rank, world, dist, device, res, t_gen)
     else:
-        tl = BeagleTreeLikelihood(wl, **kw)
-        local = tl
+        out = bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded,
+                           ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC)
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
 
-    def step():
-        # one MCMC iteration's worth of host protocol (MarkovChain.java:207-263): storeState (buffer indices flip
-        # on the next write), then a substitution-model + site-model move: everything dirty, eigen system and
-        # rates re-uploaded, all 2T-2 matrices and all T-1 partials recomputed into the alternate buffers
-        local.storeState()
-        local.set_substitution_model(wl.eig, wl.freqs)
-        local.set_site_model(wl.cat_rates, wl.cat_weights)
-        return tl.getLogLikelihood()
+
+def timed_loop(torch, device, dist, steps, step):
+    """Barrier + device synchronisation on both sides, MAX over ranks; the Python collector is paused inside (a
+    generation-2 collection of a process with torch loaded takes ~40 ms, ten evaluations' worth, and is triggered by the
+    harness' own ctypes argument objects, not by anything on the measured path)."""
+    import gc
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -132,77 +161,143 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # reach DYNAMIC steady state (first evaluation underflows and recomputes the scalers), then warm up
-    lnl0 = step()
-    step()
-    for _ in range(args.warmup):
-        step()
-    raw = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
-    raw.lib, raw._f, raw.instance = local.engine, local.engine.fn, local.instance
-    raw.kernelTimer(True)
-
-    # The harness is Python: a generation-2 garbage collection of a process that has torch loaded takes ~40 ms
-    # (measured: tools/shard_overhead.py per-step trace) — ten evaluations' worth — and is triggered by the ctypes
-    # argument objects of the harness itself, not by anything on the measured path.  Collect now, pause the collector
-    # for the timed region (no cycles are created in it), restore afterwards.
-    import gc
     gc.collect()
     gc.disable()
     barrier()
     t0 = time.perf_counter()
-    lnl = 0.0
-    for _ in range(args.steps):
-        lnl = step()
+    v = None
+    for i in range(steps):
+        v = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
-
-    kernel_ms, launches = raw.kernelTimer(False)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    return elapsed, v
+
+
+def moved_bytes(stats, p, c, s):
+    """HBM bytes the 4-state design HAS to move for what the engine actually enqueued (its own counters): every stored
+    node is written once, every child it could not keep in registers is read once, plus tip-state, scale-factor and
+    reciprocal vectors.  (Algorithmic bytes count every node as written and every internal child as read.)"""
+    b = p * s * c * 8
+    return (stats["stored"] + stats["mem_reads"]) * b + stats["tip_reads"] * p + stats["scale_reads"] * 8 * p + stats["scale_writes"] * 16 * p
+
+
+def profiled_traffic(config):
+    """roofline.traffic: HBM bytes per evaluation from the rocprofv3 PMC passes of profiles/collect.sh (FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE), accepted only when the profile was taken on THIS build of the kernels."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profile under profiles/"
+    try:
+        rec = json.load(open(path)).get(config)
+    except Exception as e:                         # noqa: BLE001
+        return None, "unreadable profile: %s" % e
+    if not rec:
+        return None, "no profile for config %s" % config
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, "profiles/hbm_traffic.json is from another build (%s, now %s): re-run profiles/collect.sh" % (
+            rec.get("kernel_source_hash"), kernel_source_hash())
+    return rec, "profiles/hbm_traffic.json (%s)" % rec.get("source", "")
+
+
+def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC):
+    import numpy as np
+    import torch
+    # DYNAMIC rescaling with beagle.delay.scaling off: scalers are recomputed on the first evaluation and every
+    # `beagle.rescale` = 100 evaluations, every other evaluation READS the stored factors (SURVEY 8d config A).
+    # (With the delay on, this realistic low-divergence tree never underflows in fp64 and scaling would never
+    # switch on: fewer bytes, an easier benchmark.)
+    kw = dict(resource_list=res, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    if sharded:
+        tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, device=device, **kw)
+        local = tl.local
+    else:
+        tl = BeagleTreeLikelihood(wl, **kw)
+        local = tl
+    models = perturbed_models(bm, wl, args.config)
+    site_buf = {"n": 0}
+
+    def step(i):
+        # one MCMC iteration's worth of host protocol (MarkovChain.java:207-263): storeState (buffer indices flip on the
+        # next write), then a substitution-model + site-model move: everything dirty, a NEW eigen system and NEW rates
+        # uploaded, all 2T-2 matrices and all T-1 partials recomputed into the alternate buffers
+        eig, freqs, rates, weights = models[i & 1]
+        local.storeState()
+        local.set_substitution_model(eig, freqs)
+        local.set_site_model(rates, weights)
+        v = tl.getLogLikelihood()
+        if args.caller == "btl":
+            site_buf["n"] += local.getSiteLogLikelihoods().shape[0]
+        return v
+
+    # reach DYNAMIC steady state (first evaluation underflows and recomputes the scalers), then warm up
+    lnl0 = step(0)
+    step(1)
+    for i in range(args.warmup):
+        step(i)
+    raw = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
+    raw.lib, raw._f, raw.instance = local.engine, local.engine.fn, local.instance
+    raw.kernelTimer(True)
+    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
+    stats = raw.walkStats()
+    kernel_ms, launches = raw.kernelTimer(False)
+    if dist is not None:
         kms = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
         kernel_ms = float(kms.item())
-
     evals_per_s = args.steps / elapsed
     counters = local.counters()
+
+    # the other caller protocol, for the record (a shorter run of the same loop)
+    other = None
+    if world == 1:
+        keep = args.caller
+        args.caller = "btl" if keep == "tdl" else "tdl"
+        n2 = max(10, args.steps // 4)
+        e2, _ = timed_loop(torch, device, dist, n2, step)
+        other = {"caller": args.caller, "evals_per_s": round(n2 / e2, 3), "ms_per_step": round(1e3 * e2 / n2, 4)}
+        args.caller = keep
 
     out = None
     if rank == 0:
         shard = wl.shard(*tl.range) if sharded else wl
-        pb = prune_bytes_per_eval(shard)                      # this rank's pruning bytes per evaluation
-        launches_per_eval = launches / max(1, args.steps)
-        kernel_s_per_eval = kernel_ms * 1e-3 / max(1, args.steps)
-        achieved = pb / kernel_s_per_eval / 1e9 if kernel_s_per_eval > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        s_ = wl.state_count
-        kname = "k_prune4<4,nt>" if s_ == 4 else ("k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral")
+        s_, p_, c_ = shard.state_count, shard.pattern_count, shard.category_count
+        alg = prune_bytes_per_eval(shard)                     # SURVEY 8d algorithmic bytes of this rank's pruning
+        kernel_s = kernel_ms * 1e-3 / max(1, args.steps)
+        walk = s_ == 4 and stats["walks"] > 0
+        if walk:
+            moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps)
+            kname = "k_walk4"
+            launches_per_eval = stats["walks"] / max(1, args.steps)
+        else:
+            moved = alg                                       # the tiled kernels store and re-read every node
+            kname = "k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
+            launches_per_eval = launches / max(1, args.steps)
+        achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        prof, prof_note = profiled_traffic(args.config) if not args.patterns and args.scale == 1.0 else (None, "not the profiled size")
         roofline = {
             "bound": "hbm", "kernel": kname,
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic if args.config == "A" else None,
-            "algorithmic_bytes_per_launch": round(pb / max(1.0, launches_per_eval)),
-            "avg_launch_us": round(kernel_ms * 1e3 / max(1, launches), 2),
-            "launches_per_eval": round(launches_per_eval, 2),
-            "kernel_time_fraction_of_step": round(kernel_s_per_eval * evals_per_s, 4),
-            "whole_eval_GBs": round(eval_bytes(shard) * evals_per_s / 1e9, 1),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": int(prof["bytes_per_eval"]) if prof else None, "traffic_source": prof_note,
+            "traffic_frac_of_peak": round(prof["bytes_per_eval"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if prof and kernel_s > 0 else None,
+            "bytes_per_eval": int(moved), "bytes_basis": "engine counters: stored + re-read partials, tip, scale vectors" if walk else "algorithmic (every node stored and re-read)",
+            "algorithmic_bytes_per_eval": int(alg), "effective_GBs": round(alg / kernel_s / 1e9, 1) if kernel_s > 0 else None,
+            "kernel_us_per_eval": round(kernel_s * 1e6, 2), "launches_per_eval": round(launches_per_eval, 2),
+            "kernel_time_fraction_of_step": round(kernel_s * evals_per_s, 4),
         }
-        # arithmetic side of the roofline (matters for 61 states): 2*S*S flops per internal child per (pattern, category)
-        # + S products; fp64 matrix/vector peak 78.6 TFLOP/s (nominal), 73.9 measured for mfma_f64_4x4x4
+        if walk:
+            roofline["per_eval"] = {k: round(v / max(1, args.steps), 1) for k, v in stats.items()}
+        # arithmetic side (matters for 61 states): 2*S*S flops per internal child per (pattern, category) + S products;
+        # fp64 matrix/vector peak 78.6 TFLOP/s nominal, 73.9 measured for mfma_f64_4x4x4 (profiles/)
         tr = shard.tree
         n_int_children = sum(1 for n in range(shard.tip_count, 2 * shard.tip_count - 1)
                              for ch in (int(tr.left[n]), int(tr.right[n])) if ch >= shard.tip_count)
-        flops = (n_int_children * 2.0 * s_ * s_ + (shard.tip_count - 1) * s_) * shard.pattern_count * shard.category_count
-        tflops = flops / kernel_s_per_eval / 1e12 if kernel_s_per_eval > 0 else 0.0
+        flops = (n_int_children * 2.0 * s_ * s_ + (shard.tip_count - 1) * s_) * p_ * c_
+        tflops = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
         roofline["fp64_TFLOPs"] = round(tflops, 2)
         roofline["fp64_frac_of_78.6"] = round(tflops / 78.6, 4)
         if tflops / 78.6 > achieved / HBM_PEAK_GBS:            # the compute roof is the nearer one (codon models)
@@ -217,19 +312,81 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "
-                                   "DYNAMIC rescaling steady state" % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count,
-                                                                     wl.category_count, args.tree, wl.tree.depth()),
-                       "patterns_per_gpu": shard.pattern_count, "parallelism": "pattern-shard x%d + 1 all-reduce" % world,
+                                   "DYNAMIC rescaling steady state, new eigen system + rates every step"
+                                   % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth()),
+                       "caller": args.caller, "patterns_per_gpu": p_, "parallelism": "pattern-shard x%d + 1 all-reduce" % world,
                        "ops_per_eval": int(counters["last_op_count"]), "matrices_per_eval": int(counters["last_branch_count"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_caller": other,
             "lnL": lnl, "lnL_first_eval": lnl0, "hbm_bytes_resident": int(raw.deviceBytes()),
-            "workload_generation_s": round(t_gen, 1),
+            "evaluations_total": int(local.counters()["evaluations"]),
+            "kernel_source_hash": kernel_source_hash(), "workload_generation_s": round(t_gen, 1),
         }
         print(json.dumps(out), flush=True)
     tl.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
+
+
+def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
+    """Config E: four partitions on ONE instance per GPU (MultiPartitionDataLikelihoodDelegate's protocol); with N GPUs every
+    partition's pattern range is cut into N contiguous blocks and the partitionCount per-partition values are all-reduced."""
+    import numpy as np
+    import torch
+    from beast_mcmc_amd.multipartition import MultiPartitionTreeLikelihood
+    local_pw = pw.shard(rank, world) if world > 1 else pw
+    tl = MultiPartitionTreeLikelihood(local_pw, resource_list=res)
+    k = len(pw.parts)
+    buf = torch.zeros(k, dtype=torch.float64, device=device)
+    rates0 = np.ones(pw.tree.node_count)
+
+    def step(i):
+        tl.set_branch_rates(rates0 * (1.0 + 1e-6 * (i & 1)))       # a clock-rate move: every matrix of every partition changes
+        by_part, total = tl.calculate()
+        if dist is not None:
+            buf.copy_(torch.from_numpy(by_part))
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            total = float(buf.sum().item())
+        return total
+
+    lnl0 = step(0)
+    for i in range(args.warmup):
+        step(i)
+    tl.b.kernelTimer(True)
+    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
+    stats = tl.b.walkStats()
+    kernel_ms, _ = tl.b.kernelTimer(False)
+    out = None
+    if rank == 0:
+        p_, c_ = local_pw.pattern_count, tl.C
+        kernel_s = kernel_ms * 1e-3 / max(1, args.steps)
+        # every partition's op touches only its own pattern range: bytes = sum over partitions
+        moved = 0.0
+        per_part = {key: v / max(1, args.steps) / k for key, v in stats.items()}
+        for w in local_pw.parts:
+            moved += moved_bytes(per_part, w.pattern_count, c_, 4)
+        alg = sum(prune_bytes_per_eval(w) for w in local_pw.parts)
+        achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_partitioned(bm, pw)
+        out = {
+            "metric": "full-tree lnL evals/sec", "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d taxa, unique patterns per partition %s, 4 states, %d rate categories, one instance, "
+                                   "updatePartialsByPartition, new branch rates every step" % (pw.name, pw.tip_count, pw.pattern_counts, c_),
+                       "patterns_per_gpu": p_, "parallelism": "pattern-shard x%d of every partition + 1 all-reduce of %d doubles" % (world, k)},
+            "roofline": {"bound": "hbm", "kernel": "k_walk4", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": "not profiled (latency-bound: %d patterns)" % p_,
+                         "bytes_per_eval": int(moved), "algorithmic_bytes_per_eval": int(alg),
+                         "kernel_us_per_eval": round(kernel_s * 1e6, 2), "kernel_time_fraction_of_step": round(kernel_s * args.steps / elapsed, 4),
+                         "per_eval": {key: round(v / max(1, args.steps), 1) for key, v in stats.items()}},
+            "cpu_baseline": cpu, "lnL": lnl, "lnL_first_eval": lnl0, "kernel_source_hash": kernel_source_hash(),
+            "evaluations_total": tl.evaluations, "workload_generation_s": round(t_gen, 1),
+        }
+        print(json.dumps(out), flush=True)
+    tl.close()
     return out
 
 
@@ -258,7 +415,10 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     from beast_mcmc_amd.inputs.synth import Workload
-    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
+    if not sample:                                            # ~10-20 s of CPU work whatever the state count
+        per_pattern = wl.tip_count * wl.category_count * wl.state_count * wl.state_count
+        sample = int(max(500, min(20000, 6.4e11 / per_pattern)))
     n = min(sample, wl.pattern_count)
     idx = np.sort(np.random.default_rng(0).choice(wl.pattern_count, size=n, replace=False))
     sub = Workload(wl.name + "-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
@@ -267,7 +427,6 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
     # a container's CPU quota can be far below the core count OpenMP sees: helpers.oracle_library() caps the oracle's
     # thread count to helpers.granted_cpus(), so the baseline runs on what the box actually grants
     threads = lib.lib.oracle_threads()
-    from beast_mcmc_amd.treelikelihood import RESCALE_DYNAMIC
     o = BeagleTreeLikelihood(sub, library=lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
     o.getLogLikelihood()
     o.makeDirty(); o.getLogLikelihood()                       # steady state (read-mode scalers), as on the GPU
@@ -280,11 +439,16 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
         if dt > 10.0 or reps >= 200:
             break
     site_cpu = o.getSiteLogLikelihoods()
-    site_gpu = gpu_tl.getSiteLogLikelihoods()[idx]
+    g = gpu_tl.local if hasattr(gpu_tl, "local") else gpu_tl
+    g.storeState()
+    g.set_substitution_model(wl.eig, wl.freqs)                # the unperturbed model, as the oracle ran
+    g.set_site_model(wl.cat_rates, wl.cat_weights)
+    gpu_tl.getLogLikelihood()
+    site_gpu = g.getSiteLogLikelihoods()[idx]
     rel = float(np.max(np.abs(site_gpu - site_cpu) / np.abs(site_cpu)))
     o.close()
     sample_evals_per_s = reps / dt
-    # the same port on ONE core (SURVEY 8d asks for both): a tenth of the sample, at most ~10 s
+    # the same port on ONE core (SURVEY 8d asks for both): a tenth of the sample, at most ~8 s
     n1 = max(1, n // 10)
     sub1 = Workload(wl.name + "-sample1", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
                     np.ascontiguousarray(wl.tip_states[:, idx[:n1]]), wl.weights[idx[:n1]], wl.state_count)
@@ -312,6 +476,33 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
             "single_core_value": round(one_core, 5),
             "single_core_sample": "%d patterns, %d evaluations in %.1f s on 1 thread" % (n1, reps1, dt1),
             "gpu_vs_cpu_site_lnL_max_rel_err": rel}
+
+
+def cpu_baseline_partitioned(bm, pw):
+    """Config E on the host: the oracle evaluates the four partitions one after the other (whole alignment: it is small)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_NONE
+    lib = helpers.oracle_library()
+    threads = lib.lib.oracle_threads()
+    tls = [BeagleTreeLikelihood(w, library=lib, rescaling=RESCALE_NONE, delay_rescaling=False) for w in pw.parts]
+    for t in tls:
+        t.getLogLikelihood()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        for t, w in zip(tls, pw.parts):
+            t.set_substitution_model(w.eig, w.freqs)
+            t.getLogLikelihood()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 200:
+            break
+    for t in tls:
+        t.close()
+    return {"value": round(reps / dt, 4), "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": "the whole alignment (%d patterns in 4 partitions, %d taxa), %d evaluations in %.1f s on %d OpenMP threads"
+                      % (pw.pattern_count, pw.tip_count, reps, dt, threads),
+            "host_cpus": _host_cpu_info()}
 
 
 if __name__ == "__main__":

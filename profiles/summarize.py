@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of profiles/collect.sh (gpurun_out/prof_<round>/) into the tracked summaries:
+"""Turn the raw rocprofv3 output of profiles/collect.sh (gpurun_out/prof_<round><tag>/) into the tracked summaries:
 
-  profiles/<round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (verbatim copy)
-  profiles/<round>_prune_launches.csv    one row per pruning launch of the last evaluation: ops in the launch, duration,
-                                         HBM read / write bytes from the two PMC passes
-  profiles/<round>_bench.json            the bench line printed by the profiled command
-  profiles/hbm_traffic.json              what bench.py reports as roofline.traffic (bytes per launch of the dominant kernel)
+  profiles/<round><tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim copy)
+  profiles/<round><tag>_bench.json         the bench line printed by the profiled command
+  profiles/<round><tag>_sq_counters.txt    where the hot kernel's wave cycles go (SQ_* pass)
+  profiles/hbm_traffic.json                per configuration: HBM bytes per evaluation of the hot kernel — what bench.py
+                                           reports as roofline.traffic, keyed to the build by a hash of the kernel sources
 
-HBM bytes from counters (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1024 B;
-on gfx950 FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read (128-B requests tallied
-at 64 B), so the read side is DOUBLED; WRITE_SIZE is used as is.  Both corrections are cross-checked below against the
-algorithmic byte count of the same launches (they agree to <1 %, which also shows the Infinity Cache absorbs nothing
-at this working-set size).
-"""
+HBM bytes from counters (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in units of 1024 B; on gfx950
+FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so the
+read side is DOUBLED; WRITE_SIZE is used as is.  (Round 1 cross-checked both corrections against a kernel whose traffic is
+known: 1.0005 x the algorithmic byte count.)  Bytes per evaluation = sum over every dispatch of the hot kernel in the
+profiled run / evaluations the run executed (bench line: evaluations_total)."""
 import csv
+import glob
 import json
 import os
 import shutil
@@ -22,55 +22,62 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def counter_rows(src, sub, kernel):
+    out = []
+    for p in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if kernel in r["Kernel_Name"]:
+                out.append(r)
+    return out
+
+
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    kernel = sys.argv[2] if len(sys.argv) > 2 else "k_prune4"
-    src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    config = sys.argv[2] if len(sys.argv) > 2 else "A"
+    kernel = sys.argv[3] if len(sys.argv) > 3 else "k_walk4"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     out = os.path.join(ROOT, "profiles")
-    shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(out, rnd + "_kernel_stats.csv"))
-    bench = json.loads(open(os.path.join(src, "bench_kt.json")).read().strip().splitlines()[-1])
-    json.dump(bench, open(os.path.join(out, rnd + "_bench.json"), "w"), indent=1)
-    per_eval = int(round(bench["roofline"]["launches_per_eval"]))
+    for p in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(p, os.path.join(out, tag + "_kernel_stats.csv"))
 
-    trace = [r for r in csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_trace.csv"))) if kernel in r["Kernel_Name"]]
+    def bench_line(name):
+        return json.loads(open(os.path.join(src, name)).read().strip().splitlines()[-1])
 
-    def pmc(sub, name):
-        path = os.path.join(src, sub, sub + "_counter_collection.csv")
-        return [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
-
-    fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
-    last_t, last_f, last_w = trace[-per_eval:], fetch[-per_eval:], write[-per_eval:]
-    rows = []
-    for t, f, w in zip(last_t, last_f, last_w):
-        dur = (int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3
-        rd = 2.0 * float(f["Counter_Value"]) * 1024.0
-        wr = float(w["Counter_Value"]) * 1024.0
-        rows.append({"ops_in_launch": int(t["Grid_Size_Y"]), "duration_us": round(dur, 2),
-                     "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
-                     "GBps": round((rd + wr) / dur / 1e3, 1), "vgpr": t["VGPR_Count"], "lds_bytes": t["LDS_Block_Size"]})
-    with open(os.path.join(out, rnd + "_prune_launches.csv"), "w", newline="") as fh:
-        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        w.writerows(rows)
-    rd = sum(r["hbm_read_bytes"] for r in rows)
-    wr = sum(r["hbm_write_bytes"] for r in rows)
-    dur = sum(r["duration_us"] for r in rows)
-    alg = bench["roofline"]["algorithmic_bytes_per_launch"] * per_eval
-    summary = {
-        "round": rnd, "kernel": kernel, "launches_per_eval": per_eval,
-        "bytes_per_launch": int((rd + wr) / per_eval),
-        "read_bytes_per_eval": rd, "write_bytes_per_eval": wr, "algorithmic_bytes_per_eval": alg,
-        "traffic_over_algorithmic": round((rd + wr) / alg, 4),
-        "kernel_time_us_per_eval": round(dur, 1), "HBM_GBps_from_counters": round((rd + wr) / dur / 1e3, 1),
-        "corrections": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), x1024 B per unit; WRITE_SIZE x1024",
-        "source": "gpurun_out/prof_%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)" % rnd,
-    }
-    json.dump(summary, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
-    json.dump(summary, open(os.path.join(out, rnd + "_hbm_traffic.json"), "w"), indent=1)
-    print(json.dumps(summary, indent=1))
-    avg = sum((int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) for t in trace) / len(trace) / 1e3
-    print("kernel-trace average %s launch: %.2f us over %d launches; bench.py HIP-event average: %.2f us"
-          % (kernel, avg, len(trace), bench["roofline"]["avg_launch_us"]))
+    bench = bench_line("bench_kt.json")
+    json.dump(bench, open(os.path.join(out, tag + "_bench.json"), "w"), indent=1)
+    rec = {"round": tag, "kernel": kernel, "kernel_source_hash": bench.get("kernel_source_hash")}
+    for sub, name, factor in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
+        rows = [r for r in counter_rows(src, sub, kernel) if r["Counter_Name"] == name]
+        b = bench_line("bench_%s.json" % sub)
+        evals = max(1, int(b.get("evaluations_total", 1)))
+        total = sum(float(r["Counter_Value"]) for r in rows) * 1024.0 * factor
+        rec["%s_bytes_per_eval" % ("read" if sub == "fetch" else "write")] = int(total / evals)
+        rec["%s_dispatches" % sub] = len(rows)
+        rec["%s_evaluations" % sub] = evals
+    rec["bytes_per_eval"] = rec["read_bytes_per_eval"] + rec["write_bytes_per_eval"]
+    rec["design_bytes_per_eval"] = bench["roofline"].get("bytes_per_eval")
+    rec["algorithmic_bytes_per_eval"] = bench["roofline"].get("algorithmic_bytes_per_eval")
+    rec["kernel_us_per_eval_unprofiled"] = bench["roofline"].get("kernel_us_per_eval")
+    rec["HBM_GBps_from_counters"] = round(rec["bytes_per_eval"] / (bench["roofline"]["kernel_us_per_eval"] * 1e-6) / 1e9, 1)
+    rec["corrections"] = "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), x1024 B per unit; WRITE_SIZE x1024"
+    rec["source"] = "gpurun_out/prof_%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)" % tag
+    path = os.path.join(out, "hbm_traffic.json")
+    allrec = json.load(open(path)) if os.path.exists(path) else {}
+    if "kernel" in allrec:          # round-1 layout (one flat record): start over
+        allrec = {}
+    allrec[config] = rec
+    json.dump(allrec, open(path, "w"), indent=1)
+    # SQ pass
+    agg = {}
+    for r in counter_rows(src, "sq", kernel):
+        agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if agg:
+        with open(os.path.join(out, tag + "_sq_counters.txt"), "w") as fh:
+            fh.write("# rocprofv3 --pmc SQ_* -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (config %s); sums over the dispatches of %s\n" % (config, kernel))
+            wc = sum(agg.get("SQ_WAVE_CYCLES", [0])) or 1.0
+            for k, v in sorted(agg.items()):
+                fh.write("%-24s %.4g   (%.3f of SQ_WAVE_CYCLES)\n" % (k, sum(v), sum(v) / wc))
+    print(json.dumps(rec, indent=1))
 
 
 if __name__ == "__main__":
