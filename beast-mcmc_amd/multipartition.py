@@ -57,31 +57,51 @@ class MultiPartitionTreeLikelihood:
     def set_branch_rates(self, rates):
         self.branch_rates = np.asarray(rates, dtype=np.float64)
 
+    def _static_tables(self):
+        """Index tables of both buffer flips, built once: the per-evaluation work of the host is then a handful of array
+        copies (the reference rebuilds its operation arrays in Java at a comparable cost per node)."""
+        tree, K, T, nodes = self.tree, self.K, self.T, self.nodes
+        branch = np.array([n for n in range(nodes) if n != tree.root], dtype=np.int64)
+        self._branch = branch
+        self._lens0 = np.array([tree.branch_length(int(n)) for n in branch])
+        self._eig_idx = np.repeat(np.arange(K, dtype=np.int32), len(branch))
+        self._mat_idx = [np.concatenate([(k * nodes + branch) * 2 + f for k in range(K)]).astype(np.int32) for f in (0, 1)]
+        order = np.array(self.order, dtype=np.int64)
+        left = np.array([int(tree.left[n]) for n in order]); right = np.array([int(tree.right[n]) for n in order])
+        self._scale_idx = (order - T).astype(np.int32)
+        self._ops = {}
+        for pf in (0, 1):                               # partials flip of the internal nodes (all flip together here)
+            pb = lambda x: np.where(x < T, x, T + 2 * (x - T) + pf)
+            for mf in (0, 1):
+                ops = np.empty((len(order), K, 9), dtype=np.int32)
+                for k in range(K):
+                    ops[:, k, 0] = pb(order)
+                    ops[:, k, 1] = (order - T) if self.always_rescale else NONE
+                    ops[:, k, 2] = NONE
+                    ops[:, k, 3] = pb(left); ops[:, k, 4] = (k * nodes + left) * 2 + mf
+                    ops[:, k, 5] = pb(right); ops[:, k, 6] = (k * nodes + right) * 2 + mf
+                    ops[:, k, 7] = k; ops[:, k, 8] = NONE
+                self._ops[(pf, mf)] = (np.ascontiguousarray(ops.reshape(-1)), np.ascontiguousarray(ops[:, 0, :7].reshape(-1)))
+
     def calculate(self):
         """One full evaluation; returns (per-partition log-likelihoods, total)."""
         b, tree, K, T = self.b, self.tree, self.K, self.T
+        if not hasattr(self, "_ops"):
+            self._static_tables()
         self.mflip ^= 1
         self.flip[T:] ^= 1
-        eig_idx, rate_idx, mat_idx, lens = [], [], [], []
+        pf = int(self.flip[T])
         for k, w in enumerate(self.pw.parts):
             b.setEigenDecomposition(k, w.eig.evec, w.eig.ievc, w.eig.evals)
             b.setCategoryRatesWithIndex(k, w.cat_rates)
-            for n in range(self.nodes):
-                if n != tree.root:
-                    eig_idx.append(k); rate_idx.append(k); mat_idx.append(self.mbuf(k, n))
-                    lens.append(tree.branch_length(n) * self.branch_rates[n])
-        b.updateTransitionMatricesWithMultipleModels(eig_idx, rate_idx, mat_idx, None, None, lens, len(lens))
-        ops, scale_idx = [], []
-        for n in self.order:
-            l, r = int(tree.left[n]), int(tree.right[n])
-            ws = (n - T) if self.always_rescale else NONE
-            for k in range(K):
-                ops += [self.pbuf(n), ws, NONE, self.pbuf(l), self.mbuf(k, l), self.pbuf(r), self.mbuf(k, r), k, NONE]
-            scale_idx.append(n - T)
+        lens = np.tile(self._lens0 * self.branch_rates[self._branch], K)
+        b.updateTransitionMatricesWithMultipleModels(self._eig_idx, self._eig_idx, self._mat_idx[self.mflip], None, None, lens, len(lens))
+        ops9, ops7 = self._ops[(pf, self.mflip)]
+        scale_idx = self._scale_idx
         if K > 1:
-            b.updatePartialsByPartition(ops, len(ops) // 9)
+            b.updatePartialsByPartition(ops9, len(ops9) // 9)
         else:
-            b.updatePartials([x for i in range(0, len(ops), 9) for x in ops[i:i + 7]], len(ops) // 9, NONE)
+            b.updatePartials(ops7, len(ops7) // 7, NONE)
         cum = (T - 1) if self.always_rescale else NONE
         if self.always_rescale:
             for k in range(K):
