@@ -232,6 +232,14 @@ class Beagle:
         assert a.size >= self.patternCount * self.stateCount * self.categoryCount
         self._check("setPartials", self._f["SetPartials"](self.instance, bufferIndex, _dp(a)))
 
+    @classmethod
+    def attach(cls, tl):
+        """This binding on the instance a host driver (treelikelihood.BeagleTreeLikelihood) already owns."""
+        raw = cls.__new__(cls)
+        raw.lib, raw._f, raw.instance = tl.engine, tl.engine.fn, tl.instance
+        raw.stateCount, raw.patternCount, raw.categoryCount = tl.state_count, tl.pattern_count, tl.category_count
+        return raw
+
     def getPartials(self, bufferIndex, scaleIndex=NONE):
         out = np.empty(self.categoryCount * self.patternCount * self.stateCount)
         self._check("getPartials", self._f["GetPartials"](self.instance, bufferIndex, scaleIndex, _dp(out)))

@@ -60,7 +60,7 @@ def build_engine(force=False):
         with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
             list(pool.map(_run, jobs))
     if jobs or force or _newer(out, objs):
-        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out])
+        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 
 

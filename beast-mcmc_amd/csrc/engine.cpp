@@ -21,8 +21,11 @@
 #include "../../include/beagle_mi355.h"
 #include "kernels.h"
 #include "planner.h"
+#include "sharded.h"
 
 using mi355::OpDesc;
+using mi355::shardedStates;
+using mi355::shardedCategories;
 
 namespace {
 
@@ -243,6 +246,13 @@ Resources* resources() {
             snprintf(buf, sizeof(buf), "device %d", d);
             r->names.push_back("AMD GPU");
         }
+        r->descs.push_back(buf);
+    }
+    if (n >= 1) {      // resource G+1: every GPU of the node behind one instance, patterns sharded (sharded.cpp)
+        char buf[256];
+        const int shards = mi355::shardedDeviceCountOverride() > 0 ? mi355::shardedDeviceCountOverride() : n;
+        snprintf(buf, sizeof(buf), "%d pattern shards over %d GPU(s) | one RCCL all-reduce of the log-likelihood per evaluation", shards, n);
+        r->names.push_back("all GPUs (pattern-sharded)");
         r->descs.push_back(buf);
     }
     for (size_t i = 0; i < r->names.size(); i++) {
@@ -948,6 +958,10 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
     if (!in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) ||
         badIndex(fIdx, in->eigenCount) || (part >= 0 && badIndex(part, in->partitionCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
     const int pStart = part < 0 ? 0 : in->partStart[part], pEnd = part < 0 ? in->P : in->partEnd[part];
+    if (pEnd <= pStart) {                                 // an empty partition (a shard that holds none of its patterns) contributes 0
+        HIP_TRY(hipMemsetAsync(dOut, 0, sizeof(double), in->stream));
+        return 0;
+    }
     const double* cum = nullptr; int cumRaw = 0;
     if (cumIdx != BEAGLE_OP_NONE) {
         if (badIndex(cumIdx, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -991,6 +1005,18 @@ void fromTiled(const Instance* in, const double* tiled, double* api) {
 
 }  // namespace
 
+// per-partition root sums of ONE (single-GPU) instance left on the device: deviceOut[k], k < partitionCount
+static int rootByPartitionDevice(int instance, const int* bufferIndices, const int* categoryWeightsIndices, const int* stateFrequenciesIndices,
+                                 const int* cumulativeScaleIndices, const int* partitionIndices, int partitionCount, double* deviceOut) {
+    GET_INSTANCE(instance);
+    for (int k = 0; k < partitionCount; k++) {
+        int rc = rootEnqueue(in, bufferIndices[k], categoryWeightsIndices[k], stateFrequenciesIndices[k], cumulativeScaleIndices[k],
+                             partitionIndices[k], deviceOut + k);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" {
 
 const char* beagleGetVersion(void) { return "4.0.0-mi355"; }
@@ -1020,8 +1046,13 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     if (resourceList == nullptr || resourceCount <= 0) {
         if (res->gpuCount > 0) device = 0;
     } else {
-        for (int i = 0; i < resourceCount && device < 0; i++)
+        for (int i = 0; i < resourceCount && device < 0; i++) {
             if (resourceList[i] >= 1 && resourceList[i] <= res->gpuCount) device = resourceList[i] - 1;
+            else if (res->gpuCount > 0 && resourceList[i] == res->gpuCount + 1)       // "all GPUs": the pattern-sharded instance
+                return mi355::shardedCreate(res->gpuCount, tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount,
+                                            eigenBufferCount, matrixBufferCount, categoryCount, scaleBufferCount, preferenceFlags,
+                                            requirementFlags, returnInfo);
+        }
     }
     if (device < 0) return BEAGLE_ERROR_NO_RESOURCE;
     if (hipSetDevice(device) != hipSuccess) return BEAGLE_ERROR_NO_RESOURCE;
@@ -1112,6 +1143,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
 }
 
 int beagleFinalizeInstance(int instance) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedFinalize(instance); }
     Instance* in = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -1124,16 +1156,19 @@ int beagleFinalizeInstance(int instance) {
 }
 
 int beagleSetCPUThreadCount(int instance, int threadCount) {
+    if (mi355::isShardedHandle(instance)) { return BEAGLE_SUCCESS; }
     (void)threadCount;
     return lookup(instance) ? BEAGLE_SUCCESS : BEAGLE_ERROR_UNINITIALIZED_INSTANCE;   // no-op on a GPU instance
 }
 
 int beagleSetPatternWeights(int instance, const double* w) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternDoubles(instance, w, 1, 1, [&](int h, const double* v) { return beagleSetPatternWeights(h, v); }); }
     GET_INSTANCE(instance);
     return upload(in, in->patternWeights, w, (size_t)in->P * sizeof(double));
 }
 
 int beagleSetPatternPartitions(int instance, int partitionCount, const int* partitions) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternInts(instance, partitions, [&](int h, const int* v) { return beagleSetPatternPartitions(h, partitionCount, v); }); }
     GET_INSTANCE(instance);
     if (partitionCount < 1) return BEAGLE_ERROR_OUT_OF_RANGE;
     for (int x = 0; x < in->partialsCount; x++) { int rcv = materializeVirtual(in, x); if (rcv) return rcv; }   // whole-range definitions
@@ -1156,6 +1191,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
 }
 
 int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternInts(instance, inStates, [&](int h, const int* v) { return beagleSetTipStates(h, tipIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->tipCount) || badIndex(tipIndex, in->partialsCount) || tipIndex >= in->compactCount)
         return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1168,6 +1204,7 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
 }
 
 int beagleGetTipStates(int instance, int tipIndex, int* outStates) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternInts(instance, outStates, [&](int h, int* v) { return beagleGetTipStates(h, tipIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->partialsCount) || !in->tipStates[tipIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
     std::vector<uint8_t> s(in->P);
@@ -1177,6 +1214,7 @@ int beagleGetTipStates(int instance, int tipIndex, int* outStates) {
 }
 
 int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternDoubles(instance, inPartials, shardedStates(instance), 1, [&](int h, const double* v) { return beagleSetTipPartials(h, tipIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;
@@ -1202,6 +1240,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
 }
 
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternDoubles(instance, inPartials, shardedStates(instance), shardedCategories(instance), [&](int h, const double* v) { return beagleSetPartials(h, bufferIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeTipUsers(in, bufferIndex); if (rc) return rc;
@@ -1217,6 +1256,7 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
 }
 
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternDoubles(instance, outPartials, shardedStates(instance), shardedCategories(instance), [&](int h, double* v) { return beagleGetPartials(h, bufferIndex, scaleIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeVirtual(in, bufferIndex); if (rc) return rc;
@@ -1245,6 +1285,7 @@ int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* out
 }
 
 int beagleGetLogScaleFactors(int instance, int scaleIndex, double* out) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternDoubles(instance, out, 1, 1, [&](int h, double* v) { return beagleGetLogScaleFactors(h, scaleIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(scaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = ensureScale(in, scaleIndex); if (rc) return rc;
@@ -1267,6 +1308,7 @@ static int uploadIfChanged(Instance* in, std::vector<double>& shadow, std::vecto
 }
 
 int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, const double* Uinv, const double* lambda) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetEigenDecomposition(h, eigenIndex, U, Uinv, lambda); }); }
     GET_INSTANCE(instance);
     if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t S = in->S, stride = 2 * S * S + S;
@@ -1278,18 +1320,21 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, c
 }
 
 int beagleSetStateFrequencies(int instance, int idx, const double* f) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetStateFrequencies(h, idx, f); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shFreqs, in->okFreqs, in->eigenCount, idx, in->S, in->freqs + (size_t)idx * in->S, f);
 }
 
 int beagleSetCategoryWeights(int instance, int idx, const double* w) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetCategoryWeights(h, idx, w); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shWeights, in->okWeights, in->eigenCount, idx, in->C, in->weights + (size_t)idx * in->C, w);
 }
 
 int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetCategoryRatesWithIndex(h, idx, r); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shRates, in->okRates, in->eigenCount, idx, in->C, in->rates + (size_t)idx * in->C, r);
@@ -1298,6 +1343,7 @@ int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
 int beagleSetCategoryRates(int instance, const double* r) { return beagleSetCategoryRatesWithIndex(instance, 0, r); }
 
 int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMatrix, double paddedValue) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetTransitionMatrix(h, matrixIndex, inMatrix, paddedValue); }); }
     (void)paddedValue;
     GET_INSTANCE(instance);
     if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1306,6 +1352,7 @@ int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMat
 }
 
 int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix) {
+    if (mi355::isShardedHandle(instance)) { bool first = true; std::mutex mu; return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleGetTransitionMatrix(h, matrixIndex, outMatrix); }); }
     GET_INSTANCE(instance);
     if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t n = (size_t)in->C * in->S * in->S;
@@ -1313,6 +1360,7 @@ int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix) 
 }
 
 int beagleConvolveTransitionMatrices(int instance, const int* first, const int* second, const int* result, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleConvolveTransitionMatrices(h, first, second, result, count); }); }
     GET_INSTANCE(instance);
     if (count <= 0) return BEAGLE_SUCCESS;
     for (int k = 0; k < count; k++) {
@@ -1373,6 +1421,7 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
 int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* probabilityIndices,
                                    const int* firstDerivativeIndices, const int* secondDerivativeIndices,
                                    const double* edgeLengths, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdateTransitionMatrices(h, eigenIndex, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count); }); }
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     return transitionMatrices(in, nullptr, eigenIndex, nullptr, probabilityIndices, edgeLengths, count);
@@ -1381,6 +1430,7 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
 int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices, const int* categoryRateIndices,
                                    const int* probabilityIndices, const int* firstDerivativeIndices,
                                    const int* secondDerivativeIndices, const double* edgeLengths, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdateTransitionMatricesWithMultipleModels(h, eigenIndices, categoryRateIndices, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count); }); }
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (!eigenIndices || !categoryRateIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1388,16 +1438,19 @@ int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* ei
 }
 
 int beagleUpdatePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return runOperations(in, operations, operationCount, BEAGLE_OP_COUNT, cumulativeScaleIndex);
 }
 
 int beagleUpdatePartialsByPartition(int instance, const int* operations, int operationCount) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePartialsByPartition(h, operations, operationCount); }); }
     GET_INSTANCE(instance);
     return runOperations(in, operations, operationCount, BEAGLE_PARTITION_OP_COUNT, BEAGLE_OP_NONE);
 }
 
 int beagleWaitForPartials(int instance, const int* destinationPartials, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleWaitForPartials(h, destinationPartials, count); }); }
     (void)destinationPartials; (void)count;
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(in->stream));
@@ -1406,23 +1459,28 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
 }
 
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleAccumulateScaleFactors(h, scaleIndices, count, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, 0);
 }
 int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleAccumulateScaleFactorsByPartition(h, scaleIndices, count, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, partitionIndex);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleRemoveScaleFactors(h, scaleIndices, count, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, 0);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleRemoveScaleFactorsByPartition(h, scaleIndices, count, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, partitionIndex);
 }
 
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleResetScaleFactorsByPartition(h, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount) || badIndex(partitionIndex, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
@@ -1437,6 +1495,7 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
     return BEAGLE_SUCCESS;
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleResetScaleFactors(h, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
@@ -1448,6 +1507,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
 }
 
 int beagleCopyScaleFactors(int instance, int dest, int src) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleCopyScaleFactors(h, dest, src); }); }
     GET_INSTANCE(instance);
     if (badIndex(dest, in->scaleCount) || badIndex(src, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, dest); if (rc) return rc;
@@ -1462,6 +1522,13 @@ int beagleCopyScaleFactors(int instance, int dest, int src) {
 int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, const int* categoryWeightsIndices,
                                       const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
                                       int count, double* outSumLogLikelihood) {
+    if (mi355::isShardedHandle(instance)) { if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+        double v = 0.0;
+        const int rc = mi355::shardedRootReduce(instance, 1, [&](int h, double* dOut) { return beagleMi355CalculateRootLogLikelihoodsDevice(h, bufferIndices[0],
+                              categoryWeightsIndices[0], stateFrequenciesIndices[0], cumulativeScaleIndices[0], dOut); }, &v);
+        if (rc) return rc;
+        *outSumLogLikelihood = v;
+        return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS; }
     GET_INSTANCE(instance);
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;   // BEAST always passes 1 (BeagleTreeLikelihood.java:1038)
     // the reduction kernel writes the sum and then a sequence number into mapped host memory; the kernel is the last
@@ -1492,6 +1559,14 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
                                       const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
                                       const int* partitionIndices, int partitionCount, int count,
                                       double* outByPartition, double* outSum) {
+    if (mi355::isShardedHandle(instance)) { if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+        const int rc = mi355::shardedRootReduce(instance, partitionCount, [&](int h, double* dOut) { return rootByPartitionDevice(h, bufferIndices, categoryWeightsIndices,
+                              stateFrequenciesIndices, cumulativeScaleIndices, partitionIndices, partitionCount, dOut); }, outByPartition);
+        if (rc) return rc;
+        double tot = 0.0;
+        for (int k = 0; k < partitionCount; k++) tot += outByPartition[k];
+        *outSum = tot;
+        return (tot != tot) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS; }
     GET_INSTANCE(instance);
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (partitionCount < 1 || partitionCount > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1509,6 +1584,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
 }
 
 int beagleGetSiteLogLikelihoods(int instance, double* out) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternDoubles(instance, out, 1, 1, [&](int h, double* v) { return beagleGetSiteLogLikelihoods(h, v); }); }
     GET_INSTANCE(instance);
     return download(in, out, in->siteLogL, (size_t)in->P * sizeof(double));
 }
@@ -1516,6 +1592,7 @@ int beagleGetSiteLogLikelihoods(int instance, double* out) {
 // ---- outside SURVEY 8 (a)-(e): exported so the JNI shim links ---------------------------------
 // ---- pre-order partials and branch gradients ----
 int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* stateFrequenciesIndices, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetRootPrePartials(h, bufferIndices, stateFrequenciesIndices, count); }); }
     GET_INSTANCE(instance);
     for (int k = 0; k < count; k++) {
         const int b = bufferIndices[k], f = stateFrequenciesIndices[k];
@@ -1537,6 +1614,7 @@ int beagleSetDifferentialMatrix(int instance, int matrixIndex, const double* inM
 int beagleAddTransitionMatrices(int, const int*, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
 
 int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleTransposeTransitionMatrices(h, inputIndices, resultIndices, matrixCount); }); }
     GET_INSTANCE(instance);
     if (matrixCount <= 0) return BEAGLE_SUCCESS;
     std::vector<int> pairs((size_t)matrixCount * 2);
@@ -1553,6 +1631,7 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 }
 
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return runPreOperations(in, operations, operationCount, cumulativeScaleIndex);
 }
@@ -1561,6 +1640,15 @@ int beagleCalculateCrossProductDifferentials(int instance, const int* postBuffer
                                              const int* categoryRateIndices, const int* categoryWeightsIndices,
                                              const double* edgeLengths, int count,
                                              double* outSumDerivatives, double* outSumSquaredDerivatives) {
+    if (mi355::isShardedHandle(instance)) {
+        if (!outSumDerivatives) return BEAGLE_ERROR_OUT_OF_RANGE;
+        const int len = shardedStates(instance) * shardedStates(instance);
+        std::vector<double> tot(len, 0.0);
+        const int rc = mi355::shardedSumDoubles(instance, len, [&](int h, double* out) { return beagleCalculateCrossProductDifferentials(h, postBufferIndices,
+                              preBufferIndices, categoryRateIndices, categoryWeightsIndices, edgeLengths, count, out, outSumSquaredDerivatives); }, tot.data());
+        for (int k = 0; k < len && !rc; k++) outSumDerivatives[k] += tot[k];
+        return rc;
+    }
     GET_INSTANCE(instance);
     if (outSumSquaredDerivatives) return BEAGLE_ERROR_NO_IMPLEMENTATION;       // BEAST passes null
     if (!postBufferIndices || !preBufferIndices || !categoryRateIndices || !categoryWeightsIndices || !edgeLengths || !outSumDerivatives)
@@ -1573,6 +1661,26 @@ int beagleCalculateCrossProductDifferentials(int instance, const int* postBuffer
 int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
                                      const int* derivativeMatrixIndices, const int* categoryWeightsIndices, int count,
                                      double* outDerivatives, double* outSumDerivatives, double* outSumSquaredDerivatives) {
+    if (mi355::isShardedHandle(instance)) {
+        if (count <= 0) return BEAGLE_SUCCESS;
+        const int P = mi355::shardedPatternCount(instance), n = mi355::shardedShardCount(instance);
+        std::vector<std::vector<double>> per(n);
+        std::vector<int> handleOf(n, -1);
+        std::vector<double> tot((size_t)2 * count, 0.0);
+        std::mutex mu; int next = 0;
+        const int rc = mi355::shardedSumDoubles(instance, 2 * count, [&](int h, double* out) {
+            int k; { std::lock_guard<std::mutex> l(mu); k = next++; handleOf[k] = h; }
+            int a, b; mi355::shardedBoundsOfHandle(instance, h, &a, &b);
+            if (outDerivatives) per[k].assign((size_t)count * (b - a), 0.0);
+            const int r = beagleCalculateEdgeDifferentials(h, postBufferIndices, preBufferIndices, derivativeMatrixIndices, categoryWeightsIndices, count,
+                                                           outDerivatives ? per[k].data() : nullptr, out, out + count);
+            if (!r && outDerivatives)
+                for (int e = 0; e < count; e++) memcpy(outDerivatives + (size_t)e * P + a, &per[k][(size_t)e * (b - a)], (size_t)(b - a) * sizeof(double));
+            return r; }, tot.data());
+        if (rc) return rc;
+        for (int e = 0; e < count; e++) { if (outSumDerivatives) outSumDerivatives[e] = tot[e]; if (outSumSquaredDerivatives) outSumSquaredDerivatives[e] = tot[count + e]; }
+        return BEAGLE_SUCCESS;
+    }
     GET_INSTANCE(instance);
     if (!postBufferIndices || !preBufferIndices || !derivativeMatrixIndices || !categoryWeightsIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (badIndex(categoryWeightsIndices[0], in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1584,6 +1692,7 @@ int beagleUpdatePrePartialsByPartition(int, const int*, int) { return BEAGLE_ERR
 
 // ---- MI355X extensions -----------------------------------------------------------------------
 int beagleMi355SetStream(int instance, void* hipStream) {
+    if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(in->stream));
     in->ringHead = 0;
@@ -1593,12 +1702,14 @@ int beagleMi355SetStream(int instance, void* hipStream) {
 
 int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
                                                  int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut) {
+    if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
     GET_INSTANCE(instance);
     if (!deviceOut) return BEAGLE_ERROR_OUT_OF_RANGE;
     return rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
 }
 
 int beagleMi355Synchronize(int instance) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355Synchronize(h); }); }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(in->stream));
     in->ringHead = 0;
@@ -1606,6 +1717,14 @@ int beagleMi355Synchronize(int instance) {
 }
 
 int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* outLaunches) {
+    if (mi355::isShardedHandle(instance)) {             // the slowest shard's kernel time, the launches of all
+        std::mutex mu; double ms = 0.0; long launches = 0;
+        const int rc = mi355::shardedBroadcast(instance, [&](int h) { double m = 0.0; long l = 0; const int r = beagleMi355KernelTimer(h, enable, &m, &l);
+                                                                       std::lock_guard<std::mutex> g(mu); ms = std::max(ms, m); launches += l; return r; });
+        if (outMillis) *outMillis = ms;
+        if (outLaunches) *outLaunches = launches;
+        return rc;
+    }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(in->stream));
     in->ringHead = 0;
@@ -1625,6 +1744,10 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
 }
 
 int beagleMi355WalkStats(int instance, long* out8) {
+    if (mi355::isShardedHandle(instance)) {             // counters of shard 0 (every shard runs the same programs)
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkStats(h, out8); });
+    }
     Instance* in = lookup(instance);
     if (!in || !out8) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out8[0] = in->statMicroOps; out8[1] = in->statStored; out8[2] = in->statMemReads; out8[3] = in->statTipReads;
@@ -1633,6 +1756,11 @@ int beagleMi355WalkStats(int instance, long* out8) {
 }
 
 long beagleMi355DeviceBytes(int instance) {
+    if (mi355::isShardedHandle(instance)) {
+        std::mutex mu; long total = 0;
+        mi355::shardedBroadcast(instance, [&](int h) { const long b = beagleMi355DeviceBytes(h); std::lock_guard<std::mutex> l(mu); total += b; return 0; });
+        return total;
+    }
     Instance* in = lookup(instance);
     return in ? (long)in->deviceBytes : -1;
 }

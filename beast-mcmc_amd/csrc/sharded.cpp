@@ -1,0 +1,313 @@
+// sharded.cpp — the pattern-sharded, multi-GPU instance INSIDE the library: resource G+1 = "all G GPUs of this node".
+//
+// BEAST already knows how to use several GPUs from one JVM: -beagle_instances G -beagle_order 1,..,G makes G
+// BeagleDataLikelihoodDelegates over contiguous pattern blocks (src/dr/evolution/alignment/Patterns.java:142-167), a Java
+// thread pool evaluates them and Java adds the G values (src/dr/evomodelxml/treedatalikelihood/TreeDataLikelihoodParser.java:
+// 205-278, src/dr/inference/model/CompoundLikelihood.java:202-214).  This file offers the same split behind ONE instance
+// handle (SURVEY 8b "Resource numbering", 8e): the caller asks for resource G+1 and drives it exactly like a single-GPU
+// instance; the library
+//   * cuts the P unique patterns into G contiguous blocks with BEAST's own block sizes (first P % G blocks get one more),
+//   * keeps one ordinary engine instance per GPU for its block, each with its own HIP stream, driven by its own host thread
+//     (the host-side planning of one evaluation takes about as long as a 12 500-pattern shard's kernels, so G shards
+//     prepared one after the other by one thread would serialise the GPUs),
+//   * replicates everything that is KB-sized (tree operations, eigen systems, matrices, rates, weights, frequencies),
+//   * slices what is indexed by pattern (tip states / partials, pattern weights, partition map) on the way in and gathers
+//     it on the way out (site log-likelihoods, partials, scale factors),
+//   * and reduces the per-shard root log-likelihoods with ONE ncclAllReduce(sum, ncclDouble, count = 1, or partitionCount
+//     for ...ByPartition) per evaluation over RCCL/xGMI, issued on each shard's stream right behind its reduction kernel;
+//     the host reads the result from shard 0.  Deterministic: RCCL's ring order is fixed for a fixed communicator.
+// Gradient sums (edge differentials, cross products) are small host-side sums of what each shard returns.
+//
+// BEAGLE_MI355_SHARDS=n (tests on a one-GPU box): n shards placed round-robin on the visible devices.  RCCL needs distinct
+// devices per rank, so when two shards share a GPU the G partial sums are added on the host instead, in shard order.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/beagle_mi355.h"
+#include "sharded.h"
+
+namespace mi355 {
+namespace {
+
+// one host thread per shard: runs the closures the API thread posts, in order
+class Worker {
+public:
+    Worker() : thread_([this] { loop(); }) {}
+    ~Worker() {
+        { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+        cv_.notify_all();
+        thread_.join();
+    }
+    void post(std::function<int()> f) {
+        { std::lock_guard<std::mutex> l(mu_); task_ = std::move(f); hasTask_ = true; done_ = false; }
+        cv_.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [this] { return done_; });
+        return rc_;
+    }
+private:
+    void loop() {
+        for (;;) {
+            std::function<int()> f;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [this] { return hasTask_ || stop_; });
+                if (stop_) return;
+                f = std::move(task_); hasTask_ = false;
+            }
+            const int rc = f();
+            { std::lock_guard<std::mutex> l(mu_); rc_ = rc; done_ = true; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<int()> task_;
+    bool hasTask_ = false, done_ = true, stop_ = false;
+    int rc_ = 0;
+    std::thread thread_;
+};
+
+struct Shard {
+    int handle = -1, device = 0;
+    int pStart = 0, pEnd = 0;
+    hipStream_t stream = nullptr;
+    double* dResult = nullptr;          // device buffer the shard's root sums land in (all-reduced in place)
+    ncclComm_t comm = nullptr;
+    Worker* worker = nullptr;
+};
+
+struct Sharded {
+    std::vector<Shard> shards;
+    int tipCount = 0, S = 0, P = 0, C = 0;
+    bool useRccl = false;
+    double* hResult = nullptr;          // pinned
+    std::string name;
+};
+
+std::mutex g_mu;
+std::vector<Sharded*> g_sharded;
+
+Sharded* find(int handle) {
+    std::lock_guard<std::mutex> l(g_mu);
+    const int i = handle - SHARD_HANDLE_BASE;
+    if (i < 0 || i >= (int)g_sharded.size()) return nullptr;
+    return g_sharded[i];
+}
+
+// run f(shard index) on every shard's thread; first non-zero return code wins
+int forAll(Sharded* sh, const std::function<int(int)>& f) {
+    const int n = (int)sh->shards.size();
+    for (int k = 0; k < n; k++) sh->shards[k].worker->post([&f, k] { return f(k); });
+    int rc = 0;
+    for (int k = 0; k < n; k++) { const int r = sh->shards[k].worker->wait(); if (r && !rc) rc = r; }
+    return rc;
+}
+
+#define GET_SHARDED(h) Sharded* sh = find(h); if (!sh) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE
+
+}  // namespace
+
+int shardedDeviceCountOverride() {
+    const char* e = getenv("BEAGLE_MI355_SHARDS");
+    return e ? atoi(e) : 0;
+}
+
+int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount, int patternCount,
+                  int eigenBufferCount, int matrixBufferCount, int categoryCount, int scaleBufferCount, long preferenceFlags,
+                  long requirementFlags, BeagleInstanceDetails* returnInfo) {
+    int n = shardedDeviceCountOverride();
+    if (n <= 0) n = gpuCount;
+    n = std::max(1, std::min(n, patternCount));
+    Sharded* sh = new Sharded();
+    sh->tipCount = tipCount; sh->S = stateCount; sh->P = patternCount; sh->C = categoryCount;
+    sh->useRccl = n <= gpuCount;                       // distinct devices: the all-reduce runs over RCCL
+    const int div = patternCount / n, rem = patternCount % n;      // Patterns.java:142-167
+    int start = 0, rc = 0;
+    for (int k = 0; k < n && !rc; k++) {
+        Shard s;
+        s.device = k % gpuCount;
+        s.pStart = start; s.pEnd = start + div + (k < rem ? 1 : 0); start = s.pEnd;
+        const int res = s.device + 1;
+        s.handle = beagleCreateInstance(tipCount, partialsBufferCount, compactBufferCount, stateCount, s.pEnd - s.pStart, eigenBufferCount,
+                                        matrixBufferCount, categoryCount, scaleBufferCount, &res, 1, preferenceFlags, requirementFlags, nullptr);
+        if (s.handle < 0) { rc = s.handle; break; }
+        if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void**)&s.dResult, 4096) != hipSuccess) { rc = BEAGLE_ERROR_OUT_OF_MEMORY; sh->shards.push_back(s); break; }
+        rc = beagleMi355SetStream(s.handle, s.stream);
+        s.worker = new Worker();
+        sh->shards.push_back(s);
+    }
+    if (!rc && hipHostMalloc((void**)&sh->hResult, 4096, hipHostMallocDefault) != hipSuccess) rc = BEAGLE_ERROR_OUT_OF_MEMORY;
+    if (!rc && sh->useRccl) {
+        std::vector<int> devs(n);
+        std::vector<ncclComm_t> comms(n);
+        for (int k = 0; k < n; k++) devs[k] = sh->shards[k].device;
+        if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) rc = BEAGLE_ERROR_GENERAL;
+        else for (int k = 0; k < n; k++) sh->shards[k].comm = comms[k];
+    }
+    if (rc) {
+        for (Shard& s : sh->shards) { if (s.handle >= 0) beagleFinalizeInstance(s.handle); delete s.worker; }
+        delete sh;
+        return rc;
+    }
+    sh->name = std::to_string(n) + " x MI355X, patterns sharded" + (sh->useRccl ? " (RCCL all-reduce)" : " (host sum)");
+    int handle;
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        g_sharded.push_back(sh);
+        handle = SHARD_HANDLE_BASE + (int)g_sharded.size() - 1;
+    }
+    if (returnInfo) {
+        returnInfo->resourceNumber = gpuCount + 1;
+        returnInfo->resourceName = (char*)sh->name.c_str();
+        returnInfo->implName = (char*)"HIP-gfx950-fp64-sharded";
+        returnInfo->implDescription = (char*)"one engine instance per GPU over contiguous pattern blocks, one RCCL all-reduce per evaluation";
+        returnInfo->flags = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_COMPUTATION_SYNCH | BEAGLE_FLAG_EIGEN_REAL | BEAGLE_FLAG_SCALING_MANUAL |
+                            BEAGLE_FLAG_SCALERS_RAW | BEAGLE_FLAG_VECTOR_NONE | BEAGLE_FLAG_THREADING_NONE | BEAGLE_FLAG_PROCESSOR_GPU |
+                            BEAGLE_FLAG_PARALLELOPS_GRID;
+    }
+    return handle;
+}
+
+int shardedFinalize(int handle) {
+    Sharded* sh;
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        const int i = handle - SHARD_HANDLE_BASE;
+        if (i < 0 || i >= (int)g_sharded.size() || !g_sharded[i]) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+        sh = g_sharded[i]; g_sharded[i] = nullptr;
+    }
+    for (Shard& s : sh->shards) {
+        delete s.worker;
+        beagleFinalizeInstance(s.handle);
+        hipSetDevice(s.device);
+        if (s.comm) ncclCommDestroy(s.comm);
+        if (s.dResult) hipFree(s.dResult);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    if (sh->hResult) hipHostFree(sh->hResult);
+    delete sh;
+    return BEAGLE_SUCCESS;
+}
+
+int shardedShardCount(int handle) { Sharded* sh = find(handle); return sh ? (int)sh->shards.size() : -1; }
+
+int shardedBroadcast(int handle, const std::function<int(int)>& call) {
+    GET_SHARDED(handle);
+    return forAll(sh, [&](int k) { return call(sh->shards[k].handle); });
+}
+
+// ---- inputs indexed by pattern ---------------------------------------------------------------------------------------
+int shardedSetPerPatternInts(int handle, const int* v, const std::function<int(int, const int*)>& call) {
+    GET_SHARDED(handle);
+    return forAll(sh, [&](int k) { return call(sh->shards[k].handle, v + sh->shards[k].pStart); });
+}
+int shardedSetPerPatternDoubles(int handle, const double* v, int perPattern, int planes, const std::function<int(int, const double*)>& call) {
+    // v is [planes][P][perPattern]; a shard gets [planes][its patterns][perPattern]
+    GET_SHARDED(handle);
+    return forAll(sh, [&](int k) {
+        const Shard& s = sh->shards[k];
+        const size_t n = (size_t)(s.pEnd - s.pStart) * perPattern;
+        if (planes == 1) return call(s.handle, v + (size_t)s.pStart * perPattern);
+        std::vector<double> tmp(n * planes);
+        for (int c = 0; c < planes; c++) memcpy(&tmp[n * c], v + ((size_t)c * sh->P + s.pStart) * perPattern, n * sizeof(double));
+        return call(s.handle, tmp.data());
+    });
+}
+// ---- outputs indexed by pattern --------------------------------------------------------------------------------------
+int shardedGetPerPatternDoubles(int handle, double* out, int perPattern, int planes, const std::function<int(int, double*)>& call) {
+    GET_SHARDED(handle);
+    return forAll(sh, [&](int k) {
+        const Shard& s = sh->shards[k];
+        const size_t n = (size_t)(s.pEnd - s.pStart) * perPattern;
+        if (planes == 1) return call(s.handle, out + (size_t)s.pStart * perPattern);
+        std::vector<double> tmp(n * planes);
+        const int rc = call(s.handle, tmp.data());
+        for (int c = 0; c < planes && !rc; c++) memcpy(out + ((size_t)c * sh->P + s.pStart) * perPattern, &tmp[n * c], n * sizeof(double));
+        return rc;
+    });
+}
+int shardedGetPerPatternInts(int handle, int* out, const std::function<int(int, int*)>& call) {
+    GET_SHARDED(handle);
+    return forAll(sh, [&](int k) { return call(sh->shards[k].handle, out + sh->shards[k].pStart); });
+}
+
+// ---- the reduction: per-shard root sums -> one all-reduce -> host -----------------------------------------------------
+int shardedRootReduce(int handle, int count, const std::function<int(int shardHandle, double* deviceOut)>& enqueue, double* outValues) {
+    GET_SHARDED(handle);
+    if (count < 1 || count > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const int n = (int)sh->shards.size();
+    int rc = forAll(sh, [&](int k) { return enqueue(sh->shards[k].handle, sh->shards[k].dResult); });
+    if (rc) return rc;
+    if (sh->useRccl) {
+        // every rank's call sits on its shard's stream, right behind the kernels that produce its operand
+        if (ncclGroupStart() != ncclSuccess) return BEAGLE_ERROR_GENERAL;
+        for (int k = 0; k < n; k++) {
+            Shard& s = sh->shards[k];
+            if (hipSetDevice(s.device) != hipSuccess ||
+                ncclAllReduce(s.dResult, s.dResult, (size_t)count, ncclDouble, ncclSum, s.comm, s.stream) != ncclSuccess) { ncclGroupEnd(); return BEAGLE_ERROR_GENERAL; }
+        }
+        if (ncclGroupEnd() != ncclSuccess) return BEAGLE_ERROR_GENERAL;
+        Shard& s0 = sh->shards[0];
+        if (hipSetDevice(s0.device) != hipSuccess ||
+            hipMemcpyAsync(sh->hResult, s0.dResult, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s0.stream) != hipSuccess ||
+            hipStreamSynchronize(s0.stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+        for (int k = 1; k < n; k++) {                   // the other streams must have drained too before their staging rings are reused
+            if (hipSetDevice(sh->shards[k].device) != hipSuccess || hipStreamSynchronize(sh->shards[k].stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+        }
+        memcpy(outValues, sh->hResult, (size_t)count * sizeof(double));
+    } else {
+        std::vector<double> acc(count, 0.0), part(count);
+        for (int k = 0; k < n; k++) {
+            Shard& s = sh->shards[k];
+            if (hipSetDevice(s.device) != hipSuccess ||
+                hipMemcpyAsync(part.data(), s.dResult, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+                hipStreamSynchronize(s.stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+            for (int q = 0; q < count; q++) acc[q] += part[q];
+        }
+        memcpy(outValues, acc.data(), (size_t)count * sizeof(double));
+    }
+    for (int k = 0; k < n; k++) beagleMi355Synchronize(sh->shards[k].handle);     // resets the shards' staging rings
+    return BEAGLE_SUCCESS;
+}
+
+// per-shard host results that simply add up (gradient sums): call fills `len` doubles per shard
+int shardedSumDoubles(int handle, int len, const std::function<int(int shardHandle, double* out)>& call, double* outSum) {
+    GET_SHARDED(handle);
+    const int n = (int)sh->shards.size();
+    std::vector<std::vector<double>> part(n, std::vector<double>(len, 0.0));
+    int rc = forAll(sh, [&](int k) { return call(sh->shards[k].handle, part[k].data()); });
+    if (rc) return rc;
+    for (int q = 0; q < len; q++) { double a = 0.0; for (int k = 0; k < n; k++) a += part[k][q]; outSum[q] = a; }
+    return BEAGLE_SUCCESS;
+}
+
+void shardedBounds(int handle, int shard, int* pStart, int* pEnd) {
+    Sharded* sh = find(handle);
+    if (!sh || shard < 0 || shard >= (int)sh->shards.size()) { *pStart = *pEnd = 0; return; }
+    *pStart = sh->shards[shard].pStart; *pEnd = sh->shards[shard].pEnd;
+}
+void shardedBoundsOfHandle(int handle, int shardHandle, int* pStart, int* pEnd) {
+    Sharded* sh = find(handle);
+    *pStart = *pEnd = 0;
+    if (!sh) return;
+    for (const Shard& s : sh->shards) if (s.handle == shardHandle) { *pStart = s.pStart; *pEnd = s.pEnd; }
+}
+int shardedPatternCount(int handle) { Sharded* sh = find(handle); return sh ? sh->P : 0; }
+int shardedStates(int handle) { Sharded* sh = find(handle); return sh ? sh->S : 0; }
+int shardedCategories(int handle) { Sharded* sh = find(handle); return sh ? sh->C : 0; }
+
+}  // namespace mi355

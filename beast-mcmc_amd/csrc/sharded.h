@@ -1,0 +1,36 @@
+// sharded.h — the multi-GPU (pattern-sharded) instance behind one handle; see sharded.cpp.
+#pragma once
+#include <functional>
+
+#include "../../include/beagle_mi355.h"
+
+namespace mi355 {
+
+constexpr int SHARD_HANDLE_BASE = 1 << 20;      // handles >= this are sharded instances
+inline bool isShardedHandle(int h) { return h >= SHARD_HANDLE_BASE; }
+
+int shardedDeviceCountOverride();               // BEAGLE_MI355_SHARDS (tests), 0 = one shard per GPU
+int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount, int patternCount,
+                  int eigenBufferCount, int matrixBufferCount, int categoryCount, int scaleBufferCount, long preferenceFlags,
+                  long requirementFlags, BeagleInstanceDetails* returnInfo);
+int shardedFinalize(int handle);
+int shardedShardCount(int handle);
+int shardedPatternCount(int handle);
+int shardedStates(int handle);
+int shardedCategories(int handle);
+void shardedBounds(int handle, int shard, int* pStart, int* pEnd);
+void shardedBoundsOfHandle(int handle, int shardHandle, int* pStart, int* pEnd);
+
+// the same call on every shard (each on its own host thread); first error wins
+int shardedBroadcast(int handle, const std::function<int(int shardHandle)>& call);
+// arrays indexed by pattern: v is [planes][P][perPattern]; every shard sees its own block
+int shardedSetPerPatternInts(int handle, const int* v, const std::function<int(int, const int*)>& call);
+int shardedSetPerPatternDoubles(int handle, const double* v, int perPattern, int planes, const std::function<int(int, const double*)>& call);
+int shardedGetPerPatternInts(int handle, int* out, const std::function<int(int, int*)>& call);
+int shardedGetPerPatternDoubles(int handle, double* out, int perPattern, int planes, const std::function<int(int, double*)>& call);
+// per-shard device-side root sums (count doubles each) -> ONE all-reduce (RCCL) -> outValues on the host
+int shardedRootReduce(int handle, int count, const std::function<int(int shardHandle, double* deviceOut)>& enqueue, double* outValues);
+// per-shard host vectors of `len` doubles that add up
+int shardedSumDoubles(int handle, int len, const std::function<int(int shardHandle, double* out)>& call, double* outSum);
+
+}  // namespace mi355
