@@ -1028,6 +1028,91 @@ const char* beagleGetCitation(void) {
 
 BeagleResourceList* beagleGetResourceList(void) { return &resources()->rl; }
 
+// -beagle_auto: a full-tree evaluation of a synthetic alignment of the caller's shape on every candidate resource.
+// Balanced tree over `tipCount` compact tips with pseudo-random states, one stochastic matrix on every branch (no eigen
+// system needed: setTransitionMatrix), rescaling as the benchmark flags ask; 2 warm-up + 5 timed evaluations.
+BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(int tipCount, int compactBufferCount, int stateCount, int patternCount,
+                                      int categoryCount, const int* resourceList, int resourceCount, long preferenceFlags,
+                                      long requirementFlags, int eigenModelCount, int partitionCount, int calculateDerivatives,
+                                      long benchmarkFlags) {
+    (void)compactBufferCount; (void)eigenModelCount; (void)partitionCount; (void)calculateDerivatives;
+    static std::mutex mu;
+    static std::vector<BeagleBenchmarkedResource> entries;
+    static std::vector<std::string> strings;
+    static BeagleBenchmarkedResourceList out;
+    std::lock_guard<std::mutex> lock(mu);
+    Resources* res = resources();
+    std::vector<int> candidates;
+    if (resourceList && resourceCount > 0) { for (int i = 0; i < resourceCount; i++) if (resourceList[i] >= 1 && resourceList[i] < res->rl.length) candidates.push_back(resourceList[i]); }
+    else for (int r = 1; r < res->rl.length; r++) candidates.push_back(r);
+    entries.clear(); strings.clear();
+    strings.reserve(candidates.size() * 3 + 1);
+    const int T = std::max(2, tipCount), S = stateCount, P = std::max(1, patternCount), C = std::max(1, categoryCount);
+    const bool always = (benchmarkFlags & BEAGLE_BENCHFLAG_SCALING_ALWAYS) != 0;
+    for (int r : candidates) {
+        BeagleBenchmarkedResource e;
+        memset(&e, 0, sizeof(e));
+        e.number = r; e.name = res->rl.list[r].name; e.description = res->rl.list[r].description;
+        e.supportFlags = res->rl.list[r].supportFlags; e.requiredFlags = 0; e.benchedFlags = benchmarkFlags;
+        BeagleInstanceDetails det = {0, nullptr, nullptr, nullptr, 0};
+        const int h = beagleCreateInstance(T, T + (T - 1), T, S, P, 1, 2 * T, C, always ? T : 0, &r, 1, preferenceFlags, requirementFlags, &det);
+        e.returnCode = h < 0 ? h : 0;
+        strings.push_back(det.implName ? det.implName : "");
+        e.implName = (char*)strings.back().c_str();
+        e.benchmarkResult = 0.0;
+        if (h >= 0) {
+            int rc = 0;
+            std::vector<int> st(P);
+            unsigned long long x = 88172645463325252ull;
+            for (int t = 0; t < T && !rc; t++) {
+                for (int p = 0; p < P; p++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; st[p] = (int)(x % (unsigned)S); }
+                rc = beagleSetTipStates(h, t, st.data());
+            }
+            std::vector<double> m((size_t)C * S * S), w(C, 1.0 / C), f(S, 1.0 / S), pw(P, 1.0);
+            for (int c = 0; c < C; c++) for (int i = 0; i < S; i++) for (int j = 0; j < S; j++)
+                m[((size_t)c * S + i) * S + j] = i == j ? 0.9 - 0.05 * c / C : (0.1 + 0.05 * c / C) / (S - 1);
+            for (int b = 0; b < 2 * T - 1 && !rc; b++) rc = beagleSetTransitionMatrix(h, b, m.data(), 0.0);
+            if (!rc) rc = beagleSetCategoryWeights(h, 0, w.data());
+            if (!rc) rc = beagleSetStateFrequencies(h, 0, f.data());
+            if (!rc) rc = beagleSetPatternWeights(h, pw.data());
+            // balanced tree: nodes 0..T-1 tips; internal node T+k joins the two oldest unjoined nodes
+            std::vector<int> ops, scaleIdx;
+            std::vector<int> queue(T);
+            for (int t = 0; t < T; t++) queue[t] = t;
+            size_t head = 0;
+            for (int k = 0; k < T - 1; k++) {
+                const int a = queue[head++], b = queue[head++], d = T + k;
+                ops.insert(ops.end(), {d, always ? k : BEAGLE_OP_NONE, BEAGLE_OP_NONE, a, a, b, b});
+                scaleIdx.push_back(k);
+                queue.push_back(d);
+            }
+            const int root = 2 * T - 2, cum = always ? T - 1 : BEAGLE_OP_NONE, zero = 0;
+            double lnl = 0.0, best = 1e300;
+            for (int rep = 0; rep < 7 && !rc; rep++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = beagleUpdatePartials(h, ops.data(), T - 1, BEAGLE_OP_NONE);
+                if (!rc && always) { rc = beagleResetScaleFactors(h, cum); if (!rc) rc = beagleAccumulateScaleFactors(h, scaleIdx.data(), T - 1, cum); }
+                if (!rc) rc = beagleCalculateRootLogLikelihoods(h, &root, &zero, &zero, &cum, 1, &lnl);
+                if (rc == BEAGLE_ERROR_FLOATING_POINT) rc = 0;
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (rep >= 2) best = std::min(best, ms);
+            }
+            e.returnCode = rc;
+            e.benchmarkResult = rc ? 0.0 : best;
+            beagleFinalizeInstance(h);
+        }
+        entries.push_back(e);
+    }
+    std::stable_sort(entries.begin(), entries.end(), [](const BeagleBenchmarkedResource& a, const BeagleBenchmarkedResource& b) {
+        const bool oa = a.returnCode == 0 && a.benchmarkResult > 0, ob = b.returnCode == 0 && b.benchmarkResult > 0;
+        if (oa != ob) return oa;
+        return a.benchmarkResult < b.benchmarkResult; });
+    const double fastest = !entries.empty() && entries[0].benchmarkResult > 0 ? entries[0].benchmarkResult : 1.0;
+    for (auto& e : entries) e.performanceRatio = e.benchmarkResult > 0 ? e.benchmarkResult / fastest : 0.0;
+    out.list = entries.data(); out.length = (int)entries.size();
+    return &out;
+}
+
 int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                          int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
                          int scaleBufferCount, const int* resourceList, int resourceCount,

@@ -48,6 +48,10 @@ enum JniSlot {
     JNI_GetDoubleArrayElements = 190,
     JNI_ReleaseIntArrayElements = 195,
     JNI_ReleaseDoubleArrayElements = 198,
+    JNI_GetIntArrayRegion = 203,
+    JNI_GetDoubleArrayRegion = 206,
+    JNI_SetIntArrayRegion = 211,
+    JNI_SetDoubleArrayRegion = 214,
     JNI_ExceptionCheck = 228,
 };
 
@@ -79,6 +83,20 @@ inline void ReleaseIntArrayElements(JNIEnv* e, jintArray a, jint* p, jint mode) 
 inline void ReleaseDoubleArrayElements(JNIEnv* e, jdoubleArray a, jdouble* p, jint mode) {
     fn<void (*)(JNIEnv*, jdoubleArray, jdouble*, jint)>(e, JNI_ReleaseDoubleArrayElements)(e, a, p, mode);
 }
+inline void GetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, jint* buf) {
+    fn<void (*)(JNIEnv*, jintArray, jsize, jsize, jint*)>(e, JNI_GetIntArrayRegion)(e, a, start, len, buf);
+}
+inline void GetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, jdouble* buf) {
+    fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, jdouble*)>(e, JNI_GetDoubleArrayRegion)(e, a, start, len, buf);
+}
+inline void SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const jint* buf) {
+    fn<void (*)(JNIEnv*, jintArray, jsize, jsize, const jint*)>(e, JNI_SetIntArrayRegion)(e, a, start, len, buf);
+}
+inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
+    fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, const jdouble*)>(e, JNI_SetDoubleArrayRegion)(e, a, start, len, buf);
+}
+inline jboolean ExceptionCheck(JNIEnv* e) { return fn<jboolean (*)(JNIEnv*)>(e, JNI_ExceptionCheck)(e); }
+inline void ExceptionClear(JNIEnv* e) { fn<void (*)(JNIEnv*)>(e, JNI_ExceptionClear)(e); }
 inline void DeleteLocalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, JNI_DeleteLocalRef)(e, o); }
 // variadic entries
 typedef jobject (*NewObjectFn)(JNIEnv*, jclass, jmethodID, ...);

@@ -5,36 +5,70 @@
 // BeagleTreeLikelihood / TreeDataLikelihood call it unchanged.
 //
 // Parameter order of every function = the method descriptor in the class file (after JNIEnv*, jobject).
-// Java arrays are borrowed with Get<Type>ArrayElements and released with JNI_ABORT when they are inputs
-// (no copy-back) and mode 0 when they are outputs.  null arrays are passed through as NULL
+// Java arrays are COPIED with Get<Type>ArrayRegion into library-owned buffers and, when they are outputs, copied back
+// with Set<Type>ArrayRegion (no pinning semantics to get wrong, and the JVM never has to hand out — or copy —
+// its heap array for the 7 (T-1) ints of an operation list).  null arrays are passed through as NULL
 // (HomogenousSubstitutionModelDelegate.java:260-261 passes null derivative indices).
 //
-// Compiled against a self-authored minimal JNI header (jni_min.h); not executed in the build image
-// (no JVM) — INTEGRATION.md §4 lists the on-JVM validation steps.
+// Compiled against a self-authored minimal JNI header (jni_min.h).  The image has no JVM; tests/native/fake_jvm.cpp is a
+// JVM-less JNIEnv (229-slot function table over plain C++ objects) that drives these symbols end to end on the GPU box
+// (tests/test_gpu_jni_shim.py); INTEGRATION.md §4 lists the on-JVM validation steps.
+#include <string.h>
+
+#include <vector>
+
 #include "../../include/beagle_mi355.h"
 #include "jni_min.h"
 
 namespace {
 
 struct IntArr {
-    JNIEnv* env; jintArray arr; jint* p; jint mode;
-    IntArr(JNIEnv* e, jintArray a, bool output = false) : env(e), arr(a), p(a ? jni::GetIntArrayElements(e, a) : nullptr), mode(output ? 0 : JNI_ABORT) {}
-    ~IntArr() { if (p) jni::ReleaseIntArrayElements(env, arr, p, mode); }
-    operator int*() const { return p; }
+    JNIEnv* env; jintArray arr; std::vector<jint> buf; bool output;
+    IntArr(JNIEnv* e, jintArray a, bool out = false) : env(e), arr(a), output(out) {
+        if (a) { buf.resize((size_t)jni::GetArrayLength(e, a)); if (!buf.empty()) jni::GetIntArrayRegion(e, a, 0, (jsize)buf.size(), buf.data()); }
+    }
+    ~IntArr() { if (arr && output && !buf.empty()) jni::SetIntArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    operator int*() { return arr ? buf.data() : nullptr; }
 };
 struct DblArr {
-    JNIEnv* env; jdoubleArray arr; jdouble* p; jint mode;
-    DblArr(JNIEnv* e, jdoubleArray a, bool output = false) : env(e), arr(a), p(a ? jni::GetDoubleArrayElements(e, a) : nullptr), mode(output ? 0 : JNI_ABORT) {}
-    ~DblArr() { if (p) jni::ReleaseDoubleArrayElements(env, arr, p, mode); }
-    operator double*() const { return p; }
+    JNIEnv* env; jdoubleArray arr; std::vector<jdouble> buf; bool output;
+    DblArr(JNIEnv* e, jdoubleArray a, bool out = false) : env(e), arr(a), output(out) {
+        if (a) { buf.resize((size_t)jni::GetArrayLength(e, a)); if (!buf.empty()) jni::GetDoubleArrayRegion(e, a, 0, (jsize)buf.size(), buf.data()); }
+    }
+    ~DblArr() { if (arr && output && !buf.empty()) jni::SetDoubleArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    operator double*() { return arr ? buf.data() : nullptr; }
 };
 
-void callSetString(JNIEnv* env, jobject obj, jclass cls, const char* method, const char* value) {
-    jmethodID m = jni::GetMethodID(env, cls, method, "(Ljava/lang/String;)V");
+// a failed class / method lookup leaves a pending NoSuchMethodError / NoClassDefFoundError: clear it, the caller sees null / skips
+bool pendingCleared(JNIEnv* env) {
+    if (!jni::ExceptionCheck(env)) return false;
+    jni::ExceptionClear(env);
+    return true;
+}
+jmethodID method(JNIEnv* env, jclass cls, const char* name, const char* sig) {
+    jmethodID m = jni::GetMethodID(env, cls, name, sig);
+    if (pendingCleared(env)) return nullptr;
+    return m;
+}
+
+void callSetString(JNIEnv* env, jobject obj, jclass cls, const char* name, const char* value) {
+    jmethodID m = method(env, cls, name, "(Ljava/lang/String;)V");
     if (!m) return;
     jstring s = jni::NewStringUTF(env, value ? value : "");
     jni::CallVoidMethod(env)(env, obj, m, s);
     jni::DeleteLocalRef(env, s);
+}
+void callSetInt(JNIEnv* env, jobject obj, jclass cls, const char* name, jint v) {
+    jmethodID m = method(env, cls, name, "(I)V");
+    if (m) jni::CallVoidMethod(env)(env, obj, m, v);
+}
+void callSetLong(JNIEnv* env, jobject obj, jclass cls, const char* name, jlong v) {
+    jmethodID m = method(env, cls, name, "(J)V");
+    if (m) jni::CallVoidMethod(env)(env, obj, m, v);
+}
+void callSetDouble(JNIEnv* env, jobject obj, jclass cls, const char* name, jdouble v) {
+    jmethodID m = method(env, cls, name, "(D)V");
+    if (m) jni::CallVoidMethod(env)(env, obj, m, v);
 }
 
 }  // namespace
@@ -48,9 +82,9 @@ JNI_FN(jstring, getCitation)(JNIEnv* env, jobject) { return jni::NewStringUTF(en
 JNI_FN(jobjectArray, getResourceList)(JNIEnv* env, jobject) {
     BeagleResourceList* rl = beagleGetResourceList();
     jclass cls = jni::FindClass(env, "beagle/ResourceDetails");
-    if (!cls) return nullptr;
-    jmethodID ctor = jni::GetMethodID(env, cls, "<init>", "(I)V");
-    jmethodID setFlags = jni::GetMethodID(env, cls, "setFlags", "(J)V");
+    if (pendingCleared(env) || !cls) return nullptr;
+    jmethodID ctor = method(env, cls, "<init>", "(I)V");
+    jmethodID setFlags = method(env, cls, "setFlags", "(J)V");
     if (!ctor) return nullptr;
     jobjectArray out = jni::NewObjectArray(env, rl->length, cls, nullptr);
     for (int i = 0; i < rl->length; i++) {
@@ -64,10 +98,39 @@ JNI_FN(jobjectArray, getResourceList)(JNIEnv* env, jobject) {
     return out;
 }
 
-// getBenchmarkedResourceList (IIIII[IIJJIIIJ)[Lbeagle/BenchmarkedResourceDetails;  — only used by -beagle_auto
-// (BeagleTreeLikelihood.java:392-414); not provided yet: null makes BeagleFactory report "no resources benchmarked".
-JNI_FN(jobjectArray, getBenchmarkedResourceList)(JNIEnv*, jobject, jint, jint, jint, jint, jint, jintArray, jint, jlong, jlong,
-                                                 jint, jint, jint, jlong) { return nullptr; }
+// getBenchmarkedResourceList (IIIII[IIJJIIIJ)[Lbeagle/BenchmarkedResourceDetails;  — BEAST's -beagle_auto
+// (BeagleTreeLikelihood.java:392-414): the entries come back fastest first, element 0's resource number is what BEAST uses.
+JNI_FN(jobjectArray, getBenchmarkedResourceList)(JNIEnv* env, jobject, jint tipCount, jint compactBufferCount, jint stateCount,
+                                                 jint patternCount, jint categoryCount, jintArray resourceList, jint resourceCount,
+                                                 jlong preferenceFlags, jlong requirementFlags, jint eigenModelCount, jint partitionCount,
+                                                 jint calculateDerivatives, jlong benchmarkFlags) {
+    IntArr res(env, resourceList);
+    BeagleBenchmarkedResourceList* bl = beagleGetBenchmarkedResourceList(tipCount, compactBufferCount, stateCount, patternCount, categoryCount,
+                                                                         res, resourceCount, (long)preferenceFlags, (long)requirementFlags,
+                                                                         eigenModelCount, partitionCount, calculateDerivatives, (long)benchmarkFlags);
+    jclass cls = jni::FindClass(env, "beagle/BenchmarkedResourceDetails");
+    if (pendingCleared(env) || !cls || !bl) return nullptr;
+    jmethodID ctor = method(env, cls, "<init>", "(I)V");
+    if (!ctor) return nullptr;
+    jobjectArray out = jni::NewObjectArray(env, bl->length, cls, nullptr);
+    for (int i = 0; i < bl->length; i++) {
+        const BeagleBenchmarkedResource& b = bl->list[i];
+        jobject r = jni::NewObject(env)(env, cls, ctor, (jint)i);
+        callSetInt(env, r, cls, "setResourceNumber", b.number);
+        callSetString(env, r, cls, "setName", b.name);
+        callSetString(env, r, cls, "setDescription", b.description);
+        callSetLong(env, r, cls, "setSupportFlags", (jlong)b.supportFlags);
+        callSetLong(env, r, cls, "setRequiredFlags", (jlong)b.requiredFlags);
+        callSetInt(env, r, cls, "setReturnCode", b.returnCode);
+        callSetString(env, r, cls, "setImplName", b.implName);
+        callSetLong(env, r, cls, "setBenchedFlags", (jlong)b.benchedFlags);
+        callSetDouble(env, r, cls, "setBenchmarkResult", b.benchmarkResult);
+        callSetDouble(env, r, cls, "setPerformanceRatio", b.performanceRatio);
+        jni::SetObjectArrayElement(env, out, i, r);
+        jni::DeleteLocalRef(env, r);
+    }
+    return out;
+}
 
 // createInstance (IIIIIIIII[IIJJLbeagle/InstanceDetails;)I
 JNI_FN(jint, createInstance)(JNIEnv* env, jobject, jint tipCount, jint partialsBufferCount, jint compactBufferCount,
@@ -81,10 +144,8 @@ JNI_FN(jint, createInstance)(JNIEnv* env, jobject, jint tipCount, jint partialsB
                                        (long)preferenceFlags, (long)requirementFlags, &d);
     if (h >= 0 && outDetails) {
         jclass cls = jni::GetObjectClass(env, outDetails);
-        jmethodID m = jni::GetMethodID(env, cls, "setResourceNumber", "(I)V");
-        if (m) jni::CallVoidMethod(env)(env, outDetails, m, (jint)d.resourceNumber);
-        m = jni::GetMethodID(env, cls, "setFlags", "(J)V");
-        if (m) jni::CallVoidMethod(env)(env, outDetails, m, (jlong)d.flags);
+        callSetInt(env, outDetails, cls, "setResourceNumber", (jint)d.resourceNumber);
+        callSetLong(env, outDetails, cls, "setFlags", (jlong)d.flags);
         callSetString(env, outDetails, cls, "setResourceName", d.resourceName);
         callSetString(env, outDetails, cls, "setImplementationName", d.implName);
     }

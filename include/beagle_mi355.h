@@ -108,6 +108,41 @@ const char* beagleGetCitation(void);
  * (BeagleTreeLikelihood.java:90-92); resources 1..G are the visible MI355X devices. */
 BeagleResourceList* beagleGetResourceList(void);
 
+/* One entry of beagleGetBenchmarkedResourceList; mirrors beagle.BenchmarkedResourceDetails (lib/beagle.jar: ctor (I),
+ * setResourceNumber, setName, setDescription, setSupportFlags, setRequiredFlags, setReturnCode, setImplName,
+ * setBenchedFlags, setBenchmarkResult, setPerformanceRatio). */
+typedef struct {
+    int    number;             /* resource number (what the caller passes back to createInstance) */
+    char*  name;
+    char*  description;
+    long   supportFlags;
+    long   requiredFlags;
+    int    returnCode;         /* of the benchmark's createInstance / evaluation on that resource */
+    char*  implName;
+    long   benchedFlags;
+    double benchmarkResult;    /* milliseconds per full-tree evaluation of the benchmark workload */
+    double performanceRatio;   /* relative to the fastest resource (1.0 = fastest) */
+} BeagleBenchmarkedResource;
+
+typedef struct {
+    BeagleBenchmarkedResource* list;
+    int length;
+} BeagleBenchmarkedResourceList;
+
+#define BEAGLE_BENCHFLAG_SCALING_NONE    (1L << 0)
+#define BEAGLE_BENCHFLAG_SCALING_ALWAYS  (1L << 1)
+#define BEAGLE_BENCHFLAG_SCALING_DYNAMIC (1L << 2)
+
+/* getBenchmarkedResourceList (IIIII[IIJJIIIJ)[Lbeagle/BenchmarkedResourceDetails;  — BEAST's -beagle_auto
+ * (BeagleTreeLikelihood.java:392-414, BeagleDataLikelihoodDelegate.java:413-433): times a full-tree evaluation of a
+ * synthetic alignment of the caller's shape (tips, states, patterns, categories) on every candidate resource
+ * (resourceList, or all GPU resources incl. the pattern-sharded one when it is NULL) and returns them fastest first.
+ * The list is owned by the library and valid until the next call. */
+BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(int tipCount, int compactBufferCount, int stateCount, int patternCount,
+                                      int categoryCount, const int* resourceList, int resourceCount, long preferenceFlags,
+                                      long requirementFlags, int eigenModelCount, int partitionCount, int calculateDerivatives,
+                                      long benchmarkFlags);
+
 /* createInstance (IIIIIIIII[IIJJLbeagle/InstanceDetails;)I
  * callers: BeagleTreeLikelihood.java:420-433, BeagleDataLikelihoodDelegate.java:439-452 */
 int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount,
