@@ -275,8 +275,11 @@ int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices,
                                      double* outDerivatives, double* outSumDerivatives, double* outSumSquaredDerivatives);
 
 /* calculateCrossProductDifferentials (I[I[I[I[I[DI[D[D)I — discrete/SubstitutionModelCrossProductDelegate.java:153-178.
- * Semantics INFERRED from the call site and its consumer (AbstractLogAdditiveSubstitutionModelGradient.java:246-270 reads the
- * result as d lnL / d Q_ij), first-order form:
+ * The arithmetic lives only in the absent beagle-lib; the semantics follow the call site and its consumer, which names what it
+ * expects: "a first-order" approximation of d lnL / d Q_ij (AbstractLogAdditiveSubstitutionModelGradient.java:74-93; its
+ * AFFINE_CORRECTED mode adds a term computed in Java from the same numbers).  First-order form, pinned by finite differences of
+ * the golden-pinned lnL along random generator perturbations (tests/test_oracle_golden.py: the error falls in proportion to
+ * the branch lengths) and exactly in the scaling direction:
  *   outSumDerivatives[i*S+j] += sum_e edgeLengths[e] sum_p weight_p (sum_c w_c r_c pre_e[c,p,i] post_e[c,p,j]) / (sum_c w_c pre_e . post_e)
  * outSumSquaredDerivatives must be NULL (BEAST passes null); otherwise BEAGLE_ERROR_NO_IMPLEMENTATION. */
 int beagleCalculateCrossProductDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,

@@ -269,3 +269,48 @@ def test_oracle_cross_products_scaling_identity(S, C):
     g.b.calculateCrossProductDifferentials(post, post + g.pre_offset, [0], [0], g.branch_lengths[post], len(post), out=acc)
     assert np.allclose(acc - 1.0, cp.ravel(), rtol=1e-12, atol=1e-12)
     g.close()
+
+
+@pytest.mark.parametrize("S,C", [(4, 2), (20, 1)])
+def test_oracle_cross_products_are_the_first_order_generator_derivative(S, C):
+    """Pins calculateCrossProductDifferentials beyond the scaling direction.  Its consumer asks for "a first-order"
+    approximation of d lnL / d Q_ij (AbstractLogAdditiveSubstitutionModelGradient.java:74-93, ApproximationMode.FIRST_ORDER;
+    AFFINE_CORRECTED adds a term computed in Java from the SAME cross products, :95-130), i.e. the exact derivative
+    sum_b int_0^t_b pre_b(s)_i post_b(s)_j ds / L with the integrand frozen at the branch's lower end: exact up to O(t_b) per
+    branch.  Check: central finite differences of the golden-pinned lnL along 10 random generator perturbations dQ — the
+    perturbed lnL is evaluated through setTransitionMatrix with P = expm((Q + h dQ) t r_c), no eigen system involved — against
+    sum_ij dQ_ij out_ij, on the same tree with all branch lengths scaled by 1, 1/2, ... 1/16: the relative error must fall in
+    proportion to the branch lengths (first order: it halves each time) and be below 2 % at the shortest.  A transposed,
+    mis-weighted or mis-indexed formula has an error that does not vanish."""
+    from scipy.linalg import expm
+    from beast_mcmc_amd.gradient import BranchGradient
+    wl = helpers.random_workload(7, 40, S, C, seed=61 + S)
+    rng = np.random.default_rng(5)
+    dqs = [rng.normal(size=(S, S)) for _ in range(10)]
+    e = wl.eig
+    q = (e.evec * e.evals[None, :]) @ e.ievc
+    errs = []
+    for scale in (1.0, 0.5, 0.25, 0.125, 0.0625):
+        g = BranchGradient(wl, library=helpers.oracle_library())
+        g.branch_lengths = g.branch_lengths * scale
+        lnl, _ = g.gradient()
+        cp = g.cross_products()
+
+        def lnl_of(qm):
+            for n in g.edges:
+                p = np.stack([expm(qm * g.branch_lengths[n] * r) for r in wl.cat_rates])
+                g.b.setTransitionMatrix(n, p.ravel(), 0.0)
+            g.b.updatePartials(g._post_ops, len(g._post_ops) // 7, bm.beagle.NONE)
+            out = [0.0]
+            g.b.calculateRootLogLikelihoods([g.tree.root], [0], [0], [bm.beagle.NONE], 1, out)
+            return out[0]
+
+        assert helpers.rel_err(lnl_of(q), lnl) < 1e-10          # expm(Q t) = the eigen-system matrices
+        h = 1e-6
+        fd = np.array([(lnl_of(q + h * d) - lnl_of(q - h * d)) / (2 * h) for d in dqs])
+        ap = np.array([float(np.sum(d * cp)) for d in dqs])
+        errs.append(float(np.linalg.norm(ap - fd) / np.linalg.norm(fd)))
+        g.close()
+    ratios = [errs[i] / errs[i + 1] for i in range(len(errs) - 1)]
+    assert errs[-1] < 0.02, errs
+    assert all(1.5 < r < 2.7 for r in ratios[1:]), (errs, ratios)
