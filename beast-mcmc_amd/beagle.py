@@ -118,7 +118,7 @@ _PROTOS = {
 ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetBenchmarkedResourceList", "beagleGetApiTable"] + \
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
-               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats"]
+               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GetPartialsBatch"]
 
 
 class EngineLibrary:
@@ -431,6 +431,15 @@ class Beagle:
         f = self._ext("beagleMi355KernelTimer", [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)])
         self._check("kernelTimer", f(self.instance, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def getPartialsBatch(self, bufferIndices, scaleIndices=None):
+        """-> [count][C][P][S]: several buffers in one call (include/beagle_mi355.h beagleMi355GetPartialsBatch)."""
+        b = _i(list(bufferIndices))
+        sc = None if scaleIndices is None else _i(list(scaleIndices))
+        out = np.empty(len(b) * self.categoryCount * self.patternCount * self.stateCount)
+        f = self._ext("beagleMi355GetPartialsBatch", [C.c_int, _IP, _IP, C.c_int, _DP])
+        self._check("getPartialsBatch", f(self.instance, _ip(b), _ip(sc), len(b), _dp(out)))
+        return out.reshape(len(b), self.categoryCount, self.patternCount, self.stateCount)
 
     def walkStats(self):
         """Counters of the 4-state pattern walk since the last kernelTimer call (include/beagle_mi355.h)."""

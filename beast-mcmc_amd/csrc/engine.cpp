@@ -53,6 +53,8 @@ struct Instance {
     std::vector<mi355::WalkOp> walkOps;                  // scratch: resolved program
     size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals], this many doubles apart
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
+    // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
+    double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
     long statMicroOps = 0, statStored = 0, statMemReads = 0, statTipReads = 0, statScaleReads = 0, statWalks = 0, statScaleWrites = 0;   // since the last timer reset
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
@@ -205,6 +207,8 @@ void destroy(Instance* in) {
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
     if (in->bigStage) hipFree(in->bigStage);
+    if (in->exportDev) hipFree(in->exportDev);
+    if (in->exportHost) hipHostFree(in->exportHost);
     if (in->hRing) hipHostFree(in->hRing);
     if (in->hResult) hipHostFree(in->hResult);
     for (auto& ev : in->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -372,6 +376,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->bigStageBytes < total) {
             if (in->bigStage) hipFree(in->bigStage);
+    if (in->exportDev) hipFree(in->exportDev);
+    if (in->exportHost) hipHostFree(in->exportHost);
             in->bigStage = nullptr; in->bigStageBytes = 0;
             HIP_TRY(hipMalloc((void**)&in->bigStage, total));
             in->bigStageBytes = total;
@@ -993,15 +999,6 @@ void toTiled(const Instance* in, const double* api, double* tiled, int categorie
             for (size_t j = 0; j < S; j++) dst[j * 32] = src[j];
         }
 }
-void fromTiled(const Instance* in, const double* tiled, double* api) {
-    const size_t S = in->S, P = in->P, nt = in->ntile;
-    for (int c = 0; c < in->C; c++)
-        for (size_t p = 0; p < P; p++) {
-            double* dst = api + ((size_t)c * P + p) * S;
-            const double* src = tiled + ((size_t)c * nt + p / 32) * S * 32 + p % 32;
-            for (size_t j = 0; j < S; j++) dst[j] = src[j * 32];
-        }
-}
 
 }  // namespace
 
@@ -1340,33 +1337,72 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     return upload(in, in->partials[bufferIndex], inPartials, (size_t)in->C * in->P * in->S * sizeof(double));
 }
 
+// Read-back of `count` partials buffers (AncestralStateBeagleTreeLikelihood.java:414-542 reads every
+// internal node once per logged sample): virtual buffers are materialised by ONE walk, every buffer is converted to the
+// API layout [C][P][S] on the device with its scale factors folded in, and the device-to-host copies stream through a
+// pinned bounce buffer, a chunk of buffers at a time, with one synchronisation per chunk.
+static int exportPartials(Instance* in, const int* bufferIndices, const int* scaleIndices, int count, double* out) {
+    std::vector<int> need;
+    for (int k = 0; k < count; k++) {
+        const int b = bufferIndices[k];
+        if (badIndex(b, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (scaleIndices && scaleIndices[k] != BEAGLE_OP_NONE && badIndex(scaleIndices[k], in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (isVirt(in, b)) need.push_back(b);
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    const size_t elems = (size_t)in->C * in->P * in->S, bytes = elems * sizeof(double);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / bytes));     // <= 256 MiB in flight
+    if (in->exportDevBuffers < chunk) {
+        if (in->exportDev) hipFree(in->exportDev);
+        in->exportDev = nullptr; in->exportDevBuffers = 0;
+        HIP_TRY(hipMalloc((void**)&in->exportDev, chunk * bytes));
+        in->exportDevBuffers = chunk;
+    }
+    if (in->exportHostBytes < chunk * bytes) {
+        if (in->exportHost) hipHostFree(in->exportHost);
+        in->exportHost = nullptr; in->exportHostBytes = 0;
+        HIP_TRY(hipHostMalloc((void**)&in->exportHost, chunk * bytes, hipHostMallocDefault));
+        in->exportHostBytes = chunk * bytes;
+    }
+    for (size_t b0 = 0; b0 < (size_t)count; b0 += chunk) {
+        const size_t n = std::min(chunk, (size_t)count - b0);
+        for (size_t k = 0; k < n; k++) {
+            const int b = bufferIndices[b0 + k];
+            if (!in->partials[b] || isCompactTip(in, b)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            const double* sc = nullptr; int raw = 0;
+            if (scaleIndices && scaleIndices[b0 + k] != BEAGLE_OP_NONE) {
+                int rc = ensureScale(in, scaleIndices[b0 + k]); if (rc) return rc;
+                sc = in->scale[scaleIndices[b0 + k]]; raw = in->scaleIsRaw[scaleIndices[b0 + k]];
+            }
+            mi355::launchExportPartials(in->stream, in->partials[b], sc, raw, in->exportDev + k * elems, in->P, in->S, in->C, in->tiled);
+        }
+        HIP_TRY(hipMemcpyAsync(in->exportHost, in->exportDev, n * bytes, hipMemcpyDeviceToHost, in->stream));
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        in->ringHead = 0;
+        memcpy(out + b0 * elems, in->exportHost, n * bytes);
+    }
+    return BEAGLE_SUCCESS;
+}
+
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternDoubles(instance, outPartials, shardedStates(instance), shardedCategories(instance), [&](int h, double* v) { return beagleGetPartials(h, bufferIndex, scaleIndex, v); }); }
     GET_INSTANCE(instance);
-    if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    int rc = materializeVirtual(in, bufferIndex); if (rc) return rc;
-    if (!in->partials[bufferIndex]) return BEAGLE_ERROR_OUT_OF_RANGE;
-    if (in->tiled) {
-        std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
-        rc = download(in, t.data(), in->partials[bufferIndex], t.size() * sizeof(double));
-        if (!rc) fromTiled(in, t.data(), outPartials);
-    } else {
-        rc = download(in, outPartials, in->partials[bufferIndex], (size_t)in->C * in->P * in->S * sizeof(double));
+    return exportPartials(in, &bufferIndex, &scaleIndex, 1, outPartials);
+}
+
+// MI355X extension: `count` buffers in one call, out = [count][C][P][S]; scaleIndices may be NULL
+int beagleMi355GetPartialsBatch(int instance, const int* bufferIndices, const int* scaleIndices, int count, double* outPartials) {
+    if (mi355::isShardedHandle(instance)) {
+        const size_t elems = (size_t)shardedCategories(instance) * mi355::shardedPatternCount(instance) * shardedStates(instance);
+        for (int k = 0; k < count; k++) {
+            const int rc = beagleGetPartials(instance, bufferIndices[k], scaleIndices ? scaleIndices[k] : BEAGLE_OP_NONE, outPartials + (size_t)k * elems);
+            if (rc) return rc;
+        }
+        return BEAGLE_SUCCESS;
     }
-    if (rc) return rc;
-    if (scaleIndex != BEAGLE_OP_NONE) {
-        if (badIndex(scaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        rc = ensureScale(in, scaleIndex); if (rc) return rc;
-        std::vector<double> f(in->P);
-        rc = download(in, f.data(), in->scale[scaleIndex], (size_t)in->P * sizeof(double)); if (rc) return rc;
-        const bool raw = in->scaleIsRaw[scaleIndex];
-        for (int c = 0; c < in->C; c++)
-            for (int p = 0; p < in->P; p++) {
-                const double m = raw ? f[p] : exp(f[p]);
-                for (int i = 0; i < in->S; i++) outPartials[((size_t)c * in->P + p) * in->S + i] *= m;
-            }
-    }
-    return BEAGLE_SUCCESS;
+    GET_INSTANCE(instance);
+    if (count <= 0) return BEAGLE_SUCCESS;
+    return exportPartials(in, bufferIndices, scaleIndices, count, outPartials);
 }
 
 int beagleGetLogScaleFactors(int instance, int scaleIndex, double* out) {

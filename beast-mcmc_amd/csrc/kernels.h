@@ -114,6 +114,10 @@ void launchAccumulateScale(hipStream_t stream, double* cum, const double* const*
 void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd);
 // out[p] = raw ? log(in[p]) : in[p]
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
+// Read-back: out[c][p][i] (API layout) = partials * scale, from either device layout.  `scale` may be
+// nullptr; scaleIsRaw: the buffer holds raw factors (else logs: the factor is exp).  One pass, then a single D2H.
+void launchExportPartials(hipStream_t stream, const double* partials, const double* scale, int scaleIsRaw, double* out,
+                          int P, int S, int C, bool tiled);
 // dst[c][p][i] = src[p][i] for every category (setTipPartials replication)
 void launchReplicateCategories(hipStream_t stream, const double* src, double* dst, int P, int S, int C);
 

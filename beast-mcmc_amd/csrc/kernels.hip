@@ -19,6 +19,7 @@
 //   k_accumulate                AbstractLikelihoodCore.java:442-458 as a persistent cumulative buffer
 #include "kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -336,6 +337,27 @@ __global__ void k_logScale(const double* in, double* out, int raw, int P) {
 }
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P) {
     hipLaunchKernelGGL(k_logScale, dim3((P + 255) / 256), dim3(256), 0, stream, in, out, raw, P);
+}
+
+// API-layout export of a partials buffer (either device layout) with the optional scale factor folded in
+__global__ __launch_bounds__(256) void k_exportPartials(const double* __restrict__ src, const double* __restrict__ scale, int scaleIsRaw,
+                                                        double* __restrict__ out, int P, int S, int C, int tiled) {
+    const size_t n = (size_t)C * P * S;
+    const int ntile = (P + 31) >> 5;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % S);
+        const size_t cp = e / S;
+        const int p = (int)(cp % P), c = (int)(cp / P);
+        double v = tiled ? src[(((size_t)c * ntile + (p >> 5)) * S + i) * 32 + (p & 31)] : src[e];
+        if (scale) v *= scaleIsRaw ? scale[p] : exp(scale[p]);
+        out[e] = v;
+    }
+}
+void launchExportPartials(hipStream_t stream, const double* partials, const double* scale, int scaleIsRaw, double* out,
+                          int P, int S, int C, bool tiled) {
+    const size_t n = (size_t)C * P * S;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_exportPartials, dim3(blocks), dim3(256), 0, stream, partials, scale, scaleIsRaw, out, P, S, C, tiled ? 1 : 0);
 }
 
 __global__ void k_replicate(const double* src, double* dst, size_t n, int C) {

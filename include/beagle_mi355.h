@@ -305,6 +305,11 @@ int beagleMi355SetStream(int instance, void* hipStream);
  * double over RCCL (DESIGN.md, row e). */
 int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
                                       int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut);
+/* getPartials for `count` buffers in one call: out = [count][C][P][S] (API layout), scale factors folded in where
+ * scaleIndices[k] != BEAGLE_OP_NONE (scaleIndices may be NULL).  One batched materialisation of virtual buffers, device-side
+ * layout conversion, pinned copies, one synchronisation per 256 MiB — for hosts that read many nodes per sample
+ * (AncestralStateBeagleTreeLikelihood.java:414-542); the per-buffer beagleGetPartials takes the same path with count 1. */
+int beagleMi355GetPartialsBatch(int instance, const int* bufferIndices, const int* scaleIndices, int count, double* outPartials);
 /* Block until everything enqueued for the instance has completed. */
 int beagleMi355Synchronize(int instance);
 /* Engine-side timing of the hot kernel: HIP events recorded on the instance's stream around
