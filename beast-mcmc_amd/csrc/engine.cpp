@@ -51,7 +51,10 @@ struct Instance {
     mi355::WalkPlanner planner;
     mi355::Plan plan;                                    // scratch of the current call
     std::vector<mi355::WalkOp> walkOps;                  // scratch: resolved program
-    size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals], this many doubles apart
+    size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals (pair-interleaved,
+                                                         // kernels.h walkPairIndex)], this many doubles apart
+    size_t statePairOff = 0;                             // walk instances: a tip's pair-interleaved states follow its plain ones, this many bytes on
+    char* matStream = nullptr; size_t matStreamBytes = 0;   // walk instances: the matrix stream of the program being run (k_gatherMatrices)
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
     double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
@@ -188,7 +191,9 @@ int ensureScale(Instance* in, int idx) {
 
 int ensureStates(Instance* in, int idx) {
     if (in->tipStates[idx]) return 0;
-    const size_t bytes = ((size_t)in->P + 2 + 255) & ~(size_t)255;
+    const size_t plain = ((size_t)in->P + 2 + 255) & ~(size_t)255;
+    const size_t bytes = in->walk ? 2 * plain : plain;      // walk instances: [plain | pair-interleaved] (the latter is what the walk reads)
+    in->statePairOff = plain;
     if (in->stateSlabLeft == 0) {
         const int n = std::max(1, std::min(in->compactCount, 1024));
         void* slab = nullptr;
@@ -207,6 +212,7 @@ void destroy(Instance* in) {
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
     if (in->bigStage) hipFree(in->bigStage);
+    if (in->matStream) hipFree(in->matStream);
     if (in->exportDev) hipFree(in->exportDev);
     if (in->exportHost) hipHostFree(in->exportHost);
     if (in->hRing) hipHostFree(in->hRing);
@@ -319,6 +325,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
     nop.m1 = in->matrices; nop.m2 = in->matrices;
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
     int maxRange = 0;
+    bool paired = true;                            // every segment starts at a multiple of 128 patterns (kernels_walk4.hip)
+    for (const mi355::PlanSeg& ps : plan.segs) if (in->partStart[ps.partition] % 128) paired = false;
     for (size_t si = 0; si < plan.segs.size(); si++) {
         const mi355::PlanSeg& ps = plan.segs[si];
         segs[si].progStart = (int)w.size();
@@ -327,9 +335,9 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
             mi355::WalkOp d;
             memset(&d, 0, sizeof(d));
             if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k1 == mi355::PK_TIPS) { d.src1 = in->tipStates[m.a1]; if (!d.src1) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+            else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + in->statePairOff; in->statTipReads++; }
             if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k2 == mi355::PK_TIPS) { d.src2 = in->tipStates[m.a2]; if (!d.src2) return BEAGLE_ERROR_OUT_OF_RANGE; in->statTipReads++; }
+            else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + in->statePairOff; in->statTipReads++; }
             if (m.smode != mi355::PS_NONE) {
                 int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
                 if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scale = in->scale[m.scaleIdx]; }
@@ -356,7 +364,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         // share the counter and may complete out of order with each other, so the stores of the previous stage are NOT
         // counted: if they are still pending the wait is merely longer than necessary, never too short.
         for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++)
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags), 12));
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags, paired), 12));
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
@@ -376,8 +384,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->bigStageBytes < total) {
             if (in->bigStage) hipFree(in->bigStage);
-    if (in->exportDev) hipFree(in->exportDev);
-    if (in->exportHost) hipHostFree(in->exportHost);
             in->bigStage = nullptr; in->bigStageBytes = 0;
             HIP_TRY(hipMalloc((void**)&in->bigStage, total));
             in->bigStageBytes = total;
@@ -390,6 +396,17 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
     if (pairBytes)
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
+    // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
+    const size_t streamBytes = w.size() * (size_t)in->C * 16 * 2 * sizeof(double);
+    if (in->matStreamBytes < streamBytes) {
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        if (in->matStream) hipFree(in->matStream);
+        in->matStream = nullptr; in->matStreamBytes = 0;
+        const size_t want = std::max(streamBytes + streamBytes / 4, (size_t)1 << 20);
+        HIP_TRY(hipMalloc((void**)&in->matStream, want));
+        in->matStreamBytes = want;
+    }
+    mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
     for (size_t b = 0; b < segs.size();) {
@@ -398,7 +415,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         int range = 0;
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                           in->P, in->C, (long)in->scaleStride);
+                           in->matStream, paired, in->P, in->C, (long)in->scaleStride);
         in->statWalks++;
         b = e;
     }
@@ -1156,7 +1173,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     int maxVirtSteps = 6;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
-    in->scaleStride = ((size_t)patternCount + 2 + 31) & ~(size_t)31;      // the walk kernel may read one pattern past the end
+    in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
@@ -1280,9 +1297,20 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
     int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;   // virtual cherries defined by the OLD states
     rc = ensureStates(in, tipIndex); if (rc) return rc;
     setCompact(in, tipIndex, true);
-    std::vector<uint8_t> s(in->P);
-    for (int p = 0; p < in->P; p++) s[p] = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
-    return upload(in, in->tipStates[tipIndex], s.data(), (size_t)in->P);
+    if (!in->walk) {
+        std::vector<uint8_t> s(in->P);
+        for (int p = 0; p < in->P; p++) s[p] = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
+        return upload(in, in->tipStates[tipIndex], s.data(), (size_t)in->P);
+    }
+    // walk instances: plain states (pre-order kernels, getTipStates), then the pair-interleaved copy the walk reads; the
+    // padding of the last block of 128 is "missing"
+    const size_t padded = ((size_t)in->P + 127) & ~(size_t)127;
+    std::vector<uint8_t> s(in->statePairOff + padded, (uint8_t)in->S);
+    for (int p = 0; p < in->P; p++) {
+        const uint8_t v = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
+        s[p] = v; s[in->statePairOff + mi355::walkPairIndex((size_t)p)] = v;
+    }
+    return upload(in, in->tipStates[tipIndex], s.data(), s.size());
 }
 
 int beagleGetTipStates(int instance, int tipIndex, int* outStates) {

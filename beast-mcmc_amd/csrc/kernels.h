@@ -50,13 +50,20 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
     double*        store;    // partials buffer the result is written to (WF_STORE)
     double*        scale;    // WS_READ: the RECIPROCAL half of the scale buffer;  WS_WRITE: the buffer (factor half first)
-    const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles)
-    const double*  m2;
+    const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles): read by
+    const double*  m2;       // k_gatherMatrices, which lays them out as the stream the walk reads
     unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13 | waitJump << 16 (walkWaitJump)
     unsigned       pad0;
     unsigned long long pad1;
 };
 static_assert(sizeof(WalkOp) == 64, "WalkOp layout");
+// Position of pattern p in a pair-interleaved per-pattern array (walk instances: compact tip states, reciprocal scale
+// factors): within every block of 128 patterns, pattern l and pattern l + 64 — the two a lane of the walk owns — are
+// neighbours.  Such arrays are padded to a multiple of 128 entries.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t walkPairIndex(size_t p) { return (p & ~(size_t)127) + 2 * (p & 63) + ((p >> 6) & 1); }
 inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     unsigned f = (unsigned)((k1 << 5) | (k2 << 8) | (hold << 11) | (smode << 13));
     if (k1 == WK_MEM) f |= WF_X;
@@ -67,7 +74,11 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     return f;
 }
 // vector-memory instructions the kernel's fetch stage issues for a micro-operation / its store stage
-inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? 2 : 0) + ((f & WF_T2) ? 2 : 0) + ((f & WF_INV) ? 2 : 0) + 2; }
+// (paired: the launch's segments all start at a multiple of 128 patterns — one load per tip child / reciprocal pair)
+inline int walkFetchCount(unsigned f, bool paired) {
+    const int one = paired ? 1 : 2;
+    return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? one : 0) + ((f & WF_T2) ? one : 0) + ((f & WF_INV) ? one : 0) + 1;
+}
 inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 // flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine.cpp runPlan, kernels_walk4.hip)
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
@@ -75,8 +86,11 @@ inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
 struct WalkSeg { int progStart, progCount, pStart, pEnd; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
-// patterns, 64 apart.
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff);
+// patterns, 64 apart; its tip states and reciprocal scale factors are stored pair-interleaved (walkPairIndex).
+// dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, bool paired,
+                 int P, int C, long recipOff);
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);
@@ -125,7 +139,7 @@ void launchReplicateCategories(hipStream_t stream, const double* src, double* ds
 // One level of pre-order ops.  The OpDesc fields are reused: dest = pre(child), child1 = pre(parent) (always partials),
 // mat1 = the child's branch matrix (used transposed), child2 / mat2 = the sibling's post-order partials (or compact
 // states, KIND_STATES2) and branch matrix.  Works on either partials layout.
-// recipOff != 0: a rescaling op also stores the reciprocal of its factor at scaleWrite[recipOff + p] (walk instances)
+// recipOff != 0: a rescaling op also stores the reciprocal of its factor at scaleWrite[recipOff + walkPairIndex(p)] (walk instances)
 void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
                        int maxRange, long recipOff);
 struct EdgeDesc {

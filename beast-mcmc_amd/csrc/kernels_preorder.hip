@@ -71,7 +71,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restr
         if (!(m > 0.0)) m = 1.0;
         gptr(op.scaleWrite)[p] = m;
         const double im = 1.0 / m;
-        if (recipOff) gptr(op.scaleWrite)[recipOff + p] = im;
+        if (recipOff) gptr(op.scaleWrite)[recipOff + (long)walkPairIndex((size_t)p)] = im;
         for (int c = 0; c < C; c++) for (int j = 0; j < S; j++) dest[pidx<TILED>(c, p, j, P, S, ntile)] *= im;
     }
 }

@@ -57,88 +57,128 @@ typedef unsigned long long u64;
 // consumed, one in flight)
 struct Fetched {
     v2d xa0, xa1, xb0, xb1;   // first child's partials (WF_X) or the hold slot it comes from: pattern a, pattern b
-    unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2), pattern a / b
-    double inva, invb;        // reciprocal scale factors of the pair (WF_INV)
-    double sp1, sp2;          // the two branch matrices, lane l = entry l & 15
+    unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2); PAIRED: s1a / s2a = a | b << 8
+    v2d inv;                  // PAIRED: the pair's reciprocal scale factors (WF_INV), one load
+    double inva, invb;        // otherwise: two loads
+    v2d sp;                   // entry l & 15 of the two branch matrices {M1, M2} (one load from the matrix stream)
 };
 
-struct Desc {                 // a WalkOp in SGPRs (13 dwords)
-    u64 src1, src2, store, scale, m1, m2;
+struct Desc {                 // a WalkOp in SGPRs (9 dwords; the matrices come through the stream, not the descriptor)
+    u64 src1, src2, store, scale;
     unsigned flags;
 };
-// three scalar loads of exactly the dwords in use: an unused lane of a wider load would be a register the allocator
-// hands out while the load is still pending
+// scalar loads of exactly the dwords in use: an unused lane of a wider load would be a register the allocator hands out
+// while the load is still pending
 __device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
     const u32x8 a = *reinterpret_cast<const u32x8 MI355_CONST*>(p);
-    const u32x4 b = *reinterpret_cast<const u32x4 MI355_CONST*>(p + 8);
     Desc r;
     r.src1 = ((u64)a.s1 << 32) | a.s0; r.src2 = ((u64)a.s3 << 32) | a.s2; r.store = ((u64)a.s5 << 32) | a.s4;
-    r.scale = ((u64)a.s7 << 32) | a.s6; r.m1 = ((u64)b.s1 << 32) | b.s0; r.m2 = ((u64)b.s3 << 32) | b.s2;
+    r.scale = ((u64)a.s7 << 32) | a.s6;
     r.flags = p[12];
     return r;
 }
 
-// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the two matrices.
+// Loop-invariant 32-bit byte offsets of the lane.  Tip states and reciprocal scale factors are stored PAIR-INTERLEAVED
+// (kernels.h walkPairIndex: the two patterns of a lane are neighbours), so a workgroup whose first pattern is a multiple
+// of 128 (PAIRED) gets both with one instruction — tipA / scaleA then address the pair; otherwise they are the two
+// patterns' own positions in that layout.
+struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };
+// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the matrix pair.
 // Registers of a skipped group keep their contents (a hold-slot operand is placed in xa0..xb1 by the caller).
-struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };   // loop-invariant 32-bit byte offsets of the lane
-__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o) {
-    asm volatile(
-        "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cbranch_scc0 .Lfx%=\n\t"
-        "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
-        "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
-        "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
-        "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
-        ".Lfx%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 1\n\t"
-        "s_cbranch_scc0 .Lft1%=\n\t"
-        "global_load_ubyte %[s1a], %[oTA], %[src1]\n\t"
-        "global_load_ubyte %[s1b], %[oTB], %[src1]\n"
-        ".Lft1%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 2\n\t"
-        "s_cbranch_scc0 .Lft2%=\n\t"
-        "global_load_ubyte %[s2a], %[oTA], %[src2]\n\t"
-        "global_load_ubyte %[s2b], %[oTB], %[src2]\n"
-        ".Lft2%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 3\n\t"
-        "s_cbranch_scc0 .Lfi%=\n\t"
-        "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
-        "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
-        ".Lfi%=:\n\t"
-        "global_load_dwordx2 %[sp1], %[oM], %[m1]\n\t"
-        "global_load_dwordx2 %[sp2], %[oM], %[m2]"
-        : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
-          [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb), [sp1] "+v"(f.sp1), [sp2] "+v"(f.sp2)
-        : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
-          [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [m1] "s"(d.m1), [m2] "s"(d.m2)
-        : "memory", "scc");
+template <bool PAIRED>
+__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o, u64 strm) {
+    if constexpr (PAIRED) {
+        asm volatile(
+            "s_bitcmp1_b32 %[fl], 0\n\t"
+            "s_cbranch_scc0 .Lfx%=\n\t"
+            "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
+            "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
+            "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
+            "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
+            ".Lfx%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 1\n\t"
+            "s_cbranch_scc0 .Lft1%=\n\t"
+            "global_load_ushort %[s1a], %[oTA], %[src1]\n"
+            ".Lft1%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 2\n\t"
+            "s_cbranch_scc0 .Lft2%=\n\t"
+            "global_load_ushort %[s2a], %[oTA], %[src2]\n"
+            ".Lft2%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 3\n\t"
+            "s_cbranch_scc0 .Lfi%=\n\t"
+            "global_load_dwordx4 %[inv], %[oSA], %[scale]\n"
+            ".Lfi%=:\n\t"
+            "global_load_dwordx4 %[sp], %[oM], %[strm]"
+            : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s2a] "+v"(f.s2a),
+              [inv] "+v"(f.inv), [sp] "+v"(f.sp)
+            : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oSA] "v"(o.scaleA), [oM] "v"(o.mat),
+              [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm)
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_bitcmp1_b32 %[fl], 0\n\t"
+            "s_cbranch_scc0 .Lfx%=\n\t"
+            "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
+            "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
+            "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
+            "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
+            ".Lfx%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 1\n\t"
+            "s_cbranch_scc0 .Lft1%=\n\t"
+            "global_load_ubyte %[s1a], %[oTA], %[src1]\n\t"
+            "global_load_ubyte %[s1b], %[oTB], %[src1]\n"
+            ".Lft1%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 2\n\t"
+            "s_cbranch_scc0 .Lft2%=\n\t"
+            "global_load_ubyte %[s2a], %[oTA], %[src2]\n\t"
+            "global_load_ubyte %[s2b], %[oTB], %[src2]\n"
+            ".Lft2%=:\n\t"
+            "s_bitcmp1_b32 %[fl], 3\n\t"
+            "s_cbranch_scc0 .Lfi%=\n\t"
+            "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
+            "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
+            ".Lfi%=:\n\t"
+            "global_load_dwordx4 %[sp], %[oM], %[strm]"
+            : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
+              [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb), [sp] "+v"(f.sp)
+            : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
+              [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm)
+            : "memory", "scc");
+    }
 }
 // The loads of `f` have landed once at most N younger vector-memory instructions are outstanding; jump = 8 N + 12 is the
 // byte offset of "s_waitcnt vmcnt(N)" in the table below, counted from the instruction after s_getpc_b64 (every
 // instruction here is 4 bytes; an entry is a wait and a branch).
-__device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
-    asm volatile(
-        "s_getpc_b64 s[80:81]\n\t"
-        "s_add_u32 s80, s80, %[jump]\n\t"
-        "s_addc_u32 s81, s81, 0\n\t"
-        "s_setpc_b64 s[80:81]\n\t"
-        "s_waitcnt vmcnt(0)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(1)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(2)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(3)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(4)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(5)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(6)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(7)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(8)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(9)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(10)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(11)\n\ts_branch .Lwd%=\n\t"
-        "s_waitcnt vmcnt(12)\n"
+#define MI355_WAIT_TABLE                                                                                                 \
+        "s_getpc_b64 s[80:81]\n\t"                                                                                       \
+        "s_add_u32 s80, s80, %[jump]\n\t"                                                                                \
+        "s_addc_u32 s81, s81, 0\n\t"                                                                                     \
+        "s_setpc_b64 s[80:81]\n\t"                                                                                       \
+        "s_waitcnt vmcnt(0)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(1)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(2)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(3)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(4)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(5)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(6)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(7)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(8)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(9)\n\ts_branch .Lwd%=\n\t"                                                                      \
+        "s_waitcnt vmcnt(10)\n\ts_branch .Lwd%=\n\t"                                                                     \
+        "s_waitcnt vmcnt(11)\n\ts_branch .Lwd%=\n\t"                                                                     \
+        "s_waitcnt vmcnt(12)\n"                                                                                          \
         ".Lwd%=:"
-        : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb),
-          "+v"(f.sp1), "+v"(f.sp2)
-        : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
+template <bool PAIRED>
+__device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
+    if constexpr (PAIRED)
+        asm volatile(MI355_WAIT_TABLE
+            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s2a), "+v"(f.inv), "+v"(f.sp)
+            : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
+    else
+        asm volatile(MI355_WAIT_TABLE
+            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb),
+              "+v"(f.sp)
+            : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
 // the stores of one micro-operation (maskA / maskB = the lanes whose first / second pattern really stores; nothing is
 // issued when the micro-operation has no destination).  Non-temporal: the line is written once and, if at all, read
@@ -197,10 +237,11 @@ __device__ __forceinline__ v4d column4(double sp, unsigned s) {
     return y;
 }
 
-// MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header)
-template <int MAXT, int MINW>
+// MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header); PAIRED: every
+// segment starts at a multiple of 128 patterns (always true for an unpartitioned instance)
+template <int MAXT, int MINW, bool PAIRED>
 __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
-                                                      int P, int C, long recipOff) {
+                                                      const v2d MI355_CONST* __restrict__ matStream, int P, int C, long recipOff) {
     extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), then exch[2][C][128] (double)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
@@ -214,8 +255,9 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     // loop-invariant 32-bit byte offsets: every address of the loop is (64-bit SGPR base from the descriptor) + one of these
     LaneOffsets o;
     o.partA = (unsigned)(((size_t)c * P + qa) * 32); o.partB = (unsigned)(((size_t)c * P + qb) * 32);
-    o.tipA = (unsigned)qa; o.tipB = (unsigned)qb; o.scaleA = (unsigned)qa * 8u; o.scaleB = (unsigned)qb * 8u;
-    o.mat = (unsigned)(c * 128 + (lane & 15) * 8);
+    if constexpr (PAIRED) { o.tipA = (unsigned)(p0 + 2 * lane); o.tipB = 0; o.scaleA = o.tipA * 8u; o.scaleB = 0; }
+    else { o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u; }
+    o.mat = (unsigned)(c * 256 + (lane & 15) * 16);
     v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
     double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 256);
     int buf = 0;
@@ -223,10 +265,14 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     v4d ACCa = v4d{1.0, 1.0, 1.0, 1.0}, ACCb = ACCa;
     const unsigned MI355_CONST* dp = prog + (size_t)progStart * 16;   // the host pads every segment: progCount is even and
     Desc D0 = loadDesc(dp), D1 = loadDesc(dp + 16);                    // two more descriptors (no-ops) follow it
+    // the matrix stream: entry k is [C][16] {M1, M2} pairs of the program's k-th micro-operation (k_gatherMatrices)
+    const unsigned strmStep = (unsigned)C * 256u;
+    u64 strm = (u64)(matStream) + (u64)progStart * strmStep;
     Fetched A, B;
-    A.xa0 = A.xa1 = A.xb0 = A.xb1 = v2d{1.0, 1.0}; A.s1a = A.s1b = A.s2a = A.s2b = 4u; A.inva = A.invb = A.sp1 = A.sp2 = 1.0;
+    A.xa0 = A.xa1 = A.xb0 = A.xb1 = v2d{1.0, 1.0}; A.s1a = A.s1b = A.s2a = A.s2b = 0x404u; A.inva = A.invb = 1.0;
+    A.inv = A.sp = v2d{1.0, 1.0};
     B = A;
-    fetchIssue(A, D0, o);
+    fetchIssue<PAIRED>(A, D0, o, strm);
 
     // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
 #define WALK_STAGE(CUR, NXT, DCUR, DNXT)                                                                                  \
@@ -238,25 +284,28 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
             const v2d* h = holdBase + (size_t)(k1n - WK_H0) * C * 256;                                                    \
             NXT.xa0 = h[0]; NXT.xa1 = h[64]; NXT.xb0 = h[128]; NXT.xb1 = h[192];                                          \
         }                                                                                                                 \
-        fetchIssue(NXT, DNXT, o);                                                               \
+        strm += strmStep;                                                                                                 \
+        fetchIssue<PAIRED>(NXT, DNXT, o, strm);                                                                           \
         DCUR = loadDesc(dp + 32);                      /* descriptor k + 2 (used two stages on) */                        \
         dp += 16;                                                                                                         \
         const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
-        fetchWait(CUR, (fl >> 16) & 0xffu);            /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
+        fetchWait<PAIRED>(CUR, (fl >> 16) & 0xffu);    /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
+        const unsigned t1a = PAIRED ? (CUR.s1a & 0xffu) : CUR.s1a, t1b = PAIRED ? (CUR.s1a >> 8) : CUR.s1b;               \
+        const unsigned t2a = PAIRED ? (CUR.s2a & 0xffu) : CUR.s2a, t2b = PAIRED ? (CUR.s2a >> 8) : CUR.s2b;               \
         v4d fa, fb, ga, gb;                                                                                               \
-        if (k1 == WK_TIPS) { fa = column4(CUR.sp1, CUR.s1a); fb = column4(CUR.sp1, CUR.s1b); }                               \
-        else matvecDpp2(CUR.sp1, v4d{CUR.xa0.x, CUR.xa0.y, CUR.xa1.x, CUR.xa1.y}, v4d{CUR.xb0.x, CUR.xb0.y, CUR.xb1.x, CUR.xb1.y}, fa, fb); \
-        if (k2 == WK_TIPS) { ga = column4(CUR.sp2, CUR.s2a); gb = column4(CUR.sp2, CUR.s2b); }                               \
-        else if (k2 == WK_ACC) matvecDpp2(CUR.sp2, ACCa, ACCb, ga, gb);                                                   \
+        if (k1 == WK_TIPS) { fa = column4(CUR.sp.x, t1a); fb = column4(CUR.sp.x, t1b); }                                  \
+        else matvecDpp2(CUR.sp.x, v4d{CUR.xa0.x, CUR.xa0.y, CUR.xa1.x, CUR.xa1.y}, v4d{CUR.xb0.x, CUR.xb0.y, CUR.xb1.x, CUR.xb1.y}, fa, fb); \
+        if (k2 == WK_TIPS) { ga = column4(CUR.sp.y, t2a); gb = column4(CUR.sp.y, t2b); }                                  \
+        else if (k2 == WK_ACC) matvecDpp2(CUR.sp.y, ACCa, ACCb, ga, gb);                                                  \
         else {                                         /* both children in memory (rare): the second one is not prefetched */ \
             v2d y0, y1, y2, y3;                                                                                           \
             asm volatile("global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:16\n\t"                \
                          "global_load_dwordx4 %2, %5, %6\n\tglobal_load_dwordx4 %3, %5, %6 offset:16\n\ts_waitcnt vmcnt(0)"   \
                          : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(o.partA), "v"(o.partB), "s"(dSrc2) : "memory"); \
-            matvecDpp2(CUR.sp2, v4d{y0.x, y0.y, y1.x, y1.y}, v4d{y2.x, y2.y, y3.x, y3.y}, ga, gb);                        \
+            matvecDpp2(CUR.sp.y, v4d{y0.x, y0.y, y1.x, y1.y}, v4d{y2.x, y2.y, y3.x, y3.y}, ga, gb);                       \
         }                                                                                                                 \
         v4d ra = fa * ga, rb = fb * gb;                                                                                   \
-        if (smode == WS_READ) { ra = ra * CUR.inva; rb = rb * CUR.invb; }                                                 \
+        if (smode == WS_READ) { ra = ra * (PAIRED ? CUR.inv.x : CUR.inva); rb = rb * (PAIRED ? CUR.inv.y : CUR.invb); }   \
         else if (smode == WS_WRITE) {                                                                                     \
             double ma = fmax(fmax(fmax(0.0, ra.x), fmax(ra.y, ra.z)), ra.w), mb = fmax(fmax(fmax(0.0, rb.x), fmax(rb.y, rb.z)), rb.w); \
             v2d* e = reinterpret_cast<v2d*>(exch + (size_t)buf * C * 128);                                                \
@@ -269,14 +318,27 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
             if (!(mb > 0.0)) mb = 1.0;                                                                                    \
             const double ia = 1.0 / ma, ib = 1.0 / mb;                                                                    \
             ra = ra * ia; rb = rb * ib;                                                                                   \
-            /* category 0 stores the pair's factors and reciprocals (8 bytes per pattern each); then drain */              \
-            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %6, %10\n\tglobal_store_dwordx2 %3, %7, %10\n\t"  \
-                         "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %4, %8, %10\n\tglobal_store_dwordx2 %5, %9, %10\n\t"     \
-                         "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                       \
-                         : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(o.scaleA), "v"(o.scaleA + (unsigned)recipOff * 8u), \
-                             "v"(o.scaleB), "v"(o.scaleB + (unsigned)recipOff * 8u), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory"); \
+            /* category 0 stores the pair's factors (8 bytes per pattern, plain layout) and their reciprocals (pair-       \
+               interleaved layout, recipOff doubles further on); then drain */                                            \
+            const unsigned oFA = o.partA - (unsigned)c * (unsigned)P * 32u, oFB = o.partB - (unsigned)c * (unsigned)P * 32u;   /* 32 q */ \
+            const unsigned oRA = o.scaleA + (unsigned)recipOff * 8u;                                                      \
+            if constexpr (PAIRED) {                                                                                       \
+                const v2d iab = v2d{ia, ib};                                                                              \
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %5, %8\n\tglobal_store_dwordx4 %4, %7, %8\n\t"   \
+                             "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %3, %6, %8\n\t"                                  \
+                             "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
+                             : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oFB >> 2), "v"(oRA),   \
+                                 "v"(ma), "v"(mb), "v"(iab), "s"(dScale) : "memory");                                     \
+            } else {                                                                                                      \
+                const unsigned oRB = o.scaleB + (unsigned)recipOff * 8u;                                                  \
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %6, %10\n\tglobal_store_dwordx2 %3, %7, %10\n\t"  \
+                             "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %4, %8, %10\n\tglobal_store_dwordx2 %5, %9, %10\n\t"     \
+                             "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
+                             : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oRA),       \
+                                 "v"(oFB >> 2), "v"(oRB), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory");    \
+            }                                                                                                             \
         }                                                                                                                 \
-        storeIssue(ra, rb, fl, validA, validB, o.partA, o.partB, dStore);                                                         \
+        storeIssue(ra, rb, fl, validA, validB, o.partA, o.partB, dStore);                                                 \
         if (hold) {                                    /* this value waits for its sibling's subtree */                   \
             v2d* h = holdBase + (size_t)(hold - 1) * C * 256;                                                             \
             h[0] = v2d{ra.x, ra.y}; h[64] = v2d{ra.z, ra.w}; h[128] = v2d{rb.x, rb.y}; h[192] = v2d{rb.z, rb.w};          \
@@ -292,15 +354,34 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, int P, int C, long recipOff) {
+// stream[k][c][e] = {M1_k[c][e], M2_k[c][e]}: the branch matrices of every micro-operation in program order, so that the
+// walk's fetch stage gets both with ONE 16-byte load per lane at an address it only has to increment
+__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int elems, v2d* __restrict__ stream) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * elems) return;
+    const int k = (int)(t / elems), r = (int)(t % elems);
+    stream[t] = v2d{gptr(prog[k].m1)[r], gptr(prog[k].m2)[r]};
+}
+
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream) {
+    if (nOps <= 0) return;
+    const int elems = C * 16;
+    const size_t total = (size_t)nOps * elems;
+    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, elems, (v2d*)dStream);
+}
+
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, bool paired,
+                 int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const size_t lds = (size_t)2 * C * 256 * sizeof(v2d) + (size_t)2 * C * 128 * sizeof(double);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
-    if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
-    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
-    else hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, P, C, recipOff);
+    const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
+#define MI355_WALK(T, PR) hipLaunchKernelGGL((k_walk4<T, 4, PR>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff)
+    if (paired) { if (C <= 4) MI355_WALK(256, true); else if (C <= 8) MI355_WALK(512, true); else MI355_WALK(1024, true); }
+    else { if (C <= 4) MI355_WALK(256, false); else if (C <= 8) MI355_WALK(512, false); else MI355_WALK(1024, false); }
+#undef MI355_WALK
 }
 
 }  // namespace mi355

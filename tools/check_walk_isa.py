@@ -32,25 +32,24 @@ def all_regs(line):
     return out
 
 
-def check_function(name, lines):
+def check_function(name, lines, paired):
     problems = []
+    want = 26 if paired else 28     # 16 partials + tip states (2 / 4) + reciprocal scale factors (4) + the matrix pair (4)
     waits = [i for i, l in enumerate(lines) if "s_setpc_b64" in l]          # the jump into the s_waitcnt table = the stage's wait
     blocks = []
     i = 0
     while i < len(lines):
         if re.match(r"\s*s_bitcmp1_b32 s\d+, 0$", lines[i]) and i + 1 < len(lines) and ".Lfx" in lines[i + 1]:
-            j, dst, seen_fi, tail = i, set(), False, 0
+            j, dst, seen_fi = i, set(), False
             while j < len(lines):
                 t = lines[j].strip()
                 if t.startswith(".Lfi"):
                     seen_fi = True
                 if t.startswith("global_load"):
                     dst |= regs(t.split()[1].rstrip(","))
-                    if seen_fi:
-                        tail += 1
-                        if tail == 2:                # the second matrix load ends the block
-                            j += 1
-                            break
+                    if seen_fi:                      # the matrix-stream load ends the block
+                        j += 1
+                        break
                 elif not (t.startswith("s_bitcmp1") or t.startswith("s_cbranch_scc0") or t.startswith(".Lf")):
                     break
                 j += 1
@@ -65,8 +64,8 @@ def check_function(name, lines):
                         % (name, len(blocks) - len(loop_blocks), len(loop_blocks), len(waits)))
         return problems
     for (a, b, dst) in blocks:
-        if len(dst) != 28:
-            problems.append("%s: fetch block at line %d writes %d registers, expected 28" % (name, a, len(dst)))
+        if len(dst) != want:
+            problems.append("%s: fetch block at line %d writes %d registers, expected %d" % (name, a, len(dst), want))
     loop_start = labels[0]
     for (a, b, dst) in loop_blocks:
         later = [w for w in waits if w >= b]
@@ -109,11 +108,11 @@ def main():
     if any(sc):
         problems.append("scratch in use: %s" % sc)
     funcs = re.findall(r"^(_ZN5mi3557k_walk4[^:\n]*):\s*;.*?\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    if len(funcs) < 3:
-        problems.append("found %d kernel instantiations, expected 3" % len(funcs))
+    if len(funcs) != 6:
+        problems.append("found %d kernel instantiations, expected 6" % len(funcs))
     for name, body in funcs:
         lines = [l for l in body.split("\n") if not l.strip().startswith(";")]
-        problems += check_function(name[:40], lines)
+        problems += check_function(name[:40], lines, "ELb1E" in name)
     for p in problems:
         print("PROBLEM:", p)
     print("walk kernel ISA check: %s (VGPRs %s, %d instantiations)" % ("FAILED" if problems else "ok", vg, len(funcs)))
