@@ -359,12 +359,15 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         if (ps.progCount & 1) w.push_back(nop);
         segs[si].progCount = (int)w.size() - segs[si].progStart;
         w.push_back(nop); w.push_back(nop);
-        // the wait of every stage: "at most N vector-memory instructions outstanding" with N = the LOADS younger than the
-        // stage's own (those of the next micro-operation).  Loads return in order among themselves, but loads and stores
-        // share the counter and may complete out of order with each other, so the stores of the previous stage are NOT
-        // counted: if they are still pending the wait is merely longer than necessary, never too short.
-        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++)
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags, paired), 12));
+        // the wait of every stage: "at most N vector-memory instructions outstanding" with N = everything issued AFTER the
+        // stage's own loads: the stores of the previous micro-operation and the loads of the next one.  Loads and stores
+        // share the counter and are counted out strictly in issue order (tools/vmcnt_order_probe.hip: a younger store is
+        // never retired before an older load), so a stage does not have to wait for the previous stage's stores to be
+        // acknowledged.  A smaller N than the true number only waits longer (the table ends at 12).
+        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
+            const int stores = i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0;
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags, paired) + stores, 12));
+        }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
@@ -397,7 +400,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
-    const size_t streamBytes = w.size() * (size_t)in->C * 16 * 2 * sizeof(double);
+    const size_t streamBytes = w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->matStream) hipFree(in->matStream);

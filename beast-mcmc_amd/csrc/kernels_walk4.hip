@@ -60,8 +60,7 @@ struct Fetched {
     unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2); PAIRED: s1a / s2a = a | b << 8
     v2d inv;                  // PAIRED: the pair's reciprocal scale factors (WF_INV), one load
     double inva, invb;        // otherwise: two loads
-    v2d sp;                   // entry l & 15 of the two branch matrices {M1, M2} (one load from the matrix stream)
-};
+};                            // (the two branch matrices go straight to LDS: fetchIssue)
 
 struct Desc {                 // a WalkOp in SGPRs (9 dwords; the matrices come through the stream, not the descriptor)
     u64 src1, src2, store, scale;
@@ -83,12 +82,18 @@ __device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
 // of 128 (PAIRED) gets both with one instruction — tipA / scaleA then address the pair; otherwise they are the two
 // patterns' own positions in that layout.
 struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };
-// issue the loads of one micro-operation: only the groups it needs (WF_* bits of the flags), then the matrix pair.
-// Registers of a skipped group keep their contents (a hold-slot operand is placed in xa0..xb1 by the caller).
+// issue the loads of one micro-operation: its matrix table (320 bytes of the matrix stream, lanes 0..19, by LDS-DMA to
+// the wave's table buffer `ldsDst` — no registers; tools/glds_probe.hip), then only the groups it needs (WF_* bits of the
+// flags).  Registers of a skipped group keep their contents (a hold-slot operand is placed in xa0..xb1 by the caller).
+#define MI355_TABLE_DMA                                                                                                  \
+            "s_mov_b32 m0, %[dst]\n\t"                                                                                   \
+            "s_mov_b64 exec, 0xfffff\n\t"                                                                                \
+            "global_load_lds_dwordx4 %[oM], %[strm]\n\t"                                                                 \
+            "s_mov_b64 exec, -1\n\t"
 template <bool PAIRED>
-__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o, u64 strm) {
+__device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o, u64 strm, unsigned ldsDst) {
     if constexpr (PAIRED) {
-        asm volatile(
+        asm volatile(MI355_TABLE_DMA
             "s_bitcmp1_b32 %[fl], 0\n\t"
             "s_cbranch_scc0 .Lfx%=\n\t"
             "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
@@ -107,15 +112,14 @@ __device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const Lane
             "s_bitcmp1_b32 %[fl], 3\n\t"
             "s_cbranch_scc0 .Lfi%=\n\t"
             "global_load_dwordx4 %[inv], %[oSA], %[scale]\n"
-            ".Lfi%=:\n\t"
-            "global_load_dwordx4 %[sp], %[oM], %[strm]"
+            ".Lfi%=:"
             : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s2a] "+v"(f.s2a),
-              [inv] "+v"(f.inv), [sp] "+v"(f.sp)
+              [inv] "+v"(f.inv)
             : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oSA] "v"(o.scaleA), [oM] "v"(o.mat),
-              [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm)
+              [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm), [dst] "s"(ldsDst)
             : "memory", "scc");
     } else {
-        asm volatile(
+        asm volatile(MI355_TABLE_DMA
             "s_bitcmp1_b32 %[fl], 0\n\t"
             "s_cbranch_scc0 .Lfx%=\n\t"
             "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
@@ -137,12 +141,12 @@ __device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const Lane
             "s_cbranch_scc0 .Lfi%=\n\t"
             "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
             "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
-            ".Lfi%=:\n\t"
-            "global_load_dwordx4 %[sp], %[oM], %[strm]"
+            ".Lfi%=:"
             : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
-              [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb), [sp] "+v"(f.sp)
+              [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb)
             : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
-              [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm)
+              [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm),
+              [dst] "s"(ldsDst)
             : "memory", "scc");
     }
 }
@@ -172,12 +176,11 @@ template <bool PAIRED>
 __device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
     if constexpr (PAIRED)
         asm volatile(MI355_WAIT_TABLE
-            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s2a), "+v"(f.inv), "+v"(f.sp)
+            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s2a), "+v"(f.inv)
             : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
     else
         asm volatile(MI355_WAIT_TABLE
-            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb),
-              "+v"(f.sp)
+            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb)
             : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
 // the stores of one micro-operation (maskA / maskB = the lanes whose first / second pattern really stores; nothing is
@@ -222,19 +225,14 @@ __device__ __forceinline__ void matvecDpp2(const double sp, const v4d xa, const 
     ya = v4d{a0, a1, a2, a3}; yb = v4d{b0, b1, b2, b3};
 }
 
-__device__ __forceinline__ double bperm(double v, int byteAddr) {
-    const int lo = __builtin_amdgcn_ds_bpermute(byteAddr, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(byteAddr, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-// column `s` of the spread matrix: y[i] = M[i][s] = lane 4i + s, or 1 for a missing state (s >= 4)
-__device__ __forceinline__ v4d column4(double sp, unsigned s) {
-    const int base = (int)(s & 3u) * 4;
-    const bool known = s < 4u;
-    v4d y;
-    y.x = bperm(sp, base); y.y = bperm(sp, base + 16); y.z = bperm(sp, base + 32); y.w = bperm(sp, base + 48);
-    y.x = known ? y.x : 1.0; y.y = known ? y.y : 1.0; y.z = known ? y.z : 1.0; y.w = known ? y.w : 1.0;
-    return y;
+// A micro-operation's matrix table in LDS (written by the LDS-DMA of fetchIssue from the stream k_gatherMatrices lays
+// out): for each of the two branch matrices five columns of four doubles, T[s][i] = M[i][s] for a state s < 4 and 1 for
+// s = 4 (missing) — what a compact tip child in state s contributes, read with two ds_read_b128 and no select.
+constexpr int WALK_TABLE_BYTES = 320, WALK_TABLE_M2 = 160;
+__device__ __forceinline__ v4d tipColumn(const char* tbl, unsigned s) {
+    const v2d* p = reinterpret_cast<const v2d*>(tbl + (s << 5));
+    const v2d lo = p[0], hi = p[1];
+    return v4d{lo.x, lo.y, hi.x, hi.y};
 }
 
 // MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header); PAIRED: every
@@ -242,7 +240,7 @@ __device__ __forceinline__ v4d column4(double sp, unsigned s) {
 template <int MAXT, int MINW, bool PAIRED>
 __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                       const v2d MI355_CONST* __restrict__ matStream, int P, int C, long recipOff) {
-    extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), then exch[2][C][128] (double)
+    extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), exch[C][128] (double), table[2][MAXT / 64][320 B]
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
     const int p0 = pStart + (int)blockIdx.x * 128;
@@ -257,25 +255,30 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     o.partA = (unsigned)(((size_t)c * P + qa) * 32); o.partB = (unsigned)(((size_t)c * P + qb) * 32);
     if constexpr (PAIRED) { o.tipA = (unsigned)(p0 + 2 * lane); o.tipB = 0; o.scaleA = o.tipA * 8u; o.scaleB = 0; }
     else { o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u; }
-    o.mat = (unsigned)(c * 256 + (lane & 15) * 16);
+    o.mat = (unsigned)(c * WALK_TABLE_BYTES + lane * 16);          // lanes 0..19 copy the wave's 320-byte table
     v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
     double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 256);
-    int buf = 0;
+    // the wave's two matrix tables (ping-pong with the fetch stage); a lane's entry (l & 15) of matrix 1 for the DPP mat-vec
+    // is T[k][i] with l & 15 = 4 i + k
+    constexpr int MAXC = MAXT / 64;
+    const char* tbl0 = reinterpret_cast<const char*>(exch + (size_t)C * 128) + c * WALK_TABLE_BYTES;
+    const unsigned tblDst0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)tbl0);
+    const int spOff = (((lane & 3) * 4) + ((lane & 15) >> 2)) * 8;
 
     v4d ACCa = v4d{1.0, 1.0, 1.0, 1.0}, ACCb = ACCa;
     const unsigned MI355_CONST* dp = prog + (size_t)progStart * 16;   // the host pads every segment: progCount is even and
     Desc D0 = loadDesc(dp), D1 = loadDesc(dp + 16);                    // two more descriptors (no-ops) follow it
-    // the matrix stream: entry k is [C][16] {M1, M2} pairs of the program's k-th micro-operation (k_gatherMatrices)
-    const unsigned strmStep = (unsigned)C * 256u;
+    // the matrix stream: entry k is the [C] matrix tables of the program's k-th micro-operation (k_gatherMatrices)
+    const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
     u64 strm = (u64)(matStream) + (u64)progStart * strmStep;
     Fetched A, B;
     A.xa0 = A.xa1 = A.xb0 = A.xb1 = v2d{1.0, 1.0}; A.s1a = A.s1b = A.s2a = A.s2b = 0x404u; A.inva = A.invb = 1.0;
-    A.inv = A.sp = v2d{1.0, 1.0};
+    A.inv = v2d{1.0, 1.0};
     B = A;
-    fetchIssue<PAIRED>(A, D0, o, strm);
+    fetchIssue<PAIRED>(A, D0, o, strm, tblDst0);
 
     // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
-#define WALK_STAGE(CUR, NXT, DCUR, DNXT)                                                                                  \
+#define WALK_STAGE(CUR, NXT, DCUR, DNXT, TB)                                                                                \
     {                                                                                                                     \
         const unsigned fl = DCUR.flags;                                                                                   \
         const u64 dStore = DCUR.store, dScale = DCUR.scale, dSrc2 = DCUR.src2;                                            \
@@ -285,35 +288,41 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
             NXT.xa0 = h[0]; NXT.xa1 = h[64]; NXT.xb0 = h[128]; NXT.xb1 = h[192];                                          \
         }                                                                                                                 \
         strm += strmStep;                                                                                                 \
-        fetchIssue<PAIRED>(NXT, DNXT, o, strm);                                                                           \
-        DCUR = loadDesc(dp + 32);                      /* descriptor k + 2 (used two stages on) */                        \
-        dp += 16;                                                                                                         \
+        fetchIssue<PAIRED>(NXT, DNXT, o, strm, tblDst0 + (1 - TB) * MAXC * WALK_TABLE_BYTES);                             \
         const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
         fetchWait<PAIRED>(CUR, (fl >> 16) & 0xffu);    /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
         const unsigned t1a = PAIRED ? (CUR.s1a & 0xffu) : CUR.s1a, t1b = PAIRED ? (CUR.s1a >> 8) : CUR.s1b;               \
         const unsigned t2a = PAIRED ? (CUR.s2a & 0xffu) : CUR.s2a, t2b = PAIRED ? (CUR.s2a >> 8) : CUR.s2b;               \
+        const char* tb = tbl0 + TB * MAXC * WALK_TABLE_BYTES;   /* this micro-operation's table landed with its loads */ \
         v4d fa, fb, ga, gb;                                                                                               \
-        if (k1 == WK_TIPS) { fa = column4(CUR.sp.x, t1a); fb = column4(CUR.sp.x, t1b); }                                  \
-        else matvecDpp2(CUR.sp.x, v4d{CUR.xa0.x, CUR.xa0.y, CUR.xa1.x, CUR.xa1.y}, v4d{CUR.xb0.x, CUR.xb0.y, CUR.xb1.x, CUR.xb1.y}, fa, fb); \
-        if (k2 == WK_TIPS) { ga = column4(CUR.sp.y, t2a); gb = column4(CUR.sp.y, t2b); }                                  \
-        else if (k2 == WK_ACC) matvecDpp2(CUR.sp.y, ACCa, ACCb, ga, gb);                                                  \
+        if (k1 == WK_TIPS) { fa = tipColumn(tb, t1a); fb = tipColumn(tb, t1b); }                                          \
+        else matvecDpp2(*reinterpret_cast<const double*>(tb + spOff), v4d{CUR.xa0.x, CUR.xa0.y, CUR.xa1.x, CUR.xa1.y},    \
+                        v4d{CUR.xb0.x, CUR.xb0.y, CUR.xb1.x, CUR.xb1.y}, fa, fb);                                         \
+        if (k2 == WK_TIPS) { ga = tipColumn(tb + WALK_TABLE_M2, t2a); gb = tipColumn(tb + WALK_TABLE_M2, t2b); }          \
+        else if (k2 == WK_ACC) matvecDpp2(*reinterpret_cast<const double*>(tb + WALK_TABLE_M2 + spOff), ACCa, ACCb, ga, gb);   \
         else {                                         /* both children in memory (rare): the second one is not prefetched */ \
             v2d y0, y1, y2, y3;                                                                                           \
             asm volatile("global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:16\n\t"                \
                          "global_load_dwordx4 %2, %5, %6\n\tglobal_load_dwordx4 %3, %5, %6 offset:16\n\ts_waitcnt vmcnt(0)"   \
                          : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(o.partA), "v"(o.partB), "s"(dSrc2) : "memory"); \
-            matvecDpp2(CUR.sp.y, v4d{y0.x, y0.y, y1.x, y1.y}, v4d{y2.x, y2.y, y3.x, y3.y}, ga, gb);                       \
+            matvecDpp2(*reinterpret_cast<const double*>(tb + WALK_TABLE_M2 + spOff), v4d{y0.x, y0.y, y1.x, y1.y},         \
+                       v4d{y2.x, y2.y, y3.x, y3.y}, ga, gb);                                                              \
         }                                                                                                                 \
+        /* descriptor k + 2 (used two stages on).  Scalar loads share the LDS counter and return out of order, so every   \
+           LDS wait also waits for them: issued HERE, behind the stage's LDS reads, they have the arithmetic below to land */ \
         v4d ra = fa * ga, rb = fb * gb;                                                                                   \
+        asm volatile("" : "+v"(ra), "+v"(rb));         /* (keeps the loads below behind the products' LDS wait) */         \
+        DCUR = loadDesc(dp + 32);                                                                                         \
+        dp += 16;                                                                                                         \
         if (smode == WS_READ) { ra = ra * (PAIRED ? CUR.inv.x : CUR.inva); rb = rb * (PAIRED ? CUR.inv.y : CUR.invb); }   \
         else if (smode == WS_WRITE) {                                                                                     \
             double ma = fmax(fmax(fmax(0.0, ra.x), fmax(ra.y, ra.z)), ra.w), mb = fmax(fmax(fmax(0.0, rb.x), fmax(rb.y, rb.z)), rb.w); \
-            v2d* e = reinterpret_cast<v2d*>(exch + (size_t)buf * C * 128);                                                \
+            v2d* e = reinterpret_cast<v2d*>(exch);                                                                        \
             e[c * 64 + lane] = v2d{ma, mb};                                                                               \
             __syncthreads();                                                                                              \
             ma = 0.0; mb = 0.0;                                                                                           \
             for (int cc = 0; cc < C; cc++) { const v2d t = e[cc * 64 + lane]; ma = fmax(ma, t.x); mb = fmax(mb, t.y); }   \
-            buf ^= 1;                                                                                                     \
+            __syncthreads();                           /* the exchange buffer is free again */                            \
             if (!(ma > 0.0)) ma = 1.0;                                                                                    \
             if (!(mb > 0.0)) mb = 1.0;                                                                                    \
             const double ia = 1.0 / ma, ib = 1.0 / mb;                                                                    \
@@ -347,34 +356,35 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     }
 
     for (int k = 0; k < progCount; k += 2) {
-        WALK_STAGE(A, B, D0, D1)
-        WALK_STAGE(B, A, D1, D0)
+        WALK_STAGE(A, B, D0, D1, 0)
+        WALK_STAGE(B, A, D1, D0, 1)
     }
 #undef WALK_STAGE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// stream[k][c][e] = {M1_k[c][e], M2_k[c][e]}: the branch matrices of every micro-operation in program order, so that the
-// walk's fetch stage gets both with ONE 16-byte load per lane at an address it only has to increment
-__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int elems, v2d* __restrict__ stream) {
+// stream[k][c] = the matrix table of micro-operation k, category c (see tipColumn): 2 x 5 columns x 4 doubles, in
+// program order, so that the walk's fetch stage copies it to LDS with ONE instruction at an address it only increments
+__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * elems) return;
-    const int k = (int)(t / elems), r = (int)(t % elems);
-    stream[t] = v2d{gptr(prog[k].m1)[r], gptr(prog[k].m2)[r]};
+    if (t >= (size_t)n * C * 40) return;
+    const int k = (int)(t / (C * 40)), r = (int)(t % (C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
+    const double MI355_GLOBAL* M = gptr(m ? prog[k].m2 : prog[k].m1) + c * 16;
+    stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
 }
 
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream) {
     if (nOps <= 0) return;
-    const int elems = C * 16;
-    const size_t total = (size_t)nOps * elems;
-    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, elems, (v2d*)dStream);
+    const size_t total = (size_t)nOps * C * 40;
+    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream);
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, bool paired,
                  int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
-    const size_t lds = (size_t)2 * C * 256 * sizeof(v2d) + (size_t)2 * C * 128 * sizeof(double);
+    const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
+    const size_t lds = (size_t)2 * C * 256 * sizeof(v2d) + (size_t)C * 128 * sizeof(double) + (size_t)2 * maxC * WALK_TABLE_BYTES;
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;

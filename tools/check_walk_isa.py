@@ -34,22 +34,20 @@ def all_regs(line):
 
 def check_function(name, lines, paired):
     problems = []
-    want = 26 if paired else 28     # 16 partials + tip states (2 / 4) + reciprocal scale factors (4) + the matrix pair (4)
+    want = 22 if paired else 24     # 16 partials + tip states (2 / 4) + reciprocal scale factors (4); the matrices go to LDS
     waits = [i for i, l in enumerate(lines) if "s_setpc_b64" in l]          # the jump into the s_waitcnt table = the stage's wait
     blocks = []
     i = 0
     while i < len(lines):
         if re.match(r"\s*s_bitcmp1_b32 s\d+, 0$", lines[i]) and i + 1 < len(lines) and ".Lfx" in lines[i + 1]:
-            j, dst, seen_fi = i, set(), False
+            j, dst = i, set()
             while j < len(lines):
                 t = lines[j].strip()
-                if t.startswith(".Lfi"):
-                    seen_fi = True
+                if t.startswith(".Lfi"):             # the label after the last group ends the block
+                    j += 1
+                    break
                 if t.startswith("global_load"):
                     dst |= regs(t.split()[1].rstrip(","))
-                    if seen_fi:                      # the matrix-stream load ends the block
-                        j += 1
-                        break
                 elif not (t.startswith("s_bitcmp1") or t.startswith("s_cbranch_scc0") or t.startswith(".Lf")):
                     break
                 j += 1

@@ -1,7 +1,8 @@
-ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/prof_r02_s1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+# SQ counter passes over the headline bench (run on the GPU box through gpurun; never add TA_* _sum counters: that pass hangs rocprofv3)
+ROOT=$GRAFT_REPO_ROOT; TAG=${1:-sq}; OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_$name.json 2> $OUT/$name.err; echo "$name rc=$?"; }
 run sqa SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM
 run sqb SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS
-run sqc SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR
-run ta TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
-find $OUT -name "*.db" -delete; du -sh $OUT
+run sqc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAVES SQ_INSTS_VMEM_WR
+find $OUT -name "*.db" -delete
+python3 $ROOT/tools/sum_counters.py $OUT
