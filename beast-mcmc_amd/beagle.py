@@ -445,7 +445,7 @@ class Beagle:
         """Counters of the 4-state pattern walk since the last kernelTimer call (include/beagle_mi355.h)."""
         out = (C.c_long * 8)()
         self._check("walkStats", self._ext("beagleMi355WalkStats", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
-        keys = ("micro_ops", "stored", "mem_reads", "tip_reads", "scale_reads", "walks", "scale_writes")
+        keys = ("micro_ops", "stored", "mem_reads", "tip_reads", "scale_reads", "walks", "scale_writes", "fast_walks")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def deviceBytes(self):

@@ -55,6 +55,9 @@ struct Instance {
                                                          // kernels.h walkPairIndex)], this many doubles apart
     size_t statePairOff = 0;                             // walk instances: a tip's pair-interleaved states follow its plain ones, this many bytes on
     char* matStream = nullptr; size_t matStreamBytes = 0;   // walk instances: the matrix stream of the program being run (k_gatherMatrices)
+    uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
+                                                                 // micro-operation does not use (the assembly loop loads them unconditionally)
+    long statFastWalks = 0;
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
     double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
@@ -301,6 +304,19 @@ inline void clearVirtual(Instance* in, int X) { if (in->walk) in->planner.clearV
 inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
 inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X] = on ? 1 : 0; }
 
+int ensureWalkDummies(Instance* in) {
+    if (in->dummyTips) return 0;
+    const size_t tipBytes = (((size_t)in->P + 127) & ~(size_t)127) + 256, scaleBytes = in->scaleStride * sizeof(double);
+    void* p = nullptr;
+    int rc = devAlloc(in, &p, ((tipBytes + 255) & ~(size_t)255) + scaleBytes); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(p, in->S, tipBytes, in->stream));
+    double* ones = (double*)((char*)p + ((tipBytes + 255) & ~(size_t)255));
+    mi355::launchFill(in->stream, ones, 1.0, 0, (int)in->scaleStride);
+    HIP_TRY(hipGetLastError());
+    in->dummyTips = (uint8_t*)p; in->onesScale = ones;
+    return 0;
+}
+
 // Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
 // micro-operations travel together) and enqueue the snapshot copies and the walk.
 int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk = nullptr) {
@@ -320,9 +336,12 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
     w.reserve(n + 3 * plan.segs.size());
     std::vector<mi355::WalkSeg> segs(plan.segs.size());
     const size_t matStride = (size_t)in->C * 16;
+    { int rc = ensureWalkDummies(in); if (rc) return rc; }
+    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
     mi355::WalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.m1 = in->matrices; nop.m2 = in->matrices;
+    nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
     int maxRange = 0;
     bool paired = true;                            // every segment starts at a multiple of 128 patterns (kernels_walk4.hip)
@@ -334,6 +353,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
             const mi355::MicroOp& m = plan.prog[i];
             mi355::WalkOp d;
             memset(&d, 0, sizeof(d));
+            d.src1 = in->dummyTips; d.src2 = in->dummyTips; d.scale = in->onesScale;     // unused operands stay readable (kernels.h launchWalk4Fast)
             if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
             else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + in->statePairOff; in->statTipReads++; }
             if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
@@ -354,6 +374,12 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
             }
             d.m1 = in->matrices + (size_t)m.mat1 * matStride; d.m2 = in->matrices + (size_t)m.mat2 * matStride;
             d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
+            if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
+                if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
+                if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
+                if (ablate & 4) d.scale = in->onesScale;
+                if (ablate & 8) { if (m.k1 == mi355::PK_TIPS) d.src1 = in->dummyTips; if (m.k2 == mi355::PK_TIPS) d.src2 = in->dummyTips; }
+            }
             w.push_back(d);
         }
         if (ps.progCount & 1) w.push_back(nop);
@@ -366,7 +392,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         // acknowledged.  A smaller N than the true number only waits longer (the table ends at 12).
         for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
             const int stores = i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0;
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags, paired) + stores, 12));
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
+            // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
+            const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
+            if (code == 1) w[i].flags |= mi355::WF_WAIT8; else if (code == 2) w[i].flags |= mi355::WF_WAIT12;
         }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
@@ -412,13 +441,24 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
     mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
+    static const bool noFast = getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0;
     for (size_t b = 0; b < segs.size();) {
         size_t e = b + 1;
         while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
         int range = 0;
-        for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
-        mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                           in->matStream, paired, in->P, in->C, (long)in->scaleStride);
+        bool fast = paired && !noFast;            // the assembly loop: aligned segments, no write-mode rescaling (kernels.h)
+        for (size_t i = b; i < e; i++) {
+            range = std::max(range, segs[i].pEnd - segs[i].pStart);
+            for (int k = plan.segs[i].progStart; fast && k < plan.segs[i].progStart + plan.segs[i].progCount; k++)
+                if (plan.prog[k].smode == mi355::PS_WRITE) fast = false;
+        }
+        if (fast) {
+            mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                                   in->matStream, in->P, in->C);
+            in->statFastWalks++;
+        } else
+            mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                               in->matStream, in->P, in->C, (long)in->scaleStride);
         in->statWalks++;
         b = e;
     }
@@ -1890,7 +1930,7 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     if (outMillis) *outMillis = in->timedMs;
     if (outLaunches) *outLaunches = in->timedLaunches;
     in->timedMs = 0.0; in->timedLaunches = 0;
-    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = 0;
+    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
     in->timing = enable != 0;
     return BEAGLE_SUCCESS;
 }
@@ -1903,7 +1943,7 @@ int beagleMi355WalkStats(int instance, long* out8) {
     Instance* in = lookup(instance);
     if (!in || !out8) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out8[0] = in->statMicroOps; out8[1] = in->statStored; out8[2] = in->statMemReads; out8[3] = in->statTipReads;
-    out8[4] = in->statScaleReads; out8[5] = in->statWalks; out8[6] = in->statScaleWrites; out8[7] = 0;
+    out8[4] = in->statScaleReads; out8[5] = in->statWalks; out8[6] = in->statScaleWrites; out8[7] = in->statFastWalks;
     return BEAGLE_SUCCESS;
 }
 

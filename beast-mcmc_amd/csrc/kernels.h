@@ -45,6 +45,10 @@ enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4 };
 enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 // flags: what the kernel's fetch stage has to load for the micro-operation (WF_*), then the kinds
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
+// more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
+// second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code (WF_WAIT8: vmcnt(8),
+// WF_WAIT12: vmcnt(12), neither: vmcnt(4))
+enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT8 = 1u << 28, WF_WAIT12 = 1u << 29 };
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
@@ -58,12 +62,13 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
 };
 static_assert(sizeof(WalkOp) == 64, "WalkOp layout");
 // Position of pattern p in a pair-interleaved per-pattern array (walk instances: compact tip states, reciprocal scale
-// factors): within every block of 128 patterns, pattern l and pattern l + 64 — the two a lane of the walk owns — are
-// neighbours.  Such arrays are padded to a multiple of 128 entries.
+// factors).  Of every block of 128 patterns, lane 2 q + r of the walk owns patterns q + 32 r and 64 + q + 32 r (that
+// assignment makes its result stores full cache lines: tools/gen_walk4_fast.py) — the two are neighbours here, pair after
+// pair in lane order.  Such arrays are padded to a multiple of 128 entries.
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline size_t walkPairIndex(size_t p) { return (p & ~(size_t)127) + 2 * (p & 63) + ((p >> 6) & 1); }
+inline size_t walkPairIndex(size_t p) { return (p & ~(size_t)127) + 4 * (p & 31) + 2 * ((p >> 5) & 1) + ((p >> 6) & 1); }
 inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     unsigned f = (unsigned)((k1 << 5) | (k2 << 8) | (hold << 11) | (smode << 13));
     if (k1 == WK_MEM) f |= WF_X;
@@ -71,14 +76,14 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     if (k2 == WK_TIPS) f |= WF_T2;
     if (smode == WS_READ) f |= WF_INV;
     if (store) f |= WF_STORE;
+    if (k1 >= WK_H0) f |= WF_HREAD | (k1 == WK_H1 ? WF_HREAD1 : 0u);
+    if (k2 == WK_MEM) f |= WF_MEM2;
+    if (hold) f |= WF_HWRITE;
     return f;
 }
 // vector-memory instructions the kernel's fetch stage issues for a micro-operation / its store stage
-// (paired: the launch's segments all start at a multiple of 128 patterns — one load per tip child / reciprocal pair)
-inline int walkFetchCount(unsigned f, bool paired) {
-    const int one = paired ? 1 : 2;
-    return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? one : 0) + ((f & WF_T2) ? one : 0) + ((f & WF_INV) ? one : 0) + 1;
-}
+// of k_walk4 (k_walk4_fast always issues 4, + 4 with WF_X)
+inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? 2 : 0) + ((f & WF_T2) ? 2 : 0) + ((f & WF_INV) ? 2 : 0) + 1; }
 inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 // flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine.cpp runPlan, kernels_walk4.hip)
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
@@ -88,9 +93,13 @@ struct WalkSeg { int progStart, progCount, pStart, pEnd; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
 // patterns, 64 apart; its tip states and reciprocal scale factors are stored pair-interleaved (walkPairIndex).
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, bool paired,
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream,
                  int P, int C, long recipOff);
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
+// The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirements: every segment starts at a multiple of 128
+// patterns, no micro-operation rescales in write mode, and EVERY descriptor carries readable addresses in src1, src2 and
+// scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
+void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);

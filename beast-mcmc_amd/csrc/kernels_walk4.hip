@@ -57,9 +57,8 @@ typedef unsigned long long u64;
 // consumed, one in flight)
 struct Fetched {
     v2d xa0, xa1, xb0, xb1;   // first child's partials (WF_X) or the hold slot it comes from: pattern a, pattern b
-    unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2); PAIRED: s1a / s2a = a | b << 8
-    v2d inv;                  // PAIRED: the pair's reciprocal scale factors (WF_INV), one load
-    double inva, invb;        // otherwise: two loads
+    unsigned s1a, s1b, s2a, s2b;   // tip states of the two children (WF_T1 / WF_T2), pattern a / b
+    double inva, invb;        // reciprocal scale factors of the pair (WF_INV)
 };                            // (the two branch matrices go straight to LDS: fetchIssue)
 
 struct Desc {                 // a WalkOp in SGPRs (9 dwords; the matrices come through the stream, not the descriptor)
@@ -78,9 +77,8 @@ __device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
 }
 
 // Loop-invariant 32-bit byte offsets of the lane.  Tip states and reciprocal scale factors are stored PAIR-INTERLEAVED
-// (kernels.h walkPairIndex: the two patterns of a lane are neighbours), so a workgroup whose first pattern is a multiple
-// of 128 (PAIRED) gets both with one instruction — tipA / scaleA then address the pair; otherwise they are the two
-// patterns' own positions in that layout.
+// (kernels.h walkPairIndex) for the assembly loop k_walk4_fast, whose lanes own other pattern pairs than this kernel's;
+// here tipA / tipB / scaleA / scaleB are simply the positions of the lane's two patterns in that layout.
 struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };
 // issue the loads of one micro-operation: its matrix table (320 bytes of the matrix stream, lanes 0..19, by LDS-DMA to
 // the wave's table buffer `ldsDst` — no registers; tools/glds_probe.hip), then only the groups it needs (WF_* bits of the
@@ -90,65 +88,36 @@ struct LaneOffsets { unsigned partA, partB, tipA, tipB, scaleA, scaleB, mat; };
             "s_mov_b64 exec, 0xfffff\n\t"                                                                                \
             "global_load_lds_dwordx4 %[oM], %[strm]\n\t"                                                                 \
             "s_mov_b64 exec, -1\n\t"
-template <bool PAIRED>
 __device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const LaneOffsets& o, u64 strm, unsigned ldsDst) {
-    if constexpr (PAIRED) {
-        asm volatile(MI355_TABLE_DMA
-            "s_bitcmp1_b32 %[fl], 0\n\t"
-            "s_cbranch_scc0 .Lfx%=\n\t"
-            "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
-            "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
-            "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
-            "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
-            ".Lfx%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 1\n\t"
-            "s_cbranch_scc0 .Lft1%=\n\t"
-            "global_load_ushort %[s1a], %[oTA], %[src1]\n"
-            ".Lft1%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 2\n\t"
-            "s_cbranch_scc0 .Lft2%=\n\t"
-            "global_load_ushort %[s2a], %[oTA], %[src2]\n"
-            ".Lft2%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 3\n\t"
-            "s_cbranch_scc0 .Lfi%=\n\t"
-            "global_load_dwordx4 %[inv], %[oSA], %[scale]\n"
-            ".Lfi%=:"
-            : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s2a] "+v"(f.s2a),
-              [inv] "+v"(f.inv)
-            : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oSA] "v"(o.scaleA), [oM] "v"(o.mat),
-              [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm), [dst] "s"(ldsDst)
-            : "memory", "scc");
-    } else {
-        asm volatile(MI355_TABLE_DMA
-            "s_bitcmp1_b32 %[fl], 0\n\t"
-            "s_cbranch_scc0 .Lfx%=\n\t"
-            "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
-            "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
-            "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
-            "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
-            ".Lfx%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 1\n\t"
-            "s_cbranch_scc0 .Lft1%=\n\t"
-            "global_load_ubyte %[s1a], %[oTA], %[src1]\n\t"
-            "global_load_ubyte %[s1b], %[oTB], %[src1]\n"
-            ".Lft1%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 2\n\t"
-            "s_cbranch_scc0 .Lft2%=\n\t"
-            "global_load_ubyte %[s2a], %[oTA], %[src2]\n\t"
-            "global_load_ubyte %[s2b], %[oTB], %[src2]\n"
-            ".Lft2%=:\n\t"
-            "s_bitcmp1_b32 %[fl], 3\n\t"
-            "s_cbranch_scc0 .Lfi%=\n\t"
-            "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
-            "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
-            ".Lfi%=:"
-            : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
-              [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb)
-            : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
-              [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm),
-              [dst] "s"(ldsDst)
-            : "memory", "scc");
-    }
+    asm volatile(MI355_TABLE_DMA
+        "s_bitcmp1_b32 %[fl], 0\n\t"
+        "s_cbranch_scc0 .Lfx%=\n\t"
+        "global_load_dwordx4 %[xa0], %[oPA], %[src1]\n\t"
+        "global_load_dwordx4 %[xa1], %[oPA], %[src1] offset:16\n\t"
+        "global_load_dwordx4 %[xb0], %[oPB], %[src1]\n\t"
+        "global_load_dwordx4 %[xb1], %[oPB], %[src1] offset:16\n"
+        ".Lfx%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 1\n\t"
+        "s_cbranch_scc0 .Lft1%=\n\t"
+        "global_load_ubyte %[s1a], %[oTA], %[src1]\n\t"
+        "global_load_ubyte %[s1b], %[oTB], %[src1]\n"
+        ".Lft1%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 2\n\t"
+        "s_cbranch_scc0 .Lft2%=\n\t"
+        "global_load_ubyte %[s2a], %[oTA], %[src2]\n\t"
+        "global_load_ubyte %[s2b], %[oTB], %[src2]\n"
+        ".Lft2%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 3\n\t"
+        "s_cbranch_scc0 .Lfi%=\n\t"
+        "global_load_dwordx2 %[inva], %[oSA], %[scale]\n\t"
+        "global_load_dwordx2 %[invb], %[oSB], %[scale]\n"
+        ".Lfi%=:"
+        : [xa0] "+v"(f.xa0), [xa1] "+v"(f.xa1), [xb0] "+v"(f.xb0), [xb1] "+v"(f.xb1), [s1a] "+v"(f.s1a), [s1b] "+v"(f.s1b),
+          [s2a] "+v"(f.s2a), [s2b] "+v"(f.s2b), [inva] "+v"(f.inva), [invb] "+v"(f.invb)
+        : [fl] "s"(d.flags), [oPA] "v"(o.partA), [oPB] "v"(o.partB), [oTA] "v"(o.tipA), [oTB] "v"(o.tipB), [oSA] "v"(o.scaleA),
+          [oSB] "v"(o.scaleB), [oM] "v"(o.mat), [src1] "s"(d.src1), [src2] "s"(d.src2), [scale] "s"(d.scale), [strm] "s"(strm),
+          [dst] "s"(ldsDst)
+        : "memory", "scc");
 }
 // The loads of `f` have landed once at most N younger vector-memory instructions are outstanding; jump = 8 N + 12 is the
 // byte offset of "s_waitcnt vmcnt(N)" in the table below, counted from the instruction after s_getpc_b64 (every
@@ -172,16 +141,10 @@ __device__ __forceinline__ void fetchIssue(Fetched& f, const Desc& d, const Lane
         "s_waitcnt vmcnt(11)\n\ts_branch .Lwd%=\n\t"                                                                     \
         "s_waitcnt vmcnt(12)\n"                                                                                          \
         ".Lwd%=:"
-template <bool PAIRED>
 __device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
-    if constexpr (PAIRED)
-        asm volatile(MI355_WAIT_TABLE
-            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s2a), "+v"(f.inv)
-            : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
-    else
-        asm volatile(MI355_WAIT_TABLE
-            : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb)
-            : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
+    asm volatile(MI355_WAIT_TABLE
+        : "+v"(f.xa0), "+v"(f.xa1), "+v"(f.xb0), "+v"(f.xb1), "+v"(f.s1a), "+v"(f.s1b), "+v"(f.s2a), "+v"(f.s2b), "+v"(f.inva), "+v"(f.invb)
+        : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
 // the stores of one micro-operation (maskA / maskB = the lanes whose first / second pattern really stores; nothing is
 // issued when the micro-operation has no destination).  Non-temporal: the line is written once and, if at all, read
@@ -235,9 +198,8 @@ __device__ __forceinline__ v4d tipColumn(const char* tbl, unsigned s) {
     return v4d{lo.x, lo.y, hi.x, hi.y};
 }
 
-// MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header); PAIRED: every
-// segment starts at a multiple of 128 patterns (always true for an unpartitioned instance)
-template <int MAXT, int MINW, bool PAIRED>
+// MAXT = 64 * C threads; MINW = waves per SIMD the register allocation must allow (see the file header)
+template <int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                       const v2d MI355_CONST* __restrict__ matStream, int P, int C, long recipOff) {
     extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), exch[C][128] (double), table[2][MAXT / 64][320 B]
@@ -253,8 +215,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     // loop-invariant 32-bit byte offsets: every address of the loop is (64-bit SGPR base from the descriptor) + one of these
     LaneOffsets o;
     o.partA = (unsigned)(((size_t)c * P + qa) * 32); o.partB = (unsigned)(((size_t)c * P + qb) * 32);
-    if constexpr (PAIRED) { o.tipA = (unsigned)(p0 + 2 * lane); o.tipB = 0; o.scaleA = o.tipA * 8u; o.scaleB = 0; }
-    else { o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u; }
+    o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u;
     o.mat = (unsigned)(c * WALK_TABLE_BYTES + lane * 16);          // lanes 0..19 copy the wave's 320-byte table
     v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
     double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 256);
@@ -273,9 +234,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     u64 strm = (u64)(matStream) + (u64)progStart * strmStep;
     Fetched A, B;
     A.xa0 = A.xa1 = A.xb0 = A.xb1 = v2d{1.0, 1.0}; A.s1a = A.s1b = A.s2a = A.s2b = 0x404u; A.inva = A.invb = 1.0;
-    A.inv = v2d{1.0, 1.0};
     B = A;
-    fetchIssue<PAIRED>(A, D0, o, strm, tblDst0);
+    fetchIssue(A, D0, o, strm, tblDst0);
 
     // one micro-operation: CUR holds its operands (issued one stage ago), NXT receives those of the following one
 #define WALK_STAGE(CUR, NXT, DCUR, DNXT, TB)                                                                                \
@@ -288,11 +248,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
             NXT.xa0 = h[0]; NXT.xa1 = h[64]; NXT.xb0 = h[128]; NXT.xb1 = h[192];                                          \
         }                                                                                                                 \
         strm += strmStep;                                                                                                 \
-        fetchIssue<PAIRED>(NXT, DNXT, o, strm, tblDst0 + (1 - TB) * MAXC * WALK_TABLE_BYTES);                             \
+        fetchIssue(NXT, DNXT, o, strm, tblDst0 + (1 - TB) * MAXC * WALK_TABLE_BYTES);                             \
         const int k1 = (fl >> 5) & 7, k2 = (fl >> 8) & 7, hold = (fl >> 11) & 3, smode = (fl >> 13) & 3;                  \
-        fetchWait<PAIRED>(CUR, (fl >> 16) & 0xffu);    /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
-        const unsigned t1a = PAIRED ? (CUR.s1a & 0xffu) : CUR.s1a, t1b = PAIRED ? (CUR.s1a >> 8) : CUR.s1b;               \
-        const unsigned t2a = PAIRED ? (CUR.s2a & 0xffu) : CUR.s2a, t2b = PAIRED ? (CUR.s2a >> 8) : CUR.s2b;               \
+        fetchWait(CUR, (fl >> 16) & 0xffu);    /* 8 N + 12, N = younger loads (kernels.h walkWaitJump) */         \
+        const unsigned t1a = CUR.s1a, t1b = CUR.s1b, t2a = CUR.s2a, t2b = CUR.s2b;                                        \
         const char* tb = tbl0 + TB * MAXC * WALK_TABLE_BYTES;   /* this micro-operation's table landed with its loads */ \
         v4d fa, fb, ga, gb;                                                                                               \
         if (k1 == WK_TIPS) { fa = tipColumn(tb, t1a); fb = tipColumn(tb, t1b); }                                          \
@@ -314,7 +273,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
         asm volatile("" : "+v"(ra), "+v"(rb));         /* (keeps the loads below behind the products' LDS wait) */         \
         DCUR = loadDesc(dp + 32);                                                                                         \
         dp += 16;                                                                                                         \
-        if (smode == WS_READ) { ra = ra * (PAIRED ? CUR.inv.x : CUR.inva); rb = rb * (PAIRED ? CUR.inv.y : CUR.invb); }   \
+        if (smode == WS_READ) { ra = ra * CUR.inva; rb = rb * CUR.invb; }                                                 \
         else if (smode == WS_WRITE) {                                                                                     \
             double ma = fmax(fmax(fmax(0.0, ra.x), fmax(ra.y, ra.z)), ra.w), mb = fmax(fmax(fmax(0.0, rb.x), fmax(rb.y, rb.z)), rb.w); \
             v2d* e = reinterpret_cast<v2d*>(exch);                                                                        \
@@ -331,21 +290,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
                interleaved layout, recipOff doubles further on); then drain */                                            \
             const unsigned oFA = o.partA - (unsigned)c * (unsigned)P * 32u, oFB = o.partB - (unsigned)c * (unsigned)P * 32u;   /* 32 q */ \
             const unsigned oRA = o.scaleA + (unsigned)recipOff * 8u;                                                      \
-            if constexpr (PAIRED) {                                                                                       \
-                const v2d iab = v2d{ia, ib};                                                                              \
-                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %5, %8\n\tglobal_store_dwordx4 %4, %7, %8\n\t"   \
-                             "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %3, %6, %8\n\t"                                  \
-                             "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
-                             : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oFB >> 2), "v"(oRA),   \
-                                 "v"(ma), "v"(mb), "v"(iab), "s"(dScale) : "memory");                                     \
-            } else {                                                                                                      \
-                const unsigned oRB = o.scaleB + (unsigned)recipOff * 8u;                                                  \
-                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %6, %10\n\tglobal_store_dwordx2 %3, %7, %10\n\t"  \
-                             "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %4, %8, %10\n\tglobal_store_dwordx2 %5, %9, %10\n\t"     \
-                             "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
-                             : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oRA),       \
-                                 "v"(oFB >> 2), "v"(oRB), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory");    \
-            }                                                                                                             \
+            const unsigned oRB = o.scaleB + (unsigned)recipOff * 8u;                                                  \
+            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %2, %6, %10\n\tglobal_store_dwordx2 %3, %7, %10\n\t"  \
+                         "s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %4, %8, %10\n\tglobal_store_dwordx2 %5, %9, %10\n\t"     \
+                         "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
+                         : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oRA),       \
+                             "v"(oFB >> 2), "v"(oRB), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory");    \
         }                                                                                                                 \
         storeIssue(ra, rb, fl, validA, validB, o.partA, o.partB, dStore);                                                 \
         if (hold) {                                    /* this value waits for its sibling's subtree */                   \
@@ -379,8 +329,46 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
     hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream);
 }
 
-void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, bool paired,
-                 int P, int C, long recipOff) {
+// ---- the assembly loop ------------------------------------------------------------------------------------------------
+#include "walk4_fast_loop.inc"
+// Same mapping, LDS layout (hold slots, then the matrix tables; no exchange buffer) and arithmetic as k_walk4; the loop
+// itself is one block of assembly with its own register map (tools/gen_walk4_fast.py says why and what it leaves to k_walk4).
+template <int MAXC>
+__global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
+                                                             const v2d MI355_CONST* __restrict__ matStream, int P, int C) {
+    extern __shared__ v2d lds[];
+    const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
+    const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
+    const int p0 = sg.pStart + (int)blockIdx.x * 128;
+    if (p0 >= pEnd || progCount <= 0) return;
+    const unsigned c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 dp = (u64)(prog + (size_t)progStart * 16);
+    const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
+    const u64 strm = (u64)matStream + (u64)progStart * strmStep;
+    const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
+    const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
+    asm volatile(WALK4_FAST_ASM
+                 : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
+                     [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
+                     [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold)
+                 : WALK4_FAST_CLOBBERS);
+}
+
+void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C) {
+    if (nSegs <= 0 || maxRange <= 0) return;
+    const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
+    const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES;
+    const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
+    const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
+    const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C);
+    else if (C <= 8) hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C);
+    else hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C);
+}
+
+void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
@@ -388,10 +376,9 @@ void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, 
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
-#define MI355_WALK(T, PR) hipLaunchKernelGGL((k_walk4<T, 4, PR>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff)
-    if (paired) { if (C <= 4) MI355_WALK(256, true); else if (C <= 8) MI355_WALK(512, true); else MI355_WALK(1024, true); }
-    else { if (C <= 4) MI355_WALK(256, false); else if (C <= 8) MI355_WALK(512, false); else MI355_WALK(1024, false); }
-#undef MI355_WALK
+    if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
+    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
+    else hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
 }
 
 }  // namespace mi355

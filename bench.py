@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable with a copy kernel)
-KERNEL_SOURCES = ("kernels_walk4.hip", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine.cpp")
+KERNEL_SOURCES = ("kernels_walk4.hip", "walk4_fast_loop.inc", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine.cpp")
 
 
 def kernel_source_hash():
@@ -271,7 +271,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         walk = s_ == 4 and stats["walks"] > 0
         if walk:
             moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps)
-            kname = "k_walk4"
+            kname = "k_walk4_fast" if stats.get("fast_walks", 0) * 2 > stats["walks"] else "k_walk4"
             launches_per_eval = stats["walks"] / max(1, args.steps)
         else:
             moved = alg                                       # the tiled kernels store and re-read every node

@@ -318,7 +318,7 @@ int beagleMi355Synchronize(int instance);
 int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* outLaunches);
 /* Traffic counters of the 4-state pattern walk since the last beagleMi355KernelTimer call: out[0] micro-operations,
  * [1] partials buffers stored, [2] partials buffers read from memory, [3] tip-state vectors read, [4] scale-factor
- * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] reserved.  bench.py turns them into the
+ * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the
  * bytes the design has to move (roofline.achieved). */
 int beagleMi355WalkStats(int instance, long* out8);
 /* Bytes of HBM currently allocated by the instance. */

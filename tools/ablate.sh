@@ -1,8 +1,4 @@
-cd $GRAFT_REPO_ROOT
-for env in "BEAGLE_MI355_CHUNK=0" "BEAGLE_MI355_CHUNK=24" "BEAGLE_MI355_CHUNK=64" "BEAGLE_MI355_CHUNK=150" "BEAGLE_MI355_CHUNK=300"; do
- for args in "" "--patterns 50000"; do
-  env $env timeout 120 python bench.py --steps 40 --warmup 5 --no-cpu-baseline $args 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$env args=[$args]', 'evals/s', d['value'], 'ms/step', d['ms_per_step'], 'kernel_us/eval', round(d['roofline']['avg_launch_us']*d['roofline']['launches_per_eval'],1), 'lnL', d['lnL'])"
- done
+# timing experiments on the walk kernel (results are WRONG by construction; only kernel_us_per_eval is of interest)
+for a in 0 1 2 4 8 15; do
+  echo "ablate=$a $(BEAGLE_MI355_ABLATE=$a timeout 150 python bench.py --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 | grep -o 'kernel_us_per_eval": [0-9.]*')"
 done

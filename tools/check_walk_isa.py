@@ -32,9 +32,9 @@ def all_regs(line):
     return out
 
 
-def check_function(name, lines, paired):
+def check_function(name, lines):
     problems = []
-    want = 22 if paired else 24     # 16 partials + tip states (2 / 4) + reciprocal scale factors (4); the matrices go to LDS
+    want = 24                       # 16 partials + 4 tip states + 2 reciprocal scale factors (4 registers); the matrices go to LDS
     waits = [i for i, l in enumerate(lines) if "s_setpc_b64" in l]          # the jump into the s_waitcnt table = the stage's wait
     blocks = []
     i = 0
@@ -106,11 +106,11 @@ def main():
     if any(sc):
         problems.append("scratch in use: %s" % sc)
     funcs = re.findall(r"^(_ZN5mi3557k_walk4[^:\n]*):\s*;.*?\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    if len(funcs) != 6:
-        problems.append("found %d kernel instantiations, expected 6" % len(funcs))
+    if len(funcs) != 3:
+        problems.append("found %d kernel instantiations, expected 3" % len(funcs))
     for name, body in funcs:
         lines = [l for l in body.split("\n") if not l.strip().startswith(";")]
-        problems += check_function(name[:40], lines, "ELb1E" in name)
+        problems += check_function(name[:40], lines)
     for p in problems:
         print("PROBLEM:", p)
     print("walk kernel ISA check: %s (VGPRs %s, %d instantiations)" % ("FAILED" if problems else "ok", vg, len(funcs)))

@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generates beast-mcmc_amd/csrc/walk4_fast_loop.inc: the main loop of k_walk4_fast (kernels_walk4.hip) as ONE block of
+gfx950 assembly with explicit registers.
+
+Why assembly: the pattern walk is bound by instruction issue (profiles/r02_*sq*: ~200 instructions per micro-operation and
+wave from the C++ kernel, 45 % of them scalar / branch glue the compiler's control-flow structurizer adds around the
+hand-pipelined loads).  This loop does the same work in ~100, with 2-3 taken branches per micro-operation: everything rare
+(partials loads, hold-slot traffic, stores, a second child in memory) is out of line, the small loads are unconditional
+(the host points unused operands at dummy buffers: all-missing tip states, all-one scale factors), and what the compute
+half of a stage needs from a descriptor is stashed in three scalar registers when the fetch half has used it, so one
+descriptor register set serves the two-deep software pipeline.
+
+It covers every micro-operation except write-mode rescaling (WS_WRITE: LDS exchange + barrier + division) and segments
+that do not start at a multiple of 128 patterns; launches containing those use the C++ kernel k_walk4, which computes the
+same values bit for bit.
+
+Run: python tools/gen_walk4_fast.py   (rewrites the .inc; tests/test_planner_native.py checks it is up to date)"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")
+
+# ---- register map -----------------------------------------------------------------------------------------------------
+# vector
+AX, BX = 0, 16                # fetched first-child partials of the two pipeline slots: pattern a = +0..7, pattern b = +8..15
+AT1, AT2, BT1, BT2 = 32, 33, 34, 35      # tip-state pairs (a | b << 8) of the two children
+AINV, BINV = 36, 40           # reciprocal scale factors {a, b}
+ACC = 44                      # the previous micro-operation's result: a = +0..7, b = +8..15
+F, G = 60, 76                 # the two children's contributions
+SP = 92                       # lane l: entry (l & 15) of a branch matrix
+T0, T1 = 94, 95
+PA, PB, TIP, SCALE, OM, HOLD, SP0, SP1, LANE, VST = 96, 97, 98, 99, 100, 101, 102, 103, 104, 105
+NV = 106
+# scalar
+DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST = 20, 22, 24, 25, 26, 27, 59, 60      # (s32 is reserved)
+MASK = 62                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
+EVEN, ODD = 70, 72            # 0x5555..., 0xaaaa...
+D, DFL = 36, 44               # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags
+SA_FL, SA_STORE, SA_SRC2 = 46, 48, 50
+SB_FL, SB_STORE, SB_SRC2 = 52, 54, 56
+LAST = 58
+S_FIRST, S_LAST = 20, 73
+
+# flag bits (kernels.h)
+B_X, B_T1, B_T2, B_STORE, B_HSLOT1 = 0, 1, 2, 4, 12
+B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1 = 24, 25, 26, 27, 28, 29
+
+STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
+lines = []
+
+
+def e(s):
+    lines.append(s)
+
+
+def v(n, w=1):
+    return "v%d" % n if w == 1 else "v[%d:%d]" % (n, n + w - 1)
+
+
+def s(n, w=1):
+    return "s%d" % n if w == 1 else "s[%d:%d]" % (n, n + w - 1)
+
+
+def L(name):
+    return ".LW4%s_%%=" % name
+
+
+def matvec(dst, x):
+    """dst (16 regs: a rows 0-3, b rows 0-3) = M . x for the two patterns; M spread over the lanes of SP.  The rounding
+    sequence is y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0))))."""
+    for i in range(8):
+        e("v_mov_b64 %s, 0" % v(dst + 2 * i, 2))
+    for j in range(4):
+        for half in range(2):
+            for i in range(4):
+                e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                  % (v(dst + 8 * half + 2 * i, 2), v(SP, 2), v(x + 8 * half + 2 * j, 2), 4 * i + j))
+
+
+def tip_columns(dst, t, tbl, off):
+    e("v_and_b32 %s, 0xff, %s" % (v(T0), v(t)))
+    e("v_lshrrev_b32 %s, 8, %s" % (v(T1), v(t)))
+    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T0), v(T0), s(tbl)))
+    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T1), v(T1), s(tbl)))
+    e("ds_read_b128 %s, %s offset:%d" % (v(dst, 4), v(T0), off))
+    e("ds_read_b128 %s, %s offset:%d" % (v(dst + 4, 4), v(T0), off + 16))
+    e("ds_read_b128 %s, %s offset:%d" % (v(dst + 8, 4), v(T1), off))
+    e("ds_read_b128 %s, %s offset:%d" % (v(dst + 12, 4), v(T1), off + 16))
+
+
+outofline = []      # (label, [lines]) blocks placed after the loop
+
+
+def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
+    """Issue everything the micro-operation described by D needs into pipeline slot (X, Tt1, Tt2, INV), stash what its
+    compute stage needs, advance the stream."""
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD))
+    e("s_cbranch_scc1 %s" % L("hr" + tag))
+    e(L("hrb" + tag) + ":")
+    blk = [L("hr" + tag) + ":",
+           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD1),
+           "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
+           "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
+    for q in range(4):
+        blk.append("ds_read_b128 %s, %s offset:%d" % (v(X + 4 * q, 4), v(T0), 1024 * q))
+    blk.append("s_branch %s" % L("hrb" + tag))
+    outofline.append(blk)
+    e("s_mov_b32 m0, %s" % s(tblDst))
+    e("s_mov_b64 exec, 0xfffff")
+    e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
+    e("s_mov_b64 exec, -1")
+    e("global_load_ushort %s, %s, %s" % (v(Tt1), v(TIP), s(D, 2)))
+    e("global_load_ushort %s, %s, %s" % (v(Tt2), v(TIP), s(D + 2, 2)))
+    e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
+    e("s_add_u32 %s, %s, %s" % (s(STRM), s(STRM), s(STEP)))
+    e("s_addc_u32 %s, %s, 0" % (s(STRM + 1), s(STRM + 1)))
+    e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
+    e("s_mov_b64 %s, %s" % (s(SSTORE, 2), s(D + 4, 2)))
+    e("s_mov_b64 %s, %s" % (s(SSRC2, 2), s(D + 2, 2)))
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_X))
+    e("s_cbranch_scc1 %s" % L("x" + tag))
+    e(L("xb" + tag) + ":")
+    blk = [L("x" + tag) + ":",
+           "global_load_dwordx4 %s, %s, %s" % (v(X, 4), v(PA), s(D, 2)),
+           "global_load_dwordx4 %s, %s, %s offset:16" % (v(X + 4, 4), v(PA), s(D, 2)),
+           "global_load_dwordx4 %s, %s, %s" % (v(X + 8, 4), v(PB), s(D, 2)),
+           "global_load_dwordx4 %s, %s, %s offset:16" % (v(X + 12, 4), v(PB), s(D, 2)),
+           "s_branch %s" % L("xb" + tag)]
+    outofline.append(blk)
+
+
+def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext):
+    """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
+    following one is fetched into the other slot."""
+    e("s_waitcnt lgkmcnt(0)")                       # the descriptor of the NEXT micro-operation (and LDS writes) have landed
+    fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext)
+    # wait for this micro-operation's loads: N = everything issued after them = 4 (+4 stores before, +4 partials loads now)
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0))
+    e("s_cbranch_scc1 %s" % L("w8" + tag))
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT1))
+    e("s_cbranch_scc1 %s" % L("w12" + tag))
+    e("s_waitcnt vmcnt(4)")
+    e(L("wd" + tag) + ":")
+    outofline.append([L("w8" + tag) + ":", "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag)])
+    outofline.append([L("w12" + tag) + ":", "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
+    # first child
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
+    e("s_cbranch_scc0 %s" % L("fm" + tag))
+    tip_columns(F, Tt1, tblCur, 0)
+    e("s_branch %s" % L("g" + tag))
+    e(L("fm" + tag) + ":")
+    e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+    e("s_waitcnt lgkmcnt(0)")
+    matvec(F, X)
+    # second child
+    e(L("g" + tag) + ":")
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
+    e("s_cbranch_scc0 %s" % L("ga" + tag))
+    tip_columns(G, Tt2, tblCur, 160)
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_branch %s" % L("mul" + tag))
+    e(L("ga" + tag) + ":")
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
+    e("s_cbranch_scc1 %s" % L("m2" + tag))
+    e(L("m2b" + tag) + ":")
+    outofline.append([L("m2" + tag) + ":",          # both children in memory: the second one is loaded into ACC, synchronously
+                      "global_load_dwordx4 %s, %s, %s" % (v(ACC, 4), v(PA), s(SSRC2, 2)),
+                      "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2)),
+                      "global_load_dwordx4 %s, %s, %s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2)),
+                      "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2)),
+                      "s_waitcnt vmcnt(0)",
+                      "s_branch %s" % L("m2b" + tag)])
+    e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
+    e("s_waitcnt lgkmcnt(0)")
+    matvec(G, ACC)
+    e(L("mul" + tag) + ":")
+    # descriptor k + 2: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)
+    e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
+    e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+    e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
+    e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
+    for i in range(8):
+        e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
+    for i in range(8):
+        e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE))
+    e("s_cbranch_scc1 %s" % L("st" + tag))
+    e(L("stb" + tag) + ":")
+    # The result leaves in FOUR FULLY CONTIGUOUS 1 KiB stores (tools/hbm_write_probe.hip: half-line non-temporal stores
+    # sustain 2.0 TB/s, full lines 4.9-5.2): lane 2 q + r owns patterns q + 32 r and 64 + q + 32 r of the workgroup's 128,
+    # store instruction j covers patterns 32 j .. 32 j + 31, lane 2 q + r writing half r (16 bytes) of pattern 32 j + q —
+    # its own data or its neighbour's, exchanged with v_cndmask_b32_dpp quad_perm:[1,0,3,2] (no LDS).
+    blk = [L("st" + tag) + ":", "s_nop 1", "s_mov_b64 vcc, %s" % s(EVEN, 2)]
+    for d in range(4):      # j = 0 (pattern q, owner r = 0): even lanes own half 0; odd lanes take the neighbour's half 1
+        blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + d), v(ACC + 4 + d), v(ACC + d)))
+    for d in range(4):      # j = 2 (pattern 64 + q): the same on the second pattern of the lanes
+        blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 8 + d), v(ACC + 12 + d), v(ACC + 8 + d)))
+    blk.append("s_mov_b64 vcc, %s" % s(ODD, 2))
+    for d in range(4):      # j = 1 (pattern 32 + q, owner r = 1): odd lanes own half 1; even lanes take the neighbour's half 0
+        blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 4 + d), v(ACC + d), v(ACC + 4 + d)))
+    for d in range(4):      # j = 3 (pattern 96 + q)
+        blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 12 + d), v(ACC + 8 + d), v(ACC + 12 + d)))
+    for j in range(4):
+        blk.append("s_mov_b64 exec, %s" % s(MASK + 2 * j, 2))
+        blk.append("global_store_dwordx4 %s, %s, %s offset:%d%s" % (v(VST), v(F + 4 * j, 4), s(SSTORE, 2), 1024 * j, STORE_POLICY))
+    blk += ["s_mov_b64 exec, -1", "s_nop 0", "s_branch %s" % L("stb" + tag)]
+    outofline.append(blk)
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HWRITE))
+    e("s_cbranch_scc1 %s" % L("hw" + tag))
+    e(L("hwb" + tag) + ":")
+    blk = [L("hw" + tag) + ":",
+           "s_bitcmp1_b32 %s, %d" % (s(SFL), B_HSLOT1),
+           "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
+           "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
+    for q in range(4):
+        blk.append("ds_write_b128 %s, %s offset:%d" % (v(T0), v(ACC + 4 * q, 4), 1024 * q))
+    blk.append("s_branch %s" % L("hwb" + tag))
+    outofline.append(blk)
+
+
+def build():
+    # ---- inputs -> fixed registers
+    e("s_mov_b64 %s, %%[dp]" % s(DP, 2))
+    e("s_mov_b64 %s, %%[strm]" % s(STRM, 2))
+    e("s_mov_b32 %s, %%[cnt]" % s(CNT))
+    e("s_mov_b32 %s, %%[tbl]" % s(TBL0))
+    e("s_add_u32 %s, %%[tbl], %%[tblStep]" % s(TBL1))
+    e("s_mov_b32 %s, %%[holdStride]" % s(HSTRIDE))
+    e("s_mov_b32 %s, %%[strmStep]" % s(STEP))
+    e("s_add_i32 %s, %%[pEnd], -1" % s(LAST))
+    # ---- lane offsets
+    e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(LANE))
+    e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(LANE), v(LANE)))
+    # lane 2 q + r owns patterns p0 + q + 32 r and p0 + 64 + q + 32 r (see the store block)
+    e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))                  # q
+    e("v_add_u32_e32 %s, %%[p0], %s" % (v(T1), v(T1)))                   # p0 + q: first pattern of store instruction 0's piece
+    for j in range(4):
+        if j:
+            e("v_add_u32_e32 %s, 32, %s" % (v(T1), v(T1)))
+        e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
+        e("s_nop 3")
+        e("s_mov_b64 %s, vcc" % s(MASK + 2 * j, 2))
+    e("s_mov_b32 %s, 0x55555555" % s(EVEN))
+    e("s_mov_b32 %s, 0x55555555" % s(EVEN + 1))
+    e("s_mov_b32 %s, 0xaaaaaaaa" % s(ODD))
+    e("s_mov_b32 %s, 0xaaaaaaaa" % s(ODD + 1))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
+    e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
+    e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
+    e("v_add_u32_e32 %s, %s, %s" % (v(VST), s(ST), v(VST)))
+    e("v_and_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))                      # r
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
+    e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))
+    e("v_add3_u32 %s, %s, %s, %%[p0]" % (v(T0), v(T0), v(T1)))           # first pattern of the lane
+    e("v_add_u32_e32 %s, 64, %s" % (v(T1), v(T0)))                      # second
+    e("v_min_i32_e32 %s, %s, %s" % (v(T0), s(LAST), v(T0)))             # lanes past the end recompute the last pattern
+    e("v_min_i32_e32 %s, %s, %s" % (v(T1), s(LAST), v(T1)))
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PA), v(T0)))
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PB), v(T1)))
+    e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PA), v(PA)))
+    e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PB), v(PB)))
+    e("v_lshlrev_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))
+    e("v_add_u32_e32 %s, %%[p0], %s" % (v(TIP), v(T0)))                  # position of the pair in the interleaved layouts
+    e("v_lshlrev_b32_e32 %s, 3, %s" % (v(SCALE), v(TIP)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(OM), v(LANE)))
+    e("v_add_u32_e32 %s, %%[cM], %s" % (v(OM), v(OM)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(HOLD), v(LANE)))
+    e("v_add_u32_e32 %s, %%[hold], %s" % (v(HOLD), v(HOLD)))
+    e("v_and_b32_e32 %s, 3, %s" % (v(T0), v(LANE)))                      # matrix entry 4 i + k of lane l & 15 is T[k][i]
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
+    e("v_bfe_u32 %s, %s, 2, 2" % (v(T1), v(LANE)))
+    e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
+    e("v_add_u32_e32 %s, %s, %s" % (v(SP0), s(TBL0), v(T0)))
+    e("v_add_u32_e32 %s, %s, %s" % (v(SP1), s(TBL1), v(T0)))
+    for i in range(8):
+        e("v_mov_b64 %s, 1.0" % v(ACC + 2 * i, 2))
+    # ---- prologue: fetch micro-operation 0 into slot A, descriptor 1 into D
+    e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
+    e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+    e("s_waitcnt lgkmcnt(0)")
+    fetch("p", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0)
+    e("s_load_dwordx8 %s, %s, 0x40" % (s(D, 8), s(DP, 2)))
+    e("s_load_dword %s, %s, 0x70" % (s(DFL), s(DP, 2)))
+    e("s_add_u32 %s, %s, 0x80" % (s(DP), s(DP)))
+    e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
+    # ---- the loop: two stages
+    e(L("top") + ":")
+    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1)
+    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0)
+    e("s_add_i32 %s, %s, -2" % (s(CNT), s(CNT)))
+    e("s_cmp_gt_i32 %s, 0" % s(CNT))
+    e("s_cbranch_scc1 %s" % L("top"))
+    e("s_branch %s" % L("end"))
+    for blk in outofline:
+        for l in blk:
+            e(l)
+    e(L("end") + ":")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+
+
+def main():
+    build()
+    text = ["// GENERATED by tools/gen_walk4_fast.py — do not edit; see that file for the register map and the design.",
+            "#define WALK4_FAST_ASM \\"]
+    for l in lines:
+        sep = "\\n" if l.endswith(":") else "\\n\\t"
+        text.append('    "%s%s" \\' % (l, sep))
+    text.append('    ""')
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1) if i not in (32, 33, 34, 35)]
+    clob += ['"vcc"', '"scc"', '"memory"']
+    text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
+    text.append("#define WALK4_FAST_VGPRS %d" % NV)
+    body = "\n".join(text) + "\n"
+    if os.environ.get("WALK4_CHECK_ONLY"):
+        raise SystemExit(0 if os.path.exists(OUT) and open(OUT).read() == body else 1)
+    open(OUT, "w").write(body)
+    print("wrote %s: %d instructions" % (OUT, sum(1 for l in lines if not l.endswith(":"))))
+
+
+if __name__ == "__main__":
+    main()
