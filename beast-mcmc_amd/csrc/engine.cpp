@@ -58,6 +58,7 @@ struct Instance {
     uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
                                                                  // micro-operation does not use (the assembly loop loads them unconditionally)
     long statFastWalks = 0;
+    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0; long hostCalls = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
     double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
@@ -211,6 +212,9 @@ int ensureStates(Instance* in, int idx) {
 
 void destroy(Instance* in) {
     hipSetDevice(in->device);
+    if (in->hostCalls && getenv("BEAGLE_MI355_HOST_TIMING"))
+        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us\n",
+                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls);
     if (in->ownStream) hipStreamSynchronize(in->ownStream);
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
@@ -506,6 +510,10 @@ int walkChunkOps(const Instance* in, int opCount) {
 // 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
 int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (count <= 0) return 0;
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    auto usSince = [](Clock::time_point a) { return std::chrono::duration<double, std::micro>(Clock::now() - a).count(); };
+    in->hostCalls++;
     const int parts = in->partitionCount;
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * tuple;
@@ -528,7 +536,9 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
     }
     int launches = 0;
+    in->hostPrepUs += usSince(t0);
     for (int begin = 0; begin < count;) {
+        Clock::time_point t1 = Clock::now();
         const int n = in->planner.hazardFreePrefix(ops, begin, count, tuple, parts);
         const int* sub = ops + (size_t)begin * tuple;
         for (int k = 0; k < n; k++) {                       // a tip index reused as a destination now holds partials
@@ -538,14 +548,17 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         std::vector<int> need;
         in->planner.mustMaterializeBefore(sub, n, tuple, need);
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+        in->hostPrepUs += usSince(t1); t1 = Clock::now();
         int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
+        in->hostPlanUs += usSince(t1); t1 = Clock::now();
         // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
         // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
         if (!in->plan.prog.empty()) {
             rc = runPlan(in, in->plan, launches == 0 ? e0 : nullptr); if (rc) return rc;
             launches++;
         } else { rc = runPlan(in, in->plan); if (rc) return rc; }
+        in->hostRunUs += usSince(t1);
         begin += n;
     }
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }

@@ -1,0 +1,52 @@
+"""Where one full-tree evaluation of the headline workload spends HOST time: wall clock of every Beagle call of a step.
+Run on the GPU box:  BEAGLE_MI355_HOST_TIMING=1 python tools/step_profile.py [patterns]"""
+import os
+import sys
+import time
+import collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+import bench
+
+bm = importlib.import_module("beast-mcmc_amd")
+from importlib import import_module
+synth = import_module("beast-mcmc_amd.inputs.synth")
+tlm = import_module("beast-mcmc_amd.treelikelihood")
+
+patterns = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+wl = synth.config_a()
+if patterns < wl.pattern_count:
+    wl = wl.shard(0, patterns)
+tl = tlm.BeagleTreeLikelihood(wl, resource_list=[1], rescaling=tlm.RESCALE_DYNAMIC, delay_rescaling=False)
+models = bench.perturbed_models(bm, wl, "A")
+acc = collections.defaultdict(float)
+
+
+def timed(name, f, *a):
+    t = time.perf_counter()
+    r = f(*a)
+    acc[name] += time.perf_counter() - t
+    return r
+
+
+def step(i):
+    eig, freqs, rates, weights = models[i & 1]
+    timed("storeState", tl.storeState)
+    timed("set_substitution_model", tl.set_substitution_model, eig, freqs)
+    timed("set_site_model", tl.set_site_model, rates, weights)
+    return timed("getLogLikelihood (matrices, partials, root, wait)", tl.getLogLikelihood)
+
+for i in range(12):
+    step(i)
+acc.clear()
+N = 50
+t0 = time.perf_counter()
+for i in range(N):
+    step(i)
+total = time.perf_counter() - t0
+print("step %.1f us" % (1e6 * total / N))
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print("  %-52s %8.1f us" % (k, 1e6 * v / N))
+print("  %-52s %8.1f us" % ("(python outside Beagle calls)", 1e6 * (total - sum(acc.values())) / N))
+tl.close()
