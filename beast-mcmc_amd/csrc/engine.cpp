@@ -58,6 +58,14 @@ struct Instance {
     uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
                                                                  // micro-operation does not use (the assembly loop loads them unconditionally)
     long statFastWalks = 0;
+    // what runPlan derived from a cached plan (planner.h plannedTag): the device program with its addresses resolved
+    struct Resolved {
+        long tag = 0, epoch = -1;
+        std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
+        int maxRange = 0; bool paired = true;
+        long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
+    } resolved[4];
+    long resolveEpoch = 0;                               // bumped when pattern ranges change
     double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0; long hostCalls = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
@@ -213,8 +221,8 @@ int ensureStates(Instance* in, int idx) {
 void destroy(Instance* in) {
     hipSetDevice(in->device);
     if (in->hostCalls && getenv("BEAGLE_MI355_HOST_TIMING"))
-        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us\n",
-                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls);
+        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us; %ld plans from the cache\n",
+                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls, in->planner.cacheHits);
     if (in->ownStream) hipStreamSynchronize(in->ownStream);
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
@@ -323,7 +331,7 @@ int ensureWalkDummies(Instance* in) {
 
 // Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
 // micro-operations travel together) and enqueue the snapshot copies and the walk.
-int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk = nullptr) {
+int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t recordBeforeWalk = nullptr) {
     const size_t n = plan.prog.size();
     if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
         if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
@@ -334,21 +342,33 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         return 0;
     }
     // Device program: per segment its micro-operations, a no-op when their number is odd, and two more no-ops the
-    // kernel's descriptor prefetch may read (kernels.h WalkSeg).
-    std::vector<mi355::WalkOp>& w = in->walkOps;
+    // kernel's descriptor prefetch may read (kernels.h WalkSeg).  For a plan that came out of the planner's cache the
+    // resolved program is kept as well: buffer addresses never change once a buffer exists.
+    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
+    Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 3] : nullptr;
+    const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
+    std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
+    std::vector<mi355::WalkSeg> segsLocal;
+    std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
+    int maxRange = 0;
+    bool paired = true;                            // every segment starts at a multiple of 128 patterns (kernels_walk4.hip)
+    if (reuse) {
+        maxRange = slot->maxRange; paired = slot->paired;
+        in->statMemReads += slot->memReads; in->statTipReads += slot->tipReads; in->statScaleReads += slot->scaleReads;
+        in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
+    } else {
+    const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
+    if (slot) slot->tag = 0;
     w.clear();
     w.reserve(n + 3 * plan.segs.size());
-    std::vector<mi355::WalkSeg> segs(plan.segs.size());
+    segs.assign(plan.segs.size(), mi355::WalkSeg());
     const size_t matStride = (size_t)in->C * 16;
     { int rc = ensureWalkDummies(in); if (rc) return rc; }
-    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
     mi355::WalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.m1 = in->matrices; nop.m2 = in->matrices;
     nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
-    int maxRange = 0;
-    bool paired = true;                            // every segment starts at a multiple of 128 patterns (kernels_walk4.hip)
     for (const mi355::PlanSeg& ps : plan.segs) if (in->partStart[ps.partition] % 128) paired = false;
     for (size_t si = 0; si < plan.segs.size(); si++) {
         const mi355::PlanSeg& ps = plan.segs[si];
@@ -403,6 +423,12 @@ int runPlan(Instance* in, const mi355::Plan& plan, hipEvent_t recordBeforeWalk =
         }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
+    }
+    if (slot) {
+        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange; slot->paired = paired;
+        slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
+        slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
+    }
     }
     in->statMicroOps += (long)n;
     // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
@@ -554,10 +580,10 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         in->hostPlanUs += usSince(t1); t1 = Clock::now();
         // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
         // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
-        if (!in->plan.prog.empty()) {
-            rc = runPlan(in, in->plan, launches == 0 ? e0 : nullptr); if (rc) return rc;
+        if (!in->planner.planned->prog.empty()) {
+            rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, launches == 0 ? e0 : nullptr); if (rc) return rc;
             launches++;
-        } else { rc = runPlan(in, in->plan); if (rc) return rc; }
+        } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
         in->hostRunUs += usSince(t1);
         begin += n;
     }
@@ -1229,6 +1255,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     int maxVirtSteps = 6;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
+    in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
@@ -1338,7 +1365,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
         e[k] = p + 1;
     }
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
-    in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e;
+    in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
     const size_t n = (size_t)in->partialsCount * partitionCount;
     in->wStamp.assign(n, 0); in->wLevel.assign(n, 0); in->rStamp.assign(n, 0); in->rLevel.assign(n, 0); in->wOp.assign(n, 0);
     in->stamp = 0;

@@ -262,6 +262,7 @@ void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {
 
 int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allowVirtual, Plan& out, int chunkOps) {
     out.clear();
+    planned = &out; plannedTag = 0;
     lastStored = lastMemReads = lastHolds = 0;
     if (count <= 0) return 0;
     parts_ = parts;
@@ -270,6 +271,42 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     if (sWStamp_.size() < nS) { sWStamp_.assign(nS, 0); sRStamp_.assign(nS, 0); sDone_.assign(nS, 0); }
     stamp_++;
     allowVirtual = allowVirtual && enabled_ && parts == 1 && tuple == 7;
+
+    // ---- closed list?  then the plan may be in the cache (planner.h)
+    CacheEntry* fill = nullptr;
+    if (cacheEnabled && count >= 16) {
+        bool closed = true;
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)count * 0x9E3779B97F4A7C15ull ^ (uint64_t)tuple << 40 ^ (uint64_t)chunkOps << 20 ^ (uint64_t)allowVirtual;
+        tipScratch_.resize((size_t)count * 2);
+        for (int k = 0; k < count && closed; k++) {
+            const int* op = ops + (size_t)k * tuple;
+            const int part = tuple > 7 ? op[7] : 0;
+            const char t1 = compactTip[op[3]], t2 = compactTip[op[5]];
+            if (!t1 && wStamp_[(size_t)op[3] * parts + part] != stamp_) closed = false;
+            if (!t2 && wStamp_[(size_t)op[5] * parts + part] != stamp_) closed = false;
+            wStamp_[(size_t)op[0] * parts + part] = stamp_;
+            tipScratch_[2 * k] = t1; tipScratch_[2 * k + 1] = t2;
+            for (int q = 0; q < tuple; q++) h = (h ^ (uint64_t)(unsigned)op[q]) * 1099511628211ull;
+            h = (h ^ (uint64_t)(t1 * 2 + t2)) * 1099511628211ull;
+        }
+        stamp_++;                                      // the marks above must not look like producers to pass 1
+        if (closed) {
+            for (CacheEntry& e : cache_)
+                if (e.valid && e.hash == h && e.count == count && e.tuple == tuple && e.parts == parts && e.chunkOps == chunkOps &&
+                    e.allowVirtual == allowVirtual && memcmp(e.ops.data(), ops, (size_t)count * tuple * sizeof(int)) == 0 &&
+                    memcmp(e.tips.data(), tipScratch_.data(), (size_t)count * 2) == 0) {
+                    replay(e, ops);
+                    cacheHits++;
+                    return 0;
+                }
+            fill = &cache_[cacheNext_];
+            cacheNext_ = (cacheNext_ + 1) % CACHE_WAYS;
+            fill->valid = false; fill->tag = ++cacheTagNext_; fill->hash = h; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
+            fill->allowVirtual = allowVirtual;
+            fill->ops.assign(ops, ops + (size_t)count * tuple);
+            fill->tips.assign(tipScratch_.begin(), tipScratch_.begin() + (size_t)count * 2);
+        }
+    }
     info_.assign(count, OpInfo());
     prod1_.assign(count, -1); prod2_.assign(count, -1);
     std::vector<char> consumed(count, 0);
@@ -436,7 +473,37 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     }
     // launches run wave by wave: order the slices that way (stable: partitions keep their order inside a wave)
     std::stable_sort(out.segs.begin(), out.segs.end(), [](const PlanSeg& a, const PlanSeg& b) { return a.wave < b.wave; });
+    if (fill) {
+        fill->plan = out;
+        fill->defs.assign(count, VirtDef());
+        for (int k = 0; k < count; k++) if (info_[k].virtDest) { virt_[info_[k].dest].cacheTag = fill->tag; fill->defs[k] = virt_[info_[k].dest]; }
+        plannedTag = fill->tag;
+        fill->stored = lastStored; fill->memReads = lastMemReads; fill->holds = lastHolds; fill->waves = lastWaves;
+        fill->valid = true;
+    }
     return 0;
+}
+
+// Put the planner into the state planning the (closed) list again would leave it in; the kept program is handed out
+// through `planned`.  A definition still tagged with this entry is the one the entry wrote (every other writer of a
+// definition resets the tag), so the steady state costs one comparison per operation.
+void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
+    for (int k = 0; k < e.count; k++) {
+        const int dest = ops[(size_t)k * e.tuple];
+        const VirtDef& want = e.defs[k];
+        VirtDef& cur = virt_[dest];
+        if (!want.on) { if (cur.on) clearVirtual(dest); continue; }
+        if (cur.on && cur.cacheTag == e.tag) { cur.stamp = stamp_; continue; }
+        if (cur.on) clearVirtual(dest);
+        cur = want;                                               // (tagged with e.tag when the entry was filled)
+        cur.stamp = stamp_;
+        cur.version = ++virtVersion_;
+        cur.childVer1 = cur.sigTip1 ? -1 : virt_[cur.sigC1].version;
+        cur.childVer2 = cur.sigTip2 ? -1 : virt_[cur.sigC2].version;
+        registerVirtual(dest);
+    }
+    planned = &e.plan; plannedTag = e.tag;
+    lastStored = e.stored; lastMemReads = e.memReads; lastHolds = e.holds; lastWaves = e.waves;
 }
 
 void WalkPlanner::planMaterialize(const std::vector<int>& xs, Plan& out) {

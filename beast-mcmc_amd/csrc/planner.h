@@ -68,6 +68,7 @@ struct VirtDef {
     int sigC1 = -1, sigM1 = -1, sigC2 = -1, sigM2 = -1, sigScale = -2;
     bool sigTip1 = false, sigTip2 = false, fresh1 = false, fresh2 = false;
     int childVer1 = -1, childVer2 = -1;
+    long cacheTag = 0;      // plan-cache entry that last wrote or confirmed this definition (0: none) — see WalkPlanner::replay
 };
 
 class WalkPlanner {
@@ -106,6 +107,12 @@ public:
 
     // statistics of the last plan() (bench / tests)
     int lastStored = 0, lastMemReads = 0, lastHolds = 0, lastWaves = 0;
+    long cacheHits = 0;                  // plans served from the cache below
+    bool cacheEnabled = true;
+    // what the last plan() produced: `out`, or the cache's copy (no copy is made on a hit).  plannedTag identifies the
+    // cache entry (0: not cached) so that the engine can keep what it derives from the plan.
+    const Plan* planned = nullptr;
+    long plannedTag = 0;
 
 private:
     struct OpInfo {
@@ -136,6 +143,29 @@ private:
     std::vector<int> prod1_, prod2_;                   // op of this list that produced each child (or -1)
     int parts_ = 1;
     bool flat_ = false;                                // recursion too deep: children of real ops are read from memory
+
+    // Plans of CLOSED lists (every child is a compact tip or the destination of an earlier operation of the same list:
+    // a full evaluation, what BEAST issues whenever a model parameter changes — MarkovChain.java:207-263 with all nodes
+    // dirty) depend on nothing but the list itself and the tips' compact flags, so they are kept and replayed: the chain
+    // alternates between two such lists (BufferIndexHelper.java:71-106).  Partial updates are planned every time.
+    struct CacheEntry {
+        bool valid = false;
+        long tag = 0;
+        uint64_t hash = 0;
+        int count = 0, tuple = 0, parts = 0, chunkOps = 0;
+        bool allowVirtual = false;
+        std::vector<int> ops;
+        std::vector<char> tips;                        // compact flags of (child1, child2) per op
+        Plan plan;
+        std::vector<VirtDef> defs;                     // per op: the definition its destination ends up with (on = false: real)
+        int stored = 0, memReads = 0, holds = 0, waves = 0;
+    };
+    static constexpr int CACHE_WAYS = 4;
+    CacheEntry cache_[CACHE_WAYS];
+    int cacheNext_ = 0;
+    long cacheTagNext_ = 0;
+    std::vector<char> tipScratch_;
+    void replay(const CacheEntry& e, const int* ops);
 };
 
 }  // namespace mi355

@@ -135,6 +135,7 @@ struct Harness {
     int parts = 1;
     std::mt19937 rng;
     long lists = 0, micro = 0, holds = 0, memReads = 0, stored = 0, materialised = 0, waves = 0, segsTotal = 0;
+    int fixedChunk = -1;          // >= 0: every list is planned with this chunk size (the engine's choice depends on the instance only)
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
@@ -211,9 +212,10 @@ struct Harness {
             std::vector<int> need;
             pl.mustMaterializeBefore(sub, n, tuple, need);
             materialiseNoCompare(need);
-            Plan p;
+            Plan scratch;
             static const int chunkChoices[6] = {0, 0, 3, 8, 20, 64};
-            const int rc = pl.plan(sub, n, tuple, parts, true, p, chunkChoices[rng() % 6]);
+            const int rc = pl.plan(sub, n, tuple, parts, true, scratch, fixedChunk >= 0 ? fixedChunk : chunkChoices[rng() % 6]);
+            const Plan& p = *pl.planned;           // `scratch`, or the planner's cached copy
             for (size_t q = 1; q < p.segs.size(); q++) assert(p.segs[q].wave >= p.segs[q - 1].wave);
             waves += pl.lastWaves; segsTotal += (long)p.segs.size();
             assert(rc == 0);
@@ -342,6 +344,52 @@ static void scenarioMcmc(int T, bool virt, bool caterpillar, unsigned seed, int 
            T, (int)virt, (int)caterpillar, h.lists, h.micro, h.stored, h.holds, h.memReads, h.materialised, h.segsTotal, h.waves);
 }
 
+// The chain's steady state when a model parameter changes every iteration: the SAME two full-evaluation lists alternate
+// (all nodes flip between their two buffers), with partial updates and rejected proposals in between.  The planner
+// serves the repeats from its plan cache; every evaluation is still checked against list-order evaluation.
+static void scenarioSteady(int T, bool level, unsigned seed) {
+    std::mt19937 rng(seed);
+    static char where[128]; snprintf(where, sizeof where, "steady T=%d level=%d seed=%u", T, (int)level, seed); g_where = where; g_list = 0;
+    Tree tree; tree.random(T, rng, false);
+    const int N = 2 * T - 1;
+    Harness h; h.init(T, T + 2 * (T - 1), 2 * N, 2 * (T - 1), true, seed + 1);
+    { static const int chunks[4] = {0, 8, 20, 64}; h.fixedChunk = chunks[seed % 4]; }
+    for (int i = 0; i < T; i++) h.setTipStates(i);
+    for (int s = 0; s < 2 * N; s++) h.setMatrix(s);
+    Protocol pr(tree);
+    std::vector<int> all; tree.postOrder(N - 1, all);
+    std::vector<int> lvl = tree.levelOrder();
+    const std::vector<int>& order = level ? lvl : all;
+    for (int it = 0; it < 14; it++) {
+        for (int n : order) pr.pFlip[n] ^= 1;
+        for (int n = 0; n < N - 1; n++) { pr.mFlip[n] ^= 1; h.setMatrix(pr.mBuf(n)); }        // new branch matrices every time
+        std::vector<int> ops; pr.emit(order, it % 5 == 0 ? 1 : 2, ops);
+        h.update(ops, 7);
+        h.compareAll();
+        if (it % 3 == 1) {                                   // a proposal on one branch, accepted or not
+            pr.store();
+            std::vector<char> dirty(N, 0);
+            const int n = rng() % (N - 1);
+            pr.mFlip[n] ^= 1; h.setMatrix(pr.mBuf(n));
+            for (int a = tree.parent[n]; a >= 0; a = tree.parent[a]) dirty[a] = 1;
+            std::vector<int> nodes;
+            for (int x : order) if (dirty[x]) nodes.push_back(x);
+            for (int x : nodes) pr.pFlip[x] ^= 1;
+            std::vector<int> ops2; pr.emit(nodes, 2, ops2);
+            h.update(ops2, 7);
+            if (it != 10) pr.restore();                      // rejected (the accepted one changes the lists that follow)
+            h.compareAll();
+        }
+        if (it == 7) { std::vector<int> xs; for (int q = 0; q < 4; q++) xs.push_back(T + rng() % (2 * (T - 1))); h.materialise(xs); }
+        if (it == 9) h.setTipStates(rng() % T);                // new tip data: the next evaluation recomputes everything anyway
+    }
+    std::vector<int> every; for (int b = T; b < h.nBuf; b++) every.push_back(b);
+    h.materialise(every);
+    h.compareAll();
+    if (T >= 16 && h.pl.cacheHits < 4) { fprintf(stderr, "steady T=%d: only %ld plan-cache hits\n", T, h.pl.cacheHits); exit(1); }
+    printf("  steady T=%d level=%d: %ld lists, %ld plan-cache hits, %ld micro-ops, %ld stored\n", T, (int)level, h.lists, h.pl.cacheHits, h.micro, h.stored);
+}
+
 static void scenarioPartitions(unsigned seed) {
     g_where = "partitions"; g_list = 0;
     std::mt19937 rng(seed);
@@ -404,6 +452,7 @@ int main(int argc, char** argv) {
             scenarioMcmc(T, false, false, 3000 * r + T, 20, false);
             scenarioMcmc(T, true, true, 4000 * r + T, 30, false);
         }
+        for (int T : {9, 40, 150, 600}) { scenarioSteady(T, false, 6000 * r + T); scenarioSteady(T, true, 7000 * r + T); }
         scenarioPartitions(77 + r);
         scenarioHazards(5 + r);
     }
