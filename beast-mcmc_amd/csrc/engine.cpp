@@ -66,6 +66,7 @@ struct Instance {
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
+    bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
     double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0; long hostCalls = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
@@ -471,12 +472,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
     mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
-    static const bool noFast = getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0;
     for (size_t b = 0; b < segs.size();) {
         size_t e = b + 1;
         while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
         int range = 0;
-        bool fast = paired && !noFast;            // the assembly loop: aligned segments, no write-mode rescaling (kernels.h)
+        bool fast = paired && in->fastWalk;       // the assembly loop: aligned segments, no write-mode rescaling (kernels.h)
         for (size_t i = b; i < e; i++) {
             range = std::max(range, segs[i].pEnd - segs[i].pStart);
             for (int k = plan.segs[i].progStart; fast && k < plan.segs[i].progStart + plan.segs[i].progCount; k++)
@@ -528,9 +528,11 @@ int walkChunkOps(const Instance* in, int opCount) {
     static const int forced = getenv("BEAGLE_MI355_CHUNK") ? atoi(getenv("BEAGLE_MI355_CHUNK")) : -1;
     if (forced >= 0) return forced;
     if (opCount < 64) return 0;
-    const int groups = (in->P + 127) / 128;
-    const int wanted = std::max(1, 1024 / std::max(1, groups));    // slices per wave that fill the chip (4 workgroups per CU)
-    return std::min(150, std::max(24, opCount / wanted));
+    const long groups = (in->P + 127) / 128;
+    // about 2 560 workgroups per wave of slices: 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the
+    // assembly loop (tools/chunk_sweep.sh): 12 500 patterns 129 us at 40 micro-operations per slice vs 145 at 99; flat
+    // between 50 and 300 from 25 000 patterns up
+    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / 2560));
 }
 
 // 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
@@ -1256,6 +1258,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
+    in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
@@ -1972,6 +1975,12 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     in->timedMs = 0.0; in->timedLaunches = 0;
     in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
     in->timing = enable != 0;
+    // event pairs for the calls to come are created here, not inside the region being timed
+    while (enable && in->events.size() < 1024) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+        in->events.emplace_back(a, b);
+    }
     return BEAGLE_SUCCESS;
 }
 
