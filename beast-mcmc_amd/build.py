@@ -1,7 +1,8 @@
 """In-tree build of the native pieces (explicit hipcc / g++ command lines, no build system):
 
   lib/libhmsbeagle-jni.so   HIP engine + C ABI + JNI shim, gfx950 only   (csrc/*.hip, csrc/*.cpp)
-  lib/libbeast_host.so      C++ host driver mirroring BeagleTreeLikelihood  (host/tree_likelihood.cpp)
+  lib/libbeast_host.so      the caller stand-in: BeagleTreeLikelihood's call protocol in C++  (tools/host/tree_likelihood.cpp;
+                            harness for tests and bench.py — in production the caller is BEAST's Java)
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the built
 ``.so`` files travel to the GPU box with the repo snapshot.
@@ -15,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib")
 CSRC = os.path.join(HERE, "csrc")
-HOST = os.path.join(HERE, "host")
+HOST = os.path.join(ROOT, "tools", "host")
 
 
 def _newer(target, sources):

@@ -1,4 +1,4 @@
-"""ctypes handle on the C++ host driver (host/tree_likelihood.cpp) — the mirror of
+"""ctypes handle on the C++ host driver (tools/host/tree_likelihood.cpp) — the mirror of
 ``dr.evomodel.treelikelihood.BeagleTreeLikelihood`` (src/dr/evomodel/treelikelihood/BeagleTreeLikelihood.java)
 plus the level-order traversal of ``dr.evomodel.treedatalikelihood.LikelihoodTreeTraversal``.
 

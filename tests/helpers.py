@@ -5,6 +5,7 @@ import os
 import numpy as np
 
 import beast_mcmc_amd as bm
+import reference_quantile
 from beast_mcmc_amd.inputs import patterns, siterates, substmodel, trees
 from beast_mcmc_amd.inputs.synth import Workload
 
@@ -68,7 +69,8 @@ def primates_case(case, site_model="new"):
     else:
         eig = substmodel.gtr(case["rates"], pi)
     cls = siterates.GammaSiteRateModel if site_model == "new" else siterates.OldGammaSiteModel
-    sm = cls(alpha=case.get("alpha"), gamma_categories=case.get("cats", 1), p_inv=case.get("pinv"))
+    sm = cls(alpha=case.get("alpha"), gamma_categories=case.get("cats", 1), p_inv=case.get("pinv"),
+             quantile=reference_quantile.gamma_quantile)      # the golden values were computed with the reference's quantile
     rates, props = sm.category_rates_and_proportions()
     return Workload("primates:" + case["name"], tree, eig, pi, rates, props, pats, weights, 4)
 

@@ -7,6 +7,7 @@ import pytest
 
 import beast_mcmc_amd as bm
 import helpers
+import reference_quantile
 from beast_mcmc_amd.inputs import patterns, siterates, substmodel, trees
 from beast_mcmc_amd.treelikelihood import (BeagleTreeLikelihood, POST_ORDER, RESCALE_ALWAYS, RESCALE_DYNAMIC,
                                            RESCALE_NONE, REVERSE_LEVEL_ORDER)
@@ -91,7 +92,8 @@ def run_branch_specific(library, stem_weight):
     n_sites = rows.shape[1]
     e1 = substmodel.gtr(g["gtr1"]["rates"], g["gtr1"]["pi"])
     e2 = substmodel.gtr(g["gtr2"]["rates"], g["gtr2"]["pi"])
-    rates, props = siterates.GammaSiteRateModel(alpha=g["alpha"], gamma_categories=g["cats"]).category_rates_and_proportions()
+    rates, props = siterates.GammaSiteRateModel(alpha=g["alpha"], gamma_categories=g["cats"],
+                                                quantile=reference_quantile.gamma_quantile).category_rates_and_proportions()
     # patterns are NOT compressed here (<patterns strip="false"> over 14 sites, weights 1)
     b = bm.beagle.Beagle(4, 4 + 3, 4, 4, n_sites, 2, 7, len(rates), 0, library=library)
     try:
@@ -186,7 +188,8 @@ def test_epoch_convolution_value(oracle_lib):
 
 def test_gamma_rates_match_reference_discretisation():
     """GammaSiteRateModel.java:445-472 with alpha = 0.5, 4 categories: AS 91 quantiles, mean-normalised."""
-    rates, props = siterates.GammaSiteRateModel(alpha=0.5, gamma_categories=4).category_rates_and_proportions()
+    rates, props = siterates.GammaSiteRateModel(alpha=0.5, gamma_categories=4,
+                                                quantile=reference_quantile.gamma_quantile).category_rates_and_proportions()
     assert abs(sum(rates) / 4 - 1.0) < 1e-15
     assert props == [0.25] * 4
     from scipy import stats
