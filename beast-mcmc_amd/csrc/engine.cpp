@@ -1254,7 +1254,12 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->walk = stateCount == 4 && categoryCount <= 16 &&
                (size_t)categoryCount * patternCount * 32 < ((size_t)1 << 32);     // the kernel addresses a buffer with 32-bit lane offsets
     const bool virtualOn = in->walk && !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
-    int maxVirtSteps = 6;
+    // Size of a virtual definition (internal nodes).  Evaluations at alignment sizes that keep the chip busy are bound by
+    // the bytes of the STORED nodes, and their time follows the cap (config A, profiles/r02_experiments.txt: cap 6 -> 247
+    // stored nodes, 0.98 ms; 8 -> 203, 0.90; 16 -> 155, 0.79) while a branch move — which re-evaluates the virtual siblings
+    // it passes instead of reading 32 C P bytes each — costs the same (123 us).  Small alignments are latency-bound: there
+    // the extra micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us at cap 16).
+    int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 16 : 8;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);

@@ -19,7 +19,7 @@
 
 namespace mi355 {
 
-constexpr int PLAN_MAX_STEPS = 8;        // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
+constexpr int PLAN_MAX_STEPS = 16;       // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
 constexpr int PLAN_NONE = -1;
 
 // kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine.cpp)

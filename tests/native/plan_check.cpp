@@ -139,7 +139,7 @@ struct Harness {
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
-        pl.init(nBuf, T, nMat, nScale, 6, virt);
+        { static const int caps[4] = {6, 8, 12, 16}; pl.init(nBuf, T, nMat, nScale, caps[seed % 4], virt); }    // the engine's: 8 or 16
         const int slots = pl.matrixSlots();
         for (World* w : {&truth, &plan}) {
             w->partials.assign(nBuf, {}); w->tips.assign(nBuf, {}); w->mats.assign(slots, std::vector<double>((size_t)C * 16, 0.0));
