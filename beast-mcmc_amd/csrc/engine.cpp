@@ -309,7 +309,7 @@ inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 // data — getPartials, use as root, the pre-order kernels — first calls materializeList, which runs the definition with
 // a store.
 static_assert(mi355::PK_MEM == mi355::WK_MEM && mi355::PK_TIPS == mi355::WK_TIPS && mi355::PK_ACC == mi355::WK_ACC &&
-              mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1, "planner kinds = kernel kinds");
+              mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1 && mi355::PK_H2 == mi355::WK_H2, "planner kinds = kernel kinds");
 static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_READ && mi355::PS_WRITE == mi355::WS_WRITE, "scale modes");
 
 inline bool isVirt(const Instance* in, int X) { return in->walk && in->planner.isVirtual(X); }
@@ -1261,7 +1261,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // the extra micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us at cap 16).
     int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 16 : 8;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
-    in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn);
+    in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn,
+                     getenv("BEAGLE_MI355_HOLD_SLOTS") ? std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), mi355::walkHoldSlots(categoryCount)) : mi355::walkHoldSlots(categoryCount));
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)

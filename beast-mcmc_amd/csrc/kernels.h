@@ -41,14 +41,21 @@ bool grantDynamicLds(const void* kernel, size_t bytes);
 // the previous micro-operation's result (WK_ACC, second operand only) or one of two hold slots (WK_H0/WK_H1, first
 // operand only; `hold` = 1 + slot: the result of THIS micro-operation is also parked there).  The product commutes
 // bitwise, so the planner is free to order the two children that way; a child in memory comes first.
-enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4 };
+enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4, WK_H2 = 5 };
+// hold slots the planner may use: k_walk4 keeps all of them in LDS (4 KiB per slot and category: three fit up to 8
+// categories), k_walk4_fast two in LDS and the third in registers
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int walkHoldSlots(int C) { return C <= 8 ? 3 : 2; }
 enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 // flags: what the kernel's fetch stage has to load for the micro-operation (WF_*), then the kinds
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
 // second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code (WF_WAIT8: vmcnt(8),
 // WF_WAIT12: vmcnt(12), neither: vmcnt(4))
-enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT8 = 1u << 28, WF_WAIT12 = 1u << 29 };
+enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT8 = 1u << 28, WF_WAIT12 = 1u << 29,
+       WF_HREAD2 = 1u << 30 };
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
@@ -76,7 +83,7 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     if (k2 == WK_TIPS) f |= WF_T2;
     if (smode == WS_READ) f |= WF_INV;
     if (store) f |= WF_STORE;
-    if (k1 >= WK_H0) f |= WF_HREAD | (k1 == WK_H1 ? WF_HREAD1 : 0u);
+    if (k1 >= WK_H0) f |= WF_HREAD | (k1 == WK_H1 ? WF_HREAD1 : 0u) | (k1 == WK_H2 ? WF_HREAD2 : 0u);
     if (k2 == WK_MEM) f |= WF_MEM2;
     if (hold) f |= WF_HWRITE;
     return f;

@@ -202,7 +202,7 @@ __device__ __forceinline__ v4d tipColumn(const char* tbl, unsigned s) {
 template <int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                       const v2d MI355_CONST* __restrict__ matStream, int P, int C, long recipOff) {
-    extern __shared__ v2d lds[];                      // hold[2][C][4][64] (v2d), exch[C][128] (double), table[2][MAXT / 64][320 B]
+    extern __shared__ v2d lds[];                      // hold[walkHoldSlots(C)][C][4][64] (v2d), exch[C][128] (double), table[2][MAXT / 64][320 B]
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
     const int p0 = pStart + (int)blockIdx.x * 128;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u;
     o.mat = (unsigned)(c * WALK_TABLE_BYTES + lane * 16);          // lanes 0..19 copy the wave's 320-byte table
     v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
-    double* exch = reinterpret_cast<double*>(lds + (size_t)2 * C * 256);
+    double* exch = reinterpret_cast<double*>(lds + (size_t)walkHoldSlots(C) * C * 256);
     // the wave's two matrix tables (ping-pong with the fetch stage); a lane's entry (l & 15) of matrix 1 for the DPP mat-vec
     // is T[k][i] with l & 15 = 4 i + k
     constexpr int MAXC = MAXT / 64;
@@ -364,21 +364,26 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
     if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C);
-    else if (C <= 8) hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C);
-    else hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C);
+    else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C); }
+    else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)2 * C * 256 * sizeof(v2d) + (size_t)C * 128 * sizeof(double) + (size_t)2 * maxC * WALK_TABLE_BYTES;
+    const int slots = walkHoldSlots(C);
+    const size_t lds = (size_t)slots * C * 256 * sizeof(v2d) + (size_t)C * 128 * sizeof(double) + (size_t)2 * maxC * WALK_TABLE_BYTES;
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
     if (C <= 4) hipLaunchKernelGGL((k_walk4<256, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
-    else if (C <= 8) hipLaunchKernelGGL((k_walk4<512, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
-    else hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff);
+    else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4<512, 4>), lds)) return;     // > 64 KiB of LDS: opt in per device
+                       hipLaunchKernelGGL((k_walk4<512, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff); }
+    else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4<1024, 4>), lds)) return;
+           hipLaunchKernelGGL((k_walk4<1024, 4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOff); }
 }
 
 }  // namespace mi355

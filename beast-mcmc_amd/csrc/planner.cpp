@@ -10,11 +10,12 @@ namespace {
 constexpr int OP_NONE = -1;                 // BEAGLE_OP_NONE
 constexpr int MAX_RECURSION = 4000;         // deeper dependency chains (caterpillar trees of >4000 taxa) are emitted flat
 enum { CL_TIPS = 0, CL_MEM = 1, CL_VIRT = 2, CL_REAL = 3 };
-inline int popcount2(unsigned m) { return (int)(m & 1u) + (int)((m >> 1) & 1u); }
-inline int lowestSlot(unsigned m) { return (m & 1u) ? 0 : 1; }
+inline int popcount2(unsigned m) { return (int)(m & 1u) + (int)((m >> 1) & 1u) + (int)((m >> 2) & 1u); }      // free hold slots (up to 3)
+inline int lowestSlot(unsigned m) { return (m & 1u) ? 0 : (m & 2u) ? 1 : 2; }
 }  // namespace
 
-void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled) {
+void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled, int holdSlots) {
+    allSlots_ = (1u << std::max(1, std::min(3, holdSlots))) - 1u;
     partialsCount_ = partialsCount; tipCount_ = tipCount; matrixCount_ = matrixCount; scaleCount_ = std::max(1, scaleCount);
     maxSteps_ = std::max(1, std::min(maxVirtSteps, PLAN_MAX_STEPS));
     enabled_ = virtualEnabled;
@@ -443,7 +444,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                         for (int k : chunkRoots) {
                             if (info_[k].emitted) continue;
                             PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part; seg.wave = wave;
-                            emitReal(k, 3u, out, 0);
+                            emitReal(k, allSlots_, out, 0);
                             seg.progCount = (int)out.prog.size() - seg.progStart;
                             out.segs.push_back(seg);
                         }
@@ -457,13 +458,13 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             for (int k = 0; k < count; k++) {
                 OpInfo& o = info_[k];
                 if (o.part != part || o.virtDest || o.emitted) continue;
-                if (flat_ || !consumed[k]) emitReal(k, 3u, out, 0);
+                if (flat_ || !consumed[k]) emitReal(k, allSlots_, out, 0);
             }
             // virtual nodes of a rescaling evaluation still owe their scale factors if nothing above evaluated them
             for (int k = 0; k < count; k++) {
                 const OpInfo& o = info_[k];
                 if (o.part != part || !o.virtDest || o.wS == OP_NONE) continue;
-                if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, 3u, true, out);
+                if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, allSlots_, true, out);
             }
             seg.progCount = (int)out.prog.size() - seg.progStart;
             if (seg.progCount > 0) { out.segs.push_back(seg); wave++; }
@@ -512,7 +513,7 @@ void WalkPlanner::planMaterialize(const std::vector<int>& xs, Plan& out) {
     PlanSeg seg; seg.progStart = 0; seg.partition = 0; seg.wave = 0;
     for (int X : xs) {
         if (!virt_[X].on) continue;
-        emitVirtual(X, 3u, false, out);
+        emitVirtual(X, allSlots_, false, out);
         out.prog.back().storeBuf = X;
         clearVirtual(X);
     }

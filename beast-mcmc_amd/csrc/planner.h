@@ -23,7 +23,7 @@ constexpr int PLAN_MAX_STEPS = 16;       // capacity of a virtual definition (sn
 constexpr int PLAN_NONE = -1;
 
 // kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine.cpp)
-enum { PK_MEM = 0, PK_TIPS = 1, PK_ACC = 2, PK_H0 = 3, PK_H1 = 4 };
+enum { PK_MEM = 0, PK_TIPS = 1, PK_ACC = 2, PK_H0 = 3, PK_H1 = 4, PK_H2 = 5 };
 enum { PS_NONE = 0, PS_READ = 1, PS_WRITE = 2 };
 
 struct MicroOp {
@@ -73,7 +73,8 @@ struct VirtDef {
 
 class WalkPlanner {
 public:
-    void init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled);
+    // holdSlots: per-thread slots a value can wait in while its sibling's subtree is evaluated (2 or 3; kernels.h)
+    void init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled, int holdSlots = 2);
 
     // maintained by the engine: buffer holds compact tip states (index < tipCount and setTipStates was the last setter)
     std::vector<char> compactTip;
@@ -141,6 +142,7 @@ private:
     std::vector<int> sWStamp_, sRStamp_, sDone_;      // per scale buffer: written / read in this list, write emitted
     std::vector<OpInfo> info_;
     std::vector<int> prod1_, prod2_;                   // op of this list that produced each child (or -1)
+    unsigned allSlots_ = 3u;                           // mask of the hold slots
     int parts_ = 1;
     bool flat_ = false;                                // recursion too deep: children of real ops are read from memory
 

@@ -87,7 +87,7 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
     for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) w.mats[plan.snapPairs[i + 1]] = src[i / 2];
     for (const PlanSeg& sg : plan.segs) {
         for (int p = partStart[sg.partition]; p < partEnd[sg.partition]; p++) {
-            V4 ACC[8], H[2][8];
+            V4 ACC[8], H[3][8];
             for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
                 const MicroOp& m = plan.prog[k];
                 V4 r[8];
@@ -97,7 +97,7 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
                     const double* M2 = &w.mats[m.mat2][(size_t)c * 16];
                     if (m.k1 == PK_TIPS) f1 = column(M1, w.tips[m.a1][p]);
                     else if (m.k1 == PK_MEM) { CHECK(!w.partials[m.a1].empty(), m, k); V4 x; memcpy(x.v, &w.partials[m.a1][((size_t)c * P + p) * 4], 32); f1 = matvec(M1, x); }
-                    else { assert(m.k1 == PK_H0 || m.k1 == PK_H1); f1 = matvec(M1, H[m.k1 - PK_H0][c]); }
+                    else { assert(m.k1 >= PK_H0 && m.k1 <= PK_H2); f1 = matvec(M1, H[m.k1 - PK_H0][c]); }
                     if (m.k2 == PK_TIPS) f2 = column(M2, w.tips[m.a2][p]);
                     else if (m.k2 == PK_MEM) { CHECK(!w.partials[m.a2].empty(), m, k); V4 x; memcpy(x.v, &w.partials[m.a2][((size_t)c * P + p) * 4], 32); f2 = matvec(M2, x); }
                     else { assert(m.k2 == PK_ACC); f2 = matvec(M2, ACC[c]); }
@@ -139,7 +139,7 @@ struct Harness {
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
-        { static const int caps[4] = {6, 8, 12, 16}; pl.init(nBuf, T, nMat, nScale, caps[seed % 4], virt); }    // the engine's: 8 or 16
+        { static const int caps[4] = {6, 8, 12, 16}; pl.init(nBuf, T, nMat, nScale, caps[seed % 4], virt, 2 + (seed / 4) % 2); }    // the engine's: 8 or 16
         const int slots = pl.matrixSlots();
         for (World* w : {&truth, &plan}) {
             w->partials.assign(nBuf, {}); w->tips.assign(nBuf, {}); w->mats.assign(slots, std::vector<double>((size_t)C * 16, 0.0));

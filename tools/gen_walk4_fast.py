@@ -30,7 +30,8 @@ F, G = 60, 76                 # the two children's contributions
 SP = 92                       # lane l: entry (l & 15) of a branch matrix
 T0, T1 = 94, 95
 PA, PB, TIP, SCALE, OM, HOLD, SP0, SP1, LANE, VST = 96, 97, 98, 99, 100, 101, 102, 103, 104, 105
-NV = 106
+H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
+NV = 122
 # scalar
 DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST = 20, 22, 24, 25, 26, 27, 59, 60      # (s32 is reserved)
 MASK = 62                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
@@ -43,7 +44,7 @@ S_FIRST, S_LAST = 20, 73
 
 # flag bits (kernels.h)
 B_X, B_T1, B_T2, B_STORE, B_HSLOT1 = 0, 1, 2, 4, 12
-B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1 = 24, 25, 26, 27, 28, 29
+B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
 
 STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
 lines = []
@@ -98,6 +99,8 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
     e("s_cbranch_scc1 %s" % L("hr" + tag))
     e(L("hrb" + tag) + ":")
     blk = [L("hr" + tag) + ":",
+           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD2),          # slot 2 is a register set: nothing to fetch
+           "s_cbranch_scc1 %s" % L("hrb" + tag),
            "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD1),
            "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
            "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
@@ -150,8 +153,19 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
     e("s_branch %s" % L("g" + tag))
     e(L("fm" + tag) + ":")
     e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
+    e("s_cbranch_scc1 %s" % L("fh2" + tag))
     e("s_waitcnt lgkmcnt(0)")
     matvec(F, X)
+    save = lines[:]
+    del lines[:]
+    e(L("fh2" + tag) + ":")                          # first child waits in the register hold slot
+    e("s_waitcnt lgkmcnt(0)")
+    matvec(F, H2)
+    e("s_branch %s" % L("g" + tag))
+    outofline.append(lines[:])
+    del lines[:]
+    lines.extend(save)
     # second child
     e(L("g" + tag) + ":")
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
@@ -209,11 +223,18 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
     e("s_cbranch_scc1 %s" % L("hw" + tag))
     e(L("hwb" + tag) + ":")
     blk = [L("hw" + tag) + ":",
-           "s_bitcmp1_b32 %s, %d" % (s(SFL), B_HSLOT1),
-           "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
+           "s_bfe_u32 %s, %s, 0x2000b" % (s(ST), s(SFL)),           # hold = 1 + slot (2 bits at 11)
+           "s_cmp_eq_u32 %s, 3" % s(ST),
+           "s_cbranch_scc1 %s" % L("hw2" + tag),
+           "s_add_i32 %s, %s, -1" % (s(ST), s(ST)),
+           "s_mul_i32 %s, %s, %s" % (s(ST), s(ST), s(HSTRIDE)),
            "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
     for q in range(4):
         blk.append("ds_write_b128 %s, %s offset:%d" % (v(T0), v(ACC + 4 * q, 4), 1024 * q))
+    blk.append("s_branch %s" % L("hwb" + tag))
+    blk.append(L("hw2" + tag) + ":")
+    for i in range(8):
+        blk.append("v_mov_b64 %s, %s" % (v(H2 + 2 * i, 2), v(ACC + 2 * i, 2)))
     blk.append("s_branch %s" % L("hwb" + tag))
     outofline.append(blk)
 
