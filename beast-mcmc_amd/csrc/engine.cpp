@@ -67,6 +67,9 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
+    bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
+    bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
+    long statCherries = 0;
     double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0; long hostCalls = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
@@ -312,8 +315,8 @@ static_assert(mi355::PK_MEM == mi355::WK_MEM && mi355::PK_TIPS == mi355::WK_TIPS
               mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1 && mi355::PK_H2 == mi355::WK_H2, "planner kinds = kernel kinds");
 static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_READ && mi355::PS_WRITE == mi355::WS_WRITE, "scale modes");
 
-inline bool isVirt(const Instance* in, int X) { return in->walk && in->planner.isVirtual(X); }
-inline void clearVirtual(Instance* in, int X) { if (in->walk) in->planner.clearVirtual(X); }
+inline bool isVirt(const Instance* in, int X) { return in->virt && in->planner.isVirtual(X); }
+inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearVirtual(X); }
 inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
 inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X] = on ? 1 : 0; }
 
@@ -497,8 +500,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
 }
 
 // Give every (virtual) buffer of `xs` its real partials: one program, one launch.
+int materializeCherries(Instance* in, const std::vector<int>& xs);
 int materializeList(Instance* in, const std::vector<int>& xs) {
-    if (!in->walk || xs.empty()) return 0;
+    if (!in->virt || xs.empty()) return 0;
+    if (!in->walk) return materializeCherries(in, xs);
     mi355::Plan mp;
     in->planner.planMaterialize(xs, mp);
     return runPlan(in, mp);
@@ -508,11 +513,11 @@ int materializeVirtual(Instance* in, int X) {
     return materializeList(in, std::vector<int>(1, X));
 }
 int materializeScaleUsers(Instance* in, int scaleIdx) {
-    if (!in->walk || in->planner.scaleUsers(scaleIdx).empty()) return 0;
+    if (!in->virt || in->planner.scaleUsers(scaleIdx).empty()) return 0;
     return materializeList(in, std::vector<int>(in->planner.scaleUsers(scaleIdx)));
 }
 int materializeTipUsers(Instance* in, int tip) {
-    if (!in->walk || in->planner.tipUsers(tip).empty()) return 0;
+    if (!in->virt || in->planner.tipUsers(tip).empty()) return 0;
     return materializeList(in, std::vector<int>(in->planner.tipUsers(tip)));
 }
 
@@ -594,6 +599,35 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
     return foldCumulative(in, ops, count, tuple, globalCum);
 }
 
+// T32 instances: give the virtual cherries of `xs` their real partials — each is one ordinary tip-tip operation on its
+// snapshot matrices; all of them are independent (one level launch).
+int materializeCherries(Instance* in, const std::vector<int>& xs) {
+    std::vector<OpDesc> descs;
+    for (int X : xs) {
+        if (!in->planner.isVirtual(X)) continue;
+        const mi355::VirtDef& v = in->planner.definition(X);
+        const mi355::VirtStep& st = v.steps[0];
+        if (v.nSteps != 1 || st.type != mi355::VT_CHERRY || !in->tipStates[st.tipA] || !in->tipStates[st.tipB]) return BEAGLE_ERROR_GENERAL;
+        int rc = ensurePartials(in, X); if (rc) return rc;
+        OpDesc d;
+        memset(&d, 0, sizeof(d));
+        d.dest = in->partials[X];
+        d.child1 = in->tipStates[st.tipA]; d.child2 = in->tipStates[st.tipB];
+        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
+        d.mat1 = in->planner.snapSlot(X, 0, 0); d.mat2 = in->planner.snapSlot(X, 0, 1);
+        if (st.scaleIdx >= 0) { if (!in->scale[st.scaleIdx]) return BEAGLE_ERROR_GENERAL; d.scaleRead = in->scale[st.scaleIdx]; }
+        d.pStart = 0; d.pEnd = in->P;
+        descs.push_back(d);
+        in->planner.clearVirtual(X);
+    }
+    if (descs.empty()) return 0;
+    void* dOps = nullptr;
+    int rc = uploadTransient(in, descs.data(), descs.size() * sizeof(OpDesc), &dOps); if (rc) return rc;
+    mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dOps, (int)descs.size(), in->matrices, in->P, in->S, in->C, false);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // Enqueue an op list level by level (every state count but 4).  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
 int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (count <= 0) return 0;
@@ -605,6 +639,31 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
     std::vector<int> predOff(count + 1, 0), predList;                 // RAW / WAW edges: producer op -> this op
     bool warSeen = false;                                             // a write-after-read hazard inside the list (never in BEAST's lists)
     predList.reserve((size_t)count * 3);
+    // virtual cherries (in->cherry): definitions that read a scale buffer this list rewrites, or that the list updates in
+    // place, get their data first; new ones are only made by single-partition 7-int lists
+    const bool cherryList = in->cherry && parts == 1 && tuple == BEAGLE_OP_COUNT;
+    std::vector<mi355::CherryDesc> cherries;
+    std::vector<int> snapPairs;
+    std::vector<char> skipped(count, 0);                             // ops that only defined a cherry
+    if (in->virt) {
+        for (int k = 0; k < count; k++) {                            // (range checks of these fields: same loop below, nothing is touched before it passes)
+            const int* op = ops + (size_t)k * tuple;
+            if (badIndex(op[0], in->partialsCount) || badIndex(op[3], in->partialsCount) || badIndex(op[5], in->partialsCount) ||
+                (op[1] != BEAGLE_OP_NONE && badIndex(op[1], in->scaleCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
+        }
+        std::vector<int> need;
+        in->planner.mustMaterializeBefore(ops, count, tuple, need);
+        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    }
+    auto cherryChild = [&](int c) -> size_t {                         // descriptor index of a virtual child
+        const mi355::VirtStep& st = in->planner.definition(c).steps[0];
+        mi355::CherryDesc cd;
+        cd.tipA = in->tipStates[st.tipA]; cd.tipB = in->tipStates[st.tipB];
+        cd.scale = st.scaleIdx >= 0 ? in->scale[st.scaleIdx] : nullptr;
+        cd.matA = in->planner.snapSlot(c, 0, 0); cd.matB = in->planner.snapSlot(c, 0, 1);
+        cherries.push_back(cd);
+        return cherries.size() - 1;
+    };
     in->stamp++;
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {
@@ -620,13 +679,34 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
         const bool tip1 = isCompactTip(in, c1), tip2 = isCompactTip(in, c2);
         const int ownScale = wS != BEAGLE_OP_NONE ? wS : rS;
         if (wS != BEAGLE_OP_NONE || rS != BEAGLE_OP_NONE) { int rcs = ensureScale(in, ownScale); if (rcs) return rcs; }
+        // a tip-tip node that does not rescale now is DEFINED, not computed: nothing is launched for it (a definition
+        // reads its scale buffer in read mode only, so that buffer must hold factors already)
+        if (cherryList && tip1 && tip2 && wS == BEAGLE_OP_NONE && dest != c1 && dest != c2 && dest >= in->tipCount &&
+            (rS == BEAGLE_OP_NONE || in->scaleIsRaw[rS]) && in->planner.defineCherry(dest, c1, m1, c2, m2, rS == BEAGLE_OP_NONE ? -1 : rS, snapPairs)) {
+            skipped[k] = 1; level[k] = 0; predOff[k] = (int)predList.size();
+            in->statCherries++;
+            continue;
+        }
+        if (isVirt(in, dest)) clearVirtual(in, dest);                // whatever it was, this op gives it real data
+        // traffic counters (beagleMi355WalkStats): one stored node; per child a partials read, a tip-state read or — for a
+        // virtual cherry — two tip-state reads and its scale factors
+        in->statMicroOps++; in->statStored++;
+        for (int w = 0; w < 2; w++) {
+            const int c = w ? c2 : c1;
+            if (w ? tip2 : tip1) in->statTipReads++;
+            else if (isVirt(in, c)) { in->statTipReads += 2; if (in->planner.definition(c).steps[0].scaleIdx >= 0) in->statScaleReads++; }
+            else in->statMemReads++;
+        }
+        if (wS != BEAGLE_OP_NONE) in->statScaleWrites++; else if (rS != BEAGLE_OP_NONE) in->statScaleReads++;
         descOf[k] = (int)descs.size(); descs.emplace_back();
         OpDesc& d = descs.back();
         memset(&d, 0, sizeof(d));
         if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
+        else if (isVirt(in, c1)) { d.child1 = (const void*)cherryChild(c1); d.kind |= mi355::KIND_CHERRY1; }
         else if (in->partials[c1]) d.child1 = in->partials[c1];
         else return BEAGLE_ERROR_OUT_OF_RANGE;
         if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
+        else if (isVirt(in, c2)) { d.child2 = (const void*)cherryChild(c2); d.kind |= mi355::KIND_CHERRY2; }
         else if (in->partials[c2]) d.child2 = in->partials[c2];
         else return BEAGLE_ERROR_OUT_OF_RANGE;
         int rc = ensurePartials(in, dest); if (rc) return rc;
@@ -671,12 +751,24 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
     }
     // counting sort by level (stable)
     std::vector<int> start(maxLevel + 2, 0);
-    for (int k = 0; k < count; k++) start[level[k] + 1]++;
+    for (int k = 0; k < count; k++) if (!skipped[k]) start[level[k] + 1]++;
     for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
     const int launchCount = start[maxLevel + 1];
     std::vector<OpDesc> sorted(std::max(1, launchCount));
     std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[descOf[k]];
+    for (int k = 0; k < count; k++) if (!skipped[k]) sorted[fill[level[k]]++] = descs[descOf[k]];
+    // the cherries' matrix snapshots and the descriptors of the virtual children, ahead of the level launches
+    const mi355::CherryDesc* dCherries = nullptr;
+    if (!snapPairs.empty()) {
+        void* dPairs = nullptr;
+        int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
+    }
+    if (!cherries.empty()) {
+        void* dC = nullptr;
+        int rc = uploadTransient(in, cherries.data(), cherries.size() * sizeof(mi355::CherryDesc), &dC); if (rc) return rc;
+        dCherries = (const mi355::CherryDesc*)dC;
+    }
     // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
     // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
     // launch per dependency level reading its slice.  With the kernel timer on, ONE HIP-event pair brackets
@@ -709,7 +801,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
             }
             if (in->tiled)
                 mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                             in->P, in->S, in->C, anyWrite);
+                                             in->P, in->S, in->C, anyWrite, dCherries);
             else
                 mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                         in->P, in->S, in->C, maxRange);
@@ -820,7 +912,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
             return BEAGLE_ERROR_OUT_OF_RANGE;
         if (isVirt(in, sib)) need.push_back(sib);
         if (isVirt(in, par)) need.push_back(par);
-        if (in->walk) {
+        if (in->virt) {
             need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
             if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
         }
@@ -1253,7 +1345,12 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // BEAGLE_MI355_VSTEPS=n caps the length of a virtual definition (A/B runs).
     in->walk = stateCount == 4 && categoryCount <= 16 &&
                (size_t)categoryCount * patternCount * 32 < ((size_t)1 << 32);     // the kernel addresses a buffer with 32-bit lane offsets
-    const bool virtualOn = in->walk && !(getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0);
+    const bool noVirtual = getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0;
+    // T32 instances with <= 20 states: tip-tip nodes ("cherries") are defined, not stored — their parent's kernel rebuilds
+    // them from the tips' states (kernels_mfma.hip cherryOperands); a definition is ONE step here
+    in->cherry = in->tiled && stateCount <= 20 && !noVirtual;
+    const bool virtualOn = (in->walk && !noVirtual) || in->cherry;
+    in->virt = virtualOn;
     // Size of a virtual definition (internal nodes).  Evaluations at alignment sizes that keep the chip busy are bound by
     // the bytes of the STORED nodes, and their time follows the cap (config A, profiles/r02_experiments.txt: cap 6 -> 247
     // stored nodes, 0.98 ms; 8 -> 203, 0.90; 16 -> 155, 0.79) while a branch move — which re-evaluates the virtual siblings
@@ -1261,6 +1358,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // the extra micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us at cap 16).
     int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 16 : 8;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
+    if (in->cherry) maxVirtSteps = 1;
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn,
                      getenv("BEAGLE_MI355_HOLD_SLOTS") ? std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), mi355::walkHoldSlots(categoryCount)) : mi355::walkHoldSlots(categoryCount));
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);

@@ -29,7 +29,18 @@ struct OpDesc {
     int            pad;
 };
 static_assert(sizeof(OpDesc) == 64, "OpDesc layout");
-enum { KIND_STATES1 = 1, KIND_STATES2 = 2 };
+enum { KIND_STATES1 = 1, KIND_STATES2 = 2, KIND_CHERRY1 = 4, KIND_CHERRY2 = 8 };
+// A child that is a "virtual cherry" (T32 instances with <= 20 states): its buffer is not stored, it IS
+// node(tipA over matrix matA, tipB over matrix matB) [/ scale] and the parent's kernel rebuilds its MFMA operands from the
+// two tips' states and LDS copies of the two matrices.  OpDesc.child1 / child2 then hold the INDEX of the descriptor in
+// the array handed to launchPruneLevelTiled.
+struct CherryDesc {
+    const uint8_t* tipA;
+    const uint8_t* tipB;
+    const double*  scale;     // the cherry node's raw scale factors (read mode), or nullptr
+    int            matA, matB;
+};
+static_assert(sizeof(CherryDesc) == 32, "CherryDesc layout");
 
 // Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: granted once per (kernel, device) —
 // several instances on different GPUs of one process (BEAST's -beagle_instances) each get theirs.  false: the runtime refused.
@@ -189,7 +200,7 @@ int  pruneBlocksForRange(int S, int range);
 // ---- T32 layout (20-/61-state MFMA path, kernels_mfma.hip): partials[c][tile][state][32 patterns] --------------
 // One dependency level on the fp64 matrix cores; anyScaleWrite adds the second (max + divide) pass.
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
-                           bool anyScaleWrite);
+                           bool anyScaleWrite, const CherryDesc* dCherries = nullptr);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)
 void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,

@@ -66,6 +66,46 @@ __device__ __forceinline__ void tiledFetch1(const OpDesc& op, bool st1, int c, i
     } else tiledLoadB<NTMAX, EXACT>(op.child1, ((size_t)c * ntile + tile) * S * TILE, S, g, m, b);
 }
 
+// A virtual-cherry child (kernels.h CherryDesc): X[j][p] = A[j][sA(p)] * B[j][sB(p)] * (1 / scale[p]) — the arithmetic, and
+// its order, of the op that would have stored the cherry (GeneralLikelihoodCore.java:52-105; a missing state contributes 1).
+// What comes from memory for a lane's two patterns (the part worth prefetching): four state codes, two factors.
+struct CherryRaw { int ae, ao, be, bo; double inve, invo; };
+__device__ __forceinline__ CherryRaw cherryFetch(const CherryDesc& cd, int tile, int P, int S, int m) {
+    const uint8_t MI355_GLOBAL* ta = gptr(cd.tipA);
+    const uint8_t MI355_GLOBAL* tb = gptr(cd.tipB);
+    const int pe = tile * TILE + 2 * m;
+    CherryRaw r;
+    r.ae = r.ao = r.be = r.bo = S; r.inve = r.invo = 1.0;
+    if (pe < P) { r.ae = ta[pe]; r.be = tb[pe]; }
+    if (pe + 1 < P) { r.ao = ta[pe + 1]; r.bo = tb[pe + 1]; }
+    r.ae = r.ae < S ? r.ae : S; r.ao = r.ao < S ? r.ao : S; r.be = r.be < S ? r.be : S; r.bo = r.bo < S ? r.bo : S;
+    if (cd.scale) {
+        const double MI355_GLOBAL* sr = gptr(cd.scale);
+        if (pe < P) r.inve = 1.0 / sr[pe];
+        if (pe + 1 < P) r.invo = 1.0 / sr[pe + 1];
+    }
+    return r;
+}
+// The cherry's two matrices sit in LDS as vm[column s = 0..S][g][jt] = M[4 jt + g][s] (column S: ones for the rows that
+// exist, so a missing state needs no select; rows >= S: zeros): the five values a lane needs of one column are contiguous.
+template <int NTMAX>
+__device__ __forceinline__ void cherryOperands(const CherryRaw& r, const double* __restrict__ vmA, const double* __restrict__ vmB, int g, v2d (&b)[NTMAX]) {
+    const double* ae = vmA + (r.ae * 4 + g) * NTMAX;
+    const double* ao = vmA + (r.ao * 4 + g) * NTMAX;
+    const double* be = vmB + (r.be * 4 + g) * NTMAX;
+    const double* bo = vmB + (r.bo * 4 + g) * NTMAX;
+#pragma unroll
+    for (int jt = 0; jt < NTMAX; jt++) b[jt] = v2d{ae[jt] * be[jt] * r.inve, ao[jt] * bo[jt] * r.invo};
+}
+template <int NTMAX>
+__device__ __forceinline__ void cherryStage(double* __restrict__ vm, const double* __restrict__ M, int S) {
+    const int n = (S + 1) * 4 * NTMAX;
+    for (int e = threadIdx.x; e < n; e += MF_BLOCK) {
+        const int jt = e % NTMAX, g = (e / NTMAX) & 3, col = e / (4 * NTMAX), i = 4 * jt + g;
+        vm[e] = i < S ? (col < S ? M[(size_t)i * S + col] : 1.0) : 0.0;
+    }
+}
+
 // One child's factor for the parent-state tiles [it0, it0 + IH): oe/oo[k] = sum_j M[4(it0+k)+g][j] * X[j][2m / 2m+1]
 template <int NTMAX, int IH>
 __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int nt, int S, bool isStates, int se, int so,
@@ -107,9 +147,9 @@ __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int 
 // NTMAX = 5 (<= 20 states) runs at 4 waves per SIMD, NTMAX = 16 (<= 64 states) at 2.
 // EXACT: the state count fills all NTMAX tiles (20 and 61..64 states), so every tile bound folds at compile time.
 // PIPE: 0 = loads where they are needed, 1 = child 2 early, 2 = child 2 early + next tile's child 1 (register budget permitting).
-template <int NTMAX, bool EXACT, int PIPE>
+template <int NTMAX, bool EXACT, int PIPE, bool CHERRY>
 __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
-                                                                              int P, int S, int C) {
+                                                                              int P, int S, int C, const CherryDesc* __restrict__ cherries) {
     constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
     extern __shared__ double frag[];          // [2][NTMAX*NTMAX][16] A fragments of the two branch matrices, current category
     const OpDesc& op = ops[blockIdx.y / C];      // one (op, rate category) per grid row: single-op levels still fill the chip
@@ -122,7 +162,14 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int fl = g * 4 + (lane & 3);
     const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
+    // virtual-cherry children (NTMAX = 5 only: four more S x S matrices fit the LDS budget of 4 workgroups per CU)
+    const bool vt1 = CHERRY && (op.kind & KIND_CHERRY1), vt2 = CHERRY && (op.kind & KIND_CHERRY2);
     constexpr int fragN = NTMAX * NTMAX * 16;
+    double* vm = frag + 2 * fragN;            // [4][(S + 1) * 4 * NTMAX]: child 1's (A, B), child 2's (A, B); see cherryOperands
+    const int vmN = (S + 1) * 4 * NTMAX;
+    CherryDesc cd1 = {}, cd2 = {};
+    if (vt1) cd1 = cherries[(size_t)op.child1];
+    if (vt2) cd2 = cherries[(size_t)op.child2];
     const int tstep = gridDim.x * 4;
     const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
 
@@ -132,7 +179,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
         int tile = tile0 + blockIdx.x * 4 + wave;
         v2d b1[NTMAX], b2[NTMAX];
         int se1 = S, so1 = S;
-        if (PIPE == 2 && tile < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);   // in flight across the staging
+        if (PIPE == 2 && !vt1 && tile < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);   // in flight across the staging
         for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) {
             const int child = e >= fragN, r = e - child * fragN;
             const int f = r >> 4, q = r & 15;
@@ -140,18 +187,31 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
             const int i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
             frag[e] = (i < S && j < S) ? (child ? M2 : M1)[(size_t)i * S + j] : 0.0;
         }
+        if (vt1) {
+            cherryStage<NTMAX>(vm, matrices + ((size_t)cd1.matA * C + c) * S * S, S);
+            cherryStage<NTMAX>(vm + vmN, matrices + ((size_t)cd1.matB * C + c) * S * S, S);
+        }
+        if (vt2) {
+            cherryStage<NTMAX>(vm + 2 * vmN, matrices + ((size_t)cd2.matA * C + c) * S * S, S);
+            cherryStage<NTMAX>(vm + 3 * vmN, matrices + ((size_t)cd2.matB * C + c) * S * S, S);
+        }
         __syncthreads();
+        CherryRaw raw1 = {};
+        if (vt1 && tile < tile1) raw1 = cherryFetch(cd1, tile, P, S, m);
         for (; tile < tile1; tile += tstep) {
             const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
             const int pe = tile * TILE + 2 * m;           // even pattern of this lane; odd = pe + 1
-            if (PIPE < 2) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);
+            if (vt1) cherryOperands<NTMAX>(raw1, vm, vm + vmN, g, b1);      // (its states and factors were fetched a tile ago)
+            else if (PIPE < 2) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);
             // child 2's operands fly while child 1's MFMAs run
             int se2 = S, so2 = S;
+            CherryRaw raw2 = {};
             if (st2) {
                 const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child2));
                 if (pe < P) se2 = st[pe];
                 if (pe + 1 < P) so2 = st[pe + 1];
-            } else if (PIPE >= 1) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
+            } else if (vt2) raw2 = cherryFetch(cd2, tile, P, S, m);
+            else if (PIPE >= 1) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
             double inve = 1.0, invo = 1.0;
             if (!op.scaleWrite && op.scaleRead) {
                 const double MI355_GLOBAL* sr = gptr(op.scaleRead);
@@ -161,9 +221,11 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
             double re[NTMAX], ro[NTMAX];
             tiledChild<NTMAX, NTMAX>(frag, nt, S, st1, se1, so1, M1, b1, 0, g, fl, re, ro);
             __builtin_amdgcn_sched_barrier(0);
-            if (PIPE == 0 && !st2) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
+            if (PIPE == 0 && !st2 && !vt2) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
             // the next tile's child-1 operands fly while child 2's MFMAs run
-            if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
+            if (vt1) { if (tile + tstep < tile1) raw1 = cherryFetch(cd1, tile + tstep, P, S, m); }
+            else if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
+            if (vt2) cherryOperands<NTMAX>(raw2, vm + 2 * vmN, vm + 3 * vmN, g, b2);
             __builtin_amdgcn_sched_barrier(0);
             const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
             double* d = op.dest + tileBase;
@@ -236,29 +298,30 @@ static int tiledBlocksPerRow(int P, int rows, int target) {
 }
 
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
-                           bool anyScaleWrite) {
+                           bool anyScaleWrite, const CherryDesc* dCherries) {
     if (nOps <= 0) return;
     const int maxOps = 65535 / C;                    // grid.y limit
     if (nOps > maxOps) {
         for (int o = 0; o < nOps; o += maxOps)
-            launchPruneLevelTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C, anyScaleWrite);
+            launchPruneLevelTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C, anyScaleWrite, dCherries);
         return;
     }
     const int nt = (S + 3) / 4;
     // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
     dim3 grid(tiledBlocksPerRow(P, nOps * C, nt <= 5 ? 2048 : 1024), nOps * C), block(MF_BLOCK);
     static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
-#define TILED_LAUNCH(NT, EX, PI) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI>), grid, block, lds, stream, dOps, matrices, P, S, C)
+#define TILED_LAUNCH(NT, EX, PI) do { if (NT <= 5 && dCherries) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, NT <= 5>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); \
+                                        else hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, false>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); } while (0)
     if (nt <= 5) {
-        const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double);
+        const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double) + (dCherries ? (size_t)4 * (S + 1) * 4 * 5 * sizeof(double) : 0);    // + the cherries' matrices
         if (nt < 5) TILED_LAUNCH(5, false, 0);
         else if (pipe >= 2) TILED_LAUNCH(5, true, 2);
         else if (pipe == 1) TILED_LAUNCH(5, true, 1);
         else TILED_LAUNCH(5, true, 0);
     } else {
         const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);          // 64 KiB: above the default 48 KiB cap
-        const void* fns[] = {(const void*)k_pruneTiled<16, false, 0>, (const void*)k_pruneTiled<16, true, 0>,
-                             (const void*)k_pruneTiled<16, true, 1>, (const void*)k_pruneTiled<16, true, 2>};
+        const void* fns[] = {(const void*)k_pruneTiled<16, false, 0, false>, (const void*)k_pruneTiled<16, true, 0, false>,
+                             (const void*)k_pruneTiled<16, true, 1, false>, (const void*)k_pruneTiled<16, true, 2, false>};
         for (const void* f : fns) if (!grantDynamicLds(f, lds)) return;
         if (nt < 16) TILED_LAUNCH(16, false, 0);
         else if (pipe >= 2) TILED_LAUNCH(16, true, 2);

@@ -103,6 +103,17 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool ti
     return true;
 }
 
+bool WalkPlanner::defineCherry(int X, int tipA, int mA, int tipB, int mB, int scaleIdx, std::vector<int>& snapPairs) {
+    if (!enabled_ || !compactTip[tipA] || !compactTip[tipB]) return false;
+    stamp_++;
+    if (virt_[X].on) clearVirtual(X);
+    if (!buildVirtual(X, tipA, true, mA, tipB, true, mB, scaleIdx, snapPairs)) return false;
+    VirtDef& nv = virt_[X];
+    nv.version = ++virtVersion_;
+    nv.sigC1 = tipA; nv.sigM1 = mA; nv.sigC2 = tipB; nv.sigM2 = mB; nv.sigScale = scaleIdx; nv.sigTip1 = nv.sigTip2 = true;
+    return true;
+}
+
 int WalkPlanner::hazardFreePrefix(const int* ops, int begin, int count, int tuple, int parts) {
     const size_t nKeys = (size_t)partialsCount_ * parts, nS = (size_t)scaleCount_ * parts;
     if (wStamp_.size() < nKeys) { wStamp_.assign(nKeys, 0); rStamp_.assign(nKeys, 0); wOp_.assign(nKeys, 0); }

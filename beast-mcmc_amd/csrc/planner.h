@@ -82,12 +82,15 @@ public:
     bool isVirtual(int buf) const { return virt_[buf].on; }
     const VirtDef& definition(int buf) const { return virt_[buf]; }
     bool virtualEnabled() const { return enabled_; }
-    int snapSlot(int buf, int step, int which) const { return matrixCount_ + buf * 2 * PLAN_MAX_STEPS + 2 * step + which; }
-    int matrixSlots() const { return matrixCount_ + (enabled_ ? partialsCount_ * 2 * PLAN_MAX_STEPS : 0); }
+    int snapSlot(int buf, int step, int which) const { return matrixCount_ + buf * 2 * maxSteps_ + 2 * step + which; }
+    int matrixSlots() const { return matrixCount_ + (enabled_ ? partialsCount_ * 2 * maxSteps_ : 0); }
 
     const std::vector<int>& tipUsers(int tip) const { return tipUsers_[tip]; }
     const std::vector<int>& scaleUsers(int idx) const { return scaleUsers_[idx]; }
     void clearVirtual(int buf);          // forget the definition (the buffer is about to get real data)
+    // Define `buf` as the cherry node(tipA over matrix mA, tipB over matrix mB) [read-mode scale buffer scaleIdx or PLAN_NONE]
+    // (the level-scheduled T32 path, engine.cpp runOperationsLevels); appends the matrix snapshot copies to snapPairs.
+    bool defineCherry(int buf, int tipA, int mA, int tipB, int mB, int scaleIdx, std::vector<int>& snapPairs);
 
     // Length of the longest prefix of ops[begin..count) that can run as one walk: no buffer (or scale buffer) is written
     // twice, written after an earlier op of the prefix read it, or read through a scale index another op writes.

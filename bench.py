@@ -274,7 +274,9 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             kname = "k_walk4_fast" if stats.get("fast_walks", 0) * 2 > stats["walks"] else "k_walk4"
             launches_per_eval = stats["walks"] / max(1, args.steps)
         else:
-            moved = alg                                       # the tiled kernels store and re-read every node
+            # the level kernels store and re-read every node they compute (= the algorithmic bytes), minus the tip-tip nodes
+            # a <= 20-state instance defines instead of storing (engine counters)
+            moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps) if stats["micro_ops"] > 0 else alg
             kname = "k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
             launches_per_eval = launches / max(1, args.steps)
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
