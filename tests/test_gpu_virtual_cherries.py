@@ -1,5 +1,5 @@
-"""The 4-state engine never writes tip-tip nodes' partials to HBM unless somebody needs the real data ("virtual
-cherries", engine.cpp).  BEAGLE semantics must survive that: a partials buffer keeps the value its op gave it even
+"""The 4-state engine — and, on the T32 layout, the <= 20-state one — never writes tip-tip nodes' partials to HBM unless
+somebody needs the real data ("virtual cherries", engine.cpp; kernels_mfma.hip cherryOperands).  BEAGLE semantics must survive that: a partials buffer keeps the value its op gave it even
 if the tip states, the matrices or the scale buffer it was computed from are changed afterwards.  Every step below is
 issued identically to the HIP engine and to the CPU oracle, and every buffer is compared after every step."""
 import numpy as np
@@ -14,8 +14,8 @@ NONE = bm.beagle.NONE
 T, P, C = 4, 300, 4          # tips 0..3; internal buffers 4 = (0,1) cherry, 5 = (2,3) cherry, 6 = (4,5) root, 7 = (4,2)
 
 
-def make(lib, states, eig, rates):
-    b = bm.beagle.Beagle(T, 8, T, 4, P, 1, 8, C, 6, library=lib)
+def make(lib, states, eig, rates, S=4):
+    b = bm.beagle.Beagle(T, 8, T, S, P, 1, 8, C, 6, library=lib)
     for t in range(T):
         b.setTipStates(t, states[t])
     b.setEigenDecomposition(0, eig.evec, eig.ievc, eig.evals)
@@ -30,13 +30,17 @@ def same(g, o, bufs, what):
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b).max(axis=(0, 2), keepdims=True), 1e-300)) <= 1e-12, (what, x)
 
 
-def test_virtual_cherries_keep_beagle_semantics(oracle_lib, engine_lib):
+@pytest.mark.parametrize("S", [4, 20, 16])
+def test_virtual_cherries_keep_beagle_semantics(S, oracle_lib, engine_lib):
     rng = np.random.default_rng(5)
-    states = rng.integers(0, 5, size=(T, P)).astype(np.int32)           # 4 = missing
-    pi = np.array([0.3, 0.2, 0.25, 0.25])
-    eig = substmodel.gtr([1.0, 3.0, 0.7, 1.1, 4.0, 1.0], pi)
+    states = rng.integers(0, S + 1, size=(T, P)).astype(np.int32)       # S = missing
+    if S == 4:
+        pi = np.array([0.3, 0.2, 0.25, 0.25])
+        eig = substmodel.gtr([1.0, 3.0, 0.7, 1.1, 4.0, 1.0], pi)
+    else:
+        eig, pi = substmodel.random_reversible(S, rng)
     rates = [0.1, 0.5, 1.0, 2.4]
-    g, o = make(engine_lib, states, eig, rates), make(oracle_lib, states, eig, rates)
+    g, o = make(engine_lib, states, eig, rates, S), make(oracle_lib, states, eig, rates, S)
     try:
         both = (g, o)
         # 1. write-mode rescaling: cherries 4, 5 (scale buffers 0, 1), root 6 (scale 2)
@@ -51,7 +55,7 @@ def test_virtual_cherries_keep_beagle_semantics(oracle_lib, engine_lib):
             b.updatePartials(ops2, 2, NONE)
         same(g, o, [7], "parent of a read-mode virtual cherry")
         # 3. change a tip of cherry 4: buffers 4 and 7 must keep their OLD values (no op recomputed them) ...
-        new0 = rng.integers(0, 4, size=P).astype(np.int32)
+        new0 = rng.integers(0, S, size=P).astype(np.int32)
         for b in both:
             b.setTipStates(0, new0)
         same(g, o, [4, 7, 6], "after setTipStates")
@@ -82,12 +86,13 @@ def test_virtual_cherries_keep_beagle_semantics(oracle_lib, engine_lib):
         g.finalize(); o.finalize()
 
 
-def test_virtual_and_stored_cherries_agree_bitwise(engine_lib):
+@pytest.mark.parametrize("S", [4, 20])
+def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib):
     """BEAGLE_MI355_NO_VIRTUAL is read at instance creation: the same evaluation with virtual cherries on and off
     must give the same lnL to the last bit (the fused recomputation repeats the cherry op's own arithmetic)."""
     import os
     from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_ALWAYS, RESCALE_DYNAMIC
-    wl = helpers.random_workload(60, 2000, 4, 4, seed=77)
+    wl = helpers.random_workload(60, 2000, S, 4, seed=77)
     vals = {}
     for flag in ("0", "1"):
         os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
