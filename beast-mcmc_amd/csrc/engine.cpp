@@ -1311,6 +1311,9 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     if (tipCount < 0 || partialsBufferCount < 1 || compactBufferCount < 0 || stateCount < 2 || stateCount > 255 ||
         patternCount < 1 || eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
         return BEAGLE_ERROR_OUT_OF_RANGE;
+    // more than 64 states: no kernel of this engine is built for it (the MFMA path tiles up to 64, the gradient kernels
+    // accumulate 64 x 64 outputs, the general kernels stage S x S doubles in LDS) — refuse loudly instead of half-working
+    if (stateCount > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     // requirement flags this engine cannot honour
     if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CPU | BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL |

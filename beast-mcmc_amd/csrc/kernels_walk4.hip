@@ -5,40 +5,38 @@
 // what it reads was either there before the launch or written by the same thread earlier in the same launch (program
 // order makes a thread's own stores visible to its later loads).  The host (planner.cpp) turns an updatePartials list
 // into a post-order program of micro-operations; the result of a micro-operation stays in the thread's registers (ACC)
-// or in one of two LDS hold slots (a value that has to wait for its sibling's subtree), so a child that was computed by
+// or in one of three hold slots (a value that has to wait for its sibling's subtree), so a child that was computed by
 // the previous micro-operation is not read back from HBM, and a node whose subtree is a few compact tips ("virtual"
 // buffer) is never written at all.
 //
-// Mapping:  workgroup = 128 consecutive patterns x all C categories; wave w = category w; lane l owns the TWO patterns
-//           p0 + l and p0 + 64 + l, so every vector-memory instruction of a wave is dense (64 x 16 B = 1 KiB contiguous
-//           for a partials buffer [C][P][4] doubles; pairing ADJACENT patterns instead makes every access 16 B at a 64-B
-//           stride and the kernel twice as slow).  What a micro-operation costs PER WAVE whatever the lane does — ~50 scalar and
-//           branch instructions on the CU's single scalar pipe, the two matrix loads — is so shared by two patterns:
-//           measured, those per-wave costs and the address unit (~16 cycles per vector-memory instruction per CU,
-//           tools/vmem_rate_probe.hip), not HBM or the fp64 pipes, are what saturates first.
-//           All C*P/128 waves of a 1e5-pattern alignment are resident at once (3.05 waves per SIMD at C = 4; the kernel
-//           is held to 128 VGPRs = 4 waves per SIMD for that reason: a wave walks the whole list, so a second round of
-//           workgroups would double the time).
+// Two kernels execute such programs (bit-identical results, tests/test_gpu_walk_kernels.py):
+//   k_walk4_fast  the main loop as ONE block of generated gfx950 assembly (tools/gen_walk4_fast.py, walk4_fast_loop.inc; the
+//                 design notes live in that generator) — every launch whose segments start at a multiple of 128 patterns
+//                 and that does not rescale in write mode;
+//   k_walk4       the C++ kernel below: everything else (write-mode rescaling: per-pattern maximum over all categories
+//                 through LDS and a barrier; partitions at arbitrary pattern offsets).
 //
-// What bounds a wave is LATENCY: it executes ~T dependent micro-operations.  So the loop is software-pipelined by hand:
-// while micro-operation k computes, everything k+1 needs from memory is already in flight — its child partials (32 B per
-// lane), tip-state bytes, reciprocal scale factor and BOTH branch matrices.  The compiler cannot express that (its
-// s_waitcnt insertion has to assume the worst path of the kind-dependent branches and drains the queue every iteration:
-// measured 64 % of wave cycles parked, profiles/r02_*), therefore every vector-memory instruction of the loop is inline
-// assembly, and the one wait per stage is EXACT: "s_waitcnt vmcnt(N)" with N = the number of vector-memory instructions
-// issued after the loads of micro-operation k (the stores of k-1 and the loads of k+1), which the host knows when it
-// builds the program and passes in the descriptor; the kernel jumps into a table of s_waitcnt instructions.
-// Loads a micro-operation does not need are BRANCHED around, not masked: on this chip a vector-memory instruction with 8
-// or 16 bytes per lane occupies the CU's address unit for ~16 cycles whatever its EXEC mask or coalescing, a byte load
-// for ~4 (tools/vmem_rate_probe.hip) — with 24 waves per CU that unit, not HBM, is the first thing to saturate.
+// Common to both.  Workgroup = 128 consecutive patterns x all C categories; wave w = category w; a lane owns TWO patterns (here
+// p0 + l and p0 + 64 + l), so what a micro-operation costs per wave whatever the lanes do — scalar and branch instructions,
+// the matrix table — is shared by two patterns.  A wave walks its whole program in order, so the loop is software-pipelined
+// by hand: while micro-operation k computes, everything k+1 needs from memory is in flight.  The compiler cannot express
+// that (its s_waitcnt insertion assumes the worst path of the kind-dependent branches and drains the queue every
+// iteration), therefore every vector-memory instruction of the loop is inline assembly and the one wait per stage is EXACT:
+// "s_waitcnt vmcnt(N)", N = the vector-memory instructions issued after the loads of micro-operation k — the stores of k-1
+// and the loads of k+1 (loads and stores retire in issue order: tools/vmcnt_order_probe.hip) — which the host knows when it
+// builds the program and passes in the descriptor; this kernel jumps into a table of s_waitcnt instructions.  Loads a
+// micro-operation does not need are BRANCHED around, not masked: a vector-memory instruction with 8 or 16 bytes per lane
+// occupies the CU's address unit for ~16 cycles whatever its EXEC mask or coalescing (tools/vmem_rate_probe.hip).
 //
-// Branch matrices are wave-uniform (one category per wave).  A matrix lives in ONE 64-bit VGPR, lane l holding entry
-// l & 15 (one 8-byte load per lane, 128 B per wave), and the 4x4 mat-vec is 16 x v_fmac_f64_dpp row_newbcast:n (DPP64:
-// every lane multiplies by lane n of its 16-lane row) — no SGPRs, no LDS, no scalar loads, full fp64 rate
-// (tools/walk_probe.hip).  A compact tip child picks column `state` of the same register with ds_bpermute (crossbar
-// only, no LDS storage).
-// Rescaling in write mode needs the per-pattern maximum over all categories: the C waves exchange their maxima
-// through 2 x C x 64 doubles of LDS and one barrier (double-buffered); read mode multiplies by the stored reciprocal.
+// Branch matrices are wave-uniform (one category per wave).  k_gatherMatrices lays the two matrices of every
+// micro-operation out as a 320-byte table (5 columns x 4 doubles each, column 4 = ones for a missing state) in program
+// order; the fetch stage copies the next table into wave-private LDS with ONE LDS-DMA instruction (lanes 0..19, no
+// registers: tools/glds_probe.hip).  A compact tip child's contribution is column `state` of the table (two
+// ds_read_b128, no select); an internal child's 4x4 mat-vec is 16 x v_fmac_f64_dpp row_newbcast:n on the matrix spread
+// over the lanes of ONE 64-bit VGPR (DPP64: every lane multiplies by lane n of its 16-lane row) — no SGPRs, no LDS
+// operands, full fp64 rate (tools/walk_probe.hip).
+// Tip states and reciprocal scale factors are stored pair-interleaved (kernels.h walkPairIndex) so that the assembly
+// loop gets a lane's pair with one load; this kernel's lanes own other pairs and address the same layout per pattern.
 //
 // Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
 // GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.

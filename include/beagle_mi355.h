@@ -144,7 +144,8 @@ BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(int tipCount, in
                                       long benchmarkFlags);
 
 /* createInstance (IIIIIIIII[IIJJLbeagle/InstanceDetails;)I
- * callers: BeagleTreeLikelihood.java:420-433, BeagleDataLikelihoodDelegate.java:439-452 */
+ * callers: BeagleTreeLikelihood.java:420-433, BeagleDataLikelihoodDelegate.java:439-452
+ * 2..64 states; more returns BEAGLE_ERROR_NO_IMPLEMENTATION (no kernel of this engine is built for it). */
 int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount,
                          int stateCount, int patternCount, int eigenBufferCount,
                          int matrixBufferCount, int categoryCount, int scaleBufferCount,
