@@ -47,7 +47,7 @@ def build_engine(force=False):
     os.makedirs(obj_dir, exist_ok=True)
     out = os.path.join(LIB, "libhmsbeagle-jni.so")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "beagle_mi355.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DBEAGLE_MI355_BUILD", "-Wall",
              "-Wno-unused-result", "-Wno-unused-value", "-Wno-cuda-compat"]

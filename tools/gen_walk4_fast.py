@@ -47,6 +47,8 @@ B_X, B_T1, B_T2, B_STORE, B_HSLOT1 = 0, 1, 2, 4, 12
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
 
 STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
+# TIMING EXPERIMENTS ONLY (wrong results; tools/walk_floor.sh, profiles/r02_experiments.txt): comma-separated parts to leave out
+EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if x)
 lines = []
 
 
@@ -71,7 +73,7 @@ def matvec(dst, x):
     sequence is y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0))))."""
     for i in range(8):
         e("v_mov_b64 %s, 0" % v(dst + 2 * i, 2))
-    for j in range(4):
+    for j in range(0 if "nofma" in EXPERIMENT else 4):
         for half in range(2):
             for i in range(4):
                 e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
@@ -83,6 +85,8 @@ def tip_columns(dst, t, tbl, off):
     e("v_lshrrev_b32 %s, 8, %s" % (v(T1), v(t)))
     e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T0), v(T0), s(tbl)))
     e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T1), v(T1), s(tbl)))
+    if "notipread" in EXPERIMENT:
+        return
     e("ds_read_b128 %s, %s offset:%d" % (v(dst, 4), v(T0), off))
     e("ds_read_b128 %s, %s offset:%d" % (v(dst + 4, 4), v(T0), off + 16))
     e("ds_read_b128 %s, %s offset:%d" % (v(dst + 8, 4), v(T1), off))
@@ -108,13 +112,20 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
         blk.append("ds_read_b128 %s, %s offset:%d" % (v(X + 4 * q, 4), v(T0), 1024 * q))
     blk.append("s_branch %s" % L("hrb" + tag))
     outofline.append(blk)
-    e("s_mov_b32 m0, %s" % s(tblDst))
-    e("s_mov_b64 exec, 0xfffff")
-    e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
-    e("s_mov_b64 exec, -1")
+    # (an experiment that drops a load replaces it by a cheap one to the same register so that the waits still balance)
+    if "nodma" in EXPERIMENT:
+        e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
+    else:
+        e("s_mov_b32 m0, %s" % s(tblDst))
+        e("s_mov_b64 exec, 0xfffff")
+        e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
+        e("s_mov_b64 exec, -1")
     e("global_load_ushort %s, %s, %s" % (v(Tt1), v(TIP), s(D, 2)))
     e("global_load_ushort %s, %s, %s" % (v(Tt2), v(TIP), s(D + 2, 2)))
-    e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
+    if "noinv" in EXPERIMENT:
+        e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
+    else:
+        e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
     e("s_add_u32 %s, %s, %s" % (s(STRM), s(STRM), s(STEP)))
     e("s_addc_u32 %s, %s, 0" % (s(STRM + 1), s(STRM + 1)))
     e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
