@@ -1354,12 +1354,13 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->cherry = in->tiled && stateCount <= 20 && !noVirtual;
     const bool virtualOn = (in->walk && !noVirtual) || in->cherry;
     in->virt = virtualOn;
-    // Size of a virtual definition (internal nodes).  Evaluations at alignment sizes that keep the chip busy are bound by
-    // the bytes of the STORED nodes, and their time follows the cap (config A, profiles/r02_experiments.txt: cap 6 -> 247
-    // stored nodes, 0.98 ms; 8 -> 203, 0.90; 16 -> 155, 0.79) while a branch move — which re-evaluates the virtual siblings
-    // it passes instead of reading 32 C P bytes each — costs the same (123 us).  Small alignments are latency-bound: there
-    // the extra micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us at cap 16).
-    int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 16 : 8;
+    // Size of a virtual definition (internal nodes; any subtree shape whose evaluation needs at most two hold slots).
+    // Evaluations at alignment sizes that keep the chip busy are bound by the bytes of the STORED nodes and their time
+    // follows the cap (config A, profiles/r02_experiments.txt: cap 8 -> 207 stored nodes; 16 -> 112, 0.70 ms; 24 -> 78,
+    // 0.64 ms; 32 -> 62, 0.63 ms) while a branch move — which re-evaluates the virtual siblings it passes instead of reading
+    // 32 C P bytes each — costs 139 / 141 / 162 us at 16 / 24 / 32.  Small alignments are latency-bound: there the extra
+    // micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us from cap 8 to 16).
+    int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 24 : 8;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn,

@@ -53,50 +53,59 @@ void WalkPlanner::registerVirtual(int X) {
 }
 
 // Try to define buffer X = node(child1 over matrix m1, child2 over matrix m2, scale).  Children are compact tips or
-// virtual buffers.  Appends (source, destination) matrix-copy pairs.  false: not expressible with one hold slot.
+// virtual buffers.  Appends (source, destination) matrix-copy pairs.  false: too many steps, or its evaluation would need
+// more hold slots than a definition may take.
 bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
     VirtDef nv;
     nv.on = true; nv.stamp = stamp_; nv.nSteps = 0; nv.chainOnly = true;
     std::vector<int> pairs;
-    auto append = [&](int srcBuf) -> bool {
+    const int maxNeed = popcount2(allSlots_) - 1;
+    // copies the steps of srcBuf's definition behind what nv holds; returns the index of its last step, -1: no room
+    auto append = [&](int srcBuf) -> int {
         const VirtDef& src = virt_[srcBuf];
+        const int base = nv.nSteps;
         for (int s = 0; s < src.nSteps; s++) {
-            if (nv.nSteps >= maxSteps_) return false;
+            if (nv.nSteps >= maxSteps_) return -1;
             VirtStep h = src.steps[s];
             // a child defined in THIS list has its slots written by the same snapshot launch: copy from its origins
             const int fromA = src.stamp == stamp_ ? h.originA : snapSlot(srcBuf, s, 0);
             const int fromB = src.stamp == stamp_ ? h.originB : snapSlot(srcBuf, s, 1);
             h.originA = fromA; h.originB = fromB;
+            if (h.subA >= 0) h.subA += base;
+            if (h.subB >= 0) h.subB += base;
             pairs.push_back(fromA); pairs.push_back(snapSlot(X, nv.nSteps, 0));
             pairs.push_back(fromB); pairs.push_back(snapSlot(X, nv.nSteps, 1));
             nv.steps[nv.nSteps++] = h;
         }
-        return true;
+        return nv.nSteps - 1;
     };
     VirtStep last;
-    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.split = 0;
+    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.subA = -1; last.subB = -1; last.need = 0;
     if (tip1 && tip2) {
         last.type = VT_CHERRY; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
     } else if (tip1 != tip2) {
-        const int v = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
-        if (!virt_[v].on || !append(v)) return false;
-        nv.chainOnly = virt_[v].chainOnly;
-        last.type = VT_EXTEND; last.tipB = t; last.originA = mv; last.originB = mt;
+        const int vb = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
+        if (!virt_[vb].on) return false;
+        const int r = append(vb);
+        if (r < 0) return false;
+        last.type = VT_EXTEND; last.subA = r; last.tipB = t; last.originA = mv; last.originB = mt;
+        last.need = nv.steps[r].need;
     } else {
-        int u = c1, v = c2, mu = m1, mv = m2;
-        if (!virt_[u].on || !virt_[v].on) return false;
-        if (!virt_[v].chainOnly) { std::swap(u, v); std::swap(mu, mv); }
-        if (!virt_[v].chainOnly) return false;                 // the second operand would need a hold slot of its own
-        if (!append(u)) return false;
-        last.split = nv.nSteps;
-        if (!append(v)) return false;
-        nv.chainOnly = false;
-        last.type = VT_JOIN; last.originA = mu; last.originB = mv;
+        if (!virt_[c1].on || !virt_[c2].on) return false;
+        const int ra = append(c1);
+        if (ra < 0) return false;
+        const int rb = append(c2);
+        if (rb < 0) return false;
+        last.type = VT_JOIN; last.subA = ra; last.subB = rb; last.originA = m1; last.originB = m2;
+        const int na = nv.steps[ra].need, nb = nv.steps[rb].need;
+        last.need = std::min(std::max(na, 1 + nb), std::max(nb, 1 + na));
+        if (last.need > maxNeed) return false;
     }
     if (nv.nSteps >= maxSteps_) return false;
     pairs.push_back(last.originA); pairs.push_back(snapSlot(X, nv.nSteps, 0));
     pairs.push_back(last.originB); pairs.push_back(snapSlot(X, nv.nSteps, 1));
     nv.steps[nv.nSteps++] = last;
+    nv.chainOnly = last.need == 0;
     virt_[X] = nv;
     registerVirtual(X);
     snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
@@ -163,26 +172,30 @@ inline void setLeaf(MicroOp& m, int which, const Child& c) {
 }
 }  // namespace
 
-void WalkPlanner::emitVirtualSteps(int buf, int lo, int hi, unsigned freeMask, bool writeMode, Plan& out) {
+void WalkPlanner::emitVirtualStep(int buf, int idx, unsigned freeMask, bool writeMode, Plan& out) {
     const VirtDef& v = virt_[buf];
-    const int idx = hi - 1;
     const VirtStep& st = v.steps[idx];
     MicroOp m = blankOp();
     if (st.type == VT_CHERRY) {
         m.k1 = PK_TIPS; m.a1 = st.tipA; m.mat1 = snapSlot(buf, idx, 0);
         m.k2 = PK_TIPS; m.a2 = st.tipB; m.mat2 = snapSlot(buf, idx, 1);
     } else if (st.type == VT_EXTEND) {
-        emitVirtualSteps(buf, lo, hi - 1, freeMask, writeMode, out);
+        emitVirtualStep(buf, st.subA, freeMask, writeMode, out);
         m.k1 = PK_TIPS; m.a1 = st.tipB; m.mat1 = snapSlot(buf, idx, 1);
         m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, 0);
-    } else {   // VT_JOIN: first operand = steps [0, split), then the JOIN-free second chain [split, idx)
-        emitVirtualSteps(buf, lo, st.split, freeMask, writeMode, out);
+    } else {   // VT_JOIN: the operand that needs more hold slots first, parked while the other one is evaluated
+        const int F = popcount2(freeMask);
+        const int na = v.steps[st.subA].need, nb = v.steps[st.subB].need;
+        const bool aOK = na <= F && 1 + nb <= F, bOK = nb <= F && 1 + na <= F;
+        const bool aFirst = aOK && (!bOK || na >= nb);            // (one of them holds: need <= F by construction)
+        const int first = aFirst ? st.subA : st.subB, second = aFirst ? st.subB : st.subA;
+        emitVirtualStep(buf, first, freeMask, writeMode, out);
         const int h = lowestSlot(freeMask);
         out.prog.back().hold = h + 1;
         lastHolds++;
-        emitVirtualSteps(buf, st.split, idx, freeMask & ~(1u << h), writeMode, out);
-        m.k1 = PK_H0 + h; m.mat1 = snapSlot(buf, idx, 0);
-        m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, 1);
+        emitVirtualStep(buf, second, freeMask & ~(1u << h), writeMode, out);
+        m.k1 = PK_H0 + h; m.mat1 = snapSlot(buf, idx, aFirst ? 0 : 1);
+        m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, aFirst ? 1 : 0);
     }
     if (st.scaleIdx >= 0) {
         m.scaleIdx = st.scaleIdx;
@@ -194,7 +207,7 @@ void WalkPlanner::emitVirtualSteps(int buf, int lo, int hi, unsigned freeMask, b
 }
 
 void WalkPlanner::emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out) {
-    emitVirtualSteps(buf, 0, virt_[buf].nSteps, freeMask, writeMode, out);
+    emitVirtualStep(buf, virt_[buf].nSteps - 1, freeMask, writeMode, out);
 }
 
 void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {

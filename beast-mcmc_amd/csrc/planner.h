@@ -19,7 +19,7 @@
 
 namespace mi355 {
 
-constexpr int PLAN_MAX_STEPS = 16;       // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
+constexpr int PLAN_MAX_STEPS = 32;       // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
 constexpr int PLAN_NONE = -1;
 
 // kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine.cpp)
@@ -46,19 +46,23 @@ struct Plan {
     void clear() { prog.clear(); segs.clear(); snapPairs.clear(); }
 };
 
-// Definition of a virtual buffer: one step per internal node of a small all-compact-tip subtree, in evaluation order,
-// evaluable with the accumulator and ONE hold slot (the "A operand" first, then a JOIN-free "B chain").
+// Definition of a virtual buffer: one step per internal node of a small all-compact-tip subtree, in post-order (a step's
+// sub-steps precede it; the last step is the buffer's own node).  An operand of a step is a compact tip or an earlier
+// step; `need` = hold slots its evaluation takes (Sethi-Ullman: two internal operands -> the costlier one first, parked
+// in a hold slot while the other one is evaluated), at most one less than the walk has, so that a parent can still park
+// the definition's own result.
 enum { VT_CHERRY = 1, VT_EXTEND = 2, VT_JOIN = 3 };
 struct VirtStep {
-    int type;               // VT_*
-    int tipA, tipB;         // CHERRY: both tips; EXTEND: tipB
+    int type;               // VT_CHERRY: tipA, tipB;  VT_EXTEND: subA, tipB;  VT_JOIN: subA, subB
+    int tipA, tipB;         // tip buffers (or -1)
+    int subA, subB;         // earlier steps of the same definition (or -1)
     int scaleIdx;           // this node's scale buffer, or PLAN_NONE
-    int originA, originB;   // matrix slots the snapshots were last copied FROM
-    int split;              // JOIN: number of leading steps of the program that form its first operand
+    int originA, originB;   // matrix slots the snapshots of operand A's / B's branch were last copied FROM
+    int need;               // hold slots the evaluation of this step takes
 };
 struct VirtDef {
     bool on = false;
-    bool chainOnly = true;  // no JOIN: evaluates without a hold slot
+    bool chainOnly = true;  // evaluates without a hold slot (need of the last step == 0)
     int nSteps = 0;
     int stamp = -1;         // planner stamp of the list that created or last re-confirmed it
     VirtStep steps[PLAN_MAX_STEPS];
@@ -130,9 +134,9 @@ private:
     void registerVirtual(int X);
     // emission
     void emitReal(int j, unsigned freeMask, Plan& out, int depth);
-    void emitVirtualSteps(int buf, int lo, int hi, unsigned freeMask, bool writeMode, Plan& out);
+    void emitVirtualStep(int buf, int idx, unsigned freeMask, bool writeMode, Plan& out);
     void emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out);
-    int virtNeed(int buf) const { return virt_[buf].chainOnly ? 0 : 1; }
+    int virtNeed(int buf) const { return virt_[buf].nSteps ? virt_[buf].steps[virt_[buf].nSteps - 1].need : 0; }
 
     int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6;
     bool enabled_ = false;

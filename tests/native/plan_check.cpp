@@ -139,7 +139,7 @@ struct Harness {
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
-        { static const int caps[4] = {6, 8, 12, 16}; pl.init(nBuf, T, nMat, nScale, caps[seed % 4], virt, 2 + (seed / 4) % 2); }    // the engine's: 8 or 16
+        { static const int caps[6] = {6, 8, 12, 16, 24, 32}; pl.init(nBuf, T, nMat, nScale, caps[seed % 6], virt, 2 + (seed / 6) % 2); }    // the engine's: 8 or 16
         const int slots = pl.matrixSlots();
         for (World* w : {&truth, &plan}) {
             w->partials.assign(nBuf, {}); w->tips.assign(nBuf, {}); w->mats.assign(slots, std::vector<double>((size_t)C * 16, 0.0));
