@@ -23,6 +23,31 @@ def test_planner_programs_equal_list_order_evaluation(tmp_path):
 
 def test_walk_kernel_isa_keeps_in_flight_registers_untouched():
     """tools/check_walk_isa.py: the hand-pipelined kernel's in-flight load destinations are not read or written before
-    their s_waitcnt, no scratch, <= 72 VGPRs (cross-compiles gfx950 on the CPU box)."""
+    their s_waitcnt, no scratch, <= 128 VGPRs (cross-compiles gfx950 on the CPU box)."""
     out = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_walk_isa.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_generated_assembly_loop_is_up_to_date_and_balanced():
+    """csrc/walk4_fast_loop.inc is what tools/gen_walk4_fast.py emits now, and the stream is structurally sound: every
+    out-of-line block returns, every label that is branched to exists exactly once, the fetch stage issues the four small
+    loads the host's wait codes assume (kernels.h WF_WAIT8 / WF_WAIT12), and nothing above v121 / s73 is named."""
+    import re
+    env = dict(os.environ, WALK4_CHECK_ONLY="1")
+    env.pop("WALK4_EXPERIMENT", None)
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_walk4_fast.py")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, "walk4_fast_loop.inc is stale: run python tools/gen_walk4_fast.py"
+    text = open(os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")).read()
+    lines = re.findall(r'^\s+"(.*?)\\n(?:\\t)?" \\$', text, flags=re.M)
+    labels = [l[:-1] for l in lines if l.endswith(":")]
+    assert len(labels) == len(set(labels))
+    targets = set(re.findall(r"s_c?branch\w* (\.LW4\w+_%=)", "\n".join(lines)))
+    assert targets <= set(labels), targets - set(labels)
+    # per stage: one LDS-DMA, two tip-pair loads, one reciprocal-pair load (prologue + two stages = 3 of each group)
+    assert sum("global_load_lds_dwordx4" in l for l in lines) == 3
+    assert sum(l.startswith("global_load_ushort") for l in lines) == 6
+    regs = [int(x) for x in re.findall(r"\bv\[?(\d+)", "\n".join(lines))]
+    assert max(regs) <= 121
+    sregs = [int(x) for x in re.findall(r"\bs\[?(\d+)", "\n".join(lines))]
+    assert max(sregs) <= 73 and not set(sregs) & {32, 33, 34, 35}
+    assert lines[-1].startswith("s_waitcnt vmcnt(0)")
