@@ -20,6 +20,7 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
     maxSteps_ = std::max(1, std::min(maxVirtSteps, PLAN_MAX_STEPS));
     enabled_ = virtualEnabled;
     virt_.assign(partialsCount, VirtDef());
+    tagOf_.assign(partialsCount, -1);
     tipUsers_.assign(partialsCount, std::vector<int>());
     scaleUsers_.assign(scaleCount_, std::vector<int>());
     compactTip.assign(partialsCount, 0);
@@ -39,6 +40,7 @@ void WalkPlanner::clearVirtual(int X) {
         if (h.scaleIdx >= 0) drop(scaleUsers_[h.scaleIdx]);
     }
     v.on = false;
+    tagOf_[X] = -1;
 }
 
 void WalkPlanner::registerVirtual(int X) {
@@ -107,6 +109,7 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool ti
     nv.steps[nv.nSteps++] = last;
     nv.chainOnly = last.need == 0;
     virt_[X] = nv;
+    tagOf_[X] = 0;
     registerVirtual(X);
     snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
     return true;
@@ -377,7 +380,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 VirtDef saved = ev;
                 if (saved.on) clearVirtual(o.dest);
                 makeVirtual = buildVirtual(o.dest, o.c1, o.tip1, o.m1, o.c2, o.tip2, o.m2, ownScale, out.snapPairs);
-                if (!makeVirtual && saved.on) { virt_[o.dest] = saved; registerVirtual(o.dest); }
+                if (!makeVirtual && saved.on) { virt_[o.dest] = saved; tagOf_[o.dest] = saved.cacheTag; registerVirtual(o.dest); }
                 if (makeVirtual) {
                     VirtDef& nv = virt_[o.dest];
                     nv.version = ++virtVersion_;
@@ -501,7 +504,9 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     if (fill) {
         fill->plan = out;
         fill->defs.assign(count, VirtDef());
-        for (int k = 0; k < count; k++) if (info_[k].virtDest) { virt_[info_[k].dest].cacheTag = fill->tag; fill->defs[k] = virt_[info_[k].dest]; }
+        fill->defOn.assign(count, 0);
+        for (int k = 0; k < count; k++)
+            if (info_[k].virtDest) { virt_[info_[k].dest].cacheTag = fill->tag; tagOf_[info_[k].dest] = fill->tag; fill->defs[k] = virt_[info_[k].dest]; fill->defOn[k] = 1; }
         plannedTag = fill->tag;
         fill->stored = lastStored; fill->memReads = lastMemReads; fill->holds = lastHolds; fill->waves = lastWaves;
         fill->valid = true;
@@ -515,12 +520,13 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
 void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
     for (int k = 0; k < e.count; k++) {
         const int dest = ops[(size_t)k * e.tuple];
+        if (e.defOn[k] ? tagOf_[dest] == e.tag : tagOf_[dest] < 0) continue;        // already what the entry leaves behind
         const VirtDef& want = e.defs[k];
         VirtDef& cur = virt_[dest];
-        if (!want.on) { if (cur.on) clearVirtual(dest); continue; }
-        if (cur.on && cur.cacheTag == e.tag) { cur.stamp = stamp_; continue; }
         if (cur.on) clearVirtual(dest);
+        if (!want.on) continue;
         cur = want;                                               // (tagged with e.tag when the entry was filled)
+        tagOf_[dest] = e.tag;
         cur.stamp = stamp_;
         cur.version = ++virtVersion_;
         cur.childVer1 = cur.sigTip1 ? -1 : virt_[cur.sigC1].version;

@@ -141,6 +141,8 @@ private:
     int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6;
     bool enabled_ = false;
     std::vector<VirtDef> virt_;
+    std::vector<long> tagOf_;                          // per buffer: -1 not virtual, 0 virtual, > 0 virtual and written by that cache entry
+                                                       // (a compact mirror of on / cacheTag: replaying a plan touches 8 bytes per op)
     std::vector<std::vector<int>> tipUsers_, scaleUsers_;
     int virtVersion_ = 0;
     int stamp_ = 0;
@@ -167,6 +169,7 @@ private:
         std::vector<char> tips;                        // compact flags of (child1, child2) per op
         Plan plan;
         std::vector<VirtDef> defs;                     // per op: the definition its destination ends up with (on = false: real)
+        std::vector<char> defOn;                       // defs[k].on
         int stored = 0, memReads = 0, holds = 0, waves = 0;
     };
     static constexpr int CACHE_WAYS = 4;
