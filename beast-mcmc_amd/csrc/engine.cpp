@@ -64,13 +64,14 @@ struct Instance {
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
         int maxRange = 0; bool paired = true;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
+        char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
     bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
     bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
     long statCherries = 0;
-    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0; long hostCalls = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
+    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
     double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
@@ -225,13 +226,15 @@ int ensureStates(Instance* in, int idx) {
 void destroy(Instance* in) {
     hipSetDevice(in->device);
     if (in->hostCalls && getenv("BEAGLE_MI355_HOST_TIMING"))
-        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us; %ld plans from the cache\n",
-                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls, in->planner.cacheHits);
+        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us; %ld plans from the cache: planner %.1f us, resolve+upload+launch %.1f us\n",
+                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls, in->planner.cacheHits,
+                in->hostHits ? in->hostPlanHitUs / in->hostHits : 0.0, in->hostHits ? in->hostRunHitUs / in->hostHits : 0.0);
     if (in->ownStream) hipStreamSynchronize(in->ownStream);
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
     if (in->bigStage) hipFree(in->bigStage);
     if (in->matStream) hipFree(in->matStream);
+    for (auto& r : in->resolved) if (r.dProg) hipFree(r.dProg);
     if (in->exportDev) hipFree(in->exportDev);
     if (in->exportHost) hipHostFree(in->exportHost);
     if (in->hRing) hipHostFree(in->hRing);
@@ -362,7 +365,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
     } else {
     const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
-    if (slot) slot->tag = 0;
+    if (slot) { slot->tag = 0; slot->dProgValid = false; }
     w.clear();
     w.reserve(n + 3 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
@@ -439,13 +442,24 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
     const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
     char* dBase = nullptr;
-    if (total <= RING_BYTES / 4) {
+    if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
+    else if (total <= RING_BYTES / 4) {
         const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
         if (off < 0) return BEAGLE_ERROR_GENERAL;
         memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
         if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
         HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
         dBase = in->dRing + off;
+        if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
+            if (slot->dProgBytes < total) {
+                if (slot->dProg) { HIP_TRY(hipStreamSynchronize(in->stream)); hipFree(slot->dProg); }
+                slot->dProg = nullptr; slot->dProgBytes = 0;
+                HIP_TRY(hipMalloc((void**)&slot->dProg, total + total / 4));
+                slot->dProgBytes = total + total / 4;
+            }
+            HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, in->stream));
+            slot->dProgValid = true;
+        }
     } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->bigStageBytes < total) {
@@ -582,16 +596,19 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         in->planner.mustMaterializeBefore(sub, n, tuple, need);
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
         in->hostPrepUs += usSince(t1); t1 = Clock::now();
+        const long hitsBefore = in->planner.cacheHits;
         int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
-        in->hostPlanUs += usSince(t1); t1 = Clock::now();
+        const bool hit = in->planner.cacheHits != hitsBefore;
+        { const double us = usSince(t1); in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
+        t1 = Clock::now();
         // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
         // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
         if (!in->planner.planned->prog.empty()) {
             rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, launches == 0 ? e0 : nullptr); if (rc) return rc;
             launches++;
         } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
-        in->hostRunUs += usSince(t1);
+        { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us; }
         begin += n;
     }
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
