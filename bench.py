@@ -146,6 +146,15 @@ def main():
                            ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC)
     if dist is not None:
         dist.destroy_process_group()
+    # ONE JSON line, and it is the LAST thing on stdout: libraries that print through C stdio (RCCL's version banner on the
+    # multi-GPU path) are flushed first, so nothing of theirs can follow the line when the process exits
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                       # noqa: BLE001
+        pass
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
     return out
 
 
@@ -325,7 +334,6 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "evaluations_total": int(local.counters()["evaluations"]),
             "kernel_source_hash": kernel_source_hash(), "workload_generation_s": round(t_gen, 1),
         }
-        print(json.dumps(out), flush=True)
     tl.close()
     return out
 
@@ -387,7 +395,6 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
             "cpu_baseline": cpu, "lnL": lnl, "lnL_first_eval": lnl0, "kernel_source_hash": kernel_source_hash(),
             "evaluations_total": tl.evaluations, "workload_generation_s": round(t_gen, 1),
         }
-        print(json.dumps(out), flush=True)
     tl.close()
     return out
 
