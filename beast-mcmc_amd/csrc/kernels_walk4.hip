@@ -145,19 +145,21 @@ __device__ __forceinline__ void fetchWait(Fetched& f, unsigned jump) {
         : [jump] "s"(jump) : "memory", "scc", "s80", "s81");
 }
 // the stores of one micro-operation (maskA / maskB = the lanes whose first / second pattern really stores; nothing is
-// issued when the micro-operation has no destination).  Non-temporal: the line is written once and, if at all, read
-// back by this very thread (+7 % on the headline configuration).
+// issued when the micro-operation has no destination).  Default cache policy: these are HALF-LINE stores (16 bytes at a
+// 32-byte stride, twice), which the non-temporal hint makes slower (tools/hbm_write_probe.hip: 2.0 against 4.9 TB/s;
+// config E, which runs entirely on this kernel: 179 -> 145 us; tools/generic_store_policy.sh).  The assembly loop's stores
+// are full lines and keep the hint (12 500 patterns: 121 against 144 us, tools/fast_store_policy.sh).
 __device__ __forceinline__ void storeIssue(const v4d ra, const v4d rb, unsigned flags, u64 maskA, u64 maskB, unsigned oPartA, unsigned oPartB, u64 base) {
     const v2d a0 = v2d{ra.x, ra.y}, a1 = v2d{ra.z, ra.w}, b0 = v2d{rb.x, rb.y}, b1 = v2d{rb.z, rb.w};
     asm volatile(
         "s_bitcmp1_b32 %[fl], 4\n\t"
         "s_cbranch_scc0 .Lst%=\n\t"
         "s_mov_b64 exec, %[ma]\n\t"
-        "global_store_dwordx4 %[oPA], %[a0], %[base] nt\n\t"
-        "global_store_dwordx4 %[oPA], %[a1], %[base] offset:16 nt\n\t"
+        "global_store_dwordx4 %[oPA], %[a0], %[base]\n\t"
+        "global_store_dwordx4 %[oPA], %[a1], %[base] offset:16\n\t"
         "s_mov_b64 exec, %[mb]\n\t"
-        "global_store_dwordx4 %[oPB], %[b0], %[base] nt\n\t"
-        "global_store_dwordx4 %[oPB], %[b1], %[base] offset:16 nt\n\t"
+        "global_store_dwordx4 %[oPB], %[b0], %[base]\n\t"
+        "global_store_dwordx4 %[oPB], %[b1], %[base] offset:16\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_nop 0\n"
         ".Lst%=:"
