@@ -295,7 +295,10 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": int(prof["bytes_per_eval"]) if prof else None, "traffic_source": prof_note,
             "traffic_frac_of_peak": round(prof["bytes_per_eval"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if prof and kernel_s > 0 else None,
-            "bytes_per_eval": int(moved), "bytes_basis": "engine counters: stored + re-read partials, tip, scale vectors" if walk else "algorithmic (every node stored and re-read)",
+            "bytes_per_eval": int(moved), "bytes_basis": "engine counters: stored + re-read partials, tip, scale vectors" if stats["micro_ops"] > 0 else "algorithmic (every node stored and re-read)",
+            # context for `frac`: what a plain grid-strided copy kernel sustains on this chip (tools/hbm_write_probe.hip,
+            # profiles/r02_probes.txt: 2 x 2.6 TB/s; the guide's best float4 copy: 6.3 TB/s)
+            "copy_rate_GBs_measured": 5200.0,
             "algorithmic_bytes_per_eval": int(alg), "effective_GBs": round(alg / kernel_s / 1e9, 1) if kernel_s > 0 else None,
             "kernel_us_per_eval": round(kernel_s * 1e6, 2), "launches_per_eval": round(launches_per_eval, 2),
             "kernel_time_fraction_of_step": round(kernel_s * evals_per_s, 4),
