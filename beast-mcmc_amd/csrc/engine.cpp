@@ -220,6 +220,7 @@ int ensureStates(Instance* in, int idx) {
     }
     in->tipStates[idx] = (uint8_t*)in->stateSlabCur;
     in->stateSlabCur += bytes; in->stateSlabLeft--;
+    in->resolveEpoch++;                       // a kept device program may still point at the slot this tip had before (Instance::Resolved)
     return 0;
 }
 
@@ -381,7 +382,14 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         const mi355::PlanSeg& ps = plan.segs[si];
         segs[si].progStart = (int)w.size();
         for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
-            const mi355::MicroOp& m = plan.prog[i];
+            mi355::MicroOp m = plan.prog[i];
+            // The kernels request a first child's partials one stage early — before the previous micro-operation's store
+            // is issued (kernels_walk4.hip WALK_STAGE).  The planner never emits that sequence (tests/native/plan_check.cpp
+            // checks every program for it); should one arrive anyway, a no-op in between restores the distance.
+            if (i > ps.progStart && m.k1 == mi355::PK_MEM && plan.prog[i - 1].storeBuf == m.a1) {
+                if (m.k2 == mi355::PK_ACC) { m.k2 = mi355::PK_MEM; m.a2 = m.a1; }      // the no-op overwrites ACC; the value is in memory as well
+                w.push_back(nop);
+            }
             mi355::WalkOp d;
             memset(&d, 0, sizeof(d));
             d.src1 = in->dummyTips; d.src2 = in->dummyTips; d.scale = in->onesScale;     // unused operands stay readable (kernels.h launchWalk4Fast)
@@ -1849,6 +1857,7 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
         // a per-node (raw) buffer is being recycled as a cumulative one: clear all of it first
         mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     }
+    if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;    // kept programs were validated against the raw flags
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
     mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, in->partStart[partitionIndex], in->partEnd[partitionIndex]);
     HIP_TRY(hipGetLastError());
@@ -1860,6 +1869,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
+    if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
     mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     HIP_TRY(hipGetLastError());
@@ -1875,6 +1885,7 @@ int beagleCopyScaleFactors(int instance, int dest, int src) {
     rc = ensureScale(in, src); if (rc) return rc;
     const size_t scaleDoubles = in->walk ? 2 * in->scaleStride : (size_t)in->P;      // walk instances: factors and reciprocals
     HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], scaleDoubles * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+    if (in->scaleIsRaw[dest] != in->scaleIsRaw[src]) in->resolveEpoch++;
     in->scaleIsRaw[dest] = in->scaleIsRaw[src];
     return BEAGLE_SUCCESS;
 }

@@ -8,7 +8,6 @@ namespace mi355 {
 
 namespace {
 constexpr int OP_NONE = -1;                 // BEAGLE_OP_NONE
-constexpr int MAX_RECURSION = 4000;         // deeper dependency chains (caterpillar trees of >4000 taxa) are emitted flat
 enum { CL_TIPS = 0, CL_MEM = 1, CL_VIRT = 2, CL_REAL = 3 };
 inline int popcount2(unsigned m) { return (int)(m & 1u) + (int)((m >> 1) & 1u) + (int)((m >> 2) & 1u); }      // free hold slots (up to 3)
 inline int lowestSlot(unsigned m) { return (m & 1u) ? 0 : (m & 2u) ? 1 : 2; }
@@ -213,79 +212,102 @@ void WalkPlanner::emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& 
     emitVirtualStep(buf, virt_[buf].nSteps - 1, freeMask, writeMode, out);
 }
 
-void WalkPlanner::emitReal(int j, unsigned freeMask, Plan& out, int depth) {
-    OpInfo& o = info_[j];
-    Child ch[2];
-    for (int w = 0; w < 2; w++) {
-        Child& c = ch[w];
-        c.buf = w ? o.c2 : o.c1; c.mat = w ? o.m2 : o.m1;
-        const bool tip = w ? o.tip2 : o.tip1;
-        c.prod = -1; c.need = 0; c.size = 0;
-        if (tip) { c.cls = CL_TIPS; continue; }
-        const int prod = w ? prod2_[j] : prod1_[j];
-        if (prod >= 0) {
-            const OpInfo& p = info_[prod];
-            if (p.virtDest) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); c.size = 0; }
-            else if (p.emitted || flat_) c.cls = CL_MEM;
-            else { c.cls = CL_REAL; c.prod = prod; c.need = p.need; c.size = p.size; }
-        } else if (virt_[c.buf].on) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); }
-        else c.cls = CL_MEM;
-    }
-    auto emitChild = [&](const Child& c, unsigned fm) {
-        if (c.cls == CL_VIRT) emitVirtual(c.buf, fm, true, out);
-        else emitReal(c.prod, fm, out, depth + 1);
-    };
-    const bool e0 = ch[0].cls >= CL_VIRT, e1 = ch[1].cls >= CL_VIRT;
-    MicroOp m = blankOp();
-    if (!e0 && !e1) {
-        const int firstLeaf = (ch[0].cls == CL_TIPS && ch[1].cls == CL_MEM) ? 1 : 0;      // a child in memory goes first
-        setLeaf(m, 0, ch[firstLeaf]); setLeaf(m, 1, ch[1 - firstLeaf]);
-        if (ch[0].cls == CL_MEM) lastMemReads++;
-        if (ch[1].cls == CL_MEM) lastMemReads++;
-    } else if (e0 != e1) {
-        const Child& e = e0 ? ch[0] : ch[1];
-        const Child& l = e0 ? ch[1] : ch[0];
-        emitChild(e, freeMask);
-        setLeaf(m, 0, l);
-        if (l.cls == CL_MEM) lastMemReads++;
-        m.k2 = PK_ACC; m.mat2 = e.mat;
-    } else {
-        const int F = popcount2(freeMask);
-        auto holdOK = [&](const Child& a, const Child& b) { return a.need <= F && 1 + b.need <= F; };
-        auto plainOK = [&](const Child& a, const Child& b) { return a.cls == CL_REAL && a.need <= F && b.need <= F; };
-        int first = -1; bool hold = false;
-        const bool h01 = holdOK(ch[0], ch[1]), h10 = holdOK(ch[1], ch[0]);
-        if (h01 || h10) {
-            hold = true;
-            if (h01 && h10) first = (ch[1].need > ch[0].need || (ch[1].need == ch[0].need && ch[1].size > ch[0].size)) ? 1 : 0;
-            else first = h01 ? 0 : 1;
-        } else {
-            const bool p01 = plainOK(ch[0], ch[1]), p10 = plainOK(ch[1], ch[0]);
-            if (p01 && p10) first = ch[1].size > ch[0].size ? 1 : 0;
-            else first = p01 ? 0 : 1;      // by construction one of them holds (planner.h: need <= 2)
+// Emission of the real op `root` and everything below it that this walk evaluates.  Iterative (explicit frame stack on the
+// heap): the dependency depth of an operation list is unbounded — a 5000-tip ladder tree is 4999 frames deep — and under
+// BEAST this runs on a JVM thread whose native stack is 1 MiB or less (-Xss).
+void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
+    struct Frame { int j; unsigned freeMask; int phase; Child ch[2]; int first; bool hold; MicroOp m; };
+    std::vector<Frame> st;
+    auto push = [&](int j, unsigned fm) { Frame f; f.j = j; f.freeMask = fm; f.phase = 0; f.first = 0; f.hold = false; f.m = blankOp(); st.push_back(f); };
+    push(root, rootMask);
+    while (!st.empty()) {
+        const size_t top = st.size() - 1;                 // (a push invalidates references: every path that pushes `continue`s)
+        OpInfo& o = info_[st[top].j];
+        if (st[top].phase == 0) {
+            Frame& f = st[top];
+            for (int w = 0; w < 2; w++) {
+                Child& c = f.ch[w];
+                c.buf = w ? o.c2 : o.c1; c.mat = w ? o.m2 : o.m1;
+                const bool tip = w ? o.tip2 : o.tip1;
+                c.prod = -1; c.need = 0; c.size = 0;
+                if (tip) { c.cls = CL_TIPS; continue; }
+                const int prod = w ? prod2_[f.j] : prod1_[f.j];
+                if (prod >= 0) {
+                    const OpInfo& p = info_[prod];
+                    if (p.virtDest) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); c.size = 0; }
+                    else if (p.emitted) c.cls = CL_MEM;
+                    else { c.cls = CL_REAL; c.prod = prod; c.need = p.need; c.size = p.size; }
+                } else if (virt_[c.buf].on) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); }
+                else c.cls = CL_MEM;
+            }
+            const bool e0 = f.ch[0].cls >= CL_VIRT, e1 = f.ch[1].cls >= CL_VIRT;
+            if (!e0 && !e1) {
+                const int firstLeaf = (f.ch[0].cls == CL_TIPS && f.ch[1].cls == CL_MEM) ? 1 : 0;      // a child in memory goes first
+                setLeaf(f.m, 0, f.ch[firstLeaf]); setLeaf(f.m, 1, f.ch[1 - firstLeaf]);
+                if (f.ch[0].cls == CL_MEM) lastMemReads++;
+                if (f.ch[1].cls == CL_MEM) lastMemReads++;
+                f.phase = 9;
+            } else if (e0 != e1) {
+                const Child e = e0 ? f.ch[0] : f.ch[1];
+                const Child l = e0 ? f.ch[1] : f.ch[0];
+                setLeaf(f.m, 0, l);
+                if (l.cls == CL_MEM) lastMemReads++;
+                f.m.k2 = PK_ACC; f.m.mat2 = e.mat;
+                f.phase = 9;
+                if (e.cls == CL_VIRT) emitVirtual(e.buf, f.freeMask, true, out);
+                else { push(e.prod, f.freeMask); continue; }
+            } else {
+                const int F = popcount2(f.freeMask);
+                auto holdOK = [&](const Child& a, const Child& b) { return a.need <= F && 1 + b.need <= F; };
+                auto plainOK = [&](const Child& a, const Child& b) { return a.cls == CL_REAL && a.need <= F && b.need <= F; };
+                const Child* ch = f.ch;
+                const bool h01 = holdOK(ch[0], ch[1]), h10 = holdOK(ch[1], ch[0]);
+                if (h01 || h10) {
+                    f.hold = true;
+                    if (h01 && h10) f.first = (ch[1].need > ch[0].need || (ch[1].need == ch[0].need && ch[1].size > ch[0].size)) ? 1 : 0;
+                    else f.first = h01 ? 0 : 1;
+                } else {
+                    const bool p01 = plainOK(ch[0], ch[1]), p10 = plainOK(ch[1], ch[0]);
+                    if (p01 && p10) f.first = ch[1].size > ch[0].size ? 1 : 0;
+                    else f.first = p01 ? 0 : 1;      // by construction one of them holds (planner.h: need <= 2)
+                }
+                f.phase = 1;
+                const Child a = ch[f.first];
+                if (a.cls == CL_VIRT) emitVirtual(a.buf, f.freeMask, true, out);
+                else { push(a.prod, f.freeMask); continue; }
+            }
         }
-        const Child& a = ch[first];
-        const Child& b = ch[1 - first];
-        emitChild(a, freeMask);
-        if (hold) {
-            const int h = lowestSlot(freeMask);
-            out.prog.back().hold = h + 1;
-            lastHolds++;
-            emitChild(b, freeMask & ~(1u << h));
-            m.k1 = PK_H0 + h; m.mat1 = a.mat;
-        } else {
-            emitChild(b, freeMask);
-            m.k1 = PK_MEM; m.a1 = a.buf; m.mat1 = a.mat;
-            lastMemReads++;
+        if (st[top].phase == 1) {                         // the first of two evaluated children is done
+            Frame& f = st[top];
+            const Child a = f.ch[f.first], b = f.ch[1 - f.first];
+            unsigned mask2 = f.freeMask;
+            if (f.hold) {
+                const int h = lowestSlot(f.freeMask);
+                out.prog.back().hold = h + 1;
+                lastHolds++;
+                mask2 = f.freeMask & ~(1u << h);
+                f.m.k1 = PK_H0 + h; f.m.mat1 = a.mat;
+            } else {
+                f.m.k1 = PK_MEM; f.m.a1 = a.buf; f.m.mat1 = a.mat;
+                lastMemReads++;
+            }
+            f.m.k2 = PK_ACC; f.m.mat2 = b.mat;
+            f.phase = 9;
+            if (b.cls == CL_VIRT) emitVirtual(b.buf, mask2, true, out);
+            else { push(b.prod, mask2); continue; }
         }
-        m.k2 = PK_ACC; m.mat2 = b.mat;
+        {                                                 // phase 9: the node itself
+            Frame& f = st[top];
+            MicroOp& m = f.m;
+            m.storeBuf = o.dest;
+            if (o.wS != OP_NONE) { m.scaleIdx = o.wS; m.smode = PS_WRITE; sDone_[(size_t)o.wS * parts_ + o.part] = stamp_; }
+            else if (o.rS != OP_NONE) { m.scaleIdx = o.rS; m.smode = PS_READ; }
+            out.prog.push_back(m);
+            o.emitted = true;
+            lastStored++;
+            st.pop_back();
+        }
     }
-    m.storeBuf = o.dest;
-    if (o.wS != OP_NONE) { m.scaleIdx = o.wS; m.smode = PS_WRITE; sDone_[(size_t)o.wS * parts_ + o.part] = stamp_; }
-    else if (o.rS != OP_NONE) { m.scaleIdx = o.rS; m.smode = PS_READ; }
-    out.prog.push_back(m);
-    o.emitted = true;
-    lastStored++;
 }
 
 int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allowVirtual, Plan& out, int chunkOps) {
@@ -338,8 +360,6 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     info_.assign(count, OpInfo());
     prod1_.assign(count, -1); prod2_.assign(count, -1);
     std::vector<char> consumed(count, 0);
-    std::vector<int> depthOf(count, 1);
-    int maxDepth = 1;
 
     // ---- pass 1, list order: virtual definitions, producers, hold needs
     for (int k = 0; k < count; k++) {
@@ -402,10 +422,9 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 const bool tip = w ? o.tip2 : o.tip1;
                 const int c = w ? o.c2 : o.c1, prod = w ? prod2_[k] : prod1_[k];
                 if (tip) continue;
-                if (prod >= 0 && !info_[prod].virtDest) { eval[w] = real[w] = true; need[w] = info_[prod].need; size[w] = info_[prod].size; depthOf[k] = std::max(depthOf[k], depthOf[prod] + 1); }
+                if (prod >= 0 && !info_[prod].virtDest) { eval[w] = real[w] = true; need[w] = info_[prod].need; size[w] = info_[prod].size; }
                 else if (virt_[c].on) { eval[w] = true; need[w] = virtNeed(c); }
             }
-            maxDepth = std::max(maxDepth, depthOf[k]);
             o.size = 1 + size[0] + size[1];
             if (eval[0] && eval[1]) {
                 auto cost = [&](int a, int b) { return real[a] ? std::max(need[a], need[b]) : std::max(need[a], 1 + need[b]); };
@@ -413,7 +432,6 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             } else o.need = eval[0] ? need[0] : eval[1] ? need[1] : 0;
         }
     }
-    flat_ = maxDepth > MAX_RECURSION;
 
     // ---- pass 2: walk order.  One slice per partition; inside it, every unconsumed real op is a root of the forest.
     // With chunkOps > 0 the forest is peeled in waves: a wave = the maximal subtrees of at most chunkOps micro-operations
@@ -429,7 +447,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         int wave = 0;
         for (;;) {
             bool chunked = false;
-            if (chunkOps > 0 && !flat_) {
+            if (chunkOps > 0) {
                 // micro-operations below every op that is still to be emitted (children precede parents in the list)
                 weight.assign(count, 0);
                 long total = 0;
@@ -471,7 +489,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                         for (int k : chunkRoots) {
                             if (info_[k].emitted) continue;
                             PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part; seg.wave = wave;
-                            emitReal(k, allSlots_, out, 0);
+                            emitReal(k, allSlots_, out);
                             seg.progCount = (int)out.prog.size() - seg.progStart;
                             out.segs.push_back(seg);
                         }
@@ -485,7 +503,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             for (int k = 0; k < count; k++) {
                 OpInfo& o = info_[k];
                 if (o.part != part || o.virtDest || o.emitted) continue;
-                if (flat_ || !consumed[k]) emitReal(k, allSlots_, out, 0);
+                if (!consumed[k]) emitReal(k, allSlots_, out);
             }
             // virtual nodes of a rescaling evaluation still owe their scale factors if nothing above evaluated them
             for (int k = 0; k < count; k++) {

@@ -133,7 +133,7 @@ private:
     bool buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs);
     void registerVirtual(int X);
     // emission
-    void emitReal(int j, unsigned freeMask, Plan& out, int depth);
+    void emitReal(int root, unsigned freeMask, Plan& out);
     void emitVirtualStep(int buf, int idx, unsigned freeMask, bool writeMode, Plan& out);
     void emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out);
     int virtNeed(int buf) const { return virt_[buf].nSteps ? virt_[buf].steps[virt_[buf].nSteps - 1].need : 0; }
@@ -153,7 +153,6 @@ private:
     std::vector<int> prod1_, prod2_;                   // op of this list that produced each child (or -1)
     unsigned allSlots_ = 3u;                           // mask of the hold slots
     int parts_ = 1;
-    bool flat_ = false;                                // recursion too deep: children of real ops are read from memory
 
     // Plans of CLOSED lists (every child is a compact tip or the destination of an earlier operation of the same list:
     // a full evaluation, what BEAST issues whenever a model parameter changes — MarkovChain.java:207-263 with all nodes

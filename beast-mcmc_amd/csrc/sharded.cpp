@@ -116,6 +116,21 @@ int forAll(Sharded* sh, const std::function<int(int)>& f) {
     return rc;
 }
 
+// everything a (possibly half-built) sharded instance owns: worker threads first (nothing is in flight afterwards), the
+// shard instances — which must go before the streams they were pointed at —, then communicator, result buffer, stream
+void destroySharded(Sharded* sh) {
+    for (Shard& s : sh->shards) {
+        delete s.worker;
+        if (s.handle >= 0) beagleFinalizeInstance(s.handle);
+        hipSetDevice(s.device);
+        if (s.comm) ncclCommDestroy(s.comm);
+        if (s.dResult) hipFree(s.dResult);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    if (sh->hResult) hipHostFree(sh->hResult);
+    delete sh;
+}
+
 #define GET_SHARDED(h) Sharded* sh = find(h); if (!sh) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE
 
 }  // namespace
@@ -158,11 +173,7 @@ int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compa
         if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) rc = BEAGLE_ERROR_GENERAL;
         else for (int k = 0; k < n; k++) sh->shards[k].comm = comms[k];
     }
-    if (rc) {
-        for (Shard& s : sh->shards) { if (s.handle >= 0) beagleFinalizeInstance(s.handle); delete s.worker; }
-        delete sh;
-        return rc;
-    }
+    if (rc) { destroySharded(sh); return rc; }
     sh->name = std::to_string(n) + " x MI355X, patterns sharded" + (sh->useRccl ? " (RCCL all-reduce)" : " (host sum)");
     int handle;
     {
@@ -190,16 +201,7 @@ int shardedFinalize(int handle) {
         if (i < 0 || i >= (int)g_sharded.size() || !g_sharded[i]) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
         sh = g_sharded[i]; g_sharded[i] = nullptr;
     }
-    for (Shard& s : sh->shards) {
-        delete s.worker;
-        beagleFinalizeInstance(s.handle);
-        hipSetDevice(s.device);
-        if (s.comm) ncclCommDestroy(s.comm);
-        if (s.dResult) hipFree(s.dResult);
-        if (s.stream) hipStreamDestroy(s.stream);
-    }
-    if (sh->hResult) hipHostFree(sh->hResult);
-    delete sh;
+    destroySharded(sh);
     return BEAGLE_SUCCESS;
 }
 

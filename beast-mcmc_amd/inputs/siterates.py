@@ -2,14 +2,26 @@
 
 Mirror of src/dr/evomodel/siteratemodel/GammaSiteRateModel.java:233-268 (``calculateCategoryRates``) and :445-472
 (``setEqualRates`` / ``normalize``): equal-probability discretisation at the class medians.  The gamma quantile is a
-parameter: the default is the exact inverse CDF (scipy); the parity tests pass the reference's own approximation
-(tests/reference_quantile.py: AS 91 / AS 32), which its golden values were computed with.
+parameter: ``quantile="beast"`` (the DEFAULT) is the reference's own AS 91 / AS 32 approximation (as91_quantile.py; what
+its golden values were computed with, and what a BEAST run hands the engine), ``quantile="exact"`` the exact inverse CDF
+(scipy, imported only when asked for), or any callable ``(y, shape, scale) -> x``.
 """
 
 
-def gamma_quantile(y, shape, scale):
-    from scipy.stats import gamma
+def exact_gamma_quantile(y, shape, scale):
+    from scipy.stats import gamma                # lazily: the package does not depend on scipy otherwise
     return float(gamma.ppf(y, shape, scale=scale))
+
+
+def resolve_quantile(quantile):
+    if quantile is None or quantile == "beast":
+        from .as91_quantile import gamma_quantile
+        return gamma_quantile
+    if quantile == "exact":
+        return exact_gamma_quantile
+    if callable(quantile):
+        return quantile
+    raise ValueError("quantile must be 'beast', 'exact' or a callable, not %r" % (quantile,))
 
 
 class GammaSiteRateModel:
@@ -20,7 +32,7 @@ class GammaSiteRateModel:
     """
 
     def __init__(self, alpha=None, gamma_categories=1, p_inv=None, mu=1.0, quantile=None):
-        self.quantile = quantile or gamma_quantile
+        self.quantile = resolve_quantile(quantile)
         self.alpha = alpha
         self.p_inv = p_inv
         self.gamma_categories = gamma_categories if alpha is not None else (1 if p_inv is not None else 1)
@@ -68,7 +80,7 @@ class OldGammaSiteModel:
 
     def __init__(self, alpha=None, gamma_categories=1, p_inv=None, quantile=None):
         self.alpha, self.gamma_categories, self.p_inv = alpha, gamma_categories, p_inv
-        self.quantile = quantile or gamma_quantile
+        self.quantile = resolve_quantile(quantile)
 
     def category_rates_and_proportions(self):
         rates, props = [], []

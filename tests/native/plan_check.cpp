@@ -9,7 +9,7 @@
 // materialised (at random, and all of them at the end).  Scenarios: full evaluations in both traversal orders, rescaling
 // write / read mode, MCMC-style partial updates with BufferIndexHelper flips and rejections
 // (src/dr/evomodel/treedatalikelihood/BufferIndexHelper.java:71-106), tip-state changes, partitioned 9-int lists,
-// lists with hazards, a 5000-tip caterpillar (flat emission).
+// lists with hazards, a 5000-tip caterpillar (4999 dependency levels: the emission must not recurse on the native stack).
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -85,6 +85,30 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
     std::vector<std::vector<double>> src;
     for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) src.push_back(w.mats[plan.snapPairs[i]]);
     for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) w.mats[plan.snapPairs[i + 1]] = src[i / 2];
+    // The kernels are software-pipelined two micro-operations deep: the partials a micro-operation reads as its FIRST child
+    // (PK_MEM in k1) are requested at the start of the PREVIOUS micro-operation's stage, before that one stores its result
+    // (kernels_walk4.hip WALK_STAGE, tools/gen_walk4_fast.py stage()).  A program must therefore never read in k1 what the
+    // micro-operation right before it stores; and slices of one wave run side by side, so none may read what another stores.
+    for (size_t a = 0; a < plan.segs.size(); a++) {
+        const PlanSeg& sg = plan.segs[a];
+        for (int k = sg.progStart + 1; k < sg.progStart + sg.progCount; k++) {
+            const MicroOp& m = plan.prog[k];
+            CHECK(!(m.k1 == PK_MEM && plan.prog[k - 1].storeBuf == m.a1), m, k);
+        }
+        for (size_t b = 0; b < plan.segs.size(); b++) {
+            const PlanSeg& ob = plan.segs[b];
+            if (a == b || ob.wave != sg.wave || ob.partition != sg.partition) continue;
+            for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
+                const MicroOp& m = plan.prog[k];
+                for (int q = ob.progStart; q < ob.progStart + ob.progCount; q++) {
+                    const int st = plan.prog[q].storeBuf;
+                    if (st < 0) continue;
+                    CHECK(!(m.k1 == PK_MEM && m.a1 == st), m, k);
+                    CHECK(!(m.k2 == PK_MEM && m.a2 == st), m, k);
+                }
+            }
+        }
+    }
     for (const PlanSeg& sg : plan.segs) {
         for (int p = partStart[sg.partition]; p < partEnd[sg.partition]; p++) {
             V4 ACC[8], H[3][8];
@@ -256,7 +280,16 @@ struct Tree {
             roots.push_back(n);
         }
     }
-    void postOrder(int n, std::vector<int>& out) const { if (n < T) return; postOrder(left[n], out); postOrder(right[n], out); out.push_back(n); }
+    void postOrder(int root, std::vector<int>& out) const {      // iterative: the ladder tree is 4999 levels deep
+        std::vector<std::pair<int, int>> st{{root, 0}};
+        while (!st.empty()) {
+            const int n = st.back().first, phase = st.back().second++;
+            if (n < T) { st.pop_back(); continue; }
+            if (phase == 0) st.push_back({left[n], 0});
+            else if (phase == 1) st.push_back({right[n], 0});
+            else { out.push_back(n); st.pop_back(); }
+        }
+    }
     std::vector<int> levelOrder() const {   // reverse level order: deepest internal nodes first
         const int N = 2 * T - 1;
         std::vector<int> depth(N, 0), order;
@@ -457,7 +490,8 @@ int main(int argc, char** argv) {
         scenarioHazards(5 + r);
     }
     P = 2; C = 1;
-    scenarioMcmc(5000, true, true, 9, 3, false);     // deeper than the recursion limit: flat emission
+    scenarioMcmc(5000, true, true, 9, 3, false);     // 4999 dependency levels
+    scenarioMcmc(5000, false, true, 11, 2, false);
     scenarioMcmc(3000, true, false, 10, 5, false);
     printf("plan_check: OK\n");
     return 0;

@@ -326,3 +326,38 @@ def test_concurrent_instances_from_two_threads(oracle_lib):
     o.storeState(); o.set_branch_rates(np.full(wls[0].tree.node_count, 1.0))
     assert helpers.rel_err(serial[0][0], o.getLogLikelihood()) <= REL_TOL
     o.close()
+
+
+@pytest.mark.parametrize("traversal", [POST_ORDER, REVERSE_LEVEL_ORDER])
+def test_ladder_tree_of_5000_taxa(traversal, oracle_lib):
+    """4999 dependency levels: the planner's emission is iterative (no native-stack recursion under a JVM thread) and the
+    whole ladder runs as one chain in registers; a first child must never be fetched from a buffer the micro-operation right
+    before it stores (the kernels request it one stage early — ADVICE round 2, planner.cpp / engine.cpp runPlan)."""
+    rng = np.random.default_rng(5)
+    pi = rng.dirichlet(np.full(4, 10.0))
+    eig = bm.substmodel.gtr(rng.gamma(2.0, 1.0, size=6) + 0.1, pi)
+    wl = synth.make_workload("ladder", 5000, 300, eig, pi, alpha=0.7, categories=4, seed=12, tree_kind="caterpillar",
+                             root_to_tip=2.0, unknown_fraction=0.02)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False, traversal=traversal)
+    assert_parity(g, o, "ladder write mode")
+    for tl in (g, o):
+        tl.makeDirty()
+    assert_parity(g, o, "ladder again")
+    # the same with virtual buffers off: every node stored, every internal child the previous micro-operation's result
+    g.close(); o.close()
+
+
+def test_ladder_tree_every_node_stored(oracle_lib, monkeypatch):
+    monkeypatch.setenv("BEAGLE_MI355_NO_VIRTUAL", "1")
+    rng = np.random.default_rng(6)
+    pi = rng.dirichlet(np.full(4, 10.0))
+    eig = bm.substmodel.gtr(rng.gamma(2.0, 1.0, size=6) + 0.1, pi)
+    wl = synth.make_workload("ladder", 4500, 200, eig, pi, alpha=0.7, categories=2, seed=13, tree_kind="caterpillar",
+                             root_to_tip=2.0, unknown_fraction=0.02)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    assert_parity(g, o, "ladder, all stored")
+    for node in (wl.tip_count, wl.tip_count + 1, 2 * wl.tip_count - 3, 2 * wl.tip_count - 2):
+        pg, po = _partials(g, node), _partials(o, node)
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= REL_TOL, node
+    g.close(); o.close()
