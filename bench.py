@@ -15,9 +15,16 @@ All inputs are resident in HBM before the timed region.
 --config A (default) | B (20 states, 500 x 5e4) | C (61 states, 200 x 2e4) | D (benchmark1-like) | E (Makona-like, four
 partitions on one instance through updatePartialsByPartition).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the patterns (of every partition) are split into contiguous
-blocks (Patterns.java:142-167), every rank evaluates its block, ONE RCCL all-reduce of the per-shard lnL per step (E: of
-the partitionCount per-partition values).  Total work is fixed as N grows -> "scaling": "strong".
+N > 1: one rank per GPU.  Started under torch.distributed.run (what the driver does) the ranks are there already; started
+PLAINLY (`python bench.py --gpus N`) this script brings them up itself (re-executes under `python -m torch.distributed.run
+--nproc-per-node N --master-addr 127.0.0.1`), and it refuses to print a line whose n_gpus differs from --gpus.  The patterns
+(of every partition) are split into contiguous blocks (Patterns.java:142-167), every rank evaluates its block, ONE RCCL
+all-reduce of the per-shard lnL per step (E: of the partitionCount per-partition values).  Total work is fixed as N grows
+-> "scaling": "strong".  Reference equivalent: -beagle_instances N -beagle_order 1,..,N
+(src/dr/evomodelxml/treedatalikelihood/TreeDataLikelihoodParser.java:205-278).
+`--route library` times the OTHER multi-GPU route instead: ONE process, the library's resource G+1 ("all GPUs",
+csrc/sharded.cpp: one engine instance per GPU on its own host thread, ncclAllReduce of the root sums); with the default
+`--route ranks` rank 0 appends a shorter run of that route to the line as "library_route" (configs A-D).
 
 Prints ONE JSON line on rank 0.
 """
@@ -95,7 +102,18 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="patterns in the CPU-baseline sample (0 = sized for ~10-20 s of CPU work)")
+    ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
+                    help="ranks: one process per GPU + torch.distributed all-reduce (default); library: one process, the engine's resource G+1")
+    ap.add_argument("--no-library-route", action="store_true", help="do not append the in-library route's run to the line")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU check of the N-rank bring-up only (gloo, no engine, no GPU): tests/test_host_and_abi.py")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.route == "ranks" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # started plainly: bring up the N ranks ourselves
+    if args.selftest_launcher:
+        return selftest_launcher(args)
 
     import numpy as np
     import torch
@@ -106,10 +124,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.route == "library":
+        if world > 1:
+            raise SystemExit("--route library is ONE process driving all GPUs; do not start it under torch.distributed.run")
+    elif world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a line whose n_gpus is not what was asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d but only %d GPU(s) are visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -138,6 +161,10 @@ def main():
     if args.patterns and args.config != "E":
         wl = wl.shard(0, min(args.patterns, wl.pattern_count))
     res = (local_rank + 1,)                              # resource numbering: 0 = CPU (absent), 1..G = GPUs as THIS process sees them
+    if args.route == "library":
+        # resource G+1 = "all GPUs, pattern-sharded" (csrc/sharded.cpp); BEAGLE_MI355_SHARDS = N keeps it to the first N devices
+        os.environ["BEAGLE_MI355_SHARDS"] = str(args.gpus)
+        res = (torch.cuda.device_count() + 1,)
 
     if args.config == "E":
         out = bench_partitioned(args, bm, wl, rank, world, dist, device, res, t_gen)
@@ -145,7 +172,14 @@ def main():
         out = bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded,
                            ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and out is not None and args.route == "ranks" and not args.no_library_route and args.config != "E":
+        # the other multi-GPU route on the same workload (a shorter run), after this route's instances and process group are gone
+        try:
+            out["library_route"] = library_route(args, bm, wl, world, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC)
+        except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
+            out["library_route"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ONE JSON line, and it is the LAST thing on stdout: libraries that print through C stdio (RCCL's version banner on the
     # multi-GPU path) are flushed first, so nothing of theirs can follow the line when the process exits
     import ctypes
@@ -154,6 +188,45 @@ def main():
     except Exception:                       # noqa: BLE001
         pass
     if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started plainly: run the same command line under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launcher(args):
+    """The rank bring-up without the engine (no GPU in the build container): every rank joins a gloo group, one all-reduce,
+    rank 0 prints a line whose n_gpus is the world size it really ran with."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a line whose n_gpus is not what was asked for" % (args.gpus, world))
+    total = float(rank + 1)
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([total], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    out = {"metric": "launcher selftest", "n_gpus": world, "rank_sum": total}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     return out
 
@@ -273,7 +346,12 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
 
     out = None
     if rank == 0:
-        shard = wl.shard(*tl.range) if sharded else wl
+        n_gpus = args.gpus if args.route == "library" else world
+        if args.route == "library":                       # the engine's counters are shard 0's, the kernel time the slowest shard's
+            from beast_mcmc_amd.inputs import patterns as _pat
+            shard = wl.shard(*_pat.shard_bounds(wl.pattern_count, n_gpus)[0])
+        else:
+            shard = wl.shard(*tl.range) if sharded else wl
         s_, p_, c_ = shard.state_count, shard.pattern_count, shard.category_count
         alg = prune_bytes_per_eval(shard)                     # SURVEY 8d algorithmic bytes of this rank's pruning
         kernel_s = kernel_ms * 1e-3 / max(1, args.steps)
@@ -318,17 +396,18 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             roofline.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s",
                              "frac": round(tflops / 78.6, 4), "hbm_GBs": round(achieved, 1)})
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and args.route == "ranks" and not args.no_cpu_baseline:
             cpu = cpu_baseline(bm, wl, args.cpu_sample, tl)
         out = {
             "metric": "full-tree lnL evals/sec (GTR+G4, 1e5 patterns)" if args.config == "A" else "full-tree lnL evals/sec",
-            "value": round(evals_per_s, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(evals_per_s, 3), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "route": args.route,
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "
                                    "DYNAMIC rescaling steady state, new eigen system + rates every step"
                                    % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth()),
-                       "caller": args.caller, "patterns_per_gpu": p_, "parallelism": "pattern-shard x%d + 1 all-reduce" % world,
+                       "caller": args.caller, "patterns_per_gpu": p_, "parallelism": ("pattern-shard x%d + 1 all-reduce (torch.distributed over RCCL, one process per GPU)" % n_gpus) if args.route == "ranks"
+                                      else "pattern-shard x%d inside the library (resource G+1, ncclAllReduce), one process" % n_gpus,
                        "ops_per_eval": int(counters["last_op_count"]), "matrices_per_eval": int(counters["last_branch_count"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -339,6 +418,32 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         }
     tl.close()
     return out
+
+
+def library_route(args, bm, wl, n, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC):
+    """The same step through ONE instance of resource G+1 with n shards (csrc/sharded.cpp): what a JVM gets with
+    -beagle_order <G+1> and no Java-side change.  One process; the library's host threads drive the GPUs."""
+    if torch.cuda.device_count() < n:
+        return {"error": "needs %d visible GPUs, this process sees %d" % (n, torch.cuda.device_count())}
+    os.environ["BEAGLE_MI355_SHARDS"] = str(n)
+    tl = BeagleTreeLikelihood(wl, resource_list=(torch.cuda.device_count() + 1,), rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    models = perturbed_models(bm, wl, args.config)
+
+    def step(i):
+        eig, freqs, rates, weights = models[i & 1]
+        tl.storeState()
+        tl.set_substitution_model(eig, freqs)
+        tl.set_site_model(rates, weights)
+        return tl.getLogLikelihood()
+
+    step(0); step(1)
+    for i in range(min(args.warmup, 10)):
+        step(i)
+    n2 = max(10, args.steps // 2)
+    elapsed, lnl = timed_loop(torch, device, None, n2, step)
+    tl.close()
+    return {"route": "library", "n_gpus": n, "value": round(n2 / elapsed, 3), "unit": "evals/s", "steps": n2,
+            "ms_per_step": round(1e3 * elapsed / n2, 4), "lnL": lnl}
 
 
 def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):

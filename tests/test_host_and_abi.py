@@ -200,6 +200,23 @@ def test_pattern_sharded_two_ranks_gloo(tmp_path):
     assert abs(a - whole) / abs(whole) < 1e-12 and abs(b - whole) / abs(whole) < 1e-12
 
 
+def test_bench_brings_up_its_own_ranks():
+    """`python bench.py --gpus 2` started PLAINLY (no launcher, as the driver starts --gpus 1) must run TWO ranks and say so
+    (it silently ran one).  The engine needs a GPU, so this exercises the bring-up only: the same self-launch
+    under torch.distributed.run, a gloo group instead of RCCL, one all-reduce; and a line is refused when the world size is
+    not what --gpus asked for."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rank_sum"] == 3.0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "refusing" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
 # ---- gradient call sequence (SURVEY 8f row f1): host-side structure, checked without a GPU ---------------------------
 
 def test_pre_order_op_list_mirrors_the_reference_delegate():
