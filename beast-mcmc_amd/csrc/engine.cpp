@@ -68,6 +68,8 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
+    bool strictWaits = false;                            // BEAGLE_MI355_STRICT_WAITS=1 at creation: a stage's wait does not count the previous
+                                                         // stage's stores as retiring behind its loads (runPlan)
     bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
     bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
     long statCherries = 0;
@@ -426,11 +428,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         w.push_back(nop); w.push_back(nop);
         // the wait of every stage: "at most N vector-memory instructions outstanding" with N = everything issued AFTER the
         // stage's own loads: the stores of the previous micro-operation and the loads of the next one.  Loads and stores
-        // share the counter and are counted out strictly in issue order (tools/vmcnt_order_probe.hip: a younger store is
-        // never retired before an older load), so a stage does not have to wait for the previous stage's stores to be
-        // acknowledged.  A smaller N than the true number only waits longer (the table ends at 12).
+        // share the counter and are counted out strictly in issue order (tests/test_gpu_vmcnt_order.py: a younger store is
+        // never retired before an older load in > 1e9 lane-trials), so a stage does not have to wait for the previous stage's
+        // stores to be acknowledged.  A smaller N than the true number only waits longer (the table ends at 12).
+        // BEAGLE_MI355_STRICT_WAITS=1 does not use that observation: N = the loads of the next micro-operation only.  That
+        // is sufficient under the one ordering rule the ISA guides state for this counter — vector-memory LOADS return in
+        // the order they were issued: when at most N operations are outstanding and the N youngest loads are all younger
+        // than this stage's loads, an unfinished load of this stage would leave N + 1 unfinished — whatever the stores
+        // (of this or any earlier stage) do.  Costs the acknowledgement latency of four stores per stored node.
         for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
-            const int stores = i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0;
+            const int stores = in->strictWaits ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
             w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
             // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
             const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
@@ -1392,6 +1399,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
                      getenv("BEAGLE_MI355_HOLD_SLOTS") ? std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), mi355::walkHoldSlots(categoryCount)) : mi355::walkHoldSlots(categoryCount));
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
+    in->strictWaits = getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) != 0;
     in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
