@@ -16,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ENGINE_LIB = os.path.join(_HERE, "lib", "libhmsbeagle-jni.so")
+if os.environ.get("BEAGLE_MI355_ENGINE_LIB"):        # development: an A/B build of the same engine (tools/build_variant.sh)
+    ENGINE_LIB = os.environ["BEAGLE_MI355_ENGINE_LIB"]
 HOST_LIB = os.path.join(_HERE, "lib", "libbeast_host.so")
 
 NONE = -1

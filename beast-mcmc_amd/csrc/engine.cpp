@@ -502,6 +502,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         in->matStreamBytes = want;
     }
     mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
+    if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
+        fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
+        for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
+        fprintf(stderr, "\n");
+    }
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
     for (size_t b = 0; b < segs.size();) {

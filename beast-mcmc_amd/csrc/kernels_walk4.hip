@@ -357,6 +357,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C) {
     if (nSegs <= 0 || maxRange <= 0) return;
+    // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
+    // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
+    // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
     const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES;

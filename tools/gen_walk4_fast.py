@@ -18,7 +18,7 @@ Run: python tools/gen_walk4_fast.py   (rewrites the .inc; tests/test_planner_nat
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")
+OUT = os.environ.get("WALK4_OUT") or os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")
 
 # ---- register map -----------------------------------------------------------------------------------------------------
 # vector
@@ -27,26 +27,32 @@ AT1, AT2, BT1, BT2 = 32, 33, 34, 35      # tip-state pairs (a | b << 8) of the t
 AINV, BINV = 36, 40           # reciprocal scale factors {a, b}
 ACC = 44                      # the previous micro-operation's result: a = +0..7, b = +8..15
 F, G = 60, 76                 # the two children's contributions
-SP = 92                       # lane l: entry (l & 15) of a branch matrix
+SP = 92                       # lane l: entry (l & 15) of the first child's branch matrix
+SPB = 122                     # ... of the second child's
 T0, T1 = 94, 95
 PA, PB, TIP, SCALE, OM, HOLD, SP0, SP1, LANE, VST = 96, 97, 98, 99, 100, 101, 102, 103, 104, 105
 H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
-NV = 122
-# scalar
-DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST = 20, 22, 24, 25, 26, 27, 59, 60      # (s32 is reserved)
-MASK = 62                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
-EVEN, ODD = 70, 72            # 0x5555..., 0xaaaa...
-D, DFL = 36, 44               # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags
+NV = 124
+# scalar (s32..s35 are left to the compiler)
+DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 25, 26, 27, 28, 29, 30, 31
+D, DFL, CM160 = 36, 44, 45    # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags
 SA_FL, SA_STORE, SA_SRC2 = 46, 48, 50
 SB_FL, SB_STORE, SB_SRC2 = 52, 54, 56
-LAST = 58
-S_FIRST, S_LAST = 20, 73
+MASK = 58                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
+C0A, C0B = 68, 84             # column 0 of the two branch matrices of the even / odd micro-operations (8 + 8 SGPRs each): M[i][0]
+S_FIRST, S_LAST = 20, 99
 
 # flag bits (kernels.h)
 B_X, B_T1, B_T2, B_STORE, B_HSLOT1 = 0, 1, 2, 4, 12
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
 
 STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
+# A/B switches (tools/build_variant.sh): both give the same bits
+# (measured on config A and the 12 500-pattern shard, profiles/r03_experiments.txt: neither changes the time — the loop is not
+# bound by its vector-instruction count or by LDS round trips — so both stay off and the round-2 stream is what ships)
+SCOL = os.environ.get("WALK4_SCOL", "0") != "0"             # first term of every mat-vec row from SGPRs (no zeroing moves)
+LDSBATCH = os.environ.get("WALK4_LDSBATCH", "0") != "0"     # every LDS read of a stage is issued before its one LDS wait
+EARLYDESC = os.environ.get("WALK4_EARLYDESC", "0") != "0"   # descriptor k + 2 is requested right after the fetch of k + 1 has used the registers
 # TIMING EXPERIMENTS ONLY (wrong results; tools/walk_floor.sh, profiles/r02_experiments.txt): comma-separated parts to leave out
 EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if x)
 lines = []
@@ -68,16 +74,26 @@ def L(name):
     return ".LW4%s_%%=" % name
 
 
-def matvec(dst, x):
-    """dst (16 regs: a rows 0-3, b rows 0-3) = M . x for the two patterns; M spread over the lanes of SP.  The rounding
-    sequence is y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, fma(m_i0, x0, 0))))."""
-    for i in range(8):
-        e("v_mov_b64 %s, 0" % v(dst + 2 * i, 2))
+def matvec(dst, x, sp=None, col0=None):
+    """dst (16 regs: a rows 0-3, b rows 0-3) = M . x for the two patterns; M spread over the lanes of `sp`.  The rounding
+    sequence is y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, m_i0 * x0))) (= fma(m_i0, x0, 0) bit for bit: both
+    factors are never negative).  col0: the SGPRs holding M[0..3][0] — the first term is then a plain multiply by a scalar
+    operand and nothing has to be zeroed (v_mul_f64 has no DPP form; 32 instead of 40 vector instructions)."""
+    sp = SP if sp is None else sp
+    if col0 is None:
+        for i in range(8):
+            e("v_mov_b64 %s, 0" % v(dst + 2 * i, 2))
+    else:
+        for half in range(2):
+            for i in range(4):
+                e("v_mul_f64 %s, %s, %s" % (v(dst + 8 * half + 2 * i, 2), s(col0 + 2 * i, 2), v(x + 8 * half, 2)))
     for j in range(0 if "nofma" in EXPERIMENT else 4):
+        if j == 0 and col0 is not None:
+            continue
         for half in range(2):
             for i in range(4):
                 e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                  % (v(dst + 8 * half + 2 * i, 2), v(SP, 2), v(x + 8 * half + 2 * j, 2), 4 * i + j))
+                  % (v(dst + 8 * half + 2 * i, 2), v(sp, 2), v(x + 8 * half + 2 * j, 2), 4 * i + j))
 
 
 def tip_columns(dst, t, tbl, off):
@@ -143,11 +159,16 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
     outofline.append(blk)
 
 
-def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext):
+def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext, c0set):
     """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
     following one is fetched into the other slot."""
     e("s_waitcnt lgkmcnt(0)")                       # the descriptor of the NEXT micro-operation (and LDS writes) have landed
     fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext)
+    if EARLYDESC:   # descriptor k + 2, a whole stage before its use: its latency (a scalar-cache miss goes to L2) hides behind the wait below
+        e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
+        e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+        e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
+        e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # wait for this micro-operation's loads: N = everything issued after them = 4 (+4 stores before, +4 partials loads now)
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0))
     e("s_cbranch_scc1 %s" % L("w8" + tag))
@@ -157,53 +178,101 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
     e(L("wd" + tag) + ":")
     outofline.append([L("w8" + tag) + ":", "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag)])
     outofline.append([L("w12" + tag) + ":", "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
-    # first child
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
-    e("s_cbranch_scc0 %s" % L("fm" + tag))
-    tip_columns(F, Tt1, tblCur, 0)
-    e("s_branch %s" % L("g" + tag))
-    e(L("fm" + tag) + ":")
-    e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
-    e("s_cbranch_scc1 %s" % L("fh2" + tag))
-    e("s_waitcnt lgkmcnt(0)")
-    matvec(F, X)
-    save = lines[:]
-    del lines[:]
-    e(L("fh2" + tag) + ":")                          # first child waits in the register hold slot
-    e("s_waitcnt lgkmcnt(0)")
-    matvec(F, H2)
-    e("s_branch %s" % L("g" + tag))
-    outofline.append(lines[:])
-    del lines[:]
-    lines.extend(save)
-    # second child
-    e(L("g" + tag) + ":")
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
-    e("s_cbranch_scc0 %s" % L("ga" + tag))
-    tip_columns(G, Tt2, tblCur, 160)
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_branch %s" % L("mul" + tag))
-    e(L("ga" + tag) + ":")
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
-    e("s_cbranch_scc1 %s" % L("m2" + tag))
-    e(L("m2b" + tag) + ":")
-    outofline.append([L("m2" + tag) + ":",          # both children in memory: the second one is loaded into ACC, synchronously
-                      "global_load_dwordx4 %s, %s, %s" % (v(ACC, 4), v(PA), s(SSRC2, 2)),
-                      "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2)),
-                      "global_load_dwordx4 %s, %s, %s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2)),
-                      "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2)),
-                      "s_waitcnt vmcnt(0)",
-                      "s_branch %s" % L("m2b" + tag)])
-    e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
-    e("s_waitcnt lgkmcnt(0)")
-    matvec(G, ACC)
+    c0 = c0set if SCOL else None
+    m2blk = [L("m2" + tag) + ":",                    # both children in memory: the second one is loaded into ACC, synchronously
+             "global_load_dwordx4 %s, %s, %s" % (v(ACC, 4), v(PA), s(SSRC2, 2)),
+             "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2)),
+             "global_load_dwordx4 %s, %s, %s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2)),
+             "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2)),
+             "s_waitcnt vmcnt(0)",
+             "s_branch %s" % L("m2b" + tag)]
+    if LDSBATCH:
+        # every LDS read of the stage first — a tip child's two columns or the lane's entry of the branch matrix, for both
+        # children — then ONE wait, then the arithmetic (a wave used to park once per child)
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
+        e("s_cbranch_scc0 %s" % L("fm" + tag))
+        tip_columns(F, Tt1, tblCur, 0)
+        e("s_branch %s" % L("g" + tag))
+        e(L("fm" + tag) + ":")
+        e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+        e(L("g" + tag) + ":")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
+        e("s_cbranch_scc0 %s" % L("ga" + tag))
+        tip_columns(G, Tt2, tblCur, 160)
+        e("s_branch %s" % L("lw" + tag))
+        e(L("ga" + tag) + ":")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
+        e("s_cbranch_scc1 %s" % L("m2" + tag))
+        e(L("m2b" + tag) + ":")
+        outofline.append(m2blk)
+        e("ds_read_b64 %s, %s offset:160" % (v(SPB, 2), v(spCur)))
+        e(L("lw" + tag) + ":")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
+        e("s_cbranch_scc1 %s" % L("c2" + tag))
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
+        e("s_cbranch_scc1 %s" % L("fh2" + tag))
+        matvec(F, X, SP, c0)
+        save = lines[:]
+        del lines[:]
+        e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
+        matvec(F, H2, SP, c0)
+        e("s_branch %s" % L("c2" + tag))
+        outofline.append(lines[:])
+        del lines[:]
+        lines.extend(save)
+        e(L("c2" + tag) + ":")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
+        e("s_cbranch_scc1 %s" % L("mul" + tag))
+        matvec(G, ACC, SPB, None if c0 is None else c0 + 8)
+    else:
+        # first child
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
+        e("s_cbranch_scc0 %s" % L("fm" + tag))
+        tip_columns(F, Tt1, tblCur, 0)
+        e("s_branch %s" % L("g" + tag))
+        e(L("fm" + tag) + ":")
+        e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
+        e("s_cbranch_scc1 %s" % L("fh2" + tag))
+        e("s_waitcnt lgkmcnt(0)")
+        matvec(F, X, SP, c0)
+        save = lines[:]
+        del lines[:]
+        e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
+        e("s_waitcnt lgkmcnt(0)")
+        matvec(F, H2, SP, c0)
+        e("s_branch %s" % L("g" + tag))
+        outofline.append(lines[:])
+        del lines[:]
+        lines.extend(save)
+        # second child
+        e(L("g" + tag) + ":")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
+        e("s_cbranch_scc0 %s" % L("ga" + tag))
+        tip_columns(G, Tt2, tblCur, 160)
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_branch %s" % L("mul" + tag))
+        e(L("ga" + tag) + ":")
+        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
+        e("s_cbranch_scc1 %s" % L("m2" + tag))
+        e(L("m2b" + tag) + ":")
+        outofline.append(m2blk)
+        e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
+        e("s_waitcnt lgkmcnt(0)")
+        matvec(G, ACC, SP, None if c0 is None else c0 + 8)
     e(L("mul" + tag) + ":")
     # descriptor k + 2: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)
-    e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-    e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
-    e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
-    e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
+    if not EARLYDESC:
+        e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
+        e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+    if SCOL:    # column 0 of both tables of micro-operation k + 2 (STRM points there since this stage's fetch) into the set this
+        #         stage's mat-vecs have just finished with
+        e("s_load_dwordx8 %s, %s, %s" % (s(c0set, 8), s(STRM, 2), s(CM0)))
+        e("s_load_dwordx8 %s, %s, %s" % (s(c0set + 8, 8), s(STRM, 2), s(CM160)))
+    if not EARLYDESC:
+        e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
+        e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
     for i in range(8):
@@ -215,12 +284,12 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
     # sustain 2.0 TB/s, full lines 4.9-5.2): lane 2 q + r owns patterns q + 32 r and 64 + q + 32 r of the workgroup's 128,
     # store instruction j covers patterns 32 j .. 32 j + 31, lane 2 q + r writing half r (16 bytes) of pattern 32 j + q —
     # its own data or its neighbour's, exchanged with v_cndmask_b32_dpp quad_perm:[1,0,3,2] (no LDS).
-    blk = [L("st" + tag) + ":", "s_nop 1", "s_mov_b64 vcc, %s" % s(EVEN, 2)]
+    blk = [L("st" + tag) + ":", "s_mov_b32 vcc_lo, 0x55555555", "s_mov_b32 vcc_hi, 0x55555555", "s_nop 1"]
     for d in range(4):      # j = 0 (pattern q, owner r = 0): even lanes own half 0; odd lanes take the neighbour's half 1
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + d), v(ACC + 4 + d), v(ACC + d)))
     for d in range(4):      # j = 2 (pattern 64 + q): the same on the second pattern of the lanes
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 8 + d), v(ACC + 12 + d), v(ACC + 8 + d)))
-    blk.append("s_mov_b64 vcc, %s" % s(ODD, 2))
+    blk += ["s_mov_b32 vcc_lo, 0xaaaaaaaa", "s_mov_b32 vcc_hi, 0xaaaaaaaa", "s_nop 1"]
     for d in range(4):      # j = 1 (pattern 32 + q, owner r = 1): odd lanes own half 1; even lanes take the neighbour's half 0
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 4 + d), v(ACC + d), v(ACC + 4 + d)))
     for d in range(4):      # j = 3 (pattern 96 + q)
@@ -272,10 +341,8 @@ def build():
         e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
         e("s_nop 3")
         e("s_mov_b64 %s, vcc" % s(MASK + 2 * j, 2))
-    e("s_mov_b32 %s, 0x55555555" % s(EVEN))
-    e("s_mov_b32 %s, 0x55555555" % s(EVEN + 1))
-    e("s_mov_b32 %s, 0xaaaaaaaa" % s(ODD))
-    e("s_mov_b32 %s, 0xaaaaaaaa" % s(ODD + 1))
+    e("s_mov_b32 %s, %%[cM]" % s(CM0))
+    e("s_add_u32 %s, %%[cM], 160" % s(CM160))
     e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
     e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
     e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
@@ -310,15 +377,21 @@ def build():
     e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
     e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
     e("s_waitcnt lgkmcnt(0)")
+    if SCOL:
+        e("s_load_dwordx8 %s, %s, %s" % (s(C0A, 8), s(STRM, 2), s(CM0)))
+        e("s_load_dwordx8 %s, %s, %s" % (s(C0A + 8, 8), s(STRM, 2), s(CM160)))
     fetch("p", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0)
+    if SCOL:
+        e("s_load_dwordx8 %s, %s, %s" % (s(C0B, 8), s(STRM, 2), s(CM0)))
+        e("s_load_dwordx8 %s, %s, %s" % (s(C0B + 8, 8), s(STRM, 2), s(CM160)))
     e("s_load_dwordx8 %s, %s, 0x40" % (s(D, 8), s(DP, 2)))
     e("s_load_dword %s, %s, 0x70" % (s(DFL), s(DP, 2)))
     e("s_add_u32 %s, %s, 0x80" % (s(DP), s(DP)))
     e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # ---- the loop: two stages
     e(L("top") + ":")
-    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1)
-    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0)
+    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, C0A)
+    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, C0B)
     e("s_add_i32 %s, %s, -2" % (s(CNT), s(CNT)))
     e("s_cmp_gt_i32 %s, 0" % s(CNT))
     e("s_cbranch_scc1 %s" % L("top"))

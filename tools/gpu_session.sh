@@ -1,0 +1,34 @@
+#!/bin/bash
+# One GPU-box call of a development session:  bash tools/gpu_session.sh <tag> [what...]
+# what: tests | benchA | shard | trace | host     (default: all)
+TAG=${1:-s}; shift
+WHAT=${*:-tests benchA shard trace host}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT"; mkdir -p gpurun_out
+for w in $WHAT; do case $w in
+tests)
+  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/${TAG}_pytest.log)";;
+benchA)
+  timeout 400 python bench.py > gpurun_out/${TAG}_bench_A.json 2> gpurun_out/${TAG}_bench_A.err; echo "benchA rc=$?"
+  python - <<PY
+import json
+d=json.loads(open('gpurun_out/${TAG}_bench_A.json').read().strip().splitlines()[-1])
+print('A', d['value'], 'evals/s kernel us', d['roofline']['kernel_us_per_eval'], 'frac', d['roofline']['frac'], 'lib', d.get('library_route'), 'cpu', d['cpu_baseline'] and d['cpu_baseline']['value'])
+PY
+  ;;
+shard)
+  timeout 300 python bench.py --patterns 12500 --no-cpu-baseline > gpurun_out/${TAG}_bench_shard.json 2> gpurun_out/${TAG}_bench_shard.err; echo "shard rc=$?"
+  python - <<PY
+import json
+d=json.loads(open('gpurun_out/${TAG}_bench_shard.json').read().strip().splitlines()[-1])
+print('shard12500', d['value'], 'evals/s ms', d['ms_per_step'], 'kernel us', d['roofline']['kernel_us_per_eval'], 'lib', d.get('library_route'))
+PY
+  ;;
+trace)
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}_trace" -o kt -- \
+     python "$ROOT/bench.py" --patterns 12500 --steps 20 --warmup 3 --no-cpu-baseline --no-library-route > "$ROOT/gpurun_out/${TAG}_trace.json" 2> "$ROOT/gpurun_out/${TAG}_trace.err"; echo "trace rc=$?")
+  find gpurun_out/${TAG}_trace -name "*.db" -delete 2>/dev/null
+  python tools/timeline.py gpurun_out/${TAG}_trace 2>&1 | tail -40;;
+host)
+  BEAGLE_MI355_HOST_TIMING=1 timeout 200 python tools/step_profile.py 12500 2>&1 | tail -14;;
+esac; done
