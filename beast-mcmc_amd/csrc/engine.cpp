@@ -68,8 +68,8 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
-    bool strictWaits = false;                            // BEAGLE_MI355_STRICT_WAITS=1 at creation: a stage's wait does not count the previous
-                                                         // stage's stores as retiring behind its loads (runPlan)
+    bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
+                                                         // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)
     bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
     bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
     long statCherries = 0;
@@ -401,7 +401,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
             else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + in->statePairOff; in->statTipReads++; }
             if (m.smode != mi355::PS_NONE) {
                 int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scale = in->scale[m.scaleIdx]; }
+                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
                 else {
                     if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
                     in->statScaleReads++;
@@ -426,16 +426,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         if (ps.progCount & 1) w.push_back(nop);
         segs[si].progCount = (int)w.size() - segs[si].progStart;
         w.push_back(nop); w.push_back(nop);
-        // the wait of every stage: "at most N vector-memory instructions outstanding" with N = everything issued AFTER the
-        // stage's own loads: the stores of the previous micro-operation and the loads of the next one.  Loads and stores
-        // share the counter and are counted out strictly in issue order (tests/test_gpu_vmcnt_order.py: a younger store is
-        // never retired before an older load in > 1e9 lane-trials), so a stage does not have to wait for the previous stage's
-        // stores to be acknowledged.  A smaller N than the true number only waits longer (the table ends at 12).
-        // BEAGLE_MI355_STRICT_WAITS=1 does not use that observation: N = the loads of the next micro-operation only.  That
-        // is sufficient under the one ordering rule the ISA guides state for this counter — vector-memory LOADS return in
-        // the order they were issued: when at most N operations are outstanding and the N youngest loads are all younger
-        // than this stage's loads, an unfinished load of this stage would leave N + 1 unfinished — whatever the stores
-        // (of this or any earlier stage) do.  Costs the acknowledgement latency of four stores per stored node.
+        // the wait of every stage: "at most N vector-memory instructions outstanding".  Loads and stores share the counter.
+        // DEFAULT (strict): N = the loads of the NEXT micro-operation only.  Sufficient under the one ordering rule the ISA
+        // guides state for this counter — vector-memory LOADS return in the order they were issued: when at most N operations
+        // are outstanding and the N youngest loads are all younger than this stage's loads, an unfinished load of this stage
+        // would leave N + 1 unfinished, whatever the stores (of this or any earlier stage) do.
+        // BEAGLE_MI355_STRICT_WAITS=0: N also counts the previous micro-operation's stores, i.e. assumes that a younger store
+        // is never counted out before an older load.  That held in > 1e9 lane-trials (tests/test_gpu_vmcnt_order.py) and saves a
+        // stage the acknowledgement of four stores per stored node — 1 % of config A (profiles/r03_experiments.txt 7) — but it
+        // is an observation, not a documented guarantee, so it is not what ships by default.
+        // A smaller N than the true number only waits longer (the table ends at 12).
         for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
             const int stores = in->strictWaits ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
             w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
@@ -513,15 +513,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         size_t e = b + 1;
         while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
         int range = 0;
-        bool fast = paired && in->fastWalk;       // the assembly loop: aligned segments, no write-mode rescaling (kernels.h)
-        for (size_t i = b; i < e; i++) {
-            range = std::max(range, segs[i].pEnd - segs[i].pStart);
-            for (int k = plan.segs[i].progStart; fast && k < plan.segs[i].progStart + plan.segs[i].progCount; k++)
-                if (plan.prog[k].smode == mi355::PS_WRITE) fast = false;
-        }
+        const bool fast = paired && in->fastWalk;       // the assembly loop: segments aligned to 128 patterns (kernels.h)
+        for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         if (fast) {
             mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                   in->matStream, in->P, in->C);
+                                   in->matStream, in->P, in->C, (long)in->scaleStride);
             in->statFastWalks++;
         } else
             mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
@@ -1404,7 +1400,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
                      getenv("BEAGLE_MI355_HOLD_SLOTS") ? std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), mi355::walkHoldSlots(categoryCount)) : mi355::walkHoldSlots(categoryCount));
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
-    in->strictWaits = getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) != 0;
+    in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);
     in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());

@@ -62,6 +62,7 @@ inline int walkHoldSlots(int C) { return C <= 8 ? 3 : 2; }
 enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 // flags: what the kernel's fetch stage has to load for the micro-operation (WF_*), then the kinds
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
+// (bit 14 = WS_WRITE of the scale mode: the assembly loop tests it directly)
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
 // second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code (WF_WAIT8: vmcnt(8),
 // WF_WAIT12: vmcnt(12), neither: vmcnt(4))
@@ -71,12 +72,12 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
     double*        store;    // partials buffer the result is written to (WF_STORE)
-    double*        scale;    // WS_READ: the RECIPROCAL half of the scale buffer;  WS_WRITE: the buffer (factor half first)
+    const double*  scale;    // WS_READ: the RECIPROCAL half of the scale buffer; otherwise all-ones (the assembly loop multiplies unconditionally)
     const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles): read by
     const double*  m2;       // k_gatherMatrices, which lays them out as the stream the walk reads
     unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13 | waitJump << 16 (walkWaitJump)
     unsigned       pad0;
-    unsigned long long pad1;
+    double*        scaleW;   // WS_WRITE: the scale buffer that receives the factors (plain layout) and, recipOff doubles on, their reciprocals
 };
 static_assert(sizeof(WalkOp) == 64, "WalkOp layout");
 // Position of pattern p in a pair-interleaved per-pattern array (walk instances: compact tip states, reciprocal scale
@@ -115,9 +116,10 @@ void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, 
                  int P, int C, long recipOff);
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirements: every segment starts at a multiple of 128
-// patterns, no micro-operation rescales in write mode, and EVERY descriptor carries readable addresses in src1, src2 and
-// scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
-void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C);
+// patterns, and EVERY descriptor carries readable addresses in src1, src2 and scale even where unused (the small loads
+// are unconditional): all-missing tip states / all-one scale factors.
+void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
+                     long recipOff);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);

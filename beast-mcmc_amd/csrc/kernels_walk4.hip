@@ -12,9 +12,8 @@
 // Two kernels execute such programs (bit-identical results, tests/test_gpu_walk_kernels.py):
 //   k_walk4_fast  the main loop as ONE block of generated gfx950 assembly (tools/gen_walk4_fast.py, walk4_fast_loop.inc; the
 //                 design notes live in that generator) — every launch whose segments start at a multiple of 128 patterns
-//                 and that does not rescale in write mode;
-//   k_walk4       the C++ kernel below: everything else (write-mode rescaling: per-pattern maximum over all categories
-//                 through LDS and a barrier; partitions at arbitrary pattern offsets).
+//                 (which the engine arranges: partitions are padded internally);
+//   k_walk4       the C++ kernel below: the reference implementation of the same walk (BEAGLE_MI355_NO_FAST_WALK=1, tests).
 //
 // Common to both.  Workgroup = 128 consecutive patterns x all C categories; wave w = category w; a lane owns TWO patterns (here
 // p0 + l and p0 + 64 + l), so what a micro-operation costs per wave whatever the lanes do — scalar and branch instructions,
@@ -22,8 +21,8 @@
 // by hand: while micro-operation k computes, everything k+1 needs from memory is in flight.  The compiler cannot express
 // that (its s_waitcnt insertion assumes the worst path of the kind-dependent branches and drains the queue every
 // iteration), therefore every vector-memory instruction of the loop is inline assembly and the one wait per stage is EXACT:
-// "s_waitcnt vmcnt(N)", N = the vector-memory instructions issued after the loads of micro-operation k — the stores of k-1
-// and the loads of k+1 (loads and stores retire in issue order: tools/vmcnt_order_probe.hip) — which the host knows when it
+// "s_waitcnt vmcnt(N)", N = the loads of micro-operation k+1 (issued after those of k; loads return in issue order — with
+// BEAGLE_MI355_STRICT_WAITS=0 also the stores of k-1, see engine.cpp runPlan) — which the host knows when it
 // builds the program and passes in the descriptor; this kernel jumps into a table of s_waitcnt instructions.  Loads a
 // micro-operation does not need are BRANCHED around, not masked: a vector-memory instruction with 8 or 16 bytes per lane
 // occupies the CU's address unit for ~16 cycles whatever its EXEC mask or coalescing (tools/vmem_rate_probe.hip).
@@ -59,8 +58,8 @@ struct Fetched {
     double inva, invb;        // reciprocal scale factors of the pair (WF_INV)
 };                            // (the two branch matrices go straight to LDS: fetchIssue)
 
-struct Desc {                 // a WalkOp in SGPRs (9 dwords; the matrices come through the stream, not the descriptor)
-    u64 src1, src2, store, scale;
+struct Desc {                 // a WalkOp in SGPRs (11 dwords; the matrices come through the stream, not the descriptor)
+    u64 src1, src2, store, scale, scaleW;
     unsigned flags;
 };
 // scalar loads of exactly the dwords in use: an unused lane of a wider load would be a register the allocator hands out
@@ -71,6 +70,7 @@ __device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
     r.src1 = ((u64)a.s1 << 32) | a.s0; r.src2 = ((u64)a.s3 << 32) | a.s2; r.store = ((u64)a.s5 << 32) | a.s4;
     r.scale = ((u64)a.s7 << 32) | a.s6;
     r.flags = p[12];
+    r.scaleW = ((u64)p[15] << 32) | p[14];
     return r;
 }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
 #define WALK_STAGE(CUR, NXT, DCUR, DNXT, TB)                                                                                \
     {                                                                                                                     \
         const unsigned fl = DCUR.flags;                                                                                   \
-        const u64 dStore = DCUR.store, dScale = DCUR.scale, dSrc2 = DCUR.src2;                                            \
+        const u64 dStore = DCUR.store, dScale = DCUR.scaleW, dSrc2 = DCUR.src2;                                            \
         const int k1n = (DNXT.flags >> 5) & 7;         /* a hold-slot operand of the NEXT micro-operation is read now */  \
         if (k1n >= WK_H0) {                                                                                               \
             const v2d* h = holdBase + (size_t)(k1n - WK_H0) * C * 256;                                                    \
@@ -335,8 +335,8 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 // itself is one block of assembly with its own register map (tools/gen_walk4_fast.py says why and what it leaves to k_walk4).
 template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
-                                                             const v2d MI355_CONST* __restrict__ matStream, int P, int C) {
-    extern __shared__ v2d lds[];
+                                                             const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes) {
+    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[2][MAXC][320 B], exch[C][1 KiB] (write-mode rescaling)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
     const int p0 = sg.pStart + (int)blockIdx.x * 128;
@@ -351,26 +351,30 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     asm volatile(WALK4_FAST_ASM
                  : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
                      [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
-                     [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold)
+                     [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
+                     [exch] "s"(ldsBase + 2u * holdStride + 2u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
+                     [roff] "s"(recipOffBytes), [cat] "s"(c)
                  : WALK4_FAST_CLOBBERS);
 }
 
-void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C) {
+void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
+                     long recipOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)C * 1024;
+    const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

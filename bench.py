@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="patterns in the CPU-baseline sample (0 = sized for ~10-20 s of CPU work)")
+    ap.add_argument("--rescaling", default="dynamic", choices=["dynamic", "always"],
+                    help="dynamic (default, the metric's protocol): steady state = read mode, every 100th evaluation recomputes the factors; "
+                         "always: PartialsRescalingScheme ALWAYS, every evaluation rescales in write mode")
     ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
                     help="ranks: one process per GPU + torch.distributed all-reduce (default); library: one process, the engine's resource G+1")
     ap.add_argument("--no-library-route", action="store_true", help="do not append the in-library route's run to the line")
@@ -293,7 +296,8 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
     # `beagle.rescale` = 100 evaluations, every other evaluation READS the stored factors.
     # (With the delay on, this realistic low-divergence tree never underflows in fp64 and scaling would never
     # switch on: fewer bytes, an easier benchmark.)
-    kw = dict(resource_list=res, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    from beast_mcmc_amd.treelikelihood import RESCALE_ALWAYS
+    kw = dict(resource_list=res, rescaling=RESCALE_ALWAYS if args.rescaling == "always" else RESCALE_DYNAMIC, delay_rescaling=False)
     if sharded:
         tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, device=device, **kw)
         local = tl.local
@@ -404,8 +408,9 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic", "route": args.route,
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "
-                                   "DYNAMIC rescaling steady state, new eigen system + rates every step"
-                                   % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth()),
+                                   "%s, new eigen system + rates every step"
+                                   % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth(),
+                                      "ALWAYS rescaling (write mode every evaluation)" if args.rescaling == "always" else "DYNAMIC rescaling steady state"),
                        "caller": args.caller, "patterns_per_gpu": p_, "parallelism": ("pattern-shard x%d + 1 all-reduce (torch.distributed over RCCL, one process per GPU)" % n_gpus) if args.route == "ranks"
                                       else "pattern-shard x%d inside the library (resource G+1, ncclAllReduce), one process" % n_gpus,
                        "ops_per_eval": int(counters["last_op_count"]), "matrices_per_eval": int(counters["last_branch_count"])},

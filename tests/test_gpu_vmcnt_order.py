@@ -1,10 +1,10 @@
 """The hardware ordering the 4-state walk's waits rest on, and the switch that makes the engine independent of it.
 
-Default build: a stage waits with ``s_waitcnt vmcnt(N)`` where N counts the previous stage's STORES as retiring behind the
-stage's own (older) loads (engine.cpp runPlan, kernels_walk4.hip) — gfx9 counts loads and stores in one counter; the ISA
-guides promise in-order return only for loads among themselves.  tests/native/vmcnt_order_probe.hip looks for a
-counter-example in the four situations the kernels create (> 1e9 lane-trials); ``BEAGLE_MI355_STRICT_WAITS=1`` builds the
-wait from the next stage's loads only, which needs nothing but the documented rule, and must give the same bits."""
+A stage of the walk waits with ``s_waitcnt vmcnt(N)``; gfx9 counts loads and stores in one counter and the ISA guides promise
+in-order return only for loads among themselves.  The DEFAULT build takes N from the next stage's loads only, which needs
+nothing but that rule (engine.cpp runPlan).  ``BEAGLE_MI355_STRICT_WAITS=0`` also counts the previous stage's STORES as
+retiring behind the stage's own (older) loads — 1 % faster, resting on an observation: tests/native/vmcnt_order_probe.hip
+looks for a counter-example in the four situations the kernels create (> 1e9 lane-trials).  Both must give the same bits."""
 import os
 import re
 import subprocess

@@ -1,9 +1,10 @@
 """The two implementations of the 4-state pattern walk against each other and against the oracle.
 
-k_walk4_fast (the generated assembly loop, tools/gen_walk4_fast.py) runs every launch whose segments start at a multiple of
-128 patterns and that does not rescale in write mode; k_walk4 (C++) runs the rest.  They must produce the same bits: same
-mat-vec order, same products, same reciprocal scaling — the difference is the instruction stream, the lane <-> pattern
-assignment and the shape of the stores.  Checked here for every rate-category bracket (kernel instantiations for <= 4,
+k_walk4_fast (the generated assembly loop, tools/gen_walk4_fast.py) runs every launch of a default instance — read mode,
+write-mode rescaling (LDS exchange across the category waves, two barriers, a true division) and no scaling alike; k_walk4
+(C++) is the reference implementation (BEAGLE_MI355_NO_FAST_WALK=1).  They must produce the same bits: same mat-vec order,
+same products, same factors and reciprocals — the difference is the instruction stream, the lane <-> pattern assignment and
+the shape of the stores.  Checked here for every rate-category bracket (kernel instantiations for <= 4,
 <= 8, <= 16 categories), ragged pattern counts (the masked last workgroup), all tree shapes (hold slots, partials
 re-read from memory, both children in memory) and the read-mode steady state of DYNAMIC rescaling."""
 import os
@@ -13,7 +14,8 @@ import pytest
 
 import beast_mcmc_amd as bm
 import helpers
-from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC, RESCALE_NONE, POST_ORDER, REVERSE_LEVEL_ORDER
+from beast_mcmc_amd.treelikelihood import (BeagleTreeLikelihood, RESCALE_ALWAYS, RESCALE_DYNAMIC, RESCALE_NONE, POST_ORDER,
+                                           REVERSE_LEVEL_ORDER)
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-10
@@ -32,26 +34,28 @@ def evaluate(wl, fast, scheme, traversal, nodes):
             os.environ["BEAGLE_MI355_NO_FAST_WALK"] = old
     raw = bm.beagle.Beagle.attach(tl)
     raw.kernelTimer(True)
-    first = tl.getLogLikelihood()          # DYNAMIC: rescaling in write mode (k_walk4 in both runs)
+    first = tl.getLogLikelihood()          # DYNAMIC / ALWAYS: rescaling in write mode
     tl.makeDirty()
-    lnl = tl.getLogLikelihood()            # read mode / no scaling: the assembly loop when `fast`
+    lnl = tl.getLogLikelihood()            # DYNAMIC: read mode;  ALWAYS: write mode again;  NONE: no scaling
     stats = raw.walkStats()
     raw.kernelTimer(False)
     site = tl.getSiteLogLikelihoods().copy()
     parts = [raw.getPartials(tl.node_buffer_index(n), bm.beagle.NONE).copy() for n in nodes]
+    if scheme != RESCALE_NONE:             # the factors themselves (log of what the rescaling operations stored)
+        parts += [raw.getLogScaleFactors(tl.node_scale_index(n)).copy() for n in nodes]
     tl.close()
     return first, lnl, site, parts, stats
 
 
 @pytest.mark.parametrize("C,T,P", [(4, 60, 1000), (1, 33, 129), (3, 25, 127), (8, 20, 700), (16, 12, 300), (5, 90, 2049)])
-@pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_DYNAMIC])
+@pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_DYNAMIC, RESCALE_ALWAYS])
 @pytest.mark.parametrize("kind,traversal", [("coalescent", REVERSE_LEVEL_ORDER), ("yule", POST_ORDER), ("caterpillar", POST_ORDER)])
 def test_assembly_loop_equals_cpp_kernel_bit_for_bit(C, T, P, scheme, kind, traversal, oracle_lib):
     wl = helpers.random_workload(T, P, 4, C, seed=900 + C + T, tree_kind=kind)
     nodes = list(range(wl.tree.tip_count, wl.tree.node_count))
     f0, fl, fs, fp, fstats = evaluate(wl, True, scheme, traversal, nodes)
     g0, gl, gs, gp, gstats = evaluate(wl, False, scheme, traversal, nodes)
-    assert fstats["fast_walks"] > 0 and gstats["fast_walks"] == 0          # each run really used its kernel
+    assert fstats["fast_walks"] == fstats["walks"] > 0 and gstats["fast_walks"] == 0          # each run really used its kernel
     assert f0 == g0 and fl == gl
     assert np.array_equal(fs, gs)
     for a, b in zip(fp, gp):

@@ -10,9 +10,10 @@ hand-pipelined loads).  This loop does the same work in ~100, with 2-3 taken bra
 half of a stage needs from a descriptor is stashed in three scalar registers when the fetch half has used it, so one
 descriptor register set serves the two-deep software pipeline.
 
-It covers every micro-operation except write-mode rescaling (WS_WRITE: LDS exchange + barrier + division) and segments
-that do not start at a multiple of 128 patterns; launches containing those use the C++ kernel k_walk4, which computes the
-same values bit for bit.
+It covers every micro-operation, write-mode rescaling included (rescale_block: LDS exchange across the category waves, two
+barriers, a true division).  What it requires is that every segment starts at a multiple of 128 patterns — the engine pads
+partitions internally to arrange that; the C++ kernel k_walk4 computes the same values bit for bit and is the reference
+implementation (BEAGLE_MI355_NO_FAST_WALK=1, tests/test_gpu_walk_kernels.py).
 
 Run: python tools/gen_walk4_fast.py   (rewrites the .inc; tests/test_planner_native.py checks it is up to date)"""
 import os
@@ -35,22 +36,24 @@ H2 = 106                      # the third hold slot lives in registers (LDS hold
 NV = 124
 # scalar (s32..s35 are left to the compiler)
 DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 25, 26, 27, 28, 29, 30, 31
-D, DFL, CM160 = 36, 44, 45    # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags
-SA_FL, SA_STORE, SA_SRC2 = 46, 48, 50
-SB_FL, SB_STORE, SB_SRC2 = 52, 54, 56
-MASK = 58                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
-C0A, C0B = 68, 84             # column 0 of the two branch matrices of the even / odd micro-operations (8 + 8 SGPRs each): M[i][0]
-S_FIRST, S_LAST = 20, 99
+D, DFL, CM160, DW = 36, 44, 45, 46    # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags; the scale buffer a rescaling operation writes
+SA_FL, SA_STORE, SA_SRC2, SA_SCALEW = 48, 50, 52, 54
+SB_FL, SB_STORE, SB_SRC2, SB_SCALEW = 56, 58, 60, 62
+MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
+VALA, VALB = 72, 74           # lanes whose first / second pattern lies inside the range (scale-factor stores)
+DIVS, SCNT, EXCH, NCAT, ROFF = 76, 78, 79, 80, 81
+C0A, C0B = 84, 100            # (WALK4_SCOL) column 0 of the two branch matrices of the even / odd micro-operations: M[i][0]
+S_FIRST = 20
 
 # flag bits (kernels.h)
-B_X, B_T1, B_T2, B_STORE, B_HSLOT1 = 0, 1, 2, 4, 12
+B_X, B_T1, B_T2, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 4, 12, 14
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
 
 STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
 # A/B switches (tools/build_variant.sh): both give the same bits
 # (measured on config A and the 12 500-pattern shard, profiles/r03_experiments.txt: neither changes the time — the loop is not
 # bound by its vector-instruction count or by LDS round trips — so both stay off and the round-2 stream is what ships)
-SCOL = os.environ.get("WALK4_SCOL", "0") != "0"             # first term of every mat-vec row from SGPRs (no zeroing moves)
+SCOL = False                                                # (first term of every mat-vec row from SGPRs: 32 more scalar registers than are left now)
 LDSBATCH = os.environ.get("WALK4_LDSBATCH", "0") != "0"     # every LDS read of a stage is issued before its one LDS wait
 EARLYDESC = os.environ.get("WALK4_EARLYDESC", "0") != "0"   # descriptor k + 2 is requested right after the fetch of k + 1 has used the registers
 # TIMING EXPERIMENTS ONLY (wrong results; tools/walk_floor.sh, profiles/r02_experiments.txt): comma-separated parts to leave out
@@ -112,7 +115,87 @@ def tip_columns(dst, t, tbl, off):
 outofline = []      # (label, [lines]) blocks placed after the loop
 
 
-def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
+def fdiv_one(out, den, d0, r, t, n0, q):
+    """out = 1.0 / den, correctly rounded: the sequence the compiler emits for a double division (k_walk4 has the same)."""
+    return ["v_div_scale_f64 %s, %s, %s, %s, 1.0" % (v(d0, 2), s(DIVS, 2), v(den, 2), v(den, 2)),
+            "v_rcp_f64_e32 %s, %s" % (v(r, 2), v(d0, 2)),
+            "s_nop 3",                              # a transcendental result must not be read by the very next vector instruction
+            "v_fma_f64 %s, -%s, %s, 1.0" % (v(t, 2), v(d0, 2), v(r, 2)),
+            "v_fmac_f64_e32 %s, %s, %s" % (v(r, 2), v(r, 2), v(t, 2)),
+            "v_fma_f64 %s, -%s, %s, 1.0" % (v(t, 2), v(d0, 2), v(r, 2)),
+            "v_fmac_f64_e32 %s, %s, %s" % (v(r, 2), v(r, 2), v(t, 2)),
+            "v_div_scale_f64 %s, vcc, 1.0, %s, 1.0" % (v(n0, 2), v(den, 2)),
+            "v_mul_f64 %s, %s, %s" % (v(q, 2), v(n0, 2), v(r, 2)),
+            "v_fma_f64 %s, -%s, %s, %s" % (v(t, 2), v(d0, 2), v(q, 2), v(n0, 2)),
+            "s_nop 3",
+            "v_div_fmas_f64 %s, %s, %s, %s" % (v(t, 2), v(t, 2), v(r, 2), v(q, 2)),
+            "v_div_fixup_f64 %s, %s, %s, 1.0" % (v(out, 2), v(t, 2), v(den, 2))]
+
+
+def rescale_block(tag, SSCALEW):
+    """Write-mode rescaling of the result in ACC (AbstractLikelihoodCore.java:406-440 applied unconditionally, as k_walk4):
+    per pattern the largest entry over the 4 states and ALL rate categories — one category per wave, exchanged through LDS
+    between two barriers —, a factor that is not positive becomes 1, the result is multiplied by the reciprocal (a true
+    division, so that the bits equal k_walk4's); the wave of category 0 stores the factor (plain layout) and the reciprocal
+    (pair-interleaved, ROFF bytes further on) of the lane's two patterns, then everything drains.  F and G are free here."""
+    MA, MB, RD, A2, B2, IA, IB = F, F + 2, F + 4, G, G + 2, G + 4, G + 6
+    d0, r, t, n0, q = F + 8, F + 10, F + 12, F + 14, G + 8
+    b = [L("wr" + tag) + ":"]
+    for m, base in ((MA, ACC), (MB, ACC + 8)):
+        b += ["v_max_f64 %s, 0, %s" % (v(m, 2), v(base, 2)),
+              "v_max_f64 %s, %s, %s" % (v(RD, 2), v(base + 2, 2), v(base + 4, 2)),
+              "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(RD, 2)),
+              "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(base + 6, 2))]
+    b += ["v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)),
+          "v_add_u32_e32 %s, %s, %s" % (v(T0), s(EXCH), v(T0)),           # exchange buffer: [category][lane] x 16 bytes
+          "s_lshl_b32 %s, %s, 10" % (s(ST), s(SCNT)),                       # (SCNT holds the wave's category outside the loop below)
+          "v_add_u32_e32 %s, %s, %s" % (v(T1), s(ST), v(T0)),
+          "ds_write_b128 %s, %s" % (v(T1), v(MA, 4)),
+          "s_waitcnt lgkmcnt(0)",
+          "s_barrier",
+          "v_mov_b64 %s, 0" % v(A2, 2), "v_mov_b64 %s, 0" % v(B2, 2),
+          "s_mov_b32 %s, %s" % (s(ST), s(NCAT)),
+          L("wrl" + tag) + ":",
+          "ds_read_b128 %s, %s" % (v(RD, 4), v(T0)),
+          "v_add_u32_e32 %s, 0x400, %s" % (v(T0), v(T0)),
+          "s_add_i32 %s, %s, -1" % (s(ST), s(ST)),
+          "s_waitcnt lgkmcnt(0)",
+          "v_max_f64 %s, %s, %s" % (v(A2, 2), v(A2, 2), v(RD, 2)),
+          "v_max_f64 %s, %s, %s" % (v(B2, 2), v(B2, 2), v(RD + 2, 2)),
+          "s_cmp_gt_i32 %s, 0" % s(ST),
+          "s_cbranch_scc1 %s" % L("wrl" + tag),
+          "s_barrier"]                                                      # the exchange buffer is free again
+    b.append("v_mov_b32_e32 %s, 0x3ff00000" % v(T1))                        # (a literal and VCC together exceed the constant bus)
+    for m in (A2, B2):                                                      # if (!(m > 0)) m = 1
+        b += ["v_cmp_lt_f64_e32 vcc, 0, %s" % v(m, 2),
+              "s_nop 1",
+              "v_cndmask_b32_e32 %s, %s, %s, vcc" % (v(m + 1), v(T1), v(m + 1)),
+              "v_cndmask_b32_e32 %s, 0, %s, vcc" % (v(m), v(m))]
+    b += fdiv_one(IA, A2, d0, r, t, n0, q)
+    b += fdiv_one(IB, B2, d0, r, t, n0, q)
+    for i in range(8):
+        b.append("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(IA if i < 4 else IB, 2)))
+    # category 0 stores: factor at 8 p (PA = 32 p for that wave), reciprocal at ROFF + 8 * (pair position)
+    b += ["s_cmp_lg_u32 %s, 0" % s(SCNT),
+          "s_cbranch_scc1 %s" % L("wrd" + tag),
+          "v_lshrrev_b32_e32 %s, 2, %s" % (v(T0), v(PA)),
+          "v_lshrrev_b32_e32 %s, 2, %s" % (v(T1), v(PB)),
+          "v_add_u32_e32 %s, %s, %s" % (v(RD), s(ROFF), v(SCALE)),
+          "s_mov_b64 exec, %s" % s(VALA, 2),
+          "global_store_dwordx2 %s, %s, %s" % (v(T0), v(A2, 2), s(SSCALEW, 2)),
+          "global_store_dwordx2 %s, %s, %s" % (v(RD), v(IA, 2), s(SSCALEW, 2)),
+          "s_mov_b64 exec, %s" % s(VALB, 2),
+          "global_store_dwordx2 %s, %s, %s" % (v(T1), v(B2, 2), s(SSCALEW, 2)),
+          "global_store_dwordx2 %s, %s, %s offset:8" % (v(RD), v(IB, 2), s(SSCALEW, 2)),
+          "s_mov_b64 exec, -1",
+          "s_nop 0",
+          L("wrd" + tag) + ":",
+          "s_waitcnt vmcnt(0)",
+          "s_branch %s" % L("wrb" + tag)]
+    return b
+
+
+def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
     """Issue everything the micro-operation described by D needs into pipeline slot (X, Tt1, Tt2, INV), stash what its
     compute stage needs, advance the stream."""
     e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD))
@@ -147,6 +230,7 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
     e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
     e("s_mov_b64 %s, %s" % (s(SSTORE, 2), s(D + 4, 2)))
     e("s_mov_b64 %s, %s" % (s(SSRC2, 2), s(D + 2, 2)))
+    e("s_mov_b64 %s, %s" % (s(SSCALEW, 2), s(DW, 2)))
     e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_X))
     e("s_cbranch_scc1 %s" % L("x" + tag))
     e(L("xb" + tag) + ":")
@@ -159,14 +243,15 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblDst):
     outofline.append(blk)
 
 
-def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext, c0set):
+def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext, c0set):
     """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
     following one is fetched into the other slot."""
     e("s_waitcnt lgkmcnt(0)")                       # the descriptor of the NEXT micro-operation (and LDS writes) have landed
-    fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, tblNext)
+    fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext)
     if EARLYDESC:   # descriptor k + 2, a whole stage before its use: its latency (a scalar-cache miss goes to L2) hides behind the wait below
         e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
         e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+        e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
         e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
         e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # wait for this micro-operation's loads: N = everything issued after them = 4 (+4 stores before, +4 partials loads now)
@@ -266,6 +351,7 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
     if not EARLYDESC:
         e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
         e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+        e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
     if SCOL:    # column 0 of both tables of micro-operation k + 2 (STRM points there since this stage's fetch) into the set this
         #         stage's mat-vecs have just finished with
         e("s_load_dwordx8 %s, %s, %s" % (s(c0set, 8), s(STRM, 2), s(CM0)))
@@ -277,6 +363,10 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, tblCur, spCur, nX, nT1, nT2
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WRITE))
+    e("s_cbranch_scc1 %s" % L("wr" + tag))
+    e(L("wrb" + tag) + ":")
+    outofline.append(rescale_block(tag, SSCALEW))
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE))
     e("s_cbranch_scc1 %s" % L("st" + tag))
     e(L("stb" + tag) + ":")
@@ -343,6 +433,10 @@ def build():
         e("s_mov_b64 %s, vcc" % s(MASK + 2 * j, 2))
     e("s_mov_b32 %s, %%[cM]" % s(CM0))
     e("s_add_u32 %s, %%[cM], 160" % s(CM160))
+    e("s_mov_b32 %s, %%[exch]" % s(EXCH))
+    e("s_mov_b32 %s, %%[ncat]" % s(NCAT))
+    e("s_mov_b32 %s, %%[roff]" % s(ROFF))
+    e("s_mov_b32 %s, %%[cat]" % s(SCNT))
     e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
     e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
     e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
@@ -352,6 +446,12 @@ def build():
     e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))
     e("v_add3_u32 %s, %s, %s, %%[p0]" % (v(T0), v(T0), v(T1)))           # first pattern of the lane
     e("v_add_u32_e32 %s, 64, %s" % (v(T1), v(T0)))                      # second
+    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T0))
+    e("s_nop 3")
+    e("s_mov_b64 %s, vcc" % s(VALA, 2))
+    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
+    e("s_nop 3")
+    e("s_mov_b64 %s, vcc" % s(VALB, 2))
     e("v_min_i32_e32 %s, %s, %s" % (v(T0), s(LAST), v(T0)))             # lanes past the end recompute the last pattern
     e("v_min_i32_e32 %s, %s, %s" % (v(T1), s(LAST), v(T1)))
     e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PA), v(T0)))
@@ -376,22 +476,24 @@ def build():
     # ---- prologue: fetch micro-operation 0 into slot A, descriptor 1 into D
     e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
     e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
+    e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
     e("s_waitcnt lgkmcnt(0)")
     if SCOL:
         e("s_load_dwordx8 %s, %s, %s" % (s(C0A, 8), s(STRM, 2), s(CM0)))
         e("s_load_dwordx8 %s, %s, %s" % (s(C0A + 8, 8), s(STRM, 2), s(CM160)))
-    fetch("p", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0)
+    fetch("p", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0)
     if SCOL:
         e("s_load_dwordx8 %s, %s, %s" % (s(C0B, 8), s(STRM, 2), s(CM0)))
         e("s_load_dwordx8 %s, %s, %s" % (s(C0B + 8, 8), s(STRM, 2), s(CM160)))
     e("s_load_dwordx8 %s, %s, 0x40" % (s(D, 8), s(DP, 2)))
     e("s_load_dword %s, %s, 0x70" % (s(DFL), s(DP, 2)))
+    e("s_load_dwordx2 %s, %s, 0x78" % (s(DW, 2), s(DP, 2)))
     e("s_add_u32 %s, %s, 0x80" % (s(DP), s(DP)))
     e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # ---- the loop: two stages
     e(L("top") + ":")
-    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, C0A)
-    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, TBL0, C0B)
+    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, C0A)
+    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, C0B)
     e("s_add_i32 %s, %s, -2" % (s(CNT), s(CNT)))
     e("s_cmp_gt_i32 %s, 0" % s(CNT))
     e("s_cbranch_scc1 %s" % L("top"))
@@ -411,7 +513,7 @@ def main():
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
-    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1) if i not in (32, 33, 34, 35)]
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else ROFF + 1)) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
     text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
     text.append("#define WALK4_FAST_VGPRS %d" % NV)
