@@ -54,6 +54,10 @@ struct Instance {
     size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals (pair-interleaved,
                                                          // kernels.h walkPairIndex)], this many doubles apart
     size_t statePairOff = 0;                             // walk instances: a tip's pair-interleaved states follow its plain ones, this many bytes on
+    // walk instances: position of pattern p in the pair-interleaved arrays (tip states, reciprocal scale factors).  They are
+    // laid out partition by partition, each padded to whole blocks of 128 patterns (kernels.h WalkSeg), so that the assembly
+    // loop runs whatever the caller's partition boundaries are; one partition: walkPairIndex(p).
+    std::vector<unsigned> pairPos; size_t pairLen = 0; std::vector<int> padStart; unsigned* dPairPos = nullptr;
     char* matStream = nullptr; size_t matStreamBytes = 0;   // walk instances: the matrix stream of the program being run (k_gatherMatrices)
     uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
                                                                  // micro-operation does not use (the assembly loop loads them unconditionally)
@@ -62,7 +66,7 @@ struct Instance {
     struct Resolved {
         long tag = 0, epoch = -1;
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
-        int maxRange = 0; bool paired = true;
+        int maxRange = 0;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
     } resolved[4];
@@ -211,7 +215,7 @@ int ensureScale(Instance* in, int idx) {
 int ensureStates(Instance* in, int idx) {
     if (in->tipStates[idx]) return 0;
     const size_t plain = ((size_t)in->P + 2 + 255) & ~(size_t)255;
-    const size_t bytes = in->walk ? 2 * plain : plain;      // walk instances: [plain | pair-interleaved] (the latter is what the walk reads)
+    const size_t bytes = in->walk ? plain + ((in->pairLen + 255) & ~(size_t)255) : plain;      // walk instances: [plain | pair-interleaved] (the latter is what the walk reads)
     in->statePairOff = plain;
     if (in->stateSlabLeft == 0) {
         const int n = std::max(1, std::min(in->compactCount, 1024));
@@ -326,9 +330,29 @@ inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearV
 inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
 inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X] = on ? 1 : 0; }
 
+// The pair-interleaved layout for the instance's current partitions (Instance::pairPos), and the scale-buffer stride that
+// holds either half ([factors, plain | reciprocals, pair-interleaved]).
+void setPairLayout(Instance* in) {
+    const int K = in->partitionCount;
+    in->padStart.assign(K, 0);
+    in->pairPos.assign((size_t)in->P, 0u);
+    size_t at = 0;
+    // partitions in pattern order (they are contiguous ranges; an empty one takes no room)
+    std::vector<int> order(K);
+    for (int k = 0; k < K; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return in->partStart[a] < in->partStart[b]; });
+    for (int k : order) {
+        in->padStart[k] = (int)at;
+        for (int p = in->partStart[k]; p < in->partEnd[k]; p++) in->pairPos[p] = (unsigned)(at + mi355::walkPairIndex((size_t)(p - in->partStart[k])));
+        at += ((size_t)(in->partEnd[k] - in->partStart[k]) + 127) & ~(size_t)127;
+    }
+    in->pairLen = std::max<size_t>(at, 128);
+    in->scaleStride = (std::max<size_t>((size_t)in->P, in->pairLen) + 2 + 127) & ~(size_t)127;
+}
+
 int ensureWalkDummies(Instance* in) {
     if (in->dummyTips) return 0;
-    const size_t tipBytes = (((size_t)in->P + 127) & ~(size_t)127) + 256, scaleBytes = in->scaleStride * sizeof(double);
+    const size_t tipBytes = in->pairLen + 256, scaleBytes = in->scaleStride * sizeof(double);
     void* p = nullptr;
     int rc = devAlloc(in, &p, ((tipBytes + 255) & ~(size_t)255) + scaleBytes); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(p, in->S, tipBytes, in->stream));
@@ -361,9 +385,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
     std::vector<mi355::WalkSeg> segsLocal;
     std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
     int maxRange = 0;
-    bool paired = true;                            // every segment starts at a multiple of 128 patterns (kernels_walk4.hip)
     if (reuse) {
-        maxRange = slot->maxRange; paired = slot->paired;
+        maxRange = slot->maxRange;
         in->statMemReads += slot->memReads; in->statTipReads += slot->tipReads; in->statScaleReads += slot->scaleReads;
         in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
     } else {
@@ -379,7 +402,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
     nop.m1 = in->matrices; nop.m2 = in->matrices;
     nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
-    for (const mi355::PlanSeg& ps : plan.segs) if (in->partStart[ps.partition] % 128) paired = false;
     for (size_t si = 0; si < plan.segs.size(); si++) {
         const mi355::PlanSeg& ps = plan.segs[si];
         segs[si].progStart = (int)w.size();
@@ -443,11 +465,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
             const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
             if (code == 1) w[i].flags |= mi355::WF_WAIT8; else if (code == 2) w[i].flags |= mi355::WF_WAIT12;
         }
-        segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition];
+        segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
     if (slot) {
-        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange; slot->paired = paired;
+        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
         slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
     }
@@ -513,7 +535,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
         size_t e = b + 1;
         while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
         int range = 0;
-        const bool fast = paired && in->fastWalk;       // the assembly loop: segments aligned to 128 patterns (kernels.h)
+        const bool fast = in->fastWalk;                 // the assembly loop (BEAGLE_MI355_NO_FAST_WALK=1: the C++ reference kernel)
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         if (fast) {
             mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
@@ -1401,7 +1423,6 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);
-    in->scaleStride = ((size_t)patternCount + 2 + 127) & ~(size_t)127;    // whole blocks of 128 patterns (pair-interleaved reciprocals)
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
@@ -1412,6 +1433,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->scale.assign(std::max(1, scaleBufferCount), nullptr);
     in->scaleIsRaw.assign(std::max(1, scaleBufferCount), 0);
     in->partStart.assign(1, 0); in->partEnd.assign(1, patternCount);
+    setPairLayout(in);                                                    // one partition: whole blocks of 128 patterns
     in->wStamp.assign(partialsBufferCount, 0); in->wLevel.assign(partialsBufferCount, 0); in->wOp.assign(partialsBufferCount, 0);
     in->rStamp.assign(partialsBufferCount, 0); in->rLevel.assign(partialsBufferCount, 0);
     in->resourceName = res->names[device + 1];
@@ -1511,6 +1533,35 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     }
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
+    if (in->walk) {
+        // the pair-interleaved arrays follow the partitions (Instance::pairPos): what exists already — tips are uploaded before
+        // this call, MultiPartitionDataLikelihoodDelegate.java:544-553 — moves to the new layout on the device
+        setPairLayout(in);
+        if (!in->dPairPos) { int rc = devAlloc(in, (void**)&in->dPairPos, (size_t)in->P * sizeof(unsigned)); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipMemcpy(in->dPairPos, in->pairPos.data(), (size_t)in->P * sizeof(unsigned), hipMemcpyHostToDevice));
+        in->stateSlabLeft = 0; in->scaleSlabLeft = 0;                      // new slabs: the element sizes changed
+        for (int t = 0; t < in->partialsCount; t++) {
+            uint8_t* old = in->tipStates[t];
+            if (!old) continue;
+            in->tipStates[t] = nullptr;
+            int rc = ensureStates(in, t); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(in->tipStates[t] + in->statePairOff, in->S, in->pairLen, in->stream));
+            mi355::launchRelayoutStates(in->stream, old, in->tipStates[t], in->tipStates[t] + in->statePairOff, in->dPairPos, in->P);
+        }
+        for (int k = 0; k < (int)in->scale.size(); k++) {
+            double* old = in->scale[k];
+            if (!old) continue;
+            const char raw = in->scaleIsRaw[k];
+            in->scale[k] = nullptr;
+            int rc = ensureScale(in, k); if (rc) return rc;                // (zero-filled)
+            in->scaleIsRaw[k] = raw;
+            HIP_TRY(hipMemcpyAsync(in->scale[k], old, (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+            if (raw) mi355::launchRecipFromFactors(in->stream, in->scale[k], in->scale[k] + in->scaleStride, in->dPairPos, in->P);
+        }
+        in->dummyTips = nullptr; in->onesScale = nullptr;                  // re-made at their new sizes on first use
+        HIP_TRY(hipGetLastError());
+    }
     const size_t n = (size_t)in->partialsCount * partitionCount;
     in->wStamp.assign(n, 0); in->wLevel.assign(n, 0); in->rStamp.assign(n, 0); in->rLevel.assign(n, 0); in->wOp.assign(n, 0);
     in->stamp = 0;
@@ -1532,11 +1583,10 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates) {
     }
     // walk instances: plain states (pre-order kernels, getTipStates), then the pair-interleaved copy the walk reads; the
     // padding of the last block of 128 is "missing"
-    const size_t padded = ((size_t)in->P + 127) & ~(size_t)127;
-    std::vector<uint8_t> s(in->statePairOff + padded, (uint8_t)in->S);
+    std::vector<uint8_t> s(in->statePairOff + in->pairLen, (uint8_t)in->S);
     for (int p = 0; p < in->P; p++) {
         const uint8_t v = (inStates[p] >= 0 && inStates[p] < in->S) ? (uint8_t)inStates[p] : (uint8_t)in->S;
-        s[p] = v; s[in->statePairOff + mi355::walkPairIndex((size_t)p)] = v;
+        s[p] = v; s[in->statePairOff + in->pairPos[p]] = v;
     }
     return upload(in, in->tipStates[tipIndex], s.data(), s.size());
 }

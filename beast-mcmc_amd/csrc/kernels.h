@@ -108,16 +108,18 @@ inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
 // software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
-struct WalkSeg { int progStart, progCount, pStart, pEnd; };
+// tStart: where the segment's patterns begin in the PAIR-INTERLEAVED arrays — those are laid out partition by partition, every
+// partition padded to whole blocks of 128 (engine.cpp pairPos), so that a lane's pair is one aligned load wherever a
+// partition starts; partials and plain per-pattern arrays keep the caller's pattern numbering.
+struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, pad0, pad1, pad2; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
 // patterns, 64 apart; its tip states and reciprocal scale factors are stored pair-interleaved (walkPairIndex).
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream,
                  int P, int C, long recipOff);
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
-// The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirements: every segment starts at a multiple of 128
-// patterns, and EVERY descriptor carries readable addresses in src1, src2 and scale even where unused (the small loads
-// are unconditional): all-missing tip states / all-one scale factors.
+// The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
+// src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff);
 
@@ -159,6 +161,10 @@ void launchFill(hipStream_t stream, double* dst, double value, int pStart, int p
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
 // Read-back: out[c][p][i] (API layout) = partials * scale, from either device layout.  `scale` may be
 // nullptr; scaleIsRaw: the buffer holds raw factors (else logs: the factor is exp).  One pass, then a single D2H.
+// walk instances, after the pattern partitions changed: pair[pos[p]] = plain[p] for a tip's states (the rest "missing"), and
+// the reciprocal half of a raw scale buffer rebuilt from its factors
+void launchRelayoutStates(hipStream_t stream, const uint8_t* oldPlain, uint8_t* newPlain, uint8_t* newPair, const unsigned* dPairPos, int P);
+void launchRecipFromFactors(hipStream_t stream, const double* factors, double* recip, const unsigned* dPairPos, int P);
 void launchExportPartials(hipStream_t stream, const double* partials, const double* scale, int scaleIsRaw, double* out,
                           int P, int S, int C, bool tiled);
 // dst[c][p][i] = src[p][i] for every category (setTipPartials replication)

@@ -360,6 +360,23 @@ void launchExportPartials(hipStream_t stream, const double* partials, const doub
     hipLaunchKernelGGL(k_exportPartials, dim3(blocks), dim3(256), 0, stream, partials, scale, scaleIsRaw, out, P, S, C, tiled ? 1 : 0);
 }
 
+__global__ void k_relayoutStates(const uint8_t* oldPlain, uint8_t* newPlain, uint8_t* newPair, const unsigned* pos, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const uint8_t v = oldPlain[p];
+    newPlain[p] = v; newPair[pos[p]] = v;
+}
+void launchRelayoutStates(hipStream_t stream, const uint8_t* oldPlain, uint8_t* newPlain, uint8_t* newPair, const unsigned* dPairPos, int P) {
+    hipLaunchKernelGGL(k_relayoutStates, dim3((P + 255) / 256), dim3(256), 0, stream, oldPlain, newPlain, newPair, dPairPos, P);
+}
+__global__ void k_recipFromFactors(const double* f, double* recip, const unsigned* pos, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) recip[pos[p]] = 1.0 / f[p];
+}
+void launchRecipFromFactors(hipStream_t stream, const double* factors, double* recip, const unsigned* dPairPos, int P) {
+    hipLaunchKernelGGL(k_recipFromFactors, dim3((P + 255) / 256), dim3(256), 0, stream, factors, recip, dPairPos, P);
+}
+
 __global__ void k_replicate(const double* src, double* dst, size_t n, int C) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;

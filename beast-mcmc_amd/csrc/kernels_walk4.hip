@@ -204,7 +204,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
                                                       const v2d MI355_CONST* __restrict__ matStream, int P, int C, long recipOff) {
     extern __shared__ v2d lds[];                      // hold[walkHoldSlots(C)][C][4][64] (v2d), exch[C][128] (double), table[2][MAXT / 64][320 B]
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
-    const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd;
+    const int progStart = sg.progStart, progCount = sg.progCount, pStart = sg.pStart, pEnd = sg.pEnd, tStart = sg.tStart;
     const int p0 = pStart + (int)blockIdx.x * 128;
     if (p0 >= pEnd) return;                           // the whole workgroup
     const int lane = threadIdx.x & 63;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     // loop-invariant 32-bit byte offsets: every address of the loop is (64-bit SGPR base from the descriptor) + one of these
     LaneOffsets o;
     o.partA = (unsigned)(((size_t)c * P + qa) * 32); o.partB = (unsigned)(((size_t)c * P + qb) * 32);
-    o.tipA = (unsigned)walkPairIndex((size_t)qa); o.tipB = (unsigned)walkPairIndex((size_t)qb); o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u;
+    o.tipA = (unsigned)tStart + (unsigned)walkPairIndex((size_t)(qa - pStart)); o.tipB = (unsigned)tStart + (unsigned)walkPairIndex((size_t)(qb - pStart));
+    o.scaleA = o.tipA * 8u; o.scaleB = o.tipB * 8u;
     o.mat = (unsigned)(c * WALK_TABLE_BYTES + lane * 16);          // lanes 0..19 copy the wave's 320-byte table
     v2d* holdBase = lds + (size_t)c * 256 + lane;     // + slot * C * 256, quarter q at + 64 q
     double* exch = reinterpret_cast<double*>(lds + (size_t)walkHoldSlots(C) * C * 256);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                      [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
                      [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
                      [exch] "s"(ldsBase + 2u * holdStride + 2u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
-                     [roff] "s"(recipOffBytes), [cat] "s"(c)
+                     [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(sg.tStart + (int)blockIdx.x * 128)
                  : WALK4_FAST_CLOBBERS);
 }
 

@@ -459,7 +459,7 @@ def build():
     e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PA), v(PA)))
     e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PB), v(PB)))
     e("v_lshlrev_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))
-    e("v_add_u32_e32 %s, %%[p0], %s" % (v(TIP), v(T0)))                  # position of the pair in the interleaved layouts
+    e("v_add_u32_e32 %s, %%[t0], %s" % (v(TIP), v(T0)))                  # position of the pair in the interleaved layouts (t0: kernels.h WalkSeg)
     e("v_lshlrev_b32_e32 %s, 3, %s" % (v(SCALE), v(TIP)))
     e("v_lshlrev_b32_e32 %s, 4, %s" % (v(OM), v(LANE)))
     e("v_add_u32_e32 %s, %%[cM], %s" % (v(OM), v(OM)))
