@@ -551,7 +551,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t 
     return 0;
 }
 
-// Give every (virtual) buffer of `xs` its real partials: one program, one launch.
+// Give every definition of `xs` its real partials: one program, one launch.  xs are definition KEYS (planner.h: buffer x
+// partitionCount + partition; the buffer index itself on an instance with one partition).
 int materializeCherries(Instance* in, const std::vector<int>& xs);
 int materializeList(Instance* in, const std::vector<int>& xs) {
     if (!in->virt || xs.empty()) return 0;
@@ -560,9 +561,11 @@ int materializeList(Instance* in, const std::vector<int>& xs) {
     in->planner.planMaterialize(xs, mp);
     return runPlan(in, mp);
 }
-int materializeVirtual(Instance* in, int X) {
+int materializeVirtual(Instance* in, int X) {         // every partition of buffer X
     if (!isVirt(in, X)) return 0;
-    return materializeList(in, std::vector<int>(1, X));
+    std::vector<int> keys;
+    in->planner.keysOf(X, keys);
+    return materializeList(in, keys);
 }
 int materializeScaleUsers(Instance* in, int scaleIdx) {
     if (!in->virt || in->planner.scaleUsers(scaleIdx).empty()) return 0;
@@ -635,7 +638,9 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
         in->hostPrepUs += usSince(t1); t1 = Clock::now();
         const long hitsBefore = in->planner.cacheHits;
-        int rc = in->planner.plan(sub, n, tuple, parts, parts == 1 && tuple == BEAGLE_OP_COUNT, in->plan, walkChunkOps(in, n));
+        // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
+        const bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
+        int rc = in->planner.plan(sub, n, tuple, parts, allowVirtual, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
         const bool hit = in->planner.cacheHits != hitsBefore;
         { const double us = usSince(t1); in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
@@ -1533,6 +1538,16 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     }
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
+    if (in->walk) in->planner.setPartitionCount(partitionCount);
+    if (in->walk && in->virt) {
+        // definitions are kept per (buffer, partition): more snapshot slots behind the caller's matrices
+        const size_t per = (size_t)in->C * in->S * in->S, slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());
+        double* grown = nullptr;
+        int rcm = devAlloc(in, (void**)&grown, slots * per * sizeof(double)); if (rcm) return rcm;
+        HIP_TRY(hipMemsetAsync(grown, 0, slots * per * sizeof(double), in->stream));
+        HIP_TRY(hipMemcpyAsync(grown, in->matrices, (size_t)std::max(1, in->matrixCount) * per * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+        in->matrices = grown;                              // (the old block stays owned by the instance until it is destroyed)
+    }
     if (in->walk) {
         // the pair-interleaved arrays follow the partitions (Instance::pairPos): what exists already — tips are uploaded before
         // this call, MultiPartitionDataLikelihoodDelegate.java:544-553 — moves to the new layout on the device
@@ -1653,7 +1668,7 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
         const int b = bufferIndices[k];
         if (badIndex(b, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
         if (scaleIndices && scaleIndices[k] != BEAGLE_OP_NONE && badIndex(scaleIndices[k], in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, b)) need.push_back(b);
+        if (isVirt(in, b)) in->planner.keysOf(b, need);
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     const size_t elems = (size_t)in->C * in->P * in->S, bytes = elems * sizeof(double);

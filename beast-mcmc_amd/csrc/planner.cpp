@@ -18,6 +18,7 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
     partialsCount_ = partialsCount; tipCount_ = tipCount; matrixCount_ = matrixCount; scaleCount_ = std::max(1, scaleCount);
     maxSteps_ = std::max(1, std::min(maxVirtSteps, PLAN_MAX_STEPS));
     enabled_ = virtualEnabled;
+    keyParts_ = 1;
     virt_.assign(partialsCount, VirtDef());
     tagOf_.assign(partialsCount, -1);
     tipUsers_.assign(partialsCount, std::vector<int>());
@@ -28,7 +29,16 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
     stamp_ = 0; virtVersion_ = 0;
 }
 
-void WalkPlanner::clearVirtual(int X) {
+void WalkPlanner::setPartitionCount(int parts) {
+    keyParts_ = std::max(1, parts);
+    virt_.assign((size_t)partialsCount_ * keyParts_, VirtDef());
+    tagOf_.assign((size_t)partialsCount_ * keyParts_, -1);
+    for (auto& u : tipUsers_) u.clear();
+    for (auto& u : scaleUsers_) u.clear();
+    for (CacheEntry& e : cache_) e.valid = false;
+}
+
+void WalkPlanner::clearVirtualKey(int X) {
     VirtDef& v = virt_[X];
     if (!v.on) return;
     auto drop = [X](std::vector<int>& u) { u.erase(std::remove(u.begin(), u.end(), X), u.end()); };
@@ -117,7 +127,7 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool ti
 bool WalkPlanner::defineCherry(int X, int tipA, int mA, int tipB, int mB, int scaleIdx, std::vector<int>& snapPairs) {
     if (!enabled_ || !compactTip[tipA] || !compactTip[tipB]) return false;
     stamp_++;
-    if (virt_[X].on) clearVirtual(X);
+    if (virt_[X].on) clearVirtualKey(X);
     if (!buildVirtual(X, tipA, true, mA, tipB, true, mB, scaleIdx, snapPairs)) return false;
     VirtDef& nv = virt_[X];
     nv.version = ++virtVersion_;
@@ -149,10 +159,13 @@ int WalkPlanner::hazardFreePrefix(const int* ops, int begin, int count, int tupl
 void WalkPlanner::mustMaterializeBefore(const int* ops, int count, int tuple, std::vector<int>& out) {
     if (!enabled_) return;
     stamp_++;
-    for (int k = 0; k < count; k++) wStamp_[ops[(size_t)k * tuple]] = stamp_;
+    const size_t nKeys = (size_t)partialsCount_ * keyParts_;
+    if (wStamp_.size() < nKeys) { wStamp_.assign(nKeys, 0); rStamp_.assign(nKeys, 0); wOp_.assign(nKeys, 0); }
+    auto keyOf = [&](const int* op) { return (size_t)op[0] * keyParts_ + (tuple > 7 ? op[7] : 0); };
+    for (int k = 0; k < count; k++) wStamp_[keyOf(ops + (size_t)k * tuple)] = stamp_;
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * tuple;
-        if ((op[3] == op[0] || op[5] == op[0]) && virt_[op[0]].on) out.push_back(op[0]);     // in-place update of a virtual buffer
+        if ((op[3] == op[0] || op[5] == op[0]) && virt_[keyOf(op)].on) out.push_back((int)keyOf(op));     // in-place update of a virtual buffer
         const int wS = op[1];
         if (wS == OP_NONE || wS < 0 || wS >= scaleCount_) continue;
         for (int u : scaleUsers_[wS])
@@ -162,7 +175,7 @@ void WalkPlanner::mustMaterializeBefore(const int* ops, int count, int tuple, st
 
 // ---- emission ----------------------------------------------------------------------------------------------------
 namespace {
-struct Child { int cls, buf, mat, prod, need, size; };
+struct Child { int cls, buf, mat, prod, need, size, vkey; };      // vkey: definition key of (buf, the op's partition)
 inline MicroOp blankOp() {
     MicroOp m; m.storeBuf = PLAN_NONE; m.k1 = PK_MEM; m.a1 = 0; m.k2 = PK_MEM; m.a2 = 0; m.mat1 = 0; m.mat2 = 0;
     m.scaleIdx = PLAN_NONE; m.smode = PS_NONE; m.hold = 0;
@@ -201,9 +214,10 @@ void WalkPlanner::emitVirtualStep(int buf, int idx, unsigned freeMask, bool writ
     }
     if (st.scaleIdx >= 0) {
         m.scaleIdx = st.scaleIdx;
-        const bool w = writeMode && sWStamp_[st.scaleIdx] == stamp_;
+        const size_t sk = (size_t)st.scaleIdx * parts_ + partitionOf(buf);      // scale-buffer use is tracked per partition
+        const bool w = writeMode && sWStamp_[sk] == stamp_;
         m.smode = w ? PS_WRITE : PS_READ;
-        if (w) sDone_[st.scaleIdx] = stamp_;
+        if (w) sDone_[sk] = stamp_;
     }
     out.prog.push_back(m);
 }
@@ -229,15 +243,15 @@ void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
                 Child& c = f.ch[w];
                 c.buf = w ? o.c2 : o.c1; c.mat = w ? o.m2 : o.m1;
                 const bool tip = w ? o.tip2 : o.tip1;
-                c.prod = -1; c.need = 0; c.size = 0;
+                c.prod = -1; c.need = 0; c.size = 0; c.vkey = key(c.buf, o.part);
                 if (tip) { c.cls = CL_TIPS; continue; }
                 const int prod = w ? prod2_[f.j] : prod1_[f.j];
                 if (prod >= 0) {
                     const OpInfo& p = info_[prod];
-                    if (p.virtDest) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); c.size = 0; }
+                    if (p.virtDest) { c.cls = CL_VIRT; c.need = virtNeed(c.vkey); c.size = 0; }
                     else if (p.emitted) c.cls = CL_MEM;
                     else { c.cls = CL_REAL; c.prod = prod; c.need = p.need; c.size = p.size; }
-                } else if (virt_[c.buf].on) { c.cls = CL_VIRT; c.need = virtNeed(c.buf); }
+                } else if (virt_[c.vkey].on) { c.cls = CL_VIRT; c.need = virtNeed(c.vkey); }
                 else c.cls = CL_MEM;
             }
             const bool e0 = f.ch[0].cls >= CL_VIRT, e1 = f.ch[1].cls >= CL_VIRT;
@@ -254,7 +268,7 @@ void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
                 if (l.cls == CL_MEM) lastMemReads++;
                 f.m.k2 = PK_ACC; f.m.mat2 = e.mat;
                 f.phase = 9;
-                if (e.cls == CL_VIRT) emitVirtual(e.buf, f.freeMask, true, out);
+                if (e.cls == CL_VIRT) emitVirtual(e.vkey, f.freeMask, true, out);
                 else { push(e.prod, f.freeMask); continue; }
             } else {
                 const int F = popcount2(f.freeMask);
@@ -273,7 +287,7 @@ void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
                 }
                 f.phase = 1;
                 const Child a = ch[f.first];
-                if (a.cls == CL_VIRT) emitVirtual(a.buf, f.freeMask, true, out);
+                if (a.cls == CL_VIRT) emitVirtual(a.vkey, f.freeMask, true, out);
                 else { push(a.prod, f.freeMask); continue; }
             }
         }
@@ -293,7 +307,7 @@ void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
             }
             f.m.k2 = PK_ACC; f.m.mat2 = b.mat;
             f.phase = 9;
-            if (b.cls == CL_VIRT) emitVirtual(b.buf, mask2, true, out);
+            if (b.cls == CL_VIRT) emitVirtual(b.vkey, mask2, true, out);
             else { push(b.prod, mask2); continue; }
         }
         {                                                 // phase 9: the node itself
@@ -320,7 +334,8 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     if (wStamp_.size() < nKeys) { wStamp_.assign(nKeys, 0); rStamp_.assign(nKeys, 0); wOp_.assign(nKeys, 0); }
     if (sWStamp_.size() < nS) { sWStamp_.assign(nS, 0); sRStamp_.assign(nS, 0); sDone_.assign(nS, 0); }
     stamp_++;
-    allowVirtual = allowVirtual && enabled_ && parts == 1 && tuple == 7;
+    if (parts != keyParts_) return -1;                 // (BEAGLE_ERROR_GENERAL) the engine sets the partition count first
+    allowVirtual = allowVirtual && enabled_;
 
     // ---- closed list?  then the plan may be in the cache (planner.h)
     CacheEntry* fill = nullptr;
@@ -374,44 +389,44 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         if (!o.tip2 && wStamp_[kc2] == stamp_) { prod2_[k] = wOp_[kc2]; consumed[prod2_[k]] = 1; }
         if (o.wS != OP_NONE) sWStamp_[(size_t)o.wS * parts + o.part] = stamp_;
 
-        const bool v1 = !o.tip1 && virt_[o.c1].on, v2 = !o.tip2 && virt_[o.c2].on;
+        const bool v1 = !o.tip1 && virt_[kc1].on, v2 = !o.tip2 && virt_[kc2].on;
         const int ownScale = o.wS != OP_NONE ? o.wS : o.rS;
         bool makeVirtual = false;
         if (allowVirtual && (o.tip1 || v1) && (o.tip2 || v2) && o.c1 != o.dest && o.c2 != o.dest) {
-            VirtDef& ev = virt_[o.dest];
+            VirtDef& ev = virt_[kd];
             // Steady state: the same op on the same buffers as when `dest` was last defined, its virtual children unchanged
             // (same definition version) and re-confirmed in this list exactly as they were fresh then -> the definition
             // stands; only its matrix snapshots are refreshed.  Anything else rebuilds it.
-            auto childSame = [&](int c, bool tip, bool sigTip, int ver, bool fresh) {
+            auto childSame = [&](size_t c, bool tip, bool sigTip, int ver, bool fresh) {      // c: the child's key
                 if (tip != sigTip) return false;
                 if (tip) return true;
                 const VirtDef& cv = virt_[c];
                 return fresh && cv.stamp == stamp_ && cv.version == ver;
             };
             if (ev.on && ev.sigC1 == o.c1 && ev.sigM1 == o.m1 && ev.sigC2 == o.c2 && ev.sigM2 == o.m2 && ev.sigScale == ownScale &&
-                childSame(o.c1, o.tip1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(o.c2, o.tip2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
+                childSame(kc1, o.tip1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(kc2, o.tip2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
                 for (int st = 0; st < ev.nSteps; st++) {
-                    out.snapPairs.push_back(ev.steps[st].originA); out.snapPairs.push_back(snapSlot(o.dest, st, 0));
-                    out.snapPairs.push_back(ev.steps[st].originB); out.snapPairs.push_back(snapSlot(o.dest, st, 1));
+                    out.snapPairs.push_back(ev.steps[st].originA); out.snapPairs.push_back(snapSlot((int)kd, st, 0));
+                    out.snapPairs.push_back(ev.steps[st].originB); out.snapPairs.push_back(snapSlot((int)kd, st, 1));
                 }
                 ev.stamp = stamp_;
                 makeVirtual = true;
             } else {
                 VirtDef saved = ev;
-                if (saved.on) clearVirtual(o.dest);
-                makeVirtual = buildVirtual(o.dest, o.c1, o.tip1, o.m1, o.c2, o.tip2, o.m2, ownScale, out.snapPairs);
-                if (!makeVirtual && saved.on) { virt_[o.dest] = saved; tagOf_[o.dest] = saved.cacheTag; registerVirtual(o.dest); }
+                if (saved.on) clearVirtualKey((int)kd);
+                makeVirtual = buildVirtual((int)kd, o.tip1 ? o.c1 : (int)kc1, o.tip1, o.m1, o.tip2 ? o.c2 : (int)kc2, o.tip2, o.m2, ownScale, out.snapPairs);
+                if (!makeVirtual && saved.on) { virt_[kd] = saved; tagOf_[kd] = saved.cacheTag; registerVirtual((int)kd); }
                 if (makeVirtual) {
-                    VirtDef& nv = virt_[o.dest];
+                    VirtDef& nv = virt_[kd];
                     nv.version = ++virtVersion_;
                     nv.sigC1 = o.c1; nv.sigM1 = o.m1; nv.sigC2 = o.c2; nv.sigM2 = o.m2; nv.sigScale = ownScale;
                     nv.sigTip1 = o.tip1; nv.sigTip2 = o.tip2;
-                    nv.fresh1 = !o.tip1 && virt_[o.c1].stamp == stamp_; nv.fresh2 = !o.tip2 && virt_[o.c2].stamp == stamp_;
-                    nv.childVer1 = o.tip1 ? -1 : virt_[o.c1].version; nv.childVer2 = o.tip2 ? -1 : virt_[o.c2].version;
+                    nv.fresh1 = !o.tip1 && virt_[kc1].stamp == stamp_; nv.fresh2 = !o.tip2 && virt_[kc2].stamp == stamp_;
+                    nv.childVer1 = o.tip1 ? -1 : virt_[kc1].version; nv.childVer2 = o.tip2 ? -1 : virt_[kc2].version;
                 }
             }
         }
-        if (!makeVirtual && virt_[o.dest].on) clearVirtual(o.dest);      // whatever it was, this op replaces it
+        if (!makeVirtual && virt_[kd].on) clearVirtualKey((int)kd);      // whatever it was, this op replaces it
         o.virtDest = makeVirtual;
         wStamp_[kd] = stamp_; wOp_[kd] = k;
 
@@ -423,7 +438,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 const int c = w ? o.c2 : o.c1, prod = w ? prod2_[k] : prod1_[k];
                 if (tip) continue;
                 if (prod >= 0 && !info_[prod].virtDest) { eval[w] = real[w] = true; need[w] = info_[prod].need; size[w] = info_[prod].size; }
-                else if (virt_[c].on) { eval[w] = true; need[w] = virtNeed(c); }
+                else if (virt_[key(c, o.part)].on) { eval[w] = true; need[w] = virtNeed(key(c, o.part)); }
             }
             o.size = 1 + size[0] + size[1];
             if (eval[0] && eval[1]) {
@@ -460,7 +475,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                         const int buf = c ? o.c2 : o.c1, prod = c ? prod2_[k] : prod1_[k];
                         if (tip) continue;
                         if (prod >= 0 && !info_[prod].virtDest) { if (!info_[prod].emitted) w += weight[prod]; }
-                        else if (virt_[buf].on) w += virt_[buf].nSteps;
+                        else if (virt_[key(buf, o.part)].on) w += virt_[key(buf, o.part)].nSteps;
                     }
                     weight[k] = w;
                     if (!consumed[k]) total += w;
@@ -509,7 +524,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             for (int k = 0; k < count; k++) {
                 const OpInfo& o = info_[k];
                 if (o.part != part || !o.virtDest || o.wS == OP_NONE) continue;
-                if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(o.dest, allSlots_, true, out);
+                if (sDone_[(size_t)o.wS * parts + o.part] != stamp_) emitVirtual(key(o.dest, o.part), allSlots_, true, out);
             }
             seg.progCount = (int)out.prog.size() - seg.progStart;
             if (seg.progCount > 0) { out.segs.push_back(seg); wave++; }
@@ -524,7 +539,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         fill->defs.assign(count, VirtDef());
         fill->defOn.assign(count, 0);
         for (int k = 0; k < count; k++)
-            if (info_[k].virtDest) { virt_[info_[k].dest].cacheTag = fill->tag; tagOf_[info_[k].dest] = fill->tag; fill->defs[k] = virt_[info_[k].dest]; fill->defOn[k] = 1; }
+            if (info_[k].virtDest) { const int kk = key(info_[k].dest, info_[k].part); virt_[kk].cacheTag = fill->tag; tagOf_[kk] = fill->tag; fill->defs[k] = virt_[kk]; fill->defOn[k] = 1; }
         plannedTag = fill->tag;
         fill->stored = lastStored; fill->memReads = lastMemReads; fill->holds = lastHolds; fill->waves = lastWaves;
         fill->valid = true;
@@ -537,36 +552,39 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
 // definition resets the tag), so the steady state costs one comparison per operation.
 void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
     for (int k = 0; k < e.count; k++) {
-        const int dest = ops[(size_t)k * e.tuple];
+        const int part = e.tuple > 7 ? ops[(size_t)k * e.tuple + 7] : 0;
+        const int dest = key(ops[(size_t)k * e.tuple], part);
         if (e.defOn[k] ? tagOf_[dest] == e.tag : tagOf_[dest] < 0) continue;        // already what the entry leaves behind
         const VirtDef& want = e.defs[k];
         VirtDef& cur = virt_[dest];
-        if (cur.on) clearVirtual(dest);
+        if (cur.on) clearVirtualKey(dest);
         if (!want.on) continue;
         cur = want;                                               // (tagged with e.tag when the entry was filled)
         tagOf_[dest] = e.tag;
         cur.stamp = stamp_;
         cur.version = ++virtVersion_;
-        cur.childVer1 = cur.sigTip1 ? -1 : virt_[cur.sigC1].version;
-        cur.childVer2 = cur.sigTip2 ? -1 : virt_[cur.sigC2].version;
+        cur.childVer1 = cur.sigTip1 ? -1 : virt_[key(cur.sigC1, part)].version;
+        cur.childVer2 = cur.sigTip2 ? -1 : virt_[key(cur.sigC2, part)].version;
         registerVirtual(dest);
     }
     planned = &e.plan; plannedTag = e.tag;
     lastStored = e.stored; lastMemReads = e.memReads; lastHolds = e.holds; lastWaves = e.waves;
 }
 
-void WalkPlanner::planMaterialize(const std::vector<int>& xs, Plan& out) {
+void WalkPlanner::planMaterialize(const std::vector<int>& keys, Plan& out) {
     out.clear();
-    parts_ = 1;
-    PlanSeg seg; seg.progStart = 0; seg.partition = 0; seg.wave = 0;
-    for (int X : xs) {
-        if (!virt_[X].on) continue;
-        emitVirtual(X, allSlots_, false, out);
-        out.prog.back().storeBuf = X;
-        clearVirtual(X);
+    parts_ = keyParts_;
+    for (int part = 0; part < keyParts_; part++) {      // one slice per partition that has something to materialise
+        PlanSeg seg; seg.progStart = (int)out.prog.size(); seg.partition = part; seg.wave = 0;
+        for (int X : keys) {
+            if (partitionOf(X) != part || !virt_[X].on) continue;
+            emitVirtual(X, allSlots_, false, out);
+            out.prog.back().storeBuf = bufferOf(X);
+            clearVirtualKey(X);
+        }
+        seg.progCount = (int)out.prog.size() - seg.progStart;
+        if (seg.progCount > 0) out.segs.push_back(seg);
     }
-    seg.progCount = (int)out.prog.size();
-    if (seg.progCount > 0) out.segs.push_back(seg);
 }
 
 }  // namespace mi355

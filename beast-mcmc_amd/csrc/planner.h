@@ -14,6 +14,7 @@
 //     (src/dr/evomodel/treedatalikelihood/BufferIndexHelper.java:71-106 flips between two indices per node and expects
 //     the unflipped one to survive a rejected proposal).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -83,35 +84,46 @@ public:
     // maintained by the engine: buffer holds compact tip states (index < tipCount and setTipStates was the last setter)
     std::vector<char> compactTip;
 
-    bool isVirtual(int buf) const { return virt_[buf].on; }
-    const VirtDef& definition(int buf) const { return virt_[buf]; }
+    // A definition belongs to a (buffer, partition) pair — a partitioned instance updates the pattern ranges of one buffer
+    // independently (MultiPartitionDataLikelihoodDelegate.java:972-997: every partition flips its own buffer indices) — and
+    // is identified by its KEY = buffer * partitionCount + partition; with one partition the key is the buffer index.
+    void setPartitionCount(int parts);       // forgets every definition (the engine materialises them first)
+    int partitionCount() const { return keyParts_; }
+    int key(int buf, int part) const { return buf * keyParts_ + part; }
+    int bufferOf(int key) const { return key / keyParts_; }
+    int partitionOf(int key) const { return key % keyParts_; }
+    bool isVirtualKey(int key) const { return virt_[key].on; }
+    bool isVirtual(int buf) const { for (int k = 0; k < keyParts_; k++) if (virt_[(std::size_t)buf * keyParts_ + k].on) return true; return false; }
+    void keysOf(int buf, std::vector<int>& out) const { for (int k = 0; k < keyParts_; k++) if (virt_[(std::size_t)buf * keyParts_ + k].on) out.push_back(buf * keyParts_ + k); }
+    const VirtDef& definition(int key) const { return virt_[key]; }
     bool virtualEnabled() const { return enabled_; }
-    int snapSlot(int buf, int step, int which) const { return matrixCount_ + buf * 2 * maxSteps_ + 2 * step + which; }
-    int matrixSlots() const { return matrixCount_ + (enabled_ ? partialsCount_ * 2 * maxSteps_ : 0); }
+    int snapSlot(int key, int step, int which) const { return matrixCount_ + key * 2 * maxSteps_ + 2 * step + which; }
+    int matrixSlots() const { return matrixCount_ + (enabled_ ? partialsCount_ * keyParts_ * 2 * maxSteps_ : 0); }
 
-    const std::vector<int>& tipUsers(int tip) const { return tipUsers_[tip]; }
-    const std::vector<int>& scaleUsers(int idx) const { return scaleUsers_[idx]; }
-    void clearVirtual(int buf);          // forget the definition (the buffer is about to get real data)
+    const std::vector<int>& tipUsers(int tip) const { return tipUsers_[tip]; }       // KEYS of the definitions that read this tip
+    const std::vector<int>& scaleUsers(int idx) const { return scaleUsers_[idx]; }   // ... this scale buffer
+    void clearVirtualKey(int key);       // forget the definition (that range of the buffer is about to get real data)
+    void clearVirtual(int buf) { for (int k = 0; k < keyParts_; k++) clearVirtualKey(buf * keyParts_ + k); }
     // Define `buf` as the cherry node(tipA over matrix mA, tipB over matrix mB) [read-mode scale buffer scaleIdx or PLAN_NONE]
-    // (the level-scheduled T32 path, engine.cpp runOperationsLevels); appends the matrix snapshot copies to snapPairs.
+    // (the level-scheduled T32 path, engine.cpp runOperationsLevels: one partition); appends the matrix snapshot copies to snapPairs.
     bool defineCherry(int buf, int tipA, int mA, int tipB, int mB, int scaleIdx, std::vector<int>& snapPairs);
 
     // Length of the longest prefix of ops[begin..count) that can run as one walk: no buffer (or scale buffer) is written
     // twice, written after an earlier op of the prefix read it, or read through a scale index another op writes.
     int hazardFreePrefix(const int* ops, int begin, int count, int tuple, int partitionCount);
 
-    // Virtual buffers that must get real data before this (hazard-free) list runs: definitions that read a scale buffer
-    // the list rewrites (unless the list redefines that buffer anyway), and a virtual destination that is its own child.
+    // Definitions (KEYS) that must get real data before this (hazard-free) list runs: those that read a scale buffer the list
+    // rewrites (unless the list redefines them anyway), and a virtual destination that is its own child.
     void mustMaterializeBefore(const int* ops, int count, int tuple, std::vector<int>& out);
 
-    // Plan a hazard-free list.  Indices must have been range-checked by the caller.  `allowVirtual`: destinations may
-    // become virtual (single-partition 7-int lists only).  Returns 0, or a BEAGLE error code.
+    // Plan a hazard-free list.  Indices must have been range-checked by the caller; partitionCount must be the planner's.
+    // `allowVirtual`: destinations may become virtual.  Returns 0, or a BEAGLE error code.
     // `chunkOps` > 0 (few pattern groups, so a launch cannot fill the chip with one walk per group): the forest is cut
     // into independent subtrees of about that many micro-operations, run side by side, wave after wave.
     int plan(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, Plan& out, int chunkOps = 0);
 
-    // Program that gives every (virtual) buffer of xs its real partials; the definitions are dropped.
-    void planMaterialize(const std::vector<int>& xs, Plan& out);
+    // Program that gives every definition of `keys` its real partials (one slice per partition); the definitions are dropped.
+    void planMaterialize(const std::vector<int>& keys, Plan& out);
 
     // statistics of the last plan() (bench / tests)
     int lastStored = 0, lastMemReads = 0, lastHolds = 0, lastWaves = 0;
@@ -130,7 +142,7 @@ private:
         int size;           // real micro-ops below (ordering heuristic)
         bool emitted;
     };
-    bool buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs);
+    bool buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs);   // X, and a non-tip child: KEYS
     void registerVirtual(int X);
     // emission
     void emitReal(int root, unsigned freeMask, Plan& out);
@@ -138,10 +150,10 @@ private:
     void emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out);
     int virtNeed(int buf) const { return virt_[buf].nSteps ? virt_[buf].steps[virt_[buf].nSteps - 1].need : 0; }
 
-    int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6;
+    int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6, keyParts_ = 1;
     bool enabled_ = false;
     std::vector<VirtDef> virt_;
-    std::vector<long> tagOf_;                          // per buffer: -1 not virtual, 0 virtual, > 0 virtual and written by that cache entry
+    std::vector<long> tagOf_;                          // per key: -1 not virtual, 0 virtual, > 0 virtual and written by that cache entry
                                                        // (a compact mirror of on / cacheTag: replaying a plan touches 8 bytes per op)
     std::vector<std::vector<int>> tipUsers_, scaleUsers_;
     int virtVersion_ = 0;

@@ -173,14 +173,14 @@ struct Harness {
         partEnd.assign(1, P);
     }
     void setTipStates(int tip) {
-        materialise(pl.tipUsers(tip));
+        materialiseKeys(pl.tipUsers(tip));
         std::vector<uint8_t> s(P);
         for (int p = 0; p < P; p++) s[p] = (uint8_t)(rng() % 5);
         truth.tips[tip] = s; plan.tips[tip] = s;
         compact[tip] = 1; pl.compactTip[tip] = 1;
     }
     void setTipPartials(int tip) {
-        materialise(pl.tipUsers(tip));
+        materialiseKeys(pl.tipUsers(tip));
         pl.clearVirtual(tip);
         std::vector<double> x((size_t)C * P * 4);
         std::uniform_real_distribution<double> u(0.05, 1.0);
@@ -194,25 +194,32 @@ struct Harness {
         for (double& v : m) v = u(rng) * 1e-3;     // small entries: products shrink, rescaling matters
         truth.mats[slot] = m; plan.mats[slot] = m;
     }
-    void materialise(std::vector<int> xs) {
-        if (xs.empty()) return;
+    void materialise(const std::vector<int>& bufs) {       // buffers -> the keys of their (virtual) partitions
+        std::vector<int> keys;
+        for (int b : bufs) pl.keysOf(b, keys);
+        materialiseKeys(keys);
+    }
+    void materialiseKeys(std::vector<int> keys) {
+        if (keys.empty()) return;
         Plan mp;
         std::vector<int> which;
-        for (int x : xs) if (pl.isVirtual(x)) which.push_back(x);
-        pl.planMaterialize(xs, mp);
+        for (int x : keys) if (pl.isVirtualKey(x)) which.push_back(x);
+        pl.planMaterialize(keys, mp);
         runPlan(plan, mp, partStart, partEnd);
-        for (int x : which) { compareBuffer(x, "materialised"); materialised++; }
+        for (int x : which) { compareRange(pl.bufferOf(x), partStart[pl.partitionOf(x)], partEnd[pl.partitionOf(x)], "materialised"); materialised++; }
     }
-    void compareBuffer(int b, const char* what) {
+    void compareRange(int b, int p0, int p1, const char* what) {
         if (truth.partials[b].empty()) return;
-        if (plan.partials[b].size() != truth.partials[b].size() ||
-            memcmp(plan.partials[b].data(), truth.partials[b].data(), truth.partials[b].size() * 8) != 0) {
-            fprintf(stderr, "MISMATCH (%s) buffer %d after %ld lists\n", what, b, lists);
-            exit(1);
-        }
+        bool ok = plan.partials[b].size() == truth.partials[b].size();
+        for (int c = 0; ok && c < C; c++)
+            ok = memcmp(&plan.partials[b][((size_t)c * P + p0) * 4], &truth.partials[b][((size_t)c * P + p0) * 4], (size_t)(p1 - p0) * 32) == 0;
+        if (!ok) { fprintf(stderr, "MISMATCH (%s) buffer %d patterns [%d, %d) after %ld lists [%s]\n", what, b, p0, p1, lists, g_where); exit(1); }
     }
     void compareAll() {
-        for (int b = 0; b < nBuf; b++) if (!pl.isVirtual(b) && !compact[b]) compareBuffer(b, "real");
+        for (int b = 0; b < nBuf; b++) {
+            if (compact[b]) continue;
+            for (int k = 0; k < parts; k++) if (!pl.isVirtualKey(pl.key(b, k))) compareRange(b, partStart[k], partEnd[k], "real");
+        }
         for (int s = 0; s < nScale; s++) {
             if (truth.scale[s].empty()) continue;
             if (plan.scale[s].size() != truth.scale[s].size() || memcmp(plan.scale[s].data(), truth.scale[s].data(), (size_t)P * 8) != 0) {
@@ -233,7 +240,7 @@ struct Harness {
             const int n = pl.hazardFreePrefix(ops.data(), begin, count, tuple, parts);
             assert(n >= 1);
             const int* sub = ops.data() + (size_t)begin * tuple;
-            std::vector<int> need;
+            std::vector<int> need;                 // (keys)
             pl.mustMaterializeBefore(sub, n, tuple, need);
             materialiseNoCompare(need);
             Plan scratch;
@@ -423,13 +430,15 @@ static void scenarioSteady(int T, bool level, unsigned seed) {
     printf("  steady T=%d level=%d: %ld lists, %ld plan-cache hits, %ld micro-ops, %ld stored\n", T, (int)level, h.lists, h.pl.cacheHits, h.micro, h.stored);
 }
 
-static void scenarioPartitions(unsigned seed) {
+static void scenarioPartitions(unsigned seed, int T) {
     g_where = "partitions"; g_list = 0;
     std::mt19937 rng(seed);
-    const int T = 9; Tree tree; tree.random(T, rng, false);
+    Tree tree; tree.random(T, rng, false);
     const int N = 2 * T - 1;
     Harness h; h.init(T, T + 2 * (T - 1), 2 * N * 3, 2 * (T - 1) * 3, true, seed);
     h.parts = 3; h.partStart = {0, 2, 5}; h.partEnd = {2, 5, P};
+    h.pl.setPartitionCount(3);               // definitions per (buffer, partition); more snapshot slots
+    for (World* w : {&h.truth, &h.plan}) w->mats.assign(h.pl.matrixSlots(), std::vector<double>((size_t)C * 16, 0.0));
     for (int i = 0; i < T; i++) h.setTipStates(i);
     for (int s = 0; s < 2 * N * 3; s++) h.setMatrix(s);
     std::vector<int> all; tree.postOrder(N - 1, all);
@@ -457,7 +466,34 @@ static void scenarioPartitions(unsigned seed) {
         }
         h.update(ops, 9);
     }
-    printf("  partitions: %ld lists, %ld micro-ops\n", h.lists, h.micro);
+    // per-partition buffer flips, as MultiPartitionDataLikelihoodDelegate's partialBufferHelper[i] does: partial updates of
+    // ONE partition at a time on the path to the root, with rejections; definitions of the other partitions must survive
+    {
+        std::vector<std::vector<int>> flip(3, std::vector<int>(N, 1));       // the last full lists above wrote flip (5 & 1) = 1
+        auto pbk = [&](int part, int x) { return x < T ? x : T + 2 * (x - T) + flip[part][x]; };
+        for (int step = 0; step < 30; step++) {
+            const int part = rng() % 3;
+            std::vector<char> dirty(N, 0);
+            const int n0 = rng() % (N - 1);
+            h.setMatrix((2 * n0) * 3 + part);
+            for (int a = tree.parent[n0]; a >= 0; a = tree.parent[a]) dirty[a] = 1;
+            std::vector<int> saved = flip[part], ops;
+            for (int n : all) if (dirty[n]) flip[part][n] ^= 1;
+            for (int n : all) {
+                if (!dirty[n]) continue;
+                const int sc = (2 * (n - T)) * 3 + part;
+                ops.insert(ops.end(), {pbk(part, n), -1, sc, pbk(part, tree.left[n]), (2 * tree.left[n]) * 3 + part,
+                                       pbk(part, tree.right[n]), (2 * tree.right[n]) * 3 + part, part, -1});
+            }
+            h.update(ops, 9);
+            if (rng() % 3 == 0) flip[part] = saved;            // rejected
+            if (rng() % 5 == 0) { std::vector<int> xs; for (int q = 0; q < 3; q++) xs.push_back(T + rng() % (2 * (T - 1))); h.materialise(xs); }
+        }
+    }
+    std::vector<int> every; for (int b = T; b < h.nBuf; b++) every.push_back(b);
+    h.materialise(every);
+    h.compareAll();
+    printf("  partitions T=%d: %ld lists, %ld micro-ops, %ld stored, %ld materialised\n", T, h.lists, h.micro, h.stored, h.materialised);
 }
 
 static void scenarioHazards(unsigned seed) {
@@ -486,7 +522,7 @@ int main(int argc, char** argv) {
             scenarioMcmc(T, true, true, 4000 * r + T, 30, false);
         }
         for (int T : {9, 40, 150, 600}) { scenarioSteady(T, false, 6000 * r + T); scenarioSteady(T, true, 7000 * r + T); }
-        scenarioPartitions(77 + r);
+        scenarioPartitions(77 + r, 9); scenarioPartitions(177 + r, 40);
         scenarioHazards(5 + r);
     }
     P = 2; C = 1;

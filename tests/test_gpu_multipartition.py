@@ -102,3 +102,115 @@ def test_multi_partition_protocol(S, scaling, oracle_lib):
         assert np.max(np.abs(site[off:off + w.pattern_count] - so) / np.abs(so)) <= 1e-10
         off += w.pattern_count
     assert helpers.rel_err(total[0], sum(expect)) <= 1e-10
+
+
+def test_partitioned_instance_partial_updates_with_per_partition_flips(oracle_lib):
+    """What MultiPartitionDataLikelihoodDelegate does between full evaluations: ONE partition's branch changes, only that
+    partition's path to the root is re-evaluated, into ITS alternate buffers (partialBufferHelper[i], one per partition,
+    MultiPartitionDataLikelihoodDelegate.java:972-997), and a rejected proposal flips back.  The engine keeps definitions of
+    unstored nodes per (buffer, partition) (planner.h); the reference here is one oracle instance per partition given the
+    same operations as 7-int tuples.  Checked after every step: the per-partition log-likelihoods; at the end: the partials
+    of every internal node of every partition (the engine materialises what it had not stored)."""
+    S, T, C = 4, 24, 4
+    tree, wls = two_partitions(S, T, [300, 77, 140], seed=77)
+    K = len(wls)
+    P = sum(w.pattern_count for w in wls)
+    nodes = 2 * T - 1
+    starts = np.concatenate([[0], np.cumsum([w.pattern_count for w in wls])])
+    eng = bm.beagle.Beagle(T, T + 2 * (T - 1), T, S, P, K, 2 * K * nodes, C, T)
+    ora = [bm.beagle.Beagle(T, T + 2 * (T - 1), T, S, w.pattern_count, 1, 2 * nodes, C, T, library=oracle_lib) for w in wls]
+    rng = np.random.default_rng(5)
+    try:
+        for t in range(T):
+            eng.setTipStates(t, np.concatenate([w.tip_states[t] for w in wls]))
+            for k, w in enumerate(wls):
+                ora[k].setTipStates(t, w.tip_states[t])
+        eng.setPatternWeights(np.concatenate([w.weights for w in wls]))
+        eng.setPatternPartitions(K, np.concatenate([np.full(w.pattern_count, k, dtype=np.int32) for k, w in enumerate(wls)]))
+        for k, w in enumerate(wls):
+            ora[k].setPatternWeights(w.weights)
+            for b_, e_ in ((eng, k), (ora[k], 0)):
+                b_.setEigenDecomposition(e_, w.eig.evec, w.eig.ievc, w.eig.evals)
+                b_.setCategoryWeights(e_, w.cat_weights)
+                b_.setStateFrequencies(e_, w.freqs)
+            eng.setCategoryRatesWithIndex(k, w.cat_rates)
+            ora[k].setCategoryRates(w.cat_rates)
+        lens = np.array([tree.branch_length(n) if n != tree.root else 0.0 for n in range(nodes)])
+        pflip = np.zeros((K, nodes), dtype=int)
+        mflip = np.zeros((K, nodes), dtype=int)
+        pb = lambda k, n: n if n < T else T + 2 * (n - T) + pflip[k][n]
+        mbe = lambda k, n: (k * nodes + n) * 2 + mflip[k][n]          # engine: all partitions' matrices in one index space
+        mbo = lambda k, n: n * 2 + mflip[k][n]
+        branches = [n for n in range(nodes) if n != tree.root]
+
+        def matrices(k, which):
+            eng.updateTransitionMatricesWithMultipleModels([k] * len(which), [k] * len(which), [mbe(k, n) for n in which], None, None,
+                                                           [lens[n] for n in which], len(which))
+            ora[k].updateTransitionMatrices(0, [mbo(k, n) for n in which], None, None, [lens[n] for n in which], len(which))
+
+        def ops_for(k, order, write):
+            e9, o7 = [], []
+            for n in order:
+                l, r = int(tree.left[n]), int(tree.right[n])
+                ws, rs = (n - T, NONE) if write else (NONE, n - T)
+                e9 += [pb(k, n), ws, rs, pb(k, l), mbe(k, l), pb(k, r), mbe(k, r), k, NONE]
+                o7 += [pb(k, n), ws, rs, pb(k, l), mbo(k, l), pb(k, r), mbo(k, r)]
+            return e9, o7
+
+        def check(what):
+            by_part, total = np.zeros(K), [0.0]
+            eng.calculateRootLogLikelihoodsByPartition([pb(k, tree.root) for k in range(K)], list(range(K)), list(range(K)), [T - 1] * K,
+                                                       list(range(K)), K, 1, by_part, total)
+            for k in range(K):
+                out = [0.0]
+                ora[k].calculateRootLogLikelihoods([pb(k, tree.root)], [0], [0], [T - 1], 1, out)
+                assert helpers.rel_err(by_part[k], out[0]) <= 1e-10, (what, k, by_part[k], out[0])
+
+        internal = [n for n in tree.postorder() if n >= T]
+        e_all = []
+        for k in range(K):                                       # full evaluation, rescaling in write mode
+            matrices(k, branches)
+            e9, o7 = ops_for(k, internal, True)
+            e_all += e9
+            ora[k].updatePartials(o7, len(o7) // 7, NONE)
+            ora[k].resetScaleFactors(T - 1)
+            ora[k].accumulateScaleFactors([n - T for n in internal], len(internal), T - 1)
+        eng.kernelTimer(True)
+        eng.updatePartialsByPartition(e_all, len(e_all) // 9)
+        for k in range(K):
+            eng.resetScaleFactorsByPartition(T - 1, k)
+            eng.accumulateScaleFactorsByPartition([n - T for n in internal], len(internal), T - 1, k)
+        check("full")
+        for step in range(25):
+            k = int(rng.integers(K))
+            n0 = int(rng.choice(branches))
+            saved = (pflip[k].copy(), mflip[k].copy(), lens[n0])
+            lens[n0] *= float(np.exp(0.3 * rng.standard_normal()))
+            mflip[k][n0] ^= 1
+            matrices(k, [n0])
+            path, a = set(), tree.parent[n0]
+            while a >= 0:
+                path.add(int(a)); a = tree.parent[a]
+            order = [n for n in internal if n in path]
+            for n in order:
+                pflip[k][n] ^= 1
+            e9, o7 = ops_for(k, order, False)
+            eng.updatePartialsByPartition(e9, len(e9) // 9)
+            ora[k].updatePartials(o7, len(o7) // 7, NONE)
+            check("step %d" % step)
+            if rng.random() < 0.35:                              # rejected: the unflipped buffers still hold their values
+                pflip[k], mflip[k], lens[n0] = saved
+                check("step %d restored" % step)
+        stats = eng.walkStats()
+        assert stats["fast_walks"] == stats["walks"] > 0 and stats["stored"] < stats["micro_ops"]      # unstored nodes exist
+        for k, w in enumerate(wls):
+            for n in internal:
+                pe = eng.getPartials(pb(k, n), NONE)[:, starts[k]:starts[k + 1], :]
+                po = ora[k].getPartials(pb(k, n), NONE)
+                scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+                assert np.max(np.abs(pe - po) / scale) <= 1e-10, (k, n)
+        check("after read-back")
+    finally:
+        eng.finalize()
+        for o in ora:
+            o.finalize()
