@@ -328,7 +328,7 @@ static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_RE
 inline bool isVirt(const Instance* in, int X) { return in->virt && in->planner.isVirtual(X); }
 inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearVirtual(X); }
 inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
-inline void setCompact(Instance* in, int X, bool on) { in->planner.compactTip[X] = on ? 1 : 0; }
+inline void setCompact(Instance* in, int X, bool on) { in->planner.setCompactTip(X, on); }
 
 // The pair-interleaved layout for the instance's current partitions (Instance::pairPos), and the scale-buffer stride that
 // holds either half ([factors, plain | reciprocals, pair-interleaved]).
@@ -603,6 +603,31 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
     auto usSince = [](Clock::time_point a) { return std::chrono::duration<double, std::micro>(Clock::now() - a).count(); };
     in->hostCalls++;
     const int parts = in->partitionCount;
+    // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
+    const bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
+    // The chain's steady state — the SAME full-evaluation list as one seen before, no rescaling in it — needs none of the
+    // per-operation work below: it was range-checked and planned then, nothing has to be materialised or accumulated for it,
+    // the planner re-establishes its definitions with one comparison per operation and the program is resident on the
+    // device (config E, 6 436 operations: 116 -> 35 us of host time per call; profiles/r03_experiments.txt).
+    {
+        bool simple = false;
+        if (in->planner.replayCached(ops, count, tuple, parts, allowVirtual, walkChunkOps(in, count), &simple)) {
+            const double usPlan = usSince(t0);
+            in->hostPlanUs += usPlan; in->hostPlanHitUs += usPlan; in->hostHits++;
+            const Clock::time_point t1 = Clock::now();
+            hipEvent_t a = nullptr, b = nullptr;
+            const bool launches = !in->planner.planned->prog.empty();
+            if (in->timing && launches) {
+                if (in->eventsUsed == in->events.size()) { hipEvent_t x, y; HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y)); in->events.emplace_back(x, y); }
+                a = in->events[in->eventsUsed].first; b = in->events[in->eventsUsed].second; in->eventsUsed++;
+            }
+            int rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, a); if (rc) return rc;
+            if (b) { HIP_TRY(hipEventRecord(b, in->stream)); in->pendingLaunches++; }
+            const double usRun = usSince(t1);
+            in->hostRunUs += usRun; in->hostRunHitUs += usRun;
+            return 0;
+        }
+    }
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * tuple;
         const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
@@ -638,8 +663,6 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
         in->hostPrepUs += usSince(t1); t1 = Clock::now();
         const long hitsBefore = in->planner.cacheHits;
-        // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
-        const bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
         int rc = in->planner.plan(sub, n, tuple, parts, allowVirtual, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
         const bool hit = in->planner.cacheHits != hitsBefore;
@@ -1460,7 +1483,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && devAlloc(in, (void**)&in->freqs, E * S * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->patternWeights, (size_t)patternCount * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->siteLogL, (size_t)patternCount * sizeof(double)) == 0;
-    ok = ok && devAlloc(in, (void**)&in->blockSums, (size_t)rootBlocks * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->blockSums, ((size_t)rootBlocks + 1024) * sizeof(double)) == 0;    // (+ one partial block per partition)
     ok = ok && devAlloc(in, (void**)&in->dResult, 4096) == 0;
     if (ok) {
         // defaults: category rates 1, weights 1/C, pattern weights 1 (beagle.jar!GeneralBeagleImpl#<init>)
@@ -2015,6 +2038,53 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
     GET_INSTANCE(instance);
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (partitionCount < 1 || partitionCount > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (!in->tiled && partitionCount <= 480) {
+        // all partitions in ONE pair of launches per eight of them, the sums written straight into mapped host memory behind a
+        // sequence word the host polls (as calculateRootLogLikelihoods): no device-to-host copy, no stream synchronisation
+        std::vector<mi355::RootParts> chunks((partitionCount + mi355::ROOT_MAX_PARTS - 1) / mi355::ROOT_MAX_PARTS);
+        int blockOff = 0;
+        for (int k = 0; k < partitionCount; k++) {
+            const int rootIdx = bufferIndices[k], wIdx = categoryWeightsIndices[k], fIdx = stateFrequenciesIndices[k], cumIdx = cumulativeScaleIndices[k], part = partitionIndices[k];
+            if (badIndex(rootIdx, in->partialsCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            { int rcv = materializeVirtual(in, rootIdx); if (rcv) return rcv; }
+            if (!in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) || badIndex(fIdx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            mi355::RootParts& ch = chunks[k / mi355::ROOT_MAX_PARTS];
+            mi355::RootPart& q = ch.p[k % mi355::ROOT_MAX_PARTS];
+            ch.n = k % mi355::ROOT_MAX_PARTS + 1;
+            q.root = in->partials[rootIdx]; q.catWeights = in->weights + (size_t)wIdx * in->C; q.freqs = in->freqs + (size_t)fIdx * in->S;
+            q.cum = nullptr; q.cumIsRaw = 0;
+            if (cumIdx != BEAGLE_OP_NONE) {
+                if (badIndex(cumIdx, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+                int rc = ensureScale(in, cumIdx); if (rc) return rc;
+                q.cum = in->scale[cumIdx]; q.cumIsRaw = in->scaleIsRaw[cumIdx];
+            }
+            q.pStart = in->partStart[part]; q.pEnd = in->partEnd[part]; q.blockOff = blockOff;
+            blockOff += (std::max(0, q.pEnd - q.pStart) + 255) / 256;
+        }
+        const unsigned long long seq = ++in->resultSeq;
+        for (size_t c = 0; c < chunks.size(); c++) {
+            const bool last = c + 1 == chunks.size();
+            mi355::launchRootLogLikelihoodParts(in->stream, chunks[c], in->patternWeights, in->siteLogL, in->blockSums,
+                                                in->hResultDev + 16 + c * mi355::ROOT_MAX_PARTS, in->P, in->S, in->C,
+                                                last ? (unsigned long long*)(in->hResultDev + 8) : nullptr, seq);
+        }
+        HIP_TRY(hipGetLastError());
+        volatile unsigned long long* flag = (volatile unsigned long long*)(in->hResult + 8);
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (*flag != seq) HIP_TRY(hipStreamSynchronize(in->stream));
+        if (*flag != seq) return BEAGLE_ERROR_GENERAL;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        in->ringHead = 0;
+        double tot = 0.0;
+        for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[16 + k]; tot += in->hResult[16 + k]; }
+        *outSum = tot;
+        return (tot != tot) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+    }
     for (int k = 0; k < partitionCount; k++) {
         int rc = rootEnqueue(in, bufferIndices[k], categoryWeightsIndices[k], stateFrequenciesIndices[k],
                              cumulativeScaleIndices[k], partitionIndices[k], in->dResult + k);

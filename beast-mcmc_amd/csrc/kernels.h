@@ -144,6 +144,14 @@ void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFi
 void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices,
                       int P, int S, int C, int maxRange);
 
+// The same for up to ROOT_MAX_PARTS pattern ranges in ONE pair of launches (calculateRootLogLikelihoodsByPartition): range k
+// has its own root buffer, weights, frequencies and cumulative buffer; out[k] = its sum; `flag` as above, after the last.
+constexpr int ROOT_MAX_PARTS = 8;
+struct RootPart { const double* root; const double* catWeights; const double* freqs; const double* cum; int cumIsRaw, pStart, pEnd, blockOff; };
+struct RootParts { RootPart p[ROOT_MAX_PARTS]; int n; };
+void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
+                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq);
+
 // site[p] = log(sum_c w_c sum_i pi_i root[c][p][i]) + cum[p];  blockSums[b] = sum_p weight[p]*site[p] over block b
 // then out[0] = sum_b blockSums[b] in a fixed order (deterministic).  cum may be nullptr; cumIsRaw says the
 // buffer holds raw factors (log is taken on the fly).  Restricted to [pStart, pEnd).

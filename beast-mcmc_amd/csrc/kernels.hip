@@ -67,10 +67,39 @@ __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrice
     }
 }
 
+// 4 states: one THREAD per (branch, category) — a workgroup per matrix would be 64 lanes for 16 outputs (and, for the 12 872
+// matrices of a four-partition 1610-taxon evaluation, 51 488 workgroups).  Same arithmetic and summation order as k_transition.
+__global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matrices, const double* __restrict__ eigen,
+                                                     const double* __restrict__ rates, const int* __restrict__ dIdx,
+                                                     const double* __restrict__ dLen, const int* __restrict__ dEig,
+                                                     const int* __restrict__ dRate, int count, int C) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * C) return;
+    const int u = t / C, c = t - u * C;
+    const double* U = eigen + (size_t)36 * dEig[u];
+    const double* Ui = U + 16;
+    const double* lam = U + 32;
+    const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
+    double ex[4];
+    for (int k = 0; k < 4; k++) ex[k] = exp(dist * lam[k]);
+    double* M = matrices + ((size_t)dIdx[u] * C + c) * 16;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * (Ui[k * 4 + j] * ex[k]);
+            M[i * 4 + j] = s > 0.0 ? s : 0.0;
+        }
+}
+
 void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,
                               const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
                               int count, int S, int C) {
     if (count <= 0) return;
+    if (S == 4) {
+        hipLaunchKernelGGL(k_transition4, dim3((unsigned)(((size_t)count * C + 255) / 256)), dim3(256), 0, stream,
+                           matrices, eigen, rates, dIdx, dLen, dEig, dRate, count, C);
+        return;
+    }
     const int threads = S * S >= 256 ? 256 : 64;
     hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), (size_t)S * S * sizeof(double), stream,
                        matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C);
@@ -295,6 +324,54 @@ void launchRootLogLikelihood(hipStream_t stream, const double* root, const doubl
     hipLaunchKernelGGL(k_rootSite, dim3(n), dim3(ROOT_BLOCK), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
                        patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
     hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
+}
+
+__global__ __launch_bounds__(ROOT_BLOCK) void k_rootSiteParts(const RootParts parts, const double* __restrict__ patternWeights,
+                                                              double* __restrict__ siteLogL, double* __restrict__ blockSums, int P, int S, int C) {
+    __shared__ double sh[ROOT_BLOCK / 64];
+    const RootPart& q = parts.p[blockIdx.y];
+    const int p = q.pStart + blockIdx.x * ROOT_BLOCK + threadIdx.x;
+    if (q.pStart + (int)blockIdx.x * ROOT_BLOCK >= q.pEnd) return;           // (the whole workgroup)
+    double contrib = 0.0;
+    if (p < q.pEnd) {
+        double sum = 0.0;
+        for (int c = 0; c < C; c++) {
+            const double* r = q.root + ((size_t)c * P + p) * S;
+            double s = 0.0;
+            if (S == 4) { const d4 v = *reinterpret_cast<const d4*>(r); s = q.freqs[0] * v.x + q.freqs[1] * v.y + q.freqs[2] * v.z + q.freqs[3] * v.w; }
+            else for (int i = 0; i < S; i++) s += q.freqs[i] * r[i];
+            sum += q.catWeights[c] * s;
+        }
+        double site = log(sum);
+        if (q.cum) site += q.cumIsRaw ? log(q.cum[p]) : q.cum[p];
+        siteLogL[p] = site;
+        contrib = site * patternWeights[p];
+    }
+    const double t = blockSum(contrib, sh);
+    if (threadIdx.x == 0) blockSums[q.blockOff + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinalParts(const double* __restrict__ blockSums, const RootParts parts, double* __restrict__ out,
+                                                               unsigned long long* flag, unsigned long long seq) {
+    __shared__ double sh[ROOT_BLOCK / 64];
+    for (int k = 0; k < parts.n; k++) {
+        const RootPart& q = parts.p[k];
+        const int n = (q.pEnd - q.pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
+        double v = 0.0;
+        for (int j = threadIdx.x; j < n; j += ROOT_BLOCK) v += blockSums[q.blockOff + j];
+        __syncthreads();
+        const double t = blockSum(v, sh);
+        if (threadIdx.x == 0) out[k] = t;
+    }
+    if (threadIdx.x == 0 && flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
+}
+
+void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
+                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq) {
+    int maxBlocks = 1;
+    for (int k = 0; k < parts.n; k++) maxBlocks = std::max(maxBlocks, (parts.p[k].pEnd - parts.p[k].pStart + ROOT_BLOCK - 1) / ROOT_BLOCK);
+    hipLaunchKernelGGL(k_rootSiteParts, dim3(maxBlocks, parts.n), dim3(ROOT_BLOCK), 0, stream, parts, patternWeights, siteLogL, blockSums, P, S, C);
+    hipLaunchKernelGGL(k_rootFinalParts, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, parts, out, flag, seq);
 }
 
 void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out, unsigned long long* flag, unsigned long long seq) {

@@ -340,36 +340,29 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     // ---- closed list?  then the plan may be in the cache (planner.h)
     CacheEntry* fill = nullptr;
     if (cacheEnabled && count >= 16) {
-        bool closed = true;
-        uint64_t h = 1469598103934665603ull ^ (uint64_t)count * 0x9E3779B97F4A7C15ull ^ (uint64_t)tuple << 40 ^ (uint64_t)chunkOps << 20 ^ (uint64_t)allowVirtual;
-        tipScratch_.resize((size_t)count * 2);
+        if (CacheEntry* hit = findCached(ops, count, tuple, parts, allowVirtual, chunkOps)) {
+            stamp_++;
+            replay(*hit, ops);
+            cacheHits++;
+            return 0;
+        }
+        bool closed = true, simple = true;
         for (int k = 0; k < count && closed; k++) {
             const int* op = ops + (size_t)k * tuple;
             const int part = tuple > 7 ? op[7] : 0;
-            const char t1 = compactTip[op[3]], t2 = compactTip[op[5]];
-            if (!t1 && wStamp_[(size_t)op[3] * parts + part] != stamp_) closed = false;
-            if (!t2 && wStamp_[(size_t)op[5] * parts + part] != stamp_) closed = false;
+            if (!compactTip[op[3]] && wStamp_[(size_t)op[3] * parts + part] != stamp_) closed = false;
+            if (!compactTip[op[5]] && wStamp_[(size_t)op[5] * parts + part] != stamp_) closed = false;
             wStamp_[(size_t)op[0] * parts + part] = stamp_;
-            tipScratch_[2 * k] = t1; tipScratch_[2 * k + 1] = t2;
-            for (int q = 0; q < tuple; q++) h = (h ^ (uint64_t)(unsigned)op[q]) * 1099511628211ull;
-            h = (h ^ (uint64_t)(t1 * 2 + t2)) * 1099511628211ull;
+            if (op[1] != OP_NONE || op[0] == op[3] || op[0] == op[5] || (op[0] < tipCount_ && compactTip[op[0]]) ||
+                (tuple > 7 && op[8] != OP_NONE)) simple = false;
         }
         stamp_++;                                      // the marks above must not look like producers to pass 1
         if (closed) {
-            for (CacheEntry& e : cache_)
-                if (e.valid && e.hash == h && e.count == count && e.tuple == tuple && e.parts == parts && e.chunkOps == chunkOps &&
-                    e.allowVirtual == allowVirtual && memcmp(e.ops.data(), ops, (size_t)count * tuple * sizeof(int)) == 0 &&
-                    memcmp(e.tips.data(), tipScratch_.data(), (size_t)count * 2) == 0) {
-                    replay(e, ops);
-                    cacheHits++;
-                    return 0;
-                }
             fill = &cache_[cacheNext_];
             cacheNext_ = (cacheNext_ + 1) % CACHE_WAYS;
-            fill->valid = false; fill->tag = ++cacheTagNext_; fill->hash = h; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
-            fill->allowVirtual = allowVirtual;
+            fill->valid = false; fill->tag = ++cacheTagNext_; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
+            fill->allowVirtual = allowVirtual; fill->tipEpoch = compactEpoch; fill->simple = simple;
             fill->ops.assign(ops, ops + (size_t)count * tuple);
-            fill->tips.assign(tipScratch_.begin(), tipScratch_.begin() + (size_t)count * 2);
         }
     }
     info_.assign(count, OpInfo());
@@ -545,6 +538,27 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         fill->valid = true;
     }
     return 0;
+}
+
+WalkPlanner::CacheEntry* WalkPlanner::findCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps) {
+    for (CacheEntry& e : cache_)
+        if (e.valid && e.count == count && e.tuple == tuple && e.parts == parts && e.chunkOps == chunkOps && e.allowVirtual == allowVirtual &&
+            e.tipEpoch == compactEpoch && memcmp(e.ops.data(), ops, (size_t)count * tuple * sizeof(int)) == 0)
+            return &e;
+    return nullptr;
+}
+
+bool WalkPlanner::replayCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps, bool* simple) {
+    if (!cacheEnabled || count < 16 || parts != keyParts_) return false;
+    allowVirtual = allowVirtual && enabled_;
+    CacheEntry* e = findCached(ops, count, tuple, parts, allowVirtual, chunkOps);
+    if (!e || (simple && !e->simple)) return false;    // (asked for a simple list only: nothing has been touched)
+    parts_ = parts;
+    stamp_ += 2;                                       // a list of its own, as in plan()
+    replay(*e, ops);
+    cacheHits++;
+    if (simple) *simple = e->simple;
+    return true;
 }
 
 // Put the planner into the state planning the (closed) list again would leave it in; the kept program is handed out

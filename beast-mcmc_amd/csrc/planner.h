@@ -81,8 +81,11 @@ public:
     // holdSlots: per-thread slots a value can wait in while its sibling's subtree is evaluated (2 or 3; kernels.h)
     void init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled, int holdSlots = 2);
 
-    // maintained by the engine: buffer holds compact tip states (index < tipCount and setTipStates was the last setter)
+    // maintained by the engine through setCompactTip: buffer holds compact tip states (index < tipCount and setTipStates was
+    // the last setter).  compactEpoch counts the changes (a cached plan is only valid for the flags it was made with).
     std::vector<char> compactTip;
+    long compactEpoch = 0;
+    void setCompactTip(int buf, bool on) { const char v = on ? 1 : 0; if (compactTip[buf] != v) { compactTip[buf] = v; compactEpoch++; } }
 
     // A definition belongs to a (buffer, partition) pair — a partitioned instance updates the pattern ranges of one buffer
     // independently (MultiPartitionDataLikelihoodDelegate.java:972-997: every partition flips its own buffer indices) — and
@@ -121,6 +124,13 @@ public:
     // `chunkOps` > 0 (few pattern groups, so a launch cannot fill the chip with one walk per group): the forest is cut
     // into independent subtrees of about that many micro-operations, run side by side, wave after wave.
     int plan(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, Plan& out, int chunkOps = 0);
+
+    // The steady state of a chain: the SAME closed list as one planned before (byte for byte, same compact-tip flags).  Returns
+    // true and leaves the planner as plan() would — `planned` is the kept program — after one memcmp and one tag comparison per
+    // operation.  `simple` (out): the list has no rescaling operation, no in-place update and no tip as a destination, so
+    // nothing has to be materialised before it and nothing accumulated after it: the engine may skip its per-operation
+    // checks too (they passed when the entry was made).  With `simple` given, a list that is not simple is left alone (false).
+    bool replayCached(const int* ops, int count, int tuple, int partitionCount, bool allowVirtual, int chunkOps, bool* simple);
 
     // Program that gives every definition of `keys` its real partials (one slice per partition); the definitions are dropped.
     void planMaterialize(const std::vector<int>& keys, Plan& out);
@@ -173,11 +183,11 @@ private:
     struct CacheEntry {
         bool valid = false;
         long tag = 0;
-        uint64_t hash = 0;
         int count = 0, tuple = 0, parts = 0, chunkOps = 0;
         bool allowVirtual = false;
         std::vector<int> ops;
-        std::vector<char> tips;                        // compact flags of (child1, child2) per op
+        long tipEpoch = -1;                            // compactEpoch the plan was made under
+        bool simple = false;                           // see replayCached
         Plan plan;
         std::vector<VirtDef> defs;                     // per op: the definition its destination ends up with (on = false: real)
         std::vector<char> defOn;                       // defs[k].on
@@ -187,8 +197,8 @@ private:
     CacheEntry cache_[CACHE_WAYS];
     int cacheNext_ = 0;
     long cacheTagNext_ = 0;
-    std::vector<char> tipScratch_;
     void replay(const CacheEntry& e, const int* ops);
+    CacheEntry* findCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps);
 };
 
 }  // namespace mi355
