@@ -328,7 +328,10 @@ static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_RE
 inline bool isVirt(const Instance* in, int X) { return in->virt && in->planner.isVirtual(X); }
 inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearVirtual(X); }
 inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
-inline void setCompact(Instance* in, int X, bool on) { in->planner.setCompactTip(X, on); }
+// what buffer X holds changed: compact tip states (on), or something else — in which case it is no uploaded-partials leaf
+// either until setLeaf says so (planner.h leafPartials)
+inline void setCompact(Instance* in, int X, bool on) { in->planner.setCompactTip(X, on); in->planner.setLeafPartials(X, false); }
+inline void setLeaf(Instance* in, int X) { if (X < in->tipCount) in->planner.setLeafPartials(X, true); }
 
 // The pair-interleaved layout for the instance's current partitions (Instance::pairPos), and the scale-buffer stride that
 // holds either half ([factors, plain | reciprocals, pair-interleaved]).
@@ -656,7 +659,7 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         const int* sub = ops + (size_t)begin * tuple;
         for (int k = 0; k < n; k++) {                       // a tip index reused as a destination now holds partials
             const int dest = sub[(size_t)k * tuple];
-            if (isCompactTip(in, dest)) { int rcm = materializeTipUsers(in, dest); if (rcm) return rcm; in->tipStates[dest] = nullptr; setCompact(in, dest, false); }
+            if (isCompactTip(in, dest) || in->planner.leafPartials[dest]) { int rcm = materializeTipUsers(in, dest); if (rcm) return rcm; in->tipStates[dest] = nullptr; setCompact(in, dest, false); }
         }
         std::vector<int> need;
         in->planner.mustMaterializeBefore(sub, n, tuple, need);
@@ -1662,6 +1665,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
     }
     in->tipStates[tipIndex] = nullptr;   // the buffer now holds partials (slab memory stays owned by the instance)
     setCompact(in, tipIndex, false);
+    setLeaf(in, tipIndex);               // ... that no operation computes: definitions may read them (planner.h leafPartials)
     return rc;
 }
 
@@ -1673,6 +1677,7 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     clearVirtual(in, bufferIndex);
     rc = ensurePartials(in, bufferIndex); if (rc) return rc;
     in->tipStates[bufferIndex] = nullptr; setCompact(in, bufferIndex, false);
+    setLeaf(in, bufferIndex);
     if (in->tiled) {
         std::vector<double> t((size_t)in->C * in->ntile * 32 * in->S);
         toTiled(in, inPartials, t.data(), in->C);

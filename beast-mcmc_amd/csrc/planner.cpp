@@ -24,6 +24,7 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
     tipUsers_.assign(partialsCount, std::vector<int>());
     scaleUsers_.assign(scaleCount_, std::vector<int>());
     compactTip.assign(partialsCount, 0);
+    leafPartials.assign(partialsCount, 0);
     wStamp_.assign(partialsCount, 0); rStamp_.assign(partialsCount, 0); wOp_.assign(partialsCount, 0);
     sWStamp_.assign(scaleCount_, 0); sRStamp_.assign(scaleCount_, 0); sDone_.assign(scaleCount_, 0);
     stamp_ = 0; virtVersion_ = 0;
@@ -66,7 +67,8 @@ void WalkPlanner::registerVirtual(int X) {
 // Try to define buffer X = node(child1 over matrix m1, child2 over matrix m2, scale).  Children are compact tips or
 // virtual buffers.  Appends (source, destination) matrix-copy pairs.  false: too many steps, or its evaluation would need
 // more hold slots than a definition may take.
-bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
+bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int c2, bool tip2, bool mem2, int m2, int scaleIdx, std::vector<int>& snapPairs) {
+    // (tip1 / tip2: the child is a LEAF — compact states, or with mem1 / mem2 uploaded tip partials)
     VirtDef nv;
     nv.on = true; nv.stamp = stamp_; nv.nSteps = 0; nv.chainOnly = true;
     std::vector<int> pairs;
@@ -93,13 +95,13 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool ti
     VirtStep last;
     last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.subA = -1; last.subB = -1; last.need = 0;
     if (tip1 && tip2) {
-        last.type = VT_CHERRY; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2;
+        last.type = VT_CHERRY; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2; last.memA = mem1; last.memB = mem2;
     } else if (tip1 != tip2) {
         const int vb = tip1 ? c2 : c1, t = tip1 ? c1 : c2, mv = tip1 ? m2 : m1, mt = tip1 ? m1 : m2;
         if (!virt_[vb].on) return false;
         const int r = append(vb);
         if (r < 0) return false;
-        last.type = VT_EXTEND; last.subA = r; last.tipB = t; last.originA = mv; last.originB = mt;
+        last.type = VT_EXTEND; last.subA = r; last.tipB = t; last.originA = mv; last.originB = mt; last.memB = tip1 ? mem1 : mem2;
         last.need = nv.steps[r].need;
     } else {
         if (!virt_[c1].on || !virt_[c2].on) return false;
@@ -128,7 +130,7 @@ bool WalkPlanner::defineCherry(int X, int tipA, int mA, int tipB, int mB, int sc
     if (!enabled_ || !compactTip[tipA] || !compactTip[tipB]) return false;
     stamp_++;
     if (virt_[X].on) clearVirtualKey(X);
-    if (!buildVirtual(X, tipA, true, mA, tipB, true, mB, scaleIdx, snapPairs)) return false;
+    if (!buildVirtual(X, tipA, true, false, mA, tipB, true, false, mB, scaleIdx, snapPairs)) return false;
     VirtDef& nv = virt_[X];
     nv.version = ++virtVersion_;
     nv.sigC1 = tipA; nv.sigM1 = mA; nv.sigC2 = tipB; nv.sigM2 = mB; nv.sigScale = scaleIdx; nv.sigTip1 = nv.sigTip2 = true;
@@ -192,12 +194,18 @@ void WalkPlanner::emitVirtualStep(int buf, int idx, unsigned freeMask, bool writ
     const VirtStep& st = v.steps[idx];
     MicroOp m = blankOp();
     if (st.type == VT_CHERRY) {
-        m.k1 = PK_TIPS; m.a1 = st.tipA; m.mat1 = snapSlot(buf, idx, 0);
-        m.k2 = PK_TIPS; m.a2 = st.tipB; m.mat2 = snapSlot(buf, idx, 1);
+        // a leaf read from memory goes first (the kernels prefetch the first child's partials; kernels.h)
+        const bool swap = st.memB && !st.memA;
+        const int tA = swap ? st.tipB : st.tipA, tB = swap ? st.tipA : st.tipB;
+        const bool mA = swap ? st.memB : st.memA, mB = swap ? st.memA : st.memB;
+        m.k1 = mA ? PK_MEM : PK_TIPS; m.a1 = tA; m.mat1 = snapSlot(buf, idx, swap ? 1 : 0);
+        m.k2 = mB ? PK_MEM : PK_TIPS; m.a2 = tB; m.mat2 = snapSlot(buf, idx, swap ? 0 : 1);
+        lastMemReads += (mA ? 1 : 0) + (mB ? 1 : 0);
     } else if (st.type == VT_EXTEND) {
         emitVirtualStep(buf, st.subA, freeMask, writeMode, out);
-        m.k1 = PK_TIPS; m.a1 = st.tipB; m.mat1 = snapSlot(buf, idx, 1);
+        m.k1 = st.memB ? PK_MEM : PK_TIPS; m.a1 = st.tipB; m.mat1 = snapSlot(buf, idx, 1);
         m.k2 = PK_ACC; m.mat2 = snapSlot(buf, idx, 0);
+        if (st.memB) lastMemReads++;
     } else {   // VT_JOIN: the operand that needs more hold slots first, parked while the other one is evaluated
         const int F = popcount2(freeMask);
         const int na = v.steps[st.subA].need, nb = v.steps[st.subB].need;
@@ -353,7 +361,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             if (!compactTip[op[3]] && wStamp_[(size_t)op[3] * parts + part] != stamp_) closed = false;
             if (!compactTip[op[5]] && wStamp_[(size_t)op[5] * parts + part] != stamp_) closed = false;
             wStamp_[(size_t)op[0] * parts + part] = stamp_;
-            if (op[1] != OP_NONE || op[0] == op[3] || op[0] == op[5] || (op[0] < tipCount_ && compactTip[op[0]]) ||
+            if (op[1] != OP_NONE || op[0] == op[3] || op[0] == op[5] || (compactTip[op[0]] || leafPartials[op[0]]) ||
                 (tuple > 7 && op[8] != OP_NONE)) simple = false;
         }
         stamp_++;                                      // the marks above must not look like producers to pass 1
@@ -376,16 +384,17 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         o.dest = op[0]; o.wS = op[1]; o.rS = op[2]; o.c1 = op[3]; o.m1 = op[4]; o.c2 = op[5]; o.m2 = op[6];
         o.part = tuple > 7 ? op[7] : 0;
         o.tip1 = compactTip[o.c1] != 0; o.tip2 = compactTip[o.c2] != 0;
+        o.leaf1 = o.tip1 || leafPartials[o.c1] != 0; o.leaf2 = o.tip2 || leafPartials[o.c2] != 0;
         o.virtDest = false; o.emitted = false; o.need = 0; o.size = 1;
         const size_t kd = (size_t)o.dest * parts + o.part, kc1 = (size_t)o.c1 * parts + o.part, kc2 = (size_t)o.c2 * parts + o.part;
         if (!o.tip1 && wStamp_[kc1] == stamp_) { prod1_[k] = wOp_[kc1]; consumed[prod1_[k]] = 1; }
         if (!o.tip2 && wStamp_[kc2] == stamp_) { prod2_[k] = wOp_[kc2]; consumed[prod2_[k]] = 1; }
         if (o.wS != OP_NONE) sWStamp_[(size_t)o.wS * parts + o.part] = stamp_;
 
-        const bool v1 = !o.tip1 && virt_[kc1].on, v2 = !o.tip2 && virt_[kc2].on;
+        const bool v1 = !o.leaf1 && virt_[kc1].on, v2 = !o.leaf2 && virt_[kc2].on;
         const int ownScale = o.wS != OP_NONE ? o.wS : o.rS;
         bool makeVirtual = false;
-        if (allowVirtual && (o.tip1 || v1) && (o.tip2 || v2) && o.c1 != o.dest && o.c2 != o.dest) {
+        if (allowVirtual && (o.leaf1 || v1) && (o.leaf2 || v2) && o.c1 != o.dest && o.c2 != o.dest) {
             VirtDef& ev = virt_[kd];
             // Steady state: the same op on the same buffers as when `dest` was last defined, its virtual children unchanged
             // (same definition version) and re-confirmed in this list exactly as they were fresh then -> the definition
@@ -397,7 +406,8 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 return fresh && cv.stamp == stamp_ && cv.version == ver;
             };
             if (ev.on && ev.sigC1 == o.c1 && ev.sigM1 == o.m1 && ev.sigC2 == o.c2 && ev.sigM2 == o.m2 && ev.sigScale == ownScale &&
-                childSame(kc1, o.tip1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(kc2, o.tip2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
+                ev.sigMem1 == (o.leaf1 && !o.tip1) && ev.sigMem2 == (o.leaf2 && !o.tip2) &&
+                childSame(kc1, o.leaf1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(kc2, o.leaf2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
                 for (int st = 0; st < ev.nSteps; st++) {
                     out.snapPairs.push_back(ev.steps[st].originA); out.snapPairs.push_back(snapSlot((int)kd, st, 0));
                     out.snapPairs.push_back(ev.steps[st].originB); out.snapPairs.push_back(snapSlot((int)kd, st, 1));
@@ -407,15 +417,16 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             } else {
                 VirtDef saved = ev;
                 if (saved.on) clearVirtualKey((int)kd);
-                makeVirtual = buildVirtual((int)kd, o.tip1 ? o.c1 : (int)kc1, o.tip1, o.m1, o.tip2 ? o.c2 : (int)kc2, o.tip2, o.m2, ownScale, out.snapPairs);
+                makeVirtual = buildVirtual((int)kd, o.leaf1 ? o.c1 : (int)kc1, o.leaf1, o.leaf1 && !o.tip1, o.m1,
+                                           o.leaf2 ? o.c2 : (int)kc2, o.leaf2, o.leaf2 && !o.tip2, o.m2, ownScale, out.snapPairs);
                 if (!makeVirtual && saved.on) { virt_[kd] = saved; tagOf_[kd] = saved.cacheTag; registerVirtual((int)kd); }
                 if (makeVirtual) {
                     VirtDef& nv = virt_[kd];
                     nv.version = ++virtVersion_;
                     nv.sigC1 = o.c1; nv.sigM1 = o.m1; nv.sigC2 = o.c2; nv.sigM2 = o.m2; nv.sigScale = ownScale;
-                    nv.sigTip1 = o.tip1; nv.sigTip2 = o.tip2;
-                    nv.fresh1 = !o.tip1 && virt_[kc1].stamp == stamp_; nv.fresh2 = !o.tip2 && virt_[kc2].stamp == stamp_;
-                    nv.childVer1 = o.tip1 ? -1 : virt_[kc1].version; nv.childVer2 = o.tip2 ? -1 : virt_[kc2].version;
+                    nv.sigTip1 = o.leaf1; nv.sigTip2 = o.leaf2; nv.sigMem1 = o.leaf1 && !o.tip1; nv.sigMem2 = o.leaf2 && !o.tip2;
+                    nv.fresh1 = !o.leaf1 && virt_[kc1].stamp == stamp_; nv.fresh2 = !o.leaf2 && virt_[kc2].stamp == stamp_;
+                    nv.childVer1 = o.leaf1 ? -1 : virt_[kc1].version; nv.childVer2 = o.leaf2 ? -1 : virt_[kc2].version;
                 }
             }
         }

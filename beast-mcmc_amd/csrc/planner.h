@@ -55,7 +55,8 @@ struct Plan {
 enum { VT_CHERRY = 1, VT_EXTEND = 2, VT_JOIN = 3 };
 struct VirtStep {
     int type;               // VT_CHERRY: tipA, tipB;  VT_EXTEND: subA, tipB;  VT_JOIN: subA, subB
-    int tipA, tipB;         // tip buffers (or -1)
+    int tipA, tipB;         // leaf buffers (or -1): compact tip states, or (memA / memB) partials the caller uploaded for a tip
+    bool memA = false, memB = false;
     int subA, subB;         // earlier steps of the same definition (or -1)
     int scaleIdx;           // this node's scale buffer, or PLAN_NONE
     int originA, originB;   // matrix slots the snapshots of operand A's / B's branch were last copied FROM
@@ -71,7 +72,7 @@ struct VirtDef {
     // other evaluation): a definition whose op and children are unchanged is re-confirmed, not rebuilt
     int version = 0;
     int sigC1 = -1, sigM1 = -1, sigC2 = -1, sigM2 = -1, sigScale = -2;
-    bool sigTip1 = false, sigTip2 = false, fresh1 = false, fresh2 = false;
+    bool sigTip1 = false, sigTip2 = false, sigMem1 = false, sigMem2 = false, fresh1 = false, fresh2 = false;   // sigTip: the child is a leaf
     int childVer1 = -1, childVer2 = -1;
     long cacheTag = 0;      // plan-cache entry that last wrote or confirmed this definition (0: none) — see WalkPlanner::replay
 };
@@ -86,6 +87,11 @@ public:
     std::vector<char> compactTip;
     long compactEpoch = 0;
     void setCompactTip(int buf, bool on) { const char v = on ? 1 : 0; if (compactTip[buf] != v) { compactTip[buf] = v; compactEpoch++; } }
+    // ... or holds PARTIALS the caller uploaded for a tip (setTipPartials / setPartials on a tip index: ambiguity codes as
+    // partials, sequence-error models — BeagleTreeLikelihood.java:497-509): data no operation computes, so a definition may
+    // read it as a leaf too (32 C bytes per pattern from memory instead of a state byte)
+    std::vector<char> leafPartials;
+    void setLeafPartials(int buf, bool on) { const char v = on ? 1 : 0; if (leafPartials[buf] != v) { leafPartials[buf] = v; compactEpoch++; } }
 
     // A definition belongs to a (buffer, partition) pair — a partitioned instance updates the pattern ranges of one buffer
     // independently (MultiPartitionDataLikelihoodDelegate.java:972-997: every partition flips its own buffer indices) — and
@@ -147,12 +153,12 @@ public:
 private:
     struct OpInfo {
         int dest, wS, rS, c1, m1, c2, m2, part;
-        bool tip1, tip2, virtDest;
+        bool tip1, tip2, leaf1, leaf2, virtDest;     // tip: compact states;  leaf: that, or uploaded tip partials
         int need;           // hold slots the evaluation needs (-1: not computed yet)
         int size;           // real micro-ops below (ordering heuristic)
         bool emitted;
     };
-    bool buildVirtual(int X, int c1, bool tip1, int m1, int c2, bool tip2, int m2, int scaleIdx, std::vector<int>& snapPairs);   // X, and a non-tip child: KEYS
+    bool buildVirtual(int X, int c1, bool leaf1, bool mem1, int m1, int c2, bool leaf2, bool mem2, int m2, int scaleIdx, std::vector<int>& snapPairs);   // X, and a non-leaf child: KEYS
     void registerVirtual(int X);
     // emission
     void emitReal(int root, unsigned freeMask, Plan& out);

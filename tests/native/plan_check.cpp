@@ -178,7 +178,7 @@ struct Harness {
         std::vector<uint8_t> s(P);
         for (int p = 0; p < P; p++) s[p] = (uint8_t)(rng() % 5);
         truth.tips[tip] = s; plan.tips[tip] = s;
-        compact[tip] = 1; pl.setCompactTip(tip, true);
+        compact[tip] = 1; pl.setCompactTip(tip, true); pl.setLeafPartials(tip, false);
     }
     void setTipPartials(int tip) {
         materialiseKeys(pl.tipUsers(tip));
@@ -187,7 +187,7 @@ struct Harness {
         std::uniform_real_distribution<double> u(0.05, 1.0);
         for (double& v : x) v = u(rng);
         truth.partials[tip] = x; plan.partials[tip] = x;
-        compact[tip] = 0; pl.setCompactTip(tip, false);
+        compact[tip] = 0; pl.setCompactTip(tip, false); pl.setLeafPartials(tip, true);      // uploaded partials: a leaf definitions may read
     }
     void setMatrix(int slot) {
         std::uniform_real_distribution<double> u(0.01, 1.0);

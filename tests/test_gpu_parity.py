@@ -361,3 +361,46 @@ def test_ladder_tree_every_node_stored(oracle_lib, monkeypatch):
         scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
         assert np.max(np.abs(pg - po) / scale) <= REL_TOL, node
     g.close(); o.close()
+
+
+def test_all_tips_as_partials_stay_unstored(oracle_lib):
+    """A useAmbiguities-style analysis: EVERY tip is uploaded as partials (soft ambiguity codes;
+    BeagleTreeLikelihood.java:497-509).  Definitions of unstored nodes read such a tip as a memory leaf (planner.h
+    leafPartials), so the evaluation keeps the shape it has with compact states; a changed tip (sequence-error models re-send
+    tips every evaluation, :917-930) materialises what was defined on it."""
+    import ctypes as C
+    wl = helpers.random_workload(60, 1500, 4, 4, seed=31)
+    rng = np.random.default_rng(3)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+
+    def upload(tips, soft):
+        for tip in tips:
+            st = wl.tip_states[tip]
+            part = np.full((wl.pattern_count, 4), soft)
+            known = st < 4
+            part[np.arange(wl.pattern_count)[known], st[known]] = 1.0
+            part[~known] = 1.0
+            part = np.ascontiguousarray(part)
+            for t in (g, o):
+                t._chk(t.h.btlSetTipPartials(t.ptr, tip, part.ctypes.data_as(C.POINTER(C.c_double))), "setTipPartials")
+    upload(range(wl.tip_count), 0.02)
+    raw = bm.beagle.Beagle.attach(g)
+    for t in (g, o):
+        t.makeDirty()
+    assert_parity(g, o, "tips as partials, write mode")
+    raw.kernelTimer(True)
+    for t in (g, o):
+        t.makeDirty()
+    assert_parity(g, o, "tips as partials, read mode")
+    stats = raw.walkStats()
+    raw.kernelTimer(False)
+    assert stats["stored"] * 4 < stats["micro_ops"], stats          # most nodes are defined, not stored
+    upload([5, 17], 0.07)                                            # new data for two tips
+    for t in (g, o):
+        t.makeDirty()
+    assert_parity(g, o, "two tips changed")
+    for node in range(wl.tip_count, 2 * wl.tip_count - 1, 5):
+        pg, po = _partials(g, node), _partials(o, node)
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= REL_TOL, node
+    g.close(); o.close()
