@@ -120,7 +120,8 @@ _PROTOS = {
 ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetBenchmarkedResourceList", "beagleGetApiTable"] + \
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
-               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GetPartialsBatch"]
+               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GetPartialsBatch",
+               "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned"]
 
 
 class EngineLibrary:

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <chrono>
 #include <atomic>
@@ -80,7 +81,8 @@ struct Instance {
     double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
-    double* exportDev = nullptr; size_t exportDevBuffers = 0; double* exportHost = nullptr; size_t exportHostBytes = 0;
+    double* exportDev[2] = {nullptr, nullptr}; double* exportHost[2] = {nullptr, nullptr}; size_t exportBytes = 0;   // two chunks in flight
+    hipEvent_t exportEvent[2] = {nullptr, nullptr};
     long statMicroOps = 0, statStored = 0, statMemReads = 0, statTipReads = 0, statScaleReads = 0, statWalks = 0, statScaleWrites = 0;   // since the last timer reset
     hipStream_t stream = nullptr, ownStream = nullptr;
     int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
@@ -242,8 +244,11 @@ void destroy(Instance* in) {
     if (in->bigStage) hipFree(in->bigStage);
     if (in->matStream) hipFree(in->matStream);
     for (auto& r : in->resolved) if (r.dProg) hipFree(r.dProg);
-    if (in->exportDev) hipFree(in->exportDev);
-    if (in->exportHost) hipHostFree(in->exportHost);
+    for (int k = 0; k < 2; k++) {
+        if (in->exportDev[k]) hipFree(in->exportDev[k]);
+        if (in->exportHost[k]) hipHostFree(in->exportHost[k]);
+        if (in->exportEvent[k]) hipEventDestroy(in->exportEvent[k]);
+    }
     if (in->hRing) hipHostFree(in->hRing);
     if (in->hResult) hipHostFree(in->hResult);
     for (auto& ev : in->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -1690,6 +1695,24 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
 // internal node once per logged sample): virtual buffers are materialised by ONE walk, every buffer is converted to the
 // API layout [C][P][S] on the device with its scale factors folded in, and the device-to-host copies stream through a
 // pinned bounce buffer, a chunk of buffers at a time, with one synchronisation per chunk.
+// host-side copy of a chunk out of the pinned bounce buffer, on a few threads when it is large: the destination is the
+// caller's array, usually touched for the first time here, and faulting its pages in is what bounds a single thread
+// (profiles/r02_readback.json: the 1.28 GB sweep ran at 8 GB/s, below the node-by-node loop)
+struct HostCopy {
+    std::vector<std::thread> th;
+    void start(char* dst, const char* src, size_t bytes) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t k = bytes < ((size_t)8 << 20) ? 1 : std::min<size_t>(8, std::max<size_t>(1, hw / 2));
+        if (k == 1) { memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes / k) + 4095) & ~(size_t)4095;
+        for (size_t i = 0; i * per < bytes; i++)
+            th.emplace_back([=] { memcpy(dst + i * per, src + i * per, std::min(per, bytes - i * per)); });
+    }
+    void join() { for (auto& t : th) t.join(); th.clear(); }
+    ~HostCopy() { join(); }
+};
+
+// out == nullptr (count must fit one chunk): the data is left in the pinned buffer exportHost[0] (beagleMi355GetPartialsPinned)
 static int exportPartials(Instance* in, const int* bufferIndices, const int* scaleIndices, int count, double* out) {
     std::vector<int> need;
     for (int k = 0; k < count; k++) {
@@ -1700,36 +1723,53 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     const size_t elems = (size_t)in->C * in->P * in->S, bytes = elems * sizeof(double);
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / bytes));     // <= 256 MiB in flight
-    if (in->exportDevBuffers < chunk) {
-        if (in->exportDev) hipFree(in->exportDev);
-        in->exportDev = nullptr; in->exportDevBuffers = 0;
-        HIP_TRY(hipMalloc((void**)&in->exportDev, chunk * bytes));
-        in->exportDevBuffers = chunk;
+    // chunks of about 32 MiB, two in flight: while the device converts and copies chunk k + 1, the host empties chunk k
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)32 << 20) / bytes));
+    if (!out && (size_t)count > chunk) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (in->exportBytes < chunk * bytes) {
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        for (int k = 0; k < 2; k++) {
+            if (in->exportDev[k]) hipFree(in->exportDev[k]);
+            if (in->exportHost[k]) hipHostFree(in->exportHost[k]);
+            in->exportDev[k] = nullptr; in->exportHost[k] = nullptr;
+        }
+        in->exportBytes = 0;
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc((void**)&in->exportDev[k], chunk * bytes));
+            HIP_TRY(hipHostMalloc((void**)&in->exportHost[k], chunk * bytes, hipHostMallocDefault));
+            if (!in->exportEvent[k]) HIP_TRY(hipEventCreateWithFlags(&in->exportEvent[k], hipEventDisableTiming));
+        }
+        in->exportBytes = chunk * bytes;
     }
-    if (in->exportHostBytes < chunk * bytes) {
-        if (in->exportHost) hipHostFree(in->exportHost);
-        in->exportHost = nullptr; in->exportHostBytes = 0;
-        HIP_TRY(hipHostMalloc((void**)&in->exportHost, chunk * bytes, hipHostMallocDefault));
-        in->exportHostBytes = chunk * bytes;
-    }
-    for (size_t b0 = 0; b0 < (size_t)count; b0 += chunk) {
-        const size_t n = std::min(chunk, (size_t)count - b0);
+    HostCopy copies[2];
+    const size_t nChunks = ((size_t)count + chunk - 1) / chunk;
+    auto chunkCount = [&](size_t c) { return std::min(chunk, (size_t)count - c * chunk); };
+    for (size_t c = 0; c < nChunks; c++) {
+        const int w = (int)(c & 1);
+        copies[w].join();                                  // the host copy that was reading exportHost[w] (chunk c - 2)
+        const size_t n = chunkCount(c);
         for (size_t k = 0; k < n; k++) {
-            const int b = bufferIndices[b0 + k];
+            const int b = bufferIndices[c * chunk + k];
             if (!in->partials[b] || isCompactTip(in, b)) return BEAGLE_ERROR_OUT_OF_RANGE;
             const double* sc = nullptr; int raw = 0;
-            if (scaleIndices && scaleIndices[b0 + k] != BEAGLE_OP_NONE) {
-                int rc = ensureScale(in, scaleIndices[b0 + k]); if (rc) return rc;
-                sc = in->scale[scaleIndices[b0 + k]]; raw = in->scaleIsRaw[scaleIndices[b0 + k]];
+            if (scaleIndices && scaleIndices[c * chunk + k] != BEAGLE_OP_NONE) {
+                int rc = ensureScale(in, scaleIndices[c * chunk + k]); if (rc) return rc;
+                sc = in->scale[scaleIndices[c * chunk + k]]; raw = in->scaleIsRaw[scaleIndices[c * chunk + k]];
             }
-            mi355::launchExportPartials(in->stream, in->partials[b], sc, raw, in->exportDev + k * elems, in->P, in->S, in->C, in->tiled);
+            mi355::launchExportPartials(in->stream, in->partials[b], sc, raw, in->exportDev[w] + k * elems, in->P, in->S, in->C, in->tiled);
         }
-        HIP_TRY(hipMemcpyAsync(in->exportHost, in->exportDev, n * bytes, hipMemcpyDeviceToHost, in->stream));
-        HIP_TRY(hipStreamSynchronize(in->stream));
-        in->ringHead = 0;
-        memcpy(out + b0 * elems, in->exportHost, n * bytes);
+        HIP_TRY(hipMemcpyAsync(in->exportHost[w], in->exportDev[w], n * bytes, hipMemcpyDeviceToHost, in->stream));
+        HIP_TRY(hipEventRecord(in->exportEvent[w], in->stream));
+        if (c >= 1 && out) {                               // chunk c - 1 has landed (or lands while this one is being produced)
+            HIP_TRY(hipEventSynchronize(in->exportEvent[1 - w]));
+            copies[1 - w].start((char*)(out + (c - 1) * chunk * elems), (const char*)in->exportHost[1 - w], chunkCount(c - 1) * bytes);
+        }
     }
+    const int last = (int)((nChunks - 1) & 1);
+    HIP_TRY(hipEventSynchronize(in->exportEvent[last]));
+    in->ringHead = 0;
+    if (out) copies[last].start((char*)(out + (nChunks - 1) * chunk * elems), (const char*)in->exportHost[last], chunkCount(nChunks - 1) * bytes);
+    copies[0].join(); copies[1].join();
     return BEAGLE_SUCCESS;
 }
 
@@ -1752,6 +1792,31 @@ int beagleMi355GetPartialsBatch(int instance, const int* bufferIndices, const in
     GET_INSTANCE(instance);
     if (count <= 0) return BEAGLE_SUCCESS;
     return exportPartials(in, bufferIndices, scaleIndices, count, outPartials);
+}
+
+// MI355X extensions for the JNI shim: the result stays in the engine's pinned bounce buffer (valid until the next call on the
+// instance) and goes from there into the Java array with ONE copy.  Not for the sharded instance (NO_IMPLEMENTATION: the
+// shim then takes the ordinary entry point).
+int beagleMi355GetPartialsPinned(int instance, int bufferIndex, int scaleIndex, const double** outPinned, long* outCount) {
+    if (mi355::isShardedHandle(instance)) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    GET_INSTANCE(instance);
+    if (!outPinned || !outCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const int rc = exportPartials(in, &bufferIndex, &scaleIndex, 1, nullptr);
+    if (rc) return rc;
+    *outPinned = in->exportHost[0]; *outCount = (long)in->C * in->P * in->S;
+    return BEAGLE_SUCCESS;
+}
+int beagleMi355GetSiteLogLikelihoodsPinned(int instance, const double** outPinned, long* outCount) {
+    if (mi355::isShardedHandle(instance)) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    GET_INSTANCE(instance);
+    if (!outPinned || !outCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const size_t bytes = (size_t)in->P * sizeof(double);
+    if (bytes > RING_BYTES) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    HIP_TRY(hipMemcpyAsync(in->hRing, in->siteLogL, bytes, hipMemcpyDeviceToHost, in->stream));     // (the ring is pinned; everything staged in it
+    HIP_TRY(hipStreamSynchronize(in->stream));                                                      //  has been consumed once the stream is idle)
+    in->ringHead = (bytes + 255) & ~(size_t)255;
+    *outPinned = (const double*)in->hRing; *outCount = in->P;
+    return BEAGLE_SUCCESS;
 }
 
 int beagleGetLogScaleFactors(int instance, int scaleIndex, double* out) {

@@ -5,16 +5,22 @@
 // BeagleTreeLikelihood / TreeDataLikelihood call it unchanged.
 //
 // Parameter order of every function = the method descriptor in the class file (after JNIEnv*, jobject).
-// Java arrays are COPIED with Get<Type>ArrayRegion into library-owned buffers and, when they are outputs, copied back
-// with Set<Type>ArrayRegion (no pinning semantics to get wrong, and the JVM never has to hand out — or copy —
-// its heap array for the 7 (T-1) ints of an operation list).  null arrays are passed through as NULL
-// (HomogenousSubstitutionModelDelegate.java:260-261 passes null derivative indices).
+// Java arrays are COPIED with Get<Type>ArrayRegion into library-owned buffers and, when they are outputs, copied back with
+// Set<Type>ArrayRegion (no pinning semantics to get wrong).  What is copied is what the call uses, not the array:
+//   * inputs: the `count`-derived number of entries — BEAST's arrays are longer than that (operations[] is sized
+//     internalNodeCount * 7 whatever the count, BeagleDataLikelihoodDelegate.java:183; edgeLengths is the whole
+//     branchLengths[nodeCount], :179, 838-843);
+//   * outputs: nothing on the way in, exactly the entries written on the way out; getPartials and getSiteLogLikelihoods
+//     (12.8 MB and 0.8 MB per call in the metric's configuration, the latter once per evaluation of BeagleTreeLikelihood,
+//     BeagleTreeLikelihood.java:1050) go from the engine's pinned bounce buffer straight into the Java array.
+// null arrays are passed through as NULL (HomogenousSubstitutionModelDelegate.java:260-261 passes null derivative indices).
 //
 // Compiled against a self-authored minimal JNI header (jni_min.h).  The image has no JVM; tests/native/fake_jvm.cpp is a
-// JVM-less JNIEnv (229-slot function table over plain C++ objects) that drives these symbols end to end on the GPU box
-// (tests/test_gpu_jni_shim.py); INTEGRATION.md §4 lists the on-JVM validation steps.
+// JVM-less JNIEnv (229-slot function table over plain C++ objects) that drives these symbols end to end on the GPU box and
+// counts the bytes every call moves (tests/test_gpu_jni_shim.py); INTEGRATION.md §4 lists the on-JVM validation steps.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/beagle_mi355.h"
@@ -22,20 +28,28 @@
 
 namespace {
 
+enum Mode { IN, OUT, INOUT };
+// n < 0: the whole array
 struct IntArr {
-    JNIEnv* env; jintArray arr; std::vector<jint> buf; bool output;
-    IntArr(JNIEnv* e, jintArray a, bool out = false) : env(e), arr(a), output(out) {
-        if (a) { buf.resize((size_t)jni::GetArrayLength(e, a)); if (!buf.empty()) jni::GetIntArrayRegion(e, a, 0, (jsize)buf.size(), buf.data()); }
+    JNIEnv* env; jintArray arr; std::vector<jint> buf; Mode mode;
+    IntArr(JNIEnv* e, jintArray a, long n = -1, Mode m = IN) : env(e), arr(a), mode(m) {
+        if (!a) return;
+        const long len = (long)jni::GetArrayLength(e, a);
+        buf.resize((size_t)(n < 0 ? len : std::min(n, len)));
+        if (mode != OUT && !buf.empty()) jni::GetIntArrayRegion(e, a, 0, (jsize)buf.size(), buf.data());
     }
-    ~IntArr() { if (arr && output && !buf.empty()) jni::SetIntArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    ~IntArr() { if (arr && mode != IN && !buf.empty()) jni::SetIntArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
     operator int*() { return arr ? buf.data() : nullptr; }
 };
 struct DblArr {
-    JNIEnv* env; jdoubleArray arr; std::vector<jdouble> buf; bool output;
-    DblArr(JNIEnv* e, jdoubleArray a, bool out = false) : env(e), arr(a), output(out) {
-        if (a) { buf.resize((size_t)jni::GetArrayLength(e, a)); if (!buf.empty()) jni::GetDoubleArrayRegion(e, a, 0, (jsize)buf.size(), buf.data()); }
+    JNIEnv* env; jdoubleArray arr; std::vector<jdouble> buf; Mode mode;
+    DblArr(JNIEnv* e, jdoubleArray a, long n = -1, Mode m = IN) : env(e), arr(a), mode(m) {
+        if (!a) return;
+        const long len = (long)jni::GetArrayLength(e, a);
+        buf.resize((size_t)(n < 0 ? len : std::min(n, len)));
+        if (mode != OUT && !buf.empty()) jni::GetDoubleArrayRegion(e, a, 0, (jsize)buf.size(), buf.data());
     }
-    ~DblArr() { if (arr && output && !buf.empty()) jni::SetDoubleArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    ~DblArr() { if (arr && mode != IN && !buf.empty()) jni::SetDoubleArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
     operator double*() { return arr ? buf.data() : nullptr; }
 };
 
@@ -104,7 +118,7 @@ JNI_FN(jobjectArray, getBenchmarkedResourceList)(JNIEnv* env, jobject, jint tipC
                                                  jint patternCount, jint categoryCount, jintArray resourceList, jint resourceCount,
                                                  jlong preferenceFlags, jlong requirementFlags, jint eigenModelCount, jint partitionCount,
                                                  jint calculateDerivatives, jlong benchmarkFlags) {
-    IntArr res(env, resourceList);
+    IntArr res(env, resourceList, resourceCount);
     BeagleBenchmarkedResourceList* bl = beagleGetBenchmarkedResourceList(tipCount, compactBufferCount, stateCount, patternCount, categoryCount,
                                                                          res, resourceCount, (long)preferenceFlags, (long)requirementFlags,
                                                                          eigenModelCount, partitionCount, calculateDerivatives, (long)benchmarkFlags);
@@ -138,7 +152,7 @@ JNI_FN(jint, createInstance)(JNIEnv* env, jobject, jint tipCount, jint partialsB
                              jint categoryCount, jint scaleBufferCount, jintArray resourceList, jint resourceCount,
                              jlong preferenceFlags, jlong requirementFlags, jobject outDetails) {
     BeagleInstanceDetails d = {0, nullptr, nullptr, nullptr, 0};
-    IntArr res(env, resourceList);
+    IntArr res(env, resourceList, resourceCount);
     const int h = beagleCreateInstance(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount,
                                        eigenBufferCount, matrixBufferCount, categoryCount, scaleBufferCount, res, resourceCount,
                                        (long)preferenceFlags, (long)requirementFlags, &d);
@@ -165,22 +179,27 @@ JNI_FN(jint, setTipStates)(JNIEnv* env, jobject, jint instance, jint tip, jintAr
     IntArr a(env, states); return beagleSetTipStates(instance, tip, a);
 }
 JNI_FN(jint, getTipStates)(JNIEnv* env, jobject, jint instance, jint tip, jintArray states) {
-    IntArr a(env, states, true); return beagleGetTipStates(instance, tip, a);
+    IntArr a(env, states, -1, OUT); return beagleGetTipStates(instance, tip, a);
 }
 JNI_FN(jint, setTipPartials)(JNIEnv* env, jobject, jint instance, jint tip, jdoubleArray partials) {
     DblArr a(env, partials); return beagleSetTipPartials(instance, tip, a);
 }
 JNI_FN(jint, setRootPrePartials)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray freqs, jint count) {
-    IntArr a(env, bufs), b(env, freqs); return beagleSetRootPrePartials(instance, a, b, count);
+    IntArr a(env, bufs, count), b(env, freqs, count); return beagleSetRootPrePartials(instance, a, b, count);
 }
 JNI_FN(jint, setPartials)(JNIEnv* env, jobject, jint instance, jint buf, jdoubleArray partials) {
     DblArr a(env, partials); return beagleSetPartials(instance, buf, a);
 }
 JNI_FN(jint, getPartials)(JNIEnv* env, jobject, jint instance, jint buf, jint scaleIndex, jdoubleArray out) {
-    DblArr a(env, out, true); return beagleGetPartials(instance, buf, scaleIndex, a);
+    // straight from the engine's pinned bounce buffer into the Java array (no copy in, one copy out)
+    const double* pinned = nullptr; long n = 0;
+    const int rc = beagleMi355GetPartialsPinned(instance, buf, scaleIndex, &pinned, &n);
+    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) { DblArr a(env, out, -1, OUT); return beagleGetPartials(instance, buf, scaleIndex, a); }
+    if (rc == BEAGLE_SUCCESS && out) jni::SetDoubleArrayRegion(env, out, 0, (jsize)std::min<long>(n, (long)jni::GetArrayLength(env, out)), pinned);
+    return rc;
 }
 JNI_FN(jint, getLogScaleFactors)(JNIEnv* env, jobject, jint instance, jint scaleIndex, jdoubleArray out) {
-    DblArr a(env, out, true); return beagleGetLogScaleFactors(instance, scaleIndex, a);
+    DblArr a(env, out, -1, OUT); return beagleGetLogScaleFactors(instance, scaleIndex, a);
 }
 JNI_FN(jint, setEigenDecomposition)(JNIEnv* env, jobject, jint instance, jint eigenIndex, jdoubleArray u, jdoubleArray ui, jdoubleArray lam) {
     DblArr a(env, u), b(env, ui), c(env, lam); return beagleSetEigenDecomposition(instance, eigenIndex, a, b, c);
@@ -204,53 +223,53 @@ JNI_FN(jint, setDifferentialMatrix)(JNIEnv* env, jobject, jint instance, jint id
     DblArr a(env, m); return beagleSetDifferentialMatrix(instance, idx, a);
 }
 JNI_FN(jint, getTransitionMatrix)(JNIEnv* env, jobject, jint instance, jint idx, jdoubleArray out) {
-    DblArr a(env, out, true); return beagleGetTransitionMatrix(instance, idx, a);
+    DblArr a(env, out, -1, OUT); return beagleGetTransitionMatrix(instance, idx, a);
 }
 JNI_FN(jint, convolveTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray f, jintArray s, jintArray r, jint count) {
-    IntArr a(env, f), b(env, s), c(env, r); return beagleConvolveTransitionMatrices(instance, a, b, c, count);
+    IntArr a(env, f, count), b(env, s, count), c(env, r, count); return beagleConvolveTransitionMatrices(instance, a, b, c, count);
 }
 JNI_FN(jint, addTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray f, jintArray s, jintArray r, jint count) {
-    IntArr a(env, f), b(env, s), c(env, r); return beagleAddTransitionMatrices(instance, a, b, c, count);
+    IntArr a(env, f, count), b(env, s, count), c(env, r, count); return beagleAddTransitionMatrices(instance, a, b, c, count);
 }
 JNI_FN(jint, transposeTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray in, jintArray out, jint count) {
-    IntArr a(env, in), b(env, out); return beagleTransposeTransitionMatrices(instance, a, b, count);
+    IntArr a(env, in, count), b(env, out, count); return beagleTransposeTransitionMatrices(instance, a, b, count);
 }
 JNI_FN(jint, updateTransitionMatrices)(JNIEnv* env, jobject, jint instance, jint eigenIndex, jintArray prob, jintArray d1,
                                        jintArray d2, jdoubleArray lengths, jint count) {
-    IntArr a(env, prob), b(env, d1), c(env, d2); DblArr t(env, lengths);
+    IntArr a(env, prob, count), b(env, d1, count), c(env, d2, count); DblArr t(env, lengths, count);
     return beagleUpdateTransitionMatrices(instance, eigenIndex, a, b, c, t, count);
 }
 JNI_FN(jint, updateTransitionMatricesWithMultipleModels)(JNIEnv* env, jobject, jint instance, jintArray eigen, jintArray rates,
                                                          jintArray prob, jintArray d1, jintArray d2, jdoubleArray lengths, jint count) {
-    IntArr e(env, eigen), r(env, rates), a(env, prob), b(env, d1), c(env, d2); DblArr t(env, lengths);
+    IntArr e(env, eigen, count), r(env, rates, count), a(env, prob, count), b(env, d1, count), c(env, d2, count); DblArr t(env, lengths, count);
     return beagleUpdateTransitionMatricesWithMultipleModels(instance, e, r, a, b, c, t, count);
 }
 JNI_FN(jint, updatePrePartials)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count, jint cum) {
-    IntArr a(env, ops); return beagleUpdatePrePartials(instance, a, count, cum);
+    IntArr a(env, ops, 7L * count); return beagleUpdatePrePartials(instance, a, count, cum);
 }
 JNI_FN(jint, updatePrePartialsByPartition)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count) {
-    IntArr a(env, ops); return beagleUpdatePrePartialsByPartition(instance, a, count);
+    IntArr a(env, ops, 9L * count); return beagleUpdatePrePartialsByPartition(instance, a, count);
 }
 JNI_FN(jint, updatePartials)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count, jint cum) {
-    IntArr a(env, ops); return beagleUpdatePartials(instance, a, count, cum);
+    IntArr a(env, ops, 7L * count); return beagleUpdatePartials(instance, a, count, cum);
 }
 JNI_FN(jint, updatePartialsByPartition)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count) {
-    IntArr a(env, ops); return beagleUpdatePartialsByPartition(instance, a, count);
+    IntArr a(env, ops, 9L * count); return beagleUpdatePartialsByPartition(instance, a, count);
 }
 JNI_FN(jint, waitForPartials)(JNIEnv* env, jobject, jint instance, jintArray dest, jint count) {
-    IntArr a(env, dest); return beagleWaitForPartials(instance, a, count);
+    IntArr a(env, dest, count); return beagleWaitForPartials(instance, a, count);
 }
 JNI_FN(jint, accumulateScaleFactors)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum) {
-    IntArr a(env, idx); return beagleAccumulateScaleFactors(instance, a, count, cum);
+    IntArr a(env, idx, count); return beagleAccumulateScaleFactors(instance, a, count, cum);
 }
 JNI_FN(jint, accumulateScaleFactorsByPartition)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum, jint part) {
-    IntArr a(env, idx); return beagleAccumulateScaleFactorsByPartition(instance, a, count, cum, part);
+    IntArr a(env, idx, count); return beagleAccumulateScaleFactorsByPartition(instance, a, count, cum, part);
 }
 JNI_FN(jint, removeScaleFactors)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum) {
-    IntArr a(env, idx); return beagleRemoveScaleFactors(instance, a, count, cum);
+    IntArr a(env, idx, count); return beagleRemoveScaleFactors(instance, a, count, cum);
 }
 JNI_FN(jint, removeScaleFactorsByPartition)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum, jint part) {
-    IntArr a(env, idx); return beagleRemoveScaleFactorsByPartition(instance, a, count, cum, part);
+    IntArr a(env, idx, count); return beagleRemoveScaleFactorsByPartition(instance, a, count, cum, part);
 }
 JNI_FN(jint, resetScaleFactors)(JNIEnv*, jobject, jint instance, jint cum) { return beagleResetScaleFactors(instance, cum); }
 JNI_FN(jint, resetScaleFactorsByPartition)(JNIEnv*, jobject, jint instance, jint cum, jint part) {
@@ -260,18 +279,23 @@ JNI_FN(jint, copyScaleFactors)(JNIEnv*, jobject, jint instance, jint dst, jint s
 
 JNI_FN(jint, calculateRootLogLikelihoods)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray weights, jintArray freqs,
                                           jintArray cums, jint count, jdoubleArray outSum) {
-    IntArr a(env, bufs), b(env, weights), c(env, freqs), d(env, cums); DblArr o(env, outSum, true);
+    IntArr a(env, bufs, count), b(env, weights, count), c(env, freqs, count), d(env, cums, count); DblArr o(env, outSum, count, OUT);
     return beagleCalculateRootLogLikelihoods(instance, a, b, c, d, count, o);
 }
 JNI_FN(jint, calculateRootLogLikelihoodsByPartition)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray weights,
                                                      jintArray freqs, jintArray cums, jintArray parts, jint partitionCount,
                                                      jint count, jdoubleArray outByPartition, jdoubleArray outSum) {
-    IntArr a(env, bufs), b(env, weights), c(env, freqs), d(env, cums), p(env, parts);
-    DblArr o1(env, outByPartition, true), o2(env, outSum, true);
+    const long n = (long)partitionCount * count;
+    IntArr a(env, bufs, n), b(env, weights, n), c(env, freqs, n), d(env, cums, n), p(env, parts, partitionCount);
+    DblArr o1(env, outByPartition, n, OUT), o2(env, outSum, count, OUT);
     return beagleCalculateRootLogLikelihoodsByPartition(instance, a, b, c, d, p, partitionCount, count, o1, o2);
 }
 JNI_FN(jint, getSiteLogLikelihoods)(JNIEnv* env, jobject, jint instance, jdoubleArray out) {
-    DblArr o(env, out, true); return beagleGetSiteLogLikelihoods(instance, o);
+    const double* pinned = nullptr; long n = 0;
+    const int rc = beagleMi355GetSiteLogLikelihoodsPinned(instance, &pinned, &n);
+    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) { DblArr o(env, out, -1, OUT); return beagleGetSiteLogLikelihoods(instance, o); }
+    if (rc == BEAGLE_SUCCESS && out) jni::SetDoubleArrayRegion(env, out, 0, (jsize)std::min<long>(n, (long)jni::GetArrayLength(env, out)), pinned);
+    return rc;
 }
 
 // gradient entry points.  BEAST passes null for outDerivatives and, on the second-derivative call, for
@@ -279,15 +303,15 @@ JNI_FN(jint, getSiteLogLikelihoods)(JNIEnv* env, jobject, jint instance, jdouble
 JNI_FN(jint, calculateEdgeDifferentials)(JNIEnv* env, jobject, jint instance, jintArray post, jintArray pre, jintArray dmat,
                                          jintArray weights, jint count, jdoubleArray outDeriv, jdoubleArray outSum,
                                          jdoubleArray outSumSquared) {
-    IntArr a(env, post), b(env, pre), c(env, dmat), w(env, weights);
-    DblArr o0(env, outDeriv, true), o1(env, outSum, true), o2(env, outSumSquared, true);
+    IntArr a(env, post, count), b(env, pre, count), c(env, dmat, count), w(env, weights);
+    DblArr o0(env, outDeriv, -1, OUT), o1(env, outSum, count, OUT), o2(env, outSumSquared, count, OUT);
     return beagleCalculateEdgeDifferentials(instance, a, b, c, w, count, o0, o1, o2);
 }
 JNI_FN(jint, calculateCrossProductDifferentials)(JNIEnv* env, jobject, jint instance, jintArray post, jintArray pre, jintArray rates,
                                                  jintArray weights, jdoubleArray lengths, jint count, jdoubleArray outSum,
                                                  jdoubleArray outSumSquared) {
-    IntArr a(env, post), b(env, pre), r(env, rates), w(env, weights);
-    DblArr t(env, lengths), o1(env, outSum, true), o2(env, outSumSquared, true);
+    IntArr a(env, post, count), b(env, pre, count), r(env, rates), w(env, weights);
+    DblArr t(env, lengths, count), o1(env, outSum, -1, INOUT), o2(env, outSumSquared, -1, INOUT);      // the sums are ADDED to what the arrays hold
     return beagleCalculateCrossProductDifferentials(instance, a, b, r, w, t, count, o1, o2);
 }
 JNI_FN(jint, calculateEdgeDerivative)(JNIEnv*, jobject, jint, jintArray, jintArray, jint, jintArray, jintArray, jint, jint, jint,

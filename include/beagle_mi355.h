@@ -311,6 +311,11 @@ int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, 
  * layout conversion, pinned copies, one synchronisation per 256 MiB — for hosts that read many nodes per sample
  * (AncestralStateBeagleTreeLikelihood.java:414-542); the per-buffer beagleGetPartials takes the same path with count 1. */
 int beagleMi355GetPartialsBatch(int instance, const int* bufferIndices, const int* scaleIndices, int count, double* outPartials);
+/* For the JNI shim: getPartials / getSiteLogLikelihoods whose result STAYS in the engine's pinned host buffer — *outPinned,
+ * *outCount doubles, valid until the next call on the instance — so that it reaches the Java array with one copy
+ * (Set<Type>ArrayRegion) instead of two.  BEAGLE_ERROR_NO_IMPLEMENTATION on the sharded instance: use the ordinary call. */
+int beagleMi355GetPartialsPinned(int instance, int bufferIndex, int scaleIndex, const double** outPinned, long* outCount);
+int beagleMi355GetSiteLogLikelihoodsPinned(int instance, const double** outPinned, long* outCount);
 /* Block until everything enqueued for the instance has completed. */
 int beagleMi355Synchronize(int instance);
 /* Engine-side timing of the hot kernel: HIP events recorded on the instance's stream around

@@ -12,6 +12,7 @@
 //       setTipStates ... updateTransitionMatrices (null derivative arrays) -> updatePartials -> calculateRootLogLikelihoods.
 // Slot numbers here are written down from the JNI specification independently of csrc/jni_min.h.
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,10 +85,14 @@ static FObj* f_NewStringUTF(FEnv*, const char* s) { FObj* o = new FObj(); o->cls
 static jsize f_GetArrayLength(FEnv*, FObj* a) { return (jsize)(a->cls == "[I" ? a->ints.size() : a->cls == "[D" ? a->dbls.size() : a->elems.size()); }
 static FObj* f_NewObjectArray(FEnv*, jsize n, FObj* cls, FObj*) { FObj* a = new FObj(); a->cls = "[L"; a->str = cls->str; a->elems.assign(n, nullptr); return a; }
 static void f_SetObjectArrayElement(FEnv*, FObj* a, jsize i, FObj* v) { a->elems[i] = v; }
-static void f_GetIntArrayRegion(FEnv*, FObj* a, jsize s, jsize n, jint* buf) { memcpy(buf, a->ints.data() + s, (size_t)n * sizeof(jint)); }
-static void f_GetDoubleArrayRegion(FEnv*, FObj* a, jsize s, jsize n, jdouble* buf) { memcpy(buf, a->dbls.data() + s, (size_t)n * sizeof(jdouble)); }
-static void f_SetIntArrayRegion(FEnv*, FObj* a, jsize s, jsize n, const jint* buf) { memcpy(a->ints.data() + s, buf, (size_t)n * sizeof(jint)); }
-static void f_SetDoubleArrayRegion(FEnv*, FObj* a, jsize s, jsize n, const jdouble* buf) { memcpy(a->dbls.data() + s, buf, (size_t)n * sizeof(jdouble)); }
+// bytes the shim moves between the "Java heap" and its own buffers (printed per call by the driver below: the shim must copy
+// what a call uses — count-derived lengths in, outputs out only — not whole arrays)
+static long g_bytesIn = 0, g_bytesOut = 0;
+static void f_GetIntArrayRegion(FEnv*, FObj* a, jsize s, jsize n, jint* buf) { memcpy(buf, a->ints.data() + s, (size_t)n * sizeof(jint)); g_bytesIn += (long)n * 4; }
+static void f_GetDoubleArrayRegion(FEnv*, FObj* a, jsize s, jsize n, jdouble* buf) { memcpy(buf, a->dbls.data() + s, (size_t)n * sizeof(jdouble)); g_bytesIn += (long)n * 8; }
+static void f_SetIntArrayRegion(FEnv*, FObj* a, jsize s, jsize n, const jint* buf) { memcpy(a->ints.data() + s, buf, (size_t)n * sizeof(jint)); g_bytesOut += (long)n * 4; }
+static void f_SetDoubleArrayRegion(FEnv*, FObj* a, jsize s, jsize n, const jdouble* buf) { memcpy(a->dbls.data() + s, buf, (size_t)n * sizeof(jdouble)); g_bytesOut += (long)n * 8; }
+static void traffic(const char* call) { printf("traffic %s in=%ld out=%ld\n", call, g_bytesIn, g_bytesOut); g_bytesIn = g_bytesOut = 0; }
 
 // JNI 1.6 Interface Function Table: 0-3 reserved, 4 GetVersion, 5 DefineClass, 6 FindClass, ... 17 ExceptionClear, ...
 // 23 DeleteLocalRef, ... 28 NewObject, ... 31 GetObjectClass, 32 IsInstanceOf, 33 GetMethodID, ... 61 CallVoidMethod, ...
@@ -165,21 +170,36 @@ int main(int argc, char** argv) {
     typedef jint (*UtmFn)(FEnv*, FObj*, jint, jint, FObj*, FObj*, FObj*, FObj*, jint);
     // the edge-length array is longer than `count`, the derivative index arrays are null (HomogenousSubstitutionModelDelegate.java:260-261)
     std::vector<jdouble> longEdges = edges; longEdges.resize(9, 123.0);
+    traffic("setup");
     rc |= sym<UtmFn>("updateTransitionMatrices")(env, self, h, 0, ints({0, 1, 2, 3}), nullptr, nullptr, dbls(longEdges), 4);
+    traffic("updateTransitionMatrices");
     typedef jint (*UpFn)(FEnv*, FObj*, jint, FObj*, jint, jint);
     std::vector<jint> ops = {3, -1, -1, 0, 0, 1, 1, 4, -1, -1, 2, 2, 3, 3};
     ops.resize(21, 0);                                                       // operations[] is sized internalNodeCount * 7 by BEAST
     rc |= sym<UpFn>("updatePartials")(env, self, h, ints(ops), 2, -1);
+    traffic("updatePartials");
     typedef jint (*RootFn)(FEnv*, FObj*, jint, FObj*, FObj*, FObj*, FObj*, jint, FObj*);
     FObj* out = dbls({0.0});
     const jint rcRoot = sym<RootFn>("calculateRootLogLikelihoods")(env, self, h, ints({4}), ints({0}), ints({0}), ints({-1}), 1, out);
+    traffic("calculateRootLogLikelihoods");
     printf("rc=%d rootRc=%d lnL=%.10f\n", rc, rcRoot, out->dbls[0]);
     FObj* site = dbls(std::vector<jdouble>(n, 0.0));
     rc = sym<IA>("getSiteLogLikelihoods")(env, self, h, site);
+    traffic("getSiteLogLikelihoods");
+    {   // getPartials (III[D)I of the root buffer: an output array, nothing goes in
+        typedef jint (*GpFn)(FEnv*, FObj*, jint, jint, jint, FObj*);
+        FObj* part = dbls(std::vector<jdouble>((size_t)n * 4, -1.0));
+        const jint rcp = sym<GpFn>("getPartials")(env, self, h, 4, -1, part);
+        traffic("getPartials");
+        double lnl = 0.0;
+        for (int p = 0; p < n; p++) lnl += log(0.25 * (part->dbls[4 * p] + part->dbls[4 * p + 1] + part->dbls[4 * p + 2] + part->dbls[4 * p + 3]));
+        printf("getPartialsRc=%d lnLfromPartials=%.10f\n", rcp, lnl);
+    }
     double s = 0.0; for (double v : site->dbls) s += v;
     printf("siteRc=%d siteSum=%.10f\n", rc, s);
     FObj* tips = ints(std::vector<jint>(n, -7));
     rc = sym<IIA>("getTipStates")(env, self, h, 1, tips);
+    traffic("getTipStates");
     int same = 0; for (int i = 0; i < n; i++) same += tips->ints[i] == rows[1][i];
     printf("getTipStatesRc=%d matching=%d of %d\n", rc, same, n);
     rc = sym<jint (*)(FEnv*, FObj*, jint)>("finalize")(env, self, h);

@@ -61,6 +61,18 @@ def test_jni_symbols_drive_the_engine_through_a_fake_jnienv(tmp_path):
     m3 = re.search(r"^getTipStatesRc=0 matching=(\d+) of (\d+)", txt, re.M)
     assert m3.group(1) == m3.group(2)                           # an OUTPUT array is copied back (SetIntArrayRegion)
     assert "finalizeRc=0" in txt
+    # what the shim copies per call: count-derived lengths in (the arrays are longer: 9 edge lengths for 4 branches, 21
+    # operation ints for 2 operations), outputs out only — never a whole output array in before it is overwritten
+    n_sites = len(rows[0])
+    traffic = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"^traffic (\w+) in=(\d+) out=(\d+)", txt, re.M)}
+    assert traffic["updateTransitionMatrices"] == (4 * 4 + 4 * 8, 0)            # 4 matrix indices + 4 lengths; null derivative arrays
+    assert traffic["updatePartials"] == (2 * 7 * 4, 0)
+    assert traffic["calculateRootLogLikelihoods"] == (4 * 4, 8)                 # four 1-entry index arrays in, one double out
+    assert traffic["getSiteLogLikelihoods"] == (0, 8 * n_sites)
+    assert traffic["getPartials"] == (0, 8 * 4 * n_sites)
+    assert traffic["getTipStates"] == (0, 4 * n_sites)
+    mp = re.search(r"^getPartialsRc=0 lnLfromPartials=(-?[\d.]+)", txt, re.M)
+    assert abs(float(mp.group(1)) - float(m.group(3))) < 1e-6                   # the root partials that came back are the right ones
     # -beagle_auto: every GPU resource benchmarked, fastest first, all ten setters of BenchmarkedResourceDetails used
     n_b = int(re.search(r"^benchmarked=(\d+) elementClass=beagle/BenchmarkedResourceDetails", txt, re.M).group(1))
     assert n_b == n_res - 1

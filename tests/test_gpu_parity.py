@@ -404,3 +404,29 @@ def test_all_tips_as_partials_stay_unstored(oracle_lib):
         scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
         assert np.max(np.abs(pg - po) / scale) <= REL_TOL, node
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("S,T,P", [(4, 40, 3000), (20, 16, 700)])
+def test_batched_read_back_of_every_internal_node(S, T, P, oracle_lib):
+    """beagleMi355GetPartialsBatch (what AncestralStateBeagleTreeLikelihood.java:414-542 does once per logged
+    sample, in one call): every internal node with its scale factors folded in, against the oracle's getPartials node by node,
+    and bitwise against the engine's own per-node getPartials.  The 4-state case reads back nodes that were never stored (one
+    batched materialisation); sizes chosen so that the sweep spans several pipeline chunks."""
+    wl = helpers.random_workload(T, P, S, 4, seed=70 + S)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+    assert_parity(g, o)
+    rg, ro = _raw(g), _raw(o)
+    nodes = list(range(wl.tip_count, 2 * wl.tip_count - 1))
+    bufs = [g.node_buffer_index(n) for n in nodes]
+    scales = [g.node_scale_index(n) for n in nodes]
+    batch = rg.getPartialsBatch(bufs, scales)
+    assert batch.shape == (len(nodes), 4, P, S)
+    for k, n in enumerate(nodes):
+        po = ro.getPartials(o.node_buffer_index(n), o.node_scale_index(n))
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(batch[k] - po) / scale) <= REL_TOL, n
+        assert np.array_equal(batch[k], rg.getPartials(bufs[k], scales[k])), n
+    unscaled = rg.getPartialsBatch(bufs, None)
+    assert np.array_equal(unscaled[3], rg.getPartials(bufs[3], bm.beagle.NONE))
+    assert_parity(g, o, "after the read-back")
+    g.close(); o.close()
