@@ -6,6 +6,8 @@ patterns, and pattern weights.  Sequences are simulated down the tree under the 
 per-pattern likelihoods have realistic magnitudes (and underflow without rescaling at T = 1000,
 which is what forces the reference's rescaling protocol into the benchmark).
 """
+import os
+
 import numpy as np
 
 from . import substmodel, trees
@@ -250,3 +252,26 @@ def config_e(scale=1.0, seed=41):
         pats, weights = patterns.site_patterns(cols, unique=True)
         parts.append(Workload("E:part%d" % k, tree, eig, pi, rates, props, pats, weights, 4))
     return PartitionedWorkload("E:Makona-like 4 x HKY+G4", tree, parts)
+
+
+def from_pattern_fixture(path, seed=51):
+    """A workload from a unique-site-pattern fixture (tests/golden/benchmark{1,2}_patterns.npz: the REAL alignments of the
+    reference's examples/Benchmarks inputs, written by tests/golden/make_fixtures.py --benchmarks) with the model the XML
+    names.  The XMLs draw a random coalescent starting tree; here it is a seeded coalescent of the same scale."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    model = json.loads(str(z["model"]))
+    pats = z["patterns"].astype(np.int32)
+    pats[pats > 3] = 4                                        # useAmbiguities="false": every ambiguity code is "unknown"
+    pi = np.asarray(model["pi"], dtype=float)
+    eig = substmodel.hky(model["kappa"], pi) if model["model"] == "hky" else substmodel.gtr(model["rates"], pi)
+    cats = int(model.get("gamma_categories", 1))
+    if cats > 1:
+        rates, props = GammaSiteRateModel(alpha=model["alpha"], gamma_categories=cats).category_rates_and_proportions()
+    else:
+        rates, props = [1.0], [1.0]
+    # substitutions from root to tip: the XML's rootHeight, or clock rate x ~2 N_e years of a constant-size coalescent
+    height = model.get("root_height") or model["clock_rate"] * 2.0 * model["popSize_years"]
+    tree = trees.coalescent_tree(pats.shape[0], np.random.default_rng(seed), root_height=height)
+    return Workload(os.path.basename(path).replace("_patterns.npz", "") + " (real alignment)", tree, eig, pi, rates, props,
+                    np.ascontiguousarray(pats), z["weights"].astype(np.float64), 4)

@@ -75,6 +75,8 @@ def perturbed_models(bm, wl, config):
     pi = np.asarray(wl.freqs)
     if config == "A":
         eig2 = substmodel.gtr([1.0, 4.0 * (1 + 1e-6), 0.8, 1.2, 4.5, 1.0], pi)
+    elif config in ("D",) and wl.name.startswith("benchmark2"):
+        eig2 = substmodel.gtr([1.0, 1.0 + 1e-6, 1.0, 1.0, 1.0, 1.0], pi)
     elif config in ("D",):
         eig2 = substmodel.hky(2.0 * (1 + 1e-6), pi)
     else:                                   # B, C: the same rate matrix at a slightly different normalisation
@@ -97,6 +99,8 @@ def main():
                     help="tdl: TreeDataLikelihood protocol (default); btl: BeagleTreeLikelihood also reads the site log-likelihoods back every evaluation")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink taxa/patterns (development only; 1.0 = the metric's config)")
     ap.add_argument("--tree", default="coalescent", choices=["coalescent", "yule", "caterpillar"])
+    ap.add_argument("--real", default="", choices=["", "benchmark1", "benchmark2"],
+                    help="config D on a REAL alignment of the reference's examples/Benchmarks (tests/golden/<name>_patterns.npz) instead of the synthetic stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--patterns", type=int, default=0, help="development: keep only the first N patterns (size of one shard of an N-GPU job)")
     ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
@@ -157,6 +161,9 @@ def main():
     cache = os.path.join(args.cache, "wl_%s_%g_%s.pkl" % (args.config, args.scale, args.tree)) if args.cache else None
     if cache and world > 1 and rank != 0:
         dist.barrier()                                  # rank 0 generates, the others read its file
+    if args.real:
+        args.config, cache = "D", None
+        makers["D"] = lambda: bm.synth.from_pattern_fixture(os.path.join(ROOT, "tests", "golden", args.real + "_patterns.npz"))
     wl = bm.synth.cached(cache, makers[args.config])
     if cache and world > 1 and rank == 0:
         dist.barrier()

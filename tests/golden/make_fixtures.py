@@ -15,6 +15,10 @@ Outputs (data only — inputs and expected outputs, no reference source text):
                          tests/TestXML/testBranchSpecificSubstitutionModel.xml:44-61, 77-79, 114-207, 209-235
   jar_smoke.json         the API-level smoke test baked into lib/beagle.jar (beagle.BeagleFactory#main):
                          3 taxa, literal JC69 eigen system, literal op list, "PAUP logL = -1574.63623"
+  benchmark{1,2}_patterns.npz   (python tests/golden/make_fixtures.py --benchmarks) the REAL alignments of
+                         examples/Benchmarks/benchmark1.xml (1441 taxa x 987 sites -> 593 patterns, HKY) and benchmark2.xml
+                         (62 x 10869 -> 5565, GTR+G4) as unique site patterns + weights; no tree (the XMLs draw a random
+                         one) and no expected value (none is published)
 """
 import json
 import os
@@ -35,7 +39,53 @@ def primate_sequences():
     return names, seqs
 
 
+def benchmark_alignment(xml_name):
+    """Taxon names and sequences of an examples/Benchmarks XML (data only)."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(os.path.join(REF, "examples", "Benchmarks", xml_name)).getroot()
+    names = [t.get("id") for t in root.find("taxa").findall("taxon")]
+    seqs = []
+    for s in root.find("alignment").findall("sequence"):
+        ref = s.find("taxon").get("idref")
+        text = "".join(t for t in s.itertext()).replace(ref, "")
+        seqs.append((ref, re.sub(r"\s+", "", text)))
+    assert [r for r, _ in seqs] == names, "alignment order differs from the taxa block"
+    return names, [q for _, q in seqs]
+
+
+def benchmark_fixture(xml_name, out_name, expect_taxa, expect_sites, expect_patterns, model, cite):
+    """Real alignments of the reference's own benchmark inputs, compressed to unique site patterns exactly as
+    SitePatterns does (state codes of Nucleotides.java incl. the IUPAC ambiguity codes; first occurrence keeps the column).
+    The XMLs draw a RANDOM coalescent starting tree and publish no expected lnL, so these fixtures pin engine <-> oracle on
+    real ambiguity patterns, pattern weights and sizes — not an absolute value."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from beast_mcmc_amd.inputs import patterns
+    names, seqs = benchmark_alignment(xml_name)
+    assert len(names) == expect_taxa and all(len(q) == expect_sites for q in seqs), (len(names), set(len(q) for q in seqs))
+    rows = np.stack([patterns.nucleotide_states(q) for q in seqs])
+    pats, weights = patterns.site_patterns(rows, unique=True)
+    assert pats.shape[1] == expect_patterns, pats.shape            # the XML's own "npatterns=" comment
+    np.savez_compressed(os.path.join(HERE, out_name), patterns=pats.astype(np.uint8), weights=weights,
+                        taxa=np.array(names), model=json.dumps(model), source=cite)
+    print("wrote %s: %d taxa x %d sites -> %d unique patterns (%d ambiguous cells)"
+          % (out_name, len(names), expect_sites, pats.shape[1], int((pats > 3).sum())))
+
+
 def main():
+    if "--benchmarks" in __import__("sys").argv:
+        benchmark_fixture("benchmark1.xml", "benchmark1_patterns.npz", 1441, 987, 593,
+                          {"model": "hky", "kappa": 2.0, "pi": [0.25] * 4, "gamma_categories": 1, "clock_rate": 3.6e-4,
+                           "popSize_years": 52.0},
+                          "examples/Benchmarks/benchmark1.xml:11 (taxa), :4340-10106 (alignment), :10108-10109 (npatterns=593), "
+                          ":10161-10186 (HKY kappa 2, equal frequencies, no gamma), :10154-10158 (clock 3.6E-4)")
+        benchmark_fixture("benchmark2.xml", "benchmark2_patterns.npz", 62, 10869, 5565,
+                          {"model": "gtr", "rates": [1.0, 1.0, 1.0, 1.0, 1.0, 1.0], "pi": [0.25] * 4, "gamma_categories": 4, "alpha": 0.5,
+                           "root_height": 0.2},
+                          "examples/Benchmarks/benchmark2.xml:11 (taxa), :79-638 (alignment), :641 (npatterns=5565), :702-735 (GTR, "
+                          "alpha 0.5, 4 categories), :664 (rootHeight 0.2)")
+        return
     names, seqs = primate_sequences()
     primates = {
         "source": "src/test/dr/inference/trace/TraceCorrelationAssert.java:145-198",

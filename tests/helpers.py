@@ -94,3 +94,11 @@ def random_workload(tip_count, pattern_count, state_count, categories, seed, tre
     return synth.make_workload("rand-S%d" % state_count, tip_count, pattern_count, eig, pi, alpha=0.7,
                                categories=categories, seed=seed, tree_kind=tree_kind,
                                root_to_tip=root_to_tip, unknown_fraction=unknown_fraction)
+
+
+def sample_with_tail(pattern_count, n_sample, seed):
+    """Pattern indices for a sampled full-size check: a seeded random sample PLUS, always, the last 256 patterns — the ragged
+    last 128-pattern group of a buffer (and the last 32-pattern tile) must be in every sample, not left to the seed."""
+    rnd = np.random.default_rng(seed).choice(pattern_count, size=min(n_sample, pattern_count), replace=False)
+    tail = np.arange(max(0, pattern_count - 256), pattern_count)
+    return np.unique(np.concatenate([rnd, tail]))

@@ -8,8 +8,10 @@
   E  Makona-like 1610 taxa, four nucleotide partitions on one instance through updatePartialsByPartition
      (MultiPartitionDataLikelihoodDelegate.java:520-553, 972-997, 1074-1083), each partition against the oracle
 
-Patterns are independent given the tree, so for B and C the oracle evaluates a random 1 % sample of the patterns (seconds
-on the CPU) and must agree with the engine's site log-likelihoods for exactly those patterns; tolerance 1e-10 relative
+  real alignments of examples/Benchmarks/benchmark1.xml and benchmark2.xml (tests/golden/*_patterns.npz), whole
+
+Patterns are independent given the tree, so for B and C the oracle evaluates a random 1 % sample of the patterns plus, always,
+the last 256 (seconds on the CPU) and must agree with the engine's site log-likelihoods for exactly those patterns; tolerance 1e-10 relative
 (BASELINE.json north_star).  First evaluation = rescaling in write mode, second = read mode."""
 import os
 import subprocess
@@ -35,7 +37,7 @@ def sampled_check(wl, oracle_lib, n_sample, seed):
     assert np.isfinite(lnl)
     site = g.getSiteLogLikelihoods()
     assert helpers.rel_err(float(np.dot(site, wl.weights)), lnl) <= 1e-12
-    idx = np.sort(np.random.default_rng(seed).choice(wl.pattern_count, size=n_sample, replace=False))
+    idx = helpers.sample_with_tail(wl.pattern_count, n_sample, seed)      # (the last 256 patterns are always in)
     sub = synth.Workload(wl.name + "-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
                          np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], wl.state_count)
     o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
@@ -145,3 +147,30 @@ def test_config_e_pattern_shards_sum_to_whole():
         t2.close()
         acc += bp
     assert np.max(np.abs(acc - whole) / np.abs(whole)) <= 1e-11
+
+
+@pytest.mark.parametrize("name", ["benchmark1", "benchmark2"])
+@pytest.mark.parametrize("rescaling", [RESCALE_DYNAMIC, RESCALE_ALWAYS])
+def test_real_benchmark_alignments_against_oracle(name, rescaling, oracle_lib):
+    """The reference's own benchmark inputs (real ambiguity codes, real pattern weights, 1441 x 593 HKY and 62 x 5565 GTR+G4;
+    tests/golden/make_fixtures.py --benchmarks), whole, engine against oracle: lnL, every site value, and a branch move with
+    its rejection.  No absolute value is published for them (the XMLs draw a random starting tree)."""
+    wl = synth.from_pattern_fixture(os.path.join(helpers.GOLDEN, name + "_patterns.npz"))
+    g = BeagleTreeLikelihood(wl, rescaling=rescaling, delay_rescaling=False)
+    o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=rescaling, delay_rescaling=False)
+    rng = np.random.default_rng(8)
+    for step in range(6):
+        a, b = g.getLogLikelihood(), o.getLogLikelihood()
+        assert np.isfinite(b) and helpers.rel_err(a, b) <= REL_TOL, (step, a, b)
+        sa, sb = g.getSiteLogLikelihoods(), o.getSiteLogLikelihoods()
+        assert np.max(np.abs(sa - sb) / np.abs(sb)) <= REL_TOL, step
+        node = int(rng.integers(wl.tip_count, wl.tree.node_count - 1))
+        h = float(wl.tree.height[node]) * (1.0 + 0.02 * rng.standard_normal())
+        for t in (g, o):
+            t.storeState(); t.set_node_height(node, h)
+        if step % 2:
+            a2, b2 = g.getLogLikelihood(), o.getLogLikelihood()
+            assert helpers.rel_err(a2, b2) <= REL_TOL
+            for t in (g, o):
+                t.restoreState()
+    g.close(); o.close()

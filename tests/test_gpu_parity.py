@@ -265,7 +265,7 @@ def test_config_a_sampled_against_oracle(config_a, oracle_lib):
     assert np.isfinite(lnl)
     site = g.getSiteLogLikelihoods()
     assert helpers.rel_err(float(np.dot(site, wl.weights)), lnl) <= 1e-12
-    idx = np.sort(np.random.default_rng(4).choice(wl.pattern_count, size=1000, replace=False))
+    idx = helpers.sample_with_tail(wl.pattern_count, 1000, 4)           # 1 % at random + always the last 256 patterns
     sub = synth.Workload("A-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
                          np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], 4)
     o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=True)

@@ -317,3 +317,22 @@ def test_oracle_cross_products_are_the_first_order_generator_derivative(S, C):
     ratios = [errs[i] / errs[i + 1] for i in range(len(errs) - 1)]
     assert errs[-1] < 0.02, errs
     assert all(1.5 < r < 2.7 for r in ratios[1:]), (errs, ratios)
+
+
+@pytest.mark.parametrize("name,taxa,sites,npatterns", [("benchmark1", 1441, 987, 593), ("benchmark2", 62, 10869, 5565)])
+def test_real_benchmark_alignments_as_fixtures(name, taxa, sites, npatterns, oracle_lib):
+    """examples/Benchmarks/benchmark{1,2}.xml transcribed as unique site patterns (make_fixtures.py --benchmarks): the pattern
+    count equals the XML's own "npatterns=" comment (benchmark1.xml:10108, benchmark2.xml:641), the weights add up to the
+    site count, and the oracle evaluates them (real ambiguity codes, real pattern weights).  No expected lnL is published
+    for them — the XMLs draw a random starting tree — so what these fixtures pin is engine <-> oracle (tests/test_gpu_configs.py)."""
+    import os
+    from beast_mcmc_amd.inputs import synth
+    wl = synth.from_pattern_fixture(os.path.join(helpers.GOLDEN, name + "_patterns.npz"))
+    assert wl.tip_count == taxa and wl.pattern_count == npatterns and wl.weights.sum() == sites
+    assert (wl.tip_states == 4).sum() > 0
+    tl = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC)
+    lnl = tl.getLogLikelihood()
+    assert np.isfinite(lnl) and lnl < 0
+    site = tl.getSiteLogLikelihoods()
+    assert abs(float((site * wl.weights).sum()) - lnl) <= 1e-9 * abs(lnl)
+    tl.close()
