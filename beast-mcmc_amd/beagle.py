@@ -21,6 +21,8 @@ if os.environ.get("BEAGLE_MI355_ENGINE_LIB"):        # development: an A/B build
 HOST_LIB = os.path.join(_HERE, "lib", "libbeast_host.so")
 
 NONE = -1
+# instance / requirement flag bits (lib/beagle.jar!beagle/BeagleFlag; include/beagle_mi355.h)
+FLAG_EIGEN_REAL, FLAG_EIGEN_COMPLEX, FLAG_PROCESSOR_GPU, FLAG_FRAMEWORK_CPU = 1 << 4, 1 << 5, 1 << 16, 1 << 27
 OPERATION_TUPLE_SIZE = 7
 
 ERROR_NAMES = {0: "NO_ERROR", -1: "GENERAL_ERROR", -2: "OUT_OF_MEMORY_ERROR", -3: "UNIDENTIFIED_EXCEPTION_ERROR",

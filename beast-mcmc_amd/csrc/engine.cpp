@@ -73,6 +73,7 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
+    bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
     bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
                                                          // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)
     bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
@@ -264,7 +265,7 @@ struct Resources {
 };
 Resources* g_resources = nullptr;
 
-const long GPU_FLAGS = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_COMPUTATION_SYNCH | BEAGLE_FLAG_EIGEN_REAL |
+const long GPU_FLAGS = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_COMPUTATION_SYNCH | BEAGLE_FLAG_EIGEN_REAL | BEAGLE_FLAG_EIGEN_COMPLEX |
                        BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC |
                        BEAGLE_FLAG_SCALERS_RAW | BEAGLE_FLAG_VECTOR_NONE | BEAGLE_FLAG_THREADING_NONE |
                        BEAGLE_FLAG_PROCESSOR_GPU | BEAGLE_FLAG_PARALLELOPS_GRID;
@@ -1398,7 +1399,6 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
                          int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
                          int scaleBufferCount, const int* resourceList, int resourceCount,
                          long preferenceFlags, long requirementFlags, BeagleInstanceDetails* returnInfo) {
-    (void)preferenceFlags;
     if (tipCount < 0 || partialsBufferCount < 1 || compactBufferCount < 0 || stateCount < 2 || stateCount > 255 ||
         patternCount < 1 || eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
         return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1406,7 +1406,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // accumulate 64 x 64 outputs, the general kernels stage S x S doubles in LDS) — refuse loudly instead of half-working
     if (stateCount > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     // requirement flags this engine cannot honour
-    if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
+    if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CPU | BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL |
                             BEAGLE_FLAG_SCALING_AUTO | BEAGLE_FLAG_VECTOR_SSE))
         return BEAGLE_ERROR_NO_RESOURCE;
@@ -1430,6 +1430,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->device = device;
     in->tipCount = tipCount; in->partialsCount = partialsBufferCount; in->compactCount = compactBufferCount;
     in->S = stateCount; in->P = patternCount; in->eigenCount = std::max(1, eigenBufferCount);
+    // BEAST adds EIGEN_COMPLEX to the flags whenever the substitution model may have complex eigenvalues (the asymmetric
+    // discrete-trait models: BeagleTreeLikelihood.java:353-355, BeagleDataLikelihoodDelegate.java:378); every eigen system of
+    // such an instance then arrives in real block form with 2 S eigenvalue entries (ComplexSubstitutionModel.java:121-173)
+    in->eigenComplex = (requirementFlags & BEAGLE_FLAG_EIGEN_COMPLEX) != 0;      // (a REQUIREMENT in both callers; a mere preference keeps EIGEN_REAL)
+    (void)preferenceFlags;
     in->matrixCount = matrixBufferCount; in->C = categoryCount; in->scaleCount = scaleBufferCount;
     // 16..64 states: T32 layout + fp64 MFMA kernels (amino acids, codons); BEAGLE_MI355_NO_MFMA=1 keeps the VALU kernel
     in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
@@ -1485,7 +1490,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     const int rootBlocks = (patternCount + 255) / 256;
     ok = ok && devAlloc(in, (void**)&in->dRing, RING_BYTES) == 0;
     ok = ok && devAlloc(in, (void**)&in->matrices, matrixSlots * C * S * S * sizeof(double)) == 0;
-    ok = ok && devAlloc(in, (void**)&in->eigen, E * (2 * S * S + S) * sizeof(double)) == 0;
+    ok = ok && devAlloc(in, (void**)&in->eigen, E * (2 * S * S + 2 * S) * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->rates, E * C * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->weights, E * C * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->freqs, E * S * sizeof(double)) == 0;
@@ -1522,7 +1527,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceName = (char*)in->resourceName.c_str();
         returnInfo->implName = (char*)"HIP-gfx950-fp64";
         returnInfo->implDescription = (char*)"hand-written CDNA4 kernels, level-batched pruning";
-        returnInfo->flags = GPU_FLAGS & ~(BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC);
+        returnInfo->flags = GPU_FLAGS & ~(BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC) &
+                            ~(in->eigenComplex ? BEAGLE_FLAG_EIGEN_REAL : BEAGLE_FLAG_EIGEN_COMPLEX);
     }
     return handle;
 }
@@ -1846,11 +1852,11 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, c
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetEigenDecomposition(h, eigenIndex, U, Uinv, lambda); }); }
     GET_INSTANCE(instance);
     if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    const size_t S = in->S, stride = 2 * S * S + S;
+    const size_t S = in->S, nLambda = in->eigenComplex ? 2 * S : S, stride = 2 * S * S + nLambda;
     std::vector<double> pack(stride);
     memcpy(&pack[0], U, S * S * sizeof(double));
     memcpy(&pack[S * S], Uinv, S * S * sizeof(double));
-    memcpy(&pack[2 * S * S], lambda, S * sizeof(double));
+    memcpy(&pack[2 * S * S], lambda, nLambda * sizeof(double));
     return uploadIfChanged(in, in->shEigen, in->okEigen, in->eigenCount, eigenIndex, stride, in->eigen + stride * eigenIndex, pack.data());
 }
 
@@ -1948,7 +1954,7 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
     const double* dLen = (const double*)dPack;
     const int* dIdx = (const int*)((const char*)dPack + (size_t)count * sizeof(double));
     mi355::launchTransitionMatrices(in->stream, in->matrices, in->eigen, in->rates, dIdx, dLen,
-                                    dIdx + count, dIdx + 2 * (size_t)count, count, in->S, in->C);
+                                    dIdx + count, dIdx + 2 * (size_t)count, count, in->S, in->C, in->eigenComplex);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }

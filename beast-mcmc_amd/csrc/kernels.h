@@ -131,9 +131,10 @@ void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSr
 // P(t) = U diag(exp(lambda * t * r_c)) U^-1, negatives clamped to 0, for `count` branches.
 // dIdx/dLen/dEig/dRate: device arrays of length `count`: destination matrix index, edge length,
 // eigen-system index and category-rate-set index per branch.
+// complexEigen: eigen systems are [U | U^-1 | Re lambda (S) | Im lambda (S)] in real block form (kernels.hip iexpEntry)
 void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,
                               const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
-                              int count, int S, int C);
+                              int count, int S, int C, bool complexEigen = false);
 
 // C_c = A_c * B_c per category, `count` triples (device index arrays).
 void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,

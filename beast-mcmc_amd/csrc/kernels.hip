@@ -42,20 +42,36 @@ bool grantDynamicLds(const void* kernel, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // transition matrices
 // ------------------------------------------------------------------------------------------------
+// complexEigen (an EIGEN_COMPLEX instance: BeagleTreeLikelihood.java:353-355, the asymmetric discrete-trait models): the
+// eigenvalue array holds S real parts, then S imaginary parts, and U / U^-1 are the REAL block form — a conjugate pair
+// a +/- b i sits in rows i, i+1 (imaginary parts b, -b) and contributes exp(a t) [cos b t, sin b t; -sin b t, cos b t] on those
+// two rows of U^-1 (ComplexSubstitutionModel.java:121-173).  Row k of a pair is its FIRST row iff an even number of rows
+// with a nonzero imaginary part precede it without a gap (the reference walks the rows in order and skips the second).
+__device__ __forceinline__ double iexpEntry(const double* __restrict__ Ui, const double* __restrict__ lam, int S, int k, int j, double dist, int complexEigen) {
+    const double im = complexEigen ? lam[S + k] : 0.0;
+    if (im == 0.0) return Ui[k * S + j] * exp(dist * lam[k]);
+    int run = 0;
+    for (int q = k - 1; q >= 0 && lam[S + q] != 0.0; q--) run++;
+    const int first = (run & 1) ? k - 1 : k;
+    const double b = lam[S + first];
+    const double expat = exp(dist * lam[first]), c = expat * cos(dist * b), sn = expat * sin(dist * b);
+    return first == k ? c * Ui[k * S + j] + sn * Ui[(k + 1) * S + j] : c * Ui[k * S + j] - sn * Ui[(k - 1) * S + j];
+}
+
 __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrices, const double* __restrict__ eigen,
                                                     const double* __restrict__ rates, const int* __restrict__ dIdx,
                                                     const double* __restrict__ dLen, const int* __restrict__ dEig,
-                                                    const int* __restrict__ dRate, int S, int C) {
+                                                    const int* __restrict__ dRate, int S, int C, int complexEigen) {
     extern __shared__ double sh[];            // iexp[S][S]
     const int u = blockIdx.x, c = blockIdx.y;
-    const size_t eigStride = (size_t)2 * S * S + S;
+    const size_t eigStride = (size_t)2 * S * S + (complexEigen ? 2 : 1) * S;
     const double* U = eigen + eigStride * dEig[u];
     const double* Ui = U + (size_t)S * S;
     const double* lam = Ui + (size_t)S * S;
     const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
     for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
         const int k = e / S;
-        sh[e] = Ui[e] * exp(dist * lam[k]);
+        sh[e] = complexEigen ? iexpEntry(Ui, lam, S, k, e - k * S, dist, 1) : Ui[e] * exp(dist * lam[k]);
     }
     __syncthreads();
     double* M = matrices + ((size_t)dIdx[u] * C + c) * S * S;
@@ -72,37 +88,38 @@ __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrice
 __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matrices, const double* __restrict__ eigen,
                                                      const double* __restrict__ rates, const int* __restrict__ dIdx,
                                                      const double* __restrict__ dLen, const int* __restrict__ dEig,
-                                                     const int* __restrict__ dRate, int count, int C) {
+                                                     const int* __restrict__ dRate, int count, int C, int complexEigen) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count * C) return;
     const int u = t / C, c = t - u * C;
-    const double* U = eigen + (size_t)36 * dEig[u];
+    const double* U = eigen + (size_t)(complexEigen ? 40 : 36) * dEig[u];
     const double* Ui = U + 16;
     const double* lam = U + 32;
     const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
-    double ex[4];
-    for (int k = 0; k < 4; k++) ex[k] = exp(dist * lam[k]);
+    double ie[16];
+    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
+    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
     double* M = matrices + ((size_t)dIdx[u] * C + c) * 16;
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
             double s = 0.0;
-            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * (Ui[k * 4 + j] * ex[k]);
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
             M[i * 4 + j] = s > 0.0 ? s : 0.0;
         }
 }
 
 void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,
                               const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
-                              int count, int S, int C) {
+                              int count, int S, int C, bool complexEigen) {
     if (count <= 0) return;
     if (S == 4) {
         hipLaunchKernelGGL(k_transition4, dim3((unsigned)(((size_t)count * C + 255) / 256)), dim3(256), 0, stream,
-                           matrices, eigen, rates, dIdx, dLen, dEig, dRate, count, C);
+                           matrices, eigen, rates, dIdx, dLen, dEig, dRate, count, C, complexEigen ? 1 : 0);
         return;
     }
     const int threads = S * S >= 256 ? 256 : 64;
     hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), (size_t)S * S * sizeof(double), stream,
-                       matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C);
+                       matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void k_convolve(double* __restrict__ matrices, const int* __restrict__ dFirst,

@@ -163,3 +163,57 @@ def gy94(kappa, omega, codon_pi=None):
             rates.append(r)
     q = reversible_q(rates, codon_pi)
     return decompose_reversible(q, codon_pi), np.asarray(codon_pi, dtype=np.float64)
+
+
+def complex_q(rates, state_count):
+    """Rate matrix of dr.evomodel.substmodel.ComplexSubstitutionModel (the asymmetric discrete-trait model): S (S - 1)
+    relative rates, the upper triangle in row order first, then the lower triangle COLUMN by column; no frequency scaling;
+    rows sum to zero (ComplexSubstitutionModel.java:205-229 ``setupQMatrix`` with flat frequencies)."""
+    s = state_count
+    q = np.zeros((s, s))
+    k = 0
+    for i in range(s):
+        for j in range(i + 1, s):
+            q[i, j] = max(rates[k], 0.0); k += 1
+    for j in range(s):
+        for i in range(j + 1, s):
+            q[i, j] = max(rates[k], 0.0); k += 1
+    np.fill_diagonal(q, -q.sum(axis=1))
+    return q
+
+
+def stationary_distribution(q):
+    """pi with pi Q = 0, sum 1 (ComplexSubstitutionModel.java:84-109 solves the same linear system)."""
+    s = q.shape[0]
+    a = np.vstack([q.T, np.ones(s)])
+    b = np.zeros(s + 1); b[s] = 1.0
+    return np.linalg.lstsq(a, b, rcond=None)[0]
+
+
+def decompose_complex(q):
+    """Eigen system of ANY rate matrix in the REAL BLOCK FORM BEAST hands to an EIGEN_COMPLEX BEAGLE instance
+    (ComplexSubstitutionModel.java:121-173, the Colt EigenvalueDecomposition it wraps): Q V = V D with D block diagonal —
+    a real eigenvalue in a 1x1 block, a conjugate pair a +/- b i as [a, b; -b, a] on two consecutive columns holding the
+    real and imaginary part of the eigenvector.  Returns (pi, EigenDecomposition) with ``evals`` of length 2 S: S real parts,
+    then S imaginary parts (b, -b for a pair), normalised to one expected substitution per unit time at stationarity."""
+    q = np.asarray(q, dtype=np.float64)
+    s = q.shape[0]
+    pi = stationary_distribution(q)
+    q = q / float(-(np.diag(q) * pi).sum())
+    w, v = np.linalg.eig(q)
+    cols, re, im = [], [], []
+    used = np.zeros(s, dtype=bool)
+    for k in range(s):
+        if used[k]:
+            continue
+        used[k] = True
+        if abs(w[k].imag) < 1e-14:
+            cols.append(v[:, k].real); re.append(w[k].real); im.append(0.0)
+            continue
+        partner = [m for m in range(s) if not used[m] and abs(w[m] - np.conj(w[k])) < 1e-9][0]
+        used[partner] = True
+        lam, vec = (w[k], v[:, k]) if w[k].imag > 0 else (w[partner], v[:, partner])
+        cols += [vec.real, vec.imag]
+        re += [lam.real, lam.real]; im += [lam.imag, -lam.imag]
+    vmat = np.stack(cols, axis=1)
+    return pi, EigenDecomposition(vmat, np.linalg.inv(vmat), np.concatenate([re, im]))

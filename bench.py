@@ -413,7 +413,9 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "metric": "full-tree lnL evals/sec (GTR+G4, 1e5 patterns)" if args.config == "A" else "full-tree lnL evals/sec",
             "value": round(evals_per_s, 3), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "route": args.route,
+            "vs_baseline": None, "dtype": "f64",
+            "data": ("real alignment of examples/Benchmarks/%s.xml (tests/golden), seeded coalescent tree" % args.real) if args.real else "synthetic",
+            "route": args.route,
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "
                                    "%s, new eigen system + rates every step"
                                    % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth(),

@@ -46,6 +46,7 @@
 typedef struct {
     int used;
     int tipCount, partialsCount, compactCount, S, P, eigenCount, matrixCount, C, scaleCount;
+    int eigenComplex;    /* created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays hold S real parts, then S imaginary parts */
     double** partials;   /* [partialsCount] -> double[C*P*S] or NULL */
     int**    tipStates;  /* [partialsCount] -> int[P] or NULL (index = tip buffer index) */
     double** matrices;   /* [matrixCount]   -> double[C*S*S] */
@@ -83,7 +84,7 @@ int oracle_beagleCreateInstance(int tipCount, int partialsBufferCount, int compa
                                 int matrixBufferCount, int categoryCount, int scaleBufferCount,
                                 const int* resourceList, int resourceCount, long pref, long req,
                                 BeagleInstanceDetails* info) {
-    (void)resourceList; (void)resourceCount; (void)pref; (void)req;
+    (void)resourceList; (void)resourceCount;
     if (stateCount < 2 || patternCount < 1 || categoryCount < 1 || partialsBufferCount < 1) return BEAGLE_ERROR_OUT_OF_RANGE;
     int h = -1;
     for (int i = 0; i < MAX_INSTANCES; i++) if (!g_inst[i].used) { h = i; break; }
@@ -94,6 +95,8 @@ int oracle_beagleCreateInstance(int tipCount, int partialsBufferCount, int compa
     in->tipCount = tipCount; in->partialsCount = partialsBufferCount; in->compactCount = compactBufferCount;
     in->S = stateCount; in->P = patternCount; in->eigenCount = eigenBufferCount > 0 ? eigenBufferCount : 1;
     in->matrixCount = matrixBufferCount; in->C = categoryCount; in->scaleCount = scaleBufferCount;
+    (void)pref;
+    in->eigenComplex = (req & BEAGLE_FLAG_EIGEN_COMPLEX) != 0;               /* BeagleTreeLikelihood.java:353-355 */
     in->partials  = (double**)calloc(partialsBufferCount, sizeof(double*));
     in->tipStates = (int**)calloc(partialsBufferCount, sizeof(int*));
     in->matrices  = (double**)calloc(matrixBufferCount > 0 ? matrixBufferCount : 1, sizeof(double*));
@@ -106,7 +109,7 @@ int oracle_beagleCreateInstance(int tipCount, int partialsBufferCount, int compa
     for (int i = 0; i < E; i++) {
         in->eigU[i] = (double*)calloc((size_t)stateCount * stateCount, sizeof(double));
         in->eigUinv[i] = (double*)calloc((size_t)stateCount * stateCount, sizeof(double));
-        in->eigLambda[i] = (double*)calloc(stateCount, sizeof(double));
+        in->eigLambda[i] = (double*)calloc(2 * (size_t)stateCount, sizeof(double));
         in->catRates[i] = (double*)calloc(categoryCount, sizeof(double));
         in->catWeights[i] = (double*)calloc(categoryCount, sizeof(double));
         in->freqs[i] = (double*)calloc(stateCount, sizeof(double));
@@ -122,7 +125,7 @@ int oracle_beagleCreateInstance(int tipCount, int partialsBufferCount, int compa
         info->implName = (char*)"CPU-oracle-fp64";
         info->implDescription = (char*)"plain C restatement, test infrastructure";
         info->flags = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_PROCESSOR_CPU | BEAGLE_FLAG_FRAMEWORK_CPU |
-                      BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALERS_LOG | BEAGLE_FLAG_EIGEN_REAL;
+                      BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALERS_LOG | (in->eigenComplex ? BEAGLE_FLAG_EIGEN_COMPLEX : BEAGLE_FLAG_EIGEN_REAL);
     }
     return h;
 }
@@ -204,7 +207,7 @@ int oracle_beagleSetEigenDecomposition(int h, int e, const double* U, const doub
     if (e < 0 || e >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
     size_t n = (size_t)in->S * in->S;
     memcpy(in->eigU[e], U, n * sizeof(double)); memcpy(in->eigUinv[e], Uinv, n * sizeof(double));
-    memcpy(in->eigLambda[e], lam, in->S * sizeof(double));
+    memcpy(in->eigLambda[e], lam, (in->eigenComplex ? 2 : 1) * (size_t)in->S * sizeof(double));
     return BEAGLE_SUCCESS;
 }
 int oracle_beagleSetStateFrequencies(int h, int i, const double* f) {
@@ -256,8 +259,32 @@ int oracle_beagleConvolveTransitionMatrices(int h, const int* first, const int* 
     return BEAGLE_SUCCESS;
 }
 
-/* BaseSubstitutionModel.java:206-245 (iexp = Uinv row scaled by exp(t*lambda), then U * iexp);
- * GeneralBeagleImpl#updateTransitionMatrices applies the category rate to t and clamps negatives. */
+/* iexp for one (branch, category): rows of Uinv scaled by exp(t lambda) — BaseSubstitutionModel.java:206-245 — or, on an
+ * EIGEN_COMPLEX instance, the real block form of ComplexSubstitutionModel.java:121-173: a real eigenvalue is a 1x1 block as
+ * before; a conjugate pair a +/- b i (imaginary parts b, -b in rows i, i+1 of the second half of the eigenvalue array) is the
+ * 2x2 block exp(a t) [cos b t, sin b t; -sin b t, cos b t] applied to rows i, i+1 of Uinv. */
+static void fill_iexp(const Inst* in, const double* Ui, const double* lam, double dist, double* iexp) {
+    const int S = in->S;
+    for (int k = 0; k < S; k++) {
+        const double im = in->eigenComplex ? lam[S + k] : 0.0;
+        if (im == 0.0) {
+            const double ex = exp(dist * lam[k]);
+            for (int j = 0; j < S; j++) iexp[k * S + j] = Ui[k * S + j] * ex;
+        } else {
+            const int k2 = k + 1;
+            const double expat = exp(dist * lam[k]), c = expat * cos(dist * im), sn = expat * sin(dist * im);
+            for (int j = 0; j < S; j++) {
+                iexp[k * S + j] = c * Ui[k * S + j] + sn * Ui[k2 * S + j];
+                iexp[k2 * S + j] = c * Ui[k2 * S + j] - sn * Ui[k * S + j];
+            }
+            k++;                                       /* processed two conjugate rows */
+        }
+    }
+}
+
+/* BaseSubstitutionModel.java:206-245 (iexp, then U * iexp);
+ * GeneralBeagleImpl#updateTransitionMatrices applies the category rate to t and clamps negatives (ComplexSubstitutionModel
+ * takes the absolute value instead, :184 — the two differ only where rounding leaves a tiny negative entry). */
 int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, const int* d1, const int* d2,
                                           const double* t, int count) {
     (void)d1; (void)d2;
@@ -272,10 +299,7 @@ int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, cons
         double* M = in->matrices[probIdx[u]];
         for (int c = 0; c < in->C; c++) {
             double dist = t[u] * in->catRates[0][c];
-            for (int k = 0; k < S; k++) {
-                double ex = exp(dist * lam[k]);
-                for (int j = 0; j < S; j++) iexp[k * S + j] = Ui[k * S + j] * ex;
-            }
+            fill_iexp(in, Ui, lam, dist, iexp);
             for (int i = 0; i < S; i++)
                 for (int j = 0; j < S; j++) {
                     double s = 0.0;

@@ -430,3 +430,38 @@ def test_batched_read_back_of_every_internal_node(S, T, P, oracle_lib):
     assert np.array_equal(unscaled[3], rg.getPartials(bufs[3], bm.beagle.NONE))
     assert_parity(g, o, "after the read-back")
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("S", [4, 7, 20, 61])
+def test_complex_eigen_instance_against_oracle(S, oracle_lib):
+    """An EIGEN_COMPLEX instance (BeagleTreeLikelihood.java:353-355, ComplexSubstitutionModel.java:121-187: the asymmetric
+    discrete-trait models of the phylogeography analyses): transition matrices of a model with complex-conjugate eigenvalue
+    pairs against the oracle (itself pinned by scipy's matrix exponential, tests/test_oracle_golden.py) and against expm
+    directly, then a whole tree likelihood with the stationary distribution at the root — on the 4-state walk, the general
+    kernel (7) and the MFMA path (20, 61)."""
+    import scipy.linalg
+    from test_oracle_golden import _cyclic_model
+    from beast_mcmc_amd.inputs import trees
+    qn, pi, eig = _cyclic_model(S, 3 + S)
+    b = bm.beagle.Beagle(3, 5, 3, S, 10, 1, 4, 2, 0, requirementFlags=bm.beagle.FLAG_EIGEN_COMPLEX)
+    assert b.details.flags & bm.beagle.FLAG_EIGEN_COMPLEX and not b.details.flags & bm.beagle.FLAG_EIGEN_REAL
+    b.setEigenDecomposition(0, eig.evec, eig.ievc, eig.evals)
+    b.setCategoryRates([0.5, 1.7])
+    b.updateTransitionMatrices(0, [0, 1], None, None, [0.3, 1.1], 2)
+    got = b.getTransitionMatrix(1).reshape(2, S, S)
+    for c, r in enumerate((0.5, 1.7)):
+        assert np.max(np.abs(got[c] - scipy.linalg.expm(qn * 1.1 * r))) <= 1e-12
+    b.finalize()
+    rng = np.random.default_rng(S)
+    T, P = 14, 333
+    tree = trees.coalescent_tree(T, rng, root_height=0.7)
+    tips = rng.integers(0, S, size=(T, P)).astype(np.int32)
+    tips[rng.random(tips.shape) < 0.05] = S
+    wl = synth.Workload("complex-S%d" % S, tree, eig, pi, [0.4, 1.0, 1.6], [0.3, 0.4, 0.3], tips, rng.integers(1, 5, size=P).astype(np.float64), S)
+    g, o = both(wl, oracle_lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False, requirement_flags=bm.beagle.FLAG_EIGEN_COMPLEX)
+    assert_parity(g, o, "complex S=%d" % S)
+    for node in (T, 2 * T - 2):
+        pg, po = _partials(g, node), _partials(o, node)
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= REL_TOL
+    g.close(); o.close()

@@ -336,3 +336,36 @@ def test_real_benchmark_alignments_as_fixtures(name, taxa, sites, npatterns, ora
     site = tl.getSiteLogLikelihoods()
     assert abs(float((site * wl.weights).sum()) - lnl) <= 1e-9 * abs(lnl)
     tl.close()
+
+
+def _cyclic_model(S, seed):
+    """An asymmetric rate matrix with a strong directed cycle: its eigenvalues come in complex-conjugate pairs."""
+    rng = np.random.default_rng(seed)
+    q = substmodel.complex_q(rng.uniform(0.02, 0.1, size=S * (S - 1)), S)
+    for i in range(S):
+        q[i, (i + 1) % S] += 2.0
+    np.fill_diagonal(q, 0.0); np.fill_diagonal(q, -q.sum(axis=1))
+    pi, eig = substmodel.decompose_complex(q)
+    assert np.count_nonzero(eig.evals[S:]) >= 2                       # at least one conjugate pair
+    return q / float(-(np.diag(q) * pi).sum()), pi, eig
+
+
+@pytest.mark.parametrize("S", [4, 7, 20])
+def test_complex_eigen_systems_against_the_matrix_exponential(S, oracle_lib):
+    """EIGEN_COMPLEX (BeagleTreeLikelihood.java:353-355: required whenever the model can return a complex
+    diagonalisation — ComplexSubstitutionModel.java:232, the asymmetric discrete-trait models): the oracle's restatement of
+    ComplexSubstitutionModel.java:121-187 (real block form, 2 S eigenvalue entries) reproduces exp(Q t r_c) computed
+    independently (scipy.linalg.expm) for every rate category — this pins the complex path, for which the reference holds
+    no golden value."""
+    import scipy.linalg
+    qn, pi, eig = _cyclic_model(S, 3 + S)
+    b = bm.beagle.Beagle(3, 5, 3, S, 10, 1, 4, 2, 0, requirementFlags=bm.beagle.FLAG_EIGEN_COMPLEX, library=oracle_lib)
+    assert b.details.flags & bm.beagle.FLAG_EIGEN_COMPLEX
+    b.setEigenDecomposition(0, eig.evec, eig.ievc, eig.evals)
+    b.setCategoryRates([0.5, 1.7])
+    b.updateTransitionMatrices(0, [0, 1], None, None, [0.3, 1.1], 2)
+    for m, t in ((0, 0.3), (1, 1.1)):
+        got = b.getTransitionMatrix(m).reshape(2, S, S)
+        for c, r in enumerate((0.5, 1.7)):
+            assert np.max(np.abs(got[c] - scipy.linalg.expm(qn * t * r))) <= 1e-13
+    b.finalize()

@@ -332,7 +332,7 @@ void* btlCreate(const BeagleApi* api, int tipCount, int stateCount, int patternC
     t->updateNode.assign(t->nodeCount, 1);
     t->branchUpdateIndices.assign(t->nodeCount, 0); t->branchLengths.assign(t->nodeCount, 0.0);
     t->operations.assign((size_t)t->internalNodeCount * BEAGLE_OP_COUNT, 0);
-    t->U.assign((size_t)stateCount * stateCount, 0.0); t->Uinv = t->U; t->lambda.assign(stateCount, 0.0);
+    t->U.assign((size_t)stateCount * stateCount, 0.0); t->Uinv = t->U; t->lambda.assign((size_t)stateCount * ((requirementFlags & (1L << 5)) ? 2 : 1), 0.0);   // EIGEN_COMPLEX: S real parts, then S imaginary parts (ComplexSubstitutionModel.java:121-135)
     t->freqs.assign(stateCount, 1.0 / stateCount);
     t->catRates.assign(categoryCount, 1.0); t->catWeights.assign(categoryCount, 1.0 / categoryCount);
     BeagleInstanceDetails details;
