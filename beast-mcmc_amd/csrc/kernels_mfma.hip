@@ -218,30 +218,40 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
                 if (pe < P) inve = 1.0 / sr[pe];
                 if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
             }
-            double re[NTMAX], ro[NTMAX];
-            tiledChild<NTMAX, NTMAX>(frag, nt, S, st1, se1, so1, M1, b1, 0, g, fl, re, ro);
-            __builtin_amdgcn_sched_barrier(0);
-            if (PIPE == 0 && !st2 && !vt2) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
-            // the next tile's child-1 operands fly while child 2's MFMAs run
-            if (vt1) { if (tile + tstep < tile1) raw1 = cherryFetch(cd1, tile + tstep, P, S, m); }
-            else if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
-            if (vt2) cherryOperands<NTMAX>(raw2, vm + 2 * vmN, vm + 3 * vmN, g, b2);
-            __builtin_amdgcn_sched_barrier(0);
+            // Child 1's factors are accumulated for RH parent-state tiles at a time (all of them up to 20 states; HALF of the 16
+            // tiles above: 32 instead of 64 accumulator registers next to the two children's 2 x 64 operand registers — the
+            // one-pass version needed 136 bytes of scratch per lane at 256 registers, profiles/r02_C_*), child 2's are then
+            // produced IH tiles at a time, multiplied in and stored.
+            constexpr int RH = NTMAX > 5 ? NTMAX / 2 : NTMAX;
             const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
             double* d = op.dest + tileBase;
 #pragma unroll
-            for (int it0 = 0; it0 < NTMAX; it0 += IH) {
-                if (it0 < nt) {
-                    double te[IH], to[IH];
-                    tiledChild<NTMAX, IH>(frag + fragN, nt, S, st2, se2, so2, M2, b2, it0, g, fl, te, to);
+            for (int h0 = 0; h0 < NTMAX; h0 += RH) {
+                double re[RH], ro[RH];
+                tiledChild<NTMAX, RH>(frag, nt, S, st1, se1, so1, M1, b1, h0, g, fl, re, ro);
+                __builtin_amdgcn_sched_barrier(0);
+                if (h0 == 0 && PIPE == 0 && !st2 && !vt2) tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, b2);
+                if (h0 + RH >= NTMAX) {
+                    // child 1's operands are dead: the next tile's fly while child 2's MFMAs run
+                    if (vt1) { if (tile + tstep < tile1) raw1 = cherryFetch(cd1, tile + tstep, P, S, m); }
+                    else if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
+                }
+                if (h0 == 0 && vt2) cherryOperands<NTMAX>(raw2, vm + 2 * vmN, vm + 3 * vmN, g, b2);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < IH; k++) {
-                        const int i = 4 * (it0 + k) + g;
-                        if (it0 + k < nt && i < S) {
-                            v2d o; o.x = re[it0 + k] * te[k] * inve; o.y = ro[it0 + k] * to[k] * invo;
-                            double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
-                            if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
-                            else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+                for (int it0 = h0; it0 < h0 + RH; it0 += IH) {
+                    if (it0 < nt) {
+                        double te[IH], to[IH];
+                        tiledChild<NTMAX, IH>(frag + fragN, nt, S, st2, se2, so2, M2, b2, it0, g, fl, te, to);
+#pragma unroll
+                        for (int k = 0; k < IH; k++) {
+                            const int i = 4 * (it0 + k) + g;
+                            if (it0 + k < nt && i < S) {
+                                v2d o; o.x = re[it0 - h0 + k] * te[k] * inve; o.y = ro[it0 - h0 + k] * to[k] * invo;
+                                double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
+                                if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                                else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+                            }
                         }
                     }
                 }
