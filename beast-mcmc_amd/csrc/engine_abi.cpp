@@ -1,1220 +1,13 @@
-// engine.cpp — host side of the MI355X engine: instance table, HBM buffer management, the C ABI of
-// include/beagle_mi355.h.  All arithmetic is in kernels.hip; this file validates indices, resolves
-// buffer indices to device pointers, levelises operation lists and enqueues kernels on the
-// instance's HIP stream.  Results are only observed at calculateRootLogLikelihoods / get*, so every
-// other call returns as soon as its work is enqueued (SURVEY 8b "Threading").
-//
-// There is no CPU path in this library: with no visible MI355X beagleCreateInstance returns
-// BEAGLE_ERROR_NO_RESOURCE.
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-#include <chrono>
-#include <atomic>
-
-#include "../../include/beagle_mi355.h"
-#include "kernels.h"
-#include "planner.h"
-#include "sharded.h"
+// engine_abi.cpp — the C ABI of include/beagle_mi355.h over the engine's internals (engine_internal.h): argument checks,
+// buffer bookkeeping, and the calls that observe results (root log-likelihoods, read-back).
+#include "engine_internal.h"
 
 using mi355::OpDesc;
 using mi355::shardedStates;
 using mi355::shardedCategories;
+using namespace mi355::eng;
 
 namespace {
-
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e__ = (expr);                                                              \
-        if (e__ != hipSuccess) {                                                              \
-            if (getenv("BEAGLE_MI355_DEBUG"))                                                 \
-                fprintf(stderr, "[beagle-mi355] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-            return e__ == hipErrorOutOfMemory ? BEAGLE_ERROR_OUT_OF_MEMORY : BEAGLE_ERROR_GENERAL; \
-        }                                                                                     \
-    } while (0)
-
-constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
-constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
-constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
-
-struct Instance {
-    int device = 0;
-    // 4 states: every operation list runs as ONE launch of the pattern-walk kernel (kernels_walk4.hip), programmed by the
-    // walk planner (planner.h), which also owns the definitions of virtual buffers
-    bool walk = false;
-    mi355::WalkPlanner planner;
-    mi355::Plan plan;                                    // scratch of the current call
-    std::vector<mi355::WalkOp> walkOps;                  // scratch: resolved program
-    size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals (pair-interleaved,
-                                                         // kernels.h walkPairIndex)], this many doubles apart
-    size_t statePairOff = 0;                             // walk instances: a tip's pair-interleaved states follow its plain ones, this many bytes on
-    // walk instances: position of pattern p in the pair-interleaved arrays (tip states, reciprocal scale factors).  They are
-    // laid out partition by partition, each padded to whole blocks of 128 patterns (kernels.h WalkSeg), so that the assembly
-    // loop runs whatever the caller's partition boundaries are; one partition: walkPairIndex(p).
-    std::vector<unsigned> pairPos; size_t pairLen = 0; std::vector<int> padStart; unsigned* dPairPos = nullptr;
-    char* matStream = nullptr; size_t matStreamBytes = 0;   // walk instances: the matrix stream of the program being run (k_gatherMatrices)
-    uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
-                                                                 // micro-operation does not use (the assembly loop loads them unconditionally)
-    long statFastWalks = 0;
-    // what runPlan derived from a cached plan (planner.h plannedTag): the device program with its addresses resolved
-    struct Resolved {
-        long tag = 0, epoch = -1;
-        std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
-        int maxRange = 0;
-        long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
-        char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
-    } resolved[4];
-    long resolveEpoch = 0;                               // bumped when pattern ranges change
-    bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
-    bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
-    bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
-                                                         // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)
-    bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
-    bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
-    long statCherries = 0;
-    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
-    char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
-    // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
-    double* exportDev[2] = {nullptr, nullptr}; double* exportHost[2] = {nullptr, nullptr}; size_t exportBytes = 0;   // two chunks in flight
-    hipEvent_t exportEvent[2] = {nullptr, nullptr};
-    long statMicroOps = 0, statStored = 0, statMemReads = 0, statTipReads = 0, statScaleReads = 0, statWalks = 0, statScaleWrites = 0;   // since the last timer reset
-    hipStream_t stream = nullptr, ownStream = nullptr;
-    int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
-    size_t partialsBytes = 0;
-    std::vector<double*> partials;
-    std::vector<uint8_t*> tipStates;
-    std::vector<void*> allocations;
-    char* slabCur = nullptr; int slabLeft = 0;
-    char* scaleSlabCur = nullptr; int scaleSlabLeft = 0;
-    char* stateSlabCur = nullptr; int stateSlabLeft = 0;
-    double* matrices = nullptr; double* eigen = nullptr; double* rates = nullptr; double* weights = nullptr;
-    double* freqs = nullptr; double* patternWeights = nullptr; double* siteLogL = nullptr;
-    std::vector<double*> scale; std::vector<char> scaleIsRaw;
-    double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr; double* hResultDev = nullptr; unsigned long long resultSeq = 0;
-    char* hRing = nullptr; char* dRing = nullptr; size_t ringHead = 0;
-    int partitionCount = 1;
-    std::vector<int> partStart, partEnd;
-    // levelisation scratch
-    std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
-    bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
-    // pre-order on the T32 layout runs as two passes of the pruning kernel (see runPreOperations): scratch partials
-    // buffers, an identity matrix and transposed-matrix slots behind the caller's matrices, an all-missing tip
-    std::vector<double*> preScratch; uint8_t* preMissing = nullptr; int preIdentity = -1, preTransposed = -1;
-    bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
-    // kernel timer
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
-    double timedMs = 0.0; long timedLaunches = 0, pendingLaunches = 0;
-    size_t deviceBytes = 0;
-    std::vector<double> shEigen, shFreqs, shWeights, shRates;      // host shadows of the small model arrays ...
-    std::vector<char> okEigen, okFreqs, okWeights, okRates;         // ... valid flags per index
-    std::string resourceName;
-};
-
-std::mutex g_mutex;
-std::vector<Instance*> g_instances;
-
-Instance* lookup(int h) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (h < 0 || h >= (int)g_instances.size()) return nullptr;
-    return g_instances[h];
-}
-
-int devAlloc(Instance* in, void** p, size_t bytes) {
-    HIP_TRY(hipMalloc(p, bytes));
-    in->allocations.push_back(*p);
-    in->deviceBytes += bytes;
-    return 0;
-}
-
-// Stage `bytes` of host data into the pinned ring; returns the ring offset (or <0).  Wrapping first
-// drains the stream, so a region is never overwritten while a copy from it is still in flight.
-long stage(Instance* in, const void* src, size_t bytes, size_t reserve = 0) {
-    const size_t need = (std::max(bytes, reserve) + 255) & ~(size_t)255;
-    if (need > RING_BYTES) return -1;
-    if (in->ringHead + need > RING_BYTES) {
-        if (hipStreamSynchronize(in->stream) != hipSuccess) return -1;
-        in->ringHead = 0;
-    }
-    const size_t off = in->ringHead;
-    memcpy(in->hRing + off, src, bytes);
-    in->ringHead += need;
-    return (long)off;
-}
-
-// host array -> persistent device location, asynchronously when it fits the ring
-int upload(Instance* in, void* dst, const void* src, size_t bytes) {
-    if (bytes == 0) return 0;
-    if (bytes <= RING_BYTES / 4) {
-        long off = stage(in, src, bytes);
-        if (off < 0) return BEAGLE_ERROR_GENERAL;
-        HIP_TRY(hipMemcpyAsync(dst, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
-        return 0;
-    }
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, in->stream));
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    return 0;
-}
-
-// host array -> the device mirror of the ring (transient kernel arguments: op descriptors, index lists)
-int uploadTransient(Instance* in, const void* src, size_t bytes, void** dptr) {
-    long off = stage(in, src, bytes);
-    if (off < 0) return BEAGLE_ERROR_GENERAL;
-    HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
-    *dptr = in->dRing + off;
-    return 0;
-}
-
-int download(Instance* in, void* dst, const void* src, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, in->stream));
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;   // everything staged so far has been consumed
-    return 0;
-}
-
-int ensurePartials(Instance* in, int idx) {
-    if (in->partials[idx]) return 0;
-    if (in->slabLeft == 0) {
-        int remaining = 0;
-        for (double* p : in->partials) if (!p) remaining++;
-        const int n = std::min(remaining, SLAB_BUFFERS);
-        void* slab = nullptr;
-        int rc = devAlloc(in, &slab, in->partialsBytes * n);
-        if (rc) return rc;
-        in->slabCur = (char*)slab; in->slabLeft = n;
-    }
-    in->partials[idx] = (double*)in->slabCur;
-    in->slabCur += in->partialsBytes; in->slabLeft--;
-    return 0;
-}
-
-int ensureScale(Instance* in, int idx) {
-    if (in->scale[idx]) return 0;
-    // walk instances keep [factors | reciprocals] so that read mode never divides (kernels_walk4.hip)
-    const size_t bytes = in->walk ? 2 * in->scaleStride * sizeof(double) : (((size_t)in->P * sizeof(double) + 255) & ~(size_t)255);
-    if (in->scaleSlabLeft == 0) {
-        int remaining = 0;
-        for (double* p : in->scale) if (!p) remaining++;
-        const int n = std::min(remaining, 256);
-        void* slab = nullptr;
-        int rc = devAlloc(in, &slab, bytes * n);
-        if (rc) return rc;
-        if (hipMemsetAsync(slab, 0, bytes * n, in->stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
-        in->scaleSlabCur = (char*)slab; in->scaleSlabLeft = n;
-    }
-    in->scale[idx] = (double*)in->scaleSlabCur;
-    in->scaleSlabCur += bytes; in->scaleSlabLeft--;
-    in->scaleIsRaw[idx] = 0;
-    return 0;
-}
-
-int ensureStates(Instance* in, int idx) {
-    if (in->tipStates[idx]) return 0;
-    const size_t plain = ((size_t)in->P + 2 + 255) & ~(size_t)255;
-    const size_t bytes = in->walk ? plain + ((in->pairLen + 255) & ~(size_t)255) : plain;      // walk instances: [plain | pair-interleaved] (the latter is what the walk reads)
-    in->statePairOff = plain;
-    if (in->stateSlabLeft == 0) {
-        const int n = std::max(1, std::min(in->compactCount, 1024));
-        void* slab = nullptr;
-        int rc = devAlloc(in, &slab, bytes * n);
-        if (rc) return rc;
-        in->stateSlabCur = (char*)slab; in->stateSlabLeft = n;
-    }
-    in->tipStates[idx] = (uint8_t*)in->stateSlabCur;
-    in->stateSlabCur += bytes; in->stateSlabLeft--;
-    in->resolveEpoch++;                       // a kept device program may still point at the slot this tip had before (Instance::Resolved)
-    return 0;
-}
-
-void destroy(Instance* in) {
-    hipSetDevice(in->device);
-    if (in->hostCalls && getenv("BEAGLE_MI355_HOST_TIMING"))
-        fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us; %ld plans from the cache: planner %.1f us, resolve+upload+launch %.1f us\n",
-                in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls, in->planner.cacheHits,
-                in->hostHits ? in->hostPlanHitUs / in->hostHits : 0.0, in->hostHits ? in->hostRunHitUs / in->hostHits : 0.0);
-    if (in->ownStream) hipStreamSynchronize(in->ownStream);
-    if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
-    for (void* p : in->allocations) hipFree(p);
-    if (in->bigStage) hipFree(in->bigStage);
-    if (in->matStream) hipFree(in->matStream);
-    for (auto& r : in->resolved) if (r.dProg) hipFree(r.dProg);
-    for (int k = 0; k < 2; k++) {
-        if (in->exportDev[k]) hipFree(in->exportDev[k]);
-        if (in->exportHost[k]) hipHostFree(in->exportHost[k]);
-        if (in->exportEvent[k]) hipEventDestroy(in->exportEvent[k]);
-    }
-    if (in->hRing) hipHostFree(in->hRing);
-    if (in->hResult) hipHostFree(in->hResult);
-    for (auto& ev : in->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    if (in->ownStream) hipStreamDestroy(in->ownStream);
-    delete in;
-}
-
-struct Resources {
-    std::vector<std::string> names, descs;
-    std::vector<BeagleResource> list;
-    BeagleResourceList rl;
-    int gpuCount = 0;
-};
-Resources* g_resources = nullptr;
-
-const long GPU_FLAGS = BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_COMPUTATION_SYNCH | BEAGLE_FLAG_EIGEN_REAL | BEAGLE_FLAG_EIGEN_COMPLEX |
-                       BEAGLE_FLAG_SCALING_MANUAL | BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC |
-                       BEAGLE_FLAG_SCALERS_RAW | BEAGLE_FLAG_VECTOR_NONE | BEAGLE_FLAG_THREADING_NONE |
-                       BEAGLE_FLAG_PROCESSOR_GPU | BEAGLE_FLAG_PARALLELOPS_GRID;
-
-Resources* resources() {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (g_resources) return g_resources;
-    Resources* r = new Resources();
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
-    r->gpuCount = n;
-    // resource 0 is "the CPU" by BEAST convention (BeagleTreeLikelihood.java:90-92); this library has no
-    // CPU implementation, the entry only keeps the numbering of the GPUs at 1..G.
-    r->names.push_back("CPU"); r->descs.push_back("not provided by this library (MI355X engine only)");
-    for (int d = 0; d < n; d++) {
-        hipDeviceProp_t prop;
-        char buf[256];
-        if (hipGetDeviceProperties(&prop, d) == hipSuccess) {
-            snprintf(buf, sizeof(buf), "Global memory (MB): %zu | Compute units: %d | Arch: %s",
-                     (size_t)(prop.totalGlobalMem >> 20), prop.multiProcessorCount, prop.gcnArchName);
-            r->names.push_back(prop.name);
-        } else {
-            snprintf(buf, sizeof(buf), "device %d", d);
-            r->names.push_back("AMD GPU");
-        }
-        r->descs.push_back(buf);
-    }
-    if (n >= 1) {      // resource G+1: every GPU of the node behind one instance, patterns sharded (sharded.cpp)
-        char buf[256];
-        const int shards = mi355::shardedDeviceCountOverride() > 0 ? mi355::shardedDeviceCountOverride() : n;
-        snprintf(buf, sizeof(buf), "%d pattern shards over %d GPU(s) | one RCCL all-reduce of the log-likelihood per evaluation", shards, n);
-        r->names.push_back("all GPUs (pattern-sharded)");
-        r->descs.push_back(buf);
-    }
-    for (size_t i = 0; i < r->names.size(); i++) {
-        BeagleResource br;
-        br.name = (char*)r->names[i].c_str(); br.description = (char*)r->descs[i].c_str();
-        br.supportFlags = i == 0 ? 0 : GPU_FLAGS; br.requiredFlags = 0;
-        r->list.push_back(br);
-    }
-    r->rl.list = r->list.data(); r->rl.length = (int)r->list.size();
-    g_resources = r;
-    return r;
-}
-
-#define GET_INSTANCE(h)                                          \
-    Instance* in = lookup(h);                                    \
-    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;         \
-    if (hipSetDevice(in->device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
-
-inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
-
-// ---- the pattern walk (4 states) ------------------------------------------------------------------------------------
-// A partials buffer is "virtual" when its content is DEFINED instead of stored (planner.h VirtDef): a few steps over
-// compact tips, private snapshots of every branch matrix in the subtree (kept behind the caller's matrices) and each
-// node's scale buffer.  Nothing is written to HBM for such a buffer; the walk recomputes it in registers where a parent
-// needs it, bitwise as the ordinary operation would have.  The definition is self-contained: it never refers to other
-// partials buffers or to the caller's matrix buffers, so buffer flips and matrix updates cannot invalidate it.  What CAN
-// change a defining input — new tip states, a write to one of its scale buffers — and everything that needs the real
-// data — getPartials, use as root, the pre-order kernels — first calls materializeList, which runs the definition with
-// a store.
-static_assert(mi355::PK_MEM == mi355::WK_MEM && mi355::PK_TIPS == mi355::WK_TIPS && mi355::PK_ACC == mi355::WK_ACC &&
-              mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1 && mi355::PK_H2 == mi355::WK_H2, "planner kinds = kernel kinds");
-static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_READ && mi355::PS_WRITE == mi355::WS_WRITE, "scale modes");
-
-inline bool isVirt(const Instance* in, int X) { return in->virt && in->planner.isVirtual(X); }
-inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearVirtual(X); }
-inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
-// what buffer X holds changed: compact tip states (on), or something else — in which case it is no uploaded-partials leaf
-// either until setLeaf says so (planner.h leafPartials)
-inline void setCompact(Instance* in, int X, bool on) { in->planner.setCompactTip(X, on); in->planner.setLeafPartials(X, false); }
-inline void setLeaf(Instance* in, int X) { if (X < in->tipCount) in->planner.setLeafPartials(X, true); }
-
-// The pair-interleaved layout for the instance's current partitions (Instance::pairPos), and the scale-buffer stride that
-// holds either half ([factors, plain | reciprocals, pair-interleaved]).
-void setPairLayout(Instance* in) {
-    const int K = in->partitionCount;
-    in->padStart.assign(K, 0);
-    in->pairPos.assign((size_t)in->P, 0u);
-    size_t at = 0;
-    // partitions in pattern order (they are contiguous ranges; an empty one takes no room)
-    std::vector<int> order(K);
-    for (int k = 0; k < K; k++) order[k] = k;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return in->partStart[a] < in->partStart[b]; });
-    for (int k : order) {
-        in->padStart[k] = (int)at;
-        for (int p = in->partStart[k]; p < in->partEnd[k]; p++) in->pairPos[p] = (unsigned)(at + mi355::walkPairIndex((size_t)(p - in->partStart[k])));
-        at += ((size_t)(in->partEnd[k] - in->partStart[k]) + 127) & ~(size_t)127;
-    }
-    in->pairLen = std::max<size_t>(at, 128);
-    in->scaleStride = (std::max<size_t>((size_t)in->P, in->pairLen) + 2 + 127) & ~(size_t)127;
-}
-
-int ensureWalkDummies(Instance* in) {
-    if (in->dummyTips) return 0;
-    const size_t tipBytes = in->pairLen + 256, scaleBytes = in->scaleStride * sizeof(double);
-    void* p = nullptr;
-    int rc = devAlloc(in, &p, ((tipBytes + 255) & ~(size_t)255) + scaleBytes); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(p, in->S, tipBytes, in->stream));
-    double* ones = (double*)((char*)p + ((tipBytes + 255) & ~(size_t)255));
-    mi355::launchFill(in->stream, ones, 1.0, 0, (int)in->scaleStride);
-    HIP_TRY(hipGetLastError());
-    in->dummyTips = (uint8_t*)p; in->onesScale = ones;
-    return 0;
-}
-
-// Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
-// micro-operations travel together) and enqueue the snapshot copies and the walk.
-int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t recordBeforeWalk = nullptr) {
-    const size_t n = plan.prog.size();
-    if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
-        if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
-        void* dPairs = nullptr;
-        int rc = uploadTransient(in, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    // Device program: per segment its micro-operations, a no-op when their number is odd, and two more no-ops the
-    // kernel's descriptor prefetch may read (kernels.h WalkSeg).  For a plan that came out of the planner's cache the
-    // resolved program is kept as well: buffer addresses never change once a buffer exists.
-    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
-    Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 3] : nullptr;
-    const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
-    std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
-    std::vector<mi355::WalkSeg> segsLocal;
-    std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
-    int maxRange = 0;
-    if (reuse) {
-        maxRange = slot->maxRange;
-        in->statMemReads += slot->memReads; in->statTipReads += slot->tipReads; in->statScaleReads += slot->scaleReads;
-        in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
-    } else {
-    const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
-    if (slot) { slot->tag = 0; slot->dProgValid = false; }
-    w.clear();
-    w.reserve(n + 3 * plan.segs.size());
-    segs.assign(plan.segs.size(), mi355::WalkSeg());
-    const size_t matStride = (size_t)in->C * 16;
-    { int rc = ensureWalkDummies(in); if (rc) return rc; }
-    mi355::WalkOp nop;
-    memset(&nop, 0, sizeof(nop));
-    nop.m1 = in->matrices; nop.m2 = in->matrices;
-    nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
-    nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
-    for (size_t si = 0; si < plan.segs.size(); si++) {
-        const mi355::PlanSeg& ps = plan.segs[si];
-        segs[si].progStart = (int)w.size();
-        for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
-            mi355::MicroOp m = plan.prog[i];
-            // The kernels request a first child's partials one stage early — before the previous micro-operation's store
-            // is issued (kernels_walk4.hip WALK_STAGE).  The planner never emits that sequence (tests/native/plan_check.cpp
-            // checks every program for it); should one arrive anyway, a no-op in between restores the distance.
-            if (i > ps.progStart && m.k1 == mi355::PK_MEM && plan.prog[i - 1].storeBuf == m.a1) {
-                if (m.k2 == mi355::PK_ACC) { m.k2 = mi355::PK_MEM; m.a2 = m.a1; }      // the no-op overwrites ACC; the value is in memory as well
-                w.push_back(nop);
-            }
-            mi355::WalkOp d;
-            memset(&d, 0, sizeof(d));
-            d.src1 = in->dummyTips; d.src2 = in->dummyTips; d.scale = in->onesScale;     // unused operands stay readable (kernels.h launchWalk4Fast)
-            if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + in->statePairOff; in->statTipReads++; }
-            if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + in->statePairOff; in->statTipReads++; }
-            if (m.smode != mi355::PS_NONE) {
-                int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
-                else {
-                    if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
-                    in->statScaleReads++;
-                    d.scale = in->scale[m.scaleIdx] + in->scaleStride;                    // read mode multiplies by the reciprocal
-                }
-            }
-            if (m.storeBuf >= 0) {
-                int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
-                d.store = in->partials[m.storeBuf];
-                in->statStored++;
-            }
-            d.m1 = in->matrices + (size_t)m.mat1 * matStride; d.m2 = in->matrices + (size_t)m.mat2 * matStride;
-            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
-            if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
-                if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
-                if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
-                if (ablate & 4) d.scale = in->onesScale;
-                if (ablate & 8) { if (m.k1 == mi355::PK_TIPS) d.src1 = in->dummyTips; if (m.k2 == mi355::PK_TIPS) d.src2 = in->dummyTips; }
-            }
-            w.push_back(d);
-        }
-        if (ps.progCount & 1) w.push_back(nop);
-        segs[si].progCount = (int)w.size() - segs[si].progStart;
-        w.push_back(nop); w.push_back(nop);
-        // the wait of every stage: "at most N vector-memory instructions outstanding".  Loads and stores share the counter.
-        // DEFAULT (strict): N = the loads of the NEXT micro-operation only.  Sufficient under the one ordering rule the ISA
-        // guides state for this counter — vector-memory LOADS return in the order they were issued: when at most N operations
-        // are outstanding and the N youngest loads are all younger than this stage's loads, an unfinished load of this stage
-        // would leave N + 1 unfinished, whatever the stores (of this or any earlier stage) do.
-        // BEAGLE_MI355_STRICT_WAITS=0: N also counts the previous micro-operation's stores, i.e. assumes that a younger store
-        // is never counted out before an older load.  That held in > 1e9 lane-trials (tests/test_gpu_vmcnt_order.py) and saves a
-        // stage the acknowledgement of four stores per stored node — 1 % of config A (profiles/r03_experiments.txt 7) — but it
-        // is an observation, not a documented guarantee, so it is not what ships by default.
-        // A smaller N than the true number only waits longer (the table ends at 12).
-        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
-            const int stores = in->strictWaits ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
-            // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
-            const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
-            if (code == 1) w[i].flags |= mi355::WF_WAIT8; else if (code == 2) w[i].flags |= mi355::WF_WAIT12;
-        }
-        segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
-        maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
-    }
-    if (slot) {
-        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
-        slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
-        slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
-    }
-    }
-    in->statMicroOps += (long)n;
-    // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
-    const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
-    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
-    char* dBase = nullptr;
-    if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
-    else if (total <= RING_BYTES / 4) {
-        const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
-        if (off < 0) return BEAGLE_ERROR_GENERAL;
-        memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
-        if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
-        HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
-        dBase = in->dRing + off;
-        if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
-            if (slot->dProgBytes < total) {
-                if (slot->dProg) { HIP_TRY(hipStreamSynchronize(in->stream)); hipFree(slot->dProg); }
-                slot->dProg = nullptr; slot->dProgBytes = 0;
-                HIP_TRY(hipMalloc((void**)&slot->dProg, total + total / 4));
-                slot->dProgBytes = total + total / 4;
-            }
-            HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, in->stream));
-            slot->dProgValid = true;
-        }
-    } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
-        HIP_TRY(hipStreamSynchronize(in->stream));
-        if (in->bigStageBytes < total) {
-            if (in->bigStage) hipFree(in->bigStage);
-            in->bigStage = nullptr; in->bigStageBytes = 0;
-            HIP_TRY(hipMalloc((void**)&in->bigStage, total));
-            in->bigStageBytes = total;
-        }
-        HIP_TRY(hipMemcpy(in->bigStage, w.data(), opBytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segBytes, hipMemcpyHostToDevice));
-        if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
-        dBase = in->bigStage;
-    }
-    if (pairBytes)
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
-                                      in->C * in->S * in->S);
-    // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
-    const size_t streamBytes = w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
-    if (in->matStreamBytes < streamBytes) {
-        HIP_TRY(hipStreamSynchronize(in->stream));
-        if (in->matStream) hipFree(in->matStream);
-        in->matStream = nullptr; in->matStreamBytes = 0;
-        const size_t want = std::max(streamBytes + streamBytes / 4, (size_t)1 << 20);
-        HIP_TRY(hipMalloc((void**)&in->matStream, want));
-        in->matStreamBytes = want;
-    }
-    mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
-    if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
-        fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
-        for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
-        fprintf(stderr, "\n");
-    }
-    if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
-    // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
-    for (size_t b = 0; b < segs.size();) {
-        size_t e = b + 1;
-        while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
-        int range = 0;
-        const bool fast = in->fastWalk;                 // the assembly loop (BEAGLE_MI355_NO_FAST_WALK=1: the C++ reference kernel)
-        for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
-        if (fast) {
-            mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                   in->matStream, in->P, in->C, (long)in->scaleStride);
-            in->statFastWalks++;
-        } else
-            mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                               in->matStream, in->P, in->C, (long)in->scaleStride);
-        in->statWalks++;
-        b = e;
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// Give every definition of `xs` its real partials: one program, one launch.  xs are definition KEYS (planner.h: buffer x
-// partitionCount + partition; the buffer index itself on an instance with one partition).
-int materializeCherries(Instance* in, const std::vector<int>& xs);
-int materializeList(Instance* in, const std::vector<int>& xs) {
-    if (!in->virt || xs.empty()) return 0;
-    if (!in->walk) return materializeCherries(in, xs);
-    mi355::Plan mp;
-    in->planner.planMaterialize(xs, mp);
-    return runPlan(in, mp);
-}
-int materializeVirtual(Instance* in, int X) {         // every partition of buffer X
-    if (!isVirt(in, X)) return 0;
-    std::vector<int> keys;
-    in->planner.keysOf(X, keys);
-    return materializeList(in, keys);
-}
-int materializeScaleUsers(Instance* in, int scaleIdx) {
-    if (!in->virt || in->planner.scaleUsers(scaleIdx).empty()) return 0;
-    return materializeList(in, std::vector<int>(in->planner.scaleUsers(scaleIdx)));
-}
-int materializeTipUsers(Instance* in, int tip) {
-    if (!in->virt || in->planner.tipUsers(tip).empty()) return 0;
-    return materializeList(in, std::vector<int>(in->planner.tipUsers(tip)));
-}
-
-int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum);
-
-// A walk is one workgroup per 128 patterns, and every wave executes its program one dependent step after the other.  The
-// planner therefore cuts the forest into independent subtrees that run side by side, wave after wave (planner.h): with few
-// patterns (a shard of a multi-GPU run, a small alignment) that is what fills the 256 CUs at all (12 500 patterns:
-// 0.83 -> 0.33 ms per evaluation); with many it keeps more workgroups than the chip holds in the queue, so that a wave
-// waiting for its stores is replaced by another one instead of idling (1e5 patterns: 1.73 -> 1.37 ms).  Returns the target
-// number of micro-operations per subtree, 0 = one walk.  BEAGLE_MI355_CHUNK overrides (0 = never).
-int walkChunkOps(const Instance* in, int opCount) {
-    static const int forced = getenv("BEAGLE_MI355_CHUNK") ? atoi(getenv("BEAGLE_MI355_CHUNK")) : -1;
-    if (forced >= 0) return forced;
-    if (opCount < 64) return 0;
-    const long groups = (in->P + 127) / 128;
-    // about 2 560 workgroups per wave of slices: 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the
-    // assembly loop (tools/chunk_sweep.sh): 12 500 patterns 129 us at 40 micro-operations per slice vs 145 at 99; flat
-    // between 50 and 300 from 25 000 patterns up
-    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / 2560));
-}
-
-// 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
-int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum) {
-    if (count <= 0) return 0;
-    typedef std::chrono::steady_clock Clock;
-    const Clock::time_point t0 = Clock::now();
-    auto usSince = [](Clock::time_point a) { return std::chrono::duration<double, std::micro>(Clock::now() - a).count(); };
-    in->hostCalls++;
-    const int parts = in->partitionCount;
-    // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
-    const bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
-    // The chain's steady state — the SAME full-evaluation list as one seen before, no rescaling in it — needs none of the
-    // per-operation work below: it was range-checked and planned then, nothing has to be materialised or accumulated for it,
-    // the planner re-establishes its definitions with one comparison per operation and the program is resident on the
-    // device (config E, 6 436 operations: 116 -> 35 us of host time per call; profiles/r03_experiments.txt).
-    {
-        bool simple = false;
-        if (in->planner.replayCached(ops, count, tuple, parts, allowVirtual, walkChunkOps(in, count), &simple)) {
-            const double usPlan = usSince(t0);
-            in->hostPlanUs += usPlan; in->hostPlanHitUs += usPlan; in->hostHits++;
-            const Clock::time_point t1 = Clock::now();
-            hipEvent_t a = nullptr, b = nullptr;
-            const bool launches = !in->planner.planned->prog.empty();
-            if (in->timing && launches) {
-                if (in->eventsUsed == in->events.size()) { hipEvent_t x, y; HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y)); in->events.emplace_back(x, y); }
-                a = in->events[in->eventsUsed].first; b = in->events[in->eventsUsed].second; in->eventsUsed++;
-            }
-            int rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, a); if (rc) return rc;
-            if (b) { HIP_TRY(hipEventRecord(b, in->stream)); in->pendingLaunches++; }
-            const double usRun = usSince(t1);
-            in->hostRunUs += usRun; in->hostRunHitUs += usRun;
-            return 0;
-        }
-    }
-    for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * tuple;
-        const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
-        int part = 0, cum = globalCum;
-        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
-        if (badIndex(dest, in->partialsCount) || badIndex(c1, in->partialsCount) || badIndex(c2, in->partialsCount) ||
-            badIndex(m1, in->matrixCount) || badIndex(m2, in->matrixCount) || badIndex(part, parts) ||
-            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
-            (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
-            return BEAGLE_ERROR_OUT_OF_RANGE;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (in->timing) {
-        if (in->eventsUsed == in->events.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-            in->events.emplace_back(a, b);
-        }
-        e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
-    }
-    int launches = 0;
-    in->hostPrepUs += usSince(t0);
-    for (int begin = 0; begin < count;) {
-        Clock::time_point t1 = Clock::now();
-        const int n = in->planner.hazardFreePrefix(ops, begin, count, tuple, parts);
-        const int* sub = ops + (size_t)begin * tuple;
-        for (int k = 0; k < n; k++) {                       // a tip index reused as a destination now holds partials
-            const int dest = sub[(size_t)k * tuple];
-            if (isCompactTip(in, dest) || in->planner.leafPartials[dest]) { int rcm = materializeTipUsers(in, dest); if (rcm) return rcm; in->tipStates[dest] = nullptr; setCompact(in, dest, false); }
-        }
-        std::vector<int> need;
-        in->planner.mustMaterializeBefore(sub, n, tuple, need);
-        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-        in->hostPrepUs += usSince(t1); t1 = Clock::now();
-        const long hitsBefore = in->planner.cacheHits;
-        int rc = in->planner.plan(sub, n, tuple, parts, allowVirtual, in->plan, walkChunkOps(in, n));
-        if (rc) return rc;
-        const bool hit = in->planner.cacheHits != hitsBefore;
-        { const double us = usSince(t1); in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
-        t1 = Clock::now();
-        // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
-        // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
-        if (!in->planner.planned->prog.empty()) {
-            rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, launches == 0 ? e0 : nullptr); if (rc) return rc;
-            launches++;
-        } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
-        { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us; }
-        begin += n;
-    }
-    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
-    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
-    return foldCumulative(in, ops, count, tuple, globalCum);
-}
-
-// T32 instances: give the virtual cherries of `xs` their real partials — each is one ordinary tip-tip operation on its
-// snapshot matrices; all of them are independent (one level launch).
-int materializeCherries(Instance* in, const std::vector<int>& xs) {
-    std::vector<OpDesc> descs;
-    for (int X : xs) {
-        if (!in->planner.isVirtual(X)) continue;
-        const mi355::VirtDef& v = in->planner.definition(X);
-        const mi355::VirtStep& st = v.steps[0];
-        if (v.nSteps != 1 || st.type != mi355::VT_CHERRY || !in->tipStates[st.tipA] || !in->tipStates[st.tipB]) return BEAGLE_ERROR_GENERAL;
-        int rc = ensurePartials(in, X); if (rc) return rc;
-        OpDesc d;
-        memset(&d, 0, sizeof(d));
-        d.dest = in->partials[X];
-        d.child1 = in->tipStates[st.tipA]; d.child2 = in->tipStates[st.tipB];
-        d.kind = mi355::KIND_STATES1 | mi355::KIND_STATES2;
-        d.mat1 = in->planner.snapSlot(X, 0, 0); d.mat2 = in->planner.snapSlot(X, 0, 1);
-        if (st.scaleIdx >= 0) { if (!in->scale[st.scaleIdx]) return BEAGLE_ERROR_GENERAL; d.scaleRead = in->scale[st.scaleIdx]; }
-        d.pStart = 0; d.pEnd = in->P;
-        descs.push_back(d);
-        in->planner.clearVirtual(X);
-    }
-    if (descs.empty()) return 0;
-    void* dOps = nullptr;
-    int rc = uploadTransient(in, descs.data(), descs.size() * sizeof(OpDesc), &dOps); if (rc) return rc;
-    mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dOps, (int)descs.size(), in->matrices, in->P, in->S, in->C, false);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// Enqueue an op list level by level (every state count but 4).  `tuple` is 7 (updatePartials) or 9 (updatePartialsByPartition).
-int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int globalCum) {
-    if (count <= 0) return 0;
-    const int parts = in->partitionCount;
-    std::vector<OpDesc> descs;                   // one per op that launches (never reallocated: references stay valid)
-    descs.reserve(count);
-    std::vector<int> descOf(count, -1);
-    std::vector<int> level(count);
-    std::vector<int> predOff(count + 1, 0), predList;                 // RAW / WAW edges: producer op -> this op
-    bool warSeen = false;                                             // a write-after-read hazard inside the list (never in BEAST's lists)
-    predList.reserve((size_t)count * 3);
-    // virtual cherries (in->cherry): definitions that read a scale buffer this list rewrites, or that the list updates in
-    // place, get their data first; new ones are only made by single-partition 7-int lists
-    const bool cherryList = in->cherry && parts == 1 && tuple == BEAGLE_OP_COUNT;
-    std::vector<mi355::CherryDesc> cherries;
-    std::vector<int> snapPairs;
-    std::vector<char> skipped(count, 0);                             // ops that only defined a cherry
-    if (in->virt) {
-        for (int k = 0; k < count; k++) {                            // (range checks of these fields: same loop below, nothing is touched before it passes)
-            const int* op = ops + (size_t)k * tuple;
-            if (badIndex(op[0], in->partialsCount) || badIndex(op[3], in->partialsCount) || badIndex(op[5], in->partialsCount) ||
-                (op[1] != BEAGLE_OP_NONE && badIndex(op[1], in->scaleCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
-        }
-        std::vector<int> need;
-        in->planner.mustMaterializeBefore(ops, count, tuple, need);
-        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-    }
-    auto cherryChild = [&](int c) -> size_t {                         // descriptor index of a virtual child
-        const mi355::VirtStep& st = in->planner.definition(c).steps[0];
-        mi355::CherryDesc cd;
-        cd.tipA = in->tipStates[st.tipA]; cd.tipB = in->tipStates[st.tipB];
-        cd.scale = st.scaleIdx >= 0 ? in->scale[st.scaleIdx] : nullptr;
-        cd.matA = in->planner.snapSlot(c, 0, 0); cd.matB = in->planner.snapSlot(c, 0, 1);
-        cherries.push_back(cd);
-        return cherries.size() - 1;
-    };
-    in->stamp++;
-    int maxLevel = 0;
-    for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * tuple;
-        const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
-        int part = 0, cum = globalCum;
-        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
-        if (badIndex(dest, in->partialsCount) || badIndex(c1, in->partialsCount) || badIndex(c2, in->partialsCount) ||
-            badIndex(m1, in->matrixCount) || badIndex(m2, in->matrixCount) || badIndex(part, parts) ||
-            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
-            (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
-            return BEAGLE_ERROR_OUT_OF_RANGE;
-        const bool tip1 = isCompactTip(in, c1), tip2 = isCompactTip(in, c2);
-        const int ownScale = wS != BEAGLE_OP_NONE ? wS : rS;
-        if (wS != BEAGLE_OP_NONE || rS != BEAGLE_OP_NONE) { int rcs = ensureScale(in, ownScale); if (rcs) return rcs; }
-        // a tip-tip node that does not rescale now is DEFINED, not computed: nothing is launched for it (a definition
-        // reads its scale buffer in read mode only, so that buffer must hold factors already)
-        if (cherryList && tip1 && tip2 && wS == BEAGLE_OP_NONE && dest != c1 && dest != c2 && dest >= in->tipCount &&
-            (rS == BEAGLE_OP_NONE || in->scaleIsRaw[rS]) && in->planner.defineCherry(dest, c1, m1, c2, m2, rS == BEAGLE_OP_NONE ? -1 : rS, snapPairs)) {
-            skipped[k] = 1; level[k] = 0; predOff[k] = (int)predList.size();
-            in->statCherries++;
-            continue;
-        }
-        if (isVirt(in, dest)) clearVirtual(in, dest);                // whatever it was, this op gives it real data
-        // traffic counters (beagleMi355WalkStats): one stored node; per child a partials read, a tip-state read or — for a
-        // virtual cherry — two tip-state reads and its scale factors
-        in->statMicroOps++; in->statStored++;
-        for (int w = 0; w < 2; w++) {
-            const int c = w ? c2 : c1;
-            if (w ? tip2 : tip1) in->statTipReads++;
-            else if (isVirt(in, c)) { in->statTipReads += 2; if (in->planner.definition(c).steps[0].scaleIdx >= 0) in->statScaleReads++; }
-            else in->statMemReads++;
-        }
-        if (wS != BEAGLE_OP_NONE) in->statScaleWrites++; else if (rS != BEAGLE_OP_NONE) in->statScaleReads++;
-        descOf[k] = (int)descs.size(); descs.emplace_back();
-        OpDesc& d = descs.back();
-        memset(&d, 0, sizeof(d));
-        if (tip1) { d.child1 = in->tipStates[c1]; d.kind |= mi355::KIND_STATES1; }
-        else if (isVirt(in, c1)) { d.child1 = (const void*)cherryChild(c1); d.kind |= mi355::KIND_CHERRY1; }
-        else if (in->partials[c1]) d.child1 = in->partials[c1];
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (tip2) { d.child2 = in->tipStates[c2]; d.kind |= mi355::KIND_STATES2; }
-        else if (isVirt(in, c2)) { d.child2 = (const void*)cherryChild(c2); d.kind |= mi355::KIND_CHERRY2; }
-        else if (in->partials[c2]) d.child2 = in->partials[c2];
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        int rc = ensurePartials(in, dest); if (rc) return rc;
-        d.dest = in->partials[dest];
-        d.mat1 = m1; d.mat2 = m2;
-        if (wS != BEAGLE_OP_NONE) {
-            rc = ensureScale(in, wS); if (rc) return rc;
-            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1;
-        } else if (rS != BEAGLE_OP_NONE) {
-            rc = ensureScale(in, rS); if (rc) return rc;
-            if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
-            d.scaleRead = in->scale[rS];
-        }
-        d.pStart = in->partStart[part]; d.pEnd = in->partEnd[part];
-        // dependency level: after the ops (of this call) that produced my children (RAW), that read my
-        // destination (WAR) or that wrote it (WAW); hazards are tracked per (buffer, partition)
-        int lvl = 0;
-        const size_t kc1 = (size_t)c1 * parts + part, kc2 = (size_t)c2 * parts + part, kd = (size_t)dest * parts + part;
-        predOff[k] = (int)predList.size();
-        if (in->wStamp[kc1] == in->stamp) { lvl = std::max(lvl, in->wLevel[kc1] + 1); predList.push_back(in->wOp[kc1]); }
-        if (in->wStamp[kc2] == in->stamp) { lvl = std::max(lvl, in->wLevel[kc2] + 1); predList.push_back(in->wOp[kc2]); }
-        if (in->wStamp[kd] == in->stamp) { lvl = std::max(lvl, in->wLevel[kd] + 1); predList.push_back(in->wOp[kd]); }
-        if (in->rStamp[kd] == in->stamp) { lvl = std::max(lvl, in->rLevel[kd] + 1); warSeen = true; }
-        level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
-        in->wStamp[kd] = in->stamp; in->wLevel[kd] = lvl; in->wOp[kd] = k;
-        if (in->rStamp[kc1] != in->stamp || in->rLevel[kc1] < lvl) { in->rStamp[kc1] = in->stamp; in->rLevel[kc1] = lvl; }
-        if (in->rStamp[kc2] != in->stamp || in->rLevel[kc2] < lvl) { in->rStamp[kc2] = in->stamp; in->rLevel[kc2] = lvl; }
-    }
-    // ASAP levels put every tip-tip op ("cherry", write-only traffic) into the first launch and leave the read-heavy
-    // ops to later ones, so the HBM sees a write-bound phase (~3.7 TB/s) followed by read-heavy phases.  ALAP levels
-    // (= depth below the root, BEAST's own "reverse level order") spread the cherries over all launches: every launch
-    // then mixes reads and writes, which is where the memory system is fastest.  Same number of launches either way.
-    predOff[count] = (int)predList.size();
-    if (in->schedAlap && !warSeen) {
-        std::vector<int> alap(count, maxLevel);
-        for (int k = count - 1; k >= 0; k--)
-            for (int e = predOff[k]; e < predOff[k + 1]; e++) {
-                const int a = predList[e];
-                if (alap[a] > alap[k] - 1) alap[a] = alap[k] - 1;
-            }
-        level.swap(alap);
-    }
-    // counting sort by level (stable)
-    std::vector<int> start(maxLevel + 2, 0);
-    for (int k = 0; k < count; k++) if (!skipped[k]) start[level[k] + 1]++;
-    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
-    const int launchCount = start[maxLevel + 1];
-    std::vector<OpDesc> sorted(std::max(1, launchCount));
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int k = 0; k < count; k++) if (!skipped[k]) sorted[fill[level[k]]++] = descs[descOf[k]];
-    // the cherries' matrix snapshots and the descriptors of the virtual children, ahead of the level launches
-    const mi355::CherryDesc* dCherries = nullptr;
-    if (!snapPairs.empty()) {
-        void* dPairs = nullptr;
-        int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
-    }
-    if (!cherries.empty()) {
-        void* dC = nullptr;
-        int rc = uploadTransient(in, cherries.data(), cherries.size() * sizeof(mi355::CherryDesc), &dC); if (rc) return rc;
-        dCherries = (const mi355::CherryDesc*)dC;
-    }
-    // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
-    // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
-    // launch per dependency level reading its slice.  With the kernel timer on, ONE HIP-event pair brackets
-    // all level launches of the call (gaps between levels included — they are part of what the path costs).
-    const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (in->timing) {
-        if (in->eventsUsed == in->events.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-            in->events.emplace_back(a, b);
-        }
-        e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
-    }
-    int launches = 0;
-    for (int chunkBegin = 0; chunkBegin < launchCount;) {
-        const int chunkEnd = (int)std::min<size_t>((size_t)launchCount, (size_t)chunkBegin + maxChunkOps);
-        void* dChunk = nullptr;
-        int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
-        if (rc) return rc;
-        if (e0 && chunkBegin == 0) HIP_TRY(hipEventRecord(e0, in->stream));
-        for (int l = 0; l <= maxLevel; l++) {
-            const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
-            if (begin >= end) continue;
-            int maxRange = 0;
-            bool anyWrite = false;
-            for (int k = begin; k < end; k++) {
-                maxRange = std::max(maxRange, sorted[k].pEnd - sorted[k].pStart);
-                anyWrite = anyWrite || sorted[k].scaleWrite != nullptr;
-            }
-            if (in->tiled)
-                mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                             in->P, in->S, in->C, anyWrite, dCherries);
-            else
-                mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                        in->P, in->S, in->C, maxRange);
-            launches++;
-        }
-        chunkBegin = chunkEnd;
-    }
-    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
-    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
-    HIP_TRY(hipGetLastError());
-    return foldCumulative(in, ops, count, tuple, globalCum);
-}
-
-// cumulative scale factors requested together with an update: fold the factors the list wrote into the cumulative
-// buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
-int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum) {
-    for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * tuple;
-        const int wS = op[1];
-        int part = 0, cum = globalCum;
-        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
-        if (cum == BEAGLE_OP_NONE || wS == BEAGLE_OP_NONE) continue;
-        int rc = materializeScaleUsers(in, cum); if (rc) return rc;
-        rc = ensureScale(in, cum); if (rc) return rc;
-        const double* src = in->scale[wS];
-        int one = 1;
-        void *dSrc = nullptr, *dRaw = nullptr;
-        rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
-        rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
-        mi355::launchAccumulateScale(in->stream, in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0,
-                                     in->partStart[part], in->partEnd[part]);
-    }
-    return 0;
-}
-
-int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
-    return in->walk ? runOperationsWalk(in, ops, count, tuple, globalCum) : runOperationsLevels(in, ops, count, tuple, globalCum);
-}
-
-// One dependency level of pre-order ops on the T32 layout, expressed with the tuned pruning kernel:
-//   pass A   tmp        = (I . pre(parent)) * (P_sib . post(sib))         a pruning op whose first branch matrix is the identity
-//   pass B   pre(child) = (P_child^T . tmp) * 1                            a pruning op whose second child is an all-missing tip
-// (products with the identity's 0/1 entries and the sums of the resulting zeros are exact, so pass A adds no rounding).
-// PRE_SCRATCH ops at a time: their tmp buffers and transposed matrices are reused by the next chunk in stream order.
-int ensurePreScratch(Instance* in) {
-    if (!in->preScratch.empty()) return 0;
-    void* slab = nullptr;
-    int rc = devAlloc(in, &slab, in->partialsBytes * PRE_SCRATCH); if (rc) return rc;
-    void* miss = nullptr;
-    rc = devAlloc(in, &miss, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
-    in->preMissing = (uint8_t*)miss;
-    HIP_TRY(hipMemsetAsync(in->preMissing, in->S, (size_t)in->P, in->stream));
-    in->preScratch.assign(PRE_SCRATCH, nullptr);
-    for (int j = 0; j < PRE_SCRATCH; j++) in->preScratch[j] = (double*)((char*)slab + in->partialsBytes * j);
-    return 0;
-}
-
-int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
-    { int rc0 = ensurePreScratch(in); if (rc0) return rc0; }
-    std::vector<OpDesc> pass(2 * PRE_SCRATCH);
-    std::vector<int> pairs(2 * PRE_SCRATCH);
-    for (int b = 0; b < nOps; b += PRE_SCRATCH) {
-        const int n = std::min(PRE_SCRATCH, nOps - b);
-        bool anyWrite = false;
-        for (int j = 0; j < n; j++) {
-            const OpDesc& o = ops[b + j];
-            pairs[2 * j] = o.mat1; pairs[2 * j + 1] = in->preTransposed + j;
-            OpDesc& a = pass[j];
-            memset(&a, 0, sizeof(a));
-            a.dest = in->preScratch[j];
-            a.child1 = o.child1; a.mat1 = in->preIdentity;
-            a.child2 = o.child2; a.mat2 = o.mat2; a.kind = o.kind & mi355::KIND_STATES2;
-            a.pStart = 0; a.pEnd = in->P;
-            OpDesc& c = pass[n + j];
-            memset(&c, 0, sizeof(c));
-            c.dest = o.dest;
-            c.child1 = in->preScratch[j]; c.mat1 = in->preTransposed + j;
-            c.child2 = in->preMissing; c.mat2 = in->preIdentity; c.kind = mi355::KIND_STATES2;
-            c.scaleWrite = o.scaleWrite; c.scaleRead = o.scaleRead;
-            c.pStart = 0; c.pEnd = in->P;
-            anyWrite = anyWrite || o.scaleWrite != nullptr;
-        }
-        void *dPairs = nullptr, *dPass = nullptr;
-        int rc = uploadTransient(in, pairs.data(), (size_t)2 * n * sizeof(int), &dPairs); if (rc) return rc;
-        rc = uploadTransient(in, pass.data(), (size_t)2 * n * sizeof(OpDesc), &dPass); if (rc) return rc;
-        mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, n, in->S, in->C);
-        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
-        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass + n, n, in->matrices, in->P, in->S, in->C, anyWrite);
-    }
-    return 0;
-}
-
-// Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
-// matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
-// levelised like a post-order one and each level is one launch.
-int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
-    if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
-    const int n = in->partialsCount;
-    // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
-    std::vector<int> need;
-    for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
-        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
-        if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
-            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
-            (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
-            return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, sib)) need.push_back(sib);
-        if (isVirt(in, par)) need.push_back(par);
-        if (in->virt) {
-            need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
-            if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
-        }
-    }
-    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-    std::vector<OpDesc> descs(count);
-    std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
-    int maxLevel = 0;
-    for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
-        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
-        OpDesc& d = descs[k];
-        memset(&d, 0, sizeof(d));
-        clearVirtual(in, dest);
-        int rc = ensurePartials(in, dest); if (rc) return rc;
-        in->tipStates[dest] = nullptr; setCompact(in, dest, false);
-        if (!in->partials[par] || (in->tipStates[par] && par < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        d.dest = in->partials[dest];
-        d.child1 = in->partials[par];
-        if (in->tipStates[sib] && sib < in->tipCount) { d.child2 = in->tipStates[sib]; d.kind = mi355::KIND_STATES2; }
-        else if (in->partials[sib]) d.child2 = in->partials[sib];
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        d.mat1 = mc; d.mat2 = ms;
-        if (wS != BEAGLE_OP_NONE) {
-            rc = ensureScale(in, wS); if (rc) return rc;
-            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
-        } else if (rS != BEAGLE_OP_NONE) {
-            rc = ensureScale(in, rS); if (rc) return rc;
-            if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;
-            d.scaleRead = in->scale[rS];
-        }
-        d.pStart = 0; d.pEnd = in->P;
-        const int lvl = std::max(std::max(wLevel[par], wLevel[sib]), std::max(wLevel[dest], rLevel[dest])) + 1;
-        level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
-        wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
-    }
-    std::vector<int> start(maxLevel + 2, 0);
-    for (int k = 0; k < count; k++) start[level[k] + 1]++;
-    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
-    std::vector<OpDesc> sorted(count);
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
-    const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
-    // T32 layout (16..64 states): two passes of the MFMA pruning kernel per op instead of the VALU pre-order kernel
-    // (BEAGLE_MI355_PRE_NAIVE=1 keeps the latter, for A/B runs)
-    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
-    const bool twoPass = in->tiled && !preNaive;
-    for (int chunkBegin = 0; chunkBegin < count;) {
-        const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
-        void* dChunk = nullptr;
-        int rc = twoPass ? 0 : uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
-        if (rc) return rc;
-        for (int l = 0; l <= maxLevel; l++) {
-            const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
-            if (begin >= end) continue;
-            if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
-            mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                     in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
-        }
-        chunkBegin = chunkEnd;
-    }
-    HIP_TRY(hipGetLastError());
-    if (globalCum != BEAGLE_OP_NONE)
-        for (int k = 0; k < count; k++) {
-            if (opWrite[k] == BEAGLE_OP_NONE) continue;
-            int rc = ensureScale(in, globalCum); if (rc) return rc;
-            const double* src = in->scale[opWrite[k]];
-            int one = 1;
-            void *dSrc = nullptr, *dRaw = nullptr;
-            rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
-            rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
-            mi355::launchAccumulateScale(in->stream, in->scale[globalCum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, 0, in->P);
-        }
-    return 0;
-}
-
-// Per-edge derivative sums (AbstractBeagleBranchGradientDelegate.java:82-92).  Edges are processed in chunks that bound
-// the scratch memory (block sums, and the optional per-pattern matrix) to a few hundred MB.
-int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
-                      double* outDerivatives, double* outSum, double* outSumSquared) {
-    if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
-    std::vector<int> need;
-    for (int e = 0; e < count; e++) {
-        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
-            return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
-        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
-    }
-    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-    const int nb = mi355::edgeBlocks(in->P);
-    const size_t perEdgeBytes = (size_t)nb * 2 * sizeof(double) + 2 * sizeof(double) + (outDerivatives ? (size_t)in->P * sizeof(double) : 0);
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / perEdgeBytes));
-    chunk = std::min(chunk, 32768);
-    double *dBlock = nullptr, *dSums = nullptr, *dPer = nullptr;
-    HIP_TRY(hipMalloc((void**)&dBlock, (size_t)chunk * nb * 2 * sizeof(double)));
-    hipError_t e1 = hipMalloc((void**)&dSums, (size_t)chunk * 2 * sizeof(double));
-    hipError_t e2 = outDerivatives ? hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) : hipSuccess;
-    int rc = (e1 != hipSuccess || e2 != hipSuccess) ? BEAGLE_ERROR_OUT_OF_MEMORY : 0;
-    std::vector<mi355::EdgeDesc> descs;
-    std::vector<double> sums;
-    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
-    const bool twoStep = in->tiled && !preNaive;
-    if (twoStep && !rc) rc = ensurePreScratch(in);
-    for (int b = 0; b < count && !rc; b += chunk) {
-        const int m = std::min(chunk, count - b);
-        descs.assign(m, mi355::EdgeDesc());
-        for (int e = 0; e < m && !rc; e++) {
-            const int po = postIdx[b + e], pr = preIdx[b + e];
-            mi355::EdgeDesc& d = descs[e];
-            if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
-            else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
-            else rc = BEAGLE_ERROR_OUT_OF_RANGE;
-            if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) rc = BEAGLE_ERROR_OUT_OF_RANGE;
-            d.pre = in->partials[pr];
-            d.dmat = dIdx[b + e];
-        }
-        if (rc) break;
-        // 16..64 states: an edge below an internal node takes the O(S^2) part through one pass of the MFMA pruning kernel
-        // (tmp = (I . pre) * (D . post)) and a streaming reduction; tip edges (O(S) per pattern) and every other state
-        // count use the direct kernel.  Output rows are addressed by EdgeDesc::slot, so the two groups can interleave.
-        std::vector<mi355::EdgeDesc> direct, viaPrune;
-        for (int e = 0; e < m; e++) {
-            descs[e].slot = e;
-            (twoStep && !descs[e].postIsStates ? viaPrune : direct).push_back(descs[e]);
-        }
-        if (!direct.empty()) {
-            void* dDesc = nullptr;
-            rc = uploadTransient(in, direct.data(), direct.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-            mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
-                                           in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
-        }
-        for (size_t q = 0; q < viaPrune.size() && !rc; q += PRE_SCRATCH) {
-            const int n = (int)std::min<size_t>(PRE_SCRATCH, viaPrune.size() - q);
-            std::vector<OpDesc> pass(n);
-            for (int j = 0; j < n; j++) {
-                mi355::EdgeDesc& ed = viaPrune[q + j];
-                OpDesc& a = pass[j];
-                memset(&a, 0, sizeof(a));
-                a.dest = in->preScratch[j];
-                a.child1 = ed.pre; a.mat1 = in->preIdentity;
-                a.child2 = ed.post; a.mat2 = ed.dmat;
-                a.pStart = 0; a.pEnd = in->P;
-                ed.tmp = in->preScratch[j];
-            }
-            void *dPass = nullptr, *dDesc = nullptr;
-            rc = uploadTransient(in, pass.data(), (size_t)n * sizeof(OpDesc), &dPass); if (rc) break;
-            rc = uploadTransient(in, &viaPrune[q], (size_t)n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-            mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
-            mi355::launchEdgeReduce(in->stream, (const mi355::EdgeDesc*)dDesc, n, in->weights + (size_t)wIdx * in->C, in->patternWeights,
-                                    dPer, dBlock, in->P, in->S, in->C, in->tiled);
-        }
-        if (rc) break;
-        mi355::launchEdgeFinal(in->stream, dBlock, m, in->P, dSums);
-        sums.resize((size_t)m * 2);
-        rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) break;
-        for (int e = 0; e < m; e++) {
-            if (outSum) outSum[b + e] = sums[2 * e];
-            if (outSumSquared) outSumSquared[b + e] = sums[2 * e + 1];
-        }
-        if (outDerivatives) rc = download(in, outDerivatives + (size_t)b * in->P, dPer, (size_t)m * in->P * sizeof(double));
-    }
-    hipStreamSynchronize(in->stream);
-    hipFree(dBlock); hipFree(dSums); if (dPer) hipFree(dPer);
-    return rc;
-}
-
-// calculateCrossProductDifferentials (semantics: include/beagle_mi355.h)
-int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum) {
-    if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
-    std::vector<int> need;
-    for (int e = 0; e < count; e++) {
-        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
-        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
-    }
-    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
-    std::vector<mi355::EdgeDesc> descs(count);
-    for (int e = 0; e < count; e++) {
-        const int po = postIdx[e], pr = preIdx[e];
-        mi355::EdgeDesc& d = descs[e];
-        if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
-        else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
-        else return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        d.pre = in->partials[pr];
-    }
-    const size_t nOut = (size_t)in->S * in->S;
-    const int nb = mi355::edgeBlocks(in->P);
-    double *dPartial = nullptr, *dOut = nullptr;
-    HIP_TRY(hipMalloc((void**)&dPartial, (size_t)nb * nOut * sizeof(double)));
-    if (hipMalloc((void**)&dOut, nOut * sizeof(double)) != hipSuccess) { hipFree(dPartial); return BEAGLE_ERROR_OUT_OF_MEMORY; }
-    std::vector<double> sums(nOut);
-    int rc = 0;
-    const size_t maxChunk = (RING_BYTES / 8) / sizeof(mi355::EdgeDesc);
-    for (size_t b = 0; b < (size_t)count && !rc; b += maxChunk) {
-        const size_t n = std::min(maxChunk, (size_t)count - b);
-        void *dDesc = nullptr, *dLen = nullptr;
-        rc = uploadTransient(in, &descs[b], n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-        rc = uploadTransient(in, lengths + b, n * sizeof(double), &dLen); if (rc) break;
-        mi355::launchCrossProducts(in->stream, (const mi355::EdgeDesc*)dDesc, (int)n, (const double*)dLen, in->weights + (size_t)wIdx * in->C,
-                                   in->rates + (size_t)rateIdx * in->C, in->patternWeights, dPartial, dOut, in->P, in->S, in->C, in->tiled);
-        rc = download(in, sums.data(), dOut, nOut * sizeof(double)); if (rc) break;
-        for (size_t k = 0; k < nOut; k++) outSum[k] += sums[k];
-    }
-    hipStreamSynchronize(in->stream);
-    hipFree(dPartial); hipFree(dOut);
-    return rc;
-}
 
 int accumulate(Instance* in, const int* idx, int count, int cum, double sign, int part) {
     if (badIndex(cum, in->scaleCount) || badIndex(part, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1285,7 +78,9 @@ void toTiled(const Instance* in, const double* api, double* tiled, int categorie
         }
 }
 
+
 }  // namespace
+
 
 // per-partition root sums of ONE (single-GPU) instance left on the device: deviceOut[k], k < partitionCount
 static int rootByPartitionDevice(int instance, const int* bufferIndices, const int* categoryWeightsIndices, const int* stateFrequenciesIndices,

@@ -1,0 +1,193 @@
+// engine_internal.h — what the engine's translation units share: the instance record and its staging / allocation helpers
+// (engine_instance.cpp), the 4-state walk runner (engine_walk.cpp), the level scheduler for every other state count
+// (engine_levels.cpp), the pre-order / gradient paths (engine_preorder.cpp); the C ABI itself is engine_abi.cpp.
+// All arithmetic is in the .hip files; these files validate indices, resolve buffer indices to device pointers and enqueue
+// kernels on the instance's HIP stream.  Results are only observed at calculateRootLogLikelihoods / get*, so every other
+// call returns as soon as its work is enqueued (SURVEY 8b "Threading").
+//
+// There is no CPU path in this library: with no visible MI355X beagleCreateInstance returns BEAGLE_ERROR_NO_RESOURCE.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include <chrono>
+#include <atomic>
+#include "../../include/beagle_mi355.h"
+#include "kernels.h"
+#include "planner.h"
+#include "sharded.h"
+
+namespace mi355 {
+namespace eng {
+
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            if (getenv("BEAGLE_MI355_DEBUG"))                                                 \
+                fprintf(stderr, "[beagle-mi355] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return e__ == hipErrorOutOfMemory ? BEAGLE_ERROR_OUT_OF_MEMORY : BEAGLE_ERROR_GENERAL; \
+        }                                                                                     \
+    } while (0)
+
+constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
+constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
+constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
+
+struct Instance {
+    int device = 0;
+    // 4 states: every operation list runs as ONE launch of the pattern-walk kernel (kernels_walk4.hip), programmed by the
+    // walk planner (planner.h), which also owns the definitions of virtual buffers
+    bool walk = false;
+    mi355::WalkPlanner planner;
+    mi355::Plan plan;                                    // scratch of the current call
+    std::vector<mi355::WalkOp> walkOps;                  // scratch: resolved program
+    size_t scaleStride = 0;                              // walk instances: a scale buffer is [factors | reciprocals (pair-interleaved,
+                                                         // kernels.h walkPairIndex)], this many doubles apart
+    size_t statePairOff = 0;                             // walk instances: a tip's pair-interleaved states follow its plain ones, this many bytes on
+    // walk instances: position of pattern p in the pair-interleaved arrays (tip states, reciprocal scale factors).  They are
+    // laid out partition by partition, each padded to whole blocks of 128 patterns (kernels.h WalkSeg), so that the assembly
+    // loop runs whatever the caller's partition boundaries are; one partition: walkPairIndex(p).
+    std::vector<unsigned> pairPos; size_t pairLen = 0; std::vector<int> padStart; unsigned* dPairPos = nullptr;
+    char* matStream = nullptr; size_t matStreamBytes = 0;   // walk instances: the matrix stream of the program being run (k_gatherMatrices)
+    uint8_t* dummyTips = nullptr; double* onesScale = nullptr;   // walk instances: all-missing states / all-one factors for the operands a
+                                                                 // micro-operation does not use (the assembly loop loads them unconditionally)
+    long statFastWalks = 0;
+    // what runPlan derived from a cached plan (planner.h plannedTag): the device program with its addresses resolved
+    struct Resolved {
+        long tag = 0, epoch = -1;
+        std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
+        int maxRange = 0;
+        long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
+        char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
+    } resolved[4];
+    long resolveEpoch = 0;                               // bumped when pattern ranges change
+    bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
+    bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
+    bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
+                                                         // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)
+    bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
+    bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
+    long statCherries = 0;
+    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
+    char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
+    // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
+    double* exportDev[2] = {nullptr, nullptr}; double* exportHost[2] = {nullptr, nullptr}; size_t exportBytes = 0;   // two chunks in flight
+    hipEvent_t exportEvent[2] = {nullptr, nullptr};
+    long statMicroOps = 0, statStored = 0, statMemReads = 0, statTipReads = 0, statScaleReads = 0, statWalks = 0, statScaleWrites = 0;   // since the last timer reset
+    hipStream_t stream = nullptr, ownStream = nullptr;
+    int tipCount = 0, partialsCount = 0, compactCount = 0, S = 0, P = 0, eigenCount = 0, matrixCount = 0, C = 0, scaleCount = 0;
+    size_t partialsBytes = 0;
+    std::vector<double*> partials;
+    std::vector<uint8_t*> tipStates;
+    std::vector<void*> allocations;
+    char* slabCur = nullptr; int slabLeft = 0;
+    char* scaleSlabCur = nullptr; int scaleSlabLeft = 0;
+    char* stateSlabCur = nullptr; int stateSlabLeft = 0;
+    double* matrices = nullptr; double* eigen = nullptr; double* rates = nullptr; double* weights = nullptr;
+    double* freqs = nullptr; double* patternWeights = nullptr; double* siteLogL = nullptr;
+    std::vector<double*> scale; std::vector<char> scaleIsRaw;
+    double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr; double* hResultDev = nullptr; unsigned long long resultSeq = 0;
+    char* hRing = nullptr; char* dRing = nullptr; size_t ringHead = 0;
+    int partitionCount = 1;
+    std::vector<int> partStart, partEnd;
+    // levelisation scratch
+    std::vector<int> wStamp, wLevel, rStamp, rLevel, wOp; int stamp = 0;
+    bool tiled = false; int ntile = 0;   // T32 partials layout (MFMA path)
+    // pre-order on the T32 layout runs as two passes of the pruning kernel (see runPreOperations): scratch partials
+    // buffers, an identity matrix and transposed-matrix slots behind the caller's matrices, an all-missing tip
+    std::vector<double*> preScratch; uint8_t* preMissing = nullptr; int preIdentity = -1, preTransposed = -1;
+    bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
+    // kernel timer
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
+    double timedMs = 0.0; long timedLaunches = 0, pendingLaunches = 0;
+    size_t deviceBytes = 0;
+    std::vector<double> shEigen, shFreqs, shWeights, shRates;      // host shadows of the small model arrays ...
+    std::vector<char> okEigen, okFreqs, okWeights, okRates;         // ... valid flags per index
+    std::string resourceName;
+};
+
+extern std::mutex g_mutex;
+extern std::vector<Instance*> g_instances;
+Instance* lookup(int h);
+
+// ---- engine_instance.cpp: memory, staging, resources
+int devAlloc(Instance* in, void** p, size_t bytes);
+long stage(Instance* in, const void* src, size_t bytes, size_t reserve = 0);
+int upload(Instance* in, void* dst, const void* src, size_t bytes);
+int uploadTransient(Instance* in, const void* src, size_t bytes, void** dptr);
+int download(Instance* in, void* dst, const void* src, size_t bytes);
+int ensurePartials(Instance* in, int idx);
+int ensureScale(Instance* in, int idx);
+int ensureStates(Instance* in, int idx);
+void destroy(Instance* in);
+struct Resources {
+    std::vector<std::string> names, descs;
+    std::vector<BeagleResource> list;
+    BeagleResourceList rl;
+    int gpuCount = 0;
+};
+extern const long GPU_FLAGS;
+Resources* resources();
+void setPairLayout(Instance* in);
+int ensureWalkDummies(Instance* in);
+
+#define GET_INSTANCE(h)                                          \
+    Instance* in = lookup(h);                                    \
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;         \
+    if (hipSetDevice(in->device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+
+inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
+
+// ---- the pattern walk (4 states) ------------------------------------------------------------------------------------
+// A partials buffer is "virtual" when its content is DEFINED instead of stored (planner.h VirtDef): a few steps over
+// compact tips, private snapshots of every branch matrix in the subtree (kept behind the caller's matrices) and each
+// node's scale buffer.  Nothing is written to HBM for such a buffer; the walk recomputes it in registers where a parent
+// needs it, bitwise as the ordinary operation would have.  The definition is self-contained: it never refers to other
+// partials buffers or to the caller's matrix buffers, so buffer flips and matrix updates cannot invalidate it.  What CAN
+// change a defining input — new tip states, a write to one of its scale buffers — and everything that needs the real
+// data — getPartials, use as root, the pre-order kernels — first calls materializeList, which runs the definition with
+// a store.
+static_assert(mi355::PK_MEM == mi355::WK_MEM && mi355::PK_TIPS == mi355::WK_TIPS && mi355::PK_ACC == mi355::WK_ACC &&
+              mi355::PK_H0 == mi355::WK_H0 && mi355::PK_H1 == mi355::WK_H1 && mi355::PK_H2 == mi355::WK_H2, "planner kinds = kernel kinds");
+static_assert(mi355::PS_NONE == mi355::WS_NONE && mi355::PS_READ == mi355::WS_READ && mi355::PS_WRITE == mi355::WS_WRITE, "scale modes");
+
+inline bool isVirt(const Instance* in, int X) { return in->virt && in->planner.isVirtual(X); }
+inline void clearVirtual(Instance* in, int X) { if (in->virt) in->planner.clearVirtual(X); }
+inline bool isCompactTip(const Instance* in, int X) { return in->tipStates[X] && X < in->tipCount; }
+// what buffer X holds changed: compact tip states (on), or something else — in which case it is no uploaded-partials leaf
+// either until setLeaf says so (planner.h leafPartials)
+inline void setCompact(Instance* in, int X, bool on) { in->planner.setCompactTip(X, on); in->planner.setLeafPartials(X, false); }
+inline void setLeaf(Instance* in, int X) { if (X < in->tipCount) in->planner.setLeafPartials(X, true); }
+
+// ---- engine_walk.cpp
+int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t recordBeforeWalk = nullptr);
+int materializeList(Instance* in, const std::vector<int>& xs);
+int materializeVirtual(Instance* in, int X);
+int materializeScaleUsers(Instance* in, int scaleIdx);
+int materializeTipUsers(Instance* in, int tip);
+int walkChunkOps(const Instance* in, int opCount);
+int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum);
+// ---- engine_levels.cpp
+int materializeCherries(Instance* in, const std::vector<int>& xs);
+int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int globalCum);
+int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum);
+int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum);
+// ---- engine_preorder.cpp
+int ensurePreScratch(Instance* in);
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum);
+int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
+                      double* outDerivatives, double* outSum, double* outSumSquared);
+int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum);
+
+}  // namespace eng
+}  // namespace mi355

@@ -1,0 +1,295 @@
+// engine_preorder.cpp — pre-order partials and the gradient sums built on them (kernels_preorder.hip).
+// See engine_internal.h.
+#include "engine_internal.h"
+
+using mi355::OpDesc;
+
+namespace mi355 {
+namespace eng {
+
+// One dependency level of pre-order ops on the T32 layout, expressed with the tuned pruning kernel:
+//   pass A   tmp        = (I . pre(parent)) * (P_sib . post(sib))         a pruning op whose first branch matrix is the identity
+//   pass B   pre(child) = (P_child^T . tmp) * 1                            a pruning op whose second child is an all-missing tip
+// (products with the identity's 0/1 entries and the sums of the resulting zeros are exact, so pass A adds no rounding).
+// PRE_SCRATCH ops at a time: their tmp buffers and transposed matrices are reused by the next chunk in stream order.
+int ensurePreScratch(Instance* in) {
+    if (!in->preScratch.empty()) return 0;
+    void* slab = nullptr;
+    int rc = devAlloc(in, &slab, in->partialsBytes * PRE_SCRATCH); if (rc) return rc;
+    void* miss = nullptr;
+    rc = devAlloc(in, &miss, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
+    in->preMissing = (uint8_t*)miss;
+    HIP_TRY(hipMemsetAsync(in->preMissing, in->S, (size_t)in->P, in->stream));
+    in->preScratch.assign(PRE_SCRATCH, nullptr);
+    for (int j = 0; j < PRE_SCRATCH; j++) in->preScratch[j] = (double*)((char*)slab + in->partialsBytes * j);
+    return 0;
+}
+
+int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
+    { int rc0 = ensurePreScratch(in); if (rc0) return rc0; }
+    std::vector<OpDesc> pass(2 * PRE_SCRATCH);
+    std::vector<int> pairs(2 * PRE_SCRATCH);
+    for (int b = 0; b < nOps; b += PRE_SCRATCH) {
+        const int n = std::min(PRE_SCRATCH, nOps - b);
+        bool anyWrite = false;
+        for (int j = 0; j < n; j++) {
+            const OpDesc& o = ops[b + j];
+            pairs[2 * j] = o.mat1; pairs[2 * j + 1] = in->preTransposed + j;
+            OpDesc& a = pass[j];
+            memset(&a, 0, sizeof(a));
+            a.dest = in->preScratch[j];
+            a.child1 = o.child1; a.mat1 = in->preIdentity;
+            a.child2 = o.child2; a.mat2 = o.mat2; a.kind = o.kind & mi355::KIND_STATES2;
+            a.pStart = 0; a.pEnd = in->P;
+            OpDesc& c = pass[n + j];
+            memset(&c, 0, sizeof(c));
+            c.dest = o.dest;
+            c.child1 = in->preScratch[j]; c.mat1 = in->preTransposed + j;
+            c.child2 = in->preMissing; c.mat2 = in->preIdentity; c.kind = mi355::KIND_STATES2;
+            c.scaleWrite = o.scaleWrite; c.scaleRead = o.scaleRead;
+            c.pStart = 0; c.pEnd = in->P;
+            anyWrite = anyWrite || o.scaleWrite != nullptr;
+        }
+        void *dPairs = nullptr, *dPass = nullptr;
+        int rc = uploadTransient(in, pairs.data(), (size_t)2 * n * sizeof(int), &dPairs); if (rc) return rc;
+        rc = uploadTransient(in, pass.data(), (size_t)2 * n * sizeof(OpDesc), &dPass); if (rc) return rc;
+        mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, n, in->S, in->C);
+        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass + n, n, in->matrices, in->P, in->S, in->C, anyWrite);
+    }
+    return 0;
+}
+
+// Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
+// matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
+// levelised like a post-order one and each level is one launch.
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    const int n = in->partialsCount;
+    // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
+    std::vector<int> need;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
+            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+            (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (isVirt(in, sib)) need.push_back(sib);
+        if (isVirt(in, par)) need.push_back(par);
+        if (in->virt) {
+            need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
+            if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
+        }
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    std::vector<OpDesc> descs(count);
+    std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
+    int maxLevel = 0;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        OpDesc& d = descs[k];
+        memset(&d, 0, sizeof(d));
+        clearVirtual(in, dest);
+        int rc = ensurePartials(in, dest); if (rc) return rc;
+        in->tipStates[dest] = nullptr; setCompact(in, dest, false);
+        if (!in->partials[par] || (in->tipStates[par] && par < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.dest = in->partials[dest];
+        d.child1 = in->partials[par];
+        if (in->tipStates[sib] && sib < in->tipCount) { d.child2 = in->tipStates[sib]; d.kind = mi355::KIND_STATES2; }
+        else if (in->partials[sib]) d.child2 = in->partials[sib];
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.mat1 = mc; d.mat2 = ms;
+        if (wS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, wS); if (rc) return rc;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
+        } else if (rS != BEAGLE_OP_NONE) {
+            rc = ensureScale(in, rS); if (rc) return rc;
+            if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;
+            d.scaleRead = in->scale[rS];
+        }
+        d.pStart = 0; d.pEnd = in->P;
+        const int lvl = std::max(std::max(wLevel[par], wLevel[sib]), std::max(wLevel[dest], rLevel[dest])) + 1;
+        level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
+        wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
+    }
+    std::vector<int> start(maxLevel + 2, 0);
+    for (int k = 0; k < count; k++) start[level[k] + 1]++;
+    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
+    std::vector<OpDesc> sorted(count);
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int k = 0; k < count; k++) sorted[fill[level[k]]++] = descs[k];
+    const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
+    // T32 layout (16..64 states): two passes of the MFMA pruning kernel per op instead of the VALU pre-order kernel
+    // (BEAGLE_MI355_PRE_NAIVE=1 keeps the latter, for A/B runs)
+    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    const bool twoPass = in->tiled && !preNaive;
+    for (int chunkBegin = 0; chunkBegin < count;) {
+        const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
+        void* dChunk = nullptr;
+        int rc = twoPass ? 0 : uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
+        if (rc) return rc;
+        for (int l = 0; l <= maxLevel; l++) {
+            const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
+            if (begin >= end) continue;
+            if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
+            mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                                     in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
+        }
+        chunkBegin = chunkEnd;
+    }
+    HIP_TRY(hipGetLastError());
+    if (globalCum != BEAGLE_OP_NONE)
+        for (int k = 0; k < count; k++) {
+            if (opWrite[k] == BEAGLE_OP_NONE) continue;
+            int rc = ensureScale(in, globalCum); if (rc) return rc;
+            const double* src = in->scale[opWrite[k]];
+            int one = 1;
+            void *dSrc = nullptr, *dRaw = nullptr;
+            rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
+            rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
+            mi355::launchAccumulateScale(in->stream, in->scale[globalCum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, 0, in->P);
+        }
+    return 0;
+}
+
+// Per-edge derivative sums (AbstractBeagleBranchGradientDelegate.java:82-92).  Edges are processed in chunks that bound
+// the scratch memory (block sums, and the optional per-pattern matrix) to a few hundred MB.
+int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
+                      double* outDerivatives, double* outSum, double* outSumSquared) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    std::vector<int> need;
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
+        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    const int nb = mi355::edgeBlocks(in->P);
+    const size_t perEdgeBytes = (size_t)nb * 2 * sizeof(double) + 2 * sizeof(double) + (outDerivatives ? (size_t)in->P * sizeof(double) : 0);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / perEdgeBytes));
+    chunk = std::min(chunk, 32768);
+    double *dBlock = nullptr, *dSums = nullptr, *dPer = nullptr;
+    HIP_TRY(hipMalloc((void**)&dBlock, (size_t)chunk * nb * 2 * sizeof(double)));
+    hipError_t e1 = hipMalloc((void**)&dSums, (size_t)chunk * 2 * sizeof(double));
+    hipError_t e2 = outDerivatives ? hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) : hipSuccess;
+    int rc = (e1 != hipSuccess || e2 != hipSuccess) ? BEAGLE_ERROR_OUT_OF_MEMORY : 0;
+    std::vector<mi355::EdgeDesc> descs;
+    std::vector<double> sums;
+    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    const bool twoStep = in->tiled && !preNaive;
+    if (twoStep && !rc) rc = ensurePreScratch(in);
+    for (int b = 0; b < count && !rc; b += chunk) {
+        const int m = std::min(chunk, count - b);
+        descs.assign(m, mi355::EdgeDesc());
+        for (int e = 0; e < m && !rc; e++) {
+            const int po = postIdx[b + e], pr = preIdx[b + e];
+            mi355::EdgeDesc& d = descs[e];
+            if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
+            else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
+            else rc = BEAGLE_ERROR_OUT_OF_RANGE;
+            if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) rc = BEAGLE_ERROR_OUT_OF_RANGE;
+            d.pre = in->partials[pr];
+            d.dmat = dIdx[b + e];
+        }
+        if (rc) break;
+        // 16..64 states: an edge below an internal node takes the O(S^2) part through one pass of the MFMA pruning kernel
+        // (tmp = (I . pre) * (D . post)) and a streaming reduction; tip edges (O(S) per pattern) and every other state
+        // count use the direct kernel.  Output rows are addressed by EdgeDesc::slot, so the two groups can interleave.
+        std::vector<mi355::EdgeDesc> direct, viaPrune;
+        for (int e = 0; e < m; e++) {
+            descs[e].slot = e;
+            (twoStep && !descs[e].postIsStates ? viaPrune : direct).push_back(descs[e]);
+        }
+        if (!direct.empty()) {
+            void* dDesc = nullptr;
+            rc = uploadTransient(in, direct.data(), direct.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+            mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                                           in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
+        }
+        for (size_t q = 0; q < viaPrune.size() && !rc; q += PRE_SCRATCH) {
+            const int n = (int)std::min<size_t>(PRE_SCRATCH, viaPrune.size() - q);
+            std::vector<OpDesc> pass(n);
+            for (int j = 0; j < n; j++) {
+                mi355::EdgeDesc& ed = viaPrune[q + j];
+                OpDesc& a = pass[j];
+                memset(&a, 0, sizeof(a));
+                a.dest = in->preScratch[j];
+                a.child1 = ed.pre; a.mat1 = in->preIdentity;
+                a.child2 = ed.post; a.mat2 = ed.dmat;
+                a.pStart = 0; a.pEnd = in->P;
+                ed.tmp = in->preScratch[j];
+            }
+            void *dPass = nullptr, *dDesc = nullptr;
+            rc = uploadTransient(in, pass.data(), (size_t)n * sizeof(OpDesc), &dPass); if (rc) break;
+            rc = uploadTransient(in, &viaPrune[q], (size_t)n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+            mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+            mi355::launchEdgeReduce(in->stream, (const mi355::EdgeDesc*)dDesc, n, in->weights + (size_t)wIdx * in->C, in->patternWeights,
+                                    dPer, dBlock, in->P, in->S, in->C, in->tiled);
+        }
+        if (rc) break;
+        mi355::launchEdgeFinal(in->stream, dBlock, m, in->P, dSums);
+        sums.resize((size_t)m * 2);
+        rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) break;
+        for (int e = 0; e < m; e++) {
+            if (outSum) outSum[b + e] = sums[2 * e];
+            if (outSumSquared) outSumSquared[b + e] = sums[2 * e + 1];
+        }
+        if (outDerivatives) rc = download(in, outDerivatives + (size_t)b * in->P, dPer, (size_t)m * in->P * sizeof(double));
+    }
+    hipStreamSynchronize(in->stream);
+    hipFree(dBlock); hipFree(dSums); if (dPer) hipFree(dPer);
+    return rc;
+}
+
+// calculateCrossProductDifferentials (semantics: include/beagle_mi355.h)
+int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum) {
+    if (count <= 0) return 0;
+    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    std::vector<int> need;
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
+        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
+    }
+    if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    std::vector<mi355::EdgeDesc> descs(count);
+    for (int e = 0; e < count; e++) {
+        const int po = postIdx[e], pr = preIdx[e];
+        mi355::EdgeDesc& d = descs[e];
+        if (in->tipStates[po] && po < in->tipCount) { d.post = in->tipStates[po]; d.postIsStates = 1; }
+        else if (in->partials[po]) { d.post = in->partials[po]; d.postIsStates = 0; }
+        else return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (!in->partials[pr] || (in->tipStates[pr] && pr < in->tipCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        d.pre = in->partials[pr];
+    }
+    const size_t nOut = (size_t)in->S * in->S;
+    const int nb = mi355::edgeBlocks(in->P);
+    double *dPartial = nullptr, *dOut = nullptr;
+    HIP_TRY(hipMalloc((void**)&dPartial, (size_t)nb * nOut * sizeof(double)));
+    if (hipMalloc((void**)&dOut, nOut * sizeof(double)) != hipSuccess) { hipFree(dPartial); return BEAGLE_ERROR_OUT_OF_MEMORY; }
+    std::vector<double> sums(nOut);
+    int rc = 0;
+    const size_t maxChunk = (RING_BYTES / 8) / sizeof(mi355::EdgeDesc);
+    for (size_t b = 0; b < (size_t)count && !rc; b += maxChunk) {
+        const size_t n = std::min(maxChunk, (size_t)count - b);
+        void *dDesc = nullptr, *dLen = nullptr;
+        rc = uploadTransient(in, &descs[b], n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+        rc = uploadTransient(in, lengths + b, n * sizeof(double), &dLen); if (rc) break;
+        mi355::launchCrossProducts(in->stream, (const mi355::EdgeDesc*)dDesc, (int)n, (const double*)dLen, in->weights + (size_t)wIdx * in->C,
+                                   in->rates + (size_t)rateIdx * in->C, in->patternWeights, dPartial, dOut, in->P, in->S, in->C, in->tiled);
+        rc = download(in, sums.data(), dOut, nOut * sizeof(double)); if (rc) break;
+        for (size_t k = 0; k < nOut; k++) outSum[k] += sums[k];
+    }
+    hipStreamSynchronize(in->stream);
+    hipFree(dPartial); hipFree(dOut);
+    return rc;
+}
+
+
+}  // namespace eng
+}  // namespace mi355

@@ -1,0 +1,329 @@
+// engine_walk.cpp — 4 states: a planned program (planner.h) resolved to device addresses and run as pattern-walk launches
+// (kernels_walk4.hip); materialisation of virtual buffers; updatePartials' steady-state fast path.  See engine_internal.h.
+#include "engine_internal.h"
+
+using mi355::OpDesc;
+
+namespace mi355 {
+namespace eng {
+
+// Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
+// micro-operations travel together) and enqueue the snapshot copies and the walk.
+int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t recordBeforeWalk) {
+    const size_t n = plan.prog.size();
+    if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
+        if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
+        void* dPairs = nullptr;
+        int rc = uploadTransient(in, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // Device program: per segment its micro-operations, a no-op when their number is odd, and two more no-ops the
+    // kernel's descriptor prefetch may read (kernels.h WalkSeg).  For a plan that came out of the planner's cache the
+    // resolved program is kept as well: buffer addresses never change once a buffer exists.
+    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
+    Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 3] : nullptr;
+    const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
+    std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
+    std::vector<mi355::WalkSeg> segsLocal;
+    std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
+    int maxRange = 0;
+    if (reuse) {
+        maxRange = slot->maxRange;
+        in->statMemReads += slot->memReads; in->statTipReads += slot->tipReads; in->statScaleReads += slot->scaleReads;
+        in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
+    } else {
+    const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
+    if (slot) { slot->tag = 0; slot->dProgValid = false; }
+    w.clear();
+    w.reserve(n + 3 * plan.segs.size());
+    segs.assign(plan.segs.size(), mi355::WalkSeg());
+    const size_t matStride = (size_t)in->C * 16;
+    { int rc = ensureWalkDummies(in); if (rc) return rc; }
+    mi355::WalkOp nop;
+    memset(&nop, 0, sizeof(nop));
+    nop.m1 = in->matrices; nop.m2 = in->matrices;
+    nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
+    nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
+    for (size_t si = 0; si < plan.segs.size(); si++) {
+        const mi355::PlanSeg& ps = plan.segs[si];
+        segs[si].progStart = (int)w.size();
+        for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
+            mi355::MicroOp m = plan.prog[i];
+            // The kernels request a first child's partials one stage early — before the previous micro-operation's store
+            // is issued (kernels_walk4.hip WALK_STAGE).  The planner never emits that sequence (tests/native/plan_check.cpp
+            // checks every program for it); should one arrive anyway, a no-op in between restores the distance.
+            if (i > ps.progStart && m.k1 == mi355::PK_MEM && plan.prog[i - 1].storeBuf == m.a1) {
+                if (m.k2 == mi355::PK_ACC) { m.k2 = mi355::PK_MEM; m.a2 = m.a1; }      // the no-op overwrites ACC; the value is in memory as well
+                w.push_back(nop);
+            }
+            mi355::WalkOp d;
+            memset(&d, 0, sizeof(d));
+            d.src1 = in->dummyTips; d.src2 = in->dummyTips; d.scale = in->onesScale;     // unused operands stay readable (kernels.h launchWalk4Fast)
+            if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+            else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + in->statePairOff; in->statTipReads++; }
+            if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
+            else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + in->statePairOff; in->statTipReads++; }
+            if (m.smode != mi355::PS_NONE) {
+                int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
+                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
+                else {
+                    if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
+                    in->statScaleReads++;
+                    d.scale = in->scale[m.scaleIdx] + in->scaleStride;                    // read mode multiplies by the reciprocal
+                }
+            }
+            if (m.storeBuf >= 0) {
+                int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
+                d.store = in->partials[m.storeBuf];
+                in->statStored++;
+            }
+            d.m1 = in->matrices + (size_t)m.mat1 * matStride; d.m2 = in->matrices + (size_t)m.mat2 * matStride;
+            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
+            if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
+                if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
+                if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
+                if (ablate & 4) d.scale = in->onesScale;
+                if (ablate & 8) { if (m.k1 == mi355::PK_TIPS) d.src1 = in->dummyTips; if (m.k2 == mi355::PK_TIPS) d.src2 = in->dummyTips; }
+            }
+            w.push_back(d);
+        }
+        if (ps.progCount & 1) w.push_back(nop);
+        segs[si].progCount = (int)w.size() - segs[si].progStart;
+        w.push_back(nop); w.push_back(nop);
+        // the wait of every stage: "at most N vector-memory instructions outstanding".  Loads and stores share the counter.
+        // DEFAULT (strict): N = the loads of the NEXT micro-operation only.  Sufficient under the one ordering rule the ISA
+        // guides state for this counter — vector-memory LOADS return in the order they were issued: when at most N operations
+        // are outstanding and the N youngest loads are all younger than this stage's loads, an unfinished load of this stage
+        // would leave N + 1 unfinished, whatever the stores (of this or any earlier stage) do.
+        // BEAGLE_MI355_STRICT_WAITS=0: N also counts the previous micro-operation's stores, i.e. assumes that a younger store
+        // is never counted out before an older load.  That held in > 1e9 lane-trials (tests/test_gpu_vmcnt_order.py) and saves a
+        // stage the acknowledgement of four stores per stored node — 1 % of config A (profiles/r03_experiments.txt 7) — but it
+        // is an observation, not a documented guarantee, so it is not what ships by default.
+        // A smaller N than the true number only waits longer (the table ends at 12).
+        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
+            const int stores = in->strictWaits ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
+            // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
+            const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
+            if (code == 1) w[i].flags |= mi355::WF_WAIT8; else if (code == 2) w[i].flags |= mi355::WF_WAIT12;
+        }
+        segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
+        maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
+    }
+    if (slot) {
+        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
+        slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
+        slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
+    }
+    }
+    in->statMicroOps += (long)n;
+    // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
+    const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
+    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
+    char* dBase = nullptr;
+    if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
+    else if (total <= RING_BYTES / 4) {
+        const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
+        if (off < 0) return BEAGLE_ERROR_GENERAL;
+        memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
+        if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
+        HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
+        dBase = in->dRing + off;
+        if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
+            if (slot->dProgBytes < total) {
+                if (slot->dProg) { HIP_TRY(hipStreamSynchronize(in->stream)); hipFree(slot->dProg); }
+                slot->dProg = nullptr; slot->dProgBytes = 0;
+                HIP_TRY(hipMalloc((void**)&slot->dProg, total + total / 4));
+                slot->dProgBytes = total + total / 4;
+            }
+            HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, in->stream));
+            slot->dProgValid = true;
+        }
+    } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        if (in->bigStageBytes < total) {
+            if (in->bigStage) hipFree(in->bigStage);
+            in->bigStage = nullptr; in->bigStageBytes = 0;
+            HIP_TRY(hipMalloc((void**)&in->bigStage, total));
+            in->bigStageBytes = total;
+        }
+        HIP_TRY(hipMemcpy(in->bigStage, w.data(), opBytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segBytes, hipMemcpyHostToDevice));
+        if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
+        dBase = in->bigStage;
+    }
+    if (pairBytes)
+        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
+                                      in->C * in->S * in->S);
+    // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
+    const size_t streamBytes = w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
+    if (in->matStreamBytes < streamBytes) {
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        if (in->matStream) hipFree(in->matStream);
+        in->matStream = nullptr; in->matStreamBytes = 0;
+        const size_t want = std::max(streamBytes + streamBytes / 4, (size_t)1 << 20);
+        HIP_TRY(hipMalloc((void**)&in->matStream, want));
+        in->matStreamBytes = want;
+    }
+    mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
+    if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
+        fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
+        for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
+        fprintf(stderr, "\n");
+    }
+    if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
+    // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
+    for (size_t b = 0; b < segs.size();) {
+        size_t e = b + 1;
+        while (e < segs.size() && plan.segs[e].wave == plan.segs[b].wave) e++;
+        int range = 0;
+        const bool fast = in->fastWalk;                 // the assembly loop (BEAGLE_MI355_NO_FAST_WALK=1: the C++ reference kernel)
+        for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
+        if (fast) {
+            mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                                   in->matStream, in->P, in->C, (long)in->scaleStride);
+            in->statFastWalks++;
+        } else
+            mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                               in->matStream, in->P, in->C, (long)in->scaleStride);
+        in->statWalks++;
+        b = e;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Give every definition of `xs` its real partials: one program, one launch.  xs are definition KEYS (planner.h: buffer x
+// partitionCount + partition; the buffer index itself on an instance with one partition).
+int materializeList(Instance* in, const std::vector<int>& xs) {
+    if (!in->virt || xs.empty()) return 0;
+    if (!in->walk) return materializeCherries(in, xs);
+    mi355::Plan mp;
+    in->planner.planMaterialize(xs, mp);
+    return runPlan(in, mp);
+}
+int materializeVirtual(Instance* in, int X) {         // every partition of buffer X
+    if (!isVirt(in, X)) return 0;
+    std::vector<int> keys;
+    in->planner.keysOf(X, keys);
+    return materializeList(in, keys);
+}
+int materializeScaleUsers(Instance* in, int scaleIdx) {
+    if (!in->virt || in->planner.scaleUsers(scaleIdx).empty()) return 0;
+    return materializeList(in, std::vector<int>(in->planner.scaleUsers(scaleIdx)));
+}
+int materializeTipUsers(Instance* in, int tip) {
+    if (!in->virt || in->planner.tipUsers(tip).empty()) return 0;
+    return materializeList(in, std::vector<int>(in->planner.tipUsers(tip)));
+}
+
+
+// A walk is one workgroup per 128 patterns, and every wave executes its program one dependent step after the other.  The
+// planner therefore cuts the forest into independent subtrees that run side by side, wave after wave (planner.h): with few
+// patterns (a shard of a multi-GPU run, a small alignment) that is what fills the 256 CUs at all (12 500 patterns:
+// 0.83 -> 0.33 ms per evaluation); with many it keeps more workgroups than the chip holds in the queue, so that a wave
+// waiting for its stores is replaced by another one instead of idling (1e5 patterns: 1.73 -> 1.37 ms).  Returns the target
+// number of micro-operations per subtree, 0 = one walk.  BEAGLE_MI355_CHUNK overrides (0 = never).
+int walkChunkOps(const Instance* in, int opCount) {
+    static const int forced = getenv("BEAGLE_MI355_CHUNK") ? atoi(getenv("BEAGLE_MI355_CHUNK")) : -1;
+    if (forced >= 0) return forced;
+    if (opCount < 64) return 0;
+    const long groups = (in->P + 127) / 128;
+    // about 2 560 workgroups per wave of slices: 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the
+    // assembly loop (tools/chunk_sweep.sh): 12 500 patterns 129 us at 40 micro-operations per slice vs 145 at 99; flat
+    // between 50 and 300 from 25 000 patterns up
+    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / 2560));
+}
+
+// 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.
+int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+    if (count <= 0) return 0;
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    auto usSince = [](Clock::time_point a) { return std::chrono::duration<double, std::micro>(Clock::now() - a).count(); };
+    in->hostCalls++;
+    const int parts = in->partitionCount;
+    // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
+    const bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
+    // The chain's steady state — the SAME full-evaluation list as one seen before, no rescaling in it — needs none of the
+    // per-operation work below: it was range-checked and planned then, nothing has to be materialised or accumulated for it,
+    // the planner re-establishes its definitions with one comparison per operation and the program is resident on the
+    // device (config E, 6 436 operations: 116 -> 35 us of host time per call; profiles/r03_experiments.txt).
+    {
+        bool simple = false;
+        if (in->planner.replayCached(ops, count, tuple, parts, allowVirtual, walkChunkOps(in, count), &simple)) {
+            const double usPlan = usSince(t0);
+            in->hostPlanUs += usPlan; in->hostPlanHitUs += usPlan; in->hostHits++;
+            const Clock::time_point t1 = Clock::now();
+            hipEvent_t a = nullptr, b = nullptr;
+            const bool launches = !in->planner.planned->prog.empty();
+            if (in->timing && launches) {
+                if (in->eventsUsed == in->events.size()) { hipEvent_t x, y; HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y)); in->events.emplace_back(x, y); }
+                a = in->events[in->eventsUsed].first; b = in->events[in->eventsUsed].second; in->eventsUsed++;
+            }
+            int rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, a); if (rc) return rc;
+            if (b) { HIP_TRY(hipEventRecord(b, in->stream)); in->pendingLaunches++; }
+            const double usRun = usSince(t1);
+            in->hostRunUs += usRun; in->hostRunHitUs += usRun;
+            return 0;
+        }
+    }
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * tuple;
+        const int dest = op[0], wS = op[1], rS = op[2], c1 = op[3], m1 = op[4], c2 = op[5], m2 = op[6];
+        int part = 0, cum = globalCum;
+        if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
+        if (badIndex(dest, in->partialsCount) || badIndex(c1, in->partialsCount) || badIndex(c2, in->partialsCount) ||
+            badIndex(m1, in->matrixCount) || badIndex(m2, in->matrixCount) || badIndex(part, parts) ||
+            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+            (cum != BEAGLE_OP_NONE && badIndex(cum, in->scaleCount)))
+            return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (in->timing) {
+        if (in->eventsUsed == in->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            in->events.emplace_back(a, b);
+        }
+        e0 = in->events[in->eventsUsed].first; e1 = in->events[in->eventsUsed].second; in->eventsUsed++;
+    }
+    int launches = 0;
+    in->hostPrepUs += usSince(t0);
+    for (int begin = 0; begin < count;) {
+        Clock::time_point t1 = Clock::now();
+        const int n = in->planner.hazardFreePrefix(ops, begin, count, tuple, parts);
+        const int* sub = ops + (size_t)begin * tuple;
+        for (int k = 0; k < n; k++) {                       // a tip index reused as a destination now holds partials
+            const int dest = sub[(size_t)k * tuple];
+            if (isCompactTip(in, dest) || in->planner.leafPartials[dest]) { int rcm = materializeTipUsers(in, dest); if (rcm) return rcm; in->tipStates[dest] = nullptr; setCompact(in, dest, false); }
+        }
+        std::vector<int> need;
+        in->planner.mustMaterializeBefore(sub, n, tuple, need);
+        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+        in->hostPrepUs += usSince(t1); t1 = Clock::now();
+        const long hitsBefore = in->planner.cacheHits;
+        int rc = in->planner.plan(sub, n, tuple, parts, allowVirtual, in->plan, walkChunkOps(in, n));
+        if (rc) return rc;
+        const bool hit = in->planner.cacheHits != hitsBefore;
+        { const double us = usSince(t1); in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
+        t1 = Clock::now();
+        // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
+        // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
+        if (!in->planner.planned->prog.empty()) {
+            rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, launches == 0 ? e0 : nullptr); if (rc) return rc;
+            launches++;
+        } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
+        { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us; }
+        begin += n;
+    }
+    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
+    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
+    return foldCumulative(in, ops, count, tuple, globalCum);
+}
+
+
+}  // namespace eng
+}  // namespace mi355

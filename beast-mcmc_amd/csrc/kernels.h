@@ -104,12 +104,12 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
 // of k_walk4 (k_walk4_fast always issues 4, + 4 with WF_X)
 inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? 2 : 0) + ((f & WF_T2) ? 2 : 0) + ((f & WF_INV) ? 2 : 0) + 1; }
 inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
-// flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine.cpp runPlan, kernels_walk4.hip)
+// flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine_walk.cpp runPlan, kernels_walk4.hip)
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
 // software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
 // tStart: where the segment's patterns begin in the PAIR-INTERLEAVED arrays — those are laid out partition by partition, every
-// partition padded to whole blocks of 128 (engine.cpp pairPos), so that a lane's pair is one aligned load wherever a
+// partition padded to whole blocks of 128 (engine_instance.cpp setPairLayout), so that a lane's pair is one aligned load wherever a
 // partition starts; partials and plain per-pattern arrays keep the caller's pattern numbering.
 struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, pad0, pad1, pad2; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two

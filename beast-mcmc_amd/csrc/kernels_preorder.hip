@@ -4,7 +4,7 @@
 // workgroup = one wavefront (64 patterns) whose matrices live in LDS (read at wave-uniform addresses) next to the wave's own
 // operand columns.  They are what 4-state (and S < 16, S > 64) instances run — at 4 states they are pure streaming and
 // sit near the HBM roofline.  For 16..64 states the engine routes the O(S^2) work through the MFMA pruning kernel instead
-// (engine.cpp preLevelTwoPass / edgeDifferentials: a pre-order op = two pruning passes, an internal edge = one pass +
+// (engine_preorder.cpp preLevelTwoPass / edgeDifferentials: a pre-order op = two pruning passes, an internal edge = one pass +
 // k_edgeReduce) and uses the direct kernels only for tip edges, which are O(S) per pattern.
 //
 // Arithmetic (callers: src/dr/evomodel/treedatalikelihood/preorder/AbstractBeagleGradientDelegate.java:207-221,

@@ -22,7 +22,7 @@
 // that (its s_waitcnt insertion assumes the worst path of the kind-dependent branches and drains the queue every
 // iteration), therefore every vector-memory instruction of the loop is inline assembly and the one wait per stage is EXACT:
 // "s_waitcnt vmcnt(N)", N = the loads of micro-operation k+1 (issued after those of k; loads return in issue order — with
-// BEAGLE_MI355_STRICT_WAITS=0 also the stores of k-1, see engine.cpp runPlan) — which the host knows when it
+// BEAGLE_MI355_STRICT_WAITS=0 also the stores of k-1, see engine_walk.cpp runPlan) — which the host knows when it
 // builds the program and passes in the descriptor; this kernel jumps into a table of s_waitcnt instructions.  Loads a
 // micro-operation does not need are BRANCHED around, not masked: a vector-memory instruction with 8 or 16 bytes per lane
 // occupies the CU's address unit for ~16 cycles whatever its EXEC mask or coalescing (tools/vmem_rate_probe.hip).

@@ -2,7 +2,7 @@
 // pattern-walk kernel executes (kernels_walk4.hip), and keeps the definitions of "virtual" partials buffers.
 //
 // Pure host logic: no HIP types, no device pointers — everything is expressed in buffer / matrix / scale INDICES; the
-// engine resolves them to addresses (engine.cpp).  That keeps the planner testable without a GPU: tests/native/ holds
+// engine resolves them to addresses (engine_walk.cpp).  That keeps the planner testable without a GPU: tests/native/ holds
 // an index-level interpreter of the micro-operations and checks planner output against list-order evaluation.
 //
 // Reference behaviour this has to preserve (all paths relative to /root/reference):
@@ -23,7 +23,7 @@ namespace mi355 {
 constexpr int PLAN_MAX_STEPS = 32;       // capacity of a virtual definition (snapshot slots per buffer = 2 * this)
 constexpr int PLAN_NONE = -1;
 
-// kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine.cpp)
+// kinds / scale modes: numerically identical to WK_* / WS_* of kernels.h (static_assert in engine_internal.h)
 enum { PK_MEM = 0, PK_TIPS = 1, PK_ACC = 2, PK_H0 = 3, PK_H1 = 4, PK_H2 = 5 };
 enum { PS_NONE = 0, PS_READ = 1, PS_WRITE = 2 };
 
@@ -114,7 +114,7 @@ public:
     void clearVirtualKey(int key);       // forget the definition (that range of the buffer is about to get real data)
     void clearVirtual(int buf) { for (int k = 0; k < keyParts_; k++) clearVirtualKey(buf * keyParts_ + k); }
     // Define `buf` as the cherry node(tipA over matrix mA, tipB over matrix mB) [read-mode scale buffer scaleIdx or PLAN_NONE]
-    // (the level-scheduled T32 path, engine.cpp runOperationsLevels: one partition); appends the matrix snapshot copies to snapPairs.
+    // (the level-scheduled T32 path, engine_levels.cpp runOperationsLevels: one partition); appends the matrix snapshot copies to snapPairs.
     bool defineCherry(int buf, int tipA, int mA, int tipB, int mB, int scaleIdx, std::vector<int>& snapPairs);
 
     // Length of the longest prefix of ops[begin..count) that can run as one walk: no buffer (or scale buffer) is written

@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable with a copy kernel)
-KERNEL_SOURCES = ("kernels_walk4.hip", "walk4_fast_loop.inc", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine.cpp")
+KERNEL_SOURCES = ("kernels_walk4.hip", "walk4_fast_loop.inc", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine_walk.cpp", "engine_levels.cpp", "engine_instance.cpp")
 
 
 def kernel_source_hash():

@@ -237,7 +237,7 @@ struct Harness {
             truthOp(truth, compact, op, partStart[part], partEnd[part]);
         }
         int begin = 0;
-        {   // the engine's fast path for a repeated closed list (engine.cpp runOperationsWalk): no checks, no planning
+        {   // the engine's fast path for a repeated closed list (engine_walk.cpp runOperationsWalk): no checks, no planning
             bool simple = false;
             if (fixedChunk >= 0 && pl.replayCached(ops.data(), count, tuple, parts, true, fixedChunk, &simple)) {
                 assert(simple);

@@ -13,7 +13,7 @@
 //   C  four cold stores FIRST (older, slow, still in the queue), then the cold load, then four hot stores, vmcnt(4)
 //   D  a cold LDS-DMA load (global_load_lds_dwordx4: the kernels' matrix-table fetch, the first load of every stage), then
 //      four hot stores, vmcnt(4): the LDS word must hold the loaded value
-// BEAGLE_MI355_STRICT_WAITS=1 makes the engine independent of the property (engine.cpp runPlan).
+// BEAGLE_MI355_STRICT_WAITS=1 makes the engine independent of the property (engine_walk.cpp runPlan).
 // Output: one "PROBE <name> <violations> <trials>" line per experiment and load level.
 // Build: hipcc --offload-arch=gfx950 -O3 tests/native/vmcnt_order_probe.hip -o /tmp/vp && /tmp/vp [iters]
 #include <hip/hip_runtime.h>

@@ -332,7 +332,7 @@ def test_concurrent_instances_from_two_threads(oracle_lib):
 def test_ladder_tree_of_5000_taxa(traversal, oracle_lib):
     """4999 dependency levels: the planner's emission is iterative (no native-stack recursion under a JVM thread) and the
     whole ladder runs as one chain in registers; a first child must never be fetched from a buffer the micro-operation right
-    before it stores (the kernels request it one stage early — ADVICE round 2, planner.cpp / engine.cpp runPlan)."""
+    before it stores (the kernels request it one stage early — ADVICE round 2, planner.cpp / engine_walk.cpp runPlan)."""
     rng = np.random.default_rng(5)
     pi = rng.dirichlet(np.full(4, 10.0))
     eig = bm.substmodel.gtr(rng.gamma(2.0, 1.0, size=6) + 0.1, pi)

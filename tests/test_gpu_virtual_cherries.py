@@ -1,5 +1,5 @@
 """The 4-state engine — and, on the T32 layout, the <= 20-state one — never writes tip-tip nodes' partials to HBM unless
-somebody needs the real data ("virtual cherries", engine.cpp; kernels_mfma.hip cherryOperands).  BEAGLE semantics must survive that: a partials buffer keeps the value its op gave it even
+somebody needs the real data ("virtual cherries", engine_levels.cpp; kernels_mfma.hip cherryOperands).  BEAGLE semantics must survive that: a partials buffer keeps the value its op gave it even
 if the tip states, the matrices or the scale buffer it was computed from are changed afterwards.  Every step below is
 issued identically to the HIP engine and to the CPU oracle, and every buffer is compared after every step."""
 import numpy as np

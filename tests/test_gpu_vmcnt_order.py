@@ -2,7 +2,7 @@
 
 A stage of the walk waits with ``s_waitcnt vmcnt(N)``; gfx9 counts loads and stores in one counter and the ISA guides promise
 in-order return only for loads among themselves.  The DEFAULT build takes N from the next stage's loads only, which needs
-nothing but that rule (engine.cpp runPlan).  ``BEAGLE_MI355_STRICT_WAITS=0`` also counts the previous stage's STORES as
+nothing but that rule (engine_walk.cpp runPlan).  ``BEAGLE_MI355_STRICT_WAITS=0`` also counts the previous stage's STORES as
 retiring behind the stage's own (older) loads — 1 % faster, resting on an observation: tests/native/vmcnt_order_probe.hip
 looks for a counter-example in the four situations the kernels create (> 1e9 lane-trials).  Both must give the same bits."""
 import os
