@@ -644,7 +644,11 @@ static int uploadIfChanged(Instance* in, std::vector<double>& shadow, std::vecto
 }
 
 int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, const double* Uinv, const double* lambda) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetEigenDecomposition(h, eigenIndex, U, Uinv, lambda); }); }
+    if (mi355::isShardedHandle(instance)) {          // (queued: every shard's thread applies its copy; sharded.h shardedPost)
+        const size_t S = (size_t)shardedStates(instance);
+        std::vector<double> u(U, U + S * S), ui(Uinv, Uinv + S * S), lam(lambda, lambda + (mi355::shardedEigenComplex(instance) ? 2 : 1) * S);
+        return mi355::shardedPost(instance, [=](int h) { return beagleSetEigenDecomposition(h, eigenIndex, u.data(), ui.data(), lam.data()); });
+    }
     GET_INSTANCE(instance);
     if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t S = in->S, nLambda = in->eigenComplex ? 2 * S : S, stride = 2 * S * S + nLambda;
@@ -656,21 +660,21 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, c
 }
 
 int beagleSetStateFrequencies(int instance, int idx, const double* f) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetStateFrequencies(h, idx, f); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<double> v(f, f + shardedStates(instance)); return mi355::shardedPost(instance, [=](int h) { return beagleSetStateFrequencies(h, idx, v.data()); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shFreqs, in->okFreqs, in->eigenCount, idx, in->S, in->freqs + (size_t)idx * in->S, f);
 }
 
 int beagleSetCategoryWeights(int instance, int idx, const double* w) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetCategoryWeights(h, idx, w); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<double> v(w, w + shardedCategories(instance)); return mi355::shardedPost(instance, [=](int h) { return beagleSetCategoryWeights(h, idx, v.data()); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shWeights, in->okWeights, in->eigenCount, idx, in->C, in->weights + (size_t)idx * in->C, w);
 }
 
 int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetCategoryRatesWithIndex(h, idx, r); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<double> v(r, r + shardedCategories(instance)); return mi355::shardedPost(instance, [=](int h) { return beagleSetCategoryRatesWithIndex(h, idx, v.data()); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return uploadIfChanged(in, in->shRates, in->okRates, in->eigenCount, idx, in->C, in->rates + (size_t)idx * in->C, r);
@@ -757,7 +761,12 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
 int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* probabilityIndices,
                                    const int* firstDerivativeIndices, const int* secondDerivativeIndices,
                                    const double* edgeLengths, int count) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdateTransitionMatrices(h, eigenIndex, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count); }); }
+    if (mi355::isShardedHandle(instance)) {
+        if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+        if (count <= 0) return BEAGLE_SUCCESS;
+        std::vector<int> p(probabilityIndices, probabilityIndices + count); std::vector<double> t(edgeLengths, edgeLengths + count);
+        return mi355::shardedPost(instance, [=](int h) { return beagleUpdateTransitionMatrices(h, eigenIndex, p.data(), nullptr, nullptr, t.data(), count); });
+    }
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     return transitionMatrices(in, nullptr, eigenIndex, nullptr, probabilityIndices, edgeLengths, count);
@@ -766,7 +775,14 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
 int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices, const int* categoryRateIndices,
                                    const int* probabilityIndices, const int* firstDerivativeIndices,
                                    const int* secondDerivativeIndices, const double* edgeLengths, int count) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdateTransitionMatricesWithMultipleModels(h, eigenIndices, categoryRateIndices, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count); }); }
+    if (mi355::isShardedHandle(instance)) {
+        if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+        if (!eigenIndices || !categoryRateIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (count <= 0) return BEAGLE_SUCCESS;
+        std::vector<int> e(eigenIndices, eigenIndices + count), r(categoryRateIndices, categoryRateIndices + count), p(probabilityIndices, probabilityIndices + count);
+        std::vector<double> t(edgeLengths, edgeLengths + count);
+        return mi355::shardedPost(instance, [=](int h) { return beagleUpdateTransitionMatricesWithMultipleModels(h, e.data(), r.data(), p.data(), nullptr, nullptr, t.data(), count); });
+    }
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (!eigenIndices || !categoryRateIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -774,13 +790,21 @@ int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* ei
 }
 
 int beagleUpdatePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
+    if (mi355::isShardedHandle(instance)) {
+        if (operationCount <= 0) return BEAGLE_SUCCESS;
+        std::vector<int> ops(operations, operations + (size_t)operationCount * BEAGLE_OP_COUNT);
+        return mi355::shardedPost(instance, [=](int h) { return beagleUpdatePartials(h, ops.data(), operationCount, cumulativeScaleIndex); });
+    }
     GET_INSTANCE(instance);
     return runOperations(in, operations, operationCount, BEAGLE_OP_COUNT, cumulativeScaleIndex);
 }
 
 int beagleUpdatePartialsByPartition(int instance, const int* operations, int operationCount) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePartialsByPartition(h, operations, operationCount); }); }
+    if (mi355::isShardedHandle(instance)) {
+        if (operationCount <= 0) return BEAGLE_SUCCESS;
+        std::vector<int> ops(operations, operations + (size_t)operationCount * BEAGLE_PARTITION_OP_COUNT);
+        return mi355::shardedPost(instance, [=](int h) { return beagleUpdatePartialsByPartition(h, ops.data(), operationCount); });
+    }
     GET_INSTANCE(instance);
     return runOperations(in, operations, operationCount, BEAGLE_PARTITION_OP_COUNT, BEAGLE_OP_NONE);
 }
@@ -795,28 +819,28 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
 }
 
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleAccumulateScaleFactors(h, scaleIndices, count, cumulativeScaleIndex); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleAccumulateScaleFactors(h, v.data(), count, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, 0);
 }
 int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleAccumulateScaleFactorsByPartition(h, scaleIndices, count, cumulativeScaleIndex, partitionIndex); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleAccumulateScaleFactorsByPartition(h, v.data(), count, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, partitionIndex);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleRemoveScaleFactors(h, scaleIndices, count, cumulativeScaleIndex); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleRemoveScaleFactors(h, v.data(), count, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, 0);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleRemoveScaleFactorsByPartition(h, scaleIndices, count, cumulativeScaleIndex, partitionIndex); }); }
+    if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleRemoveScaleFactorsByPartition(h, v.data(), count, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, partitionIndex);
 }
 
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleResetScaleFactorsByPartition(h, cumulativeScaleIndex, partitionIndex); }); }
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleResetScaleFactorsByPartition(h, cumulativeScaleIndex, partitionIndex); }); }
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount) || badIndex(partitionIndex, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
@@ -832,7 +856,7 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
     return BEAGLE_SUCCESS;
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleResetScaleFactors(h, cumulativeScaleIndex); }); }
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleResetScaleFactors(h, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
@@ -845,7 +869,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
 }
 
 int beagleCopyScaleFactors(int instance, int dest, int src) {
-    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleCopyScaleFactors(h, dest, src); }); }
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleCopyScaleFactors(h, dest, src); }); }
     GET_INSTANCE(instance);
     if (badIndex(dest, in->scaleCount) || badIndex(src, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, dest); if (rc) return rc;

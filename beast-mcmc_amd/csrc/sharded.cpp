@@ -27,7 +27,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -39,7 +41,11 @@
 namespace mi355 {
 namespace {
 
-// one host thread per shard: runs the closures the API thread posts, in order
+// one host thread per shard: runs the closures the API thread posts, in order.  post() does not wait: calls that return
+// nothing to the caller (model parameters, matrices, operation lists, scale-factor bookkeeping) are queued and the API thread
+// moves on to queue the next one — a hand-off per call and shard would cost more than a 12 500-pattern shard's kernels
+// (eight shards: two context switches x 8 x ~7 calls per evaluation); wait() drains the queue and returns the first error
+// since the last wait (BEAGLE's own asynchronous semantics: an error surfaces at the next call that observes results).
 class Worker {
 public:
     Worker() : thread_([this] { loop(); }) {}
@@ -49,13 +55,15 @@ public:
         thread_.join();
     }
     void post(std::function<int()> f) {
-        { std::lock_guard<std::mutex> l(mu_); task_ = std::move(f); hasTask_ = true; done_ = false; }
+        { std::lock_guard<std::mutex> l(mu_); q_.push_back(std::move(f)); }
         cv_.notify_all();
     }
     int wait() {
         std::unique_lock<std::mutex> l(mu_);
-        cv_.wait(l, [this] { return done_; });
-        return rc_;
+        cv_.wait(l, [this] { return q_.empty() && !busy_; });
+        const int rc = rc_;
+        rc_ = 0;
+        return rc;
     }
 private:
     void loop() {
@@ -63,19 +71,19 @@ private:
             std::function<int()> f;
             {
                 std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return hasTask_ || stop_; });
-                if (stop_) return;
-                f = std::move(task_); hasTask_ = false;
+                cv_.wait(l, [this] { return !q_.empty() || stop_; });
+                if (q_.empty()) return;                 // (stop_, and nothing left to run)
+                f = std::move(q_.front()); q_.pop_front(); busy_ = true;
             }
             const int rc = f();
-            { std::lock_guard<std::mutex> l(mu_); rc_ = rc; done_ = true; }
+            { std::lock_guard<std::mutex> l(mu_); if (rc && !rc_) rc_ = rc; busy_ = false; }
             cv_.notify_all();
         }
     }
     std::mutex mu_;
     std::condition_variable cv_;
-    std::function<int()> task_;
-    bool hasTask_ = false, done_ = true, stop_ = false;
+    std::deque<std::function<int()>> q_;
+    bool busy_ = false, stop_ = false;
     int rc_ = 0;
     std::thread thread_;
 };
@@ -92,7 +100,7 @@ struct Shard {
 struct Sharded {
     std::vector<Shard> shards;
     int tipCount = 0, S = 0, P = 0, C = 0;
-    bool useRccl = false;
+    bool useRccl = false, eigenComplex = false;
     double* hResult = nullptr;          // pinned
     std::string name;
 };
@@ -148,6 +156,7 @@ int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compa
     n = std::max(1, std::min(n, patternCount));
     Sharded* sh = new Sharded();
     sh->tipCount = tipCount; sh->S = stateCount; sh->P = patternCount; sh->C = categoryCount;
+    sh->eigenComplex = (requirementFlags & BEAGLE_FLAG_EIGEN_COMPLEX) != 0;
     sh->useRccl = n <= gpuCount;                       // distinct devices: the all-reduce runs over RCCL
     const int div = patternCount / n, rem = patternCount % n;      // Patterns.java:142-167
     int start = 0, rc = 0;
@@ -210,6 +219,13 @@ int shardedShardCount(int handle) { Sharded* sh = find(handle); return sh ? (int
 int shardedBroadcast(int handle, const std::function<int(int)>& call) {
     GET_SHARDED(handle);
     return forAll(sh, [&](int k) { return call(sh->shards[k].handle); });
+}
+
+int shardedPost(int handle, std::function<int(int)> call) {
+    GET_SHARDED(handle);
+    auto shared = std::make_shared<const std::function<int(int)>>(std::move(call));
+    for (Shard& s : sh->shards) { const int h = s.handle; s.worker->post([shared, h] { return (*shared)(h); }); }
+    return BEAGLE_SUCCESS;
 }
 
 // ---- inputs indexed by pattern ---------------------------------------------------------------------------------------
@@ -310,6 +326,7 @@ void shardedBoundsOfHandle(int handle, int shardHandle, int* pStart, int* pEnd) 
 }
 int shardedPatternCount(int handle) { Sharded* sh = find(handle); return sh ? sh->P : 0; }
 int shardedStates(int handle) { Sharded* sh = find(handle); return sh ? sh->S : 0; }
+bool shardedEigenComplex(int handle) { Sharded* sh = find(handle); return sh && sh->eigenComplex; }
 int shardedCategories(int handle) { Sharded* sh = find(handle); return sh ? sh->C : 0; }
 
 }  // namespace mi355

@@ -18,11 +18,15 @@ int shardedShardCount(int handle);
 int shardedPatternCount(int handle);
 int shardedStates(int handle);
 int shardedCategories(int handle);
+bool shardedEigenComplex(int handle);        // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays have 2 S entries
 void shardedBounds(int handle, int shard, int* pStart, int* pEnd);
 void shardedBoundsOfHandle(int handle, int shardHandle, int* pStart, int* pEnd);
 
 // the same call on every shard (each on its own host thread); first error wins
 int shardedBroadcast(int handle, const std::function<int(int shardHandle)>& call);
+// the same, WITHOUT waiting (calls that return nothing to the caller): `call` must own everything it reads — the caller's
+// arrays may be reused as soon as this returns; errors surface at the next waiting call
+int shardedPost(int handle, std::function<int(int shardHandle)> call);
 // arrays indexed by pattern: v is [planes][P][perPattern]; every shard sees its own block
 int shardedSetPerPatternInts(int handle, const int* v, const std::function<int(int, const int*)>& call);
 int shardedSetPerPatternDoubles(int handle, const double* v, int perPattern, int planes, const std::function<int(int, const double*)>& call);
