@@ -246,7 +246,8 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
 def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext, c0set):
     """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
     following one is fetched into the other slot."""
-    e("s_waitcnt lgkmcnt(0)")                       # the descriptor of the NEXT micro-operation (and LDS writes) have landed
+    if "notopwait" not in EXPERIMENT:
+        e("s_waitcnt lgkmcnt(0)")                   # the descriptor of the NEXT micro-operation (and LDS writes) have landed
     fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext)
     if EARLYDESC:   # descriptor k + 2, a whole stage before its use: its latency (a scalar-cache miss goes to L2) hides behind the wait below
         e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
@@ -259,10 +260,11 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
     e("s_cbranch_scc1 %s" % L("w8" + tag))
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT1))
     e("s_cbranch_scc1 %s" % L("w12" + tag))
-    e("s_waitcnt vmcnt(4)")
+    novm = "novmwait" in EXPERIMENT
+    e("s_nop 0" if novm else "s_waitcnt vmcnt(4)")
     e(L("wd" + tag) + ":")
-    outofline.append([L("w8" + tag) + ":", "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag)])
-    outofline.append([L("w12" + tag) + ":", "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
+    outofline.append([L("w8" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag)])
+    outofline.append([L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
     c0 = c0set if SCOL else None
     m2blk = [L("m2" + tag) + ":",                    # both children in memory: the second one is loaded into ACC, synchronously
              "global_load_dwordx4 %s, %s, %s" % (v(ACC, 4), v(PA), s(SSRC2, 2)),
@@ -320,12 +322,13 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
         e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
         e("s_cbranch_scc1 %s" % L("fh2" + tag))
-        e("s_waitcnt lgkmcnt(0)")
+        ldsw = "s_nop 0" if "noldswait" in EXPERIMENT else "s_waitcnt lgkmcnt(0)"
+        e(ldsw)
         matvec(F, X, SP, c0)
         save = lines[:]
         del lines[:]
         e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
-        e("s_waitcnt lgkmcnt(0)")
+        e(ldsw)
         matvec(F, H2, SP, c0)
         e("s_branch %s" % L("g" + tag))
         outofline.append(lines[:])
@@ -336,7 +339,7 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
         e("s_cbranch_scc0 %s" % L("ga" + tag))
         tip_columns(G, Tt2, tblCur, 160)
-        e("s_waitcnt lgkmcnt(0)")
+        e(ldsw)
         e("s_branch %s" % L("mul" + tag))
         e(L("ga" + tag) + ":")
         e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
@@ -344,7 +347,7 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e(L("m2b" + tag) + ":")
         outofline.append(m2blk)
         e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
-        e("s_waitcnt lgkmcnt(0)")
+        e(ldsw)
         matvec(G, ACC, SP, None if c0 is None else c0 + 8)
     e(L("mul" + tag) + ":")
     # descriptor k + 2: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)

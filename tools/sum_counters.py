@@ -5,7 +5,7 @@ import glob
 import sys
 
 root = sys.argv[1]
-for d in ["sqa", "sqb", "sqc"]:
+for d in ["sqa", "sqb", "sqc", "sqd"]:
     for f in glob.glob(root + "/" + d + "/**/*counter_collection.csv", recursive=True):
         tot, n = collections.defaultdict(float), 0
         for r in csv.DictReader(open(f)):
