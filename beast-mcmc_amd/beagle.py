@@ -122,7 +122,7 @@ _PROTOS = {
 ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetBenchmarkedResourceList", "beagleGetApiTable"] + \
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
-               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GetPartialsBatch",
+               "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned"]
 
 
@@ -452,6 +452,12 @@ class Beagle:
         self._check("walkStats", self._ext("beagleMi355WalkStats", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
         keys = ("micro_ops", "stored", "mem_reads", "tip_reads", "scale_reads", "walks", "scale_writes", "fast_walks")
         return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    def gradientStats(self):
+        """Pre-order lists run fused with their edge derivatives / operation by operation (include/beagle_mi355.h)."""
+        out = (C.c_long * 2)()
+        self._check("gradientStats", self._ext("beagleMi355GradientStats", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
+        return {"fused": int(out[0]), "by_operation": int(out[1])}
 
     def deviceBytes(self):
         return self._ext("beagleMi355DeviceBytes", [C.c_int], C.c_long)(self.instance)

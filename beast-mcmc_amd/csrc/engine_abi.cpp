@@ -259,6 +259,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);
+    in->fuseGradient = !(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT") && atoi(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
@@ -685,8 +686,11 @@ int beagleSetCategoryRates(int instance, const double* r) { return beagleSetCate
 int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMatrix, double paddedValue) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleSetTransitionMatrix(h, matrixIndex, inMatrix, paddedValue); }); }
     (void)paddedValue;
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);
     if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    // (setDifferentialMatrix arrives between updatePrePartials and calculateEdgeDifferentials: the held-back list stays held
+    // unless this very matrix is one of its branch matrices)
+    if (in->prePending && in->pendingPreMatrix[matrixIndex]) { int rcp = flushPendingPre(in); if (rcp) return rcp; }
     const size_t n = (size_t)in->C * in->S * in->S;
     return upload(in, in->matrices + n * matrixIndex, inMatrix, n * sizeof(double));
 }
@@ -1043,7 +1047,7 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
     GET_INSTANCE(instance);
-    return runPreOperations(in, operations, operationCount, cumulativeScaleIndex);
+    return runPreOperations(in, operations, operationCount, cumulativeScaleIndex, true);
 }
 
 int beagleCalculateCrossProductDifferentials(int instance, const int* postBufferIndices, const int* preBufferIndices,
@@ -1091,7 +1095,7 @@ int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices,
         for (int e = 0; e < count; e++) { if (outSumDerivatives) outSumDerivatives[e] = tot[e]; if (outSumSquaredDerivatives) outSumSquaredDerivatives[e] = tot[count + e]; }
         return BEAGLE_SUCCESS;
     }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list is what this call wants to run with)
     if (!postBufferIndices || !preBufferIndices || !derivativeMatrixIndices || !categoryWeightsIndices) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (badIndex(categoryWeightsIndices[0], in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     return edgeDifferentials(in, postBufferIndices, preBufferIndices, derivativeMatrixIndices, categoryWeightsIndices[0], count,
@@ -1168,6 +1172,17 @@ int beagleMi355WalkStats(int instance, long* out8) {
     if (!in || !out8) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out8[0] = in->statMicroOps; out8[1] = in->statStored; out8[2] = in->statMemReads; out8[3] = in->statTipReads;
     out8[4] = in->statScaleReads; out8[5] = in->statWalks; out8[6] = in->statScaleWrites; out8[7] = in->statFastWalks;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355GradientStats(int instance, long* out2) {
+    if (mi355::isShardedHandle(instance)) {             // counters of shard 0 (every shard is driven the same way)
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355GradientStats(h, out2); });
+    }
+    Instance* in = lookup(instance);
+    if (!in || !out2) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    out2[0] = in->statFusedGradients; out2[1] = in->statPreLists;
     return BEAGLE_SUCCESS;
 }
 

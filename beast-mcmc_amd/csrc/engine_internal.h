@@ -71,6 +71,13 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
+    // 4 states: a pre-order operation list is HELD BACK until the edge-derivative call that follows it arrives, so that both run as
+    // one sweep per tree level (engine_preorder.cpp fusedGradient); anything else that could observe or change what the list
+    // reads or writes runs it first (GET_INSTANCE -> flushPendingPre)
+    std::vector<int> pendingPre; bool prePending = false; std::vector<char> pendingPreMatrix;   // matrix indices the held list reads
+    long statFusedGradients = 0, statPreLists = 0;
+    void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
+    bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)
     bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
     bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
                                                          // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)
@@ -139,12 +146,18 @@ struct Resources {
 extern const long GPU_FLAGS;
 Resources* resources();
 void setPairLayout(Instance* in);
+int flushPendingPre(Instance* in);
 int ensureWalkDummies(Instance* in);
 
-#define GET_INSTANCE(h)                                          \
+// (a held-back pre-order list — Instance::pendingPre — runs before anything else touches the instance; the few calls that cannot
+// interact with it use GET_INSTANCE_KEEP_PENDING)
+#define GET_INSTANCE_KEEP_PENDING(h)                             \
     Instance* in = lookup(h);                                    \
     if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;         \
     if (hipSetDevice(in->device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+#define GET_INSTANCE(h)                                          \
+    GET_INSTANCE_KEEP_PENDING(h)                                 \
+    if (in->prePending) { const int rcPending__ = flushPendingPre(in); if (rcPending__) return rcPending__; }
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 
@@ -184,7 +197,9 @@ int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globa
 int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum);
 // ---- engine_preorder.cpp
 int ensurePreScratch(Instance* in);
-int runPreOperations(Instance* in, const int* ops, int count, int globalCum);
+int ensureEdgeScratch(Instance* in, size_t bytes);
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold = false);
+int flushPendingPre(Instance* in);
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared);
 int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum);

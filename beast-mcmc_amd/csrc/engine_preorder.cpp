@@ -25,6 +25,20 @@ int ensurePreScratch(Instance* in) {
     return 0;
 }
 
+// the block sums of the derivative calls: kept between calls (hipMalloc/hipFree per call cost more than the small trees' kernels)
+int ensureEdgeScratch(Instance* in, size_t bytes) {
+    if (bytes <= in->edgeScratchBytes) return 0;
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    if (in->edgeScratch) {
+        for (auto& a : in->allocations) if (a == in->edgeScratch) { a = in->allocations.back(); in->allocations.pop_back(); break; }
+        hipFree(in->edgeScratch); in->deviceBytes -= in->edgeScratchBytes; in->edgeScratch = nullptr; in->edgeScratchBytes = 0;
+    }
+    bytes = (bytes * 5 / 4 + 4095) & ~(size_t)4095;
+    int rc = devAlloc(in, &in->edgeScratch, bytes); if (rc) return rc;
+    in->edgeScratchBytes = bytes;
+    return 0;
+}
+
 int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
     { int rc0 = ensurePreScratch(in); if (rc0) return rc0; }
     std::vector<OpDesc> pass(2 * PRE_SCRATCH);
@@ -63,7 +77,7 @@ int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
 // Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
 // matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
 // levelised like a post-order one and each level is one launch.
-int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold) {
     if (count <= 0) return 0;
     if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     const int n = in->partialsCount;
@@ -115,6 +129,22 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
         level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
         wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
     }
+    // 4 states, no rescaling in the list: hold it back — the edge-derivative call that follows (AbstractBeagleBranchGradient-
+    // Delegate.java:82-92) runs it together with the derivatives, one sweep per tree level (fusedGradient below); any other
+    // call runs it first, exactly as written (flushPendingPre).  The bookkeeping above (real operands, destinations allocated
+    // and no longer tips or definitions) is done either way.
+    if (mayHold && in->fuseGradient && in->S == 4 && !in->tiled && globalCum == BEAGLE_OP_NONE) {
+        bool plain = true;
+        for (int k = 0; k < count && plain; k++) plain = ops[(size_t)k * BEAGLE_OP_COUNT + 1] == BEAGLE_OP_NONE && ops[(size_t)k * BEAGLE_OP_COUNT + 2] == BEAGLE_OP_NONE;
+        if (plain) {
+            in->pendingPre.assign(ops, ops + (size_t)count * BEAGLE_OP_COUNT);
+            in->pendingPreMatrix.assign(in->matrixCount, 0);
+            for (int k = 0; k < count; k++) { in->pendingPreMatrix[ops[(size_t)k * BEAGLE_OP_COUNT + 4]] = 1; in->pendingPreMatrix[ops[(size_t)k * BEAGLE_OP_COUNT + 6]] = 1; }
+            in->prePending = true;
+            return 0;
+        }
+    }
+    in->statPreLists++;
     std::vector<int> start(maxLevel + 2, 0);
     for (int k = 0; k < count; k++) start[level[k] + 1]++;
     for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
@@ -157,10 +187,121 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum) {
 
 // Per-edge derivative sums (AbstractBeagleBranchGradientDelegate.java:82-92).  Edges are processed in chunks that bound
 // the scratch memory (block sums, and the optional per-pattern matrix) to a few hundred MB.
+// the held-back list, operation by operation, as the caller wrote it
+int flushPendingPre(Instance* in) {
+    if (!in->prePending) return 0;
+    in->prePending = false;
+    std::vector<int> ops;
+    ops.swap(in->pendingPre);
+    return runPreOperations(in, ops.data(), (int)(ops.size() / BEAGLE_OP_COUNT), BEAGLE_OP_NONE, false);
+}
+
+// The held-back pre-order list and the edge derivatives asked for now as ONE sweep per tree level (kernels_preorder4.hip
+// k_preNode4): the two operations below a node become one job that reads pre(node), post(a), post(b) once, writes pre(a) and
+// pre(b) and leaves both edges' derivative sums.  Returns 1 when the two lists do not fit that shape (a parent with one
+// operation, an edge whose post-order buffer is not its node's, per-pattern derivatives wanted, ...): the caller then runs
+// the list and the derivatives separately.
+static int fusedGradient(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
+                         double* outSum, double* outSumSquared) {
+    const int nOps = (int)(in->pendingPre.size() / BEAGLE_OP_COUNT), nBuf = in->partialsCount;
+    std::vector<int> edgeOf(nBuf, -1), jobOfParent(nBuf, -1), jobOfDest(nBuf, -1);
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], nBuf) || badIndex(preIdx[e], nBuf) || badIndex(dIdx[e], in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (edgeOf[preIdx[e]] >= 0) return 1;                    // the same node twice
+        edgeOf[preIdx[e]] = e;
+    }
+    struct Node { int par, preA, preB, postA, postB, matA, matB, level; };
+    std::vector<Node> nodes;
+    for (int k = 0; k < nOps; k++) {
+        const int* op = &in->pendingPre[(size_t)k * BEAGLE_OP_COUNT];
+        const int dest = op[0], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+        if (jobOfDest[dest] >= 0) return 1;
+        int j = jobOfParent[par];
+        if (j < 0) {
+            j = (int)nodes.size(); jobOfParent[par] = j;
+            Node nd; nd.par = par; nd.preA = dest; nd.matA = mc; nd.postB = sib; nd.matB = ms; nd.preB = -1; nd.postA = -1;
+            nd.level = jobOfDest[par] >= 0 ? nodes[jobOfDest[par]].level + 1 : 0;      // (a parent's operation precedes its children's)
+            nodes.push_back(nd);
+        } else {
+            Node& nd = nodes[j];
+            if (nd.preB >= 0 || mc != nd.matB || ms != nd.matA) return 1;
+            nd.preB = dest; nd.postA = sib;
+        }
+        jobOfDest[dest] = j;
+    }
+    int covered = 0, maxLevel = 0;
+    for (const Node& nd : nodes) {
+        if (nd.preB < 0) return 1;
+        for (int w = 0; w < 2; w++) {
+            const int e = edgeOf[w ? nd.preB : nd.preA];
+            if (e < 0) continue;
+            if (postIdx[e] != (w ? nd.postB : nd.postA)) return 1;
+            covered++;
+        }
+        maxLevel = std::max(maxLevel, nd.level);
+    }
+    if (covered != count) return 1;                                // an edge whose pre-order partial the held list does not produce
+    const int nb = mi355::edgeBlocks(in->P);
+    if ((size_t)count * nb * 2 * sizeof(double) > ((size_t)512 << 20)) return 1;
+    // jobs, level by level
+    std::vector<mi355::PreNodeJob> jobs(nodes.size());
+    std::vector<int> start(maxLevel + 2, 0), order(nodes.size());
+    for (const Node& nd : nodes) start[nd.level + 1]++;
+    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
+    { std::vector<int> fill(start.begin(), start.end() - 1); for (size_t j = 0; j < nodes.size(); j++) order[fill[nodes[j].level]++] = (int)j; }
+    for (size_t q = 0; q < nodes.size(); q++) {
+        const Node& nd = nodes[order[q]];
+        mi355::PreNodeJob& jb = jobs[q];
+        memset(&jb, 0, sizeof(jb));
+        if (!in->partials[nd.par] || !in->partials[nd.preA] || !in->partials[nd.preB]) return BEAGLE_ERROR_OUT_OF_RANGE;
+        jb.preParent = in->partials[nd.par]; jb.preA = in->partials[nd.preA]; jb.preB = in->partials[nd.preB];
+        for (int w = 0; w < 2; w++) {
+            const int po = w ? nd.postB : nd.postA;
+            const void* ptr; int st;
+            if (in->tipStates[po] && po < in->tipCount) { ptr = in->tipStates[po]; st = 1; }
+            else if (in->partials[po]) { ptr = in->partials[po]; st = 0; }
+            else return BEAGLE_ERROR_OUT_OF_RANGE;
+            const int e = edgeOf[w ? nd.preB : nd.preA];
+            if (w) { jb.postB = ptr; jb.statesB = st; jb.slotB = e; jb.dB = e >= 0 ? dIdx[e] : 0; }
+            else { jb.postA = ptr; jb.statesA = st; jb.slotA = e; jb.dA = e >= 0 ? dIdx[e] : 0; }
+        }
+        jb.matA = nd.matA; jb.matB = nd.matB;
+    }
+    int rc = ensureEdgeScratch(in, (size_t)count * (nb + 1) * 2 * sizeof(double)); if (rc) return rc;
+    double *dBlock = (double*)in->edgeScratch, *dSums = dBlock + (size_t)count * nb * 2;
+    const size_t maxChunk = (RING_BYTES / 4) / sizeof(mi355::PreNodeJob);
+    for (size_t b = 0; b < jobs.size() && !rc; b += maxChunk) {
+        const size_t n = std::min(maxChunk, jobs.size() - b);
+        void* dJobs = nullptr;
+        rc = uploadTransient(in, &jobs[b], n * sizeof(mi355::PreNodeJob), &dJobs); if (rc) break;
+        for (int l = 0; l <= maxLevel; l++) {
+            const size_t lo = std::max((size_t)start[l], b), hi = std::min((size_t)start[l + 1], b + n);
+            if (lo >= hi) continue;
+            mi355::launchPreNodes4(in->stream, (const mi355::PreNodeJob*)dJobs + (lo - b), (int)(hi - lo), in->matrices,
+                                   in->weights + (size_t)wIdx * in->C, in->patternWeights, dBlock, in->P, in->C);
+        }
+    }
+    std::vector<double> sums((size_t)count * 2);
+    if (!rc) { mi355::launchEdgeFinal(in->stream, dBlock, count, in->P, dSums); rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); }
+    if (rc) return rc;
+    for (int e = 0; e < count; e++) {
+        if (outSum) outSum[e] = sums[2 * e];
+        if (outSumSquared) outSumSquared[e] = sums[2 * e + 1];
+    }
+    in->prePending = false; in->pendingPre.clear();                // the list has run
+    in->statFusedGradients++;
+    return 0;
+}
+
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared) {
     if (count <= 0) return 0;
     if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (in->prePending) {
+        int rc = outDerivatives ? 1 : fusedGradient(in, postIdx, preIdx, dIdx, wIdx, count, outSum, outSumSquared);
+        if (rc <= 0) return rc;
+        rc = flushPendingPre(in); if (rc) return rc;               // not the shape of one gradient pass: separately
+    }
     std::vector<int> need;
     for (int e = 0; e < count; e++) {
         if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
@@ -173,11 +314,9 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     const size_t perEdgeBytes = (size_t)nb * 2 * sizeof(double) + 2 * sizeof(double) + (outDerivatives ? (size_t)in->P * sizeof(double) : 0);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)256 << 20) / perEdgeBytes));
     chunk = std::min(chunk, 32768);
-    double *dBlock = nullptr, *dSums = nullptr, *dPer = nullptr;
-    HIP_TRY(hipMalloc((void**)&dBlock, (size_t)chunk * nb * 2 * sizeof(double)));
-    hipError_t e1 = hipMalloc((void**)&dSums, (size_t)chunk * 2 * sizeof(double));
-    hipError_t e2 = outDerivatives ? hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) : hipSuccess;
-    int rc = (e1 != hipSuccess || e2 != hipSuccess) ? BEAGLE_ERROR_OUT_OF_MEMORY : 0;
+    int rc = ensureEdgeScratch(in, (size_t)chunk * (nb + 1) * 2 * sizeof(double)); if (rc) return rc;
+    double *dBlock = (double*)in->edgeScratch, *dSums = dBlock + (size_t)chunk * nb * 2, *dPer = nullptr;
+    if (outDerivatives && hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) != hipSuccess) rc = BEAGLE_ERROR_OUT_OF_MEMORY;
     std::vector<mi355::EdgeDesc> descs;
     std::vector<double> sums;
     static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
@@ -208,8 +347,12 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
         if (!direct.empty()) {
             void* dDesc = nullptr;
             rc = uploadTransient(in, direct.data(), direct.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-            mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
-                                           in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
+            if (in->S == 4 && !in->tiled)
+                mi355::launchEdgeDifferentials4(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                                                in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->C);
+            else
+                mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                                               in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
         }
         for (size_t q = 0; q < viaPrune.size() && !rc; q += PRE_SCRATCH) {
             const int n = (int)std::min<size_t>(PRE_SCRATCH, viaPrune.size() - q);
@@ -241,8 +384,7 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
         }
         if (outDerivatives) rc = download(in, outDerivatives + (size_t)b * in->P, dPer, (size_t)m * in->P * sizeof(double));
     }
-    hipStreamSynchronize(in->stream);
-    hipFree(dBlock); hipFree(dSums); if (dPer) hipFree(dPer);
+    if (dPer) { hipStreamSynchronize(in->stream); hipFree(dPer); }
     return rc;
 }
 

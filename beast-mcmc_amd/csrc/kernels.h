@@ -195,6 +195,25 @@ struct EdgeDesc {
     int           slot;          // output row: perPattern[slot][P], blockSums[slot][blocks][2]
     int           pad;
 };
+// 4 states, plain layout (kernels_preorder4.hip): a NODE of the pre-order pass — both children's pre-order partials from one
+// read of pre(parent), post(a), post(b), and both edges' derivative sums on the way.  preA / preB may be NULL (not stored);
+// slotA / slotB < 0: no derivative asked for that edge; dA / dB: the edges' differential matrices.
+struct PreNodeJob {
+    const double* preParent;
+    const void*   postA;         // double [C][P][4], or uint8 states (statesA)
+    const void*   postB;
+    double*       preA;
+    double*       preB;
+    int           matA, matB, dA, dB;
+    int           slotA, slotB, statesA, statesB;
+    double        pad;
+};
+static_assert(sizeof(PreNodeJob) == 80, "PreNodeJob layout");
+void launchPreNodes4(hipStream_t stream, const PreNodeJob* dJobs, int nJobs, const double* matrices, const double* catWeights,
+                     const double* patternWeights, double* blockSums, int P, int C);
+// the edge derivatives alone, same shape (32-byte vector accesses); outputs as launchEdgeDifferentials
+void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
+                              const double* patternWeights, double* perPattern, double* blockSums, int P, int C);
 int  edgeBlocks(int P);          // workgroups per edge = entries per edge in blockSums (x2 doubles)
 // per edge: blockSums[slot][b] = {sum_p w_p num/den, sum_p w_p (num/den)^2} over workgroup b; perPattern (nullable) [slot][P];
 // finish with launchEdgeFinal

@@ -327,6 +327,9 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
  * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the
  * bytes the design has to move (roofline.achieved). */
 int beagleMi355WalkStats(int instance, long* out8);
+/* The gradient pass since instance creation: out[0] pre-order lists that ran together with the edge derivatives that followed
+ * them (one sweep per tree level, 4 states), out[1] pre-order lists that ran operation by operation. */
+int beagleMi355GradientStats(int instance, long* out2);
 /* Bytes of HBM currently allocated by the instance. */
 long beagleMi355DeviceBytes(int instance);
 

@@ -35,8 +35,20 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
     wl = helpers.random_workload(T, P, S, C, seed=100 + S + T)
     g = BranchGradient(wl, rescale=rescale)
     o = BranchGradient(wl, rescale=rescale, library=oracle_lib)
-    lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
+    # sums only: with 4 states (no scale indices in the pre-order list: the derivative ratio is scale-free) the engine holds the list back and runs it together
+    # with the edge derivatives, one sweep per tree level (engine_preorder.cpp fusedGradient); everything else goes operation
+    # by operation — the same numbers either way
+    lf, gf = g.gradient()
+    assert g.b.gradientStats() == ({"fused": 1, "by_operation": 0} if S == 4 else {"fused": 0, "by_operation": 1})
     lo, go, ho, po = o.gradient(second=True, per_pattern=True)
+    assert helpers.rel_err(lf, lo) <= REL_TOL
+    close(gf, go, "gradient (sums only)")
+    for n in range(g.N):
+        if n != wl.tree.root:
+            a, b = g.pre_partials(n).reshape(C, P, S), o.pre_partials(n).reshape(C, P, S)
+            ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
+            assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
+    lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
     assert helpers.rel_err(lg, lo) <= REL_TOL
     close(gg, go, "gradient")
     close(hg, ho, "second derivatives")
@@ -117,6 +129,75 @@ def test_pre_order_entry_points_and_errors(oracle_lib):
         g.b.calculateEdgeDifferentials([0], [10 ** 6], [g.q_index], [0], 1)
     assert e.value.code == -5
     g.close(); o.close(); s.close()
+
+
+def test_held_back_pre_order_list_is_seen_by_every_other_call(oracle_lib):
+    """The 4-state engine defers an unscaled pre-order list until the edge-derivative call (engine_internal.h
+    Instance::pendingPre).  Whatever the caller does in between has to see the list as executed: reading a pre-order
+    partial, rewriting a branch matrix the list uses, asking for derivatives of a subset of the edges, in another order,
+    or for edges the list does not produce."""
+    wl = helpers.random_workload(17, 333, 4, 3, seed=909)
+    g = BranchGradient(wl)
+    o = BranchGradient(wl, library=oracle_lib)
+    lo, go = o.gradient()
+    root = wl.tree.root
+    root_pre = np.tile(wl.freqs, g.P * g.C)
+    post = np.asarray(g.edges, dtype=np.int32)
+    pre = post + g.pre_offset
+    n = len(post)
+
+    def prepare():
+        g.log_likelihood()
+        g.b.setPartials(g.pre_offset + root, root_pre)
+        g.b.updatePrePartials(g._pre_ops, len(g._pre_ops) // 7, bm.beagle.NONE)
+        g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
+
+    def stats():
+        return g.b.gradientStats()
+
+    # 1. a subset of the edges, shuffled: still one fused sweep; every pre-order partial exists afterwards
+    prepare()
+    pick = np.random.default_rng(1).permutation(n)[: n // 2]
+    s1, _, _ = g.b.calculateEdgeDifferentials(post[pick], pre[pick], [g.q_index] * len(pick), [0], len(pick))
+    assert stats() == {"fused": 1, "by_operation": 0}
+    close(s1, go[post[pick]], "subset of the edges")
+    for node in (int(post[0]), int(post[-1])):
+        close(g.pre_partials(node), o.pre_partials(node), "pre-order partial after a subset")
+    # 2. a read of a pre-order partial in between: the list runs at the read
+    prepare()
+    close(g.pre_partials(int(post[3])), o.pre_partials(int(post[3])), "pre-order partial read before the edge call")
+    assert stats() == {"fused": 1, "by_operation": 1}
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
+    close(s1, go[post], "after an intervening read")
+    # 3. a branch matrix of the list rewritten in between (with its own values): the list runs first
+    prepare()
+    m = g.b.getTransitionMatrix(int(post[0]))
+    assert stats()["by_operation"] == 2                            # (getTransitionMatrix is not on the short list of calls that keep it held)
+    prepare()
+    g.b.setTransitionMatrix(int(post[0]), m, 0.0)
+    assert stats()["by_operation"] == 3
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
+    close(s1, go[post], "after a branch matrix was rewritten")
+    # 4. an edge whose pre-order partial the held list does not produce: list first, then the derivatives on what is stored
+    g.log_likelihood()
+    g.b.setPartials(g.pre_offset + root, root_pre)
+    g.b.updatePrePartials(g._pre_ops, len(g._pre_ops) // 7, bm.beagle.NONE)          # all of them, executed by the next call
+    g.b.synchronize()
+    first_two = g._pre_ops[:14]                                                       # the root's two children again
+    g.b.updatePrePartials(first_two, 2, bm.beagle.NONE)
+    g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
+    before = stats()
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
+    assert stats()["fused"] == before["fused"] and stats()["by_operation"] == before["by_operation"] + 1
+    close(s1, go[post], "edges beyond the held list")
+    # 5. half a node (one of two siblings) held: not the fused shape
+    g.b.updatePrePartials(first_two[:7], 1, bm.beagle.NONE)
+    before = stats()
+    e0 = int(first_two[0]) - g.pre_offset
+    s1, _, _ = g.b.calculateEdgeDifferentials([e0], [e0 + g.pre_offset], [g.q_index], [0], 1)
+    assert stats()["fused"] == before["fused"]
+    close(s1, go[[e0]], "one sibling only")
+    g.close(); o.close()
 
 
 def test_gradient_benchmark_sized_tree(oracle_lib):
