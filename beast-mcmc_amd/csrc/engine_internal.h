@@ -76,6 +76,7 @@ struct Instance {
     // reads or writes runs it first (GET_INSTANCE -> flushPendingPre)
     std::vector<int> pendingPre; bool prePending = false; std::vector<char> pendingPreMatrix;   // matrix indices the held list reads
     long statFusedGradients = 0, statPreLists = 0;
+    int storeAllEvaluations = 0;                         // > 0: post-order passes leave no node unstored (a pre-order pass asked for them)
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)
     bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]

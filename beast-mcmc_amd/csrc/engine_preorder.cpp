@@ -97,6 +97,11 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
         }
     }
+    // A pre-order pass reads the post-order partials of (nearly) every node: when it has to have a good part of them
+    // materialised first, the chain is evaluating gradients, and the next post-order passes store what they compute straight
+    // away instead of leaving it to a second walk (runOperationsWalk; 1000 x 20 000: 1.86 -> 0.9 ms for the post-order half).
+    // The hint is renewed by every pre-order list and runs out 16 post-order evaluations after the last one.
+    if ((int)need.size() >= std::max(4, count / 4) || in->storeAllEvaluations > 0) in->storeAllEvaluations = 16;
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     std::vector<OpDesc> descs(count);
     std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
