@@ -384,14 +384,18 @@ class Beagle:
                                                                      cumulativeScaleIndex))
 
     def calculateEdgeDifferentials(self, postBufferIndices, preBufferIndices, derivativeMatrixIndices,
-                                   categoryWeightsIndices, count, want_per_pattern=False):
-        """-> (outSumDerivatives[count], outSumSquaredDerivatives[count], outDerivatives[count, P] or None)"""
+                                   categoryWeightsIndices, count, want_per_pattern=False, want_squared=True):
+        """-> (outSumDerivatives[count], outSumSquaredDerivatives[count] or None, outDerivatives[count, P] or None); the two
+        optional outputs are passed as NULL when not wanted, as the gradient delegates do
+        (AbstractBeagleBranchGradientDelegate.java:82-92)."""
         po, pr, dm, cw = _i(postBufferIndices), _i(preBufferIndices), _i(derivativeMatrixIndices), _i(categoryWeightsIndices)
-        s1, s2 = np.zeros(count), np.zeros(count)
+        s1 = np.zeros(count)
+        s2 = np.zeros(count) if want_squared else None
         per = np.zeros((count, self.patternCount)) if want_per_pattern else None
         self._check("calculateEdgeDifferentials",
                     self._f["CalculateEdgeDifferentials"](self.instance, _ip(po), _ip(pr), _ip(dm), _ip(cw), count,
-                                                          _dp(per) if per is not None else None, _dp(s1), _dp(s2)))
+                                                          _dp(per) if per is not None else None, _dp(s1),
+                                                          _dp(s2) if s2 is not None else None))
         return s1, s2, per
 
     def calculateCrossProductDifferentials(self, postBufferIndices, preBufferIndices, categoryRateIndices,
@@ -454,10 +458,10 @@ class Beagle:
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def gradientStats(self):
-        """Pre-order lists run fused with their edge derivatives / operation by operation (include/beagle_mi355.h)."""
-        out = (C.c_long * 2)()
+        """How the pre-order lists of this instance were run (include/beagle_mi355.h beagleMi355GradientStats)."""
+        out = (C.c_long * 4)()
         self._check("gradientStats", self._ext("beagleMi355GradientStats", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
-        return {"fused": int(out[0]), "by_operation": int(out[1])}
+        return {"fused": int(out[0]), "by_operation": int(out[1]), "walked": int(out[2]), "late": int(out[3])}
 
     def deviceBytes(self):
         return self._ext("beagleMi355DeviceBytes", [C.c_int], C.c_long)(self.instance)

@@ -260,6 +260,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);
     in->fuseGradient = !(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT") && atoi(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT")) != 0);
+    in->preWalk = !(getenv("BEAGLE_MI355_NO_PRE_WALK") && atoi(getenv("BEAGLE_MI355_NO_PRE_WALK")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
@@ -478,8 +479,11 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
 
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternDoubles(instance, inPartials, shardedStates(instance), shardedCategories(instance), [&](int h, const double* v) { return beagleSetPartials(h, bufferIndex, v); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);
     if (badIndex(bufferIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    // (a held-back pre-order list has its own copy of its root's pre-order partial — the buffer the gradient delegates rewrite
+    // before every list — and waits unless this is one of the other buffers it reads or writes)
+    if (heldTouches(in, bufferIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
     int rc = materializeTipUsers(in, bufferIndex); if (rc) return rc;
     clearVirtual(in, bufferIndex);
     rc = ensurePartials(in, bufferIndex); if (rc) return rc;
@@ -690,7 +694,7 @@ int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMat
     if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     // (setDifferentialMatrix arrives between updatePrePartials and calculateEdgeDifferentials: the held-back list stays held
     // unless this very matrix is one of its branch matrices)
-    if (in->prePending && in->pendingPreMatrix[matrixIndex]) { int rcp = flushPendingPre(in); if (rcp) return rcp; }
+    if (heldReadsMatrix(in, matrixIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
     const size_t n = (size_t)in->C * in->S * in->S;
     return upload(in, in->matrices + n * matrixIndex, inMatrix, n * sizeof(double));
 }
@@ -771,8 +775,10 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
         std::vector<int> p(probabilityIndices, probabilityIndices + count); std::vector<double> t(edgeLengths, edgeLengths + count);
         return mi355::shardedPost(instance, [=](int h) { return beagleUpdateTransitionMatrices(h, eigenIndex, p.data(), nullptr, nullptr, t.data(), count); });
     }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list waits unless one of ITS matrices is rewritten)
     if (firstDerivativeIndices || secondDerivativeIndices) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (in->heldPre.held && probabilityIndices)
+        for (int k = 0; k < count; k++) if (heldReadsMatrix(in, probabilityIndices[k])) { int rcp = executeHeldPre(in); if (rcp) return rcp; break; }
     return transitionMatrices(in, nullptr, eigenIndex, nullptr, probabilityIndices, edgeLengths, count);
 }
 
@@ -799,7 +805,14 @@ int beagleUpdatePartials(int instance, const int* operations, int operationCount
         std::vector<int> ops(operations, operations + (size_t)operationCount * BEAGLE_OP_COUNT);
         return mi355::shardedPost(instance, [=](int h) { return beagleUpdatePartials(h, ops.data(), operationCount, cumulativeScaleIndex); });
     }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);
+    if (operations && (in->heldPre.held || !in->scalingSeen))
+        for (int k = 0; k < operationCount; k++) {
+            const int* op = operations + (size_t)k * BEAGLE_OP_COUNT;
+            if (op[1] != BEAGLE_OP_NONE || op[2] != BEAGLE_OP_NONE) in->scalingSeen = true;
+            // (a held-back pre-order list waits unless this list overwrites what it reads or touches what it writes)
+            if (heldTouches(in, op[0]) || heldWrites(in, op[3]) || heldWrites(in, op[5])) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
+        }
     return runOperations(in, operations, operationCount, BEAGLE_OP_COUNT, cumulativeScaleIndex);
 }
 
@@ -896,8 +909,9 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
         if (rc) return rc;
         *outSumLogLikelihood = v;
         return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS; }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);                      // (reads a post-order buffer: a held-back pre-order list writes none)
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;   // BEAST always passes 1 (BeagleTreeLikelihood.java:1038)
+    if (bufferIndices && heldWrites(in, bufferIndices[0])) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
     // the reduction kernel writes the sum and then a sequence number into mapped host memory; the kernel is the last
     // thing in the (in-order) stream, so seeing the number means everything before it has completed
     const unsigned long long seq = ++in->resultSeq;
@@ -1046,7 +1060,7 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);                      // (runPreOperations decides what becomes of a list still held back)
     return runPreOperations(in, operations, operationCount, cumulativeScaleIndex, true);
 }
 
@@ -1117,14 +1131,15 @@ int beagleMi355SetStream(int instance, void* hipStream) {
 int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
                                                  int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut) {
     if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);
     if (!deviceOut) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (heldWrites(in, bufferIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
     return rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
 }
 
 int beagleMi355Synchronize(int instance) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355Synchronize(h); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list is not work in flight)
     HIP_TRY(hipStreamSynchronize(in->stream));
     in->ringHead = 0;
     return BEAGLE_SUCCESS;
@@ -1175,14 +1190,14 @@ int beagleMi355WalkStats(int instance, long* out8) {
     return BEAGLE_SUCCESS;
 }
 
-int beagleMi355GradientStats(int instance, long* out2) {
+int beagleMi355GradientStats(int instance, long* out4) {
     if (mi355::isShardedHandle(instance)) {             // counters of shard 0 (every shard is driven the same way)
         bool first = true; std::mutex mu;
-        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355GradientStats(h, out2); });
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355GradientStats(h, out4); });
     }
     Instance* in = lookup(instance);
-    if (!in || !out2) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
-    out2[0] = in->statFusedGradients; out2[1] = in->statPreLists;
+    if (!in || !out4) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    out4[0] = in->statFusedGradients; out4[1] = in->statPreLists; out4[2] = in->statWalkedGradients; out4[3] = in->statLateLists;
     return BEAGLE_SUCCESS;
 }
 

@@ -71,13 +71,30 @@ struct Instance {
     } resolved[4];
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
-    // 4 states: a pre-order operation list is HELD BACK until the edge-derivative call that follows it arrives, so that both run as
-    // one sweep per tree level (engine_preorder.cpp fusedGradient); anything else that could observe or change what the list
-    // reads or writes runs it first (GET_INSTANCE -> flushPendingPre)
-    std::vector<int> pendingPre; bool prePending = false; std::vector<char> pendingPreMatrix;   // matrix indices the held list reads
-    long statFusedGradients = 0, statPreLists = 0;
+    // 4 states: a pre-order operation list is HELD BACK (engine_preorder.cpp): the chain that evaluates gradients wants the
+    // edge-derivative sums that follow it, not the pre-order partials, and those sums can be had without writing a single
+    // pre-order partial (kernels_preorder4.hip k_preWalk4).  The list stays held — as a closure over what it reads — until a
+    // call reads something it writes or writes something it reads; then it runs first (GET_INSTANCE -> executeHeldPre).
+    // Calls that provably do neither leave it alone (GET_INSTANCE_KEEP_PENDING + heldTouches* below), and a newer list that
+    // rewrites everything it would have written replaces it unexecuted.
+    struct HeldPreNode { int par, preA, preB, postA, postB, matA, matB, level, jobA, jobB, size; };
+    struct HeldPreList {
+        bool held = false;
+        std::vector<int> ops;                            // as the caller wrote it
+        std::vector<HeldPreNode> nodes;                  // one per parent: its two operations together
+        std::vector<int> order;                          // depth-first, smaller subtree first (the walk's program order)
+        std::vector<unsigned> walkFlags;                 // per entry of `order`: PW_* source / continuation bits
+        int maxLevel = 0, holdSlots = 0, rootBuf = -1;
+        std::vector<char> readsMatrix, readsBuf, writesBuf;   // by matrix / partials-buffer index
+    } heldPre;
+    double* preRootCopy = nullptr;                       // the held list's own copy of its root's pre-order partial
+    uint8_t* preDummyStates = nullptr;                   // [P] "missing": what a descriptor's unused tip pointer points at
+    void* dPreProg = nullptr; size_t dPreProgBytes = 0;  // the walk's program on the device (grow-only)
+    bool scalingSeen = false;                            // some updatePartials operation carried a scale index (sticky): den differs per edge
+    long statFusedGradients = 0, statPreLists = 0, statWalkedGradients = 0, statLateLists = 0;
     int storeAllEvaluations = 0;                         // > 0: post-order passes leave no node unstored (a pre-order pass asked for them)
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
+    bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials
     bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)
     bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
     bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
@@ -147,10 +164,12 @@ struct Resources {
 extern const long GPU_FLAGS;
 Resources* resources();
 void setPairLayout(Instance* in);
-int flushPendingPre(Instance* in);
+int executeHeldPre(Instance* in);
+int holdPreList(Instance* in, const int* ops, int count);
+bool supersedesHeld(Instance* in, const int* ops, int count);
 int ensureWalkDummies(Instance* in);
 
-// (a held-back pre-order list — Instance::pendingPre — runs before anything else touches the instance; the few calls that cannot
+// (a held-back pre-order list — Instance::heldPre — runs before anything else touches the instance; the few calls that cannot
 // interact with it use GET_INSTANCE_KEEP_PENDING)
 #define GET_INSTANCE_KEEP_PENDING(h)                             \
     Instance* in = lookup(h);                                    \
@@ -158,7 +177,7 @@ int ensureWalkDummies(Instance* in);
     if (hipSetDevice(in->device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
 #define GET_INSTANCE(h)                                          \
     GET_INSTANCE_KEEP_PENDING(h)                                 \
-    if (in->prePending) { const int rcPending__ = flushPendingPre(in); if (rcPending__) return rcPending__; }
+    if (in->heldPre.held) { const int rcPending__ = executeHeldPre(in); if (rcPending__) return rcPending__; }
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
 
@@ -199,8 +218,12 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
 // ---- engine_preorder.cpp
 int ensurePreScratch(Instance* in);
 int ensureEdgeScratch(Instance* in, size_t bytes);
+// does a call that writes matrix m / reads or writes partials buffer b have to wait for the held pre-order list?
+inline bool heldReadsMatrix(const Instance* in, int m) { return in->heldPre.held && m >= 0 && m < (int)in->heldPre.readsMatrix.size() && in->heldPre.readsMatrix[m]; }
+inline bool heldWrites(const Instance* in, int b) { return in->heldPre.held && b >= 0 && b < (int)in->heldPre.writesBuf.size() && in->heldPre.writesBuf[b]; }
+inline bool heldTouches(const Instance* in, int b) { return in->heldPre.held && b >= 0 && b < (int)in->heldPre.writesBuf.size() && (in->heldPre.writesBuf[b] || in->heldPre.readsBuf[b]); }
 int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold = false);
-int flushPendingPre(Instance* in);
+int executeHeldPre(Instance* in);
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared);
 int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum);

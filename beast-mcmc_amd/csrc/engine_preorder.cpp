@@ -97,6 +97,13 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
         }
     }
+    // a list still held back: the new one replaces it unexecuted when it rewrites everything the old one would have written
+    // without reading any of it first (the chain's next gradient: same destinations, other post-order buffers); otherwise the
+    // old one runs now
+    if (in->heldPre.held) {
+        if (supersedesHeld(in, ops, count)) in->heldPre.held = false;
+        else { int rc = executeHeldPre(in); if (rc) return rc; }
+    }
     // A pre-order pass reads the post-order partials of (nearly) every node: when it has to have a good part of them
     // materialised first, the chain is evaluating gradients, and the next post-order passes store what they compute straight
     // away instead of leaving it to a second walk (runOperationsWalk; 1000 x 20 000: 1.86 -> 0.9 ms for the post-order half).
@@ -134,20 +141,11 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
         wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
     }
-    // 4 states, no rescaling in the list: hold it back — the edge-derivative call that follows (AbstractBeagleBranchGradient-
-    // Delegate.java:82-92) runs it together with the derivatives, one sweep per tree level (fusedGradient below); any other
-    // call runs it first, exactly as written (flushPendingPre).  The bookkeeping above (real operands, destinations allocated
-    // and no longer tips or definitions) is done either way.
+    // 4 states, no rescaling in the list: hold it back (engine_internal.h HeldPreList).  The bookkeeping above (real operands,
+    // destinations allocated and no longer tips or definitions) is done either way.
     if (mayHold && in->fuseGradient && in->S == 4 && !in->tiled && globalCum == BEAGLE_OP_NONE) {
-        bool plain = true;
-        for (int k = 0; k < count && plain; k++) plain = ops[(size_t)k * BEAGLE_OP_COUNT + 1] == BEAGLE_OP_NONE && ops[(size_t)k * BEAGLE_OP_COUNT + 2] == BEAGLE_OP_NONE;
-        if (plain) {
-            in->pendingPre.assign(ops, ops + (size_t)count * BEAGLE_OP_COUNT);
-            in->pendingPreMatrix.assign(in->matrixCount, 0);
-            for (int k = 0; k < count; k++) { in->pendingPreMatrix[ops[(size_t)k * BEAGLE_OP_COUNT + 4]] = 1; in->pendingPreMatrix[ops[(size_t)k * BEAGLE_OP_COUNT + 6]] = 1; }
-            in->prePending = true;
-            return 0;
-        }
+        int rc = holdPreList(in, ops, count);
+        if (rc <= 0) return rc;                                    // held (0) or failed (< 0); 1 = not the shape: run it now
     }
     in->statPreLists++;
     std::vector<int> start(maxLevel + 2, 0);
@@ -192,109 +190,252 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
 
 // Per-edge derivative sums (AbstractBeagleBranchGradientDelegate.java:82-92).  Edges are processed in chunks that bound
 // the scratch memory (block sums, and the optional per-pattern matrix) to a few hundred MB.
-// the held-back list, operation by operation, as the caller wrote it
-int flushPendingPre(Instance* in) {
-    if (!in->prePending) return 0;
-    in->prePending = false;
-    std::vector<int> ops;
-    ops.swap(in->pendingPre);
-    return runPreOperations(in, ops.data(), (int)(ops.size() / BEAGLE_OP_COUNT), BEAGLE_OP_NONE, false);
+// ---- the held-back list (4 states) -----------------------------------------------------------------------------------
+// Does the list `ops` write every buffer the held list would have written, reading none of them before it has written it
+// itself?  (Operations come parent before child, so "its own destinations" are safe to read.)
+bool supersedesHeld(Instance* in, const int* ops, int count) {
+    const Instance::HeldPreList& h = in->heldPre;
+    std::vector<char> dest(in->partialsCount, 0);
+    for (int k = 0; k < count; k++) dest[ops[(size_t)k * BEAGLE_OP_COUNT]] = 1;
+    for (size_t k = 0; k < h.ops.size(); k += BEAGLE_OP_COUNT) if (!dest[h.ops[k]]) return false;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        if (h.writesBuf[op[5]]) return false;                                       // a sibling's post-order partial
+        if (h.writesBuf[op[3]] && !dest[op[3]]) return false;                       // a parent it does not produce itself
+    }
+    return true;
 }
 
-// The held-back pre-order list and the edge derivatives asked for now as ONE sweep per tree level (kernels_preorder4.hip
-// k_preNode4): the two operations below a node become one job that reads pre(node), post(a), post(b) once, writes pre(a) and
-// pre(b) and leaves both edges' derivative sums.  Returns 1 when the two lists do not fit that shape (a parent with one
-// operation, an edge whose post-order buffer is not its node's, per-pattern derivatives wanted, ...): the caller then runs
-// the list and the derivatives separately.
-static int fusedGradient(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
-                         double* outSum, double* outSumSquared) {
-    const int nOps = (int)(in->pendingPre.size() / BEAGLE_OP_COUNT), nBuf = in->partialsCount;
-    std::vector<int> edgeOf(nBuf, -1), jobOfParent(nBuf, -1), jobOfDest(nBuf, -1);
-    for (int e = 0; e < count; e++) {
-        if (badIndex(postIdx[e], nBuf) || badIndex(preIdx[e], nBuf) || badIndex(dIdx[e], in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (edgeOf[preIdx[e]] >= 0) return 1;                    // the same node twice
-        edgeOf[preIdx[e]] = e;
-    }
-    struct Node { int par, preA, preB, postA, postB, matA, matB, level; };
-    std::vector<Node> nodes;
-    for (int k = 0; k < nOps; k++) {
-        const int* op = &in->pendingPre[(size_t)k * BEAGLE_OP_COUNT];
+// Try to hold `ops` back: 0 = held, 1 = not the shape of a gradient pass (the caller runs it now), < 0 = error.  The shape: no
+// scale indices; the two operations below a node come as a pair that agrees on the two branch matrices; ONE node of the list
+// has a parent the list does not produce (the root).
+int holdPreList(Instance* in, const int* ops, int count) {
+    Instance::HeldPreList& h = in->heldPre;
+    const int nBuf = in->partialsCount;
+    for (int k = 0; k < count; k++) if (ops[(size_t)k * BEAGLE_OP_COUNT + 1] != BEAGLE_OP_NONE || ops[(size_t)k * BEAGLE_OP_COUNT + 2] != BEAGLE_OP_NONE) return 1;
+    std::vector<int> jobOfParent(nBuf, -1), jobOfDest(nBuf, -1);
+    std::vector<Instance::HeldPreNode> nodes;
+    for (int k = 0; k < count; k++) {
+        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
         const int dest = op[0], par = op[3], mc = op[4], sib = op[5], ms = op[6];
         if (jobOfDest[dest] >= 0) return 1;
         int j = jobOfParent[par];
         if (j < 0) {
             j = (int)nodes.size(); jobOfParent[par] = j;
-            Node nd; nd.par = par; nd.preA = dest; nd.matA = mc; nd.postB = sib; nd.matB = ms; nd.preB = -1; nd.postA = -1;
+            Instance::HeldPreNode nd; nd.par = par; nd.preA = dest; nd.matA = mc; nd.postB = sib; nd.matB = ms; nd.preB = -1; nd.postA = -1;
+            nd.jobA = nd.jobB = -1; nd.size = 1;
             nd.level = jobOfDest[par] >= 0 ? nodes[jobOfDest[par]].level + 1 : 0;      // (a parent's operation precedes its children's)
             nodes.push_back(nd);
         } else {
-            Node& nd = nodes[j];
+            Instance::HeldPreNode& nd = nodes[j];
             if (nd.preB >= 0 || mc != nd.matB || ms != nd.matA) return 1;
             nd.preB = dest; nd.postA = sib;
         }
         jobOfDest[dest] = j;
     }
-    int covered = 0, maxLevel = 0;
-    for (const Node& nd : nodes) {
+    int root = -1, maxLevel = 0;
+    for (size_t j = 0; j < nodes.size(); j++) {
+        Instance::HeldPreNode& nd = nodes[j];
         if (nd.preB < 0) return 1;
-        for (int w = 0; w < 2; w++) {
-            const int e = edgeOf[w ? nd.preB : nd.preA];
-            if (e < 0) continue;
-            if (postIdx[e] != (w ? nd.postB : nd.postA)) return 1;
-            covered++;
-        }
+        if (jobOfDest[nd.par] < 0) { if (root >= 0) return 1; root = (int)j; }
+        nd.jobA = jobOfParent[nd.preA]; nd.jobB = jobOfParent[nd.preB];
         maxLevel = std::max(maxLevel, nd.level);
-    }
-    if (covered != count) return 1;                                // an edge whose pre-order partial the held list does not produce
-    const int nb = mi355::edgeBlocks(in->P);
-    if ((size_t)count * nb * 2 * sizeof(double) > ((size_t)512 << 20)) return 1;
-    // jobs, level by level
-    std::vector<mi355::PreNodeJob> jobs(nodes.size());
-    std::vector<int> start(maxLevel + 2, 0), order(nodes.size());
-    for (const Node& nd : nodes) start[nd.level + 1]++;
-    for (int l = 0; l <= maxLevel; l++) start[l + 1] += start[l];
-    { std::vector<int> fill(start.begin(), start.end() - 1); for (size_t j = 0; j < nodes.size(); j++) order[fill[nodes[j].level]++] = (int)j; }
-    for (size_t q = 0; q < nodes.size(); q++) {
-        const Node& nd = nodes[order[q]];
-        mi355::PreNodeJob& jb = jobs[q];
-        memset(&jb, 0, sizeof(jb));
+        for (int w = 0; w < 2; w++) {                              // what the kernels will dereference has to be there
+            const int po = w ? nd.postB : nd.postA;
+            if (!(in->tipStates[po] && po < in->tipCount) && !in->partials[po]) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (jobOfDest[po] >= 0) return 1;                      // a post-order operand that is one of the list's own destinations
+        }
         if (!in->partials[nd.par] || !in->partials[nd.preA] || !in->partials[nd.preB]) return BEAGLE_ERROR_OUT_OF_RANGE;
-        jb.preParent = in->partials[nd.par]; jb.preA = in->partials[nd.preA]; jb.preB = in->partials[nd.preB];
+    }
+    if (root < 0) return 1;
+    // (operations come parent first: a node's job index is larger than its parent's) subtree sizes, bottom-up
+    for (size_t j = nodes.size(); j-- > 0;) {
+        const Instance::HeldPreNode& nd = nodes[j];
+        if (nd.jobA >= 0 && nd.jobA <= (int)j) return 1;
+        if (nd.jobB >= 0 && nd.jobB <= (int)j) return 1;
+        nodes[j].size = 1 + (nd.jobA >= 0 ? nodes[nd.jobA].size : 0) + (nd.jobB >= 0 ? nodes[nd.jobB].size : 0);
+    }
+    // the walk's order: depth first, the smaller subtree first, the other child's partial parked in a hold slot meanwhile
+    h.order.clear(); h.walkFlags.clear(); h.holdSlots = 0;
+    {
+        std::vector<std::pair<int, int>> parked;                   // (job, hold slot)
+        int j = root; unsigned src = 0;
+        while (j >= 0) {
+            const Instance::HeldPreNode& nd = nodes[j];
+            unsigned contA = 0, contB = 0;
+            int next = -1; unsigned nextSrc = 0;
+            if (nd.jobA >= 0 && nd.jobB >= 0) {
+                const bool aFirst = nodes[nd.jobA].size <= nodes[nd.jobB].size;
+                const int slot = (int)parked.size();
+                h.holdSlots = std::max(h.holdSlots, slot + 1);
+                (aFirst ? contA : contB) = 1u; (aFirst ? contB : contA) = 2u + (unsigned)slot;
+                parked.emplace_back(aFirst ? nd.jobB : nd.jobA, slot);
+                next = aFirst ? nd.jobA : nd.jobB;
+            } else if (nd.jobA >= 0) { contA = 1u; next = nd.jobA; }
+            else if (nd.jobB >= 0) { contB = 1u; next = nd.jobB; }
+            else if (!parked.empty()) { next = parked.back().first; nextSrc = 1u + (unsigned)parked.back().second; parked.pop_back(); }
+            h.order.push_back(j);
+            h.walkFlags.push_back((src << mi355::PW_SRC_SHIFT) | (contA << mi355::PW_CONT_A_SHIFT) | (contB << mi355::PW_CONT_B_SHIFT));
+            j = next; src = nextSrc;
+        }
+        if (h.order.size() != nodes.size()) return 1;              // (cannot happen for a tree)
+    }
+    // its own copy of the root's pre-order partial: the caller rewrites that buffer before every list (simulateRoot,
+    // AbstractBeagleGradientDelegate.java:142-151), which must not force this list to run
+    if (!in->preRootCopy) { void* q = nullptr; int rc = devAlloc(in, &q, in->partialsBytes); if (rc) return rc; in->preRootCopy = (double*)q; }
+    HIP_TRY(hipMemcpyAsync(in->preRootCopy, in->partials[nodes[root].par], in->partialsBytes, hipMemcpyDeviceToDevice, in->stream));
+    h.rootBuf = nodes[root].par;
+    h.ops.assign(ops, ops + (size_t)count * BEAGLE_OP_COUNT);
+    h.nodes.swap(nodes);
+    h.maxLevel = maxLevel;
+    h.readsMatrix.assign(in->matrixCount, 0); h.readsBuf.assign(nBuf, 0); h.writesBuf.assign(nBuf, 0);
+    for (const Instance::HeldPreNode& nd : h.nodes) {
+        h.readsMatrix[nd.matA] = h.readsMatrix[nd.matB] = 1;
+        h.readsBuf[nd.postA] = h.readsBuf[nd.postB] = 1;
+        h.writesBuf[nd.preA] = h.writesBuf[nd.preB] = 1;
+    }
+    h.held = true;
+    return 0;
+}
+
+// jobs of the held list for k_preNode4, level by level; start[l] .. start[l + 1] = level l.  edgeOf (nullable): buffer -> edge slot
+static int heldJobs(Instance* in, const int* edgeOf, const int* dIdx, std::vector<mi355::PreNodeJob>& jobs, std::vector<int>& start) {
+    const Instance::HeldPreList& h = in->heldPre;
+    start.assign(h.maxLevel + 2, 0);
+    for (const Instance::HeldPreNode& nd : h.nodes) start[nd.level + 1]++;
+    for (int l = 0; l <= h.maxLevel; l++) start[l + 1] += start[l];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    jobs.resize(h.nodes.size());
+    for (const Instance::HeldPreNode& nd : h.nodes) {
+        mi355::PreNodeJob& jb = jobs[fill[nd.level]++];
+        memset(&jb, 0, sizeof(jb));
+        jb.preParent = nd.par == h.rootBuf ? in->preRootCopy : in->partials[nd.par];
+        jb.preA = in->partials[nd.preA]; jb.preB = in->partials[nd.preB];
         for (int w = 0; w < 2; w++) {
             const int po = w ? nd.postB : nd.postA;
-            const void* ptr; int st;
-            if (in->tipStates[po] && po < in->tipCount) { ptr = in->tipStates[po]; st = 1; }
-            else if (in->partials[po]) { ptr = in->partials[po]; st = 0; }
-            else return BEAGLE_ERROR_OUT_OF_RANGE;
-            const int e = edgeOf[w ? nd.preB : nd.preA];
+            const bool st = in->tipStates[po] && po < in->tipCount;
+            const void* ptr = st ? (const void*)in->tipStates[po] : (const void*)in->partials[po];
+            const int e = edgeOf ? edgeOf[w ? nd.preB : nd.preA] : -1;
             if (w) { jb.postB = ptr; jb.statesB = st; jb.slotB = e; jb.dB = e >= 0 ? dIdx[e] : 0; }
             else { jb.postA = ptr; jb.statesA = st; jb.slotA = e; jb.dA = e >= 0 ? dIdx[e] : 0; }
         }
         jb.matA = nd.matA; jb.matB = nd.matB;
     }
-    int rc = ensureEdgeScratch(in, (size_t)count * (nb + 1) * 2 * sizeof(double)); if (rc) return rc;
-    double *dBlock = (double*)in->edgeScratch, *dSums = dBlock + (size_t)count * nb * 2;
+    return 0;
+}
+static int launchHeldLevels(Instance* in, const std::vector<mi355::PreNodeJob>& jobs, const std::vector<int>& start, int wIdx, double* dBlock) {
     const size_t maxChunk = (RING_BYTES / 4) / sizeof(mi355::PreNodeJob);
-    for (size_t b = 0; b < jobs.size() && !rc; b += maxChunk) {
+    for (size_t b = 0; b < jobs.size(); b += maxChunk) {
         const size_t n = std::min(maxChunk, jobs.size() - b);
         void* dJobs = nullptr;
-        rc = uploadTransient(in, &jobs[b], n * sizeof(mi355::PreNodeJob), &dJobs); if (rc) break;
-        for (int l = 0; l <= maxLevel; l++) {
+        int rc = uploadTransient(in, &jobs[b], n * sizeof(mi355::PreNodeJob), &dJobs); if (rc) return rc;
+        for (size_t l = 0; l + 1 < start.size(); l++) {
             const size_t lo = std::max((size_t)start[l], b), hi = std::min((size_t)start[l + 1], b + n);
             if (lo >= hi) continue;
             mi355::launchPreNodes4(in->stream, (const mi355::PreNodeJob*)dJobs + (lo - b), (int)(hi - lo), in->matrices,
                                    in->weights + (size_t)wIdx * in->C, in->patternWeights, dBlock, in->P, in->C);
         }
     }
+    return 0;
+}
+
+// the held list runs: every pre-order partial it defines is written (one sweep per tree level, k_preNode4)
+int executeHeldPre(Instance* in) {
+    if (!in->heldPre.held) return 0;
+    std::vector<mi355::PreNodeJob> jobs; std::vector<int> start;
+    heldJobs(in, nullptr, nullptr, jobs, start);
+    in->heldPre.held = false;
+    in->statLateLists++;
+    return launchHeldLevels(in, jobs, start, 0, nullptr);
+}
+
+// which edge asks for which destination of the held list; 1 = the edges are not (all) edges of the held list
+static int heldEdges(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int count, std::vector<int>& edgeOf) {
+    const Instance::HeldPreList& h = in->heldPre;
+    edgeOf.assign(in->partialsCount, -1);
+    for (int e = 0; e < count; e++) {
+        if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+        if (edgeOf[preIdx[e]] >= 0 || !h.writesBuf[preIdx[e]]) return 1;
+        edgeOf[preIdx[e]] = e;
+    }
+    for (const Instance::HeldPreNode& nd : h.nodes)
+        for (int w = 0; w < 2; w++) {
+            const int e = edgeOf[w ? nd.preB : nd.preA];
+            if (e >= 0 && postIdx[e] != (w ? nd.postB : nd.postA)) return 1;
+        }
+    return 0;
+}
+
+// The held list and the edge derivatives asked for now as ONE sweep per tree level (k_preNode4): pre-order partials written,
+// sums and sums of squares of the per-pattern derivatives.  The list has run afterwards.
+static int fusedGradient(Instance* in, const std::vector<int>& edgeOf, const int* dIdx, int wIdx, int count, double* outSum, double* outSumSquared) {
+    const int nb = mi355::edgeBlocks(in->P);
+    if ((size_t)count * nb * 2 * sizeof(double) > ((size_t)512 << 20)) return 1;
+    std::vector<mi355::PreNodeJob> jobs; std::vector<int> start;
+    heldJobs(in, edgeOf.data(), dIdx, jobs, start);
+    int rc = ensureEdgeScratch(in, (size_t)count * (nb + 1) * 2 * sizeof(double)); if (rc) return rc;
+    double *dBlock = (double*)in->edgeScratch, *dSums = dBlock + (size_t)count * nb * 2;
+    in->heldPre.held = false;                                      // (whatever happens below, the destinations are being written)
+    rc = launchHeldLevels(in, jobs, start, wIdx, dBlock); if (rc) return rc;
     std::vector<double> sums((size_t)count * 2);
-    if (!rc) { mi355::launchEdgeFinal(in->stream, dBlock, count, in->P, dSums); rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); }
-    if (rc) return rc;
+    mi355::launchEdgeFinal(in->stream, dBlock, count, in->P, dSums);
+    rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) return rc;
     for (int e = 0; e < count; e++) {
         if (outSum) outSum[e] = sums[2 * e];
         if (outSumSquared) outSumSquared[e] = sums[2 * e + 1];
     }
-    in->prePending = false; in->pendingPre.clear();                // the list has run
     in->statFusedGradients++;
+    return 0;
+}
+
+// The sums alone, nothing written (k_preWalk4): the list STAYS held.  1 = this list / instance cannot be walked.
+static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const int* dIdx, int wIdx, int count, double* outSum) {
+    const Instance::HeldPreList& h = in->heldPre;
+    if (!in->preWalk || in->scalingSeen || h.holdSlots > mi355::PW_MAX_HOLD || in->C > 16) return 1;
+    const int waves = mi355::preWalkWaves(in->P, in->C);
+    const size_t sumBytes = (size_t)(count + 1) * waves * sizeof(double), outBytes = (size_t)count * sizeof(double);
+    if (sumBytes > ((size_t)1 << 30)) return 1;
+    if ((size_t)h.holdSlots * in->C * 128 * 16 > 160 * 1024) return 1;
+    if (!in->preDummyStates) {
+        void* q = nullptr; int rc = devAlloc(in, &q, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
+        in->preDummyStates = (uint8_t*)q;
+        HIP_TRY(hipMemsetAsync(in->preDummyStates, 4, (size_t)in->P, in->stream));
+    }
+    const size_t nOps = (h.order.size() + 1) & ~(size_t)1;
+    std::vector<mi355::PreWalkOp> prog(nOps + 2);
+    for (size_t k = 0; k < prog.size(); k++) {
+        mi355::PreWalkOp& op = prog[k];
+        memset(&op, 0, sizeof(op));
+        op.postA = op.postB = in->preRootCopy; op.tipA = op.tipB = in->preDummyStates; op.slotA = op.slotB = count;
+        if (k >= h.order.size()) continue;                         // padding: computes on valid memory, contributes to the spare slot
+        const Instance::HeldPreNode& nd = h.nodes[h.order[k]];
+        op.flags = h.walkFlags[k];
+        for (int w = 0; w < 2; w++) {
+            const int po = w ? nd.postB : nd.postA;
+            const bool st = in->tipStates[po] && po < in->tipCount;
+            const int e = edgeOf[w ? nd.preB : nd.preA];
+            if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else op.postB = in->partials[po]; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
+            else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else op.postA = in->partials[po]; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+        }
+        op.matA = nd.matA; op.matB = nd.matB;
+    }
+    const size_t progBytes = prog.size() * sizeof(mi355::PreWalkOp);
+    if (progBytes > RING_BYTES / 2) return 1;
+    if (progBytes > in->dPreProgBytes) {
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        void* q = nullptr; int rc = devAlloc(in, &q, progBytes * 2); if (rc) return rc;      // (the old, smaller one stays allocated until the instance goes)
+        in->dPreProg = q; in->dPreProgBytes = progBytes * 2;
+    }
+    int rc = ensureEdgeScratch(in, sumBytes + outBytes); if (rc) return rc;
+    double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes);
+    rc = upload(in, in->dPreProg, prog.data(), progBytes); if (rc) return rc;
+    if (!mi355::launchPreWalk4(in->stream, (const mi355::PreWalkOp*)in->dPreProg, (int)nOps, in->preRootCopy, in->matrices,
+                               in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots)) return 1;
+    mi355::launchPreWalkFinal(in->stream, dSums, count, in->P, in->C, dOut);
+    std::vector<double> out(count);
+    rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;
+    if (outSum) memcpy(outSum, out.data(), outBytes);
+    in->statWalkedGradients++;
     return 0;
 }
 
@@ -302,10 +443,15 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
                       double* outDerivatives, double* outSum, double* outSumSquared) {
     if (count <= 0) return 0;
     if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
-    if (in->prePending) {
-        int rc = outDerivatives ? 1 : fusedGradient(in, postIdx, preIdx, dIdx, wIdx, count, outSum, outSumSquared);
-        if (rc <= 0) return rc;
-        rc = flushPendingPre(in); if (rc) return rc;               // not the shape of one gradient pass: separately
+    if (in->heldPre.held) {
+        // a held-back pre-order list (the usual case: these are its edges).  Sums only: no pre-order partial is written and the
+        // list stays held; sums of squares as well: the list runs together with the derivatives; anything else: it runs first
+        std::vector<int> edgeOf;
+        int rc = outDerivatives ? 1 : heldEdges(in, postIdx, preIdx, dIdx, count, edgeOf);
+        if (rc < 0) return rc;
+        if (rc == 0 && !outSumSquared) { rc = walkedGradient(in, edgeOf, dIdx, wIdx, count, outSum); if (rc <= 0) return rc; rc = 0; }
+        if (rc == 0) { rc = fusedGradient(in, edgeOf, dIdx, wIdx, count, outSum, outSumSquared); if (rc <= 0) return rc; }
+        rc = executeHeldPre(in); if (rc) return rc;
     }
     std::vector<int> need;
     for (int e = 0; e < count; e++) {

@@ -211,6 +211,32 @@ struct PreNodeJob {
 static_assert(sizeof(PreNodeJob) == 80, "PreNodeJob layout");
 void launchPreNodes4(hipStream_t stream, const PreNodeJob* dJobs, int nJobs, const double* matrices, const double* catWeights,
                      const double* patternWeights, double* blockSums, int P, int C);
+// 4 states: the edge derivative SUMS of a whole pre-order list in one launch, no pre-order partial written (kernels_preorder4.hip
+// k_preWalk4).  One descriptor per node of the list, in depth-first order; the node's own pre-order partial is in the thread's
+// registers (it was produced by the previous descriptor) or in one of the LDS hold slots.
+struct PreWalkOp {
+    const void*    postA;        // double [C][P][4]; any valid partials buffer when the child is a compact tip
+    const void*    postB;
+    const uint8_t* tipA;         // uint8 states [P]; any valid states array when the child has partials
+    const uint8_t* tipB;
+    int            matA, matB, dA, dB;
+    int            slotA, slotB; // where the edges' sums go (the launch's last slot = nobody asked)
+    unsigned       flags;        // PW_* below
+    int            pad;
+};
+static_assert(sizeof(PreWalkOp) == 64, "PreWalkOp layout");
+constexpr unsigned PW_TIP_A = 1u, PW_TIP_B = 2u;          // the child is a compact tip
+constexpr int PW_SRC_SHIFT = 4, PW_CONT_A_SHIFT = 8, PW_CONT_B_SHIFT = 12;   // 4 bits each
+// source of the node's pre-order partial: 0 = the registers, 1 + k = hold slot k
+// what becomes of a child's pre-order partial: 0 = nothing below it, 1 = the registers (the next descriptor is that child),
+// 2 + k = hold slot k (its descriptor comes after the other child's subtree)
+constexpr int PW_MAX_HOLD = 13;
+// nOps even, followed by two more no-op descriptors; sums [nSlots + 1][waves] with waves = preWalkWaves(P, C); rootPre = the
+// pre-order partial of the list's root
+int  preWalkWaves(int P, int C);
+bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, int nOps, const double* rootPre, const double* matrices,
+                    const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots);
+void launchPreWalkFinal(hipStream_t stream, const double* sums, int nSlots, int P, int C, double* out);
 // the edge derivatives alone, same shape (32-byte vector accesses); outputs as launchEdgeDifferentials
 void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
                               const double* patternWeights, double* perPattern, double* blockSums, int P, int C);

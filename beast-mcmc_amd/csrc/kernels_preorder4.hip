@@ -140,4 +140,214 @@ void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nE
     }
 }
 
+// ---- the derivative sums of a whole list, nothing stored --------------------------------------------------------------
+// The chain that evaluates gradients asks for updatePrePartials and then for the SUMS of calculateEdgeDifferentials; the
+// pre-order partials themselves are rarely looked at.  k_preWalk4 therefore runs the whole list as a depth-first walk, like
+// the post-order pattern walk (kernels_walk4.hip): a thread owns (pattern, category) — wave w of the workgroup = category w —
+// and carries the pre-order partial of the node it stands on in registers; at a node it reads post(a) and post(b), forms
+// both children's pre-order partials and both edges' contributions, steps into one child and parks the other child's
+// partial in an LDS hold slot until that subtree is done (the host orders the walk smaller subtree first, so the slots in
+// use never exceed log2 of the node count).  No pre-order partial goes to memory (the engine writes them when somebody
+// asks: engine_preorder.cpp), so the pass reads each post-order partial once and writes a few doubles per edge and wave.
+//
+// The sum over categories inside a pattern's derivative, sum_c w_c num_c / sum_c w_c den_c, would need the categories'
+// waves to meet at every edge.  It does not have to: den = sum_c w_c pre . post is the pattern's likelihood and the same on
+// every edge (post-order partials that carry no scale factors — the engine checks), so it is formed ONCE, at the root, and
+// each thread multiplies its numerators by weight_p w_c / den_p; everything after that is a plain sum.
+//
+// Loads are software-pipelined by hand exactly as in k_walk4: while descriptor k computes, the ten loads of k + 1 are in
+// flight (every descriptor issues the same ten, so the wait is a constant vmcnt(10); loads return in issue order and stores
+// in the queue only make the wait stricter).  The branch matrices and the differential matrices arrive spread over the
+// lanes of one register each (lane l = entry l & 15) and are applied with v_fmac_f64_dpp row_newbcast — no LDS, no SGPRs.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+#define MI355_CONST __attribute__((address_space(4)))
+
+struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb; double mA, mB, dA, dB; };
+struct PreDesc { u64 postA, postB, tipA, tipB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
+
+__device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
+    PreDesc d;
+    d.postA = (u64)p->postA; d.postB = (u64)p->postB; d.tipA = (u64)p->tipA; d.tipB = (u64)p->tipB;
+    d.matA = p->matA; d.matB = p->matB; d.dA = p->dA; d.dB = p->dB; d.slotA = p->slotA; d.slotB = p->slotB; d.flags = p->flags;
+    return d;
+}
+__device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, u64 matrices, unsigned matBytes) {
+    const u64 mA = matrices + (u64)(unsigned)d.matA * matBytes, mB = matrices + (u64)(unsigned)d.matB * matBytes;
+    const u64 dA = matrices + (u64)(unsigned)d.dA * matBytes, dB = matrices + (u64)(unsigned)d.dB * matBytes;
+    asm volatile(
+        "global_load_dwordx4 %[a0], %[oP], %[pA]\n\t"
+        "global_load_dwordx4 %[a1], %[oP], %[pA] offset:16\n\t"
+        "global_load_dwordx4 %[b0], %[oP], %[pB]\n\t"
+        "global_load_dwordx4 %[b1], %[oP], %[pB] offset:16\n\t"
+        "global_load_ubyte %[sa], %[oT], %[tA]\n\t"
+        "global_load_ubyte %[sb], %[oT], %[tB]\n\t"
+        "global_load_dwordx2 %[mA], %[oM], %[smA]\n\t"
+        "global_load_dwordx2 %[mB], %[oM], %[smB]\n\t"
+        "global_load_dwordx2 %[dA], %[oM], %[sdA]\n\t"
+        "global_load_dwordx2 %[dB], %[oM], %[sdB]"
+        : [a0] "+v"(f.a0), [a1] "+v"(f.a1), [b0] "+v"(f.b0), [b1] "+v"(f.b1), [sa] "+v"(f.sa), [sb] "+v"(f.sb),
+          [mA] "+v"(f.mA), [mB] "+v"(f.mB), [dA] "+v"(f.dA), [dB] "+v"(f.dB)
+        : [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
+          [smA] "s"(mA), [smB] "s"(mB), [sdA] "s"(dA), [sdB] "s"(dB)
+        : "memory");
+}
+__device__ __forceinline__ void preWait(PreFetched& f) {
+    asm volatile("s_waitcnt vmcnt(10)"
+        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB) : : "memory");
+}
+// (ya, yb) = (MA xa, MB xb), the matrices spread over the lanes (lane l = entry l & 15, row-major): eight independent chains
+__device__ __forceinline__ void matvecDppPair(const double mA, const v4d xa, const double mB, const v4d xb, v4d& ya, v4d& yb) {
+    double a0, a1, a2, a3, b0, b1, b2, b3;
+    const double p0 = xa.x, p1 = xa.y, p2 = xa.z, p3 = xa.w, q0 = xb.x, q1 = xb.y, q2 = xb.z, q3 = xb.w;
+#define FA(Y, N, X) "v_fmac_f64_dpp %[" #Y "], %[mA], %[" #X "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+#define FB(Y, N, X) "v_fmac_f64_dpp %[" #Y "], %[mB], %[" #X "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile(
+        "v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\tv_mov_b64 %[a2], 0\n\tv_mov_b64 %[a3], 0\n\t"
+        "v_mov_b64 %[b0], 0\n\tv_mov_b64 %[b1], 0\n\tv_mov_b64 %[b2], 0\n\tv_mov_b64 %[b3], 0\n\t"
+        FA(a0, 0, p0) FA(a1, 4, p0) FA(a2, 8, p0) FA(a3, 12, p0) FB(b0, 0, q0) FB(b1, 4, q0) FB(b2, 8, q0) FB(b3, 12, q0)
+        FA(a0, 1, p1) FA(a1, 5, p1) FA(a2, 9, p1) FA(a3, 13, p1) FB(b0, 1, q1) FB(b1, 5, q1) FB(b2, 9, q1) FB(b3, 13, q1)
+        FA(a0, 2, p2) FA(a1, 6, p2) FA(a2, 10, p2) FA(a3, 14, p2) FB(b0, 2, q2) FB(b1, 6, q2) FB(b2, 10, q2) FB(b3, 14, q2)
+        FA(a0, 3, p3) FA(a1, 7, p3) FA(a2, 11, p3) FA(a3, 15, p3) FB(b0, 3, q3) FB(b1, 7, q3) FB(b2, 11, q3) FB(b3, 15, q3)
+        "s_nop 0"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+        : [mA] "v"(mA), [mB] "v"(mB), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3));
+    ya = v4d{a0, a1, a2, a3}; yb = v4d{b0, b1, b2, b3};
+}
+// the transposes: (ya, yb) = (MA^T xa, MB^T xb)
+__device__ __forceinline__ void matvecDppPairT(const double mA, const v4d xa, const double mB, const v4d xb, v4d& ya, v4d& yb) {
+    double a0, a1, a2, a3, b0, b1, b2, b3;
+    const double p0 = xa.x, p1 = xa.y, p2 = xa.z, p3 = xa.w, q0 = xb.x, q1 = xb.y, q2 = xb.z, q3 = xb.w;
+    asm volatile(
+        "v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\tv_mov_b64 %[a2], 0\n\tv_mov_b64 %[a3], 0\n\t"
+        "v_mov_b64 %[b0], 0\n\tv_mov_b64 %[b1], 0\n\tv_mov_b64 %[b2], 0\n\tv_mov_b64 %[b3], 0\n\t"
+        FA(a0, 0, p0) FA(a1, 1, p0) FA(a2, 2, p0) FA(a3, 3, p0) FB(b0, 0, q0) FB(b1, 1, q0) FB(b2, 2, q0) FB(b3, 3, q0)
+        FA(a0, 4, p1) FA(a1, 5, p1) FA(a2, 6, p1) FA(a3, 7, p1) FB(b0, 4, q1) FB(b1, 5, q1) FB(b2, 6, q1) FB(b3, 7, q1)
+        FA(a0, 8, p2) FA(a1, 9, p2) FA(a2, 10, p2) FA(a3, 11, p2) FB(b0, 8, q2) FB(b1, 9, q2) FB(b2, 10, q2) FB(b3, 11, q2)
+        FA(a0, 12, p3) FA(a1, 13, p3) FA(a2, 14, p3) FA(a3, 15, p3) FB(b0, 12, q3) FB(b1, 13, q3) FB(b2, 14, q3) FB(b3, 15, q3)
+        "s_nop 0"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+        : [mA] "v"(mA), [mB] "v"(mB), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3));
+    ya = v4d{a0, a1, a2, a3}; yb = v4d{b0, b1, b2, b3};
+}
+#undef FA
+#undef FB
+// v + (the value another lane holds, 0 where the pattern has no source lane / the row is masked off)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dppAdd(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+// lane 63 <- the sum over the wave, in a fixed order (row_shr 1, 2, 4, 8: lane 15 of every row holds the row's sum; then
+// row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ double waveSumTo63(double v) {
+    v = dppAdd<0x111, 0xf>(v); v = dppAdd<0x112, 0xf>(v); v = dppAdd<0x114, 0xf>(v); v = dppAdd<0x118, 0xf>(v);
+    v = dppAdd<0x142, 0xa>(v); v = dppAdd<0x143, 0xc>(v);
+    return v;
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, int nOps, const double* __restrict__ rootPre,
+                                                   const double* __restrict__ matrices, const double* __restrict__ catWeights,
+                                                   const double* __restrict__ patternWeights, double* __restrict__ sums, int P, int C) {
+    extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d), then exch[C][64] (double) at the END (see launcher)
+    const int lane = threadIdx.x & 63;
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = (int)blockIdx.x * 64 + lane;
+    const bool valid = p < P;
+    const int q = valid ? p : P - 1;                  // lanes past the end recompute the last pattern and count for nothing
+    const unsigned oPart = (unsigned)(((size_t)c * P + q) * 32), oTip = (unsigned)q, oMat = (unsigned)(c * 128 + (lane & 15) * 8);
+    const unsigned matBytes = (unsigned)C * 128u;
+    const u64 mats = (u64)matrices;
+    const size_t waves = (size_t)gridDim.x * C, w = (size_t)blockIdx.x * C + c;
+    v2d* holdBase = preLds + (size_t)c * 128 + lane;  // + slot * C * 128, second half at + 64
+    const size_t holdStride = (size_t)C * 128;
+
+    PreDesc D0 = loadPreDesc(prog), D1 = loadPreDesc(prog + 1);
+    const PreWalkOp MI355_CONST* dp = prog;
+    PreFetched A, B;
+    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0;
+    B = A;
+    preIssue(A, D0, oPart, oTip, oMat, mats, matBytes);
+    const v4d root = gptr(reinterpret_cast<const v4d*>(rootPre))[(size_t)c * P + q];
+    v4d ACC = root;
+    // the pattern's likelihood, once: den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
+    double coef;
+    {
+        const PreWalkOp MI355_CONST& r = prog[0];
+        const v4d xa = (r.flags & PW_TIP_A) ? tipVector(gptr(r.tipA)[q]) : gptr(reinterpret_cast<const v4d*>(r.postA))[(size_t)c * P + q];
+        const v4d xb = (r.flags & PW_TIP_B) ? tipVector(gptr(r.tipB)[q]) : gptr(reinterpret_cast<const v4d*>(r.postB))[(size_t)c * P + q];
+        const v4d ua = matvec4(matrices + ((size_t)r.matA * C + c) * 16, xa), ub = matvec4(matrices + ((size_t)r.matB * C + c) * 16, xb);
+        double* exch = reinterpret_cast<double*>(preLds) + (size_t)(blockDim.x >> 6) * 0;   // the hold slots are empty now: the exchange borrows slot 0
+        exch[c * 64 + lane] = catWeights[c] * dot4(root, ua * ub);
+        __syncthreads();
+        double den = 0.0;
+        for (int cc = 0; cc < C; cc++) den += exch[cc * 64 + lane];
+        __syncthreads();
+        coef = valid ? patternWeights[p] * catWeights[c] / den : 0.0;
+    }
+
+#define PRE_STAGE(CUR, NXT, DCUR, DNXT)                                                                                     \
+    {                                                                                                                     \
+        preIssue(NXT, DNXT, oPart, oTip, oMat, mats, matBytes);                                                           \
+        const unsigned fl = DCUR.flags;                                                                                   \
+        const int slotA = DCUR.slotA, slotB = DCUR.slotB;                                                                 \
+        const unsigned src = (fl >> PW_SRC_SHIFT) & 15u, contA = (fl >> PW_CONT_A_SHIFT) & 15u, contB = (fl >> PW_CONT_B_SHIFT) & 15u; \
+        v4d pn = ACC;                                                                                                     \
+        if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; pn = v4d{lo.x, lo.y, hi.x, hi.y}; } \
+        preWait(CUR);                                                                                                     \
+        v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
+        if (fl & PW_TIP_A) xa = tipVector((int)CUR.sa);                                                                   \
+        if (fl & PW_TIP_B) xb = tipVector((int)CUR.sb);                                                                   \
+        v4d ua, ub, pa, pb, va, vb;                                                                                       \
+        matvecDppPair(CUR.mA, xa, CUR.mB, xb, ua, ub);                                                                    \
+        matvecDppPairT(CUR.mA, pn * ub, CUR.mB, pn * ua, pa, pb);                                                         \
+        matvecDppPair(CUR.dA, xa, CUR.dB, xb, va, vb);                                                                    \
+        DCUR = loadPreDesc(dp + 2);                                                                                       \
+        dp += 1;                                                                                                          \
+        const double ga = waveSumTo63(coef * dot4(pa, va)), gb = waveSumTo63(coef * dot4(pb, vb));                        \
+        if (lane == 63) { sums[(size_t)slotA * waves + w] = ga; sums[(size_t)slotB * waves + w] = gb; }                   \
+        if (contA >= 2u) { v2d* h = holdBase + (size_t)(contA - 2) * holdStride; h[0] = v2d{pa.x, pa.y}; h[64] = v2d{pa.z, pa.w}; }   \
+        if (contB >= 2u) { v2d* h = holdBase + (size_t)(contB - 2) * holdStride; h[0] = v2d{pb.x, pb.y}; h[64] = v2d{pb.z, pb.w}; }   \
+        if (contA == 1u) ACC = pa;                                                                                        \
+        if (contB == 1u) ACC = pb;                                                                                        \
+    }
+    for (int k = 0; k < nOps; k += 2) {
+        PRE_STAGE(A, B, D0, D1)
+        PRE_STAGE(B, A, D1, D0)
+    }
+#undef PRE_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int preWalkWaves(int P, int C) { return ((P + 63) / 64) * C; }
+
+bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, int nOps, const double* rootPre, const double* matrices,
+                    const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots) {
+    if (nOps <= 0 || (nOps & 1) || C < 1 || C > 16 || (size_t)C * P * 32 >= ((size_t)1 << 32)) return false;
+    const int slots = holdSlots < 1 ? 1 : holdSlots;                 // (slot 0 doubles as the categories' exchange at the start)
+    const size_t lds = (size_t)slots * C * 128 * sizeof(v2d);
+    if (lds > 160 * 1024) return false;
+    const dim3 grid((P + 63) / 64), block(64 * C);
+#define PRE_WALK_LAUNCH(T)                                                                                                  \
+    { if (!grantDynamicLds(reinterpret_cast<const void*>(k_preWalk4<T>), 160 * 1024)) return false;                        \
+      hipLaunchKernelGGL(k_preWalk4<T>, grid, block, lds, stream, (const PreWalkOp MI355_CONST*)dProg, nOps, rootPre, matrices, catWeights, patternWeights, sums, P, C); }
+    if (C <= 4) PRE_WALK_LAUNCH(256) else if (C <= 8) PRE_WALK_LAUNCH(512) else PRE_WALK_LAUNCH(1024)
+#undef PRE_WALK_LAUNCH
+    return true;
+}
+
+// out[e] = the sum of edge e's per-wave sums, in a fixed order
+__global__ __launch_bounds__(64) void k_preWalkFinal(const double* __restrict__ sums, int waves, double* __restrict__ out) {
+    const double* b = sums + (size_t)blockIdx.x * waves;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < waves; k += 64) s += b[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+void launchPreWalkFinal(hipStream_t stream, const double* sums, int nSlots, int P, int C, double* out) {
+    if (nSlots > 0) hipLaunchKernelGGL(k_preWalkFinal, dim3(nSlots), dim3(64), 0, stream, sums, preWalkWaves(P, C), out);
+}
+
 }  // namespace mi355

@@ -17,18 +17,27 @@ from . import beagle as _b
 class BranchGradient:
     """One full evaluation = post-order partials, root lnL, pre-order partials, d lnL / d(branch length) per node."""
 
-    def __init__(self, workload, library=None, rescale=False, resource_list=(1,)):
+    def __init__(self, workload, library=None, rescale=False, resource_list=(1,), double_buffer=False):
+        """double_buffer: lay the post-order partials and the branch matrices out in two sets and alternate between them from
+        one evaluation to the next, as BufferIndexHelper does for the reference (BufferIndexHelper.java:65-85 index = i + 0 or
+        i + doubleBufferCount; BeagleDataLikelihoodDelegate.java:853 flipOffset per updated node; a gradient chain updates
+        every node, so here the whole set flips)."""
         wl = self.wl = workload
         tr = self.tree = wl.tree
         self.T, self.N = tr.tip_count, tr.node_count
         self.S, self.P, self.C = wl.state_count, wl.pattern_count, wl.category_count
         self.rescale = rescale
-        # buffer plan (no double buffering: a gradient evaluation recomputes the whole tree)
-        self.pre_offset = self.N                       # pre-order partial of node n = pre_offset + n
-        self.q_index = self.N                          # differential matrix (first order) after the N branch matrices
-        self.q2_index = self.N + 1
+        self.double_buffer = double_buffer
+        internal = self.N - self.T
+        # buffer plan: pre-order partial of node n = pre_offset + n, right after the post-order ones
+        # (BeagleDataLikelihoodDelegate.java:236-244); the differential matrices right after the branch matrices
+        self._partial_set, self._matrix_set = (internal, self.N) if double_buffer else (0, 0)
+        self.pre_offset = self.T + (2 if double_buffer else 1) * internal
+        matrices = (2 if double_buffer else 1) * self.N
+        self.q_index = matrices
+        self.q2_index = matrices + 1
         self.cum_scale = self.T - 1 if rescale else _b.NONE
-        self.b = _b.Beagle(self.T, 2 * self.N, self.T, self.S, self.P, 1, self.N + 2, self.C,
+        self.b = _b.Beagle(self.T, self.pre_offset + self.N, self.T, self.S, self.P, 1, matrices + 2, self.C,
                            (self.T if rescale else 0), resourceList=resource_list, library=library)
         for t in range(self.T):
             self.b.setTipStates(t, wl.tip_states[t])
@@ -38,22 +47,45 @@ class BranchGradient:
         self.b.setCategoryWeights(0, wl.cat_weights)
         self.b.setEigenDecomposition(0, wl.eig.evec, wl.eig.ievc, wl.eig.evals)
         self.branch_lengths = np.array([tr.branch_length(n) if n != tr.root else 0.0 for n in range(self.N)])
-        self._post_ops = self._build_post_ops()
-        self._pre_ops = self._build_pre_ops()
         self.edges = [n for n in range(self.N) if n != tr.root]
+        self._infinitesimal = {}
+        self._root_pre = np.tile(wl.freqs, self.P * self.C)                      # simulateRoot, :142-151
+        self._set = 0                                    # which of the two sets the current evaluation lives in
+        sets = (0, 1) if double_buffer else (0,)
+        self._post_ops_by_set = [self._build_post_ops(v) for v in sets]
+        self._pre_ops_by_set = [self._build_pre_ops(v) for v in sets]
+        e = np.asarray(self.edges, dtype=np.int32)
+        self._edge_post = [np.asarray([self.post_index(n, v) for n in self.edges], dtype=np.int32) for v in sets]
+        self._edge_matrix = [e + v * self._matrix_set for v in sets]
+
+    def post_index(self, node, which=None):
+        v = self._set if which is None else which
+        return node if node < self.T else node + v * self._partial_set
+
+    def matrix_index(self, node, which=None):
+        return node + (self._set if which is None else which) * self._matrix_set
+
+    @property
+    def _post_ops(self):
+        return self._post_ops_by_set[self._set]
+
+    @property
+    def _pre_ops(self):
+        return self._pre_ops_by_set[self._set]
 
     # -- op lists ----------------------------------------------------------------------------------------------
-    def _build_post_ops(self):
+    def _build_post_ops(self, v=0):
         tr, ops = self.tree, []
         for n in tr.postorder():
             if n < self.T:
                 continue
             l, r = int(tr.left[n]), int(tr.right[n])
             ws = (n - self.T) if self.rescale else _b.NONE
-            ops += [n, ws, _b.NONE, l, l, r, r]
+            ops += [self.post_index(n, v), ws, _b.NONE, self.post_index(l, v), self.matrix_index(l, v),
+                    self.post_index(r, v), self.matrix_index(r, v)]
         return np.asarray(ops, dtype=np.int32)
 
-    def _build_pre_ops(self):
+    def _build_pre_ops(self, v=0):
         """AbstractBeagleGradientDelegate.java:207-221, in pre-order (TreeTraversal pre-order: parent first)."""
         tr, ops, stack = self.tree, [], [self.tree.root]
         while stack:
@@ -62,7 +94,8 @@ class BranchGradient:
                 continue
             l, r = int(tr.left[n]), int(tr.right[n])
             for child, sib in ((l, r), (r, l)):
-                ops += [self.pre_offset + child, _b.NONE, _b.NONE, self.pre_offset + n, child, sib, sib]
+                ops += [self.pre_offset + child, _b.NONE, _b.NONE, self.pre_offset + n, self.matrix_index(child, v),
+                        self.post_index(sib, v), self.matrix_index(sib, v)]
             stack += [r, l]
         return np.asarray(ops, dtype=np.int32)
 
@@ -71,43 +104,49 @@ class BranchGradient:
         self.branch_lengths[node] = t
 
     def log_likelihood(self):
+        if self.double_buffer:
+            self._set ^= 1
         idx = np.asarray(self.edges, dtype=np.int32)
-        self.b.updateTransitionMatrices(0, idx, None, None, self.branch_lengths[idx], len(idx))
+        self.b.updateTransitionMatrices(0, self._edge_matrix[self._set], None, None, self.branch_lengths[idx], len(idx))
         if self.rescale:
             self.b.resetScaleFactors(self.cum_scale)
         self.b.updatePartials(self._post_ops, len(self._post_ops) // 7, self.cum_scale)
         out = [0.0]
-        self.b.calculateRootLogLikelihoods([self.tree.root], [0], [0], [self.cum_scale], 1, out)
+        self.b.calculateRootLogLikelihoods([self.post_index(self.tree.root)], [0], [0], [self.cum_scale], 1, out)
         return out[0]
 
     def infinitesimal(self, power=1):
         """Q (or Q^2) scaled per category rate (rate^power), category-major — what the delegate caches."""
-        e = self.wl.eig
-        q = (e.evec * e.evals[None, :]) @ e.ievc
-        if power == 2:
-            q = q @ q
-        return np.concatenate([(q * r ** power).ravel() for r in self.wl.cat_rates])
+        if power not in self._infinitesimal:
+            e = self.wl.eig
+            q = (e.evec * e.evals[None, :]) @ e.ievc
+            if power == 2:
+                q = q @ q
+            self._infinitesimal[power] = np.concatenate([(q * r ** power).ravel() for r in self.wl.cat_rates])
+        return self._infinitesimal[power]
 
     def gradient(self, second=False, per_pattern=False):
         """-> lnL, d lnL/d t_n for every non-root node n (array indexed by node; root entry 0), and optionally the
         diagonal second derivatives (AbstractBeagleBranchGradientDelegate.java:82-95: second - firstSquared)."""
         lnl = self.log_likelihood()
-        root_pre = np.tile(self.wl.freqs, self.P * self.C)                       # simulateRoot, :142-151
-        self.b.setPartials(self.pre_offset + self.tree.root, root_pre)
+        self.b.setPartials(self.pre_offset + self.tree.root, self._root_pre)
         self.b.updatePrePartials(self._pre_ops, len(self._pre_ops) // 7, _b.NONE)
         self.b.setDifferentialMatrix(self.q_index, self.infinitesimal(1))
-        post = np.asarray(self.edges, dtype=np.int32)
-        pre = post + self.pre_offset
+        nodes = np.asarray(self.edges, dtype=np.int32)
+        post = self._edge_post[self._set]
+        pre = nodes + self.pre_offset
         n = len(post)
-        s1, s1sq, per = self.b.calculateEdgeDifferentials(post, pre, [self.q_index] * n, [0], n, want_per_pattern=per_pattern)
+        # (firstSquared is only asked for when the second derivatives are: AbstractBeagleBranchGradientDelegate.java:80-84)
+        s1, s1sq, per = self.b.calculateEdgeDifferentials(post, pre, [self.q_index] * n, [0], n, want_per_pattern=per_pattern,
+                                                          want_squared=second)
         grad = np.zeros(self.N)
-        grad[post] = s1
+        grad[nodes] = s1
         result = [lnl, grad]
         if second:
             self.b.setDifferentialMatrix(self.q2_index, self.infinitesimal(2))
-            s2, _, _ = self.b.calculateEdgeDifferentials(post, pre, [self.q2_index] * n, [0], n)
+            s2, _, _ = self.b.calculateEdgeDifferentials(post, pre, [self.q2_index] * n, [0], n, want_squared=False)
             hess = np.zeros(self.N)
-            hess[post] = s2 - s1sq
+            hess[nodes] = s2 - s1sq
             result.append(hess)
         if per_pattern:
             result.append(per)
@@ -116,9 +155,9 @@ class BranchGradient:
     def cross_products(self):
         """SubstitutionModelCrossProductDelegate.java:149-162 (one substitution model): d lnL / d Q_ij, first-order form.
         Call after gradient() (needs the pre-order partials)."""
-        post = np.asarray(self.edges, dtype=np.int32)
-        return self.b.calculateCrossProductDifferentials(post, post + self.pre_offset, [0], [0], self.branch_lengths[post],
-                                                         len(post)).reshape(self.S, self.S)
+        nodes = np.asarray(self.edges, dtype=np.int32)
+        return self.b.calculateCrossProductDifferentials(self._edge_post[self._set], nodes + self.pre_offset, [0], [0],
+                                                         self.branch_lengths[nodes], len(nodes)).reshape(self.S, self.S)
 
     def pre_partials(self, node):
         return self.b.getPartials(self.pre_offset + node, _b.NONE)

@@ -327,9 +327,12 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
  * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the
  * bytes the design has to move (roofline.achieved). */
 int beagleMi355WalkStats(int instance, long* out8);
-/* The gradient pass since instance creation: out[0] pre-order lists that ran together with the edge derivatives that followed
- * them (one sweep per tree level, 4 states), out[1] pre-order lists that ran operation by operation. */
-int beagleMi355GradientStats(int instance, long* out2);
+/* The gradient pass (4 states) since instance creation.  A pre-order list without scale indices is held back until a call needs
+ * what it writes (or changes what it reads): out[0] lists that ran together with the edge derivatives that followed them (one
+ * sweep per tree level; sums and sums of squares), out[1] lists that ran operation by operation, out[2] edge-derivative calls
+ * answered from a held list WITHOUT writing a pre-order partial (sums only; the list stays held), out[3] held lists that had
+ * to run after all because a later call touched their buffers. */
+int beagleMi355GradientStats(int instance, long* out4);
 /* Bytes of HBM currently allocated by the instance. */
 long beagleMi355DeviceBytes(int instance);
 

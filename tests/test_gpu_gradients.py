@@ -35,11 +35,12 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
     wl = helpers.random_workload(T, P, S, C, seed=100 + S + T)
     g = BranchGradient(wl, rescale=rescale)
     o = BranchGradient(wl, rescale=rescale, library=oracle_lib)
-    # sums only: with 4 states (no scale indices in the pre-order list: the derivative ratio is scale-free) the engine holds the list back and runs it together
-    # with the edge derivatives, one sweep per tree level (engine_preorder.cpp fusedGradient); everything else goes operation
-    # by operation — the same numbers either way
+    # Sums only.  With 4 states the engine holds the pre-order list back (no scale indices in it: the derivative ratio is scale-
+    # free) and answers from it: without writing a pre-order partial when the post-order partials carry no scale factors (the
+    # list stays held), together with the list otherwise; other state counts go operation by operation.  Same numbers.
     lf, gf = g.gradient()
-    assert g.b.gradientStats() == ({"fused": 1, "by_operation": 0} if S == 4 else {"fused": 0, "by_operation": 1})
+    none = {"fused": 0, "by_operation": 0, "walked": 0, "late": 0}
+    assert g.b.gradientStats() == dict(none, **({"by_operation": 1} if S != 4 else {"fused": 1} if rescale else {"walked": 1}))
     lo, go, ho, po = o.gradient(second=True, per_pattern=True)
     assert helpers.rel_err(lf, lo) <= REL_TOL
     close(gf, go, "gradient (sums only)")
@@ -48,6 +49,7 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
             a, b = g.pre_partials(n).reshape(C, P, S), o.pre_partials(n).reshape(C, P, S)
             ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
             assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
+    assert g.b.gradientStats()["late"] == (1 if S == 4 and not rescale else 0)      # the read made the held list run
     lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
     assert helpers.rel_err(lg, lo) <= REL_TOL
     close(gg, go, "gradient")
@@ -132,71 +134,119 @@ def test_pre_order_entry_points_and_errors(oracle_lib):
 
 
 def test_held_back_pre_order_list_is_seen_by_every_other_call(oracle_lib):
-    """The 4-state engine defers an unscaled pre-order list until the edge-derivative call (engine_internal.h
-    Instance::pendingPre).  Whatever the caller does in between has to see the list as executed: reading a pre-order
-    partial, rewriting a branch matrix the list uses, asking for derivatives of a subset of the edges, in another order,
-    or for edges the list does not produce."""
+    """The 4-state engine holds an unscaled pre-order list back (engine_internal.h HeldPreList) and answers the edge-derivative
+    sums from it without writing a pre-order partial.  Whatever the caller does next has to see the list as executed: reading
+    a pre-order partial, rewriting a branch matrix the list uses, asking for derivatives of a subset of the edges, in another
+    order, or for edges the list does not produce."""
     wl = helpers.random_workload(17, 333, 4, 3, seed=909)
     g = BranchGradient(wl)
     o = BranchGradient(wl, library=oracle_lib)
-    lo, go = o.gradient()
+    lo, go, ho = o.gradient(second=True)
     root = wl.tree.root
-    root_pre = np.tile(wl.freqs, g.P * g.C)
     post = np.asarray(g.edges, dtype=np.int32)
     pre = post + g.pre_offset
     n = len(post)
 
     def prepare():
         g.log_likelihood()
-        g.b.setPartials(g.pre_offset + root, root_pre)
+        g.b.setPartials(g.pre_offset + root, g._root_pre)
         g.b.updatePrePartials(g._pre_ops, len(g._pre_ops) // 7, bm.beagle.NONE)
         g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
 
-    def stats():
-        return g.b.gradientStats()
-
-    # 1. a subset of the edges, shuffled: still one fused sweep; every pre-order partial exists afterwards
+    stats = g.b.gradientStats
+    # 1. a subset of the edges, shuffled: one walk, the list stays held; then all of them, then the second derivatives (with the
+    #    sums of squares: the list runs together with that call); every pre-order partial exists afterwards
     prepare()
     pick = np.random.default_rng(1).permutation(n)[: n // 2]
-    s1, _, _ = g.b.calculateEdgeDifferentials(post[pick], pre[pick], [g.q_index] * len(pick), [0], len(pick))
-    assert stats() == {"fused": 1, "by_operation": 0}
+    s1, s1sq, _ = g.b.calculateEdgeDifferentials(post[pick], pre[pick], [g.q_index] * len(pick), [0], len(pick), want_squared=False)
+    assert s1sq is None and stats() == {"fused": 0, "by_operation": 0, "walked": 1, "late": 0}
     close(s1, go[post[pick]], "subset of the edges")
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n, want_squared=False)
+    assert stats() == {"fused": 0, "by_operation": 0, "walked": 2, "late": 0}
+    close(s1, go[post], "all edges, list still held")
+    g.b.setDifferentialMatrix(g.q2_index, g.infinitesimal(2))
+    s2, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q2_index] * n, [0], n, want_squared=False)
+    s1, s1sq, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
+    assert stats() == {"fused": 1, "by_operation": 0, "walked": 3, "late": 0}
+    close(s1, go[post], "first derivatives again, with their squares")
+    close(s2 - s1sq, ho[post], "second derivatives")
     for node in (int(post[0]), int(post[-1])):
-        close(g.pre_partials(node), o.pre_partials(node), "pre-order partial after a subset")
+        close(g.pre_partials(node), o.pre_partials(node), "pre-order partial after the fused call")
+    assert stats()["late"] == 0
     # 2. a read of a pre-order partial in between: the list runs at the read
     prepare()
     close(g.pre_partials(int(post[3])), o.pre_partials(int(post[3])), "pre-order partial read before the edge call")
-    assert stats() == {"fused": 1, "by_operation": 1}
+    assert stats()["late"] == 1
     s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
     close(s1, go[post], "after an intervening read")
-    # 3. a branch matrix of the list rewritten in between (with its own values): the list runs first
+    # 3. a call that is not on the short list of calls that leave it held; a branch matrix of the list rewritten (with its own
+    #    values): the list runs first.  The differential matrix is not one of the list's: it stays held
     prepare()
     m = g.b.getTransitionMatrix(int(post[0]))
-    assert stats()["by_operation"] == 2                            # (getTransitionMatrix is not on the short list of calls that keep it held)
+    assert stats()["late"] == 2
     prepare()
     g.b.setTransitionMatrix(int(post[0]), m, 0.0)
-    assert stats()["by_operation"] == 3
+    assert stats()["late"] == 3
     s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
     close(s1, go[post], "after a branch matrix was rewritten")
-    # 4. an edge whose pre-order partial the held list does not produce: list first, then the derivatives on what is stored
-    g.log_likelihood()
-    g.b.setPartials(g.pre_offset + root, root_pre)
-    g.b.updatePrePartials(g._pre_ops, len(g._pre_ops) // 7, bm.beagle.NONE)          # all of them, executed by the next call
-    g.b.synchronize()
-    first_two = g._pre_ops[:14]                                                       # the root's two children again
+    # 4. the next evaluation's calls — new branch matrices into the SAME indices (this driver does not double-buffer): the list
+    #    reads them, so it runs first, with the old matrices
+    prepare()
+    before = [g.pre_partials(int(x)).copy() for x in post[:3]]
+    prepare()
+    t_old = g.branch_lengths.copy()
+    g.branch_lengths[:] = t_old * 1.7
+    g.log_likelihood()                                             # updateTransitionMatrices hits the held list's matrices
+    for x, was in zip(post[:3], before):
+        assert np.array_equal(g.pre_partials(int(x)), was)
+    g.branch_lengths[:] = t_old
+    # 5. edges the held list does not produce: list first, then the derivatives on what is stored
+    prepare()
+    g.b.getTransitionMatrix(int(post[0]))                          # (runs it)
+    first_two = g._pre_ops[:14]                                    # the root's two children again: held
+    late = stats()["late"]
     g.b.updatePrePartials(first_two, 2, bm.beagle.NONE)
-    g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
-    before = stats()
-    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
-    assert stats()["fused"] == before["fused"] and stats()["by_operation"] == before["by_operation"] + 1
+    s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n, want_squared=False)
+    assert stats()["late"] == late + 1
     close(s1, go[post], "edges beyond the held list")
-    # 5. half a node (one of two siblings) held: not the fused shape
+    # 6. half a node (one of two siblings): not the shape, runs at once
+    by_op = stats()["by_operation"]
     g.b.updatePrePartials(first_two[:7], 1, bm.beagle.NONE)
-    before = stats()
+    assert stats()["by_operation"] == by_op + 1
     e0 = int(first_two[0]) - g.pre_offset
     s1, _, _ = g.b.calculateEdgeDifferentials([e0], [e0 + g.pre_offset], [g.q_index], [0], 1)
-    assert stats()["fused"] == before["fused"]
     close(s1, go[[e0]], "one sibling only")
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("rescale", [False, True])
+def test_gradient_chain_with_alternating_buffers(rescale, oracle_lib):
+    """What a gradient-driven chain does (HMC over branch lengths): every evaluation writes the OTHER set of post-order
+    buffers and branch matrices (BufferIndexHelper), rewrites the root's pre-order partial, sends the same pre-order
+    destinations and asks for the sums.  On the engine no held list ever has to run (each is replaced by the next one
+    unexecuted) and no pre-order partial is written until somebody reads one; the numbers are the oracle's throughout."""
+    wl = helpers.random_workload(33, 500, 4, 4, seed=31)
+    g = BranchGradient(wl, double_buffer=True, rescale=rescale)
+    o = BranchGradient(wl, double_buffer=True, rescale=rescale, library=oracle_lib)
+    rng = np.random.default_rng(3)
+    steps = 6
+    for step in range(steps):
+        scale = np.exp(0.2 * rng.standard_normal(g.N))
+        g.branch_lengths *= scale; o.branch_lengths *= scale
+        second = step == 3
+        rg, ro = g.gradient(second=second), o.gradient(second=second)
+        assert helpers.rel_err(rg[0], ro[0]) <= REL_TOL
+        close(rg[1], ro[1], "gradient, step %d" % step)
+        if second:
+            close(rg[2], ro[2], "second derivatives, step %d" % step)
+    st = g.b.gradientStats()
+    if rescale:
+        assert st == {"fused": steps, "by_operation": 0, "walked": 0, "late": 0}
+    else:
+        # (step 3 asks for the sums of squares: its list runs with that call, and its second derivatives find stored partials)
+        assert st == {"fused": 1, "by_operation": 0, "walked": steps - 1, "late": 0}
+    for n_ in g.edges[:5]:
+        close(g.pre_partials(n_), o.pre_partials(n_), "pre-order partial at the end of the chain")
     g.close(); o.close()
 
 

@@ -32,7 +32,7 @@ def main():
     wl = synth.cached(os.path.join(args.cache, "config_%s.pkl" % args.config), maker)
     if args.patterns:
         wl = wl.shard(0, min(args.patterns, wl.pattern_count))
-    g = BranchGradient(wl)
+    g = BranchGradient(wl, double_buffer=True)       # the reference's buffer plan: two sets, alternating (BufferIndexHelper)
     for _ in range(args.warmup):
         lnl, grad = g.gradient()
     g.b.synchronize()
@@ -56,7 +56,7 @@ def main():
                       "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
                                                                                           wl.state_count, wl.category_count),
                       "pre_order_plus_edge_algorithmic_GBs": round(pre_bytes / max(dt - dl, 1e-9) / 1e9, 1),
-                      "lnL": lnl, "grad_norm": float((grad ** 2).sum() ** 0.5),
+                      "lnL": lnl, "grad_norm": float((grad ** 2).sum() ** 0.5), "how": g.b.gradientStats(),
                       "hbm_bytes_resident": int(g.b.deviceBytes())}))
     g.close()
 
