@@ -84,6 +84,7 @@ struct Instance {
         std::vector<HeldPreNode> nodes;                  // one per parent: its two operations together
         std::vector<int> order;                          // depth-first, smaller subtree first (the walk's program order)
         std::vector<unsigned> walkFlags;                 // per entry of `order`: PW_* source / continuation bits
+        std::vector<int> segStart, segRoot;              // the walk's segments: entries segStart[s] .. segStart[s + 1] of `order`, headed by job segRoot[s]
         int maxLevel = 0, holdSlots = 0, rootBuf = -1;
         std::vector<char> readsMatrix, readsBuf, writesBuf;   // by matrix / partials-buffer index
     } heldPre;

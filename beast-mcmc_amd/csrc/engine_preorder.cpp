@@ -255,29 +255,50 @@ int holdPreList(Instance* in, const int* ops, int count) {
         if (nd.jobB >= 0 && nd.jobB <= (int)j) return 1;
         nodes[j].size = 1 + (nd.jobA >= 0 ? nodes[nd.jobA].size : 0) + (nd.jobB >= 0 ? nodes[nd.jobB].size : 0);
     }
-    // the walk's order: depth first, the smaller subtree first, the other child's partial parked in a hold slot meanwhile
-    h.order.clear(); h.walkFlags.clear(); h.holdSlots = 0;
+    // The walk's order: depth first, the smaller subtree first, the other child's partial parked in a hold slot meanwhile.
+    // Like the post-order walk (engine_walk.cpp walkChunkOps) it is cut into segments that run side by side — a wave executes
+    // its program one dependent step after the other, and 20 000 patterns are only 1.2 waves per SIMD: the subtrees of at
+    // most `chunk` nodes hanging off the upper part of the tree become segments of their own; the upper part stores the
+    // pre-order partials of their roots and runs first.
+    h.order.clear(); h.walkFlags.clear(); h.segStart.clear(); h.segRoot.clear(); h.holdSlots = 0;
     {
-        std::vector<std::pair<int, int>> parked;                   // (job, hold slot)
-        int j = root; unsigned src = 0;
-        while (j >= 0) {
-            const Instance::HeldPreNode& nd = nodes[j];
-            unsigned contA = 0, contB = 0;
-            int next = -1; unsigned nextSrc = 0;
-            if (nd.jobA >= 0 && nd.jobB >= 0) {
-                const bool aFirst = nodes[nd.jobA].size <= nodes[nd.jobB].size;
-                const int slot = (int)parked.size();
-                h.holdSlots = std::max(h.holdSlots, slot + 1);
-                (aFirst ? contA : contB) = 1u; (aFirst ? contB : contA) = 2u + (unsigned)slot;
-                parked.emplace_back(aFirst ? nd.jobB : nd.jobA, slot);
-                next = aFirst ? nd.jobA : nd.jobB;
-            } else if (nd.jobA >= 0) { contA = 1u; next = nd.jobA; }
-            else if (nd.jobB >= 0) { contB = 1u; next = nd.jobB; }
-            else if (!parked.empty()) { next = parked.back().first; nextSrc = 1u + (unsigned)parked.back().second; parked.pop_back(); }
-            h.order.push_back(j);
-            h.walkFlags.push_back((src << mi355::PW_SRC_SHIFT) | (contA << mi355::PW_CONT_A_SHIFT) | (contB << mi355::PW_CONT_B_SHIFT));
-            j = next; src = nextSrc;
+        const long groups = (in->P + 63) / 64;
+        static const int forced = getenv("BEAGLE_MI355_PRE_CHUNK") ? atoi(getenv("BEAGLE_MI355_PRE_CHUNK")) : -1;
+        int chunk = nodes.size() >= 64 ? (int)std::min<long>(256, std::max<long>(24, (long)nodes.size() * groups / 2560)) : 0;
+        if (forced >= 0) chunk = forced;
+        std::vector<char> head(nodes.size(), 0);
+        std::vector<int> heads(1, root);
+        if (chunk > 0)
+            for (size_t j = 0; j < nodes.size(); j++) {
+                const int pj = jobOfDest[nodes[j].par];
+                if (pj >= 0 && nodes[j].size <= chunk && nodes[j].size >= std::max(8, chunk / 4) && nodes[pj].size > chunk) { head[j] = 1; heads.push_back((int)j); }
+            }
+        for (int hd : heads) {
+            h.segStart.push_back((int)h.order.size()); h.segRoot.push_back(hd);
+            std::vector<std::pair<int, int>> parked;               // (job, hold slot)
+            int j = hd; unsigned src = 0;
+            while (j >= 0) {
+                const Instance::HeldPreNode& nd = nodes[j];
+                const bool storeA = nd.jobA >= 0 && head[nd.jobA], storeB = nd.jobB >= 0 && head[nd.jobB];
+                const int a = storeA ? -1 : nd.jobA, b = storeB ? -1 : nd.jobB;      // children the walk steps into
+                unsigned contA = storeA ? mi355::PW_CONT_STORE : 0u, contB = storeB ? mi355::PW_CONT_STORE : 0u;
+                int next = -1; unsigned nextSrc = 0;
+                if (a >= 0 && b >= 0) {
+                    const bool aFirst = nodes[a].size <= nodes[b].size;
+                    const int slot = (int)parked.size();
+                    h.holdSlots = std::max(h.holdSlots, slot + 1);
+                    (aFirst ? contA : contB) = 1u; (aFirst ? contB : contA) = 2u + (unsigned)slot;
+                    parked.emplace_back(aFirst ? b : a, slot);
+                    next = aFirst ? a : b;
+                } else if (a >= 0) { contA = 1u; next = a; }
+                else if (b >= 0) { contB = 1u; next = b; }
+                else if (!parked.empty()) { next = parked.back().first; nextSrc = 1u + (unsigned)parked.back().second; parked.pop_back(); }
+                h.order.push_back(j);
+                h.walkFlags.push_back((src << mi355::PW_SRC_SHIFT) | (contA << mi355::PW_CONT_A_SHIFT) | (contB << mi355::PW_CONT_B_SHIFT));
+                j = next; src = nextSrc;
+            }
         }
+        h.segStart.push_back((int)h.order.size());
         if (h.order.size() != nodes.size()) return 1;              // (cannot happen for a tree)
     }
     // its own copy of the root's pre-order partial: the caller rewrites that buffer before every list (simulateRoot,
@@ -401,36 +422,49 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
         in->preDummyStates = (uint8_t*)q;
         HIP_TRY(hipMemsetAsync(in->preDummyStates, 4, (size_t)in->P, in->stream));
     }
-    const size_t nOps = (h.order.size() + 1) & ~(size_t)1;
-    std::vector<mi355::PreWalkOp> prog(nOps + 2);
-    for (size_t k = 0; k < prog.size(); k++) {
-        mi355::PreWalkOp& op = prog[k];
-        memset(&op, 0, sizeof(op));
-        op.postA = op.postB = in->preRootCopy; op.tipA = op.tipB = in->preDummyStates; op.slotA = op.slotB = count;
-        if (k >= h.order.size()) continue;                         // padding: computes on valid memory, contributes to the spare slot
-        const Instance::HeldPreNode& nd = h.nodes[h.order[k]];
-        op.flags = h.walkFlags[k];
-        for (int w = 0; w < 2; w++) {
-            const int po = w ? nd.postB : nd.postA;
-            const bool st = in->tipStates[po] && po < in->tipCount;
-            const int e = edgeOf[w ? nd.preB : nd.preA];
-            if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else op.postB = in->partials[po]; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
-            else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else op.postA = in->partials[po]; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+    // every segment: its descriptors, padded to an even count, and two more no-ops (the kernel's look-ahead)
+    const int nSegs = (int)h.segRoot.size();
+    std::vector<mi355::PreWalkSeg> segs(nSegs);
+    std::vector<mi355::PreWalkOp> prog;
+    prog.reserve(h.order.size() + 3 * (size_t)nSegs);
+    mi355::PreWalkOp nop;
+    memset(&nop, 0, sizeof(nop));
+    nop.postA = nop.postB = in->preRootCopy; nop.tipA = nop.tipB = in->preDummyStates; nop.slotA = nop.slotB = count;   // valid memory, the spare slot
+    for (int sgi = 0; sgi < nSegs; sgi++) {
+        const int first = h.segStart[sgi], n = h.segStart[sgi + 1] - first;
+        segs[sgi].progStart = (int)prog.size(); segs[sgi].progCount = (n + 1) & ~1;
+        segs[sgi].rootPre = sgi == 0 ? in->preRootCopy : in->partials[h.nodes[h.segRoot[sgi]].par];
+        for (int k = first; k < first + n; k++) {
+            const Instance::HeldPreNode& nd = h.nodes[h.order[k]];
+            mi355::PreWalkOp op = nop;
+            op.flags = h.walkFlags[k];
+            for (int w = 0; w < 2; w++) {
+                const int po = w ? nd.postB : nd.postA;
+                const bool st = in->tipStates[po] && po < in->tipCount;
+                const int e = edgeOf[w ? nd.preB : nd.preA];
+                if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else op.postB = in->partials[po]; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
+                else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else op.postA = in->partials[po]; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+            }
+            op.storeA = in->partials[nd.preA]; op.storeB = in->partials[nd.preB];
+            op.matA = nd.matA; op.matB = nd.matB;
+            prog.push_back(op);
         }
-        op.matA = nd.matA; op.matB = nd.matB;
+        for (int k = n; k < segs[sgi].progCount + 2; k++) prog.push_back(nop);
     }
+    const size_t segBytes = ((size_t)nSegs * sizeof(mi355::PreWalkSeg) + 255) & ~(size_t)255;
     const size_t progBytes = prog.size() * sizeof(mi355::PreWalkOp);
-    if (progBytes > RING_BYTES / 2) return 1;
-    if (progBytes > in->dPreProgBytes) {
+    if (progBytes + segBytes > RING_BYTES / 2) return 1;
+    if (progBytes + segBytes > in->dPreProgBytes) {
         HIP_TRY(hipStreamSynchronize(in->stream));
-        void* q = nullptr; int rc = devAlloc(in, &q, progBytes * 2); if (rc) return rc;      // (the old, smaller one stays allocated until the instance goes)
-        in->dPreProg = q; in->dPreProgBytes = progBytes * 2;
+        void* q = nullptr; int rc = devAlloc(in, &q, (progBytes + segBytes) * 2); if (rc) return rc;   // (the old, smaller one stays allocated until the instance goes)
+        in->dPreProg = q; in->dPreProgBytes = (progBytes + segBytes) * 2;
     }
     int rc = ensureEdgeScratch(in, sumBytes + outBytes); if (rc) return rc;
     double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes);
-    rc = upload(in, in->dPreProg, prog.data(), progBytes); if (rc) return rc;
-    if (!mi355::launchPreWalk4(in->stream, (const mi355::PreWalkOp*)in->dPreProg, (int)nOps, in->preRootCopy, in->matrices,
-                               in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots)) return 1;
+    rc = upload(in, in->dPreProg, segs.data(), (size_t)nSegs * sizeof(mi355::PreWalkSeg)); if (rc) return rc;
+    rc = upload(in, (char*)in->dPreProg + segBytes, prog.data(), progBytes); if (rc) return rc;
+    if (!mi355::launchPreWalk4(in->stream, (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,
+                               in->preRootCopy, in->matrices, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots)) return 1;
     mi355::launchPreWalkFinal(in->stream, dSums, count, in->P, in->C, dOut);
     std::vector<double> out(count);
     rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;

@@ -219,23 +219,31 @@ struct PreWalkOp {
     const void*    postB;
     const uint8_t* tipA;         // uint8 states [P]; any valid states array when the child has partials
     const uint8_t* tipB;
+    double*        storeA;       // continuation PW_CONT_STORE: where the child's pre-order partial is written (it heads another segment)
+    double*        storeB;
     int            matA, matB, dA, dB;
     int            slotA, slotB; // where the edges' sums go (the launch's last slot = nobody asked)
     unsigned       flags;        // PW_* below
     int            pad;
 };
-static_assert(sizeof(PreWalkOp) == 64, "PreWalkOp layout");
+static_assert(sizeof(PreWalkOp) == 80, "PreWalkOp layout");
 constexpr unsigned PW_TIP_A = 1u, PW_TIP_B = 2u;          // the child is a compact tip
 constexpr int PW_SRC_SHIFT = 4, PW_CONT_A_SHIFT = 8, PW_CONT_B_SHIFT = 12;   // 4 bits each
 // source of the node's pre-order partial: 0 = the registers, 1 + k = hold slot k
 // what becomes of a child's pre-order partial: 0 = nothing below it, 1 = the registers (the next descriptor is that child),
-// 2 + k = hold slot k (its descriptor comes after the other child's subtree)
+// 2 + k = hold slot k (its descriptor comes after the other child's subtree), PW_CONT_STORE = memory (storeA / storeB)
+constexpr unsigned PW_CONT_STORE = 15u;
 constexpr int PW_MAX_HOLD = 13;
-// nOps even, followed by two more no-op descriptors; sums [nSlots + 1][waves] with waves = preWalkWaves(P, C); rootPre = the
-// pre-order partial of the list's root
+// A walk is cut into SEGMENTS that run side by side (one more grid dimension): the first one starts at the list's root and
+// stores the pre-order partials of the nodes that head the others; those run in a second launch.  progCount even, two more
+// no-op descriptors behind every segment.
+struct PreWalkSeg { int progStart, progCount; const double* rootPre; };
+static_assert(sizeof(PreWalkSeg) == 16, "PreWalkSeg layout");
+// sums [nSlots + 1][waves] with waves = preWalkWaves(P, C); dProg[0] is the list's root (what the likelihood is formed from),
+// listRootPre its pre-order partial
 int  preWalkWaves(int P, int C);
-bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, int nOps, const double* rootPre, const double* matrices,
-                    const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots);
+bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
+                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots);
 void launchPreWalkFinal(hipStream_t stream, const double* sums, int nSlots, int P, int C, double* out);
 // the edge derivatives alone, same shape (32-byte vector accesses); outputs as launchEdgeDifferentials
 void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,

@@ -164,11 +164,11 @@ typedef unsigned long long u64;
 #define MI355_CONST __attribute__((address_space(4)))
 
 struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb; double mA, mB, dA, dB; };
-struct PreDesc { u64 postA, postB, tipA, tipB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
+struct PreDesc { u64 postA, postB, tipA, tipB, storeA, storeB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
 
 __device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
     PreDesc d;
-    d.postA = (u64)p->postA; d.postB = (u64)p->postB; d.tipA = (u64)p->tipA; d.tipB = (u64)p->tipB;
+    d.postA = (u64)p->postA; d.postB = (u64)p->postB; d.tipA = (u64)p->tipA; d.tipB = (u64)p->tipB; d.storeA = (u64)p->storeA; d.storeB = (u64)p->storeB;
     d.matA = p->matA; d.matB = p->matB; d.dA = p->dA; d.dB = p->dB; d.slotA = p->slotA; d.slotB = p->slotB; d.flags = p->flags;
     return d;
 }
@@ -248,10 +248,13 @@ __device__ __forceinline__ double waveSumTo63(double v) {
 }
 
 template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, int nOps, const double* __restrict__ rootPre,
-                                                   const double* __restrict__ matrices, const double* __restrict__ catWeights,
-                                                   const double* __restrict__ patternWeights, double* __restrict__ sums, int P, int C) {
-    extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d), then exch[C][64] (double) at the END (see launcher)
+__global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, const PreWalkSeg MI355_CONST* __restrict__ segs,
+                                                   const double* __restrict__ listRootPre, const double* __restrict__ matrices,
+                                                   const double* __restrict__ catWeights, const double* __restrict__ patternWeights,
+                                                   double* __restrict__ sums, int P, int C) {
+    extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d); slot 0 doubles as the categories' exchange at the start
+    const PreWalkSeg MI355_CONST& sg = segs[blockIdx.y];
+    const int nOps = sg.progCount;
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = (int)blockIdx.x * 64 + lane;
@@ -264,22 +267,22 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     v2d* holdBase = preLds + (size_t)c * 128 + lane;  // + slot * C * 128, second half at + 64
     const size_t holdStride = (size_t)C * 128;
 
-    PreDesc D0 = loadPreDesc(prog), D1 = loadPreDesc(prog + 1);
-    const PreWalkOp MI355_CONST* dp = prog;
+    const PreWalkOp MI355_CONST* dp = prog + sg.progStart;
+    PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
     PreFetched A, B;
     A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0;
     B = A;
     preIssue(A, D0, oPart, oTip, oMat, mats, matBytes);
-    const v4d root = gptr(reinterpret_cast<const v4d*>(rootPre))[(size_t)c * P + q];
-    v4d ACC = root;
+    v4d ACC = gptr(reinterpret_cast<const v4d*>(sg.rootPre))[(size_t)c * P + q];
     // the pattern's likelihood, once: den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
     double coef;
     {
         const PreWalkOp MI355_CONST& r = prog[0];
+        const v4d root = gptr(reinterpret_cast<const v4d*>(listRootPre))[(size_t)c * P + q];
         const v4d xa = (r.flags & PW_TIP_A) ? tipVector(gptr(r.tipA)[q]) : gptr(reinterpret_cast<const v4d*>(r.postA))[(size_t)c * P + q];
         const v4d xb = (r.flags & PW_TIP_B) ? tipVector(gptr(r.tipB)[q]) : gptr(reinterpret_cast<const v4d*>(r.postB))[(size_t)c * P + q];
         const v4d ua = matvec4(matrices + ((size_t)r.matA * C + c) * 16, xa), ub = matvec4(matrices + ((size_t)r.matB * C + c) * 16, xb);
-        double* exch = reinterpret_cast<double*>(preLds) + (size_t)(blockDim.x >> 6) * 0;   // the hold slots are empty now: the exchange borrows slot 0
+        double* exch = reinterpret_cast<double*>(preLds);
         exch[c * 64 + lane] = catWeights[c] * dot4(root, ua * ub);
         __syncthreads();
         double den = 0.0;
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         preIssue(NXT, DNXT, oPart, oTip, oMat, mats, matBytes);                                                           \
         const unsigned fl = DCUR.flags;                                                                                   \
         const int slotA = DCUR.slotA, slotB = DCUR.slotB;                                                                 \
+        const u64 stA = DCUR.storeA, stB = DCUR.storeB;                                                                   \
         const unsigned src = (fl >> PW_SRC_SHIFT) & 15u, contA = (fl >> PW_CONT_A_SHIFT) & 15u, contB = (fl >> PW_CONT_B_SHIFT) & 15u; \
         v4d pn = ACC;                                                                                                     \
         if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; pn = v4d{lo.x, lo.y, hi.x, hi.y}; } \
@@ -308,8 +312,10 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         dp += 1;                                                                                                          \
         const double ga = waveSumTo63(coef * dot4(pa, va)), gb = waveSumTo63(coef * dot4(pb, vb));                        \
         if (lane == 63) { sums[(size_t)slotA * waves + w] = ga; sums[(size_t)slotB * waves + w] = gb; }                   \
-        if (contA >= 2u) { v2d* h = holdBase + (size_t)(contA - 2) * holdStride; h[0] = v2d{pa.x, pa.y}; h[64] = v2d{pa.z, pa.w}; }   \
-        if (contB >= 2u) { v2d* h = holdBase + (size_t)(contB - 2) * holdStride; h[0] = v2d{pb.x, pb.y}; h[64] = v2d{pb.z, pb.w}; }   \
+        if (contA == PW_CONT_STORE) { if (valid) gptr(reinterpret_cast<v4d*>(stA))[(size_t)c * P + q] = pa; }             \
+        else if (contA >= 2u) { v2d* h = holdBase + (size_t)(contA - 2) * holdStride; h[0] = v2d{pa.x, pa.y}; h[64] = v2d{pa.z, pa.w}; }   \
+        if (contB == PW_CONT_STORE) { if (valid) gptr(reinterpret_cast<v4d*>(stB))[(size_t)c * P + q] = pb; }             \
+        else if (contB >= 2u) { v2d* h = holdBase + (size_t)(contB - 2) * holdStride; h[0] = v2d{pb.x, pb.y}; h[64] = v2d{pb.z, pb.w}; }   \
         if (contA == 1u) ACC = pa;                                                                                        \
         if (contB == 1u) ACC = pb;                                                                                        \
     }
@@ -323,16 +329,20 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
 
 int preWalkWaves(int P, int C) { return ((P + 63) / 64) * C; }
 
-bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, int nOps, const double* rootPre, const double* matrices,
-                    const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots) {
-    if (nOps <= 0 || (nOps & 1) || C < 1 || C > 16 || (size_t)C * P * 32 >= ((size_t)1 << 32)) return false;
+bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
+                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots) {
+    if (nSegs <= 0 || nSegs > 65536 || C < 1 || C > 16 || (size_t)C * P * 32 >= ((size_t)1 << 32)) return false;
     const int slots = holdSlots < 1 ? 1 : holdSlots;                 // (slot 0 doubles as the categories' exchange at the start)
     const size_t lds = (size_t)slots * C * 128 * sizeof(v2d);
     if (lds > 160 * 1024) return false;
-    const dim3 grid((P + 63) / 64), block(64 * C);
+    const dim3 block(64 * C);
+    // the segment that starts at the list's root, then (its stores visible at the kernel boundary) all the others
 #define PRE_WALK_LAUNCH(T)                                                                                                  \
     { if (!grantDynamicLds(reinterpret_cast<const void*>(k_preWalk4<T>), 160 * 1024)) return false;                        \
-      hipLaunchKernelGGL(k_preWalk4<T>, grid, block, lds, stream, (const PreWalkOp MI355_CONST*)dProg, nOps, rootPre, matrices, catWeights, patternWeights, sums, P, C); }
+      for (int part = 0; part < 2; part++) {                                                                              \
+          const int n = part ? nSegs - 1 : 1;                                                                             \
+          if (n > 0) hipLaunchKernelGGL(k_preWalk4<T>, dim3((P + 63) / 64, n), block, lds, stream, (const PreWalkOp MI355_CONST*)dProg,   \
+                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C); } }
     if (C <= 4) PRE_WALK_LAUNCH(256) else if (C <= 8) PRE_WALK_LAUNCH(512) else PRE_WALK_LAUNCH(1024)
 #undef PRE_WALK_LAUNCH
     return true;
