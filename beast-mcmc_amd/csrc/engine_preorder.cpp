@@ -430,6 +430,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     mi355::PreWalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.postA = nop.postB = in->preRootCopy; nop.tipA = nop.tipB = in->preDummyStates; nop.slotA = nop.slotB = count;   // valid memory, the spare slot
+    nop.flags = mi355::PW_TIP_A | mi355::PW_TIP_B;
     for (int sgi = 0; sgi < nSegs; sgi++) {
         const int first = h.segStart[sgi], n = h.segStart[sgi + 1] - first;
         segs[sgi].progStart = (int)prog.size(); segs[sgi].progCount = (n + 1) & ~1;

@@ -155,9 +155,8 @@ void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nE
 // every edge (post-order partials that carry no scale factors — the engine checks), so it is formed ONCE, at the root, and
 // each thread multiplies its numerators by weight_p w_c / den_p; everything after that is a plain sum.
 //
-// Loads are software-pipelined by hand exactly as in k_walk4: while descriptor k computes, the ten loads of k + 1 are in
-// flight (every descriptor issues the same ten, so the wait is a constant vmcnt(10); loads return in issue order and stores
-// in the queue only make the wait stricter).  The branch matrices and the differential matrices arrive spread over the
+// Loads are software-pipelined by hand exactly as in k_walk4: while descriptor k computes, the loads of k + 1 are in flight,
+// and the wait before k's arithmetic is for "all but the loads of k + 1" (preWait).  The branch matrices and the differential matrices arrive spread over the
 // lanes of one register each (lane l = entry l & 15) and are applied with v_fmac_f64_dpp row_newbcast — no LDS, no SGPRs.
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
@@ -175,26 +174,53 @@ __device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
 __device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, u64 matrices, unsigned matBytes) {
     const u64 mA = matrices + (u64)(unsigned)d.matA * matBytes, mB = matrices + (u64)(unsigned)d.matB * matBytes;
     const u64 dA = matrices + (u64)(unsigned)d.dA * matBytes, dB = matrices + (u64)(unsigned)d.dB * matBytes;
+    // a compact tip is one byte, a child with partials two 16-byte loads: what is not needed is BRANCHED around (a vector-memory
+    // instruction occupies the address unit whatever it fetches, and half the children of a tree are tips)
     asm volatile(
+        "s_bitcmp1_b32 %[fl], 0\n\t"
+        "s_cbranch_scc1 .Lpa%=\n\t"
         "global_load_dwordx4 %[a0], %[oP], %[pA]\n\t"
         "global_load_dwordx4 %[a1], %[oP], %[pA] offset:16\n\t"
+        "s_branch .Lpb%=\n"
+        ".Lpa%=:\n\t"
+        "global_load_ubyte %[sa], %[oT], %[tA]\n"
+        ".Lpb%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 1\n\t"
+        "s_cbranch_scc1 .Lpc%=\n\t"
         "global_load_dwordx4 %[b0], %[oP], %[pB]\n\t"
         "global_load_dwordx4 %[b1], %[oP], %[pB] offset:16\n\t"
-        "global_load_ubyte %[sa], %[oT], %[tA]\n\t"
-        "global_load_ubyte %[sb], %[oT], %[tB]\n\t"
+        "s_branch .Lpd%=\n"
+        ".Lpc%=:\n\t"
+        "global_load_ubyte %[sb], %[oT], %[tB]\n"
+        ".Lpd%=:\n\t"
         "global_load_dwordx2 %[mA], %[oM], %[smA]\n\t"
         "global_load_dwordx2 %[mB], %[oM], %[smB]\n\t"
         "global_load_dwordx2 %[dA], %[oM], %[sdA]\n\t"
         "global_load_dwordx2 %[dB], %[oM], %[sdB]"
         : [a0] "+v"(f.a0), [a1] "+v"(f.a1), [b0] "+v"(f.b0), [b1] "+v"(f.b1), [sa] "+v"(f.sa), [sb] "+v"(f.sb),
           [mA] "+v"(f.mA), [mB] "+v"(f.mB), [dA] "+v"(f.dA), [dB] "+v"(f.dB)
-        : [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
+        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
           [smA] "s"(mA), [smB] "s"(mB), [sdA] "s"(dA), [sdB] "s"(dB)
-        : "memory");
+        : "memory", "scc");
 }
-__device__ __forceinline__ void preWait(PreFetched& f) {
-    asm volatile("s_waitcnt vmcnt(10)"
-        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB) : : "memory");
+// the loads of `f` have landed once at most as many loads as the FOLLOWING descriptor issued (6, 7 or 8: four matrices and one
+// or two per child) are outstanding: loads return in issue order, and stores in the queue only make the wait stricter
+__device__ __forceinline__ void preWait(PreFetched& f, unsigned nextTips) {      // nextTips: PW_TIP_* bits of the following descriptor
+    asm volatile(
+        "s_cmp_eq_u32 %[nt], 3\n\t"
+        "s_cbranch_scc1 .Lw6%=\n\t"
+        "s_cmp_eq_u32 %[nt], 0\n\t"
+        "s_cbranch_scc1 .Lw8%=\n\t"
+        "s_waitcnt vmcnt(7)\n\t"
+        "s_branch .Lwd%=\n"
+        ".Lw8%=:\n\t"
+        "s_waitcnt vmcnt(8)\n\t"
+        "s_branch .Lwd%=\n"
+        ".Lw6%=:\n\t"
+        "s_waitcnt vmcnt(6)\n"
+        ".Lwd%=:"
+        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB)
+        : [nt] "s"(nextTips) : "memory", "scc");
 }
 // (ya, yb) = (MA xa, MB xb), the matrices spread over the lanes (lane l = entry l & 15, row-major): eight independent chains
 __device__ __forceinline__ void matvecDppPair(const double mA, const v4d xa, const double mB, const v4d xb, v4d& ya, v4d& yb) {
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         const unsigned src = (fl >> PW_SRC_SHIFT) & 15u, contA = (fl >> PW_CONT_A_SHIFT) & 15u, contB = (fl >> PW_CONT_B_SHIFT) & 15u; \
         v4d pn = ACC;                                                                                                     \
         if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; pn = v4d{lo.x, lo.y, hi.x, hi.y}; } \
-        preWait(CUR);                                                                                                     \
+        preWait(CUR, DNXT.flags & 3u);                                                                                    \
         v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
         if (fl & PW_TIP_A) xa = tipVector((int)CUR.sa);                                                                   \
         if (fl & PW_TIP_B) xb = tipVector((int)CUR.sb);                                                                   \
