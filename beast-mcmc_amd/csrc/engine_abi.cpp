@@ -1101,7 +1101,7 @@ int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices,
             int a, b; mi355::shardedBoundsOfHandle(instance, h, &a, &b);
             if (outDerivatives) per[k].assign((size_t)count * (b - a), 0.0);
             const int r = beagleCalculateEdgeDifferentials(h, postBufferIndices, preBufferIndices, derivativeMatrixIndices, categoryWeightsIndices, count,
-                                                           outDerivatives ? per[k].data() : nullptr, out, out + count);
+                                                           outDerivatives ? per[k].data() : nullptr, out, outSumSquaredDerivatives ? out + count : nullptr);   // (NULL lets a shard answer without writing pre-order partials)
             if (!r && outDerivatives)
                 for (int e = 0; e < count; e++) memcpy(outDerivatives + (size_t)e * P + a, &per[k][(size_t)e * (b - a)], (size_t)(b - a) * sizeof(double));
             return r; }, tot.data());

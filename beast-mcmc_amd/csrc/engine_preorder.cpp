@@ -266,12 +266,14 @@ int holdPreList(Instance* in, const int* ops, int count) {
         static const int forced = getenv("BEAGLE_MI355_PRE_CHUNK") ? atoi(getenv("BEAGLE_MI355_PRE_CHUNK")) : -1;
         int chunk = nodes.size() >= 64 ? (int)std::min<long>(256, std::max<long>(24, (long)nodes.size() * groups / 2560)) : 0;
         if (forced >= 0) chunk = forced;
+        static const int forcedMin = getenv("BEAGLE_MI355_PRE_MINHEAD") ? atoi(getenv("BEAGLE_MI355_PRE_MINHEAD")) : -1;
+        const int minHead = forcedMin >= 0 ? forcedMin : std::max(8, chunk / 4);
         std::vector<char> head(nodes.size(), 0);
         std::vector<int> heads(1, root);
         if (chunk > 0)
             for (size_t j = 0; j < nodes.size(); j++) {
                 const int pj = jobOfDest[nodes[j].par];
-                if (pj >= 0 && nodes[j].size <= chunk && nodes[j].size >= std::max(8, chunk / 4) && nodes[pj].size > chunk) { head[j] = 1; heads.push_back((int)j); }
+                if (pj >= 0 && nodes[j].size <= chunk && nodes[j].size >= minHead && nodes[pj].size > chunk) { head[j] = 1; heads.push_back((int)j); }
             }
         for (int hd : heads) {
             h.segStart.push_back((int)h.order.size()); h.segRoot.push_back(hd);

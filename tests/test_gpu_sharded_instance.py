@@ -65,6 +65,26 @@ def test_sharded_instance_equals_single_instance(shards, rescaling, oracle_lib):
     o.close(); single.close(); multi.close()
 
 
+@pytest.mark.parametrize("shards", [0, 3], indirect=True)
+def test_sharded_branch_gradient(shards, oracle_lib):
+    """The gradient pass on the sharded handle (SURVEY 8f row f1 over 8e): every shard holds its pre-order list back and answers
+    the derivative sums from it; the library adds the shards' sums.  A chain of three evaluations with alternating buffers,
+    the last one with second derivatives, against the oracle."""
+    from beast_mcmc_amd.gradient import BranchGradient
+    g = gpu_count()
+    wl = helpers.random_workload(21, 1500, 4, 4, seed=77)
+    m = BranchGradient(wl, resource_list=(g + 1,), double_buffer=True)
+    o = BranchGradient(wl, library=oracle_lib, double_buffer=True)
+    for step in range(3):
+        m.branch_lengths *= 1.1; o.branch_lengths *= 1.1
+        rm, ro = m.gradient(second=step == 2), o.gradient(second=step == 2)
+        assert helpers.rel_err(rm[0], ro[0]) <= 1e-10
+        for a, b in zip(rm[1:], ro[1:]):
+            assert np.max(np.abs(a - b)) <= 1e-10 * max(1.0, np.max(np.abs(b))), step
+    assert m.b.gradientStats() == {"fused": 1, "by_operation": 0, "walked": 2, "late": 0}       # (shard 0's counters)
+    m.close(); o.close()
+
+
 @pytest.mark.parametrize("shards", [4], indirect=True)
 def test_sharded_gather_of_partials_scale_factors_and_20_states(shards):
     g = gpu_count()
