@@ -1,8 +1,10 @@
 """Secondary measurement: full branch-length gradient evaluations per second.
 
 One evaluation = post-order pass + root lnL + pre-order pass (2T-2 ops) + edge derivatives for all 2T-2 branches, driven
-exactly as beast-mcmc_amd/gradient.py mirrors the reference's gradient delegates.  Not the headline metric (bench.py);
-the pre-order kernels are the first correct version.
+exactly as beast-mcmc_amd/gradient.py mirrors the reference's gradient delegates, buffers alternating between two sets as
+BufferIndexHelper makes them.  Not the headline metric (bench.py).  A/B switches (read at instance creation):
+BEAGLE_MI355_NO_PRE_WALK=1 (pre-order partials always written, one sweep per tree level), BEAGLE_MI355_NO_FUSED_GRADIENT=1
+(operation by operation).
 
     python tools/gradient_bench.py --config A --patterns 20000 --steps 5
 """
@@ -48,15 +50,20 @@ def main():
         g.log_likelihood()
     dl = (time.perf_counter() - t0) / args.steps
     buf = wl.pattern_count * wl.state_count * wl.category_count * 8
-    n = wl.tree.node_count
-    # pre-order: read pre(parent) + post(sibling), write pre(child) per op; edge derivatives: read pre + post per edge
-    pre_bytes = (n - 1) * 3 * buf + (n - 1) * 2 * buf
+    internal = wl.tree.node_count - wl.tip_count
+    how = g.b.gradientStats()
+    # what a gradient has to move on top of a likelihood when the sums are answered from the held list (how["walked"]): every
+    # internal node's post-order partial written once by the post-order pass and read once by the pre-order walk; otherwise
+    # (pre-order partials written) also pre(parent) read and pre(child) written per operation
+    walked = how["walked"] >= args.steps
+    extra_bytes = 2 * internal * buf if walked else 2 * internal * buf + (internal + 2 * internal) * buf
     print(json.dumps({"metric": "branch-gradient evals/sec (secondary)", "value": round(1.0 / dt, 3), "ms_per_gradient": round(dt * 1e3, 2),
                       "ms_per_likelihood_same_driver": round(dl * 1e3, 2),
                       "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
                                                                                           wl.state_count, wl.category_count),
-                      "pre_order_plus_edge_algorithmic_GBs": round(pre_bytes / max(dt - dl, 1e-9) / 1e9, 1),
-                      "lnL": lnl, "grad_norm": float((grad ** 2).sum() ** 0.5), "how": g.b.gradientStats(),
+                      "gradient_over_likelihood": round(dt / dl, 2),
+                      "extra_algorithmic_GB": round(extra_bytes / 1e9, 2), "extra_GBs": round(extra_bytes / max(dt - dl, 1e-9) / 1e9, 1),
+                      "lnL": lnl, "grad_norm": float((grad ** 2).sum() ** 0.5), "how": how,
                       "hbm_bytes_resident": int(g.b.deviceBytes())}))
     g.close()
 
