@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
                     help="ranks: one process per GPU + torch.distributed all-reduce (default); library: one process, the engine's resource G+1")
     ap.add_argument("--no-library-route", action="store_true", help="do not append the in-library route's run to the line")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-run under rocprofv3 for roofline.traffic (the re-runs themselves pass this)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU check of the N-rank bring-up only (gloo, no engine, no GPU): tests/test_host_and_abi.py")
     args = ap.parse_args()
@@ -296,6 +298,73 @@ def profiled_traffic(config):
     return rec, "profiles/hbm_traffic.json (%s)" % rec.get("source", "")
 
 
+def live_traffic(args, kernel):
+    """roofline.traffic measured IN THIS RUN: two short re-runs of this very command line under rocprofv3, one per counter
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are never combined with a trace — MI355X_MICROARCH.md), summed over
+    every dispatch of the hot kernel and divided by the evaluations the re-run executed.  FETCH_SIZE is doubled (gfx950
+    tallies the 128-byte requests of a streaming read at 64 bytes), both are in units of 1024 bytes (profiles/summarize.py).
+    -> (record, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled"
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-library-route",
+            "--no-live-traffic", "--config", args.config, "--caller", args.caller, "--scale", str(args.scale), "--tree", args.tree,
+            "--rescaling", args.rescaling, "--cache", args.cache]
+    if args.patterns:
+        base += ["--patterns", str(args.patterns)]
+    if args.real:
+        base += ["--real", args.real]
+    rec = {"kernel": kernel}
+    t0 = time.time()
+    for counter, factor, key in (("FETCH_SIZE", 2.0, "read"), ("WRITE_SIZE", 1.0, "write")):
+        tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--"] + base,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            evals = max(1, int(json.loads(lines[-1]).get("evaluations_total", 1)))
+            total, n = 0.0, 0
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        total += float(row["Counter_Value"]); n += 1
+            if n == 0:
+                return None, "no dispatch of %s in the %s pass" % (kernel, counter)
+            rec["%s_bytes_per_eval" % key] = int(total * 1024.0 * factor / evals)
+            rec["%s_dispatches" % key] = n
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s timed out" % counter
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    rec["bytes_per_eval"] = rec["read_bytes_per_eval"] + rec["write_bytes_per_eval"]
+    return rec, "measured in this run: rocprofv3 --pmc FETCH_SIZE (x2) / --pmc WRITE_SIZE, separate passes of 4 evaluations each, %.0f s" % (time.time() - t0)
+
+
+def traffic_for(args, kernel, world, rank):
+    """roofline.traffic: live (live_traffic) on a 1-GPU run when rocprofv3 is there, else replayed from the committed profile
+    of the same build (profiled_traffic) and labelled so."""
+    if world == 1 and rank == 0 and not args.no_live_traffic:
+        rec, note = live_traffic(args, kernel)
+        if rec:
+            return rec, note
+        live_note = note
+    else:
+        live_note = "not measured live (%s)" % ("child of a profiled run or --no-live-traffic" if args.no_live_traffic else "multi-GPU run")
+    if args.patterns or args.scale != 1.0 or args.real or args.rescaling != "dynamic":
+        return None, live_note + "; no replay: not the profiled size / protocol"
+    rec, note = profiled_traffic(args.config)
+    return rec, ("REPLAYED from " + note if rec else note) + " [" + live_note + "]"
+
+
 def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC):
     import numpy as np
     import torch
@@ -378,7 +447,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             kname = "k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
             launches_per_eval = launches / max(1, args.steps)
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        prof, prof_note = profiled_traffic(args.config) if not args.patterns and args.scale == 1.0 else (None, "not the profiled size")
+        prof, prof_note = traffic_for(args, "k_walk4" if walk else "k_prune", world, rank)
         roofline = {
             "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -502,6 +571,7 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_partitioned(bm, pw)
+        prof, prof_note = traffic_for(args, "k_walk4", world, rank)
         out = {
             "metric": "full-tree lnL evals/sec", "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -510,7 +580,7 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
                                    "updatePartialsByPartition, new branch rates every step" % (pw.name, pw.tip_count, pw.pattern_counts, c_),
                        "patterns_per_gpu": p_, "parallelism": "pattern-shard x%d of every partition + 1 all-reduce of %d doubles" % (world, k)},
             "roofline": {"bound": "hbm", "kernel": "k_walk4", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": "not profiled (latency-bound: %d patterns)" % p_,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(prof["bytes_per_eval"]) if prof else None, "traffic_source": prof_note,
                          "bytes_per_eval": int(moved), "algorithmic_bytes_per_eval": int(alg),
                          "kernel_us_per_eval": round(kernel_s * 1e6, 2), "kernel_time_fraction_of_step": round(kernel_s * args.steps / elapsed, 4),
                          "per_eval": {key: round(v / max(1, args.steps), 1) for key, v in stats.items()}},

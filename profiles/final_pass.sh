@@ -1,17 +1,32 @@
 #!/bin/bash
-# The round's final measurement pass in ONE GPU-box call: GPU test tier, bench lines + rocprofv3 passes (run_round.sh),
-# summaries (so that roofline.traffic matches this build), then the bench lines that carry the counters' traffic.
+# The round's final measurement pass in ONE GPU-box call:   bash profiles/final_pass.sh r03
+#   1. the GPU test tier (log kept)
+#   2. the bench lines of configs A-E as the driver runs them (CPU baseline, roofline.traffic measured live by bench.py itself,
+#      the in-library multi-GPU route appended), plus the protocol variants: BeagleTreeLikelihood caller, ALWAYS rescaling, the
+#      12 500-pattern shard, config D on the reference's two real benchmark alignments
+#   3. rocprofv3 passes of profiles/collect.sh for A, B, C and E (kernel stats, FETCH/WRITE, SQ counters) and their summaries
+#      (profiles/summarize.py: <round>_<cfg>_kernel_stats.csv, _sq_counters.txt, hbm_traffic.json keyed to this build)
 # Everything the repo tracks of it is copied to gpurun_out/profiles_final/ (the box's profiles/ does not travel back).
-R=${1:-r02}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-bash profiles/run_round.sh $R 2>&1 | grep -E "^bench|rc="
-python profiles/summarize.py ${R}_A A k_walk4 > /dev/null; python profiles/summarize.py ${R}_B B k_pruneTiled > /dev/null; python profiles/summarize.py ${R}_C C k_pruneTiled > /dev/null
-for cfg in A B C; do
-  steps=200; [ $cfg != A ] && steps=60
-  timeout 300 python bench.py --config $cfg --steps $steps --warmup 5 2>/dev/null | tail -1 > profiles/${R}_bench_$cfg.json
-  python -c "import json;d=json.loads(open('profiles/${R}_bench_$cfg.json').read());print('$cfg', d['value'], d['roofline']['frac'], d['roofline']['traffic'])"
+R=${1:-r03}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/profiles_final
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/profiles_final/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/profiles_final/${R}_pytest_gpu.log)"
+line() { python -c "import json,sys;d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]);r=d['roofline'];print(sys.argv[2], d['value'],'evals/s kernel us',r['kernel_us_per_eval'],'frac',r['frac'],'traffic',r['traffic'],'|',r['traffic_source'][:60],'| cpu',d['cpu_baseline'] and d['cpu_baseline']['value'],'| lib',d.get('library_route') and d['library_route'].get('value'))" "$1" "$2" 2>&1 | tail -1; }
+for cfg in A B C D E; do
+  steps=200; [ $cfg = B ] && steps=60; [ $cfg = C ] && steps=60
+  timeout 600 python bench.py --config $cfg --steps $steps --warmup 5 2> gpurun_out/${R}_bench_$cfg.err | tail -1 > gpurun_out/profiles_final/${R}_bench_$cfg.json
+  line gpurun_out/profiles_final/${R}_bench_$cfg.json "bench $cfg"
 done
-cp gpurun_out/${R}_bench_D.json gpurun_out/${R}_bench_E.json profiles/
-timeout 120 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${R}_bench_A_btl.json
-timeout 120 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${R}_bench_A_shard12500.json
-mkdir -p gpurun_out/profiles_final; cp profiles/hbm_traffic.json profiles/${R}_* gpurun_out/profiles_final/
+timeout 300 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_btl.json; line gpurun_out/profiles_final/${R}_bench_A_btl.json "A btl"
+timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5 --no-cpu-baseline --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_always.json; line gpurun_out/profiles_final/${R}_bench_A_always.json "A always"
+timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard12500.json; line gpurun_out/profiles_final/${R}_bench_A_shard12500.json "A shard"
+for real in benchmark1 benchmark2; do
+  timeout 300 python bench.py --real $real --steps 200 --warmup 5 --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_D_$real.json; line gpurun_out/profiles_final/${R}_bench_D_$real.json "D $real"
+done
+TAG=_A STEPS=10 bash profiles/collect.sh $R --config A 2>&1 | grep rc=
+TAG=_B STEPS=5 bash profiles/collect.sh $R --config B 2>&1 | grep rc=
+TAG=_C STEPS=5 bash profiles/collect.sh $R --config C 2>&1 | grep rc=
+TAG=_E STEPS=20 bash profiles/collect.sh $R --config E 2>&1 | grep rc=
+python profiles/summarize.py ${R}_A A k_walk4 > /dev/null; python profiles/summarize.py ${R}_B B k_pruneTiled > /dev/null
+python profiles/summarize.py ${R}_C C k_pruneTiled > /dev/null; python profiles/summarize.py ${R}_E E k_walk4 > /dev/null
+cp profiles/hbm_traffic.json profiles/${R}_*_kernel_stats.csv profiles/${R}_*_sq_counters.txt profiles/${R}_?_bench.json gpurun_out/profiles_final/ 2>/dev/null
+python -c "import json;d=json.load(open('profiles/hbm_traffic.json'));[print(k, v['bytes_per_eval'], v.get('design_bytes_per_eval'), v.get('HBM_GBps_from_counters')) for k,v in d.items()]"
+ls gpurun_out/profiles_final | wc -l

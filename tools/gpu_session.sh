@@ -17,7 +17,7 @@ print('A', d['value'], 'evals/s kernel us', d['roofline']['kernel_us_per_eval'],
 PY
   ;;
 shard)
-  timeout 300 python bench.py --patterns 12500 --no-cpu-baseline > gpurun_out/${TAG}_bench_shard.json 2> gpurun_out/${TAG}_bench_shard.err; echo "shard rc=$?"
+  timeout 300 python bench.py --patterns 12500 --no-cpu-baseline --no-live-traffic > gpurun_out/${TAG}_bench_shard.json 2> gpurun_out/${TAG}_bench_shard.err; echo "shard rc=$?"
   python - <<PY
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench_shard.json').read().strip().splitlines()[-1])
@@ -26,7 +26,7 @@ PY
   ;;
 trace)
   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}_trace" -o kt -- \
-     python "$ROOT/bench.py" --patterns 12500 --steps 20 --warmup 3 --no-cpu-baseline --no-library-route > "$ROOT/gpurun_out/${TAG}_trace.json" 2> "$ROOT/gpurun_out/${TAG}_trace.err"; echo "trace rc=$?")
+     python "$ROOT/bench.py" --patterns 12500 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --no-library-route > "$ROOT/gpurun_out/${TAG}_trace.json" 2> "$ROOT/gpurun_out/${TAG}_trace.err"; echo "trace rc=$?")
   find gpurun_out/${TAG}_trace -name "*.db" -delete 2>/dev/null
   python tools/timeline.py gpurun_out/${TAG}_trace 2>&1 | tail -40;;
 host)
