@@ -398,16 +398,36 @@ void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double*
 // ------------------------------------------------------------------------------------------------
 // scale-factor bookkeeping
 // ------------------------------------------------------------------------------------------------
+// cum[p] += sign * sum_k log f_k[p] (raw factors) or sum_k l_k[p] (buffers that hold logarithms already).  A thread owns a
+// pattern and walks the buffers; the sum of logarithms of the raw factors is formed as ONE logarithm of their product, the
+// product kept as (mantissa in [0.5, 1), binary exponent) so that it cannot leave the range: per factor a mask, an add and a
+// multiply instead of a 40-instruction fp64 log (config A, 999 buffers x 1e5 patterns: 727 -> see profiles/r03_experiments.txt).
 __global__ __launch_bounds__(256) void k_accumulate(double* __restrict__ cum, const double* const* __restrict__ srcs,
                                                     const int* __restrict__ raw, int count, double sign, int pStart, int pEnd) {
     const int p = pStart + blockIdx.x * 256 + threadIdx.x;
     if (p >= pEnd) return;
-    double acc = 0.0;
-    for (int k = 0; k < count; k++) {
-        const double v = srcs[k][p];
-        acc += raw[k] ? log(v) : v;
+    double logs = 0.0, mant = 1.0;
+    long expo = 0;
+    auto take = [&](double v, int isRaw, int k) {
+        if (!isRaw) { logs += v; return; }
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const int field = (int)((bits >> 52) & 0x7ffull);
+        if (field == 0 || field == 0x7ff || (long long)bits < 0) { logs += log(v); return; }       // zero, denormal, inf / nan, negative: as written
+        mant *= __longlong_as_double((long long)((bits & 0x800fffffffffffffull) | 0x3fe0000000000000ull));
+        expo += field - 1022;
+        if ((k & 255) == 255) {                        // 256 mantissas >= 0.5 each: the product is still >= 2^-256
+            const unsigned long long mb = (unsigned long long)__double_as_longlong(mant);
+            expo += (int)((mb >> 52) & 0x7ffull) - 1022;
+            mant = __longlong_as_double((long long)((mb & 0x800fffffffffffffull) | 0x3fe0000000000000ull));
+        }
+    };
+    int k = 0;
+    for (; k + 4 <= count; k += 4) {                   // four independent loads in flight
+        const double v0 = gptr(srcs[k])[p], v1 = gptr(srcs[k + 1])[p], v2 = gptr(srcs[k + 2])[p], v3 = gptr(srcs[k + 3])[p];
+        take(v0, raw[k], k); take(v1, raw[k + 1], k + 1); take(v2, raw[k + 2], k + 2); take(v3, raw[k + 3], k + 3);
     }
-    cum[p] += sign * acc;
+    for (; k < count; k++) take(gptr(srcs[k])[p], raw[k], k);
+    cum[p] += sign * (logs + (log(mant) + (double)expo * 0.69314718055994530942));
 }
 
 void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
