@@ -242,8 +242,10 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     const bool noVirtual = getenv("BEAGLE_MI355_NO_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_VIRTUAL")) != 0;
     // T32 instances with <= 20 states: tip-tip nodes ("cherries") are defined, not stored — their parent's kernel rebuilds
     // them from the tips' states (kernels_mfma.hip cherryOperands); a definition is ONE step here
-    in->cherry = in->tiled && stateCount <= 20 && !noVirtual;
-    const bool virtualOn = (in->walk && !noVirtual) || in->cherry;
+    // 16..20 states: the pattern walk on the T32 layout (BEAGLE_MI355_NO_T32_WALK=1: the level kernels with virtual cherries)
+    in->walkT = in->tiled && stateCount <= 20 && categoryCount <= 16 && !(getenv("BEAGLE_MI355_NO_T32_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WALK")) != 0);
+    in->cherry = in->tiled && stateCount <= 20 && !noVirtual && !in->walkT;
+    const bool virtualOn = ((in->walk || in->walkT) && !noVirtual) || in->cherry;
     in->virt = virtualOn;
     // Size of a virtual definition (internal nodes; any subtree shape whose evaluation needs at most two hold slots).
     // Evaluations at alignment sizes that keep the chip busy are bound by the bytes of the STORED nodes and their time
@@ -372,7 +374,13 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     }
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
-    if (in->walk) in->planner.setPartitionCount(partitionCount);
+    if (in->walkT && partitionCount > 1) {
+        // the T32 walk's workgroups are whole tiles of one range: a partitioned instance goes back to the level kernels, with
+        // every node it had left unstored written first
+        for (int X = 0; X < in->partialsCount; X++) if (isVirt(in, X)) { int rcv = materializeVirtual(in, X); if (rcv) return rcv; }
+        in->walkT = false; in->virt = false;
+    }
+    if (in->walk || in->walkT) in->planner.setPartitionCount(partitionCount);
     if (in->walk && in->virt) {
         // definitions are kept per (buffer, partition): more snapshot slots behind the caller's matrices
         const size_t per = (size_t)in->C * in->S * in->S, slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());

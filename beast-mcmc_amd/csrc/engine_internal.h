@@ -97,6 +97,9 @@ struct Instance {
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials
     bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)
+    // 16..20 states: operation lists without write-mode rescaling run as the walk's programs on the T32 layout (kernels_mfma.hip
+    // k_walkT32: same planner, same descriptors; engine_walk.cpp); everything 4-state-specific (`walk`) stays off
+    bool walkT = false;
     bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]
     bool strictWaits = true;                             // a stage's wait does not count on the previous stage's stores retiring behind its
                                                          // loads (runPlan); BEAGLE_MI355_STRICT_WAITS=0 at creation: it does (1 % faster)

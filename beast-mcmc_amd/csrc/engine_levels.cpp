@@ -246,7 +246,23 @@ int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globa
 }
 
 int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
-    return in->walk ? runOperationsWalk(in, ops, count, tuple, globalCum) : runOperationsLevels(in, ops, count, tuple, globalCum);
+    if (in->walk) return runOperationsWalk(in, ops, count, tuple, globalCum);
+    if (in->walkT) {
+        // the T32 walk has no write mode (a pattern's factor needs all its categories, which sit in different workgroups):
+        // a list that rescales in write mode runs level by level, on operands that exist in memory
+        bool writes = false;
+        for (int k = 0; k < count && !writes; k++) writes = ops[(size_t)k * tuple + 1] != BEAGLE_OP_NONE;
+        if (!writes) return runOperationsWalk(in, ops, count, tuple, globalCum);
+        std::vector<int> need;
+        for (int k = 0; k < count; k++) {
+            const int* op = ops + (size_t)k * tuple;
+            if (badIndex(op[3], in->partialsCount) || badIndex(op[5], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (isVirt(in, op[3])) in->planner.keysOf(op[3], need);
+            if (isVirt(in, op[5])) in->planner.keysOf(op[5], need);
+        }
+        if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
+    }
+    return runOperationsLevels(in, ops, count, tuple, globalCum);
 }
 
 

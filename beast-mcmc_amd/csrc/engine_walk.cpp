@@ -39,7 +39,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     w.clear();
     w.reserve(n + 3 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
-    const size_t matStride = (size_t)in->C * 16;
+    const size_t matStride = (size_t)in->C * in->S * in->S;
+    const size_t tipOff = in->walkT ? 0 : in->statePairOff;          // the T32 walk reads the plain state arrays and the RAW scale factors
     { int rc = ensureWalkDummies(in); if (rc) return rc; }
     mi355::WalkOp nop;
     memset(&nop, 0, sizeof(nop));
@@ -62,16 +63,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             memset(&d, 0, sizeof(d));
             d.src1 = in->dummyTips; d.src2 = in->dummyTips; d.scale = in->onesScale;     // unused operands stay readable (kernels.h launchWalk4Fast)
             if (m.k1 == mi355::PK_MEM) { d.src1 = in->partials[m.a1]; if (!d.src1 || isCompactTip(in, m.a1)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + in->statePairOff; in->statTipReads++; }
+            else if (m.k1 == mi355::PK_TIPS) { if (!in->tipStates[m.a1]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src1 = in->tipStates[m.a1] + tipOff; in->statTipReads++; }
             if (m.k2 == mi355::PK_MEM) { d.src2 = in->partials[m.a2]; if (!d.src2 || isCompactTip(in, m.a2)) return BEAGLE_ERROR_OUT_OF_RANGE; in->statMemReads++; }
-            else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + in->statePairOff; in->statTipReads++; }
+            else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + tipOff; in->statTipReads++; }
             if (m.smode != mi355::PS_NONE) {
                 int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-                if (m.smode == mi355::PS_WRITE) { in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
+                if (m.smode == mi355::PS_WRITE) { if (in->walkT) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
                 else {
                     if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
                     in->statScaleReads++;
-                    d.scale = in->scale[m.scaleIdx] + in->scaleStride;                    // read mode multiplies by the reciprocal
+                    d.scale = in->scale[m.scaleIdx] + (in->walkT ? 0 : in->scaleStride);  // read mode multiplies by the reciprocal
                 }
             }
             if (m.storeBuf >= 0) {
@@ -158,7 +159,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
-    const size_t streamBytes = w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
+    const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 1024
+                                         : w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(in->stream));
         if (in->matStream) hipFree(in->matStream);
@@ -167,7 +169,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         HIP_TRY(hipMalloc((void**)&in->matStream, want));
         in->matStreamBytes = want;
     }
-    mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
+    if (in->walkT) mi355::launchGatherFragments(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    else mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
         for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
@@ -181,7 +184,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         int range = 0;
         const bool fast = in->fastWalk;                 // the assembly loop (BEAGLE_MI355_NO_FAST_WALK=1: the C++ reference kernel)
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
-        if (fast) {
+        if (in->walkT) {
+            if (!mi355::launchWalkT32(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+                                      in->matStream, in->P, in->S, in->C)) return BEAGLE_ERROR_GENERAL;
+        } else if (fast) {
             mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                    in->matStream, in->P, in->C, (long)in->scaleStride);
             in->statFastWalks++;
@@ -199,7 +205,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
 // partitionCount + partition; the buffer index itself on an instance with one partition).
 int materializeList(Instance* in, const std::vector<int>& xs) {
     if (!in->virt || xs.empty()) return 0;
-    if (!in->walk) return materializeCherries(in, xs);
+    if (!in->walk && !in->walkT) return materializeCherries(in, xs);
     mi355::Plan mp;
     in->planner.planMaterialize(xs, mp);
     return runPlan(in, mp);

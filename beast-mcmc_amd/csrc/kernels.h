@@ -269,6 +269,12 @@ int  pruneBlocksForRange(int S, int range);
 
 // ---- T32 layout (20-/61-state MFMA path, kernels_mfma.hip): partials[c][tile][state][32 patterns] --------------
 // One dependency level on the fp64 matrix cores; anyScaleWrite adds the second (max + divide) pass.
+// 17..20 states: the walk's programs on the T32 layout (kernels_mfma.hip k_walkT32): same descriptors and segments as the 4-state
+// walk (src = plain tip states / T32 partials, scale = the RAW factors, no write mode); dStream from launchGatherFragments over
+// the same device program (walkT32StreamBytes)
+size_t walkT32StreamBytes(int nEntries, int C);
+void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C);
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
                            bool anyScaleWrite, const CherryDesc* dCherries = nullptr);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)

@@ -133,8 +133,12 @@ __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int 
             for (int k = 0; k < IH; k++) {
                 if (it0 + k < nt) {
                     const double a = frag[((it0 + k) * NTMAX + jt) * 16 + fl];
+#ifdef MI355_EXP_NOMFMA      // TIMING EXPERIMENTS ONLY: one multiply-add instead of the two matrix instructions
+                    oe[k] += a * b[jt].x; oo[k] += a * b[jt].y;
+#else
                     oe[k] = mfma4(a, b[jt].x, oe[k]);
                     oo[k] = mfma4(a, b[jt].y, oo[k]);
+#endif
                 }
             }
         }
@@ -180,6 +184,10 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
         v2d b1[NTMAX], b2[NTMAX];
         int se1 = S, so1 = S;
         if (PIPE == 2 && !vt1 && tile < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);   // in flight across the staging
+#ifdef MI355_EXP_NOSTAGE     // TIMING EXPERIMENTS ONLY (tools/build_mfma_variant.sh; wrong results): what the fragment staging costs
+        for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) frag[e] = 0.5;
+        if (false)
+#endif
         for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) {
             const int child = e >= fragN, r = e - child * fragN;
             const int f = r >> 4, q = r & 15;
@@ -249,8 +257,12 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
                             if (it0 + k < nt && i < S) {
                                 v2d o; o.x = re[it0 - h0 + k] * te[k] * inve; o.y = ro[it0 - h0 + k] * to[k] * invo;
                                 double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
+#ifdef MI355_EXP_NOSTORE     // TIMING EXPERIMENTS ONLY: the result is stored only where it cannot be (keeps the arithmetic alive)
+                                if (o.x == -1.0) q[0] = o.x;
+#else
                                 if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
                                 else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+#endif
                             }
                         }
                     }
@@ -318,7 +330,8 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     }
     const int nt = (S + 3) / 4;
     // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
-    dim3 grid(tiledBlocksPerRow(P, nOps * C, nt <= 5 ? 2048 : 1024), nOps * C), block(MF_BLOCK);
+    static const int target = [] { const char* e = getenv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
+    dim3 grid(tiledBlocksPerRow(P, nOps * C, target > 0 ? target : (nt <= 5 ? 2048 : 1024)), nOps * C), block(MF_BLOCK);
     static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
 #define TILED_LAUNCH(NT, EX, PI) do { if (NT <= 5 && dCherries) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, NT <= 5>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); \
                                         else hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, false>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); } while (0)
@@ -340,6 +353,151 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     }
 #undef TILED_LAUNCH
     if (anyScaleWrite) hipLaunchKernelGGL(k_rescaleTiled, dim3(tiledBlocksPerRow(P, nOps, 2048), nOps), block, 0, stream, dOps, P, S, C);
+}
+
+// ---- the pattern walk on the T32 layout (17..20 states) ------------------------------------------------------------------
+// The level kernel above is bound by the bytes of storing every node and reading it back (config B rebuilt without its stores:
+// 4.2 -> 2.0 ms, profiles/r03_experiments.txt 11).  A pattern tile never needs another tile's data either, so the 4-state
+// walk's idea carries over: a wave that owns (tile of 32 patterns, rate category) executes a whole post-order program of
+// micro-operations (planner.h — the same programs, kinds, hold slots and definitions as kernels_walk4.hip), its running result
+// in registers (ACC: the MFMA's D layout IS the B-operand layout, so a result feeds the next product as it is), values that
+// wait for a sibling's subtree in LDS hold slots, and only the nodes the planner wants stored go to memory.
+// What does NOT carry over is the size of a branch matrix: 3.2 KB per category against 128 bytes.  A workgroup is therefore
+// four tiles of ONE category: its four waves share the two matrices of a micro-operation, which arrive as ready-made A
+// fragments in program order (k_gatherFragments lays them out once per evaluation) and are staged through LDS one
+// micro-operation ahead, double-buffered, one barrier per micro-operation.  Read-mode rescaling only (a factor per pattern
+// needs all categories of the pattern: write-mode lists take the level path).
+constexpr int WT_NT = 5, WT_FRAG = WT_NT * WT_NT * 16;                // doubles per matrix
+constexpr int WT_HOLD_V2D = WT_NT * 64;                              // v2d per wave and hold slot
+
+__global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C, int S, double* __restrict__ stream) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * C * 2 * WT_FRAG) return;
+    const int q = (int)(t & 15), f = (int)((t >> 4) % (WT_NT * WT_NT)), child = (int)((t / WT_FRAG) & 1), c = (int)((t / (2 * WT_FRAG)) % C),
+              k = (int)(t / ((size_t)2 * WT_FRAG * C));
+    const int it = f / WT_NT, jt = f - it * WT_NT, i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+    const double MI355_GLOBAL* M = gptr(child ? prog[k].m2 : prog[k].m1) + (size_t)c * S * S;
+    stream[t] = (i < S && j < S) ? M[(size_t)i * S + j] : 0.0;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+                                                         const double* __restrict__ fragStream, int P, int S, int C) {
+    extern __shared__ double wtLds[];              // frag[2][2 * WT_FRAG] doubles, then hold[3][4 waves][WT_NT][64] v2d
+    const WalkSeg& sg = segs[blockIdx.y / C];
+    const int c = blockIdx.y % C;
+    const int ntile = (P + TILE - 1) / TILE;
+    const int tile1 = (sg.pEnd + TILE - 1) / TILE;
+    const int tileB = sg.pStart / TILE + (int)blockIdx.x * 4;
+    if (tileB >= tile1) return;                    // the whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool active = tileB + wave < tile1;      // a wave past the end walks the last tile along (barriers, staging) and stores nothing
+    const int tile = active ? tileB + wave : tile1 - 1;
+    const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+    const int pe = tile * TILE + 2 * m;
+    const bool ine = active && pe >= sg.pStart && pe < sg.pEnd, ino = active && pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
+    v2d* hold = reinterpret_cast<v2d*>(wtLds + 4 * WT_FRAG) + (size_t)wave * WT_HOLD_V2D + lane;     // + slot * 4 * WT_HOLD_V2D, tile row k at + 64 k
+    const int nOps = sg.progCount;
+    const WalkOp* dp = prog + sg.progStart;
+    const v2d MI355_GLOBAL* fs = gptr(reinterpret_cast<const v2d*>(fragStream)) + ((size_t)sg.progStart * C + c) * WT_FRAG;   // (2 * WT_FRAG doubles = WT_FRAG v2d per entry and category)
+    const size_t fsStep = (size_t)C * WT_FRAG;
+    v2d* fragV = reinterpret_cast<v2d*>(wtLds);
+    {   // the first micro-operation's fragments
+        const int t = threadIdx.x;                 // 2 matrices x 400 doubles = WT_FRAG v2d
+        fragV[t] = fs[t];
+        if (t < WT_FRAG - 256) fragV[t + 256] = fs[t + 256];
+    }
+    __syncthreads();
+    v2d ACC[WT_NT];
+#pragma unroll
+    for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
+    for (int k = 0; k < nOps; k++) {
+        const WalkOp& d = dp[k];
+        const unsigned flg = d.flags;
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3, smode = (flg >> 13) & 3;
+        // the next micro-operation's fragments: requested now, written to the other buffer when this one's arithmetic is done
+        const v2d MI355_GLOBAL* fn = fs + (size_t)(k + 1) * fsStep;     // (two no-op entries follow every segment: always readable)
+        const int t = threadIdx.x;
+        const v2d n0 = fn[t];
+        v2d n1 = v2d{0.0, 0.0};
+        if (t < WT_FRAG - 256) n1 = fn[t + 256];
+        const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;
+        // operands
+        v2d b1[WT_NT], b2[WT_NT];
+        int se1 = S, so1 = S, se2 = S, so2 = S;
+        if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);
+        else if (k1 == WK_TIPS) {
+            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src1));
+            if (pe < P) se1 = st[pe];
+            if (pe + 1 < P) so1 = st[pe + 1];
+        } else {
+            const v2d* h = hold + (size_t)(k1 - WK_H0) * 4 * WT_HOLD_V2D;
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];
+        }
+        if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
+        else if (k2 == WK_TIPS) {
+            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src2));
+            if (pe < P) se2 = st[pe];
+            if (pe + 1 < P) so2 = st[pe + 1];
+        } else {
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) b2[j] = ACC[j];
+        }
+        double inve = 1.0, invo = 1.0;
+        if (smode == WS_READ) {
+            const double MI355_GLOBAL* sr = gptr(d.scale);
+            if (pe < P) inve = 1.0 / sr[pe];
+            if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
+        }
+        double re[WT_NT], ro[WT_NT], te[WT_NT], to[WT_NT];
+        tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, se1, so1, nullptr, b1, 0, g, fl, re, ro);
+        tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, se2, so2, nullptr, b2, 0, g, fl, te, to);
+#pragma unroll
+        for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};
+        if (flg & WF_STORE) {
+            char* dst = reinterpret_cast<char*>(d.store + tileBase);
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) {
+                if (EXACT || 4 * j + g < S) {
+                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u)));
+                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }
+                }
+            }
+        }
+        if (hslot) {
+            v2d* h = hold + (size_t)(hslot - 1) * 4 * WT_HOLD_V2D;
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];
+        }
+        v2d* fw = fragV + (size_t)((k + 1) & 1) * WT_FRAG;
+        fw[t] = n0;
+        if (t < WT_FRAG - 256) fw[t + 256] = n1;
+        __syncthreads();
+    }
+}
+
+constexpr size_t WT_LDS_BYTES = (size_t)4 * WT_FRAG * sizeof(double) + (size_t)3 * 4 * WT_HOLD_V2D * sizeof(v2d);
+
+// the fragment stream of a device program of nEntries descriptors: [entry][category][child][25 tile pairs][16]
+size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WT_FRAG * sizeof(double); }
+void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream) {
+    if (nEntries <= 0) return;
+    const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
+    hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
+}
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C) {
+    if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 20 || (size_t)nSegs * C > 65535) return false;
+    if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<true>), 160 * 1024) ||
+        !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<false>), 160 * 1024)) return false;
+    const dim3 grid((maxRange + 4 * TILE - 1) / (4 * TILE), nSegs * C), block(MF_BLOCK);
+    if (S == 20) hipLaunchKernelGGL(k_walkT32<true>, grid, block, WT_LDS_BYTES, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+    else hipLaunchKernelGGL(k_walkT32<false>, grid, block, WT_LDS_BYTES, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+    return true;
 }
 
 // root integration on the T32 layout: thread per pattern, consecutive lanes = consecutive patterns of a tile
