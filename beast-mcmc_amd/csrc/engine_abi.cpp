@@ -256,8 +256,10 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 24 : 8;
     if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;
-    in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn,
-                     getenv("BEAGLE_MI355_HOLD_SLOTS") ? std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), mi355::walkHoldSlots(categoryCount)) : mi355::walkHoldSlots(categoryCount));
+    // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
+    in->holdSlots = in->walkT ? 2 : mi355::walkHoldSlots(categoryCount);
+    if (getenv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
+    in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn, in->holdSlots);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
     in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);

@@ -186,7 +186,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         if (in->walkT) {
             if (!mi355::launchWalkT32(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                      in->matStream, in->P, in->S, in->C)) return BEAGLE_ERROR_GENERAL;
+                                      in->matStream, in->P, in->S, in->C, in->holdSlots)) return BEAGLE_ERROR_GENERAL;
         } else if (fast) {
             mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                    in->matStream, in->P, in->C, (long)in->scaleStride);

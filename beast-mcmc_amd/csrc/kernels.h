@@ -274,7 +274,7 @@ int  pruneBlocksForRange(int S, int range);
 // the same device program (walkT32StreamBytes)
 size_t walkT32StreamBytes(int nEntries, int C);
 void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
-bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C);
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots);
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
                            bool anyScaleWrite, const CherryDesc* dCherries = nullptr);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)

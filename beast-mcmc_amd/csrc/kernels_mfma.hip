@@ -381,7 +381,7 @@ __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C,
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+__global__ __launch_bounds__(MF_BLOCK, 3) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
                                                          const double* __restrict__ fragStream, int P, int S, int C) {
     extern __shared__ double wtLds[];              // frag[2][2 * WT_FRAG] doubles, then hold[3][4 waves][WT_NT][64] v2d
     const WalkSeg& sg = segs[blockIdx.y / C];
@@ -414,48 +414,62 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     v2d ACC[WT_NT];
 #pragma unroll
     for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
+    // what a micro-operation needs from memory is requested ONE micro-operation ahead (its first child's partials, the tips'
+    // state codes, the raw scale factors) and lands while the previous one computes; a second child in memory is rare and read
+    // where it is needed
+    struct Pref { v2d b1[WT_NT]; int se1, so1, se2, so2; double fe, fo; };
+    auto fetch = [&](const WalkOp& d, Pref& f) {
+        const unsigned flg = d.flags;
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, smode = (flg >> 13) & 3;
+        f.se1 = f.so1 = f.se2 = f.so2 = S; f.fe = f.fo = 1.0;
+        if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, f.b1);
+        else if (k1 == WK_TIPS) {
+            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src1));
+            if (pe < P) f.se1 = st[pe];
+            if (pe + 1 < P) f.so1 = st[pe + 1];
+        }
+        if (k2 == WK_TIPS) {
+            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src2));
+            if (pe < P) f.se2 = st[pe];
+            if (pe + 1 < P) f.so2 = st[pe + 1];
+        }
+        if (smode == WS_READ) {
+            const double MI355_GLOBAL* sr = gptr(d.scale);
+            if (pe < P) f.fe = sr[pe];
+            if (pe + 1 < P) f.fo = sr[pe + 1];
+        }
+    };
+    Pref cur;
+    fetch(dp[0], cur);
     for (int k = 0; k < nOps; k++) {
         const WalkOp& d = dp[k];
         const unsigned flg = d.flags;
-        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3, smode = (flg >> 13) & 3;
-        // the next micro-operation's fragments: requested now, written to the other buffer when this one's arithmetic is done
-        const v2d MI355_GLOBAL* fn = fs + (size_t)(k + 1) * fsStep;     // (two no-op entries follow every segment: always readable)
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3;
+        // the next micro-operation's fragments and operands: requested now; the fragments go to the other LDS buffer when this
+        // micro-operation's arithmetic is done (two no-op entries follow every segment: always readable)
+        const v2d MI355_GLOBAL* fn = fs + (size_t)(k + 1) * fsStep;
         const int t = threadIdx.x;
         const v2d n0 = fn[t];
         v2d n1 = v2d{0.0, 0.0};
         if (t < WT_FRAG - 256) n1 = fn[t + 256];
+        Pref nxt;
+        fetch(dp[k + 1], nxt);
         const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;
-        // operands
-        v2d b1[WT_NT], b2[WT_NT];
-        int se1 = S, so1 = S, se2 = S, so2 = S;
-        if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);
-        else if (k1 == WK_TIPS) {
-            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src1));
-            if (pe < P) se1 = st[pe];
-            if (pe + 1 < P) so1 = st[pe + 1];
-        } else {
+        v2d b2[WT_NT];
+        if (k1 >= WK_H0) {
             const v2d* h = hold + (size_t)(k1 - WK_H0) * 4 * WT_HOLD_V2D;
 #pragma unroll
-            for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];
+            for (int j = 0; j < WT_NT; j++) cur.b1[j] = h[64 * j];
         }
         if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
-        else if (k2 == WK_TIPS) {
-            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src2));
-            if (pe < P) se2 = st[pe];
-            if (pe + 1 < P) so2 = st[pe + 1];
-        } else {
+        else if (k2 == WK_ACC) {
 #pragma unroll
             for (int j = 0; j < WT_NT; j++) b2[j] = ACC[j];
         }
-        double inve = 1.0, invo = 1.0;
-        if (smode == WS_READ) {
-            const double MI355_GLOBAL* sr = gptr(d.scale);
-            if (pe < P) inve = 1.0 / sr[pe];
-            if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
-        }
+        const double inve = 1.0 / cur.fe, invo = 1.0 / cur.fo;
         double re[WT_NT], ro[WT_NT], te[WT_NT], to[WT_NT];
-        tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, se1, so1, nullptr, b1, 0, g, fl, re, ro);
-        tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, se2, so2, nullptr, b2, 0, g, fl, te, to);
+        tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, cur.se1, cur.so1, nullptr, cur.b1, 0, g, fl, re, ro);
+        tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, cur.se2, cur.so2, nullptr, b2, 0, g, fl, te, to);
 #pragma unroll
         for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};
         if (flg & WF_STORE) {
@@ -477,11 +491,13 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
         v2d* fw = fragV + (size_t)((k + 1) & 1) * WT_FRAG;
         fw[t] = n0;
         if (t < WT_FRAG - 256) fw[t + 256] = n1;
+        cur = nxt;
         __syncthreads();
     }
 }
 
-constexpr size_t WT_LDS_BYTES = (size_t)4 * WT_FRAG * sizeof(double) + (size_t)3 * 4 * WT_HOLD_V2D * sizeof(v2d);
+// LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
+static size_t walkT32Lds(int holdSlots) { return (size_t)4 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 4 * WT_HOLD_V2D * sizeof(v2d); }
 
 // the fragment stream of a device program of nEntries descriptors: [entry][category][child][25 tile pairs][16]
 size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WT_FRAG * sizeof(double); }
@@ -490,13 +506,14 @@ void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries
     const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
     hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
 }
-bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C) {
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots) {
     if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 20 || (size_t)nSegs * C > 65535) return false;
     if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<true>), 160 * 1024) ||
         !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<false>), 160 * 1024)) return false;
     const dim3 grid((maxRange + 4 * TILE - 1) / (4 * TILE), nSegs * C), block(MF_BLOCK);
-    if (S == 20) hipLaunchKernelGGL(k_walkT32<true>, grid, block, WT_LDS_BYTES, stream, dProg, dSegs, (const double*)dStream, P, S, C);
-    else hipLaunchKernelGGL(k_walkT32<false>, grid, block, WT_LDS_BYTES, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+    const size_t lds = walkT32Lds(holdSlots < 1 ? 1 : holdSlots > 3 ? 3 : holdSlots);
+    if (S == 20) hipLaunchKernelGGL(k_walkT32<true>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+    else hipLaunchKernelGGL(k_walkT32<false>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C);
     return true;
 }
 
