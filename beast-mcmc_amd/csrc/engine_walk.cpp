@@ -159,7 +159,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
-    const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 1024
+    const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
                                          : w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(in->stream));
@@ -175,6 +175,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
         for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
         fprintf(stderr, "\n");
+        if (atoi(getenv("BEAGLE_MI355_DUMP_PLAN")) > 1)
+            for (size_t i = 0; i < w.size(); i++)
+                fprintf(stderr, "[mi355]   %3zu: k1 %u k2 %u hold %u scale %u store %d\n", i, (w[i].flags >> 5) & 7, (w[i].flags >> 8) & 7, (w[i].flags >> 11) & 3,
+                        (w[i].flags >> 13) & 3, (w[i].flags & mi355::WF_STORE) ? 1 : 0);
     }
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)

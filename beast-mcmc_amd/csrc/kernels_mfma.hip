@@ -381,7 +381,7 @@ __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C,
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(MF_BLOCK, 3) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+__global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
                                                          const double* __restrict__ fragStream, int P, int S, int C) {
     extern __shared__ double wtLds[];              // frag[2][2 * WT_FRAG] doubles, then hold[3][4 waves][WT_NT][64] v2d
     const WalkSeg& sg = segs[blockIdx.y / C];
@@ -414,86 +414,107 @@ __global__ __launch_bounds__(MF_BLOCK, 3) void k_walkT32(const WalkOp* __restric
     v2d ACC[WT_NT];
 #pragma unroll
     for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
-    // what a micro-operation needs from memory is requested ONE micro-operation ahead (its first child's partials, the tips'
-    // state codes, the raw scale factors) and lands while the previous one computes; a second child in memory is rare and read
-    // where it is needed
-    struct Pref { v2d b1[WT_NT]; int se1, so1, se2, so2; double fe, fo; };
-    auto fetch = [&](const WalkOp& d, Pref& f) {
-        const unsigned flg = d.flags;
-        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, smode = (flg >> 13) & 3;
-        f.se1 = f.so1 = f.se2 = f.so2 = S; f.fe = f.fo = 1.0;
-        if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, f.b1);
-        else if (k1 == WK_TIPS) {
-            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src1));
-            if (pe < P) f.se1 = st[pe];
-            if (pe + 1 < P) f.so1 = st[pe + 1];
-        }
-        if (k2 == WK_TIPS) {
-            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(d.src2));
-            if (pe < P) f.se2 = st[pe];
-            if (pe + 1 < P) f.so2 = st[pe + 1];
-        }
-        if (smode == WS_READ) {
-            const double MI355_GLOBAL* sr = gptr(d.scale);
-            if (pe < P) f.fe = sr[pe];
-            if (pe + 1 < P) f.fo = sr[pe + 1];
-        }
+    // Everything a micro-operation needs from memory as a matter of course — its 6.4 KB of fragments (two 16-byte loads per
+    // thread), the two children's state codes (one ushort each: the lane's two patterns are neighbours), the raw scale factors
+    // (one 16-byte load) — is requested TWO micro-operations ahead, by the same five instructions whatever the kinds are (the
+    // host points unused operands at dummies, engine_walk.cpp), so the waits are constants: "all but the five youngest loads".
+    // Loads return in issue order; stores and the compiler's own loads in the queue only make a wait stricter.  The compiler
+    // cannot express that (it drains the queue at the first use), hence inline assembly, as in kernels_walk4.hip.  A child's
+    // PARTIALS in memory are rare (20 of 499 micro-operations of config B) and are read where they are needed.
+    struct Flight { v2d f0, f1; unsigned t1, t2; v2d sc; };          // one micro-operation's loads (registers written asynchronously)
+    const unsigned oFrag = (unsigned)threadIdx.x * 16u, oFrag2 = oFrag + 4096u, oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
+    auto issue = [&](Flight& f, const WalkOp& d, const v2d MI355_GLOBAL* fptr) {
+        asm volatile(
+            "global_load_dwordx4 %[f0], %[oF], %[fp]\n\t"
+            "global_load_dwordx4 %[f1], %[oF2], %[fp]\n\t"
+            "global_load_ushort %[t1], %[oP], %[s1]\n\t"
+            "global_load_ushort %[t2], %[oP], %[s2]\n\t"
+            "global_load_dwordx4 %[sc], %[oS], %[ss]"
+            : [f0] "=&v"(f.f0), [f1] "=&v"(f.f1), [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)      /* (pure outputs: a tie to the old value
+                  would make the compiler shuffle registers around the wait — and read a destination before its load has landed) */
+            : [oF] "v"(oFrag), [oF2] "v"(oFrag2), [oP] "v"(oPe), [oS] "v"(oPe8), [fp] "s"(fptr), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
+            : "memory");
     };
-    Pref cur;
-    fetch(dp[0], cur);
-    for (int k = 0; k < nOps; k++) {
-        const WalkOp& d = dp[k];
-        const unsigned flg = d.flags;
-        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3;
-        // the next micro-operation's fragments and operands: requested now; the fragments go to the other LDS buffer when this
-        // micro-operation's arithmetic is done (two no-op entries follow every segment: always readable)
-        const v2d MI355_GLOBAL* fn = fs + (size_t)(k + 1) * fsStep;
-        const int t = threadIdx.x;
-        const v2d n0 = fn[t];
-        v2d n1 = v2d{0.0, 0.0};
-        if (t < WT_FRAG - 256) n1 = fn[t + 256];
-        Pref nxt;
-        fetch(dp[k + 1], nxt);
-        const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;
-        v2d b2[WT_NT];
-        if (k1 >= WK_H0) {
-            const v2d* h = hold + (size_t)(k1 - WK_H0) * 4 * WT_HOLD_V2D;
-#pragma unroll
-            for (int j = 0; j < WT_NT; j++) cur.b1[j] = h[64 * j];
-        }
-        if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
-        else if (k2 == WK_ACC) {
-#pragma unroll
-            for (int j = 0; j < WT_NT; j++) b2[j] = ACC[j];
-        }
-        const double inve = 1.0 / cur.fe, invo = 1.0 / cur.fo;
-        double re[WT_NT], ro[WT_NT], te[WT_NT], to[WT_NT];
-        tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, cur.se1, cur.so1, nullptr, cur.b1, 0, g, fl, re, ro);
-        tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, cur.se2, cur.so2, nullptr, b2, 0, g, fl, te, to);
-#pragma unroll
-        for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};
-        if (flg & WF_STORE) {
-            char* dst = reinterpret_cast<char*>(d.store + tileBase);
-#pragma unroll
-            for (int j = 0; j < WT_NT; j++) {
-                if (EXACT || 4 * j + g < S) {
-                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u)));
-                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));
-                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }
-                }
-            }
-        }
-        if (hslot) {
-            v2d* h = hold + (size_t)(hslot - 1) * 4 * WT_HOLD_V2D;
-#pragma unroll
-            for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];
-        }
-        v2d* fw = fragV + (size_t)((k + 1) & 1) * WT_FRAG;
-        fw[t] = n0;
-        if (t < WT_FRAG - 256) fw[t + 256] = n1;
-        cur = nxt;
-        __syncthreads();
+    // "At most the five loads issued after f's are outstanding".  The registers of a Flight are written asynchronously, so the
+    // compiler must never be given a reason to copy one between issue and wait: the waits below only READ them (no tied
+    // operands — a tie made the compiler move a destination to another register BEFORE the wait), and what has to outlive the
+    // set's next issue is copied out inside the same statement, after the wait.  tools/check_walk_isa.py verifies the result.
+    auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
+        asm volatile("s_waitcnt vmcnt(5)\n\t"
+                     "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
+                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
+                     : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
+    };
+    auto landedFragments = [&](const Flight& f) {
+        asm volatile("s_waitcnt vmcnt(5)" : : "v"(f.f0), "v"(f.f1) : "memory");
+    };
+    Flight A, B;
+    A.f0 = A.f1 = A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
+    issue(A, dp[0], fs);                                             // (the first fragments were staged above; A's copy of them is not used)
+    issue(B, dp[1], fs + fsStep);
+
+    // CUR: the set that holds micro-operation k's operands (issued two stages ago) and is re-used for k + 2's; NXT: k + 1's
+#define WT_STAGE(CUR, NXT)                                                                                                  \
+    {                                                                                                                     \
+        const WalkOp& d = dp[k];                                                                                          \
+        const unsigned flg = d.flags;                                                                                     \
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3;                                      \
+        unsigned t1, t2;                                                                                                  \
+        double fe, fo;                                                                                                    \
+        landedOperands(CUR, t1, t2, fe, fo);                          /* (read out before the set is handed to the next loads) */ \
+        issue(CUR, dp[k + 2], fs + (size_t)(k + 2) * fsStep);                                                            \
+        const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
+        const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;                                                       \
+        /* the second child first: the running result (ACC) is consumed where it stands */                                \
+        double te[WT_NT], to[WT_NT];                                                                                      \
+        if (k2 == WK_ACC) tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, false, S, S, nullptr, ACC, 0, g, fl, te, to); \
+        else {                                                                                                            \
+            v2d b2[WT_NT];                                                                                                \
+            if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);                                    \
+            tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, se2, so2, nullptr, b2, 0, g, fl, te, to);   \
+        }                                                                                                                 \
+        const bool rd = ((flg >> 13) & 3) == WS_READ;                                                                     \
+        const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;                                              \
+        {                                                                                                                 \
+            v2d b1[WT_NT];                                                                                                \
+            if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);                                    \
+            else if (k1 >= WK_H0) {                                                                                       \
+                const v2d* h = hold + (size_t)(k1 - WK_H0) * 4 * WT_HOLD_V2D;                                             \
+                _Pragma("unroll") for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];                                      \
+            }                                                                                                             \
+            double re[WT_NT], ro[WT_NT];                                                                                  \
+            tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, se1, so1, nullptr, b1, 0, g, fl, re, ro);             \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};   \
+        }                                                                                                                 \
+        if (flg & WF_STORE) {                                                                                             \
+            char* dst = reinterpret_cast<char*>(d.store + tileBase);                                                      \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) {                                                           \
+                if (EXACT || 4 * j + g < S) {                                                                             \
+                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u))); \
+                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));           \
+                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }                                          \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (hslot) {                                                                                                      \
+            v2d* h = hold + (size_t)(hslot - 1) * 4 * WT_HOLD_V2D;                                                        \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];                                         \
+        }                                                                                                                 \
+        /* the next micro-operation's fragments (issued a stage ago) into the other buffer */                            \
+        landedFragments(NXT);                                                                                             \
+        v2d* fw = fragV + (size_t)((k + 1) & 1) * WT_FRAG;                                                                \
+        fw[threadIdx.x] = NXT.f0;                                                                                         \
+        if (threadIdx.x < WT_FRAG - 256) fw[threadIdx.x + 256] = NXT.f1;                                                  \
+        __syncthreads();                                                                                                  \
     }
+    for (int k = 0; k < nOps; k += 2) {            // (the host pads every segment to an even count; two more no-ops follow it, plus the stream's slack)
+        WT_STAGE(A, B)
+        k++;
+        WT_STAGE(B, A)
+        k--;
+    }
+#undef WT_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)

@@ -444,10 +444,10 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             # the level kernels store and re-read every node they compute (= the algorithmic bytes), minus the tip-tip nodes
             # a <= 20-state instance defines instead of storing (engine counters)
             moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps) if stats["micro_ops"] > 0 else alg
-            kname = "k_pruneTiled<5>" if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
+            kname = ("k_walkT32" if stats["walks"] > 0 else "k_pruneTiled<5>") if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
             launches_per_eval = launches / max(1, args.steps)
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        prof, prof_note = traffic_for(args, "k_walk4" if walk else "k_prune", world, rank)
+        prof, prof_note = traffic_for(args, "k_walk" if stats["walks"] > 0 else "k_prune", world, rank)
         roofline = {
             "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -461,7 +461,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "kernel_us_per_eval": round(kernel_s * 1e6, 2), "launches_per_eval": round(launches_per_eval, 2),
             "kernel_time_fraction_of_step": round(kernel_s * evals_per_s, 4),
         }
-        if walk:
+        if stats["micro_ops"] > 0:
             roofline["per_eval"] = {k: round(v / max(1, args.steps), 1) for k, v in stats.items()}
         # arithmetic side (matters for 61 states): 2*S*S flops per internal child per (pattern, category) + S products;
         # fp64 matrix/vector peak 78.6 TFLOP/s nominal, 73.9 measured for mfma_f64_4x4x4 (profiles/)
