@@ -440,13 +440,13 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     // operands — a tie made the compiler move a destination to another register BEFORE the wait), and what has to outlive the
     // set's next issue is copied out inside the same statement, after the wait.  tools/check_walk_isa.py verifies the result.
     auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
-        asm volatile("s_waitcnt vmcnt(5)\n\t"
+        asm volatile("s_waitcnt vmcnt(5) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
                      "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
                      : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
     };
     auto landedFragments = [&](const Flight& f) {
-        asm volatile("s_waitcnt vmcnt(5)" : : "v"(f.f0), "v"(f.f1) : "memory");
+        asm volatile("s_waitcnt vmcnt(5) ; retires %0 %1" : : "v"(f.f0), "v"(f.f1) : "memory");
     };
     Flight A, B;
     A.f0 = A.f1 = A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;

@@ -218,7 +218,7 @@ __device__ __forceinline__ void preWait(PreFetched& f, unsigned nextTips) {     
         "s_branch .Lwd%=\n"
         ".Lw6%=:\n\t"
         "s_waitcnt vmcnt(6)\n"
-        ".Lwd%=:"
+        ".Lwd%=: ; retires %0 %1 %2 %3 %4 %5 %6 %7 %8 %9"
         : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB)
         : [nt] "s"(nextTips) : "memory", "scc");
 }

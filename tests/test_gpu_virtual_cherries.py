@@ -111,29 +111,34 @@ def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib):
         assert v[0] == v[1], (k, v)
 
 
-def test_steady_state_chain_matches_stored_buffers_bitwise(oracle_lib):
+@pytest.mark.parametrize("S", [4, 20, 17])
+def test_steady_state_chain_matches_stored_buffers_bitwise(S, oracle_lib):
     """An MCMC-like chain: the same op lists come back every other evaluation (buffer flips), which is what the
     engine's steady-state fast path keys on (definitions re-confirmed, only the matrix snapshots refreshed).  Model
     parameters, branch rates and node heights change between evaluations, some moves are rejected (restoreState).
-    Every evaluation must equal, to the last bit, the same chain with virtual buffers off — and the oracle to 1e-10."""
+    Every evaluation must equal, to the last bit, the same chain with virtual buffers off — and the oracle to 1e-10.
+    4 states: the pattern walk (kernels_walk4.hip); 17 and 20 states: the same programs on the T32 layout
+    (kernels_mfma.hip k_walkT32) — there also against the level kernels (BEAGLE_MI355_NO_T32_WALK=1; other arithmetic
+    order: 1e-12), with the rescaling evaluations of the DYNAMIC scheme taking the level path in between."""
     import os
     from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
-    wl = helpers.random_workload(80, 1500, 4, 4, seed=99)
+    wl = helpers.random_workload(80, 1500, 4, 4, seed=99) if S == 4 else helpers.random_workload(40, 700, S, 4, seed=99)
     rng = np.random.default_rng(3)
     moves = []
     for step in range(14):
         kind = ("model", "rates", "height", "none")[step % 4]
-        moves.append((kind, rng.gamma(2.0, 1.0, size=6) + 0.1, rng.uniform(0.5, 1.5, size=wl.tree.node_count),
+        eig = substmodel.gtr(rng.gamma(2.0, 1.0, size=6) + 0.1, wl.freqs) if S == 4 else substmodel.random_reversible(S, rng)[0]
+        moves.append((kind, eig, rng.uniform(0.5, 1.5, size=wl.tree.node_count),
                       int(rng.integers(wl.tip_count, wl.tree.node_count)), step % 5 == 4))
 
     def chain(tl):
         out = [tl.getLogLikelihood()]
         height = wl.tree.height.copy()          # the chain's own view of the node heights (moves accumulate)
-        for kind, gtr, rates, node, reject in moves:
+        for kind, eig, rates, node, reject in moves:
             tl.storeState()
             saved = height.copy()
             if kind == "model":
-                tl.set_substitution_model(substmodel.gtr(gtr, wl.freqs), wl.freqs)
+                tl.set_substitution_model(eig, wl.freqs)
             elif kind == "rates":
                 tl.set_branch_rates(rates)
             elif kind == "height" and node != wl.tree.root:
@@ -150,19 +155,28 @@ def test_steady_state_chain_matches_stored_buffers_bitwise(oracle_lib):
                 out.append(tl.getLogLikelihood())
         return out
 
-    runs = {}
-    for flag in ("0", "1"):
-        os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
+    runs, stats = {}, {}
+    for name, env in (("virtual", {}), ("stored", {"BEAGLE_MI355_NO_VIRTUAL": "1"})) + ((("levels", {"BEAGLE_MI355_NO_T32_WALK": "1"}),) if S != 4 else ()):
+        os.environ.update(env)
         try:
             tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
-            runs[flag] = chain(tl)
+            raw = bm.beagle.Beagle.attach(tl)
+            raw.kernelTimer(True)
+            runs[name] = chain(tl)
+            stats[name] = raw.walkStats()
             tl.close()
         finally:
-            os.environ.pop("BEAGLE_MI355_NO_VIRTUAL", None)
-    assert runs["0"] == runs["1"]
+            for k in env:
+                os.environ.pop(k, None)
+    assert runs["virtual"] == runs["stored"]
+    assert stats["virtual"]["walks"] > 0 and stats["virtual"]["stored"] < stats["stored"]["stored"] == stats["stored"]["micro_ops"]
+    if S != 4:
+        assert stats["levels"]["walks"] == 0                       # (the level kernels count their operations, not walks)
+        for a, b in zip(runs["virtual"], runs["levels"]):
+            assert helpers.rel_err(a, b) <= 1e-12
     o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
     ref = chain(o)
     o.close()
-    assert len(ref) == len(runs["0"])
-    for a, b in zip(runs["0"], ref):
+    assert len(ref) == len(runs["virtual"])
+    for a, b in zip(runs["virtual"], ref):
         assert helpers.rel_err(a, b) <= 1e-10

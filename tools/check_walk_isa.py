@@ -87,6 +87,83 @@ def check_function(name, lines):
     return problems
 
 
+def check_async(name, text_lines):
+    """Kernels whose loads are inline assembly with their waits written by hand (k_walkT32, k_preWalk4): the destination
+    registers of an assembly load block are written asynchronously, so between the block and the hand-written wait that
+    names them ("; retires ...") NO instruction may read or write them — a register-allocator copy there would read a
+    value that has not arrived.  Linear scan of the listing, the loop body a second time for the back edge."""
+    problems = []
+    header = None
+    lines = []
+    for l in text_lines:
+        if header is None and re.match(r"\.LBB\d+_\d+:", l) and "Loop Header" in l:
+            header = len(lines)
+        if not l.strip().startswith(";") or "ASMSTART" in l or "ASMEND" in l:
+            lines.append(l)
+    order = list(range(len(lines))) + (list(range(header, len(lines))) if header is not None else [])
+    inflight, in_asm, issues, retires = {}, False, 0, 0
+    for idx in order:
+        t = lines[idx].strip()
+        if "ASMSTART" in t:
+            in_asm = True
+            continue
+        if "ASMEND" in t:
+            in_asm = False
+            continue
+        if in_asm and t.startswith("global_load"):
+            for r in regs(t.split()[1].rstrip(",")):
+                inflight[r] = idx
+            issues += 1
+            continue
+        if "retires" in t:
+            for tok in re.findall(r"v\[\d+:\d+\]|v\d+", t.split("retires", 1)[1]):
+                for r in regs(tok):
+                    inflight.pop(r, None)
+            retires += 1
+            continue
+        if re.match(r"s_waitcnt vmcnt\(0\)", t):
+            inflight.clear()
+            continue
+        if t.startswith("s_waitcnt") or t.startswith("s_") or t.startswith("."):
+            continue
+        hit = all_regs(t) & set(inflight)
+        if hit:
+            problems.append("%s: line %d touches registers %s of the assembly load at line %d before their wait: %s"
+                            % (name, idx, sorted(hit)[:4], inflight[sorted(hit)[0]], t))
+    if issues == 0 or retires == 0:
+        problems.append("%s: no assembly load blocks / no 'retires' waits found (%d / %d)" % (name, issues, retires))
+    return problems
+
+
+ASYNC_KERNELS = (("kernels_mfma.hip", r"_ZN5mi3559k_walkT32", 256), ("kernels_preorder4.hip", r"_ZN5mi35510k_preWalk4", 128))
+
+
+def check_async_kernels(hipcc):
+    problems, summary = [], []
+    for src, prefix, max_vgpr in ASYNC_KERNELS:
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "k.s")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
+                                os.path.join(ROOT, "beast-mcmc_amd", "csrc", src), "-o", out], capture_output=True, text=True)
+            if r.returncode:
+                return [r.stderr], summary
+            text = open(out).read()
+        funcs = re.findall(r"^(%s[^:\n]*):\s*;.*?\n(.*?)s_endpgm" % prefix, text, flags=re.S | re.M)
+        if not funcs:
+            problems.append("%s: no %s instantiation found" % (src, prefix))
+        for name, body in funcs:
+            problems += check_async(name[:48], body.split("\n"))
+            meta = re.search(r"\.name:\s+%s\n(.*?)\.wavefront_size" % re.escape(name), text, flags=re.S)
+            vg = int(re.search(r"\.vgpr_count:\s+(\d+)", meta.group(1)).group(1)) if meta else -1
+            sc = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta.group(1)).group(1)) if meta else -1
+            summary.append("%s %d VGPRs" % (name[9:24], vg))
+            if vg > max_vgpr or vg < 0:
+                problems.append("%s: %d VGPRs (limit %d)" % (name[:48], vg, max_vgpr))
+            if sc != 0:
+                problems.append("%s: %d bytes of scratch per lane — a spilled in-flight register cannot work" % (name[:48], sc))
+    return problems, summary
+
+
 def main():
     hipcc = "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory() as tmp:
@@ -111,9 +188,11 @@ def main():
     for name, body in funcs:
         lines = [l for l in body.split("\n") if not l.strip().startswith(";")]
         problems += check_function(name[:40], lines)
+    more, summary = check_async_kernels(hipcc)
+    problems += more
     for p in problems:
         print("PROBLEM:", p)
-    print("walk kernel ISA check: %s (VGPRs %s, %d instantiations)" % ("FAILED" if problems else "ok", vg, len(funcs)))
+    print("walk kernel ISA check: %s (VGPRs %s, %d instantiations; %s)" % ("FAILED" if problems else "ok", vg, len(funcs), ", ".join(summary)))
     return 1 if problems else 0
 
 
