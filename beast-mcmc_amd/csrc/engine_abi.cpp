@@ -234,7 +234,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // 16..64 states: T32 layout + fp64 MFMA kernels (amino acids, codons); BEAGLE_MI355_NO_MFMA=1 keeps the VALU kernel
     in->tiled = stateCount >= 16 && stateCount <= 64 && !(getenv("BEAGLE_MI355_NO_MFMA") && atoi(getenv("BEAGLE_MI355_NO_MFMA")) != 0);
     in->ntile = (patternCount + 31) / 32;
-    in->schedAlap = !(getenv("BEAGLE_MI355_SCHED") && strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") == 0);
+    // level order of the level kernels (engine_levels.cpp): as late as possible up to 20 states (every launch mixes the write-only
+    // tip-tip nodes with read-heavy ones), as early as possible above (61 states: 214 -> 226 evals/s, profiles/r03_experiments.txt 11);
+    // BEAGLE_MI355_SCHED=asap|alap overrides
+    in->schedAlap = stateCount <= 20;
+    if (getenv("BEAGLE_MI355_SCHED")) in->schedAlap = strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") != 0;
     // 4 states (nucleotides), up to 16 rate categories: the pattern walk.  BEAGLE_MI355_NO_VIRTUAL=1 keeps every buffer real,
     // BEAGLE_MI355_VSTEPS=n caps the length of a virtual definition (A/B runs).
     in->walk = stateCount == 4 && categoryCount <= 16 &&

@@ -330,8 +330,9 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     }
     const int nt = (S + 3) / 4;
     // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
+    // (three above 20 states: 256 / 512 / 1024 / 1536 / 2048 / 4096 workgroups per launch -> 134 / 203 / 214 / 229 / 228 / 212 evals/s on config C)
     static const int target = [] { const char* e = getenv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
-    dim3 grid(tiledBlocksPerRow(P, nOps * C, target > 0 ? target : (nt <= 5 ? 2048 : 1024)), nOps * C), block(MF_BLOCK);
+    dim3 grid(tiledBlocksPerRow(P, nOps * C, target > 0 ? target : (nt <= 5 ? 2048 : 1536)), nOps * C), block(MF_BLOCK);
     static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
 #define TILED_LAUNCH(NT, EX, PI) do { if (NT <= 5 && dCherries) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, NT <= 5>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); \
                                         else hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, false>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); } while (0)

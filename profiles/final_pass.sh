@@ -17,6 +17,7 @@ for cfg in A B C D E; do
 done
 timeout 300 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_btl.json; line gpurun_out/profiles_final/${R}_bench_A_btl.json "A btl"
 timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5 --no-cpu-baseline --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_always.json; line gpurun_out/profiles_final/${R}_bench_A_always.json "A always"
+timeout 300 python bench.py --config B --rescaling always --steps 40 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_B_always.json; line gpurun_out/profiles_final/${R}_bench_B_always.json "B always"
 timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard12500.json; line gpurun_out/profiles_final/${R}_bench_A_shard12500.json "A shard"
 for real in benchmark1 benchmark2; do
   timeout 300 python bench.py --real $real --steps 200 --warmup 5 --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_D_$real.json; line gpurun_out/profiles_final/${R}_bench_D_$real.json "D $real"
