@@ -380,14 +380,10 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     }
     for (int k = 0; k < partitionCount; k++) if (s[k] < 0) { s[k] = 0; e[k] = 0; }
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
-    if (in->walkT && partitionCount > 1) {
-        // the T32 walk's workgroups are whole tiles of one range: a partitioned instance goes back to the level kernels, with
-        // every node it had left unstored written first
-        for (int X = 0; X < in->partialsCount; X++) if (isVirt(in, X)) { int rcv = materializeVirtual(in, X); if (rcv) return rcv; }
-        in->walkT = false; in->virt = false;
-    }
+    // (the T32 walk needs no layout change: a tile that straddles two partitions is walked once per partition, each walk storing
+    // only its own patterns — kernels_mfma.hip k_walkT32 masks by the segment's range)
     if (in->walk || in->walkT) in->planner.setPartitionCount(partitionCount);
-    if (in->walk && in->virt) {
+    if ((in->walk || in->walkT) && in->virt) {
         // definitions are kept per (buffer, partition): more snapshot slots behind the caller's matrices
         const size_t per = (size_t)in->C * in->S * in->S, slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());
         double* grown = nullptr;

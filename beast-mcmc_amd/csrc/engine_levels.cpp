@@ -256,9 +256,12 @@ int runOperations(Instance* in, const int* ops, int count, int tuple, int global
         std::vector<int> need;
         for (int k = 0; k < count; k++) {
             const int* op = ops + (size_t)k * tuple;
-            if (badIndex(op[3], in->partialsCount) || badIndex(op[5], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (badIndex(op[0], in->partialsCount) || badIndex(op[3], in->partialsCount) || badIndex(op[5], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
             if (isVirt(in, op[3])) in->planner.keysOf(op[3], need);
             if (isVirt(in, op[5])) in->planner.keysOf(op[5], need);
+            // (the level path forgets a destination's definitions for ALL partitions; what another partition still defines there
+            // has to exist before that)
+            if (in->partitionCount > 1 && isVirt(in, op[0])) in->planner.keysOf(op[0], need);
         }
         if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     }

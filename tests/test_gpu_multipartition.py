@@ -104,14 +104,17 @@ def test_multi_partition_protocol(S, scaling, oracle_lib):
     assert helpers.rel_err(total[0], sum(expect)) <= 1e-10
 
 
-def test_partitioned_instance_partial_updates_with_per_partition_flips(oracle_lib):
+@pytest.mark.parametrize("S", [4, 20])
+def test_partitioned_instance_partial_updates_with_per_partition_flips(S, oracle_lib):
     """What MultiPartitionDataLikelihoodDelegate does between full evaluations: ONE partition's branch changes, only that
     partition's path to the root is re-evaluated, into ITS alternate buffers (partialBufferHelper[i], one per partition,
     MultiPartitionDataLikelihoodDelegate.java:972-997), and a rejected proposal flips back.  The engine keeps definitions of
     unstored nodes per (buffer, partition) (planner.h); the reference here is one oracle instance per partition given the
     same operations as 7-int tuples.  Checked after every step: the per-partition log-likelihoods; at the end: the partials
-    of every internal node of every partition (the engine materialises what it had not stored)."""
-    S, T, C = 4, 24, 4
+    of every internal node of every partition (the engine materialises what it had not stored).  20 states: the partitions
+    (300, 77 and 140 patterns) do not end at tile boundaries — a tile of 32 patterns that straddles two partitions is walked
+    once per partition (kernels_mfma.hip k_walkT32)."""
+    T, C = 24, 4
     tree, wls = two_partitions(S, T, [300, 77, 140], seed=77)
     K = len(wls)
     P = sum(w.pattern_count for w in wls)
@@ -202,7 +205,10 @@ def test_partitioned_instance_partial_updates_with_per_partition_flips(oracle_li
                 pflip[k], mflip[k], lens[n0] = saved
                 check("step %d restored" % step)
         stats = eng.walkStats()
-        assert stats["fast_walks"] == stats["walks"] > 0 and stats["stored"] < stats["micro_ops"]      # unstored nodes exist
+        # unstored nodes exist; 4 states: every launch on the assembly loop; 20 states: the T32 walk for the read-mode updates
+        # (the write-mode evaluation at the start ran level by level: its operations are counted as stored)
+        assert stats["walks"] > 0 and stats["stored"] < stats["micro_ops"]
+        assert S != 4 or stats["fast_walks"] == stats["walks"]
         for k, w in enumerate(wls):
             for n in internal:
                 pe = eng.getPartials(pb(k, n), NONE)[:, starts[k]:starts[k + 1], :]
