@@ -272,6 +272,90 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
     }
 }
 
+// WRITE-mode rescaling in ONE pass (<= 20 states, <= 4 rate categories): a pattern's factor is the maximum over its states AND
+// categories, so here a wave takes its tile through all categories, keeps the unscaled results in registers (5 x 16 bytes
+// per category), forms the factor (the four state rows of a tile column sit in lanes l, l ^ 16, l ^ 32, l ^ 48), divides
+// and stores once.  The two-pass form below re-reads and re-writes every node (config B with ALWAYS rescaling: 15 ms per
+// evaluation).  Grid row = operation; the two branch matrices of every category are staged as A fragments.
+template <bool EXACT>
+__global__ __launch_bounds__(MF_BLOCK, 2) void k_pruneTiledWrite(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P, int S, int C) {
+    constexpr int NT = 5, MAXC = 4, fragN = NT * NT * 16;
+    extern __shared__ double frag[];          // [C][2][fragN]
+    const OpDesc& op = ops[blockIdx.y];
+    const int ntile = (P + TILE - 1) / TILE;
+    const int tile0 = op.pStart / TILE, tile1 = (op.pEnd + TILE - 1) / TILE;
+    if (tile0 + (int)blockIdx.x * 4 >= tile1) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
+    for (int e = threadIdx.x; e < C * 2 * fragN; e += MF_BLOCK) {
+        const int c = e / (2 * fragN), r0 = e - c * 2 * fragN, child = r0 >= fragN, r = r0 - child * fragN;
+        const int f = r >> 4, q = r & 15, it = f / NT, jt = f - it * NT, i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+        const double* M = matrices + ((size_t)(child ? op.mat2 : op.mat1) * C + c) * S * S;
+        frag[e] = (i < S && j < S) ? M[(size_t)i * S + j] : 0.0;
+    }
+    __syncthreads();
+    for (int tile = tile0 + blockIdx.x * 4 + wave; tile < tile1; tile += gridDim.x * 4) {
+        const int pe = tile * TILE + 2 * m;
+        const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
+        int se1 = S, so1 = S, se2 = S, so2 = S;
+        if (st1) { const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child1)); if (pe < P) se1 = st[pe]; if (pe + 1 < P) so1 = st[pe + 1]; }
+        if (st2) { const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child2)); if (pe < P) se2 = st[pe]; if (pe + 1 < P) so2 = st[pe + 1]; }
+        double inve = 1.0, invo = 1.0;
+        if (!op.scaleWrite && op.scaleRead) {
+            const double MI355_GLOBAL* sr = gptr(op.scaleRead);
+            if (pe < P) inve = 1.0 / sr[pe];
+            if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
+        }
+        v2d res[MAXC][NT];
+        double me = 0.0, mo = 0.0;
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            if (c < C) {
+                const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+                v2d b1[NT], b2[NT];
+                if (!st1) tiledLoadB<NT, EXACT>(op.child1, tileBase, S, g, m, b1);
+                if (!st2) tiledLoadB<NT, EXACT>(op.child2, tileBase, S, g, m, b2);
+                double re[NT], ro[NT], te[NT], to[NT];
+                tiledChild<NT, NT>(frag + (size_t)c * 2 * fragN, NT, S, st1, se1, so1, nullptr, b1, 0, g, fl, re, ro);
+                tiledChild<NT, NT>(frag + (size_t)c * 2 * fragN + fragN, NT, S, st2, se2, so2, nullptr, b2, 0, g, fl, te, to);
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    res[c][j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};
+                    if (EXACT || 4 * j + g < S) { me = fmax(me, res[c][j].x); mo = fmax(mo, res[c][j].y); }
+                }
+            }
+        }
+        double ie = 1.0, io = 1.0;
+        if (op.scaleWrite) {
+            me = fmax(me, __shfl_xor(me, 16, 64)); me = fmax(me, __shfl_xor(me, 32, 64));
+            mo = fmax(mo, __shfl_xor(mo, 16, 64)); mo = fmax(mo, __shfl_xor(mo, 32, 64));
+            if (!(me > 0.0)) me = 1.0;
+            if (!(mo > 0.0)) mo = 1.0;
+            if (g == 0) { if (ine) op.scaleWrite[pe] = me; if (ino) op.scaleWrite[pe + 1] = mo; }
+            ie = 1.0 / me; io = 1.0 / mo;
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            if (c < C) {
+                char* dst = reinterpret_cast<char*>(op.dest + ((size_t)c * ntile + tile) * S * TILE);
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    if (EXACT || 4 * j + g < S) {
+                        // (the two-pass form multiplies the stored value by the reciprocal: the same two roundings)
+                        const v2d o = v2d{res[c][j].x * ie, res[c][j].y * io};
+                        double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u)));
+                        if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                        else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Second pass of a WRITE-mode rescale (only on evaluations that recompute the scalers, 1 in `beagle.rescale`): per
 // pattern, the max over categories and states of the freshly written destination becomes the scale factor and the
 // destination is divided by it.  One wave per tile.
@@ -329,6 +413,17 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
         return;
     }
     const int nt = (S + 3) / 4;
+    static const bool twoPass = getenv("BEAGLE_MI355_RESCALE_TWO_PASS") && atoi(getenv("BEAGLE_MI355_RESCALE_TWO_PASS")) != 0;
+    if (anyScaleWrite && !dCherries && nt <= 5 && S >= 16 && C <= 4 && !twoPass) {
+        // a level that rescales in write mode, <= 20 states, <= 4 categories: one pass (k_pruneTiledWrite)
+        const size_t lds = (size_t)C * 2 * 5 * 5 * 16 * sizeof(double);
+        if (grantDynamicLds(reinterpret_cast<const void*>(k_pruneTiledWrite<true>), lds) && grantDynamicLds(reinterpret_cast<const void*>(k_pruneTiledWrite<false>), lds)) {
+            dim3 grid(tiledBlocksPerRow(P, nOps, 2048), nOps), block(MF_BLOCK);
+            if (S == 20) hipLaunchKernelGGL(k_pruneTiledWrite<true>, grid, block, lds, stream, dOps, matrices, P, S, C);
+            else hipLaunchKernelGGL(k_pruneTiledWrite<false>, grid, block, lds, stream, dOps, matrices, P, S, C);
+            return;
+        }
+    }
     // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
     // (three above 20 states: 256 / 512 / 1024 / 1536 / 2048 / 4096 workgroups per launch -> 134 / 203 / 214 / 229 / 228 / 212 evals/s on config C)
     static const int target = [] { const char* e = getenv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
