@@ -463,17 +463,54 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
 // fragments in program order (k_gatherFragments lays them out once per evaluation) and are staged through LDS one
 // micro-operation ahead, double-buffered, one barrier per micro-operation.  Read-mode rescaling only (a factor per pattern
 // needs all categories of the pattern: write-mode lists take the level path).
-constexpr int WT_NT = 5, WT_FRAG = WT_NT * WT_NT * 16;                // doubles per matrix
+// A fragments of a matrix for the walk: frag[it][fl][6] — the five state-tile columns jt of (row tile it, lane slot fl) are
+// CONTIGUOUS (two 16-byte LDS reads and one 8-byte read per row tile instead of five), padded to six doubles so that the 16
+// slots of a row tile fall into distinct banks
+constexpr int WT_NT = 5, WT_ROW = 6, WT_FRAG = WT_NT * 16 * WT_ROW;   // doubles per matrix (480)
 constexpr int WT_HOLD_V2D = WT_NT * 64;                              // v2d per wave and hold slot
 
 __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C, int S, double* __restrict__ stream) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * C * 2 * WT_FRAG) return;
-    const int q = (int)(t & 15), f = (int)((t >> 4) % (WT_NT * WT_NT)), child = (int)((t / WT_FRAG) & 1), c = (int)((t / (2 * WT_FRAG)) % C),
-              k = (int)(t / ((size_t)2 * WT_FRAG * C));
-    const int it = f / WT_NT, jt = f - it * WT_NT, i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+    const int r = (int)(t % WT_FRAG), child = (int)((t / WT_FRAG) & 1), c = (int)((t / (2 * WT_FRAG)) % C), k = (int)(t / ((size_t)2 * WT_FRAG * C));
+    const int jt = r % WT_ROW, q = (r / WT_ROW) & 15, it = r / (16 * WT_ROW), i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
     const double MI355_GLOBAL* M = gptr(child ? prog[k].m2 : prog[k].m1) + (size_t)c * S * S;
-    stream[t] = (i < S && j < S) ? M[(size_t)i * S + j] : 0.0;
+    stream[t] = (jt < WT_NT && i < S && j < S) ? M[(size_t)i * S + j] : 0.0;
+}
+
+// One child's factor for all five parent-state tiles from the walk's fragment layout: oe/oo[it] = sum_j M[4 it + g][j] X[j][2m / 2m+1]
+// (a compact tip: column `state` of the matrix, ones for a missing state)
+__device__ __forceinline__ void walkChild5(const double* __restrict__ frag, int S, bool isStates, int se, int so, const v2d (&b)[WT_NT],
+                                           int g, int fl, double (&oe)[WT_NT], double (&oo)[WT_NT]) {
+    if (isStates) {
+        const bool ge = se < S, go = so < S;
+        const double* fe = frag + (ge ? (((se & 3) * 4 + g) * WT_ROW + (se >> 2)) : 0);
+        const double* fo = frag + (go ? (((so & 3) * 4 + g) * WT_ROW + (so >> 2)) : 0);
+#pragma unroll
+        for (int it = 0; it < WT_NT; it++) {
+            const double ve = fe[it * 16 * WT_ROW], vo = fo[it * 16 * WT_ROW];
+            oe[it] = ge ? ve : 1.0;
+            oo[it] = go ? vo : 1.0;
+        }
+        return;
+    }
+    double a[WT_NT][WT_NT];
+#pragma unroll
+    for (int it = 0; it < WT_NT; it++) {
+        const double* row = frag + (it * 16 + fl) * WT_ROW;
+        const v2d r0 = *reinterpret_cast<const v2d*>(row), r1 = *reinterpret_cast<const v2d*>(row + 2);
+        a[it][0] = r0.x; a[it][1] = r0.y; a[it][2] = r1.x; a[it][3] = r1.y; a[it][4] = row[4];
+    }
+#pragma unroll
+    for (int it = 0; it < WT_NT; it++) { oe[it] = 0.0; oo[it] = 0.0; }
+#pragma unroll
+    for (int jt = 0; jt < WT_NT; jt++) {
+#pragma unroll
+        for (int it = 0; it < WT_NT; it++) {
+            oe[it] = mfma4(a[it][jt], b[jt].x, oe[it]);
+            oo[it] = mfma4(a[it][jt], b[jt].y, oo[it]);
+        }
+    }
 }
 
 template <bool EXACT>
@@ -502,7 +539,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     const size_t fsStep = (size_t)C * WT_FRAG;
     v2d* fragV = reinterpret_cast<v2d*>(wtLds);
     {   // the first micro-operation's fragments
-        const int t = threadIdx.x;                 // 2 matrices x 400 doubles = WT_FRAG v2d
+        const int t = threadIdx.x;                 // 2 matrices x 480 doubles = WT_FRAG v2d
         fragV[t] = fs[t];
         if (t < WT_FRAG - 256) fragV[t + 256] = fs[t + 256];
     }
@@ -563,11 +600,11 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
         const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;                                                       \
         /* the second child first: the running result (ACC) is consumed where it stands */                                \
         double te[WT_NT], to[WT_NT];                                                                                      \
-        if (k2 == WK_ACC) tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, false, S, S, nullptr, ACC, 0, g, fl, te, to); \
+        if (k2 == WK_ACC) walkChild5(frag + WT_FRAG, S, false, S, S, ACC, g, fl, te, to);                                 \
         else {                                                                                                            \
             v2d b2[WT_NT];                                                                                                \
             if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);                                    \
-            tiledChild<WT_NT, WT_NT>(frag + WT_FRAG, WT_NT, S, k2 == WK_TIPS, se2, so2, nullptr, b2, 0, g, fl, te, to);   \
+            walkChild5(frag + WT_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);                                    \
         }                                                                                                                 \
         const bool rd = ((flg >> 13) & 3) == WS_READ;                                                                     \
         const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;                                              \
@@ -579,7 +616,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
                 _Pragma("unroll") for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];                                      \
             }                                                                                                             \
             double re[WT_NT], ro[WT_NT];                                                                                  \
-            tiledChild<WT_NT, WT_NT>(frag, WT_NT, S, k1 == WK_TIPS, se1, so1, nullptr, b1, 0, g, fl, re, ro);             \
+            walkChild5(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);                                              \
             _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};   \
         }                                                                                                                 \
         if (flg & WF_STORE) {                                                                                             \
