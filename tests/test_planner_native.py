@@ -28,6 +28,34 @@ def test_walk_kernel_isa_keeps_in_flight_registers_untouched():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
+def test_isa_check_sees_a_copy_made_before_the_wait():
+    """The checker of hand-waited assembly loads (tools/check_walk_isa.py check_async) on a listing with exactly the defect it
+    exists for — the register allocator copying a load's destination BEFORE the wait that retires it (what a tied asm operand
+    produced in an early build of k_walkT32) — and on the repaired order."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_walk_isa", os.path.join(ROOT, "tools", "check_walk_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = """.LBB0_1:                               ; =>This Inner Loop Header: Depth=1
+	;;#ASMSTART
+	global_load_ushort v167, v160, s[36:37]
+	global_load_dwordx4 v[14:17], v164, s[4:5]
+	;;#ASMEND
+	v_add_u32_e32 v1, v2, v3
+	v_mov_b32_e32 v152, v167
+	;;#ASMSTART
+	s_waitcnt vmcnt(5) ; retires v167 v[14:17]
+	;;#ASMEND
+	v_mov_b32_e32 v130, v14
+	s_cbranch_scc1 .LBB0_1""".split("\n")
+    problems = chk.check_async("bad", bad)
+    assert len(problems) >= 1 and "v_mov_b32_e32 v152, v167" in problems[0]
+    good = [l for l in bad if "v152, v167" not in l]
+    good.insert(good.index("\tv_mov_b32_e32 v130, v14"), "\tv_mov_b32_e32 v152, v167")
+    assert chk.check_async("good", good) == []
+
+
+
 def test_generated_assembly_loop_is_up_to_date_and_balanced():
     """csrc/walk4_fast_loop.inc is what tools/gen_walk4_fast.py emits now, and the stream is structurally sound: every
     out-of-line block returns, every label that is branched to exists exactly once, the fetch stage issues the four small
