@@ -189,7 +189,12 @@ def main():
     if rank == 0 and out is not None and args.route == "ranks" and not args.no_library_route and args.config != "E":
         # the other multi-GPU route on the same workload (a shorter run), after this route's instances and process group are gone
         try:
-            out["library_route"] = library_route(args, bm, wl, world, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC)
+            if world > 1:
+                # N GPUs driven from ONE process (N host threads, ncclCommInitAll): in a process of its own with a time limit, so
+                # that nothing it does — including not returning — can cost the line of the route that was asked for
+                out["library_route"] = library_route_subprocess(args, world)
+            else:
+                out["library_route"] = library_route(args, bm, wl, world, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC)
         except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
             out["library_route"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ONE JSON line, and it is the LAST thing on stdout: libraries that print through C stdio (RCCL's version banner on the
@@ -527,6 +532,29 @@ def library_route(args, bm, wl, n, torch, device, BeagleTreeLikelihood, RESCALE_
     tl.close()
     return {"route": "library", "n_gpus": n, "value": round(n2 / elapsed, 3), "unit": "evals/s", "steps": n2,
             "ms_per_step": round(1e3 * elapsed / n2, 4), "lnL": lnl}
+
+
+def library_route_subprocess(args, n, limit=300):
+    """library_route for n > 1 GPUs as `bench.py --route library --gpus n` in a child process (none of this rank's
+    torch.distributed environment), killed after `limit` seconds."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                           "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--route", "library", "--gpus", str(n), "--steps", str(max(10, args.steps // 2)),
+           "--warmup", str(min(args.warmup, 10)), "--config", args.config, "--scale", str(args.scale), "--tree", args.tree,
+           "--rescaling", args.rescaling, "--cache", args.cache, "--no-cpu-baseline", "--no-live-traffic", "--no-library-route"]
+    if args.patterns:
+        cmd += ["--patterns", str(args.patterns)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s (child killed)" % limit}
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child exited with %d: %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1:] or "")}
+    d = json.loads(lines[-1])
+    return {"route": "library", "n_gpus": d.get("n_gpus", n), "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+            "ms_per_step": d["ms_per_step"], "lnL": d.get("lnL"), "how": "child process"}
 
 
 def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
