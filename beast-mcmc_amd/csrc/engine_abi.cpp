@@ -248,7 +248,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // them from the tips' states (kernels_mfma.hip cherryOperands); a definition is ONE step here
     // 16..20 states: the pattern walk on the T32 layout (BEAGLE_MI355_NO_T32_WALK=1: the level kernels with virtual cherries)
     in->walkT = in->tiled && stateCount <= 20 && categoryCount <= 16 && !(getenv("BEAGLE_MI355_NO_T32_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WALK")) != 0);
-    in->cherry = in->tiled && stateCount <= 20 && !noVirtual && !in->walkT;
+    // (above 20 states the cherries' matrices do not fit the LDS; with the tables in global memory — BEAGLE_MI355_CHERRY61=1 — a third
+    // of config C's nodes is never stored and the time does not move: 232 against 234 evals/s, profiles/r03_experiments.txt 14 — so
+    // that stays an experiment)
+    in->cherry = in->tiled && !noVirtual && !in->walkT &&
+                 (stateCount <= 20 || (getenv("BEAGLE_MI355_CHERRY61") && atoi(getenv("BEAGLE_MI355_CHERRY61")) != 0));
     const bool virtualOn = ((in->walk || in->walkT) && !noVirtual) || in->cherry;
     in->virt = virtualOn;
     // Size of a virtual definition (internal nodes; any subtree shape whose evaluation needs at most two hold slots).

@@ -1,5 +1,5 @@
 // engine_levels.cpp — every state count but 4: an operation list levelised and enqueued one dependency level per launch
-// (kernels_mfma.hip for 16..64 states with virtual cherries up to 20, kernels.hip k_pruneGeneral otherwise).  See engine_internal.h.
+// (kernels_mfma.hip for 16..64 states with virtual cherries, kernels.hip k_pruneGeneral otherwise).  See engine_internal.h.
 #include "engine_internal.h"
 
 using mi355::OpDesc;
@@ -167,6 +167,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
     for (int k = 0; k < count; k++) if (!skipped[k]) sorted[fill[level[k]]++] = descs[descOf[k]];
     // the cherries' matrix snapshots and the descriptors of the virtual children, ahead of the level launches
     const mi355::CherryDesc* dCherries = nullptr;
+    const double* dCherryTables = nullptr;
     if (!snapPairs.empty()) {
         void* dPairs = nullptr;
         int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
@@ -176,6 +177,20 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
         void* dC = nullptr;
         int rc = uploadTransient(in, cherries.data(), cherries.size() * sizeof(mi355::CherryDesc), &dC); if (rc) return rc;
         dCherries = (const mi355::CherryDesc*)dC;
+        if (in->S > 20) {                                // 21..64 states: the cherries' matrices as column tables in global memory
+            const size_t bytes = mi355::cherryTableBytes((int)cherries.size(), in->S, in->C);
+            if (bytes > in->cherryTableBytes) {
+                HIP_TRY(hipStreamSynchronize(in->stream));
+                if (in->cherryTables) {
+                    for (auto& a : in->allocations) if (a == (void*)in->cherryTables) { a = in->allocations.back(); in->allocations.pop_back(); break; }
+                    hipFree(in->cherryTables); in->deviceBytes -= in->cherryTableBytes; in->cherryTables = nullptr; in->cherryTableBytes = 0;
+                }
+                void* q = nullptr; rc = devAlloc(in, &q, bytes + bytes / 4); if (rc) return rc;
+                in->cherryTables = (double*)q; in->cherryTableBytes = bytes + bytes / 4;
+            }
+            mi355::launchCherryTables(in->stream, dCherries, (int)cherries.size(), in->matrices, in->S, in->C, in->cherryTables);
+            dCherryTables = in->cherryTables;
+        }
     }
     // ONE descriptor upload for the whole list (every extra copy is a dependent blit kernel between two
     // level launches: ~4 us + two boundaries), chunked only when the list would not fit the ring; then one
@@ -209,7 +224,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
             }
             if (in->tiled)
                 mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                             in->P, in->S, in->C, anyWrite, dCherries);
+                                             in->P, in->S, in->C, anyWrite, dCherries, dCherryTables);
             else
                 mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                         in->P, in->S, in->C, maxRange);

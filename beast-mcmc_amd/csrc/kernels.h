@@ -275,8 +275,11 @@ int  pruneBlocksForRange(int S, int range);
 size_t walkT32StreamBytes(int nEntries, int C);
 void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
 bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots);
+// 21..64 states: the column tables of a list's virtual cherries (kernels_mfma.hip k_cherryTables), handed to launchPruneLevelTiled
+size_t cherryTableBytes(int nCherries, int S, int C);
+void launchCherryTables(hipStream_t stream, const CherryDesc* dCherries, int n, const double* matrices, int S, int C, double* out);
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
-                           bool anyScaleWrite, const CherryDesc* dCherries = nullptr);
+                           bool anyScaleWrite, const CherryDesc* dCherries = nullptr, const double* dCherryTables = nullptr);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)
 void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,

@@ -153,7 +153,8 @@ __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int 
 // PIPE: 0 = loads where they are needed, 1 = child 2 early, 2 = child 2 early + next tile's child 1 (register budget permitting).
 template <int NTMAX, bool EXACT, int PIPE, bool CHERRY>
 __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
-                                                                              int P, int S, int C, const CherryDesc* __restrict__ cherries) {
+                                                                              int P, int S, int C, const CherryDesc* __restrict__ cherries,
+                                                                              const double* __restrict__ cherryTables) {
     constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
     extern __shared__ double frag[];          // [2][NTMAX*NTMAX][16] A fragments of the two branch matrices, current category
     const OpDesc& op = ops[blockIdx.y / C];      // one (op, rate category) per grid row: single-op levels still fill the chip
@@ -166,14 +167,23 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int fl = g * 4 + (lane & 3);
     const bool st1 = op.kind & KIND_STATES1, st2 = op.kind & KIND_STATES2;
-    // virtual-cherry children (NTMAX = 5 only: four more S x S matrices fit the LDS budget of 4 workgroups per CU)
+    // virtual-cherry children.  Their two matrices as column tables (cherryOperands): NTMAX = 5 — staged in LDS (four more S x S
+    // matrices fit the LDS budget of 4 workgroups per CU); NTMAX = 16 — read from a table in global memory that k_cherryTables
+    // built for this list (32 KB per matrix and category: it lives in L2; the LDS is full with the branch matrices)
     const bool vt1 = CHERRY && (op.kind & KIND_CHERRY1), vt2 = CHERRY && (op.kind & KIND_CHERRY2);
     constexpr int fragN = NTMAX * NTMAX * 16;
-    double* vm = frag + 2 * fragN;            // [4][(S + 1) * 4 * NTMAX]: child 1's (A, B), child 2's (A, B); see cherryOperands
+    constexpr bool LDS_TABLES = NTMAX <= 5;
     const int vmN = (S + 1) * 4 * NTMAX;
     CherryDesc cd1 = {}, cd2 = {};
     if (vt1) cd1 = cherries[(size_t)op.child1];
     if (vt2) cd2 = cherries[(size_t)op.child2];
+    const double* vm = frag + 2 * fragN;      // LDS: [4][vmN]: child 1's (A, B), child 2's (A, B)
+    const double *vm1A = vm, *vm1B = vm + vmN, *vm2A = vm + 2 * vmN, *vm2B = vm + 3 * vmN;
+    if (CHERRY && !LDS_TABLES) {              // global: [cherry][A, B][category][vmN]
+        const size_t per = (size_t)C * vmN;
+        vm1A = cherryTables + ((size_t)op.child1 * 2) * per + (size_t)(blockIdx.y % C) * vmN; vm1B = vm1A + per;
+        vm2A = cherryTables + ((size_t)op.child2 * 2) * per + (size_t)(blockIdx.y % C) * vmN; vm2B = vm2A + per;
+    }
     const int tstep = gridDim.x * 4;
     const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
 
@@ -195,13 +205,16 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
             const int i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
             frag[e] = (i < S && j < S) ? (child ? M2 : M1)[(size_t)i * S + j] : 0.0;
         }
-        if (vt1) {
-            cherryStage<NTMAX>(vm, matrices + ((size_t)cd1.matA * C + c) * S * S, S);
-            cherryStage<NTMAX>(vm + vmN, matrices + ((size_t)cd1.matB * C + c) * S * S, S);
-        }
-        if (vt2) {
-            cherryStage<NTMAX>(vm + 2 * vmN, matrices + ((size_t)cd2.matA * C + c) * S * S, S);
-            cherryStage<NTMAX>(vm + 3 * vmN, matrices + ((size_t)cd2.matB * C + c) * S * S, S);
+        if (LDS_TABLES) {
+            double* vmw = frag + 2 * fragN;
+            if (vt1) {
+                cherryStage<NTMAX>(vmw, matrices + ((size_t)cd1.matA * C + c) * S * S, S);
+                cherryStage<NTMAX>(vmw + vmN, matrices + ((size_t)cd1.matB * C + c) * S * S, S);
+            }
+            if (vt2) {
+                cherryStage<NTMAX>(vmw + 2 * vmN, matrices + ((size_t)cd2.matA * C + c) * S * S, S);
+                cherryStage<NTMAX>(vmw + 3 * vmN, matrices + ((size_t)cd2.matB * C + c) * S * S, S);
+            }
         }
         __syncthreads();
         CherryRaw raw1 = {};
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
         for (; tile < tile1; tile += tstep) {
             const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
             const int pe = tile * TILE + 2 * m;           // even pattern of this lane; odd = pe + 1
-            if (vt1) cherryOperands<NTMAX>(raw1, vm, vm + vmN, g, b1);      // (its states and factors were fetched a tile ago)
+            if (vt1) cherryOperands<NTMAX>(raw1, vm1A, vm1B, g, b1);        // (its states and factors were fetched a tile ago)
             else if (PIPE < 2) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);
             // child 2's operands fly while child 1's MFMAs run
             int se2 = S, so2 = S;
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
                     if (vt1) { if (tile + tstep < tile1) raw1 = cherryFetch(cd1, tile + tstep, P, S, m); }
                     else if (PIPE == 2 && tile + tstep < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile + tstep, P, S, g, m, b1, se1, so1);
                 }
-                if (h0 == 0 && vt2) cherryOperands<NTMAX>(raw2, vm + 2 * vmN, vm + 3 * vmN, g, b2);
+                if (h0 == 0 && vt2) cherryOperands<NTMAX>(raw2, vm2A, vm2B, g, b2);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int it0 = h0; it0 < h0 + RH; it0 += IH) {
@@ -403,13 +416,31 @@ static int tiledBlocksPerRow(int P, int rows, int target) {
     return blocks < per ? blocks : per;
 }
 
+// the column tables of a list's virtual cherries for the 21..64-state kernel: out[cherry][A, B][category][(S + 1) * 4 * 16], laid out as
+// cherryStage lays a matrix out in LDS
+__global__ void k_cherryTables(const CherryDesc* __restrict__ cherries, int n, const double* __restrict__ matrices, int S, int C, double* __restrict__ out) {
+    constexpr int NT = 16;
+    const size_t vmN = (size_t)(S + 1) * 4 * NT, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * 2 * C * vmN) return;
+    const int e = (int)(t % vmN), c = (int)((t / vmN) % C), which = (int)((t / (vmN * C)) & 1), k = (int)(t / (vmN * C * 2));
+    const int jt = e % NT, g = (e / NT) & 3, col = e / (4 * NT), i = 4 * jt + g;
+    const double* M = matrices + ((size_t)(which ? cherries[k].matB : cherries[k].matA) * C + c) * S * S;
+    out[t] = i < S ? (col < S ? M[(size_t)i * S + col] : 1.0) : 0.0;
+}
+size_t cherryTableBytes(int nCherries, int S, int C) { return (size_t)nCherries * 2 * C * (S + 1) * 4 * 16 * sizeof(double); }
+void launchCherryTables(hipStream_t stream, const CherryDesc* dCherries, int n, const double* matrices, int S, int C, double* out) {
+    if (n <= 0) return;
+    const size_t total = (size_t)n * 2 * C * (S + 1) * 4 * 16;
+    hipLaunchKernelGGL(k_cherryTables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dCherries, n, matrices, S, C, out);
+}
+
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
-                           bool anyScaleWrite, const CherryDesc* dCherries) {
+                           bool anyScaleWrite, const CherryDesc* dCherries, const double* dCherryTables) {
     if (nOps <= 0) return;
     const int maxOps = 65535 / C;                    // grid.y limit
     if (nOps > maxOps) {
         for (int o = 0; o < nOps; o += maxOps)
-            launchPruneLevelTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C, anyScaleWrite, dCherries);
+            launchPruneLevelTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C, anyScaleWrite, dCherries, dCherryTables);
         return;
     }
     const int nt = (S + 3) / 4;
@@ -429,8 +460,8 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     static const int target = [] { const char* e = getenv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
     dim3 grid(tiledBlocksPerRow(P, nOps * C, target > 0 ? target : (nt <= 5 ? 2048 : 1536)), nOps * C), block(MF_BLOCK);
     static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
-#define TILED_LAUNCH(NT, EX, PI) do { if (NT <= 5 && dCherries) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, NT <= 5>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); \
-                                        else hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, false>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries); } while (0)
+#define TILED_LAUNCH(NT, EX, PI) do { if (dCherries && (NT <= 5 || dCherryTables)) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, true>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries, dCherryTables); \
+                                        else hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, false>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries, dCherryTables); } while (0)
     if (nt <= 5) {
         const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double) + (dCherries ? (size_t)4 * (S + 1) * 4 * 5 * sizeof(double) : 0);    // + the cherries' matrices
         if (nt < 5) TILED_LAUNCH(5, false, 0);
@@ -440,7 +471,9 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     } else {
         const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);          // 64 KiB: above the default 48 KiB cap
         const void* fns[] = {(const void*)k_pruneTiled<16, false, 0, false>, (const void*)k_pruneTiled<16, true, 0, false>,
-                             (const void*)k_pruneTiled<16, true, 1, false>, (const void*)k_pruneTiled<16, true, 2, false>};
+                             (const void*)k_pruneTiled<16, true, 1, false>, (const void*)k_pruneTiled<16, true, 2, false>,
+                             (const void*)k_pruneTiled<16, false, 0, true>, (const void*)k_pruneTiled<16, true, 0, true>,
+                             (const void*)k_pruneTiled<16, true, 1, true>, (const void*)k_pruneTiled<16, true, 2, true>};
         for (const void* f : fns) if (!grantDynamicLds(f, lds)) return;
         if (nt < 16) TILED_LAUNCH(16, false, 0);
         else if (pipe >= 2) TILED_LAUNCH(16, true, 2);
