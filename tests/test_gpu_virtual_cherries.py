@@ -30,8 +30,14 @@ def same(g, o, bufs, what):
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b).max(axis=(0, 2), keepdims=True), 1e-300)) <= 1e-12, (what, x)
 
 
-@pytest.mark.parametrize("S", [4, 20, 16])
-def test_virtual_cherries_keep_beagle_semantics(S, oracle_lib, engine_lib):
+@pytest.fixture
+def cherries_at_61(monkeypatch):
+    """21..64 states define tip-tip nodes only on request (an experiment switch, read at instance creation)."""
+    monkeypatch.setenv("BEAGLE_MI355_CHERRY61", "1")
+
+
+@pytest.mark.parametrize("S", [4, 20, 16, 61])
+def test_virtual_cherries_keep_beagle_semantics(S, oracle_lib, engine_lib, cherries_at_61):
     rng = np.random.default_rng(5)
     states = rng.integers(0, S + 1, size=(T, P)).astype(np.int32)       # S = missing
     if S == 4:
@@ -86,13 +92,13 @@ def test_virtual_cherries_keep_beagle_semantics(S, oracle_lib, engine_lib):
         g.finalize(); o.finalize()
 
 
-@pytest.mark.parametrize("S", [4, 20])
-def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib):
+@pytest.mark.parametrize("S", [4, 20, 61])
+def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib, cherries_at_61):
     """BEAGLE_MI355_NO_VIRTUAL is read at instance creation: the same evaluation with virtual cherries on and off
     must give the same lnL to the last bit (the fused recomputation repeats the cherry op's own arithmetic)."""
     import os
     from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_ALWAYS, RESCALE_DYNAMIC
-    wl = helpers.random_workload(60, 2000, S, 4, seed=77)
+    wl = helpers.random_workload(60, 2000, S, 4, seed=77) if S <= 20 else helpers.random_workload(30, 300, S, 2, seed=77)
     vals = {}
     for flag in ("0", "1"):
         os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
