@@ -60,7 +60,7 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
     } else {
         mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                        in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
-                                       in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd, flag, seq);
+                                       in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd, flag, seq, in->fuseLaunches ? in->rootCounter : nullptr);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -273,6 +273,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->strictWaits = !(getenv("BEAGLE_MI355_STRICT_WAITS") && atoi(getenv("BEAGLE_MI355_STRICT_WAITS")) == 0);
     in->fuseGradient = !(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT") && atoi(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT")) != 0);
     in->preWalk = !(getenv("BEAGLE_MI355_NO_PRE_WALK") && atoi(getenv("BEAGLE_MI355_NO_PRE_WALK")) != 0);
+    in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
     if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
@@ -307,6 +308,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && devAlloc(in, (void**)&in->siteLogL, (size_t)patternCount * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->blockSums, ((size_t)rootBlocks + 1024) * sizeof(double)) == 0;    // (+ one partial block per partition)
     ok = ok && devAlloc(in, (void**)&in->dResult, 4096) == 0;
+    ok = ok && devAlloc(in, (void**)&in->rootCounter, 256) == 0 && hipMemset(in->rootCounter, 0, 256) == hipSuccess;
     if (ok) {
         // defaults: category rates 1, weights 1/C, pattern weights 1 (beagle.jar!GeneralBeagleImpl#<init>)
         std::vector<double> ones(std::max<size_t>((size_t)patternCount, E * C), 1.0);

@@ -100,6 +100,8 @@ struct Instance {
     // 16..20 states: operation lists without write-mode rescaling run as the walk's programs on the T32 layout (kernels_mfma.hip
     // k_walkT32: same planner, same descriptors; engine_walk.cpp); everything 4-state-specific (`walk`) stays off
     bool walkT = false;
+    bool fuseLaunches = true;                            // BEAGLE_MI355_NO_LAUNCH_FUSION=1: snapshot / gather and root site / final as separate launches (A/B runs)
+    unsigned* rootCounter = nullptr;                     // device word of k_rootSite's last-workgroup sum (kernels.hip)
     double* cherryTables = nullptr; size_t cherryTableBytes = 0;   // 21..64 states: column tables of a list's virtual cherries (grow-only)
     int holdSlots = 3;                                   // what the planner was given
     bool eigenComplex = false;                           // created with BEAGLE_FLAG_EIGEN_COMPLEX: eigenvalue arrays are [S real parts | S imaginary parts]

@@ -1,6 +1,7 @@
 // engine_walk.cpp — 4 states: a planned program (planner.h) resolved to device addresses and run as pattern-walk launches
 // (kernels_walk4.hip); materialisation of virtual buffers; updatePartials' steady-state fast path.  See engine_internal.h.
 #include "engine_internal.h"
+#include <unordered_map>
 
 using mi355::OpDesc;
 
@@ -40,6 +41,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     w.reserve(n + 3 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
     const size_t matStride = (size_t)in->C * in->S * in->S;
+    // matrices whose snapshot is taken by THIS plan are gathered from the snapshot's source (same values; lets the snapshot copies and
+    // the gather run in one launch: kernels_walk4.hip k_gatherAndSnapshot)
+    std::unordered_map<int, int> freshSnapshot;
+    for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) freshSnapshot[plan.snapPairs[q + 1]] = plan.snapPairs[q];
+    auto gatherFrom = [&](int mat) { auto it = freshSnapshot.find(mat); return it == freshSnapshot.end() ? mat : it->second; };
     const size_t tipOff = in->walkT ? 0 : in->statePairOff;          // the T32 walk reads the plain state arrays and the RAW scale factors
     { int rc = ensureWalkDummies(in); if (rc) return rc; }
     mi355::WalkOp nop;
@@ -80,7 +86,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 d.store = in->partials[m.storeBuf];
                 in->statStored++;
             }
-            d.m1 = in->matrices + (size_t)m.mat1 * matStride; d.m2 = in->matrices + (size_t)m.mat2 * matStride;
+            d.m1 = in->matrices + (size_t)gatherFrom(m.mat1) * matStride; d.m2 = in->matrices + (size_t)gatherFrom(m.mat2) * matStride;
             d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
             if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
                 if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
@@ -155,7 +161,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
         dBase = in->bigStage;
     }
-    if (pairBytes)
+    const bool fusedSnapshot = pairBytes && !in->walkT && in->fuseLaunches;          // 4 states: together with the gather below
+    if (pairBytes && !fusedSnapshot)
         mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
@@ -170,6 +177,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->matStreamBytes = want;
     }
     if (in->walkT) mi355::launchGatherFragments(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    else if (fusedSnapshot) mi355::launchGatherAndSnapshot(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
+                                                           (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
     else mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());

@@ -118,6 +118,8 @@ struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, pad0, pad1, pad
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream,
                  int P, int C, long recipOff);
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
+// ... and the plan's matrix snapshots (src, dst index pairs) in the same launch; m1 / m2 of freshly snapshotted matrices must point at the sources
+void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
 // src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
@@ -159,7 +161,8 @@ void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, co
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                              double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,
-                             unsigned long long* flag = nullptr, unsigned long long seq = 0);
+                             unsigned long long* flag = nullptr, unsigned long long seq = 0, unsigned* counter = nullptr);
+// (counter: a zeroed device word — the workgroup that finishes last forms the sum itself, one launch instead of two)
 
 // cum[p] += sign * sum_k (raw_k ? log(src_k[p]) : src_k[p]) on [pStart, pEnd); srcs/raws are device arrays.
 void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,

@@ -291,8 +291,10 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSite(const double* __restric
                                                          const double* __restrict__ freqs, const double* __restrict__ cum,
                                                          int cumIsRaw, const double* __restrict__ patternWeights,
                                                          double* __restrict__ siteLogL, double* __restrict__ blockSums,
-                                                         int P, int S, int C, int pStart, int pEnd) {
+                                                         int P, int S, int C, int pStart, int pEnd,
+                                                         unsigned* counter, double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[ROOT_BLOCK / 64];
+    __shared__ bool lastBlock;
     const int p = pStart + blockIdx.x * ROOT_BLOCK + threadIdx.x;
     double contrib = 0.0;
     if (p < pEnd) {
@@ -317,6 +319,27 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSite(const double* __restric
     }
     const double t = blockSum(contrib, sh);
     if (threadIdx.x == 0) blockSums[blockIdx.x] = t;
+    if (!counter) return;                          // (the sum over the blocks is a launch of its own: k_rootFinal)
+    // The workgroup that finishes LAST adds the block sums up, in index order (the same fixed-order sum k_rootFinal forms: the
+    // result does not depend on which workgroup that is) — one launch per evaluation less on a path where a launch is 4 us of
+    // the GPU's time and as much of the host's.
+    if (threadIdx.x == 0) {
+        __threadfence();                                                       // my block sum before my ticket
+        lastBlock = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!lastBlock) return;
+    __threadfence();
+    double v = 0.0;
+    for (int k = threadIdx.x; k < (int)gridDim.x; k += ROOT_BLOCK)
+        v += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(blockSums) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const double total = blockSum(v, sh);
+    if (threadIdx.x == 0) {
+        out[0] = total;
+        *counter = 0u;                                                         // ready for the next launch (same stream: ordered)
+        if (flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
+    }
 }
 
 // `flag` (nullable): a word next to `out` in host-visible memory that receives `seq` after the sum — the host polls it
@@ -336,11 +359,11 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinal(const double* __restri
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                              double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,
-                             unsigned long long* flag, unsigned long long seq) {
+                             unsigned long long* flag, unsigned long long seq, unsigned* counter) {
     const int n = (pEnd - pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
     hipLaunchKernelGGL(k_rootSite, dim3(n), dim3(ROOT_BLOCK), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
-                       patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
-    hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
+                       patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd, counter, out, flag, seq);
+    if (!counter) hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
 }
 
 __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSiteParts(const RootParts parts, const double* __restrict__ patternWeights,

@@ -324,6 +324,32 @@ __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, 
     stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
 }
 
+// The same, and in the same launch the matrix snapshots of the plan's new definitions (kernels.hip k_snapshot): the stream's
+// entries of those definitions are gathered from the snapshots' SOURCES (engine_walk.cpp runPlan points m1 / m2 there), so the
+// two halves do not depend on each other and one launch does for both.
+__global__ void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
+                                    double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
+    if ((int)blockIdx.x >= gatherBlocks) {
+        const int k = (int)blockIdx.x - gatherBlocks;
+        const double* s = matrices + (size_t)srcDst[2 * k] * elems;
+        double* d = matrices + (size_t)srcDst[2 * k + 1] * elems;
+        for (int e = threadIdx.x; e < elems; e += blockDim.x) d[e] = s[e];
+        return;
+    }
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * C * 40) return;
+    const int k = (int)(t / (C * 40)), r = (int)(t % (C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
+    const double MI355_GLOBAL* M = gptr(m ? prog[k].m2 : prog[k].m1) + c * 16;
+    stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
+}
+void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems) {
+    if (nOps <= 0) { launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
+    const size_t total = (size_t)nOps * C * 40;
+    const int gatherBlocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + (nPairs > 0 ? nPairs : 0))), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
+                       gatherBlocks, matrices, dSrcDst, elems);
+}
+
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream) {
     if (nOps <= 0) return;
     const size_t total = (size_t)nOps * C * 40;
