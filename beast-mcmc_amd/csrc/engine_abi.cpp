@@ -280,6 +280,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255 + (in->walk ? 256 : 0)) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
+    in->scaleOfPartial.assign(partialsBufferCount, -2); in->scaleVersionAtWrite.assign(partialsBufferCount, 0u);     // (-2: unknown)
+    in->scaleVersion.assign(std::max(1, scaleBufferCount), 0u);
     in->tipStates.assign(partialsBufferCount, nullptr);
     in->scale.assign(std::max(1, scaleBufferCount), nullptr);
     in->scaleIsRaw.assign(std::max(1, scaleBufferCount), 0);
@@ -500,6 +502,7 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials) {
     // (a held-back pre-order list has its own copy of its root's pre-order partial — the buffer the gradient delegates rewrite
     // before every list — and waits unless this is one of the other buffers it reads or writes)
     if (heldTouches(in, bufferIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
+    in->scaleOfPartial[bufferIndex] = -1;                  // (caller's data: no scale factor of ours in it)
     int rc = materializeTipUsers(in, bufferIndex); if (rc) return rc;
     clearVirtual(in, bufferIndex);
     rc = ensurePartials(in, bufferIndex); if (rc) return rc;
@@ -822,12 +825,17 @@ int beagleUpdatePartials(int instance, const int* operations, int operationCount
         return mi355::shardedPost(instance, [=](int h) { return beagleUpdatePartials(h, ops.data(), operationCount, cumulativeScaleIndex); });
     }
     GET_INSTANCE_KEEP_PENDING(instance);
-    if (operations && (in->heldPre.held || !in->scalingSeen))
+    if (operations && (in->heldPre.held || in->trackScales))               // (only on instances that have been asked for a pre-order pass)
         for (int k = 0; k < operationCount; k++) {
             const int* op = operations + (size_t)k * BEAGLE_OP_COUNT;
-            if (op[1] != BEAGLE_OP_NONE || op[2] != BEAGLE_OP_NONE) in->scalingSeen = true;
             // (a held-back pre-order list waits unless this list overwrites what it reads or touches what it writes)
             if (heldTouches(in, op[0]) || heldWrites(in, op[3]) || heldWrites(in, op[5])) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
+            // which scale factor the destination is divided by (the pre-order walk needs it: Instance::scaleOfPartial)
+            if (badIndex(op[0], in->partialsCount)) continue;                  // (reported by runOperations)
+            const int sIdx = op[1] != BEAGLE_OP_NONE ? op[1] : op[2];
+            if (op[1] != BEAGLE_OP_NONE && !badIndex(op[1], in->scaleCount)) in->scaleVersion[op[1]]++;
+            in->scaleOfPartial[op[0]] = (sIdx != BEAGLE_OP_NONE && !badIndex(sIdx, in->scaleCount)) ? sIdx : -1;
+            in->scaleVersionAtWrite[op[0]] = in->scaleOfPartial[op[0]] >= 0 ? in->scaleVersion[sIdx] : 0u;
         }
     return runOperations(in, operations, operationCount, BEAGLE_OP_COUNT, cumulativeScaleIndex);
 }
@@ -853,28 +861,33 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
 
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleAccumulateScaleFactors(h, v.data(), count, cumulativeScaleIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, 0);
 }
 int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
     if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleAccumulateScaleFactorsByPartition(h, v.data(), count, cumulativeScaleIndex, partitionIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, 1.0, partitionIndex);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleRemoveScaleFactors(h, v.data(), count, cumulativeScaleIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, 0);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex) {
     if (mi355::isShardedHandle(instance)) { std::vector<int> v(scaleIndices, scaleIndices + std::max(0, count)); return mi355::shardedPost(instance, [=](int h) { return beagleRemoveScaleFactorsByPartition(h, v.data(), count, cumulativeScaleIndex, partitionIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     return accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1.0, partitionIndex);
 }
 
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleResetScaleFactorsByPartition(h, cumulativeScaleIndex, partitionIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     if (badIndex(cumulativeScaleIndex, in->scaleCount) || badIndex(partitionIndex, in->partitionCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
@@ -890,7 +903,8 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleResetScaleFactors(h, cumulativeScaleIndex); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);          // (scale buffers only: nothing a held-back pre-order list reads or writes)
+    if (!badIndex(cumulativeScaleIndex, in->scaleCount)) in->scaleVersion[cumulativeScaleIndex]++;
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
@@ -903,7 +917,8 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
 
 int beagleCopyScaleFactors(int instance, int dest, int src) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedPost(instance, [=](int h) { return beagleCopyScaleFactors(h, dest, src); }); }
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEP_PENDING(instance);
+    if (!badIndex(dest, in->scaleCount)) in->scaleVersion[dest]++;
     if (badIndex(dest, in->scaleCount) || badIndex(src, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, dest); if (rc) return rc;
     rc = ensureScale(in, dest); if (rc) return rc;

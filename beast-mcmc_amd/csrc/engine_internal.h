@@ -91,7 +91,13 @@ struct Instance {
     double* preRootCopy = nullptr;                       // the held list's own copy of its root's pre-order partial
     uint8_t* preDummyStates = nullptr;                   // [P] "missing": what a descriptor's unused tip pointer points at
     void* dPreProg = nullptr; size_t dPreProgBytes = 0;  // the walk's program on the device (grow-only)
-    bool scalingSeen = false;                            // some updatePartials operation carried a scale index (sticky): den differs per edge
+    // which scale buffer a partials buffer's last operation divided it by (-1: none / unknown), and that buffer's version then: the
+    // pre-order walk multiplies a step into an internal node by the reciprocal of exactly that factor (kernels_preorder4.hip) and
+    // is refused when the scale buffer has been written since (beagleUpdatePartials, the scale-factor calls)
+    // Kept only once a pre-order list has arrived (trackScales; everything written before that is "unknown", -2, and the first
+    // gradient of a chain takes the path that forms every edge's denominator itself).
+    std::vector<int> scaleOfPartial; std::vector<unsigned> scaleVersionAtWrite, scaleVersion;
+    bool trackScales = false;
     long statFusedGradients = 0, statPreLists = 0, statWalkedGradients = 0, statLateLists = 0;
     int storeAllEvaluations = 0;                         // > 0: post-order passes leave no node unstored (a pre-order pass asked for them)
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)

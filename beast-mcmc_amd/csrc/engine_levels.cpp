@@ -241,21 +241,34 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
 // cumulative scale factors requested together with an update: fold the factors the list wrote into the cumulative
 // buffer afterwards, in op order (deterministic; no cross-workgroup atomics)
 int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globalCum) {
+    // one accumulation launch per (cumulative buffer, partition) met in the list — the factors of all its operations at once (the
+    // kernel walks the list of sources in op order: deterministic) — not one per operation (999 launches for a 1000-taxon tree)
+    struct Group { int cum, part; std::vector<const double*> srcs; };
+    std::vector<Group> groups;
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * tuple;
         const int wS = op[1];
         int part = 0, cum = globalCum;
         if (tuple == BEAGLE_PARTITION_OP_COUNT) { part = op[7]; cum = op[8]; }
         if (cum == BEAGLE_OP_NONE || wS == BEAGLE_OP_NONE) continue;
-        int rc = materializeScaleUsers(in, cum); if (rc) return rc;
-        rc = ensureScale(in, cum); if (rc) return rc;
-        const double* src = in->scale[wS];
-        int one = 1;
-        void *dSrc = nullptr, *dRaw = nullptr;
-        rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
-        rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
-        mi355::launchAccumulateScale(in->stream, in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0,
-                                     in->partStart[part], in->partEnd[part]);
+        Group* g = nullptr;
+        for (Group& x : groups) if (x.cum == cum && x.part == part) { g = &x; break; }
+        if (!g) { groups.push_back(Group{cum, part, {}}); g = &groups.back(); }
+        g->srcs.push_back(in->scale[wS]);
+    }
+    for (const Group& g : groups) {
+        int rc = materializeScaleUsers(in, g.cum); if (rc) return rc;
+        rc = ensureScale(in, g.cum); if (rc) return rc;
+        const int chunk = 4096;
+        for (size_t b = 0; b < g.srcs.size(); b += chunk) {
+            const int n = (int)std::min<size_t>(chunk, g.srcs.size() - b);
+            std::vector<int> raw(n, 1);
+            void *dSrc = nullptr, *dRaw = nullptr;
+            rc = uploadTransient(in, &g.srcs[b], (size_t)n * sizeof(double*), &dSrc); if (rc) return rc;
+            rc = uploadTransient(in, raw.data(), (size_t)n * sizeof(int), &dRaw); if (rc) return rc;
+            mi355::launchAccumulateScale(in->stream, in->scale[g.cum], (const double* const*)dSrc, (const int*)dRaw, n, 1.0,
+                                         in->partStart[g.part], in->partEnd[g.part]);
+        }
     }
     return 0;
 }

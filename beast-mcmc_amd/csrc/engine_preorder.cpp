@@ -79,6 +79,7 @@ int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
 // levelised like a post-order one and each level is one launch.
 int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold) {
     if (count <= 0) return 0;
+    if (mayHold && in->S == 4 && in->fuseGradient) in->trackScales = true;     // (from now on updatePartials records scale indices: engine_abi.cpp)
     if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     const int n = in->partialsCount;
     // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
@@ -90,6 +91,8 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
             (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
             return BEAGLE_ERROR_OUT_OF_RANGE;
+        in->scaleOfPartial[dest] = -1;                    // (a pre-order partial: never a post-order operand of the walk)
+        if (wS != BEAGLE_OP_NONE) in->scaleVersion[wS]++;
         if (isVirt(in, sib)) need.push_back(sib);
         if (isVirt(in, par)) need.push_back(par);
         if (in->virt) {
@@ -414,7 +417,8 @@ static int fusedGradient(Instance* in, const std::vector<int>& edgeOf, const int
 // The sums alone, nothing written (k_preWalk4): the list STAYS held.  1 = this list / instance cannot be walked.
 static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const int* dIdx, int wIdx, int count, double* outSum) {
     const Instance::HeldPreList& h = in->heldPre;
-    if (!in->preWalk || in->scalingSeen || h.holdSlots > mi355::PW_MAX_HOLD || in->C > 16) return 1;
+    if (!in->preWalk || h.holdSlots > mi355::PW_MAX_HOLD || in->C > 16) return 1;
+    { int rcd = ensureWalkDummies(in); if (rcd) return rcd; }              // (the all-ones reciprocal array)
     const int waves = mi355::preWalkWaves(in->P, in->C);
     const size_t sumBytes = (size_t)(count + 1) * waves * sizeof(double), outBytes = (size_t)count * sizeof(double);
     if (sumBytes > ((size_t)1 << 30)) return 1;
@@ -432,6 +436,17 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     mi355::PreWalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.postA = nop.postB = in->preRootCopy; nop.tipA = nop.tipB = in->preDummyStates; nop.slotA = nop.slotB = count;   // valid memory, the spare slot
+    nop.recipA = nop.recipB = in->onesScale;
+    // 1 / (the factor a post-order operand was divided by), or ones; false: its scale buffer has been written since
+    auto reciprocalOf = [&](int po, const double*& out) {
+        out = in->onesScale;
+        const int sIdx = in->scaleOfPartial[po];
+        if (sIdx == -1) return true;
+        if (sIdx < 0) return false;                                 // written before the instance kept track
+        if (in->scaleVersion[sIdx] != in->scaleVersionAtWrite[po] || !in->scale[sIdx] || !in->scaleIsRaw[sIdx]) return false;
+        out = in->scale[sIdx] + in->scaleStride;
+        return true;
+    };
     nop.flags = mi355::PW_TIP_A | mi355::PW_TIP_B;
     for (int sgi = 0; sgi < nSegs; sgi++) {
         const int first = h.segStart[sgi], n = h.segStart[sgi + 1] - first;
@@ -445,8 +460,8 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
                 const int po = w ? nd.postB : nd.postA;
                 const bool st = in->tipStates[po] && po < in->tipCount;
                 const int e = edgeOf[w ? nd.preB : nd.preA];
-                if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else op.postB = in->partials[po]; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
-                else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else op.postA = in->partials[po]; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+                if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else { op.postB = in->partials[po]; if (!reciprocalOf(po, op.recipB)) return 1; } if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
+                else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else { op.postA = in->partials[po]; if (!reciprocalOf(po, op.recipA)) return 1; } if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
             }
             op.storeA = in->partials[nd.preA]; op.storeB = in->partials[nd.preB];
             op.matA = nd.matA; op.matB = nd.matB;
@@ -471,6 +486,9 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     mi355::launchPreWalkFinal(in->stream, dSums, count, in->P, in->C, dOut);
     std::vector<double> out(count);
     rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;
+    // (scaled partials times reciprocals of factors: should a product have left the range on a very deep path, the sums show it —
+    // the caller then gets them from the path that forms every edge's denominator itself)
+    for (int e = 0; e < count; e++) if (!std::isfinite(out[e])) return 1;
     if (outSum) memcpy(outSum, out.data(), outBytes);
     in->statWalkedGradients++;
     return 0;

@@ -224,12 +224,14 @@ struct PreWalkOp {
     const uint8_t* tipB;
     double*        storeA;       // continuation PW_CONT_STORE: where the child's pre-order partial is written (it heads another segment)
     double*        storeB;
+    const double*  recipA;       // 1 / (scale factor of post(a)), pair-interleaved (a walk instance's reciprocal array); all ones when
+    const double*  recipB;       // the child is a tip or its partials carry no factor
     int            matA, matB, dA, dB;
     int            slotA, slotB; // where the edges' sums go (the launch's last slot = nobody asked)
     unsigned       flags;        // PW_* below
     int            pad;
 };
-static_assert(sizeof(PreWalkOp) == 80, "PreWalkOp layout");
+static_assert(sizeof(PreWalkOp) == 96, "PreWalkOp layout");
 constexpr unsigned PW_TIP_A = 1u, PW_TIP_B = 2u;          // the child is a compact tip
 constexpr int PW_SRC_SHIFT = 4, PW_CONT_A_SHIFT = 8, PW_CONT_B_SHIFT = 12;   // 4 bits each
 // source of the node's pre-order partial: 0 = the registers, 1 + k = hold slot k

@@ -151,9 +151,14 @@ void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nE
 // asks: engine_preorder.cpp), so the pass reads each post-order partial once and writes a few doubles per edge and wave.
 //
 // The sum over categories inside a pattern's derivative, sum_c w_c num_c / sum_c w_c den_c, would need the categories'
-// waves to meet at every edge.  It does not have to: den = sum_c w_c pre . post is the pattern's likelihood and the same on
-// every edge (post-order partials that carry no scale factors — the engine checks), so it is formed ONCE, at the root, and
-// each thread multiplies its numerators by weight_p w_c / den_p; everything after that is a plain sum.
+// waves to meet at every edge.  It does not have to: den = sum_c w_c pre . post is the pattern's likelihood — the same on
+// every edge up to the scale factors of the post-order partials: den(edges below a) = den(edges below parent(a)) * f_a, with
+// f_a the factor post(a) was divided by.  So the denominator is formed ONCE, at the root, and because everything downstream
+// is linear in the pre-order partial, what a thread carries is not pre(n) but weight_p w_c / den * pre(n): the factor is
+// multiplied in at the root, a step into an internal child multiplies by 1 / f_a (read from the child's reciprocal scale
+// array; ones when it carries none), and every edge's contribution is a plain dot product to be summed.  (The partials this
+// walk parks in hold slots or stores for other segments are therefore scaled ones; the engine rewrites the real buffers
+// whenever somebody asks for them.)
 //
 // Loads are software-pipelined by hand exactly as in k_walk4: while descriptor k computes, the loads of k + 1 are in flight,
 // and the wait before k's arithmetic is for "all but the loads of k + 1" (preWait).  The branch matrices and the differential matrices arrive spread over the
@@ -162,16 +167,16 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 #define MI355_CONST __attribute__((address_space(4)))
 
-struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb; double mA, mB, dA, dB; };
-struct PreDesc { u64 postA, postB, tipA, tipB, storeA, storeB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
+struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb; double mA, mB, dA, dB, ra, rb; };
+struct PreDesc { u64 postA, postB, tipA, tipB, storeA, storeB, recipA, recipB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
 
 __device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
     PreDesc d;
-    d.postA = (u64)p->postA; d.postB = (u64)p->postB; d.tipA = (u64)p->tipA; d.tipB = (u64)p->tipB; d.storeA = (u64)p->storeA; d.storeB = (u64)p->storeB;
+    d.postA = (u64)p->postA; d.postB = (u64)p->postB; d.tipA = (u64)p->tipA; d.tipB = (u64)p->tipB; d.storeA = (u64)p->storeA; d.storeB = (u64)p->storeB; d.recipA = (u64)p->recipA; d.recipB = (u64)p->recipB;
     d.matA = p->matA; d.matB = p->matB; d.dA = p->dA; d.dB = p->dB; d.slotA = p->slotA; d.slotB = p->slotB; d.flags = p->flags;
     return d;
 }
-__device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, u64 matrices, unsigned matBytes) {
+__device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, unsigned oRecip, u64 matrices, unsigned matBytes) {
     const u64 mA = matrices + (u64)(unsigned)d.matA * matBytes, mB = matrices + (u64)(unsigned)d.matB * matBytes;
     const u64 dA = matrices + (u64)(unsigned)d.dA * matBytes, dB = matrices + (u64)(unsigned)d.dB * matBytes;
     // a compact tip is one byte, a child with partials two 16-byte loads: what is not needed is BRANCHED around (a vector-memory
@@ -196,30 +201,32 @@ __device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsign
         "global_load_dwordx2 %[mA], %[oM], %[smA]\n\t"
         "global_load_dwordx2 %[mB], %[oM], %[smB]\n\t"
         "global_load_dwordx2 %[dA], %[oM], %[sdA]\n\t"
-        "global_load_dwordx2 %[dB], %[oM], %[sdB]"
+        "global_load_dwordx2 %[dB], %[oM], %[sdB]\n\t"
+        "global_load_dwordx2 %[ra], %[oR], %[srA]\n\t"
+        "global_load_dwordx2 %[rb], %[oR], %[srB]"
         : [a0] "+v"(f.a0), [a1] "+v"(f.a1), [b0] "+v"(f.b0), [b1] "+v"(f.b1), [sa] "+v"(f.sa), [sb] "+v"(f.sb),
-          [mA] "+v"(f.mA), [mB] "+v"(f.mB), [dA] "+v"(f.dA), [dB] "+v"(f.dB)
-        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
-          [smA] "s"(mA), [smB] "s"(mB), [sdA] "s"(dA), [sdB] "s"(dB)
+          [mA] "+v"(f.mA), [mB] "+v"(f.mB), [dA] "+v"(f.dA), [dB] "+v"(f.dB), [ra] "+v"(f.ra), [rb] "+v"(f.rb)
+        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [oR] "v"(oRecip), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
+          [smA] "s"(mA), [smB] "s"(mB), [sdA] "s"(dA), [sdB] "s"(dB), [srA] "s"(d.recipA), [srB] "s"(d.recipB)
         : "memory", "scc");
 }
-// the loads of `f` have landed once at most as many loads as the FOLLOWING descriptor issued (6, 7 or 8: four matrices and one
-// or two per child) are outstanding: loads return in issue order, and stores in the queue only make the wait stricter
+// the loads of `f` have landed once at most as many loads as the FOLLOWING descriptor issued (8, 9 or 10: four matrices, two
+// reciprocal factors and one or two per child) are outstanding: loads return in issue order, and stores in the queue only make the wait stricter
 __device__ __forceinline__ void preWait(PreFetched& f, unsigned nextTips) {      // nextTips: PW_TIP_* bits of the following descriptor
     asm volatile(
         "s_cmp_eq_u32 %[nt], 3\n\t"
         "s_cbranch_scc1 .Lw6%=\n\t"
         "s_cmp_eq_u32 %[nt], 0\n\t"
         "s_cbranch_scc1 .Lw8%=\n\t"
-        "s_waitcnt vmcnt(7)\n\t"
+        "s_waitcnt vmcnt(9)\n\t"
         "s_branch .Lwd%=\n"
         ".Lw8%=:\n\t"
-        "s_waitcnt vmcnt(8)\n\t"
+        "s_waitcnt vmcnt(10)\n\t"
         "s_branch .Lwd%=\n"
         ".Lw6%=:\n\t"
-        "s_waitcnt vmcnt(6)\n"
-        ".Lwd%=: ; retires %0 %1 %2 %3 %4 %5 %6 %7 %8 %9"
-        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB)
+        "s_waitcnt vmcnt(8)\n"
+        ".Lwd%=: ; retires %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11"
+        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB), "+v"(f.ra), "+v"(f.rb)
         : [nt] "s"(nextTips) : "memory", "scc");
 }
 // (ya, yb) = (MA xa, MB xb), the matrices spread over the lanes (lane l = entry l & 15, row-major): eight independent chains
@@ -277,7 +284,7 @@ template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, const PreWalkSeg MI355_CONST* __restrict__ segs,
                                                    const double* __restrict__ listRootPre, const double* __restrict__ matrices,
                                                    const double* __restrict__ catWeights, const double* __restrict__ patternWeights,
-                                                   double* __restrict__ sums, int P, int C) {
+                                                   double* __restrict__ sums, int P, int C, int rootSegment) {
     extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d); slot 0 doubles as the categories' exchange at the start
     const PreWalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int nOps = sg.progCount;
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     const bool valid = p < P;
     const int q = valid ? p : P - 1;                  // lanes past the end recompute the last pattern and count for nothing
     const unsigned oPart = (unsigned)(((size_t)c * P + q) * 32), oTip = (unsigned)q, oMat = (unsigned)(c * 128 + (lane & 15) * 8);
+    const unsigned oRecip = (unsigned)(walkPairIndex((size_t)q) * 8);     // (one partition: the pair-interleaved position of pattern q)
     const unsigned matBytes = (unsigned)C * 128u;
     const u64 mats = (u64)matrices;
     const size_t waves = (size_t)gridDim.x * C, w = (size_t)blockIdx.x * C + c;
@@ -296,13 +304,13 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     const PreWalkOp MI355_CONST* dp = prog + sg.progStart;
     PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
     PreFetched A, B;
-    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0;
+    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
     B = A;
-    preIssue(A, D0, oPart, oTip, oMat, mats, matBytes);
+    preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, matBytes);
     v4d ACC = gptr(reinterpret_cast<const v4d*>(sg.rootPre))[(size_t)c * P + q];
-    // the pattern's likelihood, once: den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
-    double coef;
-    {
+    // the pattern's likelihood, once (the segment that starts at the list's root; the others start from partials that carry the
+    // factor already): den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
+    if (rootSegment) {
         const PreWalkOp MI355_CONST& r = prog[0];
         const v4d root = gptr(reinterpret_cast<const v4d*>(listRootPre))[(size_t)c * P + q];
         const v4d xa = (r.flags & PW_TIP_A) ? tipVector(gptr(r.tipA)[q]) : gptr(reinterpret_cast<const v4d*>(r.postA))[(size_t)c * P + q];
@@ -314,12 +322,13 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         double den = 0.0;
         for (int cc = 0; cc < C; cc++) den += exch[cc * 64 + lane];
         __syncthreads();
-        coef = valid ? patternWeights[p] * catWeights[c] / den : 0.0;
-    }
+        const double coef = valid ? patternWeights[p] * catWeights[c] / den : 0.0;
+        ACC = ACC * coef;
+    } else if (!valid) ACC = v4d{0.0, 0.0, 0.0, 0.0};            // (a lane past the end counts for nothing: the root's factor was 0 for it)
 
 #define PRE_STAGE(CUR, NXT, DCUR, DNXT)                                                                                     \
     {                                                                                                                     \
-        preIssue(NXT, DNXT, oPart, oTip, oMat, mats, matBytes);                                                           \
+        preIssue(NXT, DNXT, oPart, oTip, oMat, oRecip, mats, matBytes);                                                   \
         const unsigned fl = DCUR.flags;                                                                                   \
         const int slotA = DCUR.slotA, slotB = DCUR.slotB;                                                                 \
         const u64 stA = DCUR.storeA, stB = DCUR.storeB;                                                                   \
@@ -336,7 +345,8 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         matvecDppPair(CUR.dA, xa, CUR.dB, xb, va, vb);                                                                    \
         DCUR = loadPreDesc(dp + 2);                                                                                       \
         dp += 1;                                                                                                          \
-        const double ga = waveSumTo63(coef * dot4(pa, va)), gb = waveSumTo63(coef * dot4(pb, vb));                        \
+        const double ga = waveSumTo63(dot4(pa, va)), gb = waveSumTo63(dot4(pb, vb));                                      \
+        pa = pa * CUR.ra; pb = pb * CUR.rb;            /* what the children's edges see: divided by the child's own scale factor */ \
         if (lane == 63) { sums[(size_t)slotA * waves + w] = ga; sums[(size_t)slotB * waves + w] = gb; }                   \
         if (contA == PW_CONT_STORE) { if (valid) gptr(reinterpret_cast<v4d*>(stA))[(size_t)c * P + q] = pa; }             \
         else if (contA >= 2u) { v2d* h = holdBase + (size_t)(contA - 2) * holdStride; h[0] = v2d{pa.x, pa.y}; h[64] = v2d{pa.z, pa.w}; }   \
@@ -368,7 +378,7 @@ bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg
       for (int part = 0; part < 2; part++) {                                                                              \
           const int n = part ? nSegs - 1 : 1;                                                                             \
           if (n > 0) hipLaunchKernelGGL(k_preWalk4<T>, dim3((P + 63) / 64, n), block, lds, stream, (const PreWalkOp MI355_CONST*)dProg,   \
-                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C); } }
+                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C, part == 0 ? 1 : 0); } }
     if (C <= 4) PRE_WALK_LAUNCH(256) else if (C <= 8) PRE_WALK_LAUNCH(512) else PRE_WALK_LAUNCH(1024)
 #undef PRE_WALK_LAUNCH
     return true;

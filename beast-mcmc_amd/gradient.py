@@ -36,9 +36,11 @@ class BranchGradient:
         matrices = (2 if double_buffer else 1) * self.N
         self.q_index = matrices
         self.q2_index = matrices + 1
-        self.cum_scale = self.T - 1 if rescale else _b.NONE
+        # scale buffers: one per internal node and the cumulative one; with double buffering two such sets, flipped together with
+        # the partials (BeagleDataLikelihoodDelegate.java:237 scaleBufferHelper, :874 / :917 flipOffset)
+        self._scale_set = internal + 1 if (double_buffer and rescale) else 0
         self.b = _b.Beagle(self.T, self.pre_offset + self.N, self.T, self.S, self.P, 1, matrices + 2, self.C,
-                           (self.T if rescale else 0), resourceList=resource_list, library=library)
+                           ((2 if double_buffer else 1) * (internal + 1) if rescale else 0), resourceList=resource_list, library=library)
         for t in range(self.T):
             self.b.setTipStates(t, wl.tip_states[t])
         self.b.setPatternWeights(wl.weights)
@@ -57,10 +59,22 @@ class BranchGradient:
         e = np.asarray(self.edges, dtype=np.int32)
         self._edge_post = [np.asarray([self.post_index(n, v) for n in self.edges], dtype=np.int32) for v in sets]
         self._edge_matrix = [e + v * self._matrix_set for v in sets]
+        self._scale_indices_by_set = [np.asarray([self.scale_index(n, v) for n in range(self.T, self.N)], dtype=np.int32) for v in sets]
 
     def post_index(self, node, which=None):
         v = self._set if which is None else which
         return node if node < self.T else node + v * self._partial_set
+
+    def scale_index(self, node, which=None):
+        """scale buffer of internal node `node` (node = None: the cumulative one)"""
+        if not self.rescale:
+            return _b.NONE
+        v = self._set if which is None else which
+        return (self.N - self.T if node is None else node - self.T) + v * self._scale_set
+
+    @property
+    def cum_scale(self):
+        return self.scale_index(None)
 
     def matrix_index(self, node, which=None):
         return node + (self._set if which is None else which) * self._matrix_set
@@ -80,7 +94,7 @@ class BranchGradient:
             if n < self.T:
                 continue
             l, r = int(tr.left[n]), int(tr.right[n])
-            ws = (n - self.T) if self.rescale else _b.NONE
+            ws = self.scale_index(n, v)
             ops += [self.post_index(n, v), ws, _b.NONE, self.post_index(l, v), self.matrix_index(l, v),
                     self.post_index(r, v), self.matrix_index(r, v)]
         return np.asarray(ops, dtype=np.int32)
@@ -108,9 +122,13 @@ class BranchGradient:
             self._set ^= 1
         idx = np.asarray(self.edges, dtype=np.int32)
         self.b.updateTransitionMatrices(0, self._edge_matrix[self._set], None, None, self.branch_lengths[idx], len(idx))
+        # BeagleDataLikelihoodDelegate.java:863-917: the operations with NONE as the cumulative index, then (rescaling) the
+        # per-node factors reset and accumulated into the cumulative buffer
+        self.b.updatePartials(self._post_ops, len(self._post_ops) // 7, _b.NONE)
         if self.rescale:
             self.b.resetScaleFactors(self.cum_scale)
-        self.b.updatePartials(self._post_ops, len(self._post_ops) // 7, self.cum_scale)
+            idx = self._scale_indices_by_set[self._set]
+            self.b.accumulateScaleFactors(idx, len(idx), self.cum_scale)
         out = [0.0]
         self.b.calculateRootLogLikelihoods([self.post_index(self.tree.root)], [0], [0], [self.cum_scale], 1, out)
         return out[0]

@@ -36,11 +36,17 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
     g = BranchGradient(wl, rescale=rescale)
     o = BranchGradient(wl, rescale=rescale, library=oracle_lib)
     # Sums only.  With 4 states the engine holds the pre-order list back (no scale indices in it: the derivative ratio is scale-
-    # free) and answers from it: without writing a pre-order partial when the post-order partials carry no scale factors (the
-    # list stays held), together with the list otherwise; other state counts go operation by operation.  Same numbers.
+    # free) and answers from it.  The first evaluation of an instance runs the list together with the derivatives (the engine
+    # starts to keep track of which scale factor went into which post-order partial only when a pre-order list has arrived);
+    # from the second one on no pre-order partial is written and the list stays held — with or without rescaling in the
+    # post-order pass.  Other state counts go operation by operation.  Same numbers every way.
+    lo0, go0 = o.gradient()
+    lf0, gf0 = g.gradient()
+    assert helpers.rel_err(lf0, lo0) <= REL_TOL
+    close(gf0, go0, "gradient (first evaluation)")
     lf, gf = g.gradient()
     none = {"fused": 0, "by_operation": 0, "walked": 0, "late": 0}
-    assert g.b.gradientStats() == dict(none, **({"by_operation": 1} if S != 4 else {"fused": 1} if rescale else {"walked": 1}))
+    assert g.b.gradientStats() == dict(none, **({"by_operation": 2} if S != 4 else {"fused": 1, "walked": 1}))
     lo, go, ho, po = o.gradient(second=True, per_pattern=True)
     assert helpers.rel_err(lf, lo) <= REL_TOL
     close(gf, go, "gradient (sums only)")
@@ -49,7 +55,7 @@ def test_gradient_matches_oracle(S, C, T, P, rescale, oracle_lib):
             a, b = g.pre_partials(n).reshape(C, P, S), o.pre_partials(n).reshape(C, P, S)
             ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
             assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
-    assert g.b.gradientStats()["late"] == (1 if S == 4 and not rescale else 0)      # the read made the held list run
+    assert g.b.gradientStats()["late"] == (1 if S == 4 else 0)      # the read made the held list run
     lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
     assert helpers.rel_err(lg, lo) <= REL_TOL
     close(gg, go, "gradient")
@@ -154,20 +160,22 @@ def test_held_back_pre_order_list_is_seen_by_every_other_call(oracle_lib):
         g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
 
     stats = g.b.gradientStats
+    g.gradient()                                                   # (an instance's first evaluation runs its list with the derivatives)
+    assert stats() == {"fused": 1, "by_operation": 0, "walked": 0, "late": 0}
     # 1. a subset of the edges, shuffled: one walk, the list stays held; then all of them, then the second derivatives (with the
     #    sums of squares: the list runs together with that call); every pre-order partial exists afterwards
     prepare()
     pick = np.random.default_rng(1).permutation(n)[: n // 2]
     s1, s1sq, _ = g.b.calculateEdgeDifferentials(post[pick], pre[pick], [g.q_index] * len(pick), [0], len(pick), want_squared=False)
-    assert s1sq is None and stats() == {"fused": 0, "by_operation": 0, "walked": 1, "late": 0}
+    assert s1sq is None and stats() == {"fused": 1, "by_operation": 0, "walked": 1, "late": 0}
     close(s1, go[post[pick]], "subset of the edges")
     s1, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n, want_squared=False)
-    assert stats() == {"fused": 0, "by_operation": 0, "walked": 2, "late": 0}
+    assert stats() == {"fused": 1, "by_operation": 0, "walked": 2, "late": 0}
     close(s1, go[post], "all edges, list still held")
     g.b.setDifferentialMatrix(g.q2_index, g.infinitesimal(2))
     s2, _, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q2_index] * n, [0], n, want_squared=False)
     s1, s1sq, _ = g.b.calculateEdgeDifferentials(post, pre, [g.q_index] * n, [0], n)
-    assert stats() == {"fused": 1, "by_operation": 0, "walked": 3, "late": 0}
+    assert stats() == {"fused": 2, "by_operation": 0, "walked": 3, "late": 0}
     close(s1, go[post], "first derivatives again, with their squares")
     close(s2 - s1sq, ho[post], "second derivatives")
     for node in (int(post[0]), int(post[-1])):
@@ -224,7 +232,9 @@ def test_gradient_chain_with_alternating_buffers(rescale, oracle_lib):
     """What a gradient-driven chain does (HMC over branch lengths): every evaluation writes the OTHER set of post-order
     buffers and branch matrices (BufferIndexHelper), rewrites the root's pre-order partial, sends the same pre-order
     destinations and asks for the sums.  On the engine no held list ever has to run (each is replaced by the next one
-    unexecuted) and no pre-order partial is written until somebody reads one; the numbers are the oracle's throughout."""
+    unexecuted) and no pre-order partial is written until somebody reads one; the numbers are the oracle's throughout.
+    rescale: the post-order pass rescales every node in write mode, every evaluation (new factors every time) — the walk follows
+    them (kernels_preorder4.hip: a step into an internal node multiplies by the reciprocal of that node's factor)."""
     wl = helpers.random_workload(33, 500, 4, 4, seed=31)
     g = BranchGradient(wl, double_buffer=True, rescale=rescale)
     o = BranchGradient(wl, double_buffer=True, rescale=rescale, library=oracle_lib)
@@ -240,14 +250,52 @@ def test_gradient_chain_with_alternating_buffers(rescale, oracle_lib):
         if second:
             close(rg[2], ro[2], "second derivatives, step %d" % step)
     st = g.b.gradientStats()
-    if rescale:
-        assert st == {"fused": steps, "by_operation": 0, "walked": 0, "late": 0}
-    else:
-        # (step 3 asks for the sums of squares: its list runs with that call, and its second derivatives find stored partials)
-        assert st == {"fused": 1, "by_operation": 0, "walked": steps - 1, "late": 0}
+    # (the first step, and step 3, which asks for the sums of squares: the list runs with that call — its second derivatives find
+    # stored partials; every other step: the walk, with the reciprocals of the post-order pass's scale factors when it rescales)
+    assert st == {"fused": 2, "by_operation": 0, "walked": steps - 2, "late": 0}
     for n_ in g.edges[:5]:
         close(g.pre_partials(n_), o.pre_partials(n_), "pre-order partial at the end of the chain")
     g.close(); o.close()
+
+
+def test_gradient_on_a_deep_ladder_with_rescaling(oracle_lib):
+    """A caterpillar of 250 taxa (249 levels), rescaling in the post-order pass: what the pre-order walk carries down the ladder
+    is the pre-order partial times the root's 1 / likelihood times the reciprocal of every scale factor on the way.  Second
+    and third evaluation (the walk) against the oracle (whose unscaled pre-order partials are still inside the double range at
+    this depth — on deeper ladders they are not, while the walk's products shrink and grow together and stay finite); should
+    the walk's sums ever come out non-finite the call goes to the path that forms each edge's denominator itself
+    (engine_preorder.cpp walkedGradient)."""
+    wl = helpers.random_workload(250, 300, 4, 4, seed=8, tree_kind="caterpillar", root_to_tip=0.6)
+    g = BranchGradient(wl, rescale=True, double_buffer=True)
+    o = BranchGradient(wl, rescale=True, double_buffer=True, library=oracle_lib)
+    for step in range(3):
+        lg, gg = g.gradient()
+        lo, go = o.gradient()
+        assert np.isfinite(lo) and np.all(np.isfinite(go)) and helpers.rel_err(lg, lo) <= REL_TOL
+        close(gg, go, "ladder, evaluation %d" % step)
+    assert g.b.gradientStats() == {"fused": 1, "by_operation": 0, "walked": 2, "late": 0}
+    g.close(); o.close()
+
+
+def test_cumulative_index_in_update_partials_equals_accumulate(oracle_lib):
+    """updatePartials' own cumulativeScaleIndex (the factors of the list's rescaling operations folded into that buffer by the
+    call itself — one accumulation launch for the whole list, engine_levels.cpp foldCumulative) against the explicit
+    resetScaleFactors + accumulateScaleFactors the reference's delegates use, and against the oracle."""
+    wl = helpers.random_workload(40, 700, 4, 4, seed=12)
+    vals = []
+    for lib in (None, oracle_lib):
+        g = BranchGradient(wl, rescale=True, library=lib)
+        a = g.log_likelihood()                                    # explicit protocol
+        idx = np.asarray(g.edges, dtype=np.int32)
+        g.b.updateTransitionMatrices(0, g._edge_matrix[g._set], None, None, g.branch_lengths[idx], len(idx))
+        g.b.resetScaleFactors(g.cum_scale)
+        g.b.updatePartials(g._post_ops, len(g._post_ops) // 7, g.cum_scale)
+        out = [0.0]
+        g.b.calculateRootLogLikelihoods([g.post_index(wl.tree.root)], [0], [0], [g.cum_scale], 1, out)
+        vals.append((a, out[0]))
+        g.close()
+    assert helpers.rel_err(vals[0][0], vals[0][1]) <= 1e-13 and helpers.rel_err(vals[0][1], vals[1][1]) <= REL_TOL
+    assert helpers.rel_err(vals[1][0], vals[1][1]) <= 1e-13
 
 
 def test_gradient_benchmark_sized_tree(oracle_lib):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache")
+    ap.add_argument("--rescale", action="store_true", help="the post-order pass rescales every node in write mode, every evaluation")
     args = ap.parse_args()
     import beast_mcmc_amd as bm
     from beast_mcmc_amd.gradient import BranchGradient
@@ -34,7 +35,7 @@ def main():
     wl = synth.cached(os.path.join(args.cache, "config_%s.pkl" % args.config), maker)
     if args.patterns:
         wl = wl.shard(0, min(args.patterns, wl.pattern_count))
-    g = BranchGradient(wl, double_buffer=True)       # the reference's buffer plan: two sets, alternating (BufferIndexHelper)
+    g = BranchGradient(wl, double_buffer=True, rescale=args.rescale)       # the reference's buffer plan: two sets, alternating (BufferIndexHelper)
     for _ in range(args.warmup):
         lnl, grad = g.gradient()
     g.b.synchronize()
@@ -59,7 +60,7 @@ def main():
     extra_bytes = 2 * internal * buf if walked else 2 * internal * buf + (internal + 2 * internal) * buf
     print(json.dumps({"metric": "branch-gradient evals/sec (secondary)", "value": round(1.0 / dt, 3), "ms_per_gradient": round(dt * 1e3, 2),
                       "ms_per_likelihood_same_driver": round(dl * 1e3, 2),
-                      "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
+                      "rescale": bool(args.rescale), "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
                                                                                           wl.state_count, wl.category_count),
                       "gradient_over_likelihood": round(dt / dl, 2),
                       "extra_algorithmic_GB": round(extra_bytes / 1e9, 2), "extra_GBs": round(extra_bytes / max(dt - dl, 1e-9) / 1e9, 1),
