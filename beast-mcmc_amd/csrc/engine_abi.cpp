@@ -472,6 +472,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedSetPerPatternDoubles(instance, inPartials, shardedStates(instance), 1, [&](int h, const double* v) { return beagleSetTipPartials(h, tipIndex, v); }); }
     GET_INSTANCE(instance);
     if (badIndex(tipIndex, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    in->scaleOfPartial[tipIndex] = -1;                     // (caller's data: no scale factor of ours in it)
     int rc = materializeTipUsers(in, tipIndex); if (rc) return rc;
     clearVirtual(in, tipIndex);
     rc = ensurePartials(in, tipIndex); if (rc) return rc;
@@ -847,6 +848,17 @@ int beagleUpdatePartialsByPartition(int instance, const int* operations, int ope
         return mi355::shardedPost(instance, [=](int h) { return beagleUpdatePartialsByPartition(h, ops.data(), operationCount); });
     }
     GET_INSTANCE(instance);
+    if (operations && in->trackScales)                         // (Instance::scaleOfPartial, as beagleUpdatePartials keeps it)
+        for (int k = 0; k < operationCount; k++) {
+            const int* op = operations + (size_t)k * BEAGLE_PARTITION_OP_COUNT;
+            if (badIndex(op[0], in->partialsCount)) continue;
+            const int sIdx = op[1] != BEAGLE_OP_NONE ? op[1] : op[2];
+            if (op[1] != BEAGLE_OP_NONE && !badIndex(op[1], in->scaleCount)) in->scaleVersion[op[1]]++;
+            // (with several partitions a buffer's pattern ranges may carry different factors: unknown to the walk, which is
+            // single-partition anyway)
+            in->scaleOfPartial[op[0]] = in->partitionCount > 1 ? -2 : (sIdx != BEAGLE_OP_NONE && !badIndex(sIdx, in->scaleCount)) ? sIdx : -1;
+            in->scaleVersionAtWrite[op[0]] = in->scaleOfPartial[op[0]] >= 0 ? in->scaleVersion[sIdx] : 0u;
+        }
     return runOperations(in, operations, operationCount, BEAGLE_PARTITION_OP_COUNT, BEAGLE_OP_NONE);
 }
 

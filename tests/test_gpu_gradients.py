@@ -277,6 +277,25 @@ def test_gradient_on_a_deep_ladder_with_rescaling(oracle_lib):
     g.close(); o.close()
 
 
+def test_gradient_with_tips_sent_as_partials(oracle_lib):
+    """A useAmbiguities-style instance (every tip uploaded with setTipPartials): the walks treat such a tip as a memory operand
+    without a scale factor; the second evaluation is answered by the pre-order walk."""
+    wl = helpers.random_workload(30, 400, 4, 2, seed=21)
+    g = BranchGradient(wl, double_buffer=True)
+    o = BranchGradient(wl, double_buffer=True, library=oracle_lib)
+    eye = np.vstack([np.eye(4), np.ones((1, 4))])                  # state 4 = missing: all ones
+    for t in range(wl.tip_count):
+        part = np.ascontiguousarray(eye[wl.tip_states[t]]).ravel()
+        for d in (g, o):
+            d.b.setTipPartials(t, part)
+    for step in range(2):
+        (lg, gg), (lo, go) = g.gradient(), o.gradient()
+        assert helpers.rel_err(lg, lo) <= REL_TOL
+        close(gg, go, "tips as partials, evaluation %d" % step)
+    assert g.b.gradientStats() == {"fused": 1, "by_operation": 0, "walked": 1, "late": 0}
+    g.close(); o.close()
+
+
 def test_cumulative_index_in_update_partials_equals_accumulate(oracle_lib):
     """updatePartials' own cumulativeScaleIndex (the factors of the list's rescaling operations folded into that buffer by the
     call itself — one accumulation launch for the whole list, engine_levels.cpp foldCumulative) against the explicit
