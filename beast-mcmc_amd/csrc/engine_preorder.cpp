@@ -417,7 +417,7 @@ static int fusedGradient(Instance* in, const std::vector<int>& edgeOf, const int
 // The sums alone, nothing written (k_preWalk4): the list STAYS held.  1 = this list / instance cannot be walked.
 static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const int* dIdx, int wIdx, int count, double* outSum) {
     const Instance::HeldPreList& h = in->heldPre;
-    if (!in->preWalk || h.holdSlots > mi355::PW_MAX_HOLD || in->C > 16) return 1;
+    if (!in->preWalk || !in->walk || h.holdSlots > mi355::PW_MAX_HOLD || in->C > 16) return 1;     // (walk instances: reciprocal scale arrays, dummies)
     { int rcd = ensureWalkDummies(in); if (rcd) return rcd; }              // (the all-ones reciprocal array)
     const int waves = mi355::preWalkWaves(in->P, in->C);
     const size_t sumBytes = (size_t)(count + 1) * waves * sizeof(double), outBytes = (size_t)count * sizeof(double);
