@@ -59,6 +59,11 @@ class BranchGradient:
         e = np.asarray(self.edges, dtype=np.int32)
         self._edge_post = [np.asarray([self.post_index(n, v) for n in self.edges], dtype=np.int32) for v in sets]
         self._edge_matrix = [e + v * self._matrix_set for v in sets]
+        self._nodes = e
+        self._pre_idx = e + self.pre_offset
+        self._q1_idx = np.full(len(e), self.q_index, dtype=np.int32)
+        self._q2_idx = np.full(len(e), self.q2_index, dtype=np.int32)
+        self._w0 = np.zeros(1, dtype=np.int32)
         self._scale_indices_by_set = [np.asarray([self.scale_index(n, v) for n in range(self.T, self.N)], dtype=np.int32) for v in sets]
 
     def post_index(self, node, which=None):
@@ -120,7 +125,7 @@ class BranchGradient:
     def log_likelihood(self):
         if self.double_buffer:
             self._set ^= 1
-        idx = np.asarray(self.edges, dtype=np.int32)
+        idx = self._nodes
         self.b.updateTransitionMatrices(0, self._edge_matrix[self._set], None, None, self.branch_lengths[idx], len(idx))
         # BeagleDataLikelihoodDelegate.java:863-917: the operations with NONE as the cumulative index, then (rescaling) the
         # per-node factors reset and accumulated into the cumulative buffer
@@ -150,19 +155,17 @@ class BranchGradient:
         self.b.setPartials(self.pre_offset + self.tree.root, self._root_pre)
         self.b.updatePrePartials(self._pre_ops, len(self._pre_ops) // 7, _b.NONE)
         self.b.setDifferentialMatrix(self.q_index, self.infinitesimal(1))
-        nodes = np.asarray(self.edges, dtype=np.int32)
-        post = self._edge_post[self._set]
-        pre = nodes + self.pre_offset
+        nodes, post, pre = self._nodes, self._edge_post[self._set], self._pre_idx
         n = len(post)
         # (firstSquared is only asked for when the second derivatives are: AbstractBeagleBranchGradientDelegate.java:80-84)
-        s1, s1sq, per = self.b.calculateEdgeDifferentials(post, pre, [self.q_index] * n, [0], n, want_per_pattern=per_pattern,
+        s1, s1sq, per = self.b.calculateEdgeDifferentials(post, pre, self._q1_idx, self._w0, n, want_per_pattern=per_pattern,
                                                           want_squared=second)
         grad = np.zeros(self.N)
         grad[nodes] = s1
         result = [lnl, grad]
         if second:
             self.b.setDifferentialMatrix(self.q2_index, self.infinitesimal(2))
-            s2, _, _ = self.b.calculateEdgeDifferentials(post, pre, [self.q2_index] * n, [0], n, want_squared=False)
+            s2, _, _ = self.b.calculateEdgeDifferentials(post, pre, self._q2_idx, self._w0, n, want_squared=False)
             hess = np.zeros(self.N)
             hess[nodes] = s2 - s1sq
             result.append(hess)
