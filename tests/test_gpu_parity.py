@@ -33,6 +33,31 @@ def assert_parity(g, o, what=""):
     return a, b
 
 
+def test_small_and_ragged_shapes_on_the_walks(oracle_lib):
+    """The corner shapes of the two pattern walks in one sweep — 4 states (kernels_walk4.hip) and 16..20 states on the T32 layout
+    (kernels_mfma.hip k_walkT32): a single pattern, one pattern short of / past a tile and a workgroup, two taxa (one
+    operation), one and sixteen rate categories, with and without rescaling, a second evaluation after a branch move on top
+    (read mode, unstored nodes, the plan cache)."""
+    from beast_mcmc_amd.treelikelihood import RESCALE_DYNAMIC
+    checked = 0
+    for S in (4, 16, 17, 19, 20):
+        for C in (1, 3, 16):
+            for T, P in ((2, 1), (2, 4), (3, 15), (5, 33), (9, 64), (9, 127), (14, 129)) + (((2, 33), (3, 31)) if S >= 16 else ()):
+                if S != 4 and C == 16 and P > 64:
+                    continue                                   # (keeps the sweep short: the 16-category workgroups are covered at small P)
+                wl = helpers.random_workload(T, P, S, C, seed=1000 + 31 * S + 7 * C + T + P)
+                for scheme in (RESCALE_NONE, RESCALE_DYNAMIC):
+                    g, o = both(wl, oracle_lib, rescaling=scheme, delay_rescaling=False)
+                    assert_parity(g, o, "S=%d C=%d T=%d P=%d scheme=%s" % (S, C, T, P, scheme))
+                    rates = np.linspace(0.7, 1.4, wl.tree.node_count)
+                    for t in (g, o):
+                        t.storeState(); t.set_branch_rates(rates)
+                    assert_parity(g, o, "S=%d C=%d T=%d P=%d scheme=%s, after a move" % (S, C, T, P, scheme))
+                    g.close(); o.close()
+                    checked += 1
+    assert checked >= 170
+
+
 # ---- the reference's golden vectors, through the HIP engine -----------------------------------
 
 @pytest.mark.parametrize("case", PRIMATES["tree_data_likelihood_test"], ids=lambda c: c["name"])
