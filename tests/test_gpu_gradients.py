@@ -277,6 +277,30 @@ def test_gradient_on_a_deep_ladder_with_rescaling(oracle_lib):
     g.close(); o.close()
 
 
+def test_gradient_corner_shapes(oracle_lib):
+    """The pre-order walk (second evaluation of every instance) and the sweep per level (first evaluation) over corner shapes:
+    two taxa (a list of one node), a single pattern, ragged pattern counts, 1 .. 16 rate categories (the walk's 256-, 512- and
+    1024-thread instantiations), with and without rescaling in the post-order pass."""
+    checked = 0
+    for C in (1, 3, 5, 8, 11, 16):
+        for T, P in ((2, 1), (3, 15), (5, 33), (9, 64), (14, 129), (40, 700)):
+            if C > 8 and P > 200:
+                continue
+            wl = helpers.random_workload(T, P, 4, C, seed=500 + 13 * C + T)
+            for rescale in (False, True):
+                g = BranchGradient(wl, rescale=rescale, double_buffer=True)
+                o = BranchGradient(wl, rescale=rescale, double_buffer=True, library=oracle_lib)
+                for step in range(2):
+                    (lg, gg), (lo, go) = g.gradient(), o.gradient()
+                    assert helpers.rel_err(lg, lo) <= REL_TOL, (C, T, P, rescale, step)
+                    close(gg, go, "C=%d T=%d P=%d rescale=%s evaluation %d" % (C, T, P, rescale, step))
+                st = g.b.gradientStats()                          # (two taxa: no internal operand whose scale factor could be unknown — walked twice)
+                assert st == {"fused": 0 if T == 2 else 1, "by_operation": 0, "walked": 2 if T == 2 else 1, "late": 0}, (C, T, P, rescale)
+                g.close(); o.close()
+                checked += 1
+    assert checked >= 60
+
+
 def test_gradient_with_tips_sent_as_partials(oracle_lib):
     """A useAmbiguities-style instance (every tip uploaded with setTipPartials): the walks treat such a tip as a memory operand
     without a scale factor; the second evaluation is answered by the pre-order walk."""
