@@ -453,10 +453,51 @@ __global__ __launch_bounds__(256) void k_accumulate(double* __restrict__ cum, co
     cum[p] += sign * (logs + (log(mant) + (double)expo * 0.69314718055994530942));
 }
 
+// The same for a long list of buffers (a whole tree's factors into the cumulative buffer: 999 for config A).  One thread per
+// pattern walking 999 buffers is a chain of dependent-latency loads on a handful of workgroups — 250 us whatever the pattern
+// count.  Here a workgroup is 64 patterns x 16 waves; wave j takes buffers j, j + 16, ...; the sixteen partial sums of logs
+// meet in LDS and are added in wave order (fixed: deterministic).
+constexpr int ACC_CHUNKS = 16;
+__global__ __launch_bounds__(64 * ACC_CHUNKS) void k_accumulateWide(double* __restrict__ cum, const double* const* __restrict__ srcs,
+                                                                    const int* __restrict__ raw, int count, double sign, int pStart, int pEnd) {
+    __shared__ double part[ACC_CHUNKS][64];
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int p = pStart + blockIdx.x * 64 + lane;
+    const bool valid = p < pEnd;
+    const int q = valid ? p : pEnd - 1;
+    double logs = 0.0, mant = 1.0;
+    long expo = 0;
+    int taken = 0;
+    for (int k = j; k < count; k += ACC_CHUNKS) {
+        const double v = gptr(srcs[k])[q];
+        if (!raw[k]) { logs += v; continue; }
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const int field = (int)((bits >> 52) & 0x7ffull);
+        if (field == 0 || field == 0x7ff || (long long)bits < 0) { logs += log(v); continue; }
+        mant *= __longlong_as_double((long long)((bits & 0x800fffffffffffffull) | 0x3fe0000000000000ull));
+        expo += field - 1022;
+        if ((++taken & 255) == 0) {
+            const unsigned long long mb = (unsigned long long)__double_as_longlong(mant);
+            expo += (int)((mb >> 52) & 0x7ffull) - 1022;
+            mant = __longlong_as_double((long long)((mb & 0x800fffffffffffffull) | 0x3fe0000000000000ull));
+        }
+    }
+    part[j][lane] = logs + (log(mant) + (double)expo * 0.69314718055994530942);
+    __syncthreads();
+    if (j == 0 && valid) {
+        double t = 0.0;
+        for (int c = 0; c < ACC_CHUNKS; c++) t += part[c][lane];
+        cum[p] += sign * t;
+    }
+}
+
 void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
                            int count, double sign, int pStart, int pEnd) {
     if (count <= 0 || pEnd <= pStart) return;
-    hipLaunchKernelGGL(k_accumulate, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, cum, dSrcs, dRaw, count, sign, pStart, pEnd);
+    if (count >= 4 * ACC_CHUNKS)
+        hipLaunchKernelGGL(k_accumulateWide, dim3((pEnd - pStart + 63) / 64), dim3(64 * ACC_CHUNKS), 0, stream, cum, dSrcs, dRaw, count, sign, pStart, pEnd);
+    else
+        hipLaunchKernelGGL(k_accumulate, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, cum, dSrcs, dRaw, count, sign, pStart, pEnd);
 }
 
 __global__ void k_fill(double* dst, double value, int pStart, int pEnd) {
