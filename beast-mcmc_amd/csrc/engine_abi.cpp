@@ -390,8 +390,10 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     in->partitionCount = partitionCount; in->partStart = s; in->partEnd = e; in->resolveEpoch++;
     // (the T32 walk needs no layout change: a tile that straddles two partitions is walked once per partition, each walk storing
     // only its own patterns — kernels_mfma.hip k_walkT32 masks by the segment's range)
-    if (in->walk || in->walkT) in->planner.setPartitionCount(partitionCount);
-    if ((in->walk || in->walkT) && in->virt) {
+    // (every instance whose planner is in use: its tables are keyed by (buffer, partition) — the level kernels' cherry instances
+    // too, although they define nothing while there are several partitions)
+    if (in->walk || in->walkT || in->virt) in->planner.setPartitionCount(partitionCount);
+    if (in->virt) {
         // definitions are kept per (buffer, partition): more snapshot slots behind the caller's matrices
         const size_t per = (size_t)in->C * in->S * in->S, slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());
         double* grown = nullptr;
