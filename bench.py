@@ -124,6 +124,12 @@ def main():
     if args.selftest_launcher:
         return selftest_launcher(args)
 
+    # stdout carries ONE line, the JSON line: everything else that writes to file descriptor 1 in this process — RCCL's version
+    # banner at communicator creation is C stdio — goes to stderr from here on, and the line is written to the real stdout last
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import beast_mcmc_amd as bm
@@ -204,8 +210,9 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:                       # noqa: BLE001
         pass
+    sys.stdout.flush()
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     return out
 
 
