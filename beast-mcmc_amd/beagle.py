@@ -123,7 +123,8 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
-               "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned"]
+               "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
+               "beagleMi355KernelTimerCalls", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -434,12 +435,37 @@ class Beagle:
     def synchronize(self):
         self._check("synchronize", self._ext("beagleMi355Synchronize", [C.c_int])(self.instance))
 
+    # one process per GPU: the collective inside the engine (include/beagle_mi355.h)
+    def commUniqueId(self):
+        """128 bytes that identify a new communicator; produced on ONE rank and handed to all (any channel)."""
+        buf = C.create_string_buffer(128)
+        self._check("getCommUniqueId", self._ext("beagleMi355GetCommUniqueId", [C.c_void_p])(buf))
+        return buf.raw
+
+    def commInit(self, unique_id, rank, rank_count):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check("commInit", self._ext("beagleMi355CommInit", [C.c_int, C.c_void_p, C.c_int, C.c_int])(self.instance, buf, rank, rank_count))
+
+    def calculateRootLogLikelihoodsAllReduce(self, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex):
+        out = C.c_double(0.0)
+        f = self._ext("beagleMi355CalculateRootLogLikelihoodsAllReduce", [C.c_int] * 5 + [C.POINTER(C.c_double)])
+        rc = f(self.instance, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, C.byref(out))
+        if rc not in (0, -8):
+            self._check("calculateRootLogLikelihoodsAllReduce", rc)
+        return out.value
+
     def kernelTimer(self, enable):
         ms = C.c_double(0.0)
         n = C.c_long(0)
         f = self._ext("beagleMi355KernelTimer", [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)])
         self._check("kernelTimer", f(self.instance, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernelTimerCalls(self):
+        """updatePartials calls the kernel timer bracketed since this was last asked (kernelTimer(N > 1) samples every N-th)."""
+        n = C.c_long(0)
+        self._check("kernelTimerCalls", self._ext("beagleMi355KernelTimerCalls", [C.c_int, C.POINTER(C.c_long)])(self.instance, C.byref(n)))
+        return n.value
 
     def getPartialsBatch(self, bufferIndices, scaleIndices=None):
         """-> [count][C][P][S]: several buffers in one call (include/beagle_mi355.h beagleMi355GetPartialsBatch)."""

@@ -27,7 +27,7 @@ int accumulate(Instance* in, const int* idx, int count, int cum, double sign, in
         void *dSrc = nullptr, *dRaw = nullptr;
         rc = uploadTransient(in, &srcs[b], (size_t)n * sizeof(double*), &dSrc); if (rc) return rc;
         rc = uploadTransient(in, &raw[b], (size_t)n * sizeof(int), &dRaw); if (rc) return rc;
-        mi355::launchAccumulateScale(in->stream, in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, n, sign,
+        mi355::launchAccumulateScale(live(in), in->scale[cum], (const double* const*)dSrc, (const int*)dRaw, n, sign,
                                      in->partStart[part], in->partEnd[part]);
     }
     HIP_TRY(hipGetLastError());
@@ -43,7 +43,7 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         badIndex(fIdx, in->eigenCount) || (part >= 0 && badIndex(part, in->partitionCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
     const int pStart = part < 0 ? 0 : in->partStart[part], pEnd = part < 0 ? in->P : in->partEnd[part];
     if (pEnd <= pStart) {                                 // an empty partition (a shard that holds none of its patterns) contributes 0
-        HIP_TRY(hipMemsetAsync(dOut, 0, sizeof(double), in->stream));
+        HIP_TRY(hipMemsetAsync(dOut, 0, sizeof(double), live(in)));
         return 0;
     }
     const double* cum = nullptr; int cumRaw = 0;
@@ -53,17 +53,50 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         cum = in->scale[cumIdx]; cumRaw = in->scaleIsRaw[cumIdx];
     }
     if (in->tiled) {
-        mi355::launchRootSiteTiled(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+        mi355::launchRootSiteTiled(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                    in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
                                    in->blockSums, in->P, in->S, in->C, pStart, pEnd);
-        mi355::launchRootFinal(in->stream, in->blockSums, (pEnd - pStart + 255) / 256, dOut, flag, seq);
+        mi355::launchRootFinal(live(in), in->blockSums, (pEnd - pStart + 255) / 256, dOut, flag, seq);
     } else {
-        mi355::launchRootLogLikelihood(in->stream, in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+        mi355::launchRootLogLikelihood(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                        in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
                                        in->blockSums, dOut, in->P, in->S, in->C, pStart, pEnd, flag, seq, in->fuseLaunches ? in->rootCounter : nullptr);
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// The last reduction kernel of a call writes its result and then `seq` into mapped host memory (Instance::hResult); the kernel
+// is the last thing in the (in-order) stream, so seeing the number means everything before it has completed.  Polled — a stream
+// synchronisation costs a wake-up per evaluation — for 20 ms, then blocking (a long evaluation, another rank's, or an error).
+int waitResult(Instance* in, unsigned long long seq) {
+    volatile unsigned long long* flag = (volatile unsigned long long*)(in->hResult + 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    if (*flag != seq) HIP_TRY(hipStreamSynchronize(live(in)));
+    if (*flag != seq) return BEAGLE_ERROR_GENERAL;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (in->asyncError) { const int rc = in->asyncError; in->asyncError = 0; return rc; }
+    return 0;
+}
+
+// Matrix slots of an instance: the caller's, the planner's private snapshot slots behind them and — T32 layout — one identity
+// matrix and PRE_SCRATCH transposed-matrix slots behind those (the two-pass pre-order path, engine_preorder.cpp).  Sets
+// preIdentity / preTransposed; used at creation and whenever the planner's slot count changes (beagleSetPatternPartitions).
+size_t matrixSlotLayout(Instance* in) {
+    size_t slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());
+    if (in->tiled) { in->preIdentity = (int)slots; in->preTransposed = (int)slots + 1; slots += 1 + PRE_SCRATCH; }
+    return slots;
+}
+int uploadIdentityMatrix(Instance* in) {
+    const size_t S = in->S, C = in->C;
+    std::vector<double> eye(C * S * S, 0.0);
+    for (size_t c = 0; c < C; c++) for (size_t i = 0; i < S; i++) eye[c * S * S + i * S + i] = 1.0;
+    return upload(in, in->matrices + (size_t)in->preIdentity * C * S * S, eye.data(), eye.size() * sizeof(double));
 }
 
 // API layout double[C][P][S]  <->  T32 layout double[C][tile][S][32] (kernels_mfma.hip); padded patterns are zero
@@ -275,8 +308,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->preWalk = !(getenv("BEAGLE_MI355_NO_PRE_WALK") && atoi(getenv("BEAGLE_MI355_NO_PRE_WALK")) != 0);
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
-    size_t matrixSlots = std::max<size_t>(std::max<size_t>(1, matrixBufferCount), (size_t)in->planner.matrixSlots());
-    if (in->tiled) { in->preIdentity = (int)matrixSlots; in->preTransposed = (int)matrixSlots + 1; matrixSlots += 1 + PRE_SCRATCH; }
+    const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
     in->partialsBytes = (((size_t)categoryCount * patternSlots * stateCount * sizeof(double)) + 255 + (in->walk ? 256 : 0)) & ~(size_t)255;
     in->partials.assign(partialsBufferCount, nullptr);
@@ -293,7 +325,12 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
 
     bool ok = hipStreamCreateWithFlags(&in->ownStream, hipStreamNonBlocking) == hipSuccess;
     in->stream = in->ownStream;
-    ok = ok && hipHostMalloc((void**)&in->hRing, RING_BYTES, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&in->hRing, RING_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
+    in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
+    in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
+    if (in->walk && in->fuseWaves && in->fastWalk)
+        in->planner.chunkTopOps = getenv("BEAGLE_MI355_CHUNK_TOP") ? atoi(getenv("BEAGLE_MI355_CHUNK_TOP")) : 0;
     // result words live in coherent, device-mapped host memory: the final reduction kernel writes the sum straight into it
     // and the host only waits for the stream (no device-to-host copy behind the last kernel)
     ok = ok && hipHostMalloc((void**)&in->hResult, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -318,13 +355,9 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         ok = ok && upload(in, in->patternWeights, ones.data(), (size_t)patternCount * sizeof(double)) == 0;
         std::vector<double> w(E * C, 1.0 / (double)C);
         ok = ok && upload(in, in->weights, w.data(), E * C * sizeof(double)) == 0;
-        ok = ok && hipMemsetAsync(in->matrices, 0, matrixSlots * C * S * S * sizeof(double), in->stream) == hipSuccess;
-        ok = ok && hipMemsetAsync(in->siteLogL, 0, (size_t)patternCount * sizeof(double), in->stream) == hipSuccess;
-        if (ok && in->tiled) {   // identity matrix for the two-pass pre-order path
-            std::vector<double> eye(C * S * S, 0.0);
-            for (size_t c = 0; c < C; c++) for (size_t i = 0; i < S; i++) eye[c * S * S + i * S + i] = 1.0;
-            ok = upload(in, in->matrices + (size_t)in->preIdentity * C * S * S, eye.data(), eye.size() * sizeof(double)) == 0;
-        }
+        ok = ok && hipMemsetAsync(in->matrices, 0, matrixSlots * C * S * S * sizeof(double), live(in)) == hipSuccess;
+        ok = ok && hipMemsetAsync(in->siteLogL, 0, (size_t)patternCount * sizeof(double), live(in)) == hipSuccess;
+        if (ok && in->tiled) ok = uploadIdentityMatrix(in) == 0;   // for the two-pass pre-order path
     }
     if (!ok) { destroy(in); return BEAGLE_ERROR_OUT_OF_MEMORY; }
 
@@ -395,19 +428,22 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     if (in->walk || in->walkT || in->virt) in->planner.setPartitionCount(partitionCount);
     if (in->virt) {
         // definitions are kept per (buffer, partition): more snapshot slots behind the caller's matrices
-        const size_t per = (size_t)in->C * in->S * in->S, slots = std::max<size_t>(std::max<size_t>(1, in->matrixCount), (size_t)in->planner.matrixSlots());
+        // (T32 instances keep an identity matrix and the transposed-matrix scratch of the two-pass pre-order path BEHIND the
+        // snapshot slots — matrixSlotLayout, as at creation: they move with the block and the identity is sent again)
+        const size_t per = (size_t)in->C * in->S * in->S, slots = matrixSlotLayout(in);
         double* grown = nullptr;
         int rcm = devAlloc(in, (void**)&grown, slots * per * sizeof(double)); if (rcm) return rcm;
-        HIP_TRY(hipMemsetAsync(grown, 0, slots * per * sizeof(double), in->stream));
-        HIP_TRY(hipMemcpyAsync(grown, in->matrices, (size_t)std::max(1, in->matrixCount) * per * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+        HIP_TRY(hipMemsetAsync(grown, 0, slots * per * sizeof(double), live(in)));
+        HIP_TRY(hipMemcpyAsync(grown, in->matrices, (size_t)std::max(1, in->matrixCount) * per * sizeof(double), hipMemcpyDeviceToDevice, live(in)));
         in->matrices = grown;                              // (the old block stays owned by the instance until it is destroyed)
+        if (in->tiled) { int rci = uploadIdentityMatrix(in); if (rci) return rci; }
     }
     if (in->walk) {
         // the pair-interleaved arrays follow the partitions (Instance::pairPos): what exists already — tips are uploaded before
         // this call, MultiPartitionDataLikelihoodDelegate.java:544-553 — moves to the new layout on the device
         setPairLayout(in);
         if (!in->dPairPos) { int rc = devAlloc(in, (void**)&in->dPairPos, (size_t)in->P * sizeof(unsigned)); if (rc) return rc; }
-        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipStreamSynchronize(live(in)));
         HIP_TRY(hipMemcpy(in->dPairPos, in->pairPos.data(), (size_t)in->P * sizeof(unsigned), hipMemcpyHostToDevice));
         in->stateSlabLeft = 0; in->scaleSlabLeft = 0;                      // new slabs: the element sizes changed
         for (int t = 0; t < in->partialsCount; t++) {
@@ -415,8 +451,8 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
             if (!old) continue;
             in->tipStates[t] = nullptr;
             int rc = ensureStates(in, t); if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(in->tipStates[t] + in->statePairOff, in->S, in->pairLen, in->stream));
-            mi355::launchRelayoutStates(in->stream, old, in->tipStates[t], in->tipStates[t] + in->statePairOff, in->dPairPos, in->P);
+            HIP_TRY(hipMemsetAsync(in->tipStates[t] + in->statePairOff, in->S, in->pairLen, live(in)));
+            mi355::launchRelayoutStates(live(in), old, in->tipStates[t], in->tipStates[t] + in->statePairOff, in->dPairPos, in->P);
         }
         for (int k = 0; k < (int)in->scale.size(); k++) {
             double* old = in->scale[k];
@@ -425,8 +461,8 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
             in->scale[k] = nullptr;
             int rc = ensureScale(in, k); if (rc) return rc;                // (zero-filled)
             in->scaleIsRaw[k] = raw;
-            HIP_TRY(hipMemcpyAsync(in->scale[k], old, (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
-            if (raw) mi355::launchRecipFromFactors(in->stream, in->scale[k], in->scale[k] + in->scaleStride, in->dPairPos, in->P);
+            HIP_TRY(hipMemcpyAsync(in->scale[k], old, (size_t)in->P * sizeof(double), hipMemcpyDeviceToDevice, live(in)));
+            if (raw) mi355::launchRecipFromFactors(live(in), in->scale[k], in->scale[k] + in->scaleStride, in->dPairPos, in->P);
         }
         in->dummyTips = nullptr; in->onesScale = nullptr;                  // re-made at their new sizes on first use
         HIP_TRY(hipGetLastError());
@@ -490,7 +526,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials) {
         // upload one category plane to the LAST plane, replicate it into all planes on the device
         double* last = in->partials[tipIndex] + (size_t)(in->C - 1) * in->P * in->S;
         rc = upload(in, last, inPartials, n);
-        if (!rc) mi355::launchReplicateCategories(in->stream, last, in->partials[tipIndex], in->P, in->S, in->C - 1);
+        if (!rc) mi355::launchReplicateCategories(live(in), last, in->partials[tipIndex], in->P, in->S, in->C - 1);
     }
     in->tipStates[tipIndex] = nullptr;   // the buffer now holds partials (slab memory stays owned by the instance)
     setCompact(in, tipIndex, false);
@@ -555,7 +591,7 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
     const size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)32 << 20) / bytes));
     if (!out && (size_t)count > chunk) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (in->exportBytes < chunk * bytes) {
-        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipStreamSynchronize(live(in)));
         for (int k = 0; k < 2; k++) {
             if (in->exportDev[k]) hipFree(in->exportDev[k]);
             if (in->exportHost[k]) hipHostFree(in->exportHost[k]);
@@ -584,10 +620,10 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
                 int rc = ensureScale(in, scaleIndices[c * chunk + k]); if (rc) return rc;
                 sc = in->scale[scaleIndices[c * chunk + k]]; raw = in->scaleIsRaw[scaleIndices[c * chunk + k]];
             }
-            mi355::launchExportPartials(in->stream, in->partials[b], sc, raw, in->exportDev[w] + k * elems, in->P, in->S, in->C, in->tiled);
+            mi355::launchExportPartials(live(in), in->partials[b], sc, raw, in->exportDev[w] + k * elems, in->P, in->S, in->C, in->tiled);
         }
-        HIP_TRY(hipMemcpyAsync(in->exportHost[w], in->exportDev[w], n * bytes, hipMemcpyDeviceToHost, in->stream));
-        HIP_TRY(hipEventRecord(in->exportEvent[w], in->stream));
+        HIP_TRY(hipMemcpyAsync(in->exportHost[w], in->exportDev[w], n * bytes, hipMemcpyDeviceToHost, live(in)));
+        HIP_TRY(hipEventRecord(in->exportEvent[w], live(in)));
         if (c >= 1 && out) {                               // chunk c - 1 has landed (or lands while this one is being produced)
             HIP_TRY(hipEventSynchronize(in->exportEvent[1 - w]));
             copies[1 - w].start((char*)(out + (c - 1) * chunk * elems), (const char*)in->exportHost[1 - w], chunkCount(c - 1) * bytes);
@@ -595,7 +631,7 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
     }
     const int last = (int)((nChunks - 1) & 1);
     HIP_TRY(hipEventSynchronize(in->exportEvent[last]));
-    in->ringHead = 0;
+    if (in->pendingCopies.empty()) in->ringHead = 0;
     if (out) copies[last].start((char*)(out + (nChunks - 1) * chunk * elems), (const char*)in->exportHost[last], chunkCount(nChunks - 1) * bytes);
     copies[0].join(); copies[1].join();
     return BEAGLE_SUCCESS;
@@ -640,8 +676,8 @@ int beagleMi355GetSiteLogLikelihoodsPinned(int instance, const double** outPinne
     if (!outPinned || !outCount) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t bytes = (size_t)in->P * sizeof(double);
     if (bytes > RING_BYTES) return BEAGLE_ERROR_NO_IMPLEMENTATION;
-    HIP_TRY(hipMemcpyAsync(in->hRing, in->siteLogL, bytes, hipMemcpyDeviceToHost, in->stream));     // (the ring is pinned; everything staged in it
-    HIP_TRY(hipStreamSynchronize(in->stream));                                                      //  has been consumed once the stream is idle)
+    HIP_TRY(hipMemcpyAsync(in->hRing, in->siteLogL, bytes, hipMemcpyDeviceToHost, live(in)));     // (the ring is pinned; everything staged in it
+    HIP_TRY(hipStreamSynchronize(live(in)));                                                      //  has been consumed once the stream is idle)
     in->ringHead = (bytes + 255) & ~(size_t)255;
     *outPinned = (const double*)in->hRing; *outCount = in->P;
     return BEAGLE_SUCCESS;
@@ -753,7 +789,7 @@ int beagleConvolveTransitionMatrices(int instance, const int* first, const int* 
         int rc = uploadTransient(in, first + b, n * sizeof(int), &dF); if (rc) return rc;
         rc = uploadTransient(in, second + b, n * sizeof(int), &dS); if (rc) return rc;
         rc = uploadTransient(in, result + b, n * sizeof(int), &dR); if (rc) return rc;
-        mi355::launchConvolveMatrices(in->stream, in->matrices, (const int*)dF, (const int*)dS, (const int*)dR, n, in->S, in->C);
+        mi355::launchConvolveMatrices(live(in), in->matrices, (const int*)dF, (const int*)dS, (const int*)dR, n, in->S, in->C);
         b = e;
     }
     HIP_TRY(hipGetLastError());
@@ -782,7 +818,7 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
     int rc = uploadTransient(in, pack.data(), pack.size(), &dPack); if (rc) return rc;
     const double* dLen = (const double*)dPack;
     const int* dIdx = (const int*)((const char*)dPack + (size_t)count * sizeof(double));
-    mi355::launchTransitionMatrices(in->stream, in->matrices, in->eigen, in->rates, dIdx, dLen,
+    mi355::launchTransitionMatrices(live(in), in->matrices, in->eigen, in->rates, dIdx, dLen,
                                     dIdx + count, dIdx + 2 * (size_t)count, count, in->S, in->C, in->eigenComplex);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
@@ -868,8 +904,8 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleWaitForPartials(h, destinationPartials, count); }); }
     (void)destinationPartials; (void)count;
     GET_INSTANCE(instance);
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->pendingCopies.empty()) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -907,11 +943,11 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
     if (in->scaleIsRaw[cumulativeScaleIndex] && in->partitionCount > 1) {
         // a per-node (raw) buffer is being recycled as a cumulative one: clear all of it first
-        mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
+        mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     }
     if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;    // kept programs were validated against the raw flags
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
-    mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, in->partStart[partitionIndex], in->partEnd[partitionIndex]);
+    mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, in->partStart[partitionIndex], in->partEnd[partitionIndex]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -924,7 +960,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
     if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
-    mi355::launchFill(in->stream, in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
+    mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -938,7 +974,7 @@ int beagleCopyScaleFactors(int instance, int dest, int src) {
     rc = ensureScale(in, dest); if (rc) return rc;
     rc = ensureScale(in, src); if (rc) return rc;
     const size_t scaleDoubles = in->walk ? 2 * in->scaleStride : (size_t)in->P;      // walk instances: factors and reciprocals
-    HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], scaleDoubles * sizeof(double), hipMemcpyDeviceToDevice, in->stream));
+    HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], scaleDoubles * sizeof(double), hipMemcpyDeviceToDevice, live(in)));
     if (in->scaleIsRaw[dest] != in->scaleIsRaw[src]) in->resolveEpoch++;
     in->scaleIsRaw[dest] = in->scaleIsRaw[src];
     return BEAGLE_SUCCESS;
@@ -963,19 +999,8 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
     int rc = rootEnqueue(in, bufferIndices[0], categoryWeightsIndices[0], stateFrequenciesIndices[0],
                          cumulativeScaleIndices[0], -1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     if (rc) return rc;
-    {
-        volatile unsigned long long* flag = (volatile unsigned long long*)(in->hResult + 8);
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (*flag != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-        }
-        if (*flag != seq) HIP_TRY(hipStreamSynchronize(in->stream));     // long evaluation (or an error): block instead of spinning
-        if (*flag != seq) return BEAGLE_ERROR_GENERAL;
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    in->ringHead = 0;   // everything staged so far has been consumed
+    { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
+    if (in->pendingCopies.empty()) in->ringHead = 0;   // everything staged so far has been consumed
     const double v = in->hResult[0];
     *outSumLogLikelihood = v;
     return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
@@ -1022,7 +1047,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
         const unsigned long long seq = ++in->resultSeq;
         for (size_t c = 0; c < chunks.size(); c++) {
             const bool last = c + 1 == chunks.size();
-            mi355::launchRootLogLikelihoodParts(in->stream, chunks[c], in->patternWeights, in->siteLogL, in->blockSums,
+            mi355::launchRootLogLikelihoodParts(live(in), chunks[c], in->patternWeights, in->siteLogL, in->blockSums,
                                                 in->hResultDev + 16 + c * mi355::ROOT_MAX_PARTS, in->P, in->S, in->C,
                                                 last ? (unsigned long long*)(in->hResultDev + 8) : nullptr, seq);
         }
@@ -1034,10 +1059,10 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
             __builtin_ia32_pause();
             if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
-        if (*flag != seq) HIP_TRY(hipStreamSynchronize(in->stream));
+        if (*flag != seq) HIP_TRY(hipStreamSynchronize(live(in)));
         if (*flag != seq) return BEAGLE_ERROR_GENERAL;
         std::atomic_thread_fence(std::memory_order_acquire);
-        in->ringHead = 0;
+        if (in->pendingCopies.empty()) in->ringHead = 0;
         double tot = 0.0;
         for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[16 + k]; tot += in->hResult[16 + k]; }
         *outSum = tot;
@@ -1074,7 +1099,7 @@ int beagleSetRootPrePartials(int instance, const int* bufferIndices, const int* 
         clearVirtual(in, b);
         rc = ensurePartials(in, b); if (rc) return rc;
         in->tipStates[b] = nullptr; setCompact(in, b, false);
-        mi355::launchFillFrequencies(in->stream, in->partials[b], in->freqs + (size_t)f * in->S, in->P, in->S, in->C, in->tiled);
+        mi355::launchFillFrequencies(live(in), in->partials[b], in->freqs + (size_t)f * in->S, in->P, in->S, in->C, in->tiled);
     }
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
@@ -1098,7 +1123,7 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
     }
     void* dPairs = nullptr;
     int rc = uploadTransient(in, pairs.data(), pairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-    mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, matrixCount, in->S, in->C);
+    mi355::launchTransposeMatrices(live(in), in->matrices, (const int*)dPairs, matrixCount, in->S, in->C);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -1167,8 +1192,8 @@ int beagleUpdatePrePartialsByPartition(int, const int*, int) { return BEAGLE_ERR
 int beagleMi355SetStream(int instance, void* hipStream) {
     if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
     GET_INSTANCE(instance);
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->pendingCopies.empty()) in->ringHead = 0;
     in->stream = hipStream ? (hipStream_t)hipStream : in->ownStream;
     return BEAGLE_SUCCESS;
 }
@@ -1182,11 +1207,56 @@ int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, 
     return rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
 }
 
+// ---- one process per GPU: the collective inside the engine -------------------------------------------------------------
+int beagleMi355GetCommUniqueId(void* out128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!out128) return BEAGLE_ERROR_OUT_OF_RANGE;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return BEAGLE_ERROR_GENERAL;
+    memcpy(out128, &id, sizeof(id));
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355CommInit(int instance, const void* uniqueId128, int rank, int rankCount) {
+    if (mi355::isShardedHandle(instance)) return BEAGLE_ERROR_NO_IMPLEMENTATION;      // (resource G+1 owns its own communicator)
+    GET_INSTANCE(instance);
+    if (!uniqueId128 || rankCount < 1 || rank < 0 || rank >= rankCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->comm) { ncclCommDestroy(in->comm); in->comm = nullptr; in->commRanks = 0; }
+    ncclUniqueId id;
+    memcpy(&id, uniqueId128, sizeof(id));
+    if (ncclCommInitRank(&in->comm, rankCount, id, rank) != ncclSuccess) { in->comm = nullptr; return BEAGLE_ERROR_GENERAL; }
+    in->commRanks = rankCount;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferIndex, int categoryWeightsIndex, int stateFrequenciesIndex,
+                                                    int cumulativeScaleIndex, double* outGlobalSum) {
+    if (mi355::isShardedHandle(instance)) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    GET_INSTANCE_KEEP_PENDING(instance);
+    if (!outGlobalSum) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (!in->comm) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (heldWrites(in, bufferIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
+    int rc = rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, in->dResult);
+    if (rc) return rc;
+    // this shard's sum -> the sum over all ranks (RCCL over xGMI; a communicator of one rank still takes the call) -> the host's
+    // mapped result words, all on the instance's stream
+    if (ncclAllReduce(in->dResult, in->dResult, 1, ncclDouble, ncclSum, in->comm, live(in)) != ncclSuccess) return BEAGLE_ERROR_GENERAL;
+    const unsigned long long seq = ++in->resultSeq;
+    mi355::launchRootFinal(live(in), in->dResult, 1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
+    HIP_TRY(hipGetLastError());
+    { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
+    if (in->pendingCopies.empty()) in->ringHead = 0;
+    const double v = in->hResult[0];
+    *outGlobalSum = v;
+    return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+}
+
 int beagleMi355Synchronize(int instance) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355Synchronize(h); }); }
     GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list is not work in flight)
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->pendingCopies.empty()) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1200,8 +1270,8 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
         return rc;
     }
     GET_INSTANCE(instance);
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->pendingCopies.empty()) in->ringHead = 0;
     for (size_t k = 0; k < in->eventsUsed; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) in->timedMs += ms;
@@ -1214,12 +1284,25 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     in->timedMs = 0.0; in->timedLaunches = 0;
     in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
     in->timing = enable != 0;
+    in->timingEvery = enable > 1 ? enable : 1; in->timingTick = 0;
     // event pairs for the calls to come are created here, not inside the region being timed
     while (enable && in->events.size() < 1024) {
         hipEvent_t a, b;
         HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
         in->events.emplace_back(a, b);
     }
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355KernelTimerCalls(int instance, long* outCalls) {
+    if (mi355::isShardedHandle(instance)) {             // shard 0's (every shard brackets the same calls)
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355KernelTimerCalls(h, outCalls); });
+    }
+    Instance* in = lookup(instance);
+    if (!in || !outCalls) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    *outCalls = in->timedCalls;
+    in->timedCalls = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1281,6 +1364,7 @@ static const BeagleApi g_api = {
     beagleCalculateRootLogLikelihoods,
     beagleGetSiteLogLikelihoods,
     beagleMi355CalculateRootLogLikelihoodsDevice,
+    beagleMi355CalculateRootLogLikelihoodsAllReduce,
 };
 const BeagleApi* beagleGetApiTable(void) { return &g_api; }
 

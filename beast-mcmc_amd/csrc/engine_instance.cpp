@@ -29,7 +29,7 @@ long stage(Instance* in, const void* src, size_t bytes, size_t reserve) {
     const size_t need = (std::max(bytes, reserve) + 255) & ~(size_t)255;
     if (need > RING_BYTES) return -1;
     if (in->ringHead + need > RING_BYTES) {
-        if (hipStreamSynchronize(in->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(live(in)) != hipSuccess) return -1;         // (live: what is queued from the ring goes first)
         in->ringHead = 0;
     }
     const size_t off = in->ringHead;
@@ -44,11 +44,10 @@ int upload(Instance* in, void* dst, const void* src, size_t bytes) {
     if (bytes <= RING_BYTES / 4) {
         long off = stage(in, src, bytes);
         if (off < 0) return BEAGLE_ERROR_GENERAL;
-        HIP_TRY(hipMemcpyAsync(dst, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
-        return 0;
+        return queueCopy(in, dst, (size_t)off, bytes);
     }
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, in->stream));
-    HIP_TRY(hipStreamSynchronize(in->stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, live(in)));
+    HIP_TRY(hipStreamSynchronize(live(in)));
     return 0;
 }
 
@@ -56,15 +55,47 @@ int upload(Instance* in, void* dst, const void* src, size_t bytes) {
 int uploadTransient(Instance* in, const void* src, size_t bytes, void** dptr) {
     long off = stage(in, src, bytes);
     if (off < 0) return BEAGLE_ERROR_GENERAL;
-    HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
     *dptr = in->dRing + off;
+    return queueCopy(in, in->dRing + off, (size_t)off, bytes);
+}
+
+int queueCopy(Instance* in, void* dst, size_t off, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (!in->kernelUploads) {
+        HIP_TRY(hipMemcpyAsync(dst, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
+        return 0;
+    }
+    Instance::PendingCopy pc; pc.dst = dst; pc.ringOff = off; pc.bytes = bytes;
+    in->pendingCopies.push_back(pc);
     return 0;
 }
 
+// Everything queued, by one kernel per HOST_COPY_MAX arrays: each workgroup moves 4 KiB from the mapped ring (a coalesced
+// read over the host link) to its device destination.
+int flushUploads(Instance* in) {
+    std::vector<Instance::PendingCopy>& pc = in->pendingCopies;
+    int rc = 0;
+    for (size_t i = 0; i < pc.size();) {
+        mi355::HostCopyList L;
+        L.n = 0;
+        unsigned blocks = 0;
+        for (; i < pc.size() && L.n < mi355::HOST_COPY_MAX; i++) {
+            mi355::HostCopyList::Entry& e = L.e[L.n++];
+            e.dst = pc[i].dst; e.src = in->hRingDev + pc[i].ringOff; e.bytes = (unsigned)pc[i].bytes; e.firstBlock = blocks;
+            blocks += (unsigned)((pc[i].bytes + 4095) / 4096);
+        }
+        mi355::launchHostCopies(in->stream, L, (int)blocks);
+    }
+    pc.clear();
+    if (hipGetLastError() != hipSuccess) rc = BEAGLE_ERROR_GENERAL;
+    if (rc && !in->asyncError) in->asyncError = rc;
+    return rc;
+}
+
 int download(Instance* in, void* dst, const void* src, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, in->stream));
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    in->ringHead = 0;   // everything staged so far has been consumed
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, live(in)));
+    HIP_TRY(hipStreamSynchronize(live(in)));
+    if (in->pendingCopies.empty()) in->ringHead = 0;   // everything staged so far has been consumed
     return 0;
 }
 
@@ -95,7 +126,7 @@ int ensureScale(Instance* in, int idx) {
         void* slab = nullptr;
         int rc = devAlloc(in, &slab, bytes * n);
         if (rc) return rc;
-        if (hipMemsetAsync(slab, 0, bytes * n, in->stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+        if (hipMemsetAsync(slab, 0, bytes * n, live(in)) != hipSuccess) return BEAGLE_ERROR_GENERAL;
         in->scaleSlabCur = (char*)slab; in->scaleSlabLeft = n;
     }
     in->scale[idx] = (double*)in->scaleSlabCur;
@@ -128,11 +159,14 @@ void destroy(Instance* in) {
         fprintf(stderr, "[mi355] updatePartials host time per call over %ld calls: checks+materialise %.1f us, planner %.1f us, resolve+upload+launch %.1f us; %ld plans from the cache: planner %.1f us, resolve+upload+launch %.1f us\n",
                 in->hostCalls, in->hostPrepUs / in->hostCalls, in->hostPlanUs / in->hostCalls, in->hostRunUs / in->hostCalls, in->planner.cacheHits,
                 in->hostHits ? in->hostPlanHitUs / in->hostHits : 0.0, in->hostHits ? in->hostRunHitUs / in->hostHits : 0.0);
+    in->pendingCopies.clear();
     if (in->ownStream) hipStreamSynchronize(in->ownStream);
+    if (in->comm) { if (in->stream) hipStreamSynchronize(in->stream); ncclCommDestroy(in->comm); in->comm = nullptr; }
     if (in->stream && in->stream != in->ownStream) hipStreamSynchronize(in->stream);
     for (void* p : in->allocations) hipFree(p);
     if (in->bigStage) hipFree(in->bigStage);
     if (in->matStream) hipFree(in->matStream);
+    if (in->walkFlags) hipFree(in->walkFlags);
     for (auto& r : in->resolved) if (r.dProg) hipFree(r.dProg);
     for (int k = 0; k < 2; k++) {
         if (in->exportDev[k]) hipFree(in->exportDev[k]);
@@ -220,9 +254,9 @@ int ensureWalkDummies(Instance* in) {
     const size_t tipBytes = in->pairLen + 256, scaleBytes = in->scaleStride * sizeof(double);
     void* p = nullptr;
     int rc = devAlloc(in, &p, ((tipBytes + 255) & ~(size_t)255) + scaleBytes); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(p, in->S, tipBytes, in->stream));
+    HIP_TRY(hipMemsetAsync(p, in->S, tipBytes, live(in)));
     double* ones = (double*)((char*)p + ((tipBytes + 255) & ~(size_t)255));
-    mi355::launchFill(in->stream, ones, 1.0, 0, (int)in->scaleStride);
+    mi355::launchFill(live(in), ones, 1.0, 0, (int)in->scaleStride);
     HIP_TRY(hipGetLastError());
     in->dummyTips = (uint8_t*)p; in->onesScale = ones;
     return 0;

@@ -8,6 +8,7 @@
 // There is no CPU path in this library: with no visible MI355X beagleCreateInstance returns BEAGLE_ERROR_NO_RESOURCE.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -64,7 +65,7 @@ struct Instance {
     // what runPlan derived from a cached plan (planner.h plannedTag): the device program with its addresses resolved
     struct Resolved {
         long tag = 0, epoch = -1;
-        std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs;
+        std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
         int maxRange = 0;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
@@ -136,6 +137,24 @@ struct Instance {
     std::vector<double*> scale; std::vector<char> scaleIsRaw;
     double* blockSums = nullptr; double* dResult = nullptr; double* hResult = nullptr; double* hResultDev = nullptr; unsigned long long resultSeq = 0;
     char* hRing = nullptr; char* dRing = nullptr; size_t ringHead = 0;
+    // Small host arrays (model parameters, branch lengths, programs) do not go through a copy engine: they are staged in the
+    // pinned ring, which the device maps (hRingDev), and queued here; ONE kernel (kernels.hip k_hostCopies) moves everything
+    // queued so far right before the next kernel or copy of the stream (live()).  A copy-engine transfer per array costs a
+    // dependent blit or SDMA packet each — 25 us of a 12 500-pattern evaluation's 190 (profiles/r04_experiments.txt).
+    // BEAGLE_MI355_COPY_ENGINE_UPLOADS=1 at creation: hipMemcpyAsync per array, as before round 4 (A/B runs).
+    struct PendingCopy { void* dst; size_t ringOff; size_t bytes; };
+    std::vector<PendingCopy> pendingCopies;
+    char* hRingDev = nullptr;
+    bool kernelUploads = true;
+    // one process per GPU, patterns sharded over the processes: the all-reduce of the root sum runs INSIDE the engine, on the
+    // instance's stream right behind the reduction kernel, and its result reaches the host through the same mapped words as a
+    // single-GPU sum (beagleMi355CommInit / beagleMi355CalculateRootLogLikelihoodsAllReduce)
+    ncclComm_t comm = nullptr; int commRanks = 0;
+    int asyncError = 0;                                   // first error of a deferred operation; surfaces at the next call that observes results
+    // 4 states: every slice of a walk program in ONE launch (engine_walk.cpp runPlan): per (slice, pattern group) flag words the
+    // workgroups signal and poll with the launch's epoch.  BEAGLE_MI355_NO_WALK_FUSION=1 at creation: one launch per wave of slices
+    bool fuseWaves = true;
+    unsigned* walkFlags = nullptr; size_t walkFlagBytes = 0; unsigned walkEpoch = 0;
     int partitionCount = 1;
     std::vector<int> partStart, partEnd;
     // levelisation scratch
@@ -147,6 +166,7 @@ struct Instance {
     bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
     // kernel timer
     bool timing = false;
+    int timingEvery = 1, timingTick = 0; long timedCalls = 0;      // every timingEvery-th updatePartials call is bracketed (beagleMi355KernelTimer)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t eventsUsed = 0;
     double timedMs = 0.0; long timedLaunches = 0, pendingLaunches = 0;
     size_t deviceBytes = 0;
@@ -182,6 +202,12 @@ int executeHeldPre(Instance* in);
 int holdPreList(Instance* in, const int* ops, int count);
 bool supersedesHeld(Instance* in, const int* ops, int count);
 int ensureWalkDummies(Instance* in);
+// the instance's stream, with everything queued in pendingCopies enqueued on it first: what every launch, copy and
+// synchronisation of the engine passes as its stream (only flushUploads itself and the stream setters touch in->stream)
+int flushUploads(Instance* in);
+inline hipStream_t live(Instance* in) { if (!in->pendingCopies.empty()) flushUploads(in); return in->stream; }
+// queue `bytes` already staged at ring offset `off` for device address dst (or copy them now: kernelUploads off)
+int queueCopy(Instance* in, void* dst, size_t off, size_t bytes);
 
 // (a held-back pre-order list — Instance::heldPre — runs before anything else touches the instance; the few calls that cannot
 // interact with it use GET_INSTANCE_KEEP_PENDING)
@@ -194,6 +220,15 @@ int ensureWalkDummies(Instance* in);
     if (in->heldPre.held) { const int rcPending__ = executeHeldPre(in); if (rcPending__) return rcPending__; }
 
 inline bool badIndex(int i, int n) { return i < 0 || i >= n; }
+// is this updatePartials call one the kernel timer brackets with an event pair?  (an event costs a barrier packet on the stream:
+// 6 us of an evaluation each — a sampled timer keeps that out of most of a timed region)
+inline bool timeThisCall(Instance* in) {
+    if (!in->timing) return false;
+    if (++in->timingTick < in->timingEvery) return false;
+    in->timingTick = 0;
+    in->timedCalls++;
+    return true;
+}
 
 // ---- the pattern walk (4 states) ------------------------------------------------------------------------------------
 // A partials buffer is "virtual" when its content is DEFINED instead of stored (planner.h VirtDef): a few steps over

@@ -31,7 +31,7 @@ int materializeCherries(Instance* in, const std::vector<int>& xs) {
     if (descs.empty()) return 0;
     void* dOps = nullptr;
     int rc = uploadTransient(in, descs.data(), descs.size() * sizeof(OpDesc), &dOps); if (rc) return rc;
-    mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dOps, (int)descs.size(), in->matrices, in->P, in->S, in->C, false);
+    mi355::launchPruneLevelTiled(live(in), (const OpDesc*)dOps, (int)descs.size(), in->matrices, in->P, in->S, in->C, false);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -171,7 +171,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
     if (!snapPairs.empty()) {
         void* dPairs = nullptr;
         int rc = uploadTransient(in, snapPairs.data(), snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
+        mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)dPairs, (int)(snapPairs.size() / 2), in->C * in->S * in->S);
     }
     if (!cherries.empty()) {
         void* dC = nullptr;
@@ -180,7 +180,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
         if (in->S > 20) {                                // 21..64 states: the cherries' matrices as column tables in global memory
             const size_t bytes = mi355::cherryTableBytes((int)cherries.size(), in->S, in->C);
             if (bytes > in->cherryTableBytes) {
-                HIP_TRY(hipStreamSynchronize(in->stream));
+                HIP_TRY(hipStreamSynchronize(live(in)));
                 if (in->cherryTables) {
                     for (auto& a : in->allocations) if (a == (void*)in->cherryTables) { a = in->allocations.back(); in->allocations.pop_back(); break; }
                     hipFree(in->cherryTables); in->deviceBytes -= in->cherryTableBytes; in->cherryTables = nullptr; in->cherryTableBytes = 0;
@@ -188,7 +188,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
                 void* q = nullptr; rc = devAlloc(in, &q, bytes + bytes / 4); if (rc) return rc;
                 in->cherryTables = (double*)q; in->cherryTableBytes = bytes + bytes / 4;
             }
-            mi355::launchCherryTables(in->stream, dCherries, (int)cherries.size(), in->matrices, in->S, in->C, in->cherryTables);
+            mi355::launchCherryTables(live(in), dCherries, (int)cherries.size(), in->matrices, in->S, in->C, in->cherryTables);
             dCherryTables = in->cherryTables;
         }
     }
@@ -198,7 +198,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
     // all level launches of the call (gaps between levels included — they are part of what the path costs).
     const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (in->timing) {
+    if (timeThisCall(in)) {
         if (in->eventsUsed == in->events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -212,7 +212,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
         void* dChunk = nullptr;
         int rc = uploadTransient(in, &sorted[chunkBegin], (size_t)(chunkEnd - chunkBegin) * sizeof(OpDesc), &dChunk);
         if (rc) return rc;
-        if (e0 && chunkBegin == 0) HIP_TRY(hipEventRecord(e0, in->stream));
+        if (e0 && chunkBegin == 0) HIP_TRY(hipEventRecord(e0, live(in)));
         for (int l = 0; l <= maxLevel; l++) {
             const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
             if (begin >= end) continue;
@@ -223,17 +223,17 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
                 anyWrite = anyWrite || sorted[k].scaleWrite != nullptr;
             }
             if (in->tiled)
-                mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                mi355::launchPruneLevelTiled(live(in), (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                              in->P, in->S, in->C, anyWrite, dCherries, dCherryTables);
             else
-                mi355::launchPruneLevel(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+                mi355::launchPruneLevel(live(in), (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                         in->P, in->S, in->C, maxRange);
             launches++;
         }
         chunkBegin = chunkEnd;
     }
-    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
-    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
+    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, live(in))); in->pendingLaunches += launches; }
+    else if (e1) { in->eventsUsed--; in->timedCalls--; }       // nothing was launched: give the (unrecorded) event pair back
     HIP_TRY(hipGetLastError());
     return foldCumulative(in, ops, count, tuple, globalCum);
 }
@@ -266,7 +266,7 @@ int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globa
             void *dSrc = nullptr, *dRaw = nullptr;
             rc = uploadTransient(in, &g.srcs[b], (size_t)n * sizeof(double*), &dSrc); if (rc) return rc;
             rc = uploadTransient(in, raw.data(), (size_t)n * sizeof(int), &dRaw); if (rc) return rc;
-            mi355::launchAccumulateScale(in->stream, in->scale[g.cum], (const double* const*)dSrc, (const int*)dRaw, n, 1.0,
+            mi355::launchAccumulateScale(live(in), in->scale[g.cum], (const double* const*)dSrc, (const int*)dRaw, n, 1.0,
                                          in->partStart[g.part], in->partEnd[g.part]);
         }
     }

@@ -19,7 +19,7 @@ int ensurePreScratch(Instance* in) {
     void* miss = nullptr;
     rc = devAlloc(in, &miss, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
     in->preMissing = (uint8_t*)miss;
-    HIP_TRY(hipMemsetAsync(in->preMissing, in->S, (size_t)in->P, in->stream));
+    HIP_TRY(hipMemsetAsync(in->preMissing, in->S, (size_t)in->P, live(in)));
     in->preScratch.assign(PRE_SCRATCH, nullptr);
     for (int j = 0; j < PRE_SCRATCH; j++) in->preScratch[j] = (double*)((char*)slab + in->partialsBytes * j);
     return 0;
@@ -28,7 +28,7 @@ int ensurePreScratch(Instance* in) {
 // the block sums of the derivative calls: kept between calls (hipMalloc/hipFree per call cost more than the small trees' kernels)
 int ensureEdgeScratch(Instance* in, size_t bytes) {
     if (bytes <= in->edgeScratchBytes) return 0;
-    HIP_TRY(hipStreamSynchronize(in->stream));
+    HIP_TRY(hipStreamSynchronize(live(in)));
     if (in->edgeScratch) {
         for (auto& a : in->allocations) if (a == in->edgeScratch) { a = in->allocations.back(); in->allocations.pop_back(); break; }
         hipFree(in->edgeScratch); in->deviceBytes -= in->edgeScratchBytes; in->edgeScratch = nullptr; in->edgeScratchBytes = 0;
@@ -67,9 +67,9 @@ int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
         void *dPairs = nullptr, *dPass = nullptr;
         int rc = uploadTransient(in, pairs.data(), (size_t)2 * n * sizeof(int), &dPairs); if (rc) return rc;
         rc = uploadTransient(in, pass.data(), (size_t)2 * n * sizeof(OpDesc), &dPass); if (rc) return rc;
-        mi355::launchTransposeMatrices(in->stream, in->matrices, (const int*)dPairs, n, in->S, in->C);
-        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
-        mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass + n, n, in->matrices, in->P, in->S, in->C, anyWrite);
+        mi355::launchTransposeMatrices(live(in), in->matrices, (const int*)dPairs, n, in->S, in->C);
+        mi355::launchPruneLevelTiled(live(in), (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+        mi355::launchPruneLevelTiled(live(in), (const OpDesc*)dPass + n, n, in->matrices, in->P, in->S, in->C, anyWrite);
     }
     return 0;
 }
@@ -171,7 +171,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
             if (begin >= end) continue;
             if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
-            mi355::launchPrePartials(in->stream, (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
+            mi355::launchPrePartials(live(in), (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                      in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
         }
         chunkBegin = chunkEnd;
@@ -186,7 +186,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             void *dSrc = nullptr, *dRaw = nullptr;
             rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
             rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
-            mi355::launchAccumulateScale(in->stream, in->scale[globalCum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, 0, in->P);
+            mi355::launchAccumulateScale(live(in), in->scale[globalCum], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, 0, in->P);
         }
     return 0;
 }
@@ -309,7 +309,7 @@ int holdPreList(Instance* in, const int* ops, int count) {
     // its own copy of the root's pre-order partial: the caller rewrites that buffer before every list (simulateRoot,
     // AbstractBeagleGradientDelegate.java:142-151), which must not force this list to run
     if (!in->preRootCopy) { void* q = nullptr; int rc = devAlloc(in, &q, in->partialsBytes); if (rc) return rc; in->preRootCopy = (double*)q; }
-    HIP_TRY(hipMemcpyAsync(in->preRootCopy, in->partials[nodes[root].par], in->partialsBytes, hipMemcpyDeviceToDevice, in->stream));
+    HIP_TRY(hipMemcpyAsync(in->preRootCopy, in->partials[nodes[root].par], in->partialsBytes, hipMemcpyDeviceToDevice, live(in)));
     h.rootBuf = nodes[root].par;
     h.ops.assign(ops, ops + (size_t)count * BEAGLE_OP_COUNT);
     h.nodes.swap(nodes);
@@ -358,7 +358,7 @@ static int launchHeldLevels(Instance* in, const std::vector<mi355::PreNodeJob>& 
         for (size_t l = 0; l + 1 < start.size(); l++) {
             const size_t lo = std::max((size_t)start[l], b), hi = std::min((size_t)start[l + 1], b + n);
             if (lo >= hi) continue;
-            mi355::launchPreNodes4(in->stream, (const mi355::PreNodeJob*)dJobs + (lo - b), (int)(hi - lo), in->matrices,
+            mi355::launchPreNodes4(live(in), (const mi355::PreNodeJob*)dJobs + (lo - b), (int)(hi - lo), in->matrices,
                                    in->weights + (size_t)wIdx * in->C, in->patternWeights, dBlock, in->P, in->C);
         }
     }
@@ -404,7 +404,7 @@ static int fusedGradient(Instance* in, const std::vector<int>& edgeOf, const int
     in->heldPre.held = false;                                      // (whatever happens below, the destinations are being written)
     rc = launchHeldLevels(in, jobs, start, wIdx, dBlock); if (rc) return rc;
     std::vector<double> sums((size_t)count * 2);
-    mi355::launchEdgeFinal(in->stream, dBlock, count, in->P, dSums);
+    mi355::launchEdgeFinal(live(in), dBlock, count, in->P, dSums);
     rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) return rc;
     for (int e = 0; e < count; e++) {
         if (outSum) outSum[e] = sums[2 * e];
@@ -426,7 +426,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     if (!in->preDummyStates) {
         void* q = nullptr; int rc = devAlloc(in, &q, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
         in->preDummyStates = (uint8_t*)q;
-        HIP_TRY(hipMemsetAsync(in->preDummyStates, 4, (size_t)in->P, in->stream));
+        HIP_TRY(hipMemsetAsync(in->preDummyStates, 4, (size_t)in->P, live(in)));
     }
     // every segment: its descriptors, padded to an even count, and two more no-ops (the kernel's look-ahead)
     const int nSegs = (int)h.segRoot.size();
@@ -473,7 +473,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     const size_t progBytes = prog.size() * sizeof(mi355::PreWalkOp);
     if (progBytes + segBytes > RING_BYTES / 2) return 1;
     if (progBytes + segBytes > in->dPreProgBytes) {
-        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipStreamSynchronize(live(in)));
         void* q = nullptr; int rc = devAlloc(in, &q, (progBytes + segBytes) * 2); if (rc) return rc;   // (the old, smaller one stays allocated until the instance goes)
         in->dPreProg = q; in->dPreProgBytes = (progBytes + segBytes) * 2;
     }
@@ -481,9 +481,9 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes);
     rc = upload(in, in->dPreProg, segs.data(), (size_t)nSegs * sizeof(mi355::PreWalkSeg)); if (rc) return rc;
     rc = upload(in, (char*)in->dPreProg + segBytes, prog.data(), progBytes); if (rc) return rc;
-    if (!mi355::launchPreWalk4(in->stream, (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,
+    if (!mi355::launchPreWalk4(live(in), (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,
                                in->preRootCopy, in->matrices, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots)) return 1;
-    mi355::launchPreWalkFinal(in->stream, dSums, count, in->P, in->C, dOut);
+    mi355::launchPreWalkFinal(live(in), dSums, count, in->P, in->C, dOut);
     std::vector<double> out(count);
     rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;
     // (scaled partials times reciprocals of factors: should a product have left the range on a very deep path, the sums show it —
@@ -554,10 +554,10 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
             void* dDesc = nullptr;
             rc = uploadTransient(in, direct.data(), direct.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
             if (in->S == 4 && !in->tiled)
-                mi355::launchEdgeDifferentials4(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                mi355::launchEdgeDifferentials4(live(in), (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
                                                 in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->C);
             else
-                mi355::launchEdgeDifferentials(in->stream, (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
+                mi355::launchEdgeDifferentials(live(in), (const mi355::EdgeDesc*)dDesc, (int)direct.size(), in->matrices,
                                                in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C, in->tiled);
         }
         for (size_t q = 0; q < viaPrune.size() && !rc; q += PRE_SCRATCH) {
@@ -576,12 +576,12 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
             void *dPass = nullptr, *dDesc = nullptr;
             rc = uploadTransient(in, pass.data(), (size_t)n * sizeof(OpDesc), &dPass); if (rc) break;
             rc = uploadTransient(in, &viaPrune[q], (size_t)n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
-            mi355::launchPruneLevelTiled(in->stream, (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
-            mi355::launchEdgeReduce(in->stream, (const mi355::EdgeDesc*)dDesc, n, in->weights + (size_t)wIdx * in->C, in->patternWeights,
+            mi355::launchPruneLevelTiled(live(in), (const OpDesc*)dPass, n, in->matrices, in->P, in->S, in->C, false);
+            mi355::launchEdgeReduce(live(in), (const mi355::EdgeDesc*)dDesc, n, in->weights + (size_t)wIdx * in->C, in->patternWeights,
                                     dPer, dBlock, in->P, in->S, in->C, in->tiled);
         }
         if (rc) break;
-        mi355::launchEdgeFinal(in->stream, dBlock, m, in->P, dSums);
+        mi355::launchEdgeFinal(live(in), dBlock, m, in->P, dSums);
         sums.resize((size_t)m * 2);
         rc = download(in, sums.data(), dSums, sums.size() * sizeof(double)); if (rc) break;
         for (int e = 0; e < m; e++) {
@@ -590,7 +590,7 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
         }
         if (outDerivatives) rc = download(in, outDerivatives + (size_t)b * in->P, dPer, (size_t)m * in->P * sizeof(double));
     }
-    if (dPer) { hipStreamSynchronize(in->stream); hipFree(dPer); }
+    if (dPer) { hipStreamSynchronize(live(in)); hipFree(dPer); }
     return rc;
 }
 
@@ -628,12 +628,12 @@ int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateI
         void *dDesc = nullptr, *dLen = nullptr;
         rc = uploadTransient(in, &descs[b], n * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
         rc = uploadTransient(in, lengths + b, n * sizeof(double), &dLen); if (rc) break;
-        mi355::launchCrossProducts(in->stream, (const mi355::EdgeDesc*)dDesc, (int)n, (const double*)dLen, in->weights + (size_t)wIdx * in->C,
+        mi355::launchCrossProducts(live(in), (const mi355::EdgeDesc*)dDesc, (int)n, (const double*)dLen, in->weights + (size_t)wIdx * in->C,
                                    in->rates + (size_t)rateIdx * in->C, in->patternWeights, dPartial, dOut, in->P, in->S, in->C, in->tiled);
         rc = download(in, sums.data(), dOut, nOut * sizeof(double)); if (rc) break;
         for (size_t k = 0; k < nOut; k++) outSum[k] += sums[k];
     }
-    hipStreamSynchronize(in->stream);
+    hipStreamSynchronize(live(in));
     hipFree(dPartial); hipFree(dOut);
     return rc;
 }

@@ -16,7 +16,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
         void* dPairs = nullptr;
         int rc = uploadTransient(in, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int), &dPairs); if (rc) return rc;
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)dPairs, (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
+        mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)dPairs, (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -29,6 +29,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
     std::vector<mi355::WalkSeg> segsLocal;
     std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
+    std::vector<int> depsLocal;
+    std::vector<int>& devDeps = slot ? slot->deps : depsLocal;     // per device slice: the device slices it waits for (one fused launch)
+    // 4 states, assembly loop: ALL slices in one launch, dispatched critical path first, every workgroup waiting for the slices
+    // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
+    const bool fused = in->fuseWaves && in->fastWalk && !in->walkT && plan.launchOrder.size() == plan.segs.size();
     int maxRange = 0;
     if (reuse) {
         maxRange = slot->maxRange;
@@ -40,6 +45,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     w.clear();
     w.reserve(n + 3 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
+    devDeps.clear();
+    std::vector<int> posOf(plan.segs.size(), -1);
     const size_t matStride = (size_t)in->C * in->S * in->S;
     // matrices whose snapshot is taken by THIS plan are gathered from the snapshot's source (same values; lets the snapshot copies and
     // the gather run in one launch: kernels_walk4.hip k_gatherAndSnapshot)
@@ -53,8 +60,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     nop.m1 = in->matrices; nop.m2 = in->matrices;
     nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
-    for (size_t si = 0; si < plan.segs.size(); si++) {
-        const mi355::PlanSeg& ps = plan.segs[si];
+    for (size_t oi = 0; oi < plan.segs.size(); oi++) {
+        const size_t si = oi;                                   // position in the device program
+        const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)plan.launchOrder[oi] : oi];
+        posOf[fused ? (size_t)plan.launchOrder[oi] : oi] = (int)oi;
+        segs[si].depStart = (int)devDeps.size();
+        if (fused) for (int d = ps.depStart; d < ps.depStart + ps.depCount; d++) {
+            if (posOf[plan.deps[d]] < 0) return BEAGLE_ERROR_GENERAL;      // (a slice behind one that waits for it: the planner's order forbids it)
+            devDeps.push_back(posOf[plan.deps[d]]);
+        }
+        segs[si].depCount = (int)devDeps.size() - segs[si].depStart;
         segs[si].progStart = (int)w.size();
         for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
             mi355::MicroOp m = plan.prog[i];
@@ -126,30 +141,33 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     }
     }
     in->statMicroOps += (long)n;
-    // pack: [micro-ops (64 B each) | segments (16 B each) | snapshot pairs] — ONE host-to-device copy
-    const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg);
+    // pack: [micro-ops (64 B each) | segments (32 B each) | dependency lists | snapshot pairs] — ONE host-to-device copy
+    const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg) + ((devDeps.size() * sizeof(int) + 31) & ~(size_t)31);
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
+    const size_t depOff = opBytes + segs.size() * sizeof(mi355::WalkSeg);
     char* dBase = nullptr;
     if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
     else if (total <= RING_BYTES / 4) {
         const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
         if (off < 0) return BEAGLE_ERROR_GENERAL;
-        memcpy(in->hRing + off + opBytes, segs.data(), segBytes);                // ... the rest is filled in behind them
+        memcpy(in->hRing + off + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg));     // ... the rest is filled in behind them
+        if (!devDeps.empty()) memcpy(in->hRing + off + depOff, devDeps.data(), devDeps.size() * sizeof(int));
         if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
-        HIP_TRY(hipMemcpyAsync(in->dRing + off, in->hRing + off, total, hipMemcpyHostToDevice, in->stream));
+        { int rcq = queueCopy(in, in->dRing + off, (size_t)off, total); if (rcq) return rcq; }
         dBase = in->dRing + off;
         if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
             if (slot->dProgBytes < total) {
-                if (slot->dProg) { HIP_TRY(hipStreamSynchronize(in->stream)); hipFree(slot->dProg); }
+                if (slot->dProg) { HIP_TRY(hipStreamSynchronize(live(in))); hipFree(slot->dProg); }
                 slot->dProg = nullptr; slot->dProgBytes = 0;
                 HIP_TRY(hipMalloc((void**)&slot->dProg, total + total / 4));
                 slot->dProgBytes = total + total / 4;
             }
-            HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, in->stream));
+            if (in->kernelUploads) { int rcq = queueCopy(in, slot->dProg, (size_t)off, total); if (rcq) return rcq; }     // (from the same staged bytes)
+            else HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, live(in)));
             slot->dProgValid = true;
         }
     } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
-        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipStreamSynchronize(live(in)));
         if (in->bigStageBytes < total) {
             if (in->bigStage) hipFree(in->bigStage);
             in->bigStage = nullptr; in->bigStageBytes = 0;
@@ -157,39 +175,67 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             in->bigStageBytes = total;
         }
         HIP_TRY(hipMemcpy(in->bigStage, w.data(), opBytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segBytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg), hipMemcpyHostToDevice));
+        if (!devDeps.empty()) HIP_TRY(hipMemcpy(in->bigStage + depOff, devDeps.data(), devDeps.size() * sizeof(int), hipMemcpyHostToDevice));
         if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
         dBase = in->bigStage;
     }
     const bool fusedSnapshot = pairBytes && !in->walkT && in->fuseLaunches;          // 4 states: together with the gather below
     if (pairBytes && !fusedSnapshot)
-        mi355::launchSnapshotMatrices(in->stream, in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
+        mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
     const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
                                          : w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
-        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipStreamSynchronize(live(in)));
         if (in->matStream) hipFree(in->matStream);
         in->matStream = nullptr; in->matStreamBytes = 0;
         const size_t want = std::max(streamBytes + streamBytes / 4, (size_t)1 << 20);
         HIP_TRY(hipMalloc((void**)&in->matStream, want));
         in->matStreamBytes = want;
     }
-    if (in->walkT) mi355::launchGatherFragments(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
-    else if (fusedSnapshot) mi355::launchGatherAndSnapshot(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
+    if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
-    else mi355::launchGatherMatrices(in->stream, (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
+    else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
     if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
-        for (size_t i = 0; i < segs.size(); i++) fprintf(stderr, " w%d:%d", plan.segs[i].wave, segs[i].progCount);
+        for (size_t i = 0; i < segs.size(); i++) {
+            const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)plan.launchOrder[i] : i];
+            fprintf(stderr, " w%d:%d", ps.wave, segs[i].progCount);
+            if (fused) fprintf(stderr, "(t%d d%d)", ps.tail, ps.depCount);
+        }
         fprintf(stderr, "\n");
         if (atoi(getenv("BEAGLE_MI355_DUMP_PLAN")) > 1)
             for (size_t i = 0; i < w.size(); i++)
                 fprintf(stderr, "[mi355]   %3zu: k1 %u k2 %u hold %u scale %u store %d\n", i, (w[i].flags >> 5) & 7, (w[i].flags >> 8) & 7, (w[i].flags >> 11) & 3,
                         (w[i].flags >> 13) & 3, (w[i].flags & mi355::WF_STORE) ? 1 : 0);
     }
-    if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, in->stream));
+    if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, live(in)));
+    if (fused) {
+        // ONE launch: slice y of the device program is dispatched before slice y + 1 (x fastest), every slice behind the ones it
+        // waits for; a workgroup signals flags[y][x] = epoch when its stores are out, its dependants poll for exactly that value
+        int range = 0;
+        for (size_t i = 0; i < segs.size(); i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
+        const int flagStride = (in->P + 127) / 128 + 1;
+        const size_t flagBytes = segs.size() * (size_t)flagStride * sizeof(unsigned);
+        if (in->walkFlagBytes < flagBytes) {
+            HIP_TRY(hipStreamSynchronize(live(in)));
+            if (in->walkFlags) hipFree(in->walkFlags);
+            in->walkFlags = nullptr; in->walkFlagBytes = 0;
+            const size_t want = std::max(flagBytes + flagBytes / 2, (size_t)1 << 16);
+            HIP_TRY(hipMalloc((void**)&in->walkFlags, want));
+            HIP_TRY(hipMemsetAsync(in->walkFlags, 0, want, live(in)));
+            in->walkFlagBytes = want;
+        }
+        if (++in->walkEpoch == 0u) in->walkEpoch = 1u;
+        mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes), (int)segs.size(), range,
+                               in->matStream, in->P, in->C, (long)in->scaleStride, (const int*)(dBase + depOff), in->walkFlags, in->walkEpoch, flagStride);
+        in->statFastWalks++; in->statWalks++;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
     for (size_t b = 0; b < segs.size();) {
         size_t e = b + 1;
@@ -198,14 +244,14 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         const bool fast = in->fastWalk;                 // the assembly loop (BEAGLE_MI355_NO_FAST_WALK=1: the C++ reference kernel)
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         if (in->walkT) {
-            if (!mi355::launchWalkT32(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+            if (!mi355::launchWalkT32(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                       in->matStream, in->P, in->S, in->C, in->holdSlots)) return BEAGLE_ERROR_GENERAL;
         } else if (fast) {
-            mi355::launchWalk4Fast(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+            mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                    in->matStream, in->P, in->C, (long)in->scaleStride);
             in->statFastWalks++;
         } else
-            mi355::launchWalk4(in->stream, (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
+            mi355::launchWalk4(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                in->matStream, in->P, in->C, (long)in->scaleStride);
         in->statWalks++;
         b = e;
@@ -280,12 +326,12 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
             const Clock::time_point t1 = Clock::now();
             hipEvent_t a = nullptr, b = nullptr;
             const bool launches = !in->planner.planned->prog.empty();
-            if (in->timing && launches) {
+            if (launches && timeThisCall(in)) {
                 if (in->eventsUsed == in->events.size()) { hipEvent_t x, y; HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y)); in->events.emplace_back(x, y); }
                 a = in->events[in->eventsUsed].first; b = in->events[in->eventsUsed].second; in->eventsUsed++;
             }
             int rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, a); if (rc) return rc;
-            if (b) { HIP_TRY(hipEventRecord(b, in->stream)); in->pendingLaunches++; }
+            if (b) { HIP_TRY(hipEventRecord(b, live(in))); in->pendingLaunches++; }
             const double usRun = usSince(t1);
             in->hostRunUs += usRun; in->hostRunHitUs += usRun;
             return 0;
@@ -303,7 +349,7 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
             return BEAGLE_ERROR_OUT_OF_RANGE;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (in->timing) {
+    if (timeThisCall(in)) {
         if (in->eventsUsed == in->events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -340,8 +386,8 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us; }
         begin += n;
     }
-    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, in->stream)); in->pendingLaunches += launches; }
-    else if (e1) in->eventsUsed--;        // nothing was launched: give the (unrecorded) event pair back
+    if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, live(in))); in->pendingLaunches += launches; }
+    else if (e1) { in->eventsUsed--; in->timedCalls--; }       // nothing was launched: give the (unrecorded) event pair back
     return foldCumulative(in, ops, count, tuple, globalCum);
 }
 

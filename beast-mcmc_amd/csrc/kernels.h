@@ -111,7 +111,9 @@ inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // tStart: where the segment's patterns begin in the PAIR-INTERLEAVED arrays — those are laid out partition by partition, every
 // partition padded to whole blocks of 128 (engine_instance.cpp setPairLayout), so that a lane's pair is one aligned load wherever a
 // partition starts; partials and plain per-pattern arrays keep the caller's pattern numbering.
-struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, pad0, pad1, pad2; };
+// depStart / depCount (one fused launch of all slices, k_walk4_fast only): the slices — rows of this array — whose stored results
+// this one reads, as a range of the launch's dependency list; its workgroups wait for their flags first.
+struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, depStart, depCount, pad2; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
 // patterns, 64 apart; its tip states and reciprocal scale factors are stored pair-interleaved (walkPairIndex).
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
@@ -122,13 +124,22 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
 // src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
+// deps / flags / epoch / flagStride: all slices of a program in ONE launch (slice y is dispatched before y + 1): a workgroup first
+// waits until flags[d * flagStride + x] == epoch for every slice d of its dependency list, and sets flags[y * flagStride + x] =
+// epoch when its results are out.  flags == nullptr: no waiting, no signalling (one launch per wave of independent slices).
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
-                     long recipOff);
+                     long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);
 
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------------
+
+// Host -> device copies of small arrays by a kernel (engine_instance.cpp flushUploads): entry k moves `bytes` from `src` — host
+// memory the device maps — to `dst`; its workgroups are firstBlock .. firstBlock + ceil(bytes / 4096) - 1.
+constexpr int HOST_COPY_MAX = 12;
+struct HostCopyList { struct Entry { void* dst; const void* src; unsigned bytes, firstBlock; } e[HOST_COPY_MAX]; int n; };
+void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks);
 
 // P(t) = U diag(exp(lambda * t * r_c)) U^-1, negatives clamped to 0, for `count` branches.
 // dIdx/dLen/dEig/dRate: device arrays of length `count`: destination matrix index, edge length,

@@ -40,6 +40,31 @@ bool grantDynamicLds(const void* kernel, size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// host -> device copies of small arrays (kernels.h HostCopyList): a workgroup moves 4 KiB of one entry
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hostCopies(const HostCopyList L) {
+    int k = 0;
+    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].firstBlock) k++;
+    const size_t base = (size_t)(blockIdx.x - L.e[k].firstBlock) * 4096;
+    const char* s = (const char*)L.e[k].src + base;
+    char* d = (char*)L.e[k].dst + base;
+    const unsigned left = L.e[k].bytes - (unsigned)base, n = left < 4096u ? left : 4096u;
+    const unsigned t = threadIdx.x;
+    if ((((size_t)s | (size_t)d) & 15) == 0) {
+        if (t * 16 + 16 <= n) *reinterpret_cast<uint4*>(d + t * 16) = *reinterpret_cast<const uint4*>(s + t * 16);
+        for (unsigned i = (n & ~15u) + t; i < n; i += 256) d[i] = s[i];
+    } else if ((((size_t)s | (size_t)d) & 3) == 0) {
+        for (unsigned i = t * 4; i + 4 <= n; i += 1024) *reinterpret_cast<unsigned*>(d + i) = *reinterpret_cast<const unsigned*>(s + i);
+        for (unsigned i = (n & ~3u) + t; i < n; i += 256) d[i] = s[i];
+    } else
+        for (unsigned i = t; i < n; i += 256) d[i] = s[i];
+}
+void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks) {
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_hostCopies, dim3((unsigned)blocks), dim3(256), 0, stream, list);
+}
+
+// ------------------------------------------------------------------------------------------------
 // transition matrices
 // ------------------------------------------------------------------------------------------------
 // complexEigen (an EIGEN_COMPLEX instance: BeagleTreeLikelihood.java:353-355, the asymmetric discrete-trait models): the

@@ -360,15 +360,40 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 #include "walk4_fast_loop.inc"
 // Same mapping, LDS layout (hold slots, then the matrix tables; no exchange buffer) and arithmetic as k_walk4; the loop
 // itself is one block of assembly with its own register map (tools/gen_walk4_fast.py says why and what it leaves to k_walk4).
+// One launch for ALL slices of a program (flags != nullptr).  Slices of a wave are independent; a slice of a later wave reads
+// what earlier slices stored — for the same 128 patterns only.  So instead of a launch per wave (a chip-wide barrier, with the
+// tail of every wave running on a few CUs), a workgroup waits for exactly the slices it reads from: flags[slice][x] carries the
+// launch's epoch once that slice's workgroup x has its results out.  Workgroups are dispatched in index order (x fastest, then
+// the slice) and the engine orders the slices critical path first with every slice behind the ones it waits for, so a waiting
+// workgroup only ever waits for workgroups dispatched before it: no deadlock however few fit on the chip at a time.
+// Visibility across the 8 XCDs (private L2s): the loop's result stores and its loads of stored results carry the device-scope
+// bit (sc1: written through to memory before the acknowledgement; read past any stale line — tools/gen_walk4_fast.py), so a
+// producer only has to drain its stores (the loop ends with s_waitcnt vmcnt(0)) before the flag goes up and a consumer only has
+// to see the flag.  A write-back / invalidate of the whole L2 per workgroup (buffer_wbl2 / buffer_inv, what a release / acquire
+// fence at agent scope costs) made the launch five times slower instead of faster.
 template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
-                                                             const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes) {
+                                                             const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
+                                                             const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride) {
     extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[2][MAXC][320 B], exch[C][1 KiB] (write-mode rescaling)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
     const int p0 = sg.pStart + (int)blockIdx.x * 128;
-    if (p0 >= pEnd || progCount <= 0) return;
+    if (p0 >= pEnd || progCount <= 0) return;         // (no workgroup waits for this one: its dependants leave the same way)
     const unsigned c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (flags) {
+        const int depCount = sg.depCount;
+        if (depCount > 0) {
+            if (c == 0) {
+                const int MI355_CONST* dl = deps + sg.depStart;
+                for (int d = (int)(threadIdx.x & 63); d < depCount; d += 64) {
+                    const unsigned* f = flags + (size_t)dl[d] * flagStride + blockIdx.x;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+        }
+    }
     const u64 dp = (u64)(prog + (size_t)progStart * 16);
     const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
     const u64 strm = (u64)matStream + (u64)progStart * strmStep;
@@ -382,10 +407,16 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                      [exch] "s"(ldsBase + 2u * holdStride + 2u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
                      [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(sg.tStart + (int)blockIdx.x * 128)
                  : WALK4_FAST_CLOBBERS);
+    if (flags) {
+        // (the loop ends with s_waitcnt vmcnt(0): every store of this wave has been acknowledged by memory)
+        __syncthreads();
+        if (c == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+            __hip_atomic_store(flags + (size_t)blockIdx.y * flagStride + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
-                     long recipOff) {
+                     long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride) {
     if (nSegs <= 0 || maxRange <= 0) return;
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
@@ -397,11 +428,12 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes);
+    const int MI355_CONST* deps = (const int MI355_CONST*)dDeps;
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

@@ -466,7 +466,8 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         int wave = 0;
         for (;;) {
             bool chunked = false;
-            if (chunkOps > 0) {
+            const int chunk = (wave == 0 || chunkTopOps <= 0) ? chunkOps : std::min(chunkOps, chunkTopOps);
+            if (chunk > 0) {
                 // micro-operations below every op that is still to be emitted (children precede parents in the list)
                 weight.assign(count, 0);
                 long total = 0;
@@ -484,7 +485,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                     weight[k] = w;
                     if (!consumed[k]) total += w;
                 }
-                if (total > chunkOps + chunkOps / 2) {
+                if (total > chunk + chunk / 2) {
                     chunkRoots.clear(); stack.clear();
                     for (int k = count - 1; k >= 0; k--) {
                         const OpInfo& o = info_[k];
@@ -492,7 +493,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                     }
                     while (!stack.empty()) {
                         const int k = stack.back(); stack.pop_back();
-                        if (weight[k] <= chunkOps) { chunkRoots.push_back(k); continue; }
+                        if (weight[k] <= chunk) { chunkRoots.push_back(k); continue; }
                         bool descended = false;
                         for (int c = 1; c >= 0; c--) {
                             const int prod = c ? prod2_[k] : prod1_[k];
@@ -538,6 +539,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     }
     // launches run wave by wave: order the slices that way (stable: partitions keep their order inside a wave)
     std::stable_sort(out.segs.begin(), out.segs.end(), [](const PlanSeg& a, const PlanSeg& b) { return a.wave < b.wave; });
+    linkSlices(out);
     if (fill) {
         fill->plan = out;
         fill->defs.assign(count, VirtDef());
@@ -549,6 +551,53 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         fill->valid = true;
     }
     return 0;
+}
+
+// Which slices read what other slices of the same plan store (planner.h PlanSeg): a slice reads a stored result only as a
+// PK_MEM operand, and only of a slice of an EARLIER wave of the same partition (tests/native/plan_check.cpp checks both).
+void WalkPlanner::linkSlices(Plan& out) {
+    const size_t nKeys = (size_t)partialsCount_ * keyParts_;
+    if (storedBy_.size() < nKeys) { storedBy_.assign(nKeys, -1); storedStamp_.assign(nKeys, 0); }
+    linkStamp_++;
+    const int n = (int)out.segs.size();
+    for (int s = 0; s < n; s++) {
+        const PlanSeg& sg = out.segs[s];
+        for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
+            const int st = out.prog[k].storeBuf;
+            if (st >= 0) { const size_t kk = (size_t)st * keyParts_ + sg.partition; storedBy_[kk] = s; storedStamp_[kk] = linkStamp_; }
+        }
+    }
+    out.deps.clear();
+    std::vector<int> mark(n, -1);
+    for (int s = 0; s < n; s++) {
+        PlanSeg& sg = out.segs[s];
+        sg.depStart = (int)out.deps.size();
+        auto reads = [&](int kind, int buf) {
+            if (kind != PK_MEM) return;
+            const size_t kk = (size_t)buf * keyParts_ + sg.partition;
+            if (kk >= nKeys || storedStamp_[kk] != linkStamp_) return;
+            const int by = storedBy_[kk];
+            if (by == s || mark[by] == s) return;
+            mark[by] = s;
+            out.deps.push_back(by);
+        };
+        for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) { reads(out.prog[k].k1, out.prog[k].a1); reads(out.prog[k].k2, out.prog[k].a2); }
+        sg.depCount = (int)out.deps.size() - sg.depStart;
+        sg.tail = 0;
+    }
+    // tail: own length + the longest tail among the slices that wait for this one.  Slices are sorted by wave and read only
+    // earlier waves, so one backward sweep settles every slice before the ones it reads.
+    for (int s = n - 1; s >= 0; s--) {
+        PlanSeg& sg = out.segs[s];
+        sg.tail += sg.progCount;
+        for (int d = sg.depStart; d < sg.depStart + sg.depCount; d++) {
+            PlanSeg& child = out.segs[out.deps[d]];
+            child.tail = std::max(child.tail, sg.tail);
+        }
+    }
+    out.launchOrder.resize(n);
+    for (int s = 0; s < n; s++) out.launchOrder[s] = s;
+    std::stable_sort(out.launchOrder.begin(), out.launchOrder.end(), [&](int a, int b) { return out.segs[a].tail > out.segs[b].tail; });
 }
 
 WalkPlanner::CacheEntry* WalkPlanner::findCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps) {
@@ -610,6 +659,7 @@ void WalkPlanner::planMaterialize(const std::vector<int>& keys, Plan& out) {
         seg.progCount = (int)out.prog.size() - seg.progStart;
         if (seg.progCount > 0) out.segs.push_back(seg);
     }
+    linkSlices(out);
 }
 
 }  // namespace mi355

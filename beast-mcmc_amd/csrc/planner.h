@@ -38,13 +38,20 @@ struct MicroOp {
 
 // A program slice: every pattern group of `partition` walks it.  Slices of the same `wave` are independent of each other
 // (one launch); a slice may read what slices of EARLIER waves stored.
-struct PlanSeg { int progStart, progCount, partition, wave; };
+// depStart / depCount: the slices whose stored results this one reads (indices into Plan::segs, all of earlier waves), as a
+// range of Plan::deps.  tail: micro-operations from the start of this slice to the end of the last slice that (transitively)
+// waits for it — the critical path behind it.  A single launch may run ALL slices side by side when every workgroup first
+// waits for the slices in its dependency list (same pattern group) and the slices are dispatched by descending tail — an
+// order in which every slice comes after the ones it reads (tail(child) > tail(parent)); Plan::launchOrder is that order.
+struct PlanSeg { int progStart, progCount, partition, wave, depStart, depCount, tail; };
 
 struct Plan {
     std::vector<MicroOp> prog;
-    std::vector<PlanSeg> segs;
+    std::vector<PlanSeg> segs;       // sorted by wave
+    std::vector<int> deps;           // PlanSeg::depStart / depCount
+    std::vector<int> launchOrder;    // permutation of segs: descending tail (critical path first), dependencies before dependants
     std::vector<int> snapPairs;      // (source matrix slot, destination snapshot slot) pairs to copy BEFORE the program runs
-    void clear() { prog.clear(); segs.clear(); snapPairs.clear(); }
+    void clear() { prog.clear(); segs.clear(); deps.clear(); launchOrder.clear(); snapPairs.clear(); }
 };
 
 // Definition of a virtual buffer: one step per internal node of a small all-compact-tip subtree, in post-order (a step's
@@ -143,6 +150,10 @@ public:
 
     // statistics of the last plan() (bench / tests)
     int lastStored = 0, lastMemReads = 0, lastHolds = 0, lastWaves = 0;
+    // chunkTopOps > 0: every wave above the first peels subtrees of at most this many micro-operations (the engine sets it once,
+    // when ALL slices of a program run in one launch and a wave is not a launch: near the root few subtrees are left side by
+    // side, so long slices there are a long serial tail on a few CUs; short ones keep more of them in flight)
+    int chunkTopOps = 0;
     long cacheHits = 0;                  // plans served from the cache below
     bool cacheEnabled = true;
     // what the last plan() produced: `out`, or the cache's copy (no copy is made on a hit).  plannedTag identifies the
@@ -165,6 +176,9 @@ private:
     void emitVirtualStep(int buf, int idx, unsigned freeMask, bool writeMode, Plan& out);
     void emitVirtual(int buf, unsigned freeMask, bool writeMode, Plan& out);
     int virtNeed(int buf) const { return virt_[buf].nSteps ? virt_[buf].steps[virt_[buf].nSteps - 1].need : 0; }
+    void linkSlices(Plan& out);          // PlanSeg::dep*, tail and Plan::launchOrder
+    std::vector<int> storedBy_, storedStamp_;          // per (buffer, partition): the slice of the current plan that stores it
+    int linkStamp_ = 0;
 
     int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6, keyParts_ = 1;
     bool enabled_ = false;

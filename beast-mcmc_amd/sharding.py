@@ -11,7 +11,14 @@ tensors, which is how the N>1 path is tested without GPUs.
 Tree, eigen system, matrices and op lists are replicated (KB-scale); nothing else crosses GPUs.  The rescaling
 retry decision is taken on the GLOBAL value, so every rank takes the same branch.
 
-Stream discipline on the GPU: the engine, the collective and the 8-byte read-back all run on ONE dedicated torch
+Two ways to run the collective (``collective=``):
+  "engine" (default on a GPU)  the all-reduce is issued INSIDE the engine, on its own stream right behind the reduction
+           kernel, through RCCL directly (include/beagle_mi355.h beagleMi355CommInit / ...AllReduce): torch.distributed only
+           carries the 128-byte communicator id to the ranks once, at start-up; an evaluation is ONE call into the host driver.
+  "torch"  the per-shard sum stays on the device and ``torch.distributed.all_reduce`` adds it up (what round 3 shipped; what
+           the CPU tests run over gloo).
+
+Stream discipline on the GPU (collective="torch"): the engine, the collective and the 8-byte read-back all run on ONE dedicated torch
 stream (never the legacy default stream, whose handle is 0 and which the engine would read as "use your own"):
 kernels -> device-side sum -> all_reduce -> D2H are ordered by the stream itself, with no event or host sync in between.
 """
@@ -24,16 +31,32 @@ from .treelikelihood import BeagleTreeLikelihood
 
 
 class ShardedTreeLikelihood:
-    def __init__(self, workload, rank, world_size, dist=None, device=None, library=None, **kw):
+    def __init__(self, workload, rank, world_size, dist=None, device=None, library=None, collective=None, **kw):
         self.rank, self.world = rank, world_size
         self.dist = dist
+        self.collective = collective or ("engine" if device is not None else "torch")
         start, stop = _patterns.shard_bounds(workload.pattern_count, world_size)[rank]
         self.range = (start, stop)
         self.local = BeagleTreeLikelihood(workload.shard(start, stop), library=library, **kw)
         self.device = device
         self._buf = None
         self._stream = None
-        if device is not None:
+        if device is not None and self.collective == "engine":
+            import torch
+            from . import beagle as _b
+            raw = _b.Beagle.__new__(_b.Beagle)
+            raw.lib, raw._f, raw.instance = self.local.engine, self.local.engine.fn, self.local.instance
+            if dist is not None and world_size > 1:
+                ident = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(raw.commUniqueId()), dtype=torch.uint8))
+                dist.broadcast(ident, src=0)
+                unique = bytes(ident.cpu().numpy().tobytes())
+            else:
+                unique = raw.commUniqueId()
+            raw.commInit(unique, rank, world_size)
+            self.local.set_engine_collective(True)
+        elif device is not None:
             import torch
             self._torch = torch
             self._stream = torch.cuda.Stream(device=device)
@@ -70,6 +93,8 @@ class ShardedTreeLikelihood:
 
     def getLogLikelihood(self):
         tl = self.local
+        if self.device is not None and self.collective == "engine":
+            return tl.getLogLikelihood()          # prepare / attempt (kernels, all-reduce) / finish on the global value: one call
         tl.prepare()
         while True:
             if self.device is not None:

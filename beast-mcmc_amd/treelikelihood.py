@@ -40,6 +40,7 @@ def host_library():
         lib.btlSetSiteModel.argtypes = [C.c_void_p, _DP, _DP]
         lib.btlSetBranchRates.argtypes = [C.c_void_p, _DP]
         lib.btlSetNodeHeight.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.btlRestoreNodeHeight.argtypes = [C.c_void_p, C.c_int, C.c_double]
         lib.btlMakeDirty.argtypes = [C.c_void_p]
         lib.btlSetRescalingFrequency.argtypes = [C.c_void_p, C.c_int]
         lib.btlGetLogLikelihood.argtypes = [C.c_void_p]
@@ -58,6 +59,8 @@ def host_library():
         lib.btlCumulativeScaleIndex.argtypes = [C.c_void_p]
         lib.btlCounters.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         lib.btlLastOperations.argtypes = [C.c_void_p, _IP, C.c_int]
+        lib.btlTimings.argtypes = [C.c_void_p, _DP]
+        lib.btlSetEngineCollective.argtypes = [C.c_void_p, C.c_int]
         _host = lib
     return _host
 
@@ -131,11 +134,30 @@ class BeagleTreeLikelihood:
     def set_node_height(self, node, height):
         self._chk(self.h.btlSetNodeHeight(self.ptr, node, height), "setNodeHeight")
 
+    def restore_node_height(self, node, height):
+        """The tree model's restore after a rejected height move: the height goes back, nothing becomes dirty."""
+        self._chk(self.h.btlRestoreNodeHeight(self.ptr, node, height), "restoreNodeHeight")
+
     def set_rescaling_frequency(self, f):
         self.h.btlSetRescalingFrequency(self.ptr, f)
 
     def makeDirty(self):
         self.h.btlMakeDirty(self.ptr)
+
+    def set_engine_collective(self, on=True):
+        """getLogLikelihood returns the sum over all ranks of the instance's communicator (sharding.py, collective="engine")."""
+        self.h.btlSetEngineCollective(self.ptr, int(bool(on)))
+
+    # Model parameters as ready-made C pointers: a chain proposes from a handful of parameter blocks, and converting six
+    # numpy arrays per evaluation costs more host time (27 us) than the engine's own updatePartials call
+    def model_handle(self, eig, freqs, rates, weights):
+        arrs = [_d(eig.evec), _d(eig.ievc), _d(eig.evals), _d(freqs), _d(rates), _d(weights)]
+        return (arrs, [a.ctypes.data_as(_DP) for a in arrs])
+
+    def apply_model(self, handle):
+        p = handle[1]
+        self.h.btlSetSubstitutionModel(self.ptr, p[0], p[1], p[2], p[3])
+        self.h.btlSetSiteModel(self.ptr, p[4], p[5])
 
     def getLogLikelihood(self):
         v = self.h.btlGetLogLikelihood(self.ptr)
@@ -176,6 +198,15 @@ class BeagleTreeLikelihood:
         keys = ["operations", "matrix_updates", "evaluations", "rescale_retries", "last_op_count",
                 "last_branch_count", "use_scale_factors", "ever_underflowed"]
         return dict(zip(keys, list(out)))
+
+    def host_phase_times(self):
+        """Development (BTL_TIMING=1 in the environment at creation): host microseconds per phase of calculateLogLikelihood summed
+        since the last call — tools/step_profile.py."""
+        out = (C.c_double * 8)()
+        on = self.h.btlTimings(self.ptr, out)
+        keys = ["traversal", "model_uploads", "updateTransitionMatrices", "updatePartials", "scale_factor_calls",
+                "weights_frequencies", "root_enqueue_and_wait"]
+        return dict(zip(keys, list(out))) if on else None
 
     def last_operations(self):
         buf = np.zeros((self.tip_count - 1) * 7, dtype=np.int32)

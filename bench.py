@@ -38,6 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TIMER_EVERY = 4            # the engine's HIP-event kernel timer brackets every 4th evaluation of a timed region (bench_single)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable with a copy kernel)
 KERNEL_SOURCES = ("kernels_walk4.hip", "walk4_fast_loop.inc", "kernels_mfma.hip", "kernels.hip", "planner.cpp", "engine_walk.cpp", "engine_levels.cpp", "engine_instance.cpp")
 
@@ -66,8 +67,10 @@ def prune_bytes_per_eval(wl):
 
 
 def perturbed_models(bm, wl, config):
-    """Two nearby substitution + site models per workload; a step alternates between them, as a chain's substitution- and
-    site-model moves would (every step uploads a DIFFERENT eigen system and category rates)."""
+    """THREE nearby substitution + site models per workload; a step takes the next one, as a chain's substitution- and
+    site-model moves would.  Three, because the caller flips between two eigen slots every step (BufferIndexHelper): with two
+    models each slot would receive the same values every time and the engine's unchanged-upload check (engine_abi.cpp
+    uploadIfChanged) would skip that upload; with three every slot gets values it did not hold before, every step."""
     import numpy as np
     from beast_mcmc_amd.inputs import substmodel
     from beast_mcmc_amd.inputs.siterates import GammaSiteRateModel
@@ -86,6 +89,13 @@ def perturbed_models(bm, wl, config):
     else:
         r2, w2 = wl.cat_rates, wl.cat_weights
     out.append((eig2, wl.freqs, np.asarray(r2, dtype=float), np.asarray(w2, dtype=float)))
+    # the third: the first model's rate matrix at a slightly different normalisation, a third shape parameter
+    eig3 = substmodel.EigenDecomposition(wl.eig.evec, wl.eig.ievc, np.asarray(wl.eig.evals) * (1 - 1e-6))
+    if wl.category_count > 1:
+        r3, w3 = GammaSiteRateModel(alpha=0.5 * (1 - 1e-6), gamma_categories=wl.category_count).category_rates_and_proportions()
+    else:
+        r3, w3 = wl.cat_rates, wl.cat_weights
+    out.append((eig3, wl.freqs, np.asarray(r3, dtype=float), np.asarray(w3, dtype=float)))
     return out
 
 
@@ -112,6 +122,7 @@ def main():
     ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
                     help="ranks: one process per GPU + torch.distributed all-reduce (default); library: one process, the engine's resource G+1")
     ap.add_argument("--no-library-route", action="store_true", help="do not append the in-library route's run to the line")
+    ap.add_argument("--no-side-records", action="store_true", help="no shard_point / partial_update sub-records (the rocprofv3 re-runs pass this)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run under rocprofv3 for roofline.traffic (the re-runs themselves pass this)")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -203,6 +214,12 @@ def main():
                 out["library_route"] = library_route(args, bm, wl, world, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC)
         except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
             out["library_route"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if (rank == 0 and out is not None and world == 1 and args.route == "ranks" and args.config == "A" and args.scale == 1.0
+            and not args.patterns and not args.no_side_records):
+        try:
+            out["shard_point"] = shard_point(args, bm, wl, torch, device, res, ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC)
+        except Exception as e:                                        # noqa: BLE001
+            out["shard_point"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ONE JSON line, and it is the LAST thing on stdout: libraries that print through C stdio (RCCL's version banner on the
     # multi-GPU path) are flushed first, so nothing of theirs can follow the line when the process exits
     import ctypes
@@ -326,7 +343,7 @@ def live_traffic(args, kernel):
     if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself being profiled"
     base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-library-route",
-            "--no-live-traffic", "--config", args.config, "--caller", args.caller, "--scale", str(args.scale), "--tree", args.tree,
+            "--no-live-traffic", "--no-side-records", "--config", args.config, "--caller", args.caller, "--scale", str(args.scale), "--tree", args.tree,
             "--rescaling", args.rescaling, "--cache", args.cache]
     if args.patterns:
         base += ["--patterns", str(args.patterns)]
@@ -393,16 +410,16 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         tl = BeagleTreeLikelihood(wl, **kw)
         local = tl
     models = perturbed_models(bm, wl, args.config)
+    handles = [local.model_handle(*m) for m in models]       # the parameter blocks as C pointers, made once (treelikelihood.py)
     site_buf = {"n": 0}
 
     def step(i):
         # one MCMC iteration's worth of host protocol (MarkovChain.java:207-263): storeState (buffer indices flip on the
         # next write), then a substitution-model + site-model move: everything dirty, a NEW eigen system and NEW rates
-        # uploaded, all 2T-2 matrices and all T-1 partials recomputed into the alternate buffers
-        eig, freqs, rates, weights = models[i & 1]
+        # uploaded (the next of three models: perturbed_models), all 2T-2 matrices and all T-1 partials recomputed into the
+        # alternate buffers
         local.storeState()
-        local.set_substitution_model(eig, freqs)
-        local.set_site_model(rates, weights)
+        local.apply_model(handles[i % 3])
         v = tl.getLogLikelihood()
         if args.caller == "btl":
             site_buf["n"] += local.getSiteLogLikelihoods().shape[0]
@@ -415,10 +432,14 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         step(i)
     raw = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
     raw.lib, raw._f, raw.instance = local.engine, local.engine.fn, local.instance
-    raw.kernelTimer(True)
+    # HIP events around the pruning launches of every TIMER_EVERY-th evaluation of the timed region (an event pair is two
+    # barrier packets on the stream: 12 us of GPU idle per bracketed evaluation, profiles/r04_experiments.txt)
+    raw.kernelTimer(TIMER_EVERY)
+    raw.kernelTimerCalls()
     elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
     stats = raw.walkStats()
     kernel_ms, launches = raw.kernelTimer(False)
+    timed_calls = max(1, raw.kernelTimerCalls())
     if dist is not None:
         kms = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
@@ -436,6 +457,12 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         other = {"caller": args.caller, "evals_per_s": round(n2 / e2, 3), "ms_per_step": round(1e3 * e2 / n2, 4)}
         args.caller = keep
 
+    partial = None
+    if world == 1 and args.route == "ranks" and not sharded and args.config in ("A", "D") and not args.no_side_records:
+        try:
+            partial = partial_update_point(bm, wl, tl, raw)
+        except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
+            partial = {"error": "%s: %s" % (type(e).__name__, e)}
     out = None
     if rank == 0:
         n_gpus = args.gpus if args.route == "library" else world
@@ -446,7 +473,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             shard = wl.shard(*tl.range) if sharded else wl
         s_, p_, c_ = shard.state_count, shard.pattern_count, shard.category_count
         alg = prune_bytes_per_eval(shard)                     # SURVEY 8d algorithmic bytes of this rank's pruning
-        kernel_s = kernel_ms * 1e-3 / max(1, args.steps)
+        kernel_s = kernel_ms * 1e-3 / timed_calls
         walk = s_ == 4 and stats["walks"] > 0
         if walk:
             moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps)
@@ -457,7 +484,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             # a <= 20-state instance defines instead of storing (engine counters)
             moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps) if stats["micro_ops"] > 0 else alg
             kname = ("k_walkT32" if stats["walks"] > 0 else "k_pruneTiled<5>") if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
-            launches_per_eval = launches / max(1, args.steps)
+            launches_per_eval = launches / timed_calls
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
         prof, prof_note = traffic_for(args, "k_walk" if stats["walks"] > 0 else "k_prune", world, rank)
         roofline = {
@@ -468,9 +495,10 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "bytes_per_eval": int(moved), "bytes_basis": "engine counters: stored + re-read partials, tip, scale vectors" if stats["micro_ops"] > 0 else "algorithmic (every node stored and re-read)",
             # context for `frac`: what a plain grid-strided copy kernel sustains on this chip (tools/hbm_write_probe.hip,
             # profiles/r02_probes.txt: 2 x 2.6 TB/s; the guide's best float4 copy: 6.3 TB/s)
-            "copy_rate_GBs_measured": 5200.0,
+            "copy_rate_GBs_probe": 5200.0,           # NOT measured in this run: tools/hbm_write_probe.hip, profiles/r02_probes.txt
             "algorithmic_bytes_per_eval": int(alg), "effective_GBs": round(alg / kernel_s / 1e9, 1) if kernel_s > 0 else None,
             "kernel_us_per_eval": round(kernel_s * 1e6, 2), "launches_per_eval": round(launches_per_eval, 2),
+            "kernel_timed_evaluations": int(timed_calls),
             "kernel_time_fraction_of_step": round(kernel_s * evals_per_s, 4),
         }
         if stats["micro_ops"] > 0:
@@ -507,12 +535,111 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_caller": other,
+            "partial_update": partial,
             "lnL": lnl, "lnL_first_eval": lnl0, "hbm_bytes_resident": int(raw.deviceBytes()),
             "evaluations_total": int(local.counters()["evaluations"]),
             "kernel_source_hash": kernel_source_hash(), "workload_generation_s": round(t_gen, 1),
         }
     tl.close()
     return out
+
+
+def shard_point(args, bm, wl, torch, device, res, ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC, patterns=12500):
+    """What ONE GPU of an 8-GPU job does per evaluation, measured on this GPU: the first `patterns` (= 1e5 / 8) patterns of the
+    metric's alignment through the MULTI-GPU code path — sharding.py's ShardedTreeLikelihood, the engine's device-side sum, the
+    RCCL all-reduce (a communicator of one rank: ncclAllReduce is issued and waited for like any other), the decision on the
+    global value — the same step protocol as the main line.  It bounds the 2/4/8-GPU points of the metric from below: an 8-GPU
+    evaluation cannot take less than this plus what the collective costs across real links."""
+    shard = wl.shard(0, min(patterns, wl.pattern_count))
+    kw = dict(resource_list=res, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    tl = ShardedTreeLikelihood(shard, 0, 1, dist=None, device=device, collective="engine", **kw)
+    local = tl.local
+    handles = [local.model_handle(*m) for m in perturbed_models(bm, shard, args.config)]
+
+    def step(i):
+        local.storeState()
+        local.apply_model(handles[i % 3])
+        return tl.getLogLikelihood()
+
+    step(0); step(1)
+    for i in range(10):
+        step(i)
+    n = max(200, args.steps)
+    per = []
+
+    def clocked(i):
+        t = time.perf_counter()
+        v = step(i)
+        per.append(time.perf_counter() - t)
+        return v
+
+    elapsed, lnl = timed_loop(torch, device, None, n, clocked)
+    stats_eval = local.counters()["evaluations"]
+    tl.close()
+    # the same steps on a plain single-GPU instance of the same shard: the value must be the same double
+    ref = BeagleTreeLikelihood(shard, **kw)
+    rh = [ref.model_handle(*m) for m in perturbed_models(bm, shard, args.config)]
+    v = None
+    for i in [0, 1] + list(range(10)) + list(range(n)):
+        ref.storeState(); ref.apply_model(rh[i % 3]); v = ref.getLogLikelihood()
+    ref.close()
+    per.sort()
+    return {"what": "one GPU's share of an 8-GPU evaluation (pattern shard of the metric's alignment), multi-GPU code path",
+            "patterns": shard.pattern_count, "value": round(n / elapsed, 3), "unit": "evals/s", "steps": n,
+            "ms_per_step": round(1e3 * elapsed / n, 4), "ms_per_step_median": round(1e3 * per[len(per) // 2], 4),
+            "ms_per_step_max": round(1e3 * per[-1], 4),
+            "collective": "ncclAllReduce(1 double) inside the engine on its stream, communicator of 1 rank, inside every timed step",
+            "lnL": lnl, "lnL_equals_unsharded_instance": bool(lnl == v), "evaluations_total": int(stats_eval)}
+
+
+def partial_update_point(bm, wl, tl, raw, moves=300):
+    """What a chain issues most (TreeDataLikelihood.java:247-260): ONE node height changes, the path from that node to the root
+    is recomputed — its three branch matrices, then the operations up to the root —, half of the proposals are rejected
+    (restoreState: index flips only).  Microseconds per move (proposal + the 50 % restore), operations and bytes moved per move."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    t_, n_ = wl.tree.tip_count, wl.tree.node_count
+    height = np.array(wl.tree.height, dtype=float)
+    parent = np.full(n_, -1)
+    for n in range(t_, n_):
+        parent[int(wl.tree.left[n])] = n; parent[int(wl.tree.right[n])] = n
+
+    def propose():
+        node = int(rng.integers(t_, n_))
+        while parent[node] < 0:
+            node = int(rng.integers(t_, n_))
+        lo = max(height[int(wl.tree.left[node])], height[int(wl.tree.right[node])])
+        hi = height[parent[node]]
+        return node, lo + (hi - lo) * float(rng.uniform(0.05, 0.95))          # stays between its children and its parent
+
+    def run(k):
+        for _ in range(k):
+            node, h = propose()
+            tl.storeState()
+            tl.set_node_height(node, h)
+            tl.getLogLikelihood()
+            if rng.random() < 0.5:
+                tl.restoreState()
+                tl.restore_node_height(node, float(height[node]))      # (the tree model's own restore)
+                tl.getLogLikelihood()                                   # known: no engine call
+            else:
+                height[node] = h
+
+    run(30)
+    raw.kernelTimer(False)
+    c0 = tl.counters()
+    t0 = time.perf_counter()
+    run(moves)
+    dt = time.perf_counter() - t0
+    c1 = tl.counters()
+    stats = raw.walkStats()
+    p_, c_, s_ = wl.pattern_count, wl.category_count, wl.state_count
+    return {"what": "one node-height move: path to the root recomputed, 50 % of the proposals restored",
+            "us_per_branch_move": round(1e6 * dt / moves, 2), "moves": moves,
+            "ops_per_move": round((c1["operations"] - c0["operations"]) / moves, 2),
+            "matrices_per_move": round((c1["matrix_updates"] - c0["matrix_updates"]) / moves, 2),
+            "bytes_per_move": int(moved_bytes(stats, p_, c_, s_) / moves) if s_ == 4 else None,
+            "micro_ops_per_move": round(stats["micro_ops"] / moves, 1), "stored_per_move": round(stats["stored"] / moves, 2)}
 
 
 def library_route(args, bm, wl, n, torch, device, BeagleTreeLikelihood, RESCALE_DYNAMIC):
@@ -523,22 +650,34 @@ def library_route(args, bm, wl, n, torch, device, BeagleTreeLikelihood, RESCALE_
     os.environ["BEAGLE_MI355_SHARDS"] = str(n)
     tl = BeagleTreeLikelihood(wl, resource_list=(torch.cuda.device_count() + 1,), rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
     models = perturbed_models(bm, wl, args.config)
+    handles = [tl.model_handle(*m) for m in models]
 
     def step(i):
-        eig, freqs, rates, weights = models[i & 1]
         tl.storeState()
-        tl.set_substitution_model(eig, freqs)
-        tl.set_site_model(rates, weights)
+        tl.apply_model(handles[i % 3])
         return tl.getLogLikelihood()
 
     step(0); step(1)
-    for i in range(min(args.warmup, 10)):
+    for i in range(max(10, min(args.warmup, 20))):
         step(i)
-    n2 = max(10, args.steps // 2)
-    elapsed, lnl = timed_loop(torch, device, None, n2, step)
+    # >= 50 timed steps whatever --steps says: a 10-step mean is at the mercy of ONE slow posted call (BENCH_r03: 673
+    # evals/s here beside 1 302 on the rank route); every step is clocked, and the line carries the median and the
+    # slowest step next to the mean
+    n2 = max(50, args.steps // 2)
+    per = []
+
+    def clocked(i):
+        t = time.perf_counter()
+        v = step(i)
+        per.append(time.perf_counter() - t)
+        return v
+
+    elapsed, lnl = timed_loop(torch, device, None, n2, clocked)
     tl.close()
+    per.sort()
     return {"route": "library", "n_gpus": n, "value": round(n2 / elapsed, 3), "unit": "evals/s", "steps": n2,
-            "ms_per_step": round(1e3 * elapsed / n2, 4), "lnL": lnl}
+            "ms_per_step": round(1e3 * elapsed / n2, 4), "ms_per_step_median": round(1e3 * per[len(per) // 2], 4),
+            "ms_per_step_max": round(1e3 * per[-1], 4), "ms_per_step_p90": round(1e3 * per[(len(per) * 9) // 10], 4), "lnL": lnl}
 
 
 def library_route_subprocess(args, n, limit=300):
@@ -547,7 +686,7 @@ def library_route_subprocess(args, n, limit=300):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
                                                            "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-    cmd = [sys.executable, os.path.abspath(__file__), "--route", "library", "--gpus", str(n), "--steps", str(max(10, args.steps // 2)),
+    cmd = [sys.executable, os.path.abspath(__file__), "--route", "library", "--gpus", str(n), "--steps", str(max(50, args.steps // 2)),
            "--warmup", str(min(args.warmup, 10)), "--config", args.config, "--scale", str(args.scale), "--tree", args.tree,
            "--rescaling", args.rescaling, "--cache", args.cache, "--no-cpu-baseline", "--no-live-traffic", "--no-library-route"]
     if args.patterns:
@@ -588,14 +727,16 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
     lnl0 = step(0)
     for i in range(args.warmup):
         step(i)
-    tl.b.kernelTimer(True)
+    tl.b.kernelTimer(TIMER_EVERY)
+    tl.b.kernelTimerCalls()
     elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
     stats = tl.b.walkStats()
     kernel_ms, _ = tl.b.kernelTimer(False)
+    timed_calls = max(1, tl.b.kernelTimerCalls())
     out = None
     if rank == 0:
         p_, c_ = local_pw.pattern_count, tl.C
-        kernel_s = kernel_ms * 1e-3 / max(1, args.steps)
+        kernel_s = kernel_ms * 1e-3 / timed_calls
         # every partition's op touches only its own pattern range: bytes = sum over partitions
         moved = 0.0
         per_part = {key: v / max(1, args.steps) / k for key, v in stats.items()}

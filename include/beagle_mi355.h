@@ -306,6 +306,17 @@ int beagleMi355SetStream(int instance, void* hipStream);
  * double over RCCL (DESIGN.md, row e). */
 int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, int categoryWeightsIndex,
                                       int stateFrequenciesIndex, int cumulativeScaleIndex, void* deviceOut);
+/* One process per GPU, unique site patterns sharded over the processes (the job BEAST runs as -beagle_instances G,
+ * TreeDataLikelihoodParser.java:205-278, with its Java-side sum): the sum over the shards as ONE all-reduce inside the engine.
+ * beagleMi355GetCommUniqueId fills 128 bytes on one rank; the host hands them to every rank (any channel) and each calls
+ * beagleMi355CommInit(instance, id, rank, rankCount) — RCCL over xGMI, one communicator per instance.  Then
+ * beagleMi355CalculateRootLogLikelihoodsAllReduce is beagleCalculateRootLogLikelihoods with count == 1 whose result is the
+ * sum over ALL ranks: reduction kernel, ncclAllReduce of one double and the hand-over to the host are enqueued back to back on
+ * the instance's stream; every rank gets the same value (BEAGLE_ERROR_FLOATING_POINT when it is NaN, on every rank alike). */
+int beagleMi355GetCommUniqueId(void* out128);
+int beagleMi355CommInit(int instance, const void* uniqueId128, int rank, int rankCount);
+int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferIndex, int categoryWeightsIndex,
+                                      int stateFrequenciesIndex, int cumulativeScaleIndex, double* outGlobalSum);
 /* getPartials for `count` buffers in one call: out = [count][C][P][S] (API layout), scale factors folded in where
  * scaleIndices[k] != BEAGLE_OP_NONE (scaleIndices may be NULL).  One batched materialisation of virtual buffers, device-side
  * layout conversion, pinned copies, one synchronisation per 256 MiB — for hosts that read many nodes per sample
@@ -322,6 +333,10 @@ int beagleMi355Synchronize(int instance);
  * the pruning launches of every updatePartials call while enabled; returns accumulated milliseconds and the
  * number of launches since the last reset. */
 int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* outLaunches);
+/* enable = N > 1 brackets every N-th updatePartials call only (an event pair costs the stream two barrier packets, ~12 us of
+ * an evaluation): milliseconds and launches then cover those calls; beagleMi355KernelTimerCalls returns how many updatePartials
+ * calls were bracketed since it was last asked (and resets the count) — the divisor for "kernel time per evaluation". */
+int beagleMi355KernelTimerCalls(int instance, long* outCalls);
 /* Traffic counters of the 4-state pattern walk since the last beagleMi355KernelTimer call: out[0] micro-operations,
  * [1] partials buffers stored, [2] partials buffers read from memory, [3] tip-state vectors read, [4] scale-factor
  * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the
@@ -364,6 +379,8 @@ typedef struct BeagleApi {
     int (*getSiteLogLikelihoods)(int, double*);
     /* optional (NULL when the engine has no device memory): beagleMi355CalculateRootLogLikelihoodsDevice */
     int (*calculateRootLogLikelihoodsDevice)(int, int, int, int, int, void*);
+    /* optional (NULL without a communicator layer): beagleMi355CalculateRootLogLikelihoodsAllReduce */
+    int (*calculateRootLogLikelihoodsAllReduce)(int, int, int, int, int, double*);
 } BeagleApi;
 
 const BeagleApi* beagleGetApiTable(void);

@@ -102,3 +102,12 @@ def sample_with_tail(pattern_count, n_sample, seed):
     rnd = np.random.default_rng(seed).choice(pattern_count, size=min(n_sample, pattern_count), replace=False)
     tail = np.arange(max(0, pattern_count - 256), pattern_count)
     return np.unique(np.concatenate([rnd, tail]))
+
+
+def walk_stats(tl):
+    """The engine's walk counters for the instance behind a BeagleTreeLikelihood (include/beagle_mi355.h beagleMi355WalkStats):
+    which kernel a list ran on — 'walks' pattern-walk launches, of them 'fast_walks' on the assembly loop k_walk4_fast."""
+    import beast_mcmc_amd as bm
+    raw = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
+    raw.lib, raw._f, raw.instance = tl.engine, tl.engine.fn, tl.instance
+    return raw.walkStats()

@@ -109,7 +109,41 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
             }
         }
     }
-    for (const PlanSeg& sg : plan.segs) {
+    // One launch may run every slice of the plan side by side, each workgroup first waiting for the slices in its dependency
+    // list (planner.h PlanSeg): every stored result a slice reads must come from a slice it waits for, of an earlier wave, and
+    // the launch order must put every slice behind the ones it waits for.
+    {
+        CHECK(plan.launchOrder.size() == plan.segs.size(), plan.prog[0], 0);
+        std::vector<int> pos(plan.segs.size(), -1);
+        for (size_t i = 0; i < plan.launchOrder.size(); i++) { CHECK(pos[plan.launchOrder[i]] < 0, plan.prog[0], (int)i); pos[plan.launchOrder[i]] = (int)i; }
+        for (size_t a = 0; a < plan.segs.size(); a++) {
+            const PlanSeg& sg = plan.segs[a];
+            for (int d = sg.depStart; d < sg.depStart + sg.depCount; d++) {
+                const int b = plan.deps[d];
+                CHECK(plan.segs[b].wave < sg.wave && plan.segs[b].partition == sg.partition, plan.prog[sg.progStart], (int)a);
+                CHECK(pos[b] < pos[a], plan.prog[sg.progStart], (int)a);
+                CHECK(plan.segs[b].tail >= plan.segs[b].progCount + sg.tail, plan.prog[sg.progStart], (int)a);
+            }
+            for (size_t b = 0; b < plan.segs.size(); b++) {
+                const PlanSeg& ob = plan.segs[b];
+                if (a == b || ob.partition != sg.partition) continue;
+                bool waits = false;
+                for (int d = sg.depStart; d < sg.depStart + sg.depCount; d++) waits = waits || plan.deps[d] == (int)b;
+                if (waits) continue;
+                for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
+                    const MicroOp& m = plan.prog[k];
+                    for (int q = ob.progStart; q < ob.progStart + ob.progCount; q++) {
+                        const int st = plan.prog[q].storeBuf;
+                        if (st < 0) continue;
+                        CHECK(!(m.k1 == PK_MEM && m.a1 == st), m, k);
+                        CHECK(!(m.k2 == PK_MEM && m.a2 == st), m, k);
+                    }
+                }
+            }
+        }
+    }
+    for (int si : plan.launchOrder) {
+        const PlanSeg& sg = plan.segs[si];
         for (int p = partStart[sg.partition]; p < partEnd[sg.partition]; p++) {
             V4 ACC[8], H[3][8];
             for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {

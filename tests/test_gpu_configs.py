@@ -31,39 +31,65 @@ REL_TOL = 1e-10
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def sampled_check(wl, oracle_lib, n_sample, seed):
-    g = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+def sampled_check(wl, oracle_lib, n_sample, seed, rescaling=RESCALE_DYNAMIC, kernel=None):
+    """kernel: which kernel the lists must have run on (the engine's own counters; a silent fall-back to the C++ walk or to the
+    level kernels would otherwise stay green) — "fast": every launch the assembly loop k_walk4_fast; "t32": the T32 walk
+    k_walkT32 for the read-mode evaluation (its write-mode lists run level by level); "levels": no walk at all."""
+    g = BeagleTreeLikelihood(wl, rescaling=rescaling, delay_rescaling=False)
     lnl = g.getLogLikelihood()                              # write mode: every op recomputes its scale factors
     assert np.isfinite(lnl)
+    st1 = helpers.walk_stats(g)
     site = g.getSiteLogLikelihoods()
     assert helpers.rel_err(float(np.dot(site, wl.weights)), lnl) <= 1e-12
     idx = helpers.sample_with_tail(wl.pattern_count, n_sample, seed)      # (the last 256 patterns are always in)
     sub = synth.Workload(wl.name + "-sample", wl.tree, wl.eig, wl.freqs, wl.cat_rates, wl.cat_weights,
                          np.ascontiguousarray(wl.tip_states[:, idx]), wl.weights[idx], wl.state_count)
-    o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+    o = BeagleTreeLikelihood(sub, library=oracle_lib, rescaling=rescaling, delay_rescaling=False)
     o.getLogLikelihood()
     so = o.getSiteLogLikelihoods()
     assert np.max(np.abs(site[idx] - so) / np.abs(so)) <= REL_TOL
-    g.makeDirty()                                           # read mode: the stored factors divide
+    g.makeDirty()                                           # DYNAMIC: read mode, the stored factors divide; ALWAYS: write mode again
     again = g.getLogLikelihood()
+    st2 = helpers.walk_stats(g)
     site2 = g.getSiteLogLikelihoods()
     assert helpers.rel_err(again, lnl) <= 1e-12
     assert np.max(np.abs(site2[idx] - so) / np.abs(so)) <= REL_TOL
     o.makeDirty()
     assert helpers.rel_err(float(np.dot(site2[idx], wl.weights[idx])), o.getLogLikelihood()) <= REL_TOL
+    if kernel == "fast":
+        assert st1["walks"] > 0 and st1["fast_walks"] == st1["walks"], st1
+        assert st2["walks"] > st1["walks"] and st2["fast_walks"] == st2["walks"], st2
+    elif kernel == "t32":
+        if rescaling == RESCALE_DYNAMIC:                    # (the read-mode evaluation is the walk's; ALWAYS never leaves write mode)
+            assert st2["walks"] > st1["walks"] and st2["fast_walks"] == 0, (st1, st2)
+        else:
+            assert st2["fast_walks"] == 0, st2
+    elif kernel == "levels":
+        assert st2["walks"] == 0, st2
     o.close(); g.close()
+
+
+@pytest.mark.parametrize("rescaling", [RESCALE_DYNAMIC, RESCALE_ALWAYS])
+def test_config_a_full_size_under_the_benchmark_protocol(rescaling, oracle_lib):
+    """BASELINE config A at its full size under the protocol bench.py times (beagle.delay.scaling off): DYNAMIC — the first
+    evaluation rescales every node in write mode, the next one reads the stored factors (BeagleTreeLikelihood.java:883-910,
+    1013-1026) — and ALWAYS (PartialsRescalingScheme.java:34-42: write mode every evaluation); site values against the oracle
+    sample in both evaluations, every launch on the assembly loop."""
+    wl = synth.config_a()
+    assert (wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count) == (1000, 100000, 4, 4)
+    sampled_check(wl, oracle_lib, 1000, seed=4, rescaling=rescaling, kernel="fast")
 
 
 def test_config_b_sampled_against_oracle(oracle_lib):
     wl = synth.config_b()
     assert (wl.tip_count, wl.pattern_count, wl.state_count) == (500, 50000, 20)
-    sampled_check(wl, oracle_lib, 500, seed=5)
+    sampled_check(wl, oracle_lib, 500, seed=5, kernel="t32")
 
 
 def test_config_c_sampled_against_oracle(oracle_lib):
     wl = synth.config_c()
     assert (wl.tip_count, wl.pattern_count, wl.state_count) == (200, 20000, 61)
-    sampled_check(wl, oracle_lib, 200, seed=6)
+    sampled_check(wl, oracle_lib, 200, seed=6, kernel="levels")
 
 
 _MIDSIZE = r"""
@@ -103,6 +129,8 @@ def test_config_d_whole_alignment_against_oracle(categories, oracle_lib):
         o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=rescaling, delay_rescaling=False)
         a, b = g.getLogLikelihood(), o.getLogLikelihood()
         assert np.isfinite(b) and helpers.rel_err(a, b) <= REL_TOL, (categories, rescaling, a, b)
+        st = helpers.walk_stats(g)
+        assert st["walks"] > 0 and st["fast_walks"] == st["walks"], st       # every launch on the assembly loop
         sa, sb = g.getSiteLogLikelihoods(), o.getSiteLogLikelihoods()
         assert np.max(np.abs(sa - sb) / np.abs(sb)) <= REL_TOL
         g.close(); o.close()
@@ -116,6 +144,8 @@ def test_config_e_partitioned_instance_against_per_partition_oracle(always_resca
     by_part, total = tl.calculate()
     site = tl.getSiteLogLikelihoods()
     by_part2, total2 = tl.calculate()                       # the flipped buffers: same numbers
+    st = tl.b.walkStats()
+    assert st["walks"] > 0 and st["fast_walks"] == st["walks"], st           # every launch on the assembly loop
     tl.close()
     assert total2 == total and np.array_equal(by_part, by_part2)
     off, expect = 0, []

@@ -351,3 +351,24 @@ def test_gradient_benchmark_sized_tree(oracle_lib):
     assert helpers.rel_err(lg, lo) <= REL_TOL
     close(gg, go, "gradient, 1000 taxa")
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("S", [20, 61])
+def test_gradient_after_set_pattern_partitions(S, oracle_lib):
+    """setPatternPartitions re-allocates the matrix block of an instance with virtual buffers; on the T32 layout the identity
+    matrix and the transposed-matrix scratch of the two-pass pre-order path sit behind the snapshot slots and have to move
+    with it (round-3 advisor finding: they were left behind and the next pre-order pass read and wrote out of bounds)."""
+    wl = helpers.random_workload(8, 100, S, 2, seed=77 + S)
+    g = BranchGradient(wl)
+    o = BranchGradient(wl, library=oracle_lib)
+    g.b.setPatternPartitions(1, np.zeros(wl.pattern_count, dtype=np.int32))
+    for _ in range(2):
+        lo, go = o.gradient()
+        lg, gg = g.gradient()
+        assert helpers.rel_err(lg, lo) <= REL_TOL
+        close(gg, go, "gradient after setPatternPartitions")
+    for n in range(g.N):
+        if n != wl.tree.root:
+            a, b = g.pre_partials(n).reshape(2, wl.pattern_count, S), o.pre_partials(n).reshape(2, wl.pattern_count, S)
+            ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
+            assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n

@@ -49,7 +49,14 @@ S_FIRST = 20
 B_X, B_T1, B_T2, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 4, 12, 14
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
 
-STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " nt")      # cache policy suffix of the result stores
+# Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
+# in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
+# line another XCD's L2 may hold newer — what lets the slices of a program run in ONE launch and hand results over through
+# flags (kernels_walk4.hip k_walk4_fast) without writing back or invalidating a whole L2 per workgroup (buffer_wbl2 /
+# buffer_inv per workgroup: 672 against 126 us on the 12 500-pattern shard, profiles/r04_experiments.txt).  Both kinds of
+# access stream through HBM once anyway.
+STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " sc1 nt")
+LOAD_POLICY = os.environ.get("WALK4_LOAD_POLICY", " sc1")
 # A/B switches (tools/build_variant.sh): both give the same bits
 # (measured on config A and the 12 500-pattern shard, profiles/r03_experiments.txt: neither changes the time — the loop is not
 # bound by its vector-instruction count or by LDS round trips — so both stay off and the round-2 stream is what ships)
@@ -235,10 +242,10 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
     e("s_cbranch_scc1 %s" % L("x" + tag))
     e(L("xb" + tag) + ":")
     blk = [L("x" + tag) + ":",
-           "global_load_dwordx4 %s, %s, %s" % (v(X, 4), v(PA), s(D, 2)),
-           "global_load_dwordx4 %s, %s, %s offset:16" % (v(X + 4, 4), v(PA), s(D, 2)),
-           "global_load_dwordx4 %s, %s, %s" % (v(X + 8, 4), v(PB), s(D, 2)),
-           "global_load_dwordx4 %s, %s, %s offset:16" % (v(X + 12, 4), v(PB), s(D, 2)),
+           "global_load_dwordx4 %s, %s, %s%s" % (v(X, 4), v(PA), s(D, 2), LOAD_POLICY),
+           "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 4, 4), v(PA), s(D, 2), LOAD_POLICY),
+           "global_load_dwordx4 %s, %s, %s%s" % (v(X + 8, 4), v(PB), s(D, 2), LOAD_POLICY),
+           "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 12, 4), v(PB), s(D, 2), LOAD_POLICY),
            "s_branch %s" % L("xb" + tag)]
     outofline.append(blk)
 
@@ -267,10 +274,10 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
     outofline.append([L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
     c0 = c0set if SCOL else None
     m2blk = [L("m2" + tag) + ":",                    # both children in memory: the second one is loaded into ACC, synchronously
-             "global_load_dwordx4 %s, %s, %s" % (v(ACC, 4), v(PA), s(SSRC2, 2)),
-             "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2)),
-             "global_load_dwordx4 %s, %s, %s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2)),
-             "global_load_dwordx4 %s, %s, %s offset:16" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2)),
+             "global_load_dwordx4 %s, %s, %s%s" % (v(ACC, 4), v(PA), s(SSRC2, 2), LOAD_POLICY),
+             "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2), LOAD_POLICY),
+             "global_load_dwordx4 %s, %s, %s%s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2), LOAD_POLICY),
+             "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2), LOAD_POLICY),
              "s_waitcnt vmcnt(0)",
              "s_branch %s" % L("m2b" + tag)]
     if LDSBATCH:

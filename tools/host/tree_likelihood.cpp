@@ -15,10 +15,11 @@
 //   rescaling schemes         src/dr/evomodel/treelikelihood/PartialsRescalingScheme.java:34-42
 //
 // It holds no likelihood arithmetic: every O(patterns) operation is a call through BeagleApi.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <vector>
 #include "../../include/beagle_mi355.h"
 
@@ -76,10 +77,20 @@ struct TreeLikelihood {
     std::vector<int> branchUpdateIndices, operations, probIdx;
     std::vector<double> branchLengths;
     int branchUpdateCount = 0, operationCount = 0;
-    std::map<int, std::vector<int>> levelOps;   // level -> flat op tuples (reverse level order)
+    std::vector<std::vector<int>> levelOps;     // level -> flat op tuples (reverse level order); kept across evaluations (no allocation in the steady state)
+    int levelsUsed = 0;
 
     long totalOperationCount = 0, totalMatrixUpdateCount = 0, totalEvaluations = 0, totalRescaleRetries = 0;
     int lastError = 0;
+    // development (BTL_TIMING=1): host wall clock per phase of an evaluation, microseconds summed over the evaluations
+    // since the last btlTimings(reset): traversal, model uploads, updateTransitionMatrices, updatePartials, scale-factor
+    // calls, weights + frequencies, root (enqueue + wait)
+    bool timing = getenv("BTL_TIMING") != nullptr;
+    double phaseUs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef std::chrono::steady_clock Clock;
+    Clock::time_point mark;
+    void tick() { if (timing) mark = Clock::now(); }
+    void tock(int k) { if (timing) { const Clock::time_point n = Clock::now(); phaseUs[k] += std::chrono::duration<double, std::micro>(n - mark).count(); mark = n; } }
 
     void updateAllNodes() { std::fill(updateNode.begin(), updateNode.end(), 1); likelihoodKnown = false; }
 
@@ -127,6 +138,8 @@ struct TreeLikelihood {
                     std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], op, sizeof(op));
                     operationCount++;
                 } else {
+                    if (level >= (int)levelOps.size()) levelOps.resize(level + 1);
+                    if (level >= levelsUsed) levelsUsed = level + 1;
                     std::vector<int>& v = levelOps[level];
                     v.insert(v.end(), op, op + BEAGLE_OP_COUNT);
                 }
@@ -142,12 +155,14 @@ struct TreeLikelihood {
         if (traversal == POST_ORDER) {
             traverse(root, flip, -1);
         } else {
-            levelOps.clear();
+            for (int l = 0; l < levelsUsed; l++) levelOps[l].clear();
+            levelsUsed = 0;
             traverse(root, flip, 0);
-            for (auto it = levelOps.rbegin(); it != levelOps.rend(); ++it) {   // deepest level first
-                std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], it->second.data(),
-                            it->second.size() * sizeof(int));
-                operationCount += (int)(it->second.size() / BEAGLE_OP_COUNT);
+            for (int l = levelsUsed - 1; l >= 0; l--) {                          // deepest level first
+                const std::vector<int>& v = levelOps[l];
+                if (v.empty()) continue;
+                std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], v.data(), v.size() * sizeof(int));
+                operationCount += (int)(v.size() / BEAGLE_OP_COUNT);
             }
         }
     }
@@ -179,7 +194,9 @@ struct TreeLikelihood {
         }
         if (scheme == SCHEME_NONE) { useScaleFactors = false; recomputeScaleFactors = false; }
 
+        tick();
         runTraversal(true);
+        tock(0);
 
         int rc;
         if (updateSubstitutionModel) {
@@ -191,6 +208,7 @@ struct TreeLikelihood {
             rc = api->setCategoryRates(inst, catRates.data());
             if (rc) return lastError = rc;
         }
+        tock(1);
         if (branchUpdateCount > 0) {
             probIdx.resize(branchUpdateCount);
             for (int i = 0; i < branchUpdateCount; i++) probIdx[i] = matrixBufferHelper.getOffsetIndex(branchUpdateIndices[i]);
@@ -199,14 +217,22 @@ struct TreeLikelihood {
             if (rc) return lastError = rc;
             totalMatrixUpdateCount += branchUpdateCount;
         }
+        tock(2);
         firstRescaleAttempt = true;
         return 0;
     }
 
+    // pattern-sharded job, one process per GPU: the root sum is all-reduced INSIDE the engine (include/beagle_mi355.h
+    // beagleMi355CalculateRootLogLikelihoodsAllReduce) and every rank gets the global value, so the whole evaluation —
+    // including the rescale-and-retry decision, taken on that global value by every rank alike — is one call here
+    bool engineCollective = false;
+
     int attempt(void* deviceOut, double* hostOut) {
+        tick();
         int rc = api->updatePartials(inst, operations.data(), operationCount, BEAGLE_OP_NONE);
         if (rc) return lastError = rc;
         totalOperationCount += operationCount;
+        tock(3);
 
         const int rootIndex = partialBufferHelper.getOffsetIndex(root);
         int cumulateScaleBufferIndex = BEAGLE_OP_NONE;
@@ -222,23 +248,32 @@ struct TreeLikelihood {
                 cumulateScaleBufferIndex = scaleBufferHelper.getOffsetIndex(internalNodeCount);
             }
         }
+        tock(4);
         // "these could be set only when they change but store/restore would need to be considered" (:1028)
         rc = api->setCategoryWeights(inst, 0, catWeights.data());
         if (rc) return lastError = rc;
         rc = api->setStateFrequencies(inst, 0, freqs.data());
         if (rc) return lastError = rc;
+        tock(5);
 
         const int zero = 0;
         if (deviceOut) {
             if (!api->calculateRootLogLikelihoodsDevice) return lastError = BEAGLE_ERROR_NO_IMPLEMENTATION;
             rc = api->calculateRootLogLikelihoodsDevice(inst, rootIndex, 0, 0, cumulateScaleBufferIndex, deviceOut);
             if (rc) return lastError = rc;
+        } else if (engineCollective) {
+            if (!api->calculateRootLogLikelihoodsAllReduce) return lastError = BEAGLE_ERROR_NO_IMPLEMENTATION;
+            double sum = 0.0;
+            rc = api->calculateRootLogLikelihoodsAllReduce(inst, rootIndex, 0, 0, cumulateScaleBufferIndex, &sum);
+            if (rc != 0 && rc != BEAGLE_ERROR_FLOATING_POINT) return lastError = rc;
+            *hostOut = sum;
         } else {
             double sum = 0.0;
             rc = api->calculateRootLogLikelihoods(inst, &rootIndex, &zero, &zero, &cumulateScaleBufferIndex, 1, &sum);
             if (rc != 0 && rc != BEAGLE_ERROR_FLOATING_POINT) return lastError = rc;   // BeagleJNIImpl tolerates -8
             *hostOut = sum;
         }
+        tock(6);
         totalEvaluations++;
         return 0;
     }
@@ -420,6 +455,14 @@ int btlSetNodeHeight(void* h, int node, double height) {
     t->likelihoodKnown = false;
     return 0;
 }
+// The tree model's own restore after a rejected height move (TreeModel.restoreState: the likelihood's restoreState has put the
+// buffer indices back; the heights are the tree's): no node becomes dirty.
+int btlRestoreNodeHeight(void* h, int node, double height) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    if (node < 0 || node >= t->nodeCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    t->height[node] = height;
+    return 0;
+}
 int btlMakeDirty(void* h) { ((TreeLikelihood*)h)->updateAllNodes(); return 0; }
 int btlSetRescalingFrequency(void* h, int f) { ((TreeLikelihood*)h)->rescalingFrequency = f; return 0; }
 
@@ -436,6 +479,8 @@ int btlFinish(void* h, double globalLogL) {
     t->logLikelihood = v; t->likelihoodKnown = true;
     return 1;
 }
+// 1: getLogLikelihood's root sum is the engine's all-reduce over the ranks of the instance's communicator (beagleMi355CommInit)
+int btlSetEngineCollective(void* h, int on) { ((TreeLikelihood*)h)->engineCollective = on != 0; return 0; }
 int btlStoreState(void* h) { ((TreeLikelihood*)h)->storeState(); return 0; }
 int btlRestoreState(void* h) { ((TreeLikelihood*)h)->restoreState(); return 0; }
 int btlGetSiteLogLikelihoods(void* h, double* out) {
@@ -457,6 +502,12 @@ int btlCounters(void* h, long* out8) {
     out8[3] = t->totalRescaleRetries; out8[4] = t->operationCount; out8[5] = t->branchUpdateCount;
     out8[6] = t->useScaleFactors; out8[7] = t->everUnderflowed;
     return 0;
+}
+// development: the per-phase host times (TreeLikelihood::phaseUs), then reset
+int btlTimings(void* h, double* out8) {
+    TreeLikelihood* t = (TreeLikelihood*)h;
+    for (int k = 0; k < 8; k++) { out8[k] = t->phaseUs[k]; t->phaseUs[k] = 0.0; }
+    return t->timing ? 1 : 0;
 }
 // last operation list (7 ints per op), for tests that assert the call protocol
 int btlLastOperations(void* h, int* out, int maxOps) {

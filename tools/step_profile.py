@@ -40,6 +40,7 @@ def step(i):
 for i in range(12):
     step(i)
 acc.clear()
+tl.host_phase_times()
 N = 50
 t0 = time.perf_counter()
 for i in range(N):
@@ -49,4 +50,9 @@ print("step %.1f us" % (1e6 * total / N))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print("  %-52s %8.1f us" % (k, 1e6 * v / N))
 print("  %-52s %8.1f us" % ("(python outside Beagle calls)", 1e6 * (total - sum(acc.values())) / N))
+ph = tl.host_phase_times()
+if ph:
+    print("inside getLogLikelihood (host driver, BTL_TIMING=1):")
+    for k, v in ph.items():
+        print("  %-52s %8.1f us" % (k, v / N))
 tl.close()
