@@ -124,7 +124,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:

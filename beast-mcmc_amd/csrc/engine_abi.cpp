@@ -329,8 +329,14 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
-    if (in->walk && in->fuseWaves && in->fastWalk)
-        in->planner.chunkTopOps = getenv("BEAGLE_MI355_CHUNK_TOP") ? atoi(getenv("BEAGLE_MI355_CHUNK_TOP")) : 0;
+    if (in->walk && in->fuseWaves && in->fastWalk) {
+        in->planner.chunkTopOps = getenv("BEAGLE_MI355_CHUNK_TOP") ? atoi(getenv("BEAGLE_MI355_CHUNK_TOP")) : 16;
+        // slices the chip holds side by side: 4 workgroups per CU over the pattern groups of a slice (planner.h launchMachines)
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        in->planner.launchMachines = (double)(4 * cus) / (double)std::max(1, (patternCount + 127) / 128);
+        if (getenv("BEAGLE_MI355_SCHED_SIM") && atoi(getenv("BEAGLE_MI355_SCHED_SIM")) == 0) in->planner.launchMachines = 0.0;
+    }
     // result words live in coherent, device-mapped host memory: the final reduction kernel writes the sum straight into it
     // and the host only waits for the stream (no device-to-host copy behind the last kernel)
     ok = ok && hipHostMalloc((void**)&in->hResult, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -715,6 +721,16 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* U, c
     GET_INSTANCE(instance);
     if (badIndex(eigenIndex, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t S = in->S, nLambda = in->eigenComplex ? 2 * S : S, stride = 2 * S * S + nLambda;
+    if (in->eigenComplex) {
+        // imaginary parts come as adjacent conjugate pairs (b, -b) — ComplexSubstitutionModel.java:121-173 walks them that way, and
+        // the kernel (kernels.hip iexpEntry) reads the row after a pair's first row: a lone or unmatched entry is refused here
+        for (size_t k = 0; k < S; k++) {
+            const double im = lambda[S + k];
+            if (im == 0.0) continue;
+            if (k + 1 >= S || lambda[S + k + 1] != -im) return BEAGLE_ERROR_OUT_OF_RANGE;
+            k++;
+        }
+    }
     std::vector<double> pack(stride);
     memcpy(&pack[0], U, S * S * sizeof(double));
     memcpy(&pack[S * S], Uinv, S * S * sizeof(double));
@@ -1291,6 +1307,20 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
         HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
         in->events.emplace_back(a, b);
     }
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355GetDimensions(int instance, int* out8) {
+    if (!out8) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (mi355::isShardedHandle(instance)) {
+        memset(out8, 0, 8 * sizeof(int));
+        out8[2] = shardedStates(instance); out8[3] = mi355::shardedPatternCount(instance); out8[4] = shardedCategories(instance);
+        return out8[3] > 0 ? BEAGLE_SUCCESS : BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    }
+    Instance* in = lookup(instance);
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    out8[0] = in->tipCount; out8[1] = in->partialsCount; out8[2] = in->S; out8[3] = in->P; out8[4] = in->C;
+    out8[5] = in->matrixCount; out8[6] = in->scaleCount; out8[7] = in->partitionCount;
     return BEAGLE_SUCCESS;
 }
 

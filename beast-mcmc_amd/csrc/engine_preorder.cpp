@@ -79,18 +79,35 @@ int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
 // levelised like a post-order one and each level is one launch.
 int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold) {
     if (count <= 0) return 0;
-    if (mayHold && in->S == 4 && in->fuseGradient) in->trackScales = true;     // (from now on updatePartials records scale indices: engine_abi.cpp)
     if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     const int n = in->partialsCount;
+    // The whole list is checked BEFORE anything changes — indices, and that every operand will resolve (real data, a definition
+    // that can be materialised, or a destination of an earlier operation of this list; a scale buffer to read holds raw
+    // factors or is written earlier in the list): a list that fails must leave the instance — and a list still held back,
+    // which the new one may replace unexecuted below — exactly as they were.
+    {
+        std::vector<char> written(n, 0), scaleWritten(std::max(1, in->scaleCount), 0);
+        for (int k = 0; k < count; k++) {
+            const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+            const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
+            if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
+                (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
+                (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
+                return BEAGLE_ERROR_OUT_OF_RANGE;
+            auto hasData = [&](int b) { return written[b] || (in->partials[b] != nullptr && !isCompactTip(in, b)) || isVirt(in, b); };
+            if (!hasData(par)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (!(hasData(sib) || (!written[sib] && isCompactTip(in, sib)))) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (wS == BEAGLE_OP_NONE && rS != BEAGLE_OP_NONE && !(scaleWritten[rS] || (in->scale[rS] && in->scaleIsRaw[rS]))) return BEAGLE_ERROR_OUT_OF_RANGE;
+            written[dest] = 1;
+            if (wS != BEAGLE_OP_NONE) scaleWritten[wS] = 1;
+        }
+    }
+    if (mayHold && in->S == 4 && in->fuseGradient) in->trackScales = true;     // (from now on updatePartials records scale indices: engine_abi.cpp)
     // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
     std::vector<int> need;
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
-        const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
-        if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
-            (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
-            (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
-            return BEAGLE_ERROR_OUT_OF_RANGE;
+        const int dest = op[0], wS = op[1], par = op[3], sib = op[5];
         in->scaleOfPartial[dest] = -1;                    // (a pre-order partial: never a post-order operand of the walk)
         if (wS != BEAGLE_OP_NONE) in->scaleVersion[wS]++;
         if (isVirt(in, sib)) need.push_back(sib);
@@ -201,10 +218,12 @@ bool supersedesHeld(Instance* in, const int* ops, int count) {
     std::vector<char> dest(in->partialsCount, 0);
     for (int k = 0; k < count; k++) dest[ops[(size_t)k * BEAGLE_OP_COUNT]] = 1;
     for (size_t k = 0; k < h.ops.size(); k += BEAGLE_OP_COUNT) if (!dest[h.ops[k]]) return false;
+    std::vector<char> written(in->partialsCount, 0);
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
         if (h.writesBuf[op[5]]) return false;                                       // a sibling's post-order partial
-        if (h.writesBuf[op[3]] && !dest[op[3]]) return false;                       // a parent it does not produce itself
+        if (h.writesBuf[op[3]] && !written[op[3]]) return false;                    // a parent it has not produced itself by then
+        written[op[0]] = 1;
     }
     return true;
 }

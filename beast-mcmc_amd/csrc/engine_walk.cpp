@@ -125,7 +125,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         // is an observation, not a documented guarantee, so it is not what ships by default.
         // A smaller N than the true number only waits longer (the table ends at 12).
         for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
-            const int stores = in->strictWaits ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
+            // (a micro-operation that rescales in write mode also stores its factors, from one of the workgroup's waves only: behind
+            // it the count is the strict one whatever the mode)
+            const bool prevWrites = i > segs[si].progStart && ((w[i - 1].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
+            const int stores = (in->strictWaits || prevWrites) ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
             w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
             // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
             const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
@@ -296,10 +299,16 @@ int walkChunkOps(const Instance* in, int opCount) {
     if (forced >= 0) return forced;
     if (opCount < 64) return 0;
     const long groups = (in->P + 127) / 128;
-    // about 2 560 workgroups per wave of slices: 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the
-    // assembly loop (tools/chunk_sweep.sh): 12 500 patterns 129 us at 40 micro-operations per slice vs 145 at 99; flat
-    // between 50 and 300 from 25 000 patterns up
-    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / 2560));
+    // One launch per wave of slices (BEAGLE_MI355_NO_WALK_FUSION=1, the C++ walk, the T32 walk): about 2 560 workgroups per
+    // wave, 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the assembly loop (tools/chunk_sweep.sh): 12 500
+    // patterns 129 us at 40 micro-operations per slice vs 145 at 99; flat between 50 and 300 from 25 000 patterns up.
+    // All slices in ONE launch (the default at 4 states): a wave of slices is no launch and no chip-wide barrier any more, so
+    // slices can be longer — fewer stored slice roots, less polling — while the planner keeps the slices ABOVE the first wave
+    // short (planner.h chunkTopOps: near the root few subtrees are left side by side).  12 500 patterns, kernel us per
+    // evaluation at 40 / 56 / 72 / 96 / 128 micro-operations per first-wave slice: 130 / 122 / 113 / 114 / 114 with 16 above
+    // (135 / 122 / 141 / 127 / 122 with the same length above); 25 000 and more: flat (profiles/r04_experiments.txt).
+    const bool fused = in->fuseWaves && in->fastWalk && !in->walkT;
+    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / (fused ? 1400 : 2560)));
 }
 
 // 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.

@@ -29,29 +29,48 @@
 namespace {
 
 enum Mode { IN, OUT, INOUT };
-// n < 0: the whole array
+// n < 0: the whole array.  n >= 0: the number of entries the call defines (inputs: reads; outputs: writes) — a Java array
+// shorter than that is an error the wrapper reports (tooShort) instead of letting the library run past the copy.
+// Outputs go back to the Java array only when the call succeeded (commit), and only the n entries it defines.
 struct IntArr {
-    JNIEnv* env; jintArray arr; std::vector<jint> buf; Mode mode;
+    JNIEnv* env; jintArray arr; std::vector<jint> buf; Mode mode; bool tooShort = false, write = true;
     IntArr(JNIEnv* e, jintArray a, long n = -1, Mode m = IN) : env(e), arr(a), mode(m) {
         if (!a) return;
         const long len = (long)jni::GetArrayLength(e, a);
+        tooShort = n > len;
         buf.resize((size_t)(n < 0 ? len : std::min(n, len)));
         if (mode != OUT && !buf.empty()) jni::GetIntArrayRegion(e, a, 0, (jsize)buf.size(), buf.data());
     }
-    ~IntArr() { if (arr && mode != IN && !buf.empty()) jni::SetIntArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    ~IntArr() { if (arr && mode != IN && write && !tooShort && !buf.empty()) jni::SetIntArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
     operator int*() { return arr ? buf.data() : nullptr; }
 };
 struct DblArr {
-    JNIEnv* env; jdoubleArray arr; std::vector<jdouble> buf; Mode mode;
+    JNIEnv* env; jdoubleArray arr; std::vector<jdouble> buf; Mode mode; bool tooShort = false, write = true;
     DblArr(JNIEnv* e, jdoubleArray a, long n = -1, Mode m = IN) : env(e), arr(a), mode(m) {
         if (!a) return;
         const long len = (long)jni::GetArrayLength(e, a);
+        tooShort = n > len;
         buf.resize((size_t)(n < 0 ? len : std::min(n, len)));
         if (mode != OUT && !buf.empty()) jni::GetDoubleArrayRegion(e, a, 0, (jsize)buf.size(), buf.data());
     }
-    ~DblArr() { if (arr && mode != IN && !buf.empty()) jni::SetDoubleArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
+    ~DblArr() { if (arr && mode != IN && write && !tooShort && !buf.empty()) jni::SetDoubleArrayRegion(env, arr, 0, (jsize)buf.size(), buf.data()); }
     operator double*() { return arr ? buf.data() : nullptr; }
 };
+inline bool anyShort() { return false; }
+template <class A, class... R> inline bool anyShort(const A& a, const R&... r) { return a.tooShort || anyShort(r...); }
+// the result code decides whether output arrays are written back: yes on success and on BEAGLE_ERROR_FLOATING_POINT (the value IS
+// the result: NaN — BeagleJNIImpl tolerates -8), no otherwise (the Java array keeps what it held)
+inline void commitTo(int) {}
+template <class A, class... R> inline void commitTo(int rc, A& a, R&... r) { a.write = rc == BEAGLE_SUCCESS || rc == BEAGLE_ERROR_FLOATING_POINT; commitTo(rc, r...); }
+#define SHORT_CHECK(...) do { if (anyShort(__VA_ARGS__)) return BEAGLE_ERROR_OUT_OF_RANGE; } while (0)
+// what an instance's whole-array outputs define: patterns, states, categories (beagleMi355GetDimensions)
+struct Dims { long P = -1, S = -1, C = -1; bool ok = false; };
+inline Dims dimsOf(int instance) {
+    int d[8];
+    Dims r;
+    if (beagleMi355GetDimensions(instance, d) == BEAGLE_SUCCESS) { r.S = d[2]; r.P = d[3]; r.C = d[4]; r.ok = true; }
+    return r;
+}
 
 // a failed class / method lookup leaves a pending NoSuchMethodError / NoClassDefFoundError: clear it, the caller sees null / skips
 bool pendingCleared(JNIEnv* env) {
@@ -179,13 +198,16 @@ JNI_FN(jint, setTipStates)(JNIEnv* env, jobject, jint instance, jint tip, jintAr
     IntArr a(env, states); return beagleSetTipStates(instance, tip, a);
 }
 JNI_FN(jint, getTipStates)(JNIEnv* env, jobject, jint instance, jint tip, jintArray states) {
-    IntArr a(env, states, -1, OUT); return beagleGetTipStates(instance, tip, a);
+    const Dims d = dimsOf(instance);
+    IntArr a(env, states, d.ok ? d.P : -1, OUT); SHORT_CHECK(a);
+    const int rc = beagleGetTipStates(instance, tip, a); commitTo(rc, a); return rc;
 }
 JNI_FN(jint, setTipPartials)(JNIEnv* env, jobject, jint instance, jint tip, jdoubleArray partials) {
     DblArr a(env, partials); return beagleSetTipPartials(instance, tip, a);
 }
 JNI_FN(jint, setRootPrePartials)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray freqs, jint count) {
-    IntArr a(env, bufs, count), b(env, freqs, count); return beagleSetRootPrePartials(instance, a, b, count);
+    IntArr a(env, bufs, count), b(env, freqs, count); SHORT_CHECK(a, b);
+    return beagleSetRootPrePartials(instance, a, b, count);
 }
 JNI_FN(jint, setPartials)(JNIEnv* env, jobject, jint instance, jint buf, jdoubleArray partials) {
     DblArr a(env, partials); return beagleSetPartials(instance, buf, a);
@@ -194,12 +216,21 @@ JNI_FN(jint, getPartials)(JNIEnv* env, jobject, jint instance, jint buf, jint sc
     // straight from the engine's pinned bounce buffer into the Java array (no copy in, one copy out)
     const double* pinned = nullptr; long n = 0;
     const int rc = beagleMi355GetPartialsPinned(instance, buf, scaleIndex, &pinned, &n);
-    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) { DblArr a(env, out, -1, OUT); return beagleGetPartials(instance, buf, scaleIndex, a); }
-    if (rc == BEAGLE_SUCCESS && out) jni::SetDoubleArrayRegion(env, out, 0, (jsize)std::min<long>(n, (long)jni::GetArrayLength(env, out)), pinned);
+    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) {
+        const Dims d = dimsOf(instance);
+        DblArr a(env, out, d.ok ? d.C * d.P * d.S : -1, OUT); SHORT_CHECK(a);
+        const int rc2 = beagleGetPartials(instance, buf, scaleIndex, a); commitTo(rc2, a); return rc2;
+    }
+    if (rc == BEAGLE_SUCCESS && out) {
+        if ((long)jni::GetArrayLength(env, out) < n) return BEAGLE_ERROR_OUT_OF_RANGE;
+        jni::SetDoubleArrayRegion(env, out, 0, (jsize)n, pinned);
+    }
     return rc;
 }
 JNI_FN(jint, getLogScaleFactors)(JNIEnv* env, jobject, jint instance, jint scaleIndex, jdoubleArray out) {
-    DblArr a(env, out, -1, OUT); return beagleGetLogScaleFactors(instance, scaleIndex, a);
+    const Dims d = dimsOf(instance);
+    DblArr a(env, out, d.ok ? d.P : -1, OUT); SHORT_CHECK(a);
+    const int rc = beagleGetLogScaleFactors(instance, scaleIndex, a); commitTo(rc, a); return rc;
 }
 JNI_FN(jint, setEigenDecomposition)(JNIEnv* env, jobject, jint instance, jint eigenIndex, jdoubleArray u, jdoubleArray ui, jdoubleArray lam) {
     DblArr a(env, u), b(env, ui), c(env, lam); return beagleSetEigenDecomposition(instance, eigenIndex, a, b, c);
@@ -223,53 +254,69 @@ JNI_FN(jint, setDifferentialMatrix)(JNIEnv* env, jobject, jint instance, jint id
     DblArr a(env, m); return beagleSetDifferentialMatrix(instance, idx, a);
 }
 JNI_FN(jint, getTransitionMatrix)(JNIEnv* env, jobject, jint instance, jint idx, jdoubleArray out) {
-    DblArr a(env, out, -1, OUT); return beagleGetTransitionMatrix(instance, idx, a);
+    const Dims d = dimsOf(instance);
+    DblArr a(env, out, d.ok ? d.C * d.S * d.S : -1, OUT); SHORT_CHECK(a);
+    const int rc = beagleGetTransitionMatrix(instance, idx, a); commitTo(rc, a); return rc;
 }
 JNI_FN(jint, convolveTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray f, jintArray s, jintArray r, jint count) {
-    IntArr a(env, f, count), b(env, s, count), c(env, r, count); return beagleConvolveTransitionMatrices(instance, a, b, c, count);
+    IntArr a(env, f, count), b(env, s, count), c(env, r, count); SHORT_CHECK(a, b, c);
+    return beagleConvolveTransitionMatrices(instance, a, b, c, count);
 }
 JNI_FN(jint, addTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray f, jintArray s, jintArray r, jint count) {
-    IntArr a(env, f, count), b(env, s, count), c(env, r, count); return beagleAddTransitionMatrices(instance, a, b, c, count);
+    IntArr a(env, f, count), b(env, s, count), c(env, r, count); SHORT_CHECK(a, b, c);
+    return beagleAddTransitionMatrices(instance, a, b, c, count);
 }
 JNI_FN(jint, transposeTransitionMatrices)(JNIEnv* env, jobject, jint instance, jintArray in, jintArray out, jint count) {
-    IntArr a(env, in, count), b(env, out, count); return beagleTransposeTransitionMatrices(instance, a, b, count);
+    IntArr a(env, in, count), b(env, out, count); SHORT_CHECK(a, b);
+    return beagleTransposeTransitionMatrices(instance, a, b, count);
 }
 JNI_FN(jint, updateTransitionMatrices)(JNIEnv* env, jobject, jint instance, jint eigenIndex, jintArray prob, jintArray d1,
                                        jintArray d2, jdoubleArray lengths, jint count) {
     IntArr a(env, prob, count), b(env, d1, count), c(env, d2, count); DblArr t(env, lengths, count);
+    SHORT_CHECK(a, b, c, t);
     return beagleUpdateTransitionMatrices(instance, eigenIndex, a, b, c, t, count);
 }
 JNI_FN(jint, updateTransitionMatricesWithMultipleModels)(JNIEnv* env, jobject, jint instance, jintArray eigen, jintArray rates,
                                                          jintArray prob, jintArray d1, jintArray d2, jdoubleArray lengths, jint count) {
     IntArr e(env, eigen, count), r(env, rates, count), a(env, prob, count), b(env, d1, count), c(env, d2, count); DblArr t(env, lengths, count);
+    SHORT_CHECK(e, r, a, b, c, t);
     return beagleUpdateTransitionMatricesWithMultipleModels(instance, e, r, a, b, c, t, count);
 }
 JNI_FN(jint, updatePrePartials)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count, jint cum) {
-    IntArr a(env, ops, 7L * count); return beagleUpdatePrePartials(instance, a, count, cum);
+    IntArr a(env, ops, 7L * count); SHORT_CHECK(a);
+    return beagleUpdatePrePartials(instance, a, count, cum);
 }
 JNI_FN(jint, updatePrePartialsByPartition)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count) {
-    IntArr a(env, ops, 9L * count); return beagleUpdatePrePartialsByPartition(instance, a, count);
+    IntArr a(env, ops, 9L * count); SHORT_CHECK(a);
+    return beagleUpdatePrePartialsByPartition(instance, a, count);
 }
 JNI_FN(jint, updatePartials)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count, jint cum) {
-    IntArr a(env, ops, 7L * count); return beagleUpdatePartials(instance, a, count, cum);
+    IntArr a(env, ops, 7L * count); SHORT_CHECK(a);
+    return beagleUpdatePartials(instance, a, count, cum);
 }
 JNI_FN(jint, updatePartialsByPartition)(JNIEnv* env, jobject, jint instance, jintArray ops, jint count) {
-    IntArr a(env, ops, 9L * count); return beagleUpdatePartialsByPartition(instance, a, count);
+    IntArr a(env, ops, 9L * count); SHORT_CHECK(a);
+    return beagleUpdatePartialsByPartition(instance, a, count);
 }
 JNI_FN(jint, waitForPartials)(JNIEnv* env, jobject, jint instance, jintArray dest, jint count) {
-    IntArr a(env, dest, count); return beagleWaitForPartials(instance, a, count);
+    IntArr a(env, dest, count); SHORT_CHECK(a);
+    return beagleWaitForPartials(instance, a, count);
 }
 JNI_FN(jint, accumulateScaleFactors)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum) {
-    IntArr a(env, idx, count); return beagleAccumulateScaleFactors(instance, a, count, cum);
+    IntArr a(env, idx, count); SHORT_CHECK(a);
+    return beagleAccumulateScaleFactors(instance, a, count, cum);
 }
 JNI_FN(jint, accumulateScaleFactorsByPartition)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum, jint part) {
-    IntArr a(env, idx, count); return beagleAccumulateScaleFactorsByPartition(instance, a, count, cum, part);
+    IntArr a(env, idx, count); SHORT_CHECK(a);
+    return beagleAccumulateScaleFactorsByPartition(instance, a, count, cum, part);
 }
 JNI_FN(jint, removeScaleFactors)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum) {
-    IntArr a(env, idx, count); return beagleRemoveScaleFactors(instance, a, count, cum);
+    IntArr a(env, idx, count); SHORT_CHECK(a);
+    return beagleRemoveScaleFactors(instance, a, count, cum);
 }
 JNI_FN(jint, removeScaleFactorsByPartition)(JNIEnv* env, jobject, jint instance, jintArray idx, jint count, jint cum, jint part) {
-    IntArr a(env, idx, count); return beagleRemoveScaleFactorsByPartition(instance, a, count, cum, part);
+    IntArr a(env, idx, count); SHORT_CHECK(a);
+    return beagleRemoveScaleFactorsByPartition(instance, a, count, cum, part);
 }
 JNI_FN(jint, resetScaleFactors)(JNIEnv*, jobject, jint instance, jint cum) { return beagleResetScaleFactors(instance, cum); }
 JNI_FN(jint, resetScaleFactorsByPartition)(JNIEnv*, jobject, jint instance, jint cum, jint part) {
@@ -280,7 +327,8 @@ JNI_FN(jint, copyScaleFactors)(JNIEnv*, jobject, jint instance, jint dst, jint s
 JNI_FN(jint, calculateRootLogLikelihoods)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray weights, jintArray freqs,
                                           jintArray cums, jint count, jdoubleArray outSum) {
     IntArr a(env, bufs, count), b(env, weights, count), c(env, freqs, count), d(env, cums, count); DblArr o(env, outSum, count, OUT);
-    return beagleCalculateRootLogLikelihoods(instance, a, b, c, d, count, o);
+    SHORT_CHECK(a, b, c, d, o);
+    const int rc = beagleCalculateRootLogLikelihoods(instance, a, b, c, d, count, o); commitTo(rc, o); return rc;
 }
 JNI_FN(jint, calculateRootLogLikelihoodsByPartition)(JNIEnv* env, jobject, jint instance, jintArray bufs, jintArray weights,
                                                      jintArray freqs, jintArray cums, jintArray parts, jint partitionCount,
@@ -288,13 +336,22 @@ JNI_FN(jint, calculateRootLogLikelihoodsByPartition)(JNIEnv* env, jobject, jint 
     const long n = (long)partitionCount * count;
     IntArr a(env, bufs, n), b(env, weights, n), c(env, freqs, n), d(env, cums, n), p(env, parts, partitionCount);
     DblArr o1(env, outByPartition, n, OUT), o2(env, outSum, count, OUT);
-    return beagleCalculateRootLogLikelihoodsByPartition(instance, a, b, c, d, p, partitionCount, count, o1, o2);
+    SHORT_CHECK(a, b, c, d, p, o1, o2);
+    const int rc = beagleCalculateRootLogLikelihoodsByPartition(instance, a, b, c, d, p, partitionCount, count, o1, o2);
+    commitTo(rc, o1, o2); return rc;
 }
 JNI_FN(jint, getSiteLogLikelihoods)(JNIEnv* env, jobject, jint instance, jdoubleArray out) {
     const double* pinned = nullptr; long n = 0;
     const int rc = beagleMi355GetSiteLogLikelihoodsPinned(instance, &pinned, &n);
-    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) { DblArr o(env, out, -1, OUT); return beagleGetSiteLogLikelihoods(instance, o); }
-    if (rc == BEAGLE_SUCCESS && out) jni::SetDoubleArrayRegion(env, out, 0, (jsize)std::min<long>(n, (long)jni::GetArrayLength(env, out)), pinned);
+    if (rc == BEAGLE_ERROR_NO_IMPLEMENTATION) {
+        const Dims d = dimsOf(instance);
+        DblArr o(env, out, d.ok ? d.P : -1, OUT); SHORT_CHECK(o);
+        const int rc2 = beagleGetSiteLogLikelihoods(instance, o); commitTo(rc2, o); return rc2;
+    }
+    if (rc == BEAGLE_SUCCESS && out) {
+        if ((long)jni::GetArrayLength(env, out) < n) return BEAGLE_ERROR_OUT_OF_RANGE;
+        jni::SetDoubleArrayRegion(env, out, 0, (jsize)n, pinned);
+    }
     return rc;
 }
 
@@ -304,15 +361,18 @@ JNI_FN(jint, calculateEdgeDifferentials)(JNIEnv* env, jobject, jint instance, ji
                                          jintArray weights, jint count, jdoubleArray outDeriv, jdoubleArray outSum,
                                          jdoubleArray outSumSquared) {
     IntArr a(env, post, count), b(env, pre, count), c(env, dmat, count), w(env, weights);
-    DblArr o0(env, outDeriv, -1, OUT), o1(env, outSum, count, OUT), o2(env, outSumSquared, count, OUT);
-    return beagleCalculateEdgeDifferentials(instance, a, b, c, w, count, o0, o1, o2);
+    const Dims dm = dimsOf(instance);
+    DblArr o0(env, outDeriv, dm.ok ? (long)count * dm.P : -1, OUT), o1(env, outSum, count, OUT), o2(env, outSumSquared, count, OUT);
+    SHORT_CHECK(a, b, c, o0, o1, o2);
+    const int rc = beagleCalculateEdgeDifferentials(instance, a, b, c, w, count, o0, o1, o2); commitTo(rc, o0, o1, o2); return rc;
 }
 JNI_FN(jint, calculateCrossProductDifferentials)(JNIEnv* env, jobject, jint instance, jintArray post, jintArray pre, jintArray rates,
                                                  jintArray weights, jdoubleArray lengths, jint count, jdoubleArray outSum,
                                                  jdoubleArray outSumSquared) {
     IntArr a(env, post, count), b(env, pre, count), r(env, rates), w(env, weights);
     DblArr t(env, lengths, count), o1(env, outSum, -1, INOUT), o2(env, outSumSquared, -1, INOUT);      // the sums are ADDED to what the arrays hold
-    return beagleCalculateCrossProductDifferentials(instance, a, b, r, w, t, count, o1, o2);
+    SHORT_CHECK(a, b, t);
+    const int rc = beagleCalculateCrossProductDifferentials(instance, a, b, r, w, t, count, o1, o2); commitTo(rc, o1, o2); return rc;
 }
 JNI_FN(jint, calculateEdgeDerivative)(JNIEnv*, jobject, jint, jintArray, jintArray, jint, jintArray, jintArray, jint, jint, jint,
                                       jintArray, jint, jdoubleArray, jdoubleArray) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }

@@ -375,7 +375,7 @@ template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride) {
-    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[2][MAXC][320 B], exch[C][1 KiB] (write-mode rescaling)
+    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[2][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
     const int p0 = sg.pStart + (int)blockIdx.x * 128;
@@ -423,7 +423,7 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)C * 1024;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024;
     const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;

@@ -598,6 +598,51 @@ void WalkPlanner::linkSlices(Plan& out) {
     out.launchOrder.resize(n);
     for (int s = 0; s < n; s++) out.launchOrder[s] = s;
     std::stable_sort(out.launchOrder.begin(), out.launchOrder.end(), [&](int a, int b) { return out.segs[a].tail > out.segs[b].tail; });
+    if (launchMachines <= 0.0 || n < 3) return;
+    // List scheduling on `machines` identical machines, a slice taking its length: whenever a machine is free, the ready slice
+    // (all of its dependencies finished) with the longest tail starts; the order of the starts is the launch order.
+    const int machines = std::max(1, (int)(launchMachines + 0.5));
+    std::vector<int> waiting(n, 0);                       // unfinished dependencies
+    std::vector<std::vector<int>> dependants(n);
+    for (int s = 0; s < n; s++) {
+        waiting[s] = out.segs[s].depCount;
+        for (int d = out.segs[s].depStart; d < out.segs[s].depStart + out.segs[s].depCount; d++) dependants[out.deps[d]].push_back(s);
+    }
+    std::vector<long> freeAt(machines, 0);
+    std::vector<std::pair<long, int>> running;            // (finish time, slice)
+    std::vector<int> ready;
+    for (int s : out.launchOrder) if (waiting[s] == 0) ready.push_back(s);      // (kept in descending-tail order)
+    std::vector<int> order;
+    order.reserve(n);
+    auto retire = [&](long now) {
+        for (size_t i = 0; i < running.size();) {
+            if (running[i].first > now) { i++; continue; }
+            for (int c : dependants[running[i].second])
+                if (--waiting[c] == 0) {
+                    const auto at = std::upper_bound(ready.begin(), ready.end(), c, [&](int a, int b) { return out.segs[a].tail > out.segs[b].tail; });
+                    ready.insert(at, c);
+                }
+            running[i] = running.back(); running.pop_back();
+        }
+    };
+    while ((int)order.size() < n) {
+        const size_t m = std::min_element(freeAt.begin(), freeAt.end()) - freeAt.begin();
+        long now = freeAt[m];
+        retire(now);
+        if (ready.empty()) {                              // nothing can start: the machine idles until the next slice finishes
+            if (running.empty()) break;                   // (cannot happen: the dependencies are acyclic)
+            now = std::min_element(running.begin(), running.end())->first;
+            retire(now);
+            for (long& f : freeAt) f = std::max(f, now);
+            continue;
+        }
+        const int s = ready.front();
+        ready.erase(ready.begin());
+        order.push_back(s);
+        freeAt[m] = now + out.segs[s].progCount;
+        running.emplace_back(freeAt[m], s);
+    }
+    if ((int)order.size() == n) out.launchOrder = order;
 }
 
 WalkPlanner::CacheEntry* WalkPlanner::findCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps) {

@@ -154,6 +154,11 @@ public:
     // when ALL slices of a program run in one launch and a wave is not a launch: near the root few subtrees are left side by
     // side, so long slices there are a long serial tail on a few CUs; short ones keep more of them in flight)
     int chunkTopOps = 0;
+    // How many slices the chip runs side by side (workgroup slots / pattern groups of a slice; the engine sets it): linkSlices
+    // orders a one-launch program by simulating a greedy critical-path schedule on that many machines, so that a slice is
+    // dispatched about when the slices it waits for are done — dispatched earlier it would only hold its workgroup slots
+    // while it polls.  <= 0: plain descending-tail order.
+    double launchMachines = 0.0;
     long cacheHits = 0;                  // plans served from the cache below
     bool cacheEnabled = true;
     // what the last plan() produced: `out`, or the cache's copy (no copy is made on a hit).  plannedTag identifies the

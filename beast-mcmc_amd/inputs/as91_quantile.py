@@ -1,4 +1,4 @@
-"""The reference's gamma quantile, restated (``GammaSiteRateModel(quantile="beast")``, the front-end's default).
+"""The reference's gamma quantile, TRANSLITERATED statement by statement from the reference's Java (``GammaSiteRateModel(quantile="beast")``, the front-end's default).
 
 BEAST's golden lnL values depend on the exact discretisation of the among-site rate distribution, including its gamma
 quantile, which is NOT an exact inverse CDF: it is AS 91 (Best & Roberts 1975) driven by an AS 32 (Bhattacharjee 1970)

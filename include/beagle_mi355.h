@@ -348,6 +348,9 @@ int beagleMi355WalkStats(int instance, long* out8);
  * answered from a held list WITHOUT writing a pre-order partial (sums only; the list stays held), out[3] held lists that had
  * to run after all because a later call touched their buffers. */
 int beagleMi355GradientStats(int instance, long* out4);
+/* The instance's dimensions, for wrappers that have to size what a whole-array output defines (the JNI shim):
+ * out8 = {tipCount, partialsBufferCount, stateCount, patternCount, categoryCount, matrixBufferCount, scaleBufferCount, partitionCount}. */
+int beagleMi355GetDimensions(int instance, int* out8);
 /* Bytes of HBM currently allocated by the instance. */
 long beagleMi355DeviceBytes(int instance);
 

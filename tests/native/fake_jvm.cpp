@@ -202,6 +202,20 @@ int main(int argc, char** argv) {
     traffic("getTipStates");
     int same = 0; for (int i = 0; i < n; i++) same += tips->ints[i] == rows[1][i];
     printf("getTipStatesRc=%d matching=%d of %d\n", rc, same, n);
+    {   // error behaviour of output arrays: a failing call leaves the Java array as it was; an array shorter than what the call
+        // defines is refused; a longer one keeps its tail
+        FObj* keep = dbls(std::vector<jdouble>(n + 3, 123.0));
+        const jint rcBad = sym<IIA>("getLogScaleFactors")(env, self, h, 99, keep);                // scale index out of range
+        int untouched = 0; for (double v : keep->dbls) untouched += v == 123.0;
+        FObj* shortTips = ints(std::vector<jint>(n - 1, -7));
+        const jint rcShort = sym<IIA>("getTipStates")(env, self, h, 1, shortTips);
+        int shortUntouched = 0; for (int v : shortTips->ints) shortUntouched += v == -7;
+        FObj* longTips = ints(std::vector<jint>(n + 2, -7));
+        const jint rcLong = sym<IIA>("getTipStates")(env, self, h, 1, longTips);
+        printf("outputOnError rc=%d untouched=%d of %d | shortArray rc=%d untouched=%d of %d | longArray rc=%d tail=%d,%d first=%d\n", rcBad, untouched, n + 3,
+               rcShort, shortUntouched, n - 1, rcLong, longTips->ints[n], longTips->ints[n + 1], longTips->ints[0] == rows[1][0]);
+        g_bytesIn = g_bytesOut = 0;
+    }
     rc = sym<jint (*)(FEnv*, FObj*, jint)>("finalize")(env, self, h);
     printf("finalizeRc=%d\n", rc);
 

@@ -199,6 +199,9 @@ struct Harness {
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
         { static const int caps[6] = {6, 8, 12, 16, 24, 32}; pl.init(nBuf, T, nMat, nScale, caps[seed % 6], virt, 2 + (seed / 6) % 2); }    // the engine's: 8 or 16
+        // one-launch programs: the simulated schedule's machine count and the smaller slices above the first wave, varied
+        { static const double mach[4] = {0.0, 1.0, 3.0, 10.4}; pl.launchMachines = mach[(seed / 2) % 4]; }
+        { static const int top[3] = {0, 8, 16}; pl.chunkTopOps = top[(seed / 3) % 3]; }
         const int slots = pl.matrixSlots();
         for (World* w : {&truth, &plan}) {
             w->partials.assign(nBuf, {}); w->tips.assign(nBuf, {}); w->mats.assign(slots, std::vector<double>((size_t)C * 16, 0.0));

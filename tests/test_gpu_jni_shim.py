@@ -61,6 +61,13 @@ def test_jni_symbols_drive_the_engine_through_a_fake_jnienv(tmp_path):
     m3 = re.search(r"^getTipStatesRc=0 matching=(\d+) of (\d+)", txt, re.M)
     assert m3.group(1) == m3.group(2)                           # an OUTPUT array is copied back (SetIntArrayRegion)
     assert "finalizeRc=0" in txt
+    # output arrays (round-3 advisor finding): untouched when the call fails, refused (-5) when shorter than what the call defines,
+    # tail preserved when longer
+    me = re.search(r"^outputOnError rc=(-?\d+) untouched=(\d+) of (\d+) \| shortArray rc=(-?\d+) untouched=(\d+) of (\d+) \| longArray rc=(-?\d+) tail=(-?\d+),(-?\d+) first=(\d)", txt, re.M)
+    assert me, txt[-2000:]
+    assert int(me.group(1)) != 0 and me.group(2) == me.group(3)
+    assert int(me.group(4)) == -5 and me.group(5) == me.group(6)
+    assert int(me.group(7)) == 0 and me.group(8) == "-7" and me.group(9) == "-7" and me.group(10) == "1"
     # what the shim copies per call: count-derived lengths in (the arrays are longer: 9 edge lengths for 4 branches, 21
     # operation ints for 2 operations), outputs out only — never a whole output array in before it is overwritten
     n_sites = len(rows[0])

@@ -476,6 +476,16 @@ def test_complex_eigen_instance_against_oracle(S, oracle_lib):
     got = b.getTransitionMatrix(1).reshape(2, S, S)
     for c, r in enumerate((0.5, 1.7)):
         assert np.max(np.abs(got[c] - scipy.linalg.expm(qn * 1.1 * r))) <= 1e-12
+    # imaginary parts must come as adjacent conjugate pairs: a lone one (here: the second of a pair zeroed) is refused, and the
+    # eigen system the instance holds stays what it was (round-3 advisor finding: the kernel would have read past the block)
+    ev = np.array(eig.evals, dtype=float)
+    im = np.nonzero(ev[S:])[0]
+    if len(im):
+        bad = ev.copy(); bad[S + im[1]] = 0.0
+        with pytest.raises(bm.beagle.BeagleException):
+            b.setEigenDecomposition(0, eig.evec, eig.ievc, bad)
+        b.updateTransitionMatrices(0, [2], None, None, [1.1], 1)
+        assert np.array_equal(b.getTransitionMatrix(2).reshape(2, S, S), got)
     b.finalize()
     rng = np.random.default_rng(S)
     T, P = 14, 333

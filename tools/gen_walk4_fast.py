@@ -41,7 +41,7 @@ SA_FL, SA_STORE, SA_SRC2, SA_SCALEW = 48, 50, 52, 54
 SB_FL, SB_STORE, SB_SRC2, SB_SCALEW = 56, 58, 60, 62
 MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
 VALA, VALB = 72, 74           # lanes whose first / second pattern lies inside the range (scale-factor stores)
-DIVS, SCNT, EXCH, NCAT, ROFF = 76, 78, 79, 80, 81
+DIVS, SCNT, EXCH, NCAT, ROFF, RB = 76, 78, 79, 80, 81, 82    # RB: byte offset of the rescaling maximum buffer the next node uses
 C0A, C0B = 84, 100            # (WALK4_SCOL) column 0 of the two branch matrices of the even / odd micro-operations: M[i][0]
 S_FIRST = 20
 
@@ -141,10 +141,19 @@ def fdiv_one(out, den, d0, r, t, n0, q):
 
 def rescale_block(tag, SSCALEW):
     """Write-mode rescaling of the result in ACC (AbstractLikelihoodCore.java:406-440 applied unconditionally, as k_walk4):
-    per pattern the largest entry over the 4 states and ALL rate categories — one category per wave, exchanged through LDS
-    between two barriers —, a factor that is not positive becomes 1, the result is multiplied by the reciprocal (a true
-    division, so that the bits equal k_walk4's); the wave of category 0 stores the factor (plain layout) and the reciprocal
-    (pair-interleaved, ROFF bytes further on) of the lane's two patterns, then everything drains.  F and G are free here."""
+    per pattern the largest entry over the 4 states and ALL rate categories, a factor that is not positive becomes 1, the
+    result is multiplied by the reciprocal (a true division, so that the bits equal k_walk4's); the wave of category 0 stores
+    the factor (plain layout) and the reciprocal (pair-interleaved, ROFF bytes further on) of the lane's two patterns.
+    F and G are free here.
+
+    The maximum over the categories — one category per wave — is formed by LDS ATOMICS (ds_max_f64 of every wave's own maximum
+    into the lane's two words of a 1 KiB buffer that starts at zero), then ONE barrier, then every wave reads the result.  Three
+    such buffers rotate (RB): the one a node uses was zeroed by the category-0 wave two nodes earlier, behind that node's barrier
+    — by then every wave had read it for the last time (it read it before arriving at that barrier), and nobody adds to it
+    before the barrier after, which the zeroing wave only reaches with its LDS writes done.  Round 3 exchanged the maxima through
+    a [category][lane] array between TWO barriers and drained the memory queue behind the factor stores (A with ALWAYS
+    rescaling: 1 228 us against 622 in read mode); nothing needs the drain: the stage waits count loads only, and a wait that
+    sees more outstanding stores than it expects only waits longer (engine_walk.cpp runPlan)."""
     MA, MB, RD, A2, B2, IA, IB = F, F + 2, F + 4, G, G + 2, G + 4, G + 6
     d0, r, t, n0, q = F + 8, F + 10, F + 12, F + 14, G + 8
     b = [L("wr" + tag) + ":"]
@@ -154,24 +163,31 @@ def rescale_block(tag, SSCALEW):
               "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(RD, 2)),
               "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(base + 6, 2))]
     b += ["v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)),
-          "v_add_u32_e32 %s, %s, %s" % (v(T0), s(EXCH), v(T0)),           # exchange buffer: [category][lane] x 16 bytes
-          "s_lshl_b32 %s, %s, 10" % (s(ST), s(SCNT)),                       # (SCNT holds the wave's category outside the loop below)
-          "v_add_u32_e32 %s, %s, %s" % (v(T1), s(ST), v(T0)),
-          "ds_write_b128 %s, %s" % (v(T1), v(MA, 4)),
+          "v_add_u32_e32 %s, %s, %s" % (v(T0), s(EXCH), v(T0)),           # the lane's 16 bytes of buffer 0
+          "v_add_u32_e32 %s, %s, %s" % (v(T1), s(RB), v(T0)),              # ... of this node's buffer
+          "ds_max_f64 %s, %s" % (v(T1), v(MA, 2)),
+          "ds_max_f64 %s, %s offset:8" % (v(T1), v(MB, 2)),
           "s_waitcnt lgkmcnt(0)",
           "s_barrier",
-          "v_mov_b64 %s, 0" % v(A2, 2), "v_mov_b64 %s, 0" % v(B2, 2),
-          "s_mov_b32 %s, %s" % (s(ST), s(NCAT)),
-          L("wrl" + tag) + ":",
-          "ds_read_b128 %s, %s" % (v(RD, 4), v(T0)),
-          "v_add_u32_e32 %s, 0x400, %s" % (v(T0), v(T0)),
-          "s_add_i32 %s, %s, -1" % (s(ST), s(ST)),
-          "s_waitcnt lgkmcnt(0)",
-          "v_max_f64 %s, %s, %s" % (v(A2, 2), v(A2, 2), v(RD, 2)),
-          "v_max_f64 %s, %s, %s" % (v(B2, 2), v(B2, 2), v(RD + 2, 2)),
-          "s_cmp_gt_i32 %s, 0" % s(ST),
-          "s_cbranch_scc1 %s" % L("wrl" + tag),
-          "s_barrier"]                                                      # the exchange buffer is free again
+          "ds_read_b128 %s, %s" % (v(A2, 4), v(T1)),
+          # the buffer two nodes on = the one used one node ago: every wave is past its reads of it; category 0 zeroes it
+          "s_add_u32 %s, %s, 0x800" % (s(ST), s(RB)),
+          "s_cmp_ge_u32 %s, 0xc00" % s(ST),
+          "s_cbranch_scc0 %s" % L("wrz" + tag),
+          "s_sub_u32 %s, %s, 0xc00" % (s(ST), s(ST)),
+          L("wrz" + tag) + ":",
+          "s_cmp_lg_u32 %s, 0" % s(SCNT),
+          "s_cbranch_scc1 %s" % L("wrn" + tag),
+          "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(T0)),
+          "v_mov_b64 %s, 0" % v(RD, 2), "v_mov_b64 %s, 0" % v(RD + 2, 2),
+          "ds_write_b128 %s, %s" % (v(T0), v(RD, 4)),
+          L("wrn" + tag) + ":",
+          "s_add_u32 %s, %s, 0x400" % (s(RB), s(RB)),                       # next node: next buffer
+          "s_cmp_ge_u32 %s, 0xc00" % s(RB),
+          "s_cbranch_scc0 %s" % L("wrr" + tag),
+          "s_mov_b32 %s, 0" % s(RB),
+          L("wrr" + tag) + ":",
+          "s_waitcnt lgkmcnt(0)"]
     b.append("v_mov_b32_e32 %s, 0x3ff00000" % v(T1))                        # (a literal and VCC together exceed the constant bus)
     for m in (A2, B2):                                                      # if (!(m > 0)) m = 1
         b += ["v_cmp_lt_f64_e32 vcc, 0, %s" % v(m, 2),
@@ -184,7 +200,7 @@ def rescale_block(tag, SSCALEW):
         b.append("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(IA if i < 4 else IB, 2)))
     # category 0 stores: factor at 8 p (PA = 32 p for that wave), reciprocal at ROFF + 8 * (pair position)
     b += ["s_cmp_lg_u32 %s, 0" % s(SCNT),
-          "s_cbranch_scc1 %s" % L("wrd" + tag),
+          "s_cbranch_scc1 %s" % L("wrb" + tag),
           "v_lshrrev_b32_e32 %s, 2, %s" % (v(T0), v(PA)),
           "v_lshrrev_b32_e32 %s, 2, %s" % (v(T1), v(PB)),
           "v_add_u32_e32 %s, %s, %s" % (v(RD), s(ROFF), v(SCALE)),
@@ -196,8 +212,6 @@ def rescale_block(tag, SSCALEW):
           "global_store_dwordx2 %s, %s, %s offset:8" % (v(RD), v(IB, 2), s(SSCALEW, 2)),
           "s_mov_b64 exec, -1",
           "s_nop 0",
-          L("wrd" + tag) + ":",
-          "s_waitcnt vmcnt(0)",
           "s_branch %s" % L("wrb" + tag)]
     return b
 
@@ -447,6 +461,16 @@ def build():
     e("s_mov_b32 %s, %%[ncat]" % s(NCAT))
     e("s_mov_b32 %s, %%[roff]" % s(ROFF))
     e("s_mov_b32 %s, %%[cat]" % s(SCNT))
+    # the three maximum buffers of write-mode rescaling (rescale_block) start at zero: every wave clears all of them (3 KiB)
+    e("s_mov_b32 %s, 0" % s(RB))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)))
+    e("v_add_u32_e32 %s, %%[exch], %s" % (v(T0), v(T0)))
+    e("v_mov_b64 %s, 0" % v(F, 2))
+    e("v_mov_b64 %s, 0" % v(F + 2, 2))
+    for k in range(3):
+        e("ds_write_b128 %s, %s offset:%d" % (v(T0), v(F, 4), 1024 * k))
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
     e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
     e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
     e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
@@ -523,7 +547,7 @@ def main():
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
-    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else ROFF + 1)) if i not in (32, 33, 34, 35)]
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else RB + 1)) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
     text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
     text.append("#define WALK4_FAST_VGPRS %d" % NV)
