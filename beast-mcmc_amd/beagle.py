@@ -124,7 +124,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -460,6 +460,10 @@ class Beagle:
         f = self._ext("beagleMi355KernelTimer", [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)])
         self._check("kernelTimer", f(self.instance, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernelTimerRestart(self):
+        """Forget what the enabled kernel timer and the walk counters hold (no synchronisation: the caller has just done one)."""
+        self._check("kernelTimerRestart", self._ext("beagleMi355KernelTimerRestart", [C.c_int])(self.instance))
 
     def kernelTimerCalls(self):
         """updatePartials calls the kernel timer bracketed since this was last asked (kernelTimer(N > 1) samples every N-th)."""

@@ -127,6 +127,20 @@ static int rootByPartitionDevice(int instance, const int* bufferIndices, const i
     return 0;
 }
 
+namespace mi355 {
+int publishAndWait(int instance, const double* dValues, int count, double* out) {
+    GET_INSTANCE_KEEP_PENDING(instance);
+    if (!dValues || !out || count < 1 || count > 480) return BEAGLE_ERROR_OUT_OF_RANGE;
+    const unsigned long long seq = ++in->resultSeq;
+    mi355::launchPublish(live(in), dValues, count, in->hResultDev + 16, (unsigned long long*)(in->hResultDev + 8), seq);
+    HIP_TRY(hipGetLastError());
+    { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
+    if (in->pendingCopies.empty()) in->ringHead = 0;
+    memcpy(out, in->hResult + 16, (size_t)count * sizeof(double));
+    return BEAGLE_SUCCESS;
+}
+}  // namespace mi355
+
 extern "C" {
 
 const char* beagleGetVersion(void) { return "4.0.0-mi355"; }
@@ -230,9 +244,10 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     if (tipCount < 0 || partialsBufferCount < 1 || compactBufferCount < 0 || stateCount < 2 || stateCount > 255 ||
         patternCount < 1 || eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
         return BEAGLE_ERROR_OUT_OF_RANGE;
-    // more than 64 states: no kernel of this engine is built for it (the MFMA path tiles up to 64, the gradient kernels
-    // accumulate 64 x 64 outputs, the general kernels stage S x S doubles in LDS) — refuse loudly instead of half-working
-    if (stateCount > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    // (65..255 states — the large discrete-trait state spaces of phylogeography, GeneralLikelihoodCore.java:41-50 — run the
+    // likelihood path on the general kernels, which read their matrices from L2 above ~90 states instead of staging them in LDS
+    // (kernels.hip k_pruneGeneral<false>, k_transitionBig); the pre-order / gradient entry points return
+    // BEAGLE_ERROR_NO_IMPLEMENTATION there: their kernels stage S x S tiles and accumulate 64 x 64 outputs)
     // requirement flags this engine cannot honour
     if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CPU | BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL |
@@ -1147,6 +1162,7 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
     GET_INSTANCE_KEEP_PENDING(instance);                      // (runPreOperations decides what becomes of a list still held back)
+    if (in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;    // (beagleCreateInstance: the likelihood path only above 64 states)
     return runPreOperations(in, operations, operationCount, cumulativeScaleIndex, true);
 }
 
@@ -1164,6 +1180,7 @@ int beagleCalculateCrossProductDifferentials(int instance, const int* postBuffer
         return rc;
     }
     GET_INSTANCE(instance);
+    if (in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (outSumSquaredDerivatives) return BEAGLE_ERROR_NO_IMPLEMENTATION;       // BEAST passes null
     if (!postBufferIndices || !preBufferIndices || !categoryRateIndices || !categoryWeightsIndices || !edgeLengths || !outSumDerivatives)
         return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1321,6 +1338,15 @@ int beagleMi355GetDimensions(int instance, int* out8) {
     if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out8[0] = in->tipCount; out8[1] = in->partialsCount; out8[2] = in->S; out8[3] = in->P; out8[4] = in->C;
     out8[5] = in->matrixCount; out8[6] = in->scaleCount; out8[7] = in->partitionCount;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355KernelTimerRestart(int instance) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355KernelTimerRestart(h); }); }
+    Instance* in = lookup(instance);
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    in->eventsUsed = 0; in->timedMs = 0.0; in->timedLaunches = 0; in->pendingLaunches = 0; in->timingTick = 0; in->timedCalls = 0;
+    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
     return BEAGLE_SUCCESS;
 }
 

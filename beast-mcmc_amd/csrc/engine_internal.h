@@ -69,7 +69,7 @@ struct Instance {
         int maxRange = 0;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
-    } resolved[4];
+    } resolved[8];                                       // (as many as the planner's cache has ways: planner.h CACHE_WAYS)
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
     // 4 states: a pre-order operation list is HELD BACK (engine_preorder.cpp): the chain that evaluates gradients wants the

@@ -516,7 +516,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared) {
     if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (in->partitionCount != 1 || in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (in->heldPre.held) {
         // a held-back pre-order list (the usual case: these are its edges).  Sums only: no pre-order partial is written and the
         // list stays held; sums of squares as well: the list runs together with the derivatives; anything else: it runs first

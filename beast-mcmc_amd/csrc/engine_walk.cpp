@@ -24,7 +24,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // kernel's descriptor prefetch may read (kernels.h WalkSeg).  For a plan that came out of the planner's cache the
     // resolved program is kept as well: buffer addresses never change once a buffer exists.
     static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
-    Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 3] : nullptr;
+    Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 7] : nullptr;
     const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
     std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
     std::vector<mi355::WalkSeg> segsLocal;

@@ -73,11 +73,12 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
     double*        store;    // partials buffer the result is written to (WF_STORE)
     const double*  scale;    // WS_READ: the RECIPROCAL half of the scale buffer; otherwise all-ones (the assembly loop multiplies unconditionally)
-    const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles): read by
-    const double*  m2;       // k_gatherMatrices, which lays them out as the stream the walk reads
+    // (the first 48 bytes are what the assembly loop loads per micro-operation: s_load_dwordx8 at 0, s_load_dwordx4 at 32)
     unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13 | waitJump << 16 (walkWaitJump)
     unsigned       pad0;
     double*        scaleW;   // WS_WRITE: the scale buffer that receives the factors (plain layout) and, recipOff doubles on, their reciprocals
+    const double*  m1;       // first / second child's branch matrix, category 0 ([C][4][4] doubles): read by
+    const double*  m2;       // k_gatherMatrices, which lays them out as the stream the walk reads
 };
 static_assert(sizeof(WalkOp) == 64, "WalkOp layout");
 // Position of pattern p in a pair-interleaved per-pattern array (walk instances: compact tip states, reciprocal scale
@@ -140,6 +141,9 @@ void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSr
 constexpr int HOST_COPY_MAX = 12;
 struct HostCopyList { struct Entry { void* dst; const void* src; unsigned bytes, firstBlock; } e[HOST_COPY_MAX]; int n; };
 void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks);
+// dst[0..n) = src[0..n) — dst in host memory the device maps —, then *flag = seq (release, system scope): a result handed to a
+// polling host thread
+void launchPublish(hipStream_t stream, const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq);
 
 // P(t) = U diag(exp(lambda * t * r_c)) U^-1, negatives clamped to 0, for `count` branches.
 // dIdx/dLen/dEig/dRate: device arrays of length `count`: destination matrix index, edge length,

@@ -64,6 +64,15 @@ void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks) 
     hipLaunchKernelGGL(k_hostCopies, dim3((unsigned)blocks), dim3(256), 0, stream, list);
 }
 
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ src, int n, double* __restrict__ dst, unsigned long long* flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    __threadfence_system();                        // every lane's values before the flag (one wave: program order does the rest)
+    if (threadIdx.x == 0) __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+}
+void launchPublish(hipStream_t stream, const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, src, n, dst, flag, seq);
+}
+
 // ------------------------------------------------------------------------------------------------
 // transition matrices
 // ------------------------------------------------------------------------------------------------
@@ -108,6 +117,46 @@ __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrice
     }
 }
 
+// More than 90 states (S x S doubles exceed what a workgroup may ask of the LDS): per eigenvalue only its exponential — for
+// a complex pair exp(a t) cos(b t), exp(a t) sin(b t) and which row of the pair it is — stays in LDS; a thread forms one matrix
+// entry, summing over k in the same order as k_transition.
+__global__ __launch_bounds__(256) void k_transitionBig(double* __restrict__ matrices, const double* __restrict__ eigen,
+                                                       const double* __restrict__ rates, const int* __restrict__ dIdx,
+                                                       const double* __restrict__ dLen, const int* __restrict__ dEig,
+                                                       const int* __restrict__ dRate, int S, int C, int complexEigen) {
+    extern __shared__ double sh[];            // ec[S] | es[S] | role[S] (0 real, 1 first row of a pair, 2 second)
+    double* ec = sh; double* es = sh + S; double* role = sh + 2 * S;
+    const int u = blockIdx.x, c = blockIdx.y;
+    const size_t eigStride = (size_t)2 * S * S + (complexEigen ? 2 : 1) * S;
+    const double* U = eigen + eigStride * dEig[u];
+    const double* Ui = U + (size_t)S * S;
+    const double* lam = Ui + (size_t)S * S;
+    const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
+    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+        const double im = complexEigen ? lam[S + k] : 0.0;
+        if (im == 0.0) { ec[k] = exp(dist * lam[k]); es[k] = 0.0; role[k] = 0.0; continue; }
+        int run = 0;
+        for (int q = k - 1; q >= 0 && lam[S + q] != 0.0; q--) run++;
+        const int first = (run & 1) ? k - 1 : k;
+        const double b = lam[S + first], expat = exp(dist * lam[first]);
+        ec[k] = expat * cos(dist * b); es[k] = expat * sin(dist * b); role[k] = first == k ? 1.0 : 2.0;
+    }
+    __syncthreads();
+    double* M = matrices + ((size_t)dIdx[u] * C + c) * S * S;
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+        const int i = e / S, j = e - i * S;
+        double s = 0.0;
+        for (int k = 0; k < S; k++) {
+            const double r = role[k];
+            const double ie = r == 0.0 ? Ui[k * S + j] * ec[k]
+                            : r == 1.0 ? ec[k] * Ui[k * S + j] + es[k] * Ui[(k + 1) * S + j]
+                                       : ec[k] * Ui[k * S + j] - es[k] * Ui[(k - 1) * S + j];
+            s += U[i * S + k] * ie;
+        }
+        M[e] = s > 0.0 ? s : 0.0;
+    }
+}
+
 // 4 states: one THREAD per (branch, category) — a workgroup per matrix would be 64 lanes for 16 outputs (and, for the 12 872
 // matrices of a four-partition 1610-taxon evaluation, 51 488 workgroups).  Same arithmetic and summation order as k_transition.
 __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matrices, const double* __restrict__ eigen,
@@ -143,6 +192,11 @@ void launchTransitionMatrices(hipStream_t stream, double* matrices, const double
         return;
     }
     const int threads = S * S >= 256 ? 256 : 64;
+    if ((size_t)S * S * sizeof(double) > 64 * 1024) {      // more than 90 states: exp(lambda t) per eigenvalue in LDS, not the S x S product
+        hipLaunchKernelGGL(k_transitionBig, dim3(count, C), dim3(256), (size_t)3 * S * sizeof(double), stream,
+                           matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
+        return;
+    }
     hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), (size_t)S * S * sizeof(double), stream,
                        matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
 }
@@ -189,13 +243,17 @@ void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSr
 // ------------------------------------------------------------------------------------------------
 constexpr int GEN_BLOCK = 256;
 
+// STAGED = false (more than ~90 states: two transposed S x S matrices no longer fit a CU's LDS): the matrices are read where
+// they lie, row i of M by the thread that owns parent state i — from L2 after the first touch; a correctness path for the
+// large discrete-trait state spaces (GeneralLikelihoodCore.java:41-50 takes any stateCount), same arithmetic and order.
+template <bool STAGED>
 __global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
                                                             int P, int S, int C) {
     extern __shared__ double sh[];
     const int ppb = GEN_BLOCK / S;                   // patterns per pass
     double* mT1 = sh;                                // [S+1][S]  (row S = ones: unknown state)
-    double* mT2 = mT1 + (size_t)(S + 1) * S;
-    double* x1 = mT2 + (size_t)(S + 1) * S;          // [ppb][S]
+    double* mT2 = mT1 + (STAGED ? (size_t)(S + 1) * S : 0);
+    double* x1 = mT2 + (STAGED ? (size_t)(S + 1) * S : 0);          // [ppb][S]
     double* x2 = x1 + (size_t)ppb * S;
     double* red = x2 + (size_t)ppb * S;              // [ppb][S] products for the max reduction
     const OpDesc op = ops[blockIdx.y];
@@ -214,12 +272,14 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __rest
         __syncthreads();
         const double* M1 = matrices + ((size_t)op.mat1 * C + c) * S * S;
         const double* M2 = matrices + ((size_t)op.mat2 * C + c) * S * S;
-        for (int e = threadIdx.x; e < S * S; e += GEN_BLOCK) {
-            const int r = e / S, q = e - r * S;
-            mT1[q * S + r] = M1[e];
-            mT2[q * S + r] = M2[e];
+        if (STAGED) {
+            for (int e = threadIdx.x; e < S * S; e += GEN_BLOCK) {
+                const int r = e / S, q = e - r * S;
+                mT1[q * S + r] = M1[e];
+                mT2[q * S + r] = M2[e];
+            }
+            for (int e = threadIdx.x; e < S; e += GEN_BLOCK) { mT1[S * S + e] = 1.0; mT2[S * S + e] = 1.0; }
         }
-        for (int e = threadIdx.x; e < S; e += GEN_BLOCK) { mT1[S * S + e] = 1.0; mT2[S * S + e] = 1.0; }
         for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
             const int pBase = op.pStart + tile * ppb;
             const int np = min(ppb, op.pEnd - pBase);
@@ -232,10 +292,19 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_pruneGeneral(const OpDesc* __rest
             if (act) {
                 const int p = pBase + pl;
                 double sum1, sum2;
-                if (st1) sum1 = mT1[(int)s1[p] * S + i];
-                else { sum1 = 0.0; for (int j = 0; j < S; j++) sum1 += mT1[j * S + i] * x1[pl * S + j]; }
-                if (st2) sum2 = mT2[(int)s2[p] * S + i];
-                else { sum2 = 0.0; for (int j = 0; j < S; j++) sum2 += mT2[j * S + i] * x2[pl * S + j]; }
+                if (STAGED) {
+                    if (st1) sum1 = mT1[(int)s1[p] * S + i];
+                    else { sum1 = 0.0; for (int j = 0; j < S; j++) sum1 += mT1[j * S + i] * x1[pl * S + j]; }
+                    if (st2) sum2 = mT2[(int)s2[p] * S + i];
+                    else { sum2 = 0.0; for (int j = 0; j < S; j++) sum2 += mT2[j * S + i] * x2[pl * S + j]; }
+                } else {
+                    const double* r1 = M1 + (size_t)i * S;
+                    const double* r2 = M2 + (size_t)i * S;
+                    if (st1) { const int t = (int)s1[p]; sum1 = t < S ? r1[t] : 1.0; }
+                    else { sum1 = 0.0; for (int j = 0; j < S; j++) sum1 += r1[j] * x1[pl * S + j]; }
+                    if (st2) { const int t = (int)s2[p]; sum2 = t < S ? r2[t] : 1.0; }
+                    else { sum2 = 0.0; for (int j = 0; j < S; j++) sum2 += r2[j] * x2[pl * S + j]; }
+                }
                 v = sum1 * sum2;
                 if (op.scaleRead) v *= 1.0 / op.scaleRead[p];
                 op.dest[((size_t)c * P + p) * S + i] = v;
@@ -287,12 +356,17 @@ void launchPruneLevel(hipStream_t stream, const OpDesc* dOps, int nOps, const do
                       int P, int S, int C, int maxRange) {
     if (nOps <= 0 || maxRange <= 0) return;
     const int ppb = GEN_BLOCK / S;
-    const size_t lds = ((size_t)2 * (S + 1) * S + (size_t)3 * ppb * S) * sizeof(double);
+    const size_t ldsStaged = ((size_t)2 * (S + 1) * S + (size_t)3 * ppb * S) * sizeof(double);
+    const bool staged = ldsStaged <= 150 * 1024;         // two transposed matrices fit a CU's 160 KiB up to ~95 states
+    const size_t lds = staged ? ldsStaged : (size_t)3 * ppb * S * sizeof(double);
     int blocks = pruneBlocksForRange(S, maxRange);
     // keep total workgroups around a few per CU when many ops share the launch
     if (nOps > 1) { int per = (4096 + nOps - 1) / nOps; if (per < 1) per = 1; if (blocks > per) blocks = per; }
-    if (lds > 48 * 1024 && !grantDynamicLds(reinterpret_cast<const void*>(k_pruneGeneral), lds)) return;   // S = 61 needs 66 KB of the CU's 160 KB
-    hipLaunchKernelGGL(k_pruneGeneral, dim3(blocks, nOps), dim3(GEN_BLOCK), lds, stream, dOps, matrices, P, S, C);
+    if (staged) {
+        if (lds > 48 * 1024 && !grantDynamicLds(reinterpret_cast<const void*>(k_pruneGeneral<true>), lds)) return;   // S = 61 needs 66 KB of the CU's 160 KB
+        hipLaunchKernelGGL(k_pruneGeneral<true>, dim3(blocks, nOps), dim3(GEN_BLOCK), lds, stream, dOps, matrices, P, S, C);
+    } else
+        hipLaunchKernelGGL(k_pruneGeneral<false>, dim3(blocks, nOps), dim3(GEN_BLOCK), lds, stream, dOps, matrices, P, S, C);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@
 // Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
 // GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace mi355 {
 
@@ -69,8 +70,8 @@ __device__ __forceinline__ Desc loadDesc(const unsigned MI355_CONST* p) {
     Desc r;
     r.src1 = ((u64)a.s1 << 32) | a.s0; r.src2 = ((u64)a.s3 << 32) | a.s2; r.store = ((u64)a.s5 << 32) | a.s4;
     r.scale = ((u64)a.s7 << 32) | a.s6;
-    r.flags = p[12];
-    r.scaleW = ((u64)p[15] << 32) | p[14];
+    r.flags = p[8];                                  // (kernels.h WalkOp: flags at byte 32, scaleW at 40)
+    r.scaleW = ((u64)p[11] << 32) | p[10];
     return r;
 }
 
@@ -423,12 +424,16 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024;
+    // BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so that fewer
+    // workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
+    static const size_t ldsPad = getenv("BEAGLE_MI355_WALK_LDS_PAD") ? (size_t)atol(getenv("BEAGLE_MI355_WALK_LDS_PAD")) : 0;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024 + ldsPad;
     const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
     const int MI355_CONST* deps = (const int MI355_CONST*)dDeps;
+    if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
     if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
                        hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride); }

@@ -218,7 +218,10 @@ private:
         std::vector<char> defOn;                       // defs[k].on
         int stored = 0, memReads = 0, holds = 0, waves = 0;
     };
-    static constexpr int CACHE_WAYS = 4;
+    // (8: a chain under DYNAMIC rescaling cycles through 2 buffer-flip states x 2 scale-buffer sets of its read-mode list and the
+    // same four of the list that recomputes the factors every 100th evaluation — with 4 ways every such evaluation evicted a
+    // read-mode entry and the next evaluations planned, resolved and uploaded from scratch: 1.4 ms each on the 12 500-pattern shard)
+    static constexpr int CACHE_WAYS = 8;
     CacheEntry cache_[CACHE_WAYS];
     int cacheNext_ = 0;
     long cacheTagNext_ = 0;

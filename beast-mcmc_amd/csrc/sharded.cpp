@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -50,15 +51,18 @@ class Worker {
 public:
     Worker() : thread_([this] { loop(); }) {}
     ~Worker() {
-        { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+        { std::lock_guard<std::mutex> l(mu_); stop_ = true; stopFlag_.store(true); }
         cv_.notify_all();
         thread_.join();
     }
     void post(std::function<int()> f) {
-        { std::lock_guard<std::mutex> l(mu_); q_.push_back(std::move(f)); }
+        { std::lock_guard<std::mutex> l(mu_); q_.push_back(std::move(f)); pending_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
     }
     int wait() {
+        // the shard threads answer within microseconds: poll first (a condition-variable wake-up is 5-50 us of scheduler
+        // latency per call under a container's CPU quota), block only when the work is long
+        for (int spin = 0; spin < 20000 && pending_.load(std::memory_order_acquire) != 0; spin++) __builtin_ia32_pause();
         std::unique_lock<std::mutex> l(mu_);
         cv_.wait(l, [this] { return q_.empty() && !busy_; });
         const int rc = rc_;
@@ -69,6 +73,10 @@ private:
     void loop() {
         for (;;) {
             std::function<int()> f;
+            // an evaluation is a burst of ~8 posted calls some microseconds apart: poll for the next one for a while before
+            // going to sleep (BEAGLE_MI355_SHARD_SPIN_US, default 200; 0 = always block)
+            for (long spin = 0; spin < spinIters_ && pending_.load(std::memory_order_acquire) == 0 && !stopFlag_.load(std::memory_order_relaxed); spin++)
+                __builtin_ia32_pause();
             {
                 std::unique_lock<std::mutex> l(mu_);
                 cv_.wait(l, [this] { return !q_.empty() || stop_; });
@@ -76,7 +84,7 @@ private:
                 f = std::move(q_.front()); q_.pop_front(); busy_ = true;
             }
             const int rc = f();
-            { std::lock_guard<std::mutex> l(mu_); if (rc && !rc_) rc_ = rc; busy_ = false; }
+            { std::lock_guard<std::mutex> l(mu_); if (rc && !rc_) rc_ = rc; busy_ = false; pending_.fetch_sub(1, std::memory_order_release); }
             cv_.notify_all();
         }
     }
@@ -84,6 +92,9 @@ private:
     std::condition_variable cv_;
     std::deque<std::function<int()>> q_;
     bool busy_ = false, stop_ = false;
+    std::atomic<int> pending_{0};
+    std::atomic<bool> stopFlag_{false};
+    long spinIters_ = (getenv("BEAGLE_MI355_SHARD_SPIN_US") ? atol(getenv("BEAGLE_MI355_SHARD_SPIN_US")) : 200) * 25;     // ~40 ns per pause
     int rc_ = 0;
     std::thread thread_;
 };
@@ -279,14 +290,14 @@ int shardedRootReduce(int handle, int count, const std::function<int(int shardHa
                 ncclAllReduce(s.dResult, s.dResult, (size_t)count, ncclDouble, ncclSum, s.comm, s.stream) != ncclSuccess) { ncclGroupEnd(); return BEAGLE_ERROR_GENERAL; }
         }
         if (ncclGroupEnd() != ncclSuccess) return BEAGLE_ERROR_GENERAL;
-        Shard& s0 = sh->shards[0];
-        if (hipSetDevice(s0.device) != hipSuccess ||
-            hipMemcpyAsync(sh->hResult, s0.dResult, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s0.stream) != hipSuccess ||
-            hipStreamSynchronize(s0.stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
-        for (int k = 1; k < n; k++) {                   // the other streams must have drained too before their staging rings are reused
-            if (hipSetDevice(sh->shards[k].device) != hipSuccess || hipStreamSynchronize(sh->shards[k].stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
-        }
-        memcpy(outValues, sh->hResult, (size_t)count * sizeof(double));
+        // the result reaches the host from shard 0: one small kernel behind its all-reduce writes the values and a sequence word
+        // into mapped host memory, which this thread polls (engine_abi.cpp publishAndWait) — a device-to-host copy, a stream
+        // synchronisation and a synchronisation of every other shard cost more than a small shard's kernels.  The other shards
+        // are not waited for: their rank of the all-reduce has contributed when shard 0's completes, and what follows on their
+        // streams is ordered behind it by the streams themselves (their staging rings drain when they wrap).
+        const int rcp = publishAndWait(sh->shards[0].handle, sh->shards[0].dResult, count, outValues);
+        if (rcp) return rcp;
+        return BEAGLE_SUCCESS;
     } else {
         std::vector<double> acc(count, 0.0), part(count);
         for (int k = 0; k < n; k++) {

@@ -37,4 +37,10 @@ int shardedRootReduce(int handle, int count, const std::function<int(int shardHa
 // per-shard host vectors of `len` doubles that add up
 int shardedSumDoubles(int handle, int len, const std::function<int(int shardHandle, double* out)>& call, double* outSum);
 
+
+// engine_abi.cpp, for the reduction above: `count` doubles at device address dValues of (single-GPU) instance `instance` go to
+// the host through the instance's mapped result words — one small kernel behind whatever is on the instance's stream, then a
+// poll — instead of a device-to-host copy and a stream synchronisation.  count <= 480.
+int publishAndWait(int instance, const double* dValues, int count, double* out);
+
 }  // namespace mi355

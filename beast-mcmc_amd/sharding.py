@@ -46,17 +46,28 @@ class ShardedTreeLikelihood:
             from . import beagle as _b
             raw = _b.Beagle.__new__(_b.Beagle)
             raw.lib, raw._f, raw.instance = self.local.engine, self.local.engine.fn, self.local.instance
-            if dist is not None and world_size > 1:
-                ident = torch.zeros(128, dtype=torch.uint8, device=device)
-                if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(raw.commUniqueId()), dtype=torch.uint8))
-                dist.broadcast(ident, src=0)
-                unique = bytes(ident.cpu().numpy().tobytes())
+            ok = 1
+            try:
+                if dist is not None and world_size > 1:
+                    ident = torch.zeros(128, dtype=torch.uint8, device=device)
+                    if rank == 0:
+                        ident.copy_(torch.frombuffer(bytearray(raw.commUniqueId()), dtype=torch.uint8))
+                    dist.broadcast(ident, src=0)
+                    unique = bytes(ident.cpu().numpy().tobytes())
+                else:
+                    unique = raw.commUniqueId()
+                raw.commInit(unique, rank, world_size)
+            except Exception:                         # noqa: BLE001  (decided together below)
+                ok = 0
+            if dist is not None and world_size > 1:   # every rank takes the same route: all of them have a communicator, or none uses it
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                self.local.set_engine_collective(True)
             else:
-                unique = raw.commUniqueId()
-            raw.commInit(unique, rank, world_size)
-            self.local.set_engine_collective(True)
-        elif device is not None:
+                self.collective = "torch"
+        if device is not None and self.collective != "engine":
             import torch
             self._torch = torch
             self._stream = torch.cuda.Stream(device=device)
@@ -68,7 +79,7 @@ class ShardedTreeLikelihood:
             raw = _b.Beagle.__new__(_b.Beagle)
             raw.lib, raw._f, raw.instance = self.local.engine, self.local.engine.fn, self.local.instance
             raw.setStream(self._stream.cuda_stream)
-        elif dist is not None:
+        elif device is None and dist is not None:
             import torch
             self._torch = torch
             self._buf = torch.zeros(1, dtype=torch.float64)

@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
                     help="ranks: one process per GPU + torch.distributed all-reduce (default); library: one process, the engine's resource G+1")
     ap.add_argument("--no-library-route", action="store_true", help="do not append the in-library route's run to the line")
+    ap.add_argument("--spinup", type=float, default=-1.0,
+                    help="seconds of untimed evaluations BEFORE the --warmup steps (development: how long the device takes to reach its "
+                         "steady clocks after the idle seconds of workload generation); default: none")
+    ap.add_argument("--step-times", action="store_true", help="development: the wall-clock time of every timed step in the line (step_ms)")
     ap.add_argument("--no-side-records", action="store_true", help="no shard_point / partial_update sub-records (the rocprofv3 re-runs pass this)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run under rocprofv3 for roofline.traffic (the re-runs themselves pass this)")
@@ -169,6 +173,9 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29555", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=device)
 
+    import gc
+    gc.collect()
+    gc.disable()                       # (timed_loop; the process exits right after the line is printed)
     t_gen = time.time()
     makers = {"A": lambda: bm.synth.config_a(scale=args.scale, tree_kind=args.tree),
               "B": lambda: bm.synth.config_b(scale=args.scale),
@@ -272,11 +279,12 @@ def selftest_launcher(args):
     return out
 
 
-def timed_loop(torch, device, dist, steps, step):
-    """Barrier + device synchronisation on both sides, MAX over ranks; the Python collector is paused inside (a
-    generation-2 collection of a process with torch loaded takes ~40 ms, ten evaluations' worth, and is triggered by the
-    harness' own ctypes argument objects, not by anything on the measured path)."""
-    import gc
+def timed_loop(torch, device, dist, steps, step, after_barrier=None):
+    """Barrier + device synchronisation on both sides, MAX over ranks.  The Python collector is off while bench.py measures
+    (main() collects once and disables it: a generation-2 collection of a process with torch loaded takes ~40 ms — ten
+    evaluations' worth, triggered by the harness' own ctypes argument objects, and an idle gap in which the device drops its
+    clocks: the first ~30 evaluations after such a gap run up to 20 % slower, profiles/r04_experiments.txt).
+    after_barrier: called between the opening barrier and the clock (cheap bookkeeping only)."""
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -284,16 +292,15 @@ def timed_loop(torch, device, dist, steps, step):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    gc.collect()
-    gc.disable()
     barrier()
+    if after_barrier is not None:
+        after_barrier()
     t0 = time.perf_counter()
     v = None
     for i in range(steps):
         v = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    gc.enable()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -425,18 +432,53 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             site_buf["n"] += local.getSiteLogLikelihoods().shape[0]
         return v
 
-    # reach DYNAMIC steady state (first evaluation underflows and recomputes the scalers), then warm up
+    # reach DYNAMIC steady state (first evaluation underflows and recomputes the scalers)
     lnl0 = step(0)
     step(1)
-    for i in range(args.warmup):
-        step(i)
+    spin_evals = 0
+    if args.spinup > 0:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup:
+            step(spin_evals)
+            spin_evals += 1
     raw = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
     raw.lib, raw._f, raw.instance = local.engine, local.engine.fn, local.instance
     # HIP events around the pruning launches of every TIMER_EVERY-th evaluation of the timed region (an event pair is two
-    # barrier packets on the stream: 12 us of GPU idle per bracketed evaluation, profiles/r04_experiments.txt)
+    # barrier packets on the stream: 12 us of GPU idle per bracketed evaluation, profiles/r04_experiments.txt).  Armed HERE —
+    # it synchronises and creates its event pairs — and restarted (free) when the timed region begins.
     raw.kernelTimer(TIMER_EVERY)
-    raw.kernelTimerCalls()
-    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
+
+    # the other caller protocol, for the record (a shorter run of the same loop) — BEFORE the main measurement: whatever
+    # bench.py measures first finds a device that has idled through the seconds of workload generation, and the main line
+    # should not be the one that pays for that (step_ms of a cold start: profiles/r04_experiments.txt)
+    other = None
+    if world == 1:
+        keep = args.caller
+        args.caller = "btl" if keep == "tdl" else "tdl"
+        for i in range(3):
+            step(i)                                   # (its first calls allocate: read-back buffers, numpy arrays)
+        n2 = max(30, args.steps // 4)
+        e2, _ = timed_loop(torch, device, dist, n2, step)
+        other = {"caller": args.caller, "evals_per_s": round(n2 / e2, 3), "ms_per_step": round(1e3 * e2 / n2, 4), "steps": n2}
+        args.caller = keep
+
+    for i in range(args.warmup):
+        step(i)
+    step_ms = []
+    if args.step_times:
+        inner = step
+
+        def step(i, inner=inner):                    # noqa: F811
+            t = time.perf_counter()
+            v = inner(i)
+            step_ms.append(round(1e3 * (time.perf_counter() - t), 4))
+            return v
+
+    def restart():
+        raw.kernelTimerRestart()
+        raw.kernelTimerCalls()
+
+    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=restart)
     stats = raw.walkStats()
     kernel_ms, launches = raw.kernelTimer(False)
     timed_calls = max(1, raw.kernelTimerCalls())
@@ -447,22 +489,6 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
     evals_per_s = args.steps / elapsed
     counters = local.counters()
 
-    # the other caller protocol, for the record (a shorter run of the same loop)
-    other = None
-    if world == 1:
-        keep = args.caller
-        args.caller = "btl" if keep == "tdl" else "tdl"
-        n2 = max(10, args.steps // 4)
-        e2, _ = timed_loop(torch, device, dist, n2, step)
-        other = {"caller": args.caller, "evals_per_s": round(n2 / e2, 3), "ms_per_step": round(1e3 * e2 / n2, 4)}
-        args.caller = keep
-
-    partial = None
-    if world == 1 and args.route == "ranks" and not sharded and args.config in ("A", "D") and not args.no_side_records:
-        try:
-            partial = partial_update_point(bm, wl, tl, raw)
-        except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
-            partial = {"error": "%s: %s" % (type(e).__name__, e)}
     out = None
     if rank == 0:
         n_gpus = args.gpus if args.route == "library" else world
@@ -515,9 +541,17 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         if tflops / 78.6 > achieved / HBM_PEAK_GBS:            # the compute roof is the nearer one (codon models)
             roofline.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s",
                              "frac": round(tflops / 78.6, 4), "hbm_GBs": round(achieved, 1)})
+        collective_name = ("ncclAllReduce inside the engine, on its stream (RCCL over xGMI; torch.distributed only carried the communicator id)"
+                           if sharded and getattr(tl, "collective", "") == "engine" else "torch.distributed over RCCL")
         cpu = None
         if n_gpus == 1 and args.route == "ranks" and not args.no_cpu_baseline:
             cpu = cpu_baseline(bm, wl, args.cpu_sample, tl)
+        partial = None           # (after the CPU cross-check, which reads this instance's site values of the unmoved tree)
+        if world == 1 and args.route == "ranks" and not sharded and args.config in ("A", "D") and not args.no_side_records:
+            try:
+                partial = partial_update_point(bm, wl, tl, raw)
+            except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
+                partial = {"error": "%s: %s" % (type(e).__name__, e)}
         out = {
             "metric": "full-tree lnL evals/sec (GTR+G4, 1e5 patterns)" if args.config == "A" else "full-tree lnL evals/sec",
             "value": round(evals_per_s, 3), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -529,13 +563,14 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
                                    "%s, new eigen system + rates every step"
                                    % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth(),
                                       "ALWAYS rescaling (write mode every evaluation)" if args.rescaling == "always" else "DYNAMIC rescaling steady state"),
-                       "caller": args.caller, "patterns_per_gpu": p_, "parallelism": ("pattern-shard x%d + 1 all-reduce (torch.distributed over RCCL, one process per GPU)" % n_gpus) if args.route == "ranks"
+                       "caller": args.caller, "patterns_per_gpu": p_, "parallelism": ("pattern-shard x%d + 1 all-reduce (%s), one process per GPU" % (n_gpus, collective_name)) if args.route == "ranks"
                                       else "pattern-shard x%d inside the library (resource G+1, ncclAllReduce), one process" % n_gpus,
                        "ops_per_eval": int(counters["last_op_count"]), "matrices_per_eval": int(counters["last_branch_count"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_caller": other,
             "partial_update": partial,
+            "spinup_evaluations": spin_evals, "step_ms": step_ms[:args.steps] if args.step_times else None,
             "lnL": lnl, "lnL_first_eval": lnl0, "hbm_bytes_resident": int(raw.deviceBytes()),
             "evaluations_total": int(local.counters()["evaluations"]),
             "kernel_source_hash": kernel_source_hash(), "workload_generation_s": round(t_gen, 1),
@@ -725,11 +760,10 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         return total
 
     lnl0 = step(0)
+    tl.b.kernelTimer(TIMER_EVERY)                      # (armed before the warm-up, restarted for free when the timed region begins)
     for i in range(args.warmup):
         step(i)
-    tl.b.kernelTimer(TIMER_EVERY)
-    tl.b.kernelTimerCalls()
-    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step)
+    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=tl.b.kernelTimerRestart)
     stats = tl.b.walkStats()
     kernel_ms, _ = tl.b.kernelTimer(False)
     timed_calls = max(1, tl.b.kernelTimerCalls())

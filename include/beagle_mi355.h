@@ -337,6 +337,10 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
  * an evaluation): milliseconds and launches then cover those calls; beagleMi355KernelTimerCalls returns how many updatePartials
  * calls were bracketed since it was last asked (and resets the count) — the divisor for "kernel time per evaluation". */
 int beagleMi355KernelTimerCalls(int instance, long* outCalls);
+/* Forget what the (enabled) kernel timer and the walk counters have gathered so far — no synchronisation, no allocation: for a
+ * caller that has just synchronised the stream itself and wants the measurement to start here (bench.py: between its warm-up
+ * and its timed steps, without giving the device an idle gap to drop its clocks in). */
+int beagleMi355KernelTimerRestart(int instance);
 /* Traffic counters of the 4-state pattern walk since the last beagleMi355KernelTimer call: out[0] micro-operations,
  * [1] partials buffers stored, [2] partials buffers read from memory, [3] tip-state vectors read, [4] scale-factor
  * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the

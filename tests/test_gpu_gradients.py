@@ -372,3 +372,14 @@ def test_gradient_after_set_pattern_partitions(S, oracle_lib):
             a, b = g.pre_partials(n).reshape(2, wl.pattern_count, S), o.pre_partials(n).reshape(2, wl.pattern_count, S)
             ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
             assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
+
+
+def test_gradient_entry_points_above_64_states_are_refused():
+    """65..255 states run the likelihood path only (include/beagle_mi355.h, beagleCreateInstance): the pre-order / gradient entry
+    points answer BEAGLE_ERROR_NO_IMPLEMENTATION (-7) instead of running kernels that stage S x S tiles."""
+    wl = helpers.random_workload(5, 20, 70, 1, seed=9)
+    g = BranchGradient(wl)
+    with pytest.raises(bm.beagle.BeagleException) as e:
+        g.gradient()
+    assert e.value.code == -7
+    g.close()

@@ -102,7 +102,10 @@ def test_golden_epoch_convolution(engine_lib):
                                      (20, 4, 12, 333), (20, 1, 7, 50), (61, 4, 9, 150), (61, 2, 5, 33), (3, 3, 6, 100),
                                      (2, 1, 12, 77), (7, 5, 10, 200),
                                      # MFMA / T32-layout path (16..64 states), incl. partial 4-tiles and ragged 32-tiles
-                                     (16, 2, 6, 70), (21, 3, 6, 95), (60, 1, 5, 31), (64, 2, 5, 65), (20, 4, 30, 1000)])
+                                     (16, 2, 6, 70), (21, 3, 6, 95), (60, 1, 5, 31), (64, 2, 5, 65), (20, 4, 30, 1000),
+                                     # more than 64 states (large discrete-trait spaces): the general kernels, matrices staged in LDS
+                                     # up to ~95 states, read from L2 above (kernels.hip k_pruneGeneral<false>, k_transitionBig)
+                                     (65, 2, 6, 40), (90, 1, 5, 23), (100, 2, 5, 30), (128, 1, 6, 21), (200, 1, 4, 9)])
 @pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_ALWAYS])
 def test_engine_matches_oracle(S, C, T, P, scheme, oracle_lib):
     wl = helpers.random_workload(T, P, S, C, seed=100 + S + C)

@@ -33,10 +33,12 @@ SPB = 122                     # ... of the second child's
 T0, T1 = 94, 95
 PA, PB, TIP, SCALE, OM, HOLD, SP0, SP1, LANE, VST = 96, 97, 98, 99, 100, 101, 102, 103, 104, 105
 H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
-NV = 124
+TBV0, TBV1 = 124, 125          # the LDS addresses of the two table buffers, in every lane (broadcast reads of a matrix's first column)
+NV = 126
 # scalar (s32..s35 are left to the compiler)
 DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 25, 26, 27, 28, 29, 30, 31
-D, DFL, CM160, DW = 36, 44, 45, 46    # descriptor: src1 D+0, src2 D+2, store D+4, scale D+6; flags; the scale buffer a rescaling operation writes
+D, DFL, DW = 36, 44, 46             # descriptor (kernels.h WalkOp): src1 D+0, src2 D+2, store D+4, scale D+6 | flags s44, (pad s45), the scale buffer a rescaling operation writes s46:47 — two loads: x8 at 0, x4 at 0x20
+CM160 = 83
 SA_FL, SA_STORE, SA_SRC2, SA_SCALEW = 48, 50, 52, 54
 SB_FL, SB_STORE, SB_SRC2, SB_SCALEW = 56, 58, 60, 62
 MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
@@ -65,7 +67,22 @@ LDSBATCH = os.environ.get("WALK4_LDSBATCH", "0") != "0"     # every LDS read of 
 EARLYDESC = os.environ.get("WALK4_EARLYDESC", "0") != "0"   # descriptor k + 2 is requested right after the fetch of k + 1 has used the registers
 # TIMING EXPERIMENTS ONLY (wrong results; tools/walk_floor.sh, profiles/r02_experiments.txt): comma-separated parts to leave out
 EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if x)
+# TIMING EXPERIMENTS ONLY (same results): WALK4_PAD=<kind>:<n> adds n do-nothing instructions to every stage — snop (s_nop 0: 4 bytes,
+# scalar), slit (s_mov_b32 with a 32-bit literal into a scratch register: 8 bytes, scalar), vmov (v_mov_b32 of a scratch register
+# onto itself: 4 bytes, vector), vlit (v_mov_b32 of a literal into a scratch register: 8 bytes, vector) — to tell what the loop
+# is bound by: instruction count, instruction bytes or the vector pipe (profiles/r04_experiments.txt)
+PAD = os.environ.get("WALK4_PAD", "")
+COL0 = os.environ.get("WALK4_COL0", "1") != "0"            # a mat-vec's first column from broadcast LDS reads (matvec): A/B switch
 lines = []
+
+
+def pad_block():
+    if not PAD:
+        return
+    kind, n = PAD.split(":")
+    for _ in range(int(n)):
+        e({"snop": "s_nop 0", "slit": "s_mov_b32 %s, 0x12345678" % s(ST), "vmov": "v_mov_b32_e32 %s, %s" % (v(T1), v(T1)),
+           "vlit": "v_mov_b32_e32 %s, 0x12345678" % v(T1)}[kind])
 
 
 def e(s):
@@ -84,13 +101,23 @@ def L(name):
     return ".LW4%s_%%=" % name
 
 
-def matvec(dst, x, sp=None, col0=None):
+def matvec(dst, x, sp=None, col0=None, col0v=None):
     """dst (16 regs: a rows 0-3, b rows 0-3) = M . x for the two patterns; M spread over the lanes of `sp`.  The rounding
     sequence is y_i = fma(m_i3, x3, fma(m_i2, x2, fma(m_i1, x1, m_i0 * x0))) (= fma(m_i0, x0, 0) bit for bit: both
-    factors are never negative).  col0: the SGPRs holding M[0..3][0] — the first term is then a plain multiply by a scalar
-    operand and nothing has to be zeroed (v_mul_f64 has no DPP form; 32 instead of 40 vector instructions)."""
+    factors are never negative).
+    col0v: eight vector registers that hold M[0..3][0] in every lane (two broadcast ds_read_b128 of the table's first column,
+    issued by the caller together with the read of `sp`): the first term is then a plain multiply and nothing has to be zeroed
+    — v_mul_f64 has no DPP form, so without them the accumulators are cleared by eight v_mov_b64 and the first term is a
+    fourth DPP multiply-add (40 instead of 32 vector instructions; the loop is bound by instruction issue).
+    col0: the same from SGPRs (an experiment of round 3)."""
     sp = SP if sp is None else sp
-    if col0 is None:
+    if not COL0:
+        col0v = None
+    if col0v is not None:
+        for half in range(2):
+            for i in range(4):
+                e("v_mul_f64 %s, %s, %s" % (v(dst + 8 * half + 2 * i, 2), v(col0v + 2 * i, 2), v(x + 8 * half, 2)))
+    elif col0 is None:
         for i in range(8):
             e("v_mov_b64 %s, 0" % v(dst + 2 * i, 2))
     else:
@@ -98,12 +125,20 @@ def matvec(dst, x, sp=None, col0=None):
             for i in range(4):
                 e("v_mul_f64 %s, %s, %s" % (v(dst + 8 * half + 2 * i, 2), s(col0 + 2 * i, 2), v(x + 8 * half, 2)))
     for j in range(0 if "nofma" in EXPERIMENT else 4):
-        if j == 0 and col0 is not None:
+        if j == 0 and (col0 is not None or col0v is not None):
             continue
         for half in range(2):
             for i in range(4):
                 e("v_fmac_f64_dpp %s, %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf"
                   % (v(dst + 8 * half + 2 * i, 2), v(sp, 2), v(x + 8 * half + 2 * j, 2), 4 * i + j))
+
+
+def col0_reads(tmp, tbv, off):
+    """the table's first column (M[0..3][0]: its first 32 bytes, kernels_walk4.hip k_gatherMatrices) into tmp..tmp+7, every lane"""
+    if not COL0:
+        return
+    e("ds_read_b128 %s, %s offset:%d" % (v(tmp, 4), v(tbv), off))
+    e("ds_read_b128 %s, %s offset:%d" % (v(tmp + 4, 4), v(tbv), off + 16))
 
 
 def tip_columns(dst, t, tbl, off):
@@ -218,20 +253,10 @@ def rescale_block(tag, SSCALEW):
 
 def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
     """Issue everything the micro-operation described by D needs into pipeline slot (X, Tt1, Tt2, INV), stash what its
-    compute stage needs, advance the stream."""
-    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD))
-    e("s_cbranch_scc1 %s" % L("hr" + tag))
-    e(L("hrb" + tag) + ":")
-    blk = [L("hr" + tag) + ":",
-           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD2),          # slot 2 is a register set: nothing to fetch
-           "s_cbranch_scc1 %s" % L("hrb" + tag),
-           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD1),
-           "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
-           "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
-    for q in range(4):
-        blk.append("ds_read_b128 %s, %s offset:%d" % (v(X + 4 * q, 4), v(T0), 1024 * q))
-    blk.append("s_branch %s" % L("hrb" + tag))
-    outofline.append(blk)
+    compute stage needs (the flags and the scale buffer a rescaling operation writes: the two fields rare blocks need — the
+    store address, a second child in memory — are read again from the descriptor where they are used), advance the stream.
+    The loop is bound by instruction ISSUE, whatever the type (~4 cycles per instruction and SIMD): the two rare
+    cases of a fetch — a first child waiting in an LDS hold slot, a first child in memory — share ONE test on the common path."""
     # (an experiment that drops a load replaces it by a cheap one to the same register so that the waits still balance)
     if "nodma" in EXPERIMENT:
         e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
@@ -246,25 +271,33 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
         e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
     else:
         e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
-    e("s_add_u32 %s, %s, %s" % (s(STRM), s(STRM), s(STEP)))
-    e("s_addc_u32 %s, %s, 0" % (s(STRM + 1), s(STRM + 1)))
+    e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
     e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
-    e("s_mov_b64 %s, %s" % (s(SSTORE, 2), s(D + 4, 2)))
-    e("s_mov_b64 %s, %s" % (s(SSRC2, 2), s(D + 2, 2)))
     e("s_mov_b64 %s, %s" % (s(SSCALEW, 2), s(DW, 2)))
-    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_X))
-    e("s_cbranch_scc1 %s" % L("x" + tag))
-    e(L("xb" + tag) + ":")
-    blk = [L("x" + tag) + ":",
-           "global_load_dwordx4 %s, %s, %s%s" % (v(X, 4), v(PA), s(D, 2), LOAD_POLICY),
-           "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 4, 4), v(PA), s(D, 2), LOAD_POLICY),
-           "global_load_dwordx4 %s, %s, %s%s" % (v(X + 8, 4), v(PB), s(D, 2), LOAD_POLICY),
-           "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 12, 4), v(PB), s(D, 2), LOAD_POLICY),
-           "s_branch %s" % L("xb" + tag)]
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(DFL), (1 << B_HREAD) | (1 << B_X)))
+    e("s_cbranch_scc1 %s" % L("fr" + tag))
+    e(L("frb" + tag) + ":")
+    blk = [L("fr" + tag) + ":",
+           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD),
+           "s_cbranch_scc0 %s" % L("x" + tag),
+           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD2),          # slot 2 is a register set: nothing to fetch
+           "s_cbranch_scc1 %s" % L("frb" + tag),
+           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD1),
+           "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
+           "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
+    for q in range(4):
+        blk.append("ds_read_b128 %s, %s offset:%d" % (v(X + 4 * q, 4), v(T0), 1024 * q))
+    blk.append("s_branch %s" % L("frb" + tag))
+    blk += [L("x" + tag) + ":",
+            "global_load_dwordx4 %s, %s, %s%s" % (v(X, 4), v(PA), s(D, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 4, 4), v(PA), s(D, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s%s" % (v(X + 8, 4), v(PB), s(D, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 12, 4), v(PB), s(D, 2), LOAD_POLICY),
+            "s_branch %s" % L("frb" + tag)]
     outofline.append(blk)
 
 
-def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext, c0set):
+def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, tbvCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext, c0set):
     """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
     following one is fetched into the other slot."""
     if "notopwait" not in EXPERIMENT:
@@ -272,22 +305,26 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
     fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext)
     if EARLYDESC:   # descriptor k + 2, a whole stage before its use: its latency (a scalar-cache miss goes to L2) hides behind the wait below
         e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-        e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
-        e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
+        e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
         e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
         e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # wait for this micro-operation's loads: N = everything issued after them = 4 (+4 stores before, +4 partials loads now)
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0))
-    e("s_cbranch_scc1 %s" % L("w8" + tag))
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT1))
-    e("s_cbranch_scc1 %s" % L("w12" + tag))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WAIT0) | (1 << B_WAIT1)))
+    e("s_cbranch_scc1 %s" % L("ws" + tag))
     novm = "novmwait" in EXPERIMENT
     e("s_nop 0" if novm else "s_waitcnt vmcnt(4)")
     e(L("wd" + tag) + ":")
-    outofline.append([L("w8" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag)])
-    outofline.append([L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
+    outofline.append([L("ws" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc0 %s" % L("w12" + tag),
+                      "s_nop 0" if novm else "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag),
+                      L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
     c0 = c0set if SCOL else None
+    # (descriptor k of the micro-operation being computed: DP points at k + 2 until the stage's descriptor load, at k + 3 after it —
+    # with EARLYDESC at k + 3 from the fetch on; kernels.h WalkOp: src2 at 8, store at 16)
+    off_src2 = -(3 if EARLYDESC else 2) * 64 + 8
+    off_store = -3 * 64 + 16
     m2blk = [L("m2" + tag) + ":",                    # both children in memory: the second one is loaded into ACC, synchronously
+             "s_load_dwordx2 %s, %s, %d" % (s(SSRC2, 2), s(DP, 2), off_src2),
+             "s_waitcnt lgkmcnt(0)",
              "global_load_dwordx4 %s, %s, %s%s" % (v(ACC, 4), v(PA), s(SSRC2, 2), LOAD_POLICY),
              "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(ACC + 4, 4), v(PA), s(SSRC2, 2), LOAD_POLICY),
              "global_load_dwordx4 %s, %s, %s%s" % (v(ACC + 8, 4), v(PB), s(SSRC2, 2), LOAD_POLICY),
@@ -341,16 +378,17 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e("s_branch %s" % L("g" + tag))
         e(L("fm" + tag) + ":")
         e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+        col0_reads(G, tbvCur, 0)                     # (G is free until the second child's contribution is formed)
         e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
         e("s_cbranch_scc1 %s" % L("fh2" + tag))
         ldsw = "s_nop 0" if "noldswait" in EXPERIMENT else "s_waitcnt lgkmcnt(0)"
         e(ldsw)
-        matvec(F, X, SP, c0)
+        matvec(F, X, SP, c0, col0v=G)
         save = lines[:]
         del lines[:]
         e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
         e(ldsw)
-        matvec(F, H2, SP, c0)
+        matvec(F, H2, SP, c0, col0v=G)
         e("s_branch %s" % L("g" + tag))
         outofline.append(lines[:])
         del lines[:]
@@ -368,14 +406,14 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e(L("m2b" + tag) + ":")
         outofline.append(m2blk)
         e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
+        col0_reads(X, tbvCur, 160)                   # (this slot's first-child registers: consumed by the first mat-vec, or never used)
         e(ldsw)
-        matvec(G, ACC, SP, None if c0 is None else c0 + 8)
+        matvec(G, ACC, SP, None if c0 is None else c0 + 8, col0v=X)
     e(L("mul" + tag) + ":")
     # descriptor k + 2: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)
     if not EARLYDESC:
         e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-        e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
-        e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
+        e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
     if SCOL:    # column 0 of both tables of micro-operation k + 2 (STRM points there since this stage's fetch) into the set this
         #         stage's mat-vecs have just finished with
         e("s_load_dwordx8 %s, %s, %s" % (s(c0set, 8), s(STRM, 2), s(CM0)))
@@ -387,18 +425,23 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_WRITE))
-    e("s_cbranch_scc1 %s" % L("wr" + tag))
-    e(L("wrb" + tag) + ":")
+    pad_block()
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WRITE) | (1 << B_STORE)))
+    e("s_cbranch_scc1 %s" % L("tl" + tag))
+    e(L("tlb" + tag) + ":")
+    # the rare tail — write-mode rescaling, a result that is stored — out of line: the two tests of old, each with its block, then
+    # back; a result that is parked in a hold slot is every third micro-operation's case and keeps its own test
+    outofline.append([L("tl" + tag) + ":",
+                      "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WRITE), "s_cbranch_scc1 %s" % L("wr" + tag), L("wrb" + tag) + ":",
+                      "s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE), "s_cbranch_scc1 %s" % L("st" + tag), L("stb" + tag) + ":",
+                      "s_branch %s" % L("tlb" + tag)])
     outofline.append(rescale_block(tag, SSCALEW))
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE))
-    e("s_cbranch_scc1 %s" % L("st" + tag))
-    e(L("stb" + tag) + ":")
     # The result leaves in FOUR FULLY CONTIGUOUS 1 KiB stores (tools/hbm_write_probe.hip: half-line non-temporal stores
     # sustain 2.0 TB/s, full lines 4.9-5.2): lane 2 q + r owns patterns q + 32 r and 64 + q + 32 r of the workgroup's 128,
     # store instruction j covers patterns 32 j .. 32 j + 31, lane 2 q + r writing half r (16 bytes) of pattern 32 j + q —
     # its own data or its neighbour's, exchanged with v_cndmask_b32_dpp quad_perm:[1,0,3,2] (no LDS).
-    blk = [L("st" + tag) + ":", "s_mov_b32 vcc_lo, 0x55555555", "s_mov_b32 vcc_hi, 0x55555555", "s_nop 1"]
+    blk = [L("st" + tag) + ":", "s_load_dwordx2 %s, %s, %d" % (s(SSTORE, 2), s(DP, 2), off_store),
+           "s_mov_b32 vcc_lo, 0x55555555", "s_mov_b32 vcc_hi, 0x55555555", "s_nop 1"]
     for d in range(4):      # j = 0 (pattern q, owner r = 0): even lanes own half 0; odd lanes take the neighbour's half 1
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + d), v(ACC + 4 + d), v(ACC + d)))
     for d in range(4):      # j = 2 (pattern 64 + q): the same on the second pattern of the lanes
@@ -408,6 +451,7 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, nX,
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 4 + d), v(ACC + d), v(ACC + 4 + d)))
     for d in range(4):      # j = 3 (pattern 96 + q)
         blk.append("v_cndmask_b32_dpp %s, %s, %s, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (v(F + 12 + d), v(ACC + 8 + d), v(ACC + 12 + d)))
+    blk.append("s_waitcnt lgkmcnt(0)")
     for j in range(4):
         blk.append("s_mov_b64 exec, %s" % s(MASK + 2 * j, 2))
         blk.append("global_store_dwordx4 %s, %s, %s offset:%d%s" % (v(VST), v(F + 4 * j, 4), s(SSTORE, 2), 1024 * j, STORE_POLICY))
@@ -505,12 +549,13 @@ def build():
     e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
     e("v_add_u32_e32 %s, %s, %s" % (v(SP0), s(TBL0), v(T0)))
     e("v_add_u32_e32 %s, %s, %s" % (v(SP1), s(TBL1), v(T0)))
+    e("v_mov_b32_e32 %s, %s" % (v(TBV0), s(TBL0)))
+    e("v_mov_b32_e32 %s, %s" % (v(TBV1), s(TBL1)))
     for i in range(8):
         e("v_mov_b64 %s, 1.0" % v(ACC + 2 * i, 2))
     # ---- prologue: fetch micro-operation 0 into slot A, descriptor 1 into D
     e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-    e("s_load_dword %s, %s, 0x30" % (s(DFL), s(DP, 2)))
-    e("s_load_dwordx2 %s, %s, 0x38" % (s(DW, 2), s(DP, 2)))
+    e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
     e("s_waitcnt lgkmcnt(0)")
     if SCOL:
         e("s_load_dwordx8 %s, %s, %s" % (s(C0A, 8), s(STRM, 2), s(CM0)))
@@ -520,14 +565,13 @@ def build():
         e("s_load_dwordx8 %s, %s, %s" % (s(C0B, 8), s(STRM, 2), s(CM0)))
         e("s_load_dwordx8 %s, %s, %s" % (s(C0B + 8, 8), s(STRM, 2), s(CM160)))
     e("s_load_dwordx8 %s, %s, 0x40" % (s(D, 8), s(DP, 2)))
-    e("s_load_dword %s, %s, 0x70" % (s(DFL), s(DP, 2)))
-    e("s_load_dwordx2 %s, %s, 0x78" % (s(DW, 2), s(DP, 2)))
+    e("s_load_dwordx4 %s, %s, 0x60" % (s(DFL, 4), s(DP, 2)))
     e("s_add_u32 %s, %s, 0x80" % (s(DP), s(DP)))
     e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     # ---- the loop: two stages
     e(L("top") + ":")
-    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, SP0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, C0A)
-    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, SP1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, C0B)
+    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, SP0, TBV0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, C0A)
+    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, SP1, TBV1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, C0B)
     e("s_add_i32 %s, %s, -2" % (s(CNT), s(CNT)))
     e("s_cmp_gt_i32 %s, 0" % s(CNT))
     e("s_cbranch_scc1 %s" % L("top"))
@@ -547,7 +591,7 @@ def main():
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
-    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else RB + 1)) if i not in (32, 33, 34, 35)]
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else CM160 + 1)) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
     text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
     text.append("#define WALK4_FAST_VGPRS %d" % NV)
