@@ -837,6 +837,41 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
         if (badIndex(probIdx[k], in->matrixCount) || badIndex(eig[k], in->eigenCount) || badIndex(rate[k], in->eigenCount))
             return BEAGLE_ERROR_OUT_OF_RANGE;
     }
+    // 4 states, one eigen system and one rate set (beagleUpdateTransitionMatrices — what every evaluation of a chain issues): the
+    // branch lengths and matrix indices stay in the staging ring, which the device maps, and the kernel reads them — and an
+    // eigen system / rate set whose upload is still queued — from there; the queued copies ride in the same launch
+    // (kernels.hip k_transition4Fused).  One launch instead of a copy kernel and a transition kernel: 5 us of a 12 500-pattern
+    // evaluation's 170 (profiles/r04_experiments.txt).
+    if (in->S == 4 && in->kernelUploads && in->fuseLaunches && !eigenIdx && !rateIdx && (size_t)count * 12 <= RING_BYTES / 4 &&
+        (int)in->pendingCopies.size() <= mi355::HOST_COPY_MAX) {
+        const size_t lenBytes = (size_t)count * sizeof(double), idxBytes = (size_t)count * sizeof(int);
+        const long off = stage(in, lens, lenBytes, lenBytes + idxBytes);
+        if (off < 0) return BEAGLE_ERROR_GENERAL;
+        memcpy(in->hRing + off + lenBytes, probIdx, idxBytes);
+        const size_t eigStride = in->eigenComplex ? 40 : 36;
+        const double* eigSrc = in->eigen + eigStride * eigenScalar;
+        const double* ratesSrc = in->rates;                                   // (rate set 0)
+        mi355::HostCopyList L;
+        L.n = 0;
+        unsigned blocks = 0;
+        for (const Instance::PendingCopy& pc : in->pendingCopies) {
+            mi355::HostCopyList::Entry& e = L.e[L.n++];
+            e.dst = pc.dst; e.src = in->hRingDev + pc.ringOff; e.bytes = (unsigned)pc.bytes; e.firstBlock = blocks;
+            blocks += (unsigned)((pc.bytes + 4095) / 4096);
+            // (the LAST queued upload of an array is the one that counts)
+            if (pc.dst == (void*)eigSrc && pc.bytes == eigStride * sizeof(double)) eigSrc = (const double*)(in->hRingDev + pc.ringOff);
+            if (pc.dst == (void*)in->rates && pc.bytes >= (size_t)in->C * sizeof(double)) ratesSrc = (const double*)(in->hRingDev + pc.ringOff);
+        }
+        // (an array queued twice: the copies run side by side — keep only the last one of each destination)
+        for (int a = 0; a < L.n; a++)
+            for (int b = a + 1; b < L.n; b++)
+                if (L.e[a].dst == L.e[b].dst) L.e[a].bytes = 0;
+        in->pendingCopies.clear();
+        mi355::launchTransitionMatrices4Fused(in->stream, in->matrices, eigSrc, ratesSrc, (const int*)(in->hRingDev + off + lenBytes),
+                                              (const double*)(in->hRingDev + off), count, in->C, in->eigenComplex, L, (int)blocks);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
     // one packed upload: [lengths double[count] | matrix idx | eigen idx | rate idx] (each copy is a blit kernel)
     std::vector<char> pack((size_t)count * (sizeof(double) + 3 * sizeof(int)));
     double* pLen = (double*)pack.data();

@@ -84,6 +84,9 @@ int flushUploads(Instance* in) {
             e.dst = pc[i].dst; e.src = in->hRingDev + pc[i].ringOff; e.bytes = (unsigned)pc[i].bytes; e.firstBlock = blocks;
             blocks += (unsigned)((pc[i].bytes + 4095) / 4096);
         }
+        for (int a = 0; a < L.n; a++)                     // the copies of one launch run side by side: of two for the same destination
+            for (int b = a + 1; b < L.n; b++)             // only the later one may happen
+                if (L.e[a].dst == L.e[b].dst) L.e[a].bytes = 0;
         mi355::launchHostCopies(in->stream, L, (int)blocks);
     }
     pc.clear();

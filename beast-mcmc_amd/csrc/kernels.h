@@ -153,6 +153,15 @@ void launchTransitionMatrices(hipStream_t stream, double* matrices, const double
                               const int* dIdx, const double* dLen, const int* dEig, const int* dRate,
                               int count, int S, int C, bool complexEigen = false);
 
+// 4 states, ONE eigen system and ONE rate set for all `count` branches (beagleUpdateTransitionMatrices), and everything the call
+// needs still in the host's staging ring: eigSrc / ratesSrc / idx / len may be HOST addresses the device maps (each workgroup
+// stages the eigen system and the rates in LDS with one read over the link, a thread reads its own branch length and matrix
+// index), and the queued host->device copies of `pending` (kernels.h HostCopyList: the persistent copies of the same eigen
+// system and rates, whatever else was queued) ride in the same launch as extra workgroups — one launch where there were a
+// copy kernel and a transition kernel.  Same arithmetic and summation order as launchTransitionMatrices.
+void launchTransitionMatrices4Fused(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
+                                    const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks);
+
 // C_c = A_c * B_c per category, `count` triples (device index arrays).
 void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,
                             const int* dResult, int count, int S, int C);

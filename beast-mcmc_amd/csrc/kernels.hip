@@ -42,23 +42,8 @@ bool grantDynamicLds(const void* kernel, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // host -> device copies of small arrays (kernels.h HostCopyList): a workgroup moves 4 KiB of one entry
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hostCopies(const HostCopyList L) {
-    int k = 0;
-    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].firstBlock) k++;
-    const size_t base = (size_t)(blockIdx.x - L.e[k].firstBlock) * 4096;
-    const char* s = (const char*)L.e[k].src + base;
-    char* d = (char*)L.e[k].dst + base;
-    const unsigned left = L.e[k].bytes - (unsigned)base, n = left < 4096u ? left : 4096u;
-    const unsigned t = threadIdx.x;
-    if ((((size_t)s | (size_t)d) & 15) == 0) {
-        if (t * 16 + 16 <= n) *reinterpret_cast<uint4*>(d + t * 16) = *reinterpret_cast<const uint4*>(s + t * 16);
-        for (unsigned i = (n & ~15u) + t; i < n; i += 256) d[i] = s[i];
-    } else if ((((size_t)s | (size_t)d) & 3) == 0) {
-        for (unsigned i = t * 4; i + 4 <= n; i += 1024) *reinterpret_cast<unsigned*>(d + i) = *reinterpret_cast<const unsigned*>(s + i);
-        for (unsigned i = (n & ~3u) + t; i < n; i += 256) d[i] = s[i];
-    } else
-        for (unsigned i = t; i < n; i += 256) d[i] = s[i];
-}
+__device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block);
+__global__ __launch_bounds__(256) void k_hostCopies(const HostCopyList L) { hostCopyBlock(L, blockIdx.x); }
 void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks) {
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_hostCopies, dim3((unsigned)blocks), dim3(256), 0, stream, list);
@@ -180,6 +165,62 @@ __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matric
             for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
             M[i * 4 + j] = s > 0.0 ? s : 0.0;
         }
+}
+
+__device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block) {
+    int k = 0;
+    while (k + 1 < L.n && block >= L.e[k + 1].firstBlock) k++;
+    const size_t base = (size_t)(block - L.e[k].firstBlock) * 4096;
+    if (base >= L.e[k].bytes) return;                 // (an entry superseded by a later one for the same destination: bytes = 0)
+    const char* s = (const char*)L.e[k].src + base;
+    char* d = (char*)L.e[k].dst + base;
+    const unsigned left = L.e[k].bytes - (unsigned)base, n = left < 4096u ? left : 4096u;
+    const unsigned t = threadIdx.x;
+    if ((((size_t)s | (size_t)d) & 15) == 0) {
+        if (t * 16 + 16 <= n) *reinterpret_cast<uint4*>(d + t * 16) = *reinterpret_cast<const uint4*>(s + t * 16);
+        for (unsigned i = (n & ~15u) + t; i < n; i += 256) d[i] = s[i];
+    } else if ((((size_t)s | (size_t)d) & 3) == 0) {
+        for (unsigned i = t * 4; i + 4 <= n; i += 1024) *reinterpret_cast<unsigned*>(d + i) = *reinterpret_cast<const unsigned*>(s + i);
+        for (unsigned i = (n & ~3u) + t; i < n; i += 256) d[i] = s[i];
+    } else
+        for (unsigned i = t; i < n; i += 256) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ matrices, const double* __restrict__ eigSrc,
+                                                          const double* __restrict__ ratesSrc, const int* __restrict__ idx,
+                                                          const double* __restrict__ len, int count, int C, int complexEigen,
+                                                          const HostCopyList L, int transitionBlocks) {
+    if ((int)blockIdx.x >= transitionBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)transitionBlocks); return; }
+    __shared__ double sEig[40], sRate[16];
+    const int nEig = complexEigen ? 40 : 36;
+    if ((int)threadIdx.x < nEig) sEig[threadIdx.x] = eigSrc[threadIdx.x];
+    else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C && C <= 16) sRate[threadIdx.x - 64] = ratesSrc[threadIdx.x - 64];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * C) return;
+    const int u = t / C, c = t - u * C;
+    const double* U = sEig;
+    const double* Ui = U + 16;
+    const double* lam = U + 32;
+    const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
+    double ie[16];
+    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
+    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
+    double* M = matrices + ((size_t)idx[u] * C + c) * 16;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
+            M[i * 4 + j] = s > 0.0 ? s : 0.0;
+        }
+}
+
+void launchTransitionMatrices4Fused(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
+                                    const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks) {
+    if (count <= 0) return;
+    const int tb = (int)(((size_t)count * C + 255) / 256);
+    hipLaunchKernelGGL(k_transition4Fused, dim3((unsigned)(tb + copyBlocks)), dim3(256), 0, stream, matrices, eigSrc, ratesSrc, idx, len,
+                       count, C, complexEigen ? 1 : 0, pending, tb);
 }
 
 void launchTransitionMatrices(hipStream_t stream, double* matrices, const double* eigen, const double* rates,

@@ -15,6 +15,7 @@
 //   rescaling schemes         src/dr/evomodel/treelikelihood/PartialsRescalingScheme.java:34-42
 //
 // It holds no likelihood arithmetic: every O(patterns) operation is a call through BeagleApi.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -94,77 +95,95 @@ struct TreeLikelihood {
 
     void updateAllNodes() { std::fill(updateNode.begin(), updateNode.end(), 1); likelihoodKnown = false; }
 
-    // BeagleTreeLikelihood.traverse :1202-1322; `level` >= 0 collects per-depth lists as
-    // LikelihoodTreeTraversal.traverseLevelOrder :151-195 does.
-    bool traverse(int node, bool flip, int level) {
-        bool update = false;
-        if (parent[node] >= 0 && updateNode[node]) {
-            const double branchLength = branchRate[node] * (height[parent[node]] - height[node]);
-            if (branchLength < 0.0) { lastError = BEAGLE_ERROR_OUT_OF_RANGE; }
-            if (flip) matrixBufferHelper.flipOffset(node);
-            branchUpdateIndices[branchUpdateCount] = node;
-            branchLengths[branchUpdateCount] = branchLength;
-            branchUpdateCount++;
-            update = true;
+    // BeagleTreeLikelihood.traverse :1202-1322 (`levels`: per-depth lists as LikelihoodTreeTraversal.traverseLevelOrder :151-195
+    // collects them), as two flat passes over orders fixed by the topology (setTree) instead of a recursion per evaluation: the
+    // recursion records a node's branch BEFORE it descends and its operation AFTER both children — pre-order and post-order of
+    // the same walk (left child first) — so the lists come out entry for entry as the reference builds them.
+    std::vector<int> preOrder, postOrder, depth;
+    std::vector<char> subtreeUpdated;
+    void buildOrders() {
+        preOrder.clear(); postOrder.clear();
+        depth.assign(nodeCount, 0);
+        std::vector<std::pair<int, int>> st;          // (node, next child to visit)
+        st.emplace_back(root, 0);
+        preOrder.push_back(root);
+        while (!st.empty()) {
+            const int node = st.back().first, k = st.back().second;
+            if (node < tipCount || k == 2) { postOrder.push_back(node); st.pop_back(); continue; }
+            st.back().second = k + 1;
+            const int c = k == 0 ? left[node] : right[node];
+            depth[c] = depth[node] + 1;
+            preOrder.push_back(c);
+            st.emplace_back(c, 0);
         }
-        if (node >= tipCount) {
-            const int c1 = left[node], c2 = right[node];
-            const bool u1 = traverse(c1, flip, level < 0 ? -1 : level + 1);
-            const bool u2 = traverse(c2, flip, level < 0 ? -1 : level + 1);
-            if (u1 || u2) {
-                if (flip) partialBufferHelper.flipOffset(node);
-                int op[BEAGLE_OP_COUNT];
-                op[0] = partialBufferHelper.getOffsetIndex(node);
-                if (useScaleFactors) {
-                    const int n = node - tipCount;
-                    if (recomputeScaleFactors) {
-                        scaleBufferHelper.flipOffset(n);
-                        scaleBufferIndices[n] = scaleBufferHelper.getOffsetIndex(n);
-                        op[1] = scaleBufferIndices[n];     // write new scale factors
-                        op[2] = BEAGLE_OP_NONE;
-                    } else {
-                        op[1] = BEAGLE_OP_NONE;
-                        op[2] = scaleBufferIndices[n];     // read existing scale factors
-                    }
-                } else {
-                    op[1] = BEAGLE_OP_NONE;
-                    op[2] = BEAGLE_OP_NONE;
-                }
-                op[3] = partialBufferHelper.getOffsetIndex(c1);
-                op[4] = matrixBufferHelper.getOffsetIndex(c1);
-                op[5] = partialBufferHelper.getOffsetIndex(c2);
-                op[6] = matrixBufferHelper.getOffsetIndex(c2);
-                if (level < 0) {
-                    std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], op, sizeof(op));
-                    operationCount++;
-                } else {
-                    if (level >= (int)levelOps.size()) levelOps.resize(level + 1);
-                    if (level >= levelsUsed) levelsUsed = level + 1;
-                    std::vector<int>& v = levelOps[level];
-                    v.insert(v.end(), op, op + BEAGLE_OP_COUNT);
-                }
-                update = true;
-            }
-        }
-        return update;
+        subtreeUpdated.assign(nodeCount, 0);
+        int maxDepth = 0;
+        for (int d : depth) maxDepth = std::max(maxDepth, d);
+        levelOps.resize(maxDepth + 1);
     }
 
     void runTraversal(bool flip) {
         branchUpdateCount = 0;
         operationCount = 0;
-        if (traversal == POST_ORDER) {
-            traverse(root, flip, -1);
-        } else {
-            for (int l = 0; l < levelsUsed; l++) levelOps[l].clear();
-            levelsUsed = 0;
-            traverse(root, flip, 0);
+        const bool levels = traversal != POST_ORDER;
+        if (levels) { for (int l = 0; l < levelsUsed; l++) levelOps[l].clear(); levelsUsed = 0; }
+        for (int node : preOrder) {
+            subtreeUpdated[node] = 0;
+            if (parent[node] >= 0 && updateNode[node]) {
+                const double branchLength = branchRate[node] * (height[parent[node]] - height[node]);
+                if (branchLength < 0.0) { lastError = BEAGLE_ERROR_OUT_OF_RANGE; }
+                if (flip) matrixBufferHelper.flipOffset(node);
+                branchUpdateIndices[branchUpdateCount] = node;
+                branchLengths[branchUpdateCount] = branchLength;
+                branchUpdateCount++;
+                subtreeUpdated[node] = 1;
+            }
+        }
+        for (int node : postOrder) {
+            if (node < tipCount) continue;
+            const int c1 = left[node], c2 = right[node];
+            if (!(subtreeUpdated[c1] || subtreeUpdated[c2])) continue;
+            subtreeUpdated[node] = 1;
+            if (flip) partialBufferHelper.flipOffset(node);
+            int* op;
+            if (levels) {
+                const int level = depth[node];
+                if (level >= levelsUsed) levelsUsed = level + 1;
+                std::vector<int>& v = levelOps[level];
+                v.resize(v.size() + BEAGLE_OP_COUNT);
+                op = &v[v.size() - BEAGLE_OP_COUNT];
+            } else {
+                op = &operations[(size_t)operationCount * BEAGLE_OP_COUNT];
+                operationCount++;
+            }
+            op[0] = partialBufferHelper.getOffsetIndex(node);
+            if (useScaleFactors) {
+                const int n = node - tipCount;
+                if (recomputeScaleFactors) {
+                    scaleBufferHelper.flipOffset(n);
+                    scaleBufferIndices[n] = scaleBufferHelper.getOffsetIndex(n);
+                    op[1] = scaleBufferIndices[n];     // write new scale factors
+                    op[2] = BEAGLE_OP_NONE;
+                } else {
+                    op[1] = BEAGLE_OP_NONE;
+                    op[2] = scaleBufferIndices[n];     // read existing scale factors
+                }
+            } else {
+                op[1] = BEAGLE_OP_NONE;
+                op[2] = BEAGLE_OP_NONE;
+            }
+            op[3] = partialBufferHelper.getOffsetIndex(c1);
+            op[4] = matrixBufferHelper.getOffsetIndex(c1);
+            op[5] = partialBufferHelper.getOffsetIndex(c2);
+            op[6] = matrixBufferHelper.getOffsetIndex(c2);
+        }
+        if (levels)
             for (int l = levelsUsed - 1; l >= 0; l--) {                          // deepest level first
                 const std::vector<int>& v = levelOps[l];
                 if (v.empty()) continue;
                 std::memcpy(&operations[(size_t)operationCount * BEAGLE_OP_COUNT], v.data(), v.size() * sizeof(int));
                 operationCount += (int)(v.size() / BEAGLE_OP_COUNT);
             }
-        }
     }
 
     // calculateLogLikelihood (BeagleTreeLikelihood.java:863-1130) in three phases, so that a pattern-sharded
@@ -402,6 +421,7 @@ int btlSetTree(void* h, const int* left, const int* right, const double* heights
     }
     if (root < t->tipCount || root >= t->nodeCount || t->parent[root] != -1) return BEAGLE_ERROR_OUT_OF_RANGE;
     t->root = root;
+    t->buildOrders();
     t->updateAllNodes();
     return 0;
 }
