@@ -286,7 +286,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // tip-tip nodes with read-heavy ones), as early as possible above (61 states: 214 -> 226 evals/s, profiles/r03_experiments.txt 11);
     // BEAGLE_MI355_SCHED=asap|alap overrides
     in->schedAlap = stateCount <= 20;
-    if (getenv("BEAGLE_MI355_SCHED")) in->schedAlap = strcmp(getenv("BEAGLE_MI355_SCHED"), "asap") != 0;
+    if (getenv("BEAGLE_MI355_SCHED")) {
+        const char* sc = getenv("BEAGLE_MI355_SCHED");
+        in->schedAlap = strcmp(sc, "asap") != 0;
+        if (strncmp(sc, "dfs", 3) == 0) in->schedDfs = sc[3] == ':' ? std::max(1, atoi(sc + 4)) : 4;
+    }
     // 4 states (nucleotides), up to 16 rate categories: the pattern walk.  BEAGLE_MI355_NO_VIRTUAL=1 keeps every buffer real,
     // BEAGLE_MI355_VSTEPS=n caps the length of a virtual definition (A/B runs).
     in->walk = stateCount == 4 && categoryCount <= 16 &&

@@ -164,6 +164,7 @@ struct Instance {
     // buffers, an identity matrix and transposed-matrix slots behind the caller's matrices, an all-missing tip
     std::vector<double*> preScratch; uint8_t* preMissing = nullptr; int preIdentity = -1, preTransposed = -1;
     bool schedAlap = true;               // BEAGLE_MI355_SCHED=asap restores as-soon-as-possible levels
+    int schedDfs = 0;                    // > 0 (BEAGLE_MI355_SCHED=dfs[:K]): launches of at most K operations in depth-first order (engine_levels.cpp)
     // kernel timer
     bool timing = false;
     int timingEvery = 1, timingTick = 0; long timedCalls = 0;      // every timingEvery-th updatePartials call is bracketed (beagleMi355KernelTimer)

@@ -157,6 +157,50 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
             }
         level.swap(alap);
     }
+    // Depth-first launches (BEAGLE_MI355_SCHED=dfs[:K]; an experiment of round 4, profiles/r04_experiments.txt): a level-by-level
+    // sweep writes a whole level — gigabytes — before anything reads it back, so every child partial comes from HBM.  In
+    // depth-first order (the larger subtree of a node first, so that the smaller one and the node itself follow each other
+    // closely) a parent runs within a few launches of its children: what it reads was written megabytes ago and can still sit in
+    // the 256 MB memory-side cache.  Launches: greedily packed runs of at most K consecutive operations of that order that do
+    // not depend on each other.
+    if (in->schedDfs > 0 && !warSeen) {
+        std::vector<int> size(count, 1), order, launchOf(count, -1);
+        for (int k = 0; k < count; k++)                     // (producers precede consumers in the list)
+            if (!skipped[k]) for (int e = predOff[k]; e < predOff[k + 1]; e++) size[k] += size[predList[e]];
+        std::vector<char> consumed(count, 0), done(count, 0);
+        for (int k = 0; k < count; k++) for (int e = predOff[k]; e < predOff[k + 1]; e++) consumed[predList[e]] = 1;
+        std::vector<std::pair<int, int>> st;                // (op, next predecessor to visit), predecessors by descending subtree size
+        auto preds = [&](int k) {
+            std::vector<int> p(predList.begin() + predOff[k], predList.begin() + predOff[k + 1]);
+            std::sort(p.begin(), p.end(), [&](int a, int b) { return size[a] > size[b]; });
+            p.erase(std::unique(p.begin(), p.end()), p.end());
+            return p;
+        };
+        for (int r = 0; r < count; r++) {
+            if (skipped[r] || consumed[r] || done[r]) continue;
+            st.emplace_back(r, 0);
+            while (!st.empty()) {
+                const int k = st.back().first;
+                const std::vector<int> p = preds(k);
+                int& next = st.back().second;
+                while (next < (int)p.size() && (done[p[next]] || skipped[p[next]])) next++;
+                if (next < (int)p.size()) { const int c = p[next++]; st.emplace_back(c, 0); continue; }
+                if (!done[k]) { done[k] = 1; order.push_back(k); }
+                st.pop_back();
+            }
+        }
+        int cur = 0, inCur = 0;
+        for (int k : order) {
+            bool dep = inCur >= in->schedDfs;
+            for (int e = predOff[k]; e < predOff[k + 1] && !dep; e++) dep = launchOf[predList[e]] == cur;
+            if (dep) { cur++; inCur = 0; }
+            launchOf[k] = cur; inCur++;
+        }
+        if ((int)order.size() == count - (int)std::count(skipped.begin(), skipped.end(), (char)1)) {
+            for (int k = 0; k < count; k++) if (!skipped[k]) level[k] = launchOf[k];
+            maxLevel = cur;
+        }
+    }
     // counting sort by level (stable)
     std::vector<int> start(maxLevel + 2, 0);
     for (int k = 0; k < count; k++) if (!skipped[k]) start[level[k] + 1]++;

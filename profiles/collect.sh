@@ -17,17 +17,17 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-20}
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- \
-    python "$ROOT/bench.py" --steps $STEPS --warmup 3 --no-cpu-baseline --no-live-traffic --no-library-route "$@" > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
+    python "$ROOT/bench.py" --steps $STEPS --warmup 3 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records "$@" > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
 echo "kernel-trace rc=$?"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- \
-    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 echo "pmc FETCH_SIZE rc=$?"
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- \
-    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route "$@" > "$OUT/bench_write.json" 2> "$OUT/write.err"
+    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records "$@" > "$OUT/bench_write.json" 2> "$OUT/write.err"
 echo "pmc WRITE_SIZE rc=$?"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES \
     --output-format csv -d "$OUT/sq" -o sq -- \
-    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route "$@" > "$OUT/bench_sq.json" 2> "$OUT/sq.err"
+    python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records "$@" > "$OUT/bench_sq.json" 2> "$OUT/sq.err"
 echo "pmc SQ rc=$?"
 # keep the merge small: the per-dispatch CSVs are all that the summaries need
 find "$OUT" -name "*.db" -delete 2>/dev/null

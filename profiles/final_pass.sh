@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's final measurement pass in ONE GPU-box call:   bash profiles/final_pass.sh r03
+# The round's final measurement pass in ONE GPU-box call:   bash profiles/final_pass.sh r04
 #   1. the GPU test tier (log kept)
 #   2. the bench lines of configs A-E as the driver runs them (CPU baseline, roofline.traffic measured live by bench.py itself,
 #      the in-library multi-GPU route appended), plus the protocol variants: BeagleTreeLikelihood caller, ALWAYS rescaling, the
@@ -7,27 +7,45 @@
 #   3. rocprofv3 passes of profiles/collect.sh for A, B, C and E (kernel stats, FETCH/WRITE, SQ counters) and their summaries
 #      (profiles/summarize.py: <round>_<cfg>_kernel_stats.csv, _sq_counters.txt, hbm_traffic.json keyed to this build)
 # Everything the repo tracks of it is copied to gpurun_out/profiles_final/ (the box's profiles/ does not travel back).
-R=${1:-r03}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/profiles_final
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/profiles_final/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/profiles_final/${R}_pytest_gpu.log)"
+R=${1:-r04}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/profiles_final
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/profiles_final/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/profiles_final/${R}_pytest_gpu.log)"
 line() { python -c "import json,sys;d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]);r=d['roofline'];print(sys.argv[2], d['value'],'evals/s kernel us',r['kernel_us_per_eval'],'frac',r['frac'],'traffic',r['traffic'],'|',r['traffic_source'][:60],'| cpu',d['cpu_baseline'] and d['cpu_baseline']['value'],'| lib',d.get('library_route') and d['library_route'].get('value'))" "$1" "$2" 2>&1 | tail -1; }
 for cfg in A B C D E; do
   steps=200; [ $cfg = B ] && steps=60; [ $cfg = C ] && steps=60
   timeout 600 python bench.py --config $cfg --steps $steps --warmup 5 2> gpurun_out/${R}_bench_$cfg.err | tail -1 > gpurun_out/profiles_final/${R}_bench_$cfg.json
   line gpurun_out/profiles_final/${R}_bench_$cfg.json "bench $cfg"
 done
+# the driver's own command line (20 timed steps after 5 warm-up steps): shard_point, partial_update, library_route on it
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/${R}_bench_A_driver.err | tail -1 > gpurun_out/profiles_final/${R}_bench_A_driver_cmdline.json
+line gpurun_out/profiles_final/${R}_bench_A_driver_cmdline.json "A as the driver runs it"
+python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_bench_A_driver_cmdline.json').read());print('  shard_point', d.get('shard_point'));print('  partial_update', d.get('partial_update'));print('  library_route', d.get('library_route'))"
+# one GPU's share of a 2- / 4- / 8-GPU job through the multi-GPU code path (engine-side ncclAllReduce, communicator of one rank)
+for p in 50000 25000 12500; do
+  timeout 300 python bench.py --patterns $p --force-sharded --steps 200 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard${p}_sharded_path.json; line gpurun_out/profiles_final/${R}_bench_A_shard${p}_sharded_path.json "A shard $p (sharded path)"
+done
+# gradients (secondary): 4 states at 20 000 and 1e5 patterns, 20 and 61 states at their configs' sizes
+timeout 300 python tools/gradient_bench.py --config A --patterns 20000 --steps 10 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench.json
+timeout 300 python tools/gradient_bench.py --config A --steps 5 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5.json
+timeout 600 python tools/gradient_bench.py --config B --steps 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_B.json
+timeout 600 python tools/gradient_bench.py --config C --steps 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_C.json
+for g in "" _1e5 _B _C; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, roofline frac', d['roofline']['frac'], d['how'])" 2>&1 | tail -1; done
 timeout 300 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_btl.json; line gpurun_out/profiles_final/${R}_bench_A_btl.json "A btl"
 timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5 --no-cpu-baseline --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_always.json; line gpurun_out/profiles_final/${R}_bench_A_always.json "A always"
 timeout 300 python bench.py --config B --rescaling always --steps 40 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_B_always.json; line gpurun_out/profiles_final/${R}_bench_B_always.json "B always"
 timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard12500.json; line gpurun_out/profiles_final/${R}_bench_A_shard12500.json "A shard"
+python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_bench_A_shard12500.json').read());print('  partial_update at 12 500 patterns', d.get('partial_update'))"
 for real in benchmark1 benchmark2; do
   timeout 300 python bench.py --real $real --steps 200 --warmup 5 --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_D_$real.json; line gpurun_out/profiles_final/${R}_bench_D_$real.json "D $real"
 done
+TAG=_shard STEPS=20 bash profiles/collect.sh $R --config A --patterns 12500 2>&1 | grep rc=
+python profiles/summarize.py ${R}_shard A k_walk4 > /dev/null          # (hbm_traffic.json's "A" entry is overwritten by the full size below)
+python tools/timeline.py gpurun_out/prof_${R}_shard/kt > gpurun_out/profiles_final/${R}_shard_timeline.txt 2>&1
 TAG=_A STEPS=10 bash profiles/collect.sh $R --config A 2>&1 | grep rc=
 TAG=_B STEPS=5 bash profiles/collect.sh $R --config B 2>&1 | grep rc=
 TAG=_C STEPS=5 bash profiles/collect.sh $R --config C 2>&1 | grep rc=
 TAG=_E STEPS=20 bash profiles/collect.sh $R --config E 2>&1 | grep rc=
 python profiles/summarize.py ${R}_A A k_walk4 > /dev/null; python profiles/summarize.py ${R}_B B k_walkT32 > /dev/null
 python profiles/summarize.py ${R}_C C k_pruneTiled > /dev/null; python profiles/summarize.py ${R}_E E k_walk4 > /dev/null
-cp profiles/hbm_traffic.json profiles/${R}_*_kernel_stats.csv profiles/${R}_*_sq_counters.txt profiles/${R}_?_bench.json gpurun_out/profiles_final/ 2>/dev/null
+cp profiles/hbm_traffic.json profiles/${R}_*_kernel_stats.csv profiles/${R}_*_sq_counters.txt profiles/${R}_?_bench.json profiles/${R}_shard_bench.json gpurun_out/profiles_final/ 2>/dev/null
 python -c "import json;d=json.load(open('profiles/hbm_traffic.json'));[print(k, v['bytes_per_eval'], v.get('design_bytes_per_eval'), v.get('HBM_GBps_from_counters')) for k,v in d.items()]"
 ls gpurun_out/profiles_final | wc -l

@@ -61,7 +61,23 @@ def main():
     # (pre-order partials written) also pre(parent) read and pre(child) written per operation
     walked = how["walked"] >= args.steps
     extra_bytes = 2 * internal * buf if walked else 2 * internal * buf + (internal + 2 * internal) * buf
-    print(json.dumps({"metric": "branch-gradient evals/sec (secondary)", "value": round(1.0 / dt, 3), "ms_per_gradient": round(dt * 1e3, 2),
+    # roofline of the gradient evaluation as THIS engine runs it (bytes the design moves / wall time; 8 TB/s HBM):
+    #   4 states, sums answered from the held list: likelihood-side bytes (every internal node stored: written once) + every
+    #   internal post-order partial read once by the pre-order walk;
+    #   16..64 states: the pre-order pass is two passes of the pruning kernel per operation — pre(parent) o (P_sib post(sib)) into a
+    #   scratch buffer, then P_child^T times that — 5 buffer transfers per operation (engine_preorder.cpp preLevelTwoPass), the
+    #   edge derivatives read pre and post of every edge and pass their products through one more buffer (4 per edge), the
+    #   post-order pass stores every node and reads every internal child.
+    nodes = wl.tree.node_count
+    int_children = sum(1 for n in range(wl.tip_count, nodes) for ch in (int(wl.tree.left[n]), int(wl.tree.right[n])) if ch >= wl.tip_count)
+    if wl.state_count == 4:
+        moved = (internal + internal) * buf if walked else (internal + int_children) * buf + 5 * (nodes - 1) * buf // 2
+    else:
+        moved = (internal + int_children) * buf + 5 * (nodes - 1) * buf + 4 * (nodes - 1) * buf
+    roofline = {"bound": "hbm", "bytes_moved_by_design": int(moved), "achieved": round(moved / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(moved / dt / 1e9 / 8000.0, 4),
+                "note": "bytes this implementation's passes move per gradient / wall time per gradient (host included)"}
+    print(json.dumps({"metric": "branch-gradient evals/sec (secondary)", "roofline": roofline, "value": round(1.0 / dt, 3), "ms_per_gradient": round(dt * 1e3, 2),
                       "ms_per_likelihood_same_driver": round(dl * 1e3, 2),
                       "rescale": bool(args.rescale), "workload": "%s: %d taxa x %d patterns, %d states, %d categories" % (wl.name, wl.tip_count, wl.pattern_count,
                                                                                           wl.state_count, wl.category_count),
