@@ -72,6 +72,12 @@ EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if
 # onto itself: 4 bytes, vector), vlit (v_mov_b32 of a literal into a scratch register: 8 bytes, vector) — to tell what the loop
 # is bound by: instruction count, instruction bytes or the vector pipe (profiles/r04_experiments.txt)
 PAD = os.environ.get("WALK4_PAD", "")
+# The reciprocal scale factors of a micro-operation are the one load of a stage that comes from HBM (a stream read once per
+# evaluation) and they are used LAST, by the final multiply: with LATEINV the stage's first wait leaves that load outstanding
+# (vmcnt one higher: it is the youngest of its fetch and loads return in order) and a second wait in front of the multiply
+# retires it — almost a whole stage more for it to land, which is what a wave that has its SIMD to itself (the serial top of the
+# tree on a small shard) is short of.  A/B switch.
+LATEINV = os.environ.get("WALK4_LATEINV", "1") != "0"
 COL0 = os.environ.get("WALK4_COL0", "1") != "0"            # a mat-vec's first column from broadcast LDS reads (matvec): A/B switch
 lines = []
 
@@ -267,16 +273,18 @@ def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
         e("s_mov_b64 exec, -1")
     e("global_load_ushort %s, %s, %s" % (v(Tt1), v(TIP), s(D, 2)))
     e("global_load_ushort %s, %s, %s" % (v(Tt2), v(TIP), s(D + 2, 2)))
-    if "noinv" in EXPERIMENT:
-        e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
-    else:
-        e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
     e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
     e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
     e("s_mov_b64 %s, %s" % (s(SSCALEW, 2), s(DW, 2)))
     e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(DFL), (1 << B_HREAD) | (1 << B_X)))
     e("s_cbranch_scc1 %s" % L("fr" + tag))
     e(L("frb" + tag) + ":")
+    # the reciprocal scale factors LAST of the fetch's loads (behind a first child's partials, if any): the stage's first wait
+    # leaves exactly this one outstanding (LATEINV)
+    if "noinv" in EXPERIMENT:
+        e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
+    else:
+        e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
     blk = [L("fr" + tag) + ":",
            "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD),
            "s_cbranch_scc0 %s" % L("x" + tag),
@@ -312,11 +320,12 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, tbv
     e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WAIT0) | (1 << B_WAIT1)))
     e("s_cbranch_scc1 %s" % L("ws" + tag))
     novm = "novmwait" in EXPERIMENT
-    e("s_nop 0" if novm else "s_waitcnt vmcnt(4)")
+    extra = 1 if LATEINV else 0                     # the first wait leaves this stage's reciprocal-scale load outstanding
+    e("s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (4 + extra))
     e(L("wd" + tag) + ":")
     outofline.append([L("ws" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc0 %s" % L("w12" + tag),
-                      "s_nop 0" if novm else "s_waitcnt vmcnt(8)", "s_branch %s" % L("wd" + tag),
-                      L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag)])
+                      "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (8 + extra), "s_branch %s" % L("wd" + tag),
+                      L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (12 + extra), "s_branch %s" % L("wd" + tag)])
     c0 = c0set if SCOL else None
     # (descriptor k of the micro-operation being computed: DP points at k + 2 until the stage's descriptor load, at k + 3 after it —
     # with EARLYDESC at k + 3 from the fetch on; kernels.h WalkOp: src2 at 8, store at 16)
@@ -423,6 +432,16 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, tbv
         e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
+    if LATEINV and "novmwait" not in EXPERIMENT:
+        # the second wait: this stage's reciprocal scale factors (the loads of the next stage's fetch may stay outstanding: the
+        # same counts as the first wait without its extra one)
+        e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WAIT0) | (1 << B_WAIT1)))
+        e("s_cbranch_scc1 %s" % L("wt" + tag))
+        e("s_waitcnt vmcnt(4)")
+        e(L("wtd" + tag) + ":")
+        outofline.append([L("wt" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc0 %s" % L("wt12" + tag),
+                          "s_waitcnt vmcnt(8)", "s_branch %s" % L("wtd" + tag),
+                          L("wt12" + tag) + ":", "s_waitcnt vmcnt(12)", "s_branch %s" % L("wtd" + tag)])
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
     pad_block()
