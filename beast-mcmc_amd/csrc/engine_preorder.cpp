@@ -187,7 +187,20 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         for (int l = 0; l <= maxLevel; l++) {
             const int begin = std::max(start[l], chunkBegin), end = std::min(start[l + 1], chunkEnd);
             if (begin >= end) continue;
-            if (twoPass) { int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue; }
+            if (twoPass) {
+                // one pass per operation on the matrix cores (kernels_mfma.hip k_preOpTiled: three buffer transfers and two
+                // products instead of five and four) unless the level rescales in write mode (BEAGLE_MI355_PRE_TWO_PASS=1: always
+                // the two passes of the pruning kernel, for A/B runs)
+                static const bool forceTwo = getenv("BEAGLE_MI355_PRE_TWO_PASS") && atoi(getenv("BEAGLE_MI355_PRE_TWO_PASS")) != 0;
+                bool anyWrite = forceTwo;
+                for (int k = begin; k < end && !anyWrite; k++) anyWrite = sorted[k].scaleWrite != nullptr;
+                if (!anyWrite) {
+                    void* dLevel = nullptr;
+                    int rcu = uploadTransient(in, &sorted[begin], (size_t)(end - begin) * sizeof(OpDesc), &dLevel); if (rcu) return rcu;
+                    if (mi355::launchPreOpsTiled(live(in), (const OpDesc*)dLevel, end - begin, in->matrices, in->P, in->S, in->C)) continue;
+                }
+                int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue;
+            }
             mi355::launchPrePartials(live(in), (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
                                      in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
         }

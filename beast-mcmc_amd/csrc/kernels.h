@@ -309,6 +309,9 @@ size_t cherryTableBytes(int nCherries, int S, int C);
 void launchCherryTables(hipStream_t stream, const CherryDesc* dCherries, int n, const double* matrices, int S, int C, double* out);
 void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C,
                            bool anyScaleWrite, const CherryDesc* dCherries = nullptr, const double* dCherryTables = nullptr);
+// A level of pre-order operations on the T32 layout in ONE pass each (kernels_mfma.hip k_preOpTiled; OpDesc fields as
+// launchPrePartials; no write-mode rescaling: such operations take the two passes of the pruning kernel).  false: LDS refused.
+bool launchPreOpsTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)
 void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,

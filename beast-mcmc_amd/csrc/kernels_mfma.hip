@@ -484,6 +484,113 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     if (anyScaleWrite) hipLaunchKernelGGL(k_rescaleTiled, dim3(tiledBlocksPerRow(P, nOps, 2048), nOps), block, 0, stream, dOps, P, S, C);
 }
 
+// ---- a pre-order operation on the matrix cores (gradients at 16..64 states) ----------------------------------------------------
+// pre(child) = P_child^T . ( pre(parent) o (P_sib . post(sib)) )   (AbstractBeagleGradientDelegate.java:207-221), OpDesc fields as
+// launchPrePartials: dest = pre(child), child1 = pre(parent), mat1 = the child's branch matrix (used transposed), child2 =
+// post(sib) (partials, or compact states: KIND_STATES2), mat2 = the sibling's matrix; scaleRead divides the result.
+// Rounds 2-3 expressed this as TWO passes of the pruning kernel (an identity matrix in the first, an all-missing tip in the
+// second: engine_preorder.cpp preLevelTwoPass) — five buffer transfers and four matrix products per operation, two of them
+// with the identity.  Here a wave takes a tile through both products: t = P_sib . post(sib) leaves the matrix cores in the
+// B-operand layout, is multiplied by pre(parent) in place and fed straight into the product with P_child^T — three transfers,
+// two products.  Same helper functions (fragment staging, tiledLoadB, tiledChild) as k_pruneTiled.
+template <int NTMAX, bool EXACT>
+__global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_preOpTiled(const OpDesc* __restrict__ ops, const double* __restrict__ matrices,
+                                                                              int P, int S, int C) {
+    constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
+    constexpr int fragN = NTMAX * NTMAX * 16;
+    extern __shared__ double frag[];          // [2][fragN]: A fragments of P_sib, then of P_child TRANSPOSED
+    const OpDesc& op = ops[blockIdx.y / C];
+    const int c = blockIdx.y % C;
+    const int nt = EXACT ? NTMAX : (S + 3) >> 2;
+    const int ntile = (P + TILE - 1) / TILE;
+    const int tile0 = op.pStart / TILE, tile1 = (op.pEnd + TILE - 1) / TILE;
+    if (tile0 + (int)blockIdx.x * 4 >= tile1) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool st2 = op.kind & KIND_STATES2;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
+    const double* Mc = matrices + ((size_t)op.mat1 * C + c) * S * S;          // the child's branch matrix
+    const double* Ms = matrices + ((size_t)op.mat2 * C + c) * S * S;          // the sibling's
+    for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) {
+        const int second = e >= fragN, r = e - second * fragN;
+        const int f = r >> 4, q = r & 15;
+        const int it = f / NTMAX, jt = f - it * NTMAX;
+        const int i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+        frag[e] = (i < S && j < S) ? (second ? Mc[(size_t)j * S + i] : Ms[(size_t)i * S + j]) : 0.0;
+    }
+    __syncthreads();
+    for (int tile = tile0 + blockIdx.x * 4 + wave; tile < tile1; tile += gridDim.x * 4) {
+        const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+        const int pe = tile * TILE + 2 * m;
+        v2d bs[NTMAX], u[NTMAX];
+        int se = S, so = S;
+        if (st2) {
+            const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(op.child2));
+            if (pe < P) se = st[pe];
+            if (pe + 1 < P) so = st[pe + 1];
+        } else tiledLoadB<NTMAX, EXACT>(op.child2, tileBase, S, g, m, bs);
+        tiledLoadB<NTMAX, EXACT>(op.child1, tileBase, S, g, m, u);                // pre(parent): becomes u = pre(parent) o t in place
+        double inve = 1.0, invo = 1.0;
+        if (op.scaleRead) {
+            const double MI355_GLOBAL* sr = gptr(op.scaleRead);
+            if (pe < P) inve = 1.0 / sr[pe];
+            if (pe + 1 < P) invo = 1.0 / sr[pe + 1];
+        }
+#pragma unroll
+        for (int it0 = 0; it0 < NTMAX; it0 += IH) {
+            if (it0 < nt) {
+                double te[IH], to[IH];
+                tiledChild<NTMAX, IH>(frag, nt, S, st2, se, so, Ms, bs, it0, g, fl, te, to);
+#pragma unroll
+                for (int k = 0; k < IH; k++) { u[it0 + k].x *= te[k]; u[it0 + k].y *= to[k]; }
+            }
+        }
+        const bool ine = pe >= op.pStart && pe < op.pEnd, ino = pe + 1 >= op.pStart && pe + 1 < op.pEnd;
+        double* d = op.dest + tileBase;
+#pragma unroll
+        for (int it0 = 0; it0 < NTMAX; it0 += IH) {
+            if (it0 < nt) {
+                double re[IH], ro[IH];
+                tiledChild<NTMAX, IH>(frag + fragN, nt, S, false, S, S, Mc, u, it0, g, fl, re, ro);
+#pragma unroll
+                for (int k = 0; k < IH; k++) {
+                    const int i = 4 * (it0 + k) + g;
+                    if (it0 + k < nt && i < S) {
+                        v2d o; o.x = re[k] * inve; o.y = ro[k] * invo;
+                        double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
+                        if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                        else { if (ine) q[0] = o.x; if (ino) q[1] = o.y; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool launchPreOpsTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C) {
+    if (nOps <= 0) return true;
+    const int maxOps = 65535 / C;
+    if (nOps > maxOps) {
+        for (int o = 0; o < nOps; o += maxOps)
+            if (!launchPreOpsTiled(stream, dOps + o, nOps - o < maxOps ? nOps - o : maxOps, matrices, P, S, C)) return false;
+        return true;
+    }
+    const int nt = (S + 3) / 4;
+    dim3 grid(tiledBlocksPerRow(P, nOps * C, nt <= 5 ? 2048 : 1536), nOps * C), block(MF_BLOCK);
+    if (nt <= 5) {
+        const size_t lds = (size_t)2 * 5 * 5 * 16 * sizeof(double);
+        if (nt < 5) hipLaunchKernelGGL((k_preOpTiled<5, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        else hipLaunchKernelGGL((k_preOpTiled<5, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
+    } else {
+        const size_t lds = (size_t)2 * 16 * 16 * 16 * sizeof(double);
+        if (!grantDynamicLds((const void*)k_preOpTiled<16, false>, lds) || !grantDynamicLds((const void*)k_preOpTiled<16, true>, lds)) return false;
+        if (nt < 16) hipLaunchKernelGGL((k_preOpTiled<16, false>), grid, block, lds, stream, dOps, matrices, P, S, C);
+        else hipLaunchKernelGGL((k_preOpTiled<16, true>), grid, block, lds, stream, dOps, matrices, P, S, C);
+    }
+    return true;
+}
+
 // ---- the pattern walk on the T32 layout (17..20 states) ------------------------------------------------------------------
 // The level kernel above is bound by the bytes of storing every node and reading it back (config B rebuilt without its stores:
 // 4.2 -> 2.0 ms, profiles/r03_experiments.txt 11).  A pattern tile never needs another tile's data either, so the 4-state

@@ -83,47 +83,90 @@ class MultiPartitionTreeLikelihood:
                     ops[:, k, 7] = k; ops[:, k, 8] = NONE
                 self._ops[(pf, mf)] = (np.ascontiguousarray(ops.reshape(-1)), np.ascontiguousarray(ops[:, 0, :7].reshape(-1)))
 
+    def _fast_tables(self):
+        """Everything calculate() hands the engine as ready-made C pointers, built once: the per-evaluation host work is then the
+        call sequence itself (the ctypes conversions of ~25 calls cost more than the evaluation's kernels, 100 of 190 us)."""
+        import ctypes as C
+        DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        d = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = []
+
+        def dp(a):
+            a = d(a); keep.append(a); return a.ctypes.data_as(DP)
+
+        def ip(a):
+            a = i(a); keep.append(a); return a.ctypes.data_as(IP)
+        K, T = self.K, self.T
+        f = {}
+        f["eig"] = [(dp(w.eig.evec), dp(w.eig.ievc), dp(w.eig.evals)) for w in self.pw.parts]
+        f["rates"] = [dp(w.cat_rates) for w in self.pw.parts]
+        f["weights"] = [dp(w.cat_weights) for w in self.pw.parts]
+        f["freqs"] = [dp(w.freqs) for w in self.pw.parts]
+        f["eig_idx"] = ip(self._eig_idx)
+        f["mat_idx"] = [ip(m) for m in self._mat_idx]
+        self._lens = np.empty(len(self._eig_idx))
+        self._lens1 = np.empty(len(self._branch))
+        f["lens"] = self._lens.ctypes.data_as(DP)
+        f["ops"] = {key: (ip(v[0]), len(v[0]) // 9, ip(v[1]), len(v[1]) // 7) for key, v in self._ops.items()}
+        f["scale_idx"] = ip(self._scale_idx)
+        f["roots"] = {pf: ip([self.T + 2 * (self.tree.root - T) + pf] * K) for pf in (0, 1)}
+        f["range"] = ip(list(range(K)))
+        f["cum"] = {True: ip([T - 1] * K), False: ip([NONE] * K)}
+        self._by_part = np.zeros(K)
+        self._total = np.zeros(1)
+        f["by_part"] = self._by_part.ctypes.data_as(DP)
+        f["total"] = self._total.ctypes.data_as(DP)
+        f["keep"] = keep
+        self._fast = f
+
     def calculate(self):
         """One full evaluation; returns (per-partition log-likelihoods, total)."""
         b, tree, K, T = self.b, self.tree, self.K, self.T
         if not hasattr(self, "_ops"):
             self._static_tables()
+        if not hasattr(self, "_fast"):
+            self._fast_tables()
+        f, fn, h, chk = self._fast, b._f, b.instance, b._check
         self.mflip ^= 1
         self.flip[T:] ^= 1
         pf = int(self.flip[T])
-        for k, w in enumerate(self.pw.parts):
-            b.setEigenDecomposition(k, w.eig.evec, w.eig.ievc, w.eig.evals)
-            b.setCategoryRatesWithIndex(k, w.cat_rates)
-        lens = np.tile(self._lens0 * self.branch_rates[self._branch], K)
-        b.updateTransitionMatricesWithMultipleModels(self._eig_idx, self._eig_idx, self._mat_idx[self.mflip], None, None, lens, len(lens))
-        ops9, ops7 = self._ops[(pf, self.mflip)]
-        scale_idx = self._scale_idx
+        for k in range(K):
+            u, ui, lam = f["eig"][k]
+            chk("setEigenDecomposition", fn["SetEigenDecomposition"](h, k, u, ui, lam))
+            chk("setCategoryRatesWithIndex", fn["SetCategoryRatesWithIndex"](h, k, f["rates"][k]))
+        np.multiply(self._lens0, self.branch_rates[self._branch], out=self._lens1)
+        self._lens.reshape(K, -1)[:] = self._lens1
+        n = len(self._lens)
+        chk("updateTransitionMatricesWithMultipleModels",
+            fn["UpdateTransitionMatricesWithMultipleModels"](h, f["eig_idx"], f["eig_idx"], f["mat_idx"][self.mflip], None, None, f["lens"], n))
+        ops9, n9, ops7, n7 = f["ops"][(pf, self.mflip)]
         if K > 1:
-            b.updatePartialsByPartition(ops9, len(ops9) // 9)
+            chk("updatePartialsByPartition", fn["UpdatePartialsByPartition"](h, ops9, n9))
         else:
-            b.updatePartials(ops7, len(ops7) // 7, NONE)
+            chk("updatePartials", fn["UpdatePartials"](h, ops7, n7, NONE))
         cum = (T - 1) if self.always_rescale else NONE
         if self.always_rescale:
+            ns = len(self._scale_idx)
             for k in range(K):
                 if K > 1:
-                    b.resetScaleFactorsByPartition(cum, k)
-                    b.accumulateScaleFactorsByPartition(scale_idx, len(scale_idx), cum, k)
+                    chk("resetScaleFactorsByPartition", fn["ResetScaleFactorsByPartition"](h, cum, k))
+                    chk("accumulateScaleFactorsByPartition", fn["AccumulateScaleFactorsByPartition"](h, f["scale_idx"], ns, cum, k))
                 else:
-                    b.resetScaleFactors(cum)
-                    b.accumulateScaleFactors(scale_idx, len(scale_idx), cum)
-        for k, w in enumerate(self.pw.parts):
-            b.setCategoryWeights(k, w.cat_weights)
-            b.setStateFrequencies(k, w.freqs)
+                    chk("resetScaleFactors", fn["ResetScaleFactors"](h, cum))
+                    chk("accumulateScaleFactors", fn["AccumulateScaleFactors"](h, f["scale_idx"], ns, cum))
+        for k in range(K):
+            chk("setCategoryWeights", fn["SetCategoryWeights"](h, k, f["weights"][k]))
+            chk("setStateFrequencies", fn["SetStateFrequencies"](h, k, f["freqs"][k]))
         self.evaluations += 1
-        root = self.pbuf(tree.root)
         if K > 1:
-            by_part = np.zeros(K)
-            total = [0.0]
-            b.calculateRootLogLikelihoodsByPartition([root] * K, list(range(K)), list(range(K)), [cum] * K, list(range(K)), K, 1,
-                                                     by_part, total)
-            return by_part, total[0]
+            rc = fn["CalculateRootLogLikelihoodsByPartition"](h, f["roots"][pf], f["range"], f["range"], f["cum"][self.always_rescale], f["range"], K, 1,
+                                                              f["by_part"], f["total"])
+            if rc not in (0, -8):
+                chk("calculateRootLogLikelihoodsByPartition", rc)
+            return self._by_part.copy(), float(self._total[0])
         out = [0.0]
-        b.calculateRootLogLikelihoods([root], [0], [0], [cum], 1, out)
+        b.calculateRootLogLikelihoods([self.pbuf(tree.root)], [0], [0], [cum], 1, out)
         return np.array(out), out[0]
 
     def getSiteLogLikelihoods(self):
