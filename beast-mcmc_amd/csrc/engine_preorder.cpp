@@ -577,10 +577,20 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
         // 16..64 states: an edge below an internal node takes the O(S^2) part through one pass of the MFMA pruning kernel
         // (tmp = (I . pre) * (D . post)) and a streaming reduction; tip edges (O(S) per pattern) and every other state
         // count use the direct kernel.  Output rows are addressed by EdgeDesc::slot, so the two groups can interleave.
-        std::vector<mi355::EdgeDesc> direct, viaPrune;
+        // (round 4: kernels_mfma.hip k_edgeTiled takes every edge of such an instance in one pass — pre and post read once;
+        // BEAGLE_MI355_EDGE_TWO_STEP=1 keeps the older route, =2 sends only the tip edges to the direct kernel.)
+        static const int edgeTwoStep = getenv("BEAGLE_MI355_EDGE_TWO_STEP") ? atoi(getenv("BEAGLE_MI355_EDGE_TWO_STEP")) : 0;
+        std::vector<mi355::EdgeDesc> direct, viaPrune, onePass;
         for (int e = 0; e < m; e++) {
             descs[e].slot = e;
-            (twoStep && !descs[e].postIsStates ? viaPrune : direct).push_back(descs[e]);
+            if (twoStep && edgeTwoStep != 1 && !(edgeTwoStep == 2 && descs[e].postIsStates)) onePass.push_back(descs[e]);
+            else (twoStep && !descs[e].postIsStates ? viaPrune : direct).push_back(descs[e]);
+        }
+        if (!onePass.empty()) {
+            void* dDesc = nullptr;
+            rc = uploadTransient(in, onePass.data(), onePass.size() * sizeof(mi355::EdgeDesc), &dDesc); if (rc) break;
+            if (!mi355::launchEdgeTiled(live(in), (const mi355::EdgeDesc*)dDesc, (int)onePass.size(), in->matrices,
+                                        in->weights + (size_t)wIdx * in->C, in->patternWeights, dPer, dBlock, in->P, in->S, in->C)) { rc = BEAGLE_ERROR_GENERAL; break; }
         }
         if (!direct.empty()) {
             void* dDesc = nullptr;

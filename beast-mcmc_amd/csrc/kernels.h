@@ -222,6 +222,10 @@ struct EdgeDesc {
     int           slot;          // output row: perPattern[slot][P], blockSums[slot][blocks][2]
     int           pad;
 };
+// 16..64 states, T32 layout (kernels_mfma.hip k_edgeTiled): pre and post read once, the product with D on the matrix cores; same
+// outputs as launchEdgeDifferentials (blockSums rows of edgeBlocks(P) entries).  EdgeDesc::tmp unused.
+bool launchEdgeTiled(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
+                     const double* patternWeights, double* perPattern, double* blockSums, int P, int S, int C);
 // 4 states, plain layout (kernels_preorder4.hip): a NODE of the pre-order pass — both children's pre-order partials from one
 // read of pre(parent), post(a), post(b), and both edges' derivative sums on the way.  preA / preB may be NULL (not stored);
 // slotA / slotB < 0: no derivative asked for that edge; dA / dB: the edges' differential matrices.

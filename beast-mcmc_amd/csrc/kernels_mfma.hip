@@ -591,6 +591,134 @@ bool launchPreOpsTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const d
     return true;
 }
 
+// ---- edge derivatives on the matrix cores (gradients at 16..64 states) ------------------------------------------------------------
+// derivative[p] = (sum_c w_c sum_i pre[c,p,i] (D_c . post[c,p])[i]) / (sum_c w_c sum_i pre[c,p,i] post[c,p,i])   for one edge
+// (AbstractBeagleGradientDelegate.java:207-221 -> Beagle.calculateEdgeDifferentials; same outputs as k_edgeDifferentials).
+// Rounds 2-3 took the O(S^2) product through a pass of the pruning kernel into a scratch buffer and a streaming reduction
+// (6 buffer transfers per internal edge).  Here a wave owns a block of 64 patterns (two tiles) for ALL categories: pre and post
+// are read once (2 transfers), the product stays in registers, the per-state partial sums are folded across the four state
+// rows of the lane map at the end.  A tip edge's compact states become a one-hot B operand (a missing state: all ones).
+// The workgroup stages the A fragments of D_c once per category for its 4 x UNITS blocks.
+template <int NTMAX, bool EXACT, int UNITS>
+__global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_edgeTiled(const EdgeDesc* __restrict__ edges, const double* __restrict__ matrices,
+                                                                             const double* __restrict__ catWeights,
+                                                                             const double* __restrict__ patternWeights,
+                                                                             double* __restrict__ perPattern, double* __restrict__ blockSums,
+                                                                             int P, int S, int C, int nBlocks) {
+    constexpr int IH = NTMAX > 5 ? 4 : NTMAX;
+    constexpr int fragN = NTMAX * NTMAX * 16;
+    extern __shared__ double frag[];          // [fragN]: A fragments of the differential matrix of the category at hand
+    const EdgeDesc& ed = edges[blockIdx.y];
+    const int nt = EXACT ? NTMAX : (S + 3) >> 2;
+    const int ntile = (P + TILE - 1) / TILE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool postStates = ed.postIsStates != 0;
+    const int unit0 = ((int)blockIdx.x * 4 + wave) * UNITS;
+    double num[UNITS][2][2], den[UNITS][2][2];
+#pragma unroll
+    for (int un = 0; un < UNITS; un++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) { num[un][h][0] = num[un][h][1] = 0.0; den[un][h][0] = den[un][h][1] = 0.0; }
+    for (int c = 0; c < C; c++) {
+        const double* G = matrices + ((size_t)ed.dmat * C + c) * S * S;
+        __syncthreads();
+        for (int e = threadIdx.x; e < fragN; e += MF_BLOCK) {
+            const int f = e >> 4, q = e & 15;
+            const int it = f / NTMAX, jt = f - it * NTMAX;
+            const int i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+            frag[e] = (i < S && j < S) ? G[(size_t)i * S + j] : 0.0;
+        }
+        __syncthreads();
+        const double wc = catWeights[c];
+#pragma unroll
+        for (int un = 0; un < UNITS; un++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int tile = (unit0 + un) * 2 + h;
+                if (tile >= ntile) continue;                                        // (wave-uniform)
+                const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+                const int pe = tile * TILE + 2 * m;
+                v2d bs[NTMAX], u[NTMAX];
+                if (postStates) {
+                    const uint8_t MI355_GLOBAL* st = gptr(reinterpret_cast<const uint8_t*>(ed.post));
+                    const int se = pe < P ? st[pe] : S, so = pe + 1 < P ? st[pe + 1] : S;
+#pragma unroll
+                    for (int jt = 0; jt < NTMAX; jt++) {
+                        const int j = 4 * jt + g;
+                        bs[jt].x = (j < S && (se >= S || j == se)) ? 1.0 : 0.0;
+                        bs[jt].y = (j < S && (so >= S || j == so)) ? 1.0 : 0.0;
+                    }
+                } else tiledLoadB<NTMAX, EXACT>(ed.post, tileBase, S, g, m, bs);
+                tiledLoadB<NTMAX, EXACT>(ed.pre, tileBase, S, g, m, u);
+                double ne = 0.0, no = 0.0, de = 0.0, dodd = 0.0;
+#pragma unroll
+                for (int jt = 0; jt < NTMAX; jt++) { de += u[jt].x * bs[jt].x; dodd += u[jt].y * bs[jt].y; }
+#pragma unroll
+                for (int it0 = 0; it0 < NTMAX; it0 += IH) {
+                    if (it0 < nt) {
+                        double te[IH], to[IH];
+                        tiledChild<NTMAX, IH>(frag, nt, S, false, S, S, G, bs, it0, g, fl, te, to);
+#pragma unroll
+                        for (int k = 0; k < IH; k++) { ne += u[it0 + k].x * te[k]; no += u[it0 + k].y * to[k]; }
+                    }
+                }
+                num[un][h][0] += wc * ne; num[un][h][1] += wc * no;
+                den[un][h][0] += wc * de; den[un][h][1] += wc * dodd;
+            }
+        }
+    }
+    const size_t row = (size_t)ed.slot;
+#pragma unroll
+    for (int un = 0; un < UNITS; un++) {
+        const int unit = unit0 + un;
+        double w1 = 0.0, w2 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pe = (unit * 2 + h) * TILE + 2 * m;
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                double n = num[un][h][par], d = den[un][h][par];
+                n += __shfl_xor(n, 16, 64); d += __shfl_xor(d, 16, 64);            // the four state rows of the lane map
+                n += __shfl_xor(n, 32, 64); d += __shfl_xor(d, 32, 64);
+                const int p = pe + par;
+                if (g == 0 && p < P) {
+                    const double deriv = n / d;
+                    if (perPattern) perPattern[row * P + p] = deriv;
+                    const double t = patternWeights[p] * deriv;
+                    w1 += t; w2 += t * deriv;
+                }
+            }
+        }
+        // fixed-shape butterfly over the wave (only the lanes of state row 0 hold anything): deterministic
+        for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
+        if (lane == 0 && unit < nBlocks) {
+            double* b = blockSums + (row * nBlocks + unit) * 2;
+            b[0] = w1; b[1] = w2;
+        }
+    }
+}
+
+bool launchEdgeTiled(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,
+                     const double* patternWeights, double* perPattern, double* blockSums, int P, int S, int C) {
+    if (nEdges <= 0) return true;
+    const int nt = (S + 3) / 4, nBlocks = edgeBlocks(P);
+    dim3 block(MF_BLOCK);
+    if (nt <= 5) {
+        dim3 grid((nBlocks + 3) / 4, nEdges);
+        const size_t lds = (size_t)5 * 5 * 16 * sizeof(double);
+        if (nt < 5) hipLaunchKernelGGL((k_edgeTiled<5, false, 1>), grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C, nBlocks);
+        else hipLaunchKernelGGL((k_edgeTiled<5, true, 1>), grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C, nBlocks);
+    } else {
+        dim3 grid((nBlocks + 7) / 8, nEdges);
+        const size_t lds = (size_t)16 * 16 * 16 * sizeof(double);
+        if (nt < 16) hipLaunchKernelGGL((k_edgeTiled<16, false, 2>), grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C, nBlocks);
+        else hipLaunchKernelGGL((k_edgeTiled<16, true, 2>), grid, block, lds, stream, dEdges, matrices, catWeights, patternWeights, perPattern, blockSums, P, S, C, nBlocks);
+    }
+    return true;
+}
+
 // ---- the pattern walk on the T32 layout (17..20 states) ------------------------------------------------------------------
 // The level kernel above is bound by the bytes of storing every node and reading it back (config B rebuilt without its stores:
 // 4.2 -> 2.0 ms, profiles/r03_experiments.txt 11).  A pattern tile never needs another tile's data either, so the 4-state
