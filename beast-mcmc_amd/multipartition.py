@@ -31,6 +31,8 @@ class MultiPartitionTreeLikelihood:
         self.always_rescale = always_rescale
         self.flip = np.zeros(nodes, dtype=np.int32)          # BufferIndexHelper offsets of the internal nodes
         self.mflip = 0
+        self.mf = np.zeros(nodes, dtype=np.int32)            # ... and of the branch matrices (one offset per node, all partitions)
+        self._saved = None
         self.evaluations = 0
         # partials: tips 0..T-1, internal node n -> T + 2 (n - T) + flip; matrices: (partition, node, flip); scale: node + cumulative
         self.b = _b.Beagle(T, T + 2 * (T - 1), T, pw.parts[0].state_count, self.P, K, 2 * K * nodes, self.C, (T - 1) + 1,
@@ -52,7 +54,7 @@ class MultiPartitionTreeLikelihood:
         return n if n < self.T else self.T + 2 * (n - self.T) + int(self.flip[n])
 
     def mbuf(self, k, n):
-        return (k * self.nodes + n) * 2 + self.mflip
+        return (k * self.nodes + n) * 2 + int(self.mf[n])
 
     def set_branch_rates(self, rates):
         self.branch_rates = np.asarray(rates, dtype=np.float64)
@@ -129,12 +131,17 @@ class MultiPartitionTreeLikelihood:
             self._fast_tables()
         f, fn, h, chk = self._fast, b._f, b.instance, b._check
         self.mflip ^= 1
-        self.flip[T:] ^= 1
-        pf = int(self.flip[T])
+        self.mf[:] = self.mflip                              # (a full evaluation rewrites every buffer: all offsets flip together)
+        pf = int(self.flip[T]) ^ 1
+        self.flip[T:] = pf
+        self._saved = None
         for k in range(K):
             u, ui, lam = f["eig"][k]
             chk("setEigenDecomposition", fn["SetEigenDecomposition"](h, k, u, ui, lam))
             chk("setCategoryRatesWithIndex", fn["SetCategoryRatesWithIndex"](h, k, f["rates"][k]))
+        if getattr(self, "_lens_stale", False):                # node heights moved since the tables were built
+            self._lens0 = np.array([tree.branch_length(int(n)) for n in self._branch])
+            self._lens_stale = False
         np.multiply(self._lens0, self.branch_rates[self._branch], out=self._lens1)
         self._lens.reshape(K, -1)[:] = self._lens1
         n = len(self._lens)
@@ -168,6 +175,81 @@ class MultiPartitionTreeLikelihood:
         out = [0.0]
         b.calculateRootLogLikelihoods([self.pbuf(tree.root)], [0], [0], [cum], 1, out)
         return np.array(out), out[0]
+
+    def move_node_height(self, node, height):
+        """ONE node height changes (the move a chain makes most): the branch matrices of the node's two children and of the node
+        itself are recomputed for every partition in one updateTransitionMatricesWithMultipleModels, then the operations of the
+        node and of its ancestors up to the root (one 9-int tuple per node and partition), then the root integration — what
+        MultiPartitionDataLikelihoodDelegate.calculateLikelihood issues when the tree flags one node (:835-1083; only the
+        flagged buffers flip, BufferIndexHelper.flipOffset).  ``restore_move()`` takes the move back: offsets only, no engine call.
+        Returns (per-partition log-likelihoods, total)."""
+        import ctypes as C
+        b, tree, K, T, nodes = self.b, self.tree, self.K, self.T, self.nodes
+        if not hasattr(self, "_fast"):
+            raise RuntimeError("move_node_height: a full calculate() comes first")
+        if self.always_rescale:
+            raise NotImplementedError("move_node_height: without per-node scale buffers only (always_rescale=False)")
+        self._lens_stale = True
+        f, fn, h, chk = self._fast, b._f, b.instance, b._check
+        node = int(node)
+        branches = [int(tree.left[node]), int(tree.right[node])] + ([node] if node != tree.root else [])
+        path = []
+        n = node
+        while n >= 0:
+            path.append(n)
+            n = int(tree.parent[n])
+        self._saved = (node, float(tree.height[node]), branches, path)
+        tree.height[node] = height
+        mf, flip = self.mf, self.flip
+        for x in branches:
+            mf[x] ^= 1
+        for x in path:
+            flip[x] ^= 1
+        nb = len(branches)
+        lens = [tree.branch_length(x) * self.branch_rates[x] for x in branches] * K
+        eig = [k for k in range(K) for _ in range(nb)]
+        mats = [(k * nodes + x) * 2 + int(mf[x]) for k in range(K) for x in branches]
+        IA, DA = C.c_int * (K * nb), C.c_double * (K * nb)
+        eig_c = IA(*eig)
+        chk("updateTransitionMatricesWithMultipleModels",
+            fn["UpdateTransitionMatricesWithMultipleModels"](h, eig_c, eig_c, IA(*mats), None, None, DA(*lens), K * nb))
+        ops = []
+        for x in path:
+            l, r = int(tree.left[x]), int(tree.right[x])
+            pl = l if l < T else T + 2 * (l - T) + int(flip[l])
+            pr = r if r < T else T + 2 * (r - T) + int(flip[r])
+            dest = T + 2 * (x - T) + int(flip[x])
+            for k in range(K):
+                ops += [dest, NONE, NONE, pl, (k * nodes + l) * 2 + int(mf[l]), pr, (k * nodes + r) * 2 + int(mf[r]), k, NONE]
+        if K > 1:
+            chk("updatePartialsByPartition", fn["UpdatePartialsByPartition"](h, (C.c_int * len(ops))(*ops), len(ops) // 9))
+        else:
+            ops7 = [v for i in range(0, len(ops), 9) for v in ops[i:i + 7]]
+            chk("updatePartials", fn["UpdatePartials"](h, (C.c_int * len(ops7))(*ops7), len(ops7) // 7, NONE))
+        self.evaluations += 1
+        root = T + 2 * (tree.root - T) + int(flip[tree.root])
+        if K > 1:
+            rc = fn["CalculateRootLogLikelihoodsByPartition"](h, (C.c_int * K)(*([root] * K)), f["range"], f["range"], f["cum"][False], f["range"], K, 1,
+                                                              f["by_part"], f["total"])
+            if rc not in (0, -8):
+                chk("calculateRootLogLikelihoodsByPartition", rc)
+            return self._by_part.copy(), float(self._total[0])
+        out = [0.0]
+        b.calculateRootLogLikelihoods([root], [0], [0], [NONE], 1, out)
+        return np.array(out), out[0]
+
+    def restore_move(self):
+        """restoreState after a rejected move_node_height: the offsets flip back and the height returns; the engine's buffers of
+        the accepted state were never overwritten."""
+        if self._saved is None:
+            raise RuntimeError("restore_move: nothing to restore")
+        node, height, branches, path = self._saved
+        self.tree.height[node] = height
+        for x in branches:
+            self.mf[x] ^= 1
+        for x in path:
+            self.flip[x] ^= 1
+        self._saved = None
 
     def getSiteLogLikelihoods(self):
         return self.b.getSiteLogLikelihoods()

@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="development: take the multi-GPU code path (process group, device-side sum, all-reduce) even with one rank")
     ap.add_argument("--cache", default="/tmp/beagle_mi355_cache", help="directory for the generated workload ('' = off)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="patterns in the CPU-baseline sample (0 = sized for ~10-20 s of CPU work)")
-    ap.add_argument("--rescaling", default="dynamic", choices=["dynamic", "always"],
+    ap.add_argument("--rescaling", default="dynamic", choices=["dynamic", "always", "none"],
                     help="dynamic (default, the metric's protocol): steady state = read mode, every 100th evaluation recomputes the factors; "
                          "always: PartialsRescalingScheme ALWAYS, every evaluation rescales in write mode")
     ap.add_argument("--route", default="ranks", choices=["ranks", "library"],
@@ -409,7 +409,8 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
     # (With the delay on, this realistic low-divergence tree never underflows in fp64 and scaling would never
     # switch on: fewer bytes, an easier benchmark.)
     from beast_mcmc_amd.treelikelihood import RESCALE_ALWAYS
-    kw = dict(resource_list=res, rescaling=RESCALE_ALWAYS if args.rescaling == "always" else RESCALE_DYNAMIC, delay_rescaling=False)
+    from beast_mcmc_amd.treelikelihood import RESCALE_NONE
+    kw = dict(resource_list=res, rescaling={"always": RESCALE_ALWAYS, "none": RESCALE_NONE}.get(args.rescaling, RESCALE_DYNAMIC), delay_rescaling=False)
     if sharded:
         tl = ShardedTreeLikelihood(wl, rank, world, dist=dist, device=device, **kw)
         local = tl.local
@@ -562,7 +563,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "
                                    "%s, new eigen system + rates every step"
                                    % (wl.name, wl.tip_count, wl.pattern_count, wl.state_count, wl.category_count, args.tree, wl.tree.depth(),
-                                      "ALWAYS rescaling (write mode every evaluation)" if args.rescaling == "always" else "DYNAMIC rescaling steady state"),
+                                      {"always": "ALWAYS rescaling (write mode every evaluation)", "none": "NO rescaling (development)"}.get(args.rescaling, "DYNAMIC rescaling steady state")),
                        "caller": args.caller, "patterns_per_gpu": p_, "parallelism": ("pattern-shard x%d + 1 all-reduce (%s), one process per GPU" % (n_gpus, collective_name)) if args.route == "ranks"
                                       else "pattern-shard x%d inside the library (resource G+1, ncclAllReduce), one process" % n_gpus,
                        "ops_per_eval": int(counters["last_op_count"]), "matrices_per_eval": int(counters["last_branch_count"])},
@@ -782,6 +783,12 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_partitioned(bm, pw)
         prof, prof_note = traffic_for(args, "k_walk4", world, rank)
+        partial = None
+        if world == 1 and not args.no_side_records:
+            try:
+                partial = partial_update_point_partitioned(tl, local_pw)
+            except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
+                partial = {"error": "%s: %s" % (type(e).__name__, e)}
         out = {
             "metric": "full-tree lnL evals/sec", "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -794,11 +801,46 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
                          "bytes_per_eval": int(moved), "algorithmic_bytes_per_eval": int(alg),
                          "kernel_us_per_eval": round(kernel_s * 1e6, 2), "kernel_time_fraction_of_step": round(kernel_s * args.steps / elapsed, 4),
                          "per_eval": {key: round(v / max(1, args.steps), 1) for key, v in stats.items()}},
-            "cpu_baseline": cpu, "lnL": lnl, "lnL_first_eval": lnl0, "kernel_source_hash": kernel_source_hash(),
+            "cpu_baseline": cpu, "partial_update": partial, "lnL": lnl, "lnL_first_eval": lnl0, "kernel_source_hash": kernel_source_hash(),
             "evaluations_total": tl.evaluations, "workload_generation_s": round(t_gen, 1),
         }
     tl.close()
     return out
+
+
+def partial_update_point_partitioned(tl, pw, moves=300):
+    """partial_update_point for the partitioned instance (config E): one node height changes; per partition three branch matrices
+    (one updateTransitionMatricesWithMultipleModels for all), the operations of the path to the root as 9-int tuples
+    (updatePartialsByPartition), the root integration by partition; half of the proposals are taken back (offset flips only)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    tree = pw.tree
+    t_, n_ = tree.tip_count, tree.node_count
+
+    def run(k):
+        for _ in range(k):
+            node = int(rng.integers(t_, n_))
+            while node == tree.root:
+                node = int(rng.integers(t_, n_))
+            lo = max(tree.height[int(tree.left[node])], tree.height[int(tree.right[node])])
+            hi = tree.height[tree.parent[node]]
+            tl.move_node_height(node, lo + (hi - lo) * float(rng.uniform(0.05, 0.95)))
+            if rng.random() < 0.5:
+                tl.restore_move()
+
+    run(30)
+    tl.b.kernelTimer(False)
+    e0 = tl.evaluations
+    tl.b.walkStats()
+    t0 = time.perf_counter()
+    run(moves)
+    dt = time.perf_counter() - t0
+    stats = tl.b.walkStats()
+    k = len(pw.parts)
+    return {"what": "one node-height move on the partitioned instance: path to the root recomputed for every partition, 50 % of the proposals restored",
+            "us_per_branch_move": round(1e6 * dt / moves, 2), "moves": tl.evaluations - e0, "partitions": k,
+            "micro_ops_per_move": round(stats["micro_ops"] / moves, 1), "stored_per_move": round(stats["stored"] / moves, 2),
+            "matrices_per_move": 3 * k}
 
 
 def _host_cpu_info():

@@ -162,6 +162,51 @@ def test_config_e_partitioned_instance_against_per_partition_oracle(always_resca
     assert helpers.rel_err(total, sum(expect)) <= REL_TOL
 
 
+def test_config_e_node_height_moves_and_their_rejection(oracle_lib):
+    """The move a chain makes most, on the partitioned instance: one node height changes, three matrices per partition and the
+    path to the root are recomputed (MultiPartitionTreeLikelihood.move_node_height); rejected moves flip the offsets back.
+    Every move's value equals a full evaluation of the moved tree, and the per-partition oracle at the end."""
+    pw = synth.config_e(scale=0.25)
+    tree = pw.tree
+    tl = MultiPartitionTreeLikelihood(pw)
+    ref = MultiPartitionTreeLikelihood(pw)                # full evaluations only (shares the tree object: sees the moved heights)
+    by0, total0 = tl.calculate()
+    ref.calculate()
+    rng = np.random.default_rng(11)
+    t_, n_ = tree.tip_count, tree.node_count
+    accepted = 0
+    for it in range(24):
+        node = tree.root if it == 5 else int(rng.integers(t_, n_))
+        lo = max(tree.height[int(tree.left[node])], tree.height[int(tree.right[node])])
+        hi = tree.height[tree.parent[node]] if node != tree.root else tree.height[node] * 1.2
+        old = float(tree.height[node])
+        by, total = tl.move_node_height(node, lo + (hi - lo) * float(rng.uniform(0.1, 0.9)))
+        ref._lens_stale = True
+        by_full, total_full = ref.calculate()
+        assert np.max(np.abs(by - by_full) / np.abs(by_full)) <= 1e-12, (it, node, by, by_full)
+        assert helpers.rel_err(total, total_full) <= 1e-12
+        if it % 2:
+            tl.restore_move()
+            assert tree.height[node] == old
+        else:
+            accepted += 1
+    assert accepted == 12
+    ref._lens_stale = True
+    by_full, total_full = ref.calculate()
+    tl._lens_stale = True
+    by_again, total_again = tl.calculate()                 # the instance that moved, evaluated in full: the accepted state
+    assert np.max(np.abs(by_again - by_full) / np.abs(by_full)) <= 1e-12
+    assert abs(total_again - total0) > 1e-6 * abs(total0) or accepted == 0
+    st = tl.b.walkStats()
+    assert st["walks"] > 0 and st["fast_walks"] == st["walks"], st
+    tl.close(); ref.close()
+    for k, w in enumerate(pw.parts):
+        o = BeagleTreeLikelihood(w, library=oracle_lib, rescaling=RESCALE_NONE, delay_rescaling=False)
+        v = o.getLogLikelihood()
+        o.close()
+        assert np.isfinite(v) and helpers.rel_err(by_full[k], v) <= REL_TOL, (k, by_full[k], v)
+
+
 def test_config_e_pattern_shards_sum_to_whole():
     """Row (e) for a partitioned analysis: every partition's pattern range is cut into contiguous blocks
     (Patterns.java:142-167); the per-shard, per-partition log-likelihoods add up to the unsharded ones."""

@@ -64,16 +64,21 @@ def main():
     # roofline of the gradient evaluation as THIS engine runs it (bytes the design moves / wall time; 8 TB/s HBM):
     #   4 states, sums answered from the held list: likelihood-side bytes (every internal node stored: written once) + every
     #   internal post-order partial read once by the pre-order walk;
-    #   16..64 states: the pre-order pass is two passes of the pruning kernel per operation — pre(parent) o (P_sib post(sib)) into a
-    #   scratch buffer, then P_child^T times that — 5 buffer transfers per operation (engine_preorder.cpp preLevelTwoPass), the
-    #   edge derivatives read pre and post of every edge and pass their products through one more buffer (4 per edge), the
-    #   post-order pass stores every node and reads every internal child.
+    #   16..64 states: a pre-order operation reads pre(parent) and the sibling's post-order partial (nothing for a tip sibling: compact
+    #   states) and writes pre(child) (kernels_mfma.hip k_preOpTiled); an edge's derivative reads pre and post of the node below it
+    #   once (post: nothing for a tip) (k_edgeTiled); the post-order pass stores every node and reads every internal child.
+    #   (BEAGLE_MI355_PRE_TWO_PASS=1 / BEAGLE_MI355_EDGE_TWO_STEP=1, rounds 2-3: 5 and 4-6 transfers instead.)
     nodes = wl.tree.node_count
     int_children = sum(1 for n in range(wl.tip_count, nodes) for ch in (int(wl.tree.left[n]), int(wl.tree.right[n])) if ch >= wl.tip_count)
     if wl.state_count == 4:
         moved = (internal + internal) * buf if walked else (internal + int_children) * buf + 5 * (nodes - 1) * buf // 2
     else:
-        moved = (internal + int_children) * buf + 5 * (nodes - 1) * buf + 4 * (nodes - 1) * buf
+        two_pass = os.environ.get("BEAGLE_MI355_PRE_TWO_PASS", "0") not in ("", "0")
+        two_step = os.environ.get("BEAGLE_MI355_EDGE_TWO_STEP", "0") == "1"
+        tips = wl.tip_count
+        pre_ops = 5 * (nodes - 1) if two_pass else 2 * (nodes - 1) + int_children          # (a node's sibling is internal: one more read)
+        edges = (tips + 6 * (nodes - 1 - tips)) if two_step else (nodes - 1) + (nodes - 1 - tips)
+        moved = (internal + int_children) * buf + pre_ops * buf + edges * buf
     roofline = {"bound": "hbm", "bytes_moved_by_design": int(moved), "achieved": round(moved / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(moved / dt / 1e9 / 8000.0, 4),
                 "note": "bytes this implementation's passes move per gradient / wall time per gradient (host included)"}
