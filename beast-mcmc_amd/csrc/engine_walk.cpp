@@ -34,6 +34,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // 4 states, assembly loop: ALL slices in one launch, dispatched critical path first, every workgroup waiting for the slices
     // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT && plan.launchOrder.size() == plan.segs.size();
+    const bool asmLoop = in->fastWalk && !in->walkT;          // k_walk4_fast runs this program (otherwise k_walk4 / k_walkT32)
     int maxRange = 0;
     if (reuse) {
         maxRange = slot->maxRange;
@@ -43,7 +44,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
     if (slot) { slot->tag = 0; slot->dProgValid = false; }
     w.clear();
-    w.reserve(n + 3 * plan.segs.size());
+    w.reserve(n + 6 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
     devDeps.clear();
     std::vector<int> posOf(plan.segs.size(), -1);
@@ -111,28 +112,39 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             }
             w.push_back(d);
         }
-        if (ps.progCount & 1) w.push_back(nop);
+        // (the kernels' software pipelines: the assembly loop is three micro-operations deep and leaves behind any stage — any
+        // length, three more readable descriptors —; the C++ kernel and the T32 walk are two deep: an even length, two more)
+        if (!asmLoop && ((int)w.size() - segs[si].progStart) % 2) w.push_back(nop);
         segs[si].progCount = (int)w.size() - segs[si].progStart;
-        w.push_back(nop); w.push_back(nop);
+        for (int q = 0; q < (asmLoop ? 3 : 2); q++) w.push_back(nop);
         // the wait of every stage: "at most N vector-memory instructions outstanding".  Loads and stores share the counter.
-        // DEFAULT (strict): N = the loads of the NEXT micro-operation only.  Sufficient under the one ordering rule the ISA
+        // DEFAULT (strict): N = the LOADS issued behind this micro-operation's own.  Sufficient under the one ordering rule the ISA
         // guides state for this counter — vector-memory LOADS return in the order they were issued: when at most N operations
         // are outstanding and the N youngest loads are all younger than this stage's loads, an unfinished load of this stage
         // would leave N + 1 unfinished, whatever the stores (of this or any earlier stage) do.
-        // BEAGLE_MI355_STRICT_WAITS=0: N also counts the previous micro-operation's stores, i.e. assumes that a younger store
-        // is never counted out before an older load.  That held in > 1e9 lane-trials (tests/test_gpu_vmcnt_order.py) and saves a
-        // stage the acknowledgement of four stores per stored node — 1 % of config A (profiles/r03_experiments.txt 7) — but it
+        // BEAGLE_MI355_STRICT_WAITS=0: N also counts the stores issued in between, i.e. assumes that a younger store
+        // is never counted out before an older load.  That held in > 1e9 lane-trials (tests/test_gpu_vmcnt_order.py) — but it
         // is an observation, not a documented guarantee, so it is not what ships by default.
-        // A smaller N than the true number only waits longer (the table ends at 12).
-        for (int i = segs[si].progStart; i < segs[si].progStart + segs[si].progCount; i++) {
+        // A smaller N than the true number only waits longer.
+        const int first = segs[si].progStart;
+        for (int i = first; i < first + segs[si].progCount; i++) {
+            // k_walk4 (two deep): N = the fetch of the next micro-operation (+ the previous one's stores)
             // (a micro-operation that rescales in write mode also stores its factors, from one of the workgroup's waves only: behind
             // it the count is the strict one whatever the mode)
-            const bool prevWrites = i > segs[si].progStart && ((w[i - 1].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
-            const int stores = (in->strictWaits || prevWrites) ? 0 : (i > segs[si].progStart ? mi355::walkStoreCount(w[i - 1].flags) : 0);
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores, 12));
-            // the assembly loop always issues four small loads per stage: its wait is 4, 8 or 12
-            const int code = (stores ? 1 : 0) + ((w[i + 1].flags & mi355::WF_X) ? 1 : 0);
-            if (code == 1) w[i].flags |= mi355::WF_WAIT8; else if (code == 2) w[i].flags |= mi355::WF_WAIT12;
+            const bool prevWrites = i > first && ((w[i - 1].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
+            const bool prev2Writes = i > first + 1 && ((w[i - 2].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
+            const int stores1 = (in->strictWaits || prevWrites) ? 0 : (i > first ? mi355::walkStoreCount(w[i - 1].flags) : 0);
+            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores1, 12));
+            if (!asmLoop) continue;
+            // k_walk4_fast (three deep; every fetch is FOUR small loads).  Issue order around stage i: ... fetch(i) | first child of
+            // i - 1 from memory (4) | store(i - 2) | fetch(i + 1) | first child of i from memory (4) | store(i - 1) | fetch(i + 2) | WAIT.
+            // A first child of i in memory has to have landed as well: then only what follows it counts.
+            const bool lax = !in->strictWaits && !prevWrites && !prev2Writes;
+            const int st1 = lax && i > first ? mi355::walkStoreCount(w[i - 1].flags) : 0;
+            const int st2 = lax && i > first + 1 ? mi355::walkStoreCount(w[i - 2].flags) : 0;
+            const int x1 = i > first && (w[i - 1].flags & mi355::WF_X) ? 4 : 0;
+            const int nWait = (w[i].flags & mi355::WF_X) ? 4 + st1 : 8 + x1 + st1 + st2;
+            w[i].flags |= mi355::walkWaitCode(nWait);
         }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);

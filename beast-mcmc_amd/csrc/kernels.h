@@ -64,10 +64,12 @@ enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
 // (bit 14 = WS_WRITE of the scale mode: the assembly loop tests it directly)
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
-// second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code (WF_WAIT8: vmcnt(8),
-// WF_WAIT12: vmcnt(12), neither: vmcnt(4))
-enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT8 = 1u << 28, WF_WAIT12 = 1u << 29,
+// second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code at bit 28 (walkWaitCode)
+enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT_SHIFT = 28,
        WF_HREAD2 = 1u << 30 };
+// k_walk4_fast's pipeline is three micro-operations deep: the wait of stage k is "at most N vector-memory instructions outstanding",
+// N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan): 8, 12, 16 or 4
+inline unsigned walkWaitCode(int n) { return (unsigned)(n >= 16 ? 2 : n >= 12 ? 1 : n >= 8 ? 0 : 3) << WF_WAIT_SHIFT; }
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
@@ -108,7 +110,8 @@ inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 // flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine_walk.cpp runPlan, kernels_walk4.hip)
 inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // A program slice and the pattern range that executes it (one per partition of a partitioned instance).  The kernel is
-// software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow.
+// software-pipelined two micro-operations deep: progCount must be EVEN and two more readable descriptors must follow
+// (k_walk4, k_walkT32); the assembly loop k_walk4_fast is three deep and leaves behind any stage: any progCount, three more descriptors.
 // tStart: where the segment's patterns begin in the PAIR-INTERLEAVED arrays — those are laid out partition by partition, every
 // partition padded to whole blocks of 128 (engine_instance.cpp setPairLayout), so that a lane's pair is one aligned load wherever a
 // partition starts; partials and plain per-pattern arrays keep the caller's pattern numbering.

@@ -376,7 +376,7 @@ template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride) {
-    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[2][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
+    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[3][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
     const int p0 = sg.pStart + (int)blockIdx.x * 128;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                  : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
                      [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
                      [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
-                     [exch] "s"(ldsBase + 2u * holdStride + 2u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
+                     [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
                      [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(sg.tStart + (int)blockIdx.x * 128)
                  : WALK4_FAST_CLOBBERS);
     if (flags) {
@@ -427,7 +427,7 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     // BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so that fewer
     // workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
     static const size_t ldsPad = getenv("BEAGLE_MI355_WALK_LDS_PAD") ? (size_t)atol(getenv("BEAGLE_MI355_WALK_LDS_PAD")) : 0;
-    const size_t lds = (size_t)2 * C * 4096 + (size_t)2 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024 + ldsPad;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)3 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024 + ldsPad;
     const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;

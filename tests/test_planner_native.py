@@ -58,8 +58,8 @@ def test_isa_check_sees_a_copy_made_before_the_wait():
 
 def test_generated_assembly_loop_is_up_to_date_and_balanced():
     """csrc/walk4_fast_loop.inc is what tools/gen_walk4_fast.py emits now, and the stream is structurally sound: every
-    out-of-line block returns, every label that is branched to exists exactly once, the fetch stage issues the four small
-    loads the host's wait codes assume (kernels.h WF_WAIT8 / WF_WAIT12), and nothing above v125 / s83 is named (126 vector
+    out-of-line block returns, every label that is branched to exists exactly once, every fetch issues the four small
+    loads the host's wait codes assume (kernels.h walkWaitCode), and nothing above v125 / s83 is named (126 vector
     registers: four waves per SIMD)."""
     import re
     env = dict(os.environ, WALK4_CHECK_ONLY="1")
@@ -72,9 +72,10 @@ def test_generated_assembly_loop_is_up_to_date_and_balanced():
     assert len(labels) == len(set(labels))
     targets = set(re.findall(r"s_c?branch\w* (\.LW4\w+_%=)", "\n".join(lines)))
     assert targets <= set(labels), targets - set(labels)
-    # per stage: one LDS-DMA, two tip-pair loads, one reciprocal-pair load (prologue + two stages = 3 of each group)
-    assert sum("global_load_lds_dwordx4" in l for l in lines) == 3
-    assert sum(l.startswith("global_load_ushort") for l in lines) == 6
+    # per fetch: one LDS-DMA, two tip-pair loads, one reciprocal-pair load (two in the prologue + three stages = 5 of each group)
+    assert sum("global_load_lds_dwordx4" in l for l in lines) == 5
+    assert sum(l.startswith("global_load_ushort") for l in lines) == 10
+    assert sum(l.startswith("global_load_dwordx4 v[22:25]") or l.startswith("global_load_dwordx4 v[26:29]") or l.startswith("global_load_dwordx4 v[30:33]") for l in lines) == 5
     regs = [int(x) for x in re.findall(r"\bv\[?(\d+)", "\n".join(lines))]
     assert max(regs) <= 125
     sregs = [int(x) for x in re.findall(r"\bs\[?(\d+)", "\n".join(lines))]

@@ -2,18 +2,26 @@
 """Generates beast-mcmc_amd/csrc/walk4_fast_loop.inc: the main loop of k_walk4_fast (kernels_walk4.hip) as ONE block of
 gfx950 assembly with explicit registers.
 
-Why assembly: the pattern walk is bound by instruction issue (profiles/r02_*sq*: ~200 instructions per micro-operation and
-wave from the C++ kernel, 45 % of them scalar / branch glue the compiler's control-flow structurizer adds around the
-hand-pipelined loads).  This loop does the same work in ~100, with 2-3 taken branches per micro-operation: everything rare
-(partials loads, hold-slot traffic, stores, a second child in memory) is out of line, the small loads are unconditional
-(the host points unused operands at dummy buffers: all-missing tip states, all-one scale factors), and what the compute
-half of a stage needs from a descriptor is stashed in three scalar registers when the fetch half has used it, so one
-descriptor register set serves the two-deep software pipeline.
+Why assembly: the pattern walk executes ~100 instructions per micro-operation and wave here against ~200 from the C++ kernel
+(45 % of those scalar / branch glue the compiler's control-flow structurizer adds around the hand-pipelined loads), with 2-3
+taken branches per micro-operation: everything rare (partials loads, hold-slot traffic, stores, a second child in memory) is
+out of line, the small loads are unconditional (the host points unused operands at dummy buffers: all-missing tip states,
+all-one scale factors), and what the compute half of a stage needs from a descriptor is stashed in scalar registers when
+the fetch half has used it, so one descriptor register set serves the software pipeline.
 
-It covers every micro-operation, write-mode rescaling included (rescale_block: LDS exchange across the category waves, two
-barriers, a true division).  What it requires is that every segment starts at a multiple of 128 patterns — the engine pads
-partitions internally to arrange that; the C++ kernel k_walk4 computes the same values bit for bit and is the reference
-implementation (BEAGLE_MI355_NO_FAST_WALK=1, tests/test_gpu_walk_kernels.py).
+The pipeline is THREE micro-operations deep (round 4; two before): while micro-operation k computes, the small loads of k + 1
+AND k + 2 — matrix table by LDS-DMA, two tip-state pairs, the reciprocal scale factors — are in flight, in three rotating
+register / LDS-table slots, and descriptor k + 3 is on its way.  A wave's stage used to be as long as the round trip of the
+loads issued at its start (481 ns per micro-operation for a wave alone on its SIMD; with the memory system loaded by the other
+waves' traffic that round trip grows: profiles/r04_experiments.txt 12), now two stages cover it.  The registers for the third
+slot come from the first-child partials buffers: a first child in memory (2 % of the micro-operations) or in an LDS hold slot
+is requested in the MIDDLE of the stage before its use, into one buffer instead of two.
+
+It covers every micro-operation, write-mode rescaling included (rescale_block: LDS atomics across the category waves, one
+barrier, a true division).  What it requires is that every segment starts at a multiple of 128 patterns — the engine pads
+partitions internally to arrange that — and three readable descriptors behind a program (engine_walk.cpp runPlan; any length:
+the loop can leave behind each of its three stages); the C++ kernel k_walk4 computes the same values bit for bit and is the reference implementation
+(BEAGLE_MI355_NO_FAST_WALK=1, tests/test_gpu_walk_kernels.py).
 
 Run: python tools/gen_walk4_fast.py   (rewrites the .inc; tests/test_planner_native.py checks it is up to date)"""
 import os
@@ -23,33 +31,35 @@ OUT = os.environ.get("WALK4_OUT") or os.path.join(ROOT, "beast-mcmc_amd", "csrc"
 
 # ---- register map -----------------------------------------------------------------------------------------------------
 # vector
-AX, BX = 0, 16                # fetched first-child partials of the two pipeline slots: pattern a = +0..7, pattern b = +8..15
-AT1, AT2, BT1, BT2 = 32, 33, 34, 35      # tip-state pairs (a | b << 8) of the two children
-AINV, BINV = 36, 40           # reciprocal scale factors {a, b}
+XB = 0                        # a first child that comes from memory or from an LDS hold slot: ONE buffer (pattern a = +0..7, b = +8..15),
+#                               requested in the middle of the stage before its use; between uses a scratch area of the second mat-vec
+T1S, T2S = (16, 17, 18), (19, 20, 21)    # tip-state pairs (a | b << 8) of the two children: three pipeline slots
+INVS = (22, 26, 30)           # reciprocal scale factors {a, b}: three pipeline slots
 ACC = 44                      # the previous micro-operation's result: a = +0..7, b = +8..15
 F, G = 60, 76                 # the two children's contributions
-SP = 92                       # lane l: entry (l & 15) of the first child's branch matrix
-SPB = 122                     # ... of the second child's
+SP = 92                       # lane l: entry (l & 15) of the branch matrix at hand
 T0, T1 = 94, 95
-PA, PB, TIP, SCALE, OM, HOLD, SP0, SP1, LANE, VST = 96, 97, 98, 99, 100, 101, 102, 103, 104, 105
+PA, PB, TIP, SCALE, OM, HOLD, LANE, VST = 96, 97, 98, 99, 100, 101, 104, 105
+SPS = (102, 103, 34)          # the lane's LDS address inside the three table buffers
 H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
-TBV0, TBV1 = 124, 125          # the LDS addresses of the two table buffers, in every lane (broadcast reads of a matrix's first column)
+TBVS = (124, 125, 35)         # the LDS addresses of the three table buffers, in every lane (broadcast reads of a matrix's first column)
 NV = 126
 # scalar (s32..s35 are left to the compiler)
-DP, STRM, CNT, TBL0, TBL1, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 25, 26, 27, 28, 29, 30, 31
+DP, STRM, CNT, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 27, 28, 29, 30, 31
+TBLS = (25, 26, 57)           # LDS addresses of the three table buffers of this wave
 D, DFL, DW = 36, 44, 46             # descriptor (kernels.h WalkOp): src1 D+0, src2 D+2, store D+4, scale D+6 | flags s44, (pad s45), the scale buffer a rescaling operation writes s46:47 — two loads: x8 at 0, x4 at 0x20
 CM160 = 83
-SA_FL, SA_STORE, SA_SRC2, SA_SCALEW = 48, 50, 52, 54
-SB_FL, SB_STORE, SB_SRC2, SB_SCALEW = 56, 58, 60, 62
+FLS, SCALEWS = (48, 56, 49), (54, 62, 58)      # what a compute stage needs of its descriptor, stashed by the fetch: three pipeline slots
+SSTORE, SSRC2, SX = 50, 52, 60                 # addresses the rare blocks read again from the descriptor (store, second child, first child)
 MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
 VALA, VALB = 72, 74           # lanes whose first / second pattern lies inside the range (scale-factor stores)
 DIVS, SCNT, EXCH, NCAT, ROFF, RB = 76, 78, 79, 80, 81, 82    # RB: byte offset of the rescaling maximum buffer the next node uses
-C0A, C0B = 84, 100            # (WALK4_SCOL) column 0 of the two branch matrices of the even / odd micro-operations: M[i][0]
 S_FIRST = 20
 
 # flag bits (kernels.h)
 B_X, B_T1, B_T2, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 4, 12, 14
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
+# the stage's wait as a 2-bit code at B_WAIT0 (kernels.h walkWaitCode): 0 = vmcnt(8), 1 = 12, 2 = 16, 3 = 4
 
 # Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
 # in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
@@ -59,12 +69,6 @@ B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27
 # access stream through HBM once anyway.
 STORE_POLICY = os.environ.get("WALK4_STORE_POLICY", " sc1 nt")
 LOAD_POLICY = os.environ.get("WALK4_LOAD_POLICY", " sc1")
-# A/B switches (tools/build_variant.sh): both give the same bits
-# (measured on config A and the 12 500-pattern shard, profiles/r03_experiments.txt: neither changes the time — the loop is not
-# bound by its vector-instruction count or by LDS round trips — so both stay off and the round-2 stream is what ships)
-SCOL = False                                                # (first term of every mat-vec row from SGPRs: 32 more scalar registers than are left now)
-LDSBATCH = os.environ.get("WALK4_LDSBATCH", "0") != "0"     # every LDS read of a stage is issued before its one LDS wait
-EARLYDESC = os.environ.get("WALK4_EARLYDESC", "0") != "0"   # descriptor k + 2 is requested right after the fetch of k + 1 has used the registers
 # TIMING EXPERIMENTS ONLY (wrong results; tools/walk_floor.sh, profiles/r02_experiments.txt): comma-separated parts to leave out
 EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if x)
 # TIMING EXPERIMENTS ONLY (same results): WALK4_PAD=<kind>:<n> adds n do-nothing instructions to every stage — snop (s_nop 0: 4 bytes,
@@ -72,12 +76,6 @@ EXPERIMENT = set(x for x in os.environ.get("WALK4_EXPERIMENT", "").split(",") if
 # onto itself: 4 bytes, vector), vlit (v_mov_b32 of a literal into a scratch register: 8 bytes, vector) — to tell what the loop
 # is bound by: instruction count, instruction bytes or the vector pipe (profiles/r04_experiments.txt)
 PAD = os.environ.get("WALK4_PAD", "")
-# The reciprocal scale factors of a micro-operation are the one load of a stage that comes from HBM (a stream read once per
-# evaluation) and they are used LAST, by the final multiply: with LATEINV the stage's first wait leaves that load outstanding
-# (vmcnt one higher: it is the youngest of its fetch and loads return in order) and a second wait in front of the multiply
-# retires it — almost a whole stage more for it to land, which is what a wave that has its SIMD to itself (the serial top of the
-# tree on a small shard) is short of.  A/B switch.
-LATEINV = os.environ.get("WALK4_LATEINV", "1") != "0"
 COL0 = os.environ.get("WALK4_COL0", "1") != "0"            # a mat-vec's first column from broadcast LDS reads (matvec): A/B switch
 lines = []
 
@@ -257,80 +255,85 @@ def rescale_block(tag, SSCALEW):
     return b
 
 
-def fetch(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblDst):
-    """Issue everything the micro-operation described by D needs into pipeline slot (X, Tt1, Tt2, INV), stash what its
-    compute stage needs (the flags and the scale buffer a rescaling operation writes: the two fields rare blocks need — the
-    store address, a second child in memory — are read again from the descriptor where they are used), advance the stream.
-    The loop is bound by instruction ISSUE, whatever the type (~4 cycles per instruction and SIMD): the two rare
-    cases of a fetch — a first child waiting in an LDS hold slot, a first child in memory — share ONE test on the common path."""
+def fetch(tag, slot):
+    """Issue the small loads of the micro-operation described by D into pipeline slot `slot` — its matrix table (LDS-DMA into
+    table buffer `slot`), the two tip-state pairs, the reciprocal scale factors: always these FOUR vector-memory instructions —,
+    stash what its compute stage needs (the flags and the scale buffer a rescaling operation writes: the fields rare blocks need
+    — the store address, a child in memory — are read again from the descriptor where they are used), advance the stream."""
     # (an experiment that drops a load replaces it by a cheap one to the same register so that the waits still balance)
     if "nodma" in EXPERIMENT:
         e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
     else:
-        e("s_mov_b32 m0, %s" % s(tblDst))
+        e("s_mov_b32 m0, %s" % s(TBLS[slot]))
         e("s_mov_b64 exec, 0xfffff")
         e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
         e("s_mov_b64 exec, -1")
-    e("global_load_ushort %s, %s, %s" % (v(Tt1), v(TIP), s(D, 2)))
-    e("global_load_ushort %s, %s, %s" % (v(Tt2), v(TIP), s(D + 2, 2)))
+    e("global_load_ushort %s, %s, %s" % (v(T1S[slot]), v(TIP), s(D, 2)))
+    e("global_load_ushort %s, %s, %s" % (v(T2S[slot]), v(TIP), s(D + 2, 2)))
     e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
-    e("s_mov_b32 %s, %s" % (s(SFL), s(DFL)))
-    e("s_mov_b64 %s, %s" % (s(SSCALEW, 2), s(DW, 2)))
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(DFL), (1 << B_HREAD) | (1 << B_X)))
-    e("s_cbranch_scc1 %s" % L("fr" + tag))
-    e(L("frb" + tag) + ":")
-    # the reciprocal scale factors LAST of the fetch's loads (behind a first child's partials, if any): the stage's first wait
-    # leaves exactly this one outstanding (LATEINV)
+    e("s_mov_b32 %s, %s" % (s(FLS[slot]), s(DFL)))
+    e("s_mov_b64 %s, %s" % (s(SCALEWS[slot], 2), s(DW, 2)))
     if "noinv" in EXPERIMENT:
         e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
     else:
-        e("global_load_dwordx4 %s, %s, %s" % (v(INV, 4), v(SCALE), s(D + 6, 2)))
+        e("global_load_dwordx4 %s, %s, %s" % (v(INVS[slot], 4), v(SCALE), s(D + 6, 2)))
+
+
+def first_child_fetch(tag, SFLn, off_src1):
+    """The first child of the FOLLOWING micro-operation (flags in SFLn), if it waits in an LDS hold slot or in memory, into XB —
+    behind the last use of XB by the micro-operation at hand; ONE test on the common path.  off_src1: where DP finds that
+    descriptor's src1 now."""
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFLn), (1 << B_HREAD) | (1 << B_X)))
+    e("s_cbranch_scc1 %s" % L("fr" + tag))
+    e(L("frb" + tag) + ":")
     blk = [L("fr" + tag) + ":",
-           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD),
+           "s_bitcmp1_b32 %s, %d" % (s(SFLn), B_HREAD),
            "s_cbranch_scc0 %s" % L("x" + tag),
-           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD2),          # slot 2 is a register set: nothing to fetch
+           "s_bitcmp1_b32 %s, %d" % (s(SFLn), B_HREAD2),          # slot 2 is a register set: nothing to fetch
            "s_cbranch_scc1 %s" % L("frb" + tag),
-           "s_bitcmp1_b32 %s, %d" % (s(DFL), B_HREAD1),
+           "s_bitcmp1_b32 %s, %d" % (s(SFLn), B_HREAD1),
            "s_cselect_b32 %s, %s, 0" % (s(ST), s(HSTRIDE)),
            "v_add_u32_e32 %s, %s, %s" % (v(T0), s(ST), v(HOLD))]
     for q in range(4):
-        blk.append("ds_read_b128 %s, %s offset:%d" % (v(X + 4 * q, 4), v(T0), 1024 * q))
+        blk.append("ds_read_b128 %s, %s offset:%d" % (v(XB + 4 * q, 4), v(T0), 1024 * q))
     blk.append("s_branch %s" % L("frb" + tag))
     blk += [L("x" + tag) + ":",
-            "global_load_dwordx4 %s, %s, %s%s" % (v(X, 4), v(PA), s(D, 2), LOAD_POLICY),
-            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 4, 4), v(PA), s(D, 2), LOAD_POLICY),
-            "global_load_dwordx4 %s, %s, %s%s" % (v(X + 8, 4), v(PB), s(D, 2), LOAD_POLICY),
-            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(X + 12, 4), v(PB), s(D, 2), LOAD_POLICY),
+            "s_load_dwordx2 %s, %s, %d" % (s(SX, 2), s(DP, 2), off_src1),
+            "s_waitcnt lgkmcnt(0)",
+            "global_load_dwordx4 %s, %s, %s%s" % (v(XB, 4), v(PA), s(SX, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(XB + 4, 4), v(PA), s(SX, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s%s" % (v(XB + 8, 4), v(PB), s(SX, 2), LOAD_POLICY),
+            "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(XB + 12, 4), v(PB), s(SX, 2), LOAD_POLICY),
             "s_branch %s" % L("frb" + tag)]
     outofline.append(blk)
 
 
-def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, tbvCur, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext, c0set):
-    """One micro-operation: its operands are in slot (X, Tt1, Tt2, INV) and its table in LDS buffer tblCur / spCur; the
-    following one is fetched into the other slot."""
+def stage(tag, cur):
+    """One micro-operation, k: its small operands are in pipeline slot `cur` = k mod 3, its table in LDS buffer `cur`; micro-operation
+    k + 2 is fetched into slot cur + 2, the first child of k + 1 — when it has to be — into XB.  DP points at descriptor k + 3
+    until the stage's descriptor load, at k + 4 behind it (kernels.h WalkOp: src1 at 0, src2 at 8, store at 16)."""
+    nxt, far = (cur + 1) % 3, (cur + 2) % 3
+    Tt1, Tt2, INV, SFL, SSCALEW = T1S[cur], T2S[cur], INVS[cur], FLS[cur], SCALEWS[cur]
+    tblCur, spCur, tbvCur = TBLS[cur], SPS[cur], TBVS[cur]
     if "notopwait" not in EXPERIMENT:
-        e("s_waitcnt lgkmcnt(0)")                   # the descriptor of the NEXT micro-operation (and LDS writes) have landed
-    fetch(tag, nX, nT1, nT2, nINV, nSFL, nSSTORE, nSSRC2, nSSCALEW, tblNext)
-    if EARLYDESC:   # descriptor k + 2, a whole stage before its use: its latency (a scalar-cache miss goes to L2) hides behind the wait below
-        e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-        e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
-        e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
-        e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
-    # wait for this micro-operation's loads: N = everything issued after them = 4 (+4 stores before, +4 partials loads now)
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WAIT0) | (1 << B_WAIT1)))
+        e("s_waitcnt lgkmcnt(0)")                   # descriptor k + 2 (and LDS writes) have landed
+    fetch(tag, far)
+    # wait for this micro-operation's loads: N = what was issued after them and may stay outstanding — the fetches of k + 1 and
+    # k + 2 (8), a first child of k - 1 from memory (+4), stores where the engine counts them (engine_walk.cpp runPlan);
+    # 4 when this micro-operation's own first child comes from memory (requested a stage ago, behind the fetch of k + 1)
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), 3 << B_WAIT0))
     e("s_cbranch_scc1 %s" % L("ws" + tag))
     novm = "novmwait" in EXPERIMENT
-    extra = 1 if LATEINV else 0                     # the first wait leaves this stage's reciprocal-scale load outstanding
-    e("s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (4 + extra))
+    e("s_nop 0" if novm else "s_waitcnt vmcnt(8)")
     e(L("wd" + tag) + ":")
-    outofline.append([L("ws" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc0 %s" % L("w12" + tag),
-                      "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (8 + extra), "s_branch %s" % L("wd" + tag),
-                      L("w12" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % (12 + extra), "s_branch %s" % L("wd" + tag)])
-    c0 = c0set if SCOL else None
-    # (descriptor k of the micro-operation being computed: DP points at k + 2 until the stage's descriptor load, at k + 3 after it —
-    # with EARLYDESC at k + 3 from the fetch on; kernels.h WalkOp: src2 at 8, store at 16)
-    off_src2 = -(3 if EARLYDESC else 2) * 64 + 8
-    off_store = -3 * 64 + 16
+    outofline.append([L("ws" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT1), "s_cbranch_scc1 %s" % L("w16" + tag),
+                      "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag),
+                      L("w16" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc1 %s" % L("w4" + tag),
+                      "s_nop 0" if novm else "s_waitcnt vmcnt(16)", "s_branch %s" % L("wd" + tag),
+                      L("w4" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(4)", "s_branch %s" % L("wd" + tag)])
+    off_src2 = -3 * 64 + 8
+    off_src1_next = -2 * 64
+    off_store = -4 * 64 + 16
     m2blk = [L("m2" + tag) + ":",                    # both children in memory: the second one is loaded into ACC, synchronously
              "s_load_dwordx2 %s, %s, %d" % (s(SSRC2, 2), s(DP, 2), off_src2),
              "s_waitcnt lgkmcnt(0)",
@@ -340,108 +343,54 @@ def stage(tag, X, Tt1, Tt2, INV, SFL, SSTORE, SSRC2, SSCALEW, tblCur, spCur, tbv
              "global_load_dwordx4 %s, %s, %s offset:16%s" % (v(ACC + 12, 4), v(PB), s(SSRC2, 2), LOAD_POLICY),
              "s_waitcnt vmcnt(0)",
              "s_branch %s" % L("m2b" + tag)]
-    if LDSBATCH:
-        # every LDS read of the stage first — a tip child's two columns or the lane's entry of the branch matrix, for both
-        # children — then ONE wait, then the arithmetic (a wave used to park once per child)
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
-        e("s_cbranch_scc0 %s" % L("fm" + tag))
-        tip_columns(F, Tt1, tblCur, 0)
-        e("s_branch %s" % L("g" + tag))
-        e(L("fm" + tag) + ":")
-        e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
-        e(L("g" + tag) + ":")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
-        e("s_cbranch_scc0 %s" % L("ga" + tag))
-        tip_columns(G, Tt2, tblCur, 160)
-        e("s_branch %s" % L("lw" + tag))
-        e(L("ga" + tag) + ":")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
-        e("s_cbranch_scc1 %s" % L("m2" + tag))
-        e(L("m2b" + tag) + ":")
-        outofline.append(m2blk)
-        e("ds_read_b64 %s, %s offset:160" % (v(SPB, 2), v(spCur)))
-        e(L("lw" + tag) + ":")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
-        e("s_cbranch_scc1 %s" % L("c2" + tag))
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
-        e("s_cbranch_scc1 %s" % L("fh2" + tag))
-        matvec(F, X, SP, c0)
-        save = lines[:]
-        del lines[:]
-        e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
-        matvec(F, H2, SP, c0)
-        e("s_branch %s" % L("c2" + tag))
-        outofline.append(lines[:])
-        del lines[:]
-        lines.extend(save)
-        e(L("c2" + tag) + ":")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
-        e("s_cbranch_scc1 %s" % L("mul" + tag))
-        matvec(G, ACC, SPB, None if c0 is None else c0 + 8)
-    else:
-        # first child
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
-        e("s_cbranch_scc0 %s" % L("fm" + tag))
-        tip_columns(F, Tt1, tblCur, 0)
-        e("s_branch %s" % L("g" + tag))
-        e(L("fm" + tag) + ":")
-        e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
-        col0_reads(G, tbvCur, 0)                     # (G is free until the second child's contribution is formed)
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
-        e("s_cbranch_scc1 %s" % L("fh2" + tag))
-        ldsw = "s_nop 0" if "noldswait" in EXPERIMENT else "s_waitcnt lgkmcnt(0)"
-        e(ldsw)
-        matvec(F, X, SP, c0, col0v=G)
-        save = lines[:]
-        del lines[:]
-        e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
-        e(ldsw)
-        matvec(F, H2, SP, c0, col0v=G)
-        e("s_branch %s" % L("g" + tag))
-        outofline.append(lines[:])
-        del lines[:]
-        lines.extend(save)
-        # second child
-        e(L("g" + tag) + ":")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
-        e("s_cbranch_scc0 %s" % L("ga" + tag))
-        tip_columns(G, Tt2, tblCur, 160)
-        e(ldsw)
-        e("s_branch %s" % L("mul" + tag))
-        e(L("ga" + tag) + ":")
-        e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
-        e("s_cbranch_scc1 %s" % L("m2" + tag))
-        e(L("m2b" + tag) + ":")
-        outofline.append(m2blk)
-        e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
-        col0_reads(X, tbvCur, 160)                   # (this slot's first-child registers: consumed by the first mat-vec, or never used)
-        e(ldsw)
-        matvec(G, ACC, SP, None if c0 is None else c0 + 8, col0v=X)
+    # first child
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
+    e("s_cbranch_scc0 %s" % L("fm" + tag))
+    tip_columns(F, Tt1, tblCur, 0)
+    e("s_branch %s" % L("g" + tag))
+    e(L("fm" + tag) + ":")
+    e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
+    col0_reads(G, tbvCur, 0)                     # (G is free until the second child's contribution is formed)
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HREAD2))
+    e("s_cbranch_scc1 %s" % L("fh2" + tag))
+    ldsw = "s_nop 0" if "noldswait" in EXPERIMENT else "s_waitcnt lgkmcnt(0)"
+    e(ldsw)
+    matvec(F, XB, SP, None, col0v=G)
+    save = lines[:]
+    del lines[:]
+    e(L("fh2" + tag) + ":")                      # first child waits in the register hold slot
+    e(ldsw)
+    matvec(F, H2, SP, None, col0v=G)
+    e("s_branch %s" % L("g" + tag))
+    outofline.append(lines[:])
+    del lines[:]
+    lines.extend(save)
+    # second child
+    e(L("g" + tag) + ":")
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
+    e("s_cbranch_scc0 %s" % L("ga" + tag))
+    tip_columns(G, Tt2, tblCur, 160)
+    e(ldsw)
+    e("s_branch %s" % L("mul" + tag))
+    e(L("ga" + tag) + ":")
+    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
+    e("s_cbranch_scc1 %s" % L("m2" + tag))
+    e(L("m2b" + tag) + ":")
+    outofline.append(m2blk)
+    e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
+    col0_reads(XB, tbvCur, 160)                  # (the first-child buffer: consumed by the first mat-vec, or not in use)
+    e(ldsw)
+    matvec(G, ACC, SP, None, col0v=XB)
     e(L("mul" + tag) + ":")
-    # descriptor k + 2: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)
-    if not EARLYDESC:
-        e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
-        e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
-    if SCOL:    # column 0 of both tables of micro-operation k + 2 (STRM points there since this stage's fetch) into the set this
-        #         stage's mat-vecs have just finished with
-        e("s_load_dwordx8 %s, %s, %s" % (s(c0set, 8), s(STRM, 2), s(CM0)))
-        e("s_load_dwordx8 %s, %s, %s" % (s(c0set + 8, 8), s(STRM, 2), s(CM160)))
-    if not EARLYDESC:
-        e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
-        e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
+    # the first child of micro-operation k + 1, where it has to be fetched (XB is free from here on)
+    first_child_fetch(tag, FLS[nxt], off_src1_next)
+    # descriptor k + 3: behind every LDS wait of the stage (scalar loads share the counter with LDS and return out of order)
+    e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
+    e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
+    e("s_add_u32 %s, %s, 64" % (s(DP), s(DP)))
+    e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
-    if LATEINV and "novmwait" not in EXPERIMENT:
-        # the second wait: this stage's reciprocal scale factors (the loads of the next stage's fetch may stay outstanding: the
-        # same counts as the first wait without its extra one)
-        e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WAIT0) | (1 << B_WAIT1)))
-        e("s_cbranch_scc1 %s" % L("wt" + tag))
-        e("s_waitcnt vmcnt(4)")
-        e(L("wtd" + tag) + ":")
-        outofline.append([L("wt" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc0 %s" % L("wt12" + tag),
-                          "s_waitcnt vmcnt(8)", "s_branch %s" % L("wtd" + tag),
-                          L("wt12" + tag) + ":", "s_waitcnt vmcnt(12)", "s_branch %s" % L("wtd" + tag)])
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
     pad_block()
@@ -500,9 +449,10 @@ def build():
     # ---- inputs -> fixed registers
     e("s_mov_b64 %s, %%[dp]" % s(DP, 2))
     e("s_mov_b64 %s, %%[strm]" % s(STRM, 2))
-    e("s_mov_b32 %s, %%[cnt]" % s(CNT))
-    e("s_mov_b32 %s, %%[tbl]" % s(TBL0))
-    e("s_add_u32 %s, %%[tbl], %%[tblStep]" % s(TBL1))
+    e("s_add_i32 %s, %%[cnt], -1" % s(CNT))
+    e("s_mov_b32 %s, %%[tbl]" % s(TBLS[0]))
+    e("s_add_u32 %s, %%[tbl], %%[tblStep]" % s(TBLS[1]))
+    e("s_add_u32 %s, %s, %%[tblStep]" % (s(TBLS[2]), s(TBLS[1])))
     e("s_mov_b32 %s, %%[holdStride]" % s(HSTRIDE))
     e("s_mov_b32 %s, %%[strmStep]" % s(STEP))
     e("s_add_i32 %s, %%[pEnd], -1" % s(LAST))
@@ -566,34 +516,38 @@ def build():
     e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
     e("v_bfe_u32 %s, %s, 2, 2" % (v(T1), v(LANE)))
     e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
-    e("v_add_u32_e32 %s, %s, %s" % (v(SP0), s(TBL0), v(T0)))
-    e("v_add_u32_e32 %s, %s, %s" % (v(SP1), s(TBL1), v(T0)))
-    e("v_mov_b32_e32 %s, %s" % (v(TBV0), s(TBL0)))
-    e("v_mov_b32_e32 %s, %s" % (v(TBV1), s(TBL1)))
+    for j in range(3):
+        e("v_add_u32_e32 %s, %s, %s" % (v(SPS[j]), s(TBLS[j]), v(T0)))
+        e("v_mov_b32_e32 %s, %s" % (v(TBVS[j]), s(TBLS[j])))
     for i in range(8):
         e("v_mov_b64 %s, 1.0" % v(ACC + 2 * i, 2))
-    # ---- prologue: fetch micro-operation 0 into slot A, descriptor 1 into D
+    # ---- prologue: fetch micro-operations 0 and 1 into slots 0 and 1, the first child of 0 if it is in memory (no hold slot is
+    # in use at the start of a program), descriptor 2 into D; DP -> descriptor 3
     e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
     e("s_load_dwordx4 %s, %s, 0x20" % (s(DFL, 4), s(DP, 2)))
     e("s_waitcnt lgkmcnt(0)")
-    if SCOL:
-        e("s_load_dwordx8 %s, %s, %s" % (s(C0A, 8), s(STRM, 2), s(CM0)))
-        e("s_load_dwordx8 %s, %s, %s" % (s(C0A + 8, 8), s(STRM, 2), s(CM160)))
-    fetch("p", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0)
-    if SCOL:
-        e("s_load_dwordx8 %s, %s, %s" % (s(C0B, 8), s(STRM, 2), s(CM0)))
-        e("s_load_dwordx8 %s, %s, %s" % (s(C0B + 8, 8), s(STRM, 2), s(CM160)))
+    fetch("p", 0)
     e("s_load_dwordx8 %s, %s, 0x40" % (s(D, 8), s(DP, 2)))
     e("s_load_dwordx4 %s, %s, 0x60" % (s(DFL, 4), s(DP, 2)))
-    e("s_add_u32 %s, %s, 0x80" % (s(DP), s(DP)))
+    e("s_waitcnt lgkmcnt(0)")
+    fetch("q", 1)
+    first_child_fetch("p", FLS[0], 0)
+    e("s_load_dwordx8 %s, %s, 0x80" % (s(D, 8), s(DP, 2)))
+    e("s_load_dwordx4 %s, %s, 0xa0" % (s(DFL, 4), s(DP, 2)))
+    e("s_add_u32 %s, %s, 0xc0" % (s(DP), s(DP)))
     e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
-    # ---- the loop: two stages
+    # ---- the loop: three stages
+    # (CNT = micro-operations left behind the one at hand: the loop leaves behind ANY stage, so a program needs no padding)
     e(L("top") + ":")
-    stage("a", AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, SP0, TBV0, BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, C0A)
-    stage("b", BX, BT1, BT2, BINV, SB_FL, SB_STORE, SB_SRC2, SB_SCALEW, TBL1, SP1, TBV1, AX, AT1, AT2, AINV, SA_FL, SA_STORE, SA_SRC2, SA_SCALEW, TBL0, C0B)
-    e("s_add_i32 %s, %s, -2" % (s(CNT), s(CNT)))
-    e("s_cmp_gt_i32 %s, 0" % s(CNT))
-    e("s_cbranch_scc1 %s" % L("top"))
+    stage("a", 0)
+    e("s_sub_u32 %s, %s, 1" % (s(CNT), s(CNT)))
+    e("s_cbranch_scc1 %s" % L("end"))
+    stage("b", 1)
+    e("s_sub_u32 %s, %s, 1" % (s(CNT), s(CNT)))
+    e("s_cbranch_scc1 %s" % L("end"))
+    stage("c", 2)
+    e("s_sub_u32 %s, %s, 1" % (s(CNT), s(CNT)))
+    e("s_cbranch_scc0 %s" % L("top"))
     e("s_branch %s" % L("end"))
     for blk in outofline:
         for l in blk:
@@ -610,7 +564,7 @@ def main():
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
-    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, (C0B + 16 if SCOL else CM160 + 1)) if i not in (32, 33, 34, 35)]
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, CM160 + 1) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
     text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
     text.append("#define WALK4_FAST_VGPRS %d" % NV)

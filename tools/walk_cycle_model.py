@@ -24,8 +24,8 @@ INC = os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")
 WK_MEM, WK_TIPS, WK_ACC, WK_H0, WK_H1, WK_H2 = 0, 1, 2, 3, 4, 5
 WS_NONE, WS_READ, WS_WRITE = 0, 1, 2
 WF_X, WF_T1, WF_T2, WF_INV, WF_STORE = 1, 2, 4, 8, 16
-WF_HREAD, WF_HREAD1, WF_MEM2, WF_HWRITE, WF_WAIT8, WF_WAIT12, WF_HREAD2 = 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 28, 1 << 29, 1 << 30
-DFL, SA_FL, SB_FL, ST = 44, 48, 56, 29
+WF_HREAD, WF_HREAD1, WF_MEM2, WF_HWRITE, WF_HREAD2 = 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 30
+DFL, FLS, ST = 44, (48, 56, 49), 29          # tools/gen_walk4_fast.py: the descriptor's flags, their stashes of the three pipeline slots
 
 
 def walk_flags(k1, k2, hold, smode, store):
@@ -70,29 +70,27 @@ def classify(ins):
 
 
 def run_iteration(lines, labels, flags):
-    """One pass through the loop body = stage a (micro-operation 0) + stage b (micro-operation 1); flags[0..3]: the two being
-    computed and the two being fetched behind them.  -> Counter per stage."""
-    regs = {SA_FL: flags[0], DFL: flags[1], SB_FL: 0, ST: 0}
-    pending = [flags[2], flags[3]]          # what the s_load of DFL delivers, stage by stage
+    """One pass through the loop body = three stages (micro-operations 0, 1, 2 of `flags`; flags[2..5]: the ones being fetched
+    behind them: the loop is three deep).  -> Counter per stage."""
+    regs = {FLS[0]: flags[0], FLS[1]: flags[1], FLS[2]: 0, DFL: flags[2], ST: 0}
+    pending = list(flags[3:6])               # what the descriptor loads deliver, stage by stage
     pc = labels[".LW4top_%="] + 1
-    counts = [collections.Counter(), collections.Counter()]
+    counts = [collections.Counter(), collections.Counter(), collections.Counter()]
     stage, scc, steps = 0, 0, 0
     while True:
         steps += 1
-        if steps > 5000:
+        if steps > 8000:
             raise RuntimeError("runaway")
         ins = lines[pc]
         pc += 1
         if ins.endswith(":"):
-            if ins == ".LW4hwba_%=:":              # behind stage a's hold-slot write (its last out-of-line block): stage b
-                stage = 1
-                if "next_dfl" in regs:
-                    regs[DFL] = regs.pop("next_dfl")
+            if ins in (".LW4hwba_%=:", ".LW4hwbb_%=:"):       # behind a stage's hold-slot write (its last out-of-line block): the next stage
+                stage += 1
+                regs[DFL] = pending.pop(0) if pending else 0
             continue
         op = ins.split()[0]
         args = [a.strip() for a in ins[len(op):].split(",")]
         cls = classify(ins)
-        # the second stage begins at its opening "s_waitcnt lgkmcnt(0)" — the first instruction after label hwb of stage a
         counts[stage][cls] += 1
         if op == "s_bitcmp1_b32":
             r = int(args[0][1:])
@@ -105,13 +103,12 @@ def run_iteration(lines, labels, flags):
             regs[dst] = (regs.get(src, 0) >> (spec & 31)) & ((1 << (spec >> 16)) - 1)
         elif op == "s_cmp_eq_u32":
             scc = 1 if regs.get(int(args[0][1:]), 0) == int(args[1], 0) else 0
-        elif op == "s_cmp_gt_i32":                 # the loop counter: one iteration is what is counted
-            counts[stage][cls] -= 0
+        elif op == "s_sub_u32" and args[0] == "s24":     # the loop counter: never the last micro-operation here
+            scc = 0
+        elif op == "s_cbranch_scc0" and args[0] == ".LW4top_%=":     # one iteration is what is counted
             return counts
         elif op == "s_mov_b32" and args[0].startswith("s") and args[1].startswith("s") and args[1][1:].isdigit():
             regs[int(args[0][1:])] = regs.get(int(args[1][1:]), 0)
-        elif op == "s_load_dword" and int(args[0][1:]) == DFL:
-            regs["next_dfl"] = pending.pop(0) if pending else 0
         elif (op == "s_cbranch_scc1" and scc) or (op == "s_cbranch_scc0" and not scc) or op == "s_branch":
             pc = labels[args[0]]                   # (the label line itself is passed next: stage bookkeeping above)
 
@@ -128,9 +125,10 @@ KINDS = {
 CYCLES = {"valu64": 4, "valu32": 4, "valu_dpp": 4, "lds": 4, "vmem": 4, "smem": 1, "salu": 1, "branch": 1, "wait": 1, "nop": 1}
 
 
-def stage_counts(lines, labels, cur, nxt):
-    """counts of the stage that computes micro-operation `cur` while fetching `nxt` (steady state: the same pair repeating)."""
-    c = run_iteration(lines, labels, [cur, nxt, cur, nxt])
+def stage_counts(lines, labels, cur, nxt, far=None):
+    """counts of the stage that computes micro-operation `cur` while `nxt` and `far` are in flight behind it."""
+    far = nxt if far is None else far
+    c = run_iteration(lines, labels, [cur, nxt, far, far, far, far])
     return c[0]
 
 
@@ -162,9 +160,11 @@ def main():
         total = collections.Counter()
         for i, (k1, k2, hold, sm, store) in enumerate(prog):
             nk = prog[i + 1] if i + 1 < len(prog) else prog[i]
+            fk = prog[i + 2] if i + 2 < len(prog) else nk
             cur = walk_flags(k1, k2, hold, sm, bool(store))
             nxt = walk_flags(nk[0], nk[1], nk[2], nk[3], bool(nk[4]))
-            total.update(stage_counts(lines, labels, cur, nxt))
+            far = walk_flags(fk[0], fk[1], fk[2], fk[3], bool(fk[4]))
+            total.update(stage_counts(lines, labels, cur, nxt, far))
         n = len(prog)
         print("\nprogram of %d micro-operations (%s), per micro-operation and wave:" % (n, args.plan))
         for k in ("valu64", "valu_dpp", "valu32", "lds", "vmem", "smem", "salu", "branch", "wait", "nop"):
