@@ -301,6 +301,32 @@ def test_gradient_corner_shapes(oracle_lib):
     assert checked >= 60
 
 
+def test_gradient_corner_shapes_on_the_matrix_cores(oracle_lib):
+    """16..64 states: the one-pass pre-order kernel and the edge-derivative kernel (kernels_mfma.hip k_preOpTiled / k_edgeTiled) over
+    corner shapes — partial state tiles (17, 33, 61), exact ones (16, 20, 64), a single pattern, ragged tiles of 32 and blocks of 64,
+    two taxa, 1 .. 7 rate categories, with and without rescaling in the post-order pass; sums, sums of squares and per-pattern
+    derivatives against the oracle, and against the older two-pass route of the same engine where that still exists."""
+    checked = 0
+    for S, C in ((16, 3), (17, 1), (20, 4), (33, 2), (61, 3), (64, 1), (20, 7)):
+        for T, P in ((2, 1), (3, 31), (5, 32), (6, 65), (9, 130)):
+            if S > 33 and P > 65 and C > 1:
+                continue
+            wl = helpers.random_workload(T, P, S, C, seed=900 + 7 * S + T)
+            for rescale in (False, True):
+                g = BranchGradient(wl, rescale=rescale, double_buffer=True)
+                o = BranchGradient(wl, rescale=rescale, double_buffer=True, library=oracle_lib)
+                (lg, gg), (lo, go) = g.gradient(), o.gradient()
+                assert helpers.rel_err(lg, lo) <= REL_TOL, (S, C, T, P, rescale)
+                close(gg, go, "S=%d C=%d T=%d P=%d rescale=%s" % (S, C, T, P, rescale))
+                lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
+                lo, go, ho, po = o.gradient(second=True, per_pattern=True)
+                close(gg, go, "gradient"); close(hg, ho, "second derivatives"); close(pg, po, "per-pattern derivatives")
+                assert g.b.gradientStats()["by_operation"] == 2
+                g.close(); o.close()
+                checked += 1
+    assert checked >= 60
+
+
 def test_gradient_with_tips_sent_as_partials(oracle_lib):
     """A useAmbiguities-style instance (every tip uploaded with setTipPartials): the walks treat such a tip as a memory operand
     without a scale factor; the second evaluation is answered by the pre-order walk."""
