@@ -56,7 +56,7 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         mi355::launchRootSiteTiled(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                    in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
                                    in->blockSums, in->P, in->S, in->C, pStart, pEnd);
-        mi355::launchRootFinal(live(in), in->blockSums, (pEnd - pStart + 255) / 256, dOut, flag, seq);
+        mi355::launchRootFinal(live(in), in->blockSums, mi355::rootSiteTiledBlocks(pEnd - pStart), dOut, flag, seq);
     } else {
         mi355::launchRootLogLikelihood(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                        in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
@@ -361,7 +361,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostMalloc((void**)&in->hResult, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void**)&in->hResultDev, in->hResult, 0) == hipSuccess;
     const size_t S = stateCount, C = categoryCount, E = in->eigenCount;
-    const int rootBlocks = (patternCount + 255) / 256;
+    const int rootBlocks = (patternCount + 63) / 64;          // (the T32 root kernel: a partial sum per 64 patterns; 4 states: per 256)
     ok = ok && devAlloc(in, (void**)&in->dRing, RING_BYTES) == 0;
     ok = ok && devAlloc(in, (void**)&in->matrices, matrixSlots * C * S * S * sizeof(double)) == 0;
     ok = ok && devAlloc(in, (void**)&in->eigen, E * (2 * S * S + 2 * S) * sizeof(double)) == 0;

@@ -320,6 +320,7 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
 // launchPrePartials; no write-mode rescaling: such operations take the two passes of the pruning kernel).  false: LDS refused.
 bool launchPreOpsTiled(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C);
 // per-pattern site log-likelihoods + per-block weighted sums (finish with launchRootFinal)
+int  rootSiteTiledBlocks(int patterns);      // entries launchRootSiteTiled writes to blockSums for that many patterns
 void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                          double* blockSums, int P, int S, int C, int pStart, int pEnd);

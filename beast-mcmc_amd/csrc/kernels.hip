@@ -81,16 +81,22 @@ __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrice
                                                     const double* __restrict__ rates, const int* __restrict__ dIdx,
                                                     const double* __restrict__ dLen, const int* __restrict__ dEig,
                                                     const int* __restrict__ dRate, int S, int C, int complexEigen) {
-    extern __shared__ double sh[];            // iexp[S][S]
+    extern __shared__ double sh[];            // iexp[S][S] | exp(dist lambda_k)[S]
     const int u = blockIdx.x, c = blockIdx.y;
     const size_t eigStride = (size_t)2 * S * S + (complexEigen ? 2 : 1) * S;
     const double* U = eigen + eigStride * dEig[u];
     const double* Ui = U + (size_t)S * S;
     const double* lam = Ui + (size_t)S * S;
     const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
+    // (one exponential per eigenvalue, not per entry: S instead of S x S of them — 3 721 at 61 states — the same values)
+    double* ek = sh + (size_t)S * S;
+    if (!complexEigen) {
+        for (int k = threadIdx.x; k < S; k += blockDim.x) ek[k] = exp(dist * lam[k]);
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
         const int k = e / S;
-        sh[e] = complexEigen ? iexpEntry(Ui, lam, S, k, e - k * S, dist, 1) : Ui[e] * exp(dist * lam[k]);
+        sh[e] = complexEigen ? iexpEntry(Ui, lam, S, k, e - k * S, dist, 1) : Ui[e] * ek[k];
     }
     __syncthreads();
     double* M = matrices + ((size_t)dIdx[u] * C + c) * S * S;
@@ -233,12 +239,12 @@ void launchTransitionMatrices(hipStream_t stream, double* matrices, const double
         return;
     }
     const int threads = S * S >= 256 ? 256 : 64;
-    if ((size_t)S * S * sizeof(double) > 64 * 1024) {      // more than 90 states: exp(lambda t) per eigenvalue in LDS, not the S x S product
+    if (((size_t)S * S + S) * sizeof(double) > 64 * 1024) {      // more than 90 states: exp(lambda t) per eigenvalue in LDS, not the S x S product
         hipLaunchKernelGGL(k_transitionBig, dim3(count, C), dim3(256), (size_t)3 * S * sizeof(double), stream,
                            matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
         return;
     }
-    hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), (size_t)S * S * sizeof(double), stream,
+    hipLaunchKernelGGL(k_transition, dim3(count, C), dim3(threads), ((size_t)S * S + S) * sizeof(double), stream,
                        matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
 }
 

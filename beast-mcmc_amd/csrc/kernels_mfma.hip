@@ -944,34 +944,42 @@ __global__ __launch_bounds__(256) void k_rootSiteTiled(const double* __restrict_
                                                        const double* __restrict__ freqs, const double* __restrict__ cum, int cumIsRaw,
                                                        const double* __restrict__ patternWeights, double* __restrict__ siteLogL,
                                                        double* __restrict__ blockSums, int P, int S, int C, int pStart, int pEnd) {
-    __shared__ double sh[4];
-    const int p = pStart + blockIdx.x * 256 + threadIdx.x;
+    // a workgroup = 64 patterns; wave w takes the states i = w, w + 4, ... of every category (a thread used to walk all C x S
+    // entries of its pattern alone: 244 dependent loads at 61 states, 79 workgroups for 20 000 patterns — 106 us for 39 MB)
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = pStart + blockIdx.x * 64 + lane;
     const int ntile = (P + TILE - 1) / TILE;
-    double contrib = 0.0;
+    double sum = 0.0;
     if (p < pEnd) {
         const int tile = p / TILE, q = p - tile * TILE;
-        double sum = 0.0;
         for (int c = 0; c < C; c++) {
             const double* r = root + ((size_t)c * ntile + tile) * S * TILE + q;
             double s = 0.0;
-            for (int i = 0; i < S; i++) s += freqs[i] * r[(size_t)i * TILE];
+            for (int i = w; i < S; i += 4) s += freqs[i] * r[(size_t)i * TILE];
             sum += catWeights[c] * s;
         }
-        double site = log(sum);
+    }
+    part[w][lane] = sum;
+    __syncthreads();
+    if (w) return;
+    double contrib = 0.0;
+    if (p < pEnd) {
+        double site = log((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
         if (cum) site += cumIsRaw ? log(cum[p]) : cum[p];
         siteLogL[p] = site;
         contrib = site * patternWeights[p];
     }
     for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = contrib;
-    __syncthreads();
-    if (threadIdx.x == 0) blockSums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (lane == 0) blockSums[blockIdx.x] = contrib;
 }
+
+int rootSiteTiledBlocks(int patterns) { return (patterns + 63) / 64; }
 
 void launchRootSiteTiled(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                          const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                          double* blockSums, int P, int S, int C, int pStart, int pEnd) {
-    const int n = (pEnd - pStart + 255) / 256;
+    const int n = rootSiteTiledBlocks(pEnd - pStart);
     hipLaunchKernelGGL(k_rootSiteTiled, dim3(n), dim3(256), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
                        patternWeights, siteLogL, blockSums, P, S, C, pStart, pEnd);
 }

@@ -316,7 +316,7 @@ def test_gradient_corner_shapes_on_the_matrix_cores(oracle_lib):
                 g = BranchGradient(wl, rescale=rescale, double_buffer=True)
                 o = BranchGradient(wl, rescale=rescale, double_buffer=True, library=oracle_lib)
                 (lg, gg), (lo, go) = g.gradient(), o.gradient()
-                assert helpers.rel_err(lg, lo) <= REL_TOL, (S, C, T, P, rescale)
+                close(lg, lo, "lnL S=%d C=%d T=%d P=%d rescale=%s" % (S, C, T, P, rescale))      # (two taxa, one pattern: lnL ~ -1e-15)
                 close(gg, go, "S=%d C=%d T=%d P=%d rescale=%s" % (S, C, T, P, rescale))
                 lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
                 lo, go, ho, po = o.gradient(second=True, per_pattern=True)
