@@ -47,18 +47,46 @@ class ShardedTreeLikelihood:
             raw = _b.Beagle.__new__(_b.Beagle)
             raw.lib, raw._f, raw.instance = self.local.engine, self.local.engine.fn, self.local.instance
             ok = 1
-            try:
-                if dist is not None and world_size > 1:
-                    ident = torch.zeros(128, dtype=torch.uint8, device=device)
-                    if rank == 0:
-                        ident.copy_(torch.frombuffer(bytearray(raw.commUniqueId()), dtype=torch.uint8))
-                    dist.broadcast(ident, src=0)
-                    unique = bytes(ident.cpu().numpy().tobytes())
+            unique = None
+            if dist is not None and world_size > 1:
+                # rank 0's id travels with a validity byte: a rank 0 that cannot produce one still takes part in the broadcast,
+                # and every rank then skips the communicator together instead of waiting for it
+                ident = torch.zeros(129, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    try:
+                        host = bytearray(raw.commUniqueId()) + bytearray([1])
+                        ident.copy_(torch.frombuffer(host, dtype=torch.uint8))
+                    except Exception:                 # noqa: BLE001
+                        pass
+                dist.broadcast(ident, src=0)
+                got = bytes(ident.cpu().numpy().tobytes())
+                if got[128] == 1:
+                    unique = got[:128]
                 else:
+                    ok = 0
+            else:
+                try:
                     unique = raw.commUniqueId()
-                raw.commInit(unique, rank, world_size)
-            except Exception:                         # noqa: BLE001  (decided together below)
-                ok = 0
+                except Exception:                     # noqa: BLE001
+                    ok = 0
+            if ok:
+                # ncclCommInitRank is a rendezvous of all ranks: it runs on a helper thread with a deadline, so that a rank whose
+                # peers never arrive falls back to the torch.distributed collective (with everybody else: the MIN below)
+                # instead of sitting in it for ever; BEAGLE_MI355_COMM_INIT_TIMEOUT_S, default 120
+                import os
+                import threading
+                state = {"ok": 0}
+
+                def _init():
+                    try:
+                        raw.commInit(unique, rank, world_size)
+                        state["ok"] = 1
+                    except Exception:                 # noqa: BLE001  (decided together below)
+                        state["ok"] = 0
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("BEAGLE_MI355_COMM_INIT_TIMEOUT_S", "120")))
+                ok = 0 if th.is_alive() else state["ok"]
             if dist is not None and world_size > 1:   # every rank takes the same route: all of them have a communicator, or none uses it
                 flag = torch.tensor([ok], dtype=torch.int32, device=device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
