@@ -124,7 +124,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -469,6 +469,12 @@ class Beagle:
         """updatePartials calls the kernel timer bracketed since this was last asked (kernelTimer(N > 1) samples every N-th)."""
         n = C.c_long(0)
         self._check("kernelTimerCalls", self._ext("beagleMi355KernelTimerCalls", [C.c_int, C.POINTER(C.c_long)])(self.instance, C.byref(n)))
+        return n.value
+
+    def rootFusedCount(self):
+        """calculateRootLogLikelihoods calls answered inside the walk's launch (include/beagle_mi355.h beagleMi355RootFusedCount)."""
+        n = C.c_long(0)
+        self._check("rootFusedCount", self._ext("beagleMi355RootFusedCount", [C.c_int, C.POINTER(C.c_long)])(self.instance, C.byref(n)))
         return n.value
 
     def getPartialsBatch(self, bufferIndices, scaleIndices=None):

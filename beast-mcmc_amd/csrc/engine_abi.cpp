@@ -52,11 +52,29 @@ int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int p
         int rc = ensureScale(in, cumIdx); if (rc) return rc;
         cum = in->scale[cumIdx]; cumRaw = in->scaleIsRaw[cumIdx];
     }
+    if (in->pendingWalk.valid && part < 0 && !in->tiled) {
+        // the walk that computes this root is still held back: launch it with the root's slice finishing the evaluation
+        const Instance::PendingWalk& pw = in->pendingWalk;
+        int seg = -1;
+        for (size_t i = 0; i < pw.finalStore.size(); i++) if (pw.finalStore[i] == rootIdx) seg = (int)i;
+        if (seg >= 0) {
+            mi355::RootFused rf;
+            memset(&rf, 0, sizeof(rf));
+            rf.catWeights = in->weights + (size_t)wIdx * in->C; rf.freqs = in->freqs + (size_t)fIdx * in->S; rf.cum = cum; rf.cumIsRaw = cumRaw;
+            rf.patternWeights = in->patternWeights; rf.siteLogL = in->siteLogL; rf.blockSums = in->blockSums; rf.counter = in->rootCounter;
+            rf.out = dOut; rf.flag = flag; rf.seq = seq; rf.rootSeg = seg; rf.groups = (in->P + 127) / 128;
+            return flushWalk(in, &rf);
+        }
+    }
     if (in->tiled) {
         mi355::launchRootSiteTiled(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                    in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
                                    in->blockSums, in->P, in->S, in->C, pStart, pEnd);
         mi355::launchRootFinal(live(in), in->blockSums, mi355::rootSiteTiledBlocks(pEnd - pStart), dOut, flag, seq);
+    } else if (in->walk && in->fuseLaunches) {
+        mi355::launchRootLogLikelihood4W(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
+                                         in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
+                                         in->blockSums, dOut, in->P, in->C, pStart, pEnd, flag, seq, in->rootCounter);
     } else {
         mi355::launchRootLogLikelihood(live(in), in->partials[rootIdx], in->weights + (size_t)wIdx * in->C,
                                        in->freqs + (size_t)fIdx * in->S, cum, cumRaw, in->patternWeights, in->siteLogL,
@@ -135,7 +153,7 @@ int publishAndWait(int instance, const double* dValues, int count, double* out) 
     mi355::launchPublish(live(in), dValues, count, in->hResultDev + 16, (unsigned long long*)(in->hResultDev + 8), seq);
     HIP_TRY(hipGetLastError());
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     memcpy(out, in->hResult + 16, (size_t)count * sizeof(double));
     return BEAGLE_SUCCESS;
 }
@@ -326,6 +344,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseGradient = !(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT") && atoi(getenv("BEAGLE_MI355_NO_FUSED_GRADIENT")) != 0);
     in->preWalk = !(getenv("BEAGLE_MI355_NO_PRE_WALK") && atoi(getenv("BEAGLE_MI355_NO_PRE_WALK")) != 0);
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
+    in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
@@ -656,7 +675,7 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
     }
     const int last = (int)((nChunks - 1) & 1);
     HIP_TRY(hipEventSynchronize(in->exportEvent[last]));
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     if (out) copies[last].start((char*)(out + (nChunks - 1) * chunk * elems), (const char*)in->exportHost[last], chunkCount(nChunks - 1) * bytes);
     copies[0].join(); copies[1].join();
     return BEAGLE_SUCCESS;
@@ -761,14 +780,20 @@ int beagleSetStateFrequencies(int instance, int idx, const double* f) {
     if (mi355::isShardedHandle(instance)) { std::vector<double> v(f, f + shardedStates(instance)); return mi355::shardedPost(instance, [=](int h) { return beagleSetStateFrequencies(h, idx, v.data()); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    return uploadIfChanged(in, in->shFreqs, in->okFreqs, in->eigenCount, idx, in->S, in->freqs + (size_t)idx * in->S, f);
+    in->copyKeepsWalk = true;                            // (the root's input, not the walk's: a held launch stays held)
+    const int rc = uploadIfChanged(in, in->shFreqs, in->okFreqs, in->eigenCount, idx, in->S, in->freqs + (size_t)idx * in->S, f);
+    in->copyKeepsWalk = false;
+    return rc;
 }
 
 int beagleSetCategoryWeights(int instance, int idx, const double* w) {
     if (mi355::isShardedHandle(instance)) { std::vector<double> v(w, w + shardedCategories(instance)); return mi355::shardedPost(instance, [=](int h) { return beagleSetCategoryWeights(h, idx, v.data()); }); }
     GET_INSTANCE(instance);
     if (badIndex(idx, in->eigenCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-    return uploadIfChanged(in, in->shWeights, in->okWeights, in->eigenCount, idx, in->C, in->weights + (size_t)idx * in->C, w);
+    in->copyKeepsWalk = true;
+    const int rc = uploadIfChanged(in, in->shWeights, in->okWeights, in->eigenCount, idx, in->C, in->weights + (size_t)idx * in->C, w);
+    in->copyKeepsWalk = false;
+    return rc;
 }
 
 int beagleSetCategoryRatesWithIndex(int instance, int idx, const double* r) {
@@ -975,7 +1000,7 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
     (void)destinationPartials; (void)count;
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1070,7 +1095,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
                          cumulativeScaleIndices[0], -1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     if (rc) return rc;
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (in->pendingCopies.empty()) in->ringHead = 0;   // everything staged so far has been consumed
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;   // everything staged so far has been consumed
     const double v = in->hResult[0];
     *outSumLogLikelihood = v;
     return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
@@ -1132,7 +1157,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
         if (*flag != seq) HIP_TRY(hipStreamSynchronize(live(in)));
         if (*flag != seq) return BEAGLE_ERROR_GENERAL;
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (in->pendingCopies.empty()) in->ringHead = 0;
+        if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
         double tot = 0.0;
         for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[16 + k]; tot += in->hResult[16 + k]; }
         *outSum = tot;
@@ -1265,7 +1290,7 @@ int beagleMi355SetStream(int instance, void* hipStream) {
     if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     in->stream = hipStream ? (hipStream_t)hipStream : in->ownStream;
     return BEAGLE_SUCCESS;
 }
@@ -1318,7 +1343,7 @@ int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferInde
     mi355::launchRootFinal(live(in), in->dResult, 1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     HIP_TRY(hipGetLastError());
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     const double v = in->hResult[0];
     *outGlobalSum = v;
     return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
@@ -1328,7 +1353,7 @@ int beagleMi355Synchronize(int instance) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355Synchronize(h); }); }
     GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list is not work in flight)
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1343,7 +1368,7 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (in->pendingCopies.empty()) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     for (size_t k = 0; k < in->eventsUsed; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) in->timedMs += ms;
@@ -1398,6 +1423,17 @@ int beagleMi355KernelTimerCalls(int instance, long* outCalls) {
     if (!in || !outCalls) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     *outCalls = in->timedCalls;
     in->timedCalls = 0;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355RootFusedCount(int instance, long* outCount) {
+    if (mi355::isShardedHandle(instance)) {
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355RootFusedCount(h, outCount); });
+    }
+    Instance* in = lookup(instance);
+    if (!in || !outCount) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    *outCount = in->statRootFused;
     return BEAGLE_SUCCESS;
 }
 

@@ -61,6 +61,9 @@ int uploadTransient(Instance* in, const void* src, size_t bytes, void** dptr) {
 
 int queueCopy(Instance* in, void* dst, size_t off, size_t bytes) {
     if (bytes == 0) return 0;
+    // a walk whose launch is held back must not see what the caller uploads after its updatePartials: it goes first — except for
+    // the root's own inputs (category weights, state frequencies: the reference sets them between updatePartials and the root call)
+    if (in->pendingWalk.valid && !in->copyKeepsWalk) { const int rcw = flushWalk(in); if (rcw) return rcw; }
     if (!in->kernelUploads) {
         HIP_TRY(hipMemcpyAsync(dst, in->hRing + off, bytes, hipMemcpyHostToDevice, in->stream));
         return 0;
@@ -98,7 +101,7 @@ int flushUploads(Instance* in) {
 int download(Instance* in, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, live(in)));
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (in->pendingCopies.empty()) in->ringHead = 0;   // everything staged so far has been consumed
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;   // everything staged so far has been consumed
     return 0;
 }
 

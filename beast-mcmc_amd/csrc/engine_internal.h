@@ -108,6 +108,18 @@ struct Instance {
     // k_walkT32: same planner, same descriptors; engine_walk.cpp); everything 4-state-specific (`walk`) stays off
     bool walkT = false;
     bool fuseLaunches = true;                            // BEAGLE_MI355_NO_LAUNCH_FUSION=1: snapshot / gather and root site / final as separate launches (A/B runs)
+    // A one-launch walk whose launch is held back until the next call: calculateRootLogLikelihoods on the result of one of its
+    // slices launches it WITH that slice finishing the evaluation (no root kernel, no read-back of the root's partials); any other
+    // call launches it as it is (live()).  Only full-range walks of unpartitioned instances outside a timer bracket are held.
+    struct PendingWalk {
+        bool valid = false;
+        const mi355::WalkOp* prog = nullptr; const mi355::WalkSeg* segs = nullptr; const int* deps = nullptr;
+        int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
+        std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
+    } pendingWalk;
+    bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back
+    bool copyKeepsWalk = false;                          // (set around an upload the held walk does not read: engine_instance.cpp queueCopy)
+    long statRootFused = 0;
     unsigned* rootCounter = nullptr;                     // device word of k_rootSite's last-workgroup sum (kernels.hip)
     double* cherryTables = nullptr; size_t cherryTableBytes = 0;   // 21..64 states: column tables of a list's virtual cherries (grow-only)
     int holdSlots = 3;                                   // what the planner was given
@@ -206,7 +218,13 @@ int ensureWalkDummies(Instance* in);
 // the instance's stream, with everything queued in pendingCopies enqueued on it first: what every launch, copy and
 // synchronisation of the engine passes as its stream (only flushUploads itself and the stream setters touch in->stream)
 int flushUploads(Instance* in);
-inline hipStream_t live(Instance* in) { if (!in->pendingCopies.empty()) flushUploads(in); return in->stream; }
+// ... and a walk launch that is being held back for the root call (PendingWalk, engine_walk.cpp) launched behind them
+int flushWalk(Instance* in, const mi355::RootFused* root = nullptr);
+inline hipStream_t live(Instance* in) {
+    if (!in->pendingCopies.empty()) flushUploads(in);
+    if (in->pendingWalk.valid) flushWalk(in);
+    return in->stream;
+}
 // queue `bytes` already staged at ring offset `off` for device address dst (or copy them now: kernelUploads off)
 int queueCopy(Instance* in, void* dst, size_t off, size_t bytes);
 

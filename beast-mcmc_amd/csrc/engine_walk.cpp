@@ -245,11 +245,25 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             in->walkFlagBytes = want;
         }
         if (++in->walkEpoch == 0u) in->walkEpoch = 1u;
-        mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes), (int)segs.size(), range,
-                               in->matStream, in->P, in->C, (long)in->scaleStride, (const int*)(dBase + depOff), in->walkFlags, in->walkEpoch, flagStride);
+        Instance::PendingWalk& pw = in->pendingWalk;
+        if (pw.valid) { int rcf = flushWalk(in); if (rcf) return rcf; }            // (cannot happen: every path here went through live())
+        pw.prog = (const mi355::WalkOp*)dBase; pw.segs = (const mi355::WalkSeg*)(dBase + opBytes); pw.deps = (const int*)(dBase + depOff);
+        pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch;
         in->statFastWalks++; in->statWalks++;
-        HIP_TRY(hipGetLastError());
-        return 0;
+        // hold the launch back for the root call?  (one partition, the whole range, not inside a timer bracket)
+        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P;
+        if (hold) {
+            pw.finalStore.assign(segs.size(), -1);
+            for (size_t i = 0; i < segs.size(); i++) {
+                const mi355::PlanSeg& ps = plan.segs[(size_t)plan.launchOrder[i]];
+                if (ps.progCount > 0) pw.finalStore[i] = plan.prog[(size_t)ps.progStart + ps.progCount - 1].storeBuf;
+            }
+            (void)live(in);                           // the program's copies and the gather are enqueued; only the walk itself waits
+            pw.valid = true;
+            return 0;
+        }
+        pw.valid = true;
+        return flushWalk(in);
     }
     // one launch per wave of independent slices (a single one unless the planner cut the forest for a small shard)
     for (size_t b = 0; b < segs.size();) {
@@ -271,6 +285,19 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->statWalks++;
         b = e;
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Launch the walk that was held back (engine_internal.h PendingWalk) — as it is, or with the slice `root` names finishing the evaluation.
+int flushWalk(Instance* in, const mi355::RootFused* root) {
+    Instance::PendingWalk& pw = in->pendingWalk;
+    if (!pw.valid) return 0;
+    pw.valid = false;                                  // (before anything that could come back here through live())
+    if (!in->pendingCopies.empty()) { int rc = flushUploads(in); if (rc) return rc; }
+    mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
+                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root);
+    if (root) in->statRootFused++;
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -131,8 +131,20 @@ void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, 
 // deps / flags / epoch / flagStride: all slices of a program in ONE launch (slice y is dispatched before y + 1): a workgroup first
 // waits until flags[d * flagStride + x] == epoch for every slice d of its dependency list, and sets flags[y * flagStride + x] =
 // epoch when its results are out.  flags == nullptr: no waiting, no signalling (one launch per wave of independent slices).
+// what the walk's root slice needs to finish the evaluation itself (kernels_walk4.hip, root_site4.h; rootSeg < 0: nothing)
+struct RootFused {
+    const double* catWeights; const double* freqs; const double* cum; const double* patternWeights;
+    double* siteLogL; double* blockSums; unsigned* counter; double* out; unsigned long long* flag; unsigned long long seq;
+    int cumIsRaw; int rootSeg; int groups; int pad;
+};
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
-                     long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0);
+                     long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
+                     const RootFused* root = nullptr);
+// 4-state walk instances: the root integration as a launch of its own, bit-compatible with the walk's root epilogue (root_site4.h)
+void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
+                               const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
+                               double* blockSums, double* out, int P, int C, int pStart, int pEnd,
+                               unsigned long long* flag, unsigned long long seq, unsigned* counter);
 
 // matrices[dst[k]] = matrices[src[k]] for k < n (each C*S*S doubles): private snapshots of branch matrices
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems);

@@ -18,6 +18,7 @@
 //                               lib/beagle.jar!beagle/GeneralBeagleImpl#updateTransitionMatrices
 //   k_accumulate                AbstractLikelihoodCore.java:442-458 as a persistent cumulative buffer
 #include "kernels.h"
+#include "root_site4.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
@@ -502,6 +503,38 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinal(const double* __restri
     }
 }
 
+// 4-state walk instances (root_site4.h): a wave per 128 patterns with the assembly loop's lane map, so that this launch and the
+// epilogue of the walk's root slice (kernels_walk4.hip) give the same bits
+__global__ __launch_bounds__(256) void k_rootSite4W(const double* __restrict__ root, const double* __restrict__ catWeights,
+                                                    const double* __restrict__ freqs, const double* __restrict__ cum, int cumIsRaw,
+                                                    const double* __restrict__ patternWeights, double* __restrict__ siteLogL,
+                                                    double* __restrict__ blockSums, int P, int C, int pStart, int pEnd, int groups,
+                                                    unsigned* counter, double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
+    const int lane = threadIdx.x & 63, group = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (group >= groups) return;
+    const int p0 = pStart + group * 128, q = lane >> 1, r = lane & 1;
+    const int pa = p0 + q + 32 * r, pb = pa + 64;
+    const int la = pa < pEnd ? pa : pEnd - 1, lb = pb < pEnd ? pb : pEnd - 1;
+    double sumA = 0.0, sumB = 0.0;
+    for (int c = 0; c < C; c++) {
+        const d4 a = *reinterpret_cast<const d4*>(root + ((size_t)c * P + la) * 4);
+        const d4 b = *reinterpret_cast<const d4*>(root + ((size_t)c * P + lb) * 4);
+        sumA = __builtin_fma(catWeights[c], rootDot4(freqs, a.x, a.y, a.z, a.w), sumA);
+        sumB = __builtin_fma(catWeights[c], rootDot4(freqs, b.x, b.y, b.z, b.w), sumB);
+    }
+    const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, pEnd, cum, cumIsRaw, patternWeights, siteLogL));
+    rootPublishGroup(g, lane, group, groups, blockSums, counter, out, flag, seq);
+}
+
+void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
+                               const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
+                               double* blockSums, double* out, int P, int C, int pStart, int pEnd,
+                               unsigned long long* flag, unsigned long long seq, unsigned* counter) {
+    const int groups = (pEnd - pStart + 127) / 128;
+    hipLaunchKernelGGL(k_rootSite4W, dim3((groups + 3) / 4), dim3(256), 0, stream, root, catWeights, freqs, cum, cumIsRaw,
+                       patternWeights, siteLogL, blockSums, P, C, pStart, pEnd, groups, counter, out, flag, seq);
+}
+
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                              double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,
@@ -524,8 +557,12 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSiteParts(const RootParts pa
         for (int c = 0; c < C; c++) {
             const double* r = q.root + ((size_t)c * P + p) * S;
             double s = 0.0;
-            if (S == 4) { const d4 v = *reinterpret_cast<const d4*>(r); s = q.freqs[0] * v.x + q.freqs[1] * v.y + q.freqs[2] * v.z + q.freqs[3] * v.w; }
-            else for (int i = 0; i < S; i++) s += q.freqs[i] * r[i];
+            if (S == 4) {           // (the multiply-adds of root_site4.h: a site value has the same bits whichever kernel formed it)
+                const d4 v = *reinterpret_cast<const d4*>(r);
+                sum = __builtin_fma(q.catWeights[c], rootDot4(q.freqs, v.x, v.y, v.z, v.w), sum);
+                continue;
+            }
+            for (int i = 0; i < S; i++) s += q.freqs[i] * r[i];
             sum += q.catWeights[c] * s;
         }
         double site = log(sum);

@@ -40,7 +40,9 @@
 // Arithmetic restated from src/dr/oldevomodel/treelikelihood/NucleotideLikelihoodCore.java:54-270 /
 // GeneralLikelihoodCore.java:52-203; rescaling AbstractLikelihoodCore.java:406-440 applied unconditionally.
 #include "kernels.h"
+#include "root_site4.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace mi355 {
 
@@ -375,7 +377,8 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
-                                                             const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride) {
+                                                             const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
+                                                             const RootFused rootArgs) {
     extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[3][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
     const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
@@ -414,10 +417,35 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         if (c == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
             __hip_atomic_store(flags + (size_t)blockIdx.y * flagStride + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The slice that ends at the root finishes the evaluation (engine_walk.cpp PendingWalk: the launch was held back until
+    // calculateRootLogLikelihoods named this slice's last result as the root): every wave's last result sits in hold slot 0
+    // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
+    // categories up in order, takes the logarithm and folds the group's 128 site values; the last group adds the groups' sums.
+    // Same functions, same order, same bits as the launch of its own (kernels.hip k_rootSite4W).
+    if (rootArgs.rootSeg == (int)blockIdx.y) {
+        const int lane = (int)(threadIdx.x & 63);
+        const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
+        const double sa = rootDot4(rootArgs.freqs, h[0], h[1], h[128], h[129]);
+        const double sb = rootDot4(rootArgs.freqs, h[256], h[257], h[384], h[385]);
+        double* exch = reinterpret_cast<double*>(lds) + (size_t)C * 512;                                      // hold slot 1: free at the end of a program
+        exch[(size_t)c * 128 + lane * 2] = sa;
+        exch[(size_t)c * 128 + lane * 2 + 1] = sb;
+        __syncthreads();
+        if (c == 0) {
+            double sumA = 0.0, sumB = 0.0;
+            for (int cc = 0; cc < C; cc++) {
+                sumA = __builtin_fma(rootArgs.catWeights[cc], exch[(size_t)cc * 128 + lane * 2], sumA);
+                sumB = __builtin_fma(rootArgs.catWeights[cc], exch[(size_t)cc * 128 + lane * 2 + 1], sumB);
+            }
+            const int pa = p0 + (lane >> 1) + 32 * (lane & 1), pb = pa + 64;
+            const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, pEnd, rootArgs.cum, rootArgs.cumIsRaw, rootArgs.patternWeights, rootArgs.siteLogL));
+            rootPublishGroup(g, lane, (int)blockIdx.x, rootArgs.groups, rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
+        }
+    }
 }
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
-                     long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride) {
+                     long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root) {
     if (nSegs <= 0 || maxRange <= 0) return;
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
@@ -433,12 +461,16 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;
     const v2d MI355_CONST* ms = (const v2d MI355_CONST*)dStream;
     const int MI355_CONST* deps = (const int MI355_CONST*)dDeps;
+    RootFused ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.rootSeg = -1;
+    if (root) ra = *root;
     if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

@@ -337,6 +337,11 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
  * an evaluation): milliseconds and launches then cover those calls; beagleMi355KernelTimerCalls returns how many updatePartials
  * calls were bracketed since it was last asked (and resets the count) — the divisor for "kernel time per evaluation". */
 int beagleMi355KernelTimerCalls(int instance, long* outCalls);
+/* How many calculateRootLogLikelihoods calls of this instance (shard 0 of a sharded handle) were answered by the pattern walk itself —
+ * a one-launch walk of an unpartitioned 4-state instance is held back until the next call, and when that call asks for the root
+ * log-likelihood of the walk's last result the slice that computes it finishes the evaluation (no root kernel, no read-back of
+ * the root's partials).  BEAGLE_MI355_NO_ROOT_FUSION=1 switches the holding off.  Since instance creation. */
+int beagleMi355RootFusedCount(int instance, long* outCount);
 /* Forget what the (enabled) kernel timer and the walk counters have gathered so far — no synchronisation, no allocation: for a
  * caller that has just synchronised the stream itself and wants the measurement to start here (bench.py: between its warm-up
  * and its timed steps, without giving the device an idle gap to drop its clocks in). */

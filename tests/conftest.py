@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may sit for ever (a loop that never ends costs GPU-box minutes by the thousand): ten minutes each, where the
+    pytest-timeout plugin is installed."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _native_libraries():
     """Build what is missing (the GPU box receives prebuilt .so files; the build container builds)."""

@@ -553,6 +553,10 @@ def build():
         for l in blk:
             e(l)
     e(L("end") + ":")
+    # the last result also goes to LDS hold slot 0 (nothing is parked at the end of a program): the root slice's epilogue finishes
+    # the evaluation from there (kernels_walk4.hip, root_site4.h) instead of a launch that reads the root's partials back
+    for q in range(4):
+        e("ds_write_b128 %s, %s offset:%d" % (v(HOLD), v(ACC + 4 * q, 4), 1024 * q))
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
