@@ -24,10 +24,10 @@ for p in 50000 25000 12500; do
   timeout 300 python bench.py --patterns $p --force-sharded --steps 200 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard${p}_sharded_path.json; line gpurun_out/profiles_final/${R}_bench_A_shard${p}_sharded_path.json "A shard $p (sharded path)"
 done
 # gradients (secondary): 4 states at 20 000 and 1e5 patterns, 20 and 61 states at their configs' sizes
-timeout 300 python tools/gradient_bench.py --config A --patterns 20000 --steps 10 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench.json
-timeout 300 python tools/gradient_bench.py --config A --steps 5 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5.json
-timeout 600 python tools/gradient_bench.py --config B --steps 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_B.json
-timeout 600 python tools/gradient_bench.py --config C --steps 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_C.json
+timeout 300 python tools/gradient_bench.py --config A --patterns 20000 --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench.json
+timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5.json
+timeout 600 python tools/gradient_bench.py --config B --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_B.json
+timeout 600 python tools/gradient_bench.py --config C --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_C.json
 for g in "" _1e5 _B _C; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, roofline frac', d['roofline']['frac'], d['how'])" 2>&1 | tail -1; done
 timeout 300 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_btl.json; line gpurun_out/profiles_final/${R}_bench_A_btl.json "A btl"
 timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5 --no-cpu-baseline --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_always.json; line gpurun_out/profiles_final/${R}_bench_A_always.json "A always"
