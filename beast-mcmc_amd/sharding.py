@@ -34,7 +34,11 @@ class ShardedTreeLikelihood:
     def __init__(self, workload, rank, world_size, dist=None, device=None, library=None, collective=None, **kw):
         self.rank, self.world = rank, world_size
         self.dist = dist
-        self.collective = collective or ("engine" if device is not None else "torch")
+        import os
+        # (BEAGLE_MI355_COLLECTIVE=torch|engine: an operator's override of the default route on a GPU)
+        self.collective = collective or os.environ.get("BEAGLE_MI355_COLLECTIVE") or ("engine" if device is not None else "torch")
+        if self.collective not in ("engine", "torch") or device is None:
+            self.collective = "torch" if device is None else ("engine" if self.collective == "engine" else "torch")
         start, stop = _patterns.shard_bounds(workload.pattern_count, world_size)[rank]
         self.range = (start, stop)
         self.local = BeagleTreeLikelihood(workload.shard(start, stop), library=library, **kw)
