@@ -285,20 +285,22 @@ static void fill_iexp(const Inst* in, const double* Ui, const double* lam, doubl
 /* BaseSubstitutionModel.java:206-245 (iexp, then U * iexp);
  * GeneralBeagleImpl#updateTransitionMatrices applies the category rate to t and clamps negatives (ComplexSubstitutionModel
  * takes the absolute value instead, :184 — the two differ only where rounding leaves a tiny negative entry). */
-int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, const int* d1, const int* d2,
-                                          const double* t, int count) {
-    (void)d1; (void)d2;
-    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
-    if (e < 0 || e >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+/* eIdx / rIdx: one eigen system and one category-rate set for all matrices (eAll, rate set 0: updateTransitionMatrices), or one of
+ * each per matrix (updateTransitionMatricesWithMultipleModels, MultiPartitionDataLikelihoodDelegate.java:880-887) */
+static int transition_matrices(Inst* in, int eAll, const int* eIdx, const int* rIdx, const int* probIdx, const double* t, int count) {
     const int S = in->S;
-    const double* U = in->eigU[e]; const double* Ui = in->eigUinv[e]; const double* lam = in->eigLambda[e];
-    for (int u = 0; u < count; u++) if (probIdx[u] < 0 || probIdx[u] >= in->matrixCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    for (int u = 0; u < count; u++) {
+        const int e = eIdx ? eIdx[u] : eAll, r = rIdx ? rIdx[u] : 0;
+        if (probIdx[u] < 0 || probIdx[u] >= in->matrixCount || e < 0 || e >= in->eigenCount || r < 0 || r >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    }
     #pragma omp parallel for schedule(static)
     for (int u = 0; u < count; u++) {
+        const int e = eIdx ? eIdx[u] : eAll, r = rIdx ? rIdx[u] : 0;
+        const double* U = in->eigU[e]; const double* Ui = in->eigUinv[e]; const double* lam = in->eigLambda[e];
         double* iexp = (double*)malloc(sizeof(double) * S * S);
         double* M = in->matrices[probIdx[u]];
         for (int c = 0; c < in->C; c++) {
-            double dist = t[u] * in->catRates[0][c];
+            double dist = t[u] * in->catRates[r][c];
             fill_iexp(in, Ui, lam, dist, iexp);
             for (int i = 0; i < S; i++)
                 for (int j = 0; j < S; j++) {
@@ -310,6 +312,29 @@ int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, cons
         free(iexp);
     }
     return BEAGLE_SUCCESS;
+}
+int oracle_beagleUpdateTransitionMatrices(int h, int e, const int* probIdx, const int* d1, const int* d2,
+                                          const double* t, int count) {
+    (void)d1; (void)d2;
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (e < 0 || e >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return transition_matrices(in, e, NULL, NULL, probIdx, t, count);
+}
+/* beagle.jar!GeneralBeagleImpl#updateTransitionMatricesWithMultipleModels — what MultiPartitionDataLikelihoodDelegate.java:880-887
+ * issues once per evaluation for all partitions' branches; the pattern-partition calls themselves (setPatternPartitions,
+ * ...ByPartition) are NOT restated here: a partitioned instance is checked against one oracle instance per partition. */
+int oracle_beagleUpdateTransitionMatricesWithMultipleModels(int h, const int* eIdx, const int* rIdx, const int* probIdx, const int* d1,
+                                                            const int* d2, const double* t, int count) {
+    (void)d1; (void)d2;
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (!eIdx || !rIdx) return BEAGLE_ERROR_OUT_OF_RANGE;
+    return transition_matrices(in, 0, eIdx, rIdx, probIdx, t, count);
+}
+/* beagle.jar!GeneralBeagleImpl#setCategoryRatesWithIndex (MultiPartitionDataLikelihoodDelegate.java:835) */
+int oracle_beagleSetCategoryRatesWithIndex(int h, int i, const double* r) {
+    Inst* in = get(h); if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    if (i < 0 || i >= in->eigenCount) return BEAGLE_ERROR_OUT_OF_RANGE;
+    memcpy(in->catRates[i], r, in->C * sizeof(double)); return BEAGLE_SUCCESS;
 }
 
 /* GeneralLikelihoodCore.java:52-107 */
