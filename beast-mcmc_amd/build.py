@@ -3,6 +3,9 @@
   lib/libhmsbeagle-jni.so   HIP engine + C ABI + JNI shim, gfx950 only   (csrc/*.hip, csrc/*.cpp)
   lib/libbeast_host.so      the caller stand-in: BeagleTreeLikelihood's call protocol in C++  (tools/host/tree_likelihood.cpp;
                             harness for tests and bench.py — in production the caller is BEAST's Java)
+  lib/lab/libhmsbeagle-jni.so   (``--lab`` only) the same engine compiled with -DBEAGLE_MI355_LAB: the tuning knobs and timing
+                            experiments of csrc/kernels.h labEnv() — some of which give wrong results by construction — are
+                            connected to the environment ONLY in this build; select it with BEAGLE_MI355_ENGINE_LIB=<path>
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the built
 ``.so`` files travel to the GPU box with the repo snapshot.
@@ -38,19 +41,20 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_engine(force=False):
+def build_engine(force=False, lab=False):
     """Each source is compiled to its own object (in parallel, only when it or a header changed) and the objects are
     linked into the one shared library; the 4-state kernel file alone takes minutes, the rest seconds."""
     from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(LIB, exist_ok=True)
-    obj_dir = os.path.join(LIB, "obj")
+    lib_dir = os.path.join(LIB, "lab") if lab else LIB
+    os.makedirs(lib_dir, exist_ok=True)
+    obj_dir = os.path.join(lib_dir, "obj")
     os.makedirs(obj_dir, exist_ok=True)
-    out = os.path.join(LIB, "libhmsbeagle-jni.so")
+    out = os.path.join(lib_dir, "libhmsbeagle-jni.so")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "beagle_mi355.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DBEAGLE_MI355_BUILD", "-Wall",
-             "-Wno-unused-result", "-Wno-unused-value", "-Wno-cuda-compat"]
+             "-Wno-unused-result", "-Wno-unused-value", "-Wno-cuda-compat"] + (["-DBEAGLE_MI355_LAB"] if lab else [])
     objs, jobs = [], []
     for s in srcs:
         o = os.path.join(obj_dir, os.path.basename(s) + ".o")
@@ -79,4 +83,7 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--lab" in sys.argv:
+        print(build_engine(force="--force" in sys.argv, lab=True))
+    else:
+        build_all(force="--force" in sys.argv)

@@ -3,6 +3,7 @@
 #include "engine_internal.h"
 
 using mi355::OpDesc;
+using mi355::labEnv;
 using mi355::shardedStates;
 using mi355::shardedCategories;
 using namespace mi355::eng;
@@ -304,8 +305,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // tip-tip nodes with read-heavy ones), as early as possible above (61 states: 214 -> 226 evals/s, profiles/r03_experiments.txt 11);
     // BEAGLE_MI355_SCHED=asap|alap overrides
     in->schedAlap = stateCount <= 20;
-    if (getenv("BEAGLE_MI355_SCHED")) {
-        const char* sc = getenv("BEAGLE_MI355_SCHED");
+    if (labEnv("BEAGLE_MI355_SCHED")) {              // (LAB builds only: dfs is twice as slow, profiles/r04_experiments.txt 10)
+        const char* sc = labEnv("BEAGLE_MI355_SCHED");
         in->schedAlap = strcmp(sc, "asap") != 0;
         if (strncmp(sc, "dfs", 3) == 0) in->schedDfs = sc[3] == ':' ? std::max(1, atoi(sc + 4)) : 4;
     }
@@ -332,11 +333,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // 32 C P bytes each — costs 139 / 141 / 162 us at 16 / 24 / 32.  Small alignments are latency-bound: there the extra
     // micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us from cap 8 to 16).
     int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 24 : 8;
-    if (getenv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(getenv("BEAGLE_MI355_VSTEPS"))));
+    if (labEnv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(labEnv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;
     // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
     in->holdSlots = in->walkT ? 2 : mi355::walkHoldSlots(categoryCount);
-    if (getenv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(getenv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
+    if (labEnv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(labEnv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn, in->holdSlots);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);
@@ -345,6 +346,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->preWalk = !(getenv("BEAGLE_MI355_NO_PRE_WALK") && atoi(getenv("BEAGLE_MI355_NO_PRE_WALK")) != 0);
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
+    in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;
@@ -367,13 +369,14 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
+    if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {
-        in->planner.chunkTopOps = getenv("BEAGLE_MI355_CHUNK_TOP") ? atoi(getenv("BEAGLE_MI355_CHUNK_TOP")) : 16;
+        in->planner.chunkTopOps = labEnv("BEAGLE_MI355_CHUNK_TOP") ? atoi(labEnv("BEAGLE_MI355_CHUNK_TOP")) : 16;
         // slices the chip holds side by side: 4 workgroups per CU over the pattern groups of a slice (planner.h launchMachines)
         hipDeviceProp_t prop;
         const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         in->planner.launchMachines = (double)(4 * cus) / (double)std::max(1, (patternCount + 127) / 128);
-        if (getenv("BEAGLE_MI355_SCHED_SIM") && atoi(getenv("BEAGLE_MI355_SCHED_SIM")) == 0) in->planner.launchMachines = 0.0;
+        if (labEnv("BEAGLE_MI355_SCHED_SIM") && atoi(labEnv("BEAGLE_MI355_SCHED_SIM")) == 0) in->planner.launchMachines = 0.0;
     }
     // result words live in coherent, device-mapped host memory: the final reduction kernel writes the sum straight into it
     // and the host only waits for the stream (no device-to-host copy behind the last kernel)
@@ -392,6 +395,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && devAlloc(in, (void**)&in->blockSums, ((size_t)rootBlocks + 1024) * sizeof(double)) == 0;    // (+ one partial block per partition)
     ok = ok && devAlloc(in, (void**)&in->dResult, 4096) == 0;
     ok = ok && devAlloc(in, (void**)&in->rootCounter, 256) == 0 && hipMemset(in->rootCounter, 0, 256) == hipSuccess;
+    if (ok) in->walkSelfServed = in->rootCounter + 32;       // (its own 128-byte line of the same allocation)
     if (ok) {
         // defaults: category rates 1, weights 1/C, pattern weights 1 (beagle.jar!GeneralBeagleImpl#<init>)
         std::vector<double> ones(std::max<size_t>((size_t)patternCount, E * C), 1.0);
@@ -485,6 +489,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
     if (in->walk) {
         // the pair-interleaved arrays follow the partitions (Instance::pairPos): what exists already — tips are uploaded before
         // this call, MultiPartitionDataLikelihoodDelegate.java:544-553 — moves to the new layout on the device
+        forgetFolds(in);
         setPairLayout(in);
         if (!in->dPairPos) { int rc = devAlloc(in, (void**)&in->dPairPos, (size_t)in->P * sizeof(unsigned)); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(live(in)));
@@ -1040,7 +1045,7 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
         // a per-node (raw) buffer is being recycled as a cumulative one: clear all of it first
         mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     }
-    if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;    // kept programs were validated against the raw flags
+    if (in->scaleIsRaw[cumulativeScaleIndex]) { in->resolveEpoch++; scalesWritten(in); }    // kept programs were validated against the raw flags
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
     mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, in->partStart[partitionIndex], in->partEnd[partitionIndex]);
     HIP_TRY(hipGetLastError());
@@ -1053,7 +1058,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex) {
     if (badIndex(cumulativeScaleIndex, in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     int rc = materializeScaleUsers(in, cumulativeScaleIndex); if (rc) return rc;
     rc = ensureScale(in, cumulativeScaleIndex); if (rc) return rc;
-    if (in->scaleIsRaw[cumulativeScaleIndex]) in->resolveEpoch++;
+    if (in->scaleIsRaw[cumulativeScaleIndex]) { in->resolveEpoch++; scalesWritten(in); }
     in->scaleIsRaw[cumulativeScaleIndex] = 0;
     mi355::launchFill(live(in), in->scale[cumulativeScaleIndex], 0.0, 0, in->P);
     HIP_TRY(hipGetLastError());
@@ -1071,6 +1076,7 @@ int beagleCopyScaleFactors(int instance, int dest, int src) {
     const size_t scaleDoubles = in->walk ? 2 * in->scaleStride : (size_t)in->P;      // walk instances: factors and reciprocals
     HIP_TRY(hipMemcpyAsync(in->scale[dest], in->scale[src], scaleDoubles * sizeof(double), hipMemcpyDeviceToDevice, live(in)));
     if (in->scaleIsRaw[dest] != in->scaleIsRaw[src]) in->resolveEpoch++;
+    if (in->scaleIsRaw[dest] || in->scaleIsRaw[src]) scalesWritten(in);
     in->scaleIsRaw[dest] = in->scaleIsRaw[src];
     return BEAGLE_SUCCESS;
 }
@@ -1446,6 +1452,19 @@ int beagleMi355WalkStats(int instance, long* out8) {
     if (!in || !out8) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out8[0] = in->statMicroOps; out8[1] = in->statStored; out8[2] = in->statMemReads; out8[3] = in->statTipReads;
     out8[4] = in->statScaleReads; out8[5] = in->statWalks; out8[6] = in->statScaleWrites; out8[7] = in->statFastWalks;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355WalkHealth(int instance, long* out4) {
+    if (mi355::isShardedHandle(instance)) {             // shard 0's
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkHealth(h, out4); });
+    }
+    GET_INSTANCE_KEEP_PENDING(instance);
+    if (!out4) return BEAGLE_ERROR_OUT_OF_RANGE;
+    unsigned served = 0;
+    if (in->walkSelfServed) { int rc = download(in, &served, in->walkSelfServed, sizeof(served)); if (rc) return rc; }
+    out4[0] = (long)served; out4[1] = (long)(in->walkSpinLimit / 100ull); out4[2] = in->statFoldedVectors; out4[3] = in->statFoldBuilds;
     return BEAGLE_SUCCESS;
 }
 

@@ -69,7 +69,26 @@ struct Instance {
         int maxRange = 0;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
+        std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)
+        long foldEpoch = -1;                             // scaleWriteEpoch those vectors were last checked against
+        long noFoldTag = 0;                              // the plan whose folds left the safe range: resolved with per-node factors
     } resolved[8];                                       // (as many as the planner's cache has ways: planner.h CACHE_WAYS)
+    // Read mode, 4 states: a node that is not stored is seen by nobody but its parent, and a partial is linear in each child — so
+    // the reciprocal scale factors of the unstored nodes below a stored one are applied ONCE, at that node, as one vector: the
+    // entry-wise product of their reciprocal halves (a "fold"; built by k_foldReciprocals whenever a scale buffer has been written
+    // since — scaleWriteEpoch — and kept by member list).  A cached full-evaluation program then reads one scale vector per STORED
+    // node instead of one per node (config A: 78 + slice roots instead of 999; 0.8 of the evaluation's 2.2 GB).  The per-node
+    // buffers stay what getLogScaleFactors, accumulateScaleFactors, partial updates and the gradient pass expect.  A fold whose
+    // largest product leaves [1, 1e200] is refused and its plan falls back to per-node factors.  BEAGLE_MI355_NO_SCALE_FOLD=1 at
+    // creation switches folding off: every node is then rounded the same way on every evaluation path (bitwise-equal partial
+    // updates and full evaluations); with folding the paths agree to rounding (1e-15 relative).
+    struct FoldVec { std::vector<int> members; double* recip = nullptr; long builtEpoch = -1; bool bad = false; };
+    std::vector<FoldVec> folds;
+    std::vector<std::pair<size_t, int>> foldIndex;       // (hash of the member list, index into folds), sorted by hash
+    std::vector<double*> foldFree;                       // vectors of a dropped cache generation, reused
+    long scaleWriteEpoch = 0;                            // bumped by everything that writes (or re-lays) a per-node scale buffer
+    bool foldScales = true;
+    unsigned long long* foldWorst = nullptr; size_t foldWorstCount = 0;      // device: k_foldReciprocals' range check
     long resolveEpoch = 0;                               // bumped when pattern ranges change
     bool fastWalk = true;                                // BEAGLE_MI355_NO_FAST_WALK=1 at creation: k_walk4 only (A/B runs, tests)
     // 4 states: a pre-order operation list is HELD BACK (engine_preorder.cpp): the chain that evaluates gradients wants the
@@ -120,6 +139,7 @@ struct Instance {
     bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back
     bool copyKeepsWalk = false;                          // (set around an upload the held walk does not read: engine_instance.cpp queueCopy)
     long statRootFused = 0;
+    long statFoldedVectors = 0, statFoldBuilds = 0;      // read-mode programs: folded reciprocal vectors in use / (re)builds of them (engine_walk.cpp)
     unsigned* rootCounter = nullptr;                     // device word of k_rootSite's last-workgroup sum (kernels.hip)
     double* cherryTables = nullptr; size_t cherryTableBytes = 0;   // 21..64 states: column tables of a list's virtual cherries (grow-only)
     int holdSlots = 3;                                   // what the planner was given
@@ -167,6 +187,11 @@ struct Instance {
     // workgroups signal and poll with the launch's epoch.  BEAGLE_MI355_NO_WALK_FUSION=1 at creation: one launch per wave of slices
     bool fuseWaves = true;
     unsigned* walkFlags = nullptr; size_t walkFlagBytes = 0; unsigned walkEpoch = 0;
+    // how long a workgroup of that launch polls before it computes what it waits for itself (kernels_walk4.hip: forward progress does
+    // not rest on the dispatch order), in ticks of the device's 100 MHz wall clock: 20 ms — an evaluation of the largest alignment
+    // this engine is measured on takes 0.6; BEAGLE_MI355_WALK_SPIN_US=<us> at creation (tests: 0 forces the self-serve path).
+    // walkSelfServed: device word that counts the workgroups whose wait ran out (beagleMi355WalkHealth).
+    unsigned long long walkSpinLimit = 2000000ull; unsigned* walkSelfServed = nullptr;
     int partitionCount = 1;
     std::vector<int> partStart, partEnd;
     // levelisation scratch
@@ -272,6 +297,8 @@ inline void setLeaf(Instance* in, int X) { if (X < in->tipCount) in->planner.set
 
 // ---- engine_walk.cpp
 int runPlan(Instance* in, const mi355::Plan& plan, long planTag = 0, hipEvent_t recordBeforeWalk = nullptr);
+inline void scalesWritten(Instance* in) { in->scaleWriteEpoch++; }       // (Instance::folds)
+void forgetFolds(Instance* in);                                          // the layout of the scale buffers changes
 int materializeList(Instance* in, const std::vector<int>& xs);
 int materializeVirtual(Instance* in, int X);
 int materializeScaleUsers(Instance* in, int scaleIdx);

@@ -122,7 +122,7 @@ int runOperationsLevels(Instance* in, const int* ops, int count, int tuple, int 
         d.mat1 = m1; d.mat2 = m2;
         if (wS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, wS); if (rc) return rc;
-            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; scalesWritten(in);
         } else if (rS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, rS); if (rc) return rc;
             if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op

@@ -150,7 +150,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         d.mat1 = mc; d.mat2 = ms;
         if (wS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, wS); if (rc) return rc;
-            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS;
+            d.scaleWrite = in->scale[wS]; in->scaleIsRaw[wS] = 1; opWrite[k] = wS; scalesWritten(in);
         } else if (rS != BEAGLE_OP_NONE) {
             rc = ensureScale(in, rS); if (rc) return rc;
             if (!in->scaleIsRaw[rS]) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -177,7 +177,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     const size_t maxChunkOps = (RING_BYTES / 4) / sizeof(OpDesc);
     // T32 layout (16..64 states): two passes of the MFMA pruning kernel per op instead of the VALU pre-order kernel
     // (BEAGLE_MI355_PRE_NAIVE=1 keeps the latter, for A/B runs)
-    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    static const bool preNaive = labEnv("BEAGLE_MI355_PRE_NAIVE") && atoi(labEnv("BEAGLE_MI355_PRE_NAIVE")) != 0;
     const bool twoPass = in->tiled && !preNaive;
     for (int chunkBegin = 0; chunkBegin < count;) {
         const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
@@ -298,10 +298,10 @@ int holdPreList(Instance* in, const int* ops, int count) {
     h.order.clear(); h.walkFlags.clear(); h.segStart.clear(); h.segRoot.clear(); h.holdSlots = 0;
     {
         const long groups = (in->P + 63) / 64;
-        static const int forced = getenv("BEAGLE_MI355_PRE_CHUNK") ? atoi(getenv("BEAGLE_MI355_PRE_CHUNK")) : -1;
+        static const int forced = labEnv("BEAGLE_MI355_PRE_CHUNK") ? atoi(labEnv("BEAGLE_MI355_PRE_CHUNK")) : -1;
         int chunk = nodes.size() >= 64 ? (int)std::min<long>(256, std::max<long>(24, (long)nodes.size() * groups / 2560)) : 0;
         if (forced >= 0) chunk = forced;
-        static const int forcedMin = getenv("BEAGLE_MI355_PRE_MINHEAD") ? atoi(getenv("BEAGLE_MI355_PRE_MINHEAD")) : -1;
+        static const int forcedMin = labEnv("BEAGLE_MI355_PRE_MINHEAD") ? atoi(labEnv("BEAGLE_MI355_PRE_MINHEAD")) : -1;
         const int minHead = forcedMin >= 0 ? forcedMin : std::max(8, chunk / 4);
         std::vector<char> head(nodes.size(), 0);
         std::vector<int> heads(1, root);
@@ -557,7 +557,7 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     if (outDerivatives && hipMalloc((void**)&dPer, (size_t)chunk * in->P * sizeof(double)) != hipSuccess) rc = BEAGLE_ERROR_OUT_OF_MEMORY;
     std::vector<mi355::EdgeDesc> descs;
     std::vector<double> sums;
-    static const bool preNaive = getenv("BEAGLE_MI355_PRE_NAIVE") && atoi(getenv("BEAGLE_MI355_PRE_NAIVE")) != 0;
+    static const bool preNaive = labEnv("BEAGLE_MI355_PRE_NAIVE") && atoi(labEnv("BEAGLE_MI355_PRE_NAIVE")) != 0;
     const bool twoStep = in->tiled && !preNaive;
     if (twoStep && !rc) rc = ensurePreScratch(in);
     for (int b = 0; b < count && !rc; b += chunk) {

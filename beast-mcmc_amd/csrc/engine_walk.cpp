@@ -8,10 +8,97 @@ using mi355::OpDesc;
 namespace mi355 {
 namespace eng {
 
+// ---- folded reciprocal vectors (Instance::folds) ------------------------------------------------------------------------
+constexpr int FOLD_MAX_MEMBERS = 32;        // factors per fold: a longer run of unstored nodes is folded in pieces
+constexpr double FOLD_SAFE_MAX = 1e200;     // largest product of reciprocals a fold may hold (each is >= 1)
+
+// forget every fold (their vectors are kept for reuse) and every resolved program that may point at one
+static void dropFolds(Instance* in, bool keepVectors) {
+    for (Instance::FoldVec& f : in->folds) if (keepVectors && f.recip) in->foldFree.push_back(f.recip);
+    if (!keepVectors) in->foldFree.clear();                // (another layout: the old vectors stay with the instance until it is destroyed)
+    in->folds.clear(); in->foldIndex.clear();
+    for (Instance::Resolved& r : in->resolved) { r.tag = 0; r.dProgValid = false; r.folds.clear(); r.foldEpoch = -1; }
+}
+void forgetFolds(Instance* in) { dropFolds(in, false); scalesWritten(in); }
+
+// the fold of exactly these scale buffers, in this order (index into Instance::folds; < 0: out of memory)
+static int foldFor(Instance* in, const std::vector<int>& members) {
+    size_t h = 1469598103934665603ull;
+    for (int m : members) { h ^= (size_t)(unsigned)m; h *= 1099511628211ull; }
+    auto it = std::lower_bound(in->foldIndex.begin(), in->foldIndex.end(), std::make_pair(h, -1));
+    for (auto q = it; q != in->foldIndex.end() && q->first == h; ++q)
+        if (in->folds[(size_t)q->second].members == members) return q->second;
+    Instance::FoldVec f;
+    f.members = members;
+    if (!in->foldFree.empty()) { f.recip = in->foldFree.back(); in->foldFree.pop_back(); }
+    else if (devAlloc(in, (void**)&f.recip, in->scaleStride * sizeof(double))) return -1;
+    in->folds.push_back(f);
+    const int id = (int)in->folds.size() - 1;
+    in->foldIndex.insert(it, std::make_pair(h, id));
+    return id;
+}
+
+// (re)build the folds of `ids` that are older than the last scale-buffer write; *anyBad: one of `ids` leaves the safe range.
+// One launch for all of them, then ONE read-back of the range check — which stalls the stream once per write-mode evaluation
+// (DYNAMIC rescaling: every 100th), not per evaluation.
+static int refreshFolds(Instance* in, const std::vector<int>& ids, bool* anyBad) {
+    std::vector<int> stale;
+    for (int id : ids) {
+        Instance::FoldVec& f = in->folds[(size_t)id];
+        if (f.builtEpoch != in->scaleWriteEpoch) { f.builtEpoch = in->scaleWriteEpoch; stale.push_back(id); }
+    }
+    if (!stale.empty()) {
+        std::vector<const double*> srcs; std::vector<int> start; std::vector<double*> dst;
+        for (int id : stale) {
+            const Instance::FoldVec& f = in->folds[(size_t)id];
+            start.push_back((int)srcs.size());
+            for (int m : f.members) srcs.push_back(in->scale[m] + in->scaleStride);
+            dst.push_back(f.recip);
+        }
+        start.push_back((int)srcs.size());
+        if (in->foldWorstCount < stale.size()) {
+            const size_t want = std::max<size_t>(stale.size() + stale.size() / 2, 256);
+            int rc = devAlloc(in, (void**)&in->foldWorst, want * sizeof(unsigned long long)); if (rc) return rc;
+            in->foldWorstCount = want;
+        }
+        HIP_TRY(hipMemsetAsync(in->foldWorst, 0, stale.size() * sizeof(unsigned long long), live(in)));
+        const int chunk = 2048;                             // (jobs per launch: their pointer lists go through the staging ring)
+        for (size_t b = 0; b < stale.size(); b += chunk) {
+            const size_t e = std::min(stale.size(), b + chunk);
+            std::vector<int> st(start.begin() + b, start.begin() + e + 1);
+            const int base = st[0];
+            for (int& v : st) v -= base;
+            void *dSrcs = nullptr, *dStart = nullptr, *dDst = nullptr;
+            int rc = uploadTransient(in, srcs.data() + base, (size_t)st.back() * sizeof(double*), &dSrcs); if (rc) return rc;
+            rc = uploadTransient(in, st.data(), st.size() * sizeof(int), &dStart); if (rc) return rc;
+            rc = uploadTransient(in, dst.data() + b, (e - b) * sizeof(double*), &dDst); if (rc) return rc;
+            mi355::launchFoldReciprocals(live(in), (const double* const*)dSrcs, (const int*)dStart, (double* const*)dDst, (int)(e - b), (int)in->pairLen,
+                                         in->foldWorst + b);
+        }
+        HIP_TRY(hipGetLastError());
+        std::vector<unsigned long long> worst(stale.size());
+        int rc = download(in, worst.data(), in->foldWorst, worst.size() * sizeof(unsigned long long)); if (rc) return rc;
+        for (size_t k = 0; k < stale.size(); k++) {
+            double v; memcpy(&v, &worst[k], sizeof(v));
+            in->folds[(size_t)stale[k]].bad = !(v <= FOLD_SAFE_MAX);
+        }
+        in->statFoldBuilds += (long)stale.size();
+    }
+    *anyBad = false;
+    for (int id : ids) if (in->folds[(size_t)id].bad) *anyBad = true;
+    return 0;
+}
+
+// did this run of a plan write per-node scale buffers?  (folds built from them are stale then)
+static inline bool anyScaleWriteIn(const Instance* in, const Instance::Resolved* slot, bool reuse, long writesAtEntry) {
+    return reuse ? slot->scaleWrites > 0 : in->statScaleWrites != writesAtEntry;
+}
+
 // Resolve a planned program to device addresses, upload it (ONE host-to-device copy: snapshot pairs, segments and
 // micro-operations travel together) and enqueue the snapshot copies and the walk.
 int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t recordBeforeWalk) {
     const size_t n = plan.prog.size();
+    const long statsAtEntry[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
     if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
         if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
         void* dPairs = nullptr;
@@ -23,7 +110,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // Device program: per segment its micro-operations, a no-op when their number is odd, and two more no-ops the
     // kernel's descriptor prefetch may read (kernels.h WalkSeg).  For a plan that came out of the planner's cache the
     // resolved program is kept as well: buffer addresses never change once a buffer exists.
-    static const int ablate = getenv("BEAGLE_MI355_ABLATE") ? atoi(getenv("BEAGLE_MI355_ABLATE")) : 0;
+    static const int ablate = labEnv("BEAGLE_MI355_ABLATE") ? atoi(labEnv("BEAGLE_MI355_ABLATE")) : 0;     // (LAB builds only: wrong results)
     Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 7] : nullptr;
     const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
     std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
@@ -42,7 +129,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
     } else {
     const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
-    if (slot) { slot->tag = 0; slot->dProgValid = false; }
+    if (in->folds.size() > 4096) dropFolds(in, true);           // (tree shapes come and go; the vectors are reused)
+    if (slot) { slot->tag = 0; slot->dProgValid = false; slot->folds.clear(); slot->foldEpoch = -1; }
+    // read-mode programs of cached (full-evaluation) plans fold the reciprocals of unstored nodes (Instance::folds)
+    bool anyScaleWrite = false;
+    for (const mi355::MicroOp& m : plan.prog) if (m.smode == mi355::PS_WRITE) { anyScaleWrite = true; break; }
+    const bool fold = slot && in->foldScales && in->walk && !in->walkT && !anyScaleWrite && slot->noFoldTag != planTag;
+    std::vector<int> accSet, holdSet[3], cur;
     w.clear();
     w.reserve(n + 6 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
@@ -72,6 +165,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         }
         segs[si].depCount = (int)devDeps.size() - segs[si].depStart;
         segs[si].progStart = (int)w.size();
+        accSet.clear(); for (std::vector<int>& hs : holdSet) hs.clear();
         for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
             mi355::MicroOp m = plan.prog[i];
             // The kernels request a first child's partials one stage early — before the previous micro-operation's store
@@ -93,9 +187,36 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 if (m.smode == mi355::PS_WRITE) { if (in->walkT) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
                 else {
                     if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
-                    in->statScaleReads++;
-                    d.scale = in->scale[m.scaleIdx] + (in->walkT ? 0 : in->scaleStride);  // read mode multiplies by the reciprocal
+                    if (!fold) {
+                        in->statScaleReads++;
+                        d.scale = in->scale[m.scaleIdx] + (in->walkT ? 0 : in->scaleStride);  // read mode multiplies by the reciprocal
+                    }
                 }
+            }
+            int smodeNow = m.smode;
+            if (fold) {
+                // what this result still owes: the factors of the unstored operands it was formed from, and its own.  A result that
+                // is stored, ends its slice or has gathered FOLD_MAX_MEMBERS of them pays — one vector, the product of their reciprocals
+                cur.clear();
+                if (m.k1 >= mi355::PK_H0) { const std::vector<int>& hs = holdSet[m.k1 - mi355::PK_H0]; cur.insert(cur.end(), hs.begin(), hs.end()); }
+                if (m.k2 == mi355::PK_ACC) cur.insert(cur.end(), accSet.begin(), accSet.end());
+                if (m.smode == mi355::PS_READ) cur.push_back(m.scaleIdx);
+                const bool pays = m.storeBuf >= 0 || i == ps.progStart + ps.progCount - 1 || (int)cur.size() >= FOLD_MAX_MEMBERS;
+                smodeNow = mi355::PS_NONE;
+                if (pays && !cur.empty()) {
+                    smodeNow = mi355::PS_READ;
+                    if (cur.size() == 1) d.scale = in->scale[cur[0]] + in->scaleStride;
+                    else {
+                        const int f = foldFor(in, cur);
+                        if (f < 0) return BEAGLE_ERROR_OUT_OF_MEMORY;
+                        slot->folds.push_back(f);
+                        d.scale = in->folds[(size_t)f].recip;
+                    }
+                    in->statScaleReads++;
+                    cur.clear();
+                }
+                if (m.hold) holdSet[m.hold - 1] = cur;
+                accSet.swap(cur);
             }
             if (m.storeBuf >= 0) {
                 int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
@@ -103,7 +224,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 in->statStored++;
             }
             d.m1 = in->matrices + (size_t)gatherFrom(m.mat1) * matStride; d.m2 = in->matrices + (size_t)gatherFrom(m.mat2) * matStride;
-            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, m.smode, m.storeBuf >= 0);
+            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, smodeNow, m.storeBuf >= 0);
             if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
                 if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
                 if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
@@ -154,6 +275,21 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
         slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
     }
+    }
+    if (anyScaleWriteIn(in, slot, reuse, statsAtEntry[3])) scalesWritten(in);
+    if (slot && !slot->folds.empty()) {
+        if (slot->foldEpoch != in->scaleWriteEpoch) {
+            bool bad = false;
+            int rcf = refreshFolds(in, slot->folds, &bad); if (rcf) return rcf;
+            slot->foldEpoch = in->scaleWriteEpoch;
+            if (bad) {                                 // out of range: this plan keeps per-node factors from now on
+                in->statMemReads = statsAtEntry[0]; in->statTipReads = statsAtEntry[1]; in->statScaleReads = statsAtEntry[2];
+                in->statScaleWrites = statsAtEntry[3]; in->statStored = statsAtEntry[4];
+                slot->noFoldTag = planTag; slot->tag = 0; slot->dProgValid = false; slot->folds.clear();
+                return runPlan(in, plan, planTag, recordBeforeWalk);
+            }
+        }
+        in->statFoldedVectors = (long)slot->folds.size();
     }
     in->statMicroOps += (long)n;
     // pack: [micro-ops (64 B each) | segments (32 B each) | dependency lists | snapshot pairs] — ONE host-to-device copy
@@ -214,7 +350,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
     else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
-    if (getenv("BEAGLE_MI355_DUMP_PLAN")) {           // development: the slices of this program, wave by wave
+    if (labEnv("BEAGLE_MI355_DUMP_PLAN")) {           // development (LAB builds): the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
         for (size_t i = 0; i < segs.size(); i++) {
             const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)plan.launchOrder[i] : i];
@@ -222,7 +358,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             if (fused) fprintf(stderr, "(t%d d%d)", ps.tail, ps.depCount);
         }
         fprintf(stderr, "\n");
-        if (atoi(getenv("BEAGLE_MI355_DUMP_PLAN")) > 1)
+        if (atoi(labEnv("BEAGLE_MI355_DUMP_PLAN")) > 1)
             for (size_t i = 0; i < w.size(); i++)
                 fprintf(stderr, "[mi355]   %3zu: k1 %u k2 %u hold %u scale %u store %d\n", i, (w[i].flags >> 5) & 7, (w[i].flags >> 8) & 7, (w[i].flags >> 11) & 3,
                         (w[i].flags >> 13) & 3, (w[i].flags & mi355::WF_STORE) ? 1 : 0);
@@ -296,7 +432,7 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
     pw.valid = false;                                  // (before anything that could come back here through live())
     if (!in->pendingCopies.empty()) { int rc = flushUploads(in); if (rc) return rc; }
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
-                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root);
+                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed);
     if (root) in->statRootFused++;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -334,7 +470,7 @@ int materializeTipUsers(Instance* in, int tip) {
 // waiting for its stores is replaced by another one instead of idling (1e5 patterns: 1.73 -> 1.37 ms).  Returns the target
 // number of micro-operations per subtree, 0 = one walk.  BEAGLE_MI355_CHUNK overrides (0 = never).
 int walkChunkOps(const Instance* in, int opCount) {
-    static const int forced = getenv("BEAGLE_MI355_CHUNK") ? atoi(getenv("BEAGLE_MI355_CHUNK")) : -1;
+    static const int forced = labEnv("BEAGLE_MI355_CHUNK") ? atoi(labEnv("BEAGLE_MI355_CHUNK")) : -1;
     if (forced >= 0) return forced;
     if (opCount < 64) return 0;
     const long groups = (in->P + 127) / 128;

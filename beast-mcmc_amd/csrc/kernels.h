@@ -3,8 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace mi355 {
+
+// Environment switches.  The product library reads only the documented A/B switches (every one of them leaves the
+// results unchanged and selects an older or a reference code path) with plain getenv.  Tuning knobs and timing experiments —
+// slice lengths, scheduling orders, LDS padding, parts of a kernel left out (some of them give WRONG results by construction) —
+// go through labEnv(), which only a LAB build (-DBEAGLE_MI355_LAB: `python beast-mcmc_amd/build.py --lab`, tools/build_variant.sh)
+// connects to the environment; the library a maintainer ships cannot be talked into any of them.
+#ifdef BEAGLE_MI355_LAB
+inline const char* labEnv(const char* name) { return getenv(name); }
+#else
+inline const char* labEnv(const char*) { return nullptr; }
+#endif
 
 // One pruning operation as the level kernels see it (every state count but 4): pointers already resolved on the host
 // from the reference's 7-int (or 9-int) tuple {dest, writeScale, readScale, child1, matrix1, child2, matrix2
@@ -137,9 +149,11 @@ struct RootFused {
     double* siteLogL; double* blockSums; unsigned* counter; double* out; unsigned long long* flag; unsigned long long seq;
     int cumIsRaw; int rootSeg; int groups; int pad;
 };
+// spinLimit: how long a workgroup polls those flags (ticks of the 100 MHz wall clock) before it computes what it waits for itself
+// (kernels_walk4.hip: forward progress whatever the dispatch order); *selfServed counts the workgroups that did.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
-                     const RootFused* root = nullptr);
+                     const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr);
 // 4-state walk instances: the root integration as a launch of its own, bit-compatible with the walk's root epilogue (root_site4.h)
 void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                                const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
@@ -208,6 +222,9 @@ void launchAccumulateScale(hipStream_t stream, double* cum, const double* const*
                            int count, double sign, int pStart, int pEnd);
 
 void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd);
+// dst[j][i] = prod_m srcs[m][i] over m in [start[j], start[j + 1]), i < len; worst[j] (zeroed by the caller) = bit pattern of job j's
+// largest product, +infinity for anything not finite (kernels.hip k_foldReciprocals)
+void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst);
 // out[p] = raw ? log(in[p]) : in[p]
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
 // Read-back: out[c][p][i] (API layout) = partials * scale, from either device layout.  `scale` may be

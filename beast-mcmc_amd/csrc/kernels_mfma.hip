@@ -133,7 +133,7 @@ __device__ __forceinline__ void tiledChild(const double* __restrict__ frag, int 
             for (int k = 0; k < IH; k++) {
                 if (it0 + k < nt) {
                     const double a = frag[((it0 + k) * NTMAX + jt) * 16 + fl];
-#ifdef MI355_EXP_NOMFMA      // TIMING EXPERIMENTS ONLY: one multiply-add instead of the two matrix instructions
+#if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_NOMFMA)      // TIMING EXPERIMENTS ONLY: one multiply-add instead of the two matrix instructions
                     oe[k] += a * b[jt].x; oo[k] += a * b[jt].y;
 #else
                     oe[k] = mfma4(a, b[jt].x, oe[k]);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
         v2d b1[NTMAX], b2[NTMAX];
         int se1 = S, so1 = S;
         if (PIPE == 2 && !vt1 && tile < tile1) tiledFetch1<NTMAX, EXACT>(op, st1, c, ntile, tile, P, S, g, m, b1, se1, so1);   // in flight across the staging
-#ifdef MI355_EXP_NOSTAGE     // TIMING EXPERIMENTS ONLY (tools/build_mfma_variant.sh; wrong results): what the fragment staging costs
+#if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_NOSTAGE)     // TIMING EXPERIMENTS ONLY (tools/build_mfma_variant.sh; wrong results): what the fragment staging costs
         for (int e = threadIdx.x; e < 2 * fragN; e += MF_BLOCK) frag[e] = 0.5;
         if (false)
 #endif
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NTMAX > 5 ? 2 : 4)) void k_pruneTiled(co
                             if (it0 + k < nt && i < S) {
                                 v2d o; o.x = re[it0 - h0 + k] * te[k] * inve; o.y = ro[it0 - h0 + k] * to[k] * invo;
                                 double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(reinterpret_cast<char*>(d) + (lane8 + (unsigned)(it0 + k) * 4u * TILE * 8u)));
-#ifdef MI355_EXP_NOSTORE     // TIMING EXPERIMENTS ONLY: the result is stored only where it cannot be (keeps the arithmetic alive)
+#if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_NOSTORE)     // TIMING EXPERIMENTS ONLY: the result is stored only where it cannot be (keeps the arithmetic alive)
                                 if (o.x == -1.0) q[0] = o.x;
 #else
                                 if (ine && ino) __builtin_nontemporal_store(o, reinterpret_cast<v2d MI355_GLOBAL*>(q));
@@ -457,7 +457,7 @@ void launchPruneLevelTiled(hipStream_t stream, const OpDesc* dOps, int nOps, con
     }
     // resident workgroups: 4 per CU at <= 20 states (4 waves/SIMD), 2 per CU above (2 waves/SIMD, 64 KiB LDS each); two rounds
     // (three above 20 states: 256 / 512 / 1024 / 1536 / 2048 / 4096 workgroups per launch -> 134 / 203 / 214 / 229 / 228 / 212 evals/s on config C)
-    static const int target = [] { const char* e = getenv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
+    static const int target = [] { const char* e = labEnv("BEAGLE_MI355_TILED_TARGET"); return e ? atoi(e) : 0; }();
     dim3 grid(tiledBlocksPerRow(P, nOps * C, target > 0 ? target : (nt <= 5 ? 2048 : 1536)), nOps * C), block(MF_BLOCK);
     static const int pipe = [] { const char* e = getenv("BEAGLE_MI355_MFMA_PIPE"); return e ? atoi(e) : 2; }();
 #define TILED_LAUNCH(NT, EX, PI) do { if (dCherries && (NT <= 5 || dCherryTables)) hipLaunchKernelGGL((k_pruneTiled<NT, EX, PI, true>), grid, block, lds, stream, dOps, matrices, P, S, C, dCherries, dCherryTables); \

@@ -366,64 +366,105 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 // One launch for ALL slices of a program (flags != nullptr).  Slices of a wave are independent; a slice of a later wave reads
 // what earlier slices stored — for the same 128 patterns only.  So instead of a launch per wave (a chip-wide barrier, with the
 // tail of every wave running on a few CUs), a workgroup waits for exactly the slices it reads from: flags[slice][x] carries the
-// launch's epoch once that slice's workgroup x has its results out.  Workgroups are dispatched in index order (x fastest, then
+// launch's epoch once that slice's workgroup x has its results out.  gfx950 dispatches workgroups in index order (x fastest, then
 // the slice) and the engine orders the slices critical path first with every slice behind the ones it waits for, so a waiting
-// workgroup only ever waits for workgroups dispatched before it: no deadlock however few fit on the chip at a time.
+// workgroup only ever waits for workgroups dispatched before it.  That order is observed behaviour, not a documented guarantee:
+// the wait is therefore BOUNDED, and a workgroup whose wait runs out computes what it was waiting for itself (see the kernel) —
+// no deadlock whatever the dispatcher does.
 // Visibility across the 8 XCDs (private L2s): the loop's result stores and its loads of stored results carry the device-scope
 // bit (sc1: written through to memory before the acknowledgement; read past any stale line — tools/gen_walk4_fast.py), so a
 // producer only has to drain its stores (the loop ends with s_waitcnt vmcnt(0)) before the flag goes up and a consumer only has
 // to see the flag.  A write-back / invalidate of the whole L2 per workgroup (buffer_wbl2 / buffer_inv, what a release / acquire
 // fence at agent scope costs) made the launch five times slower instead of faster.
+// the lane's index without a register that has to survive the assembly block (which leaves the compiler two VGPRs)
+__device__ __forceinline__ int walkLane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
-                                                             const RootFused rootArgs) {
+                                                             unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs) {
     extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[3][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
-    const WalkSeg MI355_CONST& sg = segs[blockIdx.y];
-    const int progStart = sg.progStart, progCount = sg.progCount, pEnd = sg.pEnd;
-    const int p0 = sg.pStart + (int)blockIdx.x * 128;
-    if (p0 >= pEnd || progCount <= 0) return;         // (no workgroup waits for this one: its dependants leave the same way)
+    const int y = (int)blockIdx.y;
+    const WalkSeg MI355_CONST& sg = segs[y];
+    const int pStart = sg.pStart, pEnd = sg.pEnd;
+    const int p0 = pStart + (int)blockIdx.x * 128;
+    if (p0 >= pEnd || sg.progCount <= 0) return;      // (no workgroup waits for this one: its dependants leave the same way)
     const unsigned c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    volatile int* word = reinterpret_cast<volatile int*>(lds);          // (LDS is free between programs)
+    // Forward progress does not rest on the order in which the hardware dispatches workgroups.  A workgroup polls the flags of the
+    // slices it reads from for at most `spinLimit` ticks of the 100 MHz clock; past that it stops waiting and SERVES ITSELF: it walks
+    // every slice in front of its own (same pattern range, device order: a slice's dependencies come before it) whose flag for this
+    // pattern group is not up, then its own.  Everything a slice reads was computed for the same 128 patterns, so a workgroup can
+    // always finish alone; a result computed twice is stored twice with the same bits.  On gfx950 dispatch IS in index order and
+    // the limit is never reached (selfServed counts the workgroups that did; tests force it with a limit of 0).
+    int first = y;
     if (flags) {
         const int depCount = sg.depCount;
         if (depCount > 0) {
             if (c == 0) {
                 const int MI355_CONST* dl = deps + sg.depStart;
-                for (int d = (int)(threadIdx.x & 63); d < depCount; d += 64) {
+                const unsigned long long t0 = wall_clock64();
+                bool late = false;
+                for (int d = walkLane(); d < depCount && !late; d += 64) {
                     const unsigned* f = flags + (size_t)dl[d] * flagStride + blockIdx.x;
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        if (wall_clock64() - t0 >= spinLimit) { late = true; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
                 }
+                const bool anyLate = __ballot(late) != 0ull;
+                if (walkLane() == 0) *word = anyLate ? 1 : 0;
             }
             __syncthreads();
+            const int anyLate = __builtin_amdgcn_readfirstlane(*word);
+            __syncthreads();
+            if (anyLate) {
+                first = 0;
+                if (c == 0 && walkLane() == 0) atomicAdd(selfServed, 1u);
+            }
         }
     }
-    const u64 dp = (u64)(prog + (size_t)progStart * 16);
     const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
-    const u64 strm = (u64)matStream + (u64)progStart * strmStep;
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
     const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
-    asm volatile(WALK4_FAST_ASM
-                 : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
-                     [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
-                     [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
-                     [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
-                     [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(sg.tStart + (int)blockIdx.x * 128)
-                 : WALK4_FAST_CLOBBERS);
-    if (flags) {
-        // (the loop ends with s_waitcnt vmcnt(0): every store of this wave has been acknowledged by memory)
-        __syncthreads();
-        if (c == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
-            __hip_atomic_store(flags + (size_t)blockIdx.y * flagStride + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int s = first; s <= y; s++) {
+        const WalkSeg MI355_CONST& ss = segs[s];
+        if (s != y) {                                 // (self-serve only)
+            if (ss.pStart != pStart || ss.pEnd != pEnd || ss.progCount <= 0) continue;
+            if (c == 0 && walkLane() == 0)
+                *word = __hip_atomic_load(flags + (size_t)s * flagStride + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch ? 1 : 0;
+            __syncthreads();
+            const int done = __builtin_amdgcn_readfirstlane(*word);
+            __syncthreads();
+            if (done) continue;
+        }
+        const int progStart = ss.progStart, progCount = ss.progCount;
+        const u64 dp = (u64)(prog + (size_t)progStart * 16);
+        const u64 strm = (u64)matStream + (u64)progStart * strmStep;
+        asm volatile(WALK4_FAST_ASM
+                     : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
+                         [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
+                         [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
+                         [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
+                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)blockIdx.x * 128)
+                     : WALK4_FAST_CLOBBERS);
+        if (flags) {
+            // (the loop ends with s_waitcnt vmcnt(0): every store of this wave has been acknowledged by memory)
+            __syncthreads();
+            unsigned e = epoch;
+            asm volatile("" : "+s"(e));               // (formed here: a vector register that waits across the assembly block would be spilled)
+            if (c == 0 && walkLane() == 0)
+                __hip_atomic_store(flags + (size_t)s * flagStride + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // The slice that ends at the root finishes the evaluation (engine_walk.cpp PendingWalk: the launch was held back until
     // calculateRootLogLikelihoods named this slice's last result as the root): every wave's last result sits in hold slot 0
     // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
     // categories up in order, takes the logarithm and folds the group's 128 site values; the last group adds the groups' sums.
     // Same functions, same order, same bits as the launch of its own (kernels.hip k_rootSite4W).
-    if (rootArgs.rootSeg == (int)blockIdx.y) {
-        const int lane = (int)(threadIdx.x & 63);
+    if (rootArgs.rootSeg == y) {
+        const int lane = walkLane();
         const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
         const double sa = rootDot4(rootArgs.freqs, h[0], h[1], h[128], h[129]);
         const double sb = rootDot4(rootArgs.freqs, h[256], h[257], h[384], h[385]);
@@ -445,16 +486,17 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 }
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
-                     long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root) {
+                     long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root,
+                     unsigned long long spinLimit, unsigned* selfServed) {
     if (nSegs <= 0 || maxRange <= 0) return;
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
     const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
-    // BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so that fewer
-    // workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
-    static const size_t ldsPad = getenv("BEAGLE_MI355_WALK_LDS_PAD") ? (size_t)atol(getenv("BEAGLE_MI355_WALK_LDS_PAD")) : 0;
+    // LAB builds only, BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so
+    // that fewer workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
+    static const size_t ldsPad = labEnv("BEAGLE_MI355_WALK_LDS_PAD") ? (size_t)atol(labEnv("BEAGLE_MI355_WALK_LDS_PAD")) : 0;
     const size_t lds = (size_t)2 * C * 4096 + (size_t)3 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024 + ldsPad;
     const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
@@ -466,11 +508,11 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     ra.rootSeg = -1;
     if (root) ra = *root;
     if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, ra); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {
