@@ -124,7 +124,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CommInfo", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -445,6 +445,12 @@ class Beagle:
     def commInit(self, unique_id, rank, rank_count):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check("commInit", self._ext("beagleMi355CommInit", [C.c_int, C.c_void_p, C.c_int, C.c_int])(self.instance, buf, rank, rank_count))
+
+    def commRanks(self):
+        """Ranks of the instance's communicator as RCCL counts them (0: none) — include/beagle_mi355.h beagleMi355CommInfo."""
+        n = C.c_int(0)
+        self._check("commInfo", self._ext("beagleMi355CommInfo", [C.c_int, C.POINTER(C.c_int)])(self.instance, C.byref(n)))
+        return n.value
 
     def calculateRootLogLikelihoodsAllReduce(self, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex):
         out = C.c_double(0.0)

@@ -158,6 +158,13 @@ int publishAndWait(int instance, const double* dValues, int count, double* out) 
     memcpy(out, in->hResult + 16, (size_t)count * sizeof(double));
     return BEAGLE_SUCCESS;
 }
+int takeAsyncError(int instance) {
+    Instance* in = lookup(instance);
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    const int rc = in->asyncError;
+    in->asyncError = 0;
+    return rc;
+}
 }  // namespace mi355
 
 extern "C" {
@@ -876,8 +883,25 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
     // eigen system / rate set whose upload is still queued — from there; the queued copies ride in the same launch
     // (kernels.hip k_transition4Fused).  One launch instead of a copy kernel and a transition kernel: 5 us of a 12 500-pattern
     // evaluation's 170 (profiles/r04_experiments.txt).
-    if (in->S == 4 && in->kernelUploads && in->fuseLaunches && !eigenIdx && !rateIdx && (size_t)count * 12 <= RING_BYTES / 4 &&
-        (int)in->pendingCopies.size() <= mi355::HOST_COPY_MAX) {
+    // The queued copies would run side by side with the transition blocks and with each other, in no order: a queued copy INTO the
+    // matrix block (beagleSetTransitionMatrix of a slot this call may rewrite: the later call has to win) or two queued copies whose
+    // ranges overlap without being the same array are flushed first, in order, and the plain kernel takes this call.
+    bool fusable = in->S == 4 && in->kernelUploads && in->fuseLaunches && !eigenIdx && !rateIdx && (size_t)count * 12 <= RING_BYTES / 4 &&
+                   (int)in->pendingCopies.size() <= mi355::HOST_COPY_MAX;
+    if (fusable) {
+        const char* m0 = (const char*)in->matrices;
+        const char* m1 = m0 + (size_t)std::max(1, in->matrixCount) * in->C * in->S * in->S * sizeof(double);
+        const std::vector<Instance::PendingCopy>& pc = in->pendingCopies;
+        for (size_t a = 0; a < pc.size() && fusable; a++) {
+            const char* d0 = (const char*)pc[a].dst; const char* d1 = d0 + pc[a].bytes;
+            if (d0 < m1 && m0 < d1) fusable = false;
+            for (size_t b = a + 1; b < pc.size() && fusable; b++) {
+                const char* e0 = (const char*)pc[b].dst; const char* e1 = e0 + pc[b].bytes;
+                if (d0 < e1 && e0 < d1 && !(e0 <= d0 && d1 <= e1)) fusable = false;      // (an earlier copy fully covered by a later one is simply dropped below)
+            }
+        }
+    }
+    if (fusable) {
         const size_t lenBytes = (size_t)count * sizeof(double), idxBytes = (size_t)count * sizeof(int);
         const long off = stage(in, lens, lenBytes, lenBytes + idxBytes);
         if (off < 0) return BEAGLE_ERROR_GENERAL;
@@ -896,10 +920,12 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
             if (pc.dst == (void*)eigSrc && pc.bytes == eigStride * sizeof(double)) eigSrc = (const double*)(in->hRingDev + pc.ringOff);
             if (pc.dst == (void*)in->rates && pc.bytes >= (size_t)in->C * sizeof(double)) ratesSrc = (const double*)(in->hRingDev + pc.ringOff);
         }
-        // (an array queued twice: the copies run side by side — keep only the last one of each destination)
+        // (an array queued twice: the copies run side by side — an earlier one that a later one covers entirely is dropped; any
+        // other overlap was excluded above)
         for (int a = 0; a < L.n; a++)
             for (int b = a + 1; b < L.n; b++)
-                if (L.e[a].dst == L.e[b].dst) L.e[a].bytes = 0;
+                if ((const char*)L.e[b].dst <= (const char*)L.e[a].dst &&
+                    (const char*)L.e[a].dst + L.e[a].bytes <= (const char*)L.e[b].dst + L.e[b].bytes) L.e[a].bytes = 0;
         in->pendingCopies.clear();
         mi355::launchTransitionMatrices4Fused(in->stream, in->matrices, eigSrc, ratesSrc, (const int*)(in->hRingDev + off + lenBytes),
                                               (const double*)(in->hRingDev + off), count, in->C, in->eigenComplex, L, (int)blocks);
@@ -1330,6 +1356,17 @@ int beagleMi355CommInit(int instance, const void* uniqueId128, int rank, int ran
     memcpy(&id, uniqueId128, sizeof(id));
     if (ncclCommInitRank(&in->comm, rankCount, id, rank) != ncclSuccess) { in->comm = nullptr; return BEAGLE_ERROR_GENERAL; }
     in->commRanks = rankCount;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355CommInfo(int instance, int* outRanks) {
+    if (!outRanks) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (mi355::isShardedHandle(instance)) { *outRanks = mi355::shardedCommRanks(instance); return BEAGLE_SUCCESS; }
+    Instance* in = lookup(instance);
+    if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    int n = 0;
+    if (in->comm && ncclCommCount(in->comm, &n) != ncclSuccess) return BEAGLE_ERROR_GENERAL;     // (what RCCL says, not what the caller asked for)
+    *outRanks = n;
     return BEAGLE_SUCCESS;
 }
 

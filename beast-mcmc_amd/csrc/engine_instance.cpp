@@ -83,13 +83,20 @@ int flushUploads(Instance* in) {
         L.n = 0;
         unsigned blocks = 0;
         for (; i < pc.size() && L.n < mi355::HOST_COPY_MAX; i++) {
+            // the copies of one launch run side by side: an earlier one that this one covers entirely is dropped (the later upload of
+            // an array wins); any other overlap with an earlier one of the launch sends this copy to the next launch, behind them
+            const char* d0 = (const char*)pc[i].dst; const char* d1 = d0 + pc[i].bytes;
+            bool partial = false;
+            for (int a = 0; a < L.n; a++) {
+                const char* e0 = (const char*)L.e[a].dst; const char* e1 = e0 + L.e[a].bytes;
+                if (L.e[a].bytes == 0 || !(d0 < e1 && e0 < d1)) continue;
+                if (d0 <= e0 && e1 <= d1) L.e[a].bytes = 0; else partial = true;
+            }
+            if (partial) break;
             mi355::HostCopyList::Entry& e = L.e[L.n++];
             e.dst = pc[i].dst; e.src = in->hRingDev + pc[i].ringOff; e.bytes = (unsigned)pc[i].bytes; e.firstBlock = blocks;
             blocks += (unsigned)((pc[i].bytes + 4095) / 4096);
         }
-        for (int a = 0; a < L.n; a++)                     // the copies of one launch run side by side: of two for the same destination
-            for (int b = a + 1; b < L.n; b++)             // only the later one may happen
-                if (L.e[a].dst == L.e[b].dst) L.e[a].bytes = 0;
         mi355::launchHostCopies(in->stream, L, (int)blocks);
     }
     pc.clear();

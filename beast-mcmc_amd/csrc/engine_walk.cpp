@@ -131,11 +131,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
     if (in->folds.size() > 4096) dropFolds(in, true);           // (tree shapes come and go; the vectors are reused)
     if (slot) { slot->tag = 0; slot->dProgValid = false; slot->folds.clear(); slot->foldEpoch = -1; }
-    // read-mode programs of cached (full-evaluation) plans fold the reciprocals of unstored nodes (Instance::folds)
-    bool anyScaleWrite = false;
-    for (const mi355::MicroOp& m : plan.prog) if (m.smode == mi355::PS_WRITE) { anyScaleWrite = true; break; }
-    const bool fold = slot && in->foldScales && in->walk && !in->walkT && !anyScaleWrite && slot->noFoldTag != planTag;
-    std::vector<int> accSet, holdSet[3], cur;
+    // read-mode programs of cached (full-evaluation) plans fold the reciprocals of unstored nodes (Instance::folds, planner.h FoldMap)
+    mi355::FoldMap foldMap;
+    const bool fold = slot && in->foldScales && in->walk && !in->walkT && slot->noFoldTag != planTag &&
+                      mi355::foldScaleFactors(plan, FOLD_MAX_MEMBERS, foldMap);
+    std::vector<int> cur;
     w.clear();
     w.reserve(n + 6 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
@@ -165,7 +165,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         }
         segs[si].depCount = (int)devDeps.size() - segs[si].depStart;
         segs[si].progStart = (int)w.size();
-        accSet.clear(); for (std::vector<int>& hs : holdSet) hs.clear();
         for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
             mi355::MicroOp m = plan.prog[i];
             // The kernels request a first child's partials one stage early — before the previous micro-operation's store
@@ -194,29 +193,18 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 }
             }
             int smodeNow = m.smode;
-            if (fold) {
-                // what this result still owes: the factors of the unstored operands it was formed from, and its own.  A result that
-                // is stored, ends its slice or has gathered FOLD_MAX_MEMBERS of them pays — one vector, the product of their reciprocals
-                cur.clear();
-                if (m.k1 >= mi355::PK_H0) { const std::vector<int>& hs = holdSet[m.k1 - mi355::PK_H0]; cur.insert(cur.end(), hs.begin(), hs.end()); }
-                if (m.k2 == mi355::PK_ACC) cur.insert(cur.end(), accSet.begin(), accSet.end());
-                if (m.smode == mi355::PS_READ) cur.push_back(m.scaleIdx);
-                const bool pays = m.storeBuf >= 0 || i == ps.progStart + ps.progCount - 1 || (int)cur.size() >= FOLD_MAX_MEMBERS;
-                smodeNow = mi355::PS_NONE;
-                if (pays && !cur.empty()) {
-                    smodeNow = mi355::PS_READ;
-                    if (cur.size() == 1) d.scale = in->scale[cur[0]] + in->scaleStride;
-                    else {
-                        const int f = foldFor(in, cur);
-                        if (f < 0) return BEAGLE_ERROR_OUT_OF_MEMORY;
-                        slot->folds.push_back(f);
-                        d.scale = in->folds[(size_t)f].recip;
-                    }
-                    in->statScaleReads++;
-                    cur.clear();
+            if (fold) {                            // multiply by what the planner says this result pays for — nothing, one buffer's reciprocals, a fold
+                const int b0 = foldMap.payStart[(size_t)i], b1 = foldMap.payStart[(size_t)i + 1];
+                smodeNow = b1 > b0 ? mi355::PS_READ : mi355::PS_NONE;
+                if (b1 - b0 == 1) d.scale = in->scale[foldMap.members[(size_t)b0]] + in->scaleStride;
+                else if (b1 > b0) {
+                    cur.assign(foldMap.members.begin() + b0, foldMap.members.begin() + b1);
+                    const int f = foldFor(in, cur);
+                    if (f < 0) return BEAGLE_ERROR_OUT_OF_MEMORY;
+                    slot->folds.push_back(f);
+                    d.scale = in->folds[(size_t)f].recip;
                 }
-                if (m.hold) holdSet[m.hold - 1] = cur;
-                accSet.swap(cur);
+                if (b1 > b0) in->statScaleReads++;
             }
             if (m.storeBuf >= 0) {
                 int rc = ensurePartials(in, m.storeBuf); if (rc) return rc;
@@ -387,7 +375,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch;
         in->statFastWalks++; in->statWalks++;
         // hold the launch back for the root call?  (one partition, the whole range, not inside a timer bracket)
-        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P;
+        // ... and only a program whose slices ALL lead to one last slice: the root call's result word then says that every workgroup
+        // of the launch is done (waitResult and its callers reset the staging ring on seeing it) — a forest's other trees could
+        // still be running behind the slice that publishes
+        int sinks = 0;
+        {
+            std::vector<char> feeds(segs.size(), 0);
+            for (int d : devDeps) feeds[(size_t)d] = 1;
+            for (size_t i = 0; i < segs.size(); i++) if (!feeds[i] && segs[i].progCount > 0) sinks++;
+        }
+        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P && sinks == 1;
         if (hold) {
             pw.finalStore.assign(segs.size(), -1);
             for (size_t i = 0; i < segs.size(); i++) {

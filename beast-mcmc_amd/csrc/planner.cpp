@@ -707,4 +707,34 @@ void WalkPlanner::planMaterialize(const std::vector<int>& keys, Plan& out) {
     linkSlices(out);
 }
 
+bool foldScaleFactors(const Plan& plan, int maxMembers, FoldMap& out) {
+    const size_t n = plan.prog.size();
+    out.payStart.assign(n + 1, 0);
+    out.members.clear();
+    for (const MicroOp& m : plan.prog) if (m.smode == PS_WRITE) return false;
+    // first the count of members every micro-operation pays for (slices tile plan.prog in any order), then the lists themselves
+    std::vector<std::vector<int>> pays(n);
+    std::vector<int> acc, hold[3], cur;
+    for (const PlanSeg& sg : plan.segs) {
+        acc.clear();
+        for (std::vector<int>& h : hold) h.clear();          // (no hold slot is in use at the start of a slice)
+        for (int i = sg.progStart; i < sg.progStart + sg.progCount; i++) {
+            const MicroOp& m = plan.prog[(size_t)i];
+            cur.clear();
+            if (m.k1 >= PK_H0) { const std::vector<int>& h = hold[m.k1 - PK_H0]; cur.insert(cur.end(), h.begin(), h.end()); }
+            if (m.k2 == PK_ACC) cur.insert(cur.end(), acc.begin(), acc.end());
+            if (m.smode == PS_READ) cur.push_back(m.scaleIdx);
+            if (m.storeBuf >= 0 || i == sg.progStart + sg.progCount - 1 || (int)cur.size() >= maxMembers) { pays[(size_t)i] = cur; cur.clear(); }
+            if (m.hold) hold[m.hold - 1] = cur;
+            acc.swap(cur);
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        out.payStart[i] = (int)out.members.size();
+        out.members.insert(out.members.end(), pays[i].begin(), pays[i].end());
+    }
+    out.payStart[n] = (int)out.members.size();
+    return true;
+}
+
 }  // namespace mi355

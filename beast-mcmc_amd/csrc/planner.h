@@ -54,6 +54,16 @@ struct Plan {
     void clear() { prog.clear(); segs.clear(); deps.clear(); launchOrder.clear(); snapPairs.clear(); }
 };
 
+// Read-mode programs: where the reciprocal scale factors are applied.  A result that is not stored is seen by nobody but the
+// micro-operation that consumes it, and a partial is linear in each of its children — so an unstored result may pass the
+// factors it owes (its own and those its unstored operands passed on) to its consumer, and only a result that IS stored, that
+// ends its slice, or that has gathered `maxMembers` of them pays: one multiplication by the product of the members'
+// reciprocals.  foldScaleFactors says, per micro-operation of plan.prog, which scale buffers it pays for:
+// members[payStart[i] .. payStart[i + 1]) (none: it multiplies by nothing; one: that buffer's own reciprocals; several: a fold the
+// engine builds, engine_walk.cpp).  false: the program rescales in write mode somewhere (nothing is folded then).
+struct FoldMap { std::vector<int> payStart, members; };
+bool foldScaleFactors(const Plan& plan, int maxMembers, FoldMap& out);
+
 // Definition of a virtual buffer: one step per internal node of a small all-compact-tip subtree, in post-order (a step's
 // sub-steps precede it; the last step is the buffer's own node).  An operand of a step is a compact tip or an earlier
 // step; `need` = hold slots its evaluation takes (Sethi-Ullman: two internal operands -> the costlier one first, parked

@@ -226,6 +226,12 @@ int shardedFinalize(int handle) {
 }
 
 int shardedShardCount(int handle) { Sharded* sh = find(handle); return sh ? (int)sh->shards.size() : -1; }
+int shardedCommRanks(int handle) {
+    Sharded* sh = find(handle);
+    if (!sh || !sh->useRccl || sh->shards.empty() || !sh->shards[0].comm) return 0;
+    int n = 0;
+    return ncclCommCount(sh->shards[0].comm, &n) == ncclSuccess ? n : 0;
+}
 
 int shardedBroadcast(int handle, const std::function<int(int)>& call) {
     GET_SHARDED(handle);
@@ -295,8 +301,14 @@ int shardedRootReduce(int handle, int count, const std::function<int(int shardHa
         // synchronisation and a synchronisation of every other shard cost more than a small shard's kernels.  The other shards
         // are not waited for: their rank of the all-reduce has contributed when shard 0's completes, and what follows on their
         // streams is ordered behind it by the streams themselves (their staging rings drain when they wrap).
-        const int rcp = publishAndWait(sh->shards[0].handle, sh->shards[0].dResult, count, outValues);
-        if (rcp) return rcp;
+        // (the result page holds 480 doubles behind its header: a longer vector — up to 512 partitions — goes in two pieces)
+        for (int b = 0; b < count; b += 480) {
+            const int rcp = publishAndWait(sh->shards[0].handle, sh->shards[0].dResult + b, std::min(480, count - b), outValues + b);
+            if (rcp) return rcp;
+        }
+        // a deferred error of another shard (an upload kernel that could not be launched) must not go unseen just because nobody
+        // waits on that shard: the first one found fails this call, as shard 0's own would inside publishAndWait
+        for (int k = 1; k < n; k++) { const int rce = takeAsyncError(sh->shards[k].handle); if (rce) return rce; }
         return BEAGLE_SUCCESS;
     } else {
         std::vector<double> acc(count, 0.0), part(count);

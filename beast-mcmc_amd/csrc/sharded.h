@@ -15,6 +15,7 @@ int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compa
                   long requirementFlags, BeagleInstanceDetails* returnInfo);
 int shardedFinalize(int handle);
 int shardedShardCount(int handle);
+int shardedCommRanks(int handle);           // ranks of the in-library communicator as RCCL counts them (0: host-side sum)
 int shardedPatternCount(int handle);
 int shardedStates(int handle);
 int shardedCategories(int handle);
@@ -42,5 +43,7 @@ int shardedSumDoubles(int handle, int len, const std::function<int(int shardHand
 // the host through the instance's mapped result words — one small kernel behind whatever is on the instance's stream, then a
 // poll — instead of a device-to-host copy and a stream synchronisation.  count <= 480.
 int publishAndWait(int instance, const double* dValues, int count, double* out);
+// the first error a deferred operation of (single-GPU) instance `instance` left behind, cleared (0: none); no synchronisation
+int takeAsyncError(int instance);
 
 }  // namespace mi355

@@ -192,6 +192,8 @@ class MultiPartitionTreeLikelihood:
         self._lens_stale = True
         f, fn, h, chk = self._fast, b._f, b.instance, b._check
         node = int(node)
+        if node < T or node >= len(tree.left) or tree.left[node] < 0 or tree.right[node] < 0:
+            raise ValueError("move_node_height: node %d is not an internal node (tips keep height 0)" % node)
         branches = [int(tree.left[node]), int(tree.right[node])] + ([node] if node != tree.root else [])
         path = []
         n = node

@@ -91,6 +91,12 @@ class ShardedTreeLikelihood:
                 th.start()
                 th.join(float(os.environ.get("BEAGLE_MI355_COMM_INIT_TIMEOUT_S", "120")))
                 ok = 0 if th.is_alive() else state["ok"]
+                if th.is_alive():
+                    # the helper thread is still inside beagleMi355CommInit ON THAT INSTANCE — an instance is driven by one thread
+                    # at a time, and a late rendezvous would set its communicator under the main thread's feet.  The instance is
+                    # left to the straggler (kept alive here, never called again) and this rank continues on a fresh one.
+                    self._abandoned = (self.local, th)
+                    self.local = BeagleTreeLikelihood(workload.shard(start, stop), library=library, **kw)
             if dist is not None and world_size > 1:   # every rank takes the same route: all of them have a communicator, or none uses it
                 flag = torch.tensor([ok], dtype=torch.int32, device=device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)

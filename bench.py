@@ -3,8 +3,9 @@
 patterns, fp64 (BASELINE.json `metric`, config "GTR+G4 nucleotide (4-state), 1000 taxa x 1e5 unique patterns").
 
 One "step" = one full-tree evaluation driven through the C ABI exactly as BEAST drives it after a substitution-model
-+ site-model move: setEigenDecomposition + setCategoryRates (NEW values every step: the parameters alternate between
-two nearby models, so nothing the engine could skip as "unchanged" is) + updateTransitionMatrices(2T-2 branches) +
++ site-model move: setEigenDecomposition + setCategoryRates (NEW values every step: the parameters cycle through THREE
+nearby models while the caller flips between two eigen slots, so every slot receives values it does not hold and nothing the
+engine could skip as "unchanged" is — perturbed_models) + updateTransitionMatrices(2T-2 branches) +
 updatePartials(T-1 level-ordered ops, steady-state DYNAMIC rescaling: read mode) + setCategoryWeights /
 setStateFrequencies + calculateRootLogLikelihoods, with the scalar result read back on the host (SURVEY 8d "Timing
 protocol").  `--caller btl` adds what the class north_star names, BeagleTreeLikelihood, does on top of that every
@@ -479,14 +480,43 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         raw.kernelTimerRestart()
         raw.kernelTimerCalls()
 
+    # (the wall-clock time of every timed step: the median beside the mean says whether the mean is one slow call's — two
+    # perf_counter reads per step, ~0.1 us)
+    per_step = []
+    plain_step = step
+
+    def step(i, inner=plain_step):                   # noqa: F811
+        t = time.perf_counter()
+        v = inner(i)
+        per_step.append(time.perf_counter() - t)
+        return v
+
     elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=restart)
+    per_step.sort()
     stats = raw.walkStats()
     kernel_ms, launches = raw.kernelTimer(False)
-    timed_calls = max(1, raw.kernelTimerCalls())
+    timed_calls = None
+    rccl = None
     if dist is not None:
+        # every rank's own kernel time and what RCCL itself says about the communicator the evaluations went through
+        timed_here = max(1, raw.kernelTimerCalls())
+        mine = torch.tensor([kernel_ms * 1e3 / timed_here, float(raw.commRanks()), 1.0 if getattr(tl, "collective", "") == "engine" else 0.0],
+                            dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = [g.cpu().tolist() for g in gathered]
+        engine_route = all(r[2] == 1.0 for r in rows)
+        rccl = {"ranks": int(min(r[1] for r in rows)) if engine_route else int(dist.get_world_size()),
+                "route": "engine" if engine_route else "torch-fallback",
+                "ranks_source": "ncclCommCount of every rank's engine communicator (minimum over ranks)" if engine_route
+                                else "torch.distributed world size (the engine-side communicator was not used)",
+                "kernel_us_per_eval_by_rank": [round(r[0], 2) for r in rows]}
+        timed_calls_cached = timed_here
         kms = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
         kernel_ms = float(kms.item())
+    if timed_calls is None:
+        timed_calls = timed_calls_cached if dist is not None else max(1, raw.kernelTimerCalls())
     evals_per_s = args.steps / elapsed
     counters = local.counters()
 
@@ -556,8 +586,11 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         out = {
             "metric": "full-tree lnL evals/sec (GTR+G4, 1e5 patterns)" if args.config == "A" else "full-tree lnL evals/sec",
             "value": round(evals_per_s, 3), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step_median": round(1e3 * per_step[len(per_step) // 2], 4) if per_step else None,
+            "ms_per_step_max": round(1e3 * per_step[-1], 4) if per_step else None,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "rccl": rccl,
             "data": ("real alignment of examples/Benchmarks/%s.xml (tests/golden), seeded coalescent tree" % args.real) if args.real else "synthetic",
             "route": args.route,
             "config": {"workload": "%s: %d taxa x %d unique patterns, %d states, %d rate categories, %s tree (%d dependency levels), "

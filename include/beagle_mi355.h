@@ -317,6 +317,10 @@ int beagleMi355GetCommUniqueId(void* out128);
 int beagleMi355CommInit(int instance, const void* uniqueId128, int rank, int rankCount);
 int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferIndex, int categoryWeightsIndex,
                                       int stateFrequenciesIndex, int cumulativeScaleIndex, double* outGlobalSum);
+/* How many ranks the instance's communicator has — RCCL's own count (ncclCommCount), 0 without a communicator; on the
+ * pattern-sharded handle (resource G+1) the ranks of its in-library communicator (0: host-side sum, no RCCL).  What a multi-GPU
+ * benchmark line quotes as proof that the collective really spanned N GPUs. */
+int beagleMi355CommInfo(int instance, int* outRanks);
 /* getPartials for `count` buffers in one call: out = [count][C][P][S] (API layout), scale factors folded in where
  * scaleIndices[k] != BEAGLE_OP_NONE (scaleIndices may be NULL).  One batched materialisation of virtual buffers, device-side
  * layout conversion, pinned copies, one synchronisation per 256 MiB — for hosts that read many nodes per sample

@@ -25,6 +25,7 @@
 using namespace mi355;
 
 static int P = 7, C = 2;
+static long foldedPlans = 0, foldedPays = 0, foldedMembers = 0, unfoldedReads = 0;
 static const char* g_where = "";
 static long g_list = 0;
 #define CHECK(cond, m, k) do { if (!(cond)) { fprintf(stderr, "FAILED %s [%s, list %ld] micro-op %d: store %d k1 %d a1 %d k2 %d a2 %d mat %d %d scale %d mode %d hold %d\n", #cond, g_where, g_list, k, (m).storeBuf, (m).k1, (m).a1, (m).k2, (m).a2, (m).mat1, (m).mat2, (m).scaleIdx, (m).smode, (m).hold); exit(1); } } while (0)
@@ -80,7 +81,9 @@ static void truthOp(World& w, const std::vector<char>& compact, const int* op, i
 }
 
 // the walk kernel's register model, index level
-static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStart, const std::vector<int>& partEnd) {
+// fold != nullptr: the engine's read-mode folding (planner.h FoldMap) — a micro-operation multiplies by the product of the reciprocals
+// of the scale buffers it pays for (nothing where it pays for none) instead of by its own node's
+static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStart, const std::vector<int>& partEnd, const FoldMap* fold = nullptr) {
     // snapshot copies: one parallel launch (all sources are read before any destination is written)
     std::vector<std::vector<double>> src;
     for (size_t i = 0; i + 1 < plan.snapPairs.size(); i += 2) src.push_back(w.mats[plan.snapPairs[i]]);
@@ -169,6 +172,10 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
                     w.scale[m.scaleIdx][p] = mx;
                     const double im = 1.0 / mx;
                     for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
+                } else if (fold) {
+                    double im = 1.0;
+                    for (int q = fold->payStart[k]; q < fold->payStart[k + 1]; q++) { CHECK(!w.scale[fold->members[q]].empty(), m, k); im *= 1.0 / w.scale[fold->members[q]][p]; }
+                    if (fold->payStart[k + 1] > fold->payStart[k]) for (int c = 0; c < C; c++) for (int i = 0; i < 4; i++) r[c].v[i] *= im;
                 } else if (m.smode == PS_READ) {
                     CHECK(!w.scale[m.scaleIdx].empty(), m, k);
                     const double im = 1.0 / w.scale[m.scaleIdx][p];
@@ -278,6 +285,7 @@ struct Harness {
             bool simple = false;
             if (fixedChunk >= 0 && pl.replayCached(ops.data(), count, tuple, parts, true, fixedChunk, &simple)) {
                 assert(simple);
+                checkFolded(*pl.planned);
                 runPlan(plan, *pl.planned, partStart, partEnd);
                 fastReplays++;
                 begin = count;
@@ -298,12 +306,51 @@ struct Harness {
             waves += pl.lastWaves; segsTotal += (long)p.segs.size();
             assert(rc == 0);
             // every MEM child must be real data, every destination must end up real or virtual
+            if (begin == 0 && n == count) checkFolded(p);         // (the truth world holds the values after the WHOLE list)
             runPlan(plan, p, partStart, partEnd);
             micro += (long)p.prog.size(); holds += pl.lastHolds; memReads += pl.lastMemReads; stored += pl.lastStored;
             begin += n;
         }
         lists++; g_list = lists;
         compareAll();
+    }
+    // The engine's read-mode folding of reciprocal scale factors (planner.h foldScaleFactors): the same program with the factors of
+    // unstored results applied where the planner says must give every STORED result the value list-order evaluation gives it — to
+    // rounding (the factors are the same numbers multiplied in another order); a factor applied twice or not at all would be off
+    // by orders of magnitude.  Run on a copy of the planned world as it is before the program.
+    void checkFolded(const Plan& p) {
+        if (nBuf > 1200) return;                      // (the copy: not for the 5000-tip ladder)
+        FoldMap fm;
+        static const int caps[3] = {32, 4, 2};
+        if (!foldScaleFactors(p, caps[lists % 3], fm)) return;
+        bool anyRead = false;
+        for (const MicroOp& m : p.prog) anyRead = anyRead || m.smode == PS_READ;
+        if (!anyRead) return;
+        // every factor is paid exactly once: the members over the whole program are the program's read-mode scale indices
+        {
+            std::vector<int> want, got(fm.members);
+            for (const MicroOp& m : p.prog) if (m.smode == PS_READ) want.push_back(m.scaleIdx);
+            std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
+            if (want != got) { fprintf(stderr, "FOLD: members differ from the program's read-mode factors [%s, list %ld]\n", g_where, lists); exit(1); }
+        }
+        World shadow = plan;
+        runPlan(shadow, p, partStart, partEnd, &fm);
+        for (const PlanSeg& sg : p.segs)
+            for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) {
+                const int b = p.prog[k].storeBuf;
+                if (b < 0) continue;
+                for (int c = 0; c < C; c++)
+                    for (int q = partStart[sg.partition]; q < partEnd[sg.partition]; q++)
+                        for (int i = 0; i < 4; i++) {
+                            const double x = shadow.partials[b][((size_t)c * P + q) * 4 + i], t = truth.partials[b][((size_t)c * P + q) * 4 + i];
+                            if (!(std::fabs(x - t) <= 1e-12 * std::fabs(t))) {
+                                fprintf(stderr, "FOLD MISMATCH buffer %d pattern %d: %.17g against %.17g [%s, list %ld]\n", b, q, x, t, g_where, lists); exit(1);
+                            }
+                        }
+            }
+        foldedPlans++;
+        for (size_t k = 0; k < p.prog.size(); k++) { if (fm.payStart[k + 1] > fm.payStart[k]) foldedPays++; if (p.prog[k].smode == PS_READ) unfoldedReads++; }
+        foldedMembers += (long)fm.members.size();
     }
     // materialise without comparing: the truth world already holds the values AFTER the list (used for buffers whose
     // old definition is about to be invalidated by a scale rewrite — their truth value is the OLD one only if the list
@@ -576,6 +623,8 @@ int main(int argc, char** argv) {
     scenarioMcmc(5000, true, true, 9, 3, false);     // 4999 dependency levels
     scenarioMcmc(5000, false, true, 11, 2, false);
     scenarioMcmc(3000, true, false, 10, 5, false);
+    printf("read-mode folding: %ld programs, %ld factor reads became %ld (%ld members)\n", foldedPlans, unfoldedReads, foldedPays, foldedMembers);
+    if (foldedPlans < 100 || foldedPays * 2 > unfoldedReads) { fprintf(stderr, "read-mode folding was hardly exercised\n"); return 1; }
     printf("plan_check: OK\n");
     return 0;
 }
