@@ -241,18 +241,17 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             // (a micro-operation that rescales in write mode also stores its factors, from one of the workgroup's waves only: behind
             // it the count is the strict one whatever the mode)
             const bool prevWrites = i > first && ((w[i - 1].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
-            const bool prev2Writes = i > first + 1 && ((w[i - 2].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
             const int stores1 = (in->strictWaits || prevWrites) ? 0 : (i > first ? mi355::walkStoreCount(w[i - 1].flags) : 0);
             w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores1, 12));
             if (!asmLoop) continue;
-            // k_walk4_fast (three deep; every fetch is FOUR small loads).  Issue order around stage i: ... fetch(i) | first child of
-            // i - 1 from memory (4) | store(i - 2) | fetch(i + 1) | first child of i from memory (4) | store(i - 1) | fetch(i + 2) | WAIT.
-            // A first child of i in memory has to have landed as well: then only what follows it counts.
-            const bool lax = !in->strictWaits && !prevWrites && !prev2Writes;
-            const int st1 = lax && i > first ? mi355::walkStoreCount(w[i - 1].flags) : 0;
-            const int st2 = lax && i > first + 1 ? mi355::walkStoreCount(w[i - 2].flags) : 0;
+            // k_walk4_fast (three deep; a fetch is THREE small loads, four with the reciprocal scale factors: WF_INV).  Issue order around
+            // stage i: ... fetch(i) | first child of i - 1 from memory (4) | store(i - 2) | fetch(i + 1) | first child of i from memory
+            // (4) | store(i - 1) | fetch(i + 2) | WAIT.  A first child of i in memory has to have landed as well: then only what
+            // follows it counts.  (Loads only — the strict rule — whatever BEAGLE_MI355_STRICT_WAITS says: with two fetch sizes the
+            // code space has no room for the store counts of the lax rule, which bought 1 %.)
+            auto fetchLoads = [&](int j) { return 3 + ((w[j].flags & mi355::WF_INV) ? 1 : 0); };     // (the no-ops behind a program: 3)
             const int x1 = i > first && (w[i - 1].flags & mi355::WF_X) ? 4 : 0;
-            const int nWait = (w[i].flags & mi355::WF_X) ? 4 + st1 : 8 + x1 + st1 + st2;
+            const int nWait = (w[i].flags & mi355::WF_X) ? fetchLoads(i + 2) : fetchLoads(i + 1) + fetchLoads(i + 2) + x1;
             w[i].flags |= mi355::walkWaitCode(nWait);
         }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];

@@ -76,12 +76,18 @@ enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
 // (bit 14 = WS_WRITE of the scale mode: the assembly loop tests it directly)
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
-// second child in memory, the result is parked in a hold slot, and the stage's wait as a 2-bit code at bit 28 (walkWaitCode)
-enum { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT_SHIFT = 28,
-       WF_HREAD2 = 1u << 30 };
+// second child in memory, the result is parked in a hold slot, and the stage's wait as a 3-bit code at bit 28 (walkWaitCode)
+enum : unsigned { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT_SHIFT = 28,
+                  WF_HREAD2 = 1u << 31 };
 // k_walk4_fast's pipeline is three micro-operations deep: the wait of stage k is "at most N vector-memory instructions outstanding",
-// N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan): 8, 12, 16 or 4
-inline unsigned walkWaitCode(int n) { return (unsigned)(n >= 16 ? 2 : n >= 12 ? 1 : n >= 8 ? 0 : 3) << WF_WAIT_SHIFT; }
+// N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan).  A fetch is three loads, four
+// for a micro-operation that multiplies by reciprocal scale factors (WF_INV), so N is 6..8, + 4 behind a first child from memory,
+// or 3..4 when the stage's own first child comes from memory.  Codes (tools/gen_walk4_fast.py WAIT_N): 0..7 = 6, 7, 8, 10, 11, 12,
+// 3, 4; anything else is rounded DOWN to the next of these (a smaller N only waits longer).
+inline unsigned walkWaitCode(int n) {
+    const int code = n >= 12 ? 5 : n == 11 ? 4 : n == 10 ? 3 : n >= 8 ? 2 : n == 7 ? 1 : n == 6 ? 0 : n >= 4 ? 7 : 6;
+    return (unsigned)code << WF_WAIT_SHIFT;
+}
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
@@ -116,7 +122,7 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     return f;
 }
 // vector-memory instructions the kernel's fetch stage issues for a micro-operation / its store stage
-// of k_walk4 (k_walk4_fast always issues 4, + 4 with WF_X)
+// of k_walk4 (k_walk4_fast: 3, + 1 with WF_INV, + 4 with WF_X)
 inline int walkFetchCount(unsigned f) { return ((f & WF_X) ? 4 : 0) + ((f & WF_T1) ? 2 : 0) + ((f & WF_T2) ? 2 : 0) + ((f & WF_INV) ? 2 : 0) + 1; }
 inline int walkStoreCount(unsigned f) { return (f & WF_STORE) ? 4 : 0; }
 // flags field "waitJump" of micro-operation k: 8 N + 12 with N = walkFetchCount(k+1) (engine_walk.cpp runPlan, kernels_walk4.hip)

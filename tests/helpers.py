@@ -96,6 +96,17 @@ def random_workload(tip_count, pattern_count, state_count, categories, seed, tre
                                root_to_tip=root_to_tip, unknown_fraction=unknown_fraction)
 
 
+def proposed_height(tree, node, rng, spread=0.3):
+    """A new height for internal node `node` that keeps every branch length positive: somewhere between its higher child and its
+    parent (the root: up to 5 % above itself), `spread` of that interval around the current height at most."""
+    lo = max(float(tree.height[int(tree.left[node])]), float(tree.height[int(tree.right[node])]))
+    parent = [n for n in range(tree.tip_count, tree.node_count) if int(tree.left[n]) == node or int(tree.right[n]) == node]
+    h = float(tree.height[node])
+    hi = float(tree.height[parent[0]]) if parent else h * 1.05
+    a, b = max(lo + 1e-3 * (hi - lo), h - spread * (hi - lo)), min(hi - 1e-3 * (hi - lo), h + spread * (hi - lo))
+    return float(rng.uniform(a, b)) if b > a else h
+
+
 def sample_with_tail(pattern_count, n_sample, seed):
     """Pattern indices for a sampled full-size check: a seeded random sample PLUS, always, the last 256 patterns — the ragged
     last 128-pattern group of a buffer (and the last 32-pattern tile) must be in every sample, not left to the seed."""

@@ -121,7 +121,7 @@ def test_folds_follow_the_factors_through_a_chain(oracle_lib):
                 tl.makeDirty()
         else:                                 # a height move
             node = int(rng.integers(wl.tree.tip_count, wl.tree.node_count - 1))
-            h = float(wl.tree.height[node]) * (1.0 + 0.02 * rng.standard_normal())
+            h = helpers.proposed_height(wl.tree, node, rng)
             for tl in tls:
                 tl.storeState()
                 tl.set_node_height(node, h)
@@ -134,22 +134,22 @@ def test_folds_follow_the_factors_through_a_chain(oracle_lib):
             v = [tl.getLogLikelihood() for tl in tls]
             assert helpers.rel_err(v[0], v[1]) <= 1e-13 and helpers.rel_err(v[0], v[2]) <= 1e-10
         builds.append(bm.beagle.Beagle.attach(tls[0]).walkHealth()["fold_builds"])
-    assert builds[0] > 0 and len(set(builds)) >= 3          # rebuilt after later write-mode evaluations, not only once
+    assert builds[-1] > 0 and len(set(builds)) >= 3         # rebuilt after later write-mode evaluations, not only once
     for tl in tls:
         tl.close()
 
 
 def test_a_fold_out_of_range_falls_back_to_per_node_factors(oracle_lib):
-    """A ladder with branches of 1e-8 substitutions and random tip states: nearly every node's factor is ~1e-8, a fold of 32 of
-    them would hold 1e256 — refused (safe range 1e200); the plan is resolved again with per-node factors: the same bits as with
-    folding switched off."""
-    T, P = 140, 600
-    tree = trees.caterpillar_tree(T, root_height=1e-6)
+    """Branches of ~1e-12 substitutions and random tip states: nearly every node's factor is ~1e-12, and the unstored runs of this
+    tree (buffers of 2 MiB: definitions of up to 24 nodes) would fold 17 and more of them — beyond the safe range (1e200): refused; the
+    plan is resolved again with per-node factors: the same bits as with folding switched off."""
+    T, P = 96, 17000
     rng = np.random.default_rng(99)
+    tree = trees.coalescent_tree(T, rng, root_height=1e-10)
     pi = np.array([0.3, 0.2, 0.22, 0.28])
     eig = substmodel.gtr([1.0, 4.0, 0.8, 1.2, 4.5, 1.0], pi)
     tips = rng.integers(0, 4, size=(T, P)).astype(np.int32)
-    wl = Workload("ladder-conflict", tree, eig, pi, [1.0], [1.0], np.ascontiguousarray(tips), np.ones(P), 4)
+    wl = Workload("conflict", tree, eig, pi, [1.0, 1.0, 1.0, 1.0], [0.25, 0.25, 0.25, 0.25], np.ascontiguousarray(tips), np.ones(P), 4)
     f0, fv, fs, _, _, fstats, fh = steady_state(wl, True)
     u0, uv, us, _, _, ustats, uh = steady_state(wl, False)
     assert fh["fold_builds"] > 0 and fh["folded_vectors"] == 0           # tried, refused
@@ -158,4 +158,4 @@ def test_a_fold_out_of_range_falls_back_to_per_node_factors(oracle_lib):
     o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
     ref = o.getLogLikelihood()
     o.close()
-    assert helpers.rel_err(fv[-1], ref) <= 1e-9
+    assert helpers.rel_err(fv[-1], ref) <= 1e-6       # (matrix entries of 1e-12 carry four digits of their own rounding)

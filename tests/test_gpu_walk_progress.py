@@ -40,7 +40,7 @@ def chain(wl, spin_us, scheme, moves=12):
     for _ in range(moves):
         node = int(r.integers(wl.tree.tip_count, wl.tree.node_count - 1))
         tl.storeState()
-        tl.set_node_height(node, float(wl.tree.height[node]) * (1.0 + 0.01 * r.standard_normal()))
+        tl.set_node_height(node, helpers.proposed_height(wl.tree, node, r))
         vals.append(tl.getLogLikelihood())
         if r.random() < 0.4:
             tl.restoreState()

@@ -57,9 +57,13 @@ DIVS, SCNT, EXCH, NCAT, ROFF, RB = 76, 78, 79, 80, 81, 82    # RB: byte offset o
 S_FIRST = 20
 
 # flag bits (kernels.h)
-B_X, B_T1, B_T2, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 4, 12, 14
-B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_WAIT1, B_HREAD2 = 24, 25, 26, 27, 28, 29, 30
-# the stage's wait as a 2-bit code at B_WAIT0 (kernels.h walkWaitCode): 0 = vmcnt(8), 1 = 12, 2 = 16, 3 = 4
+B_X, B_T1, B_T2, B_INV, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 3, 4, 12, 14
+B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
+# the stage's wait as a 3-bit code at B_WAIT0 (kernels.h walkWaitCode): vmcnt(N) with N = WAIT_N[code]; code 0 is the common one
+# (a fetch is THREE small loads — matrix table, two tip-state pairs — and a fourth, the reciprocal scale factors, only for a
+# micro-operation that multiplies by them: since round 5 a read-mode program applies the factors of unstored results once, at the
+# stored result above them, so nine micro-operations in ten fetch three)
+WAIT_N = (6, 7, 8, 10, 11, 12, 3, 4)
 
 # Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
 # in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
@@ -273,10 +277,15 @@ def fetch(tag, slot):
     e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
     e("s_mov_b32 %s, %s" % (s(FLS[slot]), s(DFL)))
     e("s_mov_b64 %s, %s" % (s(SCALEWS[slot], 2), s(DW, 2)))
+    # the reciprocal scale factors: only where the micro-operation multiplies by them (WF_INV) — out of line, so that the common
+    # case is a test that falls through
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_INV))
+    e("s_cbranch_scc1 %s" % L("iv" + tag))
+    e(L("ivb" + tag) + ":")
     if "noinv" in EXPERIMENT:
-        e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
+        outofline.append([L("iv" + tag) + ":", "global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)), "s_branch %s" % L("ivb" + tag)])
     else:
-        e("global_load_dwordx4 %s, %s, %s" % (v(INVS[slot], 4), v(SCALE), s(D + 6, 2)))
+        outofline.append([L("iv" + tag) + ":", "global_load_dwordx4 %s, %s, %s" % (v(INVS[slot], 4), v(SCALE), s(D + 6, 2)), "s_branch %s" % L("ivb" + tag)])
 
 
 def first_child_fetch(tag, SFLn, off_src1):
@@ -321,16 +330,32 @@ def stage(tag, cur):
     # wait for this micro-operation's loads: N = what was issued after them and may stay outstanding — the fetches of k + 1 and
     # k + 2 (8), a first child of k - 1 from memory (+4), stores where the engine counts them (engine_walk.cpp runPlan);
     # 4 when this micro-operation's own first child comes from memory (requested a stage ago, behind the fetch of k + 1)
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), 3 << B_WAIT0))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), 7 << B_WAIT0))
     e("s_cbranch_scc1 %s" % L("ws" + tag))
     novm = "novmwait" in EXPERIMENT
-    e("s_nop 0" if novm else "s_waitcnt vmcnt(8)")
+    e("s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[0])
     e(L("wd" + tag) + ":")
-    outofline.append([L("ws" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT1), "s_cbranch_scc1 %s" % L("w16" + tag),
-                      "s_nop 0" if novm else "s_waitcnt vmcnt(12)", "s_branch %s" % L("wd" + tag),
-                      L("w16" + tag) + ":", "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WAIT0), "s_cbranch_scc1 %s" % L("w4" + tag),
-                      "s_nop 0" if novm else "s_waitcnt vmcnt(16)", "s_branch %s" % L("wd" + tag),
-                      L("w4" + tag) + ":", "s_nop 0" if novm else "s_waitcnt vmcnt(4)", "s_branch %s" % L("wd" + tag)])
+    # the other codes, out of line: code 2 (both following micro-operations fetch four: programs that pay at every node — partial
+    # updates, write-mode lists) first, the rest through a jump table of (wait, branch) pairs
+    blk = [L("ws" + tag) + ":",
+           "s_bfe_u32 %s, %s, 0x%x" % (s(ST), s(SFL), (3 << 16) | B_WAIT0),
+           "s_cmp_eq_u32 %s, 2" % s(ST),
+           "s_cbranch_scc0 %s" % L("wt" + tag),
+           "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[2],
+           "s_branch %s" % L("wd" + tag),
+           L("wt" + tag) + ":",
+           "s_lshl_b32 %s, %s, 3" % (s(ST), s(ST)),
+           "s_getpc_b64 %s" % s(SX, 2),                       # (SX: the scratch pair of the first-child block, free here)
+           "s_add_u32 %s, %s, %s" % (s(SX), s(SX), s(ST)),
+           "s_addc_u32 %s, %s, 0" % (s(SX + 1), s(SX + 1)),
+           "s_add_u32 %s, %s, 12" % (s(SX), s(SX)),          # table entry `code` starts 20 + 8 code bytes behind s_getpc's successor ...
+           "s_addc_u32 %s, %s, 0" % (s(SX + 1), s(SX + 1)),
+           "s_setpc_b64 %s" % s(SX, 2)]
+    # (... five 4-byte instructions follow s_getpc_b64 up to and including s_setpc_b64: entry 0 would sit at + 20; entries are 8 bytes
+    # and entry 0 is never taken, so the table proper starts at entry 1 = + 20 + 8 - 8: the constant above is 20 - 8 = 12)
+    for code in range(1, 8):
+        blk += ["s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[code], "s_branch %s" % L("wd" + tag)]
+    outofline.append(blk)
     off_src2 = -3 * 64 + 8
     off_src1_next = -2 * 64
     off_store = -4 * 64 + 16
@@ -391,15 +416,20 @@ def stage(tag, cur):
     e("s_addc_u32 %s, %s, 0" % (s(DP + 1), s(DP + 1)))
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
-    for i in range(8):
-        e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
     pad_block()
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WRITE) | (1 << B_STORE)))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WRITE) | (1 << B_STORE) | (1 << B_INV)))
     e("s_cbranch_scc1 %s" % L("tl" + tag))
     e(L("tlb" + tag) + ":")
-    # the rare tail — write-mode rescaling, a result that is stored — out of line: the two tests of old, each with its block, then
-    # back; a result that is parked in a hold slot is every third micro-operation's case and keeps its own test
+    # the rare tail — a result that pays scale factors (read mode: one multiplication by the reciprocals fetched with it), write-mode
+    # rescaling, a result that is stored — out of line: one test each with its block, then back; a result that is parked in a hold
+    # slot is every third micro-operation's case and keeps its own test (behind the tail: what is parked is the scaled value)
+    mulblk = [L("ml" + tag) + ":"]
+    for i in range(8):
+        mulblk.append("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(INV + (0 if i < 4 else 2), 2)))
+    mulblk.append("s_branch %s" % L("mlb" + tag))
+    outofline.append(mulblk)
     outofline.append([L("tl" + tag) + ":",
+                      "s_bitcmp1_b32 %s, %d" % (s(SFL), B_INV), "s_cbranch_scc1 %s" % L("ml" + tag), L("mlb" + tag) + ":",
                       "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WRITE), "s_cbranch_scc1 %s" % L("wr" + tag), L("wrb" + tag) + ":",
                       "s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE), "s_cbranch_scc1 %s" % L("st" + tag), L("stb" + tag) + ":",
                       "s_branch %s" % L("tlb" + tag)])
