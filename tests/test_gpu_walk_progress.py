@@ -63,7 +63,9 @@ def test_workgroups_that_stop_waiting_compute_the_same_bits(T, P, C, kind, schem
     dv, ds, dp, dh, dfused = chain(wl, None, scheme)
     fv, fs, fp, fh, ffused = chain(wl, 0, scheme)
     assert dh["spin_limit_us"] == 20000 and dh["self_served"] == 0      # gfx950 dispatches in order: nobody's wait runs out
-    assert fh["spin_limit_us"] == 0 and fh["self_served"] > 0            # ... and here everybody's did
+    assert fh["spin_limit_us"] == 0                                      # ... and here everybody's did
+    if kind != "caterpillar":                                            # (a ladder has no side subtrees to cut off: one slice, nobody waits)
+        assert fh["self_served"] > 0
     assert dv == fv
     assert np.array_equal(ds, fs)
     for a, b in zip(dp, fp):
