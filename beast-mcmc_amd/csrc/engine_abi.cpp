@@ -354,6 +354,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
+    in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&
+                          !(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL")) != 0);
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;

@@ -42,6 +42,7 @@ namespace eng {
 constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
 constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
+constexpr int GRADIENT_VIRT_STEPS = 2;     // longest definition a gradient chain leaves unstored (Instance::gradientVirtual)
 
 struct Instance {
     int device = 0;
@@ -119,7 +120,14 @@ struct Instance {
     std::vector<int> scaleOfPartial; std::vector<unsigned> scaleVersionAtWrite, scaleVersion;
     bool trackScales = false;
     long statFusedGradients = 0, statPreLists = 0, statWalkedGradients = 0, statLateLists = 0;
-    int storeAllEvaluations = 0;                         // > 0: post-order passes leave no node unstored (a pre-order pass asked for them)
+    int storeAllEvaluations = 0;                         // > 0: a gradient chain is running — its post-order passes store what the pre-order
+                                                         // pass will read: every node, or (gradientVirtual) every node but the short
+                                                         // definitions the pre-order walk re-evaluates from the tips itself
+    // 4 states: a gradient chain's post-order passes keep definitions of up to GRADIENT_VIRT_STEPS steps (tip-tip nodes, and those
+    // under one more tip — half the nodes of a coalescent tree) instead of storing every node, and k_preWalk4 re-evaluates them where
+    // it needs them (engine_preorder.cpp walkableDefinition): half the bytes of both passes.  BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1 at
+    // creation: every node stored, as before round 5 (A/B runs).
+    bool gradientVirtual = false;
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials
     bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)

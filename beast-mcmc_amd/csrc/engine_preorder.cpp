@@ -74,6 +74,32 @@ int preLevelTwoPass(Instance* in, const OpDesc* ops, int nOps) {
     return 0;
 }
 
+// Does the pre-order walk (kernels_preorder4.hip k_preWalk4) re-evaluate this post-order operand by itself?  A definition of one
+// step (a node over two compact tips) or two (such a node under one more compact tip): what a gradient chain's post-order passes
+// leave unstored (engine_walk.cpp runOperationsWalk: planner.h stepLimit) — about half the nodes of a coalescent tree.
+static bool walkableDefinition(const Instance* in, int buf) {
+    if (!in->gradientVirtual || in->partitionCount != 1 || !isVirt(in, buf)) return false;
+    const mi355::VirtDef& d = in->planner.definition(in->planner.key(buf, 0));
+    if (!d.on || d.nSteps < 1 || d.nSteps > 2) return false;
+    const mi355::VirtStep& s0 = d.steps[0];
+    if (s0.type != mi355::VT_CHERRY || s0.memA || s0.memB || !in->tipStates[s0.tipA] || !in->tipStates[s0.tipB]) return false;
+    if (d.nSteps == 2) {
+        const mi355::VirtStep& s1 = d.steps[1];
+        if (s1.type != mi355::VT_EXTEND || s1.subA != 0 || s1.memB || !in->tipStates[s1.tipB]) return false;
+    }
+    return true;
+}
+// the held list is about to run on kernels that read real partials: its unstored operands get theirs
+static int materializeHeldOperands(Instance* in) {
+    if (!in->virt) return 0;
+    std::vector<int> need;
+    for (const Instance::HeldPreNode& nd : in->heldPre.nodes) {
+        if (isVirt(in, nd.postA)) in->planner.keysOf(nd.postA, need);
+        if (isVirt(in, nd.postB)) in->planner.keysOf(nd.postB, need);
+    }
+    return need.empty() ? 0 : materializeList(in, need);
+}
+
 // Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
 // matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
 // levelised like a post-order one and each level is one launch.
@@ -103,14 +129,21 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         }
     }
     if (mayHold && in->S == 4 && in->fuseGradient) in->trackScales = true;     // (from now on updatePartials records scale indices: engine_abi.cpp)
-    // everything these ops read must be real data, and nothing they overwrite may still define a virtual buffer
-    std::vector<int> need;
+    // everything these ops read must be real data — except, for a list that is going to be held back and walked, the short
+    // definitions the walk re-evaluates itself —, and nothing they overwrite may still define a virtual buffer
+    const bool mayWalk = mayHold && in->fuseGradient && in->S == 4 && !in->tiled && globalCum == BEAGLE_OP_NONE && in->gradientVirtual && in->preWalk;
+    std::vector<int> need, deferred;
+    long unstoredOperands = 0;
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
         const int dest = op[0], wS = op[1], par = op[3], sib = op[5];
         in->scaleOfPartial[dest] = -1;                    // (a pre-order partial: never a post-order operand of the walk)
         if (wS != BEAGLE_OP_NONE) in->scaleVersion[wS]++;
-        if (isVirt(in, sib)) need.push_back(sib);
+        if (isVirt(in, sib)) {
+            unstoredOperands++;
+            if (mayWalk && wS == BEAGLE_OP_NONE && op[2] == BEAGLE_OP_NONE && walkableDefinition(in, sib)) deferred.push_back(sib);
+            else need.push_back(sib);
+        }
         if (isVirt(in, par)) need.push_back(par);
         if (in->virt) {
             need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
@@ -128,7 +161,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     // materialised first, the chain is evaluating gradients, and the next post-order passes store what they compute straight
     // away instead of leaving it to a second walk (runOperationsWalk; 1000 x 20 000: 1.86 -> 0.9 ms for the post-order half).
     // The hint is renewed by every pre-order list and runs out 16 post-order evaluations after the last one.
-    if ((int)need.size() >= std::max(4, count / 4) || in->storeAllEvaluations > 0) in->storeAllEvaluations = 16;
+    if ((int)unstoredOperands >= std::max(4, count / 4) || in->storeAllEvaluations > 0) in->storeAllEvaluations = 16;
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     std::vector<OpDesc> descs(count);
     std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
@@ -145,6 +178,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         d.dest = in->partials[dest];
         d.child1 = in->partials[par];
         if (in->tipStates[sib] && sib < in->tipCount) { d.child2 = in->tipStates[sib]; d.kind = mi355::KIND_STATES2; }
+        else if (isVirt(in, sib)) d.child2 = nullptr;     // (one of `deferred`: filled in below should the list run here after all)
         else if (in->partials[sib]) d.child2 = in->partials[sib];
         else return BEAGLE_ERROR_OUT_OF_RANGE;
         d.mat1 = mc; d.mat2 = ms;
@@ -166,6 +200,15 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     if (mayHold && in->fuseGradient && in->S == 4 && !in->tiled && globalCum == BEAGLE_OP_NONE) {
         int rc = holdPreList(in, ops, count);
         if (rc <= 0) return rc;                                    // held (0) or failed (< 0); 1 = not the shape: run it now
+    }
+    if (!deferred.empty()) {                                       // it runs now, on kernels that read real partials
+        std::vector<int> keys;
+        for (int b : deferred) if (isVirt(in, b)) in->planner.keysOf(b, keys);
+        if (!keys.empty()) { int rc = materializeList(in, keys); if (rc) return rc; }
+        for (int k = 0; k < count; k++) {
+            const int sib = ops[(size_t)k * BEAGLE_OP_COUNT + 5];
+            if (!descs[k].child2) { if (!in->partials[sib]) return BEAGLE_ERROR_OUT_OF_RANGE; descs[k].child2 = in->partials[sib]; }
+        }
     }
     in->statPreLists++;
     std::vector<int> start(maxLevel + 2, 0);
@@ -277,7 +320,7 @@ int holdPreList(Instance* in, const int* ops, int count) {
         maxLevel = std::max(maxLevel, nd.level);
         for (int w = 0; w < 2; w++) {                              // what the kernels will dereference has to be there
             const int po = w ? nd.postB : nd.postA;
-            if (!(in->tipStates[po] && po < in->tipCount) && !in->partials[po]) return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (!(in->tipStates[po] && po < in->tipCount) && !in->partials[po] && !isVirt(in, po)) return BEAGLE_ERROR_OUT_OF_RANGE;
             if (jobOfDest[po] >= 0) return 1;                      // a post-order operand that is one of the list's own destinations
         }
         if (!in->partials[nd.par] || !in->partials[nd.preA] || !in->partials[nd.preB]) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -400,6 +443,7 @@ static int launchHeldLevels(Instance* in, const std::vector<mi355::PreNodeJob>& 
 // the held list runs: every pre-order partial it defines is written (one sweep per tree level, k_preNode4)
 int executeHeldPre(Instance* in) {
     if (!in->heldPre.held) return 0;
+    { int rcm = materializeHeldOperands(in); if (rcm) return rcm; }
     std::vector<mi355::PreNodeJob> jobs; std::vector<int> start;
     heldJobs(in, nullptr, nullptr, jobs, start);
     in->heldPre.held = false;
@@ -429,6 +473,7 @@ static int heldEdges(Instance* in, const int* postIdx, const int* preIdx, const 
 static int fusedGradient(Instance* in, const std::vector<int>& edgeOf, const int* dIdx, int wIdx, int count, double* outSum, double* outSumSquared) {
     const int nb = mi355::edgeBlocks(in->P);
     if ((size_t)count * nb * 2 * sizeof(double) > ((size_t)512 << 20)) return 1;
+    { int rcm = materializeHeldOperands(in); if (rcm) return rcm; }
     std::vector<mi355::PreNodeJob> jobs; std::vector<int> start;
     heldJobs(in, edgeOf.data(), dIdx, jobs, start);
     int rc = ensureEdgeScratch(in, (size_t)count * (nb + 1) * 2 * sizeof(double)); if (rc) return rc;
@@ -454,7 +499,15 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     const int waves = mi355::preWalkWaves(in->P, in->C);
     const size_t sumBytes = (size_t)(count + 1) * waves * sizeof(double), outBytes = (size_t)count * sizeof(double);
     if (sumBytes > ((size_t)1 << 30)) return 1;
-    if ((size_t)h.holdSlots * in->C * 128 * 16 > 160 * 1024) return 1;
+    if ((size_t)(h.holdSlots + mi355::PW_POST_SLOTS) * in->C * 128 * 16 > 160 * 1024) return 1;
+    // the list's root is what the likelihood is formed from, straight from its operands' partials: those two are real
+    {
+        const Instance::HeldPreNode& rt = h.nodes[h.segRoot[0]];
+        std::vector<int> keys;
+        if (isVirt(in, rt.postA)) in->planner.keysOf(rt.postA, keys);
+        if (isVirt(in, rt.postB)) in->planner.keysOf(rt.postB, keys);
+        if (!keys.empty()) { int rcm = materializeList(in, keys); if (rcm) return rcm; }
+    }
     if (!in->preDummyStates) {
         void* q = nullptr; int rc = devAlloc(in, &q, ((size_t)in->P + 255) & ~(size_t)255); if (rc) return rc;
         in->preDummyStates = (uint8_t*)q;
@@ -464,7 +517,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     const int nSegs = (int)h.segRoot.size();
     std::vector<mi355::PreWalkSeg> segs(nSegs);
     std::vector<mi355::PreWalkOp> prog;
-    prog.reserve(h.order.size() + 3 * (size_t)nSegs);
+    prog.reserve(2 * h.order.size() + 3 * (size_t)nSegs);
     mi355::PreWalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.postA = nop.postB = in->preRootCopy; nop.tipA = nop.tipB = in->preDummyStates; nop.slotA = nop.slotB = count;   // valid memory, the spare slot
@@ -480,9 +533,41 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
         return true;
     };
     nop.flags = mi355::PW_TIP_A | mi355::PW_TIP_B;
+    // an unstored operand `po` (walkableDefinition) as descriptors in front of the node that reads it: its value ends up in post
+    // slot `result` (the inner node of the two-step kind passes through slot 2)
+    bool anyPost = false;
+    auto stepReciprocal = [&](const mi355::VirtStep& st, const double*& out) {
+        out = in->onesScale;
+        if (st.scaleIdx == mi355::PLAN_NONE) return true;
+        if (!in->scale[st.scaleIdx] || !in->scaleIsRaw[st.scaleIdx]) return false;
+        out = in->scale[st.scaleIdx] + in->scaleStride;
+        return true;
+    };
+    auto emitPost = [&](int po, unsigned result) {
+        const int key = in->planner.key(po, 0);
+        const mi355::VirtDef& d = in->planner.definition(key);
+        const mi355::VirtStep& s0 = d.steps[0];
+        mi355::PreWalkOp c = nop;
+        c.flags = mi355::PW_TIP_A | mi355::PW_TIP_B | mi355::PW_POSTOP | ((d.nSteps == 2 ? 2u : result) << mi355::PW_DST_SHIFT);
+        c.tipA = in->tipStates[s0.tipA]; c.tipB = in->tipStates[s0.tipB];
+        c.matA = in->planner.snapSlot(key, 0, 0); c.matB = in->planner.snapSlot(key, 0, 1);
+        if (!stepReciprocal(s0, c.recipA)) return false;
+        prog.push_back(c);
+        if (d.nSteps == 2) {
+            const mi355::VirtStep& s1 = d.steps[1];
+            mi355::PreWalkOp x = nop;
+            x.flags = mi355::PW_TIP_A | mi355::PW_TIP_B | mi355::PW_POSTOP | mi355::PW_SLOT_A | (2u << mi355::PW_SLOTA_SHIFT) | (result << mi355::PW_DST_SHIFT);
+            x.tipB = in->tipStates[s1.tipB];
+            x.matA = in->planner.snapSlot(key, 1, 0); x.matB = in->planner.snapSlot(key, 1, 1);
+            if (!stepReciprocal(s1, x.recipA)) return false;
+            prog.push_back(x);
+        }
+        anyPost = true;
+        return true;
+    };
     for (int sgi = 0; sgi < nSegs; sgi++) {
         const int first = h.segStart[sgi], n = h.segStart[sgi + 1] - first;
-        segs[sgi].progStart = (int)prog.size(); segs[sgi].progCount = (n + 1) & ~1;
+        segs[sgi].progStart = (int)prog.size();
         segs[sgi].rootPre = sgi == 0 ? in->preRootCopy : in->partials[h.nodes[h.segRoot[sgi]].par];
         for (int k = first; k < first + n; k++) {
             const Instance::HeldPreNode& nd = h.nodes[h.order[k]];
@@ -492,6 +577,15 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
                 const int po = w ? nd.postB : nd.postA;
                 const bool st = in->tipStates[po] && po < in->tipCount;
                 const int e = edgeOf[w ? nd.preB : nd.preA];
+                if (!st && isVirt(in, po)) {
+                    // not stored: re-evaluated in front of this descriptor, read from its post slot (no load but a dummy state byte)
+                    if (!walkableDefinition(in, po) || !emitPost(po, (unsigned)w)) return 1;
+                    const double* rc = nullptr;
+                    if (!reciprocalOf(po, rc)) return 1;
+                    if (w) { op.flags |= mi355::PW_TIP_B | mi355::PW_SLOT_B | (1u << mi355::PW_SLOTB_SHIFT); op.recipB = rc; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
+                    else { op.flags |= mi355::PW_TIP_A | mi355::PW_SLOT_A | (0u << mi355::PW_SLOTA_SHIFT); op.recipA = rc; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+                    continue;
+                }
                 if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else { op.postB = in->partials[po]; if (!reciprocalOf(po, op.recipB)) return 1; } if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
                 else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else { op.postA = in->partials[po]; if (!reciprocalOf(po, op.recipA)) return 1; } if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
             }
@@ -499,7 +593,9 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
             op.matA = nd.matA; op.matB = nd.matB;
             prog.push_back(op);
         }
-        for (int k = n; k < segs[sgi].progCount + 2; k++) prog.push_back(nop);
+        const int emitted = (int)prog.size() - segs[sgi].progStart;
+        segs[sgi].progCount = (emitted + 1) & ~1;
+        for (int k = emitted; k < segs[sgi].progCount + 2; k++) prog.push_back(nop);
     }
     const size_t segBytes = ((size_t)nSegs * sizeof(mi355::PreWalkSeg) + 255) & ~(size_t)255;
     const size_t progBytes = prog.size() * sizeof(mi355::PreWalkOp);
@@ -514,7 +610,7 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     rc = upload(in, in->dPreProg, segs.data(), (size_t)nSegs * sizeof(mi355::PreWalkSeg)); if (rc) return rc;
     rc = upload(in, (char*)in->dPreProg + segBytes, prog.data(), progBytes); if (rc) return rc;
     if (!mi355::launchPreWalk4(live(in), (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,
-                               in->preRootCopy, in->matrices, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots)) return 1;
+                               in->preRootCopy, in->matrices, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots, anyPost)) return 1;
     mi355::launchPreWalkFinal(live(in), dSums, count, in->P, in->C, dOut);
     std::vector<double> out(count);
     rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;

@@ -492,8 +492,14 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
     const int parts = in->partitionCount;
     // destinations may become virtual: 7-int lists of an unpartitioned instance, 9-int lists (definitions are per partition)
     bool allowVirtual = tuple == BEAGLE_PARTITION_OP_COUNT || parts == 1;
-    // (gradient evaluations want every node's partials: engine_preorder.cpp runPreOperations)
-    if (in->storeAllEvaluations > 0) { in->storeAllEvaluations--; allowVirtual = false; }
+    // (gradient evaluations want the partials of every node the pre-order pass cannot re-evaluate itself: engine_preorder.cpp
+    // runPreOperations, walkableDefinition)
+    struct StepLimit { mi355::WalkPlanner& pl; ~StepLimit() { pl.stepLimit = 0; } } stepLimitGuard{in->planner};
+    if (in->storeAllEvaluations > 0) {
+        in->storeAllEvaluations--;
+        if (in->gradientVirtual && parts == 1 && tuple == BEAGLE_OP_COUNT) in->planner.stepLimit = GRADIENT_VIRT_STEPS;
+        else allowVirtual = false;
+    }
     // The chain's steady state — the SAME full-evaluation list as one seen before, no rescaling in it — needs none of the
     // per-operation work below: it was range-checked and planned then, nothing has to be materialised or accumulated for it,
     // the planner re-establishes its definitions with one comparison per operation and the program is resident on the

@@ -305,6 +305,16 @@ constexpr int PW_SRC_SHIFT = 4, PW_CONT_A_SHIFT = 8, PW_CONT_B_SHIFT = 12;   // 
 // 2 + k = hold slot k (its descriptor comes after the other child's subtree), PW_CONT_STORE = memory (storeA / storeB)
 constexpr unsigned PW_CONT_STORE = 15u;
 constexpr int PW_MAX_HOLD = 13;
+// A post-order operand that is NOT stored (a gradient chain keeps its tip-tip nodes, and a tip-tip node under one more tip, as
+// definitions: engine_preorder.cpp) is re-evaluated from the tips where the walk needs it, by descriptors of a second kind placed
+// right in front of the node's own: PW_POSTOP: (M_A x_A) * (M_B tip_B) * recipA -> post slot `dst` (LDS, PW_POST_SLOTS per thread),
+// x_A a tip (tipA) or post slot `slotA` (PW_SLOT_A: the inner tip-tip node of the longer kind); matA / matB: the definition's
+// private matrix snapshots; recipA: the reciprocal of the node's own scale factor.  Such a descriptor asks for the same loads as
+// a node over two tips, writes no sum and leaves the walk's own state alone.  A node descriptor takes an unstored child from its
+// slot: PW_SLOT_A / PW_SLOT_B (+ PW_TIP_* so that nothing but a dummy state byte is loaded for it).
+constexpr unsigned PW_POSTOP = 1u << 16, PW_SLOT_A = 1u << 17, PW_SLOT_B = 1u << 18;
+constexpr int PW_SLOTA_SHIFT = 19, PW_SLOTB_SHIFT = 21, PW_DST_SHIFT = 23;      // 2 bits each
+constexpr int PW_POST_SLOTS = 3;
 // A walk is cut into SEGMENTS that run side by side (one more grid dimension): the first one starts at the list's root and
 // stores the pre-order partials of the nodes that head the others; those run in a second launch.  progCount even, two more
 // no-op descriptors behind every segment.
@@ -314,7 +324,8 @@ static_assert(sizeof(PreWalkSeg) == 16, "PreWalkSeg layout");
 // listRootPre its pre-order partial
 int  preWalkWaves(int P, int C);
 bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
-                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots);
+                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots,
+                    bool postSlots = false);
 void launchPreWalkFinal(hipStream_t stream, const double* sums, int nSlots, int P, int C, double* out);
 // the edge derivatives alone, same shape (32-byte vector accesses); outputs as launchEdgeDifferentials
 void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,

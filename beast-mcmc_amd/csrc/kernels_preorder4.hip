@@ -284,7 +284,7 @@ template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, const PreWalkSeg MI355_CONST* __restrict__ segs,
                                                    const double* __restrict__ listRootPre, const double* __restrict__ matrices,
                                                    const double* __restrict__ catWeights, const double* __restrict__ patternWeights,
-                                                   double* __restrict__ sums, int P, int C, int rootSegment) {
+                                                   double* __restrict__ sums, int P, int C, int rootSegment, int holdSlots) {
     extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d); slot 0 doubles as the categories' exchange at the start
     const PreWalkSeg MI355_CONST& sg = segs[blockIdx.y];
     const int nOps = sg.progCount;
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     const size_t waves = (size_t)gridDim.x * C, w = (size_t)blockIdx.x * C + c;
     v2d* holdBase = preLds + (size_t)c * 128 + lane;  // + slot * C * 128, second half at + 64
     const size_t holdStride = (size_t)C * 128;
+    v2d* postBase = holdBase + (size_t)holdSlots * holdStride;       // the post slots (PW_POSTOP) behind the hold slots, same shape
 
     const PreWalkOp MI355_CONST* dp = prog + sg.progStart;
     PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
@@ -339,8 +340,17 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
         if (fl & PW_TIP_A) xa = tipVector((int)CUR.sa);                                                                   \
         if (fl & PW_TIP_B) xb = tipVector((int)CUR.sb);                                                                   \
+        if (fl & PW_SLOT_A) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTA_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xa = v4d{lo.x, lo.y, hi.x, hi.y}; } \
+        if (fl & PW_SLOT_B) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTB_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xb = v4d{lo.x, lo.y, hi.x, hi.y}; } \
         v4d ua, ub, pa, pb, va, vb;                                                                                       \
         matvecDppPair(CUR.mA, xa, CUR.mB, xb, ua, ub);                                                                    \
+        if (fl & PW_POSTOP) {                          /* an unstored post-order operand, re-evaluated: nothing else happens */ \
+            const v4d r = ua * ub * CUR.ra;                                                                               \
+            v2d* h = postBase + (size_t)((fl >> PW_DST_SHIFT) & 3u) * holdStride;                                         \
+            h[0] = v2d{r.x, r.y}; h[64] = v2d{r.z, r.w};                                                                  \
+            DCUR = loadPreDesc(dp + 2);                                                                                   \
+            dp += 1;                                                                                                      \
+        } else {                                                                                                          \
         matvecDppPairT(CUR.mA, pn * ub, CUR.mB, pn * ua, pa, pb);                                                         \
         matvecDppPair(CUR.dA, xa, CUR.dB, xb, va, vb);                                                                    \
         DCUR = loadPreDesc(dp + 2);                                                                                       \
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         else if (contB >= 2u) { v2d* h = holdBase + (size_t)(contB - 2) * holdStride; h[0] = v2d{pb.x, pb.y}; h[64] = v2d{pb.z, pb.w}; }   \
         if (contA == 1u) ACC = pa;                                                                                        \
         if (contB == 1u) ACC = pb;                                                                                        \
+        }                                                                                                                 \
     }
     for (int k = 0; k < nOps; k += 2) {
         PRE_STAGE(A, B, D0, D1)
@@ -366,10 +377,11 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
 int preWalkWaves(int P, int C) { return ((P + 63) / 64) * C; }
 
 bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
-                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots) {
+                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots,
+                    bool postSlots) {
     if (nSegs <= 0 || nSegs > 65536 || C < 1 || C > 16 || (size_t)C * P * 32 >= ((size_t)1 << 32)) return false;
     const int slots = holdSlots < 1 ? 1 : holdSlots;                 // (slot 0 doubles as the categories' exchange at the start)
-    const size_t lds = (size_t)slots * C * 128 * sizeof(v2d);
+    const size_t lds = (size_t)(slots + (postSlots ? PW_POST_SLOTS : 0)) * C * 128 * sizeof(v2d);
     if (lds > 160 * 1024) return false;
     const dim3 block(64 * C);
     // the segment that starts at the list's root, then (its stores visible at the kernel boundary) all the others
@@ -378,7 +390,7 @@ bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg
       for (int part = 0; part < 2; part++) {                                                                              \
           const int n = part ? nSegs - 1 : 1;                                                                             \
           if (n > 0) hipLaunchKernelGGL(k_preWalk4<T>, dim3((P + 63) / 64, n), block, lds, stream, (const PreWalkOp MI355_CONST*)dProg,   \
-                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C, part == 0 ? 1 : 0); } }
+                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C, part == 0 ? 1 : 0, slots); } }
     if (C <= 4) PRE_WALK_LAUNCH(256) else if (C <= 8) PRE_WALK_LAUNCH(512) else PRE_WALK_LAUNCH(1024)
 #undef PRE_WALK_LAUNCH
     return true;

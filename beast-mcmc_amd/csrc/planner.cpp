@@ -73,12 +73,13 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int 
     nv.on = true; nv.stamp = stamp_; nv.nSteps = 0; nv.chainOnly = true;
     std::vector<int> pairs;
     const int maxNeed = popcount2(allSlots_) - 1;
+    const int cap = stepCap();
     // copies the steps of srcBuf's definition behind what nv holds; returns the index of its last step, -1: no room
     auto append = [&](int srcBuf) -> int {
         const VirtDef& src = virt_[srcBuf];
         const int base = nv.nSteps;
         for (int s = 0; s < src.nSteps; s++) {
-            if (nv.nSteps >= maxSteps_) return -1;
+            if (nv.nSteps >= cap) return -1;
             VirtStep h = src.steps[s];
             // a child defined in THIS list has its slots written by the same snapshot launch: copy from its origins
             const int fromA = src.stamp == stamp_ ? h.originA : snapSlot(srcBuf, s, 0);
@@ -114,7 +115,7 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int 
         last.need = std::min(std::max(na, 1 + nb), std::max(nb, 1 + na));
         if (last.need > maxNeed) return false;
     }
-    if (nv.nSteps >= maxSteps_) return false;
+    if (nv.nSteps >= cap) return false;
     pairs.push_back(last.originA); pairs.push_back(snapSlot(X, nv.nSteps, 0));
     pairs.push_back(last.originB); pairs.push_back(snapSlot(X, nv.nSteps, 1));
     nv.steps[nv.nSteps++] = last;
@@ -369,7 +370,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
             fill = &cache_[cacheNext_];
             cacheNext_ = (cacheNext_ + 1) % CACHE_WAYS;
             fill->valid = false; fill->tag = ++cacheTagNext_; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
-            fill->allowVirtual = allowVirtual; fill->tipEpoch = compactEpoch; fill->simple = simple;
+            fill->allowVirtual = allowVirtual; fill->stepLimit = allowVirtual ? stepLimit : 0; fill->tipEpoch = compactEpoch; fill->simple = simple;
             fill->ops.assign(ops, ops + (size_t)count * tuple);
         }
     }
@@ -405,7 +406,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 const VirtDef& cv = virt_[c];
                 return fresh && cv.stamp == stamp_ && cv.version == ver;
             };
-            if (ev.on && ev.sigC1 == o.c1 && ev.sigM1 == o.m1 && ev.sigC2 == o.c2 && ev.sigM2 == o.m2 && ev.sigScale == ownScale &&
+            if (ev.on && ev.nSteps <= stepCap() && ev.sigC1 == o.c1 && ev.sigM1 == o.m1 && ev.sigC2 == o.c2 && ev.sigM2 == o.m2 && ev.sigScale == ownScale &&
                 ev.sigMem1 == (o.leaf1 && !o.tip1) && ev.sigMem2 == (o.leaf2 && !o.tip2) &&
                 childSame(kc1, o.leaf1, ev.sigTip1, ev.childVer1, ev.fresh1) && childSame(kc2, o.leaf2, ev.sigTip2, ev.childVer2, ev.fresh2)) {
                 for (int st = 0; st < ev.nSteps; st++) {
@@ -648,6 +649,7 @@ void WalkPlanner::linkSlices(Plan& out) {
 WalkPlanner::CacheEntry* WalkPlanner::findCached(const int* ops, int count, int tuple, int parts, bool allowVirtual, int chunkOps) {
     for (CacheEntry& e : cache_)
         if (e.valid && e.count == count && e.tuple == tuple && e.parts == parts && e.chunkOps == chunkOps && e.allowVirtual == allowVirtual &&
+            e.stepLimit == (allowVirtual ? stepLimit : 0) &&
             e.tipEpoch == compactEpoch && memcmp(e.ops.data(), ops, (size_t)count * tuple * sizeof(int)) == 0)
             return &e;
     return nullptr;

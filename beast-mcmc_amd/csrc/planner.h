@@ -169,6 +169,11 @@ public:
     // dispatched about when the slices it waits for are done — dispatched earlier it would only hold its workgroup slots
     // while it polls.  <= 0: plain descending-tail order.
     double launchMachines = 0.0;
+    // stepLimit > 0: definitions made by the next plan() hold at most this many steps (a gradient chain: the pre-order walk
+    // re-evaluates an unstored operand from its tips every time it meets it, kernels_preorder4.hip — tip-tip nodes and a tip-tip node
+    // under one more tip, nothing longer); part of a cached plan's identity.  The snapshot slots keep the instance's own spacing.
+    int stepLimit = 0;
+    int stepCap() const { return stepLimit > 0 && stepLimit < maxSteps_ ? stepLimit : maxSteps_; }
     long cacheHits = 0;                  // plans served from the cache below
     bool cacheEnabled = true;
     // what the last plan() produced: `out`, or the cache's copy (no copy is made on a hit).  plannedTag identifies the
@@ -218,7 +223,7 @@ private:
     struct CacheEntry {
         bool valid = false;
         long tag = 0;
-        int count = 0, tuple = 0, parts = 0, chunkOps = 0;
+        int count = 0, tuple = 0, parts = 0, chunkOps = 0, stepLimit = 0;
         bool allowVirtual = false;
         std::vector<int> ops;
         long tipEpoch = -1;                            // compactEpoch the plan was made under

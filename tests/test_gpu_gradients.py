@@ -409,3 +409,56 @@ def test_gradient_entry_points_above_64_states_are_refused():
         g.gradient()
     assert e.value.code == -7
     g.close()
+
+
+@pytest.mark.parametrize("rescale", [False, True])
+def test_gradient_chain_leaves_short_definitions_unstored(rescale, oracle_lib, monkeypatch):
+    """Round 5: the post-order passes of a gradient chain no longer store every node.  A node over two compact tips, and such a
+    node under one more tip, stay definitions (planner.h stepLimit), and the pre-order walk re-evaluates them from the tips where
+    it needs them (kernels_preorder4.hip PW_POSTOP): about half the nodes of a coalescent tree are neither written by the one pass
+    nor read by the other.  Held here: the stored-node count of the chain's post-order passes, the numbers against the oracle and
+    against the same chain with every node stored (BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1), and that reading partials afterwards —
+    post-order ones of unstored nodes, pre-order ones of a list that never ran — still finds the right values."""
+    wl = helpers.random_workload(150, 1800, 4, 4, seed=61)
+    T = wl.tree.tip_count
+    runs = {}
+    for name, env in (("virtual", None), ("stored", "1")):
+        if env:
+            monkeypatch.setenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL", env)
+        g = BranchGradient(wl, double_buffer=True, rescale=rescale)
+        monkeypatch.delenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL", raising=False)
+        o = BranchGradient(wl, double_buffer=True, rescale=rescale, library=oracle_lib) if name == "virtual" else None
+        rng = np.random.default_rng(4)
+        out = []
+        for step in range(6):
+            if step == 2:
+                g.b.kernelTimer(False)                                  # (resets the walk's counters)
+            scale = np.exp(0.1 * rng.standard_normal(g.N))
+            g.branch_lengths *= scale
+            rg = g.gradient()
+            out.append(rg)
+            if o is not None:
+                o.branch_lengths *= scale
+                ro = o.gradient()
+                assert helpers.rel_err(rg[0], ro[0]) <= REL_TOL
+                close(rg[1], ro[1], "gradient, step %d" % step)
+        st = g.b.walkStats()
+        stored_per_pass = st["stored"] / 4.0
+        how = g.b.gradientStats()
+        assert how["walked"] == 5 and how["late"] == 0 and how["by_operation"] == 0, how
+        if name == "virtual":
+            assert stored_per_pass < 0.72 * (T - 1), stored_per_pass        # (a third of the nodes at the very least stays unstored)
+            # partials afterwards: an unstored post-order node (materialised on demand), pre-order partials of the held list
+            for n_ in list(range(T, g.N))[::11]:
+                close(g.post_partials(n_ + (g._set * g._partial_set if n_ >= T else 0)), o.post_partials(n_ + (o._set * o._partial_set if n_ >= T else 0)), "post-order partial %d" % n_)
+            for n_ in g.edges[:7]:
+                close(g.pre_partials(n_), o.pre_partials(n_), "pre-order partial %d" % n_)
+            assert g.b.gradientStats()["late"] == 1
+            o.close()
+        else:
+            assert stored_per_pass == T - 1
+        runs[name] = out
+        g.close()
+    for a, b in zip(runs["virtual"], runs["stored"]):
+        assert helpers.rel_err(a[0], b[0]) <= 1e-13
+        close(a[1], b[1], "virtual against stored")
