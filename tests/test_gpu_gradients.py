@@ -432,7 +432,7 @@ def test_gradient_chain_leaves_short_definitions_unstored(rescale, oracle_lib, m
         out = []
         for step in range(6):
             if step == 2:
-                g.b.kernelTimer(False)                                  # (resets the walk's counters)
+                g.b.kernelTimerRestart()                                # (resets the walk's counters; the held list stays held)
             scale = np.exp(0.1 * rng.standard_normal(g.N))
             g.branch_lengths *= scale
             rg = g.gradient()

@@ -42,7 +42,7 @@ def main():
         lnl, grad = g.gradient()
     g.b.synchronize()
     if wl.state_count == 4:
-        g.b.kernelTimer(False)              # (resets the walk's counters: stored nodes per post-order pass below)
+        g.b.kernelTimerRestart()            # (resets the walk's counters — without touching the held list: stored nodes per post-order pass below)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lnl, grad = g.gradient()
