@@ -356,6 +356,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
     in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&
                           !(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL")) != 0);
+    if (labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS")) in->gradientVirtualSteps = std::max(1, std::min(GRADIENT_VIRT_STEPS, atoi(labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS"))));
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;

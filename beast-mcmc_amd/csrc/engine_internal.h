@@ -127,7 +127,7 @@ struct Instance {
     // under one more tip — half the nodes of a coalescent tree) instead of storing every node, and k_preWalk4 re-evaluates them where
     // it needs them (engine_preorder.cpp walkableDefinition): half the bytes of both passes.  BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1 at
     // creation: every node stored, as before round 5 (A/B runs).
-    bool gradientVirtual = false;
+    bool gradientVirtual = false; int gradientVirtualSteps = GRADIENT_VIRT_STEPS;
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials
     bool fuseGradient = true;                            // BEAGLE_MI355_NO_FUSED_GRADIENT=1 at creation: operation by operation (A/B runs)

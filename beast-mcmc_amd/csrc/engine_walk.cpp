@@ -236,6 +236,25 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         // is an observation, not a documented guarantee, so it is not what ships by default.
         // A smaller N than the true number only waits longer.
         const int first = segs[si].progStart;
+        if (asmLoop) {
+            // The stage waits below count LOADS.  Stores share the counter: a stage that finds stores of the two micro-operations
+            // before it still unacknowledged waits for as many of them as its N falls short of "loads + stores".  With four loads per
+            // fetch that shortfall was covered by the loads of the fetch before (older than the stores, long landed); with three it
+            // is not — a write-mode evaluation (every micro-operation stores its factors) lost 8 % to it.  So a micro-operation
+            // whose fetch is in flight across such stores fetches four again: WF_INV on top, its scale address the all-ones array
+            // (a multiplication by one where it multiplies).  Behind write-mode rescaling only: behind the (rare) stored results of a
+            // read-mode program the padding costs what it saves (config A 503 / 503 / 507 us without, with, and with both; ALWAYS
+            // 1 053 / 1 003 / 1 005: profiles/r05_experiments.txt).  LAB builds: BEAGLE_MI355_WALK_PAD_FETCH = 0 never, 1 (default), 2 both.
+            static const int padMode = labEnv("BEAGLE_MI355_WALK_PAD_FETCH") ? atoi(labEnv("BEAGLE_MI355_WALK_PAD_FETCH")) : 1;
+            for (int i = first + segs[si].progCount - 1; i >= first + 2; i--) {      // (backwards: the test reads unpadded flags only of earlier ones — WF_INV is not what it looks at)
+                bool pad = false;
+                for (int b = 2; b <= 4 && i - b >= first && !pad; b++) {
+                    const unsigned f = w[i - b].flags;
+                    pad = (padMode >= 1 && ((f >> 13) & 3u) == (unsigned)mi355::WS_WRITE) || (padMode >= 2 && (f & mi355::WF_STORE));
+                }
+                if (pad) w[i].flags |= mi355::WF_INV;
+            }
+        }
         for (int i = first; i < first + segs[si].progCount; i++) {
             // k_walk4 (two deep): N = the fetch of the next micro-operation (+ the previous one's stores)
             // (a micro-operation that rescales in write mode also stores its factors, from one of the workgroup's waves only: behind
@@ -497,7 +516,7 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
     struct StepLimit { mi355::WalkPlanner& pl; ~StepLimit() { pl.stepLimit = 0; } } stepLimitGuard{in->planner};
     if (in->storeAllEvaluations > 0) {
         in->storeAllEvaluations--;
-        if (in->gradientVirtual && parts == 1 && tuple == BEAGLE_OP_COUNT) in->planner.stepLimit = GRADIENT_VIRT_STEPS;
+        if (in->gradientVirtual && parts == 1 && tuple == BEAGLE_OP_COUNT) in->planner.stepLimit = in->gradientVirtualSteps;
         else allowVirtual = false;
     }
     // The chain's steady state — the SAME full-evaluation list as one seen before, no rescaling in it — needs none of the
