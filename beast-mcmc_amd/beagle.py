@@ -384,6 +384,16 @@ class Beagle:
         self._check("updatePrePartials", self._f["UpdatePrePartials"](self.instance, _ip(ops), operationCount,
                                                                      cumulativeScaleIndex))
 
+    def updatePrePartialsByPartition(self, operations, operationCount):
+        """9-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling), matrix(sibling), partition,
+        cumulativeScale}"""
+        ops = _i(operations)
+        self._check("updatePrePartialsByPartition", self._f["UpdatePrePartialsByPartition"](self.instance, _ip(ops), operationCount))
+
+    def addTransitionMatrices(self, first, second, result, count):
+        a, b, c = _i(first), _i(second), _i(result)
+        self._check("addTransitionMatrices", self._f["AddTransitionMatrices"](self.instance, _ip(a), _ip(b), _ip(c), count))
+
     def calculateEdgeDifferentials(self, postBufferIndices, preBufferIndices, derivativeMatrixIndices,
                                    categoryWeightsIndices, count, want_per_pattern=False, want_squared=True):
         """-> (outSumDerivatives[count], outSumSquaredDerivatives[count] or None, outDerivatives[count, P] or None); the two

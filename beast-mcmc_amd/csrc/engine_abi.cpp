@@ -1239,7 +1239,35 @@ int beagleSetDifferentialMatrix(int instance, int matrixIndex, const double* inM
     return beagleSetTransitionMatrix(instance, matrixIndex, inMatrix, 0.0);
 }
 
-int beagleAddTransitionMatrices(int, const int*, const int*, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+// result[k] = first[k] + second[k], entry by entry and category by category (declared by BeagleJNIWrapper next to
+// convolveTransitionMatrices; no caller in BEAST today).  A result may feed a later triple of the same call: dependent triples in order.
+int beagleAddTransitionMatrices(int instance, const int* first, const int* second, const int* result, int count) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleAddTransitionMatrices(h, first, second, result, count); }); }
+    GET_INSTANCE(instance);
+    if (count <= 0) return BEAGLE_SUCCESS;
+    if (!first || !second || !result) return BEAGLE_ERROR_OUT_OF_RANGE;
+    for (int k = 0; k < count; k++)
+        if (badIndex(first[k], in->matrixCount) || badIndex(second[k], in->matrixCount) || badIndex(result[k], in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+    int b = 0;
+    while (b < count) {
+        int e = b + 1;
+        for (; e < count; e++) {
+            bool dep = false;
+            for (int k = b; k < e && !dep; k++)
+                dep = result[k] == first[e] || result[k] == second[e] || result[k] == result[e] || first[k] == result[e] || second[k] == result[e];
+            if (dep) break;
+        }
+        const int n = e - b;
+        void *dF, *dS, *dR;
+        int rc = uploadTransient(in, first + b, n * sizeof(int), &dF); if (rc) return rc;
+        rc = uploadTransient(in, second + b, n * sizeof(int), &dS); if (rc) return rc;
+        rc = uploadTransient(in, result + b, n * sizeof(int), &dR); if (rc) return rc;
+        mi355::launchAddMatrices(live(in), in->matrices, (const int*)dF, (const int*)dS, (const int*)dR, n, in->S, in->C);
+        b = e;
+    }
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
 
 int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, const int* resultIndices, int matrixCount) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleTransposeTransitionMatrices(h, inputIndices, resultIndices, matrixCount); }); }
@@ -1261,7 +1289,6 @@ int beagleTransposeTransitionMatrices(int instance, const int* inputIndices, con
 int beagleUpdatePrePartials(int instance, const int* operations, int operationCount, int cumulativeScaleIndex) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartials(h, operations, operationCount, cumulativeScaleIndex); }); }
     GET_INSTANCE_KEEP_PENDING(instance);                      // (runPreOperations decides what becomes of a list still held back)
-    if (in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;    // (beagleCreateInstance: the likelihood path only above 64 states)
     return runPreOperations(in, operations, operationCount, cumulativeScaleIndex, true);
 }
 
@@ -1279,7 +1306,6 @@ int beagleCalculateCrossProductDifferentials(int instance, const int* postBuffer
         return rc;
     }
     GET_INSTANCE(instance);
-    if (in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (outSumSquaredDerivatives) return BEAGLE_ERROR_NO_IMPLEMENTATION;       // BEAST passes null
     if (!postBufferIndices || !preBufferIndices || !categoryRateIndices || !categoryWeightsIndices || !edgeLengths || !outSumDerivatives)
         return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -1318,7 +1344,13 @@ int beagleCalculateEdgeDifferentials(int instance, const int* postBufferIndices,
                              outDerivatives, outSumDerivatives, outSumSquaredDerivatives);
 }
 
-int beagleUpdatePrePartialsByPartition(int, const int*, int) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
+// 9-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling), matrix(sibling), partition,
+// cumulativeScale}: beagleUpdatePrePartials over one partition's patterns (declared by BeagleJNIWrapper; no caller in BEAST today)
+int beagleUpdatePrePartialsByPartition(int instance, const int* operations, int operationCount) {
+    if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleUpdatePrePartialsByPartition(h, operations, operationCount); }); }
+    GET_INSTANCE(instance);
+    return runPreOperations(in, operations, operationCount, BEAGLE_OP_NONE, false, BEAGLE_PARTITION_OP_COUNT);
+}
 
 // ---- MI355X extensions -----------------------------------------------------------------------
 int beagleMi355SetStream(int instance, void* hipStream) {

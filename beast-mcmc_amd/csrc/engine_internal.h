@@ -325,7 +325,7 @@ int ensureEdgeScratch(Instance* in, size_t bytes);
 inline bool heldReadsMatrix(const Instance* in, int m) { return in->heldPre.held && m >= 0 && m < (int)in->heldPre.readsMatrix.size() && in->heldPre.readsMatrix[m]; }
 inline bool heldWrites(const Instance* in, int b) { return in->heldPre.held && b >= 0 && b < (int)in->heldPre.writesBuf.size() && in->heldPre.writesBuf[b]; }
 inline bool heldTouches(const Instance* in, int b) { return in->heldPre.held && b >= 0 && b < (int)in->heldPre.writesBuf.size() && (in->heldPre.writesBuf[b] || in->heldPre.readsBuf[b]); }
-int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold = false);
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold = false, int tuple = BEAGLE_OP_COUNT);
 int executeHeldPre(Instance* in);
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared);

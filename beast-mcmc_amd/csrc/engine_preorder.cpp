@@ -103,9 +103,11 @@ static int materializeHeldOperands(Instance* in) {
 // Enqueue a pre-order op list (7-int tuples {pre(child), writeScale, readScale, pre(parent), matrix(child), post(sibling),
 // matrix(sibling)}, AbstractBeagleGradientDelegate.java:207-221).  A parent's op precedes its children's; the list is
 // levelised like a post-order one and each level is one launch.
-int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold) {
+// tuple = 9 (beagleUpdatePrePartialsByPartition): {.., partition, cumulativeScale} — the operation covers that partition's patterns.
+// A partitioned instance takes 7-int lists too (whole pattern range); nothing is held back there (the walk is single-partition).
+int runPreOperations(Instance* in, const int* ops, int count, int globalCum, bool mayHold, int tuple) {
     if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+    if (in->partitionCount != 1 || tuple != BEAGLE_OP_COUNT) mayHold = false;
     const int n = in->partialsCount;
     // The whole list is checked BEFORE anything changes — indices, and that every operand will resolve (real data, a definition
     // that can be materialised, or a destination of an earlier operation of this list; a scale buffer to read holds raw
@@ -114,11 +116,13 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     {
         std::vector<char> written(n, 0), scaleWritten(std::max(1, in->scaleCount), 0);
         for (int k = 0; k < count; k++) {
-            const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+            const int* op = ops + (size_t)k * tuple;
             const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
             if (badIndex(dest, n) || badIndex(par, n) || badIndex(sib, n) || badIndex(mc, in->matrixCount) || badIndex(ms, in->matrixCount) ||
                 (wS != BEAGLE_OP_NONE && badIndex(wS, in->scaleCount)) || (rS != BEAGLE_OP_NONE && badIndex(rS, in->scaleCount)) ||
                 (globalCum != BEAGLE_OP_NONE && badIndex(globalCum, in->scaleCount)) || dest == par || dest == sib)
+                return BEAGLE_ERROR_OUT_OF_RANGE;
+            if (tuple > BEAGLE_OP_COUNT && (badIndex(op[7], in->partitionCount) || (op[8] != BEAGLE_OP_NONE && badIndex(op[8], in->scaleCount))))
                 return BEAGLE_ERROR_OUT_OF_RANGE;
             auto hasData = [&](int b) { return written[b] || (in->partials[b] != nullptr && !isCompactTip(in, b)) || isVirt(in, b); };
             if (!hasData(par)) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -135,16 +139,16 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     std::vector<int> need, deferred;
     long unstoredOperands = 0;
     for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int* op = ops + (size_t)k * tuple;
         const int dest = op[0], wS = op[1], par = op[3], sib = op[5];
         in->scaleOfPartial[dest] = -1;                    // (a pre-order partial: never a post-order operand of the walk)
         if (wS != BEAGLE_OP_NONE) in->scaleVersion[wS]++;
         if (isVirt(in, sib)) {
             unstoredOperands++;
             if (mayWalk && wS == BEAGLE_OP_NONE && op[2] == BEAGLE_OP_NONE && walkableDefinition(in, sib)) deferred.push_back(sib);
-            else need.push_back(sib);
+            else in->planner.keysOf(sib, need);
         }
-        if (isVirt(in, par)) need.push_back(par);
+        if (isVirt(in, par)) in->planner.keysOf(par, need);
         if (in->virt) {
             need.insert(need.end(), in->planner.tipUsers(dest).begin(), in->planner.tipUsers(dest).end());
             if (wS != BEAGLE_OP_NONE) need.insert(need.end(), in->planner.scaleUsers(wS).begin(), in->planner.scaleUsers(wS).end());
@@ -167,7 +171,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     std::vector<int> level(count), wLevel(n, -1), rLevel(n, -1), opWrite(count, BEAGLE_OP_NONE);
     int maxLevel = 0;
     for (int k = 0; k < count; k++) {
-        const int* op = ops + (size_t)k * BEAGLE_OP_COUNT;
+        const int* op = ops + (size_t)k * tuple;
         const int dest = op[0], wS = op[1], rS = op[2], par = op[3], mc = op[4], sib = op[5], ms = op[6];
         OpDesc& d = descs[k];
         memset(&d, 0, sizeof(d));
@@ -191,6 +195,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
             d.scaleRead = in->scale[rS];
         }
         d.pStart = 0; d.pEnd = in->P;
+        if (tuple > BEAGLE_OP_COUNT) { d.pStart = in->partStart[op[7]]; d.pEnd = in->partEnd[op[7]]; }
         const int lvl = std::max(std::max(wLevel[par], wLevel[sib]), std::max(wLevel[dest], rLevel[dest])) + 1;
         level[k] = lvl; maxLevel = std::max(maxLevel, lvl);
         wLevel[dest] = lvl; rLevel[par] = std::max(rLevel[par], lvl); rLevel[sib] = std::max(rLevel[sib], lvl);
@@ -206,7 +211,7 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
         for (int b : deferred) if (isVirt(in, b)) in->planner.keysOf(b, keys);
         if (!keys.empty()) { int rc = materializeList(in, keys); if (rc) return rc; }
         for (int k = 0; k < count; k++) {
-            const int sib = ops[(size_t)k * BEAGLE_OP_COUNT + 5];
+            const int sib = ops[(size_t)k * tuple + 5];
             if (!descs[k].child2) { if (!in->partials[sib]) return BEAGLE_ERROR_OUT_OF_RANGE; descs[k].child2 = in->partials[sib]; }
         }
     }
@@ -221,7 +226,9 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
     // T32 layout (16..64 states): two passes of the MFMA pruning kernel per op instead of the VALU pre-order kernel
     // (BEAGLE_MI355_PRE_NAIVE=1 keeps the latter, for A/B runs)
     static const bool preNaive = labEnv("BEAGLE_MI355_PRE_NAIVE") && atoi(labEnv("BEAGLE_MI355_PRE_NAIVE")) != 0;
-    const bool twoPass = in->tiled && !preNaive;
+    const bool twoPass = in->tiled && !preNaive && tuple == BEAGLE_OP_COUNT;      // (a partition's range: the direct kernel, which takes any range)
+    // a partitioned walk instance keeps its reciprocal halves in another order than the kernel's walkPairIndex: rebuilt below
+    const bool recipLater = in->walk && in->partitionCount > 1;
     for (int chunkBegin = 0; chunkBegin < count;) {
         const int chunkEnd = (int)std::min<size_t>((size_t)count, (size_t)chunkBegin + maxChunkOps);
         void* dChunk = nullptr;
@@ -245,11 +252,29 @@ int runPreOperations(Instance* in, const int* ops, int count, int globalCum, boo
                 int rc2 = preLevelTwoPass(in, &sorted[begin], end - begin); if (rc2) return rc2; continue;
             }
             mi355::launchPrePartials(live(in), (const OpDesc*)dChunk + (begin - chunkBegin), end - begin, in->matrices,
-                                     in->P, in->S, in->C, in->tiled, in->P, in->walk ? (long)in->scaleStride : 0);
+                                     in->P, in->S, in->C, in->tiled, in->P, in->walk && !recipLater ? (long)in->scaleStride : 0);
         }
         chunkBegin = chunkEnd;
     }
     HIP_TRY(hipGetLastError());
+    if (recipLater)
+        for (int k = 0; k < count; k++)
+            if (opWrite[k] != BEAGLE_OP_NONE && in->dPairPos)
+                mi355::launchRecipFromFactors(live(in), in->scale[opWrite[k]], in->scale[opWrite[k]] + in->scaleStride, in->dPairPos, in->P);
+    if (tuple > BEAGLE_OP_COUNT) {                  // per-operation cumulative buffers, over the partition's patterns
+        for (int k = 0; k < count; k++) {
+            const int* op = ops + (size_t)k * tuple;
+            if (opWrite[k] == BEAGLE_OP_NONE || op[8] == BEAGLE_OP_NONE) continue;
+            int rc = ensureScale(in, op[8]); if (rc) return rc;
+            const double* src = in->scale[opWrite[k]];
+            int one = 1;
+            void *dSrc = nullptr, *dRaw = nullptr;
+            rc = uploadTransient(in, &src, sizeof(src), &dSrc); if (rc) return rc;
+            rc = uploadTransient(in, &one, sizeof(one), &dRaw); if (rc) return rc;
+            mi355::launchAccumulateScale(live(in), in->scale[op[8]], (const double* const*)dSrc, (const int*)dRaw, 1, 1.0, in->partStart[op[7]], in->partEnd[op[7]]);
+        }
+        return 0;
+    }
     if (globalCum != BEAGLE_OP_NONE)
         for (int k = 0; k < count; k++) {
             if (opWrite[k] == BEAGLE_OP_NONE) continue;
@@ -625,7 +650,6 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
 int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const int* dIdx, int wIdx, int count,
                       double* outDerivatives, double* outSum, double* outSumSquared) {
     if (count <= 0) return 0;
-    if (in->partitionCount != 1 || in->S > 64) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (in->heldPre.held) {
         // a held-back pre-order list (the usual case: these are its edges).  Sums only: no pre-order partial is written and the
         // list stays held; sums of squares as well: the list runs together with the derivatives; anything else: it runs first
@@ -640,8 +664,8 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
     for (int e = 0; e < count; e++) {
         if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount) || badIndex(dIdx[e], in->matrixCount))
             return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
-        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
+        if (isVirt(in, postIdx[e])) in->planner.keysOf(postIdx[e], need);
+        if (isVirt(in, preIdx[e])) in->planner.keysOf(preIdx[e], need);
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     const int nb = mi355::edgeBlocks(in->P);
@@ -735,12 +759,11 @@ int edgeDifferentials(Instance* in, const int* postIdx, const int* preIdx, const
 // calculateCrossProductDifferentials (semantics: include/beagle_mi355.h)
 int crossProducts(Instance* in, const int* postIdx, const int* preIdx, int rateIdx, int wIdx, const double* lengths, int count, double* outSum) {
     if (count <= 0) return 0;
-    if (in->partitionCount != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     std::vector<int> need;
     for (int e = 0; e < count; e++) {
         if (badIndex(postIdx[e], in->partialsCount) || badIndex(preIdx[e], in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
-        if (isVirt(in, postIdx[e])) need.push_back(postIdx[e]);
-        if (isVirt(in, preIdx[e])) need.push_back(preIdx[e]);
+        if (isVirt(in, postIdx[e])) in->planner.keysOf(postIdx[e], need);
+        if (isVirt(in, preIdx[e])) in->planner.keysOf(preIdx[e], need);
     }
     if (!need.empty()) { int rc = materializeList(in, need); if (rc) return rc; }
     std::vector<mi355::EdgeDesc> descs(count);

@@ -200,6 +200,8 @@ void launchTransitionMatrices4Fused(hipStream_t stream, double* matrices, const 
 // C_c = A_c * B_c per category, `count` triples (device index arrays).
 void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,
                             const int* dResult, int count, int S, int C);
+// C_c = A_c + B_c per category (a result may be one of its own operands: entry by entry)
+void launchAddMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond, const int* dResult, int count, int S, int C);
 
 // One dependency level of pruning operations: `nOps` independent ops, descriptors on the device.
 // maxRange = max over ops of (pEnd - pStart).

@@ -249,6 +249,17 @@ void launchTransitionMatrices(hipStream_t stream, double* matrices, const double
                        matrices, eigen, rates, dIdx, dLen, dEig, dRate, S, C, complexEigen ? 1 : 0);
 }
 
+__global__ __launch_bounds__(256) void k_addMatrices(double* __restrict__ matrices, const int* __restrict__ dFirst, const int* __restrict__ dSecond,
+                                                     const int* __restrict__ dResult, int elems) {
+    const double* a = matrices + (size_t)dFirst[blockIdx.x] * elems;
+    const double* b = matrices + (size_t)dSecond[blockIdx.x] * elems;
+    double* r = matrices + (size_t)dResult[blockIdx.x] * elems;
+    for (int e = threadIdx.x; e < elems; e += 256) r[e] = a[e] + b[e];
+}
+void launchAddMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond, const int* dResult, int count, int S, int C) {
+    if (count > 0) hipLaunchKernelGGL(k_addMatrices, dim3(count), dim3(256), 0, stream, matrices, dFirst, dSecond, dResult, C * S * S);
+}
+
 __global__ __launch_bounds__(256) void k_convolve(double* __restrict__ matrices, const int* __restrict__ dFirst,
                                                   const int* __restrict__ dSecond, const int* __restrict__ dResult,
                                                   int S, int C) {

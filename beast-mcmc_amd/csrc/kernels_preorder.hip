@@ -78,9 +78,84 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prePartials(const OpDesc* __restr
 
 static size_t preLds(int S) { return ((size_t)2 * S * S + (size_t)2 * S * PRE_BLOCK) * sizeof(double); }
 
+// ---- more states than the kernels above can stage (65..255: discrete-trait models with many locations) ----------------------
+// The same arithmetic with both matrices read from global memory (L2: every workgroup of a level reads the same few) and the
+// operand columns of SIXTEEN patterns at a time in LDS; a workgroup still covers 64 patterns (four rounds), its 64 threads are
+// 16 patterns x 4 parts that share a pattern's states i = part, part + 4, ...  A correctness path, as k_pruneGeneral is for the
+// likelihood (kernels.hip): what SubstitutionModelCrossProductDelegate / the branch-rate gradients ask for at any stateCount
+// (discrete/SubstitutionModelCrossProductDelegate.java:153-178), not a tuned one.
+constexpr int BIG_PT = 16, BIG_PARTS = PRE_BLOCK / BIG_PT;
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_prePartialsBig(const OpDesc* __restrict__ ops, const double* __restrict__ matrices, int P, int S, int C) {
+    extern __shared__ double sh[];                 // v[S][16] | x[S][16] | red[64]
+    double* v = sh; double* x = v + S * BIG_PT; double* red = x + S * BIG_PT;
+    const OpDesc& op = ops[blockIdx.y];
+    const int tid = threadIdx.x, pt = tid & (BIG_PT - 1), part = tid / BIG_PT;
+    const bool sibStates = op.kind & KIND_STATES2;
+    const double MI355_GLOBAL* parent = gptr(reinterpret_cast<const double*>(op.child1));
+    const double MI355_GLOBAL* sib = gptr(reinterpret_cast<const double*>(op.child2));
+    double MI355_GLOBAL* dest = gptr(op.dest);
+    for (int round = 0; round < PRE_BLOCK / BIG_PT; round++) {
+        const int base = op.pStart + blockIdx.x * PRE_BLOCK + round * BIG_PT;
+        if (base >= op.pEnd) break;                                   // (uniform over the workgroup)
+        const int p = base + pt;
+        const bool valid = p < op.pEnd;
+        int s = S;
+        if (valid && sibStates) s = gptr(reinterpret_cast<const uint8_t*>(op.child2))[p];
+        double inv = 1.0;
+        if (valid && !op.scaleWrite && op.scaleRead) inv = 1.0 / gptr(op.scaleRead)[p];
+        double mx = 0.0;
+        for (int c = 0; c < C; c++) {
+            const double* GS = matrices + ((size_t)op.mat2 * C + c) * S * S;
+            const double* GC = matrices + ((size_t)op.mat1 * C + c) * S * S;
+            __syncthreads();
+            for (int i = part; i < S; i += BIG_PARTS) {
+                v[i * BIG_PT + pt] = valid ? parent[((size_t)c * P + p) * S + i] : 0.0;
+                if (!sibStates) x[i * BIG_PT + pt] = valid ? sib[((size_t)c * P + p) * S + i] : 0.0;
+            }
+            __syncthreads();
+            for (int i = part; i < S; i += BIG_PARTS) {
+                double f;
+                if (sibStates) f = s < S ? GS[(size_t)i * S + s] : 1.0;
+                else { f = 0.0; for (int k = 0; k < S; k++) f += GS[(size_t)i * S + k] * x[k * BIG_PT + pt]; }
+                v[i * BIG_PT + pt] *= f;
+            }
+            __syncthreads();
+            for (int j = part; j < S; j += BIG_PARTS) {
+                double acc = 0.0;
+                for (int i = 0; i < S; i++) acc += v[i * BIG_PT + pt] * GC[(size_t)i * S + j];
+                acc *= inv;
+                if (valid) dest[((size_t)c * P + p) * S + j] = acc;
+                mx = fmax(mx, acc);
+            }
+        }
+        if (op.scaleWrite) {                       // rescale now: max over categories and states, divide, keep the raw factor
+            __syncthreads();
+            red[tid] = mx;
+            __syncthreads();
+            double m = 0.0;
+            for (int q = 0; q < BIG_PARTS; q++) m = fmax(m, red[q * BIG_PT + pt]);
+            if (!(m > 0.0)) m = 1.0;
+            if (valid && part == 0) gptr(op.scaleWrite)[p] = m;
+            const double im = 1.0 / m;
+            if (valid)
+                for (int c = 0; c < C; c++) for (int j = part; j < S; j += BIG_PARTS) dest[((size_t)c * P + p) * S + j] *= im;
+        }
+    }
+}
+
 void launchPrePartials(hipStream_t stream, const OpDesc* dOps, int nOps, const double* matrices, int P, int S, int C, bool tiled,
                        int maxRange, long recipOff) {
     if (nOps <= 0 || maxRange <= 0) return;
+    if (preLds(S) > 160 * 1024 && !tiled) {
+        const size_t ldsBig = ((size_t)2 * S * BIG_PT + PRE_BLOCK) * sizeof(double);
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_prePartialsBig), 160 * 1024)) return;
+        for (int o = 0; o < nOps; o += 65535) {
+            const int n = nOps - o < 65535 ? nOps - o : 65535;
+            hipLaunchKernelGGL(k_prePartialsBig, dim3((maxRange + PRE_BLOCK - 1) / PRE_BLOCK, n), dim3(PRE_BLOCK), ldsBig, stream, dOps + o, matrices, P, S, C);
+        }
+        return;
+    }
     const size_t lds = preLds(S);
     if (!grantDynamicLds(reinterpret_cast<const void*>(k_prePartials<false>), 160 * 1024) ||
         !grantDynamicLds(reinterpret_cast<const void*>(k_prePartials<true>), 160 * 1024)) return;
@@ -154,6 +229,67 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentials(const EdgeDesc*
     }
 }
 
+// (65..255 states: see k_prePartialsBig) the differential matrix read from global memory, sixteen patterns' columns in LDS at a time
+__global__ __launch_bounds__(PRE_BLOCK) void k_edgeDifferentialsBig(const EdgeDesc* __restrict__ edges, const double* __restrict__ matrices,
+                                                                    const double* __restrict__ catWeights, const double* __restrict__ patternWeights,
+                                                                    double* __restrict__ perPattern, double* __restrict__ blockSums, int P, int S, int C) {
+    extern __shared__ double sh[];                 // u[S][16] | x[S][16] | rs[S] | red[2][64]
+    double* u = sh; double* x = u + S * BIG_PT; double* rs = x + S * BIG_PT; double* red = rs + S;
+    const EdgeDesc& ed = edges[blockIdx.y];
+    const int tid = threadIdx.x, pt = tid & (BIG_PT - 1), part = tid / BIG_PT;
+    const bool postStates = ed.postIsStates != 0;
+    const double MI355_GLOBAL* pre = gptr(ed.pre);
+    const double MI355_GLOBAL* post = gptr(reinterpret_cast<const double*>(ed.post));
+    const size_t row = (size_t)ed.slot;
+    double w1 = 0.0, w2 = 0.0;                      // (threads of part 0: their pattern's weighted derivative and its square)
+    for (int round = 0; round < PRE_BLOCK / BIG_PT; round++) {
+        const int p = blockIdx.x * PRE_BLOCK + round * BIG_PT + pt;
+        const bool valid = p < P;
+        int s = S;
+        if (valid && postStates) s = gptr(reinterpret_cast<const uint8_t*>(ed.post))[p];
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < C; c++) {
+            const double* G = matrices + ((size_t)ed.dmat * C + c) * S * S;
+            __syncthreads();
+            if (postStates) for (int j = tid; j < S; j += PRE_BLOCK) { double t = 0.0; for (int k = 0; k < S; k++) t += G[(size_t)j * S + k]; rs[j] = t; }
+            for (int i = part; i < S; i += BIG_PARTS) {
+                u[i * BIG_PT + pt] = valid ? pre[((size_t)c * P + p) * S + i] : 0.0;
+                if (!postStates) x[i * BIG_PT + pt] = valid ? post[((size_t)c * P + p) * S + i] : 0.0;
+            }
+            __syncthreads();
+            double n = 0.0, d = 0.0;
+            for (int j = part; j < S; j += BIG_PARTS) {
+                double t, xj;
+                if (postStates) {
+                    if (s < S) { t = G[(size_t)j * S + s]; xj = j == s ? 1.0 : 0.0; }
+                    else { t = rs[j]; xj = 1.0; }
+                } else {
+                    t = 0.0; for (int k = 0; k < S; k++) t += G[(size_t)j * S + k] * x[k * BIG_PT + pt];
+                    xj = x[j * BIG_PT + pt];
+                }
+                n += u[j * BIG_PT + pt] * t; d += u[j * BIG_PT + pt] * xj;
+            }
+            num += catWeights[c] * n; den += catWeights[c] * d;
+        }
+        __syncthreads();
+        red[tid] = num; red[PRE_BLOCK + tid] = den;
+        __syncthreads();
+        if (part == 0 && valid) {
+            double nn = 0.0, dd = 0.0;
+            for (int q = 0; q < BIG_PARTS; q++) { nn += red[q * BIG_PT + pt]; dd += red[PRE_BLOCK + q * BIG_PT + pt]; }
+            const double deriv = nn / dd;
+            if (perPattern) perPattern[row * P + p] = deriv;
+            const double w = patternWeights[p] * deriv;
+            w1 += w; w2 += w * deriv;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { w1 += __shfl_xor(w1, off, 64); w2 += __shfl_xor(w2, off, 64); }
+    if (tid == 0) {
+        double* b = blockSums + (row * gridDim.x + blockIdx.x) * 2;
+        b[0] = w1; b[1] = w2;
+    }
+}
+
 // out[e] = sum over the edge's workgroups, in a fixed order
 __global__ __launch_bounds__(64) void k_edgeFinal(const double* __restrict__ blockSums, int nBlocks, double* __restrict__ out) {
     const double* b = blockSums + (size_t)blockIdx.x * nBlocks * 2;
@@ -170,6 +306,13 @@ void launchEdgeDifferentials(hipStream_t stream, const EdgeDesc* dEdges, int nEd
                              int P, int S, int C, bool tiled) {
     if (nEdges <= 0) return;
     const size_t lds = ((size_t)S * S + S + (size_t)2 * S * PRE_BLOCK) * sizeof(double);
+    if (lds > 160 * 1024 && !tiled) {
+        const size_t ldsBig = ((size_t)2 * S * BIG_PT + S + 2 * PRE_BLOCK) * sizeof(double);
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_edgeDifferentialsBig), 160 * 1024)) return;
+        hipLaunchKernelGGL(k_edgeDifferentialsBig, dim3(edgeBlocks(P), nEdges), dim3(PRE_BLOCK), ldsBig, stream, dEdges, matrices, catWeights, patternWeights,
+                           perPattern, blockSums, P, S, C);
+        return;
+    }
     if (!grantDynamicLds(reinterpret_cast<const void*>(k_edgeDifferentials<false>), 160 * 1024) ||
         !grantDynamicLds(reinterpret_cast<const void*>(k_edgeDifferentials<true>), 160 * 1024)) return;
     dim3 grid(edgeBlocks(P), nEdges), block(PRE_BLOCK);
@@ -290,6 +433,70 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_crossProducts(const EdgeDesc* __r
     }
 }
 
+// (65..255 states) S x S outputs do not fit one thread's 64 accumulators x 64 threads: the outputs are cut into tiles of 4096
+// (blockIdx.y), and the columns of THIRTY-TWO patterns at a time go to LDS (two rounds per 64-pattern block)
+__global__ __launch_bounds__(PRE_BLOCK) void k_crossProductsBig(const EdgeDesc* __restrict__ edges, int nEdges, const double* __restrict__ edgeLengths,
+                                                                const double* __restrict__ catWeights, const double* __restrict__ catRates,
+                                                                const double* __restrict__ patternWeights, double* __restrict__ partial, int P, int S, int C) {
+    constexpr int HALF = 32;
+    extern __shared__ double sh[];                 // u[S][32] | x[S][32] | red[64]
+    double* u = sh; double* x = u + S * HALF; double* red = x + S * HALF;
+    const int tid = threadIdx.x, pt = tid & (HALF - 1), part = tid / HALF, nOut = S * S;
+    const int tile0 = (int)blockIdx.y * CROSS_MAXM * PRE_BLOCK;
+    double acc[CROSS_MAXM];
+#pragma unroll
+    for (int m = 0; m < CROSS_MAXM; m++) acc[m] = 0.0;
+    for (int e = 0; e < nEdges; e++) {
+        const EdgeDesc& ed = edges[e];
+        const bool postStates = ed.postIsStates != 0;
+        const double MI355_GLOBAL* pre = gptr(ed.pre);
+        const double MI355_GLOBAL* post = gptr(reinterpret_cast<const double*>(ed.post));
+        for (int round = 0; round < PRE_BLOCK / HALF; round++) {
+            const int p = blockIdx.x * PRE_BLOCK + round * HALF + pt;
+            const bool valid = p < P;
+            int s = S;
+            if (valid && postStates) s = gptr(reinterpret_cast<const uint8_t*>(ed.post))[p];
+            auto postAt = [&](int c, int k) { return postStates ? (s < S ? (k == s ? 1.0 : 0.0) : 1.0) : post[((size_t)c * P + p) * S + k]; };
+            double d = 0.0;
+            if (valid)
+                for (int c = 0; c < C; c++) {
+                    double dc = 0.0;
+                    for (int k = part; k < S; k += 2) dc += pre[((size_t)c * P + p) * S + k] * postAt(c, k);
+                    d += catWeights[c] * dc;
+                }
+            __syncthreads();
+            red[tid] = d;
+            __syncthreads();
+            const double den = red[pt] + red[HALF + pt];
+            const double f = valid ? edgeLengths[e] * patternWeights[p] / den : 0.0;
+            for (int c = 0; c < C; c++) {
+                const double g = f * catWeights[c] * catRates[c];
+                __syncthreads();
+                for (int k = part; k < S; k += 2) {
+                    u[k * HALF + pt] = valid ? g * pre[((size_t)c * P + p) * S + k] : 0.0;
+                    x[k * HALF + pt] = valid ? postAt(c, k) : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < CROSS_MAXM; m++) {
+                    const int o = tile0 + tid + m * PRE_BLOCK;
+                    if (o < nOut) {
+                        const int i = o / S, j = o - i * S;
+                        double t = 0.0;
+                        for (int l = 0; l < HALF; l++) t += u[i * HALF + l] * x[j * HALF + l];
+                        acc[m] += t;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < CROSS_MAXM; m++) {
+        const int o = tile0 + tid + m * PRE_BLOCK;
+        if (o < nOut) partial[(size_t)blockIdx.x * nOut + o] = acc[m];
+    }
+}
+
 __global__ void k_crossFinal(const double* __restrict__ partial, int nBlocks, int nOut, double* __restrict__ out) {
     const int o = blockIdx.x * 64 + threadIdx.x;
     if (o >= nOut) return;
@@ -305,6 +512,14 @@ void launchCrossProducts(hipStream_t stream, const EdgeDesc* dEdges, int nEdges,
     if (!grantDynamicLds(reinterpret_cast<const void*>(k_crossProducts<false>), 160 * 1024) ||
         !grantDynamicLds(reinterpret_cast<const void*>(k_crossProducts<true>), 160 * 1024)) return;
     const int nb = edgeBlocks(P);
+    if (S > 64) {
+        const size_t ldsBig = ((size_t)2 * S * 32 + PRE_BLOCK) * sizeof(double);
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_crossProductsBig), 160 * 1024)) return;
+        const int tiles = (S * S + CROSS_MAXM * PRE_BLOCK - 1) / (CROSS_MAXM * PRE_BLOCK);
+        hipLaunchKernelGGL(k_crossProductsBig, dim3(nb, tiles), dim3(PRE_BLOCK), ldsBig, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
+        hipLaunchKernelGGL(k_crossFinal, dim3((S * S + 63) / 64), dim3(64), 0, stream, partial, nb, S * S, out);
+        return;
+    }
     if (tiled) hipLaunchKernelGGL(k_crossProducts<true>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
     else hipLaunchKernelGGL(k_crossProducts<false>, dim3(nb), dim3(PRE_BLOCK), lds, stream, dEdges, nEdges, dEdgeLengths, catWeights, catRates, patternWeights, partial, P, S, C);
     hipLaunchKernelGGL(k_crossFinal, dim3((S * S + 63) / 64), dim3(64), 0, stream, partial, nb, S * S, out);

@@ -400,14 +400,84 @@ def test_gradient_after_set_pattern_partitions(S, oracle_lib):
             assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
 
 
-def test_gradient_entry_points_above_64_states_are_refused():
-    """65..255 states run the likelihood path only (include/beagle_mi355.h, beagleCreateInstance): the pre-order / gradient entry
-    points answer BEAGLE_ERROR_NO_IMPLEMENTATION (-7) instead of running kernels that stage S x S tiles."""
-    wl = helpers.random_workload(5, 20, 70, 1, seed=9)
+@pytest.mark.parametrize("S,C,T,P,rescale", [(65, 1, 6, 70, False), (100, 2, 5, 45, True), (130, 1, 4, 33, False)])
+def test_gradient_above_64_states(S, C, T, P, rescale, oracle_lib):
+    """65..255 states (discrete-trait models with many locations: SubstitutionModelCrossProductDelegate.java:153-178 takes whatever
+    stateCount the data type has): pre-order partials, edge derivatives (sums, squares, per pattern) and cross products on the
+    general kernels' large-state forms (kernels_preorder.hip k_prePartialsBig / k_edgeDifferentialsBig / k_crossProductsBig: the
+    matrices read from L2, sixteen patterns' columns in LDS at a time) — round 4 answered -7 here."""
+    wl = helpers.random_workload(T, P, S, C, seed=300 + S)
+    g = BranchGradient(wl, rescale=rescale)
+    o = BranchGradient(wl, rescale=rescale, library=oracle_lib)
+    lo, go, ho, po = o.gradient(second=True, per_pattern=True)
+    lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
+    assert helpers.rel_err(lg, lo) <= REL_TOL
+    close(gg, go, "gradient")
+    close(hg, ho, "second derivatives")
+    close(pg, po, "per-pattern derivatives")
+    close(g.cross_products(), o.cross_products(), "cross products")
+    for n in range(g.N):
+        if n != wl.tree.root:
+            a, b = g.pre_partials(n).reshape(C, P, S), o.pre_partials(n).reshape(C, P, S)
+            ref = np.max(np.abs(b), axis=(0, 2), keepdims=True)
+            assert np.max(np.abs(a - b) / np.maximum(ref, 1e-300)) <= REL_TOL, n
+    # a pre-order operation that rescales (write-scale index): rescaled partials times the factor give the unscaled ones
+    if rescale:
+        root = wl.tree.root
+        ops = g._pre_ops.copy().reshape(-1, 7)
+        child = int(ops[0, 0])
+        plain = g.b.getPartials(child, bm.beagle.NONE).reshape(C, P, S).copy()
+        ops[:, 1] = 0
+        g.b.setPartials(g.pre_offset + root, g._root_pre)
+        g.b.updatePrePartials(ops[:1].ravel(), 1, bm.beagle.NONE)
+        scaled = g.b.getPartials(child, bm.beagle.NONE).reshape(C, P, S)
+        f = np.exp(g.b.getLogScaleFactors(0))
+        assert np.allclose(scaled * f[None, :, None], plain, rtol=1e-12, atol=0) and np.allclose(scaled.max(axis=(0, 2)), 1.0)
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("S", [4, 7, 20])
+def test_gradient_on_a_partitioned_instance(S, oracle_lib):
+    """A partitioned instance (setPatternPartitions with several partitions) takes the pre-order / gradient entry points over the
+    whole pattern range — round 4 answered -7 —, and updatePrePartialsByPartition (9-int tuples, declared by BeagleJNIWrapper) covers
+    one partition's patterns: the partitions' lists together leave what the whole-range list leaves."""
+    wl = helpers.random_workload(9, 333, S, 2, seed=410 + S)
+    P = wl.pattern_count
+    parts = np.zeros(P, dtype=np.int32); parts[120:200] = 1; parts[200:] = 2
     g = BranchGradient(wl)
-    with pytest.raises(bm.beagle.BeagleException) as e:
-        g.gradient()
-    assert e.value.code == -7
+    o = BranchGradient(wl, library=oracle_lib)
+    g.b.setPatternPartitions(3, parts)
+    for _ in range(2):
+        lo, go = o.gradient()
+        lg, gg = g.gradient()
+        assert helpers.rel_err(lg, lo) <= REL_TOL
+        close(gg, go, "gradient on the partitioned instance")
+    lo, go, ho, po = o.gradient(second=True, per_pattern=True)
+    lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
+    close(gg, go, "gradient"); close(hg, ho, "second derivatives"); close(pg, po, "per-pattern derivatives")
+    close(g.cross_products(), o.cross_products(), "cross products")
+    whole = {n: g.pre_partials(n).copy() for n in g.edges}
+    # the same pre-order pass partition by partition
+    g.b.setPartials(g.pre_offset + wl.tree.root, g._root_pre)
+    ops7 = g._pre_ops.reshape(-1, 7)
+    for n in g.edges:                       # wipe the destinations
+        g.b.setPartials(g.pre_offset + n, np.zeros(g.C * P * S))
+    for part in (2, 0, 1):
+        ops9 = np.concatenate([ops7, np.full((len(ops7), 1), part, dtype=np.int32), np.full((len(ops7), 1), bm.beagle.NONE, dtype=np.int32)], axis=1)
+        g.b.updatePrePartialsByPartition(ops9.ravel(), len(ops9))
+    for n in g.edges:
+        assert np.array_equal(g.pre_partials(n), whole[n]), n
+    g.close(); o.close()
+
+
+def test_add_transition_matrices():
+    wl = helpers.random_workload(5, 40, 4, 3, seed=12)
+    g = BranchGradient(wl)
+    g.log_likelihood()
+    a, b = g.b.getTransitionMatrix(0).copy(), g.b.getTransitionMatrix(1).copy()
+    g.b.addTransitionMatrices([0, g.q_index], [1, 2], [g.q_index, g.q2_index], 2)      # the second sum reads the first one's result
+    assert np.array_equal(g.b.getTransitionMatrix(g.q_index), a + b)
+    assert np.array_equal(g.b.getTransitionMatrix(g.q2_index), (a + b) + g.b.getTransitionMatrix(2))
     g.close()
 
 
