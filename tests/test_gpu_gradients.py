@@ -438,33 +438,58 @@ def test_gradient_above_64_states(S, C, T, P, rescale, oracle_lib):
 
 @pytest.mark.parametrize("S", [4, 7, 20])
 def test_gradient_on_a_partitioned_instance(S, oracle_lib):
-    """A partitioned instance (setPatternPartitions with several partitions) takes the pre-order / gradient entry points over the
-    whole pattern range — round 4 answered -7 —, and updatePrePartialsByPartition (9-int tuples, declared by BeagleJNIWrapper) covers
-    one partition's patterns: the partitions' lists together leave what the whole-range list leaves."""
+    """A partitioned instance (setPatternPartitions with several partitions; the post-order pass issued partition by partition, as
+    MultiPartitionDataLikelihoodDelegate does) takes the pre-order / gradient entry points over the whole pattern range — round 4
+    answered -7 —, and updatePrePartialsByPartition (9-int tuples, declared by BeagleJNIWrapper) covers one partition's patterns:
+    the partitions' lists together leave what the whole-range list leaves."""
     wl = helpers.random_workload(9, 333, S, 2, seed=410 + S)
     P = wl.pattern_count
     parts = np.zeros(P, dtype=np.int32); parts[120:200] = 1; parts[200:] = 2
     g = BranchGradient(wl)
     o = BranchGradient(wl, library=oracle_lib)
     g.b.setPatternPartitions(3, parts)
+    NONE = bm.beagle.NONE
+
+    def by_partition(ops7, order=(0, 1, 2)):
+        ops7 = ops7.reshape(-1, 7)
+        return np.concatenate([np.concatenate([ops7, np.full((len(ops7), 1), k, dtype=np.int32), np.full((len(ops7), 1), NONE, dtype=np.int32)], axis=1)
+                               for k in order]).astype(np.int32)
+
+    def partitioned_gradient(second=False, per_pattern=False):
+        idx = g._nodes
+        g.b.updateTransitionMatrices(0, g._edge_matrix[0], None, None, g.branch_lengths[idx], len(idx))
+        ops9 = by_partition(g._post_ops)
+        g.b.updatePartialsByPartition(ops9.ravel(), len(ops9))
+        byp, tot = np.zeros(3), np.zeros(1)
+        root = g.post_index(wl.tree.root)
+        g.b.calculateRootLogLikelihoodsByPartition([root] * 3, [0] * 3, [0] * 3, [NONE] * 3, [0, 1, 2], 3, 1, byp, tot)
+        g.b.setPartials(g.pre_offset + wl.tree.root, g._root_pre)
+        g.b.updatePrePartials(g._pre_ops, len(g._pre_ops) // 7, NONE)            # whole range, on the partitioned instance
+        g.b.setDifferentialMatrix(g.q_index, g.infinitesimal(1))
+        n = len(g._nodes)
+        s1, s1sq, per = g.b.calculateEdgeDifferentials(g._edge_post[0], g._pre_idx, g._q1_idx, g._w0, n, want_per_pattern=per_pattern, want_squared=second)
+        grad = np.zeros(g.N); grad[g._nodes] = s1
+        return float(tot[0]), grad, s1sq, per
+
     for _ in range(2):
         lo, go = o.gradient()
-        lg, gg = g.gradient()
+        lg, gg, _, _ = partitioned_gradient()
         assert helpers.rel_err(lg, lo) <= REL_TOL
         close(gg, go, "gradient on the partitioned instance")
     lo, go, ho, po = o.gradient(second=True, per_pattern=True)
-    lg, gg, hg, pg = g.gradient(second=True, per_pattern=True)
-    close(gg, go, "gradient"); close(hg, ho, "second derivatives"); close(pg, po, "per-pattern derivatives")
+    lg, gg, sq, pg = partitioned_gradient(second=True, per_pattern=True)
+    close(gg, go, "gradient"); close(pg, po, "per-pattern derivatives")
     close(g.cross_products(), o.cross_products(), "cross products")
     whole = {n: g.pre_partials(n).copy() for n in g.edges}
+    for n in g.edges:
+        close(whole[n], o.pre_partials(n), "pre-order partial %d" % n)
     # the same pre-order pass partition by partition
     g.b.setPartials(g.pre_offset + wl.tree.root, g._root_pre)
-    ops7 = g._pre_ops.reshape(-1, 7)
     for n in g.edges:                       # wipe the destinations
         g.b.setPartials(g.pre_offset + n, np.zeros(g.C * P * S))
-    for part in (2, 0, 1):
-        ops9 = np.concatenate([ops7, np.full((len(ops7), 1), part, dtype=np.int32), np.full((len(ops7), 1), bm.beagle.NONE, dtype=np.int32)], axis=1)
-        g.b.updatePrePartialsByPartition(ops9.ravel(), len(ops9))
+    ops9 = by_partition(g._pre_ops, order=(2, 0, 1))
+    # (a parent's operation precedes its children's within a partition; the partitions are independent)
+    g.b.updatePrePartialsByPartition(ops9.ravel(), len(ops9))
     for n in g.edges:
         assert np.array_equal(g.pre_partials(n), whole[n]), n
     g.close(); o.close()
