@@ -1,3 +1,5 @@
+# (the knobs below exist in LAB builds only: python beast-mcmc_amd/build.py --lab)
+export BEAGLE_MI355_ENGINE_LIB=${BEAGLE_MI355_ENGINE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/beast-mcmc_amd/lib/lab/libhmsbeagle-jni.so}
 # how the size of the independent subtrees the planner cuts the forest into (BEAGLE_MI355_CHUNK, 0 = one walk) moves the headline
 # usage: bash tools/chunk_sweep.sh [patterns] [chunk sizes...]
 P=${1:-100000}; shift

@@ -1,3 +1,5 @@
+# (the knobs below exist in LAB builds only: python beast-mcmc_amd/build.py --lab)
+export BEAGLE_MI355_ENGINE_LIB=${BEAGLE_MI355_ENGINE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/beast-mcmc_amd/lib/lab/libhmsbeagle-jni.so}
 #!/bin/bash
 # the assembly loop's full-line result stores with and without the non-temporal hint; run on the GPU box
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT

@@ -57,7 +57,7 @@ DIVS, SCNT, EXCH, NCAT, ROFF, RB = 76, 78, 79, 80, 81, 82    # RB: byte offset o
 S_FIRST = 20
 
 # flag bits (kernels.h)
-B_X, B_T1, B_T2, B_INV, B_STORE, B_HSLOT1, B_WRITE = 0, 1, 2, 3, 4, 12, 14
+B_X, B_T1, B_T2, B_INV, B_STORE, B_HSLOT1, B_READ, B_WRITE = 0, 1, 2, 3, 4, 12, 13, 14     # (B_READ / B_WRITE: the scale mode, WS_READ = 1, WS_WRITE = 2 at bit 13)
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
 # the stage's wait as a 3-bit code at B_WAIT0 (kernels.h walkWaitCode): vmcnt(N) with N = WAIT_N[code]; code 0 is the common one
 # (a fetch is THREE small loads — matrix table, two tip-state pairs — and a fourth, the reciprocal scale factors, only for a
@@ -417,7 +417,7 @@ def stage(tag, cur):
     for i in range(8):
         e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(F + 2 * i, 2), v(G + 2 * i, 2)))
     pad_block()
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WRITE) | (1 << B_STORE) | (1 << B_INV)))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_WRITE) | (1 << B_STORE) | (1 << B_READ)))
     e("s_cbranch_scc1 %s" % L("tl" + tag))
     e(L("tlb" + tag) + ":")
     # the rare tail — a result that pays scale factors (read mode: one multiplication by the reciprocals fetched with it), write-mode
@@ -429,7 +429,8 @@ def stage(tag, cur):
     mulblk.append("s_branch %s" % L("mlb" + tag))
     outofline.append(mulblk)
     outofline.append([L("tl" + tag) + ":",
-                      "s_bitcmp1_b32 %s, %d" % (s(SFL), B_INV), "s_cbranch_scc1 %s" % L("ml" + tag), L("mlb" + tag) + ":",
+                      # (WF_INV alone — a fetch padded to four loads behind write-mode rescaling, engine_walk.cpp runPlan — multiplies nothing)
+                      "s_bitcmp1_b32 %s, %d" % (s(SFL), B_READ), "s_cbranch_scc1 %s" % L("ml" + tag), L("mlb" + tag) + ":",
                       "s_bitcmp1_b32 %s, %d" % (s(SFL), B_WRITE), "s_cbranch_scc1 %s" % L("wr" + tag), L("wrb" + tag) + ":",
                       "s_bitcmp1_b32 %s, %d" % (s(SFL), B_STORE), "s_cbranch_scc1 %s" % L("st" + tag), L("stb" + tag) + ":",
                       "s_branch %s" % L("tlb" + tag)])

@@ -1,3 +1,5 @@
+# (the knobs below exist in LAB builds only: python beast-mcmc_amd/build.py --lab)
+export BEAGLE_MI355_ENGINE_LIB=${BEAGLE_MI355_ENGINE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/beast-mcmc_amd/lib/lab/libhmsbeagle-jni.so}
 #!/bin/bash
 # k_walk4 (the C++ walk kernel: write-mode rescaling, unaligned partitions) with and without the non-temporal hint on its
 # half-line result stores; run on the GPU box.  BEAGLE_MI355_NO_FAST_WALK=1 sends every launch to it.

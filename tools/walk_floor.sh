@@ -1,3 +1,5 @@
+# (the knobs below exist in LAB builds only: python beast-mcmc_amd/build.py --lab)
+export BEAGLE_MI355_ENGINE_LIB=${BEAGLE_MI355_ENGINE_LIB:-$(cd "$(dirname "$0")/.." && pwd)/beast-mcmc_amd/lib/lab/libhmsbeagle-jni.so}
 #!/bin/bash
 # What the walk's time is made of: rebuild the assembly loop with one part left out at a time (WALK4_EXPERIMENT, wrong
 # results by construction) and time config A with and without the result stores.  Run on the GPU box (hipcc is there).
