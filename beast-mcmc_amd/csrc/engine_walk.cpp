@@ -31,7 +31,11 @@ static int foldFor(Instance* in, const std::vector<int>& members) {
     Instance::FoldVec f;
     f.members = members;
     if (!in->foldFree.empty()) { f.recip = in->foldFree.back(); in->foldFree.pop_back(); }
-    else if (devAlloc(in, (void**)&f.recip, in->scaleStride * sizeof(double))) return -1;
+    else {
+        if (devAlloc(in, (void**)&f.recip, in->scaleStride * sizeof(double))) return -1;
+        // (the T32 walk reads whole tiles: what lies past the last pattern must be a number it can divide by)
+        if (in->walkT) mi355::launchFill(live(in), f.recip, 1.0, 0, (int)in->scaleStride);
+    }
     in->folds.push_back(f);
     const int id = (int)in->folds.size() - 1;
     in->foldIndex.insert(it, std::make_pair(h, id));
@@ -52,7 +56,7 @@ static int refreshFolds(Instance* in, const std::vector<int>& ids, bool* anyBad)
         for (int id : stale) {
             const Instance::FoldVec& f = in->folds[(size_t)id];
             start.push_back((int)srcs.size());
-            for (int m : f.members) srcs.push_back(in->scale[m] + in->scaleStride);
+            for (int m : f.members) srcs.push_back(in->scale[m] + (in->walkT ? 0 : in->scaleStride));    // (reciprocal halves; T32: the factors)
             dst.push_back(f.recip);
         }
         start.push_back((int)srcs.size());
@@ -72,8 +76,8 @@ static int refreshFolds(Instance* in, const std::vector<int>& ids, bool* anyBad)
             int rc = uploadTransient(in, srcs.data() + base, (size_t)st.back() * sizeof(double*), &dSrcs); if (rc) return rc;
             rc = uploadTransient(in, st.data(), st.size() * sizeof(int), &dStart); if (rc) return rc;
             rc = uploadTransient(in, dst.data() + b, (e - b) * sizeof(double*), &dDst); if (rc) return rc;
-            mi355::launchFoldReciprocals(live(in), (const double* const*)dSrcs, (const int*)dStart, (double* const*)dDst, (int)(e - b), (int)in->pairLen,
-                                         in->foldWorst + b);
+            mi355::launchFoldReciprocals(live(in), (const double* const*)dSrcs, (const int*)dStart, (double* const*)dDst, (int)(e - b),
+                                         in->walkT ? in->P : (int)in->pairLen, in->foldWorst + b, in->walkT);
         }
         HIP_TRY(hipGetLastError());
         std::vector<unsigned long long> worst(stale.size());
@@ -133,7 +137,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     if (slot) { slot->tag = 0; slot->dProgValid = false; slot->folds.clear(); slot->foldEpoch = -1; }
     // read-mode programs of cached (full-evaluation) plans fold the reciprocals of unstored nodes (Instance::folds, planner.h FoldMap)
     mi355::FoldMap foldMap;
-    const bool fold = slot && in->foldScales && in->walk && !in->walkT && slot->noFoldTag != planTag &&
+    const bool fold = slot && in->foldScales && (in->walk || in->walkT) && slot->noFoldTag != planTag &&
                       mi355::foldScaleFactors(plan, FOLD_MAX_MEMBERS, foldMap);
     std::vector<int> cur;
     w.clear();
@@ -196,7 +200,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             if (fold) {                            // multiply by what the planner says this result pays for — nothing, one buffer's reciprocals, a fold
                 const int b0 = foldMap.payStart[(size_t)i], b1 = foldMap.payStart[(size_t)i + 1];
                 smodeNow = b1 > b0 ? mi355::PS_READ : mi355::PS_NONE;
-                if (b1 - b0 == 1) d.scale = in->scale[foldMap.members[(size_t)b0]] + in->scaleStride;
+                if (b1 - b0 == 1) d.scale = in->scale[foldMap.members[(size_t)b0]] + (in->walkT ? 0 : in->scaleStride);
                 else if (b1 > b0) {
                     cur.assign(foldMap.members.begin() + b0, foldMap.members.begin() + b1);
                     const int f = foldFor(in, cur);

@@ -232,7 +232,9 @@ void launchAccumulateScale(hipStream_t stream, double* cum, const double* const*
 void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd);
 // dst[j][i] = prod_m srcs[m][i] over m in [start[j], start[j + 1]), i < len; worst[j] (zeroed by the caller) = bit pattern of job j's
 // largest product, +infinity for anything not finite (kernels.hip k_foldReciprocals)
-void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst);
+// invert: the sources are factors (<= 1), the range check is on 1 / product (the T32 walk, which divides by what it reads)
+void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst,
+                           bool invert = false);
 // out[p] = raw ? log(in[p]) : in[p]
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
 // Read-back: out[c][p][i] (API layout) = partials * scale, from either device layout.  `scale` may be

@@ -707,22 +707,24 @@ void launchFill(hipStream_t stream, double* dst, double value, int pStart, int p
 // srcs[start[j]] .. srcs[start[j + 1] - 1] of per-node scale buffers, entry by entry in that order, into dst[j]; worst[j] receives the
 // largest product of the job as a bit pattern (positive doubles order like their bit patterns; anything not finite counts as
 // +infinity) — the host refuses a fold whose products leave the safe range.  worst[] must be zero before the launch.
+// invert: the sources are the factors themselves (<= 1: the T32 walk divides by them), the range check looks at 1 / product.
 __global__ __launch_bounds__(256) void k_foldReciprocals(const double* const* __restrict__ srcs, const int* __restrict__ start, double* const* __restrict__ dst,
-                                                         int len, unsigned long long* __restrict__ worst) {
+                                                         int len, unsigned long long* __restrict__ worst, int invert) {
     const int j = (int)blockIdx.y, i = (int)(blockIdx.x * 256 + threadIdx.x);
     double prod = 1.0;
     if (i < len) {
         for (int m = start[j]; m < start[j + 1]; m++) prod *= srcs[m][i];
         dst[j][i] = prod;
+        if (invert) prod = 1.0 / prod;
     }
     if (!(prod <= 1.7976931348623157e308)) prod = __longlong_as_double(0x7ff0000000000000ll);
     unsigned long long bits = (unsigned long long)__double_as_longlong(prod);
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(bits, o); bits = other > bits ? other : bits; }
     if ((threadIdx.x & 63) == 0) atomicMax(worst + j, bits);
 }
-void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst) {
+void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst, bool invert) {
     if (nJobs <= 0 || len <= 0) return;
-    hipLaunchKernelGGL(k_foldReciprocals, dim3((unsigned)((len + 255) / 256), (unsigned)nJobs), dim3(256), 0, stream, dSrcs, dStart, dDst, len, dWorst);
+    hipLaunchKernelGGL(k_foldReciprocals, dim3((unsigned)((len + 255) / 256), (unsigned)nJobs), dim3(256), 0, stream, dSrcs, dStart, dDst, len, dWorst, invert ? 1 : 0);
 }
 
 __global__ void k_logScale(const double* in, double* out, int raw, int P) {

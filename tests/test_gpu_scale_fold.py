@@ -65,9 +65,10 @@ def steady_state(wl, fold, fast=True, nodes=()):
     return first, vals, site, parts, factors, stats, health
 
 
-@pytest.mark.parametrize("T,P,C,kind", [(260, 2100, 4, "coalescent"), (120, 333, 1, "yule"), (90, 1500, 8, "caterpillar"), (400, 9000, 4, "coalescent")])
-def test_folded_and_per_node_factors_agree(T, P, C, kind, oracle_lib):
-    wl = helpers.random_workload(T, P, 4, C, seed=8200 + T, tree_kind=kind)
+@pytest.mark.parametrize("T,P,C,kind,S", [(260, 2100, 4, "coalescent", 4), (120, 333, 1, "yule", 4), (90, 1500, 8, "caterpillar", 4), (400, 9000, 4, "coalescent", 4),
+                                          (70, 900, 4, "coalescent", 20), (45, 333, 2, "yule", 17)])      # (16..20 states: the same programs on k_walkT32, which divides by the factors)
+def test_folded_and_per_node_factors_agree(T, P, C, kind, S, oracle_lib):
+    wl = helpers.random_workload(T, P, S, C, seed=8200 + T, tree_kind=kind)
     nodes = list(range(wl.tree.tip_count, wl.tree.node_count))
     f0, fv, fs, fp, ff, fstats, fh = steady_state(wl, True, nodes=nodes)
     u0, uv, us, up, uf, ustats, uh = steady_state(wl, False, nodes=nodes)

@@ -33,6 +33,22 @@ for n in ('A','Aalways','shard'):
     print('pad=$V', n, d['value'], 'evals/s ms', d['ms_per_step'], 'median', d.get('ms_per_step_median'), 'kernel us', d['roofline']['kernel_us_per_eval'])
 PY
   done;;
+store_ab)
+  # cache policy of the walk's result stores (tools/build_variant.sh <name> 'WALK4_STORE_POLICY=...' first): device-scope write-through
+  # + non-temporal (the build's) / non-temporal only / plain / write-through only.  Without sc1 the slices of a one-launch program
+  # may read stale lines across XCDs: TIMING ONLY.
+  for V in product st_nt st_plain st_sc1; do
+    if [ $V = product ]; then export BEAGLE_MI355_ENGINE_LIB=$R/beast-mcmc_amd/lib/libhmsbeagle-jni.so; else export BEAGLE_MI355_ENGINE_LIB=$R/build/variants/$V/libhmsbeagle-jni.so; fi
+    [ -f $BEAGLE_MI355_ENGINE_LIB ] || continue
+    timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records > gpurun_out/r5_store_${V}_A.json 2>/dev/null
+    timeout 300 python bench.py --patterns 12500 --steps 200 --warmup 10 --no-cpu-baseline --no-live-traffic --no-library-route --no-side-records > gpurun_out/r5_store_${V}_shard.json 2>/dev/null
+    python - <<PY
+import json
+for n in ('A','shard'):
+    d=json.loads(open('gpurun_out/r5_store_${V}_%s.json' % n).read().strip().splitlines()[-1])
+    print('stores=$V', n, d['value'], 'evals/s median ms', d.get('ms_per_step_median'), 'kernel us', d['roofline']['kernel_us_per_eval'], 'lnL', d['lnL'])
+PY
+  done;;
 gradtrace)
   (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5_gradtrace -o kt -- python $R/tools/gradient_bench.py --steps 6 > $R/gpurun_out/r5_gradtrace.json 2> $R/gpurun_out/r5_gradtrace.err)
   find gpurun_out/r5_gradtrace -name "*.db" -delete 2>/dev/null
