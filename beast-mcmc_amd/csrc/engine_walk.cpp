@@ -281,16 +281,17 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
     if (slot) {
-        // (a no-op's tables are fetched and never looked at — behind a program's end they are not even computed on —: no copy for them)
-        auto isNop = [&](const mi355::WalkOp& q) { return q.src1 == in->dummyTips && q.src2 == in->dummyTips && !(q.flags & (mi355::WF_STORE | mi355::WF_HWRITE)) &&
-                                                          q.m1 == in->matrices && q.m2 == in->matrices; };
+        // the no-ops read SOME matrix: the first real micro-operation's (a matrix every evaluation of this program computes anyway)
+        for (mi355::WalkOp& q : w)
+            if (q.m1 == in->matrices && q.m2 == in->matrices && q.src1 == in->dummyTips && q.src2 == in->dummyTips && !(q.flags & mi355::WF_STORE) && !w.empty())
+                for (const mi355::WalkOp& r : w) if (r.m1 != in->matrices || r.src1 != in->dummyTips) { q.m1 = q.m2 = r.m1; break; }
         // inverse map of the matrix stream (engine_internal.h PendingTransition): who takes a copy of caller matrix m
         slot->useOk = !in->walkT && in->S == 4;
         slot->useStart.assign((size_t)in->matrixCount + 1, 0); slot->useList.clear(); slot->coveredIdx.clear();
         if (slot->useOk) {
             const size_t stride = (size_t)in->C * 16;
             auto indexOf = [&](const double* ptr) { return (long)((ptr - in->matrices) / (long)stride); };
-            for (const mi355::WalkOp& q : w) if (!isNop(q)) for (const double* ptr : {q.m1, q.m2}) { const long m = indexOf(ptr); if (m < 0 || m >= in->matrixCount) slot->useOk = false; else slot->useStart[(size_t)m + 1]++; }
+            for (const mi355::WalkOp& q : w) for (const double* ptr : {q.m1, q.m2}) { const long m = indexOf(ptr); if (m < 0 || m >= in->matrixCount) slot->useOk = false; else slot->useStart[(size_t)m + 1]++; }
             for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) { const int m = plan.snapPairs[q]; if (m < 0 || m >= in->matrixCount) slot->useOk = false; else slot->useStart[(size_t)m + 1]++; }
         }
         if (slot->useOk) {
@@ -299,7 +300,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             std::vector<int> at(slot->useStart.begin(), slot->useStart.end() - 1);
             const size_t stride = (size_t)in->C * 16;
             for (size_t k = 0; k < w.size(); k++) {
-                if (isNop(w[k])) continue;
                 slot->useList[(size_t)at[(size_t)((w[k].m1 - in->matrices) / (long)stride)]++] = (unsigned)(2 * k);
                 slot->useList[(size_t)at[(size_t)((w[k].m2 - in->matrices) / (long)stride)]++] = (unsigned)(2 * k + 1);
             }
@@ -414,7 +414,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->matStream = nullptr; in->matStreamBytes = 0;
         const size_t want = std::max(streamBytes + streamBytes / 4, (size_t)1 << 20);
         HIP_TRY(hipMalloc((void**)&in->matStream, want));
-        HIP_TRY(hipMemsetAsync(in->matStream, 0, want, live(in)));        // (no-op descriptors' tables are never written by the merged launch: zeros, not whatever the allocation holds)
         in->matStreamBytes = want;
     }
     if (scattered) {}

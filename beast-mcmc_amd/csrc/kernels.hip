@@ -229,7 +229,6 @@ __global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ m
 // The same, and what k_gatherAndSnapshot (kernels_walk4.hip) would do with the result in a launch of its own: the thread that has
 // matrix (idx[u], c) in registers also writes it wherever the walk program about to run reads it — as a 5-column table of the
 // matrix stream (column 4 = ones, the missing state) or as the private snapshot of a virtual definition.  Same values, same bits.
-constexpr int SCATTER_CAP = 2048;                     // copies a workgroup stages per round (its 256 matrices take ~6 each in config A)
 __global__ __launch_bounds__(256) void k_transition4Scatter(double* __restrict__ matrices, const double* __restrict__ eigSrc,
                                                             const double* __restrict__ ratesSrc, const int* __restrict__ idx,
                                                             const double* __restrict__ len, int count, int C, int complexEigen,
@@ -238,66 +237,41 @@ __global__ __launch_bounds__(256) void k_transition4Scatter(double* __restrict__
     if ((int)blockIdx.x >= transitionBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)transitionBlocks); return; }
     __shared__ double sEig[40], sRate[16];
     __shared__ double sM[256][17];                      // the workgroup's matrices (17: the cooperative reads below stay off one bank)
-    __shared__ int sFirst[256], sOff[257];              // per matrix: where its copies start in useList / in the workgroup's work list
-    __shared__ unsigned sUse[SCATTER_CAP];
-    __shared__ unsigned char sOwner[SCATTER_CAP];
+    __shared__ int sIdx[256];
     const int nEig = complexEigen ? 40 : 36;
     if ((int)threadIdx.x < nEig) sEig[threadIdx.x] = eigSrc[threadIdx.x];
     else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C && C <= 16) sRate[threadIdx.x - 64] = ratesSrc[threadIdx.x - 64];
     __syncthreads();
-    const int tid = (int)threadIdx.x, t = blockIdx.x * 256 + tid;
+    const int t = blockIdx.x * 256 + threadIdx.x;
     const bool mine = t < count * C;
     const int u = mine ? t / C : 0, c = mine ? t - u * C : 0;
-    int first = 0, n = 0;
+    int mi = -1;
     if (mine) {
-        const int mi = idx[u];
-        first = useStart[mi]; n = useStart[mi + 1] - first;       // (requested before the arithmetic, used behind it)
         const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
         double m[16];
         transition4Matrix(sEig, dist, complexEigen, m);
+        mi = idx[u];
         double* M = matrices + ((size_t)mi * C + c) * 16;
-        for (int e = 0; e < 16; e++) { M[e] = m[e]; sM[tid][e] = m[e]; }
+        for (int e = 0; e < 16; e++) { M[e] = m[e]; sM[threadIdx.x][e] = m[e]; }
     }
-    // The copies: every one leaves as ONE contiguous piece written by neighbouring lanes — 20 lanes a 160-byte table of the stream,
-    // 16 lanes a 128-byte snapshot — and nothing in the loop that writes them waits for memory: the workgroup's work list (a
-    // matrix's copies behind one another: an exclusive scan of the counts) is staged in LDS first, all its entries requested at
-    // once.  (A thread writing its own copies one after the other, each behind a dependent load: 77 us per evaluation.)
-    sFirst[tid] = first; sOff[tid + 1] = n;
-    if (tid == 0) sOff[0] = 0;
+    sIdx[threadIdx.x] = mi;
     __syncthreads();
-    if (tid < 64) {                                     // inclusive scan of 256 counts by one wave: four per lane, then across the lanes
-        int a0 = sOff[4 * tid + 1], a1 = a0 + sOff[4 * tid + 2], a2 = a1 + sOff[4 * tid + 3], a3 = a2 + sOff[4 * tid + 4];
-        int run = a3;
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(run, o, 64); if (tid >= o) run += v; }
-        const int base = run - a3;
-        sOff[4 * tid + 1] = base + a0; sOff[4 * tid + 2] = base + a1; sOff[4 * tid + 3] = base + a2; sOff[4 * tid + 4] = base + a3;
-    }
-    __syncthreads();
-    const int total = sOff[256];
-    const int cMine = c;
-    (void)cMine;
-    const int half = tid >> 5, l = tid & 31;
-    for (int round = 0; round < total; round += SCATTER_CAP) {
-        const int lim = total - round < SCATTER_CAP ? total - round : SCATTER_CAP;
-        for (int w = tid; w < lim; w += 256) {          // entry `round + w` of the work list: whose, and which of its copies
-            const int g = round + w;
-            int lo = 0, hi = 255;                       // the owner: last matrix whose start is <= g (the counts may be 0)
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sOff[mid] <= g) lo = mid; else hi = mid - 1; }
-            sOwner[w] = (unsigned char)lo;
-            sUse[w] = useList[sFirst[lo] + (g - sOff[lo])];
-        }
-        __syncthreads();
-        for (int w = half; w < lim; w += 8) {
-            const unsigned use = sUse[w];
-            const int s = sOwner[w];
-            const int cc = (int)((blockIdx.x * 256u + (unsigned)s) % (unsigned)C);
+    // every copy leaves as ONE contiguous piece written by neighbouring lanes: half a wave per copy — 20 lanes a 160-byte table of
+    // the stream, 16 lanes a 128-byte snapshot (a thread writing its own copies alone: 64 cache lines per store instruction, 50 us
+    // per evaluation of config A instead of 8)
+    const int half = (int)(threadIdx.x >> 5), l = (int)(threadIdx.x & 31);
+    for (int s = half; s < 256; s += 8) {
+        const int m = sIdx[s];
+        if (m < 0) continue;
+        const int cc = (int)((blockIdx.x * 256u + (unsigned)s) % (unsigned)C);
+        for (int q = useStart[m]; q < useStart[m + 1]; q++) {
+            const unsigned use = useList[q];
             if (use & 0x80000000u) {
                 if (l < 16) matrices[((size_t)(use & 0x7fffffffu) * C + cc) * 16 + l] = sM[s][l];
             } else if (l < 20) {
                 matStream[((size_t)(use >> 1) * C + cc) * 40 + (use & 1u) * 20 + l] = l < 16 ? sM[s][(l & 3) * 4 + (l >> 2)] : 1.0;
             }
         }
-        __syncthreads();
     }
 }
 void launchTransitionMatrices4Scatter(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
