@@ -68,7 +68,6 @@ void launchPublish(hipStream_t stream, const double* src, int n, double* dst, un
 // two rows of U^-1 (ComplexSubstitutionModel.java:121-173).  Row k of a pair is its FIRST row iff an even number of rows
 // with a nonzero imaginary part precede it without a gap (the reference walks the rows in order and skips the second).
 __device__ __forceinline__ double iexpEntry(const double* __restrict__ Ui, const double* __restrict__ lam, int S, int k, int j, double dist, int complexEigen) {
-#pragma clang fp contract(off)
     const double im = complexEigen ? lam[S + k] : 0.0;
     if (im == 0.0) return Ui[k * S + j] * exp(dist * lam[k]);
     int run = 0;
@@ -150,26 +149,6 @@ __global__ __launch_bounds__(256) void k_transitionBig(double* __restrict__ matr
     }
 }
 
-// The 4-state matrix of one (branch, category) — P = U diag(exp(lambda dist)) U^-1, negatives clamped — with every rounding spelled
-// out (no contraction left to the compiler: the three kernels below inline it into different surroundings and must give the same
-// bits — k_transition4Scatter writes a matrix to the walk's stream that a later partial update reads back from the caller's slot).
-__device__ __forceinline__ void transition4Matrix(const double* __restrict__ U, double dist, int complexEigen, double* __restrict__ m) {
-#pragma clang fp contract(off)
-    const double* Ui = U + 16;
-    const double* lam = U + 32;
-    double ie[16];
-    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
-    else for (int k = 0; k < 4; k++) { const double x = dist * lam[k]; const double ex = exp(x); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = U[i * 4] * ie[j];
-            s = __builtin_fma(U[i * 4 + 1], ie[4 + j], s);
-            s = __builtin_fma(U[i * 4 + 2], ie[8 + j], s);
-            s = __builtin_fma(U[i * 4 + 3], ie[12 + j], s);
-            m[i * 4 + j] = s > 0.0 ? s : 0.0;
-        }
-}
-
 // 4 states: one THREAD per (branch, category) — a workgroup per matrix would be 64 lanes for 16 outputs (and, for the 12 872
 // matrices of a four-partition 1610-taxon evaluation, 51 488 workgroups).  Same arithmetic and summation order as k_transition.
 __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matrices, const double* __restrict__ eigen,
@@ -180,11 +159,19 @@ __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matric
     if (t >= count * C) return;
     const int u = t / C, c = t - u * C;
     const double* U = eigen + (size_t)(complexEigen ? 40 : 36) * dEig[u];
+    const double* Ui = U + 16;
+    const double* lam = U + 32;
     const double dist = dLen[u] * rates[(size_t)dRate[u] * C + c];
-    double m[16];
-    transition4Matrix(U, dist, complexEigen, m);
+    double ie[16];
+    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
+    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
     double* M = matrices + ((size_t)dIdx[u] * C + c) * 16;
-    for (int e = 0; e < 16; e++) M[e] = m[e];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
+            M[i * 4 + j] = s > 0.0 ? s : 0.0;
+        }
 }
 
 __device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block) {
@@ -219,11 +206,20 @@ __global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ m
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count * C) return;
     const int u = t / C, c = t - u * C;
+    const double* U = sEig;
+    const double* Ui = U + 16;
+    const double* lam = U + 32;
     const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
-    double m[16];
-    transition4Matrix(sEig, dist, complexEigen, m);
+    double ie[16];
+    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
+    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
     double* M = matrices + ((size_t)idx[u] * C + c) * 16;
-    for (int e = 0; e < 16; e++) M[e] = m[e];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
+            M[i * 4 + j] = s > 0.0 ? s : 0.0;
+        }
 }
 
 // The same, and what k_gatherAndSnapshot (kernels_walk4.hip) would do with the result in a launch of its own: the thread that has
@@ -236,41 +232,38 @@ __global__ __launch_bounds__(256) void k_transition4Scatter(double* __restrict__
                                                             const unsigned* __restrict__ useList, double* __restrict__ matStream) {
     if ((int)blockIdx.x >= transitionBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)transitionBlocks); return; }
     __shared__ double sEig[40], sRate[16];
-    __shared__ double sM[256][17];                      // the workgroup's matrices (17: the cooperative reads below stay off one bank)
-    __shared__ int sIdx[256];
     const int nEig = complexEigen ? 40 : 36;
     if ((int)threadIdx.x < nEig) sEig[threadIdx.x] = eigSrc[threadIdx.x];
     else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C && C <= 16) sRate[threadIdx.x - 64] = ratesSrc[threadIdx.x - 64];
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const bool mine = t < count * C;
-    const int u = mine ? t / C : 0, c = mine ? t - u * C : 0;
-    int mi = -1;
-    if (mine) {
-        const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
-        double m[16];
-        transition4Matrix(sEig, dist, complexEigen, m);
-        mi = idx[u];
-        double* M = matrices + ((size_t)mi * C + c) * 16;
-        for (int e = 0; e < 16; e++) { M[e] = m[e]; sM[threadIdx.x][e] = m[e]; }
-    }
-    sIdx[threadIdx.x] = mi;
-    __syncthreads();
-    // every copy leaves as ONE contiguous piece written by neighbouring lanes: half a wave per copy — 20 lanes a 160-byte table of
-    // the stream, 16 lanes a 128-byte snapshot (a thread writing its own copies alone: 64 cache lines per store instruction, 50 us
-    // per evaluation of config A instead of 8)
-    const int half = (int)(threadIdx.x >> 5), l = (int)(threadIdx.x & 31);
-    for (int s = half; s < 256; s += 8) {
-        const int m = sIdx[s];
-        if (m < 0) continue;
-        const int cc = (int)((blockIdx.x * 256u + (unsigned)s) % (unsigned)C);
-        for (int q = useStart[m]; q < useStart[m + 1]; q++) {
-            const unsigned use = useList[q];
-            if (use & 0x80000000u) {
-                if (l < 16) matrices[((size_t)(use & 0x7fffffffu) * C + cc) * 16 + l] = sM[s][l];
-            } else if (l < 20) {
-                matStream[((size_t)(use >> 1) * C + cc) * 40 + (use & 1u) * 20 + l] = l < 16 ? sM[s][(l & 3) * 4 + (l >> 2)] : 1.0;
-            }
+    if (t >= count * C) return;
+    const int u = t / C, c = t - u * C;
+    const double* U = sEig;
+    const double* Ui = U + 16;
+    const double* lam = U + 32;
+    const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
+    double ie[16], m[16];
+    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
+    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
+    const int mi = idx[u];
+    double* M = matrices + ((size_t)mi * C + c) * 16;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
+            m[i * 4 + j] = s > 0.0 ? s : 0.0;
+            M[i * 4 + j] = m[i * 4 + j];
+        }
+    for (int q = useStart[mi]; q < useStart[mi + 1]; q++) {
+        const unsigned use = useList[q];
+        if (use & 0x80000000u) {
+            double* D = matrices + ((size_t)(use & 0x7fffffffu) * C + c) * 16;
+            for (int e = 0; e < 16; e++) D[e] = m[e];
+        } else {
+            double* T = matStream + ((size_t)(use >> 1) * C + c) * 40 + (use & 1u) * 20;
+            for (int col = 0; col < 4; col++) for (int i = 0; i < 4; i++) T[col * 4 + i] = m[i * 4 + col];
+            T[16] = 1.0; T[17] = 1.0; T[18] = 1.0; T[19] = 1.0;
         }
     }
 }
