@@ -511,10 +511,9 @@ class Beagle:
 
     def walkHealth(self):
         """The one-launch walk since instance creation (include/beagle_mi355.h beagleMi355WalkHealth)."""
-        out = (C.c_long * 8)()
+        out = (C.c_long * 4)()
         self._check("walkHealth", self._ext("beagleMi355WalkHealth", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
-        return {"self_served": int(out[0]), "spin_limit_us": int(out[1]), "folded_vectors": int(out[2]), "fold_builds": int(out[3]),
-                "merged_transition_launches": int(out[4])}
+        return {"self_served": int(out[0]), "spin_limit_us": int(out[1]), "folded_vectors": int(out[2]), "fold_builds": int(out[3])}
 
     def gradientStats(self):
         """How the pre-order lists of this instance were run (include/beagle_mi355.h beagleMi355GradientStats)."""

@@ -147,18 +147,6 @@ static int rootByPartitionDevice(int instance, const int* bufferIndices, const i
 }
 
 namespace mi355 {
-namespace eng {
-// launch the transition-matrix call that was held back, as it is (k_transition4Fused)
-int flushTransition(Instance* in) {
-    Instance::PendingTransition& pt = in->pendingTransition;
-    if (!pt.valid) return 0;
-    pt.valid = false;
-    mi355::launchTransitionMatrices4Fused(in->stream, in->matrices, pt.eigSrc, pt.ratesSrc, pt.idx, pt.len, pt.count, in->C, in->eigenComplex,
-                                          pt.copies, pt.copyBlocks);
-    if (hipGetLastError() != hipSuccess) { if (!in->asyncError) in->asyncError = BEAGLE_ERROR_GENERAL; return BEAGLE_ERROR_GENERAL; }
-    return 0;
-}
-}  // namespace eng
 int publishAndWait(int instance, const double* dValues, int count, double* out) {
     GET_INSTANCE_KEEP_PENDING(instance);
     if (!dValues || !out || count < 1 || count > 480) return BEAGLE_ERROR_OUT_OF_RANGE;
@@ -166,7 +154,7 @@ int publishAndWait(int instance, const double* dValues, int count, double* out) 
     mi355::launchPublish(live(in), dValues, count, in->hResultDev + 16, (unsigned long long*)(in->hResultDev + 8), seq);
     HIP_TRY(hipGetLastError());
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     memcpy(out, in->hResult + 16, (size_t)count * sizeof(double));
     return BEAGLE_SUCCESS;
 }
@@ -366,7 +354,6 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
-    in->deferTransition = in->fuseLaunches;
     in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&
                           !(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL")) != 0);
     if (labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS")) in->gradientVirtualSteps = std::max(1, std::min(GRADIENT_VIRT_STEPS, atoi(labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS"))));
@@ -703,7 +690,7 @@ static int exportPartials(Instance* in, const int* bufferIndices, const int* sca
     }
     const int last = (int)((nChunks - 1) & 1);
     HIP_TRY(hipEventSynchronize(in->exportEvent[last]));
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     if (out) copies[last].start((char*)(out + (nChunks - 1) * chunk * elems), (const char*)in->exportHost[last], chunkCount(nChunks - 1) * bytes);
     copies[0].join(); copies[1].join();
     return BEAGLE_SUCCESS;
@@ -943,17 +930,10 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
                 if ((const char*)L.e[b].dst <= (const char*)L.e[a].dst &&
                     (const char*)L.e[a].dst + L.e[a].bytes <= (const char*)L.e[b].dst + L.e[b].bytes) L.e[a].bytes = 0;
         in->pendingCopies.clear();
-        // (an earlier call still held: it goes first, as it is)
-        if (in->pendingTransition.valid) { int rcf = flushTransition(in); if (rcf) return rcf; }
-        Instance::PendingTransition& pt = in->pendingTransition;
-        pt.copies = L; pt.copyBlocks = (int)blocks; pt.eigSrc = eigSrc; pt.ratesSrc = ratesSrc;
-        pt.idx = (const int*)(in->hRingDev + off + lenBytes); pt.len = (const double*)(in->hRingDev + off);
-        pt.hostIdx = (const int*)(in->hRing + off + lenBytes); pt.count = count;
-        pt.valid = true;
-        // held back for updatePartials when the call covers a whole tree's worth of branches (what runPlan can merge with a cached
-        // program's gather); a partial update's few matrices are launched at once
-        if (in->walk && in->deferTransition && count >= 64) return BEAGLE_SUCCESS;
-        return flushTransition(in);
+        mi355::launchTransitionMatrices4Fused(in->stream, in->matrices, eigSrc, ratesSrc, (const int*)(in->hRingDev + off + lenBytes),
+                                              (const double*)(in->hRingDev + off), count, in->C, in->eigenComplex, L, (int)blocks);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
     }
     // one packed upload: [lengths double[count] | matrix idx | eigen idx | rate idx] (each copy is a blit kernel)
     std::vector<char> pack((size_t)count * (sizeof(double) + 3 * sizeof(int)));
@@ -1054,7 +1034,7 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int coun
     (void)destinationPartials; (void)count;
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1150,7 +1130,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
                          cumulativeScaleIndices[0], -1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     if (rc) return rc;
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (ringIdle(in)) in->ringHead = 0;   // everything staged so far has been consumed
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;   // everything staged so far has been consumed
     const double v = in->hResult[0];
     *outSumLogLikelihood = v;
     return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
@@ -1212,7 +1192,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
         if (*flag != seq) HIP_TRY(hipStreamSynchronize(live(in)));
         if (*flag != seq) return BEAGLE_ERROR_GENERAL;
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (ringIdle(in)) in->ringHead = 0;
+        if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
         double tot = 0.0;
         for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[16 + k]; tot += in->hResult[16 + k]; }
         *outSum = tot;
@@ -1377,7 +1357,7 @@ int beagleMi355SetStream(int instance, void* hipStream) {
     if (mi355::isShardedHandle(instance)) { return BEAGLE_ERROR_NO_IMPLEMENTATION; }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     in->stream = hipStream ? (hipStream_t)hipStream : in->ownStream;
     return BEAGLE_SUCCESS;
 }
@@ -1441,7 +1421,7 @@ int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferInde
     mi355::launchRootFinal(live(in), in->dResult, 1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     HIP_TRY(hipGetLastError());
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     const double v = in->hResult[0];
     *outGlobalSum = v;
     return (v != v) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
@@ -1451,7 +1431,7 @@ int beagleMi355Synchronize(int instance) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedBroadcast(instance, [&](int h) { return beagleMi355Synchronize(h); }); }
     GET_INSTANCE_KEEP_PENDING(instance);                      // (a held-back pre-order list is not work in flight)
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1466,7 +1446,7 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     }
     GET_INSTANCE(instance);
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (ringIdle(in)) in->ringHead = 0;
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     for (size_t k = 0; k < in->eventsUsed; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, in->events[k].first, in->events[k].second) == hipSuccess) in->timedMs += ms;
@@ -1547,7 +1527,7 @@ int beagleMi355WalkStats(int instance, long* out8) {
     return BEAGLE_SUCCESS;
 }
 
-int beagleMi355WalkHealth(int instance, long* out4) {     // (out8)
+int beagleMi355WalkHealth(int instance, long* out4) {
     if (mi355::isShardedHandle(instance)) {             // shard 0's
         bool first = true; std::mutex mu;
         return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkHealth(h, out4); });
@@ -1557,7 +1537,6 @@ int beagleMi355WalkHealth(int instance, long* out4) {     // (out8)
     unsigned served = 0;
     if (in->walkSelfServed) { int rc = download(in, &served, in->walkSelfServed, sizeof(served)); if (rc) return rc; }
     out4[0] = (long)served; out4[1] = (long)(in->walkSpinLimit / 100ull); out4[2] = in->statFoldedVectors; out4[3] = in->statFoldBuilds;
-    out4[4] = in->statScatterLaunches; out4[5] = out4[6] = out4[7] = 0;
     return BEAGLE_SUCCESS;
 }
 

@@ -108,7 +108,7 @@ int flushUploads(Instance* in) {
 int download(Instance* in, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, live(in)));
     HIP_TRY(hipStreamSynchronize(live(in)));
-    if (ringIdle(in)) in->ringHead = 0;   // everything staged so far has been consumed
+    if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;   // everything staged so far has been consumed
     return 0;
 }
 

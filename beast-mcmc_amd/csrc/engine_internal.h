@@ -70,12 +70,6 @@ struct Instance {
         int maxRange = 0;
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
-        // inverse map of the program's matrix stream (PendingTransition): for caller matrix m the places that take a copy of it,
-        // useList[useStart[m] .. useStart[m + 1]): 2 k + which = table `which` of stream entry k, or 0x80000000 | snapshot slot.
-        // Resident on the device behind the program (dUseStart / dUseList); useOk: every place is fed by a caller matrix.
-        std::vector<int> useStart; std::vector<unsigned> useList; bool useOk = false;
-        const int* dUseStart = nullptr; const unsigned* dUseList = nullptr;
-        std::vector<int> coveredIdx;                     // the index list of the transition call last checked to cover every used matrix
         std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)
         long foldEpoch = -1;                             // scaleWriteEpoch those vectors were last checked against
         long noFoldTag = 0;                              // the plan whose folds left the safe range: resolved with per-node factors
@@ -150,22 +144,6 @@ struct Instance {
         int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
     } pendingWalk;
-    // 4 states: beagleUpdateTransitionMatrices of the whole tree is held back the same way, until the next call.  When that call is
-    // updatePartials with a cached program, ONE launch computes the matrices, writes them to their slots AND lays them out as the
-    // stream the walk reads (and as the snapshots of the program's definitions) — through the program's resident inverse map
-    // matrix -> places that read it (Resolved::dUse*; kernels.hip k_transition4Scatter) — instead of a transition launch and a
-    // gather launch; anything else launches the transition kernel as it is (live()).  The staged branch lengths and indices stay
-    // in the ring until then (ringIdle).  BEAGLE_MI355_NO_LAUNCH_FUSION=1: never held.
-    struct PendingTransition {
-        bool valid = false;
-        mi355::HostCopyList copies; int copyBlocks = 0;
-        const double* eigSrc = nullptr; const double* ratesSrc = nullptr; const int* idx = nullptr; const double* len = nullptr;
-        const int* hostIdx = nullptr;                    // the same indices where the host can read them (the staging ring)
-        int count = 0;
-    } pendingTransition;
-    long statScatterLaunches = 0;
-    std::vector<int> matrixStamp; int matrixStampNow = 0;        // (which caller matrices a held transition call computes: runPlan's cover check)
-    bool deferTransition = true;
     bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back
     bool copyKeepsWalk = false;                          // (set around an upload the held walk does not read: engine_instance.cpp queueCopy)
     long statRootFused = 0;
@@ -275,11 +253,7 @@ int ensureWalkDummies(Instance* in);
 int flushUploads(Instance* in);
 // ... and a walk launch that is being held back for the root call (PendingWalk, engine_walk.cpp) launched behind them
 int flushWalk(Instance* in, const mi355::RootFused* root = nullptr);
-// ... and a transition-matrix launch that is being held back for updatePartials (PendingTransition, engine_abi.cpp) first of all
-int flushTransition(Instance* in);
-inline bool ringIdle(const Instance* in) { return in->pendingCopies.empty() && !in->pendingWalk.valid && !in->pendingTransition.valid; }
 inline hipStream_t live(Instance* in) {
-    if (in->pendingTransition.valid) flushTransition(in);
     if (!in->pendingCopies.empty()) flushUploads(in);
     if (in->pendingWalk.valid) flushWalk(in);
     return in->stream;

@@ -281,30 +281,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
     if (slot) {
-        // the no-ops read SOME matrix: the first real micro-operation's (a matrix every evaluation of this program computes anyway)
-        for (mi355::WalkOp& q : w)
-            if (q.m1 == in->matrices && q.m2 == in->matrices && q.src1 == in->dummyTips && q.src2 == in->dummyTips && !(q.flags & mi355::WF_STORE) && !w.empty())
-                for (const mi355::WalkOp& r : w) if (r.m1 != in->matrices || r.src1 != in->dummyTips) { q.m1 = q.m2 = r.m1; break; }
-        // inverse map of the matrix stream (engine_internal.h PendingTransition): who takes a copy of caller matrix m
-        slot->useOk = !in->walkT && in->S == 4;
-        slot->useStart.assign((size_t)in->matrixCount + 1, 0); slot->useList.clear(); slot->coveredIdx.clear();
-        if (slot->useOk) {
-            const size_t stride = (size_t)in->C * 16;
-            auto indexOf = [&](const double* ptr) { return (long)((ptr - in->matrices) / (long)stride); };
-            for (const mi355::WalkOp& q : w) for (const double* ptr : {q.m1, q.m2}) { const long m = indexOf(ptr); if (m < 0 || m >= in->matrixCount) slot->useOk = false; else slot->useStart[(size_t)m + 1]++; }
-            for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) { const int m = plan.snapPairs[q]; if (m < 0 || m >= in->matrixCount) slot->useOk = false; else slot->useStart[(size_t)m + 1]++; }
-        }
-        if (slot->useOk) {
-            for (size_t m = 0; m < (size_t)in->matrixCount; m++) slot->useStart[m + 1] += slot->useStart[m];
-            slot->useList.assign((size_t)slot->useStart[(size_t)in->matrixCount], 0u);
-            std::vector<int> at(slot->useStart.begin(), slot->useStart.end() - 1);
-            const size_t stride = (size_t)in->C * 16;
-            for (size_t k = 0; k < w.size(); k++) {
-                slot->useList[(size_t)at[(size_t)((w[k].m1 - in->matrices) / (long)stride)]++] = (unsigned)(2 * k);
-                slot->useList[(size_t)at[(size_t)((w[k].m2 - in->matrices) / (long)stride)]++] = (unsigned)(2 * k + 1);
-            }
-            for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) slot->useList[(size_t)at[(size_t)plan.snapPairs[q]]++] = 0x80000000u | (unsigned)plan.snapPairs[q + 1];
-        } else { slot->useStart.clear(); slot->useList.clear(); }
         slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
         slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
@@ -328,10 +304,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     in->statMicroOps += (long)n;
     // pack: [micro-ops (64 B each) | segments (32 B each) | dependency lists | snapshot pairs] — ONE host-to-device copy
     const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg) + ((devDeps.size() * sizeof(int) + 31) & ~(size_t)31);
-    const size_t pairBytes = (plan.snapPairs.size() * sizeof(int) + 31) & ~(size_t)31;
-    const size_t useBytes = slot && slot->useOk ? ((slot->useStart.size() * sizeof(int) + 31) & ~(size_t)31) + ((slot->useList.size() * sizeof(unsigned) + 31) & ~(size_t)31) : 0;
-    const size_t useOff = opBytes + segBytes + pairBytes, useListOff = useOff + (slot && slot->useOk ? ((slot->useStart.size() * sizeof(int) + 31) & ~(size_t)31) : 0);
-    const size_t total = opBytes + segBytes + pairBytes + useBytes;
+    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
     const size_t depOff = opBytes + segs.size() * sizeof(mi355::WalkSeg);
     char* dBase = nullptr;
     if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
@@ -340,11 +313,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (off < 0) return BEAGLE_ERROR_GENERAL;
         memcpy(in->hRing + off + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg));     // ... the rest is filled in behind them
         if (!devDeps.empty()) memcpy(in->hRing + off + depOff, devDeps.data(), devDeps.size() * sizeof(int));
-        if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int));
-        if (useBytes) {
-            memcpy(in->hRing + off + useOff, slot->useStart.data(), slot->useStart.size() * sizeof(int));
-            memcpy(in->hRing + off + useListOff, slot->useList.data(), slot->useList.size() * sizeof(unsigned));
-        }
+        if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
         { int rcq = queueCopy(in, in->dRing + off, (size_t)off, total); if (rcq) return rcq; }
         dBase = in->dRing + off;
         if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
@@ -357,8 +326,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             if (in->kernelUploads) { int rcq = queueCopy(in, slot->dProg, (size_t)off, total); if (rcq) return rcq; }     // (from the same staged bytes)
             else HIP_TRY(hipMemcpyAsync(slot->dProg, in->dRing + off, total, hipMemcpyDeviceToDevice, live(in)));
             slot->dProgValid = true;
-            slot->dUseStart = useBytes ? (const int*)(slot->dProg + useOff) : nullptr;
-            slot->dUseList = useBytes ? (const unsigned*)(slot->dProg + useListOff) : nullptr;
         }
     } else {                                  // a tree of > ~60 000 nodes: its own staging buffer, synchronous copy
         HIP_TRY(hipStreamSynchronize(live(in)));
@@ -371,38 +338,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         HIP_TRY(hipMemcpy(in->bigStage, w.data(), opBytes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg), hipMemcpyHostToDevice));
         if (!devDeps.empty()) HIP_TRY(hipMemcpy(in->bigStage + depOff, devDeps.data(), devDeps.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), plan.snapPairs.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
         dBase = in->bigStage;
-        if (slot) { slot->dUseStart = nullptr; slot->dUseList = nullptr; }       // (no resident copy: no merged launch for such a program)
     }
     const bool fusedSnapshot = pairBytes && !in->walkT && in->fuseLaunches;          // 4 states: together with the gather below
-    // A transition-matrix call that is still held back and a cached program resident on the device: ONE launch computes the
-    // matrices and lays them out as this program's stream and snapshots (PendingTransition) — when the call's matrices are all the
-    // program reads (checked once per index list) and nothing else is queued in between.
-    bool scattered = false;
-    if (in->pendingTransition.valid && slot && reuse && slot->dProgValid && slot->useOk && slot->dUseStart && in->pendingCopies.empty() &&
-        in->matStreamBytes >= w.size() * (size_t)in->C * 40 * sizeof(double) + 1024) {
-        Instance::PendingTransition& pt = in->pendingTransition;
-        bool covers = slot->coveredIdx.size() == (size_t)pt.count && memcmp(slot->coveredIdx.data(), pt.hostIdx, (size_t)pt.count * sizeof(int)) == 0;
-        if (!covers) {
-            if (in->matrixStamp.size() < (size_t)in->matrixCount) in->matrixStamp.assign((size_t)in->matrixCount, 0);
-            const int stamp = ++in->matrixStampNow;
-            for (int k = 0; k < pt.count; k++) in->matrixStamp[(size_t)pt.hostIdx[k]] = stamp;
-            covers = true;
-            for (size_t m = 0; m < (size_t)in->matrixCount && covers; m++)
-                if (slot->useStart[m + 1] > slot->useStart[m] && in->matrixStamp[m] != stamp) covers = false;
-            if (covers) slot->coveredIdx.assign(pt.hostIdx, pt.hostIdx + pt.count);
-        }
-        if (covers) {
-            pt.valid = false;
-            mi355::launchTransitionMatrices4Scatter(in->stream, in->matrices, pt.eigSrc, pt.ratesSrc, pt.idx, pt.len, pt.count, in->C, in->eigenComplex,
-                                                    pt.copies, pt.copyBlocks, slot->dUseStart, slot->dUseList, (double*)in->matStream);
-            in->statScatterLaunches++;
-            scattered = true;
-        }
-    }
-    if (scattered) {}
-    else if (pairBytes && !fusedSnapshot)
+    if (pairBytes && !fusedSnapshot)
         mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
@@ -416,8 +356,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         HIP_TRY(hipMalloc((void**)&in->matStream, want));
         in->matStreamBytes = want;
     }
-    if (scattered) {}
-    else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
     else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);

@@ -196,12 +196,6 @@ void launchTransitionMatrices(hipStream_t stream, double* matrices, const double
 // copy kernel and a transition kernel.  Same arithmetic and summation order as launchTransitionMatrices.
 void launchTransitionMatrices4Fused(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
                                     const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks);
-// ... and every matrix also laid out where a walk program reads it: useList[useStart[m] .. useStart[m + 1]) for caller matrix m holds
-// 2 k + which (table `which` of entry k of the matrix stream: kernels_walk4.hip k_gatherMatrices' layout) or 0x80000000 | slot (a
-// private snapshot slot of a virtual definition) — the transition launch and the gather launch of an evaluation in one
-void launchTransitionMatrices4Scatter(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
-                                      const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks,
-                                      const int* dUseStart, const unsigned* dUseList, double* matStream);
 
 // C_c = A_c * B_c per category, `count` triples (device index arrays).
 void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFirst, const int* dSecond,

@@ -222,60 +222,6 @@ __global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ m
         }
 }
 
-// The same, and what k_gatherAndSnapshot (kernels_walk4.hip) would do with the result in a launch of its own: the thread that has
-// matrix (idx[u], c) in registers also writes it wherever the walk program about to run reads it — as a 5-column table of the
-// matrix stream (column 4 = ones, the missing state) or as the private snapshot of a virtual definition.  Same values, same bits.
-__global__ __launch_bounds__(256) void k_transition4Scatter(double* __restrict__ matrices, const double* __restrict__ eigSrc,
-                                                            const double* __restrict__ ratesSrc, const int* __restrict__ idx,
-                                                            const double* __restrict__ len, int count, int C, int complexEigen,
-                                                            const HostCopyList L, int transitionBlocks, const int* __restrict__ useStart,
-                                                            const unsigned* __restrict__ useList, double* __restrict__ matStream) {
-    if ((int)blockIdx.x >= transitionBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)transitionBlocks); return; }
-    __shared__ double sEig[40], sRate[16];
-    const int nEig = complexEigen ? 40 : 36;
-    if ((int)threadIdx.x < nEig) sEig[threadIdx.x] = eigSrc[threadIdx.x];
-    else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C && C <= 16) sRate[threadIdx.x - 64] = ratesSrc[threadIdx.x - 64];
-    __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count * C) return;
-    const int u = t / C, c = t - u * C;
-    const double* U = sEig;
-    const double* Ui = U + 16;
-    const double* lam = U + 32;
-    const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
-    double ie[16], m[16];
-    if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
-    else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
-    const int mi = idx[u];
-    double* M = matrices + ((size_t)mi * C + c) * 16;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0.0;
-            for (int k = 0; k < 4; k++) s += U[i * 4 + k] * ie[k * 4 + j];
-            m[i * 4 + j] = s > 0.0 ? s : 0.0;
-            M[i * 4 + j] = m[i * 4 + j];
-        }
-    for (int q = useStart[mi]; q < useStart[mi + 1]; q++) {
-        const unsigned use = useList[q];
-        if (use & 0x80000000u) {
-            double* D = matrices + ((size_t)(use & 0x7fffffffu) * C + c) * 16;
-            for (int e = 0; e < 16; e++) D[e] = m[e];
-        } else {
-            double* T = matStream + ((size_t)(use >> 1) * C + c) * 40 + (use & 1u) * 20;
-            for (int col = 0; col < 4; col++) for (int i = 0; i < 4; i++) T[col * 4 + i] = m[i * 4 + col];
-            T[16] = 1.0; T[17] = 1.0; T[18] = 1.0; T[19] = 1.0;
-        }
-    }
-}
-void launchTransitionMatrices4Scatter(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
-                                      const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks,
-                                      const int* dUseStart, const unsigned* dUseList, double* matStream) {
-    if (count <= 0) return;
-    const int tb = (int)(((size_t)count * C + 255) / 256);
-    hipLaunchKernelGGL(k_transition4Scatter, dim3((unsigned)(tb + copyBlocks)), dim3(256), 0, stream, matrices, eigSrc, ratesSrc, idx, len,
-                       count, C, complexEigen ? 1 : 0, pending, tb, dUseStart, dUseList, matStream);
-}
-
 void launchTransitionMatrices4Fused(hipStream_t stream, double* matrices, const double* eigSrc, const double* ratesSrc, const int* idx,
                                     const double* len, int count, int C, bool complexEigen, const HostCopyList& pending, int copyBlocks) {
     if (count <= 0) return;

@@ -355,14 +355,12 @@ int beagleMi355KernelTimerRestart(int instance);
  * vectors read, [5] walk launches, [6] scale-factor vectors written, [7] walk launches that ran the assembly loop.  bench.py turns them into the
  * bytes the design has to move (roofline.achieved). */
 int beagleMi355WalkStats(int instance, long* out8);
-/* The one-launch pattern walk (4 states) since instance creation (EIGHT longs).  out[0]: workgroups whose wait for the slices
- * they read from ran out and that computed those slices themselves (kernels_walk4.hip: the launch cannot deadlock whatever order the
- * hardware dispatches workgroups in; on gfx950 the count stays 0); out[1]: that wait's limit in microseconds
- * (BEAGLE_MI355_WALK_SPIN_US at creation, default 20 000); out[2]: folded reciprocal vectors in use by read-mode programs (one per
- * stored node instead of one per node: DESIGN.md 4.1); out[3]: how many times such vectors were (re)built from the per-node factors;
- * out[4]: updateTransitionMatrices calls that ran merged with the matrix gather of the updatePartials call behind them (one launch
- * instead of two: DESIGN.md 2); out[5..7]: reserved (0). */
-int beagleMi355WalkHealth(int instance, long* out8);
+/* The one-launch pattern walk (4 states) since instance creation.  out[0]: workgroups whose wait for the slices they read from ran
+ * out and that computed those slices themselves (kernels_walk4.hip: the launch cannot deadlock whatever order the hardware
+ * dispatches workgroups in; on gfx950 the count stays 0); out[1]: that wait's limit in microseconds (BEAGLE_MI355_WALK_SPIN_US at
+ * creation, default 20 000); out[2]: folded reciprocal vectors in use by read-mode programs (one per stored node instead of one
+ * per node: DESIGN.md 4.1); out[3]: how many times such vectors were (re)built from the per-node factors. */
+int beagleMi355WalkHealth(int instance, long* out4);
 /* The gradient pass (4 states) since instance creation.  A pre-order list without scale indices is held back until a call needs
  * what it writes (or changes what it reads): out[0] lists that ran together with the edge derivatives that followed them (one
  * sweep per tree level; sums and sums of squares), out[1] lists that ran operation by operation, out[2] edge-derivative calls
