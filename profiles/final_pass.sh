@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's final measurement pass in ONE GPU-box call:   bash profiles/final_pass.sh r04
+# The round's final measurement pass in ONE GPU-box call:   bash profiles/final_pass.sh r05
 #   1. the GPU test tier (log kept)
 #   2. the bench lines of configs A-E as the driver runs them (CPU baseline, roofline.traffic measured live by bench.py itself,
 #      the in-library multi-GPU route appended), plus the protocol variants: BeagleTreeLikelihood caller, ALWAYS rescaling, the
@@ -7,7 +7,7 @@
 #   3. rocprofv3 passes of profiles/collect.sh for A, B, C and E (kernel stats, FETCH/WRITE, SQ counters) and their summaries
 #      (profiles/summarize.py: <round>_<cfg>_kernel_stats.csv, _sq_counters.txt, hbm_traffic.json keyed to this build)
 # Everything the repo tracks of it is copied to gpurun_out/profiles_final/ (the box's profiles/ does not travel back).
-R=${1:-r04}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/profiles_final
+R=${1:-r05}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/profiles_final
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/profiles_final/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/profiles_final/${R}_pytest_gpu.log)"
 line() { python -c "import json,sys;d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]);r=d['roofline'];print(sys.argv[2], d['value'],'evals/s kernel us',r['kernel_us_per_eval'],'frac',r['frac'],'traffic',r['traffic'],'|',r['traffic_source'][:60],'| cpu',d['cpu_baseline'] and d['cpu_baseline']['value'],'| lib',d.get('library_route') and d['library_route'].get('value'))" "$1" "$2" 2>&1 | tail -1; }
 for cfg in A B C D E; do
@@ -34,6 +34,11 @@ timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5
 timeout 300 python bench.py --config B --rescaling always --steps 40 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_B_always.json; line gpurun_out/profiles_final/${R}_bench_B_always.json "B always"
 timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard12500.json; line gpurun_out/profiles_final/${R}_bench_A_shard12500.json "A shard"
 python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_bench_A_shard12500.json').read());print('  partial_update at 12 500 patterns', d.get('partial_update'))"
+timeout 300 python tools/readback_bench.py 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_readback.json; echo "readback $(cut -c1-300 gpurun_out/profiles_final/${R}_readback.json)"
+timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 --rescale 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_rescale.json
+BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_all_stored.json
+for g in _1e5_rescale _1e5_all_stored; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, stored', d.get('post_order_nodes_stored_per_gradient'), d['how'])" 2>&1 | tail -1; done
+BEAGLE_MI355_NO_SCALE_FOLD=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-library-route --no-side-records 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json; line gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json "A, driver command line, per-node factors (NO_SCALE_FOLD)"
 for real in benchmark1 benchmark2; do
   timeout 300 python bench.py --real $real --steps 200 --warmup 5 --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_D_$real.json; line gpurun_out/profiles_final/${R}_bench_D_$real.json "D $real"
 done
