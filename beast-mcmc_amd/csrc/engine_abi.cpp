@@ -354,8 +354,10 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
+    // (opt-in: it halves the post-order partials a gradient chain keeps in HBM and moves, and costs 0-5 % of the chain's time — the
+    // pre-order walk is bound by instruction issue and a re-evaluation descriptor is half a node's worth: profiles/r05_experiments.txt 5)
     in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&
-                          !(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL")) != 0);
+                          getenv("BEAGLE_MI355_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_GRADIENT_VIRTUAL")) != 0;
     if (labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS")) in->gradientVirtualSteps = std::max(1, std::min(GRADIENT_VIRT_STEPS, atoi(labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS"))));
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);

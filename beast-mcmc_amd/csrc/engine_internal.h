@@ -125,8 +125,9 @@ struct Instance {
                                                          // definitions the pre-order walk re-evaluates from the tips itself
     // 4 states: a gradient chain's post-order passes keep definitions of up to GRADIENT_VIRT_STEPS steps (tip-tip nodes, and those
     // under one more tip — half the nodes of a coalescent tree) instead of storing every node, and k_preWalk4 re-evaluates them where
-    // it needs them (engine_preorder.cpp walkableDefinition): half the bytes of both passes.  BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1 at
-    // creation: every node stored, as before round 5 (A/B runs).
+    // it needs them (engine_preorder.cpp walkableDefinition): half the bytes of both passes and half the post-order partials resident —
+    // and no time gained (the pre-order walk is bound by instruction issue; 0-5 % lost to the extra descriptors), so it is an OPTION:
+    // BEAGLE_MI355_GRADIENT_VIRTUAL=1 at creation; default: every node stored, as in round 4.
     bool gradientVirtual = false; int gradientVirtualSteps = GRADIENT_VIRT_STEPS;
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials

@@ -508,20 +508,20 @@ def test_add_transition_matrices():
 
 @pytest.mark.parametrize("rescale", [False, True])
 def test_gradient_chain_leaves_short_definitions_unstored(rescale, oracle_lib, monkeypatch):
-    """Round 5: the post-order passes of a gradient chain no longer store every node.  A node over two compact tips, and such a
-    node under one more tip, stay definitions (planner.h stepLimit), and the pre-order walk re-evaluates them from the tips where
-    it needs them (kernels_preorder4.hip PW_POSTOP): about half the nodes of a coalescent tree are neither written by the one pass
-    nor read by the other.  Held here: the stored-node count of the chain's post-order passes, the numbers against the oracle and
-    against the same chain with every node stored (BEAGLE_MI355_NO_GRADIENT_VIRTUAL=1), and that reading partials afterwards —
+    """Round 5 (BEAGLE_MI355_GRADIENT_VIRTUAL=1): the post-order passes of a gradient chain need not store every node.  A node over two
+    compact tips, and such a node under one more tip, stay definitions (planner.h stepLimit), and the pre-order walk re-evaluates them
+    from the tips where it needs them (kernels_preorder4.hip PW_POSTOP): about half the nodes of a coalescent tree are neither written by
+    the one pass nor read by the other.  Held here: the stored-node count of the chain's post-order passes, the numbers against the oracle
+    and against the same chain with every node stored (the default), and that reading partials afterwards —
     post-order ones of unstored nodes, pre-order ones of a list that never ran — still finds the right values."""
     wl = helpers.random_workload(150, 1800, 4, 4, seed=61)
     T = wl.tree.tip_count
     runs = {}
-    for name, env in (("virtual", None), ("stored", "1")):
+    for name, env in (("virtual", "1"), ("stored", None)):
         if env:
-            monkeypatch.setenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL", env)
+            monkeypatch.setenv("BEAGLE_MI355_GRADIENT_VIRTUAL", env)
         g = BranchGradient(wl, double_buffer=True, rescale=rescale)
-        monkeypatch.delenv("BEAGLE_MI355_NO_GRADIENT_VIRTUAL", raising=False)
+        monkeypatch.delenv("BEAGLE_MI355_GRADIENT_VIRTUAL", raising=False)
         o = BranchGradient(wl, double_buffer=True, rescale=rescale, library=oracle_lib) if name == "virtual" else None
         rng = np.random.default_rng(4)
         out = []
@@ -557,3 +557,28 @@ def test_gradient_chain_leaves_short_definitions_unstored(rescale, oracle_lib, m
     for a, b in zip(runs["virtual"], runs["stored"]):
         assert helpers.rel_err(a[0], b[0]) <= 1e-13
         close(a[1], b[1], "virtual against stored")
+
+
+def test_gradient_corner_shapes_with_unstored_definitions(oracle_lib, monkeypatch):
+    """The corner shapes of test_gradient_corner_shapes (two taxa, single patterns, ragged counts, 1 .. 16 categories) with the
+    gradient chain's short definitions left unstored: third evaluation of every instance (the first sets the chain's hint, the second
+    plans under the step limit) against the oracle."""
+    monkeypatch.setenv("BEAGLE_MI355_GRADIENT_VIRTUAL", "1")
+    checked = 0
+    for C in (1, 4, 8, 16):
+        for T, P in ((2, 1), (3, 15), (6, 33), (14, 129), (40, 700)):
+            if C > 8 and P > 200:
+                continue
+            wl = helpers.random_workload(T, P, 4, C, seed=700 + 13 * C + T)
+            for rescale in (False, True):
+                g = BranchGradient(wl, rescale=rescale, double_buffer=True)
+                o = BranchGradient(wl, rescale=rescale, double_buffer=True, library=oracle_lib)
+                for step in range(3):
+                    lg, gg = g.gradient()
+                    lo, go = o.gradient()
+                    assert helpers.rel_err(lg, lo) <= REL_TOL, (C, T, P, rescale, step)
+                    close(gg, go, "corner shape C=%d T=%d P=%d rescale=%s step %d" % (C, T, P, rescale, step))
+                g.close(); o.close()
+                checked += 1
+    assert checked >= 30
+
