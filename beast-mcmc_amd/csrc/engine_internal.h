@@ -67,7 +67,7 @@ struct Instance {
     struct Resolved {
         long tag = 0, epoch = -1;
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
-        int maxRange = 0;
+        int maxRange = 0, sinks = 0;                     // (sinks: slices no other slice waits for — one: the whole program leads to its last slice)
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
         std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)

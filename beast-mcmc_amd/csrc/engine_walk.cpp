@@ -400,11 +400,12 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         // ... and only a program whose slices ALL lead to one last slice: the root call's result word then says that every workgroup
         // of the launch is done (waitResult and its callers reset the staging ring on seeing it) — a forest's other trees could
         // still be running behind the slice that publishes
-        int sinks = 0;
-        {
+        int sinks = slot && reuse ? slot->sinks : 0;
+        if (!(slot && reuse)) {
             std::vector<char> feeds(segs.size(), 0);
             for (int d : devDeps) feeds[(size_t)d] = 1;
             for (size_t i = 0; i < segs.size(); i++) if (!feeds[i] && segs[i].progCount > 0) sinks++;
+            if (slot) slot->sinks = sinks;
         }
         const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P && sinks == 1;
         if (hold) {

@@ -403,12 +403,23 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         if (depCount > 0) {
             if (c == 0) {
                 const int MI355_CONST* dl = deps + sg.depStart;
-                const unsigned long long t0 = wall_clock64();
+                // (the clock is looked at on every 32nd poll: a poll that also reads the clock notices the flag a little later, and a
+                // small evaluation's time is a chain of such hand-overs — config D: 2.5 us of 46)
+                unsigned long long t0 = 0;
                 bool late = false;
+                if (spinLimit == 0) {                    // (the forward-progress test: nobody waits; whoever finds a flag down serves itself)
+                    for (int d = walkLane(); d < depCount; d += 64)
+                        late = late || __hip_atomic_load(flags + (size_t)dl[d] * flagStride + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+                } else
                 for (int d = walkLane(); d < depCount && !late; d += 64) {
                     const unsigned* f = flags + (size_t)dl[d] * flagStride + blockIdx.x;
+                    unsigned polls = 0;
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                        if (wall_clock64() - t0 >= spinLimit) { late = true; break; }
+                        if ((++polls & 31u) == 0u) {
+                            const unsigned long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 >= spinLimit) { late = true; break; }
+                        }
                         __builtin_amdgcn_s_sleep(4);
                     }
                 }
@@ -416,9 +427,11 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                 if (walkLane() == 0) *word = anyLate ? 1 : 0;
             }
             __syncthreads();
+            // (no second barrier on the way out: nothing writes LDS word 0 before the loop's own prologue barrier, which every wave
+            // reaches behind this read)
             const int anyLate = __builtin_amdgcn_readfirstlane(*word);
-            __syncthreads();
             if (anyLate) {
+                __syncthreads();
                 first = 0;
                 if (c == 0 && walkLane() == 0) atomicAdd(selfServed, 1u);
             }

@@ -335,10 +335,16 @@ def stage(tag, cur):
     novm = "novmwait" in EXPERIMENT
     e("s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[0])
     e(L("wd" + tag) + ":")
-    # the other codes, out of line: code 2 (both following micro-operations fetch four: programs that pay at every node — partial
-    # updates, write-mode lists) first, the rest through a jump table of (wait, branch) pairs
+    # the other codes, out of line: code 1 (one of the two following micro-operations pays: the neighbours of every payment in a
+    # folded program) and code 2 (both fetch four: programs that pay at every node — partial updates, write-mode lists) by a test
+    # each, the rest through a jump table of (wait, branch) pairs
     blk = [L("ws" + tag) + ":",
            "s_bfe_u32 %s, %s, 0x%x" % (s(ST), s(SFL), (3 << 16) | B_WAIT0),
+           "s_cmp_eq_u32 %s, 1" % s(ST),
+           "s_cbranch_scc0 %s" % L("wu" + tag),
+           "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[1],
+           "s_branch %s" % L("wd" + tag),
+           L("wu" + tag) + ":",
            "s_cmp_eq_u32 %s, 2" % s(ST),
            "s_cbranch_scc0 %s" % L("wt" + tag),
            "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[2],
