@@ -381,6 +381,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
+    in->hostTrace = getenv("BEAGLE_MI355_HOST_TIMING") && atoi(getenv("BEAGLE_MI355_HOST_TIMING")) > 1;     // (a line per slow updatePartials call)
     if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {
         in->planner.chunkTopOps = labEnv("BEAGLE_MI355_CHUNK_TOP") ? atoi(labEnv("BEAGLE_MI355_CHUNK_TOP")) : 16;

@@ -158,7 +158,7 @@ struct Instance {
     bool virt = false;                                   // some partials buffers may be virtual (walk instances; T32 instances: cherries)
     bool cherry = false;                                 // T32 instance with <= 20 states: tip-tip nodes are not stored (kernels.h CherryDesc)
     long statCherries = 0;
-    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
+    double hostPlanUs = 0, hostRunUs = 0, hostPrepUs = 0, hostPlanHitUs = 0, hostRunHitUs = 0; long hostCalls = 0, hostHits = 0; bool hostTrace = false, lastResolveMiss = false;   // BEAGLE_MI355_HOST_TIMING=1: where updatePartials spends host time
     char* bigStage = nullptr; size_t bigStageBytes = 0;  // device staging for programs that do not fit the ring
     // read-back (getPartials): API-layout export buffers on the device and a pinned bounce buffer on the host
     double* exportDev[2] = {nullptr, nullptr}; double* exportHost[2] = {nullptr, nullptr}; size_t exportBytes = 0;   // two chunks in flight

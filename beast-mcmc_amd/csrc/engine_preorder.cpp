@@ -546,6 +546,9 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
     mi355::PreWalkOp nop;
     memset(&nop, 0, sizeof(nop));
     nop.postA = nop.postB = in->preRootCopy; nop.tipA = nop.tipB = in->preDummyStates; nop.slotA = nop.slotB = count;   // valid memory, the spare slot
+    nop.dA = nop.dB = count;                                         // (the spare product: zeros)
+    // per edge: its branch matrix and its differential matrix — the walk applies their product (kernels_preorder4.hip k_edgeProducts)
+    std::vector<int> pairs(2 * (size_t)(count + 1), -1);
     nop.recipA = nop.recipB = in->onesScale;
     // 1 / (the factor a post-order operand was divided by), or ones; false: its scale buffer has been written since
     auto reciprocalOf = [&](int po, const double*& out) {
@@ -607,12 +610,14 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
                     if (!walkableDefinition(in, po) || !emitPost(po, (unsigned)w)) return 1;
                     const double* rc = nullptr;
                     if (!reciprocalOf(po, rc)) return 1;
-                    if (w) { op.flags |= mi355::PW_TIP_B | mi355::PW_SLOT_B | (1u << mi355::PW_SLOTB_SHIFT); op.recipB = rc; if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
-                    else { op.flags |= mi355::PW_TIP_A | mi355::PW_SLOT_A | (0u << mi355::PW_SLOTA_SHIFT); op.recipA = rc; if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+                    if (w) { op.flags |= mi355::PW_TIP_B | mi355::PW_SLOT_B | (1u << mi355::PW_SLOTB_SHIFT); op.recipB = rc; if (e >= 0) { op.slotB = e; op.dB = e; } }
+                    else { op.flags |= mi355::PW_TIP_A | mi355::PW_SLOT_A | (0u << mi355::PW_SLOTA_SHIFT); op.recipA = rc; if (e >= 0) { op.slotA = e; op.dA = e; } }
+                    if (e >= 0) { pairs[2 * (size_t)e] = w ? nd.matB : nd.matA; pairs[2 * (size_t)e + 1] = dIdx[e]; }
                     continue;
                 }
-                if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else { op.postB = in->partials[po]; if (!reciprocalOf(po, op.recipB)) return 1; } if (e >= 0) { op.slotB = e; op.dB = dIdx[e]; } }
-                else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else { op.postA = in->partials[po]; if (!reciprocalOf(po, op.recipA)) return 1; } if (e >= 0) { op.slotA = e; op.dA = dIdx[e]; } }
+                if (w) { if (st) { op.tipB = in->tipStates[po]; op.flags |= mi355::PW_TIP_B; } else { op.postB = in->partials[po]; if (!reciprocalOf(po, op.recipB)) return 1; } if (e >= 0) { op.slotB = e; op.dB = e; } }
+                else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else { op.postA = in->partials[po]; if (!reciprocalOf(po, op.recipA)) return 1; } if (e >= 0) { op.slotA = e; op.dA = e; } }
+                if (e >= 0) { pairs[2 * (size_t)e] = w ? nd.matB : nd.matA; pairs[2 * (size_t)e + 1] = dIdx[e]; }
             }
             op.storeA = in->partials[nd.preA]; op.storeB = in->partials[nd.preB];
             op.matA = nd.matA; op.matB = nd.matB;
@@ -630,12 +635,18 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
         void* q = nullptr; int rc = devAlloc(in, &q, (progBytes + segBytes) * 2); if (rc) return rc;   // (the old, smaller one stays allocated until the instance goes)
         in->dPreProg = q; in->dPreProgBytes = (progBytes + segBytes) * 2;
     }
-    int rc = ensureEdgeScratch(in, sumBytes + outBytes); if (rc) return rc;
-    double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes);
+    const size_t outPad = (outBytes + 255) & ~(size_t)255, prodBytes = (size_t)(count + 1) * in->C * 16 * sizeof(double), pairBytes = pairs.size() * sizeof(int);
+    int rc = ensureEdgeScratch(in, sumBytes + outPad + prodBytes + pairBytes); if (rc) return rc;
+    double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes), *dProducts = (double*)((char*)in->edgeScratch + sumBytes + outPad);
+    int* dPairs = (int*)((char*)dProducts + prodBytes);
+    rc = upload(in, dPairs, pairs.data(), pairBytes); if (rc) return rc;
+    mi355::launchEdgeProducts(live(in), in->matrices, dPairs, dProducts, in->C, count + 1);
     rc = upload(in, in->dPreProg, segs.data(), (size_t)nSegs * sizeof(mi355::PreWalkSeg)); if (rc) return rc;
     rc = upload(in, (char*)in->dPreProg + segBytes, prog.data(), progBytes); if (rc) return rc;
     if (!mi355::launchPreWalk4(live(in), (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,
-                               in->preRootCopy, in->matrices, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots, anyPost)) return 1;
+                               in->preRootCopy, in->matrices, dProducts, in->weights + (size_t)wIdx * in->C, in->patternWeights, dSums, in->P, in->C, h.holdSlots, anyPost)) return 1;
+    if (in->hostTrace) fprintf(stderr, "[mi355] pre-order walk: %d segments, %zu descriptors, %d hold slots (%zu KB of LDS per workgroup)\n", nSegs, prog.size(), h.holdSlots,
+                               (size_t)(h.holdSlots + (anyPost ? mi355::PW_POST_SLOTS : 0)) * in->C * 2);
     mi355::launchPreWalkFinal(live(in), dSums, count, in->P, in->C, dOut);
     std::vector<double> out(count);
     rc = download(in, out.data(), dOut, outBytes); if (rc) return rc;

@@ -117,6 +117,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     static const int ablate = labEnv("BEAGLE_MI355_ABLATE") ? atoi(labEnv("BEAGLE_MI355_ABLATE")) : 0;     // (LAB builds only: wrong results)
     Instance::Resolved* slot = planTag && !ablate ? &in->resolved[planTag & 7] : nullptr;
     const bool reuse = slot && slot->tag == planTag && slot->epoch == in->resolveEpoch;
+    in->lastResolveMiss = !reuse;
     std::vector<mi355::WalkOp>& w = slot ? slot->w : in->walkOps;
     std::vector<mi355::WalkSeg> segsLocal;
     std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
@@ -544,6 +545,9 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
             if (b) { HIP_TRY(hipEventRecord(b, live(in))); in->pendingLaunches++; }
             const double usRun = usSince(t1);
             in->hostRunUs += usRun; in->hostRunHitUs += usRun;
+            if (in->hostTrace && usPlan + usRun > 40.0)
+                fprintf(stderr, "[mi355] call %ld (replayed, tag %ld): planner %.1f us, run %.1f us (resolved again: %d, folds rebuilt so far %ld)\n", in->hostCalls,
+                        in->planner.plannedTag, usPlan, usRun, (int)in->lastResolveMiss, in->statFoldBuilds);
             return 0;
         }
     }
@@ -593,7 +597,9 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
             rc = runPlan(in, *in->planner.planned, in->planner.plannedTag, launches == 0 ? e0 : nullptr); if (rc) return rc;
             launches++;
         } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
-        { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us; }
+        { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us;
+          if (in->hostTrace) fprintf(stderr, "[mi355] call %ld (%d ops from %d, cache %s, tag %ld): run %.1f us (resolved again: %d, folds rebuilt so far %ld)\n", in->hostCalls, n, begin,
+                                     hit ? "hit" : "miss", in->planner.plannedTag, us, (int)in->lastResolveMiss, in->statFoldBuilds); }
         begin += n;
     }
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, live(in))); in->pendingLaunches += launches; }

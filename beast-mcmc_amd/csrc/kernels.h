@@ -296,7 +296,8 @@ struct PreWalkOp {
     double*        storeB;
     const double*  recipA;       // 1 / (scale factor of post(a)), pair-interleaved (a walk instance's reciprocal array); all ones when
     const double*  recipB;       // the child is a tip or its partials carry no factor
-    int            matA, matB, dA, dB;
+    int            matA, matB;   // the children's branch matrices
+    int            dA, dB;       // the edges' entries in the launch's product array (launchEdgeProducts): the slot, normally
     int            slotA, slotB; // where the edges' sums go (the launch's last slot = nobody asked)
     unsigned       flags;        // PW_* below
     int            pad;
@@ -327,9 +328,12 @@ static_assert(sizeof(PreWalkSeg) == 16, "PreWalkSeg layout");
 // sums [nSlots + 1][waves] with waves = preWalkWaves(P, C); dProg[0] is the list's root (what the likelihood is formed from),
 // listRootPre its pre-order partial
 int  preWalkWaves(int P, int C);
+// products: [nSlots + 1][C][16], entry e = (branch matrix of edge e) . (its differential matrix), the spare last one zeros
+// (launchEdgeProducts from pairs {matrix, differential matrix}, -1 -1 for zeros); PreWalkOp::dA / dB index it
+void launchEdgeProducts(hipStream_t stream, const double* matrices, const int* dPairs, double* products, int C, int n);
 bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
-                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots,
-                    bool postSlots = false);
+                    const double* matrices, const double* products, const double* catWeights, const double* patternWeights, double* sums, int P, int C,
+                    int holdSlots, bool postSlots = false);
 void launchPreWalkFinal(hipStream_t stream, const double* sums, int nSlots, int P, int C, double* out);
 // the edge derivatives alone, same shape (32-byte vector accesses); outputs as launchEdgeDifferentials
 void launchEdgeDifferentials4(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, const double* matrices, const double* catWeights,

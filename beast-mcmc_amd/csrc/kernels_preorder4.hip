@@ -176,9 +176,9 @@ __device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
     d.matA = p->matA; d.matB = p->matB; d.dA = p->dA; d.dB = p->dB; d.slotA = p->slotA; d.slotB = p->slotB; d.flags = p->flags;
     return d;
 }
-__device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, unsigned oRecip, u64 matrices, unsigned matBytes) {
+__device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsigned oPart, unsigned oTip, unsigned oMat, unsigned oRecip, u64 matrices, u64 products, unsigned matBytes) {
     const u64 mA = matrices + (u64)(unsigned)d.matA * matBytes, mB = matrices + (u64)(unsigned)d.matB * matBytes;
-    const u64 dA = matrices + (u64)(unsigned)d.dA * matBytes, dB = matrices + (u64)(unsigned)d.dB * matBytes;
+    const u64 dA = products + (u64)(unsigned)d.dA * matBytes, dB = products + (u64)(unsigned)d.dB * matBytes;       // (k_edgeProducts: branch matrix . differential matrix, per edge)
     // a compact tip is one byte, a child with partials two 16-byte loads: what is not needed is BRANCHED around (a vector-memory
     // instruction occupies the address unit whatever it fetches, and half the children of a tree are tips)
     asm volatile(
@@ -265,6 +265,33 @@ __device__ __forceinline__ void matvecDppPairT(const double mA, const v4d xa, co
 }
 #undef FA
 #undef FB
+// one matrix: y = M x and y = M^T x (four independent chains)
+#define FM(Y, N, X) "v_fmac_f64_dpp %[" #Y "], %[m], %[" #X "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ v4d matvecDpp(const double m, const v4d x) {
+    double a0, a1, a2, a3;
+    const double p0 = x.x, p1 = x.y, p2 = x.z, p3 = x.w;
+    asm volatile(
+        "v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\tv_mov_b64 %[a2], 0\n\tv_mov_b64 %[a3], 0\n\t"
+        FM(a0, 0, p0) FM(a1, 4, p0) FM(a2, 8, p0) FM(a3, 12, p0) FM(a0, 1, p1) FM(a1, 5, p1) FM(a2, 9, p1) FM(a3, 13, p1)
+        FM(a0, 2, p2) FM(a1, 6, p2) FM(a2, 10, p2) FM(a3, 14, p2) FM(a0, 3, p3) FM(a1, 7, p3) FM(a2, 11, p3) FM(a3, 15, p3)
+        "s_nop 0"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [m] "v"(m), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3));
+    return v4d{a0, a1, a2, a3};
+}
+__device__ __forceinline__ v4d matvecDppT(const double m, const v4d x) {
+    double a0, a1, a2, a3;
+    const double p0 = x.x, p1 = x.y, p2 = x.z, p3 = x.w;
+    asm volatile(
+        "v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\tv_mov_b64 %[a2], 0\n\tv_mov_b64 %[a3], 0\n\t"
+        FM(a0, 0, p0) FM(a1, 1, p0) FM(a2, 2, p0) FM(a3, 3, p0) FM(a0, 4, p1) FM(a1, 5, p1) FM(a2, 6, p1) FM(a3, 7, p1)
+        FM(a0, 8, p2) FM(a1, 9, p2) FM(a2, 10, p2) FM(a3, 11, p2) FM(a0, 12, p3) FM(a1, 13, p3) FM(a2, 14, p3) FM(a3, 15, p3)
+        "s_nop 0"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [m] "v"(m), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3));
+    return v4d{a0, a1, a2, a3};
+}
+#undef FM
 // v + (the value another lane holds, 0 where the pattern has no source lane / the row is masked off)
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dppAdd(double v) {
@@ -280,9 +307,38 @@ __device__ __forceinline__ double waveSumTo63(double v) {
     return v;
 }
 
+// the value lane `byteAddr / 4` holds (the LDS crossbar, no memory: the vector pipe is what this kernel is short of)
+__device__ __forceinline__ double laneValue(int byteAddr, double v) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byteAddr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byteAddr, __double2loint(v)));
+}
+// M e_s for a compact tip: column s (the lane's own state) of the matrix spread over the lanes of its row; a missing state
+// (s >= 4: the all-ones partial) takes the row sums.  Eight lane reads instead of sixteen multiply-adds and what surrounds them —
+// half the children of a tree are tips.
+__device__ __forceinline__ v4d columnDpp(const double m, const unsigned s, const int lane) {
+    const int row = (lane & 48) << 2, base = row + (int)((s & 3u) << 2);
+    v4d y = v4d{laneValue(base, m), laneValue(base + 16, m), laneValue(base + 32, m), laneValue(base + 48, m)};
+    if (__builtin_amdgcn_ballot_w64(s >= 4u)) {                            // (wave-uniform: nothing of this for an alignment without gaps)
+        double r = dppAdd<0xB1, 0xf>(m);                                  // quad_perm [1,0,3,2], [2,3,0,1]: every lane of a quad holds the quad's sum
+        r = dppAdd<0x4E, 0xf>(r);
+        const v4d z = v4d{laneValue(row, r), laneValue(row + 16, r), laneValue(row + 32, r), laneValue(row + 48, r)};
+        if (s >= 4u) y = z;
+    }
+    return y;
+}
+// lane 31 <- the wave's sum of a, lane 63 <- the wave's sum of b, in a fixed order: the halves of the wave change what they
+// hold (lanes < 32: a + a of the other half; lanes >= 32: b + b of the other half), then one reduction serves both
+__device__ __forceinline__ double waveSumPair(const double a, const double b, const int lane) {
+    const bool upper = lane >= 32;
+    const double keep = upper ? b : a, send = upper ? a : b;
+    double v = keep + laneValue((lane ^ 32) << 2, send);
+    v = dppAdd<0x111, 0xf>(v); v = dppAdd<0x112, 0xf>(v); v = dppAdd<0x114, 0xf>(v); v = dppAdd<0x118, 0xf>(v);
+    return dppAdd<0x142, 0xa>(v);
+}
+
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* __restrict__ prog, const PreWalkSeg MI355_CONST* __restrict__ segs,
                                                    const double* __restrict__ listRootPre, const double* __restrict__ matrices,
+                                                   const double* __restrict__ products,
                                                    const double* __restrict__ catWeights, const double* __restrict__ patternWeights,
                                                    double* __restrict__ sums, int P, int C, int rootSegment, int holdSlots) {
     extern __shared__ v2d preLds[];                   // hold[slot][C][2][64] (v2d); slot 0 doubles as the categories' exchange at the start
@@ -296,7 +352,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     const unsigned oPart = (unsigned)(((size_t)c * P + q) * 32), oTip = (unsigned)q, oMat = (unsigned)(c * 128 + (lane & 15) * 8);
     const unsigned oRecip = (unsigned)(walkPairIndex((size_t)q) * 8);     // (one partition: the pair-interleaved position of pattern q)
     const unsigned matBytes = (unsigned)C * 128u;
-    const u64 mats = (u64)matrices;
+    const u64 mats = (u64)matrices, prods = (u64)products;
     const size_t waves = (size_t)gridDim.x * C, w = (size_t)blockIdx.x * C + c;
     v2d* holdBase = preLds + (size_t)c * 128 + lane;  // + slot * C * 128, second half at + 64
     const size_t holdStride = (size_t)C * 128;
@@ -307,7 +363,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     PreFetched A, B;
     A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
     B = A;
-    preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, matBytes);
+    preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, prods, matBytes);
     v4d ACC = gptr(reinterpret_cast<const v4d*>(sg.rootPre))[(size_t)c * P + q];
     // the pattern's likelihood, once (the segment that starts at the list's root; the others start from partials that carry the
     // factor already): den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
@@ -327,23 +383,28 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         ACC = ACC * coef;
     } else if (!valid) ACC = v4d{0.0, 0.0, 0.0, 0.0};            // (a lane past the end counts for nothing: the root's factor was 0 for it)
 
+// One descriptor.  What a child costs depends on what it is: a compact tip contributes COLUMNS (columnDpp: of its branch matrix
+// for the sibling's side, of the edge's product matrix for its own derivative) and nothing goes down its edge; a child with
+// partials costs three matrix-vector products (its contribution, its derivative, the pre-order partial handed down).  The
+// derivative of edge a is  w . (E_a x_a)  with  w = pre(n) * (M_b x_b)  and  E_a = M_a . D_a  (k_edgeProducts) — the same number
+// as  (M_a^T w) . (D_a x_a)  without needing the child's pre-order partial for it.
 #define PRE_STAGE(CUR, NXT, DCUR, DNXT)                                                                                     \
     {                                                                                                                     \
-        preIssue(NXT, DNXT, oPart, oTip, oMat, oRecip, mats, matBytes);                                                   \
+        preIssue(NXT, DNXT, oPart, oTip, oMat, oRecip, mats, prods, matBytes);                                            \
         const unsigned fl = DCUR.flags;                                                                                   \
         const int slotA = DCUR.slotA, slotB = DCUR.slotB;                                                                 \
         const u64 stA = DCUR.storeA, stB = DCUR.storeB;                                                                   \
         const unsigned src = (fl >> PW_SRC_SHIFT) & 15u, contA = (fl >> PW_CONT_A_SHIFT) & 15u, contB = (fl >> PW_CONT_B_SHIFT) & 15u; \
-        v4d pn = ACC;                                                                                                     \
-        if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; pn = v4d{lo.x, lo.y, hi.x, hi.y}; } \
+        /* (a node taken from a hold slot follows the end of a subtree: what the registers carried is not needed any more) */ \
+        if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; ACC = v4d{lo.x, lo.y, hi.x, hi.y}; } \
         preWait(CUR, DNXT.flags & 3u);                                                                                    \
+        const bool tipA = (fl & (PW_TIP_A | PW_SLOT_A)) == PW_TIP_A, tipB = (fl & (PW_TIP_B | PW_SLOT_B)) == PW_TIP_B;    \
         v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
-        if (fl & PW_TIP_A) xa = tipVector((int)CUR.sa);                                                                   \
-        if (fl & PW_TIP_B) xb = tipVector((int)CUR.sb);                                                                   \
         if (fl & PW_SLOT_A) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTA_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xa = v4d{lo.x, lo.y, hi.x, hi.y}; } \
         if (fl & PW_SLOT_B) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTB_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xb = v4d{lo.x, lo.y, hi.x, hi.y}; } \
-        v4d ua, ub, pa, pb, va, vb;                                                                                       \
-        matvecDppPair(CUR.mA, xa, CUR.mB, xb, ua, ub);                                                                    \
+        v4d ua, ub;                                                                                                       \
+        if (tipA) ua = columnDpp(CUR.mA, CUR.sa, lane); else ua = matvecDpp(CUR.mA, xa);                                  \
+        if (tipB) ub = columnDpp(CUR.mB, CUR.sb, lane); else ub = matvecDpp(CUR.mB, xb);                                  \
         if (fl & PW_POSTOP) {                          /* an unstored post-order operand, re-evaluated: nothing else happens */ \
             const v4d r = ua * ub * CUR.ra;                                                                               \
             v2d* h = postBase + (size_t)((fl >> PW_DST_SHIFT) & 3u) * holdStride;                                         \
@@ -351,13 +412,18 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
             DCUR = loadPreDesc(dp + 2);                                                                                   \
             dp += 1;                                                                                                      \
         } else {                                                                                                          \
-        matvecDppPairT(CUR.mA, pn * ub, CUR.mB, pn * ua, pa, pb);                                                         \
-        matvecDppPair(CUR.dA, xa, CUR.dB, xb, va, vb);                                                                    \
+        const v4d wA = ACC * ub, wB = ACC * ua;                                                                           \
+        v4d pa = wA, pb = wB;                                                                                             \
+        double ga, gb;                                                                                                    \
+        if (tipA) ga = dot4(wA, columnDpp(CUR.dA, CUR.sa, lane));                                                         \
+        else { ga = dot4(wA, matvecDpp(CUR.dA, xa)); pa = matvecDppT(CUR.mA, wA) * CUR.ra; }   /* (what the child's edges see: divided by its own scale factor) */ \
+        if (tipB) gb = dot4(wB, columnDpp(CUR.dB, CUR.sb, lane));                                                         \
+        else { gb = dot4(wB, matvecDpp(CUR.dB, xb)); pb = matvecDppT(CUR.mB, wB) * CUR.rb; }                               \
         DCUR = loadPreDesc(dp + 2);                                                                                       \
         dp += 1;                                                                                                          \
-        const double ga = waveSumTo63(dot4(pa, va)), gb = waveSumTo63(dot4(pb, vb));                                      \
-        pa = pa * CUR.ra; pb = pb * CUR.rb;            /* what the children's edges see: divided by the child's own scale factor */ \
-        if (lane == 63) { sums[(size_t)slotA * waves + w] = ga; sums[(size_t)slotB * waves + w] = gb; }                   \
+        const double g = waveSumPair(ga, gb, lane);                                                                       \
+        if (lane == 31) sums[(size_t)slotA * waves + w] = g;                                                              \
+        if (lane == 63) sums[(size_t)slotB * waves + w] = g;                                                              \
         if (contA == PW_CONT_STORE) { if (valid) gptr(reinterpret_cast<v4d*>(stA))[(size_t)c * P + q] = pa; }             \
         else if (contA >= 2u) { v2d* h = holdBase + (size_t)(contA - 2) * holdStride; h[0] = v2d{pa.x, pa.y}; h[64] = v2d{pa.z, pa.w}; }   \
         if (contB == PW_CONT_STORE) { if (valid) gptr(reinterpret_cast<v4d*>(stB))[(size_t)c * P + q] = pb; }             \
@@ -376,9 +442,28 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
 
 int preWalkWaves(int P, int C) { return ((P + 63) / 64) * C; }
 
+// products[e][c] = M[pairs[2 e]][c] . M[pairs[2 e + 1]][c] (4 x 4, row-major): an edge's branch matrix times its differential
+// matrix — what k_preWalk4 applies to the child's post-order partial (PreWalkOp::dA / dB index this array); a pair of -1: zeros
+__global__ __launch_bounds__(256) void k_edgeProducts(const double* __restrict__ matrices, const int* __restrict__ pairs, double* __restrict__ products, int C, int n) {
+    const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (t >= n * C * 16) return;
+    const int k = t & 3, i = (t >> 2) & 3, c = (t >> 4) % C, e = (t >> 4) / C;
+    const int m = pairs[2 * e], d = pairs[2 * e + 1];
+    double v = 0.0;
+    if (m >= 0 && d >= 0) {
+        const double* M = matrices + ((size_t)m * C + c) * 16 + 4 * i;
+        const double* D = matrices + ((size_t)d * C + c) * 16 + k;
+        v = M[0] * D[0] + M[1] * D[4] + M[2] * D[8] + M[3] * D[12];
+    }
+    products[t] = v;
+}
+void launchEdgeProducts(hipStream_t stream, const double* matrices, const int* dPairs, double* products, int C, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_edgeProducts, dim3((n * C * 16 + 255) / 256), dim3(256), 0, stream, matrices, dPairs, products, C, n);
+}
+
 bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
-                    const double* matrices, const double* catWeights, const double* patternWeights, double* sums, int P, int C, int holdSlots,
-                    bool postSlots) {
+                    const double* matrices, const double* products, const double* catWeights, const double* patternWeights, double* sums, int P, int C,
+                    int holdSlots, bool postSlots) {
     if (nSegs <= 0 || nSegs > 65536 || C < 1 || C > 16 || (size_t)C * P * 32 >= ((size_t)1 << 32)) return false;
     const int slots = holdSlots < 1 ? 1 : holdSlots;                 // (slot 0 doubles as the categories' exchange at the start)
     const size_t lds = (size_t)(slots + (postSlots ? PW_POST_SLOTS : 0)) * C * 128 * sizeof(v2d);
@@ -390,7 +475,7 @@ bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg
       for (int part = 0; part < 2; part++) {                                                                              \
           const int n = part ? nSegs - 1 : 1;                                                                             \
           if (n > 0) hipLaunchKernelGGL(k_preWalk4<T>, dim3((P + 63) / 64, n), block, lds, stream, (const PreWalkOp MI355_CONST*)dProg,   \
-                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, catWeights, patternWeights, sums, P, C, part == 0 ? 1 : 0, slots); } }
+                                        (const PreWalkSeg MI355_CONST*)(dSegs + part), listRootPre, matrices, products, catWeights, patternWeights, sums, P, C, part == 0 ? 1 : 0, slots); } }
     if (C <= 4) PRE_WALK_LAUNCH(256) else if (C <= 8) PRE_WALK_LAUNCH(512) else PRE_WALK_LAUNCH(1024)
 #undef PRE_WALK_LAUNCH
     return true;
