@@ -229,6 +229,9 @@ __device__ __forceinline__ void preWait(PreFetched& f, unsigned nextTips) {     
         : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB), "+v"(f.ra), "+v"(f.rb)
         : [nt] "s"(nextTips) : "memory", "scc");
 }
+// (Measured and dropped, round 5: touching the post-order partials of the descriptor TWO ahead — one byte per lane, so that the
+// real loads a stage later find them on their way — 6.72 instead of 5.98 ms per gradient at 1e5 patterns: the touches are vector-
+// memory instructions and L2 requests of their own.)
 // (ya, yb) = (MA xa, MB xb), the matrices spread over the lanes (lane l = entry l & 15, row-major): eight independent chains
 __device__ __forceinline__ void matvecDppPair(const double mA, const v4d xa, const double mB, const v4d xb, v4d& ya, v4d& yb) {
     double a0, a1, a2, a3, b0, b1, b2, b3;
@@ -320,7 +323,9 @@ __device__ __forceinline__ v4d columnDpp(const double m, const unsigned s, const
     if (__builtin_amdgcn_ballot_w64(s >= 4u)) {                            // (wave-uniform: nothing of this for an alignment without gaps)
         double r = dppAdd<0xB1, 0xf>(m);                                  // quad_perm [1,0,3,2], [2,3,0,1]: every lane of a quad holds the quad's sum
         r = dppAdd<0x4E, 0xf>(r);
-        const v4d z = v4d{laneValue(row, r), laneValue(row + 16, r), laneValue(row + 32, r), laneValue(row + 48, r)};
+        int first = base & ~12;                                           // (= row; opaque, or four loop-invariant address registers are kept for it)
+        asm volatile("" : "+v"(first));
+        const v4d z = v4d{laneValue(first, r), laneValue(first + 16, r), laneValue(first + 32, r), laneValue(first + 48, r)};
         if (s >= 4u) y = z;
     }
     return y;
@@ -359,11 +364,6 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     v2d* postBase = holdBase + (size_t)holdSlots * holdStride;       // the post slots (PW_POSTOP) behind the hold slots, same shape
 
     const PreWalkOp MI355_CONST* dp = prog + sg.progStart;
-    PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
-    PreFetched A, B;
-    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
-    B = A;
-    preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, prods, matBytes);
     v4d ACC = gptr(reinterpret_cast<const v4d*>(sg.rootPre))[(size_t)c * P + q];
     // the pattern's likelihood, once (the segment that starts at the list's root; the others start from partials that carry the
     // factor already): den = sum_c w_c sum_i pre(root)_i (MA xa)_i (MB xb)_i through the categories' exchange
@@ -382,6 +382,12 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         const double coef = valid ? patternWeights[p] * catWeights[c] / den : 0.0;
         ACC = ACC * coef;
     } else if (!valid) ACC = v4d{0.0, 0.0, 0.0, 0.0};            // (a lane past the end counts for nothing: the root's factor was 0 for it)
+    // (the pipeline is set up behind the block above: the kernel's register count is decided where the two overlap)
+    PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
+    PreFetched A, B;
+    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
+    B = A;
+    preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, prods, matBytes);
 
 // One descriptor.  What a child costs depends on what it is: a compact tip contributes COLUMNS (columnDpp: of its branch matrix
 // for the sibling's side, of the edge's product matrix for its own derivative) and nothing goes down its edge; a child with
@@ -399,9 +405,10 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; ACC = v4d{lo.x, lo.y, hi.x, hi.y}; } \
         preWait(CUR, DNXT.flags & 3u);                                                                                    \
         const bool tipA = (fl & (PW_TIP_A | PW_SLOT_A)) == PW_TIP_A, tipB = (fl & (PW_TIP_B | PW_SLOT_B)) == PW_TIP_B;    \
-        v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
-        if (fl & PW_SLOT_A) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTA_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xa = v4d{lo.x, lo.y, hi.x, hi.y}; } \
-        if (fl & PW_SLOT_B) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTB_SHIFT) & 3u) * holdStride; const v2d lo = h[0], hi = h[64]; xb = v4d{lo.x, lo.y, hi.x, hi.y}; } \
+        /* (an unstored operand comes out of its post slot into the registers the loads would have filled) */              \
+        if (fl & PW_SLOT_A) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTA_SHIFT) & 3u) * holdStride; CUR.a0 = h[0]; CUR.a1 = h[64]; } \
+        if (fl & PW_SLOT_B) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTB_SHIFT) & 3u) * holdStride; CUR.b0 = h[0]; CUR.b1 = h[64]; } \
+        const v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};      \
         v4d ua, ub;                                                                                                       \
         if (tipA) ua = columnDpp(CUR.mA, CUR.sa, lane); else ua = matvecDpp(CUR.mA, xa);                                  \
         if (tipB) ub = columnDpp(CUR.mB, CUR.sb, lane); else ub = matvecDpp(CUR.mB, xb);                                  \
