@@ -115,6 +115,18 @@ def sample_with_tail(pattern_count, n_sample, seed):
     return np.unique(np.concatenate([rnd, tail]))
 
 
+def raw_binding(tl):
+    """A Beagle binding object over a BeagleTreeLikelihood's existing instance (no new instance): the getters the host driver does
+    not wrap."""
+    import beast_mcmc_amd as bm
+    b = bm.beagle.Beagle.__new__(bm.beagle.Beagle)
+    b.lib = tl.engine
+    b._f = tl.engine.fn
+    b.instance = tl.instance
+    b.stateCount, b.patternCount, b.categoryCount = tl.state_count, tl.pattern_count, tl.category_count
+    return b
+
+
 def walk_stats(tl):
     """The engine's walk counters for the instance behind a BeagleTreeLikelihood (include/beagle_mi355.h beagleMi355WalkStats):
     which kernel a list ran on — 'walks' pattern-walk launches, of them 'fast_walks' on the assembly loop k_walk4_fast."""

@@ -66,6 +66,26 @@ def sampled_check(wl, oracle_lib, n_sample, seed, rescaling=RESCALE_DYNAMIC, ker
             assert st2["fast_walks"] == 0, st2
     elif kernel == "levels":
         assert st2["walks"] == 0, st2
+    # node partials at the full size: the root, its two children and a spread of inner nodes, each with its own scale factors folded
+    # in, on the sampled patterns against the oracle (which holds exactly those patterns); at 4 states most of these were never stored
+    # (the engine materialises them for the read-back) — and the likelihood afterwards is the same double.  Tolerance: 1e-10 of the
+    # pattern's largest entry at 4 states; 2e-9 above — a 20- / 61-state transition matrix is an eigen sum with cancellation whose small
+    # entries differ by ~1e-11 relative between two correct summation orders (the engine's kernel, the oracle's loop), and a node near
+    # the root of 500 taxa has multiplied hundreds of them: measured 6e-13 (depth ~10) ... 2.4e-10 (the root) on config B, while the
+    # site log-likelihoods above stay inside 1e-10
+    node_tol = REL_TOL if wl.state_count == 4 else 2e-9
+    nodes = sorted(set([2 * wl.tip_count - 2, int(wl.tree.left[-1]), int(wl.tree.right[-1])] +
+                       [int(n) for n in np.linspace(wl.tip_count, 2 * wl.tip_count - 2, 9)]))
+    nodes = [n for n in nodes if n >= wl.tip_count]
+    rg, ro = helpers.raw_binding(g), helpers.raw_binding(o)
+    for n in nodes:
+        pg = rg.getPartials(g.node_buffer_index(n), g.node_scale_index(n))[:, idx, :]
+        po = ro.getPartials(o.node_buffer_index(n), o.node_scale_index(n))
+        assert pg.shape == po.shape == (wl.category_count, len(idx), wl.state_count)
+        scale = np.maximum(np.abs(po).max(axis=(0, 2), keepdims=True), 1e-300)
+        assert np.max(np.abs(pg - po) / scale) <= node_tol, n
+    g.makeDirty()
+    assert helpers.rel_err(g.getLogLikelihood(), lnl) <= 1e-12
     o.close(); g.close()
 
 
