@@ -354,7 +354,6 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
-    in->wideWrite = !(getenv("BEAGLE_MI355_NO_WIDE_WRITE") && atoi(getenv("BEAGLE_MI355_NO_WIDE_WRITE")) != 0);
     // (opt-in: it halves the post-order partials a gradient chain keeps in HBM and moves, and costs 0-5 % of the chain's time — the
     // pre-order walk is bound by instruction issue and a re-evaluation descriptor is half a node's worth: profiles/r05_experiments.txt 5)
     in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&

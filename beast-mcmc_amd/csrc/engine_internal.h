@@ -68,7 +68,6 @@ struct Instance {
         long tag = 0, epoch = -1;
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
         int maxRange = 0, sinks = 0;                     // (sinks: slices no other slice waits for — one: the whole program leads to its last slice)
-        bool wide = false;                               // resolved for the wide lane map (write-mode rescaling, four categories: kernels_walk4.hip)
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
         std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)
@@ -144,11 +143,9 @@ struct Instance {
         bool valid = false;
         const mi355::WalkOp* prog = nullptr; const mi355::WalkSeg* segs = nullptr; const int* deps = nullptr;
         int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
-        bool wide = false;                               // (a wide launch never finishes an evaluation: see flushWalk)
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
     } pendingWalk;
     bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back
-    bool wideWrite = true;                               // BEAGLE_MI355_NO_WIDE_WRITE=1: write-mode programs stay on the one-category-per-wave lane map
     bool copyKeepsWalk = false;                          // (set around an upload the held walk does not read: engine_instance.cpp queueCopy)
     long statRootFused = 0;
     long statFoldedVectors = 0, statFoldBuilds = 0;      // read-mode programs: folded reciprocal vectors in use / (re)builds of them (engine_walk.cpp)

@@ -127,11 +127,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT && plan.launchOrder.size() == plan.segs.size();
     const bool asmLoop = in->fastWalk && !in->walkT;          // k_walk4_fast runs this program (otherwise k_walk4 / k_walkT32)
-    // a program that rescales in write mode runs on the wide lane map (four categories: all of a pattern's categories in one wave)
-    bool wide = false;
-    if (reuse) wide = slot->wide;
-    else if (asmLoop && in->wideWrite && in->C == 4)
-        for (size_t i = 0; i < n && !wide; i++) wide = plan.prog[i].smode == mi355::PS_WRITE;
     int maxRange = 0;
     if (reuse) {
         maxRange = slot->maxRange;
@@ -278,16 +273,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             // (4) | store(i - 1) | fetch(i + 2) | WAIT.  A first child of i in memory has to have landed as well: then only what
             // follows it counts.  (Loads only — the strict rule — whatever BEAGLE_MI355_STRICT_WAITS says: with two fetch sizes the
             // code space has no room for the store counts of the lax rule, which bought 1 %.)
-            auto fetchLoads = [&](int j) { return (wide ? 4 : 3) + ((w[j].flags & mi355::WF_INV) ? 1 : 0); };     // (the no-ops behind a program: 3; wide: 4)
+            auto fetchLoads = [&](int j) { return 3 + ((w[j].flags & mi355::WF_INV) ? 1 : 0); };     // (the no-ops behind a program: 3)
             const int x1 = i > first && (w[i - 1].flags & mi355::WF_X) ? 4 : 0;
             const int nWait = (w[i].flags & mi355::WF_X) ? fetchLoads(i + 2) : fetchLoads(i + 1) + fetchLoads(i + 2) + x1;
-            w[i].flags |= mi355::walkWaitCode(nWait, wide);
+            w[i].flags |= mi355::walkWaitCode(nWait);
         }
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
     if (slot) {
-        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange; slot->wide = wide;
+        slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
         slot->scaleWrites = in->statScaleWrites - s0[3]; slot->stored = in->statStored - s0[4];
     }
@@ -400,7 +395,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         Instance::PendingWalk& pw = in->pendingWalk;
         if (pw.valid) { int rcf = flushWalk(in); if (rcf) return rcf; }            // (cannot happen: every path here went through live())
         pw.prog = (const mi355::WalkOp*)dBase; pw.segs = (const mi355::WalkSeg*)(dBase + opBytes); pw.deps = (const int*)(dBase + depOff);
-        pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch; pw.wide = wide;
+        pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch;
         in->statFastWalks++; in->statWalks++;
         // hold the launch back for the root call?  (one partition, the whole range, not inside a timer bracket)
         // ... and only a program whose slices ALL lead to one last slice: the root call's result word then says that every workgroup
@@ -413,7 +408,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             for (size_t i = 0; i < segs.size(); i++) if (!feeds[i] && segs[i].progCount > 0) sinks++;
             if (slot) slot->sinks = sinks;
         }
-        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P && sinks == 1 && !wide;
+        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P && sinks == 1;
         if (hold) {
             pw.finalStore.assign(segs.size(), -1);
             for (size_t i = 0; i < segs.size(); i++) {
@@ -439,7 +434,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                                       in->matStream, in->P, in->S, in->C, in->holdSlots)) return BEAGLE_ERROR_GENERAL;
         } else if (fast) {
             mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                   in->matStream, in->P, in->C, (long)in->scaleStride, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, wide);
+                                   in->matStream, in->P, in->C, (long)in->scaleStride);
             in->statFastWalks++;
         } else
             mi355::launchWalk4(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
@@ -458,7 +453,7 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
     pw.valid = false;                                  // (before anything that could come back here through live())
     if (!in->pendingCopies.empty()) { int rc = flushUploads(in); if (rc) return rc; }
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
-                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, pw.wide ? nullptr : root, in->walkSpinLimit, in->walkSelfServed, pw.wide);
+                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed);
     if (root) in->statRootFused++;
     HIP_TRY(hipGetLastError());
     return 0;

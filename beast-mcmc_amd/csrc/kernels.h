@@ -83,12 +83,9 @@ enum : unsigned { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26,
 // N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan).  A fetch is three loads, four
 // for a micro-operation that multiplies by reciprocal scale factors (WF_INV), so N is 6..8, + 4 behind a first child from memory,
 // or 3..4 when the stage's own first child comes from memory.  Codes (tools/gen_walk4_fast.py WAIT_N): 0..7 = 6, 7, 8, 10, 11, 12,
-// 3, 4; anything else is rounded DOWN to the next of these (a smaller N only waits longer).  The wide layout (write-mode programs,
-// four categories: k_walk4_fast<4, true>) fetches one load more — two LDS-DMA instructions for the four categories' tables —:
-// codes 0..7 = 8, 9, 10, 12, 13, 14, 4, 5.
-inline unsigned walkWaitCode(int n, bool wide = false) {
-    const int code = wide ? (n >= 14 ? 5 : n == 13 ? 4 : n == 12 ? 3 : n >= 10 ? 2 : n == 9 ? 1 : n == 8 ? 0 : n >= 5 ? 7 : 6)
-                          : (n >= 12 ? 5 : n == 11 ? 4 : n == 10 ? 3 : n >= 8 ? 2 : n == 7 ? 1 : n == 6 ? 0 : n >= 4 ? 7 : 6);
+// 3, 4; anything else is rounded DOWN to the next of these (a smaller N only waits longer).
+inline unsigned walkWaitCode(int n) {
+    const int code = n >= 12 ? 5 : n == 11 ? 4 : n == 10 ? 3 : n >= 8 ? 2 : n == 7 ? 1 : n == 6 ? 0 : n >= 4 ? 7 : 6;
     return (unsigned)code << WF_WAIT_SHIFT;
 }
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
@@ -162,7 +159,7 @@ struct RootFused {
 // (kernels_walk4.hip: forward progress whatever the dispatch order); *selfServed counts the workgroups that did.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
-                     const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr, bool wide = false);
+                     const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr);
 // 4-state walk instances: the root integration as a launch of its own, bit-compatible with the walk's root epilogue (root_site4.h)
 void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                                const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,

@@ -361,7 +361,6 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 
 // ---- the assembly loop ------------------------------------------------------------------------------------------------
 #include "walk4_fast_loop.inc"
-#include "walk4_fastw_loop.inc"
 // Same mapping, LDS layout (hold slots, then the matrix tables; no exchange buffer) and arithmetic as k_walk4; the loop
 // itself is one block of assembly with its own register map (tools/gen_walk4_fast.py says why and what it leaves to k_walk4).
 // One launch for ALL slices of a program (flags != nullptr).  Slices of a wave are independent; a slice of a later wave reads
@@ -379,11 +378,7 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 // fence at agent scope costs) made the launch five times slower instead of faster.
 // the lane's index without a register that has to survive the assembly block (which leaves the compiler two VGPRs)
 __device__ __forceinline__ int walkLane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-// WIDE (four categories only): the second lane map of tools/gen_walk4_fast.py — a wave holds all four categories of 32 patterns
-// (row of 16 lanes = category), wave w of the workgroup the patterns 16 w .. 16 w + 15 and 64 more of its 128 — for programs that
-// rescale in write mode: the largest entry of a pattern is formed inside one wave.  Every wave keeps the tables of all four
-// categories (3 x 1 280 B of LDS per wave: 47 KiB per workgroup, three per CU).  Same descriptors, same bits.
-template <int MAXC, bool WIDE>
+template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
@@ -445,7 +440,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
-    const unsigned tbl = ldsBase + 2u * holdStride + (WIDE ? c * 3u * 4u * (unsigned)WALK_TABLE_BYTES : c * WALK_TABLE_BYTES);
+    const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
     for (int s = first; s <= y; s++) {
         const WalkSeg MI355_CONST& ss = segs[s];
         if (s != y) {                                 // (self-serve only)
@@ -460,15 +455,6 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         const int progStart = ss.progStart, progCount = ss.progCount;
         const u64 dp = (u64)(prog + (size_t)progStart * 16);
         const u64 strm = (u64)matStream + (u64)progStart * strmStep;
-        if constexpr (WIDE)
-        asm volatile(WALK4_FASTW_ASM
-                     : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(4 * WALK_TABLE_BYTES)),
-                         [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
-                         [cP32] "s"((unsigned)P * 32u), [cM] "s"(0u), [hold] "s"(hold),
-                         [exch] "s"(0u), [ncat] "s"((unsigned)C),
-                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)blockIdx.x * 128)
-                     : WALK4_FASTW_CLOBBERS);
-        else
         asm volatile(WALK4_FAST_ASM
                      : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
                          [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
@@ -490,7 +476,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
     // categories up in order, takes the logarithm and folds the group's 128 site values; the last group adds the groups' sums.
     // Same functions, same order, same bits as the launch of its own (kernels.hip k_rootSite4W).
-    if (!WIDE && rootArgs.rootSeg == y) {        // (the engine never asks a wide launch to finish an evaluation: another lane map)
+    if (rootArgs.rootSeg == y) {
         const int lane = walkLane();
         const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
         const double sa = rootDot4(rootArgs.freqs, h[0], h[1], h[128], h[129]);
@@ -514,7 +500,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root,
-                     unsigned long long spinLimit, unsigned* selfServed, bool wide) {
+                     unsigned long long spinLimit, unsigned* selfServed) {
     if (nSegs <= 0 || maxRange <= 0) return;
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
@@ -534,20 +520,12 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     memset(&ra, 0, sizeof(ra));
     ra.rootSeg = -1;
     if (root) ra = *root;
-    if (wide) {                                       // (C == 4, no root epilogue: engine_walk.cpp)
-        if (C != 4) return;
-        ra.rootSeg = -1;
-        const size_t ldsW = (size_t)2 * C * 4096 + (size_t)4 * 3 * 4 * WALK_TABLE_BYTES + ldsPad;       // hold slots, then per wave three buffers of four tables
-        if (ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4, true>), ldsW)) return; }
-        hipLaunchKernelGGL((k_walk4_fast<4, true>), grid, block, ldsW, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra);
-        return;
-    }
-    if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4, false>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4, false>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra);
-    else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8, false>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8, false>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
-    else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16, false>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16, false>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
+    if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra);
+    else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
+    else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

@@ -8,8 +8,6 @@ updates with BufferIndexHelper flips and rejections (src/dr/evomodel/treedatalik
 import os
 import subprocess
 
-import pytest
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,32 +56,26 @@ def test_isa_check_sees_a_copy_made_before_the_wait():
 
 
 
-@pytest.mark.parametrize("layout", ["", "wide"])
-def test_generated_assembly_loop_is_up_to_date_and_balanced(layout):
-    """csrc/walk4_fast_loop.inc (and walk4_fastw_loop.inc, the wide lane map of write-mode programs) is what tools/gen_walk4_fast.py
-    emits now, and the stream is structurally sound: every out-of-line block returns, every label that is branched to exists
-    exactly once, every fetch issues the small loads the host's wait codes assume (kernels.h walkWaitCode: one LDS-DMA — two in
-    the wide layout —, two tip-pair loads, the reciprocals out of line), and nothing above v125 / s83 is named (126 vector
+def test_generated_assembly_loop_is_up_to_date_and_balanced():
+    """csrc/walk4_fast_loop.inc is what tools/gen_walk4_fast.py emits now, and the stream is structurally sound: every
+    out-of-line block returns, every label that is branched to exists exactly once, every fetch issues the four small
+    loads the host's wait codes assume (kernels.h walkWaitCode), and nothing above v125 / s83 is named (126 vector
     registers: four waves per SIMD)."""
     import re
     env = dict(os.environ, WALK4_CHECK_ONLY="1")
     env.pop("WALK4_EXPERIMENT", None)
-    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_walk4_fast.py")] + ([layout] if layout else []), env=env, capture_output=True, text=True)
-    name = "walk4_fastw_loop.inc" if layout else "walk4_fast_loop.inc"
-    assert r.returncode == 0, "%s is stale: run python tools/gen_walk4_fast.py %s" % (name, layout)
-    text = open(os.path.join(ROOT, "beast-mcmc_amd", "csrc", name)).read()
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_walk4_fast.py")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, "walk4_fast_loop.inc is stale: run python tools/gen_walk4_fast.py"
+    text = open(os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")).read()
     lines = re.findall(r'^\s+"(.*?)\\n(?:\\t)?" \\$', text, flags=re.M)
     labels = [l[:-1] for l in lines if l.endswith(":")]
     assert len(labels) == len(set(labels))
     targets = set(re.findall(r"s_c?branch\w* (\.LW4\w+_%=)", "\n".join(lines)))
     assert targets <= set(labels), targets - set(labels)
-    # per fetch (two in the prologue + three stages = 5 of each group)
-    assert sum("global_load_lds_dwordx4" in l for l in lines) == (10 if layout else 5)
+    # per fetch: one LDS-DMA, two tip-pair loads, one reciprocal-pair load (two in the prologue + three stages = 5 of each group)
+    assert sum("global_load_lds_dwordx4" in l for l in lines) == 5
     assert sum(l.startswith("global_load_ushort") for l in lines) == 10
     assert sum(l.startswith("global_load_dwordx4 v[22:25]") or l.startswith("global_load_dwordx4 v[26:29]") or l.startswith("global_load_dwordx4 v[30:33]") for l in lines) == 5
-    # write-mode rescaling: the narrow layout meets at a barrier at every node, the wide one exchanges lanes inside the wave
-    assert sum(l == "s_barrier" for l in lines) == (1 if layout else 4)
-    assert sum(l.startswith("ds_max_f64") for l in lines) == (0 if layout else 6)
     regs = [int(x) for x in re.findall(r"\bv\[?(\d+)", "\n".join(lines))]
     assert max(regs) <= 125
     sregs = [int(x) for x in re.findall(r"\bs\[?(\d+)", "\n".join(lines))]

@@ -27,17 +27,7 @@ Run: python tools/gen_walk4_fast.py   (rewrites the .inc; tests/test_planner_nat
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The second layout (`python tools/gen_walk4_fast.py wide` -> walk4_fastw_loop.inc, four rate categories only): a wave holds ALL FOUR
-# categories of 32 patterns — row r of its lanes (16 lanes) = category r — instead of one category of 128.  Programs that rescale in
-# write mode run on it: the largest entry of a pattern over states and categories is then a matter of two cross-row lane exchanges
-# inside one wave, where the first layout needs LDS atomics and a workgroup barrier at every node (A with ALWAYS rescaling: 966 us
-# against 495 in read mode).  What changes: the lane -> (category, pattern) map of the setup, one matrix table per CATEGORY per wave
-# (two LDS-DMA instructions per fetch instead of one: a fetch is 4 small loads, 5 with the reciprocals), the tables' addresses per
-# row, and rescale_block.  Arithmetic, descriptors, pipeline and every other block are shared, and so are the bits of the results.
-WIDE = (len(os.sys.argv) > 1 and os.sys.argv[1] == "wide") or os.environ.get("WALK4_LAYOUT") == "wide"
-OUT = os.environ.get("WALK4_OUT") or os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fastw_loop.inc" if WIDE else "walk4_fast_loop.inc")
-MACRO = "WALK4_FASTW" if WIDE else "WALK4_FAST"
-TABLE = 320                   # bytes of one (micro-operation, category) matrix table: 2 children x 5 columns x 4 doubles
+OUT = os.environ.get("WALK4_OUT") or os.path.join(ROOT, "beast-mcmc_amd", "csrc", "walk4_fast_loop.inc")
 
 # ---- register map -----------------------------------------------------------------------------------------------------
 # vector
@@ -73,7 +63,7 @@ B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
 # (a fetch is THREE small loads — matrix table, two tip-state pairs — and a fourth, the reciprocal scale factors, only for a
 # micro-operation that multiplies by them: since round 5 a read-mode program applies the factors of unstored results once, at the
 # stored result above them, so nine micro-operations in ten fetch three)
-WAIT_N = (8, 9, 10, 12, 13, 14, 4, 5) if WIDE else (6, 7, 8, 10, 11, 12, 3, 4)      # (kernels.h walkWaitCode(n, wide))
+WAIT_N = (6, 7, 8, 10, 11, 12, 3, 4)
 
 # Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
 # in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
@@ -160,13 +150,10 @@ def col0_reads(tmp, tbv, off):
 
 
 def tip_columns(dst, t, tbl, off):
-    """tbl: the table buffer's LDS address — a scalar (the wave's one category), or (wide layout) the vector register that holds
-    each row's own"""
-    base = v(tbl) if WIDE else s(tbl)
     e("v_and_b32 %s, 0xff, %s" % (v(T0), v(t)))
     e("v_lshrrev_b32 %s, 8, %s" % (v(T1), v(t)))
-    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T0), v(T0), base))
-    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T1), v(T1), base))
+    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T0), v(T0), s(tbl)))
+    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(T1), v(T1), s(tbl)))
     if "notipread" in EXPERIMENT:
         return
     e("ds_read_b128 %s, %s offset:%d" % (v(dst, 4), v(T0), off))
@@ -218,23 +205,7 @@ def rescale_block(tag, SSCALEW):
               "v_max_f64 %s, %s, %s" % (v(RD, 2), v(base + 2, 2), v(base + 4, 2)),
               "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(RD, 2)),
               "v_max_f64 %s, %s, %s" % (v(m, 2), v(m, 2), v(base + 6, 2))]
-    if WIDE:
-        # the four categories of a pattern sit in the four rows of THIS wave (same lane of each row): rows 0 <-> 1 and 2 <-> 3 through
-        # ds_swizzle (bit mode, xor 16: the LDS crossbar, no memory), then the two halves of the wave through ds_bpermute — no atomics,
-        # no barrier, nothing another wave has to arrive for
-        b += ["ds_swizzle_b32 %s, %s offset:0x401f" % (v(RD + k), v((MA, MA + 1, MB, MB + 1)[k])) for k in range(4)]
-        b += ["v_xor_b32_e32 %s, 32, %s" % (v(T0), v(LANE)),
-              "v_lshlrev_b32_e32 %s, 2, %s" % (v(T0), v(T0)),
-              "s_waitcnt lgkmcnt(0)",
-              "v_max_f64 %s, %s, %s" % (v(MA, 2), v(MA, 2), v(RD, 2)),
-              "v_max_f64 %s, %s, %s" % (v(MB, 2), v(MB, 2), v(RD + 2, 2)),
-              "s_nop 0"]
-        b += ["ds_bpermute_b32 %s, %s, %s" % (v(RD + k), v(T0), v((MA, MA + 1, MB, MB + 1)[k])) for k in range(4)]
-        b += ["s_waitcnt lgkmcnt(0)",
-              "v_max_f64 %s, %s, %s" % (v(A2, 2), v(MA, 2), v(RD, 2)),
-              "v_max_f64 %s, %s, %s" % (v(B2, 2), v(MB, 2), v(RD + 2, 2))]
-    else:
-      b += ["v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)),
+    b += ["v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)),
           "v_add_u32_e32 %s, %s, %s" % (v(T0), s(EXCH), v(T0)),           # the lane's 16 bytes of buffer 0
           "v_add_u32_e32 %s, %s, %s" % (v(T1), s(RB), v(T0)),              # ... of this node's buffer
           "ds_max_f64 %s, %s" % (v(T1), v(MA, 2)),
@@ -271,10 +242,9 @@ def rescale_block(tag, SSCALEW):
     for i in range(8):
         b.append("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(ACC + 2 * i, 2), v(IA if i < 4 else IB, 2)))
     # category 0 stores: factor at 8 p (PA = 32 p for that wave), reciprocal at ROFF + 8 * (pair position)
-    # (wide layout: row 0 of every wave — VALA / VALB are cut down to that row by the setup)
-    b += ([] if WIDE else ["s_cmp_lg_u32 %s, 0" % s(SCNT),
-                           "s_cbranch_scc1 %s" % L("wrb" + tag)])
-    b += ["v_lshrrev_b32_e32 %s, 2, %s" % (v(T0), v(PA)),
+    b += ["s_cmp_lg_u32 %s, 0" % s(SCNT),
+          "s_cbranch_scc1 %s" % L("wrb" + tag),
+          "v_lshrrev_b32_e32 %s, 2, %s" % (v(T0), v(PA)),
           "v_lshrrev_b32_e32 %s, 2, %s" % (v(T1), v(PB)),
           "v_add_u32_e32 %s, %s, %s" % (v(RD), s(ROFF), v(SCALE)),
           "s_mov_b64 exec, %s" % s(VALA, 2),
@@ -299,18 +269,9 @@ def fetch(tag, slot):
         e("global_load_ubyte %s, %s, %s" % (v(T1), v(TIP), s(D + 6, 2)))
     else:
         e("s_mov_b32 m0, %s" % s(TBLS[slot]))
-        if WIDE:                                                  # the four categories' tables: 1 280 contiguous bytes of the stream, 1 024 + 256
-            e("s_nop 0")
-            e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
-            e("s_add_u32 m0, %s, 0x400" % s(TBLS[slot]))
-            e("v_add_u32_e32 %s, 0x400, %s" % (v(T0), v(OM)))
-            e("s_mov_b64 exec, 0xffff")
-            e("global_load_lds_dwordx4 %s, %s" % (v(T0), s(STRM, 2)))
-            e("s_mov_b64 exec, -1")
-        else:
-            e("s_mov_b64 exec, 0xfffff")
-            e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
-            e("s_mov_b64 exec, -1")
+        e("s_mov_b64 exec, 0xfffff")
+        e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
+        e("s_mov_b64 exec, -1")
     e("global_load_ushort %s, %s, %s" % (v(T1S[slot]), v(TIP), s(D, 2)))
     e("global_load_ushort %s, %s, %s" % (v(T2S[slot]), v(TIP), s(D + 2, 2)))
     e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
@@ -416,7 +377,7 @@ def stage(tag, cur):
     # first child
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T1))
     e("s_cbranch_scc0 %s" % L("fm" + tag))
-    tip_columns(F, Tt1, tbvCur if WIDE else tblCur, 0)
+    tip_columns(F, Tt1, tblCur, 0)
     e("s_branch %s" % L("g" + tag))
     e(L("fm" + tag) + ":")
     e("ds_read_b64 %s, %s" % (v(SP, 2), v(spCur)))
@@ -439,7 +400,7 @@ def stage(tag, cur):
     e(L("g" + tag) + ":")
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_T2))
     e("s_cbranch_scc0 %s" % L("ga" + tag))
-    tip_columns(G, Tt2, tbvCur if WIDE else tblCur, 160)
+    tip_columns(G, Tt2, tblCur, 160)
     e(ldsw)
     e("s_branch %s" % L("mul" + tag))
     e(L("ga" + tag) + ":")
@@ -498,8 +459,7 @@ def stage(tag, cur):
     blk.append("s_waitcnt lgkmcnt(0)")
     for j in range(4):
         blk.append("s_mov_b64 exec, %s" % s(MASK + 2 * j, 2))
-        # (wide layout: a row's pieces are 256 bytes — 8 patterns of its category —, patterns q + 8 j and, for j >= 2, 64 more)
-        blk.append("global_store_dwordx4 %s, %s, %s offset:%d%s" % (v(VST), v(F + 4 * j, 4), s(SSTORE, 2), (0, 256, 2048, 2304)[j] if WIDE else 1024 * j, STORE_POLICY))
+        blk.append("global_store_dwordx4 %s, %s, %s offset:%d%s" % (v(VST), v(F + 4 * j, 4), s(SSTORE, 2), 1024 * j, STORE_POLICY))
     blk += ["s_mov_b64 exec, -1", "s_nop 0", "s_branch %s" % L("stb" + tag)]
     outofline.append(blk)
     e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_HWRITE))
@@ -522,59 +482,6 @@ def stage(tag, cur):
     outofline.append(blk)
 
 
-def wide_setup():
-    """Lane offsets of the wide layout (see the top of the file).  %[cat] = the wave's index w in its workgroup, %[cP32] = the bytes
-    between two categories of a partials buffer (32 P), %[cM] unused."""
-    e("s_mov_b32 %s, 0" % s(RB))
-    e("s_barrier")                                                        # (kernels_walk4.hip: every wave has read LDS word 0 by now)
-    ROW, X = F, F + 1                                                     # scratch: row r, x
-    e("v_lshrrev_b32_e32 %s, 4, %s" % (v(ROW), v(LANE)))                  # r
-    e("v_bfe_u32 %s, %s, 1, 3" % (v(T0), v(LANE)))                        # q
-    e("v_and_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))                       # h
-    e("v_lshl_add_u32 %s, %s, 3, %s" % (v(X), v(T1), v(T0)))              # q + 8 h
-    e("s_lshl_b32 %s, %%[cat], 4" % s(ST))
-    e("v_add_u32_e32 %s, %s, %s" % (v(X), s(ST), v(X)))                   # x = 16 w + q + 8 h
-    e("v_add_u32_e32 %s, %%[p0], %s" % (v(T0), v(X)))                     # first pattern of the lane
-    e("v_add_u32_e32 %s, 64, %s" % (v(T1), v(T0)))                       # second
-    # the lanes of row 0 whose patterns lie inside the range: they store the scale factors
-    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T0))
-    e("s_nop 3")
-    e("s_and_b64 %s, vcc, 0xffff" % s(VALA, 2))
-    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
-    e("s_nop 3")
-    e("s_and_b64 %s, vcc, 0xffff" % s(VALB, 2))
-    e("v_min_i32_e32 %s, %s, %s" % (v(T0), s(LAST), v(T0)))              # lanes past the end recompute the last pattern
-    e("v_min_i32_e32 %s, %s, %s" % (v(T1), s(LAST), v(T1)))
-    e("v_mul_lo_u32 %s, %s, %%[cP32]" % (v(G), v(ROW)))                   # the row's category inside a partials buffer
-    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(PA), v(T0), v(G)))
-    e("v_lshl_add_u32 %s, %s, 5, %s" % (v(PB), v(T1), v(G)))
-    # store instruction j: the row's 256-byte piece j, this lane's 16 bytes of it
-    e("s_lshl_b32 %s, %%[cat], 4" % s(ST))
-    e("s_add_u32 %s, %s, %%[p0]" % (s(ST), s(ST)))
-    e("s_lshl_b32 %s, %s, 5" % (s(ST), s(ST)))                            # 32 (p0 + 16 w)
-    e("v_and_b32_e32 %s, 15, %s" % (v(T0), v(LANE)))
-    e("v_lshl_add_u32 %s, %s, 4, %s" % (v(VST), v(T0), v(G)))
-    e("v_add_u32_e32 %s, %s, %s" % (v(VST), s(ST), v(VST)))
-    # position of the pair (x, x + 64) in the interleaved layouts: t0 + 2 k, k = 2 (x mod 32) + x div 32 (kernels.h walkPairIndex)
-    e("v_and_b32_e32 %s, 31, %s" % (v(T0), v(X)))
-    e("v_lshrrev_b32_e32 %s, 5, %s" % (v(T1), v(X)))
-    e("v_lshl_add_u32 %s, %s, 1, %s" % (v(T0), v(T0), v(T1)))             # k
-    e("v_lshlrev_b32_e32 %s, 1, %s" % (v(T0), v(T0)))
-    e("v_add_u32_e32 %s, %%[t0], %s" % (v(TIP), v(T0)))
-    e("v_lshlrev_b32_e32 %s, 3, %s" % (v(SCALE), v(TIP)))
-    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(OM), v(LANE)))                   # the stream entry's first 1 024 bytes: 16 per lane
-    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(HOLD), v(LANE)))
-    e("v_add_u32_e32 %s, %%[hold], %s" % (v(HOLD), v(HOLD)))
-    e("v_and_b32_e32 %s, 3, %s" % (v(T0), v(LANE)))                      # matrix entry 4 i + k of lane l & 15 is T[k][i]
-    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
-    e("v_bfe_u32 %s, %s, 2, 2" % (v(T1), v(LANE)))
-    e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
-    e("v_mul_u32_u24_e32 %s, %d, %s" % (v(G), TABLE, v(ROW)))             # the row's table inside a buffer
-    for j in range(3):
-        e("v_add_u32_e32 %s, %s, %s" % (v(TBVS[j]), s(TBLS[j]), v(G)))
-        e("v_add_u32_e32 %s, %s, %s" % (v(SPS[j]), v(TBVS[j]), v(T0)))
-
-
 def build():
     # ---- inputs -> fixed registers
     e("s_mov_b64 %s, %%[dp]" % s(DP, 2))
@@ -589,25 +496,10 @@ def build():
     # ---- lane offsets
     e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(LANE))
     e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(LANE), v(LANE)))
-    if WIDE:
-        # lane 16 r + 2 q + h (row r = category r; q = 0..7, h = 0 / 1) of wave w owns patterns p0 + x and p0 + 64 + x with
-        # x = 16 w + q + 8 h: the pairs (x, x + 64) the pair-interleaved tip-state and reciprocal layouts keep together (kernels.h
-        # walkPairIndex), and pairs of lanes that hold neighbouring halves of a 256-byte store piece (see the store block)
-        e("s_lshl_b32 %s, %%[cat], 4" % s(ST))                               # 16 w
-        e("s_add_u32 %s, %s, %%[p0]" % (s(ST), s(ST)))                       # p0 + 16 w
-        e("v_bfe_u32 %s, %s, 1, 3" % (v(T1), v(LANE)))                       # q
-        e("v_add_u32_e32 %s, %s, %s" % (v(T1), s(ST), v(T1)))                # p0 + 16 w + q: the pattern of store instruction 0's piece
-        for j in range(4):
-            if j:
-                e("v_add_u32_e32 %s, %d, %s" % (v(T1), (8, 56, 8)[j - 1], v(T1)))      # + 8, + 64, + 72
-            e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
-            e("s_nop 3")
-            e("s_mov_b64 %s, vcc" % s(MASK + 2 * j, 2))
-    else:
-      # lane 2 q + r owns patterns p0 + q + 32 r and p0 + 64 + q + 32 r (see the store block)
-      e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))                  # q
-      e("v_add_u32_e32 %s, %%[p0], %s" % (v(T1), v(T1)))                   # p0 + q: first pattern of store instruction 0's piece
-      for j in range(4):
+    # lane 2 q + r owns patterns p0 + q + 32 r and p0 + 64 + q + 32 r (see the store block)
+    e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))                  # q
+    e("v_add_u32_e32 %s, %%[p0], %s" % (v(T1), v(T1)))                   # p0 + q: first pattern of store instruction 0's piece
+    for j in range(4):
         if j:
             e("v_add_u32_e32 %s, 32, %s" % (v(T1), v(T1)))
         e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
@@ -619,54 +511,51 @@ def build():
     e("s_mov_b32 %s, %%[ncat]" % s(NCAT))
     e("s_mov_b32 %s, %%[roff]" % s(ROFF))
     e("s_mov_b32 %s, %%[cat]" % s(SCNT))
-    if WIDE:
-        wide_setup()
-    else:
-        # the three maximum buffers of write-mode rescaling (rescale_block) start at zero: every wave clears all of them (3 KiB)
-        e("s_mov_b32 %s, 0" % s(RB))
-        e("v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)))
-        e("v_add_u32_e32 %s, %%[exch], %s" % (v(T0), v(T0)))
-        e("v_mov_b64 %s, 0" % v(F, 2))
-        e("v_mov_b64 %s, 0" % v(F + 2, 2))
-        for k in range(3):
-            e("ds_write_b128 %s, %s offset:%d" % (v(T0), v(F, 4), 1024 * k))
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_barrier")
-        e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
-        e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
-        e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
-        e("v_add_u32_e32 %s, %s, %s" % (v(VST), s(ST), v(VST)))
-        e("v_and_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))                      # r
-        e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
-        e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))
-        e("v_add3_u32 %s, %s, %s, %%[p0]" % (v(T0), v(T0), v(T1)))           # first pattern of the lane
-        e("v_add_u32_e32 %s, 64, %s" % (v(T1), v(T0)))                      # second
-        e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T0))
-        e("s_nop 3")
-        e("s_mov_b64 %s, vcc" % s(VALA, 2))
-        e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
-        e("s_nop 3")
-        e("s_mov_b64 %s, vcc" % s(VALB, 2))
-        e("v_min_i32_e32 %s, %s, %s" % (v(T0), s(LAST), v(T0)))             # lanes past the end recompute the last pattern
-        e("v_min_i32_e32 %s, %s, %s" % (v(T1), s(LAST), v(T1)))
-        e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PA), v(T0)))
-        e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PB), v(T1)))
-        e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PA), v(PA)))
-        e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PB), v(PB)))
-        e("v_lshlrev_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))
-        e("v_add_u32_e32 %s, %%[t0], %s" % (v(TIP), v(T0)))                  # position of the pair in the interleaved layouts (t0: kernels.h WalkSeg)
-        e("v_lshlrev_b32_e32 %s, 3, %s" % (v(SCALE), v(TIP)))
-        e("v_lshlrev_b32_e32 %s, 4, %s" % (v(OM), v(LANE)))
-        e("v_add_u32_e32 %s, %%[cM], %s" % (v(OM), v(OM)))
-        e("v_lshlrev_b32_e32 %s, 4, %s" % (v(HOLD), v(LANE)))
-        e("v_add_u32_e32 %s, %%[hold], %s" % (v(HOLD), v(HOLD)))
-        e("v_and_b32_e32 %s, 3, %s" % (v(T0), v(LANE)))                      # matrix entry 4 i + k of lane l & 15 is T[k][i]
-        e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
-        e("v_bfe_u32 %s, %s, 2, 2" % (v(T1), v(LANE)))
-        e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
-        for j in range(3):
-            e("v_add_u32_e32 %s, %s, %s" % (v(SPS[j]), s(TBLS[j]), v(T0)))
-            e("v_mov_b32_e32 %s, %s" % (v(TBVS[j]), s(TBLS[j])))
+    # the three maximum buffers of write-mode rescaling (rescale_block) start at zero: every wave clears all of them (3 KiB)
+    e("s_mov_b32 %s, 0" % s(RB))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(T0), v(LANE)))
+    e("v_add_u32_e32 %s, %%[exch], %s" % (v(T0), v(T0)))
+    e("v_mov_b64 %s, 0" % v(F, 2))
+    e("v_mov_b64 %s, 0" % v(F + 2, 2))
+    for k in range(3):
+        e("ds_write_b128 %s, %s offset:%d" % (v(T0), v(F, 4), 1024 * k))
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(VST), v(LANE)))                 # store instruction j: 1 KiB j + 16 lane from the group's first pattern
+    e("s_lshl_b32 %s, %%[p0], 5" % s(ST))
+    e("s_add_u32 %s, %s, %%[cP32]" % (s(ST), s(ST)))
+    e("v_add_u32_e32 %s, %s, %s" % (v(VST), s(ST), v(VST)))
+    e("v_and_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))                      # r
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
+    e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T1), v(LANE)))
+    e("v_add3_u32 %s, %s, %s, %%[p0]" % (v(T0), v(T0), v(T1)))           # first pattern of the lane
+    e("v_add_u32_e32 %s, 64, %s" % (v(T1), v(T0)))                      # second
+    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T0))
+    e("s_nop 3")
+    e("s_mov_b64 %s, vcc" % s(VALA, 2))
+    e("v_cmp_gt_i32_e32 vcc, %%[pEnd], %s" % v(T1))
+    e("s_nop 3")
+    e("s_mov_b64 %s, vcc" % s(VALB, 2))
+    e("v_min_i32_e32 %s, %s, %s" % (v(T0), s(LAST), v(T0)))             # lanes past the end recompute the last pattern
+    e("v_min_i32_e32 %s, %s, %s" % (v(T1), s(LAST), v(T1)))
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PA), v(T0)))
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(PB), v(T1)))
+    e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PA), v(PA)))
+    e("v_add_u32_e32 %s, %%[cP32], %s" % (v(PB), v(PB)))
+    e("v_lshlrev_b32_e32 %s, 1, %s" % (v(T0), v(LANE)))
+    e("v_add_u32_e32 %s, %%[t0], %s" % (v(TIP), v(T0)))                  # position of the pair in the interleaved layouts (t0: kernels.h WalkSeg)
+    e("v_lshlrev_b32_e32 %s, 3, %s" % (v(SCALE), v(TIP)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(OM), v(LANE)))
+    e("v_add_u32_e32 %s, %%[cM], %s" % (v(OM), v(OM)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (v(HOLD), v(LANE)))
+    e("v_add_u32_e32 %s, %%[hold], %s" % (v(HOLD), v(HOLD)))
+    e("v_and_b32_e32 %s, 3, %s" % (v(T0), v(LANE)))                      # matrix entry 4 i + k of lane l & 15 is T[k][i]
+    e("v_lshlrev_b32_e32 %s, 5, %s" % (v(T0), v(T0)))
+    e("v_bfe_u32 %s, %s, 2, 2" % (v(T1), v(LANE)))
+    e("v_lshl_add_u32 %s, %s, 3, %s" % (v(T0), v(T1), v(T0)))
+    for j in range(3):
+        e("v_add_u32_e32 %s, %s, %s" % (v(SPS[j]), s(TBLS[j]), v(T0)))
+        e("v_mov_b32_e32 %s, %s" % (v(TBVS[j]), s(TBLS[j])))
     for i in range(8):
         e("v_mov_b64 %s, 1.0" % v(ACC + 2 * i, 2))
     # ---- prologue: fetch micro-operations 0 and 1 into slots 0 and 1, the first child of 0 if it is in memory (no hold slot is
@@ -710,16 +599,16 @@ def build():
 
 def main():
     build()
-    text = ["// GENERATED by tools/gen_walk4_fast.py%s — do not edit; see that file for the register map and the design." % (" wide" if WIDE else ""),
-            "#define %s_ASM \\" % MACRO]
+    text = ["// GENERATED by tools/gen_walk4_fast.py — do not edit; see that file for the register map and the design.",
+            "#define WALK4_FAST_ASM \\"]
     for l in lines:
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
     clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, CM160 + 1) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
-    text.append("#define %s_CLOBBERS " % MACRO + ", ".join(clob))
-    text.append("#define %s_VGPRS %d" % (MACRO, NV))
+    text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
+    text.append("#define WALK4_FAST_VGPRS %d" % NV)
     body = "\n".join(text) + "\n"
     if os.environ.get("WALK4_CHECK_ONLY"):
         raise SystemExit(0 if os.path.exists(OUT) and open(OUT).read() == body else 1)
