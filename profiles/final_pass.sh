@@ -39,6 +39,10 @@ timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 --res
 BEAGLE_MI355_GRADIENT_VIRTUAL=1 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_unstored_definitions.json
 for g in _1e5_rescale _1e5_unstored_definitions; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, stored', d.get('post_order_nodes_stored_per_gradient'), d['how'])" 2>&1 | tail -1; done
 BEAGLE_MI355_NO_SCALE_FOLD=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-library-route --no-side-records 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json; line gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json "A, driver command line, per-node factors (NO_SCALE_FOLD)"
+# the gradient chain at 1e5 patterns: kernel trace and the pre-order walk's SQ counters
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_${R}_grad/kt -o kt -- python $ROOT/tools/gradient_bench.py --config A --steps 4 --warmup 3 > /dev/null 2>&1)
+cp $(find gpurun_out/prof_${R}_grad/kt -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_final/${R}_gradient_1e5_kernel_stats.csv 2>/dev/null
+KERNEL=preWalk4 CMD="python $ROOT/tools/gradient_bench.py --config A --steps 2 --warmup 3" bash tools/prof_counters.sh ${R}_gradsq 2>&1 | grep -v "rc=0" > gpurun_out/profiles_final/${R}_gradient_prewalk_sq_counters.txt
 for real in benchmark1 benchmark2; do
   timeout 300 python bench.py --real $real --steps 200 --warmup 5 --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_D_$real.json; line gpurun_out/profiles_final/${R}_bench_D_$real.json "D $real"
 done
