@@ -145,6 +145,7 @@ struct Instance {
         int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
     } pendingWalk;
+    std::vector<int> snapSourceOf;                       // runPlan's scratch: matrix slot -> the slot its snapshot is being taken from in this plan (-1 between calls)
     bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back
     bool copyKeepsWalk = false;                          // (set around an upload the held walk does not read: engine_instance.cpp queueCopy)
     long statRootFused = 0;

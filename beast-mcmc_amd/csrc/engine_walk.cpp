@@ -102,6 +102,8 @@ static inline bool anyScaleWriteIn(const Instance* in, const Instance::Resolved*
 // micro-operations travel together) and enqueue the snapshot copies and the walk.
 int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t recordBeforeWalk) {
     const size_t n = plan.prog.size();
+    typedef std::chrono::steady_clock PhaseClock;                    // (BEAGLE_MI355_HOST_TIMING=2: where a call that resolves a program spends its time)
+    PhaseClock::time_point ph0 = PhaseClock::now(), ph1 = ph0, ph2 = ph0, ph3 = ph0;
     const long statsAtEntry[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
     if (n == 0) {                                  // nothing to compute (every destination became virtual): the definitions'
         if (plan.snapPairs.empty()) return 0;      // matrix snapshots still have to be taken
@@ -149,9 +151,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     const size_t matStride = (size_t)in->C * in->S * in->S;
     // matrices whose snapshot is taken by THIS plan are gathered from the snapshot's source (same values; lets the snapshot copies and
     // the gather run in one launch: kernels_walk4.hip k_gatherAndSnapshot)
-    std::unordered_map<int, int> freshSnapshot;
-    for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) freshSnapshot[plan.snapPairs[q + 1]] = plan.snapPairs[q];
-    auto gatherFrom = [&](int mat) { auto it = freshSnapshot.find(mat); return it == freshSnapshot.end() ? mat : it->second; };
+    // (a flat table over the matrix slots, entries put back behind the loop: a program on a new tree takes ~1 800 snapshots, and a hash
+    // map of them cost 200 of the 270 us this resolution took)
+    std::vector<int>& snapSrc = in->snapSourceOf;
+    if (snapSrc.size() < (size_t)in->planner.matrixSlots()) snapSrc.assign((size_t)in->planner.matrixSlots(), -1);
+    for (size_t q = 0; q + 1 < plan.snapPairs.size(); q += 2) snapSrc[(size_t)plan.snapPairs[q + 1]] = plan.snapPairs[q];
+    struct SnapReset { std::vector<int>& t; const std::vector<int>& pairs; ~SnapReset() { for (size_t q = 0; q + 1 < pairs.size(); q += 2) t[(size_t)pairs[q + 1]] = -1; } } snapReset{snapSrc, plan.snapPairs};
+    auto gatherFrom = [&](int mat) { const int s = snapSrc[(size_t)mat]; return s < 0 ? mat : s; };
     const size_t tipOff = in->walkT ? 0 : in->statePairOff;          // the T32 walk reads the plain state arrays and the RAW scale factors
     { int rc = ensureWalkDummies(in); if (rc) return rc; }
     mi355::WalkOp nop;
@@ -303,6 +309,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->statFoldedVectors = (long)slot->folds.size();
     }
     in->statMicroOps += (long)n;
+    ph1 = PhaseClock::now();
     // pack: [micro-ops (64 B each) | segments (32 B each) | dependency lists | snapshot pairs] — ONE host-to-device copy
     const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg) + ((devDeps.size() * sizeof(int) + 31) & ~(size_t)31);
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
@@ -342,6 +349,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
         dBase = in->bigStage;
     }
+    ph2 = PhaseClock::now();
     const bool fusedSnapshot = pairBytes && !in->walkT && in->fuseLaunches;          // 4 states: together with the gather below
     if (pairBytes && !fusedSnapshot)
         mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
@@ -373,6 +381,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             for (size_t i = 0; i < w.size(); i++)
                 fprintf(stderr, "[mi355]   %3zu: k1 %u k2 %u hold %u scale %u store %d\n", i, (w[i].flags >> 5) & 7, (w[i].flags >> 8) & 7, (w[i].flags >> 11) & 3,
                         (w[i].flags >> 13) & 3, (w[i].flags & mi355::WF_STORE) ? 1 : 0);
+    }
+    ph3 = PhaseClock::now();
+    if (in->hostTrace && !reuse && n >= 64) {
+        auto us = [](PhaseClock::time_point a, PhaseClock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[mi355] program of %zu micro-operations resolved: descriptors and waits %.1f us, upload %.1f us, stream + gather launch %.1f us\n", n, us(ph0, ph1), us(ph1, ph2), us(ph2, ph3));
     }
     if (recordBeforeWalk) HIP_TRY(hipEventRecord(recordBeforeWalk, live(in)));
     if (fused) {
@@ -589,7 +602,8 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
         int rc = in->planner.plan(sub, n, tuple, parts, allowVirtual, in->plan, walkChunkOps(in, n));
         if (rc) return rc;
         const bool hit = in->planner.cacheHits != hitsBefore;
-        { const double us = usSince(t1); in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
+        double usPlanThis = 0.0;
+        { const double us = usSince(t1); usPlanThis = us; in->hostPlanUs += us; if (hit) { in->hostPlanHitUs += us; in->hostHits++; } }
         t1 = Clock::now();
         // with the kernel timer on, ONE HIP-event pair brackets the walk launches of the call (the program upload and the
         // snapshot copies are outside: the events time the pruning kernel, which is what the roofline is about)
@@ -598,8 +612,9 @@ int runOperationsWalk(Instance* in, const int* ops, int count, int tuple, int gl
             launches++;
         } else { rc = runPlan(in, *in->planner.planned, in->planner.plannedTag); if (rc) return rc; }
         { const double us = usSince(t1); in->hostRunUs += us; if (hit) in->hostRunHitUs += us;
-          if (in->hostTrace) fprintf(stderr, "[mi355] call %ld (%d ops from %d, cache %s, tag %ld): run %.1f us (resolved again: %d, folds rebuilt so far %ld)\n", in->hostCalls, n, begin,
-                                     hit ? "hit" : "miss", in->planner.plannedTag, us, (int)in->lastResolveMiss, in->statFoldBuilds); }
+          if (in->hostTrace && usPlanThis + us > 40.0)
+              fprintf(stderr, "[mi355] call %ld (%d ops from %d, cache %s, tag %ld): planner %.1f us, run %.1f us (resolved again: %d, folds rebuilt so far %ld)\n", in->hostCalls, n, begin,
+                      hit ? "hit" : "miss", in->planner.plannedTag, usPlanThis, us, (int)in->lastResolveMiss, in->statFoldBuilds); }
         begin += n;
     }
     if (e1 && launches > 0) { HIP_TRY(hipEventRecord(e1, live(in))); in->pendingLaunches += launches; }

@@ -580,7 +580,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         partial = None           # (after the CPU cross-check, which reads this instance's site values of the unmoved tree)
         if world == 1 and args.route == "ranks" and not sharded and args.config in ("A", "D") and not args.no_side_records:
             try:
-                partial = partial_update_point(bm, wl, tl, raw)
+                partial = partial_update_point(bm, wl, tl, raw, handles=handles)
             except Exception as e:                                        # noqa: BLE001  (must not cost the main line)
                 partial = {"error": "%s: %s" % (type(e).__name__, e)}
         out = {
@@ -669,7 +669,7 @@ def shard_point(args, bm, wl, torch, device, res, ShardedTreeLikelihood, BeagleT
             "lnL": lnl, "lnL_equals_unsharded_instance": bool(lnl == v), "evaluations_total": int(stats_eval)}
 
 
-def partial_update_point(bm, wl, tl, raw, moves=300):
+def partial_update_point(bm, wl, tl, raw, moves=300, handles=None):
     """What a chain issues most (TreeDataLikelihood.java:247-260): ONE node height changes, the path from that node to the root
     is recomputed — its three branch matrices, then the operations up to the root —, half of the proposals are rejected
     (restoreState: index flips only).  Microseconds per move (proposal + the 50 % restore), operations and bytes moved per move."""
@@ -711,7 +711,28 @@ def partial_update_point(bm, wl, tl, raw, moves=300):
     c1 = tl.counters()
     stats = raw.walkStats()
     p_, c_, s_ = wl.pattern_count, wl.category_count, wl.state_count
+    # A chain mixes the two: after accepted moves the nodes of their paths sit in the OTHER buffer of their pair, so the next
+    # model move's full-evaluation list names a combination of buffers no earlier list had — the engine plans, resolves and uploads
+    # it from scratch (the main line's chain of full evaluations alternates between two lists and always finds its program
+    # resident).  Three accepted moves, then a model move: milliseconds per such full evaluation, beside the main line's.
+    mixed = None
+    if handles:
+        full = []
+        for i in range(40):
+            for _ in range(3):
+                node, h = propose()
+                tl.storeState(); tl.set_node_height(node, h); tl.getLogLikelihood(); height[node] = h
+            tl.storeState()
+            tl.apply_model(handles[i % 3])
+            t1 = time.perf_counter()
+            tl.getLogLikelihood()
+            full.append(time.perf_counter() - t1)
+        full.sort()
+        mixed = {"what": "a model move (every node recomputed) behind three accepted node-height moves: an operation list the engine has not seen",
+                 "ms_per_full_evaluation_median": round(1e3 * full[len(full) // 2], 4), "ms_per_full_evaluation_mean": round(1e3 * sum(full) / len(full), 4),
+                 "evaluations": len(full)}
     return {"what": "one node-height move: path to the root recomputed, 50 % of the proposals restored",
+            "full_evaluation_on_a_new_list": mixed,
             "us_per_branch_move": round(1e6 * dt / moves, 2), "moves": moves,
             "ops_per_move": round((c1["operations"] - c0["operations"]) / moves, 2),
             "matrices_per_move": round((c1["matrix_updates"] - c0["matrix_updates"]) / moves, 2),
