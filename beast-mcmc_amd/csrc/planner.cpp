@@ -71,7 +71,8 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int 
     // (tip1 / tip2: the child is a LEAF — compact states, or with mem1 / mem2 uploaded tip partials)
     VirtDef nv;
     nv.on = true; nv.stamp = stamp_; nv.nSteps = 0; nv.chainOnly = true;
-    std::vector<int> pairs;
+    std::vector<int>& pairs = pairScratch_;
+    pairs.clear();
     const int maxNeed = popcount2(allSlots_) - 1;
     const int cap = stepCap();
     // copies the steps of srcBuf's definition behind what nv holds; returns the index of its last step, -1: no room
@@ -94,7 +95,7 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int 
         return nv.nSteps - 1;
     };
     VirtStep last;
-    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.subA = -1; last.subB = -1; last.need = 0;
+    last.scaleIdx = scaleIdx; last.tipA = -1; last.tipB = -1; last.subA = -1; last.subB = -1; last.need = 0; last.memA = last.memB = false;
     if (tip1 && tip2) {
         last.type = VT_CHERRY; last.tipA = c1; last.tipB = c2; last.originA = m1; last.originB = m2; last.memA = mem1; last.memB = mem2;
     } else if (tip1 != tip2) {
@@ -542,8 +543,13 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     std::stable_sort(out.segs.begin(), out.segs.end(), [](const PlanSeg& a, const PlanSeg& b) { return a.wave < b.wave; });
     linkSlices(out);
     if (fill) {
-        fill->plan = out;
-        fill->defs.assign(count, VirtDef());
+        // (the entry TAKES the program — `out` is left with whatever the entry held — and `planned` names the entry's copy, as on
+        // a hit; the definitions of unstored destinations are copied, steps in use only, over whatever the way held before)
+        fill->plan.clear();
+        fill->plan.prog.swap(out.prog); fill->plan.segs.swap(out.segs); fill->plan.deps.swap(out.deps);
+        fill->plan.launchOrder.swap(out.launchOrder); fill->plan.snapPairs.swap(out.snapPairs);
+        planned = &fill->plan;
+        if ((int)fill->defs.size() < count) fill->defs.resize(count);
         fill->defOn.assign(count, 0);
         for (int k = 0; k < count; k++)
             if (info_[k].virtDest) { const int kk = key(info_[k].dest, info_[k].part); virt_[kk].cacheTag = fill->tag; tagOf_[kk] = fill->tag; fill->defs[k] = virt_[kk]; fill->defOn[k] = 1; }
@@ -679,7 +685,7 @@ void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
         const VirtDef& want = e.defs[k];
         VirtDef& cur = virt_[dest];
         if (cur.on) clearVirtualKey(dest);
-        if (!want.on) continue;
+        if (!e.defOn[k]) continue;                                // (defs[k] may be a leftover of an earlier list in this way)
         cur = want;                                               // (tagged with e.tag when the entry was filled)
         tagOf_[dest] = e.tag;
         cur.stamp = stamp_;

@@ -73,18 +73,19 @@ enum { VT_CHERRY = 1, VT_EXTEND = 2, VT_JOIN = 3 };
 struct VirtStep {
     int type;               // VT_CHERRY: tipA, tipB;  VT_EXTEND: subA, tipB;  VT_JOIN: subA, subB
     int tipA, tipB;         // leaf buffers (or -1): compact tip states, or (memA / memB) partials the caller uploaded for a tip
-    bool memA = false, memB = false;
+    bool memA, memB;        // (no initialisers: a definition's unused steps are never looked at, and never copied — VirtDef below)
     int subA, subB;         // earlier steps of the same definition (or -1)
     int scaleIdx;           // this node's scale buffer, or PLAN_NONE
     int originA, originB;   // matrix slots the snapshots of operand A's / B's branch were last copied FROM
     int need;               // hold slots the evaluation of this step takes
 };
+// (1.5 KB with all 32 steps; a list of 1000 operations makes, keeps and copies a thousand of them, most of one to three steps:
+// copies take the steps in use only — the planner's time on a list it has not seen: 87 -> 52 us with that, profiles/r05_experiments.txt 12)
 struct VirtDef {
     bool on = false;
     bool chainOnly = true;  // evaluates without a hold slot (need of the last step == 0)
     int nSteps = 0;
     int stamp = -1;         // planner stamp of the list that created or last re-confirmed it
-    VirtStep steps[PLAN_MAX_STEPS];
     // the op that defined it, for the steady-state path (an MCMC chain re-issues the same op on the same buffers every
     // other evaluation): a definition whose op and children are unchanged is re-confirmed, not rebuilt
     int version = 0;
@@ -92,7 +93,21 @@ struct VirtDef {
     bool sigTip1 = false, sigTip2 = false, sigMem1 = false, sigMem2 = false, fresh1 = false, fresh2 = false;   // sigTip: the child is a leaf
     int childVer1 = -1, childVer2 = -1;
     long cacheTag = 0;      // plan-cache entry that last wrote or confirmed this definition (0: none) — see WalkPlanner::replay
+    VirtStep steps[PLAN_MAX_STEPS];      // (copies take steps[0 .. nSteps) only)
+    VirtDef() {}
+    VirtDef(const VirtDef& o) { copyFrom(o); }
+    VirtDef& operator=(const VirtDef& o) { if (this != &o) copyFrom(o); return *this; }
+private:
+    void copyFrom(const VirtDef& o);
 };
+
+inline void VirtDef::copyFrom(const VirtDef& o) {
+    on = o.on; chainOnly = o.chainOnly; nSteps = o.nSteps; stamp = o.stamp; version = o.version;
+    sigC1 = o.sigC1; sigM1 = o.sigM1; sigC2 = o.sigC2; sigM2 = o.sigM2; sigScale = o.sigScale;
+    sigTip1 = o.sigTip1; sigTip2 = o.sigTip2; sigMem1 = o.sigMem1; sigMem2 = o.sigMem2; fresh1 = o.fresh1; fresh2 = o.fresh2;
+    childVer1 = o.childVer1; childVer2 = o.childVer2; cacheTag = o.cacheTag;
+    for (int s = 0; s < o.nSteps; s++) steps[s] = o.steps[s];
+}
 
 class WalkPlanner {
 public:
@@ -203,6 +218,7 @@ private:
     int partialsCount_ = 0, tipCount_ = 0, matrixCount_ = 0, scaleCount_ = 0, maxSteps_ = 6, keyParts_ = 1;
     bool enabled_ = false;
     std::vector<VirtDef> virt_;
+    std::vector<int> pairScratch_;                     // buildVirtual's snapshot pairs before they are known to be wanted
     std::vector<long> tagOf_;                          // per key: -1 not virtual, 0 virtual, > 0 virtual and written by that cache entry
                                                        // (a compact mirror of on / cacheTag: replaying a plan touches 8 bytes per op)
     std::vector<std::vector<int>> tipUsers_, scaleUsers_;

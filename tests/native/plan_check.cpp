@@ -12,6 +12,7 @@
 // lists with hazards, a 5000-tip caterpillar (4999 dependency levels: the emission must not recurse on the native stack).
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -617,7 +618,50 @@ static void scenarioHazards(unsigned seed) {
     printf("  hazards: %ld lists, %ld micro-ops\n", h.lists, h.micro);
 }
 
+// `plan_check bench`: what the planner costs the host on a list it has not seen — config A's shape (1000 taxa, full evaluation, read
+// mode, the engine's settings for 1e5 patterns) with a few accepted branch moves between the lists, as a chain produces them
+// (bench.py partial_update.full_evaluation_on_a_new_list; profiles/r05_experiments.txt 12).  Microseconds per plan() call.
+static void benchPlanner() {
+    std::mt19937 rng(7);
+    const int T = 1000, N = 2 * T - 1;
+    Tree tree; tree.random(T, rng, false);
+    WalkPlanner pl;
+    pl.init(T + 2 * (T - 1), T, 2 * N, 2 * (T - 1), 24, true, 3);
+    pl.launchMachines = 1024.0 / 782.0; pl.chunkTopOps = 16;
+    for (int i = 0; i < T; i++) pl.setCompactTip(i, true);
+    Protocol pr(tree);
+    std::vector<int> lvl = tree.levelOrder();
+    Plan out;
+    { std::vector<int> ops; for (int n : lvl) pr.pFlip[n] ^= 1; pr.emit(lvl, 1, ops); pl.plan(ops.data(), (int)ops.size() / 7, 7, 1, true, out, 150); }
+    double total = 0.0; long micro = 0; const int reps = 200;
+    for (int it = 0; it < reps; it++) {
+        for (int q = 0; q < 3; q++) {                               // three accepted branch moves: their paths flip
+            const int n = rng() % (N - 1);
+            pr.mFlip[n] ^= 1;
+            std::vector<int> nodes;
+            for (int a = tree.parent[n]; a >= 0; a = tree.parent[a]) nodes.push_back(a);
+            std::reverse(nodes.begin(), nodes.end());
+            std::vector<int> path;                                  // (list order: children before parents)
+            for (int x : lvl) if (std::find(nodes.begin(), nodes.end(), x) != nodes.end()) path.push_back(x);
+            for (int x : path) pr.pFlip[x] ^= 1;
+            std::vector<int> ops2; pr.emit(path, 2, ops2);
+            pl.plan(ops2.data(), (int)ops2.size() / 7, 7, 1, true, out, 0);
+        }
+        for (int n : lvl) pr.pFlip[n] ^= 1;
+        for (int n = 0; n < N - 1; n++) pr.mFlip[n] ^= 1;
+        std::vector<int> ops; pr.emit(lvl, 2, ops);
+        const long hits = pl.cacheHits;
+        const auto t0 = std::chrono::steady_clock::now();
+        pl.plan(ops.data(), (int)ops.size() / 7, 7, 1, true, out, 150);
+        total += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (pl.cacheHits != hits) { fprintf(stderr, "bench: the list was found in the cache\n"); exit(1); }
+        micro += (long)pl.planned->prog.size();
+    }
+    printf("planner, %d-taxon full evaluation on a new list: %.1f us per plan() (%ld micro-operations each)\n", T, total / reps, micro / reps);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "bench")) { benchPlanner(); return 0; }
     const int reps = argc > 1 ? atoi(argv[1]) : 3;
     for (int r = 0; r < reps; r++) {
         for (int T : {2, 3, 5, 8, 13, 40, 150}) {
