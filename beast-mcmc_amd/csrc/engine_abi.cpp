@@ -354,11 +354,15 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseLaunches = !(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION") && atoi(getenv("BEAGLE_MI355_NO_LAUNCH_FUSION")) != 0);
     in->deferWalk = !(getenv("BEAGLE_MI355_NO_ROOT_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_FUSION")) != 0);
     in->foldScales = !(getenv("BEAGLE_MI355_NO_SCALE_FOLD") && atoi(getenv("BEAGLE_MI355_NO_SCALE_FOLD")) != 0);
-    // (opt-in: it halves the post-order partials a gradient chain keeps in HBM and moves, and costs 0-5 % of the chain's time — the
-    // pre-order walk is bound by instruction issue and a re-evaluation descriptor is half a node's worth: profiles/r05_experiments.txt 5)
-    in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient &&
-                          getenv("BEAGLE_MI355_GRADIENT_VIRTUAL") && atoi(getenv("BEAGLE_MI355_GRADIENT_VIRTUAL")) != 0;
-    if (labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS")) in->gradientVirtualSteps = std::max(1, std::min(GRADIENT_VIRT_STEPS, atoi(labEnv("BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS"))));
+    // What a gradient chain's post-order passes leave unstored for the pre-order walk to re-evaluate (BEAGLE_MI355_GRADIENT_VIRTUAL):
+    // 0 nothing; 1 (default) nodes over two compact tips — a third of a tree's nodes, evaluated INSIDE their parent's descriptor
+    // (kernels.h PW_CHERRY); 2 also such a node under one more tip (descriptors of their own, PW_POSTOP: half the nodes, but a
+    // descriptor costs a stage whatever it computes — slower than 1, for whoever needs the memory: profiles/r05_experiments.txt 5, 14)
+    {
+        const int gv = getenv("BEAGLE_MI355_GRADIENT_VIRTUAL") ? atoi(getenv("BEAGLE_MI355_GRADIENT_VIRTUAL")) : GRADIENT_VIRT_DEFAULT;
+        in->gradientVirtual = in->walk && virtualOn && in->preWalk && in->fuseGradient && gv > 0;
+        in->gradientVirtualSteps = std::max(1, std::min(GRADIENT_VIRT_STEPS, gv));
+    }
     // matrix storage: the caller's buffers, then the private snapshot slots of virtual definitions (planner.h)
     const size_t matrixSlots = matrixSlotLayout(in);
     const size_t patternSlots = in->tiled ? (size_t)in->ntile * 32 : (size_t)patternCount;

@@ -42,7 +42,8 @@ namespace eng {
 constexpr size_t RING_BYTES = 16u << 20;   // pinned host staging ring + its device mirror
 constexpr int SLAB_BUFFERS = 32;           // partials buffers per hipMalloc
 constexpr int PRE_SCRATCH = 32;            // pre-order ops per two-pass chunk on the T32 layout
-constexpr int GRADIENT_VIRT_STEPS = 2;     // longest definition a gradient chain leaves unstored (Instance::gradientVirtual)
+constexpr int GRADIENT_VIRT_STEPS = 2;     // longest definition a gradient chain can leave unstored (Instance::gradientVirtual)
+constexpr int GRADIENT_VIRT_DEFAULT = 1;   // ... and what it does leave unstored by default: nodes over two tips (engine_abi.cpp)
 
 struct Instance {
     int device = 0;

@@ -561,6 +561,11 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
         return true;
     };
     nop.flags = mi355::PW_TIP_A | mi355::PW_TIP_B;
+    // a node over two compact tips is evaluated inside its parent's descriptor (kernels.h PW_CHERRY): per such child the definition's two
+    // snapshot matrices (interleaved for the kernel by launchCherryPairs) and where its descriptor wants their address
+    std::vector<int> cherryPairs;
+    struct CherryRef { size_t desc; int which; };
+    std::vector<CherryRef> cherryRefs;
     // an unstored operand `po` (walkableDefinition) as descriptors in front of the node that reads it: its value ends up in post
     // slot `result` (the inner node of the two-step kind passes through slot 2)
     bool anyPost = false;
@@ -606,8 +611,24 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
                 const bool st = in->tipStates[po] && po < in->tipCount;
                 const int e = edgeOf[w ? nd.preB : nd.preA];
                 if (!st && isVirt(in, po)) {
-                    // not stored: re-evaluated in front of this descriptor, read from its post slot (no load but a dummy state byte)
-                    if (!walkableDefinition(in, po) || !emitPost(po, (unsigned)w)) return 1;
+                    if (!walkableDefinition(in, po)) return 1;
+                    const mi355::VirtDef& def = in->planner.definition(in->planner.key(po, 0));
+                    const unsigned cont = (op.flags >> (w ? mi355::PW_CONT_B_SHIFT : mi355::PW_CONT_A_SHIFT)) & 15u;
+                    if (def.nSteps == 1 && cont != mi355::PW_CONT_STORE) {
+                        // a node over two tips: evaluated inside this descriptor from its tips' states and its two matrices
+                        const mi355::VirtStep& s0 = def.steps[0];
+                        const double* rc = nullptr;
+                        if (!stepReciprocal(s0, rc)) return 1;
+                        const int key = in->planner.key(po, 0);
+                        cherryRefs.push_back(CherryRef{(size_t)-1, w});          // (its descriptor's index: filled in when the descriptor is pushed)
+                        cherryPairs.push_back(in->planner.snapSlot(key, 0, 0)); cherryPairs.push_back(in->planner.snapSlot(key, 0, 1));
+                        if (w) { op.flags |= mi355::PW_CHERRY_B; op.tipB = in->tipStates[s0.tipA]; op.storeB = (double*)in->tipStates[s0.tipB]; op.recipB = rc; if (e >= 0) { op.slotB = e; op.dB = e; } }
+                        else { op.flags |= mi355::PW_CHERRY_A; op.tipA = in->tipStates[s0.tipA]; op.storeA = (double*)in->tipStates[s0.tipB]; op.recipA = rc; if (e >= 0) { op.slotA = e; op.dA = e; } }
+                        if (e >= 0) { pairs[2 * (size_t)e] = w ? nd.matB : nd.matA; pairs[2 * (size_t)e + 1] = dIdx[e]; }
+                        continue;
+                    }
+                    // a longer one: re-evaluated in front of this descriptor, read from its post slot (no load but a dummy state byte)
+                    if (!emitPost(po, (unsigned)w)) return 1;
                     const double* rc = nullptr;
                     if (!reciprocalOf(po, rc)) return 1;
                     if (w) { op.flags |= mi355::PW_TIP_B | mi355::PW_SLOT_B | (1u << mi355::PW_SLOTB_SHIFT); op.recipB = rc; if (e >= 0) { op.slotB = e; op.dB = e; } }
@@ -619,14 +640,17 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
                 else { if (st) { op.tipA = in->tipStates[po]; op.flags |= mi355::PW_TIP_A; } else { op.postA = in->partials[po]; if (!reciprocalOf(po, op.recipA)) return 1; } if (e >= 0) { op.slotA = e; op.dA = e; } }
                 if (e >= 0) { pairs[2 * (size_t)e] = w ? nd.matB : nd.matA; pairs[2 * (size_t)e + 1] = dIdx[e]; }
             }
-            op.storeA = in->partials[nd.preA]; op.storeB = in->partials[nd.preB];
+            if (!(op.flags & mi355::PW_CHERRY_A)) op.storeA = in->partials[nd.preA];
+            if (!(op.flags & mi355::PW_CHERRY_B)) op.storeB = in->partials[nd.preB];
             op.matA = nd.matA; op.matB = nd.matB;
             prog.push_back(op);
+            for (size_t q = cherryRefs.size(); q-- > 0 && cherryRefs[q].desc == (size_t)-1;) cherryRefs[q].desc = prog.size() - 1;
         }
         const int emitted = (int)prog.size() - segs[sgi].progStart;
         segs[sgi].progCount = (emitted + 1) & ~1;
         for (int k = emitted; k < segs[sgi].progCount + 2; k++) prog.push_back(nop);
     }
+    for (mi355::PreWalkOp& d : prog) d.flags = (d.flags & ~(15u << mi355::PW_LOADS_SHIFT)) | (mi355::preWalkLoads(d.flags) << mi355::PW_LOADS_SHIFT);
     const size_t segBytes = ((size_t)nSegs * sizeof(mi355::PreWalkSeg) + 255) & ~(size_t)255;
     const size_t progBytes = prog.size() * sizeof(mi355::PreWalkOp);
     if (progBytes + segBytes > RING_BYTES / 2) return 1;
@@ -636,11 +660,24 @@ static int walkedGradient(Instance* in, const std::vector<int>& edgeOf, const in
         in->dPreProg = q; in->dPreProgBytes = (progBytes + segBytes) * 2;
     }
     const size_t outPad = (outBytes + 255) & ~(size_t)255, prodBytes = (size_t)(count + 1) * in->C * 16 * sizeof(double), pairBytes = pairs.size() * sizeof(int);
-    int rc = ensureEdgeScratch(in, sumBytes + outPad + prodBytes + pairBytes); if (rc) return rc;
-    double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumBytes), *dProducts = (double*)((char*)in->edgeScratch + sumBytes + outPad);
+    const size_t pairPad = (pairBytes + 255) & ~(size_t)255, nCherries = cherryPairs.size() / 2;
+    const size_t cherryBytes = nCherries * in->C * 32 * sizeof(double), cherryPairBytes = cherryPairs.size() * sizeof(int);
+    const size_t sumPad = (sumBytes + 255) & ~(size_t)255;              // (what follows the sums keeps a 256-byte alignment: 16-byte loads)
+    int rc = ensureEdgeScratch(in, sumPad + outPad + prodBytes + pairPad + cherryBytes + cherryPairBytes); if (rc) return rc;
+    double *dSums = (double*)in->edgeScratch, *dOut = (double*)((char*)in->edgeScratch + sumPad), *dProducts = (double*)((char*)in->edgeScratch + sumPad + outPad);
     int* dPairs = (int*)((char*)dProducts + prodBytes);
+    double* dCherries = (double*)((char*)dPairs + pairPad);
+    int* dCherryPairs = (int*)((char*)dCherries + cherryBytes);
     rc = upload(in, dPairs, pairs.data(), pairBytes); if (rc) return rc;
     mi355::launchEdgeProducts(live(in), in->matrices, dPairs, dProducts, in->C, count + 1);
+    if (nCherries) {
+        rc = upload(in, dCherryPairs, cherryPairs.data(), cherryPairBytes); if (rc) return rc;
+        mi355::launchCherryPairs(live(in), in->matrices, dCherryPairs, dCherries, in->C, (int)nCherries);
+        for (size_t k = 0; k < nCherries; k++) {          // (the scratch may have moved: the addresses go in now, the program is uploaded below)
+            mi355::PreWalkOp& d = prog[cherryRefs[k].desc];
+            (cherryRefs[k].which ? d.postB : d.postA) = dCherries + k * (size_t)in->C * 32;
+        }
+    }
     rc = upload(in, in->dPreProg, segs.data(), (size_t)nSegs * sizeof(mi355::PreWalkSeg)); if (rc) return rc;
     rc = upload(in, (char*)in->dPreProg + segBytes, prog.data(), progBytes); if (rc) return rc;
     if (!mi355::launchPreWalk4(live(in), (const mi355::PreWalkOp*)((char*)in->dPreProg + segBytes), (const mi355::PreWalkSeg*)in->dPreProg, nSegs,

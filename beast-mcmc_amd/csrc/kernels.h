@@ -319,6 +319,19 @@ constexpr int PW_MAX_HOLD = 13;
 // slot: PW_SLOT_A / PW_SLOT_B (+ PW_TIP_* so that nothing but a dummy state byte is loaded for it).
 constexpr unsigned PW_POSTOP = 1u << 16, PW_SLOT_A = 1u << 17, PW_SLOT_B = 1u << 18;
 constexpr int PW_SLOTA_SHIFT = 19, PW_SLOTB_SHIFT = 21, PW_DST_SHIFT = 23;      // 2 bits each
+// The shortest unstored operand — a node over two compact tips — is evaluated INSIDE the descriptor of its parent (round 5, second
+// form: a descriptor of its own costs a whole stage whatever it computes): PW_CHERRY_A / _B.  For such a child postX points at the
+// definition's two branch matrices interleaved lane by lane ({M1[l], M2[l]}, 256 bytes per category: launchCherryPairs), tipX and
+// storeX (a node over two tips never heads a segment: nothing is stored for it) at the two tips' states, recipX at the reciprocal of
+// the node's OWN scale factor; three loads (one 16-byte, two single bytes) where a stored child asks for two.
+constexpr unsigned PW_CHERRY_A = 1u << 25, PW_CHERRY_B = 1u << 26;
+// bits 28..31: the vector-memory loads the descriptor asks for (8..12: four matrices, two reciprocal factors, one / two / three per
+// child) — what the wait of the descriptor BEFORE it leaves outstanding
+constexpr int PW_LOADS_SHIFT = 28;
+inline unsigned preWalkLoads(unsigned flags) {
+    auto child = [&](unsigned tip, unsigned cherry) { return (flags & cherry) ? 3u : (flags & tip) ? 1u : 2u; };
+    return 6u + child(PW_TIP_A, PW_CHERRY_A) + child(PW_TIP_B, PW_CHERRY_B);
+}
 constexpr int PW_POST_SLOTS = 3;
 // A walk is cut into SEGMENTS that run side by side (one more grid dimension): the first one starts at the list's root and
 // stores the pre-order partials of the nodes that head the others; those run in a second launch.  progCount even, two more
@@ -331,6 +344,8 @@ int  preWalkWaves(int P, int C);
 // products: [nSlots + 1][C][16], entry e = (branch matrix of edge e) . (its differential matrix), the spare last one zeros
 // (launchEdgeProducts from pairs {matrix, differential matrix}, -1 -1 for zeros); PreWalkOp::dA / dB index it
 void launchEdgeProducts(hipStream_t stream, const double* matrices, const int* dPairs, double* products, int C, int n);
+// out[k][c][l] = { M[pairs[2 k]][c][l], M[pairs[2 k + 1]][c][l] }, l = 0..15: what a PW_CHERRY child's postX points at
+void launchCherryPairs(hipStream_t stream, const double* matrices, const int* dPairs, double* out, int C, int n);
 bool launchPreWalk4(hipStream_t stream, const PreWalkOp* dProg, const PreWalkSeg* dSegs, int nSegs, const double* listRootPre,
                     const double* matrices, const double* products, const double* catWeights, const double* patternWeights, double* sums, int P, int C,
                     int holdSlots, bool postSlots = false);

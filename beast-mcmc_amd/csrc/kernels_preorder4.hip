@@ -167,7 +167,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 #define MI355_CONST __attribute__((address_space(4)))
 
-struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb; double mA, mB, dA, dB, ra, rb; };
+struct PreFetched { v2d a0, a1, b0, b1; unsigned sa, sb, ta, tb; double mA, mB, dA, dB, ra, rb; };     // (ta, tb: the second tip of a PW_CHERRY child)
 struct PreDesc { u64 postA, postB, tipA, tipB, storeA, storeB, recipA, recipB; int matA, matB, dA, dB, slotA, slotB; unsigned flags; };
 
 __device__ __forceinline__ PreDesc loadPreDesc(const PreWalkOp MI355_CONST* p) {
@@ -181,19 +181,36 @@ __device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsign
     const u64 dA = products + (u64)(unsigned)d.dA * matBytes, dB = products + (u64)(unsigned)d.dB * matBytes;       // (k_edgeProducts: branch matrix . differential matrix, per edge)
     // a compact tip is one byte, a child with partials two 16-byte loads: what is not needed is BRANCHED around (a vector-memory
     // instruction occupies the address unit whatever it fetches, and half the children of a tree are tips)
+    // (an unstored node over two tips, PW_CHERRY: its two matrices interleaved in ONE 16-byte load per lane — into the first of the
+    // registers the partials would have filled —, its tips' states into two registers: a d16 load into half a register clears the other
+    // half on this chip)
     asm volatile(
+        "s_bitcmp1_b32 %[fl], 25\n\t"
+        "s_cbranch_scc1 .Lqa%=\n\t"
         "s_bitcmp1_b32 %[fl], 0\n\t"
         "s_cbranch_scc1 .Lpa%=\n\t"
         "global_load_dwordx4 %[a0], %[oP], %[pA]\n\t"
         "global_load_dwordx4 %[a1], %[oP], %[pA] offset:16\n\t"
         "s_branch .Lpb%=\n"
+        ".Lqa%=:\n\t"
+        "global_load_dwordx4 %[a0], %[oM2], %[pA]\n\t"
+        "global_load_ubyte %[sa], %[oT], %[tA]\n\t"
+        "global_load_ubyte %[ta], %[oT], %[uA]\n\t"
+        "s_branch .Lpb%=\n"
         ".Lpa%=:\n\t"
         "global_load_ubyte %[sa], %[oT], %[tA]\n"
         ".Lpb%=:\n\t"
+        "s_bitcmp1_b32 %[fl], 26\n\t"
+        "s_cbranch_scc1 .Lqc%=\n\t"
         "s_bitcmp1_b32 %[fl], 1\n\t"
         "s_cbranch_scc1 .Lpc%=\n\t"
         "global_load_dwordx4 %[b0], %[oP], %[pB]\n\t"
         "global_load_dwordx4 %[b1], %[oP], %[pB] offset:16\n\t"
+        "s_branch .Lpd%=\n"
+        ".Lqc%=:\n\t"
+        "global_load_dwordx4 %[b0], %[oM2], %[pB]\n\t"
+        "global_load_ubyte %[sb], %[oT], %[tB]\n\t"
+        "global_load_ubyte %[tb], %[oT], %[uB]\n\t"
         "s_branch .Lpd%=\n"
         ".Lpc%=:\n\t"
         "global_load_ubyte %[sb], %[oT], %[tB]\n"
@@ -204,30 +221,46 @@ __device__ __forceinline__ void preIssue(PreFetched& f, const PreDesc& d, unsign
         "global_load_dwordx2 %[dB], %[oM], %[sdB]\n\t"
         "global_load_dwordx2 %[ra], %[oR], %[srA]\n\t"
         "global_load_dwordx2 %[rb], %[oR], %[srB]"
-        : [a0] "+v"(f.a0), [a1] "+v"(f.a1), [b0] "+v"(f.b0), [b1] "+v"(f.b1), [sa] "+v"(f.sa), [sb] "+v"(f.sb),
+        : [a0] "+v"(f.a0), [a1] "+v"(f.a1), [b0] "+v"(f.b0), [b1] "+v"(f.b1), [sa] "+v"(f.sa), [sb] "+v"(f.sb), [ta] "+v"(f.ta), [tb] "+v"(f.tb),
           [mA] "+v"(f.mA), [mB] "+v"(f.mB), [dA] "+v"(f.dA), [dB] "+v"(f.dB), [ra] "+v"(f.ra), [rb] "+v"(f.rb)
-        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [oR] "v"(oRecip), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
+        : [fl] "s"(d.flags), [oP] "v"(oPart), [oT] "v"(oTip), [oM] "v"(oMat), [oM2] "v"(oMat * 2u), [oR] "v"(oRecip), [pA] "s"(d.postA), [pB] "s"(d.postB), [tA] "s"(d.tipA), [tB] "s"(d.tipB),
+          [uA] "s"(d.storeA), [uB] "s"(d.storeB),
           [smA] "s"(mA), [smB] "s"(mB), [sdA] "s"(dA), [sdB] "s"(dB), [srA] "s"(d.recipA), [srB] "s"(d.recipB)
         : "memory", "scc");
 }
-// the loads of `f` have landed once at most as many loads as the FOLLOWING descriptor issued (8, 9 or 10: four matrices, two
-// reciprocal factors and one or two per child) are outstanding: loads return in issue order, and stores in the queue only make the wait stricter
-__device__ __forceinline__ void preWait(PreFetched& f, unsigned nextTips) {      // nextTips: PW_TIP_* bits of the following descriptor
+// the loads of `f` have landed once at most as many loads as the FOLLOWING descriptor issued (8..12: kernels.h preWalkLoads, bits
+// 28..31 of its flags) are outstanding: loads return in issue order, and stores in the queue only make the wait stricter
+__device__ __forceinline__ void preWait(PreFetched& f, unsigned nextLoads) {
     asm volatile(
-        "s_cmp_eq_u32 %[nt], 3\n\t"
-        "s_cbranch_scc1 .Lw6%=\n\t"
-        "s_cmp_eq_u32 %[nt], 0\n\t"
+        "s_cmp_eq_u32 %[nl], 8\n\t"
         "s_cbranch_scc1 .Lw8%=\n\t"
+        "s_cmp_eq_u32 %[nl], 9\n\t"
+        "s_cbranch_scc1 .Lw9%=\n\t"
+        "s_cmp_eq_u32 %[nl], 10\n\t"
+        "s_cbranch_scc1 .Lw10%=\n\t"
+        "s_cmp_eq_u32 %[nl], 11\n\t"
+        "s_cbranch_scc1 .Lw11%=\n\t"
+        "s_cmp_eq_u32 %[nl], 12\n\t"
+        "s_cbranch_scc1 .Lw12%=\n\t"
+        "s_waitcnt vmcnt(0)\n\t"                         // (no descriptor says anything else; waiting for everything is always right)
+        "s_branch .Lwd%=\n"
+        ".Lw12%=:\n\t"
+        "s_waitcnt vmcnt(12)\n\t"
+        "s_branch .Lwd%=\n"
+        ".Lw11%=:\n\t"
+        "s_waitcnt vmcnt(11)\n\t"
+        "s_branch .Lwd%=\n"
+        ".Lw10%=:\n\t"
+        "s_waitcnt vmcnt(10)\n\t"
+        "s_branch .Lwd%=\n"
+        ".Lw9%=:\n\t"
         "s_waitcnt vmcnt(9)\n\t"
         "s_branch .Lwd%=\n"
         ".Lw8%=:\n\t"
-        "s_waitcnt vmcnt(10)\n\t"
-        "s_branch .Lwd%=\n"
-        ".Lw6%=:\n\t"
         "s_waitcnt vmcnt(8)\n"
-        ".Lwd%=: ; retires %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11"
-        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB), "+v"(f.ra), "+v"(f.rb)
-        : [nt] "s"(nextTips) : "memory", "scc");
+        ".Lwd%=: ; retires %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13"
+        : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.sa), "+v"(f.sb), "+v"(f.mA), "+v"(f.mB), "+v"(f.dA), "+v"(f.dB), "+v"(f.ra), "+v"(f.rb), "+v"(f.ta), "+v"(f.tb)
+        : [nl] "s"(nextLoads) : "memory", "scc");
 }
 // (Measured and dropped, round 5: touching the post-order partials of the descriptor TWO ahead — one byte per lane, so that the
 // real loads a stage later find them on their way — 6.72 instead of 5.98 ms per gradient at 1e5 patterns: the touches are vector-
@@ -385,7 +418,7 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
     // (the pipeline is set up behind the block above: the kernel's register count is decided where the two overlap)
     PreDesc D0 = loadPreDesc(dp), D1 = loadPreDesc(dp + 1);
     PreFetched A, B;
-    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
+    A.a0 = A.a1 = A.b0 = A.b1 = v2d{1.0, 1.0}; A.sa = A.sb = A.ta = A.tb = 4u; A.mA = A.mB = A.dA = A.dB = 0.0; A.ra = A.rb = 1.0;
     B = A;
     preIssue(A, D0, oPart, oTip, oMat, oRecip, mats, prods, matBytes);
 
@@ -403,12 +436,15 @@ __global__ __launch_bounds__(MAXT) void k_preWalk4(const PreWalkOp MI355_CONST* 
         const unsigned src = (fl >> PW_SRC_SHIFT) & 15u, contA = (fl >> PW_CONT_A_SHIFT) & 15u, contB = (fl >> PW_CONT_B_SHIFT) & 15u; \
         /* (a node taken from a hold slot follows the end of a subtree: what the registers carried is not needed any more) */ \
         if (src) { const v2d* h = holdBase + (size_t)(src - 1) * holdStride; const v2d lo = h[0], hi = h[64]; ACC = v4d{lo.x, lo.y, hi.x, hi.y}; } \
-        preWait(CUR, DNXT.flags & 3u);                                                                                    \
+        preWait(CUR, DNXT.flags >> PW_LOADS_SHIFT);                                                                       \
         const bool tipA = (fl & (PW_TIP_A | PW_SLOT_A)) == PW_TIP_A, tipB = (fl & (PW_TIP_B | PW_SLOT_B)) == PW_TIP_B;    \
         /* (an unstored operand comes out of its post slot into the registers the loads would have filled) */              \
         if (fl & PW_SLOT_A) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTA_SHIFT) & 3u) * holdStride; CUR.a0 = h[0]; CUR.a1 = h[64]; } \
         if (fl & PW_SLOT_B) { const v2d* h = postBase + (size_t)((fl >> PW_SLOTB_SHIFT) & 3u) * holdStride; CUR.b0 = h[0]; CUR.b1 = h[64]; } \
-        const v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};      \
+        v4d xa = v4d{CUR.a0.x, CUR.a0.y, CUR.a1.x, CUR.a1.y}, xb = v4d{CUR.b0.x, CUR.b0.y, CUR.b1.x, CUR.b1.y};            \
+        /* an unstored node over two tips: (M1 e_s1) * (M2 e_s2) / its own factor, from what came in its stead (kernels.h PW_CHERRY) */ \
+        if (fl & PW_CHERRY_A) xa = columnDpp(CUR.a0.x, CUR.sa, lane) * columnDpp(CUR.a0.y, CUR.ta, lane) * CUR.ra;        \
+        if (fl & PW_CHERRY_B) xb = columnDpp(CUR.b0.x, CUR.sb, lane) * columnDpp(CUR.b0.y, CUR.tb, lane) * CUR.rb;        \
         v4d ua, ub;                                                                                                       \
         if (tipA) ua = columnDpp(CUR.mA, CUR.sa, lane); else ua = matvecDpp(CUR.mA, xa);                                  \
         if (tipB) ub = columnDpp(CUR.mB, CUR.sb, lane); else ub = matvecDpp(CUR.mB, xb);                                  \
@@ -463,6 +499,15 @@ __global__ __launch_bounds__(256) void k_edgeProducts(const double* __restrict__
         v = M[0] * D[0] + M[1] * D[4] + M[2] * D[8] + M[3] * D[12];
     }
     products[t] = v;
+}
+__global__ __launch_bounds__(256) void k_cherryPairs(const double* __restrict__ matrices, const int* __restrict__ pairs, double* __restrict__ out, int C, int n) {
+    const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;          // (k, c, l, which)
+    if (t >= n * C * 32) return;
+    const int which = t & 1, l = (t >> 1) & 15, c = (t >> 5) % C, k = (t >> 5) / C;
+    out[t] = matrices[((size_t)pairs[2 * k + which] * C + c) * 16 + l];
+}
+void launchCherryPairs(hipStream_t stream, const double* matrices, const int* dPairs, double* out, int C, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_cherryPairs, dim3((n * C * 32 + 255) / 256), dim3(256), 0, stream, matrices, dPairs, out, C, n);
 }
 void launchEdgeProducts(hipStream_t stream, const double* matrices, const int* dPairs, double* products, int C, int n) {
     if (n > 0) hipLaunchKernelGGL(k_edgeProducts, dim3((n * C * 16 + 255) / 256), dim3(256), 0, stream, matrices, dPairs, products, C, n);
