@@ -36,8 +36,9 @@ timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-
 python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_bench_A_shard12500.json').read());print('  partial_update at 12 500 patterns', d.get('partial_update'))"
 timeout 300 python tools/readback_bench.py 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_readback.json; echo "readback $(cut -c1-300 gpurun_out/profiles_final/${R}_readback.json)"
 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 --rescale 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_rescale.json
-BEAGLE_MI355_GRADIENT_VIRTUAL=1 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_unstored_definitions.json
-for g in _1e5_rescale _1e5_unstored_definitions; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, stored', d.get('post_order_nodes_stored_per_gradient'), d['how'])" 2>&1 | tail -1; done
+BEAGLE_MI355_GRADIENT_VIRTUAL=2 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_unstored_definitions.json
+BEAGLE_MI355_GRADIENT_VIRTUAL=0 timeout 300 python tools/gradient_bench.py --config A --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_1e5_every_node_stored.json
+for g in _1e5_rescale _1e5_unstored_definitions _1e5_every_node_stored; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, stored', d.get('post_order_nodes_stored_per_gradient'), d['how'])" 2>&1 | tail -1; done
 BEAGLE_MI355_NO_SCALE_FOLD=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-library-route --no-side-records 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json; line gpurun_out/profiles_final/${R}_bench_A_driver_cmdline_no_fold.json "A, driver command line, per-node factors (NO_SCALE_FOLD)"
 # the gradient chain at 1e5 patterns: kernel trace and the pre-order walk's SQ counters
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_${R}_grad/kt -o kt -- python $ROOT/tools/gradient_bench.py --config A --steps 4 --warmup 3 > /dev/null 2>&1)

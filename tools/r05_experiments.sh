@@ -11,7 +11,7 @@ case $WHAT in
 grad_ab)
   for P in 100000 20000; do
     for V in off 1 2; do
-      if [ $V = off ]; then E="BEAGLE_MI355_GRADIENT_VIRTUAL=0"; else E="BEAGLE_MI355_GRADIENT_VIRTUAL=1 BEAGLE_MI355_GRADIENT_VIRTUAL_STEPS=$V"; fi
+      if [ $V = off ]; then E="BEAGLE_MI355_GRADIENT_VIRTUAL=0"; else E="BEAGLE_MI355_GRADIENT_VIRTUAL=$V"; fi
       env $E BEAGLE_MI355_ENGINE_LIB=$LAB timeout 200 python tools/gradient_bench.py --patterns $P --steps 8 > gpurun_out/r5_grad_${P}_$V.json 2> gpurun_out/r5_grad_${P}_$V.err
       python - <<PY
 import json
