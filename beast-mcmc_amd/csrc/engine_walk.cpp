@@ -315,6 +315,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
     const size_t depOff = opBytes + segs.size() * sizeof(mi355::WalkSeg);
     char* dBase = nullptr;
+    const char* stagedProg = nullptr;                             // the program as this call staged it, seen through the ring's device mapping
     if (reuse && slot->dProgValid) dBase = slot->dProg;          // a cached plan's program is already on the device, bit for bit
     else if (total <= RING_BYTES / 4) {
         const long off = stage(in, w.data(), opBytes, total);                    // reserves `total` bytes, copies the ops ...
@@ -324,6 +325,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
         { int rcq = queueCopy(in, in->dRing + off, (size_t)off, total); if (rcq) return rcq; }
         dBase = in->dRing + off;
+        if (in->kernelUploads) stagedProg = (const char*)in->hRingDev + off;
         if (slot) {                                   // keep a device copy for the next time this plan comes out of the cache
             if (slot->dProgBytes < total) {
                 if (slot->dProg) { HIP_TRY(hipStreamSynchronize(live(in))); hipFree(slot->dProg); }
@@ -365,7 +367,43 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         HIP_TRY(hipMalloc((void**)&in->matStream, want));
         in->matStreamBytes = want;
     }
-    if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    // 4 states, a program staged by this call (a partial update, a list the engine has not seen): its upload — and whatever else is
+    // queued — rides in the gather's launch, which reads the program through the ring's mapping meanwhile (kernels_walk4.hip
+    // k_gatherAndSnapshot): three launches per such evaluation instead of four.  Not when a queued copy lands in what the gather
+    // reads or writes (the matrix block, the stream), or two queued copies overlap in part: then they go first, in order (live()).
+    bool uploadsRide = !in->walkT && in->fuseLaunches && stagedProg && !in->pendingCopies.empty() && (int)in->pendingCopies.size() <= mi355::HOST_COPY_MAX;
+    if (uploadsRide) {
+        const char* m0 = (const char*)in->matrices;
+        const char* m1 = m0 + (size_t)std::max(1, in->planner.matrixSlots()) * in->C * in->S * in->S * sizeof(double);
+        const char* t0 = (const char*)in->matStream; const char* t1 = t0 + in->matStreamBytes;
+        const std::vector<Instance::PendingCopy>& pc = in->pendingCopies;
+        for (size_t a = 0; a < pc.size() && uploadsRide; a++) {
+            const char* d0 = (const char*)pc[a].dst; const char* d1 = d0 + pc[a].bytes;
+            if ((d0 < m1 && m0 < d1) || (d0 < t1 && t0 < d1)) uploadsRide = false;
+            for (size_t b = a + 1; b < pc.size() && uploadsRide; b++) {
+                const char* e0 = (const char*)pc[b].dst; const char* e1 = e0 + pc[b].bytes;
+                if (d0 < e1 && e0 < d1 && !(e0 <= d0 && d1 <= e1)) uploadsRide = false;
+            }
+        }
+    }
+    if (uploadsRide) {
+        if (in->pendingWalk.valid) { int rcw = flushWalk(in); if (rcw) return rcw; }          // (cannot be: queueCopy above launched it)
+        mi355::HostCopyList L;
+        L.n = 0;
+        unsigned blocks = 0;
+        for (const Instance::PendingCopy& pc : in->pendingCopies) {
+            mi355::HostCopyList::Entry& e = L.e[L.n++];
+            e.dst = pc.dst; e.src = in->hRingDev + pc.ringOff; e.bytes = (unsigned)pc.bytes; e.firstBlock = blocks;
+            blocks += (unsigned)((pc.bytes + 4095) / 4096);
+        }
+        for (int a = 0; a < L.n; a++)                 // (an array queued twice: the later upload wins, the covered one is dropped)
+            for (int b = a + 1; b < L.n; b++)
+                if ((const char*)L.e[b].dst <= (const char*)L.e[a].dst && (const char*)L.e[a].dst + L.e[a].bytes <= (const char*)L.e[b].dst + L.e[b].bytes) L.e[a].bytes = 0;
+        in->pendingCopies.clear();
+        mi355::launchGatherAndSnapshot(in->stream, (const mi355::WalkOp*)stagedProg, (int)w.size(), in->C, in->matStream, in->matrices,
+                                       (const int*)(stagedProg + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, &L, (int)blocks);
+    }
+    else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
     else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);

@@ -143,7 +143,10 @@ void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, 
                  int P, int C, long recipOff);
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
 // ... and the plan's matrix snapshots (src, dst index pairs) in the same launch; m1 / m2 of freshly snapshotted matrices must point at the sources
-void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems);
+// ... and queued host copies (copies / copyBlocks: kernels_walk4.hip k_gatherAndSnapshot); dProg / dSrcDst may then be the host ring's mapping
+struct HostCopyList;
+void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
+                             const HostCopyList* copies = nullptr, int copyBlocks = 0);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
 // src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
 // deps / flags / epoch / flagStride: all slices of a program in ONE launch (slice y is dispatched before y + 1): a workgroup first
@@ -176,6 +179,28 @@ void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSr
 constexpr int HOST_COPY_MAX = 12;
 struct HostCopyList { struct Entry { void* dst; const void* src; unsigned bytes, firstBlock; } e[HOST_COPY_MAX]; int n; };
 void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks);
+#ifdef __HIPCC__
+// one workgroup of 256 threads moves 4 KiB of entry k (block = its index among the list's blocks): k_hostCopies, and the kernels the
+// queued copies ride along with (k_transition4Fused, k_gatherAndSnapshot)
+__device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block) {
+    int k = 0;
+    while (k + 1 < L.n && block >= L.e[k + 1].firstBlock) k++;
+    const size_t base = (size_t)(block - L.e[k].firstBlock) * 4096;
+    if (base >= L.e[k].bytes) return;                 // (an entry superseded by a later one for the same destination: bytes = 0)
+    const char* s = (const char*)L.e[k].src + base;
+    char* d = (char*)L.e[k].dst + base;
+    const unsigned left = L.e[k].bytes - (unsigned)base, n = left < 4096u ? left : 4096u;
+    const unsigned t = threadIdx.x;
+    if ((((size_t)s | (size_t)d) & 15) == 0) {
+        if (t * 16 + 16 <= n) *reinterpret_cast<uint4*>(d + t * 16) = *reinterpret_cast<const uint4*>(s + t * 16);
+        for (unsigned i = (n & ~15u) + t; i < n; i += 256) d[i] = s[i];
+    } else if ((((size_t)s | (size_t)d) & 3) == 0) {
+        for (unsigned i = t * 4; i + 4 <= n; i += 1024) *reinterpret_cast<unsigned*>(d + i) = *reinterpret_cast<const unsigned*>(s + i);
+        for (unsigned i = (n & ~3u) + t; i < n; i += 256) d[i] = s[i];
+    } else
+        for (unsigned i = t; i < n; i += 256) d[i] = s[i];
+}
+#endif
 // dst[0..n) = src[0..n) — dst in host memory the device maps —, then *flag = seq (release, system scope): a result handed to a
 // polling host thread
 void launchPublish(hipStream_t stream, const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq);

@@ -43,7 +43,6 @@ bool grantDynamicLds(const void* kernel, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // host -> device copies of small arrays (kernels.h HostCopyList): a workgroup moves 4 KiB of one entry
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block);
 __global__ __launch_bounds__(256) void k_hostCopies(const HostCopyList L) { hostCopyBlock(L, blockIdx.x); }
 void launchHostCopies(hipStream_t stream, const HostCopyList& list, int blocks) {
     if (blocks <= 0) return;
@@ -174,24 +173,6 @@ __global__ __launch_bounds__(256) void k_transition4(double* __restrict__ matric
         }
 }
 
-__device__ __forceinline__ void hostCopyBlock(const HostCopyList& L, unsigned block) {
-    int k = 0;
-    while (k + 1 < L.n && block >= L.e[k + 1].firstBlock) k++;
-    const size_t base = (size_t)(block - L.e[k].firstBlock) * 4096;
-    if (base >= L.e[k].bytes) return;                 // (an entry superseded by a later one for the same destination: bytes = 0)
-    const char* s = (const char*)L.e[k].src + base;
-    char* d = (char*)L.e[k].dst + base;
-    const unsigned left = L.e[k].bytes - (unsigned)base, n = left < 4096u ? left : 4096u;
-    const unsigned t = threadIdx.x;
-    if ((((size_t)s | (size_t)d) & 15) == 0) {
-        if (t * 16 + 16 <= n) *reinterpret_cast<uint4*>(d + t * 16) = *reinterpret_cast<const uint4*>(s + t * 16);
-        for (unsigned i = (n & ~15u) + t; i < n; i += 256) d[i] = s[i];
-    } else if ((((size_t)s | (size_t)d) & 3) == 0) {
-        for (unsigned i = t * 4; i + 4 <= n; i += 1024) *reinterpret_cast<unsigned*>(d + i) = *reinterpret_cast<const unsigned*>(s + i);
-        for (unsigned i = (n & ~3u) + t; i < n; i += 256) d[i] = s[i];
-    } else
-        for (unsigned i = t; i < n; i += 256) d[i] = s[i];
-}
 
 __global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ matrices, const double* __restrict__ eigSrc,
                                                           const double* __restrict__ ratesSrc, const int* __restrict__ idx,

@@ -330,8 +330,12 @@ __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, 
 // The same, and in the same launch the matrix snapshots of the plan's new definitions (kernels.hip k_snapshot): the stream's
 // entries of those definitions are gathered from the snapshots' SOURCES (engine_walk.cpp runPlan points m1 / m2 there), so the
 // two halves do not depend on each other and one launch does for both.
-__global__ void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
-                                    double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
+// ... and (round 5) the uploads queued on the instance — the program itself, when it was staged by this call: `prog` and `srcDst` are
+// then read through the host ring's device mapping, the copy blocks put the program where the walk will read it; a partial update
+// or an evaluation on a list the engine has not seen is three launches instead of four.
+__global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
+                                    double* __restrict__ matrices, const int* __restrict__ srcDst, int elems, int nPairs, const HostCopyList L) {
+    if ((int)blockIdx.x >= gatherBlocks + nPairs) { hostCopyBlock(L, blockIdx.x - (unsigned)(gatherBlocks + nPairs)); return; }
     if ((int)blockIdx.x >= gatherBlocks) {
         const int k = (int)blockIdx.x - gatherBlocks;
         const double* s = matrices + (size_t)srcDst[2 * k] * elems;
@@ -345,12 +349,17 @@ __global__ void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int 
     const double MI355_GLOBAL* M = gptr(m ? prog[k].m2 : prog[k].m1) + c * 16;
     stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
 }
-void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems) {
-    if (nOps <= 0) { launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
+void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
+                             const HostCopyList* copies, int copyBlocks) {
+    HostCopyList none;
+    none.n = 0;
+    if (nPairs < 0) nPairs = 0;
+    if (!copies || copyBlocks <= 0) { copies = &none; copyBlocks = 0; }
+    if (nOps <= 0) { if (copyBlocks) launchHostCopies(stream, *copies, copyBlocks); launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
     const size_t total = (size_t)nOps * C * 40;
     const int gatherBlocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + (nPairs > 0 ? nPairs : 0))), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
-                       gatherBlocks, matrices, dSrcDst, elems);
+    hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + nPairs + copyBlocks)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
+                       gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies);
 }
 
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream) {
