@@ -503,8 +503,43 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
     if (!pw.valid) return 0;
     pw.valid = false;                                  // (before anything that could come back here through live())
     if (!in->pendingCopies.empty()) { int rc = flushUploads(in); if (rc) return rc; }
+#ifdef BEAGLE_MI355_LAB
+    // BEAGLE_MI355_WALK_TRACE=<n>: the n-th held-or-not one-launch walk of the instance with more than 20 slices is timed workgroup by workgroup
+    static const int traceAt = labEnv("BEAGLE_MI355_WALK_TRACE") ? atoi(labEnv("BEAGLE_MI355_WALK_TRACE")) : 0;
+    static int traceSeen = 0;
+    unsigned long long* dTrace = nullptr;
+    const int groupsX = (pw.range + 127) / 128;
+    if (traceAt > 0 && pw.nSegs > 20 && ++traceSeen == traceAt) {
+        HIP_TRY(hipMalloc((void**)&dTrace, (size_t)pw.nSegs * groupsX * 3 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(dTrace, 0, (size_t)pw.nSegs * groupsX * 3 * sizeof(unsigned long long), in->stream));
+        mi355::setWalkTrace(dTrace);
+    }
+#endif
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
                            pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed);
+#ifdef BEAGLE_MI355_LAB
+    if (dTrace) {
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        std::vector<unsigned long long> t((size_t)pw.nSegs * groupsX * 3);
+        HIP_TRY(hipMemcpy(t.data(), dTrace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        mi355::setWalkTrace(nullptr);
+        hipFree(dTrace);
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < t.size(); i += 3) if (t[i] && t[i] < t0) t0 = t[i];
+        fprintf(stderr, "[mi355] walk trace, %d slices x %d groups (us from the first workgroup's entry: entry min..max | wait over min..max | end min..max):\n", pw.nSegs, groupsX);
+        for (int s = 0; s < pw.nSegs; s++) {
+            double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {0, 0, 0};
+            for (int g = 0; g < groupsX; g++)
+                for (int k = 0; k < 3; k++) {
+                    const unsigned long long v = t[((size_t)s * groupsX + g) * 3 + k];
+                    if (!v) continue;
+                    const double us = (double)(v - t0) / 100.0;
+                    lo[k] = std::min(lo[k], us); hi[k] = std::max(hi[k], us);
+                }
+            fprintf(stderr, "[mi355]   slice %2d: %6.1f..%6.1f | %6.1f..%6.1f | %6.1f..%6.1f\n", s, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
+        }
+    }
+#endif
     if (root) in->statRootFused++;
     HIP_TRY(hipGetLastError());
     return 0;

@@ -163,6 +163,9 @@ struct RootFused {
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
                      const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr);
+#ifdef BEAGLE_MI355_LAB
+void setWalkTrace(unsigned long long* devicePointer);          // (kernels_walk4.hip g_walkTrace; nullptr: off)
+#endif
 // 4-state walk instances: the root integration as a launch of its own, bit-compatible with the walk's root epilogue (root_site4.h)
 void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                                const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,

@@ -387,6 +387,12 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 // fence at agent scope costs) made the launch five times slower instead of faster.
 // the lane's index without a register that has to survive the assembly block (which leaves the compiler two VGPRs)
 __device__ __forceinline__ int walkLane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#ifdef BEAGLE_MI355_LAB
+// LAB builds, BEAGLE_MI355_WALK_TRACE=1: every workgroup's wall-clock ticks (100 MHz) at entry, behind its dependency wait and at
+// its end, [slice][group][3] — where a small shard's launch spends its time (profiles/r05_experiments.txt 17)
+__device__ unsigned long long* g_walkTrace = nullptr;
+void setWalkTrace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walkTrace), &p, sizeof(p)); }
+#endif
 template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
@@ -399,6 +405,10 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     const int p0 = pStart + (int)blockIdx.x * 128;
     if (p0 >= pEnd || sg.progCount <= 0) return;      // (no workgroup waits for this one: its dependants leave the same way)
     const unsigned c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef BEAGLE_MI355_LAB
+    unsigned long long* trace = g_walkTrace ? g_walkTrace + ((size_t)y * gridDim.x + blockIdx.x) * 3 : nullptr;
+    if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
+#endif
     volatile int* word = reinterpret_cast<volatile int*>(lds);          // (LDS is free between programs)
     // Forward progress does not rest on the order in which the hardware dispatches workgroups.  A workgroup polls the flags of the
     // slices it reads from for at most `spinLimit` ticks of the 100 MHz clock; past that it stops waiting and SERVES ITSELF: it walks
@@ -446,6 +456,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
             }
         }
     }
+#ifdef BEAGLE_MI355_LAB
+    if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+#endif
     const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
@@ -480,6 +493,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                 __hip_atomic_store(flags + (size_t)s * flagStride + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef BEAGLE_MI355_LAB
+    if (trace && walkLane() == 0 && c == 0) trace[2] = wall_clock64();
+#endif
     // The slice that ends at the root finishes the evaluation (engine_walk.cpp PendingWalk: the launch was held back until
     // calculateRootLogLikelihoods named this slice's last result as the root): every wave's last result sits in hold slot 0
     // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
