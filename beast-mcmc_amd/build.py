@@ -54,7 +54,7 @@ def build_engine(force=False, lab=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "beagle_mi355.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DBEAGLE_MI355_BUILD", "-Wall",
-             "-Wno-unused-result", "-Wno-unused-value", "-Wno-cuda-compat"] + (["-DBEAGLE_MI355_LAB"] if lab else [])
+             "-Wno-unused-result", "-Wno-unused-value", "-Wno-cuda-compat", "-fvisibility=hidden"] + (["-DBEAGLE_MI355_LAB"] if lab else [])
     objs, jobs = [], []
     for s in srcs:
         o = os.path.join(obj_dir, os.path.basename(s) + ".o")
@@ -64,8 +64,13 @@ def build_engine(force=False, lab=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
             list(pool.map(_run, jobs))
-    if jobs or force or _newer(out, objs):
-        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    # what the library exports is its interface and nothing else: the BEAGLE C API (beagle*, the engine's own beagleMi355*
+    # entry points included) and the 47 JNI natives of beagle.BeagleJNIWrapper — a JNI library lives in a JVM next to other
+    # natives, so planner / launcher / device-stub symbols stay local (csrc/exports.map)
+    exports = os.path.join(CSRC, "exports.map")
+    if jobs or force or _newer(out, objs + [exports]):
+        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
+             "-Wl,--version-script=" + exports, "-o", out])
     return out
 
 

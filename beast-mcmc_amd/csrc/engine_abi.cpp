@@ -99,7 +99,7 @@ int waitResult(Instance* in, unsigned long long seq) {
     if (*flag != seq) HIP_TRY(hipStreamSynchronize(live(in)));
     if (*flag != seq) return BEAGLE_ERROR_GENERAL;
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (in->asyncError) { const int rc = in->asyncError; in->asyncError = 0; return rc; }
+    { const int rc = in->asyncError.exchange(0); if (rc) return rc; }
     return 0;
 }
 
@@ -161,9 +161,7 @@ int publishAndWait(int instance, const double* dValues, int count, double* out) 
 int takeAsyncError(int instance) {
     Instance* in = lookup(instance);
     if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
-    const int rc = in->asyncError;
-    in->asyncError = 0;
-    return rc;
+    return in->asyncError.exchange(0);
 }
 }  // namespace mi355
 
@@ -272,8 +270,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         return BEAGLE_ERROR_OUT_OF_RANGE;
     // (65..255 states — the large discrete-trait state spaces of phylogeography, GeneralLikelihoodCore.java:41-50 — run the
     // likelihood path on the general kernels, which read their matrices from L2 above ~90 states instead of staging them in LDS
-    // (kernels.hip k_pruneGeneral<false>, k_transitionBig); the pre-order / gradient entry points return
-    // BEAGLE_ERROR_NO_IMPLEMENTATION there: their kernels stage S x S tiles and accumulate 64 x 64 outputs)
+    // (kernels.hip k_pruneGeneral<false>, k_transitionBig); the pre-order / gradient entry points run there too since round 5
+    // (kernels_preorder.hip k_prePartialsBig, k_edgeDifferentialsBig, k_crossProductsBig: correctness paths, as k_pruneGeneral))
     // requirement flags this engine cannot honour
     if (requirementFlags & (BEAGLE_FLAG_PRECISION_SINGLE | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CPU | BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL |
@@ -512,13 +510,19 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
         HIP_TRY(hipStreamSynchronize(live(in)));
         HIP_TRY(hipMemcpy(in->dPairPos, in->pairPos.data(), (size_t)in->P * sizeof(unsigned), hipMemcpyHostToDevice));
         in->stateSlabLeft = 0; in->scaleSlabLeft = 0;                      // new slabs: the element sizes changed
+        std::vector<mi355::RelayoutJob> jobs;                              // every tip in one pair of launches
         for (int t = 0; t < in->partialsCount; t++) {
             uint8_t* old = in->tipStates[t];
             if (!old) continue;
             in->tipStates[t] = nullptr;
             int rc = ensureStates(in, t); if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(in->tipStates[t] + in->statePairOff, in->S, in->pairLen, live(in)));
-            mi355::launchRelayoutStates(live(in), old, in->tipStates[t], in->tipStates[t] + in->statePairOff, in->dPairPos, in->P);
+            jobs.push_back({old, in->tipStates[t], in->tipStates[t] + in->statePairOff});
+        }
+        for (size_t b = 0; b < jobs.size(); b += 16384) {                  // (the job list goes through the staging ring)
+            const size_t e = std::min(jobs.size(), b + 16384);
+            void* dJobs = nullptr;
+            int rc = uploadTransient(in, jobs.data() + b, (e - b) * sizeof(mi355::RelayoutJob), &dJobs); if (rc) return rc;
+            mi355::launchRelayoutStatesBatch(live(in), (const mi355::RelayoutJob*)dJobs, (int)(e - b), in->dPairPos, in->P, (int)in->pairLen, in->S);
         }
         for (int k = 0; k < (int)in->scale.size(); k++) {
             double* old = in->scale[k];

@@ -101,7 +101,7 @@ int flushUploads(Instance* in) {
     }
     pc.clear();
     if (hipGetLastError() != hipSuccess) rc = BEAGLE_ERROR_GENERAL;
-    if (rc && !in->asyncError) in->asyncError = rc;
+    if (rc) { int none = 0; in->asyncError.compare_exchange_strong(none, rc); }          // (the first error sticks)
     return rc;
 }
 

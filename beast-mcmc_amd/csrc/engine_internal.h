@@ -81,7 +81,7 @@ struct Instance {
     // since — scaleWriteEpoch — and kept by member list).  A cached full-evaluation program then reads one scale vector per STORED
     // node instead of one per node (config A: 78 + slice roots instead of 999; 0.8 of the evaluation's 2.2 GB).  The per-node
     // buffers stay what getLogScaleFactors, accumulateScaleFactors, partial updates and the gradient pass expect.  A fold whose
-    // largest product leaves [1, 1e200] is refused and its plan falls back to per-node factors.  BEAGLE_MI355_NO_SCALE_FOLD=1 at
+    // largest product leaves [1, 1e100] is refused and its plan falls back to per-node factors.  BEAGLE_MI355_NO_SCALE_FOLD=1 at
     // creation switches folding off: every node is then rounded the same way on every evaluation path (bitwise-equal partial
     // updates and full evaluations); with folding the paths agree to rounding (1e-15 relative).
     struct FoldVec { std::vector<int> members; double* recip = nullptr; long builtEpoch = -1; bool bad = false; };
@@ -126,9 +126,11 @@ struct Instance {
                                                          // definitions the pre-order walk re-evaluates from the tips itself
     // 4 states: a gradient chain's post-order passes keep definitions of up to GRADIENT_VIRT_STEPS steps (tip-tip nodes, and those
     // under one more tip — half the nodes of a coalescent tree) instead of storing every node, and k_preWalk4 re-evaluates them where
-    // it needs them (engine_preorder.cpp walkableDefinition): half the bytes of both passes and half the post-order partials resident —
-    // and no time gained (the pre-order walk is bound by instruction issue; 0-5 % lost to the extra descriptors), so it is an OPTION:
-    // BEAGLE_MI355_GRADIENT_VIRTUAL=1 at creation; default: every node stored, as in round 4.
+    // it needs them (engine_preorder.cpp walkableDefinition).  BEAGLE_MI355_GRADIENT_VIRTUAL at creation (engine_abi.cpp): 0 = every
+    // node stored, as in round 4; 1 = THE DEFAULT (GRADIENT_VIRT_DEFAULT): nodes over two tips stay unstored and are evaluated inside
+    // their parents' descriptors (a third of the bytes of both passes: 6.1 -> 5.3-5.5 ms per gradient at 1e5 patterns); 2 = also such a
+    // node under one more tip, by descriptors of their own (half the bytes, slower: a descriptor costs a stage whatever it computes).
+    // (the initialisers below are overwritten at creation)
     bool gradientVirtual = false; int gradientVirtualSteps = GRADIENT_VIRT_STEPS;
     void* edgeScratch = nullptr; size_t edgeScratchBytes = 0;    // per-64-pattern derivative sums of the edges of one call (grow-only)
     bool preWalk = true;                                 // BEAGLE_MI355_NO_PRE_WALK=1 at creation: always write the pre-order partials
@@ -193,7 +195,9 @@ struct Instance {
     // instance's stream right behind the reduction kernel, and its result reaches the host through the same mapped words as a
     // single-GPU sum (beagleMi355CommInit / beagleMi355CalculateRootLogLikelihoodsAllReduce)
     ncclComm_t comm = nullptr; int commRanks = 0;
-    int asyncError = 0;                                   // first error of a deferred operation; surfaces at the next call that observes results
+    // first error of a deferred operation; surfaces at the next call that observes results.  Atomic: the sharded handle's caller reads and
+    // clears it (sharded.cpp takeAsyncError) while the shard's own worker thread may be setting it
+    std::atomic<int> asyncError{0};
     // 4 states: every slice of a walk program in ONE launch (engine_walk.cpp runPlan): per (slice, pattern group) flag words the
     // workgroups signal and poll with the launch's epoch.  BEAGLE_MI355_NO_WALK_FUSION=1 at creation: one launch per wave of slices
     bool fuseWaves = true;

@@ -10,7 +10,11 @@ namespace eng {
 
 // ---- folded reciprocal vectors (Instance::folds) ------------------------------------------------------------------------
 constexpr int FOLD_MAX_MEMBERS = 32;        // factors per fold: a longer run of unstored nodes is folded in pieces
-constexpr double FOLD_SAFE_MAX = 1e200;     // largest product of reciprocals a fold may hold (each is >= 1)
+// largest product of reciprocals a fold may hold (each is >= 1).  An unstored intermediate travels through registers and hold slots
+// UNSCALED by the members gathered so far, i.e. as small as 1 / product of its per-node-scaled size: with 1e100 its entries stay
+// normal numbers down to 1e-208 of the node's largest entry (per-node read mode keeps them down to 1e-308); beyond, the plan falls
+// back to per-node factors (runPlan: noFoldTag)
+constexpr double FOLD_SAFE_MAX = 1e100;
 
 // forget every fold (their vectors are kept for reuse) and every resolved program that may point at one
 static void dropFolds(Instance* in, bool keepVectors) {

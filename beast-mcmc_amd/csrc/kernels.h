@@ -92,7 +92,9 @@ struct WalkOp {              // 64 bytes = one scalar-cache line; every field is
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states
     const void*    src2;     // WK_TIPS: second child's states;  WK_MEM (both children in memory): its partials
     double*        store;    // partials buffer the result is written to (WF_STORE)
-    const double*  scale;    // WS_READ: the RECIPROCAL half of the scale buffer; otherwise all-ones (the assembly loop multiplies unconditionally)
+    const double*  scale;    // WF_INV: the reciprocals this result is multiplied by — a scale buffer's reciprocal half or a folded vector
+                             // (engine_walk.cpp); otherwise a readable all-ones array (the assembly loop loads and multiplies only under WF_INV,
+                             // which also pads a fetch behind write-mode stores: runPlan)
     // (the first 48 bytes are what the assembly loop loads per micro-operation: s_load_dwordx8 at 0, s_load_dwordx4 at 32)
     unsigned       flags;    // WF_* | k1 << 5 | k2 << 8 | hold << 11 | scaleMode << 13 | waitJump << 16 (walkWaitJump)
     unsigned       pad0;
@@ -270,6 +272,9 @@ void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, 
 // walk instances, after the pattern partitions changed: pair[pos[p]] = plain[p] for a tip's states (the rest "missing"), and
 // the reciprocal half of a raw scale buffer rebuilt from its factors
 void launchRelayoutStates(hipStream_t stream, const uint8_t* oldPlain, uint8_t* newPlain, uint8_t* newPair, const unsigned* dPairPos, int P);
+// ... for a list of tips at once: newPair[0 .. pairLen) = missing, then the scatter (two launches whatever the number of tips)
+struct RelayoutJob { const uint8_t* oldPlain; uint8_t* newPlain; uint8_t* newPair; };
+void launchRelayoutStatesBatch(hipStream_t stream, const RelayoutJob* dJobs, int nJobs, const unsigned* dPairPos, int P, int pairLen, int missing);
 void launchRecipFromFactors(hipStream_t stream, const double* factors, double* recip, const unsigned* dPairPos, int P);
 void launchExportPartials(hipStream_t stream, const double* partials, const double* scale, int scaleIsRaw, double* out,
                           int P, int S, int C, bool tiled);

@@ -746,6 +746,25 @@ __global__ void k_relayoutStates(const uint8_t* oldPlain, uint8_t* newPlain, uin
 void launchRelayoutStates(hipStream_t stream, const uint8_t* oldPlain, uint8_t* newPlain, uint8_t* newPair, const unsigned* dPairPos, int P) {
     hipLaunchKernelGGL(k_relayoutStates, dim3((P + 255) / 256), dim3(256), 0, stream, oldPlain, newPlain, newPair, dPairPos, P);
 }
+// every tip of an instance in two launches (a partitioned analysis re-lays 1 610 tips at set-up: one fill and one scatter each were
+// 3 200 launches of 2 us): first the pair-interleaved arrays are filled with "missing" (their padding must read as missing), then
+// the states are scattered into them
+__global__ void k_fillStatesBatch(const RelayoutJob* jobs, int pairLen, uint8_t value) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < pairLen) jobs[blockIdx.y].newPair[q] = value;
+}
+__global__ void k_relayoutStatesBatch(const RelayoutJob* jobs, const unsigned* pos, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const RelayoutJob j = jobs[blockIdx.y];
+    const uint8_t v = j.oldPlain[p];
+    j.newPlain[p] = v; j.newPair[pos[p]] = v;
+}
+void launchRelayoutStatesBatch(hipStream_t stream, const RelayoutJob* dJobs, int nJobs, const unsigned* dPairPos, int P, int pairLen, int missing) {
+    if (nJobs <= 0) return;
+    hipLaunchKernelGGL(k_fillStatesBatch, dim3((pairLen + 255) / 256, nJobs), dim3(256), 0, stream, dJobs, pairLen, (uint8_t)missing);
+    hipLaunchKernelGGL(k_relayoutStatesBatch, dim3((P + 255) / 256, nJobs), dim3(256), 0, stream, dJobs, dPairPos, P);
+}
 __global__ void k_recipFromFactors(const double* f, double* recip, const unsigned* pos, int P) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < P) recip[pos[p]] = 1.0 / f[p];

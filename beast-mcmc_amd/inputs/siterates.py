@@ -2,10 +2,11 @@
 
 Mirror of src/dr/evomodel/siteratemodel/GammaSiteRateModel.java:233-268 (``calculateCategoryRates``) and :445-472
 (``setEqualRates`` / ``normalize``): equal-probability discretisation at the class medians.  The gamma quantile is a
-parameter: ``quantile="beast"`` (the DEFAULT) is the reference's own AS 91 / AS 32 approximation — what its golden values were
-computed with, and what a BEAST run hands the engine; the transliteration lives with the test harness
-(tests/reference_quantile_impl.py), not in this package, and is loaded from there —, ``quantile="exact"`` the exact inverse CDF
-(scipy, imported only when asked for), or any callable ``(y, shape, scale) -> x``.
+parameter: ``quantile="exact"`` (the DEFAULT) is the exact inverse CDF (scipy, imported when first used); any callable
+``(y, shape, scale) -> x`` can be passed instead.  The reference itself uses an AS 91 / AS 32 approximation that is within
+~1e-6 of the exact quantile (GammaDistribution.java:530-604); its transliteration is test harness
+(tests/reference_quantile_impl.py) and is handed in explicitly — ``quantile=reference_quantile.gamma_quantile`` — by the tests
+that reproduce the reference's golden values to their last digit.  This package does not depend on the test tree.
 """
 
 
@@ -14,34 +15,12 @@ def exact_gamma_quantile(y, shape, scale):
     return float(gamma.ppf(y, shape, scale=scale))
 
 
-_harness = None
-
-
-def _harness_quantile():
-    """tests/reference_quantile_impl.py of the repository this package sits in, loaded by path (the harness is not a package)."""
-    global _harness
-    if _harness is None:
-        import importlib.util
-        import os
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "reference_quantile_impl.py")
-        if not os.path.exists(path):
-            raise ImportError("quantile='beast' needs the harness file %s (the reference's AS 91 / AS 32 approximation); "
-                              "pass quantile='exact' or a callable instead" % path)
-        spec = importlib.util.spec_from_file_location("reference_quantile_impl", path)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        _harness = mod.gamma_quantile
-    return _harness
-
-
 def resolve_quantile(quantile):
-    if quantile is None or quantile == "beast":
-        return _harness_quantile()
-    if quantile == "exact":
+    if quantile is None or quantile == "exact":
         return exact_gamma_quantile
     if callable(quantile):
         return quantile
-    raise ValueError("quantile must be 'beast', 'exact' or a callable, not %r" % (quantile,))
+    raise ValueError("quantile must be 'exact' or a callable (y, shape, scale) -> x, not %r" % (quantile,))
 
 
 class GammaSiteRateModel:

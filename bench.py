@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-side-records", action="store_true", help="no shard_point / partial_update sub-records (the rocprofv3 re-runs pass this)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run under rocprofv3 for roofline.traffic (the re-runs themselves pass this)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time limit of the CPU baseline's multi-thread loop (the one-core loop gets 0.8 of it)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="do not append the other BASELINE configs (B, C, D on the reference's benchmark1 alignment, E) to the default line")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU check of the N-rank bring-up only (gloo, no engine, no GPU): tests/test_host_and_abi.py")
     args = ap.parse_args()
@@ -228,6 +231,12 @@ def main():
             out["shard_point"] = shard_point(args, bm, wl, torch, device, res, ShardedTreeLikelihood, BeagleTreeLikelihood, RESCALE_DYNAMIC)
         except Exception as e:                                        # noqa: BLE001
             out["shard_point"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if (rank == 0 and out is not None and world == 1 and args.route == "ranks" and args.config == "A" and args.scale == 1.0
+            and not args.patterns and not args.no_side_records and not args.no_other_configs):
+        try:
+            out["other_configs"] = other_configs(args)
+        except Exception as e:                                        # noqa: BLE001
+            out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ONE JSON line, and it is the LAST thing on stdout: libraries that print through C stdio (RCCL's version banner on the
     # multi-GPU path) are flushed first, so nothing of theirs can follow the line when the process exits
     import ctypes
@@ -239,6 +248,48 @@ def main():
     if rank == 0 and out is not None:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     return out
+
+
+def other_configs(args, budget_s=420.0):
+    """BASELINE.json's other configurations on the same box, in the same run as the headline: B (20 states), C (61 states), D on
+    the reference's own examples/Benchmarks/benchmark1.xml alignment (tests/golden fixture) and E (partitioned), each as a child
+    `bench.py --config X` of >= 50 timed steps with its own kernel timer, in-run rocprofv3 traffic passes and CPU baseline (a
+    shorter one: --cpu-seconds 4), cut down to the figures a reader compares.  A child that fails or overruns costs only its own
+    entry; the whole record stops starting children once `budget_s` is spent."""
+    import subprocess
+    runs = [("B", []), ("C", []), ("D", ["--real", "benchmark1"]), ("E", [])]
+    rec, t_start = {}, time.time()
+    for name, extra in runs:
+        left = budget_s - (time.time() - t_start)
+        if left < 30.0:
+            rec[name] = {"error": "not started: the record's time budget (%.0f s) was spent" % budget_s}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "50", "--warmup", "5", "--no-library-route",
+               "--no-side-records", "--no-other-configs", "--cpu-seconds", "4", "--cache", args.cache] + extra
+        t0 = time.time()
+        try:
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 180.0))
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode != 0 or not lines:
+                rec[name] = {"error": "rc %d: %s" % (cp.returncode, (cp.stderr or "")[-300:])}
+                continue
+            d = json.loads(lines[-1])
+        except subprocess.TimeoutExpired:
+            rec[name] = {"error": "timed out"}
+            continue
+        rf, cb = d.get("roofline") or {}, d.get("cpu_baseline") or {}
+        rec[name] = {
+            "workload": (d.get("config") or {}).get("workload"), "data": d.get("data"),
+            "value": d.get("value"), "unit": d.get("unit"), "steps": d.get("steps"), "ms_per_step": d.get("ms_per_step"),
+            "ms_per_step_median": d.get("ms_per_step_median"), "lnL": d.get("lnL"),
+            "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                "bytes_per_eval", "kernel_us_per_eval", "launches_per_eval", "fp64_TFLOPs")},
+            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "gpu_vs_cpu_site_lnL_max_rel_err", "gpu_vs_cpu_partition_lnL_max_rel_err") if k in cb},
+            "kernel_source_hash": d.get("kernel_source_hash"), "wall_s": round(time.time() - t0, 1),
+        }
+    rec["what"] = ("child runs of this bench.py in the same invocation (--steps 50 --warmup 5, CPU baseline limited to 4 s); "
+                   "D = the reference's benchmark1 alignment, 593 unique patterns")
+    return rec
 
 
 def launch_ranks(n):
@@ -570,13 +621,15 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
         roofline["fp64_TFLOPs"] = round(tflops, 2)
         roofline["fp64_frac_of_78.6"] = round(tflops / 78.6, 4)
         if tflops / 78.6 > achieved / HBM_PEAK_GBS:            # the compute roof is the nearer one (codon models)
-            roofline.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s",
+            # (which pipe: the 4-state walk is DPP v_fmac_f64 on the vector ALU — no matrix-core instruction in it; 16..64 states
+            # run v_mfma_f64_4x4x4.  Both pipes have the same fp64 peak on this chip.)
+            roofline.update({"bound": "fp64-valu" if s_ == 4 else "mfma", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s",
                              "frac": round(tflops / 78.6, 4), "hbm_GBs": round(achieved, 1)})
         collective_name = ("ncclAllReduce inside the engine, on its stream (RCCL over xGMI; torch.distributed only carried the communicator id)"
                            if sharded and getattr(tl, "collective", "") == "engine" else "torch.distributed over RCCL")
         cpu = None
         if n_gpus == 1 and args.route == "ranks" and not args.no_cpu_baseline:
-            cpu = cpu_baseline(bm, wl, args.cpu_sample, tl)
+            cpu = cpu_baseline(bm, wl, args.cpu_sample, tl, seconds=args.cpu_seconds)
         partial = None           # (after the CPU cross-check, which reads this instance's site values of the unmoved tree)
         if world == 1 and args.route == "ranks" and not sharded and args.config in ("A", "D") and not args.no_side_records:
             try:
@@ -843,7 +896,11 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline_partitioned(bm, pw)
+            cpu = cpu_baseline_partitioned(bm, pw, seconds=args.cpu_seconds)
+            # ... and its per-partition values beside this instance's for the same (unperturbed) branch rates
+            tl.set_branch_rates(rates0)
+            gpu_parts, _ = tl.calculate()
+            cpu["gpu_vs_cpu_partition_lnL_max_rel_err"] = float(max(abs(a - b) / abs(b) for a, b in zip(gpu_parts, cpu.pop("partition_lnL"))))
         prof, prof_note = traffic_for(args, "k_walk4", world, rank)
         partial = None
         if world == 1 and not args.no_side_records:
@@ -921,7 +978,7 @@ def _host_cpu_info():
     return info
 
 
-def cpu_baseline(bm, wl, sample, gpu_tl):
+def cpu_baseline(bm, wl, sample, gpu_tl, seconds=10.0):
     """The CPU oracle (oracle/beagle_cpu_oracle.c — a plain-C restatement, NOT beagle-lib) timed on this box's
     host cores on a bounded sample of the same workload: the full tree, `sample` of the P patterns (patterns
     are independent, so cost is linear in P).  Reported scaled to the full pattern count.  Also cross-checks the
@@ -951,7 +1008,7 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
         o.getLogLikelihood()
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 200:
+        if dt > seconds or reps >= 200:
             break
     site_cpu = o.getSiteLogLikelihoods()
     g = gpu_tl.local if hasattr(gpu_tl, "local") else gpu_tl
@@ -977,7 +1034,7 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
             o1.getLogLikelihood()
             reps1 += 1
             dt1 = time.perf_counter() - t1
-            if dt1 > 8.0 or reps1 >= 50:
+            if dt1 > 0.8 * seconds or reps1 >= 50:
                 break
         o1.close()
     finally:
@@ -993,7 +1050,7 @@ def cpu_baseline(bm, wl, sample, gpu_tl):
             "gpu_vs_cpu_site_lnL_max_rel_err": rel}
 
 
-def cpu_baseline_partitioned(bm, pw):
+def cpu_baseline_partitioned(bm, pw, seconds=10.0):
     """Config E on the host: the oracle evaluates the four partitions one after the other (whole alignment: it is small)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
@@ -1001,8 +1058,7 @@ def cpu_baseline_partitioned(bm, pw):
     lib = helpers.oracle_library()
     threads = lib.lib.oracle_threads()
     tls = [BeagleTreeLikelihood(w, library=lib, rescaling=RESCALE_NONE, delay_rescaling=False) for w in pw.parts]
-    for t in tls:
-        t.getLogLikelihood()
+    part_lnl = [t.getLogLikelihood() for t in tls]
     reps, t0 = 0, time.perf_counter()
     while True:
         for t, w in zip(tls, pw.parts):
@@ -1010,11 +1066,11 @@ def cpu_baseline_partitioned(bm, pw):
             t.getLogLikelihood()
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 200:
+        if dt > seconds or reps >= 200:
             break
     for t in tls:
         t.close()
-    return {"value": round(reps / dt, 4), "unit": "evals/s", "cores": int(threads), "kind": "port",
+    return {"partition_lnL": part_lnl, "value": round(reps / dt, 4), "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": "the whole alignment (%d patterns in 4 partitions, %d taxa), %d evaluations in %.1f s on %d OpenMP threads"
                       % (pw.pattern_count, pw.tip_count, reps, dt, threads),
             "host_cpus": _host_cpu_info()}

@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the engine is built with -fvisibility=hidden: what this header declares is what libhmsbeagle-jni.so exports (with the JNI natives) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- error codes: lib/beagle.jar!beagle/BeagleErrorCode#<clinit> ------------------- */
 #define BEAGLE_SUCCESS                      0
@@ -407,6 +411,9 @@ typedef struct BeagleApi {
 
 const BeagleApi* beagleGetApiTable(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

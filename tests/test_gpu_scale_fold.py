@@ -142,7 +142,7 @@ def test_folds_follow_the_factors_through_a_chain(oracle_lib):
 
 def test_a_fold_out_of_range_falls_back_to_per_node_factors(oracle_lib):
     """Branches of ~1e-12 substitutions and random tip states: nearly every node's factor is ~1e-12, and the unstored runs of this
-    tree (buffers of 2 MiB: definitions of up to 24 nodes) would fold 17 and more of them — beyond the safe range (1e200): refused; the
+    tree (buffers of 2 MiB: definitions of up to 24 nodes) would fold 17 and more of them — beyond the safe range (1e100): refused; the
     plan is resolved again with per-node factors: the same bits as with folding switched off."""
     T, P = 96, 17000
     rng = np.random.default_rng(99)
