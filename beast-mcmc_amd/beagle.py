@@ -124,7 +124,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CommInfo", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355WalkLaunchInfo", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CommInfo", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -514,6 +514,12 @@ class Beagle:
         out = (C.c_long * 4)()
         self._check("walkHealth", self._ext("beagleMi355WalkHealth", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
         return {"self_served": int(out[0]), "spin_limit_us": int(out[1]), "folded_vectors": int(out[2]), "fold_builds": int(out[3])}
+
+    def walkLaunchInfo(self):
+        """How the one-launch walks were run (include/beagle_mi355.h beagleMi355WalkLaunchInfo)."""
+        out = (C.c_long * 4)()
+        self._check("walkLaunchInfo", self._ext("beagleMi355WalkLaunchInfo", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
+        return {"ticket_walks": int(out[0]), "flag_walks": int(out[1]), "rows": int(out[2]), "slices": int(out[3])}
 
     def gradientStats(self):
         """How the pre-order lists of this instance were run (include/beagle_mi355.h beagleMi355GradientStats)."""

@@ -383,10 +383,13 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
+    in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
     in->hostTrace = getenv("BEAGLE_MI355_HOST_TIMING") && atoi(getenv("BEAGLE_MI355_HOST_TIMING")) > 1;     // (a line per slow updatePartials call)
     if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {
-        in->planner.chunkTopOps = labEnv("BEAGLE_MI355_CHUNK_TOP") ? atoi(labEnv("BEAGLE_MI355_CHUNK_TOP")) : 16;
+        // (on tickets — the default — a slice above the first wave costs no workgroup slots and no polling, and the first wave is the whole
+        // grid: 8 above / about twice as long first-wave slices measured best at 12 500 patterns, tools/r06_ticket_sweep.sh)
+        in->planner.chunkTopOps = labEnv("BEAGLE_MI355_CHUNK_TOP") ? atoi(labEnv("BEAGLE_MI355_CHUNK_TOP")) : in->useTickets ? 8 : 16;
         // slices the chip holds side by side: 4 workgroups per CU over the pattern groups of a slice (planner.h launchMachines)
         hipDeviceProp_t prop;
         const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1548,6 +1551,17 @@ int beagleMi355WalkHealth(int instance, long* out4) {
     unsigned served = 0;
     if (in->walkSelfServed) { int rc = download(in, &served, in->walkSelfServed, sizeof(served)); if (rc) return rc; }
     out4[0] = (long)served; out4[1] = (long)(in->walkSpinLimit / 100ull); out4[2] = in->statFoldedVectors; out4[3] = in->statFoldBuilds;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355WalkLaunchInfo(int instance, long* out4) {
+    if (mi355::isShardedHandle(instance)) {             // shard 0's
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkLaunchInfo(h, out4); });
+    }
+    Instance* in = lookup(instance);
+    if (!in || !out4) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    out4[0] = in->statTicketWalks; out4[1] = in->statFlagWalks; out4[2] = in->lastLaunchRows; out4[3] = in->lastLaunchSlices;
     return BEAGLE_SUCCESS;
 }
 

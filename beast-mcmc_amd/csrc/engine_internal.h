@@ -69,6 +69,7 @@ struct Instance {
         long tag = 0, epoch = -1;
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
         int maxRange = 0, sinks = 0;                     // (sinks: slices no other slice waits for — one: the whole program leads to its last slice)
+        int leaves = 0;                                  // > 0: the device program is laid out for a launch on tickets — its first `leaves` slices wait for nothing
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
         std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)
@@ -146,6 +147,7 @@ struct Instance {
         bool valid = false;
         const mi355::WalkOp* prog = nullptr; const mi355::WalkSeg* segs = nullptr; const int* deps = nullptr;
         int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
+        int leaves = 0;                                  // > 0: launch on tickets, that many rows
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
     } pendingWalk;
     std::vector<int> snapSourceOf;                       // runPlan's scratch: matrix slot -> the slot its snapshot is being taken from in this plan (-1 between calls)
@@ -202,6 +204,12 @@ struct Instance {
     // workgroups signal and poll with the launch's epoch.  BEAGLE_MI355_NO_WALK_FUSION=1 at creation: one launch per wave of slices
     bool fuseWaves = true;
     unsigned* walkFlags = nullptr; size_t walkFlagBytes = 0; unsigned walkEpoch = 0;
+    // ... or, when the slices of a program form a forest (every stored slice root has one reader: planner.h PlanSeg::next), with no
+    // waiting at all: only the slices without dependencies get workgroups, and the workgroup that arrives last at a slice above runs it
+    // (kernels_walk4.hip "tickets"; walkTickets: per (slice, pattern group) arrival counts, zero between launches, in the same
+    // allocation behind the flags).  BEAGLE_MI355_NO_WALK_TICKETS=1 at creation: dependency flags always (A/B runs, tests)
+    bool useTickets = true; unsigned* walkTickets = nullptr;
+    long statTicketWalks = 0, statFlagWalks = 0, lastLaunchRows = 0, lastLaunchSlices = 0;      // (beagleMi355WalkLaunchInfo)
     // how long a workgroup of that launch polls before it computes what it waits for itself (kernels_walk4.hip: forward progress does
     // not rest on the dispatch order), in ticks of the device's 100 MHz wall clock: 20 ms — an evaluation of the largest alignment
     // this engine is measured on takes 0.6; BEAGLE_MI355_WALK_SPIN_US=<us> at creation (tests: 0 forces the self-serve path).

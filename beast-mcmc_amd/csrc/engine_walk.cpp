@@ -133,6 +133,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT && plan.launchOrder.size() == plan.segs.size();
     const bool asmLoop = in->fastWalk && !in->walkT;          // k_walk4_fast runs this program (otherwise k_walk4 / k_walkT32)
+    // ... on tickets when its slices form a forest: the slices without dependencies first (they are the launch's grid), in launch order
+    const bool ticket = fused && in->useTickets && plan.leaves > 0;
+    std::vector<int> order;
+    if (fused) {
+        order = plan.launchOrder;
+        if (ticket) std::stable_partition(order.begin(), order.end(), [&](int s) { return plan.segs[(size_t)s].depCount == 0; });
+    }
     int maxRange = 0;
     if (reuse) {
         maxRange = slot->maxRange;
@@ -171,8 +178,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
     for (size_t oi = 0; oi < plan.segs.size(); oi++) {
         const size_t si = oi;                                   // position in the device program
-        const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)plan.launchOrder[oi] : oi];
-        posOf[fused ? (size_t)plan.launchOrder[oi] : oi] = (int)oi;
+        const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)order[oi] : oi];
+        posOf[fused ? (size_t)order[oi] : oi] = (int)oi;
         segs[si].depStart = (int)devDeps.size();
         if (fused) for (int d = ps.depStart; d < ps.depStart + ps.depCount; d++) {
             if (posOf[plan.deps[d]] < 0) return BEAGLE_ERROR_GENERAL;      // (a slice behind one that waits for it: the planner's order forbids it)
@@ -291,6 +298,11 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         segs[si].pStart = in->partStart[ps.partition]; segs[si].pEnd = in->partEnd[ps.partition]; segs[si].tStart = in->padStart[ps.partition];
         maxRange = std::max(maxRange, segs[si].pEnd - segs[si].pStart);
     }
+    for (size_t oi = 0; oi < plan.segs.size(); oi++) {          // (kernels.h WalkSeg::next: rows of THIS array)
+        const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)order[oi] : oi];
+        segs[oi].next = ticket && ps.next >= 0 ? posOf[(size_t)ps.next] : -1;
+    }
+    if (slot) slot->leaves = ticket ? plan.leaves : 0;
     if (slot) {
         slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
@@ -414,7 +426,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     if (labEnv("BEAGLE_MI355_DUMP_PLAN")) {           // development (LAB builds): the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
         for (size_t i = 0; i < segs.size(); i++) {
-            const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)plan.launchOrder[i] : i];
+            const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)order[i] : i];
             fprintf(stderr, " w%d:%d", ps.wave, segs[i].progCount);
             if (fused) fprintf(stderr, "(t%d d%d)", ps.tail, ps.depCount);
         }
@@ -440,17 +452,19 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (in->walkFlagBytes < flagBytes) {
             HIP_TRY(hipStreamSynchronize(live(in)));
             if (in->walkFlags) hipFree(in->walkFlags);
-            in->walkFlags = nullptr; in->walkFlagBytes = 0;
-            const size_t want = std::max(flagBytes + flagBytes / 2, (size_t)1 << 16);
-            HIP_TRY(hipMalloc((void**)&in->walkFlags, want));
-            HIP_TRY(hipMemsetAsync(in->walkFlags, 0, want, live(in)));
+            in->walkFlags = nullptr; in->walkFlagBytes = 0; in->walkTickets = nullptr;
+            const size_t want = (std::max(flagBytes + flagBytes / 2, (size_t)1 << 16) + 255) & ~(size_t)255;
+            HIP_TRY(hipMalloc((void**)&in->walkFlags, 2 * want));               // [flags | tickets]
+            HIP_TRY(hipMemsetAsync(in->walkFlags, 0, 2 * want, live(in)));
             in->walkFlagBytes = want;
+            in->walkTickets = (unsigned*)((char*)in->walkFlags + want);
         }
         if (++in->walkEpoch == 0u) in->walkEpoch = 1u;
         Instance::PendingWalk& pw = in->pendingWalk;
         if (pw.valid) { int rcf = flushWalk(in); if (rcf) return rcf; }            // (cannot happen: every path here went through live())
         pw.prog = (const mi355::WalkOp*)dBase; pw.segs = (const mi355::WalkSeg*)(dBase + opBytes); pw.deps = (const int*)(dBase + depOff);
         pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch;
+        pw.leaves = slot && reuse ? slot->leaves : (ticket ? plan.leaves : 0);
         in->statFastWalks++; in->statWalks++;
         // hold the launch back for the root call?  (one partition, the whole range, not inside a timer bracket)
         // ... and only a program whose slices ALL lead to one last slice: the root call's result word then says that every workgroup
@@ -467,7 +481,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (hold) {
             pw.finalStore.assign(segs.size(), -1);
             for (size_t i = 0; i < segs.size(); i++) {
-                const mi355::PlanSeg& ps = plan.segs[(size_t)plan.launchOrder[i]];
+                const mi355::PlanSeg& ps = plan.segs[(size_t)order[i]];
                 if (ps.progCount > 0) pw.finalStore[i] = plan.prog[(size_t)ps.progStart + ps.progCount - 1].storeBuf;
             }
             (void)live(in);                           // the program's copies and the gather are enqueued; only the walk itself waits
@@ -520,7 +534,8 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
     }
 #endif
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
-                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed);
+                           pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed,
+                           pw.leaves > 0 ? in->walkTickets : nullptr, pw.leaves);
 #ifdef BEAGLE_MI355_LAB
     if (dTrace) {
         HIP_TRY(hipStreamSynchronize(in->stream));
@@ -545,6 +560,8 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
     }
 #endif
     if (root) in->statRootFused++;
+    if (pw.leaves > 0) in->statTicketWalks++; else in->statFlagWalks++;
+    in->lastLaunchRows = pw.leaves > 0 ? pw.leaves : pw.nSegs; in->lastLaunchSlices = pw.nSegs;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -593,8 +610,16 @@ int walkChunkOps(const Instance* in, int opCount) {
     // short (planner.h chunkTopOps: near the root few subtrees are left side by side).  12 500 patterns, kernel us per
     // evaluation at 40 / 56 / 72 / 96 / 128 micro-operations per first-wave slice: 130 / 122 / 113 / 114 / 114 with 16 above
     // (135 / 122 / 141 / 127 / 122 with the same length above); 25 000 and more: flat (profiles/r04_experiments.txt).
+    // On tickets (round 6) the grid is the first wave alone: 12 500 patterns, kernel us at 40 / 56 / 70 / 96 / 128 / 150 per first-wave
+    // slice with 8 above: 136 / 126 / 125 / 112 / 105 / 106 (16 above: 136 / 131 / 122 / 117 / 109 / 111; flags at their best: 108).
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT;
-    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / (fused ? 1400 : 2560)));
+    // 6 250 patterns: 76 us at a divisor of 500, 80 at 765, 99 at 1 400; 25 000 and more: flat.  A partitioned instance's slices span one
+    // partition's groups each, so the same divisor means fewer workgroups: config E (4 partitions) is best where it was, 73 us at 1 400 against
+    // 91 at 765 (tools/r06_ticket_sweep2.sh, profiles/r06_experiments.txt).
+    const bool fused = in->fuseWaves && in->fastWalk && !in->walkT;
+    static const long ticketDiv = labEnv("BEAGLE_MI355_CHUNK_DIV") ? atol(labEnv("BEAGLE_MI355_CHUNK_DIV")) : 0;
+    const long div = !fused ? 2560 : !in->useTickets ? 1400 : ticketDiv > 0 ? ticketDiv : in->partitionCount > 1 ? 1400 : 765;
+    return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / div));
 }
 
 // 4 states: the operation list becomes one (or, for a list with hazards, a few) pattern-walk launches.

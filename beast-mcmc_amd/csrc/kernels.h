@@ -137,7 +137,10 @@ inline unsigned walkWaitJump(int n) { return (unsigned)(8 * n + 12) << 16; }
 // partition starts; partials and plain per-pattern arrays keep the caller's pattern numbering.
 // depStart / depCount (one fused launch of all slices, k_walk4_fast only): the slices — rows of this array — whose stored results
 // this one reads, as a range of the launch's dependency list; its workgroups wait for their flags first.
-struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, depStart, depCount, pad2; };
+// next (a launch on tickets, k_walk4_fast only): the row of the ONE slice that reads this slice's stored result, -1: none.  Only the
+// rows without dependencies get workgroups then; a workgroup that finishes row s counts itself in at tickets[next][x], and the one
+// that makes the count depCount(next) carries on with row `next` itself (planner.h PlanSeg::next).
+struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, depStart, depCount, next; };
 // one launch: every 128-pattern group of every segment walks its program; maxRange = max (pEnd - pStart).  A lane owns two
 // patterns, 64 apart; its tip states and reciprocal scale factors are stored pair-interleaved (walkPairIndex).
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
@@ -164,7 +167,10 @@ struct RootFused {
 // (kernels_walk4.hip: forward progress whatever the dispatch order); *selfServed counts the workgroups that did.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
-                     const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr);
+                     const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr,
+                     unsigned* tickets = nullptr, int nLeaves = 0);
+// (tickets != nullptr: rows 0 .. nLeaves - 1 of dSegs are the slices without dependencies — the launch's grid —, the rest follow;
+// tickets[row * flagStride + x] are zero before the launch and zero again behind it; deps / flags / epoch / spinLimit unused)
 #ifdef BEAGLE_MI355_LAB
 void setWalkTrace(unsigned long long* devicePointer);          // (kernels_walk4.hip g_walkTrace; nullptr: off)
 #endif

@@ -386,7 +386,13 @@ void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int
 // to see the flag.  A write-back / invalidate of the whole L2 per workgroup (buffer_wbl2 / buffer_inv, what a release / acquire
 // fence at agent scope costs) made the launch five times slower instead of faster.
 // the lane's index without a register that has to survive the assembly block (which leaves the compiler two VGPRs)
-__device__ __forceinline__ int walkLane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (volatile: formed where it is used, every time — as a plain expression the compiler computes it once in front of the slice loop and
+// keeps it in a vector register across the assembly block, which it can only do by spilling it)
+__device__ __forceinline__ int walkLane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 #ifdef BEAGLE_MI355_LAB
 // LAB builds, BEAGLE_MI355_WALK_TRACE=1: every workgroup's wall-clock ticks (100 MHz) at entry, behind its dependency wait and at
 // its end, [slice][group][3] — where a small shard's launch spends its time (profiles/r05_experiments.txt 17)
@@ -397,7 +403,8 @@ template <int MAXC>
 __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI355_CONST* __restrict__ prog, const WalkSeg MI355_CONST* __restrict__ segs,
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
-                                                             unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs) {
+                                                             unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs,
+                                                             unsigned* __restrict__ tickets) {
     extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[3][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
     const int y = (int)blockIdx.y;
     const WalkSeg MI355_CONST& sg = segs[y];
@@ -463,9 +470,18 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
     const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
-    for (int s = first; s <= y; s++) {
+    // TICKETS (tickets != nullptr; the engine's default whenever a program's slices form a forest, planner.h PlanSeg::next): no
+    // workgroup ever waits.  The grid holds the slices without dependencies only; a workgroup that has finished slice s (its stores
+    // acknowledged by memory: the loop ends with s_waitcnt vmcnt(0), the result stores are written through at device scope) counts
+    // itself in at tickets[next(s)][x], and the workgroup whose count completes depCount(next) carries on with that slice itself —
+    // every result it reads there was stored by a workgroup that counted in before it, and is read past the L2s (sc1 loads).  The
+    // others leave.  A slice above the first wave thus starts the moment its last operand is out — no workgroup slot spent polling, no
+    // dispatch behind a full chip, no flag hand-over — and forward progress needs no assumption at all.  The last arrival puts the
+    // counter back to zero (nobody else touches it any more in this launch), so the words are zero between launches.
+    int last = y;
+    for (int s = first; s <= y || tickets; s++) {
         const WalkSeg MI355_CONST& ss = segs[s];
-        if (s != y) {                                 // (self-serve only)
+        if (s != y && !tickets) {                     // (self-serve only)
             if (ss.pStart != pStart || ss.pEnd != pEnd || ss.progCount <= 0) continue;
             if (c == 0 && walkLane() == 0)
                 *word = __hip_atomic_load(flags + (size_t)s * flagStride + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch ? 1 : 0;
@@ -492,6 +508,30 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
             if (c == 0 && walkLane() == 0)
                 __hip_atomic_store(flags + (size_t)s * flagStride + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tickets) {
+            last = s;
+            const int nxt = ss.next;
+            if (nxt < 0) break;
+#ifdef BEAGLE_MI355_LAB
+            if (trace && walkLane() == 0 && c == 0) trace[2] = wall_clock64();
+#endif
+            __syncthreads();                          // every wave's stores are out
+            if (c == 0 && walkLane() == 0) {
+                unsigned* t = tickets + (size_t)nxt * flagStride + blockIdx.x;
+                const unsigned before = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int go = before + 1u == (unsigned)segs[nxt].depCount ? 1 : 0;
+                if (go) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *word = go;
+            }
+            __syncthreads();
+            const int go = __builtin_amdgcn_readfirstlane(*word);
+            __syncthreads();                          // (word 0 is hold-slot space: nobody writes it before everybody has read it)
+            if (!go) return;
+            s = nxt - 1;                              // (the loop's increment makes it nxt)
+#ifdef BEAGLE_MI355_LAB
+            if (g_walkTrace) { trace = g_walkTrace + ((size_t)nxt * gridDim.x + blockIdx.x) * 3; if (threadIdx.x == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; } }
+#endif
+        }
     }
 #ifdef BEAGLE_MI355_LAB
     if (trace && walkLane() == 0 && c == 0) trace[2] = wall_clock64();
@@ -501,7 +541,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
     // categories up in order, takes the logarithm and folds the group's 128 site values; the last group adds the groups' sums.
     // Same functions, same order, same bits as the launch of its own (kernels.hip k_rootSite4W).
-    if (rootArgs.rootSeg == y) {
+    if (rootArgs.rootSeg == last) {
         const int lane = walkLane();
         const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
         const double sa = rootDot4(rootArgs.freqs, h[0], h[1], h[128], h[129]);
@@ -525,8 +565,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root,
-                     unsigned long long spinLimit, unsigned* selfServed) {
+                     unsigned long long spinLimit, unsigned* selfServed, unsigned* tickets, int nLeaves) {
     if (nSegs <= 0 || maxRange <= 0) return;
+    if (tickets) { if (nLeaves <= 0) return; nSegs = nLeaves; flags = nullptr; }          // (the grid: the slices that wait for nothing)
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
@@ -546,11 +587,11 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     ra.rootSeg = -1;
     if (root) ra = *root;
     if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

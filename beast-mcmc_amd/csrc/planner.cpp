@@ -547,7 +547,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         // a hit; the definitions of unstored destinations are copied, steps in use only, over whatever the way held before)
         fill->plan.clear();
         fill->plan.prog.swap(out.prog); fill->plan.segs.swap(out.segs); fill->plan.deps.swap(out.deps);
-        fill->plan.launchOrder.swap(out.launchOrder); fill->plan.snapPairs.swap(out.snapPairs);
+        fill->plan.launchOrder.swap(out.launchOrder); fill->plan.snapPairs.swap(out.snapPairs); fill->plan.leaves = out.leaves;
         planned = &fill->plan;
         if ((int)fill->defs.size() < count) fill->defs.resize(count);
         fill->defOn.assign(count, 0);
@@ -591,6 +591,20 @@ void WalkPlanner::linkSlices(Plan& out) {
         for (int k = sg.progStart; k < sg.progStart + sg.progCount; k++) { reads(out.prog[k].k1, out.prog[k].a1); reads(out.prog[k].k2, out.prog[k].a2); }
         sg.depCount = (int)out.deps.size() - sg.depStart;
         sg.tail = 0;
+    }
+    // tickets (planner.h PlanSeg::next): does every slice have at most one dependant?
+    {
+        std::vector<int> dependants(n, 0);
+        for (int s = 0; s < n; s++) out.segs[s].next = -1;
+        for (int s = 0; s < n; s++)
+            for (int d = out.segs[s].depStart; d < out.segs[s].depStart + out.segs[s].depCount; d++) { dependants[out.deps[d]]++; out.segs[out.deps[d]].next = s; }
+        bool forest = n > 0;
+        int leaves = 0;
+        for (int s = 0; s < n; s++) {
+            if (dependants[s] > 1 || out.segs[s].progCount <= 0) forest = false;
+            if (out.segs[s].depCount == 0) leaves++;
+        }
+        out.leaves = forest ? leaves : 0;
     }
     // tail: own length + the longest tail among the slices that wait for this one.  Slices are sorted by wave and read only
     // earlier waves, so one backward sweep settles every slice before the ones it reads.

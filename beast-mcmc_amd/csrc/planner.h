@@ -43,7 +43,12 @@ struct MicroOp {
 // waits for it — the critical path behind it.  A single launch may run ALL slices side by side when every workgroup first
 // waits for the slices in its dependency list (same pattern group) and the slices are dispatched by descending tail — an
 // order in which every slice comes after the ones it reads (tail(child) > tail(parent)); Plan::launchOrder is that order.
-struct PlanSeg { int progStart, progCount, partition, wave, depStart, depCount, tail; };
+// next: the ONE slice that waits for this one (-1: none — a root of the forest; meaningful when Plan::leaves > 0).  A slice's stored
+// result normally has one reader, so the slices form a forest and a launch needs no waiting at all: only the slices without
+// dependencies ("leaves") get workgroups, a workgroup that finishes slice s counts itself in at s.next for its pattern group, and
+// the one that arrives LAST there carries on with that slice itself — everything it reads was stored by workgroups that counted
+// in before it (kernels_walk4.hip: "tickets").
+struct PlanSeg { int progStart, progCount, partition, wave, depStart, depCount, tail, next; };
 
 struct Plan {
     std::vector<MicroOp> prog;
@@ -51,7 +56,9 @@ struct Plan {
     std::vector<int> deps;           // PlanSeg::depStart / depCount
     std::vector<int> launchOrder;    // permutation of segs: descending tail (critical path first), dependencies before dependants
     std::vector<int> snapPairs;      // (source matrix slot, destination snapshot slot) pairs to copy BEFORE the program runs
-    void clear() { prog.clear(); segs.clear(); deps.clear(); launchOrder.clear(); snapPairs.clear(); }
+    int leaves = 0;                  // > 0: the slices form a forest (every slice has at most one dependant, none is empty) and this many of
+                                     // them wait for nothing — the program can run on tickets (PlanSeg::next); 0: dependency flags only
+    void clear() { prog.clear(); segs.clear(); deps.clear(); launchOrder.clear(); snapPairs.clear(); leaves = 0; }
 };
 
 // Read-mode programs: where the reciprocal scale factors are applied.  A result that is not stored is seen by nobody but the

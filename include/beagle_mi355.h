@@ -365,6 +365,11 @@ int beagleMi355WalkStats(int instance, long* out8);
  * creation, default 20 000); out[2]: folded reciprocal vectors in use by read-mode programs (one per stored node instead of one
  * per node: DESIGN.md 4.1); out[3]: how many times such vectors were (re)built from the per-node factors. */
 int beagleMi355WalkHealth(int instance, long* out4);
+/* How the one-launch walks of a 4-state instance were run since its creation: out[0] launches on TICKETS (the program's slices form
+ * a forest: only the slices without dependencies get workgroups, the workgroup that arrives last at a slice above runs it — nobody
+ * waits; the default), out[1] launches on dependency FLAGS (every slice its own workgroups, which poll: programs whose slices do not
+ * form a forest, or BEAGLE_MI355_NO_WALK_TICKETS=1), out[2] / out[3]: slices with workgroups of their own / slices in all, last launch. */
+int beagleMi355WalkLaunchInfo(int instance, long* out4);
 /* The gradient pass (4 states) since instance creation.  A pre-order list without scale indices is held back until a call needs
  * what it writes (or changes what it reads): out[0] lists that ran together with the edge derivatives that followed them (one
  * sweep per tree level; sums and sums of squares), out[1] lists that ran operation by operation, out[2] edge-derivative calls

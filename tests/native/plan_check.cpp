@@ -81,6 +81,7 @@ static void truthOp(World& w, const std::vector<char>& compact, const int* op, i
     w.partials[dest] = out;
 }
 
+static long g_ticketRuns = 0;          // programs executed on tickets (runPlan below)
 // the walk kernel's register model, index level
 // fold != nullptr: the engine's read-mode folding (planner.h FoldMap) — a micro-operation multiplies by the product of the reciprocals
 // of the scale buffers it pays for (nothing where it pays for none) instead of by its own node's
@@ -146,7 +147,7 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
             }
         }
     }
-    for (int si : plan.launchOrder) {
+    auto runSlice = [&](int si) {
         const PlanSeg& sg = plan.segs[si];
         for (int p = partStart[sg.partition]; p < partEnd[sg.partition]; p++) {
             V4 ACC[8], H[3][8];
@@ -189,7 +190,47 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
                 for (int c = 0; c < C; c++) { ACC[c] = r[c]; if (m.hold) H[m.hold - 1][c] = r[c]; }
             }
         }
+    };
+    // Two ways to run a one-launch program (kernels_walk4.hip).  FLAGS: every slice has its own workgroups, which wait for the slices
+    // they read from — any order that puts a slice behind its dependencies, here the launch order.  TICKETS (plan.leaves > 0: the
+    // slices form a forest): only the slices without dependencies start; whoever finishes slice s counts itself in at s.next and the
+    // LAST to arrive there carries on with that slice.  Every other program with a forest is run that way here, the leaves in the
+    // REVERSE of the launch order (the order must not matter), and every slice must have run exactly once at the end.
+    static unsigned long ticketToggle = 0;
+    if (plan.leaves > 0) {
+        const int n = (int)plan.segs.size();
+        int leaves = 0;
+        for (int a = 0; a < n; a++) {
+            const PlanSeg& sg = plan.segs[a];
+            CHECK(sg.progCount > 0, plan.prog[0], a);
+            if (sg.depCount == 0) leaves++;
+            for (int d = sg.depStart; d < sg.depStart + sg.depCount; d++) CHECK(plan.segs[plan.deps[d]].next == a, plan.prog[sg.progStart], a);
+            if (sg.next >= 0) {
+                bool listed = false;
+                const PlanSeg& nx = plan.segs[sg.next];
+                for (int d = nx.depStart; d < nx.depStart + nx.depCount; d++) listed = listed || plan.deps[d] == a;
+                CHECK(listed, plan.prog[sg.progStart], a);
+            }
+        }
+        CHECK(leaves == plan.leaves, plan.prog[0], leaves);
     }
+    if (plan.leaves > 0 && (ticketToggle++ & 1)) {
+        const int n = (int)plan.segs.size();
+        std::vector<int> arrived(n, 0), ran(n, 0);
+        for (int i = n - 1; i >= 0; i--) {
+            int s = plan.launchOrder[i];
+            if (plan.segs[s].depCount != 0) continue;
+            for (;;) {
+                runSlice(s); ran[s]++;
+                const int nxt = plan.segs[s].next;
+                if (nxt < 0 || ++arrived[nxt] != plan.segs[nxt].depCount) break;
+                s = nxt;
+            }
+        }
+        for (int a = 0; a < n; a++) CHECK(ran[a] == 1, plan.prog[plan.segs[a].progStart], a);
+        g_ticketRuns++;
+    } else
+        for (int si : plan.launchOrder) runSlice(si);
 }
 
 struct Harness {
@@ -680,6 +721,8 @@ int main(int argc, char** argv) {
     scenarioMcmc(3000, true, false, 10, 5, false);
     printf("read-mode folding: %ld programs, %ld factor reads became %ld (%ld members)\n", foldedPlans, unfoldedReads, foldedPays, foldedMembers);
     if (foldedPlans < 100 || foldedPays * 3 > unfoldedReads * 2) { fprintf(stderr, "read-mode folding was hardly exercised\n"); return 1; }
+    printf("programs executed on tickets (slices as a forest, leaves in reverse launch order): %ld\n", g_ticketRuns);
+    if (g_ticketRuns < 100) { fprintf(stderr, "the ticket form of the one-launch walk was hardly exercised\n"); return 1; }
     printf("plan_check: OK\n");
     return 0;
 }
