@@ -612,7 +612,6 @@ int walkChunkOps(const Instance* in, int opCount) {
     // (135 / 122 / 141 / 127 / 122 with the same length above); 25 000 and more: flat (profiles/r04_experiments.txt).
     // On tickets (round 6) the grid is the first wave alone: 12 500 patterns, kernel us at 40 / 56 / 70 / 96 / 128 / 150 per first-wave
     // slice with 8 above: 136 / 126 / 125 / 112 / 105 / 106 (16 above: 136 / 131 / 122 / 117 / 109 / 111; flags at their best: 108).
-    const bool fused = in->fuseWaves && in->fastWalk && !in->walkT;
     // 6 250 patterns: 76 us at a divisor of 500, 80 at 765, 99 at 1 400; 25 000 and more: flat.  A partitioned instance's slices span one
     // partition's groups each, so the same divisor means fewer workgroups: config E (4 partitions) is best where it was, 73 us at 1 400 against
     // 91 at 765 (tools/r06_ticket_sweep2.sh, profiles/r06_experiments.txt).
