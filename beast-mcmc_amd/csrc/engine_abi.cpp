@@ -384,6 +384,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
     in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
+    in->fuseCherries = !(getenv("BEAGLE_MI355_NO_CHERRY_FUSION") && atoi(getenv("BEAGLE_MI355_NO_CHERRY_FUSION")) != 0);
     in->hostTrace = getenv("BEAGLE_MI355_HOST_TIMING") && atoi(getenv("BEAGLE_MI355_HOST_TIMING")) > 1;     // (a line per slow updatePartials call)
     if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {
@@ -1471,7 +1472,7 @@ int beagleMi355KernelTimer(int instance, int enable, double* outMillis, long* ou
     if (outMillis) *outMillis = in->timedMs;
     if (outLaunches) *outLaunches = in->timedLaunches;
     in->timedMs = 0.0; in->timedLaunches = 0;
-    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
+    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = in->statFused = 0;
     in->timing = enable != 0;
     in->timingEvery = enable > 1 ? enable : 1; in->timingTick = 0;
     // event pairs for the calls to come are created here, not inside the region being timed
@@ -1502,7 +1503,7 @@ int beagleMi355KernelTimerRestart(int instance) {
     Instance* in = lookup(instance);
     if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     in->eventsUsed = 0; in->timedMs = 0.0; in->timedLaunches = 0; in->pendingLaunches = 0; in->timingTick = 0; in->timedCalls = 0;
-    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = 0;
+    in->statMicroOps = in->statStored = in->statMemReads = in->statTipReads = in->statScaleReads = in->statWalks = in->statScaleWrites = in->statFastWalks = in->statFused = 0;
     return BEAGLE_SUCCESS;
 }
 
@@ -1554,7 +1555,7 @@ int beagleMi355WalkHealth(int instance, long* out4) {
     return BEAGLE_SUCCESS;
 }
 
-int beagleMi355WalkLaunchInfo(int instance, long* out4) {
+int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (six values)
     if (mi355::isShardedHandle(instance)) {             // shard 0's
         bool first = true; std::mutex mu;
         return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkLaunchInfo(h, out4); });
@@ -1562,6 +1563,7 @@ int beagleMi355WalkLaunchInfo(int instance, long* out4) {
     Instance* in = lookup(instance);
     if (!in || !out4) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out4[0] = in->statTicketWalks; out4[1] = in->statFlagWalks; out4[2] = in->lastLaunchRows; out4[3] = in->lastLaunchSlices;
+    out4[4] = in->statFused; out4[5] = in->statMicroOps;
     return BEAGLE_SUCCESS;
 }
 

@@ -70,6 +70,7 @@ struct Instance {
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
         int maxRange = 0, sinks = 0;                     // (sinks: slices no other slice waits for — one: the whole program leads to its last slice)
         int leaves = 0;                                  // > 0: the device program is laid out for a launch on tickets — its first `leaves` slices wait for nothing
+        std::vector<const double*> cm; long fused = 0;   // fused cherries (kernels.h WK_CHERRY): per device micro-operation the cherry's two branch matrices (empty: none fused), their number
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
         std::vector<int> folds;                          // folded reciprocal vectors the program reads (Instance::folds)
@@ -209,6 +210,11 @@ struct Instance {
     // (kernels_walk4.hip "tickets"; walkTickets: per (slice, pattern group) arrival counts, zero between launches, in the same
     // allocation behind the flags).  BEAGLE_MI355_NO_WALK_TICKETS=1 at creation: dependency flags always (A/B runs, tests)
     bool useTickets = true; unsigned* walkTickets = nullptr;
+    // 4 states, assembly loop: a node over two compact tips that is not stored, pays no scale factors and is consumed by the very next
+    // micro-operation is not a micro-operation of the device program at all: its consumer evaluates it inside its own stage (kernels.h
+    // WK_CHERRY; engine_walk.cpp runPlan).  Same arithmetic in the same order: bitwise the unfused program.  A third of a tree's nodes.
+    // BEAGLE_MI355_NO_CHERRY_FUSION=1 at creation: every micro-operation of the plan is one of the device program (A/B runs, tests)
+    bool fuseCherries = true; long statFused = 0;
     long statTicketWalks = 0, statFlagWalks = 0, lastLaunchRows = 0, lastLaunchSlices = 0;      // (beagleMi355WalkLaunchInfo)
     // how long a workgroup of that launch polls before it computes what it waits for itself (kernels_walk4.hip: forward progress does
     // not rest on the dispatch order), in ticks of the device's 100 MHz wall clock: 20 ms — an evaluation of the largest alignment

@@ -129,6 +129,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     std::vector<mi355::WalkSeg>& segs = slot ? slot->segs : segsLocal;
     std::vector<int> depsLocal;
     std::vector<int>& devDeps = slot ? slot->deps : depsLocal;     // per device slice: the device slices it waits for (one fused launch)
+    std::vector<const double*> cmLocal;
+    std::vector<const double*>& cm = slot ? slot->cm : cmLocal;    // per device micro-operation: a fused cherry's two matrices (k_gatherMatrices)
     // 4 states, assembly loop: ALL slices in one launch, dispatched critical path first, every workgroup waiting for the slices
     // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT && plan.launchOrder.size() == plan.segs.size();
@@ -144,7 +146,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     if (reuse) {
         maxRange = slot->maxRange;
         in->statMemReads += slot->memReads; in->statTipReads += slot->tipReads; in->statScaleReads += slot->scaleReads;
-        in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored;
+        in->statScaleWrites += slot->scaleWrites; in->statStored += slot->stored; in->statFused += slot->fused;
     } else {
     const long s0[5] = {in->statMemReads, in->statTipReads, in->statScaleReads, in->statScaleWrites, in->statStored};
     if (in->folds.size() > 4096) dropFolds(in, true);           // (tree shapes come and go; the vectors are reused)
@@ -154,6 +156,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     const bool fold = slot && in->foldScales && (in->walk || in->walkT) && slot->noFoldTag != planTag &&
                       mi355::foldScaleFactors(plan, FOLD_MAX_MEMBERS, foldMap);
     std::vector<int> cur;
+    // fused cherries (kernels.h WK_CHERRY): the assembly loop only, and no program that rescales in write mode anywhere (the cherry
+    // halves of the kernel's table buffers share their LDS with the maximum buffers of write-mode rescaling)
+    bool fuseOk = asmLoop && in->fuseCherries && in->walk;
+    if (fuseOk) for (const mi355::MicroOp& q : plan.prog) if (q.smode == mi355::PS_WRITE) { fuseOk = false; break; }
+    struct FusedAt { size_t at; int matA, matB; };
+    std::vector<FusedAt> fusedAt;
+    auto paysFactors = [&](int j) { return fold ? foldMap.payStart[(size_t)j + 1] > foldMap.payStart[(size_t)j] : plan.prog[(size_t)j].smode == mi355::PS_READ; };
     w.clear();
     w.reserve(n + 6 * plan.segs.size());
     segs.assign(plan.segs.size(), mi355::WalkSeg());
@@ -187,12 +196,24 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         }
         segs[si].depCount = (int)devDeps.size() - segs[si].depStart;
         segs[si].progStart = (int)w.size();
+        int lastStore = -1, lastHold = 0, cherry = -1;    // what the micro-operation emitted last stores / parks (1 + slot); a cherry waiting to be fused into the next one
         for (int i = ps.progStart; i < ps.progStart + ps.progCount; i++) {
             mi355::MicroOp m = plan.prog[i];
+            // A cherry that is consumed at once is fused into its consumer (kernels.h WK_CHERRY): tip x tip, not stored, not parked, pays no
+            // factors; the next micro-operation of the slice takes it as its second operand (ACC), multiplies by no reciprocals itself (the
+            // descriptor's scale field carries the cherry's second tip) and would not come to sit right behind the micro-operation that
+            // stores or parks its first child (the loop requests a first child from memory or from an LDS hold slot in the MIDDLE of the
+            // stage before — in front of that stage's store and hold-slot write: with the cherry's own stage between them that was safe).
+            if (fuseOk && i + 1 < ps.progStart + ps.progCount && m.k1 == mi355::PK_TIPS && m.k2 == mi355::PK_TIPS && m.storeBuf < 0 && m.hold == 0 &&
+                !paysFactors(i) && in->tipStates[m.a1] && in->tipStates[m.a2]) {
+                const mi355::MicroOp& nx = plan.prog[(size_t)i + 1];
+                if (nx.k2 == mi355::PK_ACC && !paysFactors(i + 1) && !(nx.k1 == mi355::PK_MEM && lastStore == nx.a1) &&
+                    !(nx.k1 >= mi355::PK_H0 && lastHold == nx.k1 - mi355::PK_H0 + 1)) { cherry = i; continue; }
+            }
             // The kernels request a first child's partials one stage early — before the previous micro-operation's store
             // is issued (kernels_walk4.hip WALK_STAGE).  The planner never emits that sequence (tests/native/plan_check.cpp
             // checks every program for it); should one arrive anyway, a no-op in between restores the distance.
-            if (i > ps.progStart && m.k1 == mi355::PK_MEM && plan.prog[i - 1].storeBuf == m.a1) {
+            if ((int)w.size() > segs[si].progStart && m.k1 == mi355::PK_MEM && lastStore == m.a1) {
                 if (m.k2 == mi355::PK_ACC) { m.k2 = mi355::PK_MEM; m.a2 = m.a1; }      // the no-op overwrites ACC; the value is in memory as well
                 w.push_back(nop);
             }
@@ -234,7 +255,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 in->statStored++;
             }
             d.m1 = in->matrices + (size_t)gatherFrom(m.mat1) * matStride; d.m2 = in->matrices + (size_t)gatherFrom(m.mat2) * matStride;
-            d.flags = mi355::walkFlags(m.k1, m.k2, m.hold, smodeNow, m.storeBuf >= 0);
+            int k2 = m.k2;
+            if (cherry >= 0) {
+                const mi355::MicroOp& c = plan.prog[(size_t)cherry];
+                d.src2 = in->tipStates[c.a1] + tipOff; d.scale = (const double*)(in->tipStates[c.a2] + tipOff);
+                k2 = mi355::WK_CHERRY;
+                fusedAt.push_back(FusedAt{w.size(), gatherFrom(c.mat1), gatherFrom(c.mat2)});
+                in->statTipReads += 2;
+                cherry = -1;
+            }
+            d.flags = mi355::walkFlags(m.k1, k2, m.hold, smodeNow, m.storeBuf >= 0);
             if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
                 if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
                 if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
@@ -242,6 +272,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 if (ablate & 8) { if (m.k1 == mi355::PK_TIPS) d.src1 = in->dummyTips; if (m.k2 == mi355::PK_TIPS) d.src2 = in->dummyTips; }
             }
             w.push_back(d);
+            lastStore = m.storeBuf; lastHold = m.hold;
         }
         // (the kernels' software pipelines: the assembly loop is three micro-operations deep and leaves behind any stage — any
         // length, three more readable descriptors —; the C++ kernel and the T32 walk are two deep: an even length, two more)
@@ -290,7 +321,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             // (4) | store(i - 1) | fetch(i + 2) | WAIT.  A first child of i in memory has to have landed as well: then only what
             // follows it counts.  (Loads only — the strict rule — whatever BEAGLE_MI355_STRICT_WAITS says: with two fetch sizes the
             // code space has no room for the store counts of the lax rule, which bought 1 %.)
-            auto fetchLoads = [&](int j) { return 3 + ((w[j].flags & mi355::WF_INV) ? 1 : 0); };     // (the no-ops behind a program: 3)
+            auto fetchLoads = [&](int j) { return 3 + ((w[j].flags & mi355::WF_INV) ? 1 : 0) + ((w[j].flags & mi355::WF_CHERRY2) ? 3 : 0); };     // (the no-ops behind a program: 3)
             const int x1 = i > first && (w[i - 1].flags & mi355::WF_X) ? 4 : 0;
             const int nWait = (w[i].flags & mi355::WF_X) ? fetchLoads(i + 2) : fetchLoads(i + 1) + fetchLoads(i + 2) + x1;
             w[i].flags |= mi355::walkWaitCode(nWait);
@@ -303,6 +334,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         segs[oi].next = ticket && ps.next >= 0 ? posOf[(size_t)ps.next] : -1;
     }
     if (slot) slot->leaves = ticket ? plan.leaves : 0;
+    cm.clear();
+    if (!fusedAt.empty()) {
+        cm.assign(2 * w.size(), nullptr);
+        for (const FusedAt& f : fusedAt) { cm[2 * f.at] = in->matrices + (size_t)f.matA * matStride; cm[2 * f.at + 1] = in->matrices + (size_t)f.matB * matStride; }
+    }
+    in->statFused += (long)fusedAt.size();
+    if (slot) slot->fused = (long)fusedAt.size();
     if (slot) {
         slot->tag = planTag; slot->epoch = in->resolveEpoch; slot->maxRange = maxRange;
         slot->memReads = in->statMemReads - s0[0]; slot->tipReads = in->statTipReads - s0[1]; slot->scaleReads = in->statScaleReads - s0[2];
@@ -328,7 +366,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     ph1 = PhaseClock::now();
     // pack: [micro-ops (64 B each) | segments (32 B each) | dependency lists | snapshot pairs] — ONE host-to-device copy
     const size_t opBytes = w.size() * sizeof(mi355::WalkOp), segBytes = segs.size() * sizeof(mi355::WalkSeg) + ((devDeps.size() * sizeof(int) + 31) & ~(size_t)31);
-    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), total = opBytes + segBytes + pairBytes;
+    // (... | the matrices of fused cherries, two pointers per micro-operation, where the program has any)
+    const size_t pairBytes = plan.snapPairs.size() * sizeof(int), cmOff = opBytes + segBytes + ((pairBytes + 15) & ~(size_t)15), cmBytes = cm.size() * sizeof(const double*);
+    const size_t total = cmOff + cmBytes;
+    const int entryDoubles = asmLoop ? mi355::WALK_ENTRY_FUSED : mi355::WALK_ENTRY_PLAIN;
     const size_t depOff = opBytes + segs.size() * sizeof(mi355::WalkSeg);
     char* dBase = nullptr;
     const char* stagedProg = nullptr;                             // the program as this call staged it, seen through the ring's device mapping
@@ -339,6 +380,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         memcpy(in->hRing + off + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg));     // ... the rest is filled in behind them
         if (!devDeps.empty()) memcpy(in->hRing + off + depOff, devDeps.data(), devDeps.size() * sizeof(int));
         if (pairBytes) memcpy(in->hRing + off + opBytes + segBytes, plan.snapPairs.data(), pairBytes);
+        if (cmBytes) memcpy(in->hRing + off + cmOff, cm.data(), cmBytes);
         { int rcq = queueCopy(in, in->dRing + off, (size_t)off, total); if (rcq) return rcq; }
         dBase = in->dRing + off;
         if (in->kernelUploads) stagedProg = (const char*)in->hRingDev + off;
@@ -365,6 +407,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         HIP_TRY(hipMemcpy(in->bigStage + opBytes, segs.data(), segs.size() * sizeof(mi355::WalkSeg), hipMemcpyHostToDevice));
         if (!devDeps.empty()) HIP_TRY(hipMemcpy(in->bigStage + depOff, devDeps.data(), devDeps.size() * sizeof(int), hipMemcpyHostToDevice));
         if (pairBytes) HIP_TRY(hipMemcpy(in->bigStage + opBytes + segBytes, plan.snapPairs.data(), pairBytes, hipMemcpyHostToDevice));
+        if (cmBytes) HIP_TRY(hipMemcpy(in->bigStage + cmOff, cm.data(), cmBytes, hipMemcpyHostToDevice));
         dBase = in->bigStage;
     }
     ph2 = PhaseClock::now();
@@ -374,7 +417,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
     const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
-                                         : w.size() * (size_t)in->C * 40 * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category (kernels_walk4.hip)
+                                         : w.size() * (size_t)in->C * entryDoubles * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category, twice for the assembly loop (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(live(in)));
         if (in->matStream) hipFree(in->matStream);
@@ -417,12 +460,15 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 if ((const char*)L.e[b].dst <= (const char*)L.e[a].dst && (const char*)L.e[a].dst + L.e[a].bytes <= (const char*)L.e[b].dst + L.e[b].bytes) L.e[a].bytes = 0;
         in->pendingCopies.clear();
         mi355::launchGatherAndSnapshot(in->stream, (const mi355::WalkOp*)stagedProg, (int)w.size(), in->C, in->matStream, in->matrices,
-                                       (const int*)(stagedProg + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, &L, (int)blocks);
+                                       (const int*)(stagedProg + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, &L, (int)blocks,
+                                       entryDoubles, cmBytes ? (const double* const*)(stagedProg + cmOff) : nullptr);
     }
     else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
-                                                           (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S);
-    else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream);
+                                                           (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, nullptr, 0,
+                                                           entryDoubles, cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
+    else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, entryDoubles,
+                                     cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
     if (labEnv("BEAGLE_MI355_DUMP_PLAN")) {           // development (LAB builds): the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
         for (size_t i = 0; i < segs.size(); i++) {

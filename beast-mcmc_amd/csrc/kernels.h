@@ -64,7 +64,12 @@ bool grantDynamicLds(const void* kernel, size_t bytes);
 // the previous micro-operation's result (WK_ACC, second operand only) or one of two hold slots (WK_H0/WK_H1, first
 // operand only; `hold` = 1 + slot: the result of THIS micro-operation is also parked there).  The product commutes
 // bitwise, so the planner is free to order the two children that way; a child in memory comes first.
-enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4, WK_H2 = 5 };
+enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4, WK_H2 = 5, WK_CHERRY = 6 };
+// WK_CHERRY (second operand only, k_walk4_fast only; round 6): the child is a node over two compact tips whose own micro-operation the
+// engine has FUSED into this one (engine_walk.cpp runPlan): src2 = the states of its first tip, scale = those of its second (the
+// micro-operation multiplies by no reciprocals: WF_INV and WK_CHERRY exclude each other), the second half of the matrix-stream entry =
+// its two branch-matrix tables.  The kernel forms the child's value — column x column, what the fused micro-operation would have left
+// in ACC, bit for bit — and goes on as for WK_ACC.  A third of a binary tree's internal nodes are such cherries.
 // hold slots the planner may use: k_walk4 keeps all of them in LDS (4 KiB per slot and category: three fit up to 8
 // categories), k_walk4_fast two in LDS and the third in registers
 #if defined(__HIPCC__)
@@ -73,7 +78,7 @@ __host__ __device__
 inline int walkHoldSlots(int C) { return C <= 8 ? 3 : 2; }
 enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 // flags: what the kernel's fetch stage has to load for the micro-operation (WF_*), then the kinds
-enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16 };
+enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16, WF_CHERRY2 = 1 << 15 };
 // (bit 14 = WS_WRITE of the scale mode: the assembly loop tests it directly)
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
 // second child in memory, the result is parked in a hold slot, and the stage's wait as a 3-bit code at bit 28 (walkWaitCode)
@@ -81,11 +86,12 @@ enum : unsigned { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26,
                   WF_HREAD2 = 1u << 31 };
 // k_walk4_fast's pipeline is three micro-operations deep: the wait of stage k is "at most N vector-memory instructions outstanding",
 // N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan).  A fetch is three loads, four
-// for a micro-operation that multiplies by reciprocal scale factors (WF_INV), so N is 6..8, + 4 behind a first child from memory,
-// or 3..4 when the stage's own first child comes from memory.  Codes (tools/gen_walk4_fast.py WAIT_N): 0..7 = 6, 7, 8, 10, 11, 12,
-// 3, 4; anything else is rounded DOWN to the next of these (a smaller N only waits longer).
+// for a micro-operation that multiplies by reciprocal scale factors (WF_INV), six with a fused cherry (WF_CHERRY2: its table half and
+// two more tip-state pairs), so N is 6..12, + 4 behind a first child from memory, or 3..6 when the stage's own first child comes from
+// memory.  Codes (tools/gen_walk4_fast.py WAIT_N): 0..7 = 6, 9, 7, 8, 10, 12, 3, 4; anything else is rounded DOWN to the next of these
+// (a smaller N only waits longer).
 inline unsigned walkWaitCode(int n) {
-    const int code = n >= 12 ? 5 : n == 11 ? 4 : n == 10 ? 3 : n >= 8 ? 2 : n == 7 ? 1 : n == 6 ? 0 : n >= 4 ? 7 : 6;
+    const int code = n >= 12 ? 5 : n >= 10 ? 4 : n == 9 ? 1 : n == 8 ? 3 : n == 7 ? 2 : n == 6 ? 0 : n >= 4 ? 7 : 6;
     return (unsigned)code << WF_WAIT_SHIFT;
 }
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
@@ -120,6 +126,7 @@ inline unsigned walkFlags(int k1, int k2, int hold, int smode, bool store) {
     if (store) f |= WF_STORE;
     if (k1 >= WK_H0) f |= WF_HREAD | (k1 == WK_H1 ? WF_HREAD1 : 0u) | (k1 == WK_H2 ? WF_HREAD2 : 0u);
     if (k2 == WK_MEM) f |= WF_MEM2;
+    if (k2 == WK_CHERRY) f |= WF_CHERRY2;
     if (hold) f |= WF_HWRITE;
     return f;
 }
@@ -146,12 +153,16 @@ struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, depStart, depCo
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream,
                  int P, int C, long recipOff);
-void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream);
+// entryDoubles: 40 = an entry is the two tables of the micro-operation's own children (k_walk4); 80 = behind them the two tables of
+// a fused cherry's tips (k_walk4_fast; cherryMats[2 k], [2 k + 1] = its branch matrices, category 0, or null: nothing is written there)
+constexpr int WALK_ENTRY_PLAIN = 40, WALK_ENTRY_FUSED = 80;
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, int entryDoubles = WALK_ENTRY_PLAIN,
+                          const double* const* cherryMats = nullptr);
 // ... and the plan's matrix snapshots (src, dst index pairs) in the same launch; m1 / m2 of freshly snapshotted matrices must point at the sources
 // ... and queued host copies (copies / copyBlocks: kernels_walk4.hip k_gatherAndSnapshot); dProg / dSrcDst may then be the host ring's mapping
 struct HostCopyList;
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
-                             const HostCopyList* copies = nullptr, int copyBlocks = 0);
+                             const HostCopyList* copies = nullptr, int copyBlocks = 0, int entryDoubles = WALK_ENTRY_PLAIN, const double* const* cherryMats = nullptr);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
 // src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
 // deps / flags / epoch / flagStride: all slices of a program in ONE launch (slice y is dispatched before y + 1): a workgroup first

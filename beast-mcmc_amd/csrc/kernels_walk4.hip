@@ -43,6 +43,7 @@
 #include "root_site4.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 
 namespace mi355 {
 
@@ -195,6 +196,7 @@ __device__ __forceinline__ void matvecDpp2(const double sp, const v4d xa, const 
 // out): for each of the two branch matrices five columns of four doubles, T[s][i] = M[i][s] for a state s < 4 and 1 for
 // s = 4 (missing) — what a compact tip child in state s contributes, read with two ds_read_b128 and no select.
 constexpr int WALK_TABLE_BYTES = 320, WALK_TABLE_M2 = 160;
+constexpr int WALK_ENTRY_BYTES_FUSED = WALK_ENTRY_FUSED * 8;      // the assembly loop's stream entry per category: 640 bytes
 __device__ __forceinline__ v4d tipColumn(const char* tbl, unsigned s) {
     const v2d* p = reinterpret_cast<const v2d*>(tbl + (s << 5));
     const v2d lo = p[0], hi = p[1];
@@ -319,12 +321,20 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
 
 // stream[k][c] = the matrix table of micro-operation k, category c (see tipColumn): 2 x 5 columns x 4 doubles, in
 // program order, so that the walk's fetch stage copies it to LDS with ONE instruction at an address it only increments
-__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * 40) return;
-    const int k = (int)(t / (C * 40)), r = (int)(t % (C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
-    const double MI355_GLOBAL* M = gptr(m ? prog[k].m2 : prog[k].m1) + c * 16;
+// one double of the stream: entry k, category c, position j of E (E = 40: tables of m1, m2; 80: then those of a fused cherry's two
+// matrices, where the micro-operation has one — nothing is written otherwise: the walk never reads that half)
+__device__ __forceinline__ void gatherOne(const WalkOp* __restrict__ prog, double* __restrict__ stream, size_t t, int C, int E,
+                                          const double* const* __restrict__ cherryMats) {
+    const int k = (int)(t / ((size_t)C * E)), r = (int)(t % ((size_t)C * E)), c = r / E, j = r % E, m = j / 20, col = (j % 20) >> 2, i = j & 3;
+    const double* src = m == 0 ? prog[k].m1 : m == 1 ? prog[k].m2 : cherryMats ? cherryMats[2 * k + (m - 2)] : nullptr;
+    if (!src) return;
+    const double MI355_GLOBAL* M = gptr(src) + c * 16;
     stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
+}
+__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int E, const double* const* __restrict__ cherryMats) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * C * E) return;
+    gatherOne(prog, stream, t, C, E, cherryMats);
 }
 
 // The same, and in the same launch the matrix snapshots of the plan's new definitions (kernels.hip k_snapshot): the stream's
@@ -334,7 +344,8 @@ __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, 
 // then read through the host ring's device mapping, the copy blocks put the program where the walk will read it; a partial update
 // or an evaluation on a list the engine has not seen is three launches instead of four.
 __global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
-                                    double* __restrict__ matrices, const int* __restrict__ srcDst, int elems, int nPairs, const HostCopyList L) {
+                                    double* __restrict__ matrices, const int* __restrict__ srcDst, int elems, int nPairs, const HostCopyList L,
+                                    int E, const double* const* __restrict__ cherryMats) {
     if ((int)blockIdx.x >= gatherBlocks + nPairs) { hostCopyBlock(L, blockIdx.x - (unsigned)(gatherBlocks + nPairs)); return; }
     if ((int)blockIdx.x >= gatherBlocks) {
         const int k = (int)blockIdx.x - gatherBlocks;
@@ -344,28 +355,26 @@ __global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restr
         return;
     }
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * 40) return;
-    const int k = (int)(t / (C * 40)), r = (int)(t % (C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
-    const double MI355_GLOBAL* M = gptr(m ? prog[k].m2 : prog[k].m1) + c * 16;
-    stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
+    if (t >= (size_t)n * C * E) return;
+    gatherOne(prog, stream, t, C, E, cherryMats);
 }
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
-                             const HostCopyList* copies, int copyBlocks) {
+                             const HostCopyList* copies, int copyBlocks, int entryDoubles, const double* const* cherryMats) {
     HostCopyList none;
     none.n = 0;
     if (nPairs < 0) nPairs = 0;
     if (!copies || copyBlocks <= 0) { copies = &none; copyBlocks = 0; }
     if (nOps <= 0) { if (copyBlocks) launchHostCopies(stream, *copies, copyBlocks); launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
-    const size_t total = (size_t)nOps * C * 40;
+    const size_t total = (size_t)nOps * C * entryDoubles;
     const int gatherBlocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + nPairs + copyBlocks)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
-                       gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies);
+                       gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies, entryDoubles, cherryMats);
 }
 
-void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream) {
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, int entryDoubles, const double* const* cherryMats) {
     if (nOps <= 0) return;
-    const size_t total = (size_t)nOps * C * 40;
-    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream);
+    const size_t total = (size_t)nOps * C * entryDoubles;
+    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream, entryDoubles, cherryMats);
 }
 
 // ---- the assembly loop ------------------------------------------------------------------------------------------------
@@ -405,7 +414,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
                                                              unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs,
                                                              unsigned* __restrict__ tickets) {
-    extern __shared__ v2d lds[];                      // hold[2][C][4 KiB], table[3][MAXC][320 B], max[3][1 KiB] (write-mode rescaling)
+    // hold[2][C][4 KiB], table[3][MAXC][320 B], then ONE region shared by the three 1 KiB maximum buffers of write-mode rescaling and
+    // the cherry halves of the table buffers, [3][MAXC][320 B] (a program that rescales in write mode has no fused cherries: runPlan)
+    extern __shared__ v2d lds[];
     const int y = (int)blockIdx.y;
     const WalkSeg MI355_CONST& sg = segs[y];
     const int pStart = sg.pStart, pEnd = sg.pEnd;
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 #ifdef BEAGLE_MI355_LAB
     if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
 #endif
-    const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
+    const unsigned strmStep = (unsigned)C * WALK_ENTRY_BYTES_FUSED;      // (an entry: the micro-operation's two tables, then a fused cherry's: kernels.h)
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
     const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         asm volatile(WALK4_FAST_ASM
                      : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
                          [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
-                         [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
+                         [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_ENTRY_BYTES_FUSED), [hold] "s"(hold),
                          [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
                          [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)blockIdx.x * 128)
                      : WALK4_FAST_CLOBBERS);
@@ -576,7 +587,7 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     // LAB builds only, BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so
     // that fewer workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
     static const size_t ldsPad = labEnv("BEAGLE_MI355_WALK_LDS_PAD") ? (size_t)atol(labEnv("BEAGLE_MI355_WALK_LDS_PAD")) : 0;
-    const size_t lds = (size_t)2 * C * 4096 + (size_t)3 * maxC * WALK_TABLE_BYTES + (size_t)3 * 1024 + ldsPad;
+    const size_t lds = (size_t)2 * C * 4096 + (size_t)3 * maxC * WALK_TABLE_BYTES + std::max((size_t)3 * 1024, (size_t)3 * maxC * WALK_TABLE_BYTES) + ldsPad;
     const unsigned recipOffBytes = (unsigned)(recipOff * 8);
     const unsigned MI355_CONST* prog = (const unsigned MI355_CONST*)dProg;
     const WalkSeg MI355_CONST* segs = (const WalkSeg MI355_CONST*)dSegs;

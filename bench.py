@@ -545,6 +545,7 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
     elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=restart)
     per_step.sort()
     stats = raw.walkStats()
+    stats["fused_cherries"] = raw.walkLaunchInfo()["fused_cherries"]      # (micro-operations evaluated inside their consumers' stages: not stages of their own)
     kernel_ms, launches = raw.kernelTimer(False)
     timed_calls = None
     rccl = None
@@ -881,6 +882,7 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         step(i)
     elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=tl.b.kernelTimerRestart)
     stats = tl.b.walkStats()
+    stats["fused_cherries"] = tl.b.walkLaunchInfo()["fused_cherries"]
     kernel_ms, _ = tl.b.kernelTimer(False)
     timed_calls = max(1, tl.b.kernelTimerCalls())
     out = None

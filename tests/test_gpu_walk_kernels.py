@@ -93,3 +93,67 @@ def test_partial_updates_use_the_assembly_loop_and_match(oracle_lib):
         results.append(vals)
         tl.close()
     assert results[0] == results[1]
+
+
+def _chain_with(wl, scheme, env, moves=10):
+    """A chain of full evaluations, branch moves and rejections on an instance created under `env`; everything it computes."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        tl = BeagleTreeLikelihood(wl, rescaling=scheme, delay_rescaling=False)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    raw = bm.beagle.Beagle.attach(tl)
+    raw.kernelTimer(True)
+    vals = [tl.getLogLikelihood()]
+    tl.makeDirty()
+    vals.append(tl.getLogLikelihood())
+    r = np.random.default_rng(77)
+    for _ in range(moves):
+        node = int(r.integers(wl.tree.tip_count, wl.tree.node_count - 1))
+        tl.storeState()
+        tl.set_node_height(node, helpers.proposed_height(wl.tree, node, r))
+        vals.append(tl.getLogLikelihood())
+        if r.random() < 0.4:
+            tl.restoreState()
+            vals.append(tl.getLogLikelihood())
+    tl.makeDirty()
+    vals.append(tl.getLogLikelihood())
+    info = raw.walkLaunchInfo()
+    site = tl.getSiteLogLikelihoods().copy()
+    nodes = list(range(wl.tree.tip_count, wl.tree.node_count))
+    parts = [raw.getPartials(tl.node_buffer_index(n), bm.beagle.NONE).copy() for n in nodes]
+    tl.close()
+    return vals, site, parts, info
+
+
+@pytest.mark.parametrize("scheme", [RESCALE_NONE, RESCALE_DYNAMIC, RESCALE_ALWAYS])
+@pytest.mark.parametrize("C,T,P,kind", [(4, 200, 3000, "coalescent"), (1, 64, 129, "yule"), (8, 90, 700, "coalescent"), (4, 50, 1, "coalescent"),
+                                         (4, 120, 640, "caterpillar"), (16, 30, 300, "yule")])
+def test_fused_cherries_give_the_bits_of_the_unfused_program(C, T, P, kind, scheme, oracle_lib):
+    """Round 6: a node over two compact tips that is not stored, pays no scale factors and is taken by the very next micro-operation
+    is evaluated INSIDE that micro-operation's stage (kernels.h WK_CHERRY; engine_walk.cpp runPlan) — its own stage, a third of a
+    tree's, disappears from the device program.  Same arithmetic in the same order: every log-likelihood, site value and node partial
+    of a chain must equal, bit for bit, what the unfused program (BEAGLE_MI355_NO_CHERRY_FUSION=1) and the C++ kernel give, and the
+    counters must say that cherries really were fused (read mode and no scaling; never in a program that rescales in write mode)."""
+    wl = helpers.random_workload(T, P, 4, C, seed=8800 + T + C, tree_kind=kind)
+    fv, fs, fp, finfo = _chain_with(wl, scheme, {"BEAGLE_MI355_NO_CHERRY_FUSION": "0"})
+    uv, us, up, uinfo = _chain_with(wl, scheme, {"BEAGLE_MI355_NO_CHERRY_FUSION": "1"})
+    cv, cs, cp, _ = _chain_with(wl, scheme, {"BEAGLE_MI355_NO_FAST_WALK": "1"})
+    assert uinfo["fused_cherries"] == 0
+    if scheme == RESCALE_ALWAYS:
+        assert finfo["fused_cherries"] == 0                                  # every program rescales in write mode
+    elif kind != "caterpillar":
+        assert finfo["fused_cherries"] > 0                                   # (full evaluations fuse; a ladder has ONE cherry, branch moves under per-node factors none)
+    assert fv == uv == cv
+    assert np.array_equal(fs, us) and np.array_equal(fs, cs)
+    for a, b, c in zip(fp, up, cp):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    o = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=scheme, delay_rescaling=False)
+    ref = o.getLogLikelihood()
+    o.close()
+    assert helpers.rel_err(fv[0], ref) <= REL_TOL

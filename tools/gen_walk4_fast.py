@@ -42,6 +42,7 @@ T0, T1 = 94, 95
 PA, PB, TIP, SCALE, OM, HOLD, LANE, VST = 96, 97, 98, 99, 100, 101, 104, 105
 SPS = (102, 103, 34)          # the lane's LDS address inside the three table buffers
 H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
+TCAS, TCBS = (36, 37, 38), (39, 40, 41)  # tip-state pairs of a FUSED CHERRY's two tips (B_CHERRY): three pipeline slots
 TBVS = (124, 125, 35)         # the LDS addresses of the three table buffers, in every lane (broadcast reads of a matrix's first column)
 NV = 126
 # scalar (s32..s35 are left to the compiler)
@@ -49,6 +50,8 @@ DP, STRM, CNT, HSTRIDE, STEP, ST, LAST, CM0 = 20, 22, 24, 27, 28, 29, 30, 31
 TBLS = (25, 26, 57)           # LDS addresses of the three table buffers of this wave
 D, DFL, DW = 36, 44, 46             # descriptor (kernels.h WalkOp): src1 D+0, src2 D+2, store D+4, scale D+6 | flags s44, (pad s45), the scale buffer a rescaling operation writes s46:47 — two loads: x8 at 0, x4 at 0x20
 CM160 = 83
+TBLBS = (84, 85, 86)          # LDS addresses of the cherry halves of the three table buffers of this wave (TBLS + 3 tblStep)
+S_LAST = 86
 FLS, SCALEWS = (48, 56, 49), (54, 62, 58)      # what a compute stage needs of its descriptor, stashed by the fetch: three pipeline slots
 SSTORE, SSRC2, SX = 50, 52, 60                 # addresses the rare blocks read again from the descriptor (store, second child, first child)
 MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
@@ -58,12 +61,20 @@ S_FIRST = 20
 
 # flag bits (kernels.h)
 B_X, B_T1, B_T2, B_INV, B_STORE, B_HSLOT1, B_READ, B_WRITE = 0, 1, 2, 3, 4, 12, 13, 14     # (B_READ / B_WRITE: the scale mode, WS_READ = 1, WS_WRITE = 2 at bit 13)
+# B_CHERRY (kernels.h WF_CHERRY2, round 6): the second child is a node over two compact tips that is evaluated INSIDE this stage — its
+# own micro-operation is not in the program (engine_walk.cpp runPlan fuses it away: a third of a tree's nodes are such cherries, and a
+# stage costs ~60 instructions of overhead whatever it computes).  The descriptor's src2 / scale fields then carry the two tips' state
+# arrays, the stream entry's second half the cherry's two branch-matrix tables; the value is column(A) * column(B), formed in ACC,
+# and the stage goes on as if the previous micro-operation had left it there.  Same arithmetic, same order, same bits.
+B_CHERRY = 15
 B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
 # the stage's wait as a 3-bit code at B_WAIT0 (kernels.h walkWaitCode): vmcnt(N) with N = WAIT_N[code]; code 0 is the common one
 # (a fetch is THREE small loads — matrix table, two tip-state pairs — and a fourth, the reciprocal scale factors, only for a
 # micro-operation that multiplies by them: since round 5 a read-mode program applies the factors of unstored results once, at the
 # stored result above them, so nine micro-operations in ten fetch three)
-WAIT_N = (6, 7, 8, 10, 11, 12, 3, 4)
+# (round 6: a fused cherry adds three loads to a fetch — its table half, two more tip-state pairs —, so 9 = a plain and a fused fetch
+# in flight is the second most common count and gets the second test)
+WAIT_N = (6, 9, 7, 8, 10, 12, 3, 4)
 
 # Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
 # in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
@@ -274,6 +285,20 @@ def fetch(tag, slot):
         e("s_mov_b64 exec, -1")
     e("global_load_ushort %s, %s, %s" % (v(T1S[slot]), v(TIP), s(D, 2)))
     e("global_load_ushort %s, %s, %s" % (v(T2S[slot]), v(TIP), s(D + 2, 2)))
+    # a fused cherry (B_CHERRY): the second half of the stream entry — the cherry's two matrix tables, 320 bytes further on — into the
+    # cherry half of the table buffer, and its two tips' state pairs (descriptor fields src2 and scale): out of line
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_CHERRY))
+    e("s_cbranch_scc1 %s" % L("ch" + tag))
+    e(L("chb" + tag) + ":")
+    outofline.append([L("ch" + tag) + ":",
+                      "v_add_u32_e32 %s, 0x140, %s" % (v(T1), v(OM)),
+                      "s_mov_b32 m0, %s" % s(TBLBS[slot]),
+                      "s_mov_b64 exec, 0xfffff",
+                      "global_load_lds_dwordx4 %s, %s" % (v(T1), s(STRM, 2)),
+                      "s_mov_b64 exec, -1",
+                      "global_load_ushort %s, %s, %s" % (v(TCAS[slot]), v(TIP), s(D + 2, 2)),
+                      "global_load_ushort %s, %s, %s" % (v(TCBS[slot]), v(TIP), s(D + 6, 2)),
+                      "s_branch %s" % L("chb" + tag)])
     e("v_add_u32_e32 %s, %s, %s" % (v(OM), s(STEP), v(OM)))       # the next table of the matrix stream (a 32-bit lane offset: < 4 GiB of stream)
     e("s_mov_b32 %s, %s" % (s(FLS[slot]), s(DFL)))
     e("s_mov_b64 %s, %s" % (s(SCALEWS[slot], 2), s(DW, 2)))
@@ -404,10 +429,27 @@ def stage(tag, cur):
     e(ldsw)
     e("s_branch %s" % L("mul" + tag))
     e(L("ga" + tag) + ":")
-    e("s_bitcmp1_b32 %s, %d" % (s(SFL), B_MEM2))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), (1 << B_MEM2) | (1 << B_CHERRY)))       # the two rare forms of a second child: one test
     e("s_cbranch_scc1 %s" % L("m2" + tag))
     e(L("m2b" + tag) + ":")
+    # a fused cherry: ACC = column(tip A) * column(tip B) from the cherry half of this stage's table buffer (G and the first-child
+    # buffer are free here; what ACC held is dead: the micro-operation before a cherry's consumer parked or stored its result)
+    tblB = TBLBS[cur]
+    save2 = lines[:]
+    del lines[:]
+    e(L("cc" + tag) + ":")
+    tip_columns(G, TCAS[cur], tblB, 0)
+    tip_columns(XB, TCBS[cur], tblB, 160)
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(8):
+        e("v_mul_f64 %s, %s, %s" % (v(ACC + 2 * i, 2), v(G + 2 * i, 2), v(XB + 2 * i, 2)))
+    e("s_branch %s" % L("m2b" + tag))
+    ccblk = lines[:]
+    del lines[:]
+    lines.extend(save2)
+    m2blk[1:1] = ["s_bitcmp1_b32 %s, %d" % (s(SFL), B_CHERRY), "s_cbranch_scc1 %s" % L("cc" + tag)]
     outofline.append(m2blk)
+    outofline.append(ccblk)
     e("ds_read_b64 %s, %s offset:160" % (v(SP, 2), v(spCur)))
     col0_reads(XB, tbvCur, 160)                  # (the first-child buffer: consumed by the first mat-vec, or not in use)
     e(ldsw)
@@ -490,6 +532,9 @@ def build():
     e("s_mov_b32 %s, %%[tbl]" % s(TBLS[0]))
     e("s_add_u32 %s, %%[tbl], %%[tblStep]" % s(TBLS[1]))
     e("s_add_u32 %s, %s, %%[tblStep]" % (s(TBLS[2]), s(TBLS[1])))
+    e("s_mul_i32 %s, %%[tblStep], 3" % s(ST))                           # the cherry halves follow the three table buffers of all waves
+    for j in range(3):
+        e("s_add_u32 %s, %s, %s" % (s(TBLBS[j]), s(TBLS[j]), s(ST)))
     e("s_mov_b32 %s, %%[holdStride]" % s(HSTRIDE))
     e("s_mov_b32 %s, %%[strmStep]" % s(STEP))
     e("s_add_i32 %s, %%[pEnd], -1" % s(LAST))
@@ -605,7 +650,7 @@ def main():
         sep = "\\n" if l.endswith(":") else "\\n\\t"
         text.append('    "%s%s" \\' % (l, sep))
     text.append('    ""')
-    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, CM160 + 1) if i not in (32, 33, 34, 35)]
+    clob = ['"v%d"' % i for i in range(NV)] + ['"s%d"' % i for i in range(S_FIRST, S_LAST + 1) if i not in (32, 33, 34, 35)]
     clob += ['"vcc"', '"scc"', '"memory"']
     text.append("#define WALK4_FAST_CLOBBERS " + ", ".join(clob))
     text.append("#define WALK4_FAST_VGPRS %d" % NV)
