@@ -385,6 +385,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
     in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
     in->fuseCherries = !(getenv("BEAGLE_MI355_NO_CHERRY_FUSION") && atoi(getenv("BEAGLE_MI355_NO_CHERRY_FUSION")) != 0);
+    in->skipTipLoads = !(getenv("BEAGLE_MI355_NO_LOAD_SKIP") && atoi(getenv("BEAGLE_MI355_NO_LOAD_SKIP")) != 0);
     in->hostTrace = getenv("BEAGLE_MI355_HOST_TIMING") && atoi(getenv("BEAGLE_MI355_HOST_TIMING")) > 1;     // (a line per slow updatePartials call)
     if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {

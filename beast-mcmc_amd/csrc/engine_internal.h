@@ -215,6 +215,9 @@ struct Instance {
     // WK_CHERRY; engine_walk.cpp runPlan).  Same arithmetic in the same order: bitwise the unfused program.  A third of a tree's nodes.
     // BEAGLE_MI355_NO_CHERRY_FUSION=1 at creation: every micro-operation of the plan is one of the device program (A/B runs, tests)
     bool fuseCherries = true; long statFused = 0;
+    // ... and the loop's fetch loads tip states only for children that ARE compact tips (kernels.h WF_NOLOAD1 / 2; programs without
+    // write-mode rescaling).  BEAGLE_MI355_NO_LOAD_SKIP=1 at creation: both tip-state loads in every fetch, as before round 6 (A/B runs)
+    bool skipTipLoads = true;
     long statTicketWalks = 0, statFlagWalks = 0, lastLaunchRows = 0, lastLaunchSlices = 0;      // (beagleMi355WalkLaunchInfo)
     // how long a workgroup of that launch polls before it computes what it waits for itself (kernels_walk4.hip: forward progress does
     // not rest on the dispatch order), in ticks of the device's 100 MHz wall clock: 20 ms — an evaluation of the largest alignment

@@ -158,8 +158,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     std::vector<int> cur;
     // fused cherries (kernels.h WK_CHERRY): the assembly loop only, and no program that rescales in write mode anywhere (the cherry
     // halves of the kernel's table buffers share their LDS with the maximum buffers of write-mode rescaling)
-    bool fuseOk = asmLoop && in->fuseCherries && in->walk;
-    if (fuseOk) for (const mi355::MicroOp& q : plan.prog) if (q.smode == mi355::PS_WRITE) { fuseOk = false; break; }
+    bool noWrites = asmLoop && in->walk;
+    if (noWrites) for (const mi355::MicroOp& q : plan.prog) if (q.smode == mi355::PS_WRITE) { noWrites = false; break; }
+    const bool fuseOk = noWrites && in->fuseCherries;
+    // ... and in such programs the loop's fetch skips the tip-state load of a child that is no compact tip (kernels.h WF_NOLOAD1 / 2): a
+    // vector-memory instruction less on the CU's address unit for half the children of a tree.  Programs that rescale in write mode keep
+    // every fetch at its full size: their stage waits count on it (below).
+    const unsigned skipLoads = noWrites && in->skipTipLoads ? (mi355::WF_NOLOAD1 | mi355::WF_NOLOAD2) : 0u;
     struct FusedAt { size_t at; int matA, matB; };
     std::vector<FusedAt> fusedAt;
     auto paysFactors = [&](int j) { return fold ? foldMap.payStart[(size_t)j + 1] > foldMap.payStart[(size_t)j] : plan.prog[(size_t)j].smode == mi355::PS_READ; };
@@ -184,7 +189,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     memset(&nop, 0, sizeof(nop));
     nop.m1 = in->matrices; nop.m2 = in->matrices;
     nop.src1 = in->dummyTips; nop.src2 = in->dummyTips; nop.scale = in->onesScale;
-    nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8));         // loads nothing, stores nothing
+    nop.flags = (unsigned)((mi355::WK_TIPS << 5) | (mi355::WK_TIPS << 8)) | skipLoads;         // loads nothing, stores nothing
     for (size_t oi = 0; oi < plan.segs.size(); oi++) {
         const size_t si = oi;                                   // position in the device program
         const mi355::PlanSeg& ps = plan.segs[fused ? (size_t)order[oi] : oi];
@@ -265,6 +270,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                 cherry = -1;
             }
             d.flags = mi355::walkFlags(m.k1, k2, m.hold, smodeNow, m.storeBuf >= 0);
+            if (m.k1 != mi355::PK_TIPS) d.flags |= skipLoads & mi355::WF_NOLOAD1;
+            if (k2 != mi355::PK_TIPS) d.flags |= skipLoads & mi355::WF_NOLOAD2;
             if (ablate) {       // TIMING EXPERIMENTS ONLY (wrong results): 1 no stores, 2 no partials loads, 4 no scale traffic, 8 no tip traffic
                 if (ablate & 1) d.flags &= ~(unsigned)mi355::WF_STORE;
                 if (ablate & 2) d.flags &= ~(unsigned)mi355::WF_X;
@@ -314,14 +321,14 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             // it the count is the strict one whatever the mode)
             const bool prevWrites = i > first && ((w[i - 1].flags >> 13) & 3u) == (unsigned)mi355::WS_WRITE;
             const int stores1 = (in->strictWaits || prevWrites) ? 0 : (i > first ? mi355::walkStoreCount(w[i - 1].flags) : 0);
-            w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores1, 12));
-            if (!asmLoop) continue;
+            if (!asmLoop) { w[i].flags |= mi355::walkWaitJump(std::min(mi355::walkFetchCount(w[i + 1].flags) + stores1, 12)); continue; }
             // k_walk4_fast (three deep; a fetch is THREE small loads, four with the reciprocal scale factors: WF_INV).  Issue order around
             // stage i: ... fetch(i) | first child of i - 1 from memory (4) | store(i - 2) | fetch(i + 1) | first child of i from memory
             // (4) | store(i - 1) | fetch(i + 2) | WAIT.  A first child of i in memory has to have landed as well: then only what
             // follows it counts.  (Loads only — the strict rule — whatever BEAGLE_MI355_STRICT_WAITS says: with two fetch sizes the
             // code space has no room for the store counts of the lax rule, which bought 1 %.)
-            auto fetchLoads = [&](int j) { return 3 + ((w[j].flags & mi355::WF_INV) ? 1 : 0) + ((w[j].flags & mi355::WF_CHERRY2) ? 3 : 0); };     // (the no-ops behind a program: 3)
+            auto fetchLoads = [&](int j) { const unsigned f = w[j].flags;             // (matrix table; tip states, twice; reciprocals; a fused cherry's table half and tips)
+                                           return 1 + ((f & mi355::WF_NOLOAD1) ? 0 : 1) + ((f & mi355::WF_NOLOAD2) ? 0 : 1) + ((f & mi355::WF_INV) ? 1 : 0) + ((f & mi355::WF_CHERRY2) ? 3 : 0); };
             const int x1 = i > first && (w[i - 1].flags & mi355::WF_X) ? 4 : 0;
             const int nWait = (w[i].flags & mi355::WF_X) ? fetchLoads(i + 2) : fetchLoads(i + 1) + fetchLoads(i + 2) + x1;
             w[i].flags |= mi355::walkWaitCode(nWait);

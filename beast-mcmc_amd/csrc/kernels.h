@@ -81,18 +81,21 @@ enum { WS_NONE = 0, WS_READ = 1, WS_WRITE = 2 };
 enum { WF_X = 1, WF_T1 = 2, WF_T2 = 4, WF_INV = 8, WF_STORE = 16, WF_CHERRY2 = 1 << 15 };
 // (bit 14 = WS_WRITE of the scale mode: the assembly loop tests it directly)
 // more bits for the assembly loop k_walk4_fast (tools/gen_walk4_fast.py): first child comes from a hold slot (and which),
-// second child in memory, the result is parked in a hold slot, and the stage's wait as a 3-bit code at bit 28 (walkWaitCode)
-enum : unsigned { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_WAIT_SHIFT = 28,
-                  WF_HREAD2 = 1u << 31 };
+// second child in memory, the result is parked in a hold slot; and in bits 16..23 — which belong to the kernel that runs the program:
+// k_walk4 keeps its wait-table jump there (walkWaitJump) — "the fetch skips the first / second tip-state load" (WF_NOLOAD1 / 2: the
+// child is no compact tip; set in programs that do not rescale in write mode) and the stage's wait as a 4-bit code (walkWaitCode)
+enum : unsigned { WF_HREAD = 1u << 24, WF_HREAD1 = 1u << 25, WF_MEM2 = 1u << 26, WF_HWRITE = 1u << 27, WF_NOLOAD1 = 1u << 16, WF_NOLOAD2 = 1u << 17,
+                  WF_WAIT_SHIFT = 18, WF_HREAD2 = 1u << 31 };
 // k_walk4_fast's pipeline is three micro-operations deep: the wait of stage k is "at most N vector-memory instructions outstanding",
 // N = what was issued behind the small loads of k and may stay in flight (engine_walk.cpp runPlan).  A fetch is three loads, four
 // for a micro-operation that multiplies by reciprocal scale factors (WF_INV), six with a fused cherry (WF_CHERRY2: its table half and
 // two more tip-state pairs), so N is 6..12, + 4 behind a first child from memory, or 3..6 when the stage's own first child comes from
-// memory.  Codes (tools/gen_walk4_fast.py WAIT_N): 0..7 = 6, 9, 7, 8, 10, 12, 3, 4; anything else is rounded DOWN to the next of these
-// (a smaller N only waits longer).
+// memory; a tip-state load that is skipped (WF_NOLOAD1 / 2) takes one off.  Every count from 1 to 16 has its code (tools/gen_walk4_fast.py
+// WAIT_N: 0..15 = 4, 3, 5, 2, 6, 7, 8, 9, 10, 11, 12, 1, 13, 14, 15, 16); more than 16 waits as for 16, less than 1 as for 1 (a smaller N
+// only waits longer).
 inline unsigned walkWaitCode(int n) {
-    const int code = n >= 12 ? 5 : n >= 10 ? 4 : n == 9 ? 1 : n == 8 ? 3 : n == 7 ? 2 : n == 6 ? 0 : n >= 4 ? 7 : 6;
-    return (unsigned)code << WF_WAIT_SHIFT;
+    static const int codeOf[17] = {11, 11, 3, 1, 0, 2, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15};      // index: N (0 as 1)
+    return (unsigned)codeOf[n < 0 ? 0 : n > 16 ? 16 : n] << WF_WAIT_SHIFT;
 }
 struct WalkOp {              // 64 bytes = one scalar-cache line; every field is an ADDRESS the kernel adds a 32-bit lane offset to
     const void*    src1;     // WK_MEM: first child's partials [C][P][4];  WK_TIPS: its uint8 states

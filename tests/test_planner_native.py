@@ -58,9 +58,10 @@ def test_isa_check_sees_a_copy_made_before_the_wait():
 
 def test_generated_assembly_loop_is_up_to_date_and_balanced():
     """csrc/walk4_fast_loop.inc is what tools/gen_walk4_fast.py emits now, and the stream is structurally sound: every
-    out-of-line block returns, every label that is branched to exists exactly once, every fetch issues the four small
-    loads the host's wait codes assume (kernels.h walkWaitCode), and nothing above v125 / s83 is named (126 vector
-    registers: four waves per SIMD)."""
+    out-of-line block returns, every label that is branched to exists exactly once, every fetch issues the loads the host's
+    wait codes assume (kernels.h walkWaitCode, engine_walk.cpp fetchLoads: the matrix table, two tip-state pairs — each behind its
+    skip test —, the reciprocal pair out of line, a fused cherry's table half and two tip-state pairs out of line), the wait
+    table holds every count from 1 to 16 once, and nothing above v125 / s86 is named (126 vector registers: four waves per SIMD)."""
     import re
     env = dict(os.environ, WALK4_CHECK_ONLY="1")
     env.pop("WALK4_EXPERIMENT", None)
@@ -72,12 +73,19 @@ def test_generated_assembly_loop_is_up_to_date_and_balanced():
     assert len(labels) == len(set(labels))
     targets = set(re.findall(r"s_c?branch\w* (\.LW4\w+_%=)", "\n".join(lines)))
     assert targets <= set(labels), targets - set(labels)
-    # per fetch: one LDS-DMA, two tip-pair loads, one reciprocal-pair load (two in the prologue + three stages = 5 of each group)
-    assert sum("global_load_lds_dwordx4" in l for l in lines) == 5
-    assert sum(l.startswith("global_load_ushort") for l in lines) == 10
+    # per fetch (two in the prologue + three stages = 5): one LDS-DMA and one more for a fused cherry, two tip-pair loads and two more
+    # for a fused cherry, one reciprocal-pair load
+    assert sum("global_load_lds_dwordx4" in l for l in lines) == 10
+    assert sum(l.startswith("global_load_ushort") for l in lines) == 20
+    for tag in "pqabc":                               # each tip-pair load sits right behind its own skip test
+        for n, bit in (("n1", 16), ("n2", 17)):
+            k = lines.index(".LW4%s%s_%%=:" % (n, tag))
+            assert lines[k - 1].startswith("global_load_ushort") and lines[k - 2] == "s_cbranch_scc1 .LW4%s%s_%%=" % (n, tag) and lines[k - 3].endswith(", %d" % bit)
+    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(lines))]
+    assert sorted(set(waits) - {0}) == list(range(1, 17))
     assert sum(l.startswith("global_load_dwordx4 v[22:25]") or l.startswith("global_load_dwordx4 v[26:29]") or l.startswith("global_load_dwordx4 v[30:33]") for l in lines) == 5
     regs = [int(x) for x in re.findall(r"\bv\[?(\d+)", "\n".join(lines))]
     assert max(regs) <= 125
     sregs = [int(x) for x in re.findall(r"\bs\[?(\d+)", "\n".join(lines))]
-    assert max(sregs) <= 83 and not set(sregs) & {32, 33, 34, 35}
+    assert max(sregs) <= 86 and not set(sregs) & {32, 33, 34, 35}
     assert lines[-1].startswith("s_waitcnt vmcnt(0)")

@@ -67,7 +67,12 @@ B_X, B_T1, B_T2, B_INV, B_STORE, B_HSLOT1, B_READ, B_WRITE = 0, 1, 2, 3, 4, 12, 
 # arrays, the stream entry's second half the cherry's two branch-matrix tables; the value is column(A) * column(B), formed in ACC,
 # and the stage goes on as if the previous micro-operation had left it there.  Same arithmetic, same order, same bits.
 B_CHERRY = 15
-B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
+B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_HREAD2 = 24, 25, 26, 27, 31
+# bits 16..23 belong to the kernel that runs the program (k_walk4: its wait-table jump); here: the two tip-state loads of a fetch are
+# SKIPPED under B_NOLOAD1 / B_NOLOAD2 (round 6: the host sets them, in programs that do not rescale in write mode, for a child that is
+# no compact tip — half the children of a tree; a vector-memory instruction occupies the CU's address unit for ~16 cycles whatever it
+# loads, and that unit is one of the three pipes the loop shares between its sixteen waves), and the stage's wait as a 4-bit code
+B_NOLOAD1, B_NOLOAD2, B_WAIT0 = 16, 17, 18
 # the stage's wait as a 3-bit code at B_WAIT0 (kernels.h walkWaitCode): vmcnt(N) with N = WAIT_N[code]; code 0 is the common one
 # (a fetch is THREE small loads — matrix table, two tip-state pairs — and a fourth, the reciprocal scale factors, only for a
 # micro-operation that multiplies by them: since round 5 a read-mode program applies the factors of unstored results once, at the
@@ -75,6 +80,9 @@ B_HREAD, B_HREAD1, B_MEM2, B_HWRITE, B_WAIT0, B_HREAD2 = 24, 25, 26, 27, 28, 31
 # (round 6: a fused cherry adds three loads to a fetch — its table half, two more tip-state pairs —, so 9 = a plain and a fused fetch
 # in flight is the second most common count and gets the second test)
 WAIT_N = (6, 9, 7, 8, 10, 12, 3, 4)
+# round 6, second step: with the tip-state loads skipped where a child is no tip a fetch is 1..6 loads and every count from 1 to 16 occurs:
+# a 4-bit code, every count exact; code 0 (inline) = 4, codes 1 and 2 (a test each) = 3 and 5, the rest through the jump table
+WAIT_N = (4, 3, 5, 2, 6, 7, 8, 9, 10, 11, 12, 1, 13, 14, 15, 16)
 
 # Cache policy of the result stores and of the loads that read stored results back (a first child in memory, a second child
 # in memory).  sc1 = device scope: the store is written through to memory before it is acknowledged, the load does not take a
@@ -283,8 +291,14 @@ def fetch(tag, slot):
         e("s_mov_b64 exec, 0xfffff")
         e("global_load_lds_dwordx4 %s, %s" % (v(OM), s(STRM, 2)))
         e("s_mov_b64 exec, -1")
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_NOLOAD1))
+    e("s_cbranch_scc1 %s" % L("n1" + tag))
     e("global_load_ushort %s, %s, %s" % (v(T1S[slot]), v(TIP), s(D, 2)))
+    e(L("n1" + tag) + ":")
+    e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_NOLOAD2))
+    e("s_cbranch_scc1 %s" % L("n2" + tag))
     e("global_load_ushort %s, %s, %s" % (v(T2S[slot]), v(TIP), s(D + 2, 2)))
+    e(L("n2" + tag) + ":")
     # a fused cherry (B_CHERRY): the second half of the stream entry — the cherry's two matrix tables, 320 bytes further on — into the
     # cherry half of the table buffer, and its two tips' state pairs (descriptor fields src2 and scale): out of line
     e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_CHERRY))
@@ -355,7 +369,7 @@ def stage(tag, cur):
     # wait for this micro-operation's loads: N = what was issued after them and may stay outstanding — the fetches of k + 1 and
     # k + 2 (8), a first child of k - 1 from memory (+4), stores where the engine counts them (engine_walk.cpp runPlan);
     # 4 when this micro-operation's own first child comes from memory (requested a stage ago, behind the fetch of k + 1)
-    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), 7 << B_WAIT0))
+    e("s_and_b32 %s, %s, 0x%x" % (s(ST), s(SFL), 15 << B_WAIT0))
     e("s_cbranch_scc1 %s" % L("ws" + tag))
     novm = "novmwait" in EXPERIMENT
     e("s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[0])
@@ -364,7 +378,7 @@ def stage(tag, cur):
     # folded program) and code 2 (both fetch four: programs that pay at every node — partial updates, write-mode lists) by a test
     # each, the rest through a jump table of (wait, branch) pairs
     blk = [L("ws" + tag) + ":",
-           "s_bfe_u32 %s, %s, 0x%x" % (s(ST), s(SFL), (3 << 16) | B_WAIT0),
+           "s_bfe_u32 %s, %s, 0x%x" % (s(ST), s(SFL), (4 << 16) | B_WAIT0),
            "s_cmp_eq_u32 %s, 1" % s(ST),
            "s_cbranch_scc0 %s" % L("wu" + tag),
            "s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[1],
@@ -384,7 +398,7 @@ def stage(tag, cur):
            "s_setpc_b64 %s" % s(SX, 2)]
     # (... five 4-byte instructions follow s_getpc_b64 up to and including s_setpc_b64: entry 0 would sit at + 20; entries are 8 bytes
     # and entry 0 is never taken, so the table proper starts at entry 1 = + 20 + 8 - 8: the constant above is 20 - 8 = 12)
-    for code in range(1, 8):
+    for code in range(1, 16):
         blk += ["s_nop 0" if novm else "s_waitcnt vmcnt(%d)" % WAIT_N[code], "s_branch %s" % L("wd" + tag)]
     outofline.append(blk)
     off_src2 = -3 * 64 + 8
