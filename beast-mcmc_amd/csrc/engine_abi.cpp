@@ -15,6 +15,27 @@ int accumulate(Instance* in, const int* idx, int count, int cum, double sign, in
     int rc = materializeScaleUsers(in, cum); if (rc) return rc;
     rc = ensureScale(in, cum); if (rc) return rc;
     if (in->scaleIsRaw[cum]) return BEAGLE_ERROR_OUT_OF_RANGE;
+    // exactly the scale buffers the last write-mode walk wrote, none of them touched since: a few dozen slice products instead of a factor
+    // per node (Instance::lastSums)
+    if (in->walk && in->sliceSums && in->partitionCount == 1 && in->lastSums.valid && in->lastSums.epoch == in->scaleWriteEpoch &&
+        count > 0 && count == in->lastSums.nWritten) {
+        const long stamp = ++in->seenCounter;
+        bool same = true;
+        for (int k = 0; k < count && same; k++) {
+            if (badIndex(idx[k], in->scaleCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
+            same = in->scaleGen[(size_t)idx[k]] == in->lastSums.gen && in->scaleSeen[(size_t)idx[k]] != stamp;
+            in->scaleSeen[(size_t)idx[k]] = stamp;
+        }
+        if (same) {
+            void* dRows = nullptr;
+            rc = uploadTransient(in, in->lastSums.rows.data(), in->lastSums.rows.size() * sizeof(int), &dRows); if (rc) return rc;
+            mi355::launchAccumulateSlices(live(in), in->scale[cum], in->sliceMant, in->sliceExp, (const int*)dRows, (int)in->lastSums.rows.size(), in->pairLen,
+                                          in->dPairPos, sign, in->partStart[part], in->partEnd[part]);
+            in->statSliceAccum++;
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     std::vector<const double*> srcs(count);
     std::vector<int> raw(count);
     for (int k = 0; k < count; k++) {
@@ -386,6 +407,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
     in->fuseCherries = !(getenv("BEAGLE_MI355_NO_CHERRY_FUSION") && atoi(getenv("BEAGLE_MI355_NO_CHERRY_FUSION")) != 0);
     in->skipTipLoads = !(getenv("BEAGLE_MI355_NO_LOAD_SKIP") && atoi(getenv("BEAGLE_MI355_NO_LOAD_SKIP")) != 0);
+    in->sliceSums = !(getenv("BEAGLE_MI355_NO_SLICE_SUMS") && atoi(getenv("BEAGLE_MI355_NO_SLICE_SUMS")) != 0);
     in->hostTrace = getenv("BEAGLE_MI355_HOST_TIMING") && atoi(getenv("BEAGLE_MI355_HOST_TIMING")) > 1;     // (a line per slow updatePartials call)
     if (getenv("BEAGLE_MI355_WALK_SPIN_US")) in->walkSpinLimit = (unsigned long long)std::max(0L, atol(getenv("BEAGLE_MI355_WALK_SPIN_US"))) * 100ull;
     if (in->walk && in->fuseWaves && in->fastWalk) {
@@ -1556,7 +1578,7 @@ int beagleMi355WalkHealth(int instance, long* out4) {
     return BEAGLE_SUCCESS;
 }
 
-int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (six values)
+int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (seven values)
     if (mi355::isShardedHandle(instance)) {             // shard 0's
         bool first = true; std::mutex mu;
         return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkLaunchInfo(h, out4); });
@@ -1564,7 +1586,7 @@ int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (six values)
     Instance* in = lookup(instance);
     if (!in || !out4) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out4[0] = in->statTicketWalks; out4[1] = in->statFlagWalks; out4[2] = in->lastLaunchRows; out4[3] = in->lastLaunchSlices;
-    out4[4] = in->statFused; out4[5] = in->statMicroOps;
+    out4[4] = in->statFused; out4[5] = in->statMicroOps; out4[6] = in->statSliceAccum;
     return BEAGLE_SUCCESS;
 }
 

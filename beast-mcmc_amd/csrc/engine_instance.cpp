@@ -180,6 +180,8 @@ void destroy(Instance* in) {
     if (in->bigStage) hipFree(in->bigStage);
     if (in->matStream) hipFree(in->matStream);
     if (in->walkFlags) hipFree(in->walkFlags);
+    if (in->sliceMant) hipFree(in->sliceMant);
+    if (in->sliceExp) hipFree(in->sliceExp);
     for (auto& r : in->resolved) if (r.dProg) hipFree(r.dProg);
     for (int k = 0; k < 2; k++) {
         if (in->exportDev[k]) hipFree(in->exportDev[k]);

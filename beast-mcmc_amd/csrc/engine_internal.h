@@ -70,6 +70,7 @@ struct Instance {
         std::vector<mi355::WalkOp> w; std::vector<mi355::WalkSeg> segs; std::vector<int> deps;
         int maxRange = 0, sinks = 0;                     // (sinks: slices no other slice waits for — one: the whole program leads to its last slice)
         int leaves = 0;                                  // > 0: the device program is laid out for a launch on tickets — its first `leaves` slices wait for nothing
+        std::vector<int> sumRows, wroteScale;            // write-mode programs: the device slices that leave their product of factors behind, the scale buffers the program writes (Instance::lastSums)
         std::vector<const double*> cm; long fused = 0;   // fused cherries (kernels.h WK_CHERRY): per device micro-operation the cherry's two branch matrices (empty: none fused), their number
         long memReads = 0, tipReads = 0, scaleReads = 0, scaleWrites = 0, stored = 0;
         char* dProg = nullptr; size_t dProgBytes = 0; bool dProgValid = false;    // the packed program, resident on the device
@@ -218,6 +219,15 @@ struct Instance {
     // ... and the loop's fetch loads tip states only for children that ARE compact tips (kernels.h WF_NOLOAD1 / 2; programs without
     // write-mode rescaling).  BEAGLE_MI355_NO_LOAD_SKIP=1 at creation: both tip-state loads in every fetch, as before round 6 (A/B runs)
     bool skipTipLoads = true;
+    // Write-mode programs (4 states, one partition): every slice leaves the product of the factors it wrote per pattern — mantissa and binary
+    // exponent, [slice row][pair position] — and an accumulateScaleFactors call over EXACTLY the scale buffers the last such program wrote (what
+    // BEAST issues right behind it: BeagleTreeLikelihood.java:1013-1026) adds a few dozen logarithms per pattern instead of reading a factor per
+    // node (kernels.hip k_accumulateSlices; config A, ALWAYS rescaling: 250 us and 0.8 GB per evaluation).  Anything else — another list, a
+    // scale buffer written since (scaleWriteEpoch) — takes the general kernel.  BEAGLE_MI355_NO_SLICE_SUMS=1 at creation: always the general kernel.
+    bool sliceSums = true;
+    double* sliceMant = nullptr; int* sliceExp = nullptr; size_t sliceRows = 0;
+    struct LastSums { bool valid = false; long epoch = -1, gen = 0; std::vector<int> rows; int nWritten = 0; } lastSums;
+    std::vector<long> scaleGen, scaleSeen; long sliceGen = 0, seenCounter = 0, statSliceAccum = 0;
     long statTicketWalks = 0, statFlagWalks = 0, lastLaunchRows = 0, lastLaunchSlices = 0;      // (beagleMi355WalkLaunchInfo)
     // how long a workgroup of that launch polls before it computes what it waits for itself (kernels_walk4.hip: forward progress does
     // not rest on the dispatch order), in ticks of the device's 100 MHz wall clock: 20 ms — an evaluation of the largest alignment

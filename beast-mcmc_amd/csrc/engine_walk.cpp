@@ -130,6 +130,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     std::vector<int> depsLocal;
     std::vector<int>& devDeps = slot ? slot->deps : depsLocal;     // per device slice: the device slices it waits for (one fused launch)
     std::vector<const double*> cmLocal;
+    std::vector<int> sumRowsLocal, wroteLocal;                     // (a program outside the cache: Resolved::sumRows / wroteScale)
     std::vector<const double*>& cm = slot ? slot->cm : cmLocal;    // per device micro-operation: a fused cherry's two matrices (k_gatherMatrices)
     // 4 states, assembly loop: ALL slices in one launch, dispatched critical path first, every workgroup waiting for the slices
     // whose stored results it reads (planner.h PlanSeg; kernels_walk4.hip) — instead of one launch per wave of slices
@@ -158,8 +159,27 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     std::vector<int> cur;
     // fused cherries (kernels.h WK_CHERRY): the assembly loop only, and no program that rescales in write mode anywhere (the cherry
     // halves of the kernel's table buffers share their LDS with the maximum buffers of write-mode rescaling)
-    bool noWrites = asmLoop && in->walk;
-    if (noWrites) for (const mi355::MicroOp& q : plan.prog) if (q.smode == mi355::PS_WRITE) { noWrites = false; break; }
+    bool anyWrite = false;
+    for (const mi355::MicroOp& q : plan.prog) if (q.smode == mi355::PS_WRITE) { anyWrite = true; break; }
+    const bool noWrites = asmLoop && in->walk && !anyWrite;
+    // write-mode programs: every slice leaves the product of its factors behind (Instance::lastSums); the vectors are named by the last no-op
+    // behind the slice's program.  They are the instance's, so growing them invalidates what other kept programs point at.
+    const bool sums = anyWrite && in->walk && !in->walkT && in->sliceSums && in->partitionCount == 1;
+    std::vector<int>& sumRows = slot ? slot->sumRows : sumRowsLocal;
+    std::vector<int>& wroteScale = slot ? slot->wroteScale : wroteLocal;
+    sumRows.clear(); wroteScale.clear();
+    if (sums && in->sliceRows < plan.segs.size()) {
+        HIP_TRY(hipStreamSynchronize(live(in)));
+        if (in->sliceMant) hipFree(in->sliceMant);
+        if (in->sliceExp) hipFree(in->sliceExp);
+        in->sliceMant = nullptr; in->sliceExp = nullptr; in->sliceRows = 0;
+        const size_t rows = plan.segs.size() + plan.segs.size() / 2 + 8;
+        HIP_TRY(hipMalloc((void**)&in->sliceMant, rows * in->pairLen * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&in->sliceExp, rows * in->pairLen * sizeof(int)));
+        in->sliceRows = rows;
+        in->resolveEpoch++;
+        in->lastSums.valid = false;
+    }
     const bool fuseOk = noWrites && in->fuseCherries;
     // ... and in such programs the loop's fetch skips the tip-state load of a child that is no compact tip (kernels.h WF_NOLOAD1 / 2): a
     // vector-memory instruction less on the CU's address unit for half the children of a tree.  Programs that rescale in write mode keep
@@ -231,7 +251,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + tipOff; in->statTipReads++; }
             if (m.smode != mi355::PS_NONE) {
                 int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-                if (m.smode == mi355::PS_WRITE) { if (in->walkT) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx]; }
+                if (m.smode == mi355::PS_WRITE) { if (in->walkT) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx];
+                                                  if (sums) { wroteScale.push_back(m.scaleIdx); if (sumRows.empty() || sumRows.back() != (int)si) sumRows.push_back((int)si); } }
                 else {
                     if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
                     if (!fold) {
@@ -286,6 +307,10 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         if (!asmLoop && ((int)w.size() - segs[si].progStart) % 2) w.push_back(nop);
         segs[si].progCount = (int)w.size() - segs[si].progStart;
         for (int q = 0; q < (asmLoop ? 3 : 2); q++) w.push_back(nop);
+        if (sums && !sumRows.empty() && sumRows.back() == (int)si) {      // (this slice writes factors: where its product of them goes)
+            w.back().scaleW = in->sliceMant + si * in->pairLen;
+            w.back().store = (double*)(in->sliceExp + si * in->pairLen);
+        }
         // the wait of every stage: "at most N vector-memory instructions outstanding".  Loads and stores share the counter.
         // DEFAULT (strict): N = the LOADS issued behind this micro-operation's own.  Sufficient under the one ordering rule the ISA
         // guides state for this counter — vector-memory LOADS return in the order they were issued: when at most N operations
@@ -355,6 +380,16 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     }
     }
     if (anyScaleWriteIn(in, slot, reuse, statsAtEntry[3])) scalesWritten(in);
+    {   // the slices' products of factors this run leaves behind, and which scale buffers they cover (engine_abi.cpp accumulate)
+        const std::vector<int>& rows = slot ? slot->sumRows : sumRowsLocal;
+        const std::vector<int>& wrote = slot ? slot->wroteScale : wroteLocal;
+        if (!rows.empty()) {
+            if (in->scaleGen.size() < (size_t)in->scaleCount) { in->scaleGen.assign((size_t)in->scaleCount, 0); in->scaleSeen.assign((size_t)in->scaleCount, 0); }
+            const long gen = ++in->sliceGen;
+            for (int idx : wrote) in->scaleGen[(size_t)idx] = gen;
+            in->lastSums.valid = true; in->lastSums.epoch = in->scaleWriteEpoch; in->lastSums.gen = gen; in->lastSums.rows = rows; in->lastSums.nWritten = (int)wrote.size();
+        }
+    }
     if (slot && !slot->folds.empty()) {
         if (slot->foldEpoch != in->scaleWriteEpoch) {
             bool bad = false;

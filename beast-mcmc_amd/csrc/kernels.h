@@ -279,6 +279,11 @@ void launchRootLogLikelihood(hipStream_t stream, const double* root, const doubl
 void launchAccumulateScale(hipStream_t stream, double* cum, const double* const* dSrcs, const int* dRaw,
                            int count, double sign, int pStart, int pEnd);
 
+// The same from what a write-mode walk left behind per SLICE (walk instances, round 6): slice row r holds, per pattern at its position q in
+// the pair-interleaved layout (pairPos[p]; nullptr: walkPairIndex(p)), the product of the factors the slice wrote as mantissa[r * stride + q]
+// x 2^exponent[r * stride + q];  cum[p] += sign * sum over rows[0 .. n) of (log(mantissa) + exponent ln 2), in that order.
+void launchAccumulateSlices(hipStream_t stream, double* cum, const double* mant, const int* expo, const int* dRows, int n, size_t stride,
+                            const unsigned* dPairPos, double sign, int pStart, int pEnd);
 void launchFill(hipStream_t stream, double* dst, double value, int pStart, int pEnd);
 // dst[j][i] = prod_m srcs[m][i] over m in [start[j], start[j + 1]), i < len; worst[j] (zeroed by the caller) = bit pattern of job j's
 // largest product, +infinity for anything not finite (kernels.hip k_foldReciprocals)

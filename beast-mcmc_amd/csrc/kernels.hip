@@ -675,6 +675,29 @@ void launchAccumulateScale(hipStream_t stream, double* cum, const double* const*
         hipLaunchKernelGGL(k_accumulate, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, cum, dSrcs, dRaw, count, sign, pStart, pEnd);
 }
 
+// accumulateScaleFactors over the factors one write-mode walk has just written (engine_abi.cpp accumulate): the walk's slices each left the
+// product of their factors per pattern (tools/gen_walk4_fast.py rescale_block / the loop's exit; k_walk4 likewise), so the sum of the logarithms
+// of a thousand factors is a few dozen logarithms and 12 bytes per slice and pattern instead of 8 bytes per NODE and pattern
+// (config A with ALWAYS rescaling: 0.8 GB and 250 us per evaluation).  Rows are added in the order given: deterministic.
+__global__ __launch_bounds__(256) void k_accumulateSlices(double* __restrict__ cum, const double* __restrict__ mant, const int* __restrict__ expo,
+                                                          const int* __restrict__ rows, int n, size_t stride, const unsigned* __restrict__ pairPos,
+                                                          double sign, int pStart, int pEnd) {
+    const int p = pStart + blockIdx.x * 256 + threadIdx.x;
+    if (p >= pEnd) return;
+    const size_t q = pairPos ? (size_t)pairPos[p] : walkPairIndex((size_t)p);
+    double t = 0.0;
+    for (int k = 0; k < n; k++) {
+        const size_t at = (size_t)rows[k] * stride + q;
+        t += log(mant[at]) + (double)expo[at] * 0.69314718055994530942;
+    }
+    cum[p] += sign * t;
+}
+void launchAccumulateSlices(hipStream_t stream, double* cum, const double* mant, const int* expo, const int* dRows, int n, size_t stride,
+                            const unsigned* dPairPos, double sign, int pStart, int pEnd) {
+    if (n <= 0 || pEnd <= pStart) return;
+    hipLaunchKernelGGL(k_accumulateSlices, dim3((pEnd - pStart + 255) / 256), dim3(256), 0, stream, cum, mant, expo, dRows, n, stride, dPairPos, sign, pStart, pEnd);
+}
+
 __global__ void k_fill(double* dst, double value, int pStart, int pEnd) {
     const int p = pStart + blockIdx.x * 256 + threadIdx.x;
     if (p < pEnd) dst[p] = value;

@@ -233,6 +233,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     const int spOff = (((lane & 3) * 4) + ((lane & 15) >> 2)) * 8;
 
     v4d ACCa = v4d{1.0, 1.0, 1.0, 1.0}, ACCb = ACCa;
+    // the product of the factors this slice writes for the lane's two patterns (category 0's wave), as mantissa x 2^exponent: what the
+    // slice leaves behind for accumulateScaleFactors (kernels.hip k_accumulateSlices) — the same operations as the assembly loop's
+    double pmA = 1.0, pmB = 1.0;
+    int peA = 0, peB = 0;
     const unsigned MI355_CONST* dp = prog + (size_t)progStart * 16;   // the host pads every segment: progCount is even and
     Desc D0 = loadDesc(dp), D1 = loadDesc(dp + 16);                    // two more descriptors (no-ops) follow it
     // the matrix stream: entry k is the [C] matrix tables of the program's k-th micro-operation (k_gatherMatrices)
@@ -302,6 +306,11 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
                          "s_mov_b64 exec, -1\n\ts_waitcnt vmcnt(0)"                                                   \
                          : : "s"(c == 0 ? validA : 0ull), "s"(c == 0 ? validB : 0ull), "v"(oFA >> 2), "v"(oRA),       \
                              "v"(oFB >> 2), "v"(oRB), "v"(ma), "v"(ia), "v"(mb), "v"(ib), "s"(dScale) : "memory");    \
+            if (c == 0) {                                                                                                 \
+                pmA *= ma; pmB *= mb;                                                                                     \
+                peA += __builtin_amdgcn_frexp_exp(pmA); peB += __builtin_amdgcn_frexp_exp(pmB);                           \
+                pmA = __builtin_amdgcn_frexp_mant(pmA); pmB = __builtin_amdgcn_frexp_mant(pmB);                           \
+            }                                                                                                             \
         }                                                                                                                 \
         storeIssue(ra, rb, fl, validA, validB, o.partA, o.partB, dStore);                                                 \
         if (hold) {                                    /* this value waits for its sibling's subtree */                   \
@@ -317,6 +326,14 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
     }
 #undef WALK_STAGE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the last no-op behind the program names the vectors that receive the slice's product of factors (engine_walk.cpp runPlan; null: none)
+    const unsigned MI355_CONST* last = prog + ((size_t)progStart + progCount + 1) * 16;
+    const u64 mantTo = ((u64)last[11] << 32) | last[10], expTo = ((u64)last[5] << 32) | last[4];
+    if (mantTo && c == 0) {
+        double MI355_GLOBAL* m = (double MI355_GLOBAL*)mantTo;
+        int MI355_GLOBAL* x = (int MI355_GLOBAL*)expTo;
+        m[o.tipA] = pmA; m[o.tipB] = pmB; x[o.tipA] = peA; x[o.tipB] = peB;
+    }
 }
 
 // stream[k][c] = the matrix table of micro-operation k, category c (see tipColumn): 2 x 5 columns x 4 doubles, in

@@ -371,8 +371,9 @@ int beagleMi355WalkHealth(int instance, long* out4);
  * form a forest, or BEAGLE_MI355_NO_WALK_TICKETS=1), out[2] / out[3]: slices with workgroups of their own / slices in all, last launch;
  * out[4]: micro-operations that were not part of a device program because their consumer evaluated them inside its own stage (nodes over
  * two compact tips: DESIGN.md 4.1 "fused cherries"; BEAGLE_MI355_NO_CHERRY_FUSION=1: none), out[5]: micro-operations planned, both since
- * the last beagleMi355KernelTimer call.  out6 holds six values. */
-int beagleMi355WalkLaunchInfo(int instance, long* out6);
+ * the last beagleMi355KernelTimer call; out[6]: accumulateScaleFactors calls since creation that were answered from the per-slice products of
+ * factors a write-mode walk had just left behind (BEAGLE_MI355_NO_SLICE_SUMS=1: none).  out7 holds seven values. */
+int beagleMi355WalkLaunchInfo(int instance, long* out7);
 /* The gradient pass (4 states) since instance creation.  A pre-order list without scale indices is held back until a call needs
  * what it writes (or changes what it reads): out[0] lists that ran together with the edge derivatives that followed them (one
  * sweep per tree level; sums and sums of squares), out[1] lists that ran operation by operation, out[2] edge-derivative calls

@@ -42,7 +42,9 @@ class env:
 
 
 def make(wl, fold=True, fast=True):
-    with env(BEAGLE_MI355_NO_SCALE_FOLD="0" if fold else "1", BEAGLE_MI355_NO_FAST_WALK="0" if fast else "1"):
+    # (BEAGLE_MI355_NO_SLICE_SUMS=1: the first — write-mode — evaluation's cumulative buffer from the per-node factors, the same bits on both
+    # kernels; the per-slice products of round 6 depend on the slicing, which the kernels choose differently: tests/test_gpu_slice_sums.py)
+    with env(BEAGLE_MI355_NO_SCALE_FOLD="0" if fold else "1", BEAGLE_MI355_NO_FAST_WALK="0" if fast else "1", BEAGLE_MI355_NO_SLICE_SUMS="1"):
         return BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
 
 

@@ -102,7 +102,10 @@ def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib, cherries_at_61
     vals = {}
     # (4 states: with read-mode folding the unstored nodes' factors are applied in one multiplication — the same numbers in another
     # order, tests/test_gpu_scale_fold.py; bit-equality with the all-stored evaluation is a property of per-node factors)
+    # ... and so is the cumulative buffer's: from the per-node factors (the per-slice products of round 6 follow the slicing, which the
+    # two plans do differently: tests/test_gpu_slice_sums.py holds them to rounding)
     os.environ["BEAGLE_MI355_NO_SCALE_FOLD"] = "1"
+    os.environ["BEAGLE_MI355_NO_SLICE_SUMS"] = "1"
     for flag in ("0", "1"):
         os.environ["BEAGLE_MI355_NO_VIRTUAL"] = flag
         try:
@@ -118,6 +121,7 @@ def test_virtual_and_stored_cherries_agree_bitwise(S, engine_lib, cherries_at_61
             os.environ.pop("BEAGLE_MI355_NO_VIRTUAL", None)
             if flag == "1":
                 os.environ.pop("BEAGLE_MI355_NO_SCALE_FOLD", None)
+                os.environ.pop("BEAGLE_MI355_NO_SLICE_SUMS", None)
     for k, v in vals.items():
         assert v[0] == v[1], (k, v)
 
@@ -135,6 +139,7 @@ def test_steady_state_chain_matches_stored_buffers_bitwise(S, oracle_lib, monkey
     from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
     # (bit-equality with the all-stored chain is a property of per-node scale factors: tests/test_gpu_scale_fold.py holds the folded ones)
     monkeypatch.setenv("BEAGLE_MI355_NO_SCALE_FOLD", "1")
+    monkeypatch.setenv("BEAGLE_MI355_NO_SLICE_SUMS", "1")       # (... and of cumulative buffers formed from them: tests/test_gpu_slice_sums.py holds the per-slice products)
     wl = helpers.random_workload(80, 1500, 4, 4, seed=99) if S == 4 else helpers.random_workload(40, 700, S, 4, seed=99)
     rng = np.random.default_rng(3)
     moves = []

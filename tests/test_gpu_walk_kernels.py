@@ -25,9 +25,14 @@ def evaluate(wl, fast, scheme, traversal, nodes):
     """lnL, site lnL and the partials of `nodes` after a write-mode and a read-mode evaluation."""
     old = os.environ.get("BEAGLE_MI355_NO_FAST_WALK")
     os.environ["BEAGLE_MI355_NO_FAST_WALK"] = "0" if fast else "1"      # read when the instance is created
+    # (BEAGLE_MI355_NO_SLICE_SUMS=1: the cumulative buffer from the per-node factors — which ARE the same bits on every path compared here;
+    # the per-slice products of round 6 depend on how a program is cut into slices, which differs between the kernels / launch forms:
+    # tests/test_gpu_slice_sums.py holds those to rounding)
+    os.environ["BEAGLE_MI355_NO_SLICE_SUMS"] = "1"
     try:
         tl = BeagleTreeLikelihood(wl, rescaling=scheme, delay_rescaling=False, traversal=traversal)
     finally:
+        del os.environ["BEAGLE_MI355_NO_SLICE_SUMS"]
         if old is None:
             del os.environ["BEAGLE_MI355_NO_FAST_WALK"]
         else:
@@ -76,10 +81,11 @@ def test_partial_updates_use_the_assembly_loop_and_match(oracle_lib):
     results = []
     for fast in (True, False):
         os.environ["BEAGLE_MI355_NO_FAST_WALK"] = "0" if fast else "1"
+        os.environ["BEAGLE_MI355_NO_SLICE_SUMS"] = "1"           # (see evaluate)
         try:
             tl = BeagleTreeLikelihood(wl, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
         finally:
-            del os.environ["BEAGLE_MI355_NO_FAST_WALK"]
+            del os.environ["BEAGLE_MI355_NO_FAST_WALK"], os.environ["BEAGLE_MI355_NO_SLICE_SUMS"]
         vals = [tl.getLogLikelihood()]
         r = np.random.default_rng(11)
         for step in range(25):
@@ -97,6 +103,7 @@ def test_partial_updates_use_the_assembly_loop_and_match(oracle_lib):
 
 def _chain_with(wl, scheme, env, moves=10):
     """A chain of full evaluations, branch moves and rejections on an instance created under `env`; everything it computes."""
+    env = dict(env, BEAGLE_MI355_NO_SLICE_SUMS="1")          # (see evaluate)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

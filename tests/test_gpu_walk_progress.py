@@ -26,7 +26,10 @@ pytestmark = pytest.mark.gpu
 
 
 def chain(wl, spin_us, scheme, moves=12, tickets=False):
-    env = {"BEAGLE_MI355_WALK_SPIN_US": None if spin_us is None else str(spin_us), "BEAGLE_MI355_NO_WALK_TICKETS": None if tickets else "1"}
+    # (BEAGLE_MI355_NO_SLICE_SUMS=1: the cumulative buffer from the per-node factors, which are the same bits on both launch forms; the per-slice
+    # products depend on the slice sizes, which the two forms choose differently — tests/test_gpu_slice_sums.py holds those to rounding)
+    env = {"BEAGLE_MI355_WALK_SPIN_US": None if spin_us is None else str(spin_us), "BEAGLE_MI355_NO_WALK_TICKETS": None if tickets else "1",
+           "BEAGLE_MI355_NO_SLICE_SUMS": "1"}
     old = {k: os.environ.get(k) for k in env}
     for k, v in env.items():
         if v is None:

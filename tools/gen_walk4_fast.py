@@ -43,6 +43,9 @@ PA, PB, TIP, SCALE, OM, HOLD, LANE, VST = 96, 97, 98, 99, 100, 101, 104, 105
 SPS = (102, 103, 34)          # the lane's LDS address inside the three table buffers
 H2 = 106                      # the third hold slot lives in registers (LDS holds two: 32 KiB of the 40 a workgroup may use)
 TCAS, TCBS = (36, 37, 38), (39, 40, 41)  # tip-state pairs of a FUSED CHERRY's two tips (B_CHERRY): three pipeline slots
+# ... and, in programs that rescale in write mode (which have no fused cherries: engine_walk.cpp runPlan), the running PRODUCT of the
+# factors the slice has written for the lane's two patterns, as mantissa in [0.5, 1) and binary exponent (rescale_block, category 0's wave)
+PMA, PMB, PEA, PEB = 36, 38, 40, 41
 TBVS = (124, 125, 35)         # the LDS addresses of the three table buffers, in every lane (broadcast reads of a matrix's first column)
 NV = 126
 # scalar (s32..s35 are left to the compiler)
@@ -273,7 +276,16 @@ def rescale_block(tag, SSCALEW):
           "global_store_dwordx2 %s, %s, %s" % (v(T1), v(B2, 2), s(SSCALEW, 2)),
           "global_store_dwordx2 %s, %s, %s offset:8" % (v(RD), v(IB, 2), s(SSCALEW, 2)),
           "s_mov_b64 exec, -1",
-          "s_nop 0",
+          # the slice's product of factors (round 6): what accumulateScaleFactors adds up afterwards is ONE pair of numbers per slice and
+          # pattern instead of one factor per node — the product kept as (mantissa, exponent) so that it cannot leave the range
+          "v_mul_f64 %s, %s, %s" % (v(PMA, 2), v(PMA, 2), v(A2, 2)),
+          "v_mul_f64 %s, %s, %s" % (v(PMB, 2), v(PMB, 2), v(B2, 2)),
+          "v_frexp_exp_i32_f64_e32 %s, %s" % (v(T0), v(PMA, 2)),
+          "v_frexp_exp_i32_f64_e32 %s, %s" % (v(T1), v(PMB, 2)),
+          "v_frexp_mant_f64_e32 %s, %s" % (v(PMA, 2), v(PMA, 2)),
+          "v_frexp_mant_f64_e32 %s, %s" % (v(PMB, 2), v(PMB, 2)),
+          "v_add_u32_e32 %s, %s, %s" % (v(PEA), v(PEA), v(T0)),
+          "v_add_u32_e32 %s, %s, %s" % (v(PEB), v(PEB), v(T1)),
           "s_branch %s" % L("wrb" + tag)]
     return b
 
@@ -617,6 +629,10 @@ def build():
         e("v_mov_b32_e32 %s, %s" % (v(TBVS[j]), s(TBLS[j])))
     for i in range(8):
         e("v_mov_b64 %s, 1.0" % v(ACC + 2 * i, 2))
+    e("v_mov_b64 %s, 1.0" % v(PMA, 2))                                  # the slice's product of written factors: 1 = 0.5 x 2^1
+    e("v_mov_b64 %s, 1.0" % v(PMB, 2))
+    e("v_mov_b32_e32 %s, 0" % v(PEA))
+    e("v_mov_b32_e32 %s, 0" % v(PEB))
     # ---- prologue: fetch micro-operations 0 and 1 into slots 0 and 1, the first child of 0 if it is in memory (no hold slot is
     # in use at the start of a program), descriptor 2 into D; DP -> descriptor 3
     e("s_load_dwordx8 %s, %s, 0x0" % (s(D, 8), s(DP, 2)))
@@ -653,6 +669,20 @@ def build():
     # the evaluation from there (kernels_walk4.hip, root_site4.h) instead of a launch that reads the root's partials back
     for q in range(4):
         e("ds_write_b128 %s, %s offset:%d" % (v(HOLD), v(ACC + 4 * q, 4), 1024 * q))
+    # A slice that rescaled in write mode leaves the product of its factors behind: the third no-op behind the program (DP points one
+    # descriptor past it: every stage has advanced it by one) carries the two vectors that receive it — mantissas (double, the lane's
+    # pair at its position in the pair-interleaved layout) in its scaleW field, exponents (int) in its store field; null: nothing to leave
+    e("s_load_dwordx2 %s, %s, %d" % (s(SSRC2, 2), s(DP, 2), -64 + 40))
+    e("s_load_dwordx2 %s, %s, %d" % (s(SSTORE, 2), s(DP, 2), -64 + 16))
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_cmp_eq_u64 %s, 0" % s(SSRC2, 2))
+    e("s_cbranch_scc1 %s" % L("done"))
+    e("s_cmp_lg_u32 %s, 0" % s(SCNT))
+    e("s_cbranch_scc1 %s" % L("done"))
+    e("v_lshrrev_b32_e32 %s, 1, %s" % (v(T0), v(SCALE)))
+    e("global_store_dwordx4 %s, %s, %s" % (v(SCALE), v(PMA, 4), s(SSRC2, 2)))
+    e("global_store_dwordx2 %s, %s, %s" % (v(T0), v(PEA, 2), s(SSTORE, 2)))
+    e(L("done") + ":")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
