@@ -263,6 +263,16 @@ int oracle_beagleConvolveTransitionMatrices(int h, const int* first, const int* 
  * EIGEN_COMPLEX instance, the real block form of ComplexSubstitutionModel.java:121-173: a real eigenvalue is a 1x1 block as
  * before; a conjugate pair a +/- b i (imaginary parts b, -b in rows i, i+1 of the second half of the eigenvalue array) is the
  * 2x2 block exp(a t) [cos b t, sin b t; -sin b t, cos b t] applied to rows i, i+1 of Uinv. */
+/* PRECISE MODE (oracle_set_precise(1); off by default — the default path below is the pinned restatement and is left textually alone).
+ * A third evaluation for the cases where two correct fp64 evaluations differ by more than the parity bound: a 20- / 61-state transition
+ * matrix is U exp(t Lambda) U^-1, an eigen sum with cancellation, and its small entries come out ~1e-11 relative apart between two
+ * summation orders; a node near the root has multiplied hundreds of them.  In this mode the matrix sums and the pruning sums are formed
+ * in long double (x87: 64-bit mantissa) and rounded to double once per entry, which puts this evaluation ~1e-3 of that spread from the
+ * exact value — enough to say which side of a 2e-10 difference carries what (tests/test_gpu_configs.py). */
+static int g_precise = 0;
+void oracle_set_precise(int on) { g_precise = on != 0; }
+int oracle_precise(void) { return g_precise; }
+
 static void fill_iexp(const Inst* in, const double* Ui, const double* lam, double dist, double* iexp) {
     const int S = in->S;
     for (int k = 0; k < S; k++) {
@@ -301,6 +311,15 @@ static int transition_matrices(Inst* in, int eAll, const int* eIdx, const int* r
         double* M = in->matrices[probIdx[u]];
         for (int c = 0; c < in->C; c++) {
             double dist = t[u] * in->catRates[r][c];
+            if (g_precise && !in->eigenComplex) {           /* (precise mode: exponentials, products and sums in long double) */
+                for (int i = 0; i < S; i++)
+                    for (int j = 0; j < S; j++) {
+                        long double s = 0.0L;
+                        for (int k = 0; k < S; k++) s += (long double)U[i * S + k] * ((long double)Ui[k * S + j] * expl((long double)dist * (long double)lam[k]));
+                        M[(size_t)c * S * S + i * S + j] = s > 0.0L ? (double)s : 0.0;
+                    }
+                continue;
+            }
             fill_iexp(in, Ui, lam, dist, iexp);
             for (int i = 0; i < S; i++)
                 for (int j = 0; j < S; j++) {
@@ -364,6 +383,14 @@ static void states_partials(const Inst* in, const int* s1, const double* m1, con
             const double* x2 = p2 + ((size_t)l * P + k) * S;
             double* d = dest + ((size_t)l * P + k) * S;
             int a = s1[k];
+            if (g_precise) {
+                for (int i = 0; i < S; i++) {
+                    long double sum = 0.0L;
+                    for (int j = 0; j < S; j++) sum += (long double)M2[i * S + j] * (long double)x2[j];
+                    d[i] = (double)((a < S) ? (long double)M1[i * S + a] * sum : sum);
+                }
+                continue;
+            }
             for (int i = 0; i < S; i++) {
                 double sum = 0.0;
                 for (int j = 0; j < S; j++) sum += M2[i * S + j] * x2[j];
@@ -381,6 +408,14 @@ static void partials_partials(const Inst* in, const double* c1, const double* m1
             const double* x1 = c1 + ((size_t)l * P + k) * S;
             const double* x2 = p2 + ((size_t)l * P + k) * S;
             double* d = dest + ((size_t)l * P + k) * S;
+            if (g_precise) {
+                for (int i = 0; i < S; i++) {
+                    long double sum1 = 0.0L, sum2 = 0.0L;
+                    for (int j = 0; j < S; j++) { sum1 += (long double)M1[i * S + j] * (long double)x1[j]; sum2 += (long double)M2[i * S + j] * (long double)x2[j]; }
+                    d[i] = (double)(sum1 * sum2);
+                }
+                continue;
+            }
             for (int i = 0; i < S; i++) {
                 double sum1 = 0.0, sum2 = 0.0;
                 for (int j = 0; j < S; j++) { sum1 += M1[i * S + j] * x1[j]; sum2 += M2[i * S + j] * x2[j]; }

@@ -369,3 +369,29 @@ def test_complex_eigen_systems_against_the_matrix_exponential(S, oracle_lib):
         for c, r in enumerate((0.5, 1.7)):
             assert np.max(np.abs(got[c] - scipy.linalg.expm(qn * t * r))) <= 1e-13
     b.finalize()
+
+
+def test_precise_mode_is_the_same_algorithm_in_wider_arithmetic(oracle_lib):
+    """oracle_set_precise(1) — long double sums, rounded once per entry: the third evaluation tests/test_gpu_configs.py arbitrates with —
+    must reproduce the pinned 4-state value as well as the default path does, sit within the fp64 spread of it at 20 states, and leave the
+    default path untouched when it is switched off again."""
+    import beast_mcmc_amd as bm
+    from beast_mcmc_amd.treelikelihood import BeagleTreeLikelihood, RESCALE_DYNAMIC
+    wl4 = helpers.random_workload(40, 300, 4, 4, seed=12)
+    wl20 = helpers.random_workload(30, 120, 20, 4, seed=13)
+    out = {}
+    for name, wl in (("4", wl4), ("20", wl20)):
+        vals = []
+        for precise in (0, 1, 0):
+            oracle_lib.lib.oracle_set_precise(precise)
+            try:
+                t = BeagleTreeLikelihood(wl, library=oracle_lib, rescaling=RESCALE_DYNAMIC, delay_rescaling=False)
+                vals.append((t.getLogLikelihood(), t.getSiteLogLikelihoods().copy()))
+                t.close()
+            finally:
+                oracle_lib.lib.oracle_set_precise(0)
+        out[name] = vals
+        assert vals[0][0] == vals[2][0] and np.array_equal(vals[0][1], vals[2][1])                # switched off: the pinned path, bit for bit
+        assert helpers.rel_err(vals[1][0], vals[0][0]) <= 1e-12
+        assert np.max(np.abs(vals[1][1] - vals[0][1]) / np.abs(vals[0][1])) <= 1e-10
+    assert oracle_lib.lib.oracle_precise() == 0
