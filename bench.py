@@ -257,14 +257,14 @@ def other_configs(args, budget_s=420.0):
     shorter one: --cpu-seconds 4), cut down to the figures a reader compares.  A child that fails or overruns costs only its own
     entry; the whole record stops starting children once `budget_s` is spent."""
     import subprocess
-    runs = [("B", []), ("C", []), ("D", ["--real", "benchmark1"]), ("E", [])]
+    runs = [("B", [], 50, 5), ("C", [], 50, 5), ("D", ["--real", "benchmark1"], 300, 20), ("E", [], 300, 20)]      # (config, arguments, steps, warm-up steps)
     rec, t_start = {}, time.time()
-    for name, extra in runs:
+    for name, extra, steps, warm in runs:
         left = budget_s - (time.time() - t_start)
         if left < 30.0:
             rec[name] = {"error": "not started: the record's time budget (%.0f s) was spent" % budget_s}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "50", "--warmup", "5", "--no-library-route",
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warm), "--no-library-route",
                "--no-side-records", "--no-other-configs", "--cpu-seconds", "4", "--cache", args.cache] + extra
         t0 = time.time()
         try:
@@ -287,7 +287,7 @@ def other_configs(args, budget_s=420.0):
             "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "gpu_vs_cpu_site_lnL_max_rel_err", "gpu_vs_cpu_partition_lnL_max_rel_err") if k in cb},
             "kernel_source_hash": d.get("kernel_source_hash"), "wall_s": round(time.time() - t0, 1),
         }
-    rec["what"] = ("child runs of this bench.py in the same invocation (--steps 50 --warmup 5, CPU baseline limited to 4 s); "
+    rec["what"] = ("child runs of this bench.py in the same invocation (B, C: --steps 50 --warmup 5; D, E — 0.1 ms per step —: --steps 300 --warmup 20; CPU baseline limited to 4 s); "
                    "D = the reference's benchmark1 alignment, 593 unique patterns")
     return rec
 
