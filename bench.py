@@ -785,8 +785,33 @@ def partial_update_point(bm, wl, tl, raw, moves=300, handles=None):
         mixed = {"what": "a model move (every node recomputed) behind three accepted node-height moves: an operation list the engine has not seen",
                  "ms_per_full_evaluation_median": round(1e3 * full[len(full) // 2], 4), "ms_per_full_evaluation_mean": round(1e3 * sum(full) / len(full), 4),
                  "evaluations": len(full)}
+    # ... and the two mixed as a chain mixes them: nine node-height proposals (half of them rejected) to one model move, 400 proposals —
+    # likelihood evaluations per second of such a chain, beside the headline's chain of model moves only
+    chain_mixed = None
+    if handles:
+        n_prop, n_model, evals = 400, 0, 0
+        t1 = time.perf_counter()
+        for i in range(n_prop):
+            if i % 10 == 9:
+                tl.storeState()
+                tl.apply_model(handles[n_model % 3]); n_model += 1
+                tl.getLogLikelihood(); evals += 1
+            else:
+                node, h = propose()
+                tl.storeState()
+                tl.set_node_height(node, h)
+                tl.getLogLikelihood(); evals += 1
+                if rng.random() < 0.5:
+                    tl.restoreState()
+                    tl.restore_node_height(node, float(height[node]))
+                    tl.getLogLikelihood()                               # (known: no engine call)
+                else:
+                    height[node] = h
+        dtm = time.perf_counter() - t1
+        chain_mixed = {"what": "a chain of 90 % node-height moves (half rejected) and 10 % model moves (every node recomputed, mostly on operation lists the engine has not seen)",
+                       "proposals": n_prop, "model_moves": n_model, "evals_per_s": round(evals / dtm, 1), "us_per_proposal": round(1e6 * dtm / n_prop, 2)}
     return {"what": "one node-height move: path to the root recomputed, 50 % of the proposals restored",
-            "full_evaluation_on_a_new_list": mixed,
+            "full_evaluation_on_a_new_list": mixed, "chain_mixed": chain_mixed,
             "us_per_branch_move": round(1e6 * dt / moves, 2), "moves": moves,
             "ops_per_move": round((c1["operations"] - c0["operations"]) / moves, 2),
             "matrices_per_move": round((c1["matrix_updates"] - c0["matrix_updates"]) / moves, 2),
