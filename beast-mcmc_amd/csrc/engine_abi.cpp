@@ -533,6 +533,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* part
         // this call, MultiPartitionDataLikelihoodDelegate.java:544-553 — moves to the new layout on the device
         forgetFolds(in);
         setPairLayout(in);
+        in->sliceRows = 0; in->lastSums.valid = false;                    // (the per-slice factor products are [row][pairLen]: re-made at the new length on first use)
         if (!in->dPairPos) { int rc = devAlloc(in, (void**)&in->dPairPos, (size_t)in->P * sizeof(unsigned)); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(live(in)));
         HIP_TRY(hipMemcpy(in->dPairPos, in->pairPos.data(), (size_t)in->P * sizeof(unsigned), hipMemcpyHostToDevice));
