@@ -405,6 +405,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
     in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
+    in->xcdAware = !(getenv("BEAGLE_MI355_NO_XCD_MAP") && atoi(getenv("BEAGLE_MI355_NO_XCD_MAP")) != 0);
     in->fuseCherries = !(getenv("BEAGLE_MI355_NO_CHERRY_FUSION") && atoi(getenv("BEAGLE_MI355_NO_CHERRY_FUSION")) != 0);
     in->skipTipLoads = !(getenv("BEAGLE_MI355_NO_LOAD_SKIP") && atoi(getenv("BEAGLE_MI355_NO_LOAD_SKIP")) != 0);
     in->sliceSums = !(getenv("BEAGLE_MI355_NO_SLICE_SUMS") && atoi(getenv("BEAGLE_MI355_NO_SLICE_SUMS")) != 0);

@@ -211,6 +211,9 @@ struct Instance {
     // (kernels_walk4.hip "tickets"; walkTickets: per (slice, pattern group) arrival counts, zero between launches, in the same
     // allocation behind the flags).  BEAGLE_MI355_NO_WALK_TICKETS=1 at creation: dependency flags always (A/B runs, tests)
     bool useTickets = true; unsigned* walkTickets = nullptr;
+    // ... and such a launch, when the chip holds all of it at once and it has rows for every XCD, lays its rows out XCD by XCD (kernels_walk4.hip
+    // launchWalk4Fast: small partitioned alignments).  BEAGLE_MI355_NO_XCD_MAP=1 at creation: always the plain 2-D grid (A/B runs)
+    bool xcdAware = true;
     // 4 states, assembly loop: a node over two compact tips that is not stored, pays no scale factors and is consumed by the very next
     // micro-operation is not a micro-operation of the device program at all: its consumer evaluates it inside its own stage (kernels.h
     // WK_CHERRY; engine_walk.cpp runPlan).  Same arithmetic in the same order: bitwise the unfused program.  A third of a tree's nodes.

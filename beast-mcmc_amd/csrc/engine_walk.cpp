@@ -623,7 +623,7 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
 #endif
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
                            pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed,
-                           pw.leaves > 0 ? in->walkTickets : nullptr, pw.leaves);
+                           pw.leaves > 0 ? in->walkTickets : nullptr, pw.leaves, in->xcdAware);
 #ifdef BEAGLE_MI355_LAB
     if (dTrace) {
         HIP_TRY(hipStreamSynchronize(in->stream));

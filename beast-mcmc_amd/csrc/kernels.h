@@ -182,9 +182,10 @@ struct RootFused {
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
                      const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr,
-                     unsigned* tickets = nullptr, int nLeaves = 0);
+                     unsigned* tickets = nullptr, int nLeaves = 0, bool xcdAware = false);
 // (tickets != nullptr: rows 0 .. nLeaves - 1 of dSegs are the slices without dependencies — the launch's grid —, the rest follow;
-// tickets[row * flagStride + x] are zero before the launch and zero again behind it; deps / flags / epoch / spinLimit unused)
+// tickets[row * flagStride + x] are zero before the launch and zero again behind it; deps / flags / epoch / spinLimit unused;
+// xcdAware: a launch the chip holds all at once lays its rows out so that all pattern groups of a row run on one XCD — kernels_walk4.hip)
 #ifdef BEAGLE_MI355_LAB
 void setWalkTrace(unsigned long long* devicePointer);          // (kernels_walk4.hip g_walkTrace; nullptr: off)
 #endif

@@ -430,18 +430,30 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
                                                              unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs,
-                                                             unsigned* __restrict__ tickets) {
+                                                             unsigned* __restrict__ tickets, int xcdGroups, int nRows) {
     // hold[2][C][4 KiB], table[3][MAXC][320 B], then ONE region shared by the three 1 KiB maximum buffers of write-mode rescaling and
     // the cherry halves of the table buffers, [3][MAXC][320 B] (a program that rescales in write mode has no fused cherries: runPlan)
     extern __shared__ v2d lds[];
-    const int y = (int)blockIdx.y;
+    // Which (slice row y, pattern group bx) this workgroup is.  Plain: the 2-D grid, x fastest.  XCD-aware (xcdGroups > 0; SMALL launches on
+    // tickets only — launchWalk4Fast says when): a 1-D grid in which the rows are taken eight at a time and workgroup id = group * 8 + row
+    // within its eight.  The hardware hands workgroup i to XCD i mod 8, so all pattern groups of a row run on ONE XCD and the row's
+    // descriptors and matrix tables are fetched into one L2 instead of into as many as the row has groups.
+    int y, bx;
+    if (xcdGroups > 0) {
+        const unsigned per = 8u * (unsigned)xcdGroups, batch = blockIdx.x / per, r = blockIdx.x % per;
+        y = (int)(batch * 8u + (r & 7u)); bx = (int)(r >> 3);
+        if (y >= nRows) return;
+    } else { y = (int)blockIdx.y; bx = (int)blockIdx.x; }
+#ifdef BEAGLE_MI355_LAB
+    const int gridX = xcdGroups > 0 ? xcdGroups : (int)gridDim.x;
+#endif
     const WalkSeg MI355_CONST& sg = segs[y];
     const int pStart = sg.pStart, pEnd = sg.pEnd;
-    const int p0 = pStart + (int)blockIdx.x * 128;
+    const int p0 = pStart + bx * 128;
     if (p0 >= pEnd || sg.progCount <= 0) return;      // (no workgroup waits for this one: its dependants leave the same way)
     const unsigned c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef BEAGLE_MI355_LAB
-    unsigned long long* trace = g_walkTrace ? g_walkTrace + ((size_t)y * gridDim.x + blockIdx.x) * 3 : nullptr;
+    unsigned long long* trace = g_walkTrace ? g_walkTrace + ((size_t)y * gridX + bx) * 3 : nullptr;
     if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 #endif
     volatile int* word = reinterpret_cast<volatile int*>(lds);          // (LDS is free between programs)
@@ -463,10 +475,10 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                 bool late = false;
                 if (spinLimit == 0) {                    // (the forward-progress test: nobody waits; whoever finds a flag down serves itself)
                     for (int d = walkLane(); d < depCount; d += 64)
-                        late = late || __hip_atomic_load(flags + (size_t)dl[d] * flagStride + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+                        late = late || __hip_atomic_load(flags + (size_t)dl[d] * flagStride + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
                 } else
                 for (int d = walkLane(); d < depCount && !late; d += 64) {
-                    const unsigned* f = flags + (size_t)dl[d] * flagStride + blockIdx.x;
+                    const unsigned* f = flags + (size_t)dl[d] * flagStride + bx;
                     unsigned polls = 0;
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                         if ((++polls & 31u) == 0u) {
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         if (s != y && !tickets) {                     // (self-serve only)
             if (ss.pStart != pStart || ss.pEnd != pEnd || ss.progCount <= 0) continue;
             if (c == 0 && walkLane() == 0)
-                *word = __hip_atomic_load(flags + (size_t)s * flagStride + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch ? 1 : 0;
+                *word = __hip_atomic_load(flags + (size_t)s * flagStride + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch ? 1 : 0;
             __syncthreads();
             const int done = __builtin_amdgcn_readfirstlane(*word);
             __syncthreads();
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                          [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
                          [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_ENTRY_BYTES_FUSED), [hold] "s"(hold),
                          [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
-                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)blockIdx.x * 128)
+                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)bx * 128)
                      : WALK4_FAST_CLOBBERS);
         if (flags) {
             // (the loop ends with s_waitcnt vmcnt(0): every store of this wave has been acknowledged by memory)
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
             unsigned e = epoch;
             asm volatile("" : "+s"(e));               // (formed here: a vector register that waits across the assembly block would be spilled)
             if (c == 0 && walkLane() == 0)
-                __hip_atomic_store(flags + (size_t)s * flagStride + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flags + (size_t)s * flagStride + bx, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tickets) {
             last = s;
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 #endif
             __syncthreads();                          // every wave's stores are out
             if (c == 0 && walkLane() == 0) {
-                unsigned* t = tickets + (size_t)nxt * flagStride + blockIdx.x;
+                unsigned* t = tickets + (size_t)nxt * flagStride + bx;
                 const unsigned before = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int go = before + 1u == (unsigned)segs[nxt].depCount ? 1 : 0;
                 if (go) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
             if (!go) return;
             s = nxt - 1;                              // (the loop's increment makes it nxt)
 #ifdef BEAGLE_MI355_LAB
-            if (g_walkTrace) { trace = g_walkTrace + ((size_t)nxt * gridDim.x + blockIdx.x) * 3; if (threadIdx.x == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; } }
+            if (g_walkTrace) { trace = g_walkTrace + ((size_t)nxt * gridX + bx) * 3; if (threadIdx.x == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; } }
 #endif
         }
     }
@@ -586,20 +598,28 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
             }
             const int pa = p0 + (lane >> 1) + 32 * (lane & 1), pb = pa + 64;
             const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, pEnd, rootArgs.cum, rootArgs.cumIsRaw, rootArgs.patternWeights, rootArgs.siteLogL));
-            rootPublishGroup(g, lane, (int)blockIdx.x, rootArgs.groups, rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
+            rootPublishGroup(g, lane, (int)bx, rootArgs.groups, rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
         }
     }
 }
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root,
-                     unsigned long long spinLimit, unsigned* selfServed, unsigned* tickets, int nLeaves) {
+                     unsigned long long spinLimit, unsigned* selfServed, unsigned* tickets, int nLeaves, bool xcdAware) {
     if (nSegs <= 0 || maxRange <= 0) return;
     if (tickets) { if (nLeaves <= 0) return; nSegs = nLeaves; flags = nullptr; }          // (the grid: the slices that wait for nothing)
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
     // instead — a mix of programs resident at any moment — is SLOWER, 667 against 621 us on config A: the workgroups of a
     // slice share its descriptors in the scalar cache and its matrix tables in L2; profiles/r03_experiments.txt)
-    const dim3 grid((maxRange + 127) / 128, nSegs), block(64 * C);
+    // XCD-aware layout of the rows (see the kernel): only for launches on tickets (their rows wait for nothing) that the chip holds ALL AT ONCE
+    // and that have rows for every XCD.  A launch of more workgroups than places must not use it: the dispatcher is in order, and when the XCD
+    // whose turn it is has no place free every workgroup behind it waits whichever XCD it is bound for — config A ran 60 % slower that way
+    // (profiles/r06_experiments.txt 5).  Small partitioned alignments (config E: 93 rows of 3-6 groups) are the case it is for: 72 -> 68 us
+    // and a third of the measured traffic, which was every XCD fetching the rows' tables for itself.
+    const int groupsX = (maxRange + 127) / 128;
+    const bool xcd = xcdAware && tickets && nSegs >= 16 && (long)nSegs * groupsX <= 1024;
+    const int xcdGroups = xcd ? groupsX : 0;
+    const dim3 grid = xcd ? dim3((unsigned)(((nSegs + 7) / 8) * 8 * groupsX)) : dim3(groupsX, nSegs), block(64 * C);
     const int maxC = C <= 4 ? 4 : C <= 8 ? 8 : 16;
     // LAB builds only, BEAGLE_MI355_WALK_LDS_PAD=<bytes> (timing experiments: DESIGN.md 4.1's occupancy curve): unused LDS on top, so
     // that fewer workgroups fit a CU — 37.5 KiB: 4 per CU (4 waves per SIMD); + 16 KiB: 3; + 40 KiB: 2; + 100 KiB: 1
@@ -615,11 +635,11 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     ra.rootSeg = -1;
     if (root) ra = *root;
     if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {
