@@ -905,7 +905,16 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
     tl.b.kernelTimer(TIMER_EVERY)                      # (armed before the warm-up, restarted for free when the timed region begins)
     for i in range(args.warmup):
         step(i)
-    elapsed, lnl = timed_loop(torch, device, dist, args.steps, step, after_barrier=tl.b.kernelTimerRestart)
+    per_step = []
+
+    def clocked(i, inner=step):                        # (two perf_counter reads per step: the median beside the mean)
+        t = time.perf_counter()
+        v = inner(i)
+        per_step.append(time.perf_counter() - t)
+        return v
+
+    elapsed, lnl = timed_loop(torch, device, dist, args.steps, clocked, after_barrier=tl.b.kernelTimerRestart)
+    per_step.sort()
     stats = tl.b.walkStats()
     stats["fused_cherries"] = tl.b.walkLaunchInfo()["fused_cherries"]
     kernel_ms, _ = tl.b.kernelTimer(False)
@@ -938,6 +947,7 @@ def bench_partitioned(args, bm, pw, rank, world, dist, device, res, t_gen):
         out = {
             "metric": "full-tree lnL evals/sec", "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step_median": round(1e3 * per_step[len(per_step) // 2], 4) if per_step else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d taxa, unique patterns per partition %s, 4 states, %d rate categories, one instance, "
                                    "updatePartialsByPartition, new branch rates every step" % (pw.name, pw.tip_count, pw.pattern_counts, c_),
