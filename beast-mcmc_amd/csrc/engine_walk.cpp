@@ -688,7 +688,10 @@ int materializeTipUsers(Instance* in, int tip) {
 int walkChunkOps(const Instance* in, int opCount) {
     static const int forced = labEnv("BEAGLE_MI355_CHUNK") ? atoi(labEnv("BEAGLE_MI355_CHUNK")) : -1;
     if (forced >= 0) return forced;
-    if (opCount < 64) return 0;
+    // (a short list is one walk — below 64 operations since round 2; on tickets, where a slice above the first wave costs no workgroup
+    // slots and no polling, from 32: the reference's benchmark2 alignment — 62 taxa, 44 pattern groups — ran its 61 operations as ONE
+    // serial slice, 32 us; cut into three and a top it takes 23: tools/r06_small_sweep.sh)
+    if (opCount < (in->fuseWaves && in->fastWalk && !in->walkT && in->useTickets ? 32 : 64)) return 0;
     const long groups = (in->P + 127) / 128;
     // One launch per wave of slices (BEAGLE_MI355_NO_WALK_FUSION=1, the C++ walk, the T32 walk): about 2 560 workgroups per
     // wave, 2.5 rounds of the 1 024 the chip holds (4 per CU).  Measured with the assembly loop (tools/chunk_sweep.sh): 12 500
