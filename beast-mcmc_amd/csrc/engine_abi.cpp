@@ -358,7 +358,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // 0.64 ms; 32 -> 62, 0.63 ms) while a branch move — which re-evaluates the virtual siblings it passes instead of reading
     // 32 C P bytes each — costs 139 / 141 / 162 us at 16 / 24 / 32.  Small alignments are latency-bound: there the extra
     // micro-operations of long definitions show (12 500 patterns: branch move 65 -> 71 us from cap 8 to 16).
-    int maxVirtSteps = (size_t)categoryCount * patternCount * 32 >= ((size_t)2 << 20) ? 24 : 8;
+    // Round 6, the smallest alignments (a partials buffer under 64 KiB: the reference's benchmark1 alignment, 593 patterns): storing a
+    // node costs next to nothing there, re-evaluating it costs stages — cap 2: a full evaluation 84.5 -> 78.6 us, a branch move 54 -> 46 us,
+    // the mixed chain 12 070 -> 13 800 evaluations/s (tools/r06_vsteps_sweep.sh; at 5 565 patterns the full evaluation already prefers 8).
+    const size_t bufferBytes = (size_t)categoryCount * patternCount * 32;
+    int maxVirtSteps = bufferBytes >= ((size_t)2 << 20) ? 24 : bufferBytes < ((size_t)64 << 10) && stateCount == 4 ? 2 : 8;
     if (labEnv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(labEnv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;
     // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
