@@ -361,7 +361,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // Round 6, the smallest alignments (a partials buffer under 64 KiB: the reference's benchmark1 alignment, 593 patterns): storing a
     // node costs next to nothing there, re-evaluating it costs stages — cap 2: a full evaluation 84.5 -> 78.6 us, a branch move 54 -> 46 us,
     // the mixed chain 12 070 -> 13 800 evaluations/s (tools/r06_vsteps_sweep.sh; at 5 565 patterns the full evaluation already prefers 8).
-    const size_t bufferBytes = (size_t)categoryCount * patternCount * 32;
+    const size_t bufferBytes = (size_t)categoryCount * std::max(patternCount, mi355::tlsWholePatternCount) * 32;      // (a shard of a sharded instance: as the whole would, sharded.h)
     int maxVirtSteps = bufferBytes >= ((size_t)2 << 20) ? 24 : bufferBytes < ((size_t)64 << 10) && stateCount == 4 ? 2 : 8;
     if (labEnv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(labEnv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;

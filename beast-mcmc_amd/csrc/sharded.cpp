@@ -40,6 +40,8 @@
 #include "sharded.h"
 
 namespace mi355 {
+
+thread_local int tlsWholePatternCount = 0;
 namespace {
 
 // one host thread per shard: runs the closures the API thread posts, in order.  post() does not wait: calls that return
@@ -176,8 +178,10 @@ int shardedCreate(int gpuCount, int tipCount, int partialsBufferCount, int compa
         s.device = k % gpuCount;
         s.pStart = start; s.pEnd = start + div + (k < rem ? 1 : 0); start = s.pEnd;
         const int res = s.device + 1;
+        tlsWholePatternCount = patternCount;
         s.handle = beagleCreateInstance(tipCount, partialsBufferCount, compactBufferCount, stateCount, s.pEnd - s.pStart, eigenBufferCount,
                                         matrixBufferCount, categoryCount, scaleBufferCount, &res, 1, preferenceFlags, requirementFlags, nullptr);
+        tlsWholePatternCount = 0;
         if (s.handle < 0) { rc = s.handle; break; }
         if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc((void**)&s.dResult, 4096) != hipSuccess) { rc = BEAGLE_ERROR_OUT_OF_MEMORY; sh->shards.push_back(s); break; }

@@ -7,6 +7,10 @@
 namespace mi355 {
 
 constexpr int SHARD_HANDLE_BASE = 1 << 20;      // handles >= this are sharded instances
+// While the library creates the shards of a sharded instance: the pattern count of the WHOLE alignment.  The size-dependent choices an
+// instance makes for itself (how long a virtual definition may be: engine_abi.cpp) are then made as the single-GPU instance of the same
+// alignment would make them — same programs per pattern, hence the same site values bit for bit (tests/test_gpu_sharded_instance.py).
+extern thread_local int tlsWholePatternCount;
 inline bool isShardedHandle(int h) { return h >= SHARD_HANDLE_BASE; }
 
 int shardedDeviceCountOverride();               // BEAGLE_MI355_SHARDS (tests), 0 = one shard per GPU

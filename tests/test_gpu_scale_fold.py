@@ -78,7 +78,9 @@ def test_folded_and_per_node_factors_agree(T, P, C, kind, S, oracle_lib):
     assert fh["folded_vectors"] > 0 and fh["fold_builds"] > 0 and uh["folded_vectors"] == 0 and uh["fold_builds"] == 0
     assert ustats["scale_reads"] == 3 * (T - 1)                # one vector per node and evaluation ...
     # ... against one per stored node (and per 32 unstored in a row); a ladder stores most of its nodes (only the definition at its foot is unstored)
-    assert fstats["scale_reads"] * (1 if kind == "caterpillar" else 2) < ustats["scale_reads"]
+    # (... and an alignment whose partials buffer is under 64 KiB keeps definitions of two steps only since round 6 — many stored nodes, each paying)
+    tiny = S == 4 and P * C * 32 < (64 << 10)
+    assert fstats["scale_reads"] * (1 if kind == "caterpillar" or tiny else 2) < ustats["scale_reads"]
     assert fstats["stored"] == ustats["stored"] and fstats["micro_ops"] == ustats["micro_ops"]
     for a, b in zip(fv, uv):
         assert helpers.rel_err(a, b) <= 1e-13
