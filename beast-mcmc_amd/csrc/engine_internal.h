@@ -150,6 +150,7 @@ struct Instance {
         const mi355::WalkOp* prog = nullptr; const mi355::WalkSeg* segs = nullptr; const int* deps = nullptr;
         int nSegs = 0, range = 0, flagStride = 0; unsigned epoch = 0;
         int leaves = 0;                                  // > 0: launch on tickets, that many rows
+        unsigned cherryOff = 0;                          // byte offset of the matrix stream's cherry region (0: the program has no fused cherries)
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
     } pendingWalk;
     std::vector<int> snapSourceOf;                       // runPlan's scratch: matrix slot -> the slot its snapshot is being taken from in this plan (-1 between calls)

@@ -411,7 +411,6 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
     // (... | the matrices of fused cherries, two pointers per micro-operation, where the program has any)
     const size_t pairBytes = plan.snapPairs.size() * sizeof(int), cmOff = opBytes + segBytes + ((pairBytes + 15) & ~(size_t)15), cmBytes = cm.size() * sizeof(const double*);
     const size_t total = cmOff + cmBytes;
-    const int entryDoubles = asmLoop ? mi355::WALK_ENTRY_FUSED : mi355::WALK_ENTRY_PLAIN;
     const size_t depOff = opBytes + segs.size() * sizeof(mi355::WalkSeg);
     char* dBase = nullptr;
     const char* stagedProg = nullptr;                             // the program as this call staged it, seen through the ring's device mapping
@@ -459,7 +458,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
     const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
-                                         : w.size() * (size_t)in->C * entryDoubles * sizeof(double) + 1024;   // 2 x 5 columns x 4 per category, twice for the assembly loop (kernels_walk4.hip)
+                                         : w.size() * (size_t)in->C * 40 * sizeof(double) * (cmBytes ? 2 : 1) + 1024;   // 2 x 5 columns x 4 per category; behind them the cherry region (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(live(in)));
         if (in->matStream) hipFree(in->matStream);
@@ -503,13 +502,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         in->pendingCopies.clear();
         mi355::launchGatherAndSnapshot(in->stream, (const mi355::WalkOp*)stagedProg, (int)w.size(), in->C, in->matStream, in->matrices,
                                        (const int*)(stagedProg + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, &L, (int)blocks,
-                                       entryDoubles, cmBytes ? (const double* const*)(stagedProg + cmOff) : nullptr);
+                                       cmBytes ? (const double* const*)(stagedProg + cmOff) : nullptr);
     }
     else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, nullptr, 0,
-                                                           entryDoubles, cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
-    else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, entryDoubles,
+                                                           cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
+    else mi355::launchGatherMatrices(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream,
                                      cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
     if (labEnv("BEAGLE_MI355_DUMP_PLAN")) {           // development (LAB builds): the slices of this program, wave by wave
         fprintf(stderr, "[mi355] plan: %zu micro-ops in %zu slices:", n, segs.size());
@@ -553,6 +552,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         pw.prog = (const mi355::WalkOp*)dBase; pw.segs = (const mi355::WalkSeg*)(dBase + opBytes); pw.deps = (const int*)(dBase + depOff);
         pw.nSegs = (int)segs.size(); pw.range = range; pw.flagStride = flagStride; pw.epoch = in->walkEpoch;
         pw.leaves = slot && reuse ? slot->leaves : (ticket ? plan.leaves : 0);
+        pw.cherryOff = cmBytes ? (unsigned)(w.size() * (size_t)in->C * 40 * sizeof(double)) : 0u;
         in->statFastWalks++; in->statWalks++;
         // hold the launch back for the root call?  (one partition, the whole range, not inside a timer bracket)
         // ... and only a program whose slices ALL lead to one last slice: the root call's result word then says that every workgroup
@@ -591,7 +591,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                                       in->matStream, in->P, in->S, in->C, in->holdSlots)) return BEAGLE_ERROR_GENERAL;
         } else if (fast) {
             mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                   in->matStream, in->P, in->C, (long)in->scaleStride);
+                                   in->matStream, in->P, in->C, (long)in->scaleStride, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, false,
+                                   cmBytes ? (unsigned)(w.size() * (size_t)in->C * 40 * sizeof(double)) : 0u);
             in->statFastWalks++;
         } else
             mi355::launchWalk4(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
@@ -623,7 +624,7 @@ int flushWalk(Instance* in, const mi355::RootFused* root) {
 #endif
     mi355::launchWalk4Fast(in->stream, pw.prog, pw.segs, pw.nSegs, pw.range, in->matStream, in->P, in->C, (long)in->scaleStride,
                            pw.deps, in->walkFlags, pw.epoch, pw.flagStride, root, in->walkSpinLimit, in->walkSelfServed,
-                           pw.leaves > 0 ? in->walkTickets : nullptr, pw.leaves, in->xcdAware);
+                           pw.leaves > 0 ? in->walkTickets : nullptr, pw.leaves, in->xcdAware, pw.cherryOff);
 #ifdef BEAGLE_MI355_LAB
     if (dTrace) {
         HIP_TRY(hipStreamSynchronize(in->stream));

@@ -67,8 +67,8 @@ bool grantDynamicLds(const void* kernel, size_t bytes);
 enum { WK_MEM = 0, WK_TIPS = 1, WK_ACC = 2, WK_H0 = 3, WK_H1 = 4, WK_H2 = 5, WK_CHERRY = 6 };
 // WK_CHERRY (second operand only, k_walk4_fast only; round 6): the child is a node over two compact tips whose own micro-operation the
 // engine has FUSED into this one (engine_walk.cpp runPlan): src2 = the states of its first tip, scale = those of its second (the
-// micro-operation multiplies by no reciprocals: WF_INV and WK_CHERRY exclude each other), the second half of the matrix-stream entry =
-// its two branch-matrix tables.  The kernel forms the child's value — column x column, what the fused micro-operation would have left
+// micro-operation multiplies by no reciprocals: WF_INV and WK_CHERRY exclude each other), the same entry of the matrix stream's cherry
+// region = its two branch-matrix tables.  The kernel forms the child's value — column x column, what the fused micro-operation would have left
 // in ACC, bit for bit — and goes on as for WK_ACC.  A third of a binary tree's internal nodes are such cherries.
 // hold slots the planner may use: k_walk4 keeps all of them in LDS (4 KiB per slot and category: three fit up to 8
 // categories), k_walk4_fast two in LDS and the third in registers
@@ -156,16 +156,14 @@ struct WalkSeg { int progStart, progCount, pStart, pEnd, tStart, depStart, depCo
 // dStream = the matrix stream of the WHOLE device program (launchGatherMatrices), nOps * C * 16 {M1, M2} pairs.
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream,
                  int P, int C, long recipOff);
-// entryDoubles: 40 = an entry is the two tables of the micro-operation's own children (k_walk4); 80 = behind them the two tables of
-// a fused cherry's tips (k_walk4_fast; cherryMats[2 k], [2 k + 1] = its branch matrices, category 0, or null: nothing is written there)
-constexpr int WALK_ENTRY_PLAIN = 40, WALK_ENTRY_FUSED = 80;
-void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, int entryDoubles = WALK_ENTRY_PLAIN,
-                          const double* const* cherryMats = nullptr);
+// cherryMats != nullptr (programs of k_walk4_fast with fused cherries): behind the stream's nOps * C entries a CHERRY region of as many, the
+// tables of cherryMats[2 k], [2 k + 1] (a fused cherry's branch matrices, category 0) at entry k where they are not null
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, const double* const* cherryMats = nullptr);
 // ... and the plan's matrix snapshots (src, dst index pairs) in the same launch; m1 / m2 of freshly snapshotted matrices must point at the sources
 // ... and queued host copies (copies / copyBlocks: kernels_walk4.hip k_gatherAndSnapshot); dProg / dSrcDst may then be the host ring's mapping
 struct HostCopyList;
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
-                             const HostCopyList* copies = nullptr, int copyBlocks = 0, int entryDoubles = WALK_ENTRY_PLAIN, const double* const* cherryMats = nullptr);
+                             const HostCopyList* copies = nullptr, int copyBlocks = 0, const double* const* cherryMats = nullptr);
 // The same walk by the assembly loop (tools/gen_walk4_fast.py).  Requirement: EVERY descriptor carries readable addresses in
 // src1, src2 and scale even where unused (the small loads are unconditional): all-missing tip states / all-one scale factors.
 // deps / flags / epoch / flagStride: all slices of a program in ONE launch (slice y is dispatched before y + 1): a workgroup first
@@ -182,7 +180,8 @@ struct RootFused {
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps = nullptr, unsigned* flags = nullptr, unsigned epoch = 0, int flagStride = 0,
                      const RootFused* root = nullptr, unsigned long long spinLimit = 0, unsigned* selfServed = nullptr,
-                     unsigned* tickets = nullptr, int nLeaves = 0, bool xcdAware = false);
+                     unsigned* tickets = nullptr, int nLeaves = 0, bool xcdAware = false, unsigned cherryOff = 0);
+// (cherryOff: byte offset of the stream's cherry region — nOps * C * 320 of the WHOLE device program — where it has fused cherries)
 // (tickets != nullptr: rows 0 .. nLeaves - 1 of dSegs are the slices without dependencies — the launch's grid —, the rest follow;
 // tickets[row * flagStride + x] are zero before the launch and zero again behind it; deps / flags / epoch / spinLimit unused;
 // xcdAware: a launch the chip holds all at once lays its rows out so that all pattern groups of a row run on one XCD — kernels_walk4.hip)

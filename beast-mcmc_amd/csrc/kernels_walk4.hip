@@ -196,7 +196,6 @@ __device__ __forceinline__ void matvecDpp2(const double sp, const v4d xa, const 
 // out): for each of the two branch matrices five columns of four doubles, T[s][i] = M[i][s] for a state s < 4 and 1 for
 // s = 4 (missing) — what a compact tip child in state s contributes, read with two ds_read_b128 and no select.
 constexpr int WALK_TABLE_BYTES = 320, WALK_TABLE_M2 = 160;
-constexpr int WALK_ENTRY_BYTES_FUSED = WALK_ENTRY_FUSED * 8;      // the assembly loop's stream entry per category: 640 bytes
 __device__ __forceinline__ v4d tipColumn(const char* tbl, unsigned s) {
     const v2d* p = reinterpret_cast<const v2d*>(tbl + (s << 5));
     const v2d lo = p[0], hi = p[1];
@@ -338,20 +337,26 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
 
 // stream[k][c] = the matrix table of micro-operation k, category c (see tipColumn): 2 x 5 columns x 4 doubles, in
 // program order, so that the walk's fetch stage copies it to LDS with ONE instruction at an address it only increments
-// one double of the stream: entry k, category c, position j of E (E = 40: tables of m1, m2; 80: then those of a fused cherry's two
-// matrices, where the micro-operation has one — nothing is written otherwise: the walk never reads that half)
-__device__ __forceinline__ void gatherOne(const WalkOp* __restrict__ prog, double* __restrict__ stream, size_t t, int C, int E,
+// one double of the stream.  MAIN region, t < n C 40: entry k, category c, position j of the 40 doubles of m1's and m2's tables — contiguous,
+// every line written whole.  CHERRY region behind it (only where the program has fused cherries: t up to 2 n C 40), the same indexing: the
+// tables of a fused cherry's two matrices where micro-operation k has one; nothing is written elsewhere (the walk never reads it).
+// (Round 6's first form interleaved the two per entry, 640 bytes: every main half then ended in the middle of a line, and the gather of a
+// small partitioned alignment moved three times its bytes — read-modify-write of the shared lines: config E 13 -> 20 us.)
+__device__ __forceinline__ void gatherOne(const WalkOp* __restrict__ prog, double* __restrict__ stream, size_t t, int n, int C,
                                           const double* const* __restrict__ cherryMats) {
-    const int k = (int)(t / ((size_t)C * E)), r = (int)(t % ((size_t)C * E)), c = r / E, j = r % E, m = j / 20, col = (j % 20) >> 2, i = j & 3;
-    const double* src = m == 0 ? prog[k].m1 : m == 1 ? prog[k].m2 : cherryMats ? cherryMats[2 * k + (m - 2)] : nullptr;
+    const size_t mainCount = (size_t)n * C * 40;
+    const bool cherry = t >= mainCount;
+    const size_t u = cherry ? t - mainCount : t;
+    const int k = (int)(u / ((size_t)C * 40)), r = (int)(u % ((size_t)C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
+    const double* src = cherry ? cherryMats[2 * k + m] : (m == 0 ? prog[k].m1 : prog[k].m2);
     if (!src) return;
     const double MI355_GLOBAL* M = gptr(src) + c * 16;
     stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
 }
-__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int E, const double* const* __restrict__ cherryMats) {
+__global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, const double* const* __restrict__ cherryMats) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * E) return;
-    gatherOne(prog, stream, t, C, E, cherryMats);
+    if (t >= (size_t)n * C * (cherryMats ? 80 : 40)) return;
+    gatherOne(prog, stream, t, n, C, cherryMats);
 }
 
 // The same, and in the same launch the matrix snapshots of the plan's new definitions (kernels.hip k_snapshot): the stream's
@@ -362,7 +367,7 @@ __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, 
 // or an evaluation on a list the engine has not seen is three launches instead of four.
 __global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
                                     double* __restrict__ matrices, const int* __restrict__ srcDst, int elems, int nPairs, const HostCopyList L,
-                                    int E, const double* const* __restrict__ cherryMats) {
+                                    const double* const* __restrict__ cherryMats) {
     if ((int)blockIdx.x >= gatherBlocks + nPairs) { hostCopyBlock(L, blockIdx.x - (unsigned)(gatherBlocks + nPairs)); return; }
     if ((int)blockIdx.x >= gatherBlocks) {
         const int k = (int)blockIdx.x - gatherBlocks;
@@ -372,26 +377,26 @@ __global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restr
         return;
     }
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * E) return;
-    gatherOne(prog, stream, t, C, E, cherryMats);
+    if (t >= (size_t)n * C * (cherryMats ? 80 : 40)) return;
+    gatherOne(prog, stream, t, n, C, cherryMats);
 }
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
-                             const HostCopyList* copies, int copyBlocks, int entryDoubles, const double* const* cherryMats) {
+                             const HostCopyList* copies, int copyBlocks, const double* const* cherryMats) {
     HostCopyList none;
     none.n = 0;
     if (nPairs < 0) nPairs = 0;
     if (!copies || copyBlocks <= 0) { copies = &none; copyBlocks = 0; }
     if (nOps <= 0) { if (copyBlocks) launchHostCopies(stream, *copies, copyBlocks); launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
-    const size_t total = (size_t)nOps * C * entryDoubles;
+    const size_t total = (size_t)nOps * C * (cherryMats ? 80 : 40);
     const int gatherBlocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + nPairs + copyBlocks)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
-                       gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies, entryDoubles, cherryMats);
+                       gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies, cherryMats);
 }
 
-void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, int entryDoubles, const double* const* cherryMats) {
+void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, const double* const* cherryMats) {
     if (nOps <= 0) return;
-    const size_t total = (size_t)nOps * C * entryDoubles;
-    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream, entryDoubles, cherryMats);
+    const size_t total = (size_t)nOps * C * (cherryMats ? 80 : 40);
+    hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream, cherryMats);
 }
 
 // ---- the assembly loop ------------------------------------------------------------------------------------------------
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
                                                              const v2d MI355_CONST* __restrict__ matStream, int P, int C, unsigned recipOffBytes,
                                                              const int MI355_CONST* __restrict__ deps, unsigned* __restrict__ flags, unsigned epoch, int flagStride,
                                                              unsigned long long spinLimit, unsigned* __restrict__ selfServed, const RootFused rootArgs,
-                                                             unsigned* __restrict__ tickets, int xcdGroups, int nRows) {
+                                                             unsigned* __restrict__ tickets, int xcdGroups, int nRows, unsigned cherryOff) {
     // hold[2][C][4 KiB], table[3][MAXC][320 B], then ONE region shared by the three 1 KiB maximum buffers of write-mode rescaling and
     // the cherry halves of the table buffers, [3][MAXC][320 B] (a program that rescales in write mode has no fused cherries: runPlan)
     extern __shared__ v2d lds[];
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 #ifdef BEAGLE_MI355_LAB
     if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
 #endif
-    const unsigned strmStep = (unsigned)C * WALK_ENTRY_BYTES_FUSED;      // (an entry: the micro-operation's two tables, then a fused cherry's: kernels.h)
+    const unsigned strmStep = (unsigned)C * WALK_TABLE_BYTES;
     const unsigned ldsBase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned hold = ldsBase + c * 4096u, holdStride = (unsigned)C * 4096u;
     const unsigned tbl = ldsBase + 2u * holdStride + c * WALK_TABLE_BYTES;
@@ -536,9 +541,9 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         asm volatile(WALK4_FAST_ASM
                      : : [dp] "s"(dp), [strm] "s"(strm), [cnt] "s"(progCount), [tbl] "s"(tbl), [tblStep] "s"((unsigned)(MAXC * WALK_TABLE_BYTES)),
                          [holdStride] "s"(holdStride), [strmStep] "s"(strmStep), [pEnd] "s"(pEnd), [p0] "s"(p0),
-                         [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_ENTRY_BYTES_FUSED), [hold] "s"(hold),
+                         [cP32] "s"(c * (unsigned)P * 32u), [cM] "s"(c * (unsigned)WALK_TABLE_BYTES), [hold] "s"(hold),
                          [exch] "s"(ldsBase + 2u * holdStride + 3u * (unsigned)(MAXC * WALK_TABLE_BYTES)), [ncat] "s"((unsigned)C),
-                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)bx * 128)
+                         [roff] "s"(recipOffBytes), [cat] "s"(c), [t0] "s"(ss.tStart + (int)bx * 128), [choff] "s"(cherryOff)
                      : WALK4_FAST_CLOBBERS);
         if (flags) {
             // (the loop ends with s_waitcnt vmcnt(0): every store of this wave has been acknowledged by memory)
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
 
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
                      long recipOff, const int* dDeps, unsigned* flags, unsigned epoch, int flagStride, const RootFused* root,
-                     unsigned long long spinLimit, unsigned* selfServed, unsigned* tickets, int nLeaves, bool xcdAware) {
+                     unsigned long long spinLimit, unsigned* selfServed, unsigned* tickets, int nLeaves, bool xcdAware, unsigned cherryOff) {
     if (nSegs <= 0 || maxRange <= 0) return;
     if (tickets) { if (nLeaves <= 0) return; nSegs = nLeaves; flags = nullptr; }          // (the grid: the slices that wait for nothing)
     // (x = pattern group, y = slice: the chip holds little more than one slice at a time.  Dispatching slice-index-fastest
@@ -635,11 +640,11 @@ void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSe
     ra.rootSeg = -1;
     if (root) ra = *root;
     if (C <= 4 && ldsPad) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<4>), lds)) return; }
-    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs);
+    if (C <= 4) hipLaunchKernelGGL((k_walk4_fast<4>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs, cherryOff);
     else if (C <= 8) { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<8>), lds)) return;
-                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs); }
+                       hipLaunchKernelGGL((k_walk4_fast<8>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs, cherryOff); }
     else { if (!grantDynamicLds(reinterpret_cast<const void*>(k_walk4_fast<16>), lds)) return;
-           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs); }
+           hipLaunchKernelGGL((k_walk4_fast<16>), grid, block, lds, stream, prog, segs, ms, P, C, recipOffBytes, deps, flags, epoch, flagStride, spinLimit, selfServed, ra, tickets, xcdGroups, nSegs, cherryOff); }
 }
 
 void launchWalk4(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C, long recipOff) {

@@ -54,7 +54,8 @@ TBLS = (25, 26, 57)           # LDS addresses of the three table buffers of this
 D, DFL, DW = 36, 44, 46             # descriptor (kernels.h WalkOp): src1 D+0, src2 D+2, store D+4, scale D+6 | flags s44, (pad s45), the scale buffer a rescaling operation writes s46:47 — two loads: x8 at 0, x4 at 0x20
 CM160 = 83
 TBLBS = (84, 85, 86)          # LDS addresses of the cherry halves of the three table buffers of this wave (TBLS + 3 tblStep)
-S_LAST = 86
+CHOFF = 87                    # byte offset of the stream's cherry region from its main region (the same entry index in both)
+S_LAST = 87
 FLS, SCALEWS = (48, 56, 49), (54, 62, 58)      # what a compute stage needs of its descriptor, stashed by the fetch: three pipeline slots
 SSTORE, SSRC2, SX = 50, 52, 60                 # addresses the rare blocks read again from the descriptor (store, second child, first child)
 MASK = 64                     # MASK + 2 j: lanes whose piece of store instruction j lies inside the pattern range (4 pairs)
@@ -311,13 +312,13 @@ def fetch(tag, slot):
     e("s_cbranch_scc1 %s" % L("n2" + tag))
     e("global_load_ushort %s, %s, %s" % (v(T2S[slot]), v(TIP), s(D + 2, 2)))
     e(L("n2" + tag) + ":")
-    # a fused cherry (B_CHERRY): the second half of the stream entry — the cherry's two matrix tables, 320 bytes further on — into the
-    # cherry half of the table buffer, and its two tips' state pairs (descriptor fields src2 and scale): out of line
+    # a fused cherry (B_CHERRY): the same entry of the stream's cherry region — the cherry's two matrix tables, CHOFF bytes further on —
+    # into the cherry half of the table buffer, and its two tips' state pairs (descriptor fields src2 and scale): out of line
     e("s_bitcmp1_b32 %s, %d" % (s(DFL), B_CHERRY))
     e("s_cbranch_scc1 %s" % L("ch" + tag))
     e(L("chb" + tag) + ":")
     outofline.append([L("ch" + tag) + ":",
-                      "v_add_u32_e32 %s, 0x140, %s" % (v(T1), v(OM)),
+                      "v_add_u32_e32 %s, %s, %s" % (v(T1), s(CHOFF), v(OM)),
                       "s_mov_b32 m0, %s" % s(TBLBS[slot]),
                       "s_mov_b64 exec, 0xfffff",
                       "global_load_lds_dwordx4 %s, %s" % (v(T1), s(STRM, 2)),
@@ -558,6 +559,7 @@ def build():
     e("s_mov_b32 %s, %%[tbl]" % s(TBLS[0]))
     e("s_add_u32 %s, %%[tbl], %%[tblStep]" % s(TBLS[1]))
     e("s_add_u32 %s, %s, %%[tblStep]" % (s(TBLS[2]), s(TBLS[1])))
+    e("s_mov_b32 %s, %%[choff]" % s(CHOFF))
     e("s_mul_i32 %s, %%[tblStep], 3" % s(ST))                           # the cherry halves follow the three table buffers of all waves
     for j in range(3):
         e("s_add_u32 %s, %s, %s" % (s(TBLBS[j]), s(TBLS[j]), s(ST)))
