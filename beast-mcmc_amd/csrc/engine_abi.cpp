@@ -979,6 +979,24 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
+    // 4 states, several eigen systems or rate sets (beagleUpdateTransitionMatricesWithMultipleModels — what every evaluation of a
+    // partitioned chain issues): lengths and the three index lists stay in the staging ring as above and k_transition4 reads them from
+    // there; queued uploads (an eigen system, a rate set) go first, in their own launch — a chain's steady state has none.  One launch
+    // instead of a copy kernel (the ring's 20 bytes per branch over PCIe: 9 us for config E's 12 900 branches) and a transition
+    // kernel (5 us) behind it: the reads now overlap the arithmetic.
+    if (in->S == 4 && in->kernelUploads && in->fuseLaunches && (size_t)count * 20 <= RING_BYTES / 4) {
+        const size_t lenBytes = (size_t)count * sizeof(double), idxBytes = (size_t)count * sizeof(int);
+        const long off = stage(in, lens, lenBytes, lenBytes + 3 * idxBytes);
+        if (off < 0) return BEAGLE_ERROR_GENERAL;
+        memcpy(in->hRing + off + lenBytes, probIdx, idxBytes);
+        memcpy(in->hRing + off + lenBytes + idxBytes, eig.data(), idxBytes);
+        memcpy(in->hRing + off + lenBytes + 2 * idxBytes, rate.data(), idxBytes);
+        const int* rIdx = (const int*)(in->hRingDev + off + lenBytes);
+        mi355::launchTransitionMatrices(live(in), in->matrices, in->eigen, in->rates, rIdx, (const double*)(in->hRingDev + off),
+                                        rIdx + count, rIdx + 2 * (size_t)count, count, in->S, in->C, in->eigenComplex);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
     // one packed upload: [lengths double[count] | matrix idx | eigen idx | rate idx] (each copy is a blit kernel)
     std::vector<char> pack((size_t)count * (sizeof(double) + 3 * sizeof(int)));
     double* pLen = (double*)pack.data();
@@ -1223,7 +1241,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
             const bool last = c + 1 == chunks.size();
             mi355::launchRootLogLikelihoodParts(live(in), chunks[c], in->patternWeights, in->siteLogL, in->blockSums,
                                                 in->hResultDev + 16 + c * mi355::ROOT_MAX_PARTS, in->P, in->S, in->C,
-                                                last ? (unsigned long long*)(in->hResultDev + 8) : nullptr, seq);
+                                                last ? (unsigned long long*)(in->hResultDev + 8) : nullptr, seq, in->fuseLaunches ? in->rootCounter : nullptr);
         }
         HIP_TRY(hipGetLastError());
         volatile unsigned long long* flag = (volatile unsigned long long*)(in->hResult + 8);

@@ -1,6 +1,7 @@
 // engine_walk.cpp — 4 states: a planned program (planner.h) resolved to device addresses and run as pattern-walk launches
 // (kernels_walk4.hip); materialisation of virtual buffers; updatePartials' steady-state fast path.  See engine_internal.h.
 #include "engine_internal.h"
+#include <atomic>
 #include <unordered_map>
 
 using mi355::OpDesc;
@@ -524,6 +525,13 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                         (w[i].flags >> 13) & 3, (w[i].flags & mi355::WF_STORE) ? 1 : 0);
     }
     ph3 = PhaseClock::now();
+    if (in->hostTrace) {                               // (BEAGLE_MI355_HOST_TIMING=2: what the first few gather launches of the process were made of)
+        static std::atomic<int> left{6};
+        if (left.fetch_sub(1) > 0)
+            fprintf(stderr, "[mi355] gather launch: %zu micro-operations x %d categories%s, %zu matrix snapshots, program %s (%zu bytes), %zu queued uploads ride along\n",
+                    w.size(), in->C, cmBytes ? " + cherry region" : "", plan.snapPairs.size() / 2, stagedProg ? "staged by this call" : "on the device",
+                    total, uploadsRide ? (size_t)1 : (size_t)0);
+    }
     if (in->hostTrace && !reuse && n >= 64) {
         auto us = [](PhaseClock::time_point a, PhaseClock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         fprintf(stderr, "[mi355] program of %zu micro-operations resolved: descriptors and waits %.1f us, upload %.1f us, stream + gather launch %.1f us\n", n, us(ph0, ph1), us(ph1, ph2), us(ph2, ph3));

@@ -264,7 +264,8 @@ constexpr int ROOT_MAX_PARTS = 8;
 struct RootPart { const double* root; const double* catWeights; const double* freqs; const double* cum; int cumIsRaw, pStart, pEnd, blockOff; };
 struct RootParts { RootPart p[ROOT_MAX_PARTS]; int n; };
 void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
-                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq);
+                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq, unsigned* counter = nullptr);
+// (counter: a zeroed device word, zero again behind the launch — the last workgroup of the site kernel forms the sums; nullptr: a second launch does)
 
 // site[p] = log(sum_c w_c sum_i pi_i root[c][p][i]) + cum[p];  blockSums[b] = sum_p weight[p]*site[p] over block b
 // then out[0] = sum_b blockSums[b] in a fixed order (deterministic).  cum may be nullptr; cumIsRaw says the

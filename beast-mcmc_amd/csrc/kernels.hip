@@ -537,14 +537,36 @@ void launchRootLogLikelihood(hipStream_t stream, const double* root, const doubl
     if (!counter) hipLaunchKernelGGL(k_rootFinal, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, n, out, flag, seq);
 }
 
+// the sums of parts.n partitions from their workgroups' sums, one after the other, by ONE workgroup (k_rootFinalParts, and the last
+// workgroup of k_rootSiteParts: the same order of additions, the same bits)
+template <bool ATOMIC>
+__device__ __forceinline__ void rootFinalPartsBody(const double* __restrict__ blockSums, const RootParts& parts, double* __restrict__ out, double* sh) {
+    for (int k = 0; k < parts.n; k++) {
+        const RootPart& q = parts.p[k];
+        const int n = (q.pEnd - q.pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
+        double v = 0.0;
+        for (int j = threadIdx.x; j < n; j += ROOT_BLOCK)
+            v += ATOMIC ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(blockSums) + q.blockOff + j,
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        : blockSums[q.blockOff + j];
+        __syncthreads();
+        const double t = blockSum(v, sh);
+        if (threadIdx.x == 0) out[k] = t;
+    }
+}
+
+// counter (nullable): as k_rootSite's — the workgroup that finishes last forms the partitions' sums (no k_rootFinalParts launch)
 __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSiteParts(const RootParts parts, const double* __restrict__ patternWeights,
-                                                              double* __restrict__ siteLogL, double* __restrict__ blockSums, int P, int S, int C) {
+                                                              double* __restrict__ siteLogL, double* __restrict__ blockSums, int P, int S, int C,
+                                                              unsigned* counter, double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[ROOT_BLOCK / 64];
+    __shared__ bool lastBlock;
     const RootPart& q = parts.p[blockIdx.y];
     const int p = q.pStart + blockIdx.x * ROOT_BLOCK + threadIdx.x;
-    if (q.pStart + (int)blockIdx.x * ROOT_BLOCK >= q.pEnd) return;           // (the whole workgroup)
+    const bool active = q.pStart + (int)blockIdx.x * ROOT_BLOCK < q.pEnd;    // (the whole workgroup)
+    if (!active && !counter) return;
     double contrib = 0.0;
-    if (p < q.pEnd) {
+    if (active && p < q.pEnd) {
         double sum = 0.0;
         for (int c = 0; c < C; c++) {
             const double* r = q.root + ((size_t)c * P + p) * S;
@@ -562,31 +584,39 @@ __global__ __launch_bounds__(ROOT_BLOCK) void k_rootSiteParts(const RootParts pa
         siteLogL[p] = site;
         contrib = site * patternWeights[p];
     }
-    const double t = blockSum(contrib, sh);
-    if (threadIdx.x == 0) blockSums[q.blockOff + blockIdx.x] = t;
+    if (active) {                                                            // (uniform over the workgroup)
+        const double t = blockSum(contrib, sh);
+        if (threadIdx.x == 0) blockSums[q.blockOff + blockIdx.x] = t;
+    }
+    if (!counter) return;
+    if (threadIdx.x == 0) {
+        __threadfence();                                                       // my block sum before my ticket
+        lastBlock = atomicAdd(counter, 1u) == gridDim.x * gridDim.y - 1;       // (every workgroup of the grid takes one, the idle ones too)
+    }
+    __syncthreads();
+    if (!lastBlock) return;
+    __threadfence();
+    rootFinalPartsBody<true>(blockSums, parts, out, sh);
+    if (threadIdx.x == 0) {
+        *counter = 0u;                                                         // ready for the next launch (same stream: ordered)
+        if (flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
+    }
 }
 
 __global__ __launch_bounds__(ROOT_BLOCK) void k_rootFinalParts(const double* __restrict__ blockSums, const RootParts parts, double* __restrict__ out,
                                                                unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[ROOT_BLOCK / 64];
-    for (int k = 0; k < parts.n; k++) {
-        const RootPart& q = parts.p[k];
-        const int n = (q.pEnd - q.pStart + ROOT_BLOCK - 1) / ROOT_BLOCK;
-        double v = 0.0;
-        for (int j = threadIdx.x; j < n; j += ROOT_BLOCK) v += blockSums[q.blockOff + j];
-        __syncthreads();
-        const double t = blockSum(v, sh);
-        if (threadIdx.x == 0) out[k] = t;
-    }
+    rootFinalPartsBody<false>(blockSums, parts, out, sh);
     if (threadIdx.x == 0 && flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
 }
 
 void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
-                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq) {
+                                  double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq, unsigned* counter) {
     int maxBlocks = 1;
     for (int k = 0; k < parts.n; k++) maxBlocks = std::max(maxBlocks, (parts.p[k].pEnd - parts.p[k].pStart + ROOT_BLOCK - 1) / ROOT_BLOCK);
-    hipLaunchKernelGGL(k_rootSiteParts, dim3(maxBlocks, parts.n), dim3(ROOT_BLOCK), 0, stream, parts, patternWeights, siteLogL, blockSums, P, S, C);
-    hipLaunchKernelGGL(k_rootFinalParts, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, parts, out, flag, seq);
+    hipLaunchKernelGGL(k_rootSiteParts, dim3(maxBlocks, parts.n), dim3(ROOT_BLOCK), 0, stream, parts, patternWeights, siteLogL, blockSums, P, S, C,
+                       counter, out, flag, seq);
+    if (!counter) hipLaunchKernelGGL(k_rootFinalParts, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, parts, out, flag, seq);
 }
 
 void launchRootFinal(hipStream_t stream, const double* blockSums, int n, double* out, unsigned long long* flag, unsigned long long seq) {

@@ -337,25 +337,30 @@ __global__ __launch_bounds__(MAXT, MINW) void k_walk4(const unsigned MI355_CONST
 
 // stream[k][c] = the matrix table of micro-operation k, category c (see tipColumn): 2 x 5 columns x 4 doubles, in
 // program order, so that the walk's fetch stage copies it to LDS with ONE instruction at an address it only increments
-// one double of the stream.  MAIN region, t < n C 40: entry k, category c, position j of the 40 doubles of m1's and m2's tables — contiguous,
-// every line written whole.  CHERRY region behind it (only where the program has fused cherries: t up to 2 n C 40), the same indexing: the
-// tables of a fused cherry's two matrices where micro-operation k has one; nothing is written elsewhere (the walk never reads it).
+// one COLUMN of the stream (4 doubles, 32 bytes: column `col` of a matrix, or the table's fifth column of ones).  MAIN region, t < n C 10:
+// entry k, category c, column j of the 10 of m1's and m2's tables — contiguous, every line written whole.  CHERRY region behind it (only
+// where the program has fused cherries: t up to 2 n C 10), the same indexing: the tables of a fused cherry's two matrices where
+// micro-operation k has one; nothing is written elsewhere (the walk never reads it).
 // (Round 6's first form interleaved the two per entry, 640 bytes: every main half then ended in the middle of a line, and the gather of a
 // small partitioned alignment moved three times its bytes — read-modify-write of the shared lines: config E 13 -> 20 us.)
 __device__ __forceinline__ void gatherOne(const WalkOp* __restrict__ prog, double* __restrict__ stream, size_t t, int n, int C,
                                           const double* const* __restrict__ cherryMats) {
-    const size_t mainCount = (size_t)n * C * 40;
+    const unsigned mainCount = (unsigned)n * C * 10;                   // (the stream stays below 4 GiB: 32-bit arithmetic throughout)
     const bool cherry = t >= mainCount;
-    const size_t u = cherry ? t - mainCount : t;
-    const int k = (int)(u / ((size_t)C * 40)), r = (int)(u % ((size_t)C * 40)), c = r / 40, j = r % 40, m = j / 20, col = (j % 20) >> 2, i = j & 3;
+    const unsigned u = cherry ? (unsigned)t - mainCount : (unsigned)t;
+    const unsigned k = u / ((unsigned)C * 10), r = u - k * ((unsigned)C * 10), c = r / 10, j = r - c * 10, m = j >= 5 ? 1 : 0, col = j - m * 5;
     const double* src = cherry ? cherryMats[2 * k + m] : (m == 0 ? prog[k].m1 : prog[k].m2);
     if (!src) return;
     const double MI355_GLOBAL* M = gptr(src) + c * 16;
-    stream[t] = col < 4 ? M[i * 4 + col] : 1.0;
+    double2 lo, hi;
+    if (col < 4) { lo = make_double2(M[col], M[4 + col]); hi = make_double2(M[8 + col], M[12 + col]); }
+    else lo = hi = make_double2(1.0, 1.0);
+    double2* out = reinterpret_cast<double2*>(stream + (size_t)t * 4);
+    out[0] = lo; out[1] = hi;
 }
 __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, const double* const* __restrict__ cherryMats) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * (cherryMats ? 80 : 40)) return;
+    if (t >= (size_t)n * C * (cherryMats ? 20 : 10)) return;
     gatherOne(prog, stream, t, n, C, cherryMats);
 }
 
@@ -368,16 +373,21 @@ __global__ void k_gatherMatrices(const WalkOp* __restrict__ prog, int n, int C, 
 __global__ __launch_bounds__(256) void k_gatherAndSnapshot(const WalkOp* __restrict__ prog, int n, int C, double* __restrict__ stream, int gatherBlocks,
                                     double* __restrict__ matrices, const int* __restrict__ srcDst, int elems, int nPairs, const HostCopyList L,
                                     const double* const* __restrict__ cherryMats) {
-    if ((int)blockIdx.x >= gatherBlocks + nPairs) { hostCopyBlock(L, blockIdx.x - (unsigned)(gatherBlocks + nPairs)); return; }
+    // (a snapshot is C x 16 doubles — 512 bytes with four categories —: a thread moves 16 bytes of one, a workgroup 256 / (8 C) of them.
+    // A workgroup per snapshot, as k_snapshot has it for the wide state counts, left three of its four waves idle, and a partitioned
+    // alignment of 1 600 taxa takes 26 000 snapshots per evaluation: config E's launch 11.6 -> see profiles/r06_experiments.txt)
+    const int unitsPerPair = elems >> 1, snapBlocks = (int)(((size_t)nPairs * unitsPerPair + 255) / 256);
+    if ((int)blockIdx.x >= gatherBlocks + snapBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)(gatherBlocks + snapBlocks)); return; }
     if ((int)blockIdx.x >= gatherBlocks) {
-        const int k = (int)blockIdx.x - gatherBlocks;
-        const double* s = matrices + (size_t)srcDst[2 * k] * elems;
-        double* d = matrices + (size_t)srcDst[2 * k + 1] * elems;
-        for (int e = threadIdx.x; e < elems; e += blockDim.x) d[e] = s[e];
+        const unsigned u = ((unsigned)blockIdx.x - (unsigned)gatherBlocks) * 256u + threadIdx.x, k = u / (unsigned)unitsPerPair, e = u - k * (unsigned)unitsPerPair;
+        if ((int)k >= nPairs) return;
+        const double2* s = reinterpret_cast<const double2*>(matrices + (size_t)srcDst[2 * k] * elems);
+        double2* d = reinterpret_cast<double2*>(matrices + (size_t)srcDst[2 * k + 1] * elems);
+        d[e] = s[e];
         return;
     }
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * (cherryMats ? 80 : 40)) return;
+    if (t >= (size_t)n * C * (cherryMats ? 20 : 10)) return;
     gatherOne(prog, stream, t, n, C, cherryMats);
 }
 void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, double* matrices, const int* dSrcDst, int nPairs, int elems,
@@ -387,15 +397,16 @@ void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, 
     if (nPairs < 0) nPairs = 0;
     if (!copies || copyBlocks <= 0) { copies = &none; copyBlocks = 0; }
     if (nOps <= 0) { if (copyBlocks) launchHostCopies(stream, *copies, copyBlocks); launchSnapshotMatrices(stream, matrices, dSrcDst, nPairs, elems); return; }
-    const size_t total = (size_t)nOps * C * (cherryMats ? 80 : 40);
+    const size_t total = (size_t)nOps * C * (cherryMats ? 20 : 10);
     const int gatherBlocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + nPairs + copyBlocks)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
+    const int snapBlocks = (int)(((size_t)nPairs * (elems >> 1) + 255) / 256);          // (elems = 16 C: even)
+    hipLaunchKernelGGL(k_gatherAndSnapshot, dim3((unsigned)(gatherBlocks + snapBlocks + copyBlocks)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream,
                        gatherBlocks, matrices, dSrcDst, elems, nPairs, *copies, cherryMats);
 }
 
 void launchGatherMatrices(hipStream_t stream, const WalkOp* dProg, int nOps, int C, void* dStream, const double* const* cherryMats) {
     if (nOps <= 0) return;
-    const size_t total = (size_t)nOps * C * (cherryMats ? 80 : 40);
+    const size_t total = (size_t)nOps * C * (cherryMats ? 20 : 10);
     hipLaunchKernelGGL(k_gatherMatrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nOps, C, (double*)dStream, cherryMats);
 }
 

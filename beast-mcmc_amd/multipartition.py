@@ -49,6 +49,38 @@ class MultiPartitionTreeLikelihood:
                 depth[n] = depth[tree.parent[n]] + 1
         self.order = [int(n) for n in sorted((n for n in range(T, nodes)), key=lambda n: -depth[n])]
         self.branch_rates = np.ones(nodes)
+        # the reference's model flags (MultiPartitionDataLikelihoodDelegate.java:579-583, :621-647): set at construction, by a model
+        # change (make_dirty / set_substitution_model / set_site_model) — cleared when an evaluation is through (:1116-1117)
+        self.update_substitution_models = [True] * K
+        self.update_site_rate_models = [True] * K
+
+    def make_dirty(self):
+        """The reference's makeDirty (:1229-1234): every model goes out again with the next evaluation."""
+        self.update_substitution_models = [True] * self.K
+        self.update_site_rate_models = [True] * self.K
+
+    def set_substitution_model(self, k, eig=None, freqs=None):
+        """Partition k's substitution model changed (its eigen system and / or root frequencies): the reference's
+        modelChangedEvent -> updateSubstitutionModels (:626-631)."""
+        w = self.pw.parts[k]
+        if eig is not None:
+            w.eig = eig
+        if freqs is not None:
+            w.freqs = np.asarray(freqs, dtype=np.float64)
+        self.update_substitution_models[k] = True
+        if hasattr(self, "_fast"):
+            del self._fast
+
+    def set_site_model(self, k, cat_rates=None, cat_weights=None):
+        """Partition k's site-rate model changed (:640-645)."""
+        w = self.pw.parts[k]
+        if cat_rates is not None:
+            w.cat_rates = np.asarray(cat_rates, dtype=np.float64)
+        if cat_weights is not None:
+            w.cat_weights = np.asarray(cat_weights, dtype=np.float64)
+        self.update_site_rate_models[k] = True
+        if hasattr(self, "_fast"):
+            del self._fast
 
     def pbuf(self, n):
         return n if n < self.T else self.T + 2 * (n - self.T) + int(self.flip[n])
@@ -135,10 +167,12 @@ class MultiPartitionTreeLikelihood:
         pf = int(self.flip[T]) ^ 1
         self.flip[T:] = pf
         self._saved = None
-        for k in range(K):
-            u, ui, lam = f["eig"][k]
-            chk("setEigenDecomposition", fn["SetEigenDecomposition"](h, k, u, ui, lam))
-            chk("setCategoryRatesWithIndex", fn["SetCategoryRatesWithIndex"](h, k, f["rates"][k]))
+        for k in range(K):                                   # (:800-840: only the models flagged as changed go out)
+            if self.update_substitution_models[k]:
+                u, ui, lam = f["eig"][k]
+                chk("setEigenDecomposition", fn["SetEigenDecomposition"](h, k, u, ui, lam))
+            if self.update_site_rate_models[k]:
+                chk("setCategoryRatesWithIndex", fn["SetCategoryRatesWithIndex"](h, k, f["rates"][k]))
         if getattr(self, "_lens_stale", False):                # node heights moved since the tables were built
             self._lens0 = np.array([tree.branch_length(int(n)) for n in self._branch])
             self._lens_stale = False
@@ -162,10 +196,12 @@ class MultiPartitionTreeLikelihood:
                 else:
                     chk("resetScaleFactors", fn["ResetScaleFactors"](h, cum))
                     chk("accumulateScaleFactors", fn["AccumulateScaleFactors"](h, f["scale_idx"], ns, cum))
-        for k in range(K):
+        for k in range(K):                                   # (:1027-1035: weights and root frequencies every time)
             chk("setCategoryWeights", fn["SetCategoryWeights"](h, k, f["weights"][k]))
             chk("setStateFrequencies", fn["SetStateFrequencies"](h, k, f["freqs"][k]))
         self.evaluations += 1
+        self.update_substitution_models = [False] * K        # (:1116-1117)
+        self.update_site_rate_models = [False] * K
         if K > 1:
             rc = fn["CalculateRootLogLikelihoodsByPartition"](h, f["roots"][pf], f["range"], f["range"], f["cum"][self.always_rescale], f["range"], K, 1,
                                                               f["by_part"], f["total"])

@@ -185,6 +185,41 @@ def test_config_e_partitioned_instance_against_per_partition_oracle(always_resca
     assert helpers.rel_err(total, sum(expect)) <= REL_TOL
 
 
+def test_partitioned_instance_sends_a_model_only_when_it_is_flagged(oracle_lib):
+    """The reference's updateSubstitutionModels / updateSiteRateModels flags (MultiPartitionDataLikelihoodDelegate.java:800-840,
+    :1116-1117): an evaluation sends eigen systems and category rates of flagged partitions only.  A changed kappa / alpha of ONE
+    partition must reach the engine (the partition's value follows the oracle's for the new model, the others keep their bits);
+    an unflagged evaluation issues no model call at all."""
+    from beast_mcmc_amd.inputs import substmodel
+    from beast_mcmc_amd.inputs.siterates import GammaSiteRateModel
+    pw = synth.config_e(scale=0.05)
+    tl = MultiPartitionTreeLikelihood(pw)
+    base, _ = tl.calculate()
+    assert not any(tl.update_substitution_models) and not any(tl.update_site_rate_models)
+    calls = []
+    fn = tl.b._f
+    for name in ("SetEigenDecomposition", "SetCategoryRatesWithIndex"):
+        inner = fn[name]
+        fn[name] = (lambda inner, name: lambda *a: (calls.append((name, a[1])), inner(*a))[1])(inner, name)
+    again, _ = tl.calculate()
+    assert calls == [] and np.array_equal(again, base)
+    w = pw.parts[2]
+    tl.set_substitution_model(2, eig=substmodel.hky(2.5, w.freqs))
+    rates, props = GammaSiteRateModel(alpha=0.9, gamma_categories=4).category_rates_and_proportions()
+    tl.set_site_model(1, cat_rates=np.asarray(rates) * 0.4, cat_weights=props)
+    moved, _ = tl.calculate()
+    assert sorted(calls) == [("SetCategoryRatesWithIndex", 1), ("SetEigenDecomposition", 2)], calls
+    assert moved[0] == base[0] and moved[3] == base[3] and moved[1] != base[1] and moved[2] != base[2]
+    for k in (1, 2):
+        o = BeagleTreeLikelihood(pw.parts[k], library=oracle_lib, rescaling=RESCALE_NONE, delay_rescaling=False)
+        v = o.getLogLikelihood()
+        o.close()
+        assert helpers.rel_err(moved[k], v) <= REL_TOL, (k, moved[k], v)
+    tl.make_dirty()
+    assert all(tl.update_substitution_models) and all(tl.update_site_rate_models)
+    tl.close()
+
+
 def test_config_e_node_height_moves_and_their_rejection(oracle_lib):
     """The move a chain makes most, on the partitioned instance: one node height changes, three matrices per partition and the
     path to the root are recomputed (MultiPartitionTreeLikelihood.move_node_height); rejected moves flip the offsets back.

@@ -20,9 +20,13 @@ for L in "$@"; do
     extra=""; [ $c = E ] && extra="--config E"
     rocprofv3 --kernel-trace --stats -d $R/gpurun_out/gather_ab/$n$c -o p -- python $R/bench.py $extra --steps 60 --warmup 10 --no-cpu-baseline --no-live-traffic --no-side-records --no-other-configs > /dev/null 2>&1
     echo "== $n $c kernel stats"; python - <<PY
-import csv,glob
-f=glob.glob("$R/gpurun_out/gather_ab/$n$c/**/*kernel_stats.csv", recursive=True)
-for r in list(csv.DictReader(open(f[0])))[:6]: print(r["Name"][:60], r["Calls"], r["AverageNs"])
+import sqlite3
+db = sqlite3.connect("$R/gpurun_out/gather_ab/$n$c/p_results.db")
+tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+for r in db.execute("select s.kernel_name, count(*), avg(d.end-d.start) from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by sum(d.end-d.start) desc limit 7" % (kd, ks)):
+    print("   %-56s %5d calls  %8.2f us" % (r[0][:56], r[1], r[2] / 1000))
 PY
   done
 done
