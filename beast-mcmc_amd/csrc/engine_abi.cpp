@@ -368,6 +368,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
     in->holdSlots = in->walkT ? 2 : mi355::walkHoldSlots(categoryCount);
     if (labEnv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(labEnv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
+    in->walkTWrite = in->walkT && categoryCount <= mi355::WALK_T32_WRITE_MAX_CATEGORIES && in->holdSlots <= mi355::WALK_T32_WRITE_MAX_HOLD &&
+                     !(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK")) != 0);
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn, in->holdSlots);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);
     in->fastWalk = !(getenv("BEAGLE_MI355_NO_FAST_WALK") && atoi(getenv("BEAGLE_MI355_NO_FAST_WALK")) != 0);

@@ -141,6 +141,9 @@ struct Instance {
     // 16..20 states: operation lists without write-mode rescaling run as the walk's programs on the T32 layout (kernels_mfma.hip
     // k_walkT32: same planner, same descriptors; engine_walk.cpp); everything 4-state-specific (`walk`) stays off
     bool walkT = false;
+    // ... and its write-mode form (k_walkT32W: lists that rescale in write mode stay on the walk; at most four categories, two hold slots;
+    // BEAGLE_MI355_NO_T32_WRITE_WALK=1: they run level by level, as until round 6)
+    bool walkTWrite = false;
     bool fuseLaunches = true;                            // BEAGLE_MI355_NO_LAUNCH_FUSION=1: snapshot / gather and root site / final as separate launches (A/B runs)
     // A one-launch walk whose launch is held back until the next call: calculateRootLogLikelihoods on the result of one of its
     // slices launches it WITH that slice finishing the evaluation (no root kernel, no read-back of the root's partials); any other

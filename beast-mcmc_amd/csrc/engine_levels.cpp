@@ -320,11 +320,11 @@ int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globa
 int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (in->walk) return runOperationsWalk(in, ops, count, tuple, globalCum);
     if (in->walkT) {
-        // the T32 walk has no write mode (a pattern's factor needs all its categories, which sit in different workgroups):
-        // a list that rescales in write mode runs level by level, on operands that exist in memory
+        // a list that rescales in write mode: the walk's write-mode form (kernels_mfma.hip k_walkT32W) up to four categories; beyond
+        // that (a pattern's factor needs all its categories in one workgroup) level by level, on operands that exist in memory
         bool writes = false;
         for (int k = 0; k < count && !writes; k++) writes = ops[(size_t)k * tuple + 1] != BEAGLE_OP_NONE;
-        if (!writes) return runOperationsWalk(in, ops, count, tuple, globalCum);
+        if (!writes || in->walkTWrite) return runOperationsWalk(in, ops, count, tuple, globalCum);
         std::vector<int> need;
         for (int k = 0; k < count; k++) {
             const int* op = ops + (size_t)k * tuple;

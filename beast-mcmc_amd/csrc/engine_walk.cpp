@@ -252,7 +252,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             else if (m.k2 == mi355::PK_TIPS) { if (!in->tipStates[m.a2]) return BEAGLE_ERROR_OUT_OF_RANGE; d.src2 = in->tipStates[m.a2] + tipOff; in->statTipReads++; }
             if (m.smode != mi355::PS_NONE) {
                 int rc = ensureScale(in, m.scaleIdx); if (rc) return rc;
-                if (m.smode == mi355::PS_WRITE) { if (in->walkT) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx];
+                if (m.smode == mi355::PS_WRITE) { if (in->walkT && !in->walkTWrite) return BEAGLE_ERROR_GENERAL; in->scaleIsRaw[m.scaleIdx] = 1; in->statScaleWrites++; d.scaleW = in->scale[m.scaleIdx];
                                                   if (sums) { wroteScale.push_back(m.scaleIdx); if (sumRows.empty() || sumRows.back() != (int)si) sumRows.push_back((int)si); } }
                 else {
                     if (!in->scaleIsRaw[m.scaleIdx]) return BEAGLE_ERROR_OUT_OF_RANGE;   // never written by a rescaling op
@@ -596,7 +596,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         for (size_t i = b; i < e; i++) range = std::max(range, segs[i].pEnd - segs[i].pStart);
         if (in->walkT) {
             if (!mi355::launchWalkT32(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
-                                      in->matStream, in->P, in->S, in->C, in->holdSlots)) return BEAGLE_ERROR_GENERAL;
+                                      in->matStream, in->P, in->S, in->C, in->holdSlots, anyScaleWriteIn(in, slot, reuse, statsAtEntry[3]))) return BEAGLE_ERROR_GENERAL;
         } else if (fast) {
             mi355::launchWalk4Fast(live(in), (const mi355::WalkOp*)dBase, (const mi355::WalkSeg*)(dBase + opBytes) + b, (int)(e - b), range,
                                    in->matStream, in->P, in->C, (long)in->scaleStride, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, false,

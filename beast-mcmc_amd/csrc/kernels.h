@@ -438,7 +438,11 @@ int  pruneBlocksForRange(int S, int range);
 // the same device program (walkT32StreamBytes)
 size_t walkT32StreamBytes(int nEntries, int C);
 void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
-bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots);
+// writeMode (a program with write-mode rescaling in it — k_walkT32W: a workgroup is two tiles x all categories; at most
+// WALK_T32_WRITE_MAX_CATEGORIES of them and two hold slots: false otherwise)
+constexpr int WALK_T32_WRITE_MAX_CATEGORIES = 4, WALK_T32_WRITE_MAX_HOLD = 2;
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
+                   bool writeMode = false);
 // 21..64 states: the column tables of a list's virtual cherries (kernels_mfma.hip k_cherryTables), handed to launchPruneLevelTiled
 size_t cherryTableBytes(int nCherries, int S, int C);
 void launchCherryTables(hipStream_t stream, const CherryDesc* dCherries, int n, const double* matrices, int S, int C, double* out);

@@ -918,6 +918,194 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the same walk with WRITE-mode rescaling (PartialsRescalingScheme ALWAYS, and DYNAMIC's every-100th evaluation) --------------
+// A pattern's factor is the maximum over its states AND its rate categories (GeneralLikelihoodCore.java:281-318 scalePartials), and
+// k_walkT32 keeps a workgroup to ONE category so that its waves can share the matrices: it has no write mode, and until round 6 a
+// list that rescaled ran level by level — every node stored and read back, 32 GB per evaluation of config B, 6.5 ms against the
+// read-mode walk's 2.5.  Here a workgroup is TWO tiles x all C (<= 4) categories, wave = (tile, category): the C waves of a tile
+// leave their per-pattern maxima in LDS on the way into the stage's barrier (which the fragment staging needs anyway: no barrier
+// more), every wave reads the C of them behind it, divides its result — the same two roundings as k_pruneTiledWrite: the stored
+// value times the reciprocal of the factor — and category 0's wave stores the factor.  The price is the matrices: a workgroup
+// stages all C categories' fragments of a micro-operation (30 KB at C = 4, double-buffered: 61 KB) for two tiles instead of one
+// category's 7.7 KB for four; with two hold slots that is 145 KB of LDS — one workgroup of eight waves per CU, the two waves per
+// SIMD k_walkT32 has.  Read-mode and unscaled micro-operations run as there (a DYNAMIC chain's lists that rescale mix both).
+// Seven loads per micro-operation and thread, two micro-operations ahead: four of fragments (C x 480 v2d over 128 C threads:
+// 3.75 each), two state codes, one pair of raw factors; the waits are "all but the seven youngest".
+// max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four state rows of a tile column), in every one of them: gfx950's lane-row
+// swaps — two instructions per 32-bit half and step, no LDS round trip (ds_bpermute, what __shfl_xor compiles to, is one per half and step)
+__device__ __forceinline__ double maxOverRows(double v) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto a1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double w = fmax(__hiloint2double((int)a1[0], (int)a0[0]), __hiloint2double((int)a1[1], (int)a0[1]));
+    lo = (unsigned)__double2loint(w); hi = (unsigned)__double2hiint(w);
+    auto b0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return fmax(__hiloint2double((int)b1[0], (int)b0[0]), __hiloint2double((int)b1[1], (int)b0[1]));
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+                                                     const double* __restrict__ fragStream, int P, int S, int C, int holdSlots) {
+    extern __shared__ double wtLds[];              // frag[2][C * 2 * WT_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles
+    const WalkSeg& sg = segs[blockIdx.y];
+    const int nthr = 128 * C, nw = 2 * C;
+    const int ntile = (P + TILE - 1) / TILE;
+    const int tile1 = (sg.pEnd + TILE - 1) / TILE;
+    const int tileB = sg.pStart / TILE + (int)blockIdx.x * 2;
+    if (tileB >= tile1) return;                    // the whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = wave % C, tw = wave / C;
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool active = tileB + tw < tile1;        // a wave past the end walks the last tile along (barriers, staging, maxima) and stores nothing
+    const int tile = active ? tileB + tw : tile1 - 1;
+    const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+    const int pe = tile * TILE + 2 * m;
+    const bool ine = active && pe >= sg.pStart && pe < sg.pEnd, ino = active && pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
+    const int fragD = C * 2 * WT_FRAG, fragV2 = C * WT_FRAG;           // doubles / v2d per micro-operation (all categories, both children)
+    v2d* hold = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)wave * WT_HOLD_V2D + lane;     // + slot * nw * WT_HOLD_V2D, tile row k at + 64 k
+    v2d* mx = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)holdSlots * nw * WT_HOLD_V2D;     // [parity][wave][16] v2d: (even, odd) maxima of pattern pair m
+    const int nOps = sg.progCount;
+    const WalkOp* dp = prog + sg.progStart;
+    const v2d MI355_GLOBAL* fs = gptr(reinterpret_cast<const v2d*>(fragStream)) + (size_t)sg.progStart * fragV2;
+    const size_t fsStep = (size_t)fragV2;
+    v2d* fragV = reinterpret_cast<v2d*>(wtLds);
+    const int t = threadIdx.x;
+    const bool last4 = t + 3 * nthr < fragV2;      // (96 C of the 128 C threads carry a fourth piece)
+    {   // the first micro-operation's fragments
+        fragV[t] = fs[t]; fragV[t + nthr] = fs[t + nthr]; fragV[t + 2 * nthr] = fs[t + 2 * nthr];
+        if (last4) fragV[t + 3 * nthr] = fs[t + 3 * nthr];
+    }
+    __syncthreads();
+    v2d ACC[WT_NT];
+#pragma unroll
+    for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
+    struct Flight { v2d f0, f1, f2, f3; unsigned t1, t2; v2d sc; };      // one micro-operation's loads (registers written asynchronously: k_walkT32)
+    const unsigned oF0 = (unsigned)t * 16u, oF1 = oF0 + (unsigned)nthr * 16u, oF2 = oF1 + (unsigned)nthr * 16u, oF3 = oF2 + (unsigned)nthr * 16u;
+    const unsigned oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
+    auto issue = [&](Flight& f, const WalkOp& d, const v2d MI355_GLOBAL* fptr) {
+        asm volatile(
+            "global_load_dwordx4 %[f0], %[o0], %[fp]\n\t"
+            "global_load_dwordx4 %[f1], %[o1], %[fp]\n\t"
+            "global_load_dwordx4 %[f2], %[o2], %[fp]\n\t"
+            "global_load_dwordx4 %[f3], %[o3], %[fp]\n\t"
+            "global_load_ushort %[t1], %[oP], %[s1]\n\t"
+            "global_load_ushort %[t2], %[oP], %[s2]\n\t"
+            "global_load_dwordx4 %[sc], %[oS], %[ss]"
+            : [f0] "=&v"(f.f0), [f1] "=&v"(f.f1), [f2] "=&v"(f.f2), [f3] "=&v"(f.f3), [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)
+            : [o0] "v"(oF0), [o1] "v"(oF1), [o2] "v"(oF2), [o3] "v"(oF3), [oP] "v"(oPe), [oS] "v"(oPe8), [fp] "s"(fptr), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
+            : "memory");
+    };
+    auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
+        asm volatile("s_waitcnt vmcnt(7) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
+                     "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
+                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
+                     : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
+    };
+    auto landedFragments = [&](const Flight& f) {
+        asm volatile("s_waitcnt vmcnt(7) ; retires %0 %1 %2 %3" : : "v"(f.f0), "v"(f.f1), "v"(f.f2), "v"(f.f3) : "memory");
+    };
+    Flight A, B;
+    A.f0 = A.f1 = A.f2 = A.f3 = A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
+    // (the first fragments were staged above: A's first issue requests the operands only — four loads nobody waits for would land in
+    // registers the compiler has long given to something else)
+    asm volatile("global_load_ushort %[t1], %[oP], %[s1]\n\t"
+                 "global_load_ushort %[t2], %[oP], %[s2]\n\t"
+                 "global_load_dwordx4 %[sc], %[oS], %[ss]"
+                 : [t1] "=&v"(A.t1), [t2] "=&v"(A.t2), [sc] "=&v"(A.sc)
+                 : [oP] "v"(oPe), [oS] "v"(oPe8), [s1] "s"(dp[0].src1), [s2] "s"(dp[0].src2), [ss] "s"(dp[0].scale) : "memory");
+    issue(B, dp[1], fs + fsStep);
+
+#define WTW_STAGE(CUR, NXT)                                                                                                 \
+    {                                                                                                                     \
+        const WalkOp& d = dp[k];                                                                                          \
+        const unsigned flg = d.flags;                                                                                     \
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3, smode = (flg >> 13) & 3;             \
+        unsigned t1, t2;                                                                                                  \
+        double fe, fo;                                                                                                    \
+        landedOperands(CUR, t1, t2, fe, fo);                                                                              \
+        issue(CUR, dp[k + 2], fs + (size_t)(k + 2) * fsStep);                                                            \
+        const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
+        const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WT_FRAG;                                   \
+        double te[WT_NT], to[WT_NT];                                                                                      \
+        if (k2 == WK_ACC) walkChild5(frag + WT_FRAG, S, false, S, S, ACC, g, fl, te, to);                                 \
+        else {                                                                                                            \
+            v2d b2[WT_NT];                                                                                                \
+            if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);                                    \
+            walkChild5(frag + WT_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);                                    \
+        }                                                                                                                 \
+        const bool rd = smode == WS_READ, wr = smode == WS_WRITE;                                                         \
+        const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;                                              \
+        {                                                                                                                 \
+            v2d b1[WT_NT];                                                                                                \
+            if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);                                    \
+            else if (k1 >= WK_H0) {                                                                                       \
+                const v2d* h = hold + (size_t)(k1 - WK_H0) * nw * WT_HOLD_V2D;                                            \
+                _Pragma("unroll") for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];                                      \
+            }                                                                                                             \
+            double re[WT_NT], ro[WT_NT];                                                                                  \
+            walkChild5(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);                                              \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};   \
+        }                                                                                                                 \
+        /* this (tile, category)'s maxima over the states (rows 4 j + g, g in lanes l ^ 16, l ^ 32) — formed and exchanged by EVERY    \
+           micro-operation, used by those that rescale: straight-line code (a program of this kernel rescales nearly everywhere), and   \
+           a multiplication by 1.0 changes no bit */                                                                     \
+        v2d* mxk = mx + (size_t)(k & 1) * nw * 16;                                                                        \
+        {                                                                                                                 \
+            double me = 0.0, mo = 0.0;                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++)                                                             \
+                if (EXACT || 4 * j + g < S) { me = fmax(me, ACC[j].x); mo = fmax(mo, ACC[j].y); }                         \
+            me = maxOverRows(me); mo = maxOverRows(mo);                                                                   \
+            mxk[wave * 16 + m] = v2d{me, mo};       /* (the four lanes of a pattern pair hold the same two values) */      \
+        }                                                                                                                 \
+        /* the next micro-operation's fragments (issued a stage ago) into the other buffer */                            \
+        landedFragments(NXT);                                                                                             \
+        v2d* fw = fragV + (size_t)((k + 1) & 1) * fragV2;                                                                 \
+        fw[t] = NXT.f0; fw[t + nthr] = NXT.f1; fw[t + 2 * nthr] = NXT.f2;                                                 \
+        if (last4) fw[t + 3 * nthr] = NXT.f3;                                                                             \
+        __syncthreads();                                                                                                  \
+        {                                           /* the factor: the maximum over the tile's C categories; zero or NaN: 1 (k_pruneTiledWrite) */ \
+            double me = 0.0, mo = 0.0;                                                                                    \
+            _Pragma("unroll") for (int cc = 0; cc < WALK_T32_WRITE_MAX_CATEGORIES; cc++) {                                \
+                const v2d v = mxk[(tw * C + (cc < C ? cc : C - 1)) * 16 + m];                                             \
+                me = fmax(me, v.x); mo = fmax(mo, v.y);                                                                   \
+            }                                                                                                             \
+            if (!(me > 0.0)) me = 1.0;                                                                                    \
+            if (!(mo > 0.0)) mo = 1.0;                                                                                    \
+            if (wr && c == 0 && g == 0) { if (ine) d.scaleW[pe] = me; if (ino) d.scaleW[pe + 1] = mo; }                   \
+            const double ie = wr ? 1.0 / me : 1.0, io = wr ? 1.0 / mo : 1.0;                                              \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{ACC[j].x * ie, ACC[j].y * io};                 \
+        }                                                                                                                 \
+        if (flg & WF_STORE) {                                                                                             \
+            char* dst = reinterpret_cast<char*>(d.store + tileBase);                                                      \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) {                                                           \
+                if (EXACT || 4 * j + g < S) {                                                                             \
+                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u))); \
+                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));           \
+                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }                                          \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (hslot) {                                                                                                      \
+            v2d* h = hold + (size_t)(hslot - 1) * nw * WT_HOLD_V2D;                                                       \
+            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];                                         \
+        }                                                                                                                 \
+    }
+    for (int k = 0; k < nOps; k += 2) {            // (even count, two no-ops behind it: k_walkT32)
+        WTW_STAGE(A, B)
+        k++;
+        WTW_STAGE(B, A)
+        k--;
+    }
+#undef WTW_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+static size_t walkT32WLds(int holdSlots, int C) {
+    return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d);
+}
+
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
 static size_t walkT32Lds(int holdSlots) { return (size_t)4 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 4 * WT_HOLD_V2D * sizeof(v2d); }
 
@@ -928,8 +1116,20 @@ void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries
     const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
     hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
 }
-bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots) {
+bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
+                   bool writeMode) {
     if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 20 || (size_t)nSegs * C > 65535) return false;
+    if (writeMode) {                               // a program with write-mode micro-operations: all categories of a tile in one workgroup
+        if (C < 1 || C > WALK_T32_WRITE_MAX_CATEGORIES || holdSlots > WALK_T32_WRITE_MAX_HOLD) return false;
+        const int slots = holdSlots < 1 ? 1 : holdSlots;
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W<true>), 160 * 1024) ||
+            !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W<false>), 160 * 1024)) return false;
+        const dim3 grid((maxRange + 2 * TILE - 1) / (2 * TILE), nSegs), block(128 * C);
+        const size_t lds = walkT32WLds(slots, C);
+        if (S == 20) hipLaunchKernelGGL(k_walkT32W<true>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C, slots);
+        else hipLaunchKernelGGL(k_walkT32W<false>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C, slots);
+        return true;
+    }
     if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<true>), 160 * 1024) ||
         !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<false>), 160 * 1024)) return false;
     const dim3 grid((maxRange + 4 * TILE - 1) / (4 * TILE), nSegs * C), block(MF_BLOCK);
