@@ -929,8 +929,6 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
 // stages all C categories' fragments of a micro-operation (30 KB at C = 4, double-buffered: 61 KB) for two tiles instead of one
 // category's 7.7 KB for four; with two hold slots that is 145 KB of LDS — one workgroup of eight waves per CU, the two waves per
 // SIMD k_walkT32 has.  Read-mode and unscaled micro-operations run as there (a DYNAMIC chain's lists that rescale mix both).
-// Seven loads per micro-operation and thread, two micro-operations ahead: four of fragments (C x 480 v2d over 128 C threads:
-// 3.75 each), two state codes, one pair of raw factors; the waits are "all but the seven youngest".
 // max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four state rows of a tile column), in every one of them: gfx950's lane-row
 // swaps — two instructions per 32-bit half and step, no LDS round trip (ds_bpermute, what __shfl_xor compiles to, is one per half and step)
 __device__ __forceinline__ double maxOverRows(double v) {
@@ -947,7 +945,7 @@ __device__ __forceinline__ double maxOverRows(double v) {
 template <bool EXACT>
 __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
                                                      const double* __restrict__ fragStream, int P, int S, int C, int holdSlots) {
-    extern __shared__ double wtLds[];              // frag[2][C * 2 * WT_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles
+    extern __shared__ double wtLds[];              // frag[2][C * 2 * WT_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles | a spare KB
     const WalkSeg& sg = segs[blockIdx.y];
     const int nthr = 128 * C, nw = 2 * C;
     const int ntile = (P + TILE - 1) / TILE;
@@ -973,50 +971,69 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     const size_t fsStep = (size_t)fragV2;
     v2d* fragV = reinterpret_cast<v2d*>(wtLds);
     const int t = threadIdx.x;
-    const bool last4 = t + 3 * nthr < fragV2;      // (96 C of the 128 C threads carry a fourth piece)
     {   // the first micro-operation's fragments
         fragV[t] = fs[t]; fragV[t + nthr] = fs[t + nthr]; fragV[t + 2 * nthr] = fs[t + 2 * nthr];
-        if (last4) fragV[t + 3 * nthr] = fs[t + 3 * nthr];
+        if (t + 3 * nthr < fragV2) fragV[t + 3 * nthr] = fs[t + 3 * nthr];
     }
     __syncthreads();
     v2d ACC[WT_NT];
 #pragma unroll
     for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
-    struct Flight { v2d f0, f1, f2, f3; unsigned t1, t2; v2d sc; };      // one micro-operation's loads (registers written asynchronously: k_walkT32)
-    const unsigned oF0 = (unsigned)t * 16u, oF1 = oF0 + (unsigned)nthr * 16u, oF2 = oF1 + (unsigned)nthr * 16u, oF3 = oF2 + (unsigned)nthr * 16u;
+    // What a micro-operation needs from memory as a matter of course:
+    //  * its fragments, all categories (C x 480 v2d): ONE micro-operation ahead, by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
+    //    land in 1 KB of LDS at M0, no registers, no ds_write) — four per wave, 128 C threads x 4 x 16 bytes covering the 480 C x 16; the
+    //    fourth piece is short (96 C lanes of the workgroup): its last wave issues it under a partial EXEC, the waves behind it send theirs
+    //    to a spare KB, so that every wave has issued the same number of vector-memory instructions wherever it waits;
+    //  * the two children's state codes and the pair of raw factors: TWO ahead, into registers, as k_walkT32.
+    // Issue order in stage k: [wait: operands of k] DMA(k + 1) x 4, operands(k + 2) x 3, ... [wait: DMA(k + 1)] barrier.  Both waits are
+    // "all but the three youngest": at the stage's start those are operands(k + 1) (DMA(k) was waited for before the last barrier), at
+    // its end operands(k + 2); the compiler's own loads and stores in between only make a wait stricter.  The barrier is the bare
+    // instruction behind that wait (a __syncthreads() would be too — the compiler does not see the DMA — but says less).
+    struct Flight { unsigned t1, t2; v2d sc; };                        // (registers written asynchronously: k_walkT32)
+    const unsigned oF0 = (unsigned)t * 16u, oF1 = oF0 + (unsigned)nthr * 16u, oF2 = oF1 + (unsigned)nthr * 16u;
+    const int n3 = 96 * C - 64 * wave;                                 // lanes of this wave that carry a fourth piece
+    const unsigned oF3 = n3 > 0 ? oF2 + (unsigned)nthr * 16u : oF0;
+    const unsigned long long mask3 = n3 >= 64 || n3 <= 0 ? ~0ull : (1ull << n3) - 1ull;
+    const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (the dynamic LDS starts behind the static: there is none)
+    const unsigned ldsSpare = ldsBase + (unsigned)(2 * fragD) * 8u + (unsigned)(holdSlots * nw * WT_HOLD_V2D + 2 * nw * 16) * 16u;
+    const unsigned ldsW = ldsBase + (unsigned)wave * 1024u, pieceStep = (unsigned)nthr * 16u;
     const unsigned oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
-    auto issue = [&](Flight& f, const WalkOp& d, const v2d MI355_GLOBAL* fptr) {
+    auto issue = [&](Flight& f, const WalkOp& d) {
         asm volatile(
-            "global_load_dwordx4 %[f0], %[o0], %[fp]\n\t"
-            "global_load_dwordx4 %[f1], %[o1], %[fp]\n\t"
-            "global_load_dwordx4 %[f2], %[o2], %[fp]\n\t"
-            "global_load_dwordx4 %[f3], %[o3], %[fp]\n\t"
             "global_load_ushort %[t1], %[oP], %[s1]\n\t"
             "global_load_ushort %[t2], %[oP], %[s2]\n\t"
             "global_load_dwordx4 %[sc], %[oS], %[ss]"
-            : [f0] "=&v"(f.f0), [f1] "=&v"(f.f1), [f2] "=&v"(f.f2), [f3] "=&v"(f.f3), [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)
-            : [o0] "v"(oF0), [o1] "v"(oF1), [o2] "v"(oF2), [o3] "v"(oF3), [oP] "v"(oPe), [oS] "v"(oPe8), [fp] "s"(fptr), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
+            : [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)
+            : [oP] "v"(oPe), [oS] "v"(oPe8), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
             : "memory");
     };
+    auto dma = [&](const v2d MI355_GLOBAL* fptr, unsigned buf) {       // buf: LDS byte address of the fragment buffer that receives the entry at fptr
+        unsigned keep;
+        unsigned long long ex;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(buf + ldsW - ldsBase), l1 = l0 + pieceStep, l2 = l1 + pieceStep;
+        const unsigned l3 = __builtin_amdgcn_readfirstlane(n3 > 0 ? l2 + pieceStep : ldsSpare);
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
+            "s_mov_b32 m0, %[l1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[fp]\n\t"
+            "s_mov_b32 m0, %[l2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[fp]\n\t"
+            "s_mov_b32 m0, %[l3]\n\ts_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], %[m3]\n\tglobal_load_lds_dwordx4 %[o3], %[fp]\n\ts_mov_b64 exec, %[ex]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep), [ex] "=&s"(ex)
+            : [l0] "s"(l0), [l1] "s"(l1), [l2] "s"(l2), [l3] "s"(l3), [o0] "v"(oF0), [o1] "v"(oF1), [o2] "v"(oF2), [o3] "v"(oF3), [fp] "s"(fptr), [m3] "s"(mask3)
+            : "memory", "scc");
+    };
     auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
-        asm volatile("s_waitcnt vmcnt(7) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
+        asm volatile("s_waitcnt vmcnt(3) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
                      "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
                      : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
     };
-    auto landedFragments = [&](const Flight& f) {
-        asm volatile("s_waitcnt vmcnt(7) ; retires %0 %1 %2 %3" : : "v"(f.f0), "v"(f.f1), "v"(f.f2), "v"(f.f3) : "memory");
-    };
     Flight A, B;
-    A.f0 = A.f1 = A.f2 = A.f3 = A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
-    // (the first fragments were staged above: A's first issue requests the operands only — four loads nobody waits for would land in
-    // registers the compiler has long given to something else)
-    asm volatile("global_load_ushort %[t1], %[oP], %[s1]\n\t"
-                 "global_load_ushort %[t2], %[oP], %[s2]\n\t"
-                 "global_load_dwordx4 %[sc], %[oS], %[ss]"
-                 : [t1] "=&v"(A.t1), [t2] "=&v"(A.t2), [sc] "=&v"(A.sc)
-                 : [oP] "v"(oPe), [oS] "v"(oPe8), [s1] "s"(dp[0].src1), [s2] "s"(dp[0].src2), [ss] "s"(dp[0].scale) : "memory");
-    issue(B, dp[1], fs + fsStep);
+    A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
+    issue(A, dp[0]);
+    issue(B, dp[1]);
+    const unsigned fragBytes = (unsigned)fragD * 8u;
 
 #define WTW_STAGE(CUR, NXT)                                                                                                 \
     {                                                                                                                     \
@@ -1026,7 +1043,8 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
         unsigned t1, t2;                                                                                                  \
         double fe, fo;                                                                                                    \
         landedOperands(CUR, t1, t2, fe, fo);                                                                              \
-        issue(CUR, dp[k + 2], fs + (size_t)(k + 2) * fsStep);                                                            \
+        dma(fs + (size_t)(k + 1) * fsStep, ldsBase + (unsigned)((k + 1) & 1) * fragBytes);                                \
+        issue(CUR, dp[k + 2]);                                                                                            \
         const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
         const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WT_FRAG;                                   \
         double te[WT_NT], to[WT_NT];                                                                                      \
@@ -1060,12 +1078,8 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
             me = maxOverRows(me); mo = maxOverRows(mo);                                                                   \
             mxk[wave * 16 + m] = v2d{me, mo};       /* (the four lanes of a pattern pair hold the same two values) */      \
         }                                                                                                                 \
-        /* the next micro-operation's fragments (issued a stage ago) into the other buffer */                            \
-        landedFragments(NXT);                                                                                             \
-        v2d* fw = fragV + (size_t)((k + 1) & 1) * fragV2;                                                                 \
-        fw[t] = NXT.f0; fw[t + nthr] = NXT.f1; fw[t + 2 * nthr] = NXT.f2;                                                 \
-        if (last4) fw[t + 3 * nthr] = NXT.f3;                                                                             \
-        __syncthreads();                                                                                                  \
+        /* the next micro-operation's fragments have landed in the other buffer (this wave's share: the barrier makes it everybody's) */ \
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
         {                                           /* the factor: the maximum over the tile's C categories; zero or NaN: 1 (k_pruneTiledWrite) */ \
             double me = 0.0, mo = 0.0;                                                                                    \
             _Pragma("unroll") for (int cc = 0; cc < WALK_T32_WRITE_MAX_CATEGORIES; cc++) {                                \
@@ -1103,7 +1117,7 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 static size_t walkT32WLds(int holdSlots, int C) {
-    return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d);
+    return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d) + 1024;   // (+ the spare KB)
 }
 
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
