@@ -67,6 +67,26 @@ def main():
         allrec = {}
     allrec[config] = rec
     json.dump(allrec, open(path, "w"), indent=1)
+    # every kernel of the run, not only the hot one: HBM bytes per evaluation by kernel (same corrections), so that what the
+    # configuration moves beyond its hot kernel — gathers, snapshots, matrices, root — has a name
+    by = {}
+    evals_of = {}
+    for sub, name, factor in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
+        evals_of[sub] = max(1, int(bench_line("bench_%s.json" % sub).get("evaluations_total", 1)))
+        for r in counter_rows(src, sub, ""):
+            if r["Counter_Name"] != name:
+                continue
+            kn = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mi355::", "")[:44]
+            e = by.setdefault(kn, {"fetch": 0.0, "write": 0.0, "n": 0})
+            e[sub] += float(r["Counter_Value"]) * 1024.0 * factor
+            e["n"] += 1 if sub == "fetch" else 0
+    if by:
+        with open(os.path.join(out, tag + "_traffic_by_kernel.txt"), "w") as fh:
+            fh.write("# HBM bytes per evaluation by kernel, config %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH x2, x1024 B per unit);\n"
+                     "# %d / %d evaluations in the two passes, set-up launches included (divided over the same evaluations)\n" % (config, evals_of["fetch"], evals_of["write"]))
+            fh.write("%-46s %10s %14s %14s\n" % ("kernel", "launches", "read MB/eval", "written MB/eval"))
+            for kn, e in sorted(by.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"])):
+                fh.write("%-46s %10d %14.2f %14.2f\n" % (kn, e["n"], e["fetch"] / evals_of["fetch"] / 1e6, e["write"] / evals_of["write"] / 1e6))
     # SQ pass
     agg = {}
     for r in counter_rows(src, "sq", kernel):
