@@ -815,44 +815,61 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     v2d ACC[WT_NT];
 #pragma unroll
     for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
-    // Everything a micro-operation needs from memory as a matter of course — its 6.4 KB of fragments (two 16-byte loads per
-    // thread), the two children's state codes (one ushort each: the lane's two patterns are neighbours), the raw scale factors
-    // (one 16-byte load) — is requested TWO micro-operations ahead, by the same five instructions whatever the kinds are (the
-    // host points unused operands at dummies, engine_walk.cpp), so the waits are constants: "all but the five youngest loads".
-    // Loads return in issue order; stores and the compiler's own loads in the queue only make a wait stricter.  The compiler
-    // cannot express that (it drains the queue at the first use), hence inline assembly, as in kernels_walk4.hip.  A child's
-    // PARTIALS in memory are rare (20 of 499 micro-operations of config B) and are read where they are needed.
-    struct Flight { v2d f0, f1; unsigned t1, t2; v2d sc; };          // one micro-operation's loads (registers written asynchronously)
+    // What a micro-operation needs from memory as a matter of course — the host points unused operands at dummies, engine_walk.cpp, so
+    // the same instructions go out whatever the kinds are and the waits are constants:
+    //  * its 7.7 KB of fragments (480 v2d): ONE micro-operation ahead, by LDS-DMA (round 6; global_load_lds_dwordx4 — 64 lanes x 16
+    //    bytes land in 1 KB of LDS at M0: no registers, no ds_write; rounds 3-5 took them through registers two ahead), two per wave:
+    //    256 threads x 2 x 16 bytes over the 480 x 16 — the second piece is short (224 lanes of the workgroup): wave 3 issues it with
+    //    half its EXEC;
+    //  * the two children's state codes (one ushort each: the lane's two patterns are neighbours) and the raw scale factors (one
+    //    16-byte load): TWO ahead, into registers.
+    // Issue order in stage k: [wait: operands of k] DMA(k + 1) x 2, operands(k + 2) x 3, ... [wait: DMA(k + 1)] barrier.  Both waits
+    // are "all but the three youngest": at the stage's start those are operands(k + 1) (DMA(k) was waited for before the last
+    // barrier), at its end operands(k + 2).  Loads return in issue order; stores and the compiler's own loads in the queue only make a
+    // wait stricter.  The compiler cannot express that (it drains the queue at the first use), hence inline assembly, as in
+    // kernels_walk4.hip.  A child's PARTIALS in memory are rare (20 of 499 micro-operations of config B) and are read where needed.
+    struct Flight { unsigned t1, t2; v2d sc; };                      // one micro-operation's operand loads (registers written asynchronously)
     const unsigned oFrag = (unsigned)threadIdx.x * 16u, oFrag2 = oFrag + 4096u, oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
-    auto issue = [&](Flight& f, const WalkOp& d, const v2d MI355_GLOBAL* fptr) {
+    const unsigned long long mask2 = wave == 3 ? 0xffffffffull : ~0ull;                   // (480 - 256 = 224 lanes: three waves and a half)
+    const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (the dynamic LDS starts behind the static: there is none)
+    const unsigned ldsW = ldsBase + (unsigned)wave * 1024u, fragBytes = (unsigned)(2 * WT_FRAG) * 8u;
+    auto issue = [&](Flight& f, const WalkOp& d) {
         asm volatile(
-            "global_load_dwordx4 %[f0], %[oF], %[fp]\n\t"
-            "global_load_dwordx4 %[f1], %[oF2], %[fp]\n\t"
             "global_load_ushort %[t1], %[oP], %[s1]\n\t"
             "global_load_ushort %[t2], %[oP], %[s2]\n\t"
             "global_load_dwordx4 %[sc], %[oS], %[ss]"
-            : [f0] "=&v"(f.f0), [f1] "=&v"(f.f1), [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)      /* (pure outputs: a tie to the old value
-                  would make the compiler shuffle registers around the wait — and read a destination before its load has landed) */
-            : [oF] "v"(oFrag), [oF2] "v"(oFrag2), [oP] "v"(oPe), [oS] "v"(oPe8), [fp] "s"(fptr), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
+            : [t1] "=&v"(f.t1), [t2] "=&v"(f.t2), [sc] "=&v"(f.sc)      /* (pure outputs: a tie to the old value would make the compiler shuffle
+                  registers around the wait — and read a destination before its load has landed) */
+            : [oP] "v"(oPe), [oS] "v"(oPe8), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
             : "memory");
     };
-    // "At most the five loads issued after f's are outstanding".  The registers of a Flight are written asynchronously, so the
-    // compiler must never be given a reason to copy one between issue and wait: the waits below only READ them (no tied
+    auto dma = [&](const v2d MI355_GLOBAL* fptr, unsigned parity) {    // the entry at fptr into fragment buffer `parity`
+        unsigned keep;
+        unsigned long long ex;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(ldsW + parity * fragBytes), l1 = l0 + 4096u;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
+            "s_mov_b32 m0, %[l1]\n\ts_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], %[m2]\n\tglobal_load_lds_dwordx4 %[o1], %[fp]\n\ts_mov_b64 exec, %[ex]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep), [ex] "=&s"(ex)
+            : [l0] "s"(l0), [l1] "s"(l1), [o0] "v"(oFrag), [o1] "v"(oFrag2), [fp] "s"(fptr), [m2] "s"(mask2)
+            : "memory", "scc");
+    };
+    // "At most the three loads issued last are outstanding".  The registers of a Flight are written asynchronously, so the
+    // compiler must never be given a reason to copy one between issue and wait: the wait below only READS them (no tied
     // operands — a tie made the compiler move a destination to another register BEFORE the wait), and what has to outlive the
     // set's next issue is copied out inside the same statement, after the wait.  tools/check_walk_isa.py verifies the result.
     auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
-        asm volatile("s_waitcnt vmcnt(5) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
+        asm volatile("s_waitcnt vmcnt(3) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
                      "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
                      : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
     };
-    auto landedFragments = [&](const Flight& f) {
-        asm volatile("s_waitcnt vmcnt(5) ; retires %0 %1" : : "v"(f.f0), "v"(f.f1) : "memory");
-    };
     Flight A, B;
-    A.f0 = A.f1 = A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
-    issue(A, dp[0], fs);                                             // (the first fragments were staged above; A's copy of them is not used)
-    issue(B, dp[1], fs + fsStep);
+    A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
+    issue(A, dp[0]);
+    issue(B, dp[1]);
 
     // CUR: the set that holds micro-operation k's operands (issued two stages ago) and is re-used for k + 2's; NXT: k + 1's
 #define WT_STAGE(CUR, NXT)                                                                                                  \
@@ -863,7 +880,8 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
         unsigned t1, t2;                                                                                                  \
         double fe, fo;                                                                                                    \
         landedOperands(CUR, t1, t2, fe, fo);                          /* (read out before the set is handed to the next loads) */ \
-        issue(CUR, dp[k + 2], fs + (size_t)(k + 2) * fsStep);                                                            \
+        dma(fs + (size_t)(k + 1) * fsStep, (unsigned)((k + 1) & 1));                                                      \
+        issue(CUR, dp[k + 2]);                                                                                            \
         const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
         const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;                                                       \
         /* the second child first: the running result (ACC) is consumed where it stands */                                \
@@ -901,12 +919,8 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
             v2d* h = hold + (size_t)(hslot - 1) * 4 * WT_HOLD_V2D;                                                        \
             _Pragma("unroll") for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];                                         \
         }                                                                                                                 \
-        /* the next micro-operation's fragments (issued a stage ago) into the other buffer */                            \
-        landedFragments(NXT);                                                                                             \
-        v2d* fw = fragV + (size_t)((k + 1) & 1) * WT_FRAG;                                                                \
-        fw[threadIdx.x] = NXT.f0;                                                                                         \
-        if (threadIdx.x < WT_FRAG - 256) fw[threadIdx.x + 256] = NXT.f1;                                                  \
-        __syncthreads();                                                                                                  \
+        /* the next micro-operation's fragments have landed in the other buffer (this wave's share: the barrier makes it everybody's) */ \
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
     }
     for (int k = 0; k < nOps; k += 2) {            // (the host pads every segment to an even count; two more no-ops follow it, plus the stream's slack)
         WT_STAGE(A, B)
