@@ -517,10 +517,10 @@ class Beagle:
 
     def walkLaunchInfo(self):
         """How the one-launch walks were run (include/beagle_mi355.h beagleMi355WalkLaunchInfo)."""
-        out = (C.c_long * 7)()
+        out = (C.c_long * 8)()
         self._check("walkLaunchInfo", self._ext("beagleMi355WalkLaunchInfo", [C.c_int, C.POINTER(C.c_long)])(self.instance, out))
         return {"ticket_walks": int(out[0]), "flag_walks": int(out[1]), "rows": int(out[2]), "slices": int(out[3]),
-                "fused_cherries": int(out[4]), "micro_ops": int(out[5]), "slice_accumulations": int(out[6])}
+                "fused_cherries": int(out[4]), "micro_ops": int(out[5]), "slice_accumulations": int(out[6]), "partition_roots_in_walk": int(out[7])}
 
     def gradientStats(self):
         """How the pre-order lists of this instance were run (include/beagle_mi355.h beagleMi355GradientStats)."""

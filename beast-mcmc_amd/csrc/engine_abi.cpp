@@ -368,6 +368,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
     in->holdSlots = in->walkT ? 2 : mi355::walkHoldSlots(categoryCount);
     if (labEnv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(labEnv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
+    in->fuseRootParts = !(getenv("BEAGLE_MI355_NO_ROOT_PARTS_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_PARTS_FUSION")) != 0);
     in->walkTWrite = in->walkT && categoryCount <= mi355::WALK_T32_WRITE_MAX_CATEGORIES && in->holdSlots <= mi355::WALK_T32_WRITE_MAX_HOLD &&
                      !(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK")) != 0);
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn, in->holdSlots);
@@ -1216,6 +1217,62 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (partitionCount < 1 || partitionCount > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (!in->tiled && partitionCount <= 480) {
+        // 4-state walk instances, up to eight partitions: 128-pattern groups with the assembly loop's lane map (k_rootSite4WParts) — and
+        // when the walk that computes these roots is still held back (engine_walk.cpp runPlan) and its last slices are exactly the
+        // named roots, the slices' own epilogues do it: no root launch at all
+        const bool groups128 = in->walk && in->fuseLaunches && partitionCount <= mi355::ROOT_MAX_PARTS;
+        if (groups128 && in->pendingWalk.valid && in->fuseRootParts) {
+            const Instance::PendingWalk& pw = in->pendingWalk;
+            mi355::RootFusedParts rp;
+            memset(&rp, 0, sizeof(rp));
+            bool ok = (int)pw.sinkRows.size() == partitionCount && in->partitionCount > 1;
+            int off = 0;
+            for (int k = 0; k < partitionCount && ok; k++) {
+                const int rootIdx = bufferIndices[k], wIdx = categoryWeightsIndices[k], fIdx = stateFrequenciesIndices[k], cumIdx = cumulativeScaleIndices[k], part = partitionIndices[k];
+                if (badIndex(rootIdx, in->partialsCount) || badIndex(part, in->partitionCount) || badIndex(wIdx, in->eigenCount) || badIndex(fIdx, in->eigenCount) ||
+                    (cumIdx != BEAGLE_OP_NONE && badIndex(cumIdx, in->scaleCount))) { ok = false; break; }
+                int seg = -1;
+                for (int row : pw.sinkRows) if (pw.finalStore[(size_t)row] == rootIdx && pw.finalPart[(size_t)row] == part) seg = row;
+                for (int j = 0; j < k; j++) if (rp.p[j].rootSeg == seg) seg = -1;                       // (a root named twice: the plain path)
+                if (seg < 0) { ok = false; break; }
+                mi355::RootFusedPart& q = rp.p[k];
+                q.catWeights = in->weights + (size_t)wIdx * in->C; q.freqs = in->freqs + (size_t)fIdx * in->S; q.cum = nullptr; q.cumIsRaw = 0;
+                if (cumIdx != BEAGLE_OP_NONE) { int rc = ensureScale(in, cumIdx); if (rc) return rc; q.cum = in->scale[cumIdx]; q.cumIsRaw = in->scaleIsRaw[cumIdx]; }
+                q.rootSeg = seg; q.blockOff = off; q.groups = (std::max(0, in->partEnd[part] - in->partStart[part]) + 127) / 128;
+                off += q.groups;
+            }
+            if (ok && off > 0) {
+                rp.n = partitionCount; rp.totalGroups = off;
+                const unsigned long long seq = ++in->resultSeq;
+                mi355::RootFused rf;
+                memset(&rf, 0, sizeof(rf));
+                rf.rootSeg = -1;
+                rf.patternWeights = in->patternWeights; rf.siteLogL = in->siteLogL; rf.blockSums = in->blockSums; rf.counter = in->rootCounter;
+                rf.out = in->hResultDev + 16; rf.flag = (unsigned long long*)(in->hResultDev + 8); rf.seq = seq;
+                if (!in->rootPartsDev) { int rca = devAlloc(in, (void**)&in->rootPartsDev, Instance::ROOT_PARTS_TABLES * sizeof(rp)); if (rca) return rca; }
+                int table = -1;
+                for (int t = 0; t < Instance::ROOT_PARTS_TABLES; t++)
+                    if (in->rootPartsShadow[t].size() == sizeof(rp) && memcmp(in->rootPartsShadow[t].data(), &rp, sizeof(rp)) == 0) table = t;
+                if (table < 0) {
+                    table = in->rootPartsNext; in->rootPartsNext = (table + 1) % Instance::ROOT_PARTS_TABLES;
+                    in->copyKeepsWalk = true;                        // (the held walk's own input)
+                    const int rcu = upload(in, in->rootPartsDev + table, &rp, sizeof(rp));
+                    in->copyKeepsWalk = false;
+                    if (rcu) return rcu;
+                    in->rootPartsShadow[table].assign((const char*)&rp, (const char*)&rp + sizeof(rp));
+                }
+                rf.parts = in->rootPartsDev + table;
+                in->statRootPartsFused++;
+                { const int rcw = flushWalk(in, &rf); if (rcw) return rcw; }
+                HIP_TRY(hipGetLastError());
+                { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
+                if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
+                double tot = 0.0;
+                for (int k = 0; k < partitionCount; k++) { outByPartition[k] = in->hResult[16 + k]; tot += in->hResult[16 + k]; }
+                *outSum = tot;
+                return (tot != tot) ? BEAGLE_ERROR_FLOATING_POINT : BEAGLE_SUCCESS;
+            }
+        }
         // all partitions in ONE pair of launches per eight of them, the sums written straight into mapped host memory behind a
         // sequence word the host polls (as calculateRootLogLikelihoods): no device-to-host copy, no stream synchronisation
         std::vector<mi355::RootParts> chunks((partitionCount + mi355::ROOT_MAX_PARTS - 1) / mi355::ROOT_MAX_PARTS);
@@ -1236,11 +1293,15 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
                 q.cum = in->scale[cumIdx]; q.cumIsRaw = in->scaleIsRaw[cumIdx];
             }
             q.pStart = in->partStart[part]; q.pEnd = in->partEnd[part]; q.blockOff = blockOff;
-            blockOff += (std::max(0, q.pEnd - q.pStart) + 255) / 256;
+            blockOff += (std::max(0, q.pEnd - q.pStart) + (groups128 ? 127 : 255)) / (groups128 ? 128 : 256);
         }
         const unsigned long long seq = ++in->resultSeq;
         for (size_t c = 0; c < chunks.size(); c++) {
             const bool last = c + 1 == chunks.size();
+            if (groups128)
+                mi355::launchRootLogLikelihoodParts4W(live(in), chunks[c], in->patternWeights, in->siteLogL, in->blockSums, in->hResultDev + 16, in->P, in->C,
+                                                      (unsigned long long*)(in->hResultDev + 8), seq, in->rootCounter);
+            else
             mi355::launchRootLogLikelihoodParts(live(in), chunks[c], in->patternWeights, in->siteLogL, in->blockSums,
                                                 in->hResultDev + 16 + c * mi355::ROOT_MAX_PARTS, in->P, in->S, in->C,
                                                 last ? (unsigned long long*)(in->hResultDev + 8) : nullptr, seq, in->fuseLaunches ? in->rootCounter : nullptr);
@@ -1604,7 +1665,7 @@ int beagleMi355WalkHealth(int instance, long* out4) {
     return BEAGLE_SUCCESS;
 }
 
-int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (seven values)
+int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (eight values)
     if (mi355::isShardedHandle(instance)) {             // shard 0's
         bool first = true; std::mutex mu;
         return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355WalkLaunchInfo(h, out4); });
@@ -1612,7 +1673,7 @@ int beagleMi355WalkLaunchInfo(int instance, long* out4) {       // (seven values
     Instance* in = lookup(instance);
     if (!in || !out4) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     out4[0] = in->statTicketWalks; out4[1] = in->statFlagWalks; out4[2] = in->lastLaunchRows; out4[3] = in->lastLaunchSlices;
-    out4[4] = in->statFused; out4[5] = in->statMicroOps; out4[6] = in->statSliceAccum;
+    out4[4] = in->statFused; out4[5] = in->statMicroOps; out4[6] = in->statSliceAccum; out4[7] = in->statRootPartsFused;
     return BEAGLE_SUCCESS;
 }
 

@@ -144,6 +144,16 @@ struct Instance {
     // ... and its write-mode form (k_walkT32W: lists that rescale in write mode stay on the walk; at most four categories, two hold slots;
     // BEAGLE_MI355_NO_T32_WRITE_WALK=1: they run level by level, as until round 6)
     bool walkTWrite = false;
+    // 4-state partitioned instances: the top slices of the partitions finish calculateRootLogLikelihoodsByPartition inside the walk's launch
+    // (kernels.h RootFusedParts; BEAGLE_MI355_NO_ROOT_PARTS_FUSION=1: a launch of its own behind it, k_rootSite4WParts — the same bits)
+    bool fuseRootParts = true;
+    long statRootPartsFused = 0;                         // by-partition root calls that were finished inside the walk's launch
+    // the tables the kernel reads and what each holds: a chain's evaluations alternate between a few (buffer flips: two programs, two
+    // root slices), so four are kept and one is uploaded only when none of them matches
+    static constexpr int ROOT_PARTS_TABLES = 4;
+    mi355::RootFusedParts* rootPartsDev = nullptr;       // [ROOT_PARTS_TABLES]
+    std::vector<char> rootPartsShadow[ROOT_PARTS_TABLES];
+    int rootPartsNext = 0;
     bool fuseLaunches = true;                            // BEAGLE_MI355_NO_LAUNCH_FUSION=1: snapshot / gather and root site / final as separate launches (A/B runs)
     // A one-launch walk whose launch is held back until the next call: calculateRootLogLikelihoods on the result of one of its
     // slices launches it WITH that slice finishing the evaluation (no root kernel, no read-back of the root's partials); any other
@@ -155,6 +165,8 @@ struct Instance {
         int leaves = 0;                                  // > 0: launch on tickets, that many rows
         unsigned cherryOff = 0;                          // byte offset of the matrix stream's cherry region (0: the program has no fused cherries)
         std::vector<int> finalStore;                     // per device slice: the buffer its last micro-operation stores (-1: none)
+        std::vector<int> finalPart;                      // ... and its partition; sinkRows: the slices nothing waits for (a partitioned
+        std::vector<int> sinkRows;                       // instance: one per partition in the list — their epilogues finish the partitions' roots)
     } pendingWalk;
     std::vector<int> snapSourceOf;                       // runPlan's scratch: matrix slot -> the slot its snapshot is being taken from in this plan (-1 between calls)
     bool deferWalk = true;                               // BEAGLE_MI355_NO_ROOT_FUSION=1: never hold a launch back

@@ -573,12 +573,21 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
             for (size_t i = 0; i < segs.size(); i++) if (!feeds[i] && segs[i].progCount > 0) sinks++;
             if (slot) slot->sinks = sinks;
         }
-        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && in->partitionCount == 1 && range == in->P && sinks == 1;
+        // (a partitioned instance, round 6: up to eight partitions in the list, every one ending in ONE slice — the by-partition root call
+        // names them all or the launch goes out without it: engine_abi.cpp beagleCalculateRootLogLikelihoodsByPartition)
+        const bool holdParts = in->partitionCount > 1 && sinks >= 1 && sinks <= mi355::ROOT_MAX_PARTS && in->fuseRootParts;
+        const bool hold = in->deferWalk && in->fuseLaunches && !recordBeforeWalk && ((in->partitionCount == 1 && range == in->P && sinks == 1) || holdParts);
         if (hold) {
             pw.finalStore.assign(segs.size(), -1);
+            pw.finalPart.assign(segs.size(), 0);
+            pw.sinkRows.clear();
+            std::vector<char> feeds(segs.size(), 0);
+            for (int d : devDeps) feeds[(size_t)d] = 1;         // (the slot's own list: what it held when the program was resolved)
             for (size_t i = 0; i < segs.size(); i++) {
                 const mi355::PlanSeg& ps = plan.segs[(size_t)order[i]];
                 if (ps.progCount > 0) pw.finalStore[i] = plan.prog[(size_t)ps.progStart + ps.progCount - 1].storeBuf;
+                pw.finalPart[i] = ps.partition;
+                if (!feeds[i] && ps.progCount > 0) pw.sinkRows.push_back((int)i);
             }
             (void)live(in);                           // the program's copies and the gather are enqueued; only the walk itself waits
             pw.valid = true;

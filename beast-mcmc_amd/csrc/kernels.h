@@ -170,11 +170,20 @@ void launchGatherAndSnapshot(hipStream_t stream, const WalkOp* dProg, int nOps, 
 // waits until flags[d * flagStride + x] == epoch for every slice d of its dependency list, and sets flags[y * flagStride + x] =
 // epoch when its results are out.  flags == nullptr: no waiting, no signalling (one launch per wave of independent slices).
 // what the walk's root slice needs to finish the evaluation itself (kernels_walk4.hip, root_site4.h; rootSeg < 0: nothing)
+struct RootFusedParts;
 struct RootFused {
     const double* catWeights; const double* freqs; const double* cum; const double* patternWeights;
     double* siteLogL; double* blockSums; unsigned* counter; double* out; unsigned long long* flag; unsigned long long seq;
     int cumIsRaw; int rootSeg; int groups; int pad;
+    const RootFusedParts* parts;     // DEVICE memory, or nullptr: the roots of a partitioned instance's partitions (below)
 };
+// ... and the same for the roots of up to ROOT_MAX_PARTS partitions (calculateRootLogLikelihoodsByPartition behind updatePartialsByPartition:
+// every partition's top slice finishes its own partition; RootFused carries what the partitions share — pattern weights, site values,
+// blockSums, counter, out[partition], flag, seq —, rootSeg = -1 and a pointer to this table in device memory: by value it kept more
+// scalars alive across the assembly loop than the kernel has).  A pattern group's sum goes to blockSums[blockOff + group],
+// the last of ALL groups adds every partition's up in index order (root_site4.h rootPublishGroupParts; k_rootSite4WParts: the same bits).
+struct RootFusedPart { const double* catWeights; const double* freqs; const double* cum; int cumIsRaw, rootSeg, blockOff, groups; };
+struct RootFusedParts { RootFusedPart p[8]; int n, totalGroups; };
 // spinLimit: how long a workgroup polls those flags (ticks of the 100 MHz wall clock) before it computes what it waits for itself
 // (kernels_walk4.hip: forward progress whatever the dispatch order); *selfServed counts the workgroups that did.
 void launchWalk4Fast(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int C,
@@ -266,6 +275,11 @@ struct RootParts { RootPart p[ROOT_MAX_PARTS]; int n; };
 void launchRootLogLikelihoodParts(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
                                   double* out, int P, int S, int C, unsigned long long* flag, unsigned long long seq, unsigned* counter = nullptr);
 // (counter: a zeroed device word, zero again behind the launch — the last workgroup of the site kernel forms the sums; nullptr: a second launch does)
+// 4-state walk instances: a wave per 128 patterns with the assembly loop's lane map, the groups' sums as the walk's own root slices leave
+// them (kernels_walk4.hip, RootFusedParts) — the same bits whether a partition's root is integrated there or here.  Uses RootPart::root,
+// catWeights, freqs, cum, cumIsRaw, pStart, pEnd; blockOff counts 128-pattern groups.
+void launchRootLogLikelihoodParts4W(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
+                                    double* out, int P, int C, unsigned long long* flag, unsigned long long seq, unsigned* counter);
 
 // site[p] = log(sum_c w_c sum_i pi_i root[c][p][i]) + cum[p];  blockSums[b] = sum_p weight[p]*site[p] over block b
 // then out[0] = sum_b blockSums[b] in a fixed order (deterministic).  cum may be nullptr; cumIsRaw says the

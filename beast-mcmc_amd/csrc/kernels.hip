@@ -527,6 +527,43 @@ void launchRootLogLikelihood4W(hipStream_t stream, const double* root, const dou
                        patternWeights, siteLogL, blockSums, P, C, pStart, pEnd, groups, counter, out, flag, seq);
 }
 
+__global__ void k_rootFinalParts(const double* __restrict__ blockSums, const RootParts parts, double* __restrict__ out, unsigned long long* flag, unsigned long long seq);
+// ... and for up to ROOT_MAX_PARTS partitions in one launch (grid row = partition): the launch of its own beside the epilogues of the
+// partitions' top slices (kernels_walk4.hip, RootFusedParts) — same functions, same order, same bits
+__global__ __launch_bounds__(256) void k_rootSite4WParts(const RootParts parts, const double* __restrict__ patternWeights, double* __restrict__ siteLogL,
+                                                         double* __restrict__ blockSums, int P, int C, int totalGroups, unsigned* counter,
+                                                         double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
+    const RootPart& q = parts.p[blockIdx.y];
+    const int lane = threadIdx.x & 63, group = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int groups = (q.pEnd - q.pStart + 127) / 128;
+    if (group >= groups) return;
+    const int p0 = q.pStart + group * 128, h = lane >> 1, r = lane & 1;
+    const int pa = p0 + h + 32 * r, pb = pa + 64;
+    const int la = pa < q.pEnd ? pa : q.pEnd - 1, lb = pb < q.pEnd ? pb : q.pEnd - 1;
+    double sumA = 0.0, sumB = 0.0;
+    for (int c = 0; c < C; c++) {
+        const d4 a = *reinterpret_cast<const d4*>(q.root + ((size_t)c * P + la) * 4);
+        const d4 b = *reinterpret_cast<const d4*>(q.root + ((size_t)c * P + lb) * 4);
+        sumA = __builtin_fma(q.catWeights[c], rootDot4(q.freqs, a.x, a.y, a.z, a.w), sumA);
+        sumB = __builtin_fma(q.catWeights[c], rootDot4(q.freqs, b.x, b.y, b.z, b.w), sumB);
+    }
+    const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, q.pEnd, q.cum, q.cumIsRaw, patternWeights, siteLogL));
+    rootPublishGroupParts(g, lane, q.blockOff + group, totalGroups, parts.n, parts,
+                          [](const RootParts& s, int i) { return (s.p[i].pEnd - s.p[i].pStart + 127) / 128; }, [](const RootParts& s, int i) { return s.p[i].blockOff; },
+                          blockSums, counter, out, flag, seq);
+}
+void launchRootLogLikelihoodParts4W(hipStream_t stream, const RootParts& parts, const double* patternWeights, double* siteLogL, double* blockSums,
+                                    double* out, int P, int C, unsigned long long* flag, unsigned long long seq, unsigned* counter) {
+    int maxGroups = 1, total = 0;
+    for (int k = 0; k < parts.n; k++) { const int g = (std::max(0, parts.p[k].pEnd - parts.p[k].pStart) + 127) / 128; maxGroups = std::max(maxGroups, g); total += g; }
+    if (total == 0) {                                  // nothing but empty ranges (a shard that holds none of these partitions' patterns): zeros, and the word
+        hipLaunchKernelGGL(k_rootFinalParts, dim3(1), dim3(ROOT_BLOCK), 0, stream, blockSums, parts, out, flag, seq);
+        return;
+    }
+    hipLaunchKernelGGL(k_rootSite4WParts, dim3((maxGroups + 3) / 4, parts.n), dim3(256), 0, stream, parts, patternWeights, siteLogL, blockSums, P, C, total,
+                       counter, out, flag, seq);
+}
+
 void launchRootLogLikelihood(hipStream_t stream, const double* root, const double* catWeights, const double* freqs,
                              const double* cum, int cumIsRaw, const double* patternWeights, double* siteLogL,
                              double* blockSums, double* out, int P, int S, int C, int pStart, int pEnd,

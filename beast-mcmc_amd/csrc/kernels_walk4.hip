@@ -597,11 +597,24 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
     // (the loop's exit writes it there), wave c forms sum_i pi_i L[c][p][i] for its two patterns, category 0's wave adds the
     // categories up in order, takes the logarithm and folds the group's 128 site values; the last group adds the groups' sums.
     // Same functions, same order, same bits as the launch of its own (kernels.hip k_rootSite4W).
-    if (rootArgs.rootSeg == last) {
+    // (a partitioned instance: the top slice of every partition finishes ITS partition — rootParts, kernels.h)
+    int part = -1;
+    const RootFusedParts MI355_GLOBAL* rootPartsP = gptr(rootArgs.parts);
+    if (rootPartsP) {
+        const int n = rootPartsP->n;
+#pragma unroll 1
+        for (int i = 0; i < n; i++) if (rootPartsP->p[i].rootSeg == last) part = i;
+    }
+    if (rootArgs.rootSeg == last || part >= 0) {
+        const RootFusedParts MI355_GLOBAL& rootParts = *rootPartsP;               // (only read where part >= 0)
         const int lane = walkLane();
+        const double* freqs = part >= 0 ? rootParts.p[part].freqs : rootArgs.freqs;
+        const double* catWeights = part >= 0 ? rootParts.p[part].catWeights : rootArgs.catWeights;
+        const double* cum = part >= 0 ? rootParts.p[part].cum : rootArgs.cum;
+        const int cumIsRaw = part >= 0 ? rootParts.p[part].cumIsRaw : rootArgs.cumIsRaw;
         const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
-        const double sa = rootDot4(rootArgs.freqs, h[0], h[1], h[128], h[129]);
-        const double sb = rootDot4(rootArgs.freqs, h[256], h[257], h[384], h[385]);
+        const double sa = rootDot4(freqs, h[0], h[1], h[128], h[129]);
+        const double sb = rootDot4(freqs, h[256], h[257], h[384], h[385]);
         double* exch = reinterpret_cast<double*>(lds) + (size_t)C * 512;                                      // hold slot 1: free at the end of a program
         exch[(size_t)c * 128 + lane * 2] = sa;
         exch[(size_t)c * 128 + lane * 2 + 1] = sb;
@@ -609,12 +622,15 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         if (c == 0) {
             double sumA = 0.0, sumB = 0.0;
             for (int cc = 0; cc < C; cc++) {
-                sumA = __builtin_fma(rootArgs.catWeights[cc], exch[(size_t)cc * 128 + lane * 2], sumA);
-                sumB = __builtin_fma(rootArgs.catWeights[cc], exch[(size_t)cc * 128 + lane * 2 + 1], sumB);
+                sumA = __builtin_fma(catWeights[cc], exch[(size_t)cc * 128 + lane * 2], sumA);
+                sumB = __builtin_fma(catWeights[cc], exch[(size_t)cc * 128 + lane * 2 + 1], sumB);
             }
             const int pa = p0 + (lane >> 1) + 32 * (lane & 1), pb = pa + 64;
-            const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, pEnd, rootArgs.cum, rootArgs.cumIsRaw, rootArgs.patternWeights, rootArgs.siteLogL));
-            rootPublishGroup(g, lane, (int)bx, rootArgs.groups, rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
+            const double g = rootWaveSum(rootFinishPair(sumA, sumB, pa, pb, pEnd, cum, cumIsRaw, rootArgs.patternWeights, rootArgs.siteLogL));
+            if (part < 0) rootPublishGroup(g, lane, (int)bx, rootArgs.groups, rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
+            else rootPublishGroupParts(g, lane, rootParts.p[part].blockOff + (int)bx, rootParts.totalGroups, rootParts.n, rootParts,
+                                       [](const RootFusedParts MI355_GLOBAL& q, int i) { return q.p[i].groups; }, [](const RootFusedParts MI355_GLOBAL& q, int i) { return q.p[i].blockOff; },
+                                       rootArgs.blockSums, rootArgs.counter, rootArgs.out, rootArgs.flag, rootArgs.seq);
         }
     }
 }

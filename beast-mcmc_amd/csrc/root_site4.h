@@ -62,4 +62,34 @@ __device__ __forceinline__ void rootPublishGroup(double groupSum, int lane, int 
     }
 }
 
+// ... the same for several partitions in one launch: group `slot` = blockOff(partition) + its index within the partition; the LAST of all
+// `total` groups adds every partition's sums up in index order (64 interleaved partial sums folded by the same tree) and writes out[k].
+template <class Parts, class GroupsOf, class OffOf>
+__device__ __forceinline__ void rootPublishGroupParts(double groupSum, int lane, int slot, int total, int n, const Parts& parts, GroupsOf groupsOf, OffOf offOf,
+                                                      double* __restrict__ blockSums, unsigned* counter, double* __restrict__ out,
+                                                      unsigned long long* flag, unsigned long long seq) {
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(blockSums) + slot, (unsigned long long)__double_as_longlong(groupSum),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                                       // my group's sum before my ticket
+        last = atomicAdd(counter, 1u) == (unsigned)(total - 1);
+    }
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    __threadfence();
+    for (int i = 0; i < n; i++) {
+        const int groups = groupsOf(parts, i), off = offOf(parts, i);
+        double v = 0.0;
+        for (int k = lane; k < groups; k += 64)
+            v += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(blockSums) + off + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        v = rootWaveSum(v);
+        if (lane == 0) out[i] = v;
+    }
+    if (lane == 0) {
+        *counter = 0u;                                                         // ready for the next evaluation (same stream: ordered)
+        if (flag) { __threadfence_system(); __atomic_store_n(flag, seq, __ATOMIC_RELEASE); }
+    }
+}
+
 }  // namespace mi355

@@ -372,8 +372,10 @@ int beagleMi355WalkHealth(int instance, long* out4);
  * out[4]: micro-operations that were not part of a device program because their consumer evaluated them inside its own stage (nodes over
  * two compact tips: DESIGN.md 4.1 "fused cherries"; BEAGLE_MI355_NO_CHERRY_FUSION=1: none), out[5]: micro-operations planned, both since
  * the last beagleMi355KernelTimer call; out[6]: accumulateScaleFactors calls since creation that were answered from the per-slice products of
- * factors a write-mode walk had just left behind (BEAGLE_MI355_NO_SLICE_SUMS=1: none).  out7 holds seven values. */
-int beagleMi355WalkLaunchInfo(int instance, long* out7);
+ * factors a write-mode walk had just left behind (BEAGLE_MI355_NO_SLICE_SUMS=1: none); out[7]: calculateRootLogLikelihoodsByPartition
+ * calls since creation that the top slices of the partitions finished inside the walk's own launch (4 states, up to eight partitions;
+ * BEAGLE_MI355_NO_ROOT_PARTS_FUSION=1: none).  out8 holds eight values. */
+int beagleMi355WalkLaunchInfo(int instance, long* out8);
 /* The gradient pass (4 states) since instance creation.  A pre-order list without scale indices is held back until a call needs
  * what it writes (or changes what it reads): out[0] lists that ran together with the edge derivatives that followed them (one
  * sweep per tree level; sums and sums of squares), out[1] lists that ran operation by operation, out[2] edge-derivative calls

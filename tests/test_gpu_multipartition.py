@@ -220,3 +220,46 @@ def test_partitioned_instance_partial_updates_with_per_partition_flips(S, oracle
         eng.finalize()
         for o in ora:
             o.finalize()
+
+
+def test_partition_roots_inside_the_walk_launch_give_the_bits_of_the_launch_of_their_own(monkeypatch):
+    """calculateRootLogLikelihoodsByPartition right behind updatePartialsByPartition on a 4-state instance: the top slice of every
+    partition integrates its own root inside the walk's launch (kernels.h RootFusedParts) — the same functions in the same order as
+    k_rootSite4WParts, the launch of its own that BEAGLE_MI355_NO_ROOT_PARTS_FUSION=1 keeps: per-partition sums, total and site values
+    bit for bit, through flipped buffers, changing branch rates and node-height moves (whose lists are the partitions' paths to their roots)."""
+    from beast_mcmc_amd.inputs import synth
+    from beast_mcmc_amd.multipartition import MultiPartitionTreeLikelihood
+    pw = synth.config_e(scale=0.08)
+
+    heights = np.array(pw.tree.height, dtype=float).copy()
+
+    def run():
+        pw.tree.height[:] = heights                          # (the moves below change the shared tree)
+        tl = MultiPartitionTreeLikelihood(pw)
+        out = []
+        for i in range(4):
+            tl.set_branch_rates(np.ones(pw.tree.node_count) * (1.0 + 0.01 * i))
+            by_part, total = tl.calculate()
+            out.append((by_part.copy(), total, tl.getSiteLogLikelihoods().copy()))
+        rng = np.random.default_rng(3)
+        tree = pw.tree
+        for _ in range(6):
+            node = int(rng.integers(tree.tip_count, tree.node_count))
+            if node == tree.root:
+                continue
+            lo = max(tree.height[int(tree.left[node])], tree.height[int(tree.right[node])]); hi = tree.height[tree.parent[node]]
+            by_part, total = tl.move_node_height(node, lo + 0.4 * (hi - lo))
+            out.append((by_part.copy(), total, tl.getSiteLogLikelihoods().copy()))
+        by_part, total = tl.calculate()
+        out.append((by_part.copy(), total, tl.getSiteLogLikelihoods().copy()))
+        info = tl.b.walkLaunchInfo()
+        tl.close()
+        return out, info
+
+    fused, info = run()
+    assert info["partition_roots_in_walk"] >= 5, info
+    monkeypatch.setenv("BEAGLE_MI355_NO_ROOT_PARTS_FUSION", "1")
+    plain, info1 = run()
+    assert info1["partition_roots_in_walk"] == 0
+    for (a, ta, sa), (b, tb, sb) in zip(fused, plain):
+        assert ta == tb and np.array_equal(a, b) and np.array_equal(sa, sb)
