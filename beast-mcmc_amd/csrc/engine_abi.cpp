@@ -921,13 +921,15 @@ int beagleConvolveTransitionMatrices(int instance, const int* first, const int* 
 static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar, const int* rateIdx,
                               const int* probIdx, const double* lens, int count) {
     if (count <= 0) return BEAGLE_SUCCESS;
-    std::vector<int> eig(count), rate(count);
-    for (int k = 0; k < count; k++) {
-        eig[k] = eigenIdx ? eigenIdx[k] : eigenScalar;
-        rate[k] = rateIdx ? rateIdx[k] : 0;
-        if (badIndex(probIdx[k], in->matrixCount) || badIndex(eig[k], in->eigenCount) || badIndex(rate[k], in->eigenCount))
-            return BEAGLE_ERROR_OUT_OF_RANGE;
-    }
+    // range checks as minimum / maximum scans (they vectorise; a partitioned evaluation names 12 900 branches, and a loop with an early
+    // return per branch cost more than the kernel it fed)
+    auto outOfRange = [count](const int* v, int limit) {
+        int lo = v[0], hi = v[0];
+        for (int k = 1; k < count; k++) { lo = v[k] < lo ? v[k] : lo; hi = v[k] > hi ? v[k] : hi; }
+        return lo < 0 || hi >= limit;
+    };
+    if (outOfRange(probIdx, in->matrixCount) || (eigenIdx ? outOfRange(eigenIdx, in->eigenCount) : badIndex(eigenScalar, in->eigenCount)) ||
+        (rateIdx && outOfRange(rateIdx, in->eigenCount))) return BEAGLE_ERROR_OUT_OF_RANGE;
     // 4 states, one eigen system and one rate set (beagleUpdateTransitionMatrices — what every evaluation of a chain issues): the
     // branch lengths and matrix indices stay in the staging ring, which the device maps, and the kernel reads them — and an
     // eigen system / rate set whose upload is still queued — from there; the queued copies ride in the same launch
@@ -992,8 +994,10 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
         const long off = stage(in, lens, lenBytes, lenBytes + 3 * idxBytes);
         if (off < 0) return BEAGLE_ERROR_GENERAL;
         memcpy(in->hRing + off + lenBytes, probIdx, idxBytes);
-        memcpy(in->hRing + off + lenBytes + idxBytes, eig.data(), idxBytes);
-        memcpy(in->hRing + off + lenBytes + 2 * idxBytes, rate.data(), idxBytes);
+        int* rEig = (int*)(in->hRing + off + lenBytes + idxBytes);
+        int* rRate = rEig + count;
+        if (eigenIdx) memcpy(rEig, eigenIdx, idxBytes); else std::fill(rEig, rEig + count, eigenScalar);
+        if (rateIdx) memcpy(rRate, rateIdx, idxBytes); else std::fill(rRate, rRate + count, 0);
         const int* rIdx = (const int*)(in->hRingDev + off + lenBytes);
         mi355::launchTransitionMatrices(live(in), in->matrices, in->eigen, in->rates, rIdx, (const double*)(in->hRingDev + off),
                                         rIdx + count, rIdx + 2 * (size_t)count, count, in->S, in->C, in->eigenComplex);
@@ -1006,8 +1010,8 @@ static int transitionMatrices(Instance* in, const int* eigenIdx, int eigenScalar
     int* pIdx = (int*)(pack.data() + (size_t)count * sizeof(double));
     memcpy(pLen, lens, (size_t)count * sizeof(double));
     memcpy(pIdx, probIdx, (size_t)count * sizeof(int));
-    memcpy(pIdx + count, eig.data(), (size_t)count * sizeof(int));
-    memcpy(pIdx + 2 * (size_t)count, rate.data(), (size_t)count * sizeof(int));
+    if (eigenIdx) memcpy(pIdx + count, eigenIdx, (size_t)count * sizeof(int)); else std::fill(pIdx + count, pIdx + 2 * (size_t)count, eigenScalar);
+    if (rateIdx) memcpy(pIdx + 2 * (size_t)count, rateIdx, (size_t)count * sizeof(int)); else std::fill(pIdx + 2 * (size_t)count, pIdx + 3 * (size_t)count, 0);
     void* dPack;
     int rc = uploadTransient(in, pack.data(), pack.size(), &dPack); if (rc) return rc;
     const double* dLen = (const double*)dPack;
