@@ -119,7 +119,8 @@ _PROTOS = {
 }
 
 # symbols every engine library must export (tests assert this list against include/beagle_mi355.h)
-ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetBenchmarkedResourceList", "beagleGetApiTable"] + \
+ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleGetBenchmarkedResourceList", "beagleGetApiTable",
+               "beagleGetPartitionApiTable"] + \
               ["beagle" + k for k in _PROTOS] + \
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
@@ -152,6 +153,11 @@ class EngineLibrary:
         tab = getattr(self.lib, prefix + "beagleGetApiTable")
         tab.restype = C.c_void_p
         self.api_table = tab()
+        ptab = getattr(self.lib, prefix + "beagleGetPartitionApiTable", None)       # (the engine; the oracle restates no ...ByPartition call)
+        self.partition_api_table = None
+        if ptab is not None:
+            ptab.restype = C.c_void_p
+            self.partition_api_table = ptab()
 
     def has(self, name):
         return name in self.fn

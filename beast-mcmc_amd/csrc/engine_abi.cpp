@@ -1731,4 +1731,14 @@ static const BeagleApi g_api = {
 };
 const BeagleApi* beagleGetApiTable(void) { return &g_api; }
 
+static const BeaglePartitionApi g_partitionApi = {
+    beagleSetCategoryRatesWithIndex,
+    beagleUpdateTransitionMatricesWithMultipleModels,
+    beagleUpdatePartialsByPartition,
+    beagleResetScaleFactorsByPartition,
+    beagleAccumulateScaleFactorsByPartition,
+    beagleCalculateRootLogLikelihoodsByPartition,
+};
+const BeaglePartitionApi* beagleGetPartitionApiTable(void) { return &g_partitionApi; }
+
 }  // extern "C"

@@ -19,9 +19,34 @@ from . import beagle as _b
 NONE = _b.NONE
 
 
+_MP_EVALUATION = None
+
+
+def _mp_evaluation_type():
+    """ctypes image of tools/host/tree_likelihood.cpp MpEvaluation (one type per process: the host function's argtypes name it)."""
+    global _MP_EVALUATION
+    if _MP_EVALUATION is None:
+        import ctypes as C
+        DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        DPP = C.POINTER(DP)
+
+        class MpEvaluation(C.Structure):
+            _fields_ = [(n, C.c_int) for n in ("K", "always_rescale", "n_matrices", "n_ops9", "n_ops7", "n_scale", "cum", "n_branches")] + \
+                       [("update_substitution_model", IP), ("update_site_rate_model", IP),
+                        ("U", DPP), ("Uinv", DPP), ("lambda_", DPP), ("rates", DPP), ("weights", DPP), ("freqs", DPP),
+                        ("eig_idx", IP), ("mat_idx", IP), ("lens0", DP), ("branch", IP), ("lens", DP),
+                        ("ops9", IP), ("ops7", IP), ("scale_idx", IP), ("roots", IP), ("range", IP), ("cum_idx", IP),
+                        ("by_part", DP), ("total", DP)]
+        _MP_EVALUATION = MpEvaluation
+    return _MP_EVALUATION
+
+
 class MultiPartitionTreeLikelihood:
-    def __init__(self, pw, *, library=None, resource_list=(1,), always_rescale=False):
+    def __init__(self, pw, *, library=None, resource_list=(1,), always_rescale=False, native_sequence=True):
         self.pw = pw
+        # the per-evaluation call sequence of calculate() in C++ (tools/host/tree_likelihood.cpp mpEvaluate: the same calls in the same
+        # order; the reference's caller is compiled code) — False: call by call from here (what a test that watches the calls wants)
+        self.native_sequence = native_sequence
         self.tree = tree = pw.tree
         self.T = T = tree.tip_count
         self.K = K = len(pw.parts)
@@ -153,6 +178,34 @@ class MultiPartitionTreeLikelihood:
         f["total"] = self._total.ctypes.data_as(DP)
         f["keep"] = keep
         self._fast = f
+        # ... and the record the native call sequence reads (fields that change per evaluation are set in calculate())
+        f["native"] = None
+        eng = self.b.lib
+        if self.native_sequence and getattr(eng, "partition_api_table", None):
+            from .treelikelihood import host_library
+            host = host_library()
+            DPP = C.POINTER(DP)
+            MpEvaluation = _mp_evaluation_type()
+
+            def dpp(ptrs):
+                arr = (DP * K)(*ptrs); keep.append(arr); return C.cast(arr, DPP)
+            e = MpEvaluation()
+            e.K, e.always_rescale, e.n_matrices, e.n_scale = K, int(self.always_rescale), len(self._eig_idx), len(self._scale_idx)
+            e.cum, e.n_branches = (T - 1) if self.always_rescale else NONE, len(self._branch)
+            self._flag_subst = np.zeros(K, dtype=np.int32); self._flag_site = np.zeros(K, dtype=np.int32)
+            e.update_substitution_model = self._flag_subst.ctypes.data_as(IP); e.update_site_rate_model = self._flag_site.ctypes.data_as(IP)
+            e.U, e.Uinv, e.lambda_ = dpp([x[0] for x in f["eig"]]), dpp([x[1] for x in f["eig"]]), dpp([x[2] for x in f["eig"]])
+            e.rates, e.weights, e.freqs = dpp(f["rates"]), dpp(f["weights"]), dpp(f["freqs"])
+            e.eig_idx = f["eig_idx"]
+            self._branch32 = i(self._branch); keep.append(self._branch32)
+            e.branch = self._branch32.ctypes.data_as(IP)
+            e.lens = f["lens"]
+            e.scale_idx, e.range, e.cum_idx = f["scale_idx"], f["range"], f["cum"][self.always_rescale]
+            e.by_part, e.total = f["by_part"], f["total"]
+            host.mpEvaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MpEvaluation), DP, IP]
+            host.mpEvaluate.restype = C.c_int
+            self._failed = C.c_int(0)
+            f["native"] = (host.mpEvaluate, e, eng.api_table, eng.partition_api_table)
 
     def calculate(self):
         """One full evaluation; returns (per-partition log-likelihoods, total)."""
@@ -161,21 +214,40 @@ class MultiPartitionTreeLikelihood:
             self._static_tables()
         if not hasattr(self, "_fast"):
             self._fast_tables()
+        import ctypes as C
         f, fn, h, chk = self._fast, b._f, b.instance, b._check
         self.mflip ^= 1
         self.mf[:] = self.mflip                              # (a full evaluation rewrites every buffer: all offsets flip together)
         pf = int(self.flip[T]) ^ 1
         self.flip[T:] = pf
         self._saved = None
+        if getattr(self, "_lens_stale", False):                # node heights moved since the tables were built
+            self._lens0 = np.array([tree.branch_length(int(n)) for n in self._branch])
+            self._lens_stale = False
+        if f["native"] is not None:
+            call, e, api, papi = f["native"]
+            self._flag_subst[:] = self.update_substitution_models; self._flag_site[:] = self.update_site_rate_models
+            ops9, n9, ops7, n7 = f["ops"][(pf, self.mflip)]
+            e.mat_idx, e.ops9, e.n_ops9, e.ops7, e.n_ops7, e.roots = f["mat_idx"][self.mflip], ops9, n9, ops7, n7, f["roots"][pf]
+            e.lens0 = self._lens0.ctypes.data_as(C.POINTER(C.c_double))
+            rates = np.ascontiguousarray(self.branch_rates, dtype=np.float64)
+            rc = call(api, papi, h, C.byref(e), rates.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self._failed))
+            if self._failed.value:
+                chk(("", "setEigenDecomposition", "setCategoryRatesWithIndex", "updateTransitionMatricesWithMultipleModels", "updatePartials(ByPartition)",
+                     "resetScaleFactors(ByPartition)", "accumulateScaleFactors(ByPartition)", "setCategoryWeights", "setStateFrequencies",
+                     "calculateRootLogLikelihoods(ByPartition)")[self._failed.value], rc)
+            self.evaluations += 1
+            self.update_substitution_models = [False] * K        # (:1116-1117)
+            self.update_site_rate_models = [False] * K
+            if K > 1:
+                return self._by_part.copy(), float(self._total[0])
+            return np.array([float(self._total[0])]), float(self._total[0])
         for k in range(K):                                   # (:800-840: only the models flagged as changed go out)
             if self.update_substitution_models[k]:
                 u, ui, lam = f["eig"][k]
                 chk("setEigenDecomposition", fn["SetEigenDecomposition"](h, k, u, ui, lam))
             if self.update_site_rate_models[k]:
                 chk("setCategoryRatesWithIndex", fn["SetCategoryRatesWithIndex"](h, k, f["rates"][k]))
-        if getattr(self, "_lens_stale", False):                # node heights moved since the tables were built
-            self._lens0 = np.array([tree.branch_length(int(n)) for n in self._branch])
-            self._lens_stale = False
         np.multiply(self._lens0, self.branch_rates[self._branch], out=self._lens1)
         self._lens.reshape(K, -1)[:] = self._lens1
         n = len(self._lens)

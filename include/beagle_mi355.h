@@ -422,6 +422,18 @@ typedef struct BeagleApi {
 
 const BeagleApi* beagleGetApiTable(void);
 
+/* The calls of a PARTITIONED instance's evaluation (MultiPartitionDataLikelihoodDelegate.java:800-1083), for a native caller that is
+ * handed a table instead of linking the library (tools/host: the multi-partition call sequence in C++, as the single-partition one). */
+typedef struct BeaglePartitionApi {
+    int (*setCategoryRatesWithIndex)(int, int, const double*);
+    int (*updateTransitionMatricesWithMultipleModels)(int, const int*, const int*, const int*, const int*, const int*, const double*, int);
+    int (*updatePartialsByPartition)(int, const int*, int);
+    int (*resetScaleFactorsByPartition)(int, int, int);
+    int (*accumulateScaleFactorsByPartition)(int, const int*, int, int, int);
+    int (*calculateRootLogLikelihoodsByPartition)(int, const int*, const int*, const int*, const int*, const int*, int, int, double*, double*);
+} BeaglePartitionApi;
+const BeaglePartitionApi* beagleGetPartitionApiTable(void);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

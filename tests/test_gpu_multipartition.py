@@ -263,3 +263,38 @@ def test_partition_roots_inside_the_walk_launch_give_the_bits_of_the_launch_of_t
     assert info1["partition_roots_in_walk"] == 0
     for (a, ta, sa), (b, tb, sb) in zip(fused, plain):
         assert ta == tb and np.array_equal(a, b) and np.array_equal(sa, sb)
+
+
+@pytest.mark.parametrize("always_rescale", [False, True])
+def test_native_call_sequence_is_the_python_one(always_rescale):
+    """calculate() issues its calls from C++ (tools/host mpEvaluate) by default and call by call from Python with
+    native_sequence=False: the same calls in the same order, so the same bits — through rate changes, a model change of one partition
+    (flags) and evaluations in between node-height moves (which are issued from Python either way)."""
+    from beast_mcmc_amd.inputs import synth
+    from beast_mcmc_amd.multipartition import MultiPartitionTreeLikelihood
+    pw = synth.config_e(scale=0.06)
+    heights = np.array(pw.tree.height, dtype=float).copy()
+    kappa0 = pw.parts[1].eig
+
+    def run(native):
+        pw.tree.height[:] = heights
+        pw.parts[1].eig = kappa0
+        tl = MultiPartitionTreeLikelihood(pw, always_rescale=always_rescale, native_sequence=native)
+        out = []
+        for i in range(3):
+            tl.set_branch_rates(np.ones(pw.tree.node_count) * (1.0 + 0.02 * i))
+            by_part, total = tl.calculate()
+            out.append((by_part.copy(), total))
+        tl.set_substitution_model(1, eig=substmodel.hky(3.3, pw.parts[1].freqs))
+        out.append(tuple(x if np.isscalar(x) else x.copy() for x in tl.calculate()))
+        if not always_rescale:
+            tl.move_node_height(pw.tree.tip_count + 3, float(0.5 * (pw.tree.height[pw.tree.tip_count + 3] + pw.tree.height[pw.tree.parent[pw.tree.tip_count + 3]]))) if pw.tree.parent[pw.tree.tip_count + 3] >= 0 else None
+            out.append(tuple(x if np.isscalar(x) else x.copy() for x in tl.calculate()))
+        assert (tl._fast["native"] is not None) == native
+        tl.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for (pa, ta), (pb, tb) in zip(a, b):
+        assert ta == tb and np.array_equal(pa, pb)

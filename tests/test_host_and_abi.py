@@ -24,7 +24,7 @@ def declared_functions():
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     body = hdr[:hdr.index("typedef struct BeagleApi")]
     names = re.findall(r"\b(beagle[A-Za-z0-9]+)\s*\(", body)
-    return sorted(set(names) | {"beagleGetApiTable"})
+    return sorted(set(names) | {"beagleGetApiTable", "beagleGetPartitionApiTable"})
 
 
 def test_engine_library_exports_every_declared_symbol(engine_lib):

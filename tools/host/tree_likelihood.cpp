@@ -529,6 +529,62 @@ int btlTimings(void* h, double* out8) {
     for (int k = 0; k < 8; k++) { out8[k] = t->phaseUs[k]; t->phaseUs[k] = 0.0; }
     return t->timing ? 1 : 0;
 }
+// ---- the multi-partition caller's per-evaluation call sequence ------------------------------------------------------------------
+// What MultiPartitionDataLikelihoodDelegate.calculateLikelihood issues for ONE full evaluation, call for call and in its order
+// (src/dr/evomodel/treedatalikelihood/MultiPartitionDataLikelihoodDelegate.java): models flagged as changed (:800-840), all branch
+// matrices of all partitions in one updateTransitionMatricesWithMultipleModels (:880-887), the operation list (:972-997, 9-int tuples
+// through updatePartialsByPartition), scale factors per partition (:1016-1017), weights and root frequencies of every partition
+// (:1027-1035), the root integration by partition (:1074-1083).  The bookkeeping that decides WHAT is sent — buffer flips, the operation
+// tables of both flips, the model flags — stays in beast_mcmc_amd/multipartition.py, which fills this record; the reference's caller is
+// compiled code, and twenty calls through an interpreter's FFI cost a small partitioned evaluation a fifth of its time.
+struct MpEvaluation {
+    int K, always_rescale, n_matrices, n_ops9, n_ops7, n_scale, cum, n_branches;
+    const int* update_substitution_model; const int* update_site_rate_model;         // [K] flags
+    const double* const* U; const double* const* Uinv; const double* const* lambda;  // [K]
+    const double* const* rates; const double* const* weights; const double* const* freqs;
+    const int* eig_idx; const int* mat_idx; const double* lens0; const int* branch; double* lens;   // lens[k * n_branches + j] = lens0[j] * branch_rates[branch[j]]
+    const int* ops9; const int* ops7; const int* scale_idx;
+    const int* roots; const int* range; const int* cum_idx;
+    double* by_part; double* total;
+};
+// returns 0, or the failing call's return code with *failed = its position in the sequence (1 setEigenDecomposition, 2 setCategoryRates-
+// WithIndex, 3 updateTransitionMatrices..., 4 updatePartials..., 5 reset / 6 accumulateScaleFactors..., 7 setCategoryWeights,
+// 8 setStateFrequencies, 9 the root call); the root call's -8 (a NaN) is returned with *failed = 0: the caller's to judge
+int mpEvaluate(const BeagleApi* api, const BeaglePartitionApi* papi, int inst, const MpEvaluation* e, const double* branchRates, int* failed) {
+    int rc = 0;
+    *failed = 0;
+    const int K = e->K;
+    for (int k = 0; k < K; k++) {
+        if (e->update_substitution_model[k] && (rc = api->setEigenDecomposition(inst, k, e->U[k], e->Uinv[k], e->lambda[k]))) { *failed = 1; return rc; }
+        if (e->update_site_rate_model[k] && (rc = papi->setCategoryRatesWithIndex(inst, k, e->rates[k]))) { *failed = 2; return rc; }
+    }
+    const int nb = e->n_branches;
+    for (int j = 0; j < nb; j++) e->lens[j] = e->lens0[j] * branchRates[e->branch[j]];
+    for (int k = 1; k < K; k++) std::memcpy(e->lens + (size_t)k * nb, e->lens, (size_t)nb * sizeof(double));
+    if ((rc = papi->updateTransitionMatricesWithMultipleModels(inst, e->eig_idx, e->eig_idx, e->mat_idx, nullptr, nullptr, e->lens, e->n_matrices))) { *failed = 3; return rc; }
+    if (K > 1) rc = papi->updatePartialsByPartition(inst, e->ops9, e->n_ops9);
+    else rc = api->updatePartials(inst, e->ops7, e->n_ops7, BEAGLE_OP_NONE);
+    if (rc) { *failed = 4; return rc; }
+    if (e->always_rescale)
+        for (int k = 0; k < K; k++) {
+            if (K > 1) {
+                if ((rc = papi->resetScaleFactorsByPartition(inst, e->cum, k))) { *failed = 5; return rc; }
+                if ((rc = papi->accumulateScaleFactorsByPartition(inst, e->scale_idx, e->n_scale, e->cum, k))) { *failed = 6; return rc; }
+            } else {
+                if ((rc = api->resetScaleFactors(inst, e->cum))) { *failed = 5; return rc; }
+                if ((rc = api->accumulateScaleFactors(inst, e->scale_idx, e->n_scale, e->cum))) { *failed = 6; return rc; }
+            }
+        }
+    for (int k = 0; k < K; k++) {
+        if ((rc = api->setCategoryWeights(inst, k, e->weights[k]))) { *failed = 7; return rc; }
+        if ((rc = api->setStateFrequencies(inst, k, e->freqs[k]))) { *failed = 8; return rc; }
+    }
+    if (K > 1) rc = papi->calculateRootLogLikelihoodsByPartition(inst, e->roots, e->range, e->range, e->cum_idx, e->range, K, 1, e->by_part, e->total);
+    else { rc = api->calculateRootLogLikelihoods(inst, e->roots, e->range, e->range, e->cum_idx, 1, e->total); e->by_part[0] = e->total[0]; }
+    if (rc && rc != -8) *failed = 9;
+    return rc;
+}
+
 // last operation list (7 ints per op), for tests that assert the call protocol
 int btlLastOperations(void* h, int* out, int maxOps) {
     TreeLikelihood* t = (TreeLikelihood*)h;
