@@ -86,3 +86,62 @@ def test_more_categories_than_the_kernel_takes_run_level_by_level(oracle_lib):
     lnl, _, _, _, st = evaluate(wl, RESCALE_ALWAYS, evaluations=1)
     o_lnl, _, _, _, _ = evaluate(wl, RESCALE_ALWAYS, library=oracle_lib, evaluations=1)
     assert st["walks"] == 0 and helpers.rel_err(lnl[0], o_lnl[0]) <= 1e-10
+
+
+@pytest.mark.parametrize("S", [20, 17])
+def test_chain_of_moves_under_always_rescaling(S, oracle_lib):
+    """Scheme ALWAYS through what a chain does: node-height moves (partial lists that write the factors of one path and read their
+    siblings from memory), rejections (restoreState: index flips only), a model change and rate changes in between — every value against
+    the same chain on the level kernels (1e-12) and on the oracle (1e-10)."""
+    from beast_mcmc_amd.inputs import substmodel
+    wl = helpers.random_workload(40, 700, S, 4, seed=31)
+    rng = np.random.default_rng(4)
+    moves = []
+    for step in range(12):
+        kind = ("height", "height", "rates", "model")[step % 4]
+        moves.append((kind, substmodel.random_reversible(S, rng)[0], rng.uniform(0.7, 1.4, size=wl.tree.node_count),
+                      int(rng.integers(wl.tip_count, wl.tree.node_count)), step % 3 == 2))
+
+    def chain(tl):
+        out = [tl.getLogLikelihood()]
+        height = wl.tree.height.copy()
+        for kind, eig, rates, node, reject in moves:
+            tl.storeState()
+            saved = height.copy()
+            if kind == "model":
+                tl.set_substitution_model(eig, wl.freqs)
+            elif kind == "rates":
+                tl.set_branch_rates(rates)
+            elif node != wl.tree.root:
+                lo = max(height[wl.tree.left[node]], height[wl.tree.right[node]])
+                hi = height[wl.tree.parent[node]]
+                height[node] = lo + 0.41 * (hi - lo)
+                tl.set_node_height(node, float(height[node]))
+            else:
+                tl.makeDirty()
+            out.append(tl.getLogLikelihood())
+            if reject:
+                tl.restoreState()
+                height = saved
+                out.append(tl.getLogLikelihood())
+        return out
+
+    runs = {}
+    for name, env, lib in (("walk", {}, None), ("levels", {"BEAGLE_MI355_NO_T32_WRITE_WALK": "1"}, None), ("oracle", {}, oracle_lib)):
+        os.environ.update(env)
+        try:
+            tl = BeagleTreeLikelihood(wl, library=lib, rescaling=RESCALE_ALWAYS, delay_rescaling=False)
+            if name == "walk":
+                raw = bm.beagle.Beagle.attach(tl)
+                raw.kernelTimer(True)
+            runs[name] = chain(tl)
+            if name == "walk":
+                st = raw.walkStats()
+                assert st["walks"] > 0 and st["scale_writes"] > 0
+            tl.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert len(runs["walk"]) == len(runs["levels"]) == len(runs["oracle"])
+    for a, b, c in zip(runs["walk"], runs["levels"], runs["oracle"]):
+        assert helpers.rel_err(a, b) <= 1e-12 and helpers.rel_err(a, c) <= 1e-10
