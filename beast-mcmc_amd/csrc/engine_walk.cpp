@@ -505,7 +505,8 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
                                        (const int*)(stagedProg + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, &L, (int)blocks,
                                        cmBytes ? (const double* const*)(stagedProg + cmOff) : nullptr);
     }
-    else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream);
+    else if (in->walkT) mi355::launchGatherFragments(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->S, in->matStream,
+                                                     anyScaleWriteIn(in, slot, reuse, statsAtEntry[3]));
     else if (fusedSnapshot) mi355::launchGatherAndSnapshot(live(in), (const mi355::WalkOp*)dBase, (int)w.size(), in->C, in->matStream, in->matrices,
                                                            (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2), in->C * in->S * in->S, nullptr, 0,
                                                            cmBytes ? (const double* const*)(dBase + cmOff) : nullptr);
@@ -726,7 +727,9 @@ int walkChunkOps(const Instance* in, int opCount) {
     // 91 at 765 (tools/r06_ticket_sweep2.sh, profiles/r06_experiments.txt).
     const bool fused = in->fuseWaves && in->fastWalk && !in->walkT;
     static const long ticketDiv = labEnv("BEAGLE_MI355_CHUNK_DIV") ? atol(labEnv("BEAGLE_MI355_CHUNK_DIV")) : 0;
-    const long div = !fused ? 2560 : !in->useTickets ? 1400 : ticketDiv > 0 ? ticketDiv : in->partitionCount > 1 ? 1400 : 765;
+    // (the T32 walk since it runs three workgroups per CU — 768 places, round 6 —: config B, 20 states, evaluations/s at 40 / 56 / 76 / 100 /
+    // 130 / 180 micro-operations per slice: 467 / 467 / 475 / 479 / 480 / 455; 76 is what 2 560 gives there, 102 what 1 900 does)
+    const long div = in->walkT ? 1900 : !fused ? 2560 : !in->useTickets ? 1400 : ticketDiv > 0 ? ticketDiv : in->partitionCount > 1 ? 1400 : 765;
     return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / div));
 }
 

@@ -734,55 +734,83 @@ bool launchEdgeTiled(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, con
 // A fragments of a matrix for the walk: frag[it][fl][6] — the five state-tile columns jt of (row tile it, lane slot fl) are
 // CONTIGUOUS (two 16-byte LDS reads and one 8-byte read per row tile instead of five), padded to six doubles so that the 16
 // slots of a row tile fall into distinct banks
-constexpr int WT_NT = 5, WT_ROW = 6, WT_FRAG = WT_NT * 16 * WT_ROW;   // doubles per matrix (480)
+constexpr int WT_NT = 5, WT_ROW = 5, WT_FRAG = WT_NT * 16 * WT_ROW;   // doubles per matrix (400): k_walkT32
+constexpr int WTW_ROW = 6, WTW_FRAG = WT_NT * 16 * WTW_ROW;          // k_walkT32W keeps rows of 6 (480 per matrix: 16-byte LDS reads; its LDS has the room)
 constexpr int WT_HOLD_V2D = WT_NT * 64;                              // v2d per wave and hold slot
 
+template <int ROW>
 __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C, int S, double* __restrict__ stream) {
+    constexpr int FRAG = WT_NT * 16 * ROW;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * C * 2 * WT_FRAG) return;
-    const int r = (int)(t % WT_FRAG), child = (int)((t / WT_FRAG) & 1), c = (int)((t / (2 * WT_FRAG)) % C), k = (int)(t / ((size_t)2 * WT_FRAG * C));
-    const int jt = r % WT_ROW, q = (r / WT_ROW) & 15, it = r / (16 * WT_ROW), i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
+    if (t >= (size_t)n * C * 2 * FRAG) return;
+    const int r = (int)(t % FRAG), child = (int)((t / FRAG) & 1), c = (int)((t / (2 * FRAG)) % C), k = (int)(t / ((size_t)2 * FRAG * C));
+    const int jt = r % ROW, q = (r / ROW) & 15, it = r / (16 * ROW), i = 4 * it + (q & 3), j = 4 * jt + (q >> 2);
     const double MI355_GLOBAL* M = gptr(child ? prog[k].m2 : prog[k].m1) + (size_t)c * S * S;
     stream[t] = (jt < WT_NT && i < S && j < S) ? M[(size_t)i * S + j] : 0.0;
 }
 
 // One child's factor for all five parent-state tiles from the walk's fragment layout: oe/oo[it] = sum_j M[4 it + g][j] X[j][2m / 2m+1]
 // (a compact tip: column `state` of the matrix, ones for a missing state)
+template <bool ROWWISE = true, int ROW = WT_ROW>
 __device__ __forceinline__ void walkChild5(const double* __restrict__ frag, int S, bool isStates, int se, int so, const v2d (&b)[WT_NT],
                                            int g, int fl, double (&oe)[WT_NT], double (&oo)[WT_NT]) {
     if (isStates) {
         const bool ge = se < S, go = so < S;
-        const double* fe = frag + (ge ? (((se & 3) * 4 + g) * WT_ROW + (se >> 2)) : 0);
-        const double* fo = frag + (go ? (((so & 3) * 4 + g) * WT_ROW + (so >> 2)) : 0);
+        const double* fe = frag + (ge ? (((se & 3) * 4 + g) * ROW + (se >> 2)) : 0);
+        const double* fo = frag + (go ? (((so & 3) * 4 + g) * ROW + (so >> 2)) : 0);
 #pragma unroll
         for (int it = 0; it < WT_NT; it++) {
-            const double ve = fe[it * 16 * WT_ROW], vo = fo[it * 16 * WT_ROW];
+            const double ve = fe[it * 16 * ROW], vo = fo[it * 16 * ROW];
             oe[it] = ge ? ve : 1.0;
             oo[it] = go ? vo : 1.0;
         }
         return;
     }
-    double a[WT_NT][WT_NT];
-#pragma unroll
-    for (int it = 0; it < WT_NT; it++) {
-        const double* row = frag + (it * 16 + fl) * WT_ROW;
-        const v2d r0 = *reinterpret_cast<const v2d*>(row), r1 = *reinterpret_cast<const v2d*>(row + 2);
-        a[it][0] = r0.x; a[it][1] = r0.y; a[it][2] = r1.x; a[it][3] = r1.y; a[it][4] = row[4];
-    }
-#pragma unroll
-    for (int it = 0; it < WT_NT; it++) { oe[it] = 0.0; oo[it] = 0.0; }
-#pragma unroll
-    for (int jt = 0; jt < WT_NT; jt++) {
+    // row tile by row tile (round 6): a row's five fragments (40 bytes in LDS: rows of 5 doubles fall into distinct banks as they
+    // are — lane slot fl starts at bank 10 fl mod 64 —, so no padding: 12.5 KiB of fragment buffers, and with the hold slots' 40 KiB a
+    // workgroup fits a CU three times), then its ten MFMAs — two accumulators (even / odd patterns), each a chain over the five column
+    // tiles; the matrix pipe takes a wave's instructions one after the other anyway.  Rounds 3-5 read all 25 fragments first (50
+    // registers live at once: 208 VGPRs, two waves per SIMD) — and k_walkT32W, whose occupancy the LDS decides, still does (ROWWISE = false).
+    if (!ROWWISE) {
+        double a[WT_NT][WT_NT];
 #pragma unroll
         for (int it = 0; it < WT_NT; it++) {
-            oe[it] = mfma4(a[it][jt], b[jt].x, oe[it]);
-            oo[it] = mfma4(a[it][jt], b[jt].y, oo[it]);
+            const double* row = frag + (it * 16 + fl) * ROW;
+            if (ROW % 2 == 0) {                   // (rows of 6: 16-byte aligned — two 16-byte reads and one of 8 per row tile)
+                const v2d r0 = *reinterpret_cast<const v2d*>(row), r1 = *reinterpret_cast<const v2d*>(row + 2);
+                a[it][0] = r0.x; a[it][1] = r0.y; a[it][2] = r1.x; a[it][3] = r1.y; a[it][4] = row[4];
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < WT_NT; jt++) a[it][jt] = row[jt];
+            }
         }
+#pragma unroll
+        for (int it = 0; it < WT_NT; it++) { oe[it] = 0.0; oo[it] = 0.0; }
+#pragma unroll
+        for (int jt = 0; jt < WT_NT; jt++) {
+#pragma unroll
+            for (int it = 0; it < WT_NT; it++) {
+                oe[it] = mfma4(a[it][jt], b[jt].x, oe[it]);
+                oo[it] = mfma4(a[it][jt], b[jt].y, oo[it]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < WT_NT; it++) {
+        const double* row = frag + (it * 16 + fl) * ROW;
+        double a[WT_NT];
+#pragma unroll
+        for (int jt = 0; jt < WT_NT; jt++) a[jt] = row[jt];
+        double e = 0.0, o = 0.0;
+#pragma unroll
+        for (int jt = 0; jt < WT_NT; jt++) { e = mfma4(a[jt], b[jt].x, e); o = mfma4(a[jt], b[jt].y, o); }
+        oe[it] = e; oo[it] = o;
     }
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+__global__ __launch_bounds__(MF_BLOCK, 3) void k_walkT32(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
                                                          const double* __restrict__ fragStream, int P, int S, int C) {
     extern __shared__ double wtLds[];              // frag[2][2 * WT_FRAG] doubles, then hold[3][4 waves][WT_NT][64] v2d
     const WalkSeg& sg = segs[blockIdx.y / C];
@@ -807,7 +835,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     const size_t fsStep = (size_t)C * WT_FRAG;
     v2d* fragV = reinterpret_cast<v2d*>(wtLds);
     {   // the first micro-operation's fragments
-        const int t = threadIdx.x;                 // 2 matrices x 480 doubles = WT_FRAG v2d
+        const int t = threadIdx.x;                 // 2 matrices x 400 doubles = WT_FRAG v2d
         fragV[t] = fs[t];
         if (t < WT_FRAG - 256) fragV[t + 256] = fs[t + 256];
     }
@@ -817,20 +845,22 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
     for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
     // What a micro-operation needs from memory as a matter of course — the host points unused operands at dummies, engine_walk.cpp, so
     // the same instructions go out whatever the kinds are and the waits are constants:
-    //  * its 7.7 KB of fragments (480 v2d): ONE micro-operation ahead, by LDS-DMA (round 6; global_load_lds_dwordx4 — 64 lanes x 16
+    //  * its 6.4 KB of fragments (400 v2d): ONE micro-operation ahead, by LDS-DMA (round 6; global_load_lds_dwordx4 — 64 lanes x 16
     //    bytes land in 1 KB of LDS at M0: no registers, no ds_write; rounds 3-5 took them through registers two ahead), two per wave:
-    //    256 threads x 2 x 16 bytes over the 480 x 16 — the second piece is short (224 lanes of the workgroup): wave 3 issues it with
-    //    half its EXEC;
+    //    256 threads x 2 x 16 bytes over the 400 x 16 — the second piece is short (144 lanes of the workgroup): wave 2 issues it with
+    //    a quarter of its EXEC, wave 3 not at all;
     //  * the two children's state codes (one ushort each: the lane's two patterns are neighbours) and the raw scale factors (one
-    //    16-byte load): TWO ahead, into registers.
-    // Issue order in stage k: [wait: operands of k] DMA(k + 1) x 2, operands(k + 2) x 3, ... [wait: DMA(k + 1)] barrier.  Both waits
-    // are "all but the three youngest": at the stage's start those are operands(k + 1) (DMA(k) was waited for before the last
-    // barrier), at its end operands(k + 2).  Loads return in issue order; stores and the compiler's own loads in the queue only make a
-    // wait stricter.  The compiler cannot express that (it drains the queue at the first use), hence inline assembly, as in
+    //    16-byte load): ONE ahead as well, into ONE set of six registers (rounds 3-5: two sets, two ahead; at three waves per SIMD
+    //    the second set made the register allocator split the live range of a register a load was still writing — tools/
+    //    check_walk_isa.py caught it — and a stage is ~1 us: one ahead covers an L2 hit several times over).
+    // Issue order in stage k: [wait: operands of k = everything outstanding] DMA(k + 1) x 2, operands(k + 1) x 3, ... [wait: DMA(k + 1) =
+    // all but the three youngest] barrier.  Loads return in issue order; stores and the compiler's own loads in the queue only make a
+    // wait stricter (a stage that stored its result finds its last stores waited for at the next stage's start).  The compiler cannot express that (it drains the queue at the first use), hence inline assembly, as in
     // kernels_walk4.hip.  A child's PARTIALS in memory are rare (20 of 499 micro-operations of config B) and are read where needed.
     struct Flight { unsigned t1, t2; v2d sc; };                      // one micro-operation's operand loads (registers written asynchronously)
     const unsigned oFrag = (unsigned)threadIdx.x * 16u, oFrag2 = oFrag + 4096u, oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
-    const unsigned long long mask2 = wave == 3 ? 0xffffffffull : ~0ull;                   // (480 - 256 = 224 lanes: three waves and a half)
+    const int n1 = WT_FRAG - 256 - 64 * wave;                                             // lanes of this wave that carry a second piece (400 - 256 = 144: two waves and a quarter)
+    const unsigned long long mask2 = n1 >= 64 ? ~0ull : n1 > 0 ? (1ull << n1) - 1ull : 0ull;
     const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (the dynamic LDS starts behind the static: there is none)
     const unsigned ldsW = ldsBase + (unsigned)wave * 1024u, fragBytes = (unsigned)(2 * WT_FRAG) * 8u;
     auto issue = [&](Flight& f, const WalkOp& d) {
@@ -847,41 +877,50 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
         unsigned keep;
         unsigned long long ex;
         const unsigned l0 = __builtin_amdgcn_readfirstlane(ldsW + parity * fragBytes), l1 = l0 + 4096u;
-        asm volatile(
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
-            "s_mov_b32 m0, %[l1]\n\ts_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], %[m2]\n\tglobal_load_lds_dwordx4 %[o1], %[fp]\n\ts_mov_b64 exec, %[ex]\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep), [ex] "=&s"(ex)
-            : [l0] "s"(l0), [l1] "s"(l1), [o0] "v"(oFrag), [o1] "v"(oFrag2), [fp] "s"(fptr), [m2] "s"(mask2)
-            : "memory", "scc");
+        // (the waits count the OPERAND loads behind the DMAs, not the DMAs: a wave without a second piece simply issues one)
+        if (n1 > 0)
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\t"
+                "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
+                "s_mov_b32 m0, %[l1]\n\ts_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], %[m2]\n\tglobal_load_lds_dwordx4 %[o1], %[fp]\n\ts_mov_b64 exec, %[ex]\n\t"
+                "s_mov_b32 m0, %[keep]"
+                : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                : [l0] "s"(l0), [l1] "s"(l1), [o0] "v"(oFrag), [o1] "v"(oFrag2), [fp] "s"(fptr), [m2] "s"(mask2)
+                : "memory", "scc");
+        else
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\t"
+                "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
+                "s_mov_b32 m0, %[keep]"
+                : [keep] "=&s"(keep)
+                : [l0] "s"(l0), [o0] "v"(oFrag), [fp] "s"(fptr)
+                : "memory");
     };
     // "At most the three loads issued last are outstanding".  The registers of a Flight are written asynchronously, so the
     // compiler must never be given a reason to copy one between issue and wait: the wait below only READS them (no tied
     // operands — a tie made the compiler move a destination to another register BEFORE the wait), and what has to outlive the
     // set's next issue is copied out inside the same statement, after the wait.  tools/check_walk_isa.py verifies the result.
     auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
-        asm volatile("s_waitcnt vmcnt(3) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
+        asm volatile("s_waitcnt vmcnt(0) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
                      "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
                      : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
     };
-    Flight A, B;
-    A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
-    issue(A, dp[0]);
-    issue(B, dp[1]);
+    Flight F;
+    F.sc = v2d{1.0, 1.0}; F.t1 = F.t2 = 0u;
+    issue(F, dp[0]);
 
-    // CUR: the set that holds micro-operation k's operands (issued two stages ago) and is re-used for k + 2's; NXT: k + 1's
-#define WT_STAGE(CUR, NXT)                                                                                                  \
+    // F: the one set of operand registers — micro-operation k's when the stage begins, handed to k + 1's loads as soon as they are read out
+#define WT_STAGE()                                                                                                  \
     {                                                                                                                     \
         const WalkOp& d = dp[k];                                                                                          \
         const unsigned flg = d.flags;                                                                                     \
         const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3;                                      \
         unsigned t1, t2;                                                                                                  \
         double fe, fo;                                                                                                    \
-        landedOperands(CUR, t1, t2, fe, fo);                          /* (read out before the set is handed to the next loads) */ \
+        landedOperands(F, t1, t2, fe, fo);                            /* (read out before the set is handed to the next loads) */ \
         dma(fs + (size_t)(k + 1) * fsStep, (unsigned)((k + 1) & 1));                                                      \
-        issue(CUR, dp[k + 2]);                                                                                            \
+        issue(F, dp[k + 1]);                                                                                              \
         const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
         const double* frag = wtLds + (size_t)(k & 1) * 2 * WT_FRAG;                                                       \
         /* the second child first: the running result (ACC) is consumed where it stands */                                \
@@ -922,11 +961,8 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT32(const WalkOp* __restric
         /* the next micro-operation's fragments have landed in the other buffer (this wave's share: the barrier makes it everybody's) */ \
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
     }
-    for (int k = 0; k < nOps; k += 2) {            // (the host pads every segment to an even count; two more no-ops follow it, plus the stream's slack)
-        WT_STAGE(A, B)
-        k++;
-        WT_STAGE(B, A)
-        k--;
+    for (int k = 0; k < nOps; k++) {               // (one more readable descriptor and stream entry follow the segment: its trailing no-ops)
+        WT_STAGE()
     }
 #undef WT_STAGE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -959,7 +995,7 @@ __device__ __forceinline__ double maxOverRows(double v) {
 template <bool EXACT>
 __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
                                                      const double* __restrict__ fragStream, int P, int S, int C, int holdSlots) {
-    extern __shared__ double wtLds[];              // frag[2][C * 2 * WT_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles | a spare KB
+    extern __shared__ double wtLds[];              // frag[2][C * 2 * WTW_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles | a spare KB
     const WalkSeg& sg = segs[blockIdx.y];
     const int nthr = 128 * C, nw = 2 * C;
     const int ntile = (P + TILE - 1) / TILE;
@@ -976,7 +1012,7 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     const int pe = tile * TILE + 2 * m;
     const bool ine = active && pe >= sg.pStart && pe < sg.pEnd, ino = active && pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
     const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
-    const int fragD = C * 2 * WT_FRAG, fragV2 = C * WT_FRAG;           // doubles / v2d per micro-operation (all categories, both children)
+    const int fragD = C * 2 * WTW_FRAG, fragV2 = C * WTW_FRAG;           // doubles / v2d per micro-operation (all categories, both children)
     v2d* hold = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)wave * WT_HOLD_V2D + lane;     // + slot * nw * WT_HOLD_V2D, tile row k at + 64 k
     v2d* mx = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)holdSlots * nw * WT_HOLD_V2D;     // [parity][wave][16] v2d: (even, odd) maxima of pattern pair m
     const int nOps = sg.progCount;
@@ -997,7 +1033,7 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     //  * its fragments, all categories (C x 480 v2d): ONE micro-operation ahead, by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
     //    land in 1 KB of LDS at M0, no registers, no ds_write) — four per wave, 128 C threads x 4 x 16 bytes covering the 480 C x 16; the
     //    fourth piece is short (96 C lanes of the workgroup): its last wave issues it under a partial EXEC, the waves behind it send theirs
-    //    to a spare KB, so that every wave has issued the same number of vector-memory instructions wherever it waits;
+    //    to a spare KB;
     //  * the two children's state codes and the pair of raw factors: TWO ahead, into registers, as k_walkT32.
     // Issue order in stage k: [wait: operands of k] DMA(k + 1) x 4, operands(k + 2) x 3, ... [wait: DMA(k + 1)] barrier.  Both waits are
     // "all but the three youngest": at the stage's start those are operands(k + 1) (DMA(k) was waited for before the last barrier), at
@@ -1005,7 +1041,7 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     // instruction behind that wait (a __syncthreads() would be too — the compiler does not see the DMA — but says less).
     struct Flight { unsigned t1, t2; v2d sc; };                        // (registers written asynchronously: k_walkT32)
     const unsigned oF0 = (unsigned)t * 16u, oF1 = oF0 + (unsigned)nthr * 16u, oF2 = oF1 + (unsigned)nthr * 16u;
-    const int n3 = 96 * C - 64 * wave;                                 // lanes of this wave that carry a fourth piece
+    const int n3 = (WTW_FRAG - 384) * C - 64 * wave;                    // lanes of this wave that carry a fourth piece (96 C of the workgroup's)
     const unsigned oF3 = n3 > 0 ? oF2 + (unsigned)nthr * 16u : oF0;
     const unsigned long long mask3 = n3 >= 64 || n3 <= 0 ? ~0ull : (1ull << n3) - 1ull;
     const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (the dynamic LDS starts behind the static: there is none)
@@ -1060,13 +1096,13 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
         dma(fs + (size_t)(k + 1) * fsStep, ldsBase + (unsigned)((k + 1) & 1) * fragBytes);                                \
         issue(CUR, dp[k + 2]);                                                                                            \
         const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
-        const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WT_FRAG;                                   \
+        const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WTW_FRAG;                                   \
         double te[WT_NT], to[WT_NT];                                                                                      \
-        if (k2 == WK_ACC) walkChild5(frag + WT_FRAG, S, false, S, S, ACC, g, fl, te, to);                                 \
+        if (k2 == WK_ACC) walkChild5<false, WTW_ROW>(frag + WTW_FRAG, S, false, S, S, ACC, g, fl, te, to);                                 \
         else {                                                                                                            \
             v2d b2[WT_NT];                                                                                                \
             if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);                                    \
-            walkChild5(frag + WT_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);                                    \
+            walkChild5<false, WTW_ROW>(frag + WTW_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);                                    \
         }                                                                                                                 \
         const bool rd = smode == WS_READ, wr = smode == WS_WRITE;                                                         \
         const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;                                              \
@@ -1078,7 +1114,7 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
                 _Pragma("unroll") for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];                                      \
             }                                                                                                             \
             double re[WT_NT], ro[WT_NT];                                                                                  \
-            walkChild5(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);                                              \
+            walkChild5<false, WTW_ROW>(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);                                              \
             _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};   \
         }                                                                                                                 \
         /* this (tile, category)'s maxima over the states (rows 4 j + g, g in lanes l ^ 16, l ^ 32) — formed and exchanged by EVERY    \
@@ -1131,18 +1167,19 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 static size_t walkT32WLds(int holdSlots, int C) {
-    return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d) + 1024;   // (+ the spare KB)
+    return (size_t)2 * C * 2 * WTW_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d) + 1024;   // (+ the spare KB)
 }
 
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
 static size_t walkT32Lds(int holdSlots) { return (size_t)4 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 4 * WT_HOLD_V2D * sizeof(v2d); }
 
 // the fragment stream of a device program of nEntries descriptors: [entry][category][child][25 tile pairs][16]
-size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WT_FRAG * sizeof(double); }
-void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream) {
+size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WTW_FRAG * sizeof(double); }      // (the larger of the two layouts)
+void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream, bool writeMode) {
     if (nEntries <= 0) return;
-    const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
-    hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
+    const size_t total = (size_t)nEntries * C * 2 * (writeMode ? WTW_FRAG : WT_FRAG);
+    if (writeMode) hipLaunchKernelGGL(k_gatherFragments<WTW_ROW>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
+    else hipLaunchKernelGGL(k_gatherFragments<WT_ROW>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
 }
 bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
                    bool writeMode) {
