@@ -141,7 +141,7 @@ struct Instance {
     // 16..20 states: operation lists without write-mode rescaling run as the walk's programs on the T32 layout (kernels_mfma.hip
     // k_walkT32: same planner, same descriptors; engine_walk.cpp); everything 4-state-specific (`walk`) stays off
     bool walkT = false;
-    // ... and its write-mode form (k_walkT32W: lists that rescale in write mode stay on the walk; at most four categories, two hold slots;
+    // ... and its write-mode form (k_walkT32W1: lists that rescale in write mode stay on the walk; at most four categories, two hold slots;
     // BEAGLE_MI355_NO_T32_WRITE_WALK=1: they run level by level, as until round 6)
     bool walkTWrite = false;
     // 4-state partitioned instances: the top slices of the partitions finish calculateRootLogLikelihoodsByPartition inside the walk's launch

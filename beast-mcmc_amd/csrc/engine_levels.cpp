@@ -320,7 +320,7 @@ int foldCumulative(Instance* in, const int* ops, int count, int tuple, int globa
 int runOperations(Instance* in, const int* ops, int count, int tuple, int globalCum) {
     if (in->walk) return runOperationsWalk(in, ops, count, tuple, globalCum);
     if (in->walkT) {
-        // a list that rescales in write mode: the walk's write-mode form (kernels_mfma.hip k_walkT32W) up to four categories; beyond
+        // a list that rescales in write mode: the walk's write-mode form (kernels_mfma.hip k_walkT32W1) up to four categories; beyond
         // that (a pattern's factor needs all its categories in one workgroup) level by level, on operands that exist in memory
         bool writes = false;
         for (int k = 0; k < count && !writes; k++) writes = ops[(size_t)k * tuple + 1] != BEAGLE_OP_NONE;

@@ -451,10 +451,9 @@ int  pruneBlocksForRange(int S, int range);
 // walk (src = plain tip states / T32 partials, scale = the RAW factors, no write mode); dStream from launchGatherFragments over
 // the same device program (walkT32StreamBytes)
 size_t walkT32StreamBytes(int nEntries, int C);
-void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream, bool writeMode = false);
-// (writeMode: the program goes to k_walkT32W, which reads fragment rows of 6 doubles where k_walkT32 reads rows of 5)
-// writeMode (a program with write-mode rescaling in it — k_walkT32W: a workgroup is two tiles x all categories; at most
-// WALK_T32_WRITE_MAX_CATEGORIES of them and two hold slots: false otherwise)
+void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
+// writeMode (a program with write-mode rescaling in it — k_walkT32W1: a workgroup is all categories of one tile, hold slots in registers;
+// at most WALK_T32_WRITE_MAX_CATEGORIES of them and two hold slots: false otherwise)
 constexpr int WALK_T32_WRITE_MAX_CATEGORIES = 4, WALK_T32_WRITE_MAX_HOLD = 2;
 bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
                    bool writeMode = false);

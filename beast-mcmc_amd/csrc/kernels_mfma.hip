@@ -735,12 +735,10 @@ bool launchEdgeTiled(hipStream_t stream, const EdgeDesc* dEdges, int nEdges, con
 // CONTIGUOUS (two 16-byte LDS reads and one 8-byte read per row tile instead of five), padded to six doubles so that the 16
 // slots of a row tile fall into distinct banks
 constexpr int WT_NT = 5, WT_ROW = 5, WT_FRAG = WT_NT * 16 * WT_ROW;   // doubles per matrix (400): k_walkT32
-constexpr int WTW_ROW = 6, WTW_FRAG = WT_NT * 16 * WTW_ROW;          // k_walkT32W keeps rows of 6 (480 per matrix: 16-byte LDS reads; its LDS has the room)
 constexpr int WT_HOLD_V2D = WT_NT * 64;                              // v2d per wave and hold slot
 
-template <int ROW>
 __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C, int S, double* __restrict__ stream) {
-    constexpr int FRAG = WT_NT * 16 * ROW;
+    constexpr int ROW = WT_ROW, FRAG = WT_FRAG;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * C * 2 * FRAG) return;
     const int r = (int)(t % FRAG), child = (int)((t / FRAG) & 1), c = (int)((t / (2 * FRAG)) % C), k = (int)(t / ((size_t)2 * FRAG * C));
@@ -751,16 +749,15 @@ __global__ void k_gatherFragments(const WalkOp* __restrict__ prog, int n, int C,
 
 // One child's factor for all five parent-state tiles from the walk's fragment layout: oe/oo[it] = sum_j M[4 it + g][j] X[j][2m / 2m+1]
 // (a compact tip: column `state` of the matrix, ones for a missing state)
-template <bool ROWWISE = true, int ROW = WT_ROW>
 __device__ __forceinline__ void walkChild5(const double* __restrict__ frag, int S, bool isStates, int se, int so, const v2d (&b)[WT_NT],
                                            int g, int fl, double (&oe)[WT_NT], double (&oo)[WT_NT]) {
     if (isStates) {
         const bool ge = se < S, go = so < S;
-        const double* fe = frag + (ge ? (((se & 3) * 4 + g) * ROW + (se >> 2)) : 0);
-        const double* fo = frag + (go ? (((so & 3) * 4 + g) * ROW + (so >> 2)) : 0);
+        const double* fe = frag + (ge ? (((se & 3) * 4 + g) * WT_ROW + (se >> 2)) : 0);
+        const double* fo = frag + (go ? (((so & 3) * 4 + g) * WT_ROW + (so >> 2)) : 0);
 #pragma unroll
         for (int it = 0; it < WT_NT; it++) {
-            const double ve = fe[it * 16 * ROW], vo = fo[it * 16 * ROW];
+            const double ve = fe[it * 16 * WT_ROW], vo = fo[it * 16 * WT_ROW];
             oe[it] = ge ? ve : 1.0;
             oo[it] = go ? vo : 1.0;
         }
@@ -770,35 +767,10 @@ __device__ __forceinline__ void walkChild5(const double* __restrict__ frag, int 
     // are — lane slot fl starts at bank 10 fl mod 64 —, so no padding: 12.5 KiB of fragment buffers, and with the hold slots' 40 KiB a
     // workgroup fits a CU three times), then its ten MFMAs — two accumulators (even / odd patterns), each a chain over the five column
     // tiles; the matrix pipe takes a wave's instructions one after the other anyway.  Rounds 3-5 read all 25 fragments first (50
-    // registers live at once: 208 VGPRs, two waves per SIMD) — and k_walkT32W, whose occupancy the LDS decides, still does (ROWWISE = false).
-    if (!ROWWISE) {
-        double a[WT_NT][WT_NT];
-#pragma unroll
-        for (int it = 0; it < WT_NT; it++) {
-            const double* row = frag + (it * 16 + fl) * ROW;
-            if (ROW % 2 == 0) {                   // (rows of 6: 16-byte aligned — two 16-byte reads and one of 8 per row tile)
-                const v2d r0 = *reinterpret_cast<const v2d*>(row), r1 = *reinterpret_cast<const v2d*>(row + 2);
-                a[it][0] = r0.x; a[it][1] = r0.y; a[it][2] = r1.x; a[it][3] = r1.y; a[it][4] = row[4];
-            } else {
-#pragma unroll
-                for (int jt = 0; jt < WT_NT; jt++) a[it][jt] = row[jt];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < WT_NT; it++) { oe[it] = 0.0; oo[it] = 0.0; }
-#pragma unroll
-        for (int jt = 0; jt < WT_NT; jt++) {
-#pragma unroll
-            for (int it = 0; it < WT_NT; it++) {
-                oe[it] = mfma4(a[it][jt], b[jt].x, oe[it]);
-                oo[it] = mfma4(a[it][jt], b[jt].y, oo[it]);
-            }
-        }
-        return;
-    }
+    // registers live at once: 208 VGPRs, two waves per SIMD).
 #pragma unroll
     for (int it = 0; it < WT_NT; it++) {
-        const double* row = frag + (it * 16 + fl) * ROW;
+        const double* row = frag + (it * 16 + fl) * WT_ROW;
         double a[WT_NT];
 #pragma unroll
         for (int jt = 0; jt < WT_NT; jt++) a[jt] = row[jt];
@@ -972,13 +944,14 @@ __global__ __launch_bounds__(MF_BLOCK, 3) void k_walkT32(const WalkOp* __restric
 // A pattern's factor is the maximum over its states AND its rate categories (GeneralLikelihoodCore.java:281-318 scalePartials), and
 // k_walkT32 keeps a workgroup to ONE category so that its waves can share the matrices: it has no write mode, and until round 6 a
 // list that rescaled ran level by level — every node stored and read back, 32 GB per evaluation of config B, 6.5 ms against the
-// read-mode walk's 2.5.  Here a workgroup is TWO tiles x all C (<= 4) categories, wave = (tile, category): the C waves of a tile
-// leave their per-pattern maxima in LDS on the way into the stage's barrier (which the fragment staging needs anyway: no barrier
-// more), every wave reads the C of them behind it, divides its result — the same two roundings as k_pruneTiledWrite: the stored
-// value times the reciprocal of the factor — and category 0's wave stores the factor.  The price is the matrices: a workgroup
-// stages all C categories' fragments of a micro-operation (30 KB at C = 4, double-buffered: 61 KB) for two tiles instead of one
-// category's 7.7 KB for four; with two hold slots that is 145 KB of LDS — one workgroup of eight waves per CU, the two waves per
-// SIMD k_walkT32 has.  Read-mode and unscaled micro-operations run as there (a DYNAMIC chain's lists that rescale mix both).
+// read-mode walk's 2.5.  k_walkT32W1 below puts all C (<= 4) categories of a tile into one workgroup: its waves leave their
+// per-pattern maxima in LDS on the way into the stage's barrier (which the fragment staging needs anyway: no barrier more), every
+// wave reads the C of them behind it and multiplies its result by the reciprocal of their maximum — the two roundings of
+// k_pruneTiledWrite: the stored value times the reciprocal of the factor — and category 0's wave stores the factor.  The exchange
+// runs for every micro-operation, straight-line (a program of this kernel rescales nearly everywhere; a multiplication by 1.0 changes
+// no bit); read-mode and unscaled micro-operations of the same list behave as in k_walkT32.
+// (The first form, earlier in round 6: TWO tiles x C categories per workgroup, the hold slots in LDS — 145 KB, one workgroup of eight
+// waves per CU: config B under ALWAYS 154 -> 282 evaluations/s; this one: 328.  profiles/r06_experiments.txt 11, 16.)
 // max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four state rows of a tile column), in every one of them: gfx950's lane-row
 // swaps — two instructions per 32-bit half and step, no LDS round trip (ds_bpermute, what __shfl_xor compiles to, is one per half and step)
 __device__ __forceinline__ double maxOverRows(double v) {
@@ -992,62 +965,51 @@ __device__ __forceinline__ double maxOverRows(double v) {
     return fmax(__hiloint2double((int)b1[0], (int)b0[0]), __hiloint2double((int)b1[1], (int)b0[1]));
 }
 
+// ONE tile per workgroup, the hold slots in registers.
+// What held the first form at one workgroup of eight waves per CU was 80 KB of LDS hold slots.  A hold slot is lane-private — the wave
+// that parks a result is the wave that takes it back, lane for lane — so it can be ten registers instead of 5 KB of LDS: with the
+// changes that took k_walkT32 to 120 registers (fragments row tile by row tile, one set of operand registers, one stage per loop
+// iteration) two slots fit a 168-register budget.  The workgroup is then the C categories of ONE tile (wave = category), its LDS
+// the two fragment buffers (rows of 5: 12.5 KB per category and buffer, every wave DMAs its own category's) and the maxima:
+// 52 KB at C = 4 — THREE workgroups per CU, three waves per SIMD, and a barrier couples four waves instead of eight.
 template <bool EXACT>
-__global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
-                                                     const double* __restrict__ fragStream, int P, int S, int C, int holdSlots) {
-    extern __shared__ double wtLds[];              // frag[2][C * 2 * WTW_FRAG] doubles | hold[slots][waves][WT_NT][64] v2d | mx[2][waves][32] doubles | a spare KB
+__global__ __launch_bounds__(256, 3) void k_walkT32W1(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+                                                      const double* __restrict__ fragStream, int P, int S, int C) {
+    extern __shared__ double wtLds[];              // frag[2][C][2 * WT_FRAG] doubles | mx[2][C][16] v2d
     const WalkSeg& sg = segs[blockIdx.y];
-    const int nthr = 128 * C, nw = 2 * C;
     const int ntile = (P + TILE - 1) / TILE;
     const int tile1 = (sg.pEnd + TILE - 1) / TILE;
-    const int tileB = sg.pStart / TILE + (int)blockIdx.x * 2;
-    if (tileB >= tile1) return;                    // the whole workgroup
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = wave % C, tw = wave / C;
+    const int tile = sg.pStart / TILE + (int)blockIdx.x;
+    if (tile >= tile1) return;                     // the whole workgroup
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave = rate category
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int fl = g * 4 + (lane & 3);
-    const bool active = tileB + tw < tile1;        // a wave past the end walks the last tile along (barriers, staging, maxima) and stores nothing
-    const int tile = active ? tileB + tw : tile1 - 1;
     const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
     const int pe = tile * TILE + 2 * m;
-    const bool ine = active && pe >= sg.pStart && pe < sg.pEnd, ino = active && pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
+    const bool ine = pe >= sg.pStart && pe < sg.pEnd, ino = pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
     const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
-    const int fragD = C * 2 * WTW_FRAG, fragV2 = C * WTW_FRAG;           // doubles / v2d per micro-operation (all categories, both children)
-    v2d* hold = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)wave * WT_HOLD_V2D + lane;     // + slot * nw * WT_HOLD_V2D, tile row k at + 64 k
-    v2d* mx = reinterpret_cast<v2d*>(wtLds + 2 * fragD) + (size_t)holdSlots * nw * WT_HOLD_V2D;     // [parity][wave][16] v2d: (even, odd) maxima of pattern pair m
+    const int fragD = C * 2 * WT_FRAG;             // doubles per micro-operation (all categories, both children)
+    v2d* mx = reinterpret_cast<v2d*>(wtLds + 2 * fragD);                     // [parity][category][16] v2d: (even, odd) maxima of pattern pair m
     const int nOps = sg.progCount;
     const WalkOp* dp = prog + sg.progStart;
-    const v2d MI355_GLOBAL* fs = gptr(reinterpret_cast<const v2d*>(fragStream)) + (size_t)sg.progStart * fragV2;
-    const size_t fsStep = (size_t)fragV2;
-    v2d* fragV = reinterpret_cast<v2d*>(wtLds);
-    const int t = threadIdx.x;
-    {   // the first micro-operation's fragments
-        fragV[t] = fs[t]; fragV[t + nthr] = fs[t + nthr]; fragV[t + 2 * nthr] = fs[t + 2 * nthr];
-        if (t + 3 * nthr < fragV2) fragV[t + 3 * nthr] = fs[t + 3 * nthr];
+    // this wave's category of every entry: WT_FRAG v2d at [entry][category]
+    const v2d MI355_GLOBAL* fs = gptr(reinterpret_cast<const v2d*>(fragStream)) + ((size_t)sg.progStart * C + c) * WT_FRAG;
+    const size_t fsStep = (size_t)C * WT_FRAG;
+    {   // the first micro-operation's fragments (this wave's category)
+        v2d* fw = reinterpret_cast<v2d*>(wtLds) + (size_t)c * WT_FRAG;
+        for (int i = lane; i < WT_FRAG; i += 64) fw[i] = fs[i];
     }
     __syncthreads();
-    v2d ACC[WT_NT];
+    v2d ACC[WT_NT], H0[WT_NT], H1[WT_NT];
 #pragma unroll
-    for (int k = 0; k < WT_NT; k++) ACC[k] = v2d{1.0, 1.0};
-    // What a micro-operation needs from memory as a matter of course:
-    //  * its fragments, all categories (C x 480 v2d): ONE micro-operation ahead, by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
-    //    land in 1 KB of LDS at M0, no registers, no ds_write) — four per wave, 128 C threads x 4 x 16 bytes covering the 480 C x 16; the
-    //    fourth piece is short (96 C lanes of the workgroup): its last wave issues it under a partial EXEC, the waves behind it send theirs
-    //    to a spare KB;
-    //  * the two children's state codes and the pair of raw factors: TWO ahead, into registers, as k_walkT32.
-    // Issue order in stage k: [wait: operands of k] DMA(k + 1) x 4, operands(k + 2) x 3, ... [wait: DMA(k + 1)] barrier.  Both waits are
-    // "all but the three youngest": at the stage's start those are operands(k + 1) (DMA(k) was waited for before the last barrier), at
-    // its end operands(k + 2); the compiler's own loads and stores in between only make a wait stricter.  The barrier is the bare
-    // instruction behind that wait (a __syncthreads() would be too — the compiler does not see the DMA — but says less).
-    struct Flight { unsigned t1, t2; v2d sc; };                        // (registers written asynchronously: k_walkT32)
-    const unsigned oF0 = (unsigned)t * 16u, oF1 = oF0 + (unsigned)nthr * 16u, oF2 = oF1 + (unsigned)nthr * 16u;
-    const int n3 = (WTW_FRAG - 384) * C - 64 * wave;                    // lanes of this wave that carry a fourth piece (96 C of the workgroup's)
-    const unsigned oF3 = n3 > 0 ? oF2 + (unsigned)nthr * 16u : oF0;
-    const unsigned long long mask3 = n3 >= 64 || n3 <= 0 ? ~0ull : (1ull << n3) - 1ull;
-    const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (the dynamic LDS starts behind the static: there is none)
-    const unsigned ldsSpare = ldsBase + (unsigned)(2 * fragD) * 8u + (unsigned)(holdSlots * nw * WT_HOLD_V2D + 2 * nw * 16) * 16u;
-    const unsigned ldsW = ldsBase + (unsigned)wave * 1024u, pieceStep = (unsigned)nthr * 16u;
-    const unsigned oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
+    for (int k = 0; k < WT_NT; k++) { ACC[k] = v2d{1.0, 1.0}; H0[k] = ACC[k]; H1[k] = ACC[k]; }
+    // Per stage and wave: seven LDS-DMAs (its category's 400 v2d of the NEXT micro-operation: six of 64 lanes and one of 16) into the
+    // other buffer, then the three operand loads of the next micro-operation into the one set of operand registers (k_walkT32).
+    // Waits: everything outstanding at the stage's start (the operands), all but the three youngest before the barrier (the DMAs).
+    struct Flight { unsigned t1, t2; v2d sc; };
+    const unsigned oFa = (unsigned)lane * 16u, oFb = oFa + 4096u, oPe = (unsigned)pe, oPe8 = (unsigned)pe * 8u;
+    const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();                // (no static LDS: the dynamic block starts here)
+    const unsigned fragBytes = (unsigned)fragD * 8u, ldsC = ldsBase + (unsigned)c * (unsigned)(2 * WT_FRAG) * 8u;
     auto issue = [&](Flight& f, const WalkOp& d) {
         asm volatile(
             "global_load_ushort %[t1], %[oP], %[s1]\n\t"
@@ -1057,146 +1019,145 @@ __global__ __launch_bounds__(512, 1) void k_walkT32W(const WalkOp* __restrict__ 
             : [oP] "v"(oPe), [oS] "v"(oPe8), [s1] "s"(d.src1), [s2] "s"(d.src2), [ss] "s"(d.scale)
             : "memory");
     };
-    auto dma = [&](const v2d MI355_GLOBAL* fptr, unsigned buf) {       // buf: LDS byte address of the fragment buffer that receives the entry at fptr
+    auto dma = [&](const v2d MI355_GLOBAL* fptr, unsigned parity) {
         unsigned keep;
         unsigned long long ex;
-        const unsigned l0 = __builtin_amdgcn_readfirstlane(buf + ldsW - ldsBase), l1 = l0 + pieceStep, l2 = l1 + pieceStep;
-        const unsigned l3 = __builtin_amdgcn_readfirstlane(n3 > 0 ? l2 + pieceStep : ldsSpare);
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(ldsC + parity * fragBytes);
         asm volatile(
             "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[fp]\n\t"
-            "s_mov_b32 m0, %[l1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[fp]\n\t"
-            "s_mov_b32 m0, %[l2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[fp]\n\t"
-            "s_mov_b32 m0, %[l3]\n\ts_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], %[m3]\n\tglobal_load_lds_dwordx4 %[o3], %[fp]\n\ts_mov_b64 exec, %[ex]\n\t"
+            /* (the instruction's offset field moves BOTH ends: memory address and LDS address — measured: with M0 advanced as well the   \
+               pieces landed 1 KB too far per step) */                                                                              \
+            "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[oa], %[fp]\n\t"
+            "global_load_lds_dwordx4 %[oa], %[fp] offset:1024\n\t"
+            "global_load_lds_dwordx4 %[oa], %[fp] offset:2048\n\t"
+            "global_load_lds_dwordx4 %[oa], %[fp] offset:3072\n\t"
+            "s_add_u32 m0, %[l0], 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[ob], %[fp]\n\t"
+            "global_load_lds_dwordx4 %[ob], %[fp] offset:1024\n\t"
+            "s_mov_b64 %[ex], exec\n\ts_and_b64 exec, %[ex], 0xffff\n\tglobal_load_lds_dwordx4 %[ob], %[fp] offset:2048\n\ts_mov_b64 exec, %[ex]\n\t"
             "s_mov_b32 m0, %[keep]"
             : [keep] "=&s"(keep), [ex] "=&s"(ex)
-            : [l0] "s"(l0), [l1] "s"(l1), [l2] "s"(l2), [l3] "s"(l3), [o0] "v"(oF0), [o1] "v"(oF1), [o2] "v"(oF2), [o3] "v"(oF3), [fp] "s"(fptr), [m3] "s"(mask3)
+            : [l0] "s"(l0), [oa] "v"(oFa), [ob] "v"(oFb), [fp] "s"(fptr)
             : "memory", "scc");
     };
     auto landedOperands = [&](const Flight& f, unsigned& t1, unsigned& t2, double& fe, double& fo) {
-        asm volatile("s_waitcnt vmcnt(3) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
+        asm volatile("s_waitcnt vmcnt(0) ; retires %[i1] %[i2] %[ie] %[io]\n\t"
                      "v_mov_b32 %[t1], %[i1]\n\tv_mov_b32 %[t2], %[i2]\n\tv_mov_b64 %[fe], %[ie]\n\tv_mov_b64 %[fo], %[io]"
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [fe] "=&v"(fe), [fo] "=&v"(fo)
                      : [i1] "v"(f.t1), [i2] "v"(f.t2), [ie] "v"(f.sc.x), [io] "v"(f.sc.y) : "memory");
     };
-    Flight A, B;
-    A.sc = v2d{1.0, 1.0}; A.t1 = A.t2 = 0u; B = A;
-    issue(A, dp[0]);
-    issue(B, dp[1]);
-    const unsigned fragBytes = (unsigned)fragD * 8u;
-
-#define WTW_STAGE(CUR, NXT)                                                                                                 \
-    {                                                                                                                     \
-        const WalkOp& d = dp[k];                                                                                          \
-        const unsigned flg = d.flags;                                                                                     \
-        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3, smode = (flg >> 13) & 3;             \
-        unsigned t1, t2;                                                                                                  \
-        double fe, fo;                                                                                                    \
-        landedOperands(CUR, t1, t2, fe, fo);                                                                              \
-        dma(fs + (size_t)(k + 1) * fsStep, ldsBase + (unsigned)((k + 1) & 1) * fragBytes);                                \
-        issue(CUR, dp[k + 2]);                                                                                            \
-        const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff; \
-        const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WTW_FRAG;                                   \
-        double te[WT_NT], to[WT_NT];                                                                                      \
-        if (k2 == WK_ACC) walkChild5<false, WTW_ROW>(frag + WTW_FRAG, S, false, S, S, ACC, g, fl, te, to);                                 \
-        else {                                                                                                            \
-            v2d b2[WT_NT];                                                                                                \
-            if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);                                    \
-            walkChild5<false, WTW_ROW>(frag + WTW_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);                                    \
-        }                                                                                                                 \
-        const bool rd = smode == WS_READ, wr = smode == WS_WRITE;                                                         \
-        const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;                                              \
-        {                                                                                                                 \
-            v2d b1[WT_NT];                                                                                                \
-            if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);                                    \
-            else if (k1 >= WK_H0) {                                                                                       \
-                const v2d* h = hold + (size_t)(k1 - WK_H0) * nw * WT_HOLD_V2D;                                            \
-                _Pragma("unroll") for (int j = 0; j < WT_NT; j++) b1[j] = h[64 * j];                                      \
-            }                                                                                                             \
-            double re[WT_NT], ro[WT_NT];                                                                                  \
-            walkChild5<false, WTW_ROW>(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);                                              \
-            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};   \
-        }                                                                                                                 \
-        /* this (tile, category)'s maxima over the states (rows 4 j + g, g in lanes l ^ 16, l ^ 32) — formed and exchanged by EVERY    \
-           micro-operation, used by those that rescale: straight-line code (a program of this kernel rescales nearly everywhere), and   \
-           a multiplication by 1.0 changes no bit */                                                                     \
-        v2d* mxk = mx + (size_t)(k & 1) * nw * 16;                                                                        \
-        {                                                                                                                 \
-            double me = 0.0, mo = 0.0;                                                                                    \
-            _Pragma("unroll") for (int j = 0; j < WT_NT; j++)                                                             \
-                if (EXACT || 4 * j + g < S) { me = fmax(me, ACC[j].x); mo = fmax(mo, ACC[j].y); }                         \
-            me = maxOverRows(me); mo = maxOverRows(mo);                                                                   \
-            mxk[wave * 16 + m] = v2d{me, mo};       /* (the four lanes of a pattern pair hold the same two values) */      \
-        }                                                                                                                 \
-        /* the next micro-operation's fragments have landed in the other buffer (this wave's share: the barrier makes it everybody's) */ \
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
-        {                                           /* the factor: the maximum over the tile's C categories; zero or NaN: 1 (k_pruneTiledWrite) */ \
-            double me = 0.0, mo = 0.0;                                                                                    \
-            _Pragma("unroll") for (int cc = 0; cc < WALK_T32_WRITE_MAX_CATEGORIES; cc++) {                                \
-                const v2d v = mxk[(tw * C + (cc < C ? cc : C - 1)) * 16 + m];                                             \
-                me = fmax(me, v.x); mo = fmax(mo, v.y);                                                                   \
-            }                                                                                                             \
-            if (!(me > 0.0)) me = 1.0;                                                                                    \
-            if (!(mo > 0.0)) mo = 1.0;                                                                                    \
-            if (wr && c == 0 && g == 0) { if (ine) d.scaleW[pe] = me; if (ino) d.scaleW[pe + 1] = mo; }                   \
-            const double ie = wr ? 1.0 / me : 1.0, io = wr ? 1.0 / mo : 1.0;                                              \
-            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{ACC[j].x * ie, ACC[j].y * io};                 \
-        }                                                                                                                 \
-        if (flg & WF_STORE) {                                                                                             \
-            char* dst = reinterpret_cast<char*>(d.store + tileBase);                                                      \
-            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) {                                                           \
-                if (EXACT || 4 * j + g < S) {                                                                             \
-                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u))); \
-                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));           \
-                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }                                          \
-                }                                                                                                         \
-            }                                                                                                             \
-        }                                                                                                                 \
-        if (hslot) {                                                                                                      \
-            v2d* h = hold + (size_t)(hslot - 1) * nw * WT_HOLD_V2D;                                                       \
-            _Pragma("unroll") for (int j = 0; j < WT_NT; j++) h[64 * j] = ACC[j];                                         \
-        }                                                                                                                 \
+    Flight F;
+    F.sc = v2d{1.0, 1.0}; F.t1 = F.t2 = 0u;
+    issue(F, dp[0]);
+    for (int k = 0; k < nOps; k++) {               // (one more readable descriptor and stream entry follow the segment: its trailing no-ops)
+        const WalkOp& d = dp[k];
+        const unsigned flg = d.flags;
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7, hslot = (flg >> 11) & 3, smode = (flg >> 13) & 3;
+        unsigned t1, t2;
+        double fe, fo;
+        landedOperands(F, t1, t2, fe, fo);
+        dma(fs + (size_t)(k + 1) * fsStep, (unsigned)((k + 1) & 1));
+        issue(F, dp[k + 1]);
+        const int se1 = (int)(t1 & 0xffu), so1 = (int)(t1 >> 8) & 0xff, se2 = (int)(t2 & 0xffu), so2 = (int)(t2 >> 8) & 0xff;
+        const double* frag = wtLds + (size_t)(k & 1) * fragD + (size_t)c * 2 * WT_FRAG;
+        double te[WT_NT], to[WT_NT];
+        if (k2 == WK_ACC) walkChild5(frag + WT_FRAG, S, false, S, S, ACC, g, fl, te, to);
+        else {
+            v2d b2[WT_NT];
+            if (k2 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
+            walkChild5(frag + WT_FRAG, S, k2 == WK_TIPS, se2, so2, b2, g, fl, te, to);
+        }
+        const bool rd = smode == WS_READ, wr = smode == WS_WRITE;
+        const double inve = rd ? 1.0 / fe : 1.0, invo = rd ? 1.0 / fo : 1.0;
+        {
+            v2d b1[WT_NT];
+            if (k1 == WK_MEM) tiledLoadB<WT_NT, EXACT>(d.src1, tileBase, S, g, m, b1);
+            else if (k1 == WK_H0) {
+#pragma unroll
+                for (int j = 0; j < WT_NT; j++) b1[j] = H0[j];
+            } else if (k1 > WK_H0) {
+#pragma unroll
+                for (int j = 0; j < WT_NT; j++) b1[j] = H1[j];
+            }
+            double re[WT_NT], ro[WT_NT];
+            walkChild5(frag, S, k1 == WK_TIPS, se1, so1, b1, g, fl, re, ro);
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{re[j] * te[j] * inve, ro[j] * to[j] * invo};
+        }
+        // the maxima over the states, exchanged by every micro-operation (the header above: straight-line, a multiplication by 1.0 changes no bit)
+        v2d* mxk = mx + (size_t)(k & 1) * C * 16;
+        {
+            double me = 0.0, mo = 0.0;
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++)
+                if (EXACT || 4 * j + g < S) { me = fmax(me, ACC[j].x); mo = fmax(mo, ACC[j].y); }
+            me = maxOverRows(me); mo = maxOverRows(mo);
+            mxk[c * 16 + m] = v2d{me, mo};
+        }
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            double me = 0.0, mo = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < WALK_T32_WRITE_MAX_CATEGORIES; cc++) {
+                const v2d v = mxk[(cc < C ? cc : C - 1) * 16 + m];
+                me = fmax(me, v.x); mo = fmax(mo, v.y);
+            }
+            if (!(me > 0.0)) me = 1.0;
+            if (!(mo > 0.0)) mo = 1.0;
+            if (wr && c == 0 && g == 0) { if (ine) d.scaleW[pe] = me; if (ino) d.scaleW[pe + 1] = mo; }
+            const double ie = wr ? 1.0 / me : 1.0, io = wr ? 1.0 / mo : 1.0;
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) ACC[j] = v2d{ACC[j].x * ie, ACC[j].y * io};
+        }
+        if (flg & WF_STORE) {
+            char* dst = reinterpret_cast<char*>(d.store + tileBase);
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) {
+                if (EXACT || 4 * j + g < S) {
+                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u)));
+                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }
+                }
+            }
+        }
+        if (hslot == 1) {
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) H0[j] = ACC[j];
+        } else if (hslot == 2) {
+#pragma unroll
+            for (int j = 0; j < WT_NT; j++) H1[j] = ACC[j];
+        }
     }
-    for (int k = 0; k < nOps; k += 2) {            // (even count, two no-ops behind it: k_walkT32)
-        WTW_STAGE(A, B)
-        k++;
-        WTW_STAGE(B, A)
-        k--;
-    }
-#undef WTW_STAGE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-static size_t walkT32WLds(int holdSlots, int C) {
-    return (size_t)2 * C * 2 * WTW_FRAG * sizeof(double) + (size_t)holdSlots * 2 * C * WT_HOLD_V2D * sizeof(v2d) + (size_t)2 * 2 * C * 16 * sizeof(v2d) + 1024;   // (+ the spare KB)
-}
+static size_t walkT32W1Lds(int C) { return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)2 * C * 16 * sizeof(v2d); }
+
 
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
 static size_t walkT32Lds(int holdSlots) { return (size_t)4 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 4 * WT_HOLD_V2D * sizeof(v2d); }
 
 // the fragment stream of a device program of nEntries descriptors: [entry][category][child][25 tile pairs][16]
-size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WTW_FRAG * sizeof(double); }      // (the larger of the two layouts)
-void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream, bool writeMode) {
+size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WT_FRAG * sizeof(double); }
+void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream) {
     if (nEntries <= 0) return;
-    const size_t total = (size_t)nEntries * C * 2 * (writeMode ? WTW_FRAG : WT_FRAG);
-    if (writeMode) hipLaunchKernelGGL(k_gatherFragments<WTW_ROW>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
-    else hipLaunchKernelGGL(k_gatherFragments<WT_ROW>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
+    const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
+    hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
 }
 bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
                    bool writeMode) {
     if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 20 || (size_t)nSegs * C > 65535) return false;
     if (writeMode) {                               // a program with write-mode micro-operations: all categories of a tile in one workgroup
         if (C < 1 || C > WALK_T32_WRITE_MAX_CATEGORIES || holdSlots > WALK_T32_WRITE_MAX_HOLD) return false;
-        const int slots = holdSlots < 1 ? 1 : holdSlots;
-        if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W<true>), 160 * 1024) ||
-            !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W<false>), 160 * 1024)) return false;
-        const dim3 grid((maxRange + 2 * TILE - 1) / (2 * TILE), nSegs), block(128 * C);
-        const size_t lds = walkT32WLds(slots, C);
-        if (S == 20) hipLaunchKernelGGL(k_walkT32W<true>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C, slots);
-        else hipLaunchKernelGGL(k_walkT32W<false>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C, slots);
+        // one tile per workgroup, hold slots in registers (k_walkT32W1)
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W1<true>), 160 * 1024) ||
+            !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32W1<false>), 160 * 1024)) return false;
+        const dim3 grid1((maxRange + TILE - 1) / TILE + 1, nSegs), block1(64 * C);      // (+ 1: a range that starts inside a tile)
+        const size_t lds1 = walkT32W1Lds(C);
+        if (S == 20) hipLaunchKernelGGL(k_walkT32W1<true>, grid1, block1, lds1, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+        else hipLaunchKernelGGL(k_walkT32W1<false>, grid1, block1, lds1, stream, dProg, dSegs, (const double*)dStream, P, S, C);
         return true;
     }
-    if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<true>), 160 * 1024) ||
-        !grantDynamicLds(reinterpret_cast<const void*>(k_walkT32<false>), 160 * 1024)) return false;
     const dim3 grid((maxRange + 4 * TILE - 1) / (4 * TILE), nSegs * C), block(MF_BLOCK);
     const size_t lds = walkT32Lds(holdSlots < 1 ? 1 : holdSlots > 3 ? 3 : holdSlots);
     if (S == 20) hipLaunchKernelGGL(k_walkT32<true>, grid, block, lds, stream, dProg, dSegs, (const double*)dStream, P, S, C);

@@ -1,4 +1,4 @@
-"""Write-mode rescaling on the T32 walk (kernels_mfma.hip k_walkT32W; 17..20 states, up to four rate categories).
+"""Write-mode rescaling on the T32 walk (kernels_mfma.hip k_walkT32W1; 17..20 states, up to four rate categories).
 
 PartialsRescalingScheme ALWAYS and DYNAMIC's rescaling evaluations (BeagleTreeLikelihood.java:1013-1026, 1059-1113) hand the
 engine lists whose operations WRITE scale factors: a pattern's factor is the maximum over its states and rate categories

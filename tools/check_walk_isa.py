@@ -135,7 +135,7 @@ def check_async(name, text_lines):
     return problems
 
 
-ASYNC_KERNELS = (("kernels_mfma.hip", r"_ZN5mi3559k_walkT32", 168), ("kernels_mfma.hip", r"_ZN5mi35510k_walkT32W", 256),
+ASYNC_KERNELS = (("kernels_mfma.hip", r"_ZN5mi3559k_walkT32", 168), ("kernels_mfma.hip", r"_ZN5mi35511k_walkT32W1", 168),
                  ("kernels_preorder4.hip", r"_ZN5mi35510k_preWalk4", 128))
 
 
