@@ -344,7 +344,9 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     // T32 instances with <= 20 states: tip-tip nodes ("cherries") are defined, not stored — their parent's kernel rebuilds
     // them from the tips' states (kernels_mfma.hip cherryOperands); a definition is ONE step here
     // 16..20 states: the pattern walk on the T32 layout (BEAGLE_MI355_NO_T32_WALK=1: the level kernels with virtual cherries)
-    in->walkT = in->tiled && stateCount <= 20 && categoryCount <= 16 && !(getenv("BEAGLE_MI355_NO_T32_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WALK")) != 0);
+    // 21..64 states (round 6): the same walk without hold slots (kernels_mfma.hip k_walkT64; BEAGLE_MI355_NO_T64_WALK=1: the level kernels)
+    const bool walk64 = in->tiled && stateCount > 20 && categoryCount <= 16 && !(getenv("BEAGLE_MI355_NO_T64_WALK") && atoi(getenv("BEAGLE_MI355_NO_T64_WALK")) != 0);
+    in->walkT = in->tiled && categoryCount <= 16 && (stateCount <= 20 || walk64) && !(getenv("BEAGLE_MI355_NO_T32_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WALK")) != 0);
     // (above 20 states the cherries' matrices do not fit the LDS; with the tables in global memory — BEAGLE_MI355_CHERRY61=1 — a third
     // of config C's nodes is never stored and the time does not move: 232 against 234 evals/s, profiles/r03_experiments.txt 14 — so
     // that stays an experiment)
@@ -365,11 +367,13 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     int maxVirtSteps = bufferBytes >= ((size_t)2 << 20) ? 24 : bufferBytes < ((size_t)64 << 10) && stateCount == 4 ? 2 : 8;
     if (labEnv("BEAGLE_MI355_VSTEPS")) maxVirtSteps = std::max(1, std::min(mi355::PLAN_MAX_STEPS, atoi(labEnv("BEAGLE_MI355_VSTEPS"))));
     if (in->cherry) maxVirtSteps = 1;
+    // (k_walkT64's definitions are ladders — no hold slots —, and a step's two matrix snapshots are 2 x 119 KB at 61 states and four categories)
+    if (in->walkT && stateCount > 20) maxVirtSteps = std::min(maxVirtSteps, 8);
     // hold slots: three where the 4-state walk's LDS allows; TWO for the T32 walk (20 KiB each there: 3 workgroups per CU instead of 2)
-    in->holdSlots = in->walkT ? 2 : mi355::walkHoldSlots(categoryCount);
-    if (labEnv("BEAGLE_MI355_HOLD_SLOTS")) in->holdSlots = std::max(1, std::min(atoi(labEnv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
+    in->holdSlots = in->walkT ? (stateCount > 20 ? 0 : 2) : mi355::walkHoldSlots(categoryCount);
+    if (labEnv("BEAGLE_MI355_HOLD_SLOTS") && !(in->walkT && stateCount > 20)) in->holdSlots = std::max(1, std::min(atoi(labEnv("BEAGLE_MI355_HOLD_SLOTS")), in->walkT ? 3 : mi355::walkHoldSlots(categoryCount)));
     in->fuseRootParts = !(getenv("BEAGLE_MI355_NO_ROOT_PARTS_FUSION") && atoi(getenv("BEAGLE_MI355_NO_ROOT_PARTS_FUSION")) != 0);
-    in->walkTWrite = in->walkT && categoryCount <= mi355::WALK_T32_WRITE_MAX_CATEGORIES && in->holdSlots <= mi355::WALK_T32_WRITE_MAX_HOLD &&
+    in->walkTWrite = in->walkT && stateCount <= 20 && categoryCount <= mi355::WALK_T32_WRITE_MAX_CATEGORIES && in->holdSlots <= mi355::WALK_T32_WRITE_MAX_HOLD &&
                      !(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK") && atoi(getenv("BEAGLE_MI355_NO_T32_WRITE_WALK")) != 0);
     in->planner.init(partialsBufferCount, tipCount, matrixBufferCount, scaleBufferCount, maxVirtSteps, virtualOn, in->holdSlots);
     in->planner.cacheEnabled = !(getenv("BEAGLE_MI355_NO_PLAN_CACHE") && atoi(getenv("BEAGLE_MI355_NO_PLAN_CACHE")) != 0);

@@ -305,7 +305,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         }
         // (the kernels' software pipelines: the assembly loop is three micro-operations deep and leaves behind any stage — any
         // length, three more readable descriptors —; the C++ kernel and the T32 walk are two deep: an even length, two more)
-        if (!asmLoop && ((int)w.size() - segs[si].progStart) % 2) w.push_back(nop);
+        if (!asmLoop && !(in->walkT && in->S > 20) && ((int)w.size() - segs[si].progStart) % 2) w.push_back(nop);      // (k_walkT64 prefetches nothing across stages)
         segs[si].progCount = (int)w.size() - segs[si].progStart;
         for (int q = 0; q < (asmLoop ? 3 : 2); q++) w.push_back(nop);
         if (sums && !sumRows.empty() && sumRows.back() == (int)si) {      // (this slice writes factors: where its product of them goes)
@@ -458,7 +458,7 @@ int runPlan(Instance* in, const mi355::Plan& plan, long planTag, hipEvent_t reco
         mi355::launchSnapshotMatrices(live(in), in->matrices, (const int*)(dBase + opBytes + segBytes), (int)(plan.snapPairs.size() / 2),
                                       in->C * in->S * in->S);
     // the matrix stream: both branch matrices of every micro-operation, in program order (after the snapshots they may name)
-    const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
+    const size_t streamBytes = in->walkT ? mi355::walkT32StreamBytes((int)w.size(), in->C, in->S) + 8192          // (the kernel's second fragment load reads up to 1.8 KB past an entry)
                                          : w.size() * (size_t)in->C * 40 * sizeof(double) * (cmBytes ? 2 : 1) + 1024;   // 2 x 5 columns x 4 per category; behind them the cherry region (kernels_walk4.hip)
     if (in->matStreamBytes < streamBytes) {
         HIP_TRY(hipStreamSynchronize(live(in)));

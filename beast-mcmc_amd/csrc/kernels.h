@@ -450,7 +450,7 @@ int  pruneBlocksForRange(int S, int range);
 // 17..20 states: the walk's programs on the T32 layout (kernels_mfma.hip k_walkT32): same descriptors and segments as the 4-state
 // walk (src = plain tip states / T32 partials, scale = the RAW factors, no write mode); dStream from launchGatherFragments over
 // the same device program (walkT32StreamBytes)
-size_t walkT32StreamBytes(int nEntries, int C);
+size_t walkT32StreamBytes(int nEntries, int C, int S);
 void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream);
 // writeMode (a program with write-mode rescaling in it — k_walkT32W1: a workgroup is all categories of one tile, hold slots in registers;
 // at most WALK_T32_WRITE_MAX_CATEGORIES of them and two hold slots: false otherwise)

@@ -1133,20 +1133,260 @@ __global__ __launch_bounds__(256, 3) void k_walkT32W1(const WalkOp* __restrict__
 }
 static size_t walkT32W1Lds(int C) { return (size_t)2 * C * 2 * WT_FRAG * sizeof(double) + (size_t)2 * C * 16 * sizeof(v2d); }
 
+// ---- the pattern walk at 21..64 states (codon models): k_walkT64 ---------------------------------------------------------------
+// The level kernel k_pruneTiled<16> stores every node and reads it back — 16 GB per evaluation of config C, and rebuilt without its
+// stores it runs in 2.5 ms instead of 4.1 (profiles/r03_experiments.txt 11).  The walk's idea carries over once more, with two
+// differences that follow from the size of things at 64 states:
+//  * a wave's running result (ACC) is 16 v2d = 64 registers, a hold slot would be 16 KiB of LDS per wave: there are NO hold slots.
+//    The planner is initialised with none (planner.h): its definitions are ladders (a tip-tip node under further tips), a node over
+//    two evaluated children takes one of them through ACC and the other one from memory — every real node is stored, a stored node
+//    is read back at most once, and only as the sibling of a subtree that was evaluated in registers.
+//  * a branch matrix is 32 KiB of A fragments per category.  A workgroup is four tiles of ONE category, 64 KiB of LDS for the two
+//    matrices of the current micro-operation (two workgroups per CU).  The halves are refilled separately by LDS-DMA
+//    (global_load_lds_dwordx4: no registers, no ds_write): a stage multiplies by the second child's matrix first; behind the barrier
+//    that ends that phase the next micro-operation's second matrix streams into the half just freed while the first child's MFMAs
+//    run, and behind the barrier that ends those the next first matrix follows, under the products, the stores and the next second
+//    phase.  Two barriers per micro-operation, each in front of ~512 MFMAs per wave (3.4 us) unless the child is a tip.
+// Fragment layout of a matrix in the stream and in LDS: [jt][it / 2][q][it & 1] doubles — the A operands of row tiles 2i and 2i + 1
+// for column tile jt are ONE 16-byte LDS read per lane (16 distinct addresses = 256 contiguous bytes per wave: every bank once),
+// q = 4 * (column in tile) + (row in tile) as everywhere in this file.  Accumulation order per result element: column tiles
+// ascending, exactly k_pruneTiled's — the walk and the level kernel agree bit for bit (tests/test_gpu_t64_walk.py).
+// Read-mode rescaling and unscaled lists only (a pattern's write-mode factor needs all categories of the pattern): lists that
+// rescale in write mode take the level path (engine_levels.cpp runOperations), on operands materialised first.
+constexpr int W64_NT = 16, W64_FRAG = W64_NT * W64_NT * 16;          // doubles per matrix (4096 = 32 KiB)
+
+__global__ void k_gatherFragments64(const WalkOp* __restrict__ prog, int n, int C, int S, v2d* __restrict__ stream) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 16-byte pair
+    constexpr int HALF = W64_FRAG / 2;
+    if (t >= (size_t)n * C * 2 * HALF) return;
+    const int r = (int)(t % HALF), child = (int)((t / HALF) & 1), c = (int)((t / (2 * HALF)) % C), k = (int)(t / ((size_t)2 * HALF * C));
+    const int q = r & 15, ip = (r >> 4) & 7, jt = r >> 7;
+    const int i0 = 8 * ip + (q & 3), j = 4 * jt + (q >> 2);                  // rows of tiles 2 ip and 2 ip + 1: i0, i0 + 4
+    const double MI355_GLOBAL* M = gptr(child ? prog[k].m2 : prog[k].m1) + (size_t)c * S * S;
+    v2d v;
+    v.x = (i0 < S && j < S) ? M[(size_t)i0 * S + j] : 0.0;
+    v.y = (i0 + 4 < S && j < S) ? M[(size_t)(i0 + 4) * S + j] : 0.0;
+    stream[t] = v;
+}
+
+// One child's factor for all sixteen parent-state tiles: T[it] = { sum_j M[4 it + g][j] X[j][2m], ... X[j][2m + 1] }; a compact tip:
+// column `state` of the matrix (ones for a missing state).  (Even- and odd-pattern sums of a tile share a 16-byte register tuple from
+// the start: the running result is stored and multiplied as v2d, and a register file full of 8-byte values that die one by one leaves
+// no aligned tuples free — the first version, with separate arrays, spilled 87 registers.)
+template <bool EXACT>
+__device__ __forceinline__ void walkChild16(const v2d* __restrict__ frag, int nt, int S, bool isStates, int se, int so, const v2d (&b)[W64_NT],
+                                            int g, int fl, v2d (&T)[W64_NT]) {
+    if (isStates) {
+        const bool ge = se < S, go = so < S;
+        const v2d* fe = frag + (ge ? (se >> 2) * 128 + (se & 3) * 4 + g : 0);
+        const v2d* fo = frag + (go ? (so >> 2) * 128 + (so & 3) * 4 + g : 0);
+#pragma unroll
+        for (int ip = 0; ip < W64_NT / 2; ip++) {
+            const v2d ve = fe[ip * 16], vo = fo[ip * 16];
+            T[2 * ip] = v2d{ge ? ve.x : 1.0, go ? vo.x : 1.0};
+            T[2 * ip + 1] = v2d{ge ? ve.y : 1.0, go ? vo.y : 1.0};
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < W64_NT; it++) T[it] = v2d{0.0, 0.0};
+    // 64 steps of two 16-byte fragment reads and eight MFMAs (128 cycles of the matrix pipe); the next step's fragments are requested
+    // before this step's MFMAs, and the scheduler is kept from pulling more reads forward
+    v2d a0 = frag[fl], a1 = frag[16 + fl];
+#pragma unroll
+    for (int s = 0; s < 4 * W64_NT; s++) {
+        const int jt = s >> 2, ip = (s & 3) * 2;
+        const int sn = s + 1, jn = sn >> 2, in = (sn & 3) * 2;
+        v2d n0 = a0, n1 = a1;
+        if (sn < 4 * W64_NT && (EXACT || jn < nt)) { n0 = frag[(jn * 8 + in) * 16 + fl]; n1 = frag[(jn * 8 + in + 1) * 16 + fl]; }
+        if (EXACT || (jt < nt && 2 * ip < nt)) {
+            T[2 * ip].x = mfma4(a0.x, b[jt].x, T[2 * ip].x);
+            T[2 * ip].y = mfma4(a0.x, b[jt].y, T[2 * ip].y);
+            T[2 * ip + 1].x = mfma4(a0.y, b[jt].x, T[2 * ip + 1].x);
+            T[2 * ip + 1].y = mfma4(a0.y, b[jt].y, T[2 * ip + 1].y);
+        }
+        if (EXACT || (jt < nt && 2 * ip + 2 < nt)) {
+            T[2 * ip + 2].x = mfma4(a1.x, b[jt].x, T[2 * ip + 2].x);
+            T[2 * ip + 2].y = mfma4(a1.x, b[jt].y, T[2 * ip + 2].y);
+            T[2 * ip + 3].x = mfma4(a1.y, b[jt].x, T[2 * ip + 3].x);
+            T[2 * ip + 3].y = mfma4(a1.y, b[jt].y, T[2 * ip + 3].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1;
+    }
+}
+
+// The first child's factor, four parent-state tiles at a time, multiplied into the second child's (T) as it comes:
+// T[it] = first * T[it] * inv — k_pruneTiled's order of operations.  Sixteen accumulator registers instead of sixty-four next to the
+// operand's sixty-four and the second child's sixty-four.
+template <bool EXACT>
+__device__ __forceinline__ void walkChild16Into(const v2d* __restrict__ frag, int nt, int S, bool isStates, int se, int so, const v2d (&b)[W64_NT],
+                                                int g, int fl, double inve, double invo, v2d (&T)[W64_NT]) {
+    if (isStates) {
+        const bool ge = se < S, go = so < S;
+        const v2d* fe = frag + (ge ? (se >> 2) * 128 + (se & 3) * 4 + g : 0);
+        const v2d* fo = frag + (go ? (so >> 2) * 128 + (so & 3) * 4 + g : 0);
+#pragma unroll
+        for (int ip = 0; ip < W64_NT / 2; ip++) {
+            const v2d ve = fe[ip * 16], vo = fo[ip * 16];
+            T[2 * ip] = v2d{(ge ? ve.x : 1.0) * T[2 * ip].x * inve, (go ? vo.x : 1.0) * T[2 * ip].y * invo};
+            T[2 * ip + 1] = v2d{(ge ? ve.y : 1.0) * T[2 * ip + 1].x * inve, (go ? vo.y : 1.0) * T[2 * ip + 1].y * invo};
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < W64_NT / 4; c++) {
+        double ce[4] = {0.0, 0.0, 0.0, 0.0}, co[4] = {0.0, 0.0, 0.0, 0.0};
+        if (EXACT || 4 * c < nt) {
+            v2d a0 = frag[(2 * c) * 16 + fl], a1 = frag[(2 * c + 1) * 16 + fl];
+#pragma unroll
+            for (int jt = 0; jt < W64_NT; jt++) {
+                v2d n0 = a0, n1 = a1;
+                if (jt + 1 < W64_NT && (EXACT || jt + 1 < nt)) { n0 = frag[((jt + 1) * 8 + 2 * c) * 16 + fl]; n1 = frag[((jt + 1) * 8 + 2 * c + 1) * 16 + fl]; }
+                if (EXACT || jt < nt) {
+                    ce[0] = mfma4(a0.x, b[jt].x, ce[0]); co[0] = mfma4(a0.x, b[jt].y, co[0]);
+                    ce[1] = mfma4(a0.y, b[jt].x, ce[1]); co[1] = mfma4(a0.y, b[jt].y, co[1]);
+                    ce[2] = mfma4(a1.x, b[jt].x, ce[2]); co[2] = mfma4(a1.x, b[jt].y, co[2]);
+                    ce[3] = mfma4(a1.y, b[jt].x, ce[3]); co[3] = mfma4(a1.y, b[jt].y, co[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = n0; a1 = n1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) T[4 * c + i] = v2d{ce[i] * T[4 * c + i].x * inve, co[i] * T[4 * c + i].y * invo};
+    }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT64(const WalkOp* __restrict__ prog, const WalkSeg* __restrict__ segs,
+                                                         const double* __restrict__ fragStream, int P, int S, int C) {
+    extern __shared__ double w64Lds[];             // [first child's matrix | second child's matrix], W64_FRAG doubles each
+    const WalkSeg& sg = segs[blockIdx.y / C];
+    const int c = blockIdx.y % C;
+    const int nt = EXACT ? W64_NT : (S + 3) >> 2;
+    const int ntile = (P + TILE - 1) / TILE;
+    const int tile1 = (sg.pEnd + TILE - 1) / TILE;
+    const int tileB = sg.pStart / TILE + (int)blockIdx.x * 4;
+    if (tileB >= tile1) return;                    // the whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    const int fl = g * 4 + (lane & 3);
+    const bool active = tileB + wave < tile1;      // a wave past the end walks the last tile along (barriers, staging) and stores nothing
+    const int tile = active ? tileB + wave : tile1 - 1;
+    const size_t tileBase = ((size_t)c * ntile + tile) * S * TILE;
+    const int pe = tile * TILE + 2 * m;
+    const bool ine = active && pe >= sg.pStart && pe < sg.pEnd, ino = active && pe + 1 >= sg.pStart && pe + 1 < sg.pEnd;
+    const unsigned lane8 = (unsigned)(g * TILE + 2 * m) * 8u;
+    const int nOps = sg.progCount;
+    const WalkOp* dp = prog + sg.progStart;
+    // stream entry of micro-operation k, this category: [m1's fragments | m2's fragments]
+    const char MI355_GLOBAL* fs = reinterpret_cast<const char MI355_GLOBAL*>(gptr(fragStream)) + ((size_t)sg.progStart * C + c) * (2 * W64_FRAG * sizeof(double));
+    const size_t fsStep = (size_t)C * 2 * W64_FRAG * sizeof(double);
+    constexpr unsigned HALF_BYTES = W64_FRAG * sizeof(double);            // 32 KiB
+    const unsigned ldsBase = (unsigned)__builtin_amdgcn_groupstaticsize();
+    const unsigned oLane = (unsigned)lane * 16u;
+    // a matrix's 32 KiB into LDS half `half` (0: first child's, 1: second child's): 32 pieces of 1 KiB, eight per wave
+    auto dma = [&](const char MI355_GLOBAL* src, unsigned half) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %[keep], m0" : [keep] "=&s"(keep) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned piece = (unsigned)(wave * 8 + i) * 1024u;
+            const unsigned l = __builtin_amdgcn_readfirstlane(ldsBase + half * HALF_BYTES + piece);
+            const char MI355_GLOBAL* p = src + piece;
+            asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o], %[p]"
+                         :: [l] "s"(l), [o] "v"(oLane), [p] "s"(p) : "memory");
+        }
+        asm volatile("s_mov_b32 m0, %[keep]" :: [keep] "s"(keep) : "memory");
+    };
+    const v2d* fragA = reinterpret_cast<const v2d*>(w64Lds);
+    const v2d* fragB = fragA + W64_FRAG / 2;
+    dma(fs + HALF_BYTES, 1u);
+    dma(fs, 0u);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    v2d ACC[W64_NT];
+#pragma unroll
+    for (int k = 0; k < W64_NT; k++) ACC[k] = v2d{1.0, 1.0};
+    for (int k = 0; k < nOps; k++) {
+        const WalkOp& d = dp[k];
+        const unsigned flg = d.flags;
+        const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7;
+        const bool rd = ((flg >> 13) & 3) == WS_READ;
+        // the stage's small operands: state codes of compact tips (the lane's two patterns are neighbours), raw scale factors
+        int se1 = S, so1 = S, se2 = S, so2 = S;
+        if (k1 == WK_TIPS) { const unsigned t = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src1)) + pe); se1 = (int)(t & 0xffu); so1 = (int)(t >> 8); }
+        if (k2 == WK_TIPS) { const unsigned t = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src2)) + pe); se2 = (int)(t & 0xffu); so2 = (int)(t >> 8); }
+        v2d sc = v2d{1.0, 1.0};
+        if (rd) sc = *reinterpret_cast<const v2d MI355_GLOBAL*>(gptr(d.scale) + pe);
+        // ---- second child (the running result is consumed where it stands)
+        v2d T[W64_NT];
+        {
+            v2d b2[W64_NT];
+            if (k2 == WK_ACC) {
+#pragma unroll
+                for (int j = 0; j < W64_NT; j++) b2[j] = ACC[j];
+            } else if (k2 == WK_MEM) tiledLoadB<W64_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
+            walkChild16<EXACT>(fragB, nt, S, k2 == WK_TIPS, se2, so2, b2, g, fl, T);
+        }
+        // everybody is done with the second matrix, and this micro-operation's first one has landed (requested a phase ago)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (k + 1 < nOps) dma(fs + (size_t)(k + 1) * fsStep + HALF_BYTES, 1u);
+        // ---- first child, multiplied into the second's as it comes
+        {
+            const double inve = rd ? 1.0 / sc.x : 1.0, invo = rd ? 1.0 / sc.y : 1.0;
+            v2d b1[W64_NT];
+            if (k1 == WK_MEM) tiledLoadB<W64_NT, EXACT>(d.src1, tileBase, S, g, m, b1);
+            walkChild16Into<EXACT>(fragA, nt, S, k1 == WK_TIPS, se1, so1, b1, g, fl, inve, invo, T);
+        }
+#pragma unroll
+        for (int j = 0; j < W64_NT; j++) ACC[j] = T[j];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (k + 1 < nOps) dma(fs + (size_t)(k + 1) * fsStep, 0u);
+        if (flg & WF_STORE) {
+            char* dst = reinterpret_cast<char*>(d.store + tileBase);
+#pragma unroll
+            for (int j = 0; j < W64_NT; j++) {
+                if ((EXACT && j < W64_NT - 1) || 4 * j + g < S) {
+                    double MI355_GLOBAL* q = gptr(reinterpret_cast<double*>(dst + (lane8 + (unsigned)j * 4u * TILE * 8u)));
+                    if (ine && ino) __builtin_nontemporal_store(ACC[j], reinterpret_cast<v2d MI355_GLOBAL*>(q));
+                    else { if (ine) q[0] = ACC[j].x; if (ino) q[1] = ACC[j].y; }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 
 // LDS per workgroup: 12.5 KiB of fragments + 20 KiB per hold slot (2 slots: 3 workgroups per CU, 3: 2)
 static size_t walkT32Lds(int holdSlots) { return (size_t)4 * WT_FRAG * sizeof(double) + (size_t)holdSlots * 4 * WT_HOLD_V2D * sizeof(v2d); }
 
 // the fragment stream of a device program of nEntries descriptors: [entry][category][child][25 tile pairs][16]
-size_t walkT32StreamBytes(int nEntries, int C) { return (size_t)nEntries * C * 2 * WT_FRAG * sizeof(double); }
+// (21..64 states, k_walkT64: [entry][category][child][16 x 8 tile pairs][16][2])
+size_t walkT32StreamBytes(int nEntries, int C, int S) { return (size_t)nEntries * C * 2 * (S > 20 ? W64_FRAG : WT_FRAG) * sizeof(double); }
 void launchGatherFragments(hipStream_t stream, const WalkOp* dProg, int nEntries, int C, int S, void* dStream) {
     if (nEntries <= 0) return;
+    if (S > 20) {
+        const size_t pairs = (size_t)nEntries * C * W64_FRAG;
+        hipLaunchKernelGGL(k_gatherFragments64, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (v2d*)dStream);
+        return;
+    }
     const size_t total = (size_t)nEntries * C * 2 * WT_FRAG;
     hipLaunchKernelGGL(k_gatherFragments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dProg, nEntries, C, S, (double*)dStream);
 }
 bool launchWalkT32(hipStream_t stream, const WalkOp* dProg, const WalkSeg* dSegs, int nSegs, int maxRange, const void* dStream, int P, int S, int C, int holdSlots,
                    bool writeMode) {
-    if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 20 || (size_t)nSegs * C > 65535) return false;
+    if (nSegs <= 0 || maxRange <= 0 || S < 16 || S > 64 || (size_t)nSegs * C > 65535) return false;
+    if (S > 20) {                                  // 21..64 states: no hold slots, no write mode (k_walkT64)
+        if (writeMode) return false;
+        const size_t lds64 = (size_t)2 * W64_FRAG * sizeof(double);
+        if (!grantDynamicLds(reinterpret_cast<const void*>(k_walkT64<true>), lds64) || !grantDynamicLds(reinterpret_cast<const void*>(k_walkT64<false>), lds64)) return false;
+        const dim3 grid64((maxRange + 4 * TILE - 1) / (4 * TILE) + 1, nSegs * C), block64(MF_BLOCK);      // (+ 1: a range that starts inside a group of four tiles)
+        if (S > 60) hipLaunchKernelGGL(k_walkT64<true>, grid64, block64, lds64, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+        else hipLaunchKernelGGL(k_walkT64<false>, grid64, block64, lds64, stream, dProg, dSegs, (const double*)dStream, P, S, C);
+        return true;
+    }
     if (writeMode) {                               // a program with write-mode micro-operations: all categories of a tile in one workgroup
         if (C < 1 || C > WALK_T32_WRITE_MAX_CATEGORIES || holdSlots > WALK_T32_WRITE_MAX_HOLD) return false;
         // one tile per workgroup, hold slots in registers (k_walkT32W1)

@@ -14,7 +14,7 @@ inline int lowestSlot(unsigned m) { return (m & 1u) ? 0 : (m & 2u) ? 1 : 2; }
 }  // namespace
 
 void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int scaleCount, int maxVirtSteps, bool virtualEnabled, int holdSlots) {
-    allSlots_ = (1u << std::max(1, std::min(3, holdSlots))) - 1u;
+    allSlots_ = (1u << std::max(0, std::min(3, holdSlots))) - 1u;          // (0: no hold slots at all — the 21..64-state walk)
     partialsCount_ = partialsCount; tipCount_ = tipCount; matrixCount_ = matrixCount; scaleCount_ = std::max(1, scaleCount);
     maxSteps_ = std::max(1, std::min(maxVirtSteps, PLAN_MAX_STEPS));
     enabled_ = virtualEnabled;
@@ -293,11 +293,17 @@ void WalkPlanner::emitReal(int root, unsigned rootMask, Plan& out) {
                 } else {
                     const bool p01 = plainOK(ch[0], ch[1]), p10 = plainOK(ch[1], ch[0]);
                     if (p01 && p10) f.first = ch[1].size > ch[0].size ? 1 : 0;
-                    else f.first = p01 ? 0 : 1;      // by construction one of them holds (planner.h: need <= 2)
+                    else if (p01 || p10) f.first = p01 ? 0 : 1;      // by construction one of them holds (planner.h: need <= 2) ...
+                    // ... unless the walk has no hold slots (21..64 states): a real child first if there is one (it is stored anyway),
+                    // otherwise a definition — evaluated and STORED for once (it stays a definition: the data is what it evaluates to)
+                    else f.first = ch[0].cls == CL_REAL ? 0 : ch[1].cls == CL_REAL ? 1 : 0;
                 }
                 f.phase = 1;
                 const Child a = ch[f.first];
-                if (a.cls == CL_VIRT) emitVirtual(a.vkey, f.freeMask, true, out);
+                if (a.cls == CL_VIRT) {
+                    emitVirtual(a.vkey, f.freeMask, true, out);
+                    if (!f.hold) { out.prog.back().storeBuf = a.buf; lastStored++; }      // (read back as PK_MEM below)
+                }
                 else { push(a.prod, f.freeMask); continue; }
             }
         }
@@ -451,6 +457,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 auto cost = [&](int a, int b) { return real[a] ? std::max(need[a], need[b]) : std::max(need[a], 1 + need[b]); };
                 o.need = std::min(cost(0, 1), cost(1, 0));
             } else o.need = eval[0] ? need[0] : eval[1] ? need[1] : 0;
+            if (allSlots_ == 0u) o.need = 0;            // no hold slots: the first of two evaluated children goes through memory
         }
     }
 

@@ -248,7 +248,7 @@ struct Harness {
 
     void init(int tips, int nBuffers, int nMatrices, int nScales, bool virt, unsigned seed) {
         T = tips; nBuf = nBuffers; nMat = nMatrices; nScale = nScales; rng.seed(seed);
-        { static const int caps[6] = {6, 8, 12, 16, 24, 32}; pl.init(nBuf, T, nMat, nScale, caps[seed % 6], virt, 2 + (seed / 6) % 2); }    // the engine's: 8 or 16
+        { static const int caps[6] = {6, 8, 12, 16, 24, 32}; static const int holdChoice[3] = {2, 3, 0}; pl.init(nBuf, T, nMat, nScale, caps[seed % 6], virt, holdChoice[(seed / 6) % 3]); }     // (0 hold slots: the 21..64-state walk, kernels_mfma.hip k_walkT64)
         // one-launch programs: the simulated schedule's machine count and the smaller slices above the first wave, varied
         { static const double mach[4] = {0.0, 1.0, 3.0, 10.4}; pl.launchMachines = mach[(seed / 2) % 4]; }
         { static const int top[3] = {0, 8, 16}; pl.chunkTopOps = top[(seed / 3) % 3]; }
