@@ -1154,6 +1154,11 @@ static size_t walkT32W1Lds(int C) { return (size_t)2 * C * 2 * WT_FRAG * sizeof(
 // Read-mode rescaling and unscaled lists only (a pattern's write-mode factor needs all categories of the pattern): lists that
 // rescale in write mode take the level path (engine_levels.cpp runOperations), on operands materialised first.
 constexpr int W64_NT = 16, W64_FRAG = W64_NT * W64_NT * 16;          // doubles per matrix (4096 = 32 KiB)
+#if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NOMFMA)       // TIMING EXPERIMENTS ONLY: one of every sixteen matrix instructions (keeps the operands alive)
+#define W64_MFMA(a, b, c, sel) ((sel) ? (c) : mfma4(a, b, c))
+#else
+#define W64_MFMA(a, b, c, sel) mfma4(a, b, c)
+#endif
 
 __global__ void k_gatherFragments64(const WalkOp* __restrict__ prog, int n, int C, int S, v2d* __restrict__ stream) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 16-byte pair
@@ -1169,92 +1174,69 @@ __global__ void k_gatherFragments64(const WalkOp* __restrict__ prog, int n, int 
     stream[t] = v;
 }
 
-// One child's factor for all sixteen parent-state tiles: T[it] = { sum_j M[4 it + g][j] X[j][2m], ... X[j][2m + 1] }; a compact tip:
-// column `state` of the matrix (ones for a missing state).  (Even- and odd-pattern sums of a tile share a 16-byte register tuple from
-// the start: the running result is stored and multiplied as v2d, and a register file full of 8-byte values that die one by one leaves
-// no aligned tuples free — the first version, with separate arrays, spilled 87 registers.)
+// A child's partials in memory are STREAMED: row tile jt of the operand (16 bytes per lane) is requested four column steps — 128
+// MFMAs — before its products, through a ring of four registers pairs, instead of all 64 registers up front: with the whole operand
+// loaded first a stage held an operand, two sets of sixteen results and the fragments — the compiler wanted 338 registers, spilled
+// at 256 and serialised the loads behind the spills (10 us per operand: profiles/r06_experiments.txt 17).
 template <bool EXACT>
-__device__ __forceinline__ void walkChild16(const v2d* __restrict__ frag, int nt, int S, bool isStates, int se, int so, const v2d (&b)[W64_NT],
-                                            int g, int fl, v2d (&T)[W64_NT]) {
-    if (isStates) {
-        const bool ge = se < S, go = so < S;
-        const v2d* fe = frag + (ge ? (se >> 2) * 128 + (se & 3) * 4 + g : 0);
-        const v2d* fo = frag + (go ? (so >> 2) * 128 + (so & 3) * 4 + g : 0);
-#pragma unroll
-        for (int ip = 0; ip < W64_NT / 2; ip++) {
-            const v2d ve = fe[ip * 16], vo = fo[ip * 16];
-            T[2 * ip] = v2d{ge ? ve.x : 1.0, go ? vo.x : 1.0};
-            T[2 * ip + 1] = v2d{ge ? ve.y : 1.0, go ? vo.y : 1.0};
-        }
-        return;
+__device__ __forceinline__ v2d w64LoadRowTile(const char* __restrict__ x, unsigned lane8, int S, int g, int m, int jt) {
+    if (jt < W64_NT - 1 || !EXACT) {
+        if (EXACT) return __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (lane8 + (unsigned)jt * 4u * TILE * 8u))));
     }
+    const int j = 4 * jt + g, jc = j < S ? j : S - 1;          // rows >= S do not exist in the buffer: the last real row, zeroed
+    const v2d v = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (unsigned)(jc * TILE + 2 * m) * 8u)));
+    return j < S ? v : v2d{0.0, 0.0};
+}
+
+// T[it] = { sum_j M[4 it + g][j] X[j][2m], ... X[j][2m + 1] } for all sixteen parent-state tiles.  The operand X: registers (b; STREAM
+// false) or memory (x: the tile's first byte; q holds row tiles 0..3 on entry).  64 steps of two 16-byte fragment reads and eight MFMAs
+// (128 cycles of the matrix pipe); the next step's fragments are requested before this step's MFMAs, and the scheduler is kept from
+// pulling more forward.  Even- and odd-pattern sums share a 16-byte register tuple: that is what is stored and multiplied later.
+template <bool EXACT, bool STREAM>
+__device__ __forceinline__ void walkAcc16(const v2d* __restrict__ frag, int nt, int S, const v2d (&b)[W64_NT], const char* __restrict__ x, v2d (&q)[4],
+                                          unsigned lane8, int g, int m, int fl, v2d (&T)[W64_NT]) {
 #pragma unroll
     for (int it = 0; it < W64_NT; it++) T[it] = v2d{0.0, 0.0};
-    // 64 steps of two 16-byte fragment reads and eight MFMAs (128 cycles of the matrix pipe); the next step's fragments are requested
-    // before this step's MFMAs, and the scheduler is kept from pulling more reads forward
     v2d a0 = frag[fl], a1 = frag[16 + fl];
+    v2d bj = v2d{0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4 * W64_NT; s++) {
         const int jt = s >> 2, ip = (s & 3) * 2;
         const int sn = s + 1, jn = sn >> 2, in = (sn & 3) * 2;
+        if ((s & 3) == 0) {
+            if (STREAM) {
+                bj = q[jt & 3];
+                if (jt + 4 < W64_NT && (EXACT || jt + 4 < nt)) q[jt & 3] = w64LoadRowTile<EXACT>(x, lane8, S, g, m, jt + 4);
+            } else bj = b[jt];
+        }
         v2d n0 = a0, n1 = a1;
         if (sn < 4 * W64_NT && (EXACT || jn < nt)) { n0 = frag[(jn * 8 + in) * 16 + fl]; n1 = frag[(jn * 8 + in + 1) * 16 + fl]; }
         if (EXACT || (jt < nt && 2 * ip < nt)) {
-            T[2 * ip].x = mfma4(a0.x, b[jt].x, T[2 * ip].x);
-            T[2 * ip].y = mfma4(a0.x, b[jt].y, T[2 * ip].y);
-            T[2 * ip + 1].x = mfma4(a0.y, b[jt].x, T[2 * ip + 1].x);
-            T[2 * ip + 1].y = mfma4(a0.y, b[jt].y, T[2 * ip + 1].y);
+            T[2 * ip].x = W64_MFMA(a0.x, bj.x, T[2 * ip].x, jt != 0);
+            T[2 * ip].y = W64_MFMA(a0.x, bj.y, T[2 * ip].y, jt != 0);
+            T[2 * ip + 1].x = W64_MFMA(a0.y, bj.x, T[2 * ip + 1].x, jt != 0);
+            T[2 * ip + 1].y = W64_MFMA(a0.y, bj.y, T[2 * ip + 1].y, jt != 0);
         }
         if (EXACT || (jt < nt && 2 * ip + 2 < nt)) {
-            T[2 * ip + 2].x = mfma4(a1.x, b[jt].x, T[2 * ip + 2].x);
-            T[2 * ip + 2].y = mfma4(a1.x, b[jt].y, T[2 * ip + 2].y);
-            T[2 * ip + 3].x = mfma4(a1.y, b[jt].x, T[2 * ip + 3].x);
-            T[2 * ip + 3].y = mfma4(a1.y, b[jt].y, T[2 * ip + 3].y);
+            T[2 * ip + 2].x = W64_MFMA(a1.x, bj.x, T[2 * ip + 2].x, jt != 0);
+            T[2 * ip + 2].y = W64_MFMA(a1.x, bj.y, T[2 * ip + 2].y, jt != 0);
+            T[2 * ip + 3].x = W64_MFMA(a1.y, bj.x, T[2 * ip + 3].x, jt != 0);
+            T[2 * ip + 3].y = W64_MFMA(a1.y, bj.y, T[2 * ip + 3].y, jt != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0; a1 = n1;
     }
 }
-
-// The first child's factor, four parent-state tiles at a time, multiplied into the second child's (T) as it comes:
-// T[it] = first * T[it] * inv — k_pruneTiled's order of operations.  Sixteen accumulator registers instead of sixty-four next to the
-// operand's sixty-four and the second child's sixty-four.
-template <bool EXACT>
-__device__ __forceinline__ void walkChild16Into(const v2d* __restrict__ frag, int nt, int S, bool isStates, int se, int so, const v2d (&b)[W64_NT],
-                                                int g, int fl, double inve, double invo, v2d (&T)[W64_NT]) {
-    if (isStates) {
-        const bool ge = se < S, go = so < S;
-        const v2d* fe = frag + (ge ? (se >> 2) * 128 + (se & 3) * 4 + g : 0);
-        const v2d* fo = frag + (go ? (so >> 2) * 128 + (so & 3) * 4 + g : 0);
+// a compact tip: column `state` of the matrix (ones for a missing state)
+__device__ __forceinline__ void walkTip16(const v2d* __restrict__ frag, int S, int se, int so, int g, v2d (&T)[W64_NT]) {
+    const bool ge = se < S, go = so < S;
+    const v2d* fe = frag + (ge ? (se >> 2) * 128 + (se & 3) * 4 + g : 0);
+    const v2d* fo = frag + (go ? (so >> 2) * 128 + (so & 3) * 4 + g : 0);
 #pragma unroll
-        for (int ip = 0; ip < W64_NT / 2; ip++) {
-            const v2d ve = fe[ip * 16], vo = fo[ip * 16];
-            T[2 * ip] = v2d{(ge ? ve.x : 1.0) * T[2 * ip].x * inve, (go ? vo.x : 1.0) * T[2 * ip].y * invo};
-            T[2 * ip + 1] = v2d{(ge ? ve.y : 1.0) * T[2 * ip + 1].x * inve, (go ? vo.y : 1.0) * T[2 * ip + 1].y * invo};
-        }
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < W64_NT / 4; c++) {
-        double ce[4] = {0.0, 0.0, 0.0, 0.0}, co[4] = {0.0, 0.0, 0.0, 0.0};
-        if (EXACT || 4 * c < nt) {
-            v2d a0 = frag[(2 * c) * 16 + fl], a1 = frag[(2 * c + 1) * 16 + fl];
-#pragma unroll
-            for (int jt = 0; jt < W64_NT; jt++) {
-                v2d n0 = a0, n1 = a1;
-                if (jt + 1 < W64_NT && (EXACT || jt + 1 < nt)) { n0 = frag[((jt + 1) * 8 + 2 * c) * 16 + fl]; n1 = frag[((jt + 1) * 8 + 2 * c + 1) * 16 + fl]; }
-                if (EXACT || jt < nt) {
-                    ce[0] = mfma4(a0.x, b[jt].x, ce[0]); co[0] = mfma4(a0.x, b[jt].y, co[0]);
-                    ce[1] = mfma4(a0.y, b[jt].x, ce[1]); co[1] = mfma4(a0.y, b[jt].y, co[1]);
-                    ce[2] = mfma4(a1.x, b[jt].x, ce[2]); co[2] = mfma4(a1.x, b[jt].y, co[2]);
-                    ce[3] = mfma4(a1.y, b[jt].x, ce[3]); co[3] = mfma4(a1.y, b[jt].y, co[3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = n0; a1 = n1;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) T[4 * c + i] = v2d{ce[i] * T[4 * c + i].x * inve, co[i] * T[4 * c + i].y * invo};
+    for (int ip = 0; ip < W64_NT / 2; ip++) {
+        const v2d ve = fe[ip * 16], vo = fo[ip * 16];
+        T[2 * ip] = v2d{ge ? ve.x : 1.0, go ? vo.x : 1.0};
+        T[2 * ip + 1] = v2d{ge ? ve.y : 1.0, go ? vo.y : 1.0};
     }
 }
 
@@ -1302,8 +1284,33 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT64(const WalkOp* __restric
     };
     const v2d* fragA = reinterpret_cast<const v2d*>(w64Lds);
     const v2d* fragB = fragA + W64_FRAG / 2;
+    // What a stage needs from memory, and when it is asked for (loads return in the order they were issued; the waits in front of the
+    // two barriers count on that, as kernels_walk4.hip's do):
+    //  * its state codes and raw scale factors (two ushorts, 16 bytes) and its descriptor: a stage ahead, behind the barrier that ends
+    //    the stage before (unused operands are readable dummies: the same loads go out whatever the kinds are);
+    //  * a child's partials: streamed (walkAcc16); the first four row tiles of the SECOND child together with the small operands, the
+    //    first four of the FIRST child in front of the barrier that ends the second child's phase — always four loads (a child that is
+    //    no buffer: four loads from the fragment stream, never used), so that the barrier's wait is "all but the four youngest";
+    //  * the matrices: see the header.
+    const char* dummyRows = reinterpret_cast<const char*>(fragStream);
+    struct Small { unsigned t1, t2; v2d sc; };
+    auto small = [&](const WalkOp& d) {
+        Small r;
+        r.t1 = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src1)) + pe);
+        r.t2 = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src2)) + pe);
+        r.sc = *reinterpret_cast<const v2d MI355_GLOBAL*>(gptr(d.scale) + pe);
+        return r;
+    };
+    auto head = [&](const char* x, v2d (&q)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (lane8 + (unsigned)j * 4u * TILE * 8u))));
+    };
+    auto rowsOf = [&](const void* buf) { return reinterpret_cast<const char*>(reinterpret_cast<const double*>(buf) + tileBase); };
     dma(fs + HALF_BYTES, 1u);
     dma(fs, 0u);
+    Small sm = small(dp[0]);
+    v2d q2[4];
+    head(((dp[0].flags >> 8) & 7) == WK_MEM ? rowsOf(dp[0].src2) : dummyRows, q2);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     v2d ACC[W64_NT];
 #pragma unroll
@@ -1313,37 +1320,51 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT64(const WalkOp* __restric
         const unsigned flg = d.flags;
         const int k1 = (flg >> 5) & 7, k2 = (flg >> 8) & 7;
         const bool rd = ((flg >> 13) & 3) == WS_READ;
-        // the stage's small operands: state codes of compact tips (the lane's two patterns are neighbours), raw scale factors
-        int se1 = S, so1 = S, se2 = S, so2 = S;
-        if (k1 == WK_TIPS) { const unsigned t = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src1)) + pe); se1 = (int)(t & 0xffu); so1 = (int)(t >> 8); }
-        if (k2 == WK_TIPS) { const unsigned t = *reinterpret_cast<const unsigned short MI355_GLOBAL*>(gptr(reinterpret_cast<const char*>(d.src2)) + pe); se2 = (int)(t & 0xffu); so2 = (int)(t >> 8); }
-        v2d sc = v2d{1.0, 1.0};
-        if (rd) sc = *reinterpret_cast<const v2d MI355_GLOBAL*>(gptr(d.scale) + pe);
+        const int se1 = (int)(sm.t1 & 0xffu), so1 = (int)(sm.t1 >> 8) & 0xff, se2 = (int)(sm.t2 & 0xffu), so2 = (int)(sm.t2 >> 8) & 0xff;
+        const double inve = rd ? 1.0 / sm.sc.x : 1.0, invo = rd ? 1.0 / sm.sc.y : 1.0;
         // ---- second child (the running result is consumed where it stands)
         v2d T[W64_NT];
-        {
-            v2d b2[W64_NT];
-            if (k2 == WK_ACC) {
-#pragma unroll
-                for (int j = 0; j < W64_NT; j++) b2[j] = ACC[j];
-            } else if (k2 == WK_MEM) tiledLoadB<W64_NT, EXACT>(d.src2, tileBase, S, g, m, b2);
-            walkChild16<EXACT>(fragB, nt, S, k2 == WK_TIPS, se2, so2, b2, g, fl, T);
-        }
-        // everybody is done with the second matrix, and this micro-operation's first one has landed (requested a phase ago)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (k2 == WK_TIPS) walkTip16(fragB, S, se2, so2, g, T);
+        else if (k2 == WK_ACC) walkAcc16<EXACT, false>(fragB, nt, S, ACC, nullptr, q2, lane8, g, m, fl, T);
+#if !(defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NOLOAD))      // TIMING EXPERIMENTS ONLY (tools/build_mfma_variant.sh; wrong results)
+        else walkAcc16<EXACT, true>(fragB, nt, S, ACC, rowsOf(d.src2), q2, lane8, g, m, fl, T);
+#else
+        else walkAcc16<EXACT, false>(fragB, nt, S, ACC, nullptr, q2, lane8, g, m, fl, T);
+#endif
+        // the first child's first row tiles (or four loads of nothing), then: everybody is done with the second matrix, and this
+        // micro-operation's first one has landed (requested a phase ago: older than the four)
+        v2d q1[4];
+        head(k1 == WK_MEM ? rowsOf(d.src1) : dummyRows, q1);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if !(defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NODMA))
         if (k + 1 < nOps) dma(fs + (size_t)(k + 1) * fsStep + HALF_BYTES, 1u);
-        // ---- first child, multiplied into the second's as it comes
+#endif
+        // ---- first child, then the product: first * second * 1/factor, k_pruneTiled's order of operations
         {
-            const double inve = rd ? 1.0 / sc.x : 1.0, invo = rd ? 1.0 / sc.y : 1.0;
-            v2d b1[W64_NT];
-            if (k1 == WK_MEM) tiledLoadB<W64_NT, EXACT>(d.src1, tileBase, S, g, m, b1);
-            walkChild16Into<EXACT>(fragA, nt, S, k1 == WK_TIPS, se1, so1, b1, g, fl, inve, invo, T);
-        }
+            v2d R[W64_NT];
+            if (k1 == WK_TIPS) walkTip16(fragA, S, se1, so1, g, R);
+#if !(defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NOLOAD))
+            else walkAcc16<EXACT, true>(fragA, nt, S, ACC, rowsOf(d.src1), q1, lane8, g, m, fl, R);
+#else
+            else walkAcc16<EXACT, false>(fragA, nt, S, T, nullptr, q1, lane8, g, m, fl, R);
+#endif
 #pragma unroll
-        for (int j = 0; j < W64_NT; j++) ACC[j] = T[j];
+            for (int j = 0; j < W64_NT; j++) ACC[j] = v2d{R[j].x * T[j].x * inve, R[j].y * T[j].y * invo};
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (k + 1 < nOps) dma(fs + (size_t)(k + 1) * fsStep, 0u);
+        if (k + 1 < nOps) {
+#if !(defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NODMA))
+            dma(fs + (size_t)(k + 1) * fsStep, 0u);
+#endif
+            const WalkOp& dn = dp[k + 1];
+            sm = small(dn);
+            head(((dn.flags >> 8) & 7) == WK_MEM ? rowsOf(dn.src2) : dummyRows, q2);
+        }
+#if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NOSTORE)
+        if ((flg & WF_STORE) && ACC[0].x == -1.0) {
+#else
         if (flg & WF_STORE) {
+#endif
             char* dst = reinterpret_cast<char*>(d.store + tileBase);
 #pragma unroll
             for (int j = 0; j < W64_NT; j++) {
