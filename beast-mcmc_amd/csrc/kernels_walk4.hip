@@ -612,6 +612,13 @@ __global__ __launch_bounds__(MAXC * 64, 4) void k_walk4_fast(const unsigned MI35
         const double* catWeights = part >= 0 ? rootParts.p[part].catWeights : rootArgs.catWeights;
         const double* cum = part >= 0 ? rootParts.p[part].cum : rootArgs.cum;
         const int cumIsRaw = part >= 0 ? rootParts.p[part].cumIsRaw : rootArgs.cumIsRaw;
+        // Every wave of the workgroup has left the loop before any of them writes the exchange area below — it is hold slot 1 of the
+        // FIRST waves, and a wave that is a stage or two behind may still have a value parked there.  On flags the barrier in front of
+        // the flag store did that; on tickets the last slice leaves the loop through a `break` in front of every barrier, and with
+        // another instance's workgroups sharing the CU's SIMDs unevenly (a 20-state write-mode walk, three workgroups per CU) the waves
+        // drifted far enough apart: whole pattern groups of the 4-state instance came out wrong in the two-thread test, half the runs
+        // (tools/r06_flake_diag.py; profiles/r06_experiments.txt 18).
+        __syncthreads();
         const double* h = reinterpret_cast<const double*>(lds) + (size_t)c * 512 + (size_t)lane * 2;       // hold slot 0: [c][4 x 1 KiB][lane x 16 B]
         const double sa = rootDot4(freqs, h[0], h[1], h[128], h[129]);
         const double sb = rootDot4(freqs, h[256], h[257], h[384], h[385]);
