@@ -728,6 +728,9 @@ int walkChunkOps(const Instance* in, int opCount) {
     static const long ticketDiv = labEnv("BEAGLE_MI355_CHUNK_DIV") ? atol(labEnv("BEAGLE_MI355_CHUNK_DIV")) : 0;
     // (the T32 walk since it runs three workgroups per CU — 768 places, round 6 —: config B, 20 states, evaluations/s at 40 / 56 / 76 / 100 /
     // 130 / 180 micro-operations per slice: 467 / 467 / 475 / 479 / 480 / 455; 76 is what 2 560 gives there, 102 what 1 900 does)
+    // (21..64 states, k_walkT64 — 512 places of four tiles, a stage is microseconds long: config C, 61 states, evaluations/s at 8 / 12 / 16 / 24 /
+    // 32 / 48 / 64 micro-operations per slice: 340 / 342 / 338 / 332 / 334 / 336 / 334, one walk: 180 — tools/r06_t64_ring.sh)
+    if (in->walkT && in->S > 20) return (int)std::min<long>(150, std::max<long>(8, (long)opCount * groups / 2600));
     const long div = in->walkT ? 1900 : !fused ? 2560 : !in->useTickets ? 1400 : ticketDiv > 0 ? ticketDiv : in->partitionCount > 1 ? 1400 : 765;
     return (int)std::min<long>(150, std::max<long>(24, (long)opCount * groups / div));
 }

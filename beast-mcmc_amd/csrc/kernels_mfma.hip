@@ -1154,6 +1154,9 @@ static size_t walkT32W1Lds(int C) { return (size_t)2 * C * 2 * WT_FRAG * sizeof(
 // Read-mode rescaling and unscaled lists only (a pattern's write-mode factor needs all categories of the pattern): lists that
 // rescale in write mode take the level path (engine_levels.cpp runOperations), on operands materialised first.
 constexpr int W64_NT = 16, W64_FRAG = W64_NT * W64_NT * 16;          // doubles per matrix (4096 = 32 KiB)
+#ifndef W64_RING
+#define W64_RING 4                                                    // row tiles of a streamed operand in flight
+#endif
 #if defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NOMFMA)       // TIMING EXPERIMENTS ONLY: one of every sixteen matrix instructions (keeps the operands alive)
 #define W64_MFMA(a, b, c, sel) ((sel) ? (c) : mfma4(a, b, c))
 #else
@@ -1193,7 +1196,7 @@ __device__ __forceinline__ v2d w64LoadRowTile(const char* __restrict__ x, unsign
 // (128 cycles of the matrix pipe); the next step's fragments are requested before this step's MFMAs, and the scheduler is kept from
 // pulling more forward.  Even- and odd-pattern sums share a 16-byte register tuple: that is what is stored and multiplied later.
 template <bool EXACT, bool STREAM>
-__device__ __forceinline__ void walkAcc16(const v2d* __restrict__ frag, int nt, int S, const v2d (&b)[W64_NT], const char* __restrict__ x, v2d (&q)[4],
+__device__ __forceinline__ void walkAcc16(const v2d* __restrict__ frag, int nt, int S, const v2d (&b)[W64_NT], const char* __restrict__ x, v2d (&q)[W64_RING],
                                           unsigned lane8, int g, int m, int fl, v2d (&T)[W64_NT]) {
 #pragma unroll
     for (int it = 0; it < W64_NT; it++) T[it] = v2d{0.0, 0.0};
@@ -1205,8 +1208,8 @@ __device__ __forceinline__ void walkAcc16(const v2d* __restrict__ frag, int nt, 
         const int sn = s + 1, jn = sn >> 2, in = (sn & 3) * 2;
         if ((s & 3) == 0) {
             if (STREAM) {
-                bj = q[jt & 3];
-                if (jt + 4 < W64_NT && (EXACT || jt + 4 < nt)) q[jt & 3] = w64LoadRowTile<EXACT>(x, lane8, S, g, m, jt + 4);
+                bj = q[jt % W64_RING];
+                if (jt + W64_RING < W64_NT && (EXACT || jt + W64_RING < nt)) q[jt % W64_RING] = w64LoadRowTile<EXACT>(x, lane8, S, g, m, jt + W64_RING);
             } else bj = b[jt];
         }
         v2d n0 = a0, n1 = a1;
@@ -1301,15 +1304,15 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT64(const WalkOp* __restric
         r.sc = *reinterpret_cast<const v2d MI355_GLOBAL*>(gptr(d.scale) + pe);
         return r;
     };
-    auto head = [&](const char* x, v2d (&q)[4]) {
+    auto head = [&](const char* x, v2d (&q)[W64_RING]) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (lane8 + (unsigned)j * 4u * TILE * 8u))));
+        for (int j = 0; j < W64_RING; j++) q[j] = __builtin_nontemporal_load(gptr(reinterpret_cast<const v2d*>(x + (lane8 + (unsigned)j * 4u * TILE * 8u))));
     };
     auto rowsOf = [&](const void* buf) { return reinterpret_cast<const char*>(reinterpret_cast<const double*>(buf) + tileBase); };
     dma(fs + HALF_BYTES, 1u);
     dma(fs, 0u);
     Small sm = small(dp[0]);
-    v2d q2[4];
+    v2d q2[W64_RING];
     head(((dp[0].flags >> 8) & 7) == WK_MEM ? rowsOf(dp[0].src2) : dummyRows, q2);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     v2d ACC[W64_NT];
@@ -1333,9 +1336,9 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void k_walkT64(const WalkOp* __restric
 #endif
         // the first child's first row tiles (or four loads of nothing), then: everybody is done with the second matrix, and this
         // micro-operation's first one has landed (requested a phase ago: older than the four)
-        v2d q1[4];
+        v2d q1[W64_RING];
         head(k1 == WK_MEM ? rowsOf(d.src1) : dummyRows, q1);
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(W64_RING) : "memory");
 #if !(defined(BEAGLE_MI355_LAB) && defined(MI355_EXP_T64_NODMA))
         if (k + 1 < nOps) dma(fs + (size_t)(k + 1) * fsStep + HALF_BYTES, 1u);
 #endif

@@ -40,7 +40,7 @@ def two_partitions(S, T, sizes, seed):
     return tree, wls
 
 
-@pytest.mark.parametrize("S", [4, 20])
+@pytest.mark.parametrize("S", [4, 20, 61])
 @pytest.mark.parametrize("scaling", [False, True])
 def test_multi_partition_protocol(S, scaling, oracle_lib):
     T = 9
@@ -104,7 +104,7 @@ def test_multi_partition_protocol(S, scaling, oracle_lib):
     assert helpers.rel_err(total[0], sum(expect)) <= 1e-10
 
 
-@pytest.mark.parametrize("S", [4, 20])
+@pytest.mark.parametrize("S", [4, 20, 61])
 def test_partitioned_instance_partial_updates_with_per_partition_flips(S, oracle_lib):
     """What MultiPartitionDataLikelihoodDelegate does between full evaluations: ONE partition's branch changes, only that
     partition's path to the root is re-evaluated, into ITS alternate buffers (partialBufferHelper[i], one per partition,
