@@ -592,7 +592,8 @@ def bench_single(args, bm, wl, rank, world, dist, device, res, t_gen, sharded, S
             # the level kernels store and re-read every node they compute (= the algorithmic bytes), minus the tip-tip nodes
             # a <= 20-state instance defines instead of storing (engine counters)
             moved = moved_bytes(stats, p_, c_, s_) / max(1, args.steps) if stats["micro_ops"] > 0 else alg
-            kname = ("k_walkT32" if stats["walks"] > 0 else "k_pruneTiled<5>") if 16 <= s_ <= 20 else "k_pruneTiled<16>" if s_ <= 64 else "k_pruneGeneral"
+            kname = (("k_walkT32" if stats["walks"] > 0 else "k_pruneTiled<5>") if 16 <= s_ <= 20 else
+                     ("k_walkT64" if stats["walks"] > 0 else "k_pruneTiled<16>") if s_ <= 64 else "k_pruneGeneral")
             launches_per_eval = launches / timed_calls
         achieved = moved / kernel_s / 1e9 if kernel_s > 0 else 0.0
         prof, prof_note = traffic_for(args, "k_walk" if stats["walks"] > 0 else "k_prune", world, rank)

@@ -56,7 +56,7 @@ TAG=_C STEPS=5 bash profiles/collect.sh $R --config C 2>&1 | grep rc=
 TAG=_E STEPS=20 bash profiles/collect.sh $R --config E 2>&1 | grep rc=
 TAG=_B_always STEPS=5 bash profiles/collect.sh $R --config B --rescaling always 2>&1 | grep rc=     # (round 6: the write-mode T32 walk, k_walkT32W1)
 python profiles/summarize.py ${R}_A A k_walk4 > /dev/null; python profiles/summarize.py ${R}_B B k_walkT32 > /dev/null
-python profiles/summarize.py ${R}_C C k_pruneTiled > /dev/null; python profiles/summarize.py ${R}_E E k_walk4 > /dev/null
+python profiles/summarize.py ${R}_C C k_walkT64 > /dev/null; python profiles/summarize.py ${R}_E E k_walk4 > /dev/null
 python profiles/summarize.py ${R}_B_always B_always k_walkT32W1 > /dev/null
 cp profiles/hbm_traffic.json profiles/${R}_*_kernel_stats.csv profiles/${R}_*_sq_counters.txt profiles/${R}_*_traffic_by_kernel.txt profiles/${R}_?_bench.json profiles/${R}_B_always_bench.json profiles/${R}_shard_bench.json gpurun_out/profiles_final/ 2>/dev/null
 python -c "import json;d=json.load(open('profiles/hbm_traffic.json'));[print(k, v['bytes_per_eval'], v.get('design_bytes_per_eval'), v.get('HBM_GBps_from_counters')) for k,v in d.items()]"
