@@ -100,11 +100,31 @@ __global__ __launch_bounds__(256) void k_transition(double* __restrict__ matrice
     }
     __syncthreads();
     double* M = matrices + ((size_t)dIdx[u] * C + c) * S * S;
-    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
-        const int i = e / S, j = e - i * S;
-        double s = 0.0;
-        for (int k = 0; k < S; k++) s += U[i * S + k] * sh[k * S + j];
-        M[e] = s > 0.0 ? s : 0.0;
+    // a thread forms a 4 x 4 block of entries: eight loads per sixteen multiply-adds instead of two per one (round 6: the 1 592 matrices
+    // of a 61-state evaluation 127 -> ~40 us); every entry still sums over k in ascending order — the same bits as entry by entry
+    const int nb = (S + 3) >> 2;
+    for (int b = threadIdx.x; b < nb * nb; b += blockDim.x) {
+        const int bi = b / nb, bj = b - bi * nb, i0 = 4 * bi, j0 = 4 * bj;
+        const double* u0 = U + (size_t)(i0 < S ? i0 : S - 1) * S;
+        const double* u1 = U + (size_t)(i0 + 1 < S ? i0 + 1 : S - 1) * S;
+        const double* u2 = U + (size_t)(i0 + 2 < S ? i0 + 2 : S - 1) * S;
+        const double* u3 = U + (size_t)(i0 + 3 < S ? i0 + 3 : S - 1) * S;
+        const int c0 = j0 < S ? j0 : S - 1, c1 = j0 + 1 < S ? j0 + 1 : S - 1, c2 = j0 + 2 < S ? j0 + 2 : S - 1, c3 = j0 + 3 < S ? j0 + 3 : S - 1;
+        double a[4][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        for (int k = 0; k < S; k++) {
+            const double* row = sh + (size_t)k * S;
+            const double v[4] = {row[c0], row[c1], row[c2], row[c3]};
+            const double w[4] = {u0[k], u1[k], u2[k], u3[k]};
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[r][q] += w[r] * v[q];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i0 + r < S && j0 + q < S) M[(size_t)(i0 + r) * S + j0 + q] = a[r][q] > 0.0 ? a[r][q] : 0.0;
     }
 }
 
@@ -263,15 +283,18 @@ void launchConvolveMatrices(hipStream_t stream, double* matrices, const int* dFi
                        matrices, dFirst, dSecond, dResult, S, C);
 }
 
-__global__ void k_snapshot(double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
+// (one 64-thread workgroup per matrix moved a 61-state matrix block — 119 KB — 8 bytes per thread and step: 72 us for the ~600 snapshots
+// of a config-C evaluation; now a matrix is cut into pieces of 2 048 doubles, a workgroup of 256 threads each)
+__global__ __launch_bounds__(256) void k_snapshot(double* __restrict__ matrices, const int* __restrict__ srcDst, int elems) {
     const double* s = matrices + (size_t)srcDst[2 * blockIdx.x] * elems;
     double* d = matrices + (size_t)srcDst[2 * blockIdx.x + 1] * elems;
-    for (int e = threadIdx.x; e < elems; e += blockDim.x) d[e] = s[e];
+    const int e0 = blockIdx.y * 2048, e1 = e0 + 2048 < elems ? e0 + 2048 : elems;
+    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) d[e] = s[e];
 }
 
 void launchSnapshotMatrices(hipStream_t stream, double* matrices, const int* dSrcDst, int n, int elems) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_snapshot, dim3(n), dim3(64), 0, stream, matrices, dSrcDst, elems);
+    hipLaunchKernelGGL(k_snapshot, dim3(n, (elems + 2047) / 2048), dim3(256), 0, stream, matrices, dSrcDst, elems);
 }
 
 // ------------------------------------------------------------------------------------------------
