@@ -125,7 +125,7 @@ ABI_SYMBOLS = ["beagleGetVersion", "beagleGetCitation", "beagleGetResourceList",
               ["beagleMi355SetStream", "beagleMi355CalculateRootLogLikelihoodsDevice", "beagleMi355Synchronize",
                "beagleMi355KernelTimer", "beagleMi355DeviceBytes", "beagleMi355WalkStats", "beagleMi355GradientStats", "beagleMi355GetPartialsBatch",
                "beagleMi355GetPartialsPinned", "beagleMi355GetSiteLogLikelihoodsPinned",
-               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355WalkLaunchInfo", "beagleMi355RootFusedCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CommInfo", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
+               "beagleMi355KernelTimerCalls", "beagleMi355WalkHealth", "beagleMi355WalkLaunchInfo", "beagleMi355RootFusedCount", "beagleMi355SitePrefetchCount", "beagleMi355KernelTimerRestart", "beagleMi355GetDimensions", "beagleMi355GetCommUniqueId", "beagleMi355CommInit", "beagleMi355CommInfo", "beagleMi355CalculateRootLogLikelihoodsAllReduce"]
 
 
 class EngineLibrary:
@@ -497,6 +497,12 @@ class Beagle:
         """calculateRootLogLikelihoods calls answered inside the walk's launch (include/beagle_mi355.h beagleMi355RootFusedCount)."""
         n = C.c_long(0)
         self._check("rootFusedCount", self._ext("beagleMi355RootFusedCount", [C.c_int, C.POINTER(C.c_long)])(self.instance, C.byref(n)))
+        return n.value
+
+    def sitePrefetchCount(self):
+        """getSiteLogLikelihoods calls that found the values already on the host (include/beagle_mi355.h beagleMi355SitePrefetchCount)."""
+        n = C.c_long(0)
+        self._check("sitePrefetchCount", self._ext("beagleMi355SitePrefetchCount", [C.c_int, C.POINTER(C.c_long)])(self.instance, C.byref(n)))
         return n.value
 
     def getPartialsBatch(self, bufferIndices, scaleIndices=None):

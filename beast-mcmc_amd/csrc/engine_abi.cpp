@@ -56,9 +56,52 @@ int accumulate(Instance* in, const int* idx, int count, int cum, double sign, in
     return 0;
 }
 
+// The site log-likelihoods of the root sum just enqueued, on their way to the host before anybody asks (Instance::hSites): called by the
+// whole-alignment root entry points right behind their last launch.  A caller that read the site values after each of the last two such
+// sums (BeagleTreeLikelihood.java:1050 does after every one) is served; the copy is a kernel of the stream (k_hostCopies writing through
+// the buffer's device mapping: the next evaluation's launches queue behind 800 KB of PCIe writes at the metric's size, ~20 us, which the
+// caller's own traversal covers), its end an event.
+int sitePrefetchAfterRoot(Instance* in) {
+    if (!in->siteReadSinceRoot) in->siteReadStreak = 0;            // the sum before this one: nobody looked at its site values
+    in->siteReadSinceRoot = false;
+    const size_t bytes = (size_t)in->P * sizeof(double);
+    if (!in->sitePrefetch || in->siteReadStreak < 2 || bytes > ((size_t)1 << 30)) return 0;
+    if (!in->hSites) {
+        if (hipHostMalloc((void**)&in->hSites, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { in->hSites = nullptr; in->sitePrefetch = false; (void)hipGetLastError(); return 0; }
+        if (hipHostGetDevicePointer((void**)&in->hSitesDev, in->hSites, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&in->siteEvent, hipEventDisableTiming) != hipSuccess) { in->sitePrefetch = false; (void)hipGetLastError(); return 0; }
+    }
+    const unsigned blocks = (unsigned)((bytes + 4095) / 4096);
+    mi355::HostCopyList L;
+    L.n = 1;
+    L.e[0].dst = in->hSitesDev; L.e[0].src = (const char*)in->siteLogL; L.e[0].bytes = (unsigned)bytes; L.e[0].firstBlock = 0;
+    mi355::launchHostCopies(live(in), L, (int)blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(in->siteEvent, live(in)));
+    in->sitePrefetched = true;
+    return 0;
+}
+// ... and the other end: true when `out` (nullable: the caller reads Instance::hSites itself) has the site values of the last root sum
+bool sitePrefetchTake(Instance* in, double* out) {
+    if (!in->siteReadSinceRoot) { in->siteReadStreak++; in->siteReadSinceRoot = true; }
+    if (!in->sitePrefetched) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    hipError_t st;
+    while ((st = hipEventQuery(in->siteEvent)) == hipErrorNotReady) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) { st = hipEventSynchronize(in->siteEvent); break; }
+    }
+    if (st != hipSuccess) { (void)hipGetLastError(); in->sitePrefetched = false; return false; }      // (the stream-ordered download then says what went wrong)
+    if (out) memcpy(out, in->hSites, (size_t)in->P * sizeof(double));
+    in->statSitePrefetched++;
+    return true;
+}
+
 int rootEnqueue(Instance* in, int rootIdx, int wIdx, int fIdx, int cumIdx, int part, double* dOut,
                 unsigned long long* flag = nullptr, unsigned long long seq = 0) {
     // part < 0: the whole pattern range
+    in->sitePrefetched = false;                           // (whatever this sum writes into siteLogL, the host's copy is of the one before)
     if (badIndex(rootIdx, in->partialsCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     { int rcv = materializeVirtual(in, rootIdx); if (rcv) return rcv; }
     if (!in->partials[rootIdx] || badIndex(wIdx, in->eigenCount) ||
@@ -414,6 +457,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     ok = ok && hipHostMalloc((void**)&in->hRing, RING_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void**)&in->hRingDev, in->hRing, 0) == hipSuccess;     // (the copies out of the ring are a kernel's: flushUploads)
     in->kernelUploads = !(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS") && atoi(getenv("BEAGLE_MI355_COPY_ENGINE_UPLOADS")) != 0);
+    in->sitePrefetch = !(getenv("BEAGLE_MI355_NO_SITE_PREFETCH") && atoi(getenv("BEAGLE_MI355_NO_SITE_PREFETCH")) != 0);
     in->fuseWaves = !(getenv("BEAGLE_MI355_NO_WALK_FUSION") && atoi(getenv("BEAGLE_MI355_NO_WALK_FUSION")) != 0);
     in->useTickets = !(getenv("BEAGLE_MI355_NO_WALK_TICKETS") && atoi(getenv("BEAGLE_MI355_NO_WALK_TICKETS")) != 0);
     in->xcdAware = !(getenv("BEAGLE_MI355_NO_XCD_MAP") && atoi(getenv("BEAGLE_MI355_NO_XCD_MAP")) != 0);
@@ -785,6 +829,7 @@ int beagleMi355GetSiteLogLikelihoodsPinned(int instance, const double** outPinne
     GET_INSTANCE(instance);
     if (!outPinned || !outCount) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t bytes = (size_t)in->P * sizeof(double);
+    if (sitePrefetchTake(in, nullptr)) { *outPinned = in->hSites; *outCount = in->P; return BEAGLE_SUCCESS; }      // (valid until the next root sum)
     if (bytes > RING_BYTES) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     HIP_TRY(hipMemcpyAsync(in->hRing, in->siteLogL, bytes, hipMemcpyDeviceToHost, live(in)));     // (the ring is pinned; everything staged in it
     HIP_TRY(hipStreamSynchronize(live(in)));                                                      //  has been consumed once the stream is idle)
@@ -1202,6 +1247,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
     int rc = rootEnqueue(in, bufferIndices[0], categoryWeightsIndices[0], stateFrequenciesIndices[0],
                          cumulativeScaleIndices[0], -1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     if (rc) return rc;
+    rc = sitePrefetchAfterRoot(in); if (rc) return rc;
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
     if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;   // everything staged so far has been consumed
     const double v = in->hResult[0];
@@ -1224,6 +1270,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
     GET_INSTANCE(instance);
     if (count != 1) return BEAGLE_ERROR_NO_IMPLEMENTATION;
     if (partitionCount < 1 || partitionCount > 512) return BEAGLE_ERROR_OUT_OF_RANGE;
+    in->sitePrefetched = false; in->siteReadStreak = 0;          // (per-partition sums rewrite siteLogL piece by piece: always the stream-ordered download)
     if (!in->tiled && partitionCount <= 480) {
         // 4-state walk instances, up to eight partitions: 128-pattern groups with the assembly loop's lane map (k_rootSite4WParts) — and
         // when the walk that computes these roots is still held back (engine_walk.cpp runPlan) and its last slices are exactly the
@@ -1347,6 +1394,8 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
 int beagleGetSiteLogLikelihoods(int instance, double* out) {
     if (mi355::isShardedHandle(instance)) { return mi355::shardedGetPerPatternDoubles(instance, out, 1, 1, [&](int h, double* v) { return beagleGetSiteLogLikelihoods(h, v); }); }
     GET_INSTANCE(instance);
+    if (!out) return BEAGLE_ERROR_OUT_OF_RANGE;
+    if (sitePrefetchTake(in, out)) return BEAGLE_SUCCESS;         // (already on the host: Instance::hSites)
     return download(in, out, in->siteLogL, (size_t)in->P * sizeof(double));
 }
 
@@ -1501,7 +1550,8 @@ int beagleMi355CalculateRootLogLikelihoodsDevice(int instance, int bufferIndex, 
     GET_INSTANCE_KEEP_PENDING(instance);
     if (!deviceOut) return BEAGLE_ERROR_OUT_OF_RANGE;
     if (heldWrites(in, bufferIndex)) { int rcp = executeHeldPre(in); if (rcp) return rcp; }
-    return rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
+    const int rc = rootEnqueue(in, bufferIndex, categoryWeightsIndex, stateFrequenciesIndex, cumulativeScaleIndex, -1, (double*)deviceOut);
+    return rc ? rc : sitePrefetchAfterRoot(in);
 }
 
 // ---- one process per GPU: the collective inside the engine -------------------------------------------------------------
@@ -1553,6 +1603,7 @@ int beagleMi355CalculateRootLogLikelihoodsAllReduce(int instance, int bufferInde
     const unsigned long long seq = ++in->resultSeq;
     mi355::launchRootFinal(live(in), in->dResult, 1, in->hResultDev, (unsigned long long*)(in->hResultDev + 8), seq);
     HIP_TRY(hipGetLastError());
+    rc = sitePrefetchAfterRoot(in); if (rc) return rc;          // (behind the publishing kernel: neither the collective nor the result waits for the copy)
     { const int rcw = waitResult(in, seq); if (rcw) return rcw; }
     if (in->pendingCopies.empty() && !in->pendingWalk.valid) in->ringHead = 0;
     const double v = in->hResult[0];
@@ -1645,6 +1696,17 @@ int beagleMi355RootFusedCount(int instance, long* outCount) {
     Instance* in = lookup(instance);
     if (!in || !outCount) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
     *outCount = in->statRootFused;
+    return BEAGLE_SUCCESS;
+}
+
+int beagleMi355SitePrefetchCount(int instance, long* outCount) {
+    if (mi355::isShardedHandle(instance)) {
+        bool first = true; std::mutex mu;
+        return mi355::shardedBroadcast(instance, [&](int h) { { std::lock_guard<std::mutex> l(mu); if (!first) return 0; first = false; } return beagleMi355SitePrefetchCount(h, outCount); });
+    }
+    Instance* in = lookup(instance);
+    if (!in || !outCount) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
+    *outCount = in->statSitePrefetched;
     return BEAGLE_SUCCESS;
 }
 

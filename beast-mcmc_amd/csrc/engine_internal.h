@@ -215,6 +215,17 @@ struct Instance {
     // instance's stream right behind the reduction kernel, and its result reaches the host through the same mapped words as a
     // single-GPU sum (beagleMi355CommInit / beagleMi355CalculateRootLogLikelihoodsAllReduce)
     ncclComm_t comm = nullptr; int commRanks = 0;
+    // BeagleTreeLikelihood reads the site log-likelihoods back after EVERY evaluation (BeagleTreeLikelihood.java:1050: P doubles, 800 KB at
+    // the metric's size — through a pageable destination a quarter of a 4-state evaluation's step).  A caller that has done so after each
+    // of the last two whole-alignment root sums gets the next one's site values sent to a pinned host buffer (hSites; the device writes it
+    // through its mapping, a kernel right behind the root's: no copy engine, no staging) before it asks: beagleGetSiteLogLikelihoods is then
+    // a wait for siteEvent — over by the time the call arrives — and one host copy.  Any later root sum of the instance makes the prefetched
+    // values stale (sitePrefetched = false: rootEnqueue / the by-partition sums); a caller that stops asking stops being served
+    // (siteReadStreak).  BEAGLE_MI355_NO_SITE_PREFETCH=1 at creation: always the stream-ordered download (A/B runs, tests).
+    bool sitePrefetch = true, sitePrefetched = false, siteReadSinceRoot = true;
+    int siteReadStreak = 0; long statSitePrefetched = 0;
+    double* hSites = nullptr; double* hSitesDev = nullptr; hipEvent_t siteEvent = nullptr;
+    ~Instance() { if (hSites) hipHostFree(hSites); if (siteEvent) hipEventDestroy(siteEvent); }      // (destroy() has drained the streams by then)
     // first error of a deferred operation; surfaces at the next call that observes results.  Atomic: the sharded handle's caller reads and
     // clears it (sharded.cpp takeAsyncError) while the shard's own worker thread may be setting it
     std::atomic<int> asyncError{0};

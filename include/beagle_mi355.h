@@ -350,6 +350,11 @@ int beagleMi355KernelTimerCalls(int instance, long* outCalls);
  * log-likelihood of the walk's last result the slice that computes it finishes the evaluation (no root kernel, no read-back of
  * the root's partials).  BEAGLE_MI355_NO_ROOT_FUSION=1 switches the holding off.  Since instance creation. */
 int beagleMi355RootFusedCount(int instance, long* outCount);
+/* beagleGetSiteLogLikelihoods (and its pinned form below) calls since instance creation that found the site values ALREADY ON THE HOST: a
+ * caller that reads them after every whole-alignment root sum — BeagleTreeLikelihood.java:1050 does — has them sent to a pinned buffer right
+ * behind the root's kernel, before it asks (two such reads in a row switch it on, a sum nobody reads the values of switches it off;
+ * the values are those of the stream-ordered download, bit for bit).  BEAGLE_MI355_NO_SITE_PREFETCH=1 at creation: never. */
+int beagleMi355SitePrefetchCount(int instance, long* outCount);
 /* Forget what the (enabled) kernel timer and the walk counters have gathered so far — no synchronisation, no allocation: for a
  * caller that has just synchronised the stream itself and wants the measurement to start here (bench.py: between its warm-up
  * and its timed steps, without giving the device an idle gap to drop its clocks in). */
