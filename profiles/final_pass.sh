@@ -30,6 +30,9 @@ timeout 600 python tools/gradient_bench.py --config B --steps 5 --warmup 3 2>/de
 timeout 600 python tools/gradient_bench.py --config C --steps 5 --warmup 3 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_gradient_bench_C.json
 for g in "" _1e5 _B _C; do python -c "import json;d=json.loads(open('gpurun_out/profiles_final/${R}_gradient_bench$g.json').read());print('gradient$g', d['ms_per_gradient'],'ms, likelihood', d['ms_per_likelihood_same_driver'],'ms, roofline frac', d['roofline']['frac'], d['how'])" 2>&1 | tail -1; done
 timeout 300 python bench.py --config A --caller btl --steps 100 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_btl.json; line gpurun_out/profiles_final/${R}_bench_A_btl.json "A btl"
+# BeagleTreeLikelihood's protocol with and without the site prefetch (round 6), alternating; and the step times of a long DYNAMIC chain
+(bash tools/r06_site_prefetch_ab.sh A; bash tools/r06_site_prefetch_ab.sh D --real benchmark1) > gpurun_out/profiles_final/${R}_site_prefetch_ab.txt 2>&1; cat gpurun_out/profiles_final/${R}_site_prefetch_ab.txt
+bash tools/r06_cycle_times.sh 2>&1 | grep -v "gather launch\|amdgpu.ids" > gpurun_out/profiles_final/${R}_cycle_times_A.txt; head -18 gpurun_out/profiles_final/${R}_cycle_times_A.txt
 timeout 300 python bench.py --config A --rescaling always --steps 100 --warmup 5 --no-cpu-baseline --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_always.json; line gpurun_out/profiles_final/${R}_bench_A_always.json "A always"
 timeout 300 python bench.py --config B --rescaling always --steps 40 --warmup 5 --no-cpu-baseline --no-live-traffic --no-library-route 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_B_always.json; line gpurun_out/profiles_final/${R}_bench_B_always.json "B always"
 timeout 300 python bench.py --patterns 12500 --steps 200 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 > gpurun_out/profiles_final/${R}_bench_A_shard12500.json; line gpurun_out/profiles_final/${R}_bench_A_shard12500.json "A shard"
