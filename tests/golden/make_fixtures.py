@@ -15,6 +15,7 @@ Outputs (data only — inputs and expected outputs, no reference source text):
                          tests/TestXML/testBranchSpecificSubstitutionModel.xml:44-61, 77-79, 114-207, 209-235
   jar_smoke.json         the API-level smoke test baked into lib/beagle.jar (beagle.BeagleFactory#main):
                          3 taxa, literal JC69 eigen system, literal op list, "PAUP logL = -1574.63623"
+  transition_probabilities.json   the ten 4 x 4 known-answer matrices of HKYTest / TN93Test / GeneralF81Test (scilab expm, 1e-10)
   benchmark{1,2}_patterns.npz   (python tests/golden/make_fixtures.py --benchmarks) the REAL alignments of
                          examples/Benchmarks/benchmark1.xml (1441 taxa x 987 sites -> 593 patterns, HKY) and benchmark2.xml
                          (62 x 10869 -> 5565, GTR+G4) as unique site patterns + weights; no tree (the XMLs draw a random
@@ -37,6 +38,45 @@ def primate_sequences():
     assert names == ["human", "chimp", "bonobo", "gorilla", "orangutan", "siamang"], names
     assert all(len(s) == 768 for s in seqs), [len(s) for s in seqs]
     return names, seqs
+
+
+def java_numbers(text):
+    return [float(x) for x in re.findall(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?", text)]
+
+
+def transition_probabilities():
+    """The known-answer transition-probability matrices of the reference's substitution-model tests (expm of the normalised
+    generator, computed with scilab by the tests' authors, asserted to 1e-10): instance by instance the frequencies, the
+    model's parameters, the distance and the 16 expected entries.  The relative rates are written out in the row-major
+    upper-triangle order A-C, A-G, A-T, C-G, C-T, G-T the tests' own generator comments use
+    (XQ = [0 1 k1 1; 1 0 1 k2; k1 1 0 1; 1 k2 1 0], Q = XQ diag(pi) with the diagonal filled in, normalised to one expected
+    substitution per unit time)."""
+    cases = []
+    for path, params in (("src/test/dr/evomodel/substmodel/HKYTest.java", ("getKappa",)),
+                         ("src/test/dr/evomodel/substmodel/TN93Test.java", ("getKappa1", "getKappa2")),
+                         ("src/test/dr/evomodel/substmodel/GeneralF81Test.java", ())):
+        src = open(os.path.join(REF, path)).read()
+        src = re.sub(r"//[^\n]*", "", src)
+        blocks = re.split(r"Instance\s+(test\d+)\s*=\s*new\s+Instance\s*\(\s*\)", src)
+        # blocks = [head, name, body, name, body, ...]; the last body runs on into the test method: cut it at "Instance[] all"
+        for name, body in zip(blocks[1::2], blocks[2::2]):
+            body = body.split("Instance[]")[0]
+
+            def method(m):
+                return re.search(m + r"\s*\(\s*\)\s*\{(.*?)\}\s*;?\s*\}", body, re.S).group(1) if (m + "(") in body.replace(" ", "") else None
+            pi = java_numbers(re.search(r"getPi\s*\(\s*\)\s*\{\s*return\s+new\s+double\[\]\s*\{(.*?)\}", body, re.S).group(1))
+            expected = java_numbers(re.search(r"getExpectedResult\s*\(\s*\)\s*\{\s*return\s+new\s+double\[\]\s*\{(.*?)\}", body, re.S).group(1))
+            distance = java_numbers(re.search(r"getDistance\s*\(\s*\)\s*\{\s*return(.*?);", body, re.S).group(1))[0]
+            k = [java_numbers(re.search(m + r"\s*\(\s*\)\s*\{\s*return(.*?);", body, re.S).group(1))[0] for m in params]
+            assert len(pi) == 4 and len(expected) == 16 and abs(sum(pi) - 1.0) < 1e-12, (path, name, pi, expected)
+            k1, k2 = (k[0], k[0]) if len(k) == 1 else (k[0], k[1]) if len(k) == 2 else (1.0, 1.0)
+            cases.append({"source": "%s %s" % (path, name), "model": os.path.basename(path)[:-len("Test.java")], "pi": pi,
+                          "relative_rates_ac_ag_at_cg_ct_gt": [1.0, k1, 1.0, 1.0, k2, 1.0], "distance": distance,
+                          "expected_row_major": expected, "tolerance": 1e-10})
+    assert len(cases) == 10, len(cases)
+    return {"what": "known-answer transition-probability matrices asserted by the reference's substitution-model tests "
+                    "(HKYTest.java:151-156, TN93Test.java:167-172, GeneralF81Test.java:158-163: |P - expected| <= 1e-10 entry by entry)",
+            "cases": cases}
 
 
 def benchmark_alignment(xml_name):
@@ -179,7 +219,8 @@ def main():
                 "(the test's name: the other order gives -1.74802)",
     }
     json.dump(epoch, open(os.path.join(HERE, "epoch_convolution.json"), "w"), indent=1)
-    print("wrote primates.json, branch_specific.json, jar_smoke.json")
+    json.dump(transition_probabilities(), open(os.path.join(HERE, "transition_probabilities.json"), "w"), indent=1)
+    print("wrote primates.json, branch_specific.json, jar_smoke.json, epoch_convolution.json, transition_probabilities.json")
 
 
 if __name__ == "__main__":

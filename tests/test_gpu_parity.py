@@ -89,6 +89,16 @@ def test_golden_branch_specific(case, engine_lib):
     assert abs(lnl - c["lnL"]) < 5e-13, (lnl, c["lnL"])
 
 
+def test_golden_transition_probabilities(engine_lib, oracle_lib):
+    """The reference's known-answer transition-probability matrices (HKYTest / TN93Test / GeneralF81Test, 1e-10) through the HIP
+    engine's updateTransitionMatrices, and the engine against the oracle on the same eigen systems."""
+    from test_oracle_golden import check_transition_probabilities, run_transition_probabilities
+    rows = run_transition_probabilities(engine_lib)
+    check_transition_probabilities(rows)
+    for (c, a0, a1), (_, o0, o1) in zip(rows, run_transition_probabilities(oracle_lib)):
+        assert np.abs(a0 - o0).max() <= 1e-14 and np.abs(a1 - o1).max() <= 1e-14, c["source"]
+
+
 def test_golden_epoch_convolution(engine_lib):
     """tests/TestXML/testEpochConvolutionOrder.xml:179-193 — pins convolveTransitionMatrices and its order."""
     from test_oracle_golden import run_epoch_convolution

@@ -125,6 +125,41 @@ def run_branch_specific(library, stem_weight):
         b.finalize()
 
 
+def run_transition_probabilities(library):
+    """tests/golden/transition_probabilities.json through setEigenDecomposition -> updateTransitionMatrices -> getTransitionMatrix:
+    -> [(case, P(t) of category 0 from a branch of length t, P(t) of category 1 — rate 1/2 — from a branch of length 2 t)]"""
+    g = helpers.golden("transition_probabilities.json")
+    n = len(g["cases"])
+    b = bm.beagle.Beagle(2, 3, 2, 4, 1, 1, 2 * n, 2, 0, library=library)
+    try:
+        b.setCategoryRates([1.0, 0.5])
+        out = []
+        for k, c in enumerate(g["cases"]):
+            q = substmodel.reversible_q(c["relative_rates_ac_ag_at_cg_ct_gt"], c["pi"])
+            e = substmodel.decompose_reversible(q, c["pi"])
+            b.setEigenDecomposition(0, e.evec, e.ievc, e.evals)
+            b.updateTransitionMatrices(0, [2 * k, 2 * k + 1], None, None, [c["distance"], 2.0 * c["distance"]], 2)
+            out.append((c, b.getTransitionMatrix(2 * k)[0].reshape(-1), b.getTransitionMatrix(2 * k + 1)[1].reshape(-1)))
+        return out
+    finally:
+        b.finalize()
+
+
+def check_transition_probabilities(rows):
+    assert len(rows) == 10
+    for c, p_t, p_half_rate in rows:
+        want = np.asarray(c["expected_row_major"])
+        assert np.abs(p_t - want).max() <= c["tolerance"], (c["source"], np.abs(p_t - want).max())
+        assert np.abs(p_half_rate - want).max() <= c["tolerance"], (c["source"], np.abs(p_half_rate - want).max())
+        np.testing.assert_allclose(p_t.reshape(4, 4).sum(axis=1), 1.0, rtol=0, atol=1e-14)
+
+
+def test_transition_probability_known_answers(oracle_lib):
+    """HKYTest.java:151-156, TN93Test.java:167-172, GeneralF81Test.java:158-163: the ten scilab expm matrices, entry by entry to 1e-10
+    (row a2 / a3 pinned on its own, not only through a tree's log-likelihood)."""
+    check_transition_probabilities(run_transition_probabilities(oracle_lib))
+
+
 @pytest.mark.parametrize("case", [0, 1])
 def test_branch_specific_full_precision(case, oracle_lib):
     """The only full-precision lnL values the reference pins on this path (tolerance 1e-13, absolute)."""
