@@ -201,20 +201,25 @@ __global__ __launch_bounds__(256) void k_transition4Fused(double* __restrict__ m
     if ((int)blockIdx.x >= transitionBlocks) { hostCopyBlock(L, blockIdx.x - (unsigned)transitionBlocks); return; }
     __shared__ double sEig[40], sRate[16];
     const int nEig = complexEigen ? 40 : 36;
+    // (the branch's length and matrix index are asked for BEFORE the barrier: they come out of the host's staging ring, as a freshly set
+    // eigen system does, and two round trips across PCIe one after the other were a fifth of this kernel's 10 us)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < count * C;
+    const int u = live ? t / C : 0, c = live ? t - u * C : 0;
+    const double myLen = len[u];
+    const int myIdx = idx[u];
     if ((int)threadIdx.x < nEig) sEig[threadIdx.x] = eigSrc[threadIdx.x];
     else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C && C <= 16) sRate[threadIdx.x - 64] = ratesSrc[threadIdx.x - 64];
     __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count * C) return;
-    const int u = t / C, c = t - u * C;
+    if (!live) return;
     const double* U = sEig;
     const double* Ui = U + 16;
     const double* lam = U + 32;
-    const double dist = len[u] * (C <= 16 ? sRate[c] : ratesSrc[c]);
+    const double dist = myLen * (C <= 16 ? sRate[c] : ratesSrc[c]);
     double ie[16];
     if (complexEigen) { for (int e = 0; e < 16; e++) ie[e] = iexpEntry(Ui, lam, 4, e >> 2, e & 3, dist, 1); }
     else for (int k = 0; k < 4; k++) { const double ex = exp(dist * lam[k]); for (int j = 0; j < 4; j++) ie[k * 4 + j] = Ui[k * 4 + j] * ex; }
-    double* M = matrices + ((size_t)idx[u] * C + c) * 16;
+    double* M = matrices + ((size_t)myIdx * C + c) * 16;
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
             double s = 0.0;
