@@ -812,7 +812,16 @@ __global__ __launch_bounds__(256) void k_foldReciprocals(const double* const* __
     const int j = (int)blockIdx.y, i = (int)(blockIdx.x * 256 + threadIdx.x);
     double prod = 1.0;
     if (i < len) {
-        for (int m = start[j]; m < start[j + 1]; m++) prod *= srcs[m][i];
+        // (four members' values in flight at once, multiplied in member order: a load per multiplication, each behind its pointer's, left
+        // the 0.74 GB of config A's 58 folds at 1.5 TB/s — 0.5 ms of every rescaling cycle)
+        int m = start[j];
+        const int e = start[j + 1];
+        for (; m + 4 <= e; m += 4) {
+            const double* p0 = srcs[m]; const double* p1 = srcs[m + 1]; const double* p2 = srcs[m + 2]; const double* p3 = srcs[m + 3];
+            const double a = p0[i], b = p1[i], c = p2[i], d = p3[i];
+            prod *= a; prod *= b; prod *= c; prod *= d;
+        }
+        for (; m < e; m++) prod *= srcs[m][i];
         dst[j][i] = prod;
         if (invert) prod = 1.0 / prod;
     }

@@ -703,17 +703,49 @@ void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
         const int part = e.tuple > 7 ? ops[(size_t)k * e.tuple + 7] : 0;
         const int dest = key(ops[(size_t)k * e.tuple], part);
         if (e.defOn[k] ? tagOf_[dest] == e.tag : tagOf_[dest] < 0) continue;        // already what the entry leaves behind
+        if (k + 6 < e.count) {                                   // (a definition is 1.5 KB: both sides of the copy below miss the caches otherwise)
+            const int aheadPart = e.tuple > 7 ? ops[(size_t)(k + 6) * e.tuple + 7] : 0;
+            const char* a = reinterpret_cast<const char*>(&e.defs[(size_t)k + 6]);
+            const char* b = reinterpret_cast<const char*>(&virt_[key(ops[(size_t)(k + 6) * e.tuple], aheadPart)]);
+            __builtin_prefetch(a); __builtin_prefetch(a + 64); __builtin_prefetch(a + 128); __builtin_prefetch(a + 192);
+            __builtin_prefetch(b, 1); __builtin_prefetch(b + 64, 1); __builtin_prefetch(b + 128, 1); __builtin_prefetch(b + 192, 1);
+        }
         const VirtDef& want = e.defs[k];
         VirtDef& cur = virt_[dest];
-        if (cur.on) clearVirtualKey(dest);
-        if (!e.defOn[k]) continue;                                // (defs[k] may be a leftover of an earlier list in this way)
+        // The usual reason to be here: the same node over the same tips, defined by the entry of the OTHER scale-buffer set (the evaluations
+        // right behind a rescaling one) — the definition's leaves stand in the tips' user lists already, only its scale buffers change.
+        // Taking the key out of every list and putting it back cost more than planning the list from scratch (tests/native/plan_check.cpp
+        // bench-replay: 303 us against 218 for a 1000-taxon list on the build container).
+        bool sameLeaves = cur.on && e.defOn[k] && cur.nSteps == want.nSteps;
+        for (int st = 0; sameLeaves && st < want.nSteps; st++)
+            sameLeaves = cur.steps[st].tipA == want.steps[st].tipA && cur.steps[st].tipB == want.steps[st].tipB;
+        if (sameLeaves) {
+            replayInPlace++;
+            for (int st = 0; st < want.nSteps; st++) {
+                const int was = cur.steps[st].scaleIdx;
+                if (was < 0 || was == want.steps[st].scaleIdx) continue;
+                bool still = false;
+                for (int q = 0; q < want.nSteps && !still; q++) still = want.steps[q].scaleIdx == was;
+                if (!still) { std::vector<int>& u = scaleUsers_[was]; u.erase(std::remove(u.begin(), u.end(), dest), u.end()); }
+            }
+        } else {
+            if (cur.on) clearVirtualKey(dest);
+            if (!e.defOn[k]) continue;                            // (defs[k] may be a leftover of an earlier list in this way)
+        }
         cur = want;                                               // (tagged with e.tag when the entry was filled)
         tagOf_[dest] = e.tag;
         cur.stamp = stamp_;
         cur.version = ++virtVersion_;
         cur.childVer1 = cur.sigTip1 ? -1 : virt_[key(cur.sigC1, part)].version;
         cur.childVer2 = cur.sigTip2 ? -1 : virt_[key(cur.sigC2, part)].version;
-        registerVirtual(dest);
+        if (sameLeaves) {
+            for (int st = 0; st < cur.nSteps; st++) {
+                const int sc = cur.steps[st].scaleIdx;
+                if (sc < 0) continue;
+                std::vector<int>& u = scaleUsers_[sc];
+                if (std::find(u.begin(), u.end(), dest) == u.end()) u.push_back(dest);
+            }
+        } else registerVirtual(dest);
     }
     planned = &e.plan; plannedTag = e.tag;
     lastStored = e.stored; lastMemReads = e.memReads; lastHolds = e.holds; lastWaves = e.waves;

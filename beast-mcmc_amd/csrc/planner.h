@@ -197,6 +197,7 @@ public:
     int stepLimit = 0;
     int stepCap() const { return stepLimit > 0 && stepLimit < maxSteps_ ? stepLimit : maxSteps_; }
     long cacheHits = 0;                  // plans served from the cache below
+    long replayInPlace = 0;              // definitions a replay took over from another entry with their leaves unchanged (user lists edited in place)
     bool cacheEnabled = true;
     // what the last plan() produced: `out`, or the cache's copy (no copy is made on a hit).  plannedTag identifies the
     // cache entry (0: not cached) so that the engine can keep what it derives from the plan.

@@ -233,7 +233,32 @@ static void runPlan(World& w, const Plan& plan, const std::vector<int>& partStar
         for (int si : plan.launchOrder) runSlice(si);
 }
 
+// The planner's user lists against its definitions: a definition's key stands in the list of every leaf and every scale buffer its steps
+// name, and in no other (replay() edits the lists in place when a definition keeps its leaves: planner.cpp).
+static void checkUserLists(const WalkPlanner& pl, int nBuf, int nScale, const char* where) {
+    const int parts = pl.partitionCount();
+    std::vector<std::vector<int>> wantTip((size_t)nBuf), wantScale((size_t)nScale);
+    for (int k = 0; k < nBuf * parts; k++) {
+        if (!pl.isVirtualKey(k)) continue;
+        const VirtDef& v = pl.definition(k);
+        for (int s = 0; s < v.nSteps; s++) {
+            if (v.steps[s].tipA >= 0) wantTip[(size_t)v.steps[s].tipA].push_back(k);
+            if (v.steps[s].tipB >= 0) wantTip[(size_t)v.steps[s].tipB].push_back(k);
+            if (v.steps[s].scaleIdx >= 0) wantScale[(size_t)v.steps[s].scaleIdx].push_back(k);
+        }
+    }
+    auto same = [](std::vector<int> a, std::vector<int> b) {
+        std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end());
+        std::sort(b.begin(), b.end());
+        return a == b;                               // (b unsorted-unique on purpose: a key listed twice is an error too)
+    };
+    for (int t = 0; t < nBuf; t++) if (!same(wantTip[(size_t)t], pl.tipUsers(t))) { fprintf(stderr, "USER LISTS: leaf %d [%s]\n", t, where); exit(1); }
+    for (int x = 0; x < nScale; x++) if (!same(wantScale[(size_t)x], pl.scaleUsers(x))) { fprintf(stderr, "USER LISTS: scale buffer %d [%s]\n", x, where); exit(1); }
+}
+
+static long g_replayInPlace = 0;
 struct Harness {
+    ~Harness() { g_replayInPlace += pl.replayInPlace; }
     int T, nBuf, nMat, nScale;
     World truth, plan;
     WalkPlanner pl;
@@ -365,6 +390,7 @@ struct Harness {
         pl.stepLimit = 0;
         lists++; g_list = lists;
         compareAll();
+        if (nBuf <= 1200) checkUserLists(pl, nBuf, nScale, g_where);
     }
     // The engine's read-mode folding of reciprocal scale factors (planner.h foldScaleFactors): the same program with the factors of
     // unstored results applied where the planner says must give every STORED result the value list-order evaluation gives it — to
@@ -659,6 +685,42 @@ static void scenarioHazards(unsigned seed) {
     printf("  hazards: %ld lists, %ld micro-ops\n", h.lists, h.micro);
 }
 
+// A DYNAMIC chain's rescaling cycles (BeagleTreeLikelihood.java:1059-1113): full evaluations in read mode alternating between the two
+// buffer parities, every few of them one in WRITE mode into the other scale-buffer set, after which the read-mode lists name that set —
+// closed lists throughout, so from the second cycle on every plan comes out of the cache, and right behind a rescaling evaluation it is
+// replayed over definitions another entry left behind (same leaves, other scale buffers: WalkPlanner::replay edits the user lists in place).
+static void scenarioRescaleCycles(int T, unsigned seed, int cycles, int chunk) {
+    std::mt19937 rng(seed);
+    static char where[96]; snprintf(where, sizeof where, "rescale cycles T=%d seed=%u chunk=%d", T, seed, chunk); g_where = where; g_list = 0;
+    Tree tree; tree.random(T, rng, false);
+    const int N = 2 * T - 1;
+    Harness h; h.init(T, T + 2 * (T - 1), 2 * N, 2 * (T - 1), true, seed + 1);
+    h.fixedChunk = chunk;
+    for (int i = 0; i < T; i++) h.setTipStates(i);
+    for (int s = 0; s < 2 * N; s++) h.setMatrix(s);
+    Protocol pr(tree);
+    std::vector<int> lvl = tree.levelOrder();
+    auto evaluation = [&](int mode) {
+        for (int n : lvl) pr.pFlip[n] ^= 1;
+        for (int n = 0; n < N - 1; n++) { pr.mFlip[n] ^= 1; h.setMatrix(pr.mBuf(n)); }
+        std::vector<int> ops; pr.emit(lvl, mode, ops); h.update(ops, 7);
+    };
+    for (int c = 0; c < cycles; c++) {
+        evaluation(1);                                   // the rescaling evaluation: new factors into the other set
+        for (int k = 0; k < 5; k++) evaluation(2);
+        if (c % 2) {                                     // ... and a branch move with its rejection in between, as a chain has them
+            pr.store();
+            const int n = rng() % (N - 1);
+            pr.mFlip[n] ^= 1; h.setMatrix(pr.mBuf(n));
+            std::vector<int> path;
+            for (int x : lvl) { bool on = false; for (int a = tree.parent[n]; a >= 0; a = tree.parent[a]) on = on || a == x; if (on) path.push_back(x); }
+            for (int x : path) pr.pFlip[x] ^= 1;
+            std::vector<int> ops; pr.emit(path, 2, ops); h.update(ops, 7);
+            pr.restore();
+        }
+    }
+}
+
 // `plan_check bench`: what the planner costs the host on a list it has not seen — config A's shape (1000 taxa, full evaluation, read
 // mode, the engine's settings for 1e5 patterns) with a few accepted branch moves between the lists, as a chain produces them
 // (bench.py partial_update.full_evaluation_on_a_new_list; profiles/r05_experiments.txt 12).  Microseconds per plan() call.
@@ -701,8 +763,50 @@ static void benchPlanner() {
     printf("planner, %d-taxon full evaluation on a new list: %.1f us per plan() (%ld micro-operations each)\n", T, total / reps, micro / reps);
 }
 
+// `plan_check bench-replay`: what a plan out of the cache costs when the definitions its list leaves behind are another entry's — the
+// evaluations of a DYNAMIC chain right behind a rescaling evaluation (the scale-buffer set has flipped: every definition of the tree is
+// registered again under the other entry; profiles/r06_experiments.txt 23).  Four lists: two buffer parities x two scale sets, read mode.
+static void benchReplay() {
+    std::mt19937 rng(7);
+    const int T = 1000, N = 2 * T - 1;
+    Tree tree; tree.random(T, rng, false);
+    WalkPlanner pl;
+    pl.init(T + 2 * (T - 1), T, 2 * N, 2 * (T - 1), 24, true, 3);
+    pl.launchMachines = 1024.0 / 782.0; pl.chunkTopOps = 16;
+    for (int i = 0; i < T; i++) pl.setCompactTip(i, true);
+    Protocol pr(tree);
+    std::vector<int> lvl = tree.levelOrder();
+    std::vector<std::vector<int>> lists;
+    for (int sset = 0; sset < 2; sset++) {
+        for (int n : lvl) pr.sFlip[n] = sset;
+        for (int parity = 0; parity < 2; parity++) {
+            for (int n : lvl) pr.pFlip[n] = parity;
+            for (int n = 0; n < N - 1; n++) pr.mFlip[n] = parity;
+            std::vector<int> ops; pr.emit(lvl, 2, ops); lists.push_back(ops);
+        }
+    }
+    Plan out;
+    for (auto& ops : lists) pl.plan(ops.data(), (int)ops.size() / 7, 7, 1, true, out, 150);
+    double same = 0.0, other = 0.0; const int reps = 300;
+    for (int it = 0; it < reps; it++) {
+        const int sset = it & 1;
+        for (int k = 0; k < 4; k++) {            // parity 0, 1 (both behind the flip: the other entry's definitions), then 0, 1 again (their own)
+            std::vector<int>& ops = lists[(size_t)(2 * sset + (k & 1))];
+            const long hits = pl.cacheHits;
+            const auto t0 = std::chrono::steady_clock::now();
+            pl.plan(ops.data(), (int)ops.size() / 7, 7, 1, true, out, 150);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (pl.cacheHits == hits) { fprintf(stderr, "bench-replay: the list was planned again\n"); exit(1); }
+            (k < 2 ? other : same) += us;
+            if (it < 3) checkUserLists(pl, T + 2 * (T - 1), 2 * (T - 1), "bench-replay");
+        }
+    }
+    printf("planner, %d-taxon full evaluation out of the cache: %.1f us behind a flipped scale-buffer set, %.1f us in steady state\n", T, other / (2 * reps), same / (2 * reps));
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "bench")) { benchPlanner(); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "bench-replay")) { benchReplay(); return 0; }
     const int reps = argc > 1 ? atoi(argv[1]) : 3;
     for (int r = 0; r < reps; r++) {
         for (int T : {2, 3, 5, 8, 13, 40, 150}) {
@@ -721,6 +825,9 @@ int main(int argc, char** argv) {
     scenarioMcmc(3000, true, false, 10, 5, false);
     printf("read-mode folding: %ld programs, %ld factor reads became %ld (%ld members)\n", foldedPlans, unfoldedReads, foldedPays, foldedMembers);
     if (foldedPlans < 100 || foldedPays * 3 > unfoldedReads * 2) { fprintf(stderr, "read-mode folding was hardly exercised\n"); return 1; }
+    for (int T : {17, 40, 150}) { scenarioRescaleCycles(T, 77 + T, 6, 8); scenarioRescaleCycles(T, 99 + T, 4, 0); }
+    printf("definitions taken over in place by a replayed plan (same leaves, the other scale-buffer set): %ld\n", g_replayInPlace);
+    if (g_replayInPlace < 500) { fprintf(stderr, "the in-place replay was hardly exercised\n"); return 1; }
     printf("programs executed on tickets (slices as a forest, leaves in reverse launch order): %ld\n", g_ticketRuns);
     if (g_ticketRuns < 100) { fprintf(stderr, "the ticket form of the one-launch walk was hardly exercised\n"); return 1; }
     printf("plan_check: OK\n");
