@@ -388,6 +388,11 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
     // ---- pass 1, list order: virtual definitions, producers, hold needs
     for (int k = 0; k < count; k++) {
         const int* op = ops + (size_t)k * tuple;
+        if (k + 6 < count) {                               // (a definition is 1.5 KB: the destination's two lines that matter, a few operations ahead)
+            const int* ahead = op + (size_t)6 * tuple;
+            const char* a = reinterpret_cast<const char*>(&virt_[(size_t)ahead[0] * parts + (tuple > 7 ? ahead[7] : 0)]);
+            __builtin_prefetch(a, 1); __builtin_prefetch(a + 64, 1);
+        }
         OpInfo& o = info_[k];
         o.dest = op[0]; o.wS = op[1]; o.rS = op[2]; o.c1 = op[3]; o.m1 = op[4]; o.c2 = op[5]; o.m2 = op[6];
         o.part = tuple > 7 ? op[7] : 0;
