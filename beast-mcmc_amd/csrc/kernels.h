@@ -304,7 +304,7 @@ void launchFill(hipStream_t stream, double* dst, double value, int pStart, int p
 // largest product, +infinity for anything not finite (kernels.hip k_foldReciprocals)
 // invert: the sources are factors (<= 1), the range check is on 1 / product (the T32 walk, which divides by what it reads)
 void launchFoldReciprocals(hipStream_t stream, const double* const* dSrcs, const int* dStart, double* const* dDst, int nJobs, int len, unsigned long long* dWorst,
-                           bool invert = false);
+                           bool invert = false, bool pairs = true);        // (pairs: two elements per thread where `len` is even — the same bits)
 // out[p] = raw ? log(in[p]) : in[p]
 void launchLogScale(hipStream_t stream, const double* in, double* out, int raw, int P);
 // Read-back: out[c][p][i] (API layout) = partials * scale, from either device layout.  `scale` may be

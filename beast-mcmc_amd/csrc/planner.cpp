@@ -20,7 +20,7 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
     enabled_ = virtualEnabled;
     keyParts_ = 1;
     virt_.assign(partialsCount, VirtDef());
-    tagOf_.assign(partialsCount, -1);
+    tagOf_.assign(partialsCount, -1); tagEpoch_++;
     tipUsers_.assign(partialsCount, std::vector<int>());
     scaleUsers_.assign(scaleCount_, std::vector<int>());
     compactTip.assign(partialsCount, 0);
@@ -33,7 +33,7 @@ void WalkPlanner::init(int partialsCount, int tipCount, int matrixCount, int sca
 void WalkPlanner::setPartitionCount(int parts) {
     keyParts_ = std::max(1, parts);
     virt_.assign((size_t)partialsCount_ * keyParts_, VirtDef());
-    tagOf_.assign((size_t)partialsCount_ * keyParts_, -1);
+    tagOf_.assign((size_t)partialsCount_ * keyParts_, -1); tagEpoch_++;
     for (auto& u : tipUsers_) u.clear();
     for (auto& u : scaleUsers_) u.clear();
     for (CacheEntry& e : cache_) e.valid = false;
@@ -50,7 +50,7 @@ void WalkPlanner::clearVirtualKey(int X) {
         if (h.scaleIdx >= 0) drop(scaleUsers_[h.scaleIdx]);
     }
     v.on = false;
-    tagOf_[X] = -1;
+    tagOf_[X] = -1; tagEpoch_++;
 }
 
 void WalkPlanner::registerVirtual(int X) {
@@ -122,7 +122,7 @@ bool WalkPlanner::buildVirtual(int X, int c1, bool tip1, bool mem1, int m1, int 
     nv.steps[nv.nSteps++] = last;
     nv.chainOnly = last.need == 0;
     virt_[X] = nv;
-    tagOf_[X] = 0;
+    tagOf_[X] = 0; tagEpoch_++;
     registerVirtual(X);
     snapPairs.insert(snapPairs.end(), pairs.begin(), pairs.end());
     return true;
@@ -376,7 +376,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         if (closed) {
             fill = &cache_[cacheNext_];
             cacheNext_ = (cacheNext_ + 1) % CACHE_WAYS;
-            fill->valid = false; fill->tag = ++cacheTagNext_; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
+            fill->valid = false; fill->cleanAtEpoch = -1; fill->tag = ++cacheTagNext_; fill->count = count; fill->tuple = tuple; fill->parts = parts; fill->chunkOps = chunkOps;
             fill->allowVirtual = allowVirtual; fill->stepLimit = allowVirtual ? stepLimit : 0; fill->tipEpoch = compactEpoch; fill->simple = simple;
             fill->ops.assign(ops, ops + (size_t)count * tuple);
         }
@@ -432,7 +432,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
                 if (saved.on) clearVirtualKey((int)kd);
                 makeVirtual = buildVirtual((int)kd, o.leaf1 ? o.c1 : (int)kc1, o.leaf1, o.leaf1 && !o.tip1, o.m1,
                                            o.leaf2 ? o.c2 : (int)kc2, o.leaf2, o.leaf2 && !o.tip2, o.m2, ownScale, out.snapPairs);
-                if (!makeVirtual && saved.on) { virt_[kd] = saved; tagOf_[kd] = saved.cacheTag; registerVirtual((int)kd); }
+                if (!makeVirtual && saved.on) { virt_[kd] = saved; tagOf_[kd] = saved.cacheTag; tagEpoch_++; registerVirtual((int)kd); }
                 if (makeVirtual) {
                     VirtDef& nv = virt_[kd];
                     nv.version = ++virtVersion_;
@@ -564,7 +564,7 @@ int WalkPlanner::plan(const int* ops, int count, int tuple, int parts, bool allo
         if ((int)fill->defs.size() < count) fill->defs.resize(count);
         fill->defOn.assign(count, 0);
         for (int k = 0; k < count; k++)
-            if (info_[k].virtDest) { const int kk = key(info_[k].dest, info_[k].part); virt_[kk].cacheTag = fill->tag; tagOf_[kk] = fill->tag; fill->defs[k] = virt_[kk]; fill->defOn[k] = 1; }
+            if (info_[k].virtDest) { const int kk = key(info_[k].dest, info_[k].part); virt_[kk].cacheTag = fill->tag; tagOf_[kk] = fill->tag; tagEpoch_++; fill->defs[k] = virt_[kk]; fill->defOn[k] = 1; }
         plannedTag = fill->tag;
         fill->stored = lastStored; fill->memReads = lastMemReads; fill->holds = lastHolds; fill->waves = lastWaves;
         fill->valid = true;
@@ -704,7 +704,8 @@ bool WalkPlanner::replayCached(const int* ops, int count, int tuple, int parts, 
 // through `planned`.  A definition still tagged with this entry is the one the entry wrote (every other writer of a
 // definition resets the tag), so the steady state costs one comparison per operation.
 void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
-    for (int k = 0; k < e.count; k++) {
+    // (nobody has written a tag since this entry was last replayed: every key is as that replay left it)
+    for (int k = 0; e.cleanAtEpoch != tagEpoch_ && k < e.count; k++) {
         const int part = e.tuple > 7 ? ops[(size_t)k * e.tuple + 7] : 0;
         const int dest = key(ops[(size_t)k * e.tuple], part);
         if (e.defOn[k] ? tagOf_[dest] == e.tag : tagOf_[dest] < 0) continue;        // already what the entry leaves behind
@@ -738,7 +739,7 @@ void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
             if (!e.defOn[k]) continue;                            // (defs[k] may be a leftover of an earlier list in this way)
         }
         cur = want;                                               // (tagged with e.tag when the entry was filled)
-        tagOf_[dest] = e.tag;
+        tagOf_[dest] = e.tag; tagEpoch_++;
         cur.stamp = stamp_;
         cur.version = ++virtVersion_;
         cur.childVer1 = cur.sigTip1 ? -1 : virt_[key(cur.sigC1, part)].version;
@@ -752,6 +753,7 @@ void WalkPlanner::replay(const CacheEntry& e, const int* ops) {
             }
         } else registerVirtual(dest);
     }
+    e.cleanAtEpoch = tagEpoch_;
     planned = &e.plan; plannedTag = e.tag;
     lastStored = e.stored; lastMemReads = e.memReads; lastHolds = e.holds; lastWaves = e.waves;
 }

@@ -228,6 +228,9 @@ private:
     std::vector<VirtDef> virt_;
     std::vector<int> pairScratch_;                     // buildVirtual's snapshot pairs before they are known to be wanted
     std::vector<long> tagOf_;                          // per key: -1 not virtual, 0 virtual, > 0 virtual and written by that cache entry
+    long tagEpoch_ = 0;                                // counts the writes to tagOf_: an entry replayed at this count and asked for again at
+                                                       // the same count finds every key as it left it (CacheEntry::cleanAtEpoch) — the chain's
+                                                       // steady state, two lists alternating, costs no pass over the list at all
                                                        // (a compact mirror of on / cacheTag: replaying a plan touches 8 bytes per op)
     std::vector<std::vector<int>> tipUsers_, scaleUsers_;
     int virtVersion_ = 0;
@@ -256,6 +259,7 @@ private:
         std::vector<VirtDef> defs;                     // per op: the definition its destination ends up with (on = false: real)
         std::vector<char> defOn;                       // defs[k].on
         int stored = 0, memReads = 0, holds = 0, waves = 0;
+        mutable long cleanAtEpoch = -1;                // tagEpoch_ right after the last replay of this entry (-1: never replayed since it was filled)
     };
     // (8: a chain under DYNAMIC rescaling cycles through 2 buffer-flip states x 2 scale-buffer sets of its read-mode list and the
     // same four of the list that recomputes the factors every 100th evaluation — with 4 ways every such evaluation evicted a
