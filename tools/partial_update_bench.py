@@ -34,15 +34,22 @@ for warm in (True, False):
     n = 40 if warm else moves
     t0 = time.perf_counter()
     for i in range(n):
-        node = int(rng.integers(T, N - 1))
+        node = int(rng.integers(T, N))
+        while wl.tree.parent[node] < 0:
+            node = int(rng.integers(T, N))
+        # a new height between the node's children and its parent (a negative branch length is an error, as in BEAST)
+        lo = max(height[int(wl.tree.left[node])], height[int(wl.tree.right[node])])
+        hi = height[wl.tree.parent[node]]
+        old = float(height[node])
         tl.storeState()
-        tl.set_node_height(node, float(height[node]) * (1.0 + 0.002 * rng.standard_normal()))
+        height[node] = lo + (hi - lo) * float(rng.uniform(0.1, 0.9))
+        tl.set_node_height(node, float(height[node]))
         v = tl.getLogLikelihood()
         if rng.random() < 0.5:
             tl.restoreState()
+            tl.restore_node_height(node, old)
+            height[node] = old
             tl.getLogLikelihood()
-        else:
-            height[node] = height[node]
     dt = time.perf_counter() - t0
 print("patterns %d  VSTEPS %s: full evaluation %.0f us; branch move (proposal + 50%% restore) %.1f us per move; lnL %.6f"
       % (patterns, os.environ.get("BEAGLE_MI355_VSTEPS", "default"), 1e6 * t_full, 1e6 * dt / moves, v))
