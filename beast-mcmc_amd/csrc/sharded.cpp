@@ -315,17 +315,23 @@ int shardedRootReduce(int handle, int count, const std::function<int(int shardHa
         for (int k = 1; k < n; k++) { const int rce = takeAsyncError(sh->shards[k].handle); if (rce) return rce; }
         return BEAGLE_SUCCESS;
     } else {
+        // no communicator (one GPU, or BEAGLE_MI355_SHARDS on one): every shard's sums reach the host the way a single instance's do — a
+        // small kernel behind the shard's root kernels writes them and a sequence word into mapped host memory, which this thread polls
+        // (engine_abi.cpp publishAndWait; it resets the shard's staging ring) — and are added in shard order.  A device-to-host copy and a
+        // stream synchronisation per shard cost 20-50 us of an evaluation (round 6: the reference's benchmark1 alignment through this
+        // handle on one GPU 7 080 -> see profiles/r06_experiments.txt 25).
         std::vector<double> acc(count, 0.0), part(count);
         for (int k = 0; k < n; k++) {
             Shard& s = sh->shards[k];
-            if (hipSetDevice(s.device) != hipSuccess ||
-                hipMemcpyAsync(part.data(), s.dResult, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
-                hipStreamSynchronize(s.stream) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+            if (hipSetDevice(s.device) != hipSuccess) return BEAGLE_ERROR_GENERAL;
+            for (int b = 0; b < count; b += 480) {
+                const int rcp = publishAndWait(s.handle, s.dResult + b, std::min(480, count - b), part.data() + b);
+                if (rcp) return rcp;
+            }
             for (int q = 0; q < count; q++) acc[q] += part[q];
         }
         memcpy(outValues, acc.data(), (size_t)count * sizeof(double));
     }
-    for (int k = 0; k < n; k++) beagleMi355Synchronize(sh->shards[k].handle);     // resets the shards' staging rings
     return BEAGLE_SUCCESS;
 }
 
