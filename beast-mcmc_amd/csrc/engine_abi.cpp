@@ -933,6 +933,10 @@ int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix) 
     GET_INSTANCE(instance);
     if (badIndex(matrixIndex, in->matrixCount)) return BEAGLE_ERROR_OUT_OF_RANGE;
     const size_t n = (size_t)in->C * in->S * in->S;
+    // a small matrix (4 states: 64 doubles with four categories) comes back through the polled result page, as a root sum does: callers that
+    // read one per branch (ancestral states, Markov jumps: AncestralStateBeagleTreeLikelihood.java:414-542) paid a device-to-host copy and a
+    // stream synchronisation each — 27 us a matrix
+    if (outMatrix && n <= 480) return mi355::publishAndWait(instance, in->matrices + n * matrixIndex, (int)n, outMatrix);
     return download(in, outMatrix, in->matrices + n * matrixIndex, n * sizeof(double));
 }
 
